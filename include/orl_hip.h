@@ -1,0 +1,276 @@
+/*
+ * orl_hip.h - C ABI of the MI355X-native on-policy rollout + PPO update engine.
+ *
+ * The reference (OpenRL-Lab/openrl v0.2.1) has no native layer and therefore no FFI to be
+ * compatible with; its seams are Python classes.  Every entry point below
+ * replaces one group of torch/numpy ops on the reference hot path and cites it.  The host-side
+ * mirror of the reference's Python interface (openrl_amd/) binds these symbols with ctypes; a
+ * maintainer of the reference would bind them the same way.
+ *
+ * Conventions (all entry points):
+ *   - extern "C"; plain pointers and sizes only, no torch / STL types;
+ *   - return 0 on success, a negative ORL_E_* for an invalid argument, a positive value is a
+ *     hipError_t from the launch; orl_last_error_string() describes the last failure (thread local);
+ *   - every data pointer is a DEVICE pointer to contiguous float32 unless stated; the caller owns
+ *     all memory; the library never allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream, or NULL);
+ *     launches are asynchronous and the functions are re-entrant.
+ *
+ * Buffer geometry (openrl/buffers/replay_data.py:41-184):
+ *   T = episode_length, N = n_rollout_threads (envs), A = num_agents, L = N*A "lanes",
+ *   arrays are [T(+1), N, A, width] C-contiguous; flat sample row of (t,n,a) = (t*N+n)*A+a.
+ */
+#ifndef ORL_HIP_H
+#define ORL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORL_VERSION 100 /* 0.1.0 */
+
+#define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
+#define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
+
+/* ---- network description -------------------------------------------------------------------
+ * One MLP "tower": [feature LayerNorm(D)] -> Linear(D,H) -> ReLU -> LayerNorm(H)
+ *                  -> Linear(H,H) -> LayerNorm(H) -> head Linear(H,n_out)
+ * = MLPBase/MLPLayer with layer_N = 1 (openrl/modules/networks/utils/mlp.py:8-46,100-180) followed
+ * by ACTLayer's Categorical / DiagGaussian linear (utils/act.py:14-25, utils/distributions.py:58-98)
+ * or ValueNetwork.v_out (networks/value_network.py:103-109).
+ * `theta` is ONE flat float32 buffer in the reference's state_dict order:
+ *   W1[H*D] b1[H] g1[H] be1[H] W2[H*H] b2[H] g2[H] be2[H] W3[n_out*H] b3[n_out] (logstd[n_out] if Gaussian)
+ * All weight matrices are row-major [out][in] exactly as torch.nn.Linear stores them.
+ */
+#define ORL_HEAD_VALUE 0       /* critic: n_out = 1 */
+#define ORL_HEAD_CATEGORICAL 1 /* Discrete(n_out) */
+#define ORL_HEAD_GAUSSIAN 2    /* Box(n_out): mean head + state-independent logstd */
+
+typedef struct orl_net_desc {
+  int32_t obs_dim;   /* D */
+  int32_t hidden;    /* H, must be 64 */
+  int32_t n_out;     /* head width */
+  int32_t head_kind; /* ORL_HEAD_* */
+} orl_net_desc;
+
+/* number of float32 parameters of a tower (== sum of reference state_dict numels) */
+int orl_param_count(const orl_net_desc* net);
+
+int orl_version(void);
+const char* orl_last_error_string(void);
+
+/* ---- K6 + K7a: GAE / return reverse scan -----------------------------------------------------
+ * Replaces ReplayData.compute_returns (openrl/buffers/replay_data.py:320-423), all four variants.
+ * flags: bit0 use_gae, bit1 use_proper_time_limits.
+ * vn_state: NULL, or the 3 ValueNorm state floats {running_mean, running_mean_sq, debiasing_term}
+ *   (openrl/modules/utils/valuenorm.py:24-35); when given, value_preds are de-normalised with
+ *   ValueNorm.denormalize (valuenorm.py:93-106) exactly where the reference does.
+ * next_value [L] is stored into value_preds[T] (use_gae) or returns[T] (otherwise) first.
+ * Optional fused outputs (K7a, openrl/algorithms/ppo.py:384-400): adv_raw [T,L] =
+ *   returns[:-1] - denorm(value_preds[:-1]) and stat_partials [gridDim][8] doubles holding per-block
+ *   {sum, sumsq, count} over ALL entries and over entries with active_masks != 0, plus
+ *   {sum, sumsq} of returns[:-1] (ValueNorm batch moments); pass NULL to skip.
+ * *n_partials receives the number of partial rows written (host int, may be NULL).
+ */
+int orl_gae_scan(const float* rewards, float* value_preds, const float* masks, const float* bad_masks,
+                 const float* next_value, const float* vn_state, float* returns, int T, int L,
+                 double gamma, double gae_lambda, int flags, const float* active_masks, float* adv_raw,
+                 double* stat_partials, int* n_partials, void* stream);
+int orl_gae_max_partials(int T, int L);
+
+/* ---- K7b: advantage normalisation (+ record packing) -------------------------------------------
+ * Replaces openrl/algorithms/ppo.py:402-409: optional global (x-mean)/(std+1e-5) (use_adv_normalize)
+ * followed - always - by the same transform with nanmean/nanstd over entries whose active mask != 0.
+ * Reads the partials of orl_gae_scan; writes adv [T*L] in place over adv_raw (may alias).
+ * stats_out (device, 8 doubles, optional): the reduced sums, for logging / all-reduce.
+ * When `records` != NULL also packs the per-sample update record (see orl_record_width):
+ *   [policy_obs Dp | critic_obs Dc | action a | old_logp a | adv | value_pred | return | active | action_mask K]
+ * in flat row order (t*N+n)*A+a, i.e. the row order of feed_forward_generator
+ * (openrl/buffers/replay_data.py:594-613).
+ */
+typedef struct orl_pack_src {
+  const float* policy_obs;       /* [T+1, L, Dp] */
+  const float* critic_obs;       /* [T+1, L, Dc] */
+  const float* actions;          /* [T, L, a]    */
+  const float* action_log_probs; /* [T, L, a]    */
+  const float* value_preds;      /* [T+1, L, 1]  */
+  const float* returns;          /* [T+1, L, 1]  */
+  const float* active_masks;     /* [T+1, L, 1]  */
+  const float* action_masks;     /* [T+1, L, K] or NULL */
+  int32_t Dp, Dc, a, K;
+} orl_pack_src;
+
+int orl_record_width(int Dp, int Dc, int a, int K); /* floats per record, multiple of 4 */
+int orl_adv_normalize_pack(float* adv, const double* stat_partials, int n_partials, int T, int L,
+                           int use_adv_normalize, double* stats_out, const orl_pack_src* src,
+                           float* records, void* stream);
+
+/* ---- K5: buffer insert + mask construction ----------------------------------------------------
+ * Replaces OnPolicyDriver.add2buffer mask logic (openrl/drivers/onpolicy_driver.py:91-138) and
+ * ReplayData.insert (openrl/buffers/replay_data.py:245-284) for one rollout step `step`:
+ *   policy_obs/critic_obs[step+1] <- next obs, rewards[step] <- rewards,
+ *   masks[step+1] = 0 where ALL agents of the env are done else 1,
+ *   active_masks[step+1] = 0 for a done agent unless the whole env is done, else 1,
+ *   bad_masks[step+1] = 0 where bad_transition else 1, action_masks[step+1] <- next masks (optional).
+ * dones / bad_transition are uint8 [N, A]; bad_transition and next_action_masks may be NULL.
+ */
+typedef struct orl_buffer_ptrs {
+  float* policy_obs;   /* [T+1, N, A, Dp] */
+  float* critic_obs;   /* [T+1, N, A, Dc] (may alias policy_obs) */
+  float* rewards;      /* [T, N, A, 1] */
+  float* masks;        /* [T+1, N, A, 1] */
+  float* bad_masks;    /* [T+1, N, A, 1] */
+  float* active_masks; /* [T+1, N, A, 1] */
+  float* action_masks; /* [T+1, N, A, K] or NULL */
+  int32_t T, N, A, Dp, Dc, K;
+} orl_buffer_ptrs;
+
+int orl_buffer_insert(const orl_buffer_ptrs* buf, int step, const float* next_policy_obs,
+                      const float* next_critic_obs, const float* rewards, const uint8_t* dones,
+                      const uint8_t* bad_transition, const float* next_action_masks, void* stream);
+
+/* ---- K8: minibatch gather ------------------------------------------------------------------------
+ * Replaces the fancy-index gathers of ReplayData.feed_forward_generator
+ * (openrl/buffers/replay_data.py:615-646): dst[i, :] = src[idx[i], :] for up to 12 arrays at once.
+ * idx is int64 (the dtype torch.randperm produces); rows are `width` floats.
+ */
+#define ORL_GATHER_MAX 12
+typedef struct orl_gather_desc {
+  const float* src[ORL_GATHER_MAX];
+  float* dst[ORL_GATHER_MAX];
+  int32_t width[ORL_GATHER_MAX];
+  int32_t count;
+} orl_gather_desc;
+int orl_gather_minibatch(const orl_gather_desc* desc, const int64_t* idx, int n_rows, void* stream);
+
+/* Keyed pseudo-random permutation of [0, n): idx[i] = cycle-walking 4-round Feistel over
+ * ceil(log2 n) bits keyed by (seed, stream).  Engine-native alternative to the host
+ * torch.randperm used by BatchSampler(SubsetRandomSampler) (replay_data.py:578-580); NOT
+ * bit-identical to it (documented in DESIGN.md). */
+int orl_perm_feistel(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+
+/* ---- K1-K4: rollout forward + sampling -------------------------------------------------------------
+ * Replaces PPOModule.get_actions (openrl/modules/ppo_module.py:102-138) =
+ * PolicyNetwork.forward_original (networks/policy_network.py:130-162) + ValueNetwork.forward
+ * (networks/value_network.py:113-136) + ACTLayer.forward (utils/act.py:45-83) for B rows.
+ *   values  [B,1]   = critic(critic_obs)         (NULL critic theta -> skipped)
+ *   actions [B,a]   sampled (or mode if deterministic) as float32, logp [B,a]
+ * Categorical: logits[mask==0] = -6e4 (distributions.py:71), a = 1, action = index as float.
+ * Gaussian: per-dimension log-prob, no sum (distributions.py:34-43), a = n_out.
+ * Sampling uses Philox4x32-10 keyed by `seed`, counter (row0 + row, rng_step): u = top 24 bits;
+ * categorical = inverse CDF over softmax probabilities; normal = Box-Muller.  If `forced_u` != NULL
+ * its [B, a] uniforms (categorical) / standard normals (Gaussian) replace the generator
+ * (teacher-forced parity tests).
+ */
+int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,
+                 const float* ctheta, const float* policy_obs, const float* critic_obs,
+                 const float* action_masks, int B, int deterministic, uint64_t seed, uint64_t row0,
+                 uint64_t rng_step, const float* forced_u, float* values, float* actions, float* logp,
+                 void* stream);
+
+/* ---- K9-K12: fused PPO minibatch forward + loss + backward ----------------------------------------
+ * Replaces PPOAlgorithm.prepare_loss + loss.backward() x2 (openrl/algorithms/ppo.py:238-361,
+ * 123-124) with PPOModule.evaluate_actions (modules/ppo_module.py:149-193), cal_value_loss
+ * (ppo.py:178-220) and huber/mse (modules/utils/util.py:20-27) for the rows idx[0..mb) of
+ * `records`.  Produces UNNORMALISED gradient sums (per-workgroup partials, reduced by
+ * orl_ppo_finalize) so that multi-GPU runs can all-reduce sums and denominators exactly.
+ */
+typedef struct orl_ppo_hparams {
+  float clip_param;
+  float entropy_coef;
+  float value_loss_coef;
+  float huber_delta;
+  float dual_clip_coeff;
+  float max_grad_norm;
+  int32_t use_clipped_value_loss;
+  int32_t use_huber_loss;
+  int32_t use_value_active_masks;
+  int32_t use_policy_active_masks;
+  int32_t use_valuenorm; /* normalise returns with vn_state inside the value loss */
+  int32_t dual_clip_ppo;
+  int32_t use_max_grad_norm;
+  int32_t reserved;
+} orl_ppo_hparams;
+
+/* size (floats) of the raw gradient-sum vector of one tower and of the stats vector */
+int orl_raw_grad_count(const orl_net_desc* net);
+#define ORL_N_STATS 16
+int orl_ppo_max_blocks(void); /* upper bound of workgroups => rows of `partials` */
+
+/* partials: float32 device scratch of orl_ppo_max_blocks() * (raw_p + ORL_N_STATS + raw_c + ORL_N_STATS)
+ * floats: policy rows [n_blocks][raw_p + ORL_N_STATS] start at 0, critic rows
+ * [n_blocks][raw_c + ORL_N_STATS] start at orl_ppo_max_blocks() * (raw_p + ORL_N_STATS).
+ * idx may be NULL (identity order).  vn_state is read AFTER the caller applied
+ * orl_valuenorm_update for this minibatch (ppo.py:190-195 order). */
+int orl_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,
+                    const float* ctheta, const float* records, int rec_width, const int64_t* idx,
+                    int mb, const float* vn_state, const orl_ppo_hparams* hp, float* partials,
+                    int* n_blocks_out, void* stream);
+
+/* ---- K13 + K14 (+ ValueNorm state, stats) -----------------------------------------------------------
+ * orl_ppo_reduce: sums the per-workgroup partials into `sums` [raw_p + raw_c + ORL_N_STATS]
+ *   (this is the vector a multi-GPU run all-reduces - SURVEY.md section 8e).
+ * orl_ppo_apply: turns the summed raw vector into parameter gradients (divides by the masked-mean
+ *   denominators), computes both global grad norms, clips (torch clip_grad_norm_,
+ *   ppo.py:132-145), runs one torch.optim.Adam step per tower (modules/rl_module.py:80-85;
+ *   lr/eps/weight_decay as given, betas (0.9, 0.999)) and writes the six train_info scalars
+ *   {value_loss, policy_loss, dist_entropy, actor_grad_norm, critic_grad_norm, ratio} (ppo.py:445-451)
+ *   to train_info_accum[0..6) by ADDING (so an epoch loop accumulates like ppo.py:445-451).
+ */
+typedef struct orl_adam_state {
+  float* theta; /* parameters, updated in place */
+  float* grad;  /* gradient out (parameter order), for inspection */
+  float* m;     /* exp_avg */
+  float* v;     /* exp_avg_sq */
+  float lr, eps, weight_decay;
+  int32_t step; /* 1-based step count of THIS update */
+} orl_adam_state;
+
+int orl_ppo_reduce(const float* partials, int n_blocks, int width, float* sums, void* stream);
+int orl_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums,
+                  const orl_ppo_hparams* hp, const orl_adam_state* padam, const orl_adam_state* cadam,
+                  float* train_info_accum, void* stream);
+
+/* ValueNorm.update (openrl/modules/utils/valuenorm.py:58-77) from reduced batch sums:
+ * moments = {sum(x), sum(x^2), count} as doubles on the device; beta = 0.99999. */
+int orl_valuenorm_update(float* vn_state, const double* moments, float beta, void* stream);
+/* sum / sumsq / count of returns over minibatch rows (records column `ret_col`) -> moments[3]. */
+int orl_minibatch_moments(const float* records, int rec_width, int ret_col, const int64_t* idx, int mb,
+                          double* scratch, double* moments, void* stream);
+
+/* ---- fused device-resident rollout ---------------------------------------
+ * One launch performs `T` steps of {policy+value forward, sample, env.step, buffer insert} for a
+ * device-resident batched env, i.e. OnPolicyDriver.actor_rollout (onpolicy_driver.py:154-203) with
+ * act (:235-279) and add2buffer (:80-152) fused; env lanes never leave the GPU.
+ */
+#define ORL_ENV_SYNTH 0    /* fixed-step synthetic env: obs ~ N(0,1) keyed (seed, env, t), reward U(0,1) */
+#define ORL_ENV_CARTPOLE 1 /* CartPole-v1 dynamics (gymnasium classic_control cartpole.py) */
+
+typedef struct orl_rollout_args {
+  orl_buffer_ptrs buf;
+  float* value_preds;      /* [T+1, N, A, 1] */
+  float* actions;          /* [T, N, A, a]   */
+  float* action_log_probs; /* [T, N, A, a]   */
+  float* env_state;        /* [N, env_state_width] persistent env state */
+  float* ep_stats;         /* [N, 4]: running episode return, length, sum of finished returns, finished count */
+  int32_t env_kind;
+  int32_t episode_limit;   /* synthetic: fixed episode length; cartpole: 500 */
+  uint64_t env_seed;
+  uint64_t act_seed;
+  uint64_t rng_step0;      /* global step counter at the first step of this rollout */
+} orl_rollout_args;
+
+int orl_env_state_width(int env_kind);
+int orl_env_reset(int env_kind, float* env_state, float* ep_stats, float* obs0, int N, int obs_dim,
+                  uint64_t env_seed, int episode_limit, void* stream);
+/* next_value [N] (optional): critic value of the observation in slot T, i.e. the bootstrap value
+ * OnPolicyDriver.compute_returns feeds ReplayData.compute_returns (onpolicy_driver.py:205-233). */
+int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,
+                      const float* ctheta, const orl_rollout_args* args, float* next_value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORL_HIP_H */

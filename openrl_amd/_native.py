@@ -1,0 +1,163 @@
+"""ctypes binding of ``liborl_hip.so`` - the C ABI declared in ``include/orl_hip.h``.
+
+This is the ONLY compute backend of the package: there is no eager / CPU fallback.  If the
+shared object is missing and cannot be built, or a call returns non-zero, an exception is raised.
+Tensors are passed as raw device pointers (``tensor.data_ptr()``) plus the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liborl_hip.so")
+
+ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
+ORL_ENV_SYNTH, ORL_ENV_CARTPOLE = 0, 1
+ORL_GATHER_MAX = 12
+ORL_N_STATS = 16
+
+c_f32p = C.c_void_p  # device pointers travel as void*
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32), ("hidden", C.c_int32), ("n_out", C.c_int32), ("head_kind", C.c_int32)]
+
+
+class PackSrc(C.Structure):
+    _fields_ = [("policy_obs", C.c_void_p), ("critic_obs", C.c_void_p), ("actions", C.c_void_p),
+                ("action_log_probs", C.c_void_p), ("value_preds", C.c_void_p), ("returns", C.c_void_p),
+                ("active_masks", C.c_void_p), ("action_masks", C.c_void_p),
+                ("Dp", C.c_int32), ("Dc", C.c_int32), ("a", C.c_int32), ("K", C.c_int32)]
+
+
+class BufferPtrs(C.Structure):
+    _fields_ = [("policy_obs", C.c_void_p), ("critic_obs", C.c_void_p), ("rewards", C.c_void_p),
+                ("masks", C.c_void_p), ("bad_masks", C.c_void_p), ("active_masks", C.c_void_p),
+                ("action_masks", C.c_void_p),
+                ("T", C.c_int32), ("N", C.c_int32), ("A", C.c_int32), ("Dp", C.c_int32), ("Dc", C.c_int32),
+                ("K", C.c_int32)]
+
+
+class GatherDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p * ORL_GATHER_MAX), ("dst", C.c_void_p * ORL_GATHER_MAX),
+                ("width", C.c_int32 * ORL_GATHER_MAX), ("count", C.c_int32)]
+
+
+class PPOHParams(C.Structure):
+    _fields_ = [("clip_param", C.c_float), ("entropy_coef", C.c_float), ("value_loss_coef", C.c_float),
+                ("huber_delta", C.c_float), ("dual_clip_coeff", C.c_float), ("max_grad_norm", C.c_float),
+                ("use_clipped_value_loss", C.c_int32), ("use_huber_loss", C.c_int32),
+                ("use_value_active_masks", C.c_int32), ("use_policy_active_masks", C.c_int32),
+                ("use_valuenorm", C.c_int32), ("dual_clip_ppo", C.c_int32), ("use_max_grad_norm", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class AdamState(C.Structure):
+    _fields_ = [("theta", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("lr", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step", C.c_int32)]
+
+
+class RolloutArgs(C.Structure):
+    _fields_ = [("buf", BufferPtrs), ("value_preds", C.c_void_p), ("actions", C.c_void_p),
+                ("action_log_probs", C.c_void_p), ("env_state", C.c_void_p), ("ep_stats", C.c_void_p),
+                ("env_kind", C.c_int32), ("episode_limit", C.c_int32), ("env_seed", C.c_uint64),
+                ("act_seed", C.c_uint64), ("rng_step0", C.c_uint64)]
+
+
+# name -> (restype, argtypes); must list EVERY symbol of include/orl_hip.h (tests check this)
+_P = C.c_void_p
+_SIGNATURES = {
+    "orl_version": (C.c_int, []),
+    "orl_last_error_string": (C.c_char_p, []),
+    "orl_param_count": (C.c_int, [C.POINTER(NetDesc)]),
+    "orl_raw_grad_count": (C.c_int, [C.POINTER(NetDesc)]),
+    "orl_gae_scan": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                               _P, _P, _P, C.POINTER(C.c_int), _P]),
+    "orl_gae_max_partials": (C.c_int, [C.c_int, C.c_int]),
+    "orl_record_width": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "orl_adv_normalize_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(PackSrc), _P, _P]),
+    "orl_buffer_insert": (C.c_int, [C.POINTER(BufferPtrs), C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "orl_gather_minibatch": (C.c_int, [C.POINTER(GatherDesc), _P, C.c_int, _P]),
+    "orl_perm_feistel": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
+    "orl_act_step": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, C.c_int, C.c_int,
+                               C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
+    "orl_ppo_max_blocks": (C.c_int, []),
+    "orl_ppo_fwd_bwd": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, C.c_int, _P, C.c_int, _P,
+                                  C.POINTER(PPOHParams), _P, C.POINTER(C.c_int), _P]),
+    "orl_ppo_reduce": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "orl_ppo_apply": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
+                                C.POINTER(AdamState), C.POINTER(AdamState), _P, _P]),
+    "orl_valuenorm_update": (C.c_int, [_P, _P, C.c_float, _P]),
+    "orl_minibatch_moments": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "orl_env_state_width": (C.c_int, [C.c_int]),
+    "orl_env_reset": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int, _P]),
+    "orl_rollout_fused": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, C.POINTER(RolloutArgs), _P, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load (building first if necessary) the gfx950 extension.  Raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise NativeError("%s is missing - run `python -m openrl_amd.csrc.build`" % LIB_PATH)
+        from .csrc import build as _b
+
+        _b.build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale -> loud failure
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().orl_last_error_string()
+        raise NativeError("%s failed (rc=%d): %s" % (what or "native call", rc, msg.decode() if msg else ""))
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise NativeError("non-contiguous tensor passed to the native engine")
+    return t.data_ptr()
+
+
+def fptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is not None and t.dtype != torch.float32:
+        raise NativeError("float32 tensor expected, got %s" % t.dtype)
+    return ptr(t)
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise NativeError(
+            "openrl_amd is a MI355X (ROCm) engine: device %r has no HIP runtime behind it and there is no CPU "
+            "fallback. Use the reference on CPU, or run on a gfx950 device." % (str(device),))
+    return device

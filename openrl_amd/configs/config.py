@@ -1,0 +1,102 @@
+"""``create_config_parser()`` - the flat ``cfg`` namespace of the drop-in API.
+
+Mirrors the reference entry point ``openrl/configs/config.py:24`` (``create_config_parser``):
+same flag names, same defaults, ``--config file.yaml`` support (plain YAML with an optional
+``globals:`` Jinja pre-pass, ``openrl/configs/utils.py:28-101``).  Built on ``argparse`` +
+``yaml`` only (``jsonargparse`` is not available offline).
+
+MI355X-engine extensions live under the ``amd_`` prefix so they can never collide with a
+reference flag.
+"""
+from __future__ import annotations
+
+import argparse
+from typing import Any, List, Optional
+
+from ._flag_table import FLAGS
+
+# Engine-side extensions (not in the reference).
+AMD_FLAGS = [
+    # minibatch permutation source: "reference" = host torch.randperm on the CPU generator, bit-exact
+    # with replay_data.py:578-580; "device" = keyed Feistel bijection generated on the GPU.
+    ("amd_perm_mode", "str", "reference", "opt", ["reference", "device"]),
+    # rollout engine: "auto" picks the fused persistent kernel for device-resident envs.
+    ("amd_rollout_mode", "str", "auto", "opt", ["auto", "fused", "stepwise"]),
+    # capture the PPO update epoch in a hipGraph.
+    ("amd_use_graph", "bool", True, "opt", None),
+]
+
+
+def _str2bool(v: Any) -> bool:
+    if isinstance(v, bool):
+        return v
+    s = str(v).strip().lower()
+    if s in ("1", "true", "t", "yes", "y"):
+        return True
+    if s in ("0", "false", "f", "no", "n"):
+        return False
+    raise argparse.ArgumentTypeError("expected a boolean, got %r" % (v,))
+
+
+def _identity(v):
+    return v
+
+
+_TYPES = {"int": int, "float": float, "str": str, "bool": _str2bool, "any": _identity}
+
+
+class _YamlConfigAction(argparse.Action):
+    """``--config x.yaml``: YAML keys become defaults; later CLI flags still override."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        import yaml
+
+        with open(values, "r") as fh:
+            text = fh.read()
+        # optional jinja ``globals:`` block (configs/utils.py:28-101)
+        try:
+            head = yaml.safe_load(text.split("\n\n")[0]) if text.lstrip().startswith("globals:") else None
+        except Exception:
+            head = None
+        if isinstance(head, dict) and "globals" in head:
+            import jinja2
+
+            text = jinja2.Template(text).render(**head["globals"])
+        data = yaml.safe_load(text) or {}
+        data.pop("globals", None)
+        for k, v in _flatten(data).items():
+            setattr(namespace, k, v)
+        setattr(namespace, self.dest, values)
+
+
+def _flatten(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        key = prefix + str(k)
+        if isinstance(v, dict) and key in ("selfplay_api", "reward_class", "vec_info_class", "env"):
+            out.update(_flatten(v, key + "."))
+        else:
+            out[key] = v
+    return out
+
+
+def create_config_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser(description="openrl_amd", formatter_class=argparse.RawDescriptionHelpFormatter)
+    parser.add_argument("--config", action=_YamlConfigAction, default=None)
+    for name, tname, default, kind, choices in list(FLAGS) + AMD_FLAGS:
+        if kind == "flag":
+            parser.add_argument("--" + name, dest=name, action="store_false" if default is True else "store_true",
+                                default=default)
+        elif kind == "pos":
+            parser.add_argument(name, type=_TYPES[tname], default=default, nargs="?")
+        else:
+            kw = dict(dest=name, type=_TYPES[tname], default=default)
+            if choices:
+                kw["choices"] = choices
+            parser.add_argument("--" + name, **kw)
+    return parser
+
+
+def default_cfg(argv: Optional[List[str]] = None):
+    """Convenience: ``create_config_parser().parse_args(argv or [])``."""
+    return create_config_parser().parse_args(list(argv or []))

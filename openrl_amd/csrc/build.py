@@ -1,0 +1,59 @@
+"""Build ``liborl_hip.so`` (all HIP kernels + the C ABI) for gfx950, in-tree.
+
+``python -m openrl_amd.csrc.build`` or ``__graft_entry__.build()``.  hipcc cross-compiles without
+a GPU.  The shared object is git-ignored but travels with the repo snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["orl_buffer.hip", "orl_act.hip", "orl_ppo.hip"]
+HEADERS = ["orl_common.h", "orl_mlp.h", os.path.join("..", "..", "include", "orl_hip.h")]
+LIB = os.path.join(HERE, "liborl_hip.so")
+STAMP = os.path.join(HERE, ".liborl_hip.stamp")
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; cannot build the gfx950 extension")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        p = os.path.join(HERE, f)
+        if os.path.exists(p):
+            with open(p, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            if fh.read().strip() == dig:
+                return LIB
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    with open(STAMP, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,526 @@
+// orl_act.hip - rollout side of the hot path for gfx950:
+//   orl_act_step      : K1-K4 fused policy + value forward and action sampling for B rows
+//   orl_rollout_fused : T steps of {forward, sample, env.step, buffer insert} in ONE launch for
+//                       device-resident batched envs (synthetic fixed-step env, CartPole-v1)
+//   orl_env_reset     : initial env state + first observation
+//
+// Geometry: one workgroup = 2 wavefronts = one 16-row tile; wave 0 runs the policy tower, wave 1
+// the critic tower (fp32 MFMA 16x16x4, see orl_mlp.h).  Env lanes are independent, so the fused
+// rollout needs no inter-workgroup communication: each workgroup owns 16 envs for all T steps and
+// keeps both towers' weights in LDS for the whole rollout.
+#include "orl_common.h"
+#include "orl_mlp.h"
+
+namespace orl {
+
+struct ActArgs {
+  orl_net_desc pnet, cnet;
+  const float* ptheta;
+  const float* ctheta;  // may be NULL
+  const float* pobs;
+  const float* cobs;
+  const float* amask;   // [B, n_out] or NULL
+  const float* forced;  // [B, a] or NULL
+  float* values;
+  float* actions;
+  float* logp;
+  int B;
+  int deterministic;
+  uint64_t seed, row0, rng_step;
+};
+
+// Sample / evaluate the action head for batch row `row` of this lane (all 4 lanes of a row agree).
+// Returns through act_out/logp_out (arrays of NO; categorical uses slot 0).
+template <int NO, int HEAD>
+__device__ inline void sample_head(float (&hd)[NO], int n_out, const float* lds_logstd, const float* amask_row,
+                                   const float* forced_row, int deterministic, uint64_t seed, uint64_t grow,
+                                   uint64_t rng_step, float (&act_out)[NO], float (&logp_out)[NO]) {
+  if (HEAD == ORL_HEAD_CATEGORICAL) {
+    const float lse = cat_lse<NO>(hd, n_out, amask_row);
+    int a;
+    if (deterministic) {
+      a = cat_mode<NO>(hd, n_out);
+    } else {
+      float u;
+      if (forced_row != nullptr) u = forced_row[0];
+      else {
+        const u4 r = philox4x32_10(seed, (uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)rng_step,
+                                   (uint32_t)(rng_step >> 32) << 8);
+        u = u01(r.x);
+      }
+      a = cat_sample<NO>(hd, n_out, lse, u);
+    }
+    act_out[0] = (float)a;
+    logp_out[0] = pick<NO>(hd, a) - lse;
+  } else {
+    // DiagGaussian: std = exp(logstd), per-dimension log-prob (distributions.py:34-43, 75-98)
+#pragma unroll
+    for (int b = 0; b < (NO + 3) / 4; ++b) {
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!deterministic && forced_row == nullptr && 4 * b < n_out) {
+        const u4 r = philox4x32_10(seed, (uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)rng_step,
+                                   ((uint32_t)(rng_step >> 32) << 8) | (uint32_t)b);
+        box_muller(r.x, r.y, e[0], e[1]);
+        box_muller(r.z, r.w, e[2], e[3]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = 4 * b + k;
+        if (c < NO) {
+          float av = 0.f, lp = 0.f;
+          if (c < n_out) {
+            const float ls = lds_logstd[c];
+            const float sd = expf(ls);
+            float eps = e[k];
+            if (forced_row != nullptr && !deterministic) eps = forced_row[c];
+            av = deterministic ? hd[c] : hd[c] + sd * eps;
+            const float d = av - hd[c];
+            // Normal.log_prob: -(x-mu)^2/(2 var) - log(sd) - log(sqrt(2 pi))
+            lp = -(d * d) / (2.f * (sd * sd)) - ls - 0.91893853320467274178f;
+          }
+          act_out[c] = av;
+          logp_out[c] = lp;
+        }
+      }
+    }
+  }
+}
+
+template <int NO, int HEAD>
+__global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const TowerLayout tlp(A.pnet);
+  const TowerLds twp(A.pnet.obs_dim, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false);
+  TowerLayout tlc;
+  TowerLds twc;
+  const bool has_c = A.ctheta != nullptr;
+  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x);
+  if (has_c) {
+    tlc = TowerLayout(A.cnet);
+    twc = TowerLds(A.cnet.obs_dim, 1, false, false);
+    stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x);
+  }
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int row = blockIdx.x * TILE_B + j;
+  const bool row_ok = row < A.B;
+  if (wave == 0) {
+    const int D = A.pnet.obs_dim;
+    const float* xrow = A.pobs + (size_t)row * D;
+    auto xb = [&](int s) -> float {
+      const int k = 4 * s + q;
+      return (row_ok && k < D) ? xrow[k] : 0.f;
+    };
+    f32x4 n2[4];
+    trunk_fwd_T(smem, twp, xb, j, q, n2);
+    float hd[NO];
+    head_T<NO>(smem + twp.W3, smem + twp.b3, A.pnet.n_out, n2, q, hd);
+    const int n_out = A.pnet.n_out;
+    const int a_w = (HEAD == ORL_HEAD_CATEGORICAL) ? 1 : n_out;
+    float act_o[NO], lp_o[NO];
+    const float* am = (A.amask != nullptr && row_ok) ? A.amask + (size_t)row * n_out : nullptr;
+    const float* fr = (A.forced != nullptr && row_ok) ? A.forced + (size_t)row * a_w : nullptr;
+    sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, am, fr, A.deterministic, A.seed, A.row0 + (uint64_t)row,
+                          A.rng_step, act_o, lp_o);
+    if (row_ok && q == 0) {
+#pragma unroll
+      for (int c = 0; c < NO; ++c) {
+        if (c < a_w) {
+          A.actions[(size_t)row * a_w + c] = act_o[c];
+          A.logp[(size_t)row * a_w + c] = lp_o[c];
+        }
+      }
+    }
+  } else if (has_c) {
+    const int D = A.cnet.obs_dim;
+    const float* xrow = A.cobs + (size_t)row * D;
+    auto xb = [&](int s) -> float {
+      const int k = 4 * s + q;
+      return (row_ok && k < D) ? xrow[k] : 0.f;
+    };
+    f32x4 n2[4];
+    const float* lc = smem + twp.total;
+    trunk_fwd_T(lc, twc, xb, j, q, n2);
+    float v[1];
+    head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
+    if (row_ok && q == 0) A.values[row] = v[0];
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Device-resident envs.  State lives in `env_state[N][W]`; one lane (q == 0) owns one env.
+// --------------------------------------------------------------------------------------------------
+constexpr int SYNTH_STATE_W = 4;     // {steps_in_episode, -, -, -}
+constexpr int CARTPOLE_STATE_W = 8;  // {x, x_dot, theta, theta_dot, steps_in_episode, episodes, -, -}
+
+// synthetic obs component block b (4 normals) for (env, global time t)
+__device__ inline void synth_obs_block(uint64_t seed, uint32_t env, uint64_t t, uint32_t b, float (&o)[4]) {
+  const u4 r = philox4x32_10(seed, env, 0x0B5E0000u + b, (uint32_t)t, (uint32_t)(t >> 32));
+  box_muller(r.x, r.y, o[0], o[1]);
+  box_muller(r.z, r.w, o[2], o[3]);
+}
+__device__ inline float synth_reward(uint64_t seed, uint32_t env, uint64_t t) {
+  const u4 r = philox4x32_10(seed, env, 0x4E3A0000u, (uint32_t)t, (uint32_t)(t >> 32));
+  return u01(r.x);
+}
+
+// CartPole-v1 (gymnasium/envs/classic_control/cartpole.py, euler integrator) in fp32.
+__device__ inline void cartpole_reset(uint64_t seed, uint32_t env, uint32_t episode, float (&s)[4]) {
+  const u4 r = philox4x32_10(seed, env, 0xCA470000u, episode, 0u);
+  s[0] = u01(r.x) * 0.1f - 0.05f;
+  s[1] = u01(r.y) * 0.1f - 0.05f;
+  s[2] = u01(r.z) * 0.1f - 0.05f;
+  s[3] = u01(r.w) * 0.1f - 0.05f;
+}
+__device__ inline bool cartpole_step(float (&s)[4], int action) {
+  const float gravity = 9.8f, masspole = 0.1f, total_mass = 1.1f, length = 0.5f, polemass_length = 0.05f,
+              force_mag = 10.0f, tau = 0.02f;
+  const float force = action == 1 ? force_mag : -force_mag;
+  const float costh = cosf(s[2]), sinth = sinf(s[2]);
+  const float temp = (force + polemass_length * s[3] * s[3] * sinth) / total_mass;
+  const float thetaacc =
+      (gravity * sinth - costh * temp) / (length * (4.0f / 3.0f - masspole * costh * costh / total_mass));
+  const float xacc = temp - polemass_length * thetaacc * costh / total_mass;
+  s[0] = s[0] + tau * s[1];
+  s[1] = s[1] + tau * xacc;
+  s[2] = s[2] + tau * s[3];
+  s[3] = s[3] + tau * thetaacc;
+  const float th_lim = 12.0f * 2.0f * 3.14159265358979323846f / 360.0f;
+  return (s[0] < -2.4f) || (s[0] > 2.4f) || (s[2] < -th_lim) || (s[2] > th_lim);
+}
+
+template <int ENV>
+__global__ __launch_bounds__(256) void env_reset_kernel(float* __restrict__ env_state, float* __restrict__ ep_stats,
+                                                        float* __restrict__ obs0, int N, int D, uint64_t seed,
+                                                        int episode_limit) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  if (ep_stats != nullptr) {
+    ep_stats[n * 4 + 0] = 0.f; ep_stats[n * 4 + 1] = 0.f; ep_stats[n * 4 + 2] = 0.f; ep_stats[n * 4 + 3] = 0.f;
+  }
+  if (ENV == ORL_ENV_SYNTH) {
+    float* st = env_state + (size_t)n * SYNTH_STATE_W;
+    st[0] = (float)((n * 7) % episode_limit);  // per-env phase offset so that dones are staggered
+    st[1] = st[2] = st[3] = 0.f;
+    for (int b = 0; b < (D + 3) / 4; ++b) {
+      float o[4];
+      synth_obs_block(seed, (uint32_t)n, 0, (uint32_t)b, o);
+      for (int k = 0; k < 4; ++k)
+        if (4 * b + k < D) obs0[(size_t)n * D + 4 * b + k] = o[k];
+    }
+  } else {
+    float* st = env_state + (size_t)n * CARTPOLE_STATE_W;
+    float s[4];
+    cartpole_reset(seed, (uint32_t)n, 0u, s);
+    for (int k = 0; k < 4; ++k) { st[k] = s[k]; obs0[(size_t)n * 4 + k] = s[k]; }
+    st[4] = 0.f; st[5] = 0.f; st[6] = 0.f; st[7] = 0.f;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Fused T-step rollout.  LDS: [policy tower | critic tower | obs tile 2 x 16 x DP].
+// --------------------------------------------------------------------------------------------------
+struct RolloutArgs {
+  orl_net_desc pnet, cnet;
+  const float* ptheta;
+  const float* ctheta;
+  orl_rollout_args r;
+  float* next_value;  // [N] bootstrap value of slot T (may be NULL)
+};
+
+template <int NO, int HEAD, int ENV>
+__global__ __launch_bounds__(128) void rollout_kernel(RolloutArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const orl_buffer_ptrs& b = A.r.buf;
+  const int D = A.pnet.obs_dim;
+  const int N = b.N, T = b.T;
+  const TowerLayout tlp(A.pnet), tlc(A.cnet);
+  const TowerLds twp(D, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false);
+  const TowerLds twc(D, 1, false, false);
+  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x);
+  stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x);
+  const int DP = twp.DP;
+  float* s_obs = smem + twp.total + twc.total;  // [2][16][DP]
+
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int n = blockIdx.x * TILE_B + j;
+  const bool ok = n < N;
+  const int n_out = A.pnet.n_out;
+  const int a_w = (HEAD == ORL_HEAD_CATEGORICAL) ? 1 : n_out;
+  const bool sep_c = b.critic_obs != b.policy_obs;
+
+  // obs tile for slot 0 comes from the buffer (after_update / init_buffer put it there)
+  for (int e = threadIdx.x; e < TILE_B * DP; e += blockDim.x) {
+    const int jj = e / DP, k = e - jj * DP;
+    const int nn = blockIdx.x * TILE_B + jj;
+    s_obs[e] = (nn < N && k < D) ? b.policy_obs[(size_t)nn * D + k] : 0.f;
+  }
+  // env state in registers of the owning lane (wave 0, q == 0)
+  float est[8];
+  const int SW = (ENV == ORL_ENV_SYNTH) ? SYNTH_STATE_W : CARTPOLE_STATE_W;
+  float ep_ret = 0.f, ep_len = 0.f, fin_ret = 0.f, fin_cnt = 0.f;
+  if (wave == 0 && q == 0 && ok) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) est[k] = (k < SW) ? A.r.env_state[(size_t)n * SW + k] : 0.f;
+    ep_ret = A.r.ep_stats[n * 4 + 0]; ep_len = A.r.ep_stats[n * 4 + 1];
+    fin_ret = A.r.ep_stats[n * 4 + 2]; fin_cnt = A.r.ep_stats[n * 4 + 3];
+  }
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    const float* cur = s_obs + (t & 1) * TILE_B * DP;
+    float* nxt = s_obs + ((t + 1) & 1) * TILE_B * DP;
+    auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
+    const uint64_t tg = A.r.rng_step0 + (uint64_t)t;
+    if (wave == 0) {
+      f32x4 n2[4];
+      trunk_fwd_T(smem, twp, xb, j, q, n2);
+      float hd[NO];
+      head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);
+      float act_o[NO], lp_o[NO];
+      const float* am = (b.action_masks != nullptr && ok) ? b.action_masks + ((size_t)t * N + n) * b.K : nullptr;
+      sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, am, nullptr, 0, A.r.act_seed, (uint64_t)n, tg, act_o, lp_o);
+      if (ok && q == 0) {
+#pragma unroll
+        for (int c = 0; c < NO; ++c) {
+          if (c < a_w) {
+            A.r.actions[((size_t)t * N + n) * a_w + c] = act_o[c];
+            A.r.action_log_probs[((size_t)t * N + n) * a_w + c] = lp_o[c];
+          }
+        }
+      }
+      // ---- env.step + insert (slot t+1) ----
+      const size_t s1 = (size_t)(t + 1) * N + n;
+      if (ENV == ORL_ENV_SYNTH) {
+        // every lane of the row helps generating obs blocks b = q, q+4, ...
+        bool done = false;
+        if (q == 0 && ok) {
+          const float rew = synth_reward(A.r.env_seed, (uint32_t)n, tg);
+          est[0] += 1.f;
+          done = est[0] >= (float)A.r.episode_limit;
+          if (done) est[0] = 0.f;
+          b.rewards[(size_t)t * N + n] = rew;
+          b.masks[s1] = done ? 0.f : 1.f;
+          b.active_masks[s1] = 1.f;
+          b.bad_masks[s1] = 1.f;
+          ep_ret += rew; ep_len += 1.f;
+          if (done) { fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f; }
+        }
+        for (int bb = q; bb < (D + 3) / 4; bb += 4) {
+          float o[4];
+          synth_obs_block(A.r.env_seed, (uint32_t)n, tg + 1, (uint32_t)bb, o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int d = 4 * bb + k;
+            if (d < DP) nxt[j * DP + d] = (d < D) ? o[k] : 0.f;
+            if (ok && d < D) {
+              b.policy_obs[s1 * D + d] = o[k];
+              if (sep_c) b.critic_obs[s1 * D + d] = o[k];
+            }
+          }
+        }
+      } else {
+        if (q == 0 && ok) {
+          float s[4] = {est[0], est[1], est[2], est[3]};
+          const int action = (int)act_o[0];
+          const bool term = cartpole_step(s, action);
+          est[4] += 1.f;
+          const bool trunc = est[4] >= (float)A.r.episode_limit;
+          const bool done = term || trunc;
+          const float rew = 1.0f;
+          b.rewards[(size_t)t * N + n] = rew;
+          b.masks[s1] = done ? 0.f : 1.f;
+          b.active_masks[s1] = 1.f;
+          b.bad_masks[s1] = 1.f;
+          ep_ret += rew; ep_len += 1.f;
+          if (done) {
+            fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f;
+            est[5] += 1.f;
+            est[4] = 0.f;
+            cartpole_reset(A.r.env_seed, (uint32_t)n, (uint32_t)est[5], s);  // auto-reset: obs = first obs of new episode
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            est[k] = s[k];
+            nxt[j * DP + k] = s[k];
+            b.policy_obs[s1 * 4 + k] = s[k];
+            if (sep_c) b.critic_obs[s1 * 4 + k] = s[k];
+          }
+        } else if (q == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) nxt[j * DP + k] = 0.f;
+        }
+      }
+      if (b.action_masks != nullptr && ok && q == 0) {
+        for (int c = 0; c < b.K; ++c) b.action_masks[s1 * b.K + c] = 1.f;
+      }
+    } else {
+      f32x4 n2[4];
+      const float* lc = smem + twp.total;
+      trunk_fwd_T(lc, twc, xb, j, q, n2);
+      float v[1];
+      head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
+      if (ok && q == 0) A.r.value_preds[(size_t)t * N + n] = v[0];
+    }
+    __syncthreads();
+  }
+  // bootstrap value of the last observation (OnPolicyDriver.compute_returns, onpolicy_driver.py:205-233)
+  if (wave == 1 && A.next_value != nullptr) {
+    const float* cur = s_obs + (T & 1) * TILE_B * DP;
+    auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
+    f32x4 n2[4];
+    const float* lc = smem + twp.total;
+    trunk_fwd_T(lc, twc, xb, j, q, n2);
+    float v[1];
+    head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
+    if (ok && q == 0) A.next_value[n] = v[0];
+  }
+  if (wave == 0 && q == 0 && ok) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < SW) A.r.env_state[(size_t)n * SW + k] = est[k];
+    A.r.ep_stats[n * 4 + 0] = ep_ret; A.r.ep_stats[n * 4 + 1] = ep_len;
+    A.r.ep_stats[n * 4 + 2] = fin_ret; A.r.ep_stats[n * 4 + 3] = fin_cnt;
+  }
+}
+
+static int check_net(const orl_net_desc* n, const char* who, bool is_critic) {
+  if (!n) return fail(ORL_E_INVALID, "%s: null net descriptor", who);
+  if (n->hidden != HID) return fail(ORL_E_UNSUPPORTED, "%s: hidden_size %d not built (only 64)", who, n->hidden);
+  if (n->obs_dim < 1 || n->obs_dim > 256) return fail(ORL_E_INVALID, "%s: obs_dim %d outside [1,256]", who, n->obs_dim);
+  if (is_critic) {
+    if (n->head_kind != ORL_HEAD_VALUE || n->n_out != 1) return fail(ORL_E_INVALID, "%s: critic must be a value head", who);
+  } else {
+    if (n->head_kind != ORL_HEAD_CATEGORICAL && n->head_kind != ORL_HEAD_GAUSSIAN)
+      return fail(ORL_E_UNSUPPORTED, "%s: head kind %d not built (Discrete / Box only)", who, n->head_kind);
+    if (n->n_out < 1 || n->n_out > 16) return fail(ORL_E_UNSUPPORTED, "%s: n_out %d outside [1,16]", who, n->n_out);
+  }
+  return 0;
+}
+
+}  // namespace orl
+
+using namespace orl;
+
+#define ORL_DISPATCH_HEAD(KERNEL_MACRO)                                        \
+  do {                                                                         \
+    const int no = pnet->n_out;                                                \
+    if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {                             \
+      if (no <= 2) KERNEL_MACRO(2, ORL_HEAD_CATEGORICAL);                      \
+      else if (no <= 8) KERNEL_MACRO(8, ORL_HEAD_CATEGORICAL);                 \
+      else KERNEL_MACRO(16, ORL_HEAD_CATEGORICAL);                             \
+    } else {                                                                   \
+      if (no <= 2) KERNEL_MACRO(2, ORL_HEAD_GAUSSIAN);                         \
+      else if (no <= 8) KERNEL_MACRO(8, ORL_HEAD_GAUSSIAN);                    \
+      else KERNEL_MACRO(16, ORL_HEAD_GAUSSIAN);                                \
+    }                                                                          \
+  } while (0)
+
+extern "C" {
+
+int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                 const float* policy_obs, const float* critic_obs, const float* action_masks, int B,
+                 int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const float* forced_u,
+                 float* values, float* actions, float* logp, void* stream) {
+  int rc = check_net(pnet, "orl_act_step(policy)", false);
+  if (rc) return rc;
+  ORL_REQUIRE(ptheta && policy_obs && actions && logp, "orl_act_step: null policy pointer");
+  ORL_REQUIRE(B > 0, "orl_act_step: B=%d", B);
+  size_t lds = TowerLds(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false).total;
+  if (ctheta) {
+    rc = check_net(cnet, "orl_act_step(critic)", true);
+    if (rc) return rc;
+    ORL_REQUIRE(critic_obs && values, "orl_act_step: critic given without critic_obs/values");
+    lds += TowerLds(cnet->obs_dim, 1, false, false).total;
+  }
+  lds *= sizeof(float);
+  ORL_REQUIRE(lds <= 160 * 1024, "orl_act_step: towers need %zu B of LDS (> 160 KiB)", lds);
+  ActArgs A;
+  A.pnet = *pnet;
+  A.cnet = ctheta ? *cnet : *pnet;
+  A.ptheta = ptheta; A.ctheta = ctheta; A.pobs = policy_obs; A.cobs = critic_obs; A.amask = action_masks;
+  A.forced = forced_u; A.values = values; A.actions = actions; A.logp = logp; A.B = B;
+  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step;
+  const int grid = (B + TILE_B - 1) / TILE_B;
+#define ORL_ACT_LAUNCH(NO, HD)                                                                                  \
+  do {                                                                                                          \
+    if (lds > 48 * 1024)                                                                                        \
+      (void)hipFuncSetAttribute((const void*)act_step_kernel<NO, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                      \
+    hipLaunchKernelGGL((act_step_kernel<NO, HD>), dim3(grid), dim3(128), lds, (hipStream_t)stream, A);          \
+  } while (0)
+  ORL_DISPATCH_HEAD(ORL_ACT_LAUNCH);
+#undef ORL_ACT_LAUNCH
+  return launch_status("orl_act_step");
+}
+
+int orl_env_state_width(int env_kind) {
+  if (env_kind == ORL_ENV_SYNTH) return SYNTH_STATE_W;
+  if (env_kind == ORL_ENV_CARTPOLE) return CARTPOLE_STATE_W;
+  return fail(ORL_E_INVALID, "orl_env_state_width: unknown env kind %d", env_kind);
+}
+
+int orl_env_reset(int env_kind, float* env_state, float* ep_stats, float* obs0, int N, int obs_dim,
+                  uint64_t env_seed, int episode_limit, void* stream) {
+  ORL_REQUIRE(env_state && obs0 && N > 0 && obs_dim > 0 && episode_limit > 0, "orl_env_reset: bad arguments");
+  const int grid = (N + 255) / 256;
+  if (env_kind == ORL_ENV_SYNTH) {
+    hipLaunchKernelGGL((env_reset_kernel<ORL_ENV_SYNTH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, env_state,
+                       ep_stats, obs0, N, obs_dim, env_seed, episode_limit);
+  } else if (env_kind == ORL_ENV_CARTPOLE) {
+    ORL_REQUIRE(obs_dim == 4, "orl_env_reset: CartPole obs_dim must be 4");
+    hipLaunchKernelGGL((env_reset_kernel<ORL_ENV_CARTPOLE>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       env_state, ep_stats, obs0, N, obs_dim, env_seed, episode_limit);
+  } else {
+    return fail(ORL_E_INVALID, "orl_env_reset: unknown env kind %d", env_kind);
+  }
+  return launch_status("orl_env_reset");
+}
+
+int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                      const orl_rollout_args* args, float* next_value, void* stream) {
+  int rc = check_net(pnet, "orl_rollout_fused(policy)", false);
+  if (rc) return rc;
+  rc = check_net(cnet, "orl_rollout_fused(critic)", true);
+  if (rc) return rc;
+  ORL_REQUIRE(ptheta && ctheta && args, "orl_rollout_fused: null pointer");
+  const orl_buffer_ptrs& b = args->buf;
+  ORL_REQUIRE(b.A == 1, "orl_rollout_fused: device envs are single-agent (A=%d)", b.A);
+  ORL_REQUIRE(b.Dp == pnet->obs_dim && b.Dc == cnet->obs_dim && b.Dp == b.Dc,
+              "orl_rollout_fused: obs dims buffer(%d,%d) nets(%d,%d)", b.Dp, b.Dc, pnet->obs_dim, cnet->obs_dim);
+  ORL_REQUIRE(b.policy_obs && b.critic_obs && b.rewards && b.masks && b.bad_masks && b.active_masks &&
+                  args->value_preds && args->actions && args->action_log_probs && args->env_state && args->ep_stats,
+              "orl_rollout_fused: null buffer array");
+  ORL_REQUIRE(args->episode_limit > 0, "orl_rollout_fused: episode_limit");
+  if (args->env_kind == ORL_ENV_CARTPOLE)
+    ORL_REQUIRE(pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 2 && b.Dp == 4,
+                "orl_rollout_fused: CartPole needs Discrete(2) and 4-d obs");
+  const TowerLds twp(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false);
+  const TowerLds twc(cnet->obs_dim, 1, false, false);
+  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP) * sizeof(float);
+  ORL_REQUIRE(lds <= 160 * 1024, "orl_rollout_fused: needs %zu B of LDS", lds);
+  RolloutArgs A;
+  A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.r = *args; A.next_value = next_value;
+  const int grid = (b.N + TILE_B - 1) / TILE_B;
+#define ORL_RO_LAUNCH2(NO, HD, EV)                                                                                  \
+  do {                                                                                                              \
+    if (lds > 48 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)rollout_kernel<NO, HD, EV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                          \
+    hipLaunchKernelGGL((rollout_kernel<NO, HD, EV>), dim3(grid), dim3(128), lds, (hipStream_t)stream, A);          \
+  } while (0)
+  if (args->env_kind == ORL_ENV_SYNTH) {
+#define ORL_RO_LAUNCH(NO, HD) ORL_RO_LAUNCH2(NO, HD, ORL_ENV_SYNTH)
+    ORL_DISPATCH_HEAD(ORL_RO_LAUNCH);
+#undef ORL_RO_LAUNCH
+  } else if (args->env_kind == ORL_ENV_CARTPOLE) {
+    ORL_RO_LAUNCH2(2, ORL_HEAD_CATEGORICAL, ORL_ENV_CARTPOLE);
+  } else {
+    return fail(ORL_E_INVALID, "orl_rollout_fused: unknown env kind %d", args->env_kind);
+  }
+#undef ORL_RO_LAUNCH2
+  return launch_status("orl_rollout_fused");
+}
+
+}  // extern "C"

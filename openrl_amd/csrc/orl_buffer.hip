@@ -1,0 +1,570 @@
+// orl_buffer.hip - replay-buffer side of the hot path for gfx950:
+//   K5 insert + mask construction, K6 GAE/return reverse scan (+K7a advantage & statistics),
+//   K7b advantage normalisation + update-record packing, K8 minibatch gather, keyed permutation,
+//   ValueNorm state update, minibatch return moments.
+// All of these are HBM / latency bound integer-and-fp32 streaming kernels: coalesced row
+// accesses over the [T(+1), N*A] lane grid, LDS staging for the time scan, wave64 shuffles for
+// reductions.  No MFMA here by design.
+#include "orl_common.h"
+
+namespace orl {
+
+thread_local char g_err[512] = {0};
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: GAE / return scan.  One workgroup = 64 lanes x all T steps, processed in reverse time chunks
+// staged through LDS: the 4 waves stream a [TC x 64] tile of each input with every thread keeping
+// several independent 256-byte-row loads in flight, then wave 0 runs the sequential recurrence out
+// of LDS and writes returns / raw advantages as coalesced 256-byte rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int GAE_LANES = 64;
+constexpr int GAE_TC = 32;  // time chunk
+constexpr int GAE_THREADS = 256;
+
+struct VnCoef {
+  float sd, mean;
+  int on;
+};
+
+__device__ inline VnCoef vn_coef(const float* vn_state) {
+#pragma clang fp contract(off)
+  VnCoef c;
+  c.on = vn_state != nullptr;
+  c.sd = 1.f;
+  c.mean = 0.f;
+  if (c.on) {
+    // ValueNorm.running_mean_var (valuenorm.py:45-52): clamp(debias, 1e-5), var >= 1e-2
+    const float deb = fmaxf(vn_state[2], 1e-5f);
+    const float m = vn_state[0] / deb;
+    const float msq = vn_state[1] / deb;
+    const float var = fmaxf(msq - m * m, 1e-2f);
+    c.sd = sqrtf(var);
+    c.mean = m;
+  }
+  return c;
+}
+
+__device__ inline float vn_denorm(const VnCoef& c, float v) {
+#pragma clang fp contract(off)
+  if (!c.on) return v;
+  const float t = v * c.sd;
+  return t + c.mean;
+}
+
+template <bool USE_GAE, bool PROPER>
+__global__ __launch_bounds__(GAE_THREADS) void gae_scan_kernel(
+    const float* __restrict__ rewards, float* __restrict__ value_preds, const float* __restrict__ masks,
+    const float* __restrict__ bad_masks, const float* __restrict__ next_value, const float* __restrict__ vn_state,
+    float* __restrict__ returns, int T, int L, float gamma, float gl, const float* __restrict__ active_masks,
+    float* __restrict__ adv_raw, double* __restrict__ stat_partials) {
+#pragma clang fp contract(off)
+  // LDS tiles: index [tt][lane]; v has TC+1 rows (needs V[t+1]), m/bad rows are for t+1.
+  __shared__ float s_r[GAE_TC][GAE_LANES];
+  __shared__ float s_v[GAE_TC + 1][GAE_LANES];
+  __shared__ float s_m[GAE_TC][GAE_LANES];
+  __shared__ float s_b[GAE_TC][GAE_LANES];
+  __shared__ float s_a[GAE_TC][GAE_LANES];
+
+  const int lane0 = blockIdx.x * GAE_LANES;
+  const int tid = threadIdx.x;
+  const int ln = tid & 63;
+  const int l = lane0 + ln;
+  const bool lane_ok = l < L;
+  const VnCoef vc = vn_coef(vn_state);
+  const bool want_stats = stat_partials != nullptr;
+
+  // slot T gets next_value first (replay_data.py:323/360/384/418)
+  if (tid < GAE_LANES && lane_ok) {
+    const float nv = next_value[l];
+    if (USE_GAE) value_preds[(size_t)T * L + l] = nv;
+    else returns[(size_t)T * L + l] = nv;
+  }
+
+  float carry = 0.f;  // gae (USE_GAE) or returns[t+1] (otherwise)
+  if (!USE_GAE && tid < GAE_LANES && lane_ok) carry = next_value[l];
+  double s_all = 0, q_all = 0, n_all = 0, s_act = 0, q_act = 0, n_act = 0, s_ret = 0, q_ret = 0;
+
+  for (int t_hi = T; t_hi > 0; t_hi -= GAE_TC) {
+    const int t_lo = (t_hi - GAE_TC > 0) ? t_hi - GAE_TC : 0;
+    const int nt = t_hi - t_lo;
+    __syncthreads();
+    // cooperative staged load: element e -> (tt = e / 64, lane = e % 64)
+    for (int e = tid; e < nt * GAE_LANES; e += GAE_THREADS) {
+      const int tt = e >> 6, la = e & 63;
+      const int gl_ = lane0 + la;
+      if (gl_ < L) {
+        const size_t t = (size_t)(t_lo + tt);
+        s_r[tt][la] = rewards[t * L + gl_];
+        s_v[tt][la] = value_preds[t * L + gl_];
+        s_m[tt][la] = masks[(t + 1) * L + gl_];
+        if (PROPER) s_b[tt][la] = bad_masks[(t + 1) * L + gl_];
+        if (want_stats) s_a[tt][la] = active_masks[t * L + gl_];
+      }
+    }
+    if (tid < GAE_LANES && lane_ok) {
+      // V[t_hi]: slot T is next_value (just written by this thread - read the source instead)
+      s_v[nt][ln] = (t_hi == T) ? (USE_GAE ? next_value[l] : 0.f) : value_preds[(size_t)t_hi * L + l];
+    }
+    __syncthreads();
+    if (tid < GAE_LANES && lane_ok) {
+      for (int tt = nt - 1; tt >= 0; --tt) {
+        const size_t t = (size_t)(t_lo + tt);
+        const float r = s_r[tt][ln];
+        const float m = s_m[tt][ln];
+        const float v_cur = vn_denorm(vc, s_v[tt][ln]);
+        float ret;
+        if (USE_GAE) {
+          const float v_nxt = vn_denorm(vc, s_v[tt + 1][ln]);
+          // delta = r + gamma * V'(t+1) * m(t+1) - V'(t)      (replay_data.py:390-396)
+          const float a0 = gamma * v_nxt;
+          const float a1 = a0 * m;
+          const float a2 = r + a1;
+          const float delta = a2 - v_cur;
+          // gae = delta + gamma*lambda * m(t+1) * gae        (:397-400)
+          const float b0 = gl * m;
+          const float b1 = b0 * carry;
+          float gae = delta + b1;
+          if (PROPER) gae = gae * s_b[tt][ln];  // (:341/357)
+          carry = gae;
+          ret = gae + v_cur;
+        } else {
+          // returns[t] = returns[t+1]*gamma*m(t+1) + r  [ *bad + (1-bad)*V'(t) ]  (:365-381, :420-423)
+          const float c0 = carry * gamma;
+          const float c1 = c0 * m;
+          float x = c1 + r;
+          if (PROPER) {
+            const float b = s_b[tt][ln];
+            const float y0 = x * b;
+            const float y1 = (1.f - b) * v_cur;
+            x = y0 + y1;
+          }
+          carry = x;
+          ret = x;
+        }
+        returns[t * L + l] = ret;
+        if (adv_raw != nullptr || want_stats) {
+          const float adv = ret - v_cur;  // ppo.py:394-400
+          if (adv_raw != nullptr) adv_raw[t * L + l] = adv;
+          if (want_stats) {
+            const double a = (double)adv;
+            s_all += a; q_all += a * a; n_all += 1.0;
+            if (s_a[tt][ln] != 0.f) { s_act += a; q_act += a * a; n_act += 1.0; }
+            const double rr = (double)ret;
+            s_ret += rr; q_ret += rr * rr;
+          }
+        }
+      }
+    }
+  }
+  if (want_stats && tid < GAE_LANES) {
+    s_all = wave_sum(s_all); q_all = wave_sum(q_all); n_all = wave_sum(n_all);
+    s_act = wave_sum(s_act); q_act = wave_sum(q_act); n_act = wave_sum(n_act);
+    s_ret = wave_sum(s_ret); q_ret = wave_sum(q_ret);
+    if (tid == 0) {
+      double* p = stat_partials + (size_t)blockIdx.x * 8;
+      p[0] = s_all; p[1] = q_all; p[2] = n_all; p[3] = s_act; p[4] = q_act; p[5] = n_act; p[6] = s_ret; p[7] = q_ret;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7b: advantage normalisation + record packing.  Every workgroup re-reduces the (few) partial
+// rows with wave shuffles, then streams its slice of the T*L samples.
+// ------------------------------------------------------------------------------------------------
+struct AdvCoef {
+  float m1, s1;  // use_adv_normalize stage
+  float m2, s2;  // active-mask nan-stats stage
+};
+
+__device__ inline void reduce_partials(const double* __restrict__ partials, int n, double out[8]) {
+  __shared__ double s_red[4][8];
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += partials[(size_t)i * 8 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_red[w][k] = acc[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double s = 0;
+    for (int ww = 0; ww < (int)(blockDim.x >> 6); ++ww) s += s_red[ww][k];
+    out[k] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void adv_normalize_pack_kernel(float* __restrict__ adv,
+                                                                 const double* __restrict__ partials, int n_partials,
+                                                                 long long M, int L, int use_adv_normalize,
+                                                                 double* __restrict__ stats_out, orl_pack_src src,
+                                                                 float* __restrict__ records, int R) {
+#pragma clang fp contract(off)
+  double st[8];
+  reduce_partials(partials, n_partials, st);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && stats_out != nullptr) {
+    for (int k = 0; k < 8; ++k) stats_out[k] = st[k];
+  }
+  AdvCoef c;
+  // stage 1 (optional): numpy mean()/std() over ALL entries (ppo.py:402-403)
+  double mean_all = st[0] / st[2];
+  double var_all = st[1] / st[2] - mean_all * mean_all;
+  if (var_all < 0) var_all = 0;
+  double mean_act = st[3] / st[5];
+  double var_act = st[4] / st[5] - mean_act * mean_act;
+  if (var_act < 0) var_act = 0;
+  double std_act = sqrt(var_act);
+  if (use_adv_normalize) {
+    c.m1 = (float)mean_all;
+    c.s1 = (float)sqrt(var_all) + 1e-5f;
+    // statistics of y = (x - m1)/s1 over the active subset follow analytically
+    const double m1 = (double)c.m1, s1 = (double)c.s1;
+    mean_act = (mean_act - m1) / s1;
+    std_act = std_act / s1;
+  } else {
+    c.m1 = 0.f;
+    c.s1 = 1.f;
+  }
+  // stage 2 (always): nanmean / nanstd over active entries (ppo.py:405-409)
+  c.m2 = (float)mean_act;
+  c.s2 = (float)std_act + 1e-5f;
+
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (records == nullptr) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
+      float x = adv[i];
+      if (use_adv_normalize) x = (x - c.m1) / c.s1;
+      adv[i] = (x - c.m2) / c.s2;
+    }
+    return;
+  }
+  // fused: each thread produces one float of one record (coalesced record writes)
+  const int Dp = src.Dp, Dc = src.Dc, a = src.a, K = src.K;
+  const int o_co = Dp, o_ac = o_co + Dc, o_lp = o_ac + a, o_adv = o_lp + a, o_vp = o_adv + 1, o_rt = o_vp + 1,
+            o_am = o_rt + 1, o_mk = o_am + 1, o_end = o_mk + K;
+  const long long total = M * (long long)R;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const long long row = e / R;
+    const int col = (int)(e - row * R);
+    float v;
+    if (col < o_co) v = src.policy_obs[row * Dp + col];
+    else if (col < o_ac) v = src.critic_obs[row * Dc + (col - o_co)];
+    else if (col < o_lp) v = src.actions[row * a + (col - o_ac)];
+    else if (col < o_adv) v = src.action_log_probs[row * a + (col - o_lp)];
+    else if (col == o_adv) {
+      float x = adv[row];
+      if (use_adv_normalize) x = (x - c.m1) / c.s1;
+      v = (x - c.m2) / c.s2;
+      adv[row] = v;
+    } else if (col == o_vp) v = src.value_preds[row];
+    else if (col == o_rt) v = src.returns[row];
+    else if (col == o_am) v = src.active_masks[row];
+    else if (col < o_end) v = (src.action_masks != nullptr) ? src.action_masks[row * K + (col - o_mk)] : 1.f;
+    else v = 0.f;
+    records[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: insert + mask construction for one step.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void buffer_insert_kernel(orl_buffer_ptrs b, int step,
+                                                            const float* __restrict__ nobs_p,
+                                                            const float* __restrict__ nobs_c,
+                                                            const float* __restrict__ rew,
+                                                            const uint8_t* __restrict__ dones,
+                                                            const uint8_t* __restrict__ bad,
+                                                            const float* __restrict__ namask) {
+  const int LA = b.N * b.A;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t s1 = (size_t)(step + 1);
+  for (long long i = i0; i < (long long)LA * b.Dp; i += stride) b.policy_obs[s1 * LA * b.Dp + i] = nobs_p[i];
+  if (b.critic_obs != b.policy_obs || nobs_c != nobs_p) {
+    for (long long i = i0; i < (long long)LA * b.Dc; i += stride) b.critic_obs[s1 * LA * b.Dc + i] = nobs_c[i];
+  }
+  if (b.action_masks != nullptr && namask != nullptr) {
+    for (long long i = i0; i < (long long)LA * b.K; i += stride) b.action_masks[s1 * LA * b.K + i] = namask[i];
+  }
+  for (long long i = i0; i < LA; i += stride) {
+    const int n = (int)(i / b.A);
+    bool all_done = true;
+    for (int a = 0; a < b.A; ++a) all_done = all_done && (dones[n * b.A + a] != 0);
+    const bool d = dones[i] != 0;
+    b.rewards[(size_t)step * LA + i] = rew[i];
+    b.masks[s1 * LA + i] = all_done ? 0.f : 1.f;                 // onpolicy_driver.py:110-113
+    b.active_masks[s1 * LA + i] = (d && !all_done) ? 0.f : 1.f;  // :119-125
+    b.bad_masks[s1 * LA + i] = (bad != nullptr && bad[i] != 0) ? 0.f : 1.f;  // :126-138
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: multi-array row gather.  One thread per output float; descriptors live in kernel args.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_kernel(orl_gather_desc d, const int64_t* __restrict__ idx, int n_rows,
+                                                     int total_w) {
+  const long long total = (long long)n_rows * total_w;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int row = (int)(e / total_w);
+    int col = (int)(e - (long long)row * total_w);
+    const long long src_row = idx[row];
+    for (int k = 0; k < d.count; ++k) {
+      const int w = d.width[k];
+      if (col < w) {
+        d.dst[k][(size_t)row * w + col] = d.src[k][(size_t)src_row * w + col];
+        break;
+      }
+      col -= w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Keyed permutation of [0,n): balanced Feistel network over 2*hb bits (2^(2hb) >= n) with
+// cycle walking; round function = one Philox4x32-10 block of (half, round) under the key.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t feistel_perm(uint64_t i, uint64_t n, int hb, uint64_t seed, uint64_t stream_id) {
+  const uint64_t hmask = ((uint64_t)1 << hb) - 1;
+  uint64_t x = i;
+  do {
+    uint64_t lft = x >> hb, rgt = x & hmask;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u4 f = philox4x32_10(seed, (uint32_t)rgt, (uint32_t)(rgt >> 32), (uint32_t)stream_id,
+                                 (uint32_t)(stream_id >> 32) * 4u + (uint32_t)r);
+      const uint64_t fv = (((uint64_t)f.y << 32) | f.x) & hmask;
+      const uint64_t nl = rgt;
+      rgt = lft ^ fv;
+      lft = nl;
+    }
+    x = (lft << hb) | rgt;
+  } while (x >= n);
+  return x;
+}
+
+__global__ __launch_bounds__(256) void perm_feistel_kernel(int64_t* __restrict__ idx, long long n, int hb,
+                                                           uint64_t seed, uint64_t stream_id) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    idx[i] = (int64_t)feistel_perm((uint64_t)i, (uint64_t)n, hb, seed, stream_id);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ValueNorm.update (valuenorm.py:58-77) from batch sums, and minibatch return moments.
+// ------------------------------------------------------------------------------------------------
+__global__ void valuenorm_update_kernel(float* __restrict__ vn, const double* __restrict__ mom, float beta) {
+#pragma clang fp contract(off)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double cnt = mom[2];
+  const float bm = (float)(mom[0] / cnt);
+  const float bsq = (float)(mom[1] / cnt);
+  const float omw = (float)(1.0 - (double)beta);  // python: (1.0 - weight) in double, cast by torch to f32
+  const float t0 = bm * omw;
+  const float t1 = bsq * omw;
+  vn[0] = vn[0] * beta + t0;
+  vn[1] = vn[1] * beta + t1;
+  vn[2] = vn[2] * beta + omw;
+}
+
+__global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ records, int R, int col,
+                                                              const int64_t* __restrict__ idx, int mb,
+                                                              double* __restrict__ scratch) {
+  double s = 0, q = 0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < mb; i += stride) {
+    const long long r = idx != nullptr ? idx[i] : i;
+    const double x = (double)records[(size_t)r * R + col];
+    s += x;
+    q += x * x;
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  __shared__ double sh[4][2];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w][0] = s; sh[w][1] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ss = 0, qq = 0;
+    for (int k = 0; k < 4; ++k) { ss += sh[k][0]; qq += sh[k][1]; }
+    scratch[blockIdx.x * 2 + 0] = ss;
+    scratch[blockIdx.x * 2 + 1] = qq;
+  }
+}
+
+__global__ __launch_bounds__(64) void moments_final_kernel(const double* __restrict__ scratch, int nb, int mb,
+                                                           double* __restrict__ moments) {
+  double s = 0, q = 0;
+  for (int i = threadIdx.x; i < nb; i += 64) { s += scratch[i * 2]; q += scratch[i * 2 + 1]; }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (threadIdx.x == 0) { moments[0] = s; moments[1] = q; moments[2] = (double)mb; }
+}
+
+constexpr int MOM_BLOCKS = 256;
+
+}  // namespace orl
+
+using namespace orl;
+
+extern "C" {
+
+int orl_version(void) { return ORL_VERSION; }
+const char* orl_last_error_string(void) { return g_err; }
+
+int orl_param_count(const orl_net_desc* net) {
+  if (!net) return ORL_E_INVALID;
+  return TowerLayout(*net).total;
+}
+
+int orl_raw_grad_count(const orl_net_desc* net) {
+  if (!net) return ORL_E_INVALID;
+  return RawLayout(*net).total;
+}
+
+int orl_gae_max_partials(int T, int L) {
+  (void)T;
+  return (L + GAE_LANES - 1) / GAE_LANES;
+}
+
+int orl_gae_scan(const float* rewards, float* value_preds, const float* masks, const float* bad_masks,
+                 const float* next_value, const float* vn_state, float* returns, int T, int L, double gamma,
+                 double gae_lambda, int flags, const float* active_masks, float* adv_raw, double* stat_partials,
+                 int* n_partials, void* stream) {
+  ORL_REQUIRE(rewards && value_preds && masks && next_value && returns, "orl_gae_scan: null buffer pointer");
+  ORL_REQUIRE(T > 0 && L > 0, "orl_gae_scan: T=%d L=%d must be positive", T, L);
+  const bool use_gae = flags & 1, proper = flags & 2;
+  ORL_REQUIRE(!proper || bad_masks, "orl_gae_scan: use_proper_time_limits needs bad_masks");
+  ORL_REQUIRE(!stat_partials || active_masks, "orl_gae_scan: statistics need active_masks");
+  const int grid = (L + GAE_LANES - 1) / GAE_LANES;
+  const float g = (float)gamma;
+  const float gl = (float)(gamma * gae_lambda);  // python computes gamma*gae_lambda in double first
+  hipStream_t s = (hipStream_t)stream;
+#define ORL_GAE_LAUNCH(UG, PR)                                                                                     \
+  hipLaunchKernelGGL((gae_scan_kernel<UG, PR>), dim3(grid), dim3(GAE_THREADS), 0, s, rewards, value_preds, masks, \
+                     bad_masks, next_value, vn_state, returns, T, L, g, gl, active_masks, adv_raw, stat_partials)
+  if (use_gae && proper) ORL_GAE_LAUNCH(true, true);
+  else if (use_gae) ORL_GAE_LAUNCH(true, false);
+  else if (proper) ORL_GAE_LAUNCH(false, true);
+  else ORL_GAE_LAUNCH(false, false);
+#undef ORL_GAE_LAUNCH
+  if (n_partials) *n_partials = grid;
+  return launch_status("orl_gae_scan");
+}
+
+int orl_record_width(int Dp, int Dc, int a, int K) {
+  const int w = Dp + Dc + 2 * a + 4 + K;
+  return (w + 3) & ~3;
+}
+
+int orl_adv_normalize_pack(float* adv, const double* stat_partials, int n_partials, int T, int L,
+                           int use_adv_normalize, double* stats_out, const orl_pack_src* src, float* records,
+                           void* stream) {
+  ORL_REQUIRE(adv && stat_partials && n_partials > 0, "orl_adv_normalize_pack: null adv/partials");
+  ORL_REQUIRE(T > 0 && L > 0, "orl_adv_normalize_pack: bad geometry");
+  ORL_REQUIRE((records == nullptr) == (src == nullptr), "orl_adv_normalize_pack: records and src go together");
+  orl_pack_src s0 = {};
+  int R = 0;
+  if (src) {
+    s0 = *src;
+    ORL_REQUIRE(s0.policy_obs && s0.critic_obs && s0.actions && s0.action_log_probs && s0.value_preds &&
+                    s0.returns && s0.active_masks,
+                "orl_adv_normalize_pack: null source array");
+    R = orl_record_width(s0.Dp, s0.Dc, s0.a, s0.K);
+  }
+  const long long M = (long long)T * L;
+  long long work = records ? M * R : M;
+  int grid = (int)((work + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(adv_normalize_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, adv, stat_partials,
+                     n_partials, M, L, use_adv_normalize, stats_out, s0, records, R);
+  return launch_status("orl_adv_normalize_pack");
+}
+
+int orl_buffer_insert(const orl_buffer_ptrs* buf, int step, const float* next_policy_obs,
+                      const float* next_critic_obs, const float* rewards, const uint8_t* dones,
+                      const uint8_t* bad_transition, const float* next_action_masks, void* stream) {
+  ORL_REQUIRE(buf && next_policy_obs && next_critic_obs && rewards && dones, "orl_buffer_insert: null pointer");
+  ORL_REQUIRE(step >= 0 && step < buf->T, "orl_buffer_insert: step %d outside [0,%d)", step, buf->T);
+  ORL_REQUIRE(buf->policy_obs && buf->critic_obs && buf->rewards && buf->masks && buf->bad_masks && buf->active_masks,
+              "orl_buffer_insert: null buffer array");
+  const long long work = (long long)buf->N * buf->A * (buf->Dp > buf->Dc ? buf->Dp : buf->Dc);
+  int grid = (int)((work + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(buffer_insert_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *buf, step,
+                     next_policy_obs, next_critic_obs, rewards, dones, bad_transition, next_action_masks);
+  return launch_status("orl_buffer_insert");
+}
+
+int orl_gather_minibatch(const orl_gather_desc* desc, const int64_t* idx, int n_rows, void* stream) {
+  ORL_REQUIRE(desc && idx, "orl_gather_minibatch: null pointer");
+  ORL_REQUIRE(desc->count > 0 && desc->count <= ORL_GATHER_MAX, "orl_gather_minibatch: count %d", desc->count);
+  if (n_rows == 0) return 0;
+  ORL_REQUIRE(n_rows > 0, "orl_gather_minibatch: negative n_rows");
+  int total_w = 0;
+  for (int k = 0; k < desc->count; ++k) {
+    ORL_REQUIRE(desc->src[k] && desc->dst[k] && desc->width[k] > 0, "orl_gather_minibatch: bad descriptor %d", k);
+    total_w += desc->width[k];
+  }
+  const long long work = (long long)n_rows * total_w;
+  int grid = (int)((work + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *desc, idx, n_rows, total_w);
+  return launch_status("orl_gather_minibatch");
+}
+
+int orl_perm_feistel(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+  ORL_REQUIRE(idx && n > 0, "orl_perm_feistel: bad arguments");
+  int bits = 1;
+  while (((int64_t)1 << bits) < n) ++bits;
+  const int hb = (bits + 1) / 2;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(perm_feistel_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, (long long)n, hb, seed,
+                     stream_id);
+  return launch_status("orl_perm_feistel");
+}
+
+int orl_valuenorm_update(float* vn_state, const double* moments, float beta, void* stream) {
+  ORL_REQUIRE(vn_state && moments, "orl_valuenorm_update: null pointer");
+  hipLaunchKernelGGL(valuenorm_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vn_state, moments, beta);
+  return launch_status("orl_valuenorm_update");
+}
+
+int orl_minibatch_moments(const float* records, int rec_width, int ret_col, const int64_t* idx, int mb,
+                          double* scratch, double* moments, void* stream) {
+  ORL_REQUIRE(records && scratch && moments && mb > 0, "orl_minibatch_moments: bad arguments");
+  ORL_REQUIRE(ret_col >= 0 && ret_col < rec_width, "orl_minibatch_moments: column outside record");
+  int nb = (mb + 255) / 256;
+  if (nb > MOM_BLOCKS) nb = MOM_BLOCKS;
+  hipLaunchKernelGGL(moments_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, records, rec_width,
+                     ret_col, idx, mb, scratch);
+  hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, nb, mb, moments);
+  return launch_status("orl_minibatch_moments");
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// orl_common.h - shared device/host helpers for the gfx950 kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/orl_hip.h"
+
+#define ORL_WAVE 64
+
+namespace orl {
+
+// ---- error reporting -----------------------------------------------------------------------
+extern thread_local char g_err[512];
+int fail(int code, const char* fmt, ...);
+int launch_status(const char* what);  // hipGetLastError -> return code (+message)
+
+#define ORL_REQUIRE(cond, ...)                            \
+  do {                                                    \
+    if (!(cond)) return ::orl::fail(ORL_E_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// ---- parameter layout of one tower (matches the reference state_dict order) -------------------------
+struct TowerLayout {
+  int D, H, n_out, head;
+  int oW1, ob1, og1, obe1, oW2, ob2, og2, obe2, oW3, ob3, ologstd, total;
+  __host__ __device__ TowerLayout() {}
+  __host__ __device__ explicit TowerLayout(const orl_net_desc& n) {
+    D = n.obs_dim; H = n.hidden; n_out = n.n_out; head = n.head_kind;
+    int o = 0;
+    oW1 = o; o += H * D;
+    ob1 = o; o += H;
+    og1 = o; o += H;
+    obe1 = o; o += H;
+    oW2 = o; o += H * H;
+    ob2 = o; o += H;
+    og2 = o; o += H;
+    obe2 = o; o += H;
+    oW3 = o; o += n_out * H;
+    ob3 = o; o += n_out;
+    ologstd = o;
+    if (head == ORL_HEAD_GAUSSIAN) o += n_out;
+    total = o;
+  }
+};
+
+// Raw gradient-sum vector of one tower (what the fused backward accumulates; see orl_ppo.hip):
+//   G[H*H]   = sum_r dz2[r][o] * xhat1[r][i]          (dW2 = g1[i]*G + be1[i]*db2[o])
+//   S3[n_out*H] = sum_r dhead[r][c] * xhat2[r][f]     (dW3 = g2[f]*S3 + be2[f]*db3[c])
+//   db3[n_out], dg2[H], dbe2[H], db2[H], dg1[H], dbe1[H], dW1[H*D], db1[H], dlogstd[n_out]
+struct RawLayout {
+  int oG, oS3, odb3, odg2, odbe2, odb2, odg1, odbe1, odW1, odb1, odlogstd, total;
+  __host__ __device__ RawLayout() {}
+  __host__ __device__ explicit RawLayout(const orl_net_desc& n) {
+    const int H = n.hidden, D = n.obs_dim, K = n.n_out;
+    int o = 0;
+    oG = o; o += H * H;
+    oS3 = o; o += K * H;
+    odb3 = o; o += K;
+    odg2 = o; o += H;
+    odbe2 = o; o += H;
+    odb2 = o; o += H;
+    odg1 = o; o += H;
+    odbe1 = o; o += H;
+    odW1 = o; o += H * D;
+    odb1 = o; o += H;
+    odlogstd = o; o += (n.head_kind == ORL_HEAD_GAUSSIAN ? K : 0);
+    total = o;
+  }
+};
+
+// stats vector slots (sums over the minibatch rows; see orl_ppo.hip)
+enum {
+  ST_ACTIVE_SUM = 0,   // sum(active)
+  ST_ROWS = 1,         // number of rows
+  ST_VLOSS_SUM = 2,    // sum(value_loss_row * (active or 1))
+  ST_PLOSS_SUM = 3,    // sum(-sum_dim surr * (active or 1))
+  ST_ENT_SUM = 4,      // sum(entropy_row * (active or 1))
+  ST_RATIO_SUM = 5,    // sum over rows and dims of ratio
+  ST_RATIO_CNT = 6,    // rows * dims
+};
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based RNG used for action sampling and the
+// synthetic env.  The oracle restates it in numpy (oracle/philox.py) so streams are comparable.
+struct u4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline void philox_round(u4& c, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint64_t p0 = (uint64_t)M0 * c.x;
+  const uint64_t p1 = (uint64_t)M1 * c.z;
+  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+  u4 r;
+  r.x = hi1 ^ c.y ^ k0;
+  r.y = lo1;
+  r.z = hi0 ^ c.w ^ k1;
+  r.w = lo0;
+  c = r;
+}
+
+__host__ __device__ inline u4 philox4x32_10(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  u4 c{c0, c1, c2, c3};
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// uniform in [0,1) with 24 bits; uniform in (0,1] for log()
+__host__ __device__ inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+__host__ __device__ inline float u01_open0(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
+
+// ---- wave helpers ------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+}  // namespace orl

@@ -1,0 +1,278 @@
+// orl_mlp.h - wave-level MLP tower primitives for gfx950, shared by the rollout and update kernels.
+//
+// Tile = 16 batch rows per wavefront.  All activations live in registers in the "T layout"
+// (transposed: features down the MFMA M dimension, batch rows across the N dimension), i.e. the
+// C/D fragment of v_mfma_f32_16x16x4_f32 computing  Z^T[64 x 16] = W[64 x K] * X^T[K x 16]:
+//
+//   lane l:  j = l & 15 (batch row of the tile),  q = l >> 4;
+//   act[m][r]  (m = 0..3 M-tiles, r = 0..3)  holds feature f = 16*m + 4*q + r of batch row j.
+//
+// Because the reduction index of a GEMM can be enumerated in any order as long as A and B agree,
+// the C fragment of one layer is fed DIRECTLY as the B operand of the next layer: k-step (m', r')
+// consumes register act[m'][r'] (lane (j,q) contributes feature 16m'+4q+r') and the matching A
+// operand is W[out][16m'+4q+r'], which for r' = 0..3 is one 16-byte LDS read.  No cross-lane
+// movement between layers; LayerNorm statistics of a batch row are an in-lane sum of 16 values
+// plus two xor-shuffles (lanes l, l^16, l^32, l^48 share j).
+//
+// fp32 MFMA is bit-for-bit an fmaf chain (MI355X guide section 3), i.e. plain fp32 GEMM numerics.
+#pragma once
+#include "orl_common.h"
+
+namespace orl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HID = 64;    // hidden width supported by the MFMA towers
+constexpr int W2S = 68;    // padded LDS row stride (floats) of the 64x64 matrices
+constexpr int TILE_B = 16; // batch rows per wave tile
+
+#define ORL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// LDS image of one tower (offsets in floats, all multiples of 4 => 16-byte aligned).
+struct TowerLds {
+  int DP, n_out, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, logstd, W2T, total;
+  __host__ __device__ TowerLds() {}
+  __host__ __device__ TowerLds(int D, int n_out_, bool gaussian, bool with_w2t) {
+    DP = (D + 3) & ~3;
+    n_out = n_out_;
+    const int no4 = (n_out + 3) & ~3;
+    int o = 0;
+    W1 = o; o += HID * DP;
+    b1 = o; o += HID;
+    g1 = o; o += HID;
+    be1 = o; o += HID;
+    W2 = o; o += HID * W2S;
+    b2 = o; o += HID;
+    g2 = o; o += HID;
+    be2 = o; o += HID;
+    W3 = o; o += no4 * HID;
+    b3 = o; o += no4;
+    logstd = o; o += gaussian ? no4 : 0;
+    W2T = o; o += with_w2t ? HID * W2S : 0;
+    total = o;
+  }
+};
+
+// Cooperative global -> LDS staging of a tower (any thread count).  W1 is zero padded to DP
+// columns, W2 re-strided to W2S, optionally also stored transposed (for the backward GEMM).
+__device__ inline void stage_tower(float* __restrict__ lds, const float* __restrict__ theta, const TowerLayout& tl,
+                                   const TowerLds& tw, bool with_w2t, int tid, int nthreads) {
+  const int D = tl.D;
+  for (int e = tid; e < HID * tw.DP; e += nthreads) {
+    const int f = e / tw.DP, k = e - f * tw.DP;
+    lds[tw.W1 + e] = (k < D) ? theta[tl.oW1 + f * D + k] : 0.f;
+  }
+  for (int e = tid; e < HID; e += nthreads) {
+    lds[tw.b1 + e] = theta[tl.ob1 + e];
+    lds[tw.g1 + e] = theta[tl.og1 + e];
+    lds[tw.be1 + e] = theta[tl.obe1 + e];
+    lds[tw.b2 + e] = theta[tl.ob2 + e];
+    lds[tw.g2 + e] = theta[tl.og2 + e];
+    lds[tw.be2 + e] = theta[tl.obe2 + e];
+  }
+  for (int e = tid; e < HID * HID; e += nthreads) {
+    const int o = e >> 6, i = e & 63;
+    const float w = theta[tl.oW2 + e];
+    lds[tw.W2 + o * W2S + i] = w;
+    if (with_w2t) lds[tw.W2T + i * W2S + o] = w;
+  }
+  const int no4 = (tl.n_out + 3) & ~3;
+  for (int e = tid; e < no4 * HID; e += nthreads) lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] : 0.f;
+  for (int e = tid; e < no4; e += nthreads) {
+    lds[tw.b3 + e] = (e < tl.n_out) ? theta[tl.ob3 + e] : 0.f;
+    if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = (e < tl.n_out) ? theta[tl.ologstd + e] : 0.f;
+  }
+}
+
+// acc[m] <- vec[16m+4q .. +3]   (bias init of an accumulator in T layout)
+__device__ inline void load_vec_T(const float* __restrict__ v, int q, f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) acc[m] = *(const f32x4*)(v + 16 * m + 4 * q);
+}
+
+// fc1: acc += W1[64 x DP] * X^T ; xb(s) returns this lane's B operand x[j][4s+q] (0 beyond D).
+template <class XB>
+__device__ inline void fc1_T(const float* __restrict__ W1s, int DP, XB xb, f32x4 (&acc)[4], int j, int q) {
+  for (int s = 0; s < (DP >> 2); ++s) {
+    const float b = xb(s);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float a = W1s[(16 * m + j) * DP + 4 * s + q];
+      acc[m] = ORL_MFMA(a, b, acc[m]);
+    }
+  }
+}
+
+// acc += Ws[64 x 64 (stride W2S)] * in   (both T layout).  64 MFMAs, 16 ds_read_b128.
+__device__ inline void mm64_T(const float* __restrict__ Ws, const f32x4 (&in)[4], f32x4 (&acc)[4], int j, int q) {
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    f32x4 a4[4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) a4[mo] = *(const f32x4*)(Ws + (16 * mo + j) * W2S + 16 * mi + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(a4[mo][r], in[mi][r], acc[mo]);
+    }
+  }
+}
+
+// sum over the 64 features of batch row j (in-lane 16 + lanes l^16, l^32)
+__device__ inline float feat_sum(const f32x4 (&x)[4]) {
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) s += (x[m][0] + x[m][1]) + (x[m][2] + x[m][3]);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  return s;
+}
+
+// LayerNorm statistics + normalisation in place: x <- (x - mean) * rstd   (eps = 1e-5, biased var)
+__device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd) {
+  const float mean = feat_sum(x) * (1.0f / 64.0f);
+  float v = 0.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    x[m] = x[m] - mean;
+    v += (x[m][0] * x[m][0] + x[m][1] * x[m][1]) + (x[m][2] * x[m][2] + x[m][3] * x[m][3]);
+  }
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  rstd = 1.0f / sqrtf(v * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) x[m] = x[m] * rstd;
+}
+
+// out = xhat * g + be
+__device__ inline void ln_affine_T(const f32x4 (&xhat)[4], const float* __restrict__ g, const float* __restrict__ be,
+                                   int q, f32x4 (&out)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const f32x4 gg = *(const f32x4*)(g + 16 * m + 4 * q);
+    const f32x4 bb = *(const f32x4*)(be + 16 * m + 4 * q);
+    out[m] = xhat[m] * gg + bb;
+  }
+}
+
+__device__ inline void relu_T(f32x4 (&x)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[m][r] = fmaxf(x[m][r], 0.f);
+  }
+}
+
+// head: out[c] = b3[c] + sum_f W3[c][f] * n2[f]  for c < NO (compile-time bound, runtime n_out).
+// Every lane of a batch row ends up with the full result.
+template <int NO>
+__device__ inline void head_T(const float* __restrict__ W3s, const float* __restrict__ b3s, int n_out,
+                              const f32x4 (&n2)[4], int q, float (&out)[NO]) {
+#pragma unroll
+  for (int c = 0; c < NO; ++c) {
+    float p = 0.f;
+    if (c < n_out) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const f32x4 w = *(const f32x4*)(W3s + c * HID + 16 * m + 4 * q);
+        p += (w[0] * n2[m][0] + w[1] * n2[m][1]) + (w[2] * n2[m][2] + w[3] * n2[m][3]);
+      }
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      p += b3s[c];
+    }
+    out[c] = p;
+  }
+}
+
+// Whole trunk forward for one tile: returns n2 (post-LN2 activations) in T layout.
+template <class XB>
+__device__ inline void trunk_fwd_T(const float* __restrict__ lds, const TowerLds& tw, XB xb, int j, int q,
+                                   f32x4 (&n2)[4]) {
+  f32x4 z[4], n1[4];
+  float rstd;
+  load_vec_T(lds + tw.b1, q, z);
+  fc1_T(lds + tw.W1, tw.DP, xb, z, j, q);
+  relu_T(z);
+  ln_normalize_T(z, rstd);
+  ln_affine_T(z, lds + tw.g1, lds + tw.be1, q, n1);
+  load_vec_T(lds + tw.b2, q, z);
+  mm64_T(lds + tw.W2, n1, z, j, q);
+  ln_normalize_T(z, rstd);
+  ln_affine_T(z, lds + tw.g2, lds + tw.be2, q, n2);
+}
+
+// ---- distribution heads ----------------------------------------------------------------------------
+
+// Categorical over lg[0..n_out): masked logits, log-sum-exp, returns lse.  (distributions.py:68-72)
+template <int NO>
+__device__ inline float cat_lse(float (&lg)[NO], int n_out, const float* __restrict__ amask_row) {
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int c = 0; c < NO; ++c) {
+    if (c < n_out) {
+      if (amask_row != nullptr && amask_row[c] == 0.f) lg[c] = -6e4f;
+      mx = fmaxf(mx, lg[c]);
+    }
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int c = 0; c < NO; ++c) {
+    if (c < n_out) se += expf(lg[c] - mx);
+  }
+  return mx + logf(se);
+}
+
+// inverse-CDF sample of softmax(lg) with uniform u in [0,1)
+template <int NO>
+__device__ inline int cat_sample(const float (&lg)[NO], int n_out, float lse, float u) {
+  float p[NO];
+  float tot = 0.f;
+#pragma unroll
+  for (int c = 0; c < NO; ++c) {
+    p[c] = (c < n_out) ? expf(lg[c] - lse) : 0.f;
+    tot += p[c];
+  }
+  const float ut = u * tot;
+  int a = -1, last = 0;
+  float cum = 0.f;
+#pragma unroll
+  for (int c = 0; c < NO; ++c) {
+    if (c < n_out) {
+      cum += p[c];
+      if (p[c] > 0.f) last = c;
+      if (a < 0 && cum > ut) a = c;
+    }
+  }
+  return a < 0 ? last : a;
+}
+
+template <int NO>
+__device__ inline int cat_mode(const float (&lg)[NO], int n_out) {
+  int a = 0;
+  float best = lg[0];
+#pragma unroll
+  for (int c = 1; c < NO; ++c) {
+    if (c < n_out && lg[c] > best) { best = lg[c]; a = c; }
+  }
+  return a;
+}
+
+template <int NO>
+__device__ inline float pick(const float (&v)[NO], int a) {
+  float r = v[0];
+#pragma unroll
+  for (int c = 1; c < NO; ++c) r = (c == a) ? v[c] : r;
+  return r;
+}
+
+// standard normal pair from two uniforms (Box-Muller)
+__device__ inline void box_muller(uint32_t x0, uint32_t x1, float& n0, float& n1) {
+  const float u1 = u01_open0(x0), u2 = u01(x1);
+  const float rad = sqrtf(-2.0f * logf(u1));
+  const float ang = 6.28318530717958647692f * u2;
+  n0 = rad * cosf(ang);
+  n1 = rad * sinf(ang);
+}
+
+}  // namespace orl

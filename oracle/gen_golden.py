@@ -1,0 +1,225 @@
+"""Generate ``tests/golden/*.npz`` by running the REAL reference (``/root/reference/openrl``) on CPU.
+
+TEST INFRASTRUCTURE.  Runs only where ``/root/reference`` exists (the authoring container):
+
+    python -m oracle.gen_golden
+
+The reference's drivers/runners/envs cannot be imported offline (gymnasium, wandb, pettingzoo are
+missing - SURVEY.md section 8c), so the rollout part follows ``openrl/drivers/onpolicy_driver.py:154-203``
+by hand while every numeric object is the reference's own: ``PPOModule``, ``NormalReplayBuffer``
+(``ReplayData.insert/compute_returns/feed_forward_generator``), ``PPOAlgorithm.train``, ``ValueNorm``.
+The vectors are small (a few hundred KB in total) and committed; the GPU box never needs the reference.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_stubs
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _flat(model) -> np.ndarray:
+    # trainable parameters in registration order; ValueNetwork also registers the three ValueNorm state
+    # scalars as requires_grad=False Parameters (valuenorm.py:24-35) - they are recorded as vn_state1
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters() if p.requires_grad]).numpy().copy()
+
+
+def _cfg(argv, N, T):
+    cfg = ref_stubs.reference_cfg(argv)
+    cfg.num_agents = 1
+    cfg.n_rollout_threads = N
+    cfg.learner_n_rollout_threads = N
+    cfg.rnn_hidden_size = cfg.hidden_size
+    cfg.episode_length = T
+    return cfg
+
+
+def gae_cases():
+    from gymnasium.spaces import Box, Discrete
+    from openrl.buffers import NormalReplayBuffer
+    from openrl.modules.utils.valuenorm import ValueNorm
+
+    out = {}
+    # known-answer vector of SURVEY.md section 8c
+    for proper in (False, True):
+        cfg = _cfg(["--use_proper_time_limits", str(proper), "--use_valuenorm", "false"], 2, 4)
+        buf = NormalReplayBuffer(cfg, 1, Box(-1, 1, (4,)), Discrete(2), data_client=None).data
+        buf.rewards[:] = np.array([[1, .5], [1, -1], [1, 2], [1, .25]], np.float32).reshape(4, 2, 1, 1)
+        buf.value_preds[:4] = np.array([[.5, .1], [.4, -.2], [.3, .7], [.2, 0]], np.float32).reshape(4, 2, 1, 1)
+        buf.masks[:] = np.array([[1, 1], [1, 1], [1, 0], [1, 1], [1, 1]], np.float32).reshape(5, 2, 1, 1)
+        buf.bad_masks[:] = np.array([[1, 1], [1, 1], [1, 1], [1, 0], [1, 1]], np.float32).reshape(5, 2, 1, 1)
+        buf.compute_returns(np.array([.1, .9], np.float32).reshape(2, 1, 1), None)
+        out["kat_proper%d_returns" % proper] = buf.returns.copy()
+    # random cases: use_gae x proper x valuenorm
+    rs = np.random.RandomState(7)
+    T, N, A = 9, 5, 2
+    base = dict(rewards=rs.randn(T, N, A, 1).astype(np.float32), value_preds=rs.randn(T + 1, N, A, 1).astype(np.float32),
+                masks=(rs.rand(T + 1, N, A, 1) > 0.2).astype(np.float32),
+                bad_masks=(rs.rand(T + 1, N, A, 1) > 0.15).astype(np.float32),
+                active_masks=(rs.rand(T + 1, N, A, 1) > 0.1).astype(np.float32),
+                next_value=rs.randn(N, A, 1).astype(np.float32),
+                vn_state=np.array([0.3e-3, 2.5e-3, 1.2e-3], np.float32))
+    for k, v in base.items():
+        out["rand_" + k] = v
+    for use_gae in (True, False):
+        for proper in (False, True):
+            for use_vn in (False, True):
+                cfg = _cfg(["--use_gae", str(use_gae), "--use_proper_time_limits", str(proper), "--use_valuenorm",
+                            str(use_vn)], N, T)
+                cfg.num_agents = A
+                buf = NormalReplayBuffer(cfg, A, Box(-1, 1, (4,)), Discrete(2), data_client=None).data
+                buf.rewards[:] = base["rewards"]
+                buf.value_preds[:] = base["value_preds"]
+                buf.masks[:] = base["masks"]
+                buf.bad_masks[:] = base["bad_masks"]
+                vn = None
+                if use_vn:
+                    vn = ValueNorm(1)
+                    vn.running_mean[:] = float(base["vn_state"][0])
+                    vn.running_mean_sq[:] = float(base["vn_state"][1])
+                    vn.debiasing_term.fill_(float(base["vn_state"][2]))
+                buf.compute_returns(base["next_value"].copy(), vn)
+                tag = "rand_g%d_p%d_v%d" % (use_gae, proper, use_vn)
+                out[tag + "_returns"] = buf.returns.copy()
+                out[tag + "_value_preds"] = buf.value_preds.copy()
+    np.savez_compressed(os.path.join(OUT, "gae.npz"), **out)
+    print("gae.npz", len(out))
+
+
+def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, seed=0):
+    """Fill a reference buffer with a hand-driven rollout of the reference module, then run
+    PPOAlgorithm.train and record everything needed to replay it."""
+    from gymnasium.spaces import Box
+    from openrl.algorithms.ppo import PPOAlgorithm
+    from openrl.buffers import NormalReplayBuffer
+    from openrl.modules.ppo_module import PPOModule
+    from openrl.utils.util import set_seed
+
+    cfg = _cfg(argv, N, T)
+    cfg.seed = seed
+    act_space = act_space_fn()
+    obs_space = Box(-np.inf, np.inf, (obs_dim,))
+    set_seed(cfg.seed)
+    module = PPOModule(cfg, policy_input_space=obs_space, critic_input_space=obs_space, act_space=act_space,
+                       share_model=False, rank=0, world_size=1)
+    out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"])}
+    buffer = NormalReplayBuffer(cfg, 1, obs_space, act_space, data_client=None)
+    algo = PPOAlgorithm(cfg, module, agent_num=1)
+    rs = np.random.RandomState(100 + seed)
+    obs = rs.randn(N, 1, obs_dim).astype(np.float32)
+    K = act_space.n if act_space.__class__.__name__ == "Discrete" else 0
+    am0 = None
+    if use_masks:
+        am0 = (rs.rand(N, 1, K) > 0.3).astype(np.float32)
+        am0[..., 0] = 1.0
+    buffer.init_buffer(obs.copy(), action_masks=am0)
+    algo.prep_rollout()
+    d = buffer.data
+    for step in range(T):  # onpolicy_driver.py:159-192
+        with torch.no_grad():
+            value, action, logp, rs_a, rs_c = module.get_actions(
+                d.get_batch_data("critic_obs", step), d.get_batch_data("policy_obs", step),
+                d.get_batch_data("rnn_states", step), d.get_batch_data("rnn_states_critic", step),
+                d.get_batch_data("masks", step), action_masks=d.get_batch_data("action_masks", step))
+        split = lambda x: np.array(np.split(x.detach().cpu().numpy(), N))
+        values, actions, logps = split(value), split(action), split(logp)
+        obs = rs.randn(N, 1, obs_dim).astype(np.float32)
+        rewards = rs.rand(N, 1, 1).astype(np.float32)
+        dones = rs.rand(N, 1) < 0.15
+        dones_env = np.all(dones, axis=1)
+        masks = np.ones((N, 1, 1), np.float32)
+        masks[dones_env] = 0.0
+        active = np.ones((N, 1, 1), np.float32)
+        active[dones] = 0.0
+        active[dones_env] = 1.0
+        if step % 5 == 3:  # exercise active_masks == 0 (only reachable for multi-agent envs in the driver)
+            active[rs.randint(N)] = 0.0
+        bad = np.ones((N, 1, 1), np.float32)
+        amask = None
+        if use_masks:
+            amask = (rs.rand(N, 1, K) > 0.3).astype(np.float32)
+            amask[..., 0] = 1.0
+        buffer.insert(obs, split(rs_a), split(rs_c), actions, logps, values, rewards, masks, active_masks=active,
+                      bad_masks=bad, action_masks=amask)
+    with torch.no_grad():
+        nv = module.get_values(d.get_batch_data("critic_obs", -1), np.concatenate(d.rnn_states_critic[-1]),
+                               np.concatenate(d.masks[-1]))
+    next_values = np.array(np.split(nv.detach().cpu().numpy(), N))
+    vn = module.get_critic_value_normalizer()
+    buffer.compute_returns(next_values, vn)
+    for f in ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks",
+              "bad_masks", "active_masks"):
+        out["buf_" + f] = getattr(d, f).copy()
+    if d.action_masks is not None:
+        out["buf_action_masks"] = d.action_masks.copy()
+    out["next_values"] = next_values
+    # the update: RNG state at entry decides the permutations
+    torch.manual_seed(1234 + seed)
+    algo.prep_training()
+    info = algo.train(d)
+    out["train_info"] = np.array([float(info[k]) for k in
+                                  ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
+                                   "ratio")], np.float64)
+    out["theta_p1"] = _flat(module.models["policy"])
+    out["theta_c1"] = _flat(module.models["critic"])
+    if vn is not None:
+        out["vn_state1"] = np.array([vn.running_mean.item(), vn.running_mean_sq.item(), vn.debiasing_term.item()],
+                                    np.float32)
+    out["argv"] = np.array(argv, dtype=object) if False else np.array(" ".join(argv))
+    out["perm_seed"] = np.array(1234 + seed)
+    # deterministic action / value probe on fresh weights is covered by theta_p0 + oracle; record a probe on theta_p1
+    probe = rs.randn(16, obs_dim).astype(np.float32)
+    algo.prep_rollout()
+    with torch.no_grad():
+        pm = None
+        if use_masks:
+            pm = (rs.rand(16, K) > 0.3).astype(np.float32)
+            pm[:, 0] = 1.0
+            out["probe_masks"] = pm
+        v, a, lp, _, _ = module.get_actions(probe, probe, np.zeros((16, 1, 64), np.float32),
+                                            np.zeros((16, 1, 64), np.float32), np.ones((16, 1), np.float32),
+                                            action_masks=pm, deterministic=True)
+    out["probe_obs"], out["probe_values"] = probe, v.numpy()
+    out["probe_actions"], out["probe_logp"] = a.numpy().astype(np.float32), lp.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: float(info[k]) for k in info})
+
+
+def perm_case():
+    from torch.utils.data.sampler import BatchSampler, SubsetRandomSampler
+
+    out = {}
+    for seed, M, nmb in ((0, 10, 1), (3, 96, 4), (11, 1000, 3)):
+        torch.manual_seed(seed)
+        mbs = M // nmb
+        idx = [np.array(b) for b in BatchSampler(SubsetRandomSampler(range(M)), mbs, drop_last=True)]
+        out["perm_s%d_M%d_n%d" % (seed, M, nmb)] = np.stack(idx)
+    np.savez_compressed(os.path.join(OUT, "perm.npz"), **out)
+    print("perm.npz")
+
+
+def main():
+    ref_stubs.install()
+    os.makedirs(OUT, exist_ok=True)
+    from gymnasium.spaces import Box, Discrete
+
+    gae_cases()
+    perm_case()
+    _train_case("train_discrete", ["--ppo_epoch", "3", "--num_mini_batch", "2"], 4, lambda: Discrete(2))
+    _train_case("train_discrete_masks", ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_adv_normalize", "true",
+                                         "--use_huber_loss"], 6, lambda: Discrete(5), use_masks=True, seed=1)
+    _train_case("train_gaussian", ["--ppo_epoch", "2", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"],
+                5, lambda: Box(-1, 1, (3,)), seed=2)
+    _train_case("train_novn_proper", ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_valuenorm", "false",
+                                      "--use_proper_time_limits", "true", "--dual_clip_ppo", "true",
+                                      "--use_clipped_value_loss", "--use_value_active_masks", "false",
+                                      "--use_policy_active_masks"], 4, lambda: Discrete(2), seed=3)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,108 @@
+"""Pin the oracle (oracle/*.py) against the golden vectors minted from the REAL reference
+(oracle/gen_golden.py) and against published known-answer vectors.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox as px
+from oracle import ppo_oracle as po
+from tests import helpers as H
+
+
+def test_philox_random123_kat():
+    # Random123 kat_vectors, philox4x32-10
+    assert [int(v) for v in px.philox4x32_10(0, 0, 0, 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert [int(v) for v in px.philox4x32_10(0xFFFFFFFFFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)] == [
+        0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert [int(v) for v in px.philox4x32_10((0x299F31D0 << 32) | 0xA4093822, 0x243F6A88, 0x85A308D3, 0x13198A2E,
+                                             0x03707344)] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_feistel_is_a_permutation():
+    for n in (1, 2, 7, 100, 4097):
+        p = px.feistel_perm(n, 42, 9)
+        assert sorted(p.tolist()) == list(range(n))
+    assert not np.array_equal(px.feistel_perm(100, 1, 0), px.feistel_perm(100, 1, 1))
+
+
+def test_gae_known_answer_vector():
+    """minted from ReplayData.compute_returns."""
+    g = H.load_golden("gae")
+    rewards = np.array([[1, .5], [1, -1], [1, 2], [1, .25]], np.float32).reshape(4, 2, 1, 1)
+    vp = np.zeros((5, 2, 1, 1), np.float32)
+    vp[:4] = np.array([[.5, .1], [.4, -.2], [.3, .7], [.2, 0]], np.float32).reshape(4, 2, 1, 1)
+    masks = np.array([[1, 1], [1, 1], [1, 0], [1, 1], [1, 1]], np.float32).reshape(5, 2, 1, 1)
+    bad = np.array([[1, 1], [1, 1], [1, 1], [1, 0], [1, 1]], np.float32).reshape(5, 2, 1, 1)
+    nv = np.array([.1, .9], np.float32).reshape(2, 1, 1)
+    for proper in (False, True):
+        ret, _ = po.compute_returns(rewards, vp, masks, bad, nv, 0.99, 0.95, True, proper, None)
+        assert np.array_equal(ret, g["kat_proper%d_returns" % proper])
+    ret, _ = po.compute_returns(rewards, vp, masks, bad, nv, 0.99, 0.95, True, False, None)
+    np.testing.assert_allclose(ret[:4, 0, 0, 0], [3.7818331718, 2.9367709160, 2.0435094833, 1.0989999771], rtol=1e-7)
+    np.testing.assert_allclose(ret[:4, 1, 0, 0], [-0.4504000247, -1.0, 3.0731105804, 1.1410000324], rtol=1e-7)
+
+
+@pytest.mark.parametrize("use_gae", [True, False])
+@pytest.mark.parametrize("proper", [False, True])
+@pytest.mark.parametrize("use_vn", [False, True])
+def test_gae_random_cases_bit_exact(use_gae, proper, use_vn):
+    g = H.load_golden("gae")
+    vn = None
+    if use_vn:
+        vn = po.ValueNormOracle()
+        vn.set_state(g["rand_vn_state"])
+    ret, vp = po.compute_returns(g["rand_rewards"], g["rand_value_preds"], g["rand_masks"], g["rand_bad_masks"],
+                                 g["rand_next_value"], 0.99, 0.95, use_gae, proper, vn)
+    tag = "rand_g%d_p%d_v%d" % (use_gae, proper, use_vn)
+    assert np.array_equal(ret, g[tag + "_returns"])
+    assert np.array_equal(vp, g[tag + "_value_preds"])
+
+
+def test_minibatch_permutation_is_randperm_chunks():
+    g = H.load_golden("perm")
+    for key in g:
+        _, s, M, n = key.split("_")
+        seed, M, nmb = int(s[1:]), int(M[1:]), int(n[1:])
+        torch.manual_seed(seed)
+        got = np.stack(po.feed_forward_indices(M, nmb))
+        assert np.array_equal(got, g[key])
+    torch.manual_seed(0)
+    assert po.feed_forward_indices(10, 1)[0].tolist() == [4, 1, 7, 5, 3, 9, 0, 8, 6, 2]
+
+
+@pytest.mark.parametrize("case,seed", [("train_discrete", 0), ("train_discrete_masks", 1), ("train_gaussian", 2)])
+def test_init_matches_reference_rng_order(case, seed):
+    """PPONet: set_seed(cfg.seed) then policy tower, then critic tower (ppo_net.py:66, ppo_module.py:58-89)."""
+    g = H.load_golden(case)
+    cfg = H.case_cfg(g)
+    pspec, cspec = H.case_specs(g)
+    import random
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    tp = po.init_tower(pspec, cfg.gain, cfg.use_orthogonal, cfg.activation_id)
+    tc = po.init_tower(cspec, 1.0, cfg.use_orthogonal, cfg.activation_id)
+    assert np.array_equal(tp.numpy(), g["theta_p0"])
+    assert np.array_equal(tc.numpy(), g["theta_c0"])
+
+
+@pytest.mark.parametrize("case", H.TRAIN_CASES)
+def test_train_replay_matches_reference(case):
+    g = H.load_golden(case)
+    r = H.oracle_replay(g)
+    np.testing.assert_allclose(r["ptheta"], g["theta_p1"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(r["ctheta"], g["theta_c1"], rtol=2e-5, atol=2e-6)
+    got = np.array([r["info"][k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
+                                           "critic_grad_norm", "ratio")])
+    np.testing.assert_allclose(got, g["train_info"], rtol=1e-5, atol=1e-6)
+    if "vn_state1" in g:
+        np.testing.assert_allclose(r["vn"], g["vn_state1"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("case", H.TRAIN_CASES)
+def test_deterministic_probe_matches_reference(case):
+    g = H.load_golden(case)
+    pspec, cspec = H.case_specs(g)
+    v, a, lp = po.get_actions(pspec, torch.tensor(g["theta_p1"]), cspec, torch.tensor(g["theta_c1"]), g["probe_obs"],
+                              g["probe_obs"], g.get("probe_masks"), deterministic=True)
+    np.testing.assert_allclose(v, g["probe_values"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a, g["probe_actions"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lp, g["probe_logp"], rtol=1e-5, atol=1e-6)
