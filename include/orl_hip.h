@@ -80,6 +80,13 @@ int orl_gae_scan(const float* rewards, float* value_preds, const float* masks, c
                  double* stat_partials, int* n_partials, void* stream);
 int orl_gae_max_partials(int T, int L);
 
+/* K7a stand-alone (openrl/algorithms/ppo.py:384-400): adv_raw[T*L] = returns[:-1] - denorm(value_preds[:-1])
+ * and the same per-block statistics rows as orl_gae_scan, for callers that did not take its fused outputs
+ * (e.g. returns were edited after compute_returns).  stat_partials holds orl_gae_max_partials(T, L) rows. */
+int orl_adv_stats(const float* returns, const float* value_preds, const float* active_masks,
+                  const float* vn_state, int T, int L, float* adv_raw, double* stat_partials, int* n_partials,
+                  void* stream);
+
 /* ---- K7b: advantage normalisation (+ record packing) -------------------------------------------
  * Replaces openrl/algorithms/ppo.py:402-409: optional global (x-mean)/(std+1e-5) (use_adv_normalize)
  * followed - always - by the same transform with nanmean/nanstd over entries whose active mask != 0.
@@ -155,7 +162,8 @@ int orl_perm_feistel(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id,
  * Replaces PPOModule.get_actions (openrl/modules/ppo_module.py:102-138) =
  * PolicyNetwork.forward_original (networks/policy_network.py:130-162) + ValueNetwork.forward
  * (networks/value_network.py:113-136) + ACTLayer.forward (utils/act.py:45-83) for B rows.
- *   values  [B,1]   = critic(critic_obs)         (NULL critic theta -> skipped)
+ *   values  [B,1]   = critic(critic_obs)         (NULL critic theta -> skipped; NULL policy theta ->
+ *                                                  value-only call = PPOModule.get_values, :140-147)
  *   actions [B,a]   sampled (or mode if deterministic) as float32, logp [B,a]
  * Categorical: logits[mask==0] = -6e4 (distributions.py:71), a = 1, action = index as float.
  * Gaussian: per-dimension log-prob, no sum (distributions.py:34-43), a = n_out.
@@ -235,7 +243,7 @@ int orl_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const floa
 
 /* ValueNorm.update (openrl/modules/utils/valuenorm.py:58-77) from reduced batch sums:
  * moments = {sum(x), sum(x^2), count} as doubles on the device; beta = 0.99999. */
-int orl_valuenorm_update(float* vn_state, const double* moments, float beta, void* stream);
+int orl_valuenorm_update(float* vn_state, const double* moments, double beta, void* stream);
 /* sum / sumsq / count of returns over minibatch rows (records column `ret_col`) -> moments[3]. */
 int orl_minibatch_moments(const float* records, int rec_width, int ret_col, const int64_t* idx, int mb,
                           double* scratch, double* moments, void* stream);

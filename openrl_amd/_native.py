@@ -82,6 +82,7 @@ _SIGNATURES = {
     "orl_gae_scan": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                _P, _P, _P, C.POINTER(C.c_int), _P]),
     "orl_gae_max_partials": (C.c_int, [C.c_int, C.c_int]),
+    "orl_adv_stats": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.POINTER(C.c_int), _P]),
     "orl_record_width": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "orl_adv_normalize_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(PackSrc), _P, _P]),
     "orl_buffer_insert": (C.c_int, [C.POINTER(BufferPtrs), C.c_int, _P, _P, _P, _P, _P, _P, _P]),
@@ -95,7 +96,7 @@ _SIGNATURES = {
     "orl_ppo_reduce": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "orl_ppo_apply": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
                                 C.POINTER(AdamState), C.POINTER(AdamState), _P, _P]),
-    "orl_valuenorm_update": (C.c_int, [_P, _P, C.c_float, _P]),
+    "orl_valuenorm_update": (C.c_int, [_P, _P, C.c_double, _P]),
     "orl_minibatch_moments": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
     "orl_env_state_width": (C.c_int, [C.c_int]),
     "orl_env_reset": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int, _P]),

@@ -1,0 +1,134 @@
+"""``PPOAlgorithm`` - the PPO update (``openrl/algorithms/ppo.py:32-469``) as a short chain of fused
+HIP launches per minibatch:
+
+    train_ppo (ppo.py:383-458)
+      advantages + nan-stats normalisation (:384-409)      -> orl_gae_scan's fused stats / orl_adv_stats
+                                                              + orl_adv_normalize_pack (also packs records)
+      for epoch, for minibatch (:424-451):
+        minibatch order (replay_data.py:553-580)            -> host torch.randperm (bit-exact, default)
+                                                              or orl_perm_feistel (device, amd_perm_mode)
+        ValueNorm.update(return_batch) (:190-191)           -> orl_minibatch_moments + orl_valuenorm_update
+        prepare_loss + 2x backward (:98-124)                -> orl_ppo_fwd_bwd   (one launch per tower)
+        [multi-GPU] sum over ranks                          -> orl_ppo_reduce + ONE all-reduce (RCCL)
+        clip_grad_norm_ x2 + Adam x2 + .item() x4 (:132-164, :445-451) -> orl_ppo_apply (stats stay on device)
+
+The six ``train_info`` scalars are accumulated on the device and read back ONCE per ``train`` call.
+"""
+from __future__ import annotations
+
+from typing import Dict, Union
+
+import torch
+
+from .. import _native as nat
+from .. import distributed as dist_utils
+from .. import ops
+from .base_algorithm import BaseAlgorithm
+
+INFO_KEYS = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
+
+
+class PPOAlgorithm(BaseAlgorithm):
+    def __init__(self, cfg, init_module, agent_num: int = 1, device: Union[str, torch.device] = "cuda:0") -> None:
+        if cfg.use_share_model or cfg.use_joint_action_loss or cfg.use_deepspeed or cfg.use_amp:
+            raise NotImplementedError("share_model / joint_action_loss / deepspeed / amp are not built in this engine")
+        if cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy:
+            raise NotImplementedError("recurrent generators are not built in this engine yet")
+        super().__init__(cfg, init_module, agent_num, device)
+        self.train_list = [self.train_ppo]
+        self.hp = ops.make_hparams(cfg)
+        p, c = self.algo_module.models["policy"], self.algo_module.models["critic"]
+        self._raw_p = ops.raw_grad_count(p.net) + ops.N_STATS
+        self._raw_c = ops.raw_grad_count(c.net) + ops.N_STATS
+        mb = ops.ppo_max_blocks()
+        dev = self.device
+        self._partials = torch.empty(mb * (self._raw_p + self._raw_c), dtype=torch.float32, device=dev)
+        self._sums = torch.zeros(self._raw_p + self._raw_c, dtype=torch.float32, device=dev)
+        self._info = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
+        self._mom_scratch = torch.zeros(512, dtype=torch.float64, device=dev)
+        self._adv_stats = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.perm_mode = getattr(cfg, "amd_perm_mode", "reference")
+        self._perm_counter = 0
+        self.last_indices = None  # minibatch index tensors of the last train() (tests / inspection)
+
+    # ------------------------------------------------------------------------------------------ advantages
+    def _advantages_and_records(self, buffer) -> None:
+        T, N, A = buffer.episode_length, buffer.n_rollout_threads, buffer.num_agents
+        L = N * A
+        vn = self.algo_module.get_critic_value_normalizer() if (self._use_popart or self._use_valuenorm) else None
+        vn_state = vn.state if vn is not None else None
+        if not (buffer._adv_fresh and (getattr(buffer, "_adv_vn", None) is vn_state)):
+            buffer.n_partials = ops.adv_stats(buffer.returns, buffer.value_preds, buffer.active_masks, vn_state, T, L,
+                                              buffer.advantages, buffer.stat_partials)
+        partials, n_part = buffer.stat_partials, buffer.n_partials
+        if self.world_size > 1:
+            # global statistics (ppo.py:405-409 is over the WHOLE batch): sum the 8 doubles over ranks
+            row = dist_utils.allreduce_stat_rows(partials[:n_part])
+            partials, n_part = row, 1
+        ops.adv_normalize_pack(buffer.advantages, partials, n_part, T, L, self._use_adv_normalize, self._adv_stats,
+                               buffer.pack_src(), buffer.ensure_records())
+        buffer._adv_fresh = False  # advantages are now normalised in place
+
+    # ------------------------------------------------------------------------------------------ one minibatch
+    def _update_minibatch(self, buffer, idx, mb: int, turn_on: bool) -> None:
+        mod = self.algo_module
+        p, c = mod.models["policy"], mod.models["critic"]
+        po, co = mod.optimizers["policy"], mod.optimizers["critic"]
+        rec = buffer.records
+        vn = mod.get_critic_value_normalizer() if self._use_valuenorm else None
+        vn_state = None
+        if vn is not None:
+            ret_col = buffer.Dp + buffer.Dc + 2 * buffer.act_shape + 2
+            ops.minibatch_moments(rec, ret_col, idx, mb, self._mom_scratch, self._moments)
+            if self.world_size > 1:
+                dist_utils.allreduce_(self._moments)
+            ops.valuenorm_update(vn.state, self._moments, vn.beta)  # BEFORE normalize (ppo.py:190-195)
+            vn_state = vn.state
+        nb = ops.ppo_fwd_bwd(p.net, p.theta, c.net, c.theta, rec, idx, mb, vn_state, self.hp, self._partials)
+        base = self._partials.data_ptr()
+        sums = self._sums.data_ptr()
+        ops.ppo_reduce(base, nb, self._raw_p, sums, self.device)
+        ops.ppo_reduce(base + 4 * ops.ppo_max_blocks() * self._raw_p, nb, self._raw_c, sums + 4 * self._raw_p,
+                       self.device)
+        if self.world_size > 1:
+            dist_utils.allreduce_(self._sums)  # ONE small collective per optimiser step
+        po.step_count += 1 if turn_on else 0
+        co.step_count += 1
+        hp = self.hp
+        if not turn_on:
+            hp = nat.PPOHParams.from_buffer_copy(self.hp)
+            hp.reserved = 1  # critic-only update (construct_loss_list, ppo.py:226-236)
+        ops.ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
+                      co.native_state(co.step_count), self._info)
+
+    def _minibatch_indices(self, M: int):
+        mbs = M // self.num_mini_batch
+        n_batches = M // mbs  # drop_last=True (replay_data.py:578-580)
+        if self.perm_mode == "device":
+            self._perm_counter += 1
+            perm = ops.perm_feistel(M, int(self.cfg.seed), self._perm_counter, self.device)
+        else:
+            perm = torch.randperm(M).to(self.device, non_blocking=True)  # CPU generator, like the reference
+        return [perm[b * mbs:(b + 1) * mbs] for b in range(n_batches)], mbs
+
+    # ------------------------------------------------------------------------------------------ reference API
+    def train_ppo(self, buffer, turn_on: bool = True) -> Dict[str, float]:
+        self._advantages_and_records(buffer)
+        M = buffer.episode_length * buffer.n_rollout_threads * buffer.num_agents
+        self._info.zero_()
+        self.last_indices = []
+        for _ in range(self.ppo_epoch):
+            batches, mbs = self._minibatch_indices(M)
+            for idx in batches:
+                self.last_indices.append(idx)
+                self._update_minibatch(buffer, idx, mbs, turn_on)
+        num_updates = self.ppo_epoch * self.num_mini_batch
+        vals = (self._info[:6] / float(num_updates)).cpu().tolist()  # the only device->host sync of train()
+        return {k: v for k, v in zip(INFO_KEYS, vals)}
+
+    def train(self, buffer, turn_on: bool = True) -> Dict[str, float]:
+        train_info = {}
+        for train_func in self.train_list:
+            train_info.update(train_func(buffer, turn_on))
+        return train_info

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
   TowerLayout tlc;
   TowerLds twc;
   const bool has_c = A.ctheta != nullptr;
-  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x);
+  const bool has_p = A.ptheta != nullptr;
+  if (has_p) stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x);
   if (has_c) {
     tlc = TowerLayout(A.cnet);
     twc = TowerLds(A.cnet.obs_dim, 1, false, false);
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
   const int row = blockIdx.x * TILE_B + j;
   const bool row_ok = row < A.B;
   if (wave == 0) {
+    if (!has_p) return;
     const int D = A.pnet.obs_dim;
     const float* xrow = A.pobs + (size_t)row * D;
     auto xb = [&](int s) -> float {
@@ -425,7 +427,8 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
                  float* values, float* actions, float* logp, void* stream) {
   int rc = check_net(pnet, "orl_act_step(policy)", false);
   if (rc) return rc;
-  ORL_REQUIRE(ptheta && policy_obs && actions && logp, "orl_act_step: null policy pointer");
+  ORL_REQUIRE(ptheta || ctheta, "orl_act_step: neither tower given");
+  if (ptheta) ORL_REQUIRE(policy_obs && actions && logp, "orl_act_step: null policy pointer");
   ORL_REQUIRE(B > 0, "orl_act_step: B=%d", B);
   size_t lds = TowerLds(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false).total;
   if (ctheta) {

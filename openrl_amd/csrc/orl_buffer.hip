@@ -375,13 +375,13 @@ __global__ __launch_bounds__(256) void perm_feistel_kernel(int64_t* __restrict__
 // ------------------------------------------------------------------------------------------------
 // ValueNorm.update (valuenorm.py:58-77) from batch sums, and minibatch return moments.
 // ------------------------------------------------------------------------------------------------
-__global__ void valuenorm_update_kernel(float* __restrict__ vn, const double* __restrict__ mom, float beta) {
+__global__ void valuenorm_update_kernel(float* __restrict__ vn, const double* __restrict__ mom, float beta, float omw) {
 #pragma clang fp contract(off)
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double cnt = mom[2];
   const float bm = (float)(mom[0] / cnt);
   const float bsq = (float)(mom[1] / cnt);
-  const float omw = (float)(1.0 - (double)beta);  // python: (1.0 - weight) in double, cast by torch to f32
+  // omw = float32(1.0 - weight) with the subtraction done in double on the host (python float semantics)
   const float t0 = bm * omw;
   const float t1 = bsq * omw;
   vn[0] = vn[0] * beta + t0;
@@ -421,6 +421,46 @@ __global__ __launch_bounds__(64) void moments_final_kernel(const double* __restr
   s = wave_sum(s);
   q = wave_sum(q);
   if (threadIdx.x == 0) { moments[0] = s; moments[1] = q; moments[2] = (double)mb; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7a stand-alone: adv_raw = returns[:-1] - denorm(value_preds[:-1]) + per-block statistics, for
+// callers that did not take the fused outputs of the GAE scan (ppo.py:384-400).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adv_stats_kernel(const float* __restrict__ returns,
+                                                        const float* __restrict__ value_preds,
+                                                        const float* __restrict__ active_masks,
+                                                        const float* __restrict__ vn_state, long long M,
+                                                        float* __restrict__ adv_raw, double* __restrict__ partials) {
+#pragma clang fp contract(off)
+  const VnCoef vc = vn_coef(vn_state);
+  double s_all = 0, q_all = 0, n_all = 0, s_act = 0, q_act = 0, n_act = 0, s_ret = 0, q_ret = 0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
+    const float ret = returns[i];
+    const float adv = ret - vn_denorm(vc, value_preds[i]);
+    adv_raw[i] = adv;
+    const double a = (double)adv;
+    s_all += a; q_all += a * a; n_all += 1.0;
+    if (active_masks[i] != 0.f) { s_act += a; q_act += a * a; n_act += 1.0; }
+    const double rr = (double)ret;
+    s_ret += rr; q_ret += rr * rr;
+  }
+  double v[8] = {s_all, q_all, n_all, s_act, q_act, n_act, s_ret, q_ret};
+  __shared__ double sh[4][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = wave_sum(v[k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[w][k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double t = 0;
+    for (int ww = 0; ww < 4; ++ww) t += sh[ww][threadIdx.x];
+    partials[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
+  }
 }
 
 constexpr int MOM_BLOCKS = 256;
@@ -474,6 +514,21 @@ int orl_gae_scan(const float* rewards, float* value_preds, const float* masks, c
   return launch_status("orl_gae_scan");
 }
 
+int orl_adv_stats(const float* returns, const float* value_preds, const float* active_masks, const float* vn_state,
+                  int T, int L, float* adv_raw, double* stat_partials, int* n_partials, void* stream) {
+  ORL_REQUIRE(returns && value_preds && active_masks && adv_raw && stat_partials, "orl_adv_stats: null pointer");
+  ORL_REQUIRE(T > 0 && L > 0, "orl_adv_stats: bad geometry");
+  const long long M = (long long)T * L;
+  int grid = (int)((M + 255) / 256);
+  const int cap = orl_gae_max_partials(T, L);
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, returns, value_preds,
+                     active_masks, vn_state, M, adv_raw, stat_partials);
+  if (n_partials) *n_partials = grid;
+  return launch_status("orl_adv_stats");
+}
+
 int orl_record_width(int Dp, int Dc, int a, int K) {
   const int w = Dp + Dc + 2 * a + 4 + K;
   return (w + 3) & ~3;
@@ -521,9 +576,9 @@ int orl_buffer_insert(const orl_buffer_ptrs* buf, int step, const float* next_po
 }
 
 int orl_gather_minibatch(const orl_gather_desc* desc, const int64_t* idx, int n_rows, void* stream) {
+  if (n_rows == 0) return 0;  // empty minibatch: nothing to do (pointers may legitimately be NULL)
   ORL_REQUIRE(desc && idx, "orl_gather_minibatch: null pointer");
   ORL_REQUIRE(desc->count > 0 && desc->count <= ORL_GATHER_MAX, "orl_gather_minibatch: count %d", desc->count);
-  if (n_rows == 0) return 0;
   ORL_REQUIRE(n_rows > 0, "orl_gather_minibatch: negative n_rows");
   int total_w = 0;
   for (int k = 0; k < desc->count; ++k) {
@@ -549,9 +604,9 @@ int orl_perm_feistel(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id,
   return launch_status("orl_perm_feistel");
 }
 
-int orl_valuenorm_update(float* vn_state, const double* moments, float beta, void* stream) {
+int orl_valuenorm_update(float* vn_state, const double* moments, double beta, void* stream) {
   ORL_REQUIRE(vn_state && moments, "orl_valuenorm_update: null pointer");
-  hipLaunchKernelGGL(valuenorm_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vn_state, moments, beta);
+  hipLaunchKernelGGL(valuenorm_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, vn_state, moments, (float)beta, (float)(1.0 - beta));
   return launch_status("orl_valuenorm_update");
 }
 

@@ -561,6 +561,12 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     const RawLayout& rl = t == 0 ? rlp : rlc;
     const float* raw = t == 0 ? rawp : rawc;
     const float inv_den = 1.0f / (t == 0 ? den_p : den_v);
+    if (t == 0 && (hp.reserved & 1)) {
+      // turn_on == False: the policy loss is not in the loss list (ppo.py:226-236) -> no gradient, no step
+      for (int p = threadIdx.x; p < tl.total; p += blockDim.x) W.ad.grad[p] = 0.f;
+      norms[0] = 0.f;
+      continue;
+    }
     float ss = 0.f;
     for (int p = threadIdx.x; p < tl.total; p += blockDim.x) {
       float g = raw_to_grad(raw, W.ad.theta, tl, rl, p, inv_den);

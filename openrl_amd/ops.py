@@ -1,0 +1,217 @@
+"""Tensor-level wrappers over the C ABI (``include/orl_hip.h``).
+
+Thin and mechanical on purpose: shape/dtype checks, raw pointers, current stream.  Every function
+launches HIP kernels asynchronously on ``torch.cuda.current_stream()`` and raises ``NativeError``
+on any failure.  No function here computes anything in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as nat
+from ._native import (AdamState, BufferPtrs, GatherDesc, NetDesc, PackSrc, PPOHParams, RolloutArgs, fptr, ptr,
+                      stream_ptr)
+
+HEAD_VALUE, HEAD_CATEGORICAL, HEAD_GAUSSIAN = nat.ORL_HEAD_VALUE, nat.ORL_HEAD_CATEGORICAL, nat.ORL_HEAD_GAUSSIAN
+ENV_SYNTH, ENV_CARTPOLE = nat.ORL_ENV_SYNTH, nat.ORL_ENV_CARTPOLE
+N_STATS = nat.ORL_N_STATS
+
+
+def _lib():
+    return nat.load()
+
+
+def net_desc(obs_dim: int, n_out: int, head_kind: int, hidden: int = 64) -> NetDesc:
+    return NetDesc(int(obs_dim), int(hidden), int(n_out), int(head_kind))
+
+
+def param_count(net: NetDesc) -> int:
+    n = _lib().orl_param_count(C.byref(net))
+    if n < 0:
+        nat.check(n, "orl_param_count")
+    return n
+
+
+def raw_grad_count(net: NetDesc) -> int:
+    n = _lib().orl_raw_grad_count(C.byref(net))
+    if n < 0:
+        nat.check(n, "orl_raw_grad_count")
+    return n
+
+
+def record_width(Dp: int, Dc: int, a: int, K: int) -> int:
+    return _lib().orl_record_width(Dp, Dc, a, K)
+
+
+def ppo_max_blocks() -> int:
+    return _lib().orl_ppo_max_blocks()
+
+
+def _dev(t: torch.Tensor):
+    nat.require_gpu(t.device)
+    return t.device
+
+
+# ------------------------------------------------------------------------------------------------ K6/K7
+def gae_max_partials(T: int, L: int) -> int:
+    return _lib().orl_gae_max_partials(T, L)
+
+
+def gae_scan(rewards, value_preds, masks, bad_masks, next_value, vn_state, returns, gamma: float, gae_lambda: float,
+             use_gae: bool, use_proper_time_limits: bool, active_masks=None, adv_raw=None, stat_partials=None) -> int:
+    """In-place on ``value_preds`` (slot T) and ``returns``; returns the number of stat partial rows."""
+    dev = _dev(rewards)
+    T = rewards.shape[0]
+    L = rewards[0].numel()
+    flags = (1 if use_gae else 0) | (2 if use_proper_time_limits else 0)
+    n_part = C.c_int(0)
+    rc = _lib().orl_gae_scan(fptr(rewards), fptr(value_preds), fptr(masks), fptr(bad_masks), fptr(next_value),
+                             fptr(vn_state), fptr(returns), T, L, float(gamma), float(gae_lambda), flags,
+                             fptr(active_masks), fptr(adv_raw), ptr(stat_partials), C.byref(n_part), stream_ptr(dev))
+    nat.check(rc, "orl_gae_scan")
+    return n_part.value
+
+
+def adv_stats(returns, value_preds, active_masks, vn_state, T: int, L: int, adv_raw, stat_partials) -> int:
+    dev = _dev(returns)
+    n_part = C.c_int(0)
+    rc = _lib().orl_adv_stats(fptr(returns), fptr(value_preds), fptr(active_masks), fptr(vn_state), T, L,
+                              fptr(adv_raw), ptr(stat_partials), C.byref(n_part), stream_ptr(dev))
+    nat.check(rc, "orl_adv_stats")
+    return n_part.value
+
+
+def adv_normalize_pack(adv, stat_partials, n_partials: int, T: int, L: int, use_adv_normalize: bool, stats_out=None,
+                       src: Optional[PackSrc] = None, records=None) -> None:
+    dev = _dev(adv)
+    rc = _lib().orl_adv_normalize_pack(fptr(adv), ptr(stat_partials), n_partials, T, L, int(bool(use_adv_normalize)),
+                                       ptr(stats_out), C.byref(src) if src is not None else None, fptr(records),
+                                       stream_ptr(dev))
+    nat.check(rc, "orl_adv_normalize_pack")
+
+
+# ------------------------------------------------------------------------------------------------ K5 / K8
+def buffer_insert(buf: BufferPtrs, step: int, next_policy_obs, next_critic_obs, rewards, dones, bad_transition=None,
+                  next_action_masks=None) -> None:
+    dev = _dev(rewards)
+    if dones.dtype != torch.uint8:
+        raise nat.NativeError("dones must be uint8")
+    rc = _lib().orl_buffer_insert(C.byref(buf), step, fptr(next_policy_obs), fptr(next_critic_obs), fptr(rewards),
+                                  ptr(dones), ptr(bad_transition), fptr(next_action_masks), stream_ptr(dev))
+    nat.check(rc, "orl_buffer_insert")
+
+
+def gather_minibatch(srcs: Sequence[torch.Tensor], idx: torch.Tensor) -> List[torch.Tensor]:
+    """dst[k][i, :] = srcs[k][idx[i], :] for up to 12 row-major 2-D float32 arrays in one launch."""
+    dev = _dev(idx)
+    if idx.dtype != torch.int64:
+        raise nat.NativeError("minibatch indices must be int64")
+    n = idx.numel()
+    d = GatherDesc()
+    outs = []
+    if len(srcs) > nat.ORL_GATHER_MAX:
+        raise nat.NativeError("too many arrays for one gather")
+    for k, s in enumerate(srcs):
+        w = s.shape[1]
+        o = torch.empty((n, w), dtype=torch.float32, device=dev)
+        d.src[k], d.dst[k], d.width[k] = fptr(s), fptr(o), w
+        outs.append(o)
+    d.count = len(srcs)
+    rc = _lib().orl_gather_minibatch(C.byref(d), ptr(idx), n, stream_ptr(dev))
+    nat.check(rc, "orl_gather_minibatch")
+    return outs
+
+
+def perm_feistel(n: int, seed: int, stream_id: int, device) -> torch.Tensor:
+    dev = nat.require_gpu(device)
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    rc = _lib().orl_perm_feistel(ptr(idx), n, seed & (2 ** 64 - 1), stream_id & (2 ** 64 - 1), stream_ptr(dev))
+    nat.check(rc, "orl_perm_feistel")
+    return idx
+
+
+# ------------------------------------------------------------------------------------------------ K1-K4
+def act_step(pnet: NetDesc, ptheta, cnet: Optional[NetDesc], ctheta, policy_obs, critic_obs, action_masks, B: int,
+             deterministic: bool, seed: int, row0: int, rng_step: int, forced_u, values, actions, logp) -> None:
+    dev = _dev(policy_obs)
+    rc = _lib().orl_act_step(C.byref(pnet), fptr(ptheta), C.byref(cnet) if cnet is not None else None, fptr(ctheta),
+                             fptr(policy_obs), fptr(critic_obs), fptr(action_masks), B, int(bool(deterministic)),
+                             seed & (2 ** 64 - 1), row0, rng_step, fptr(forced_u), fptr(values), fptr(actions),
+                             fptr(logp), stream_ptr(dev))
+    nat.check(rc, "orl_act_step")
+
+
+# ------------------------------------------------------------------------------------------------ K9-K14
+def ppo_fwd_bwd(pnet, ptheta, cnet, ctheta, records, idx, mb: int, vn_state, hp: PPOHParams, partials) -> int:
+    dev = _dev(records)
+    nb = C.c_int(0)
+    rc = _lib().orl_ppo_fwd_bwd(C.byref(pnet), fptr(ptheta), C.byref(cnet), fptr(ctheta), fptr(records),
+                                records.shape[1], ptr(idx), mb, fptr(vn_state), C.byref(hp), fptr(partials),
+                                C.byref(nb), stream_ptr(dev))
+    nat.check(rc, "orl_ppo_fwd_bwd")
+    return nb.value
+
+
+def ppo_reduce(partials_ptr: int, n_blocks: int, width: int, sums_ptr: int, dev) -> None:
+    rc = _lib().orl_ppo_reduce(partials_ptr, n_blocks, width, sums_ptr, stream_ptr(dev))
+    nat.check(rc, "orl_ppo_reduce")
+
+
+def ppo_apply(pnet, cnet, sums, hp: PPOHParams, padam: AdamState, cadam: AdamState, train_info_accum) -> None:
+    dev = _dev(sums)
+    rc = _lib().orl_ppo_apply(C.byref(pnet), C.byref(cnet), fptr(sums), C.byref(hp), C.byref(padam), C.byref(cadam),
+                              fptr(train_info_accum), stream_ptr(dev))
+    nat.check(rc, "orl_ppo_apply")
+
+
+def valuenorm_update(vn_state, moments, beta: float = 0.99999) -> None:
+    dev = _dev(vn_state)
+    rc = _lib().orl_valuenorm_update(fptr(vn_state), ptr(moments), float(beta), stream_ptr(dev))
+    nat.check(rc, "orl_valuenorm_update")
+
+
+def minibatch_moments(records, ret_col: int, idx, mb: int, scratch, moments) -> None:
+    dev = _dev(records)
+    rc = _lib().orl_minibatch_moments(fptr(records), records.shape[1], ret_col, ptr(idx), mb, ptr(scratch),
+                                      ptr(moments), stream_ptr(dev))
+    nat.check(rc, "orl_minibatch_moments")
+
+
+# ------------------------------------------------------------------------------------------------ device envs
+def env_state_width(env_kind: int) -> int:
+    n = _lib().orl_env_state_width(env_kind)
+    if n < 0:
+        nat.check(n, "orl_env_state_width")
+    return n
+
+
+def env_reset(env_kind: int, env_state, ep_stats, obs0, N: int, obs_dim: int, env_seed: int, episode_limit: int) -> None:
+    dev = _dev(env_state)
+    rc = _lib().orl_env_reset(env_kind, fptr(env_state), fptr(ep_stats), fptr(obs0), N, obs_dim,
+                              env_seed & (2 ** 64 - 1), episode_limit, stream_ptr(dev))
+    nat.check(rc, "orl_env_reset")
+
+
+def rollout_fused(pnet, ptheta, cnet, ctheta, args: RolloutArgs, next_value) -> None:
+    dev = _dev(ptheta)
+    rc = _lib().orl_rollout_fused(C.byref(pnet), fptr(ptheta), C.byref(cnet), fptr(ctheta), C.byref(args),
+                                  fptr(next_value), stream_ptr(dev))
+    nat.check(rc, "orl_rollout_fused")
+
+
+def make_hparams(cfg) -> PPOHParams:
+    """cfg flags -> orl_ppo_hparams (defaults: SURVEY.md section 5.6)."""
+    return PPOHParams(clip_param=float(cfg.clip_param), entropy_coef=float(cfg.entropy_coef),
+                      value_loss_coef=float(cfg.value_loss_coef), huber_delta=float(cfg.huber_delta),
+                      dual_clip_coeff=float(cfg.dual_clip_coeff), max_grad_norm=float(cfg.max_grad_norm),
+                      use_clipped_value_loss=int(bool(cfg.use_clipped_value_loss)),
+                      use_huber_loss=int(bool(cfg.use_huber_loss)),
+                      use_value_active_masks=int(bool(cfg.use_value_active_masks)),
+                      use_policy_active_masks=int(bool(cfg.use_policy_active_masks)),
+                      use_valuenorm=int(bool(cfg.use_valuenorm or cfg.use_popart)),
+                      dual_clip_ppo=int(bool(cfg.dual_clip_ppo)), use_max_grad_norm=int(bool(cfg.use_max_grad_norm)),
+                      reserved=0)

@@ -1,0 +1,93 @@
+"""Minimal observation/action spaces with gymnasium's class NAMES.
+
+The reference dispatches on ``space.__class__.__name__`` (buffers/utils/util.py:59-85,
+replay_data.py:148, act.py:14-25), so real ``gymnasium.spaces`` objects work here unchanged; these
+classes exist because gymnasium is not installable offline.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Space:
+    def __init__(self, shape=None, dtype=None):
+        self._shape = None if shape is None else tuple(int(s) for s in shape)
+        self.dtype = dtype
+
+    @property
+    def shape(self):
+        return self._shape
+
+    def __repr__(self):
+        return "%s(%s)" % (self.__class__.__name__, self._shape)
+
+
+class Box(Space):
+    def __init__(self, low=-np.inf, high=np.inf, shape=None, dtype=np.float32):
+        if shape is None:
+            shape = np.shape(low)
+        super().__init__(shape, dtype)
+        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), self._shape).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), self._shape).copy()
+
+
+class Discrete(Space):
+    def __init__(self, n, start=0):
+        super().__init__((), np.int64)
+        self.n = int(n)
+        self.start = int(start)
+
+    def __repr__(self):
+        return "Discrete(%d)" % self.n
+
+
+class Dict(Space):  # noqa: A001 - the name is the contract
+    def __init__(self, spaces=None, **kw):
+        super().__init__(None, None)
+        self.spaces = dict(spaces or {})
+        self.spaces.update(kw)
+
+    def __getitem__(self, k):
+        return self.spaces[k]
+
+    def keys(self):
+        return self.spaces.keys()
+
+
+def kind(space) -> str:
+    return space.__class__.__name__
+
+
+def policy_obs_space(obs_space):
+    """buffers/utils/util.py:42-53: Dict{"policy","critic"} selects per-tower spaces."""
+    if kind(obs_space) == "Dict" and "policy" in obs_space.spaces:
+        return obs_space["policy"]
+    return obs_space
+
+
+def critic_obs_space(obs_space):
+    if kind(obs_space) == "Dict" and "critic" in obs_space.spaces:
+        return obs_space["critic"]
+    return obs_space
+
+
+def obs_dim(space) -> int:
+    """Flat observation width of a Box / Discrete space (get_shape_from_obs_space_v2, util.py:56-71)."""
+    k = kind(space)
+    if k == "Box":
+        if len(space.shape) != 1:
+            raise NotImplementedError("openrl_amd builds MLP towers only: Box obs must be 1-D, got %s" % (space.shape,))
+        return int(space.shape[0])
+    if k == "Discrete":
+        return int(space.n)
+    raise NotImplementedError("obs space type %s not built in the MI355X engine" % k)
+
+
+def act_shape(space) -> int:
+    """Stored action width (get_shape_from_act_space, buffers/utils/util.py:74-85)."""
+    k = kind(space)
+    if k == "Discrete":
+        return 1
+    if k == "Box":
+        return int(space.shape[0])
+    raise NotImplementedError("action space type %s not built in the MI355X engine (Discrete / Box only)" % k)
