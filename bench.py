@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""bench.py - env-steps/sec (collect + GAE + PPO update) of the MI355X engine on BASELINE.json's
+config 2: CartPole-shaped PPO, 4096 envs x 128-step rollout per GPU, obs 4, Discrete(2), hidden 64,
+ppo_epoch 10, num_mini_batch 1, ValueNorm on (reference defaults).
+
+A "step" = ONE training iteration of the hot path over one batch: a 128-step rollout of 4096 envs on the
+synthetic fixed-step env + bootstrap value + GAE/advantages + 10 PPO epochs
+(forward, loss, backward, grad-clip, Adam for both towers).  Weak scaling: every rank runs 4096 envs;
+gradients / statistics are summed over ranks with one small RCCL all-reduce per optimiser step.
+
+    python bench.py [--gpus N --steps K --warmup W]           (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel pair (``orl_ppo_fwd_bwd`` =
+ppo_tower_kernel policy + critic, fp32 MFMA bound) timed live with HIP events on the launch stream;
+``cpu_baseline`` times the oracle port of the reference's CPU path (oracle/cpu_trainer.py) on the host
+cores - a reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+N_ENVS, T_ROLL, OBS_DIM, N_ACT, PPO_EPOCH = 4096, 128, 4, 2, 10
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (dense)
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--perm", default="device", choices=["device", "reference"],
+                    help="minibatch permutation source; 'reference' = host torch.randperm (bit-exact stream)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rollout-len", type=int, default=128, help="rollout length of the CPU baseline sample")
+    args = ap.parse_args()
+
+    from openrl_amd import distributed as du
+    from openrl_amd import ops
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+
+    local_rank = du.init_from_env()
+    world = du.world_size()
+    rank = du.rank()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+
+    cfg = default_cfg(["--episode_length", str(T_ROLL), "--ppo_epoch", str(PPO_EPOCH), "--amd_perm_mode", args.perm,
+                       "--log_interval", "1000000"])
+    env = make("SyntheticFixedStep-v0", env_num=N_ENVS, obs_dim=OBS_DIM, episode_limit=200, device=dev,
+               seed=cfg.seed + 10086 * rank)
+    net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=N_ENVS)
+    cfg.num_env_steps = N_ENVS * T_ROLL * (args.steps + args.warmup)
+
+    class _Agent:
+        num_time_steps = 0
+
+    trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=dev)
+    buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=dev)
+    drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": dev}, trainer, buf,
+                         _Agent(), rank=rank, world_size=world)
+    assert drv.fused
+    drv.reset_and_buffer_init()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        drv.episode = i
+        drv._inner_loop()
+    # live timing of the dominant kernel pair with HIP events on the launch stream (torch current stream)
+    trainer.profile_events = []
+    gae_events = []
+    orig_cr = buf.data.compute_returns
+
+    def timed_compute_returns(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_cr(*a, **k)
+        e1.record()
+        gae_events.append((e0, e1))
+
+    buf.data.compute_returns = timed_compute_returns
+    barrier()
+    t0 = time.perf_counter()
+    info = {}
+    for i in range(args.steps):
+        drv.episode = args.warmup + i
+        drv._inner_loop()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    steps_total = N_ENVS * T_ROLL * args.steps * world
+    value = steps_total / dt
+
+    # ---- roofline of the dominant kernel pair
+    M = N_ENVS * T_ROLL
+    f_fwd = 2 * ((OBS_DIM + OBS_DIM) * 64 + 2 * 64 * 64 + 64 * (N_ACT + 1))  # 17 792 flop / row
+    flops_per_launch = 3 * f_fwd * M                                          # fwd + dgrad + wgrad, both towers
+    ev = trainer.profile_events
+    k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    achieved_tf = flops_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    gae_ms = sum(a.elapsed_time(b) for a, b in gae_events) / max(len(gae_events), 1)
+    gae_bytes = 16 * M  # S_gae: 3 reads + 1 write per sample
+    roofline = {"kernel": "orl_ppo_fwd_bwd (ppo_tower_kernel policy+critic)", "bound": "mfma",
+                "achieved": round(achieved_tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launch_ms": round(k_ms, 4), "launches_timed": len(ev),
+                "flops_per_launch": flops_per_launch,
+                "gae_scan": {"bound": "hbm", "achieved": round(gae_bytes / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else 0,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "launch_ms": round(gae_ms, 4),
+                             "note": "8.4 MB per launch: latency-bound, includes adv statistics"}}
+
+    out = {"metric": "env-steps/sec (collect+PPO update), 4096-env CartPole-shape", "value": round(value, 1),
+           "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[1]: PPO, 4096 envs x 128-step rollout per GPU, obs 4, Discrete(2), "
+                                  "MLP 64x64, ppo_epoch 10, num_mini_batch 1, ValueNorm on; synthetic fixed-step env",
+                      "global_envs": N_ENVS * world, "rollout_len": T_ROLL, "ppo_epoch": PPO_EPOCH,
+                      "perm_mode": args.perm, "parallelism": "env-shard dp%d" % world},
+           "roofline": roofline}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_trainer import time_cpu_baseline
+
+        cb = time_cpu_baseline(n_envs=N_ENVS, T=args.cpu_rollout_len, ppo_epoch=PPO_EPOCH, iters=1)
+        out["cpu_baseline"] = {"value": round(cb["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": cb["cores"],
+                               "kind": "port",
+                               "sample": "1 iteration: %d envs x %d-step rollout + %d epochs (%.1f s; act %.1f s, "
+                                         "insert %.1f s, update %.1f s)" % (N_ENVS, args.cpu_rollout_len, PPO_EPOCH,
+                                                                           cb["seconds"], cb["phase_act"],
+                                                                           cb["phase_insert"], cb["phase_update"])}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -273,6 +273,13 @@ typedef struct orl_rollout_args {
 int orl_env_state_width(int env_kind);
 int orl_env_reset(int env_kind, float* env_state, float* ep_stats, float* obs0, int N, int obs_dim,
                   uint64_t env_seed, int episode_limit, void* stream);
+/* One env.step of a device env outside the fused rollout (evaluation loops, the stepwise driver; the
+ * VecEnv.step contract of openrl/envs/vec_env/base_venv.py): auto-reset semantics, obs [N, obs_dim],
+ * rewards [N], dones uint8 [N].  `global_step` is the env's step counter (keys the synthetic stream). */
+int orl_env_step(int env_kind, float* env_state, float* ep_stats, const float* actions, int action_width,
+                 float* obs, float* rewards, uint8_t* dones, int N, int obs_dim, uint64_t env_seed,
+                 int episode_limit, uint64_t global_step, void* stream);
+
 /* next_value [N] (optional): critic value of the observation in slot T, i.e. the bootstrap value
  * OnPolicyDriver.compute_returns feeds ReplayData.compute_returns (onpolicy_driver.py:205-233). */
 int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,

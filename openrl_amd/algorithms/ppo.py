@@ -85,7 +85,14 @@ class PPOAlgorithm(BaseAlgorithm):
                 dist_utils.allreduce_(self._moments)
             ops.valuenorm_update(vn.state, self._moments, vn.beta)  # BEFORE normalize (ppo.py:190-195)
             vn_state = vn.state
+        ev = getattr(self, "profile_events", None)
+        if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel pair
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         nb = ops.ppo_fwd_bwd(p.net, p.theta, c.net, c.theta, rec, idx, mb, vn_state, self.hp, self._partials)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         base = self._partials.data_ptr()
         sums = self._sums.data_ptr()
         ops.ppo_reduce(base, nb, self._raw_p, sums, self.device)

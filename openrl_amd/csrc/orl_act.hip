@@ -387,6 +387,53 @@ __global__ __launch_bounds__(128) void rollout_kernel(RolloutArgs A) {
   }
 }
 
+// Stand-alone env.step for device envs (evaluation loops, the stepwise driver): same dynamics and RNG
+// streams as the fused rollout; one thread per env.
+template <int ENV>
+__global__ __launch_bounds__(256) void env_step_kernel(float* __restrict__ env_state, float* __restrict__ ep_stats,
+                                                       const float* __restrict__ actions, int a_w,
+                                                       float* __restrict__ obs, float* __restrict__ rew,
+                                                       uint8_t* __restrict__ done, int N, int D, uint64_t seed,
+                                                       int episode_limit, uint64_t tg) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float r;
+  bool d;
+  if (ENV == ORL_ENV_SYNTH) {
+    float* st = env_state + (size_t)n * SYNTH_STATE_W;
+    r = synth_reward(seed, (uint32_t)n, tg);
+    float c = st[0] + 1.f;
+    d = c >= (float)episode_limit;
+    st[0] = d ? 0.f : c;
+    for (int b = 0; b < (D + 3) / 4; ++b) {
+      float o[4];
+      synth_obs_block(seed, (uint32_t)n, tg + 1, (uint32_t)b, o);
+      for (int k = 0; k < 4; ++k)
+        if (4 * b + k < D) obs[(size_t)n * D + 4 * b + k] = o[k];
+    }
+  } else {
+    float* st = env_state + (size_t)n * CARTPOLE_STATE_W;
+    float s[4] = {st[0], st[1], st[2], st[3]};
+    const bool term = cartpole_step(s, (int)actions[(size_t)n * a_w]);
+    const float steps = st[4] + 1.f;
+    d = term || steps >= (float)episode_limit;
+    r = 1.0f;
+    st[4] = d ? 0.f : steps;
+    if (d) {
+      st[5] += 1.f;
+      cartpole_reset(seed, (uint32_t)n, (uint32_t)st[5], s);
+    }
+    for (int k = 0; k < 4; ++k) { st[k] = s[k]; obs[(size_t)n * 4 + k] = s[k]; }
+  }
+  rew[n] = r;
+  done[n] = d ? 1 : 0;
+  if (ep_stats != nullptr) {
+    float* e = ep_stats + (size_t)n * 4;
+    e[0] += r; e[1] += 1.f;
+    if (d) { e[2] += e[0]; e[3] += 1.f; e[0] = 0.f; e[1] = 0.f; }
+  }
+}
+
 static int check_net(const orl_net_desc* n, const char* who, bool is_critic) {
   if (!n) return fail(ORL_E_INVALID, "%s: null net descriptor", who);
   if (n->hidden != HID) return fail(ORL_E_UNSUPPORTED, "%s: hidden_size %d not built (only 64)", who, n->hidden);
@@ -479,6 +526,27 @@ int orl_env_reset(int env_kind, float* env_state, float* ep_stats, float* obs0, 
     return fail(ORL_E_INVALID, "orl_env_reset: unknown env kind %d", env_kind);
   }
   return launch_status("orl_env_reset");
+}
+
+int orl_env_step(int env_kind, float* env_state, float* ep_stats, const float* actions, int action_width, float* obs,
+                 float* rewards, uint8_t* dones, int N, int obs_dim, uint64_t env_seed, int episode_limit,
+                 uint64_t global_step, void* stream) {
+  ORL_REQUIRE(env_state && obs && rewards && dones && N > 0 && obs_dim > 0 && episode_limit > 0,
+              "orl_env_step: bad arguments");
+  const int grid = (N + 255) / 256;
+  if (env_kind == ORL_ENV_SYNTH) {
+    hipLaunchKernelGGL((env_step_kernel<ORL_ENV_SYNTH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, env_state,
+                       ep_stats, actions, action_width, obs, rewards, dones, N, obs_dim, env_seed, episode_limit,
+                       global_step);
+  } else if (env_kind == ORL_ENV_CARTPOLE) {
+    ORL_REQUIRE(actions && action_width >= 1 && obs_dim == 4, "orl_env_step: CartPole needs actions and 4-d obs");
+    hipLaunchKernelGGL((env_step_kernel<ORL_ENV_CARTPOLE>), dim3(grid), dim3(256), 0, (hipStream_t)stream, env_state,
+                       ep_stats, actions, action_width, obs, rewards, dones, N, obs_dim, env_seed, episode_limit,
+                       global_step);
+  } else {
+    return fail(ORL_E_INVALID, "orl_env_step: unknown env kind %d", env_kind);
+  }
+  return launch_status("orl_env_step");
 }
 
 int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,

@@ -1,0 +1,229 @@
+"""``OnPolicyDriver`` - the rollout / update loop (``openrl/drivers/rl_driver.py:28-180`` +
+``openrl/drivers/onpolicy_driver.py:32-279``) for the MI355X engine.
+
+Two rollout paths behind the same ``actor_rollout``:
+
+* **fused** (device-resident envs, no per-step callback): ONE launch of ``orl_rollout_fused`` runs all
+  ``episode_length`` steps of {policy+value forward, sample, env.step, buffer insert, bootstrap value};
+  nothing crosses PCIe.  The reference crosses the device boundary twice per step and spends most of
+  its rollout time in ``np.split`` / ``np.concatenate`` (K16).
+* **stepwise** (any duck-typed VecEnv, or callbacks that need ``on_step``): per step one ``orl_act_step``
+  writing values / actions / log-probs straight into the buffer slot, ``env.step``, one
+  ``orl_buffer_insert`` that also builds masks / active_masks / bad_masks on the device
+  (onpolicy_driver.py:91-138).
+
+Callback protocol, ``agent.num_time_steps`` accounting and the ``({}, False)`` abort are those of
+onpolicy_driver.py:155-196.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .. import ops
+from ..utils.callbacks import as_callback
+from ..utils.logger import Logger
+
+
+def prepare_action_masks(infos, agent_num: int):
+    """envs/vec_env/utils/util.py:54-88 (as_batch=False): ``info["action_masks"]`` per env -> [N, A, K] or None."""
+    if infos is None:
+        return None
+    if isinstance(infos, dict):
+        return np.asarray(infos["action_masks"]) if "action_masks" in infos else None
+    if len(infos) == 0 or not isinstance(infos[0], dict) or "action_masks" not in infos[0]:
+        return None
+    return np.stack([np.asarray(i["action_masks"]).reshape(agent_num, -1) for i in infos])
+
+
+class OnPolicyDriver:
+    def __init__(self, config: Dict[str, Any], trainer, buffer, agent, rank: int = 0, world_size: int = 1, client=None,
+                 logger: Optional[Logger] = None, callback=None) -> None:
+        self.trainer = trainer
+        self.buffer = buffer
+        self.world_size = world_size
+        self.rank = rank
+        self.logger = logger if logger is not None else Logger()
+        cfg = config["cfg"]
+        self.cfg = cfg
+        self.envs = config["envs"]
+        self.device = nat.require_gpu(config["device"])
+        self.callback = as_callback(callback)
+        self.agent = agent
+        if self.callback.agent is None:
+            self.callback.init_callback(agent)
+        self.num_agents = config["num_agents"]
+        self.num_env_steps = cfg.num_env_steps
+        self.episode_length = cfg.episode_length
+        self.n_rollout_threads = cfg.n_rollout_threads
+        self.learner_n_rollout_threads = cfg.learner_n_rollout_threads
+        self.use_linear_lr_decay = cfg.use_linear_lr_decay
+        self.hidden_size = cfg.hidden_size
+        self.recurrent_N = cfg.recurrent_N
+        self.log_interval = cfg.log_interval
+        self.episode = 0
+        self.episodes = 0
+        self.total_num_steps = 0
+        mode = getattr(cfg, "amd_rollout_mode", "auto")
+        dev_env = bool(getattr(self.envs, "is_device_env", False))
+        if mode == "fused" and not dev_env:
+            raise ValueError("amd_rollout_mode=fused needs a device-resident env")
+        self.fused = dev_env and mode in ("auto", "fused") and not self.callback.needs_per_step
+        d = self.buffer.data
+        self._next_value = torch.zeros(d.n_rollout_threads, d.num_agents, 1, dtype=torch.float32, device=self.device)
+        self._have_next_value = False
+
+    # ---------------------------------------------------------------------------------------- rl_driver.py
+    def reset_and_buffer_init(self):
+        if getattr(self.envs, "is_device_env", False):
+            obs = self.envs.reset_device(seed=getattr(self.envs, "seed", None))
+            info = None
+        else:
+            returns = self.envs.reset()
+            if isinstance(returns, tuple):
+                assert len(returns) == 2, "length of env reset returns must be 2, but get {}".format(len(returns))
+                obs, info = returns
+            else:
+                obs, info = returns, None
+        self.buffer.init_buffer(obs, action_masks=prepare_action_masks(info, self.num_agents))
+
+    def run(self) -> None:
+        episodes = int(self.num_env_steps) // self.episode_length // self.learner_n_rollout_threads
+        self.episodes = episodes
+        self.reset_and_buffer_init()
+        for episode in range(episodes):
+            self.episode = episode
+            if not self._inner_loop():
+                break
+
+    def learner_update(self):
+        if self.use_linear_lr_decay:
+            self.trainer.algo_module.lr_decay(self.episode, self.episodes)
+        self.compute_returns()
+        self.trainer.prep_training()
+        return self.trainer.train(self.buffer.data)
+
+    # ---------------------------------------------------------------------------------------- onpolicy_driver.py
+    def _inner_loop(self) -> bool:
+        rollout_infos, continue_training = self.actor_rollout()
+        if not continue_training:
+            return False
+        train_infos = self.learner_update()
+        self.buffer.after_update()
+        self.total_num_steps = (self.episode + 1) * self.episode_length * self.n_rollout_threads
+        if self.episode % self.log_interval == 0:
+            self.logger.log_info(rollout_infos, step=self.total_num_steps)
+            self.logger.log_info(train_infos, step=self.total_num_steps)
+        return True
+
+    def actor_rollout(self) -> Tuple[Dict[str, Any], bool]:
+        self.callback.on_rollout_start()
+        self.trainer.prep_rollout()
+        if self.fused:
+            self._fused_rollout()
+        else:
+            for step in range(self.episode_length):
+                if not self._rollout_step(step):
+                    return {}, False
+        batch_rew_infos = self.envs.batch_rewards(self.buffer)
+        self.callback.on_rollout_end()
+        if getattr(self.envs, "use_monitor", False):
+            if self.episode % self.log_interval == 0:
+                statistics_info = self.envs.statistics(self.buffer)
+            else:  # keep the FPS step count without a device->host sync
+                statistics_info = {}
+                if hasattr(self.envs, "count_steps"):
+                    self.envs.count_steps(self.buffer)
+                else:
+                    statistics_info = self.envs.statistics(self.buffer)
+            statistics_info.update(batch_rew_infos)
+            return statistics_info, True
+        return batch_rew_infos, True
+
+    def _fused_rollout(self) -> None:
+        d = self.buffer.data
+        mod = self.trainer.algo_module
+        p, c = mod.models["policy"], mod.models["critic"]
+        env = self.envs
+        f = nat.fptr
+        args = nat.RolloutArgs(d.buffer_ptrs(), f(d.value_preds), f(d.actions), f(d.action_log_probs), f(env.env_state),
+                               f(env.ep_stats), env.env_kind, env.episode_limit, env.seed & (2 ** 64 - 1),
+                               mod.act_seed & (2 ** 64 - 1), env.global_step)
+        ops.rollout_fused(p.net, p.theta, c.net, c.theta, args, self._next_value)
+        env.global_step += self.episode_length
+        mod.rng_step += self.episode_length
+        self._have_next_value = True
+        d.step = 0
+        d._adv_fresh = False
+        self.agent.num_time_steps += env.parallel_env_num * self.episode_length
+
+    def _rollout_step(self, step: int) -> bool:
+        d = self.buffer.data
+        values, actions, action_log_probs, rnn_states, rnn_states_critic = self.act(step)
+        extra_data = {"actions": actions, "values": values, "action_log_probs": action_log_probs, "step": step,
+                      "buffer": self.buffer}
+        if getattr(self.envs, "is_device_env", False):
+            obs, rewards, dones = self.envs.step_device(actions)
+            infos = None
+        else:
+            obs, rewards, dones, infos = self.envs.step(actions.cpu().numpy(), extra_data)
+        self.agent.num_time_steps += self.envs.parallel_env_num
+        self.callback.update_locals(locals())
+        if self.callback.on_step() is False:
+            return False
+        self.add2buffer({"obs": obs, "rewards": rewards, "dones": dones, "infos": infos, "step": step})
+        return True
+
+    @torch.no_grad()
+    def act(self, step: int):
+        """get_actions on slot ``step`` (onpolicy_driver.py:235-279); results land directly in the buffer
+        slot ([N, A, .] views) - no np.split / np.concatenate round trips."""
+        d = self.buffer.data
+        mod = self.trainer.algo_module
+        out = (d.value_preds[step].view(-1, 1), d.actions[step].view(-1, d.act_shape),
+               d.action_log_probs[step].view(-1, d.act_shape))
+        mod._forward(d.get_batch_data("critic_obs", step), d.get_batch_data("policy_obs", step),
+                     d.get_batch_data("action_masks", step), False, out=out)
+        return d.value_preds[step], d.actions[step], d.action_log_probs[step], None, None
+
+    def _as_dev(self, x, dtype=torch.float32):
+        if isinstance(x, torch.Tensor):
+            return x.to(self.device, dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(x)).to(self.device, dtype).contiguous()
+
+    def add2buffer(self, data):
+        """Mask construction + insert on the device (onpolicy_driver.py:80-152 -> orl_buffer_insert)."""
+        d = self.buffer.data
+        step = data["step"] if "step" in data else d.step
+        obs = data["obs"]
+        p_obs, c_obs = (obs.get("policy", obs), obs.get("critic", obs)) if isinstance(obs, dict) else (obs, obs)
+        p_obs = self._as_dev(p_obs)
+        c_obs = p_obs if c_obs is obs or d.critic_obs is d.policy_obs else self._as_dev(c_obs)
+        infos = data["infos"]
+        bad = None
+        if infos is not None and len(infos) and isinstance(infos[0], dict) and any("bad_transition" in i for i in infos):
+            bad = np.array([[bool(i.get("bad_transition", [False] * self.num_agents)[a]) for a in range(self.num_agents)]
+                            for i in infos], dtype=np.uint8)
+            bad = self._as_dev(bad, torch.uint8)
+        amask = prepare_action_masks(infos, self.num_agents)
+        ops.buffer_insert(d.buffer_ptrs(), step, p_obs, c_obs, self._as_dev(data["rewards"]),
+                          self._as_dev(data["dones"], torch.uint8), bad,
+                          None if amask is None else self._as_dev(amask))
+        d.step = (step + 1) % d.episode_length
+        d._adv_fresh = False
+
+    @torch.no_grad()
+    def compute_returns(self):
+        self.trainer.prep_rollout()
+        d = self.buffer.data
+        mod = self.trainer.algo_module
+        if self._have_next_value:
+            next_values = self._next_value
+            self._have_next_value = False
+        else:
+            next_values = mod.get_values(d.get_batch_data("critic_obs", -1), None, None).view(
+                d.n_rollout_threads, d.num_agents, 1)
+        self.buffer.compute_returns(next_values, mod.get_critic_value_normalizer())

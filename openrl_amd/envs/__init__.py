@@ -1,0 +1,3 @@
+from .common import make
+
+__all__ = ["make"]

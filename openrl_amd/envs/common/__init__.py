@@ -1,0 +1,3 @@
+from .registration import make
+
+__all__ = ["make"]

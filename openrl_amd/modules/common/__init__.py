@@ -1,0 +1,3 @@
+from .ppo_net import PPONet
+
+__all__ = ["PPONet"]

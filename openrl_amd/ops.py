@@ -196,6 +196,16 @@ def env_reset(env_kind: int, env_state, ep_stats, obs0, N: int, obs_dim: int, en
     nat.check(rc, "orl_env_reset")
 
 
+def env_step(env_kind: int, env_state, ep_stats, actions, obs, rewards, dones, N: int, obs_dim: int, env_seed: int,
+             episode_limit: int, global_step: int) -> None:
+    dev = _dev(env_state)
+    a_w = 0 if actions is None else actions.shape[-1]
+    rc = _lib().orl_env_step(env_kind, fptr(env_state), fptr(ep_stats), fptr(actions), a_w, fptr(obs), fptr(rewards),
+                             ptr(dones), N, obs_dim, env_seed & (2 ** 64 - 1), episode_limit, global_step,
+                             stream_ptr(dev))
+    nat.check(rc, "orl_env_step")
+
+
 def rollout_fused(pnet, ptheta, cnet, ctheta, args: RolloutArgs, next_value) -> None:
     dev = _dev(ptheta)
     rc = _lib().orl_rollout_fused(C.byref(pnet), fptr(ptheta), C.byref(cnet), fptr(ctheta), C.byref(args),

@@ -1,0 +1,185 @@
+"""Rollout-side parity on a MI355X: device envs vs their oracle restatements, fused vs stepwise rollout,
+teacher-forced check of the fused rollout against the oracle towers, and end-to-end training."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox as px
+from oracle import ppo_oracle as po
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg(argv=()):
+    from openrl_amd.configs.config import default_cfg
+
+    return default_cfg(list(argv))
+
+
+def test_synthetic_env_matches_oracle_stream():
+    from openrl_amd.envs.common import make
+
+    N, D, L = 37, 6, 5
+    env = make("SyntheticFixedStep-v0", env_num=N, obs_dim=D, episode_limit=L, seed=123, device=DEV)
+    orc = po.SynthEnvOracle(N, D, 123, L)
+    obs, _ = env.reset(seed=123)
+    np.testing.assert_allclose(obs, orc.reset(), rtol=1e-5, atol=2e-6)
+    for _ in range(12):
+        o, r, d, _ = env.step(None)
+        oo, rr, dd, _ = orc.step()
+        np.testing.assert_allclose(o, oo, rtol=1e-5, atol=2e-6)
+        assert np.array_equal(r, rr)          # rewards: integer->float conversion only, bit-exact
+        assert np.array_equal(d, dd)          # done schedule: integer arithmetic, bit-exact
+
+
+def test_cartpole_step_matches_gymnasium_dynamics_restatement():
+    from openrl_amd.envs.common import make
+
+    N = 512
+    env = make("CartPole-v1", env_num=N, seed=7, device=DEV)
+    obs0, _ = env.reset(seed=7)
+    want0 = po.cartpole_reset_state(7, np.arange(N), np.zeros(N))
+    np.testing.assert_allclose(obs0[:, 0], want0, rtol=0, atol=1e-7)
+    rs = np.random.RandomState(0)
+    state = obs0[:, 0].copy()
+    for t in range(30):
+        a = rs.randint(0, 2, N)
+        o, r, d, _ = env.step(a.reshape(N, 1, 1).astype(np.float32))
+        nxt, term = po.cartpole_step_f32(state, a)
+        live = ~d[:, 0]
+        np.testing.assert_allclose(o[live, 0], nxt[live], rtol=2e-5, atol=2e-6)
+        assert np.array_equal(d[:, 0], term)   # no truncation within 30 steps
+        assert np.all(r == 1.0)
+        # auto-reset: a finished env restarts from its next keyed reset state
+        state = np.where(d, o[:, 0], nxt)
+
+
+def _build(env_id, N, T, seed=3, **kw):
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+
+    cfg = _cfg(["--seed", str(seed), "--episode_length", str(T)])
+    env = make(env_id, env_num=N, device=DEV, seed=seed, **kw)
+    net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+
+    class _Agent:
+        num_time_steps = 0
+
+    cfg.num_env_steps = N * T
+    trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=DEV)
+    buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=DEV)
+    return cfg, env, net, trainer, buf, _Agent()
+
+
+@pytest.mark.parametrize("env_id,kw", [("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=7)), ("CartPole-v1", {})])
+def test_fused_rollout_equals_stepwise_rollout(env_id, kw):
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+
+    N, T = 50, 23
+    bufs = []
+    for mode in ("fused", "stepwise"):
+        cfg, env, net, trainer, buf, agent = _build(env_id, N, T, **kw)
+        cfg.amd_rollout_mode = mode
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf,
+                             agent)
+        assert drv.fused == (mode == "fused")
+        drv.reset_and_buffer_init()
+        drv.actor_rollout()
+        drv.compute_returns()
+        assert agent.num_time_steps == N * T
+        bufs.append(buf.data)
+    a, b = bufs
+    for f in ("policy_obs", "actions", "action_log_probs", "value_preds", "rewards", "masks", "active_masks",
+              "bad_masks", "returns", "advantages"):
+        x, y = getattr(a, f).cpu().numpy(), getattr(b, f).cpu().numpy()
+        assert np.array_equal(x, y), f
+
+
+def test_fused_rollout_teacher_forced_vs_oracle_towers():
+    N, T = 64, 16
+    cfg, env, net, trainer, buf, agent = _build("SyntheticFixedStep-v0", N, T, obs_dim=5, episode_limit=6)
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+
+    drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, agent)
+    drv.reset_and_buffer_init()
+    drv.actor_rollout()
+    d = buf.data
+    mod = net.module
+    pspec, cspec = po.TowerSpec(5, 2, po.HEAD_CATEGORICAL), po.TowerSpec(5, 1, po.HEAD_VALUE)
+    tp, tc = mod.models["policy"].theta.cpu(), mod.models["critic"].theta.cpu()
+    obs = d.policy_obs.cpu().numpy()
+    agree = []
+    for t in range(T):
+        x, _, _, _ = px.philox4x32_10(mod.act_seed, np.arange(N, dtype=np.uint32), 0, t, 0)
+        u = px.u01(x).reshape(N, 1)
+        v, a, lp = po.get_actions(pspec, tp, cspec, tc, obs[t, :, 0], obs[t, :, 0], None, False, u)
+        np.testing.assert_allclose(d.value_preds[t, :, 0].cpu().numpy(), v, rtol=1e-4, atol=1e-5)
+        same = d.actions[t, :, 0, 0].cpu().numpy() == a[:, 0]
+        agree.append(same.mean())
+        np.testing.assert_allclose(d.action_log_probs[t, :, 0].cpu().numpy()[same], lp[same], rtol=1e-4, atol=1e-5)
+    assert np.mean(agree) >= 0.995
+    # env side: obs slots follow the oracle env stream, masks follow the done schedule
+    orc = po.SynthEnvOracle(N, 5, env.seed, 6)
+    np.testing.assert_allclose(obs[0], orc.reset(), rtol=1e-5, atol=2e-6)
+    for t in range(T):
+        oo, rr, dd, _ = orc.step()
+        np.testing.assert_allclose(obs[t + 1], oo, rtol=1e-5, atol=2e-6)
+        assert np.array_equal(d.rewards[t].cpu().numpy(), rr)
+        assert np.array_equal(d.masks[t + 1].cpu().numpy()[:, :, 0], np.where(dd, 0.0, 1.0).astype(np.float32))
+
+
+def test_agent_train_api_and_callbacks():
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import PPOAgent as Agent
+    from openrl_amd.utils.callbacks import BaseCallback
+
+    class Count(BaseCallback):
+        def _on_step(self):
+            assert "obs" in self.locals
+            return True
+
+    cfg = _cfg(["--episode_length", "20", "--ppo_epoch", "2"])
+    env = make("CartPole-v1", env_num=9, device=DEV)
+    net = Net(env, cfg=cfg, device=DEV)
+    agent = Agent(net)
+    cb = Count()
+    agent.train(total_time_steps=9 * 20 * 3, callback=cb)
+    assert cb.n_calls * 9 == agent.num_time_steps == 9 * 20 * 3
+    obs, info = env.reset()
+    action, _ = agent.act(obs, deterministic=True)
+    assert action.shape == (9, 1, 1)
+    o, r, d, i = env.step(action)
+    assert o.shape == (9, 1, 4) and r.shape == (9, 1, 1) and d.shape == (9, 1)
+
+
+def test_cartpole_learns_like_the_reference_threshold(tmp_path):
+    """tests/test_examples/test_train_cartpole.py:39-54 of the reference: default cfg, 9 envs, 20 000 steps,
+    deterministic evaluation must reach a total reward >= 450 (episode cap 500)."""
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import PPOAgent as Agent
+
+    cfg = _cfg([])
+    env = make("CartPole-v1", env_num=9, device=DEV)
+    agent = Agent(Net(env, cfg=cfg, device=DEV))
+    agent.train(total_time_steps=20000)
+    agent.save(tmp_path / "ckpt")
+    agent.load(tmp_path / "ckpt")
+    env2 = make("CartPole-v1", env_num=9, device=DEV, seed=99)
+    agent.set_env(env2)
+    obs, _ = env2.reset(seed=99)
+    total = np.zeros(9)
+    alive = np.ones(9, bool)
+    for _ in range(500):
+        action, _ = agent.act(obs, deterministic=True)
+        obs, r, done, _ = env2.step(action)
+        total += r[:, 0, 0] * alive
+        alive &= ~done[:, 0]
+        if not alive.any():
+            break
+    assert total.mean() >= 450, total
