@@ -48,6 +48,8 @@ class PPOAlgorithm(BaseAlgorithm):
         self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
         self._mom_scratch = torch.zeros(512, dtype=torch.float64, device=dev)
         self._adv_stats = torch.zeros(8, dtype=torch.float64, device=dev)
+        self._mom_sel = torch.tensor([6, 7, 2], dtype=torch.int64, device=dev)
+        self._full_batch_moments = False
         self.perm_mode = getattr(cfg, "amd_perm_mode", "reference")
         self._perm_counter = 0
         self.last_indices = None  # minibatch index tensors of the last train() (tests / inspection)
@@ -79,10 +81,15 @@ class PPOAlgorithm(BaseAlgorithm):
         vn = mod.get_critic_value_normalizer() if self._use_valuenorm else None
         vn_state = None
         if vn is not None:
-            ret_col = buffer.Dp + buffer.Dc + 2 * buffer.act_shape + 2
-            ops.minibatch_moments(rec, ret_col, idx, mb, self._mom_scratch, self._moments)
-            if self.world_size > 1:
-                dist_utils.allreduce_(self._moments)
+            if self._full_batch_moments:
+                # one minibatch == the whole batch: sum(ret), sum(ret^2), count are the (already globally
+                # reduced) return statistics the GAE kernel produced - no extra pass over the rows
+                pass
+            else:
+                ret_col = buffer.Dp + buffer.Dc + 2 * buffer.act_shape + 2
+                ops.minibatch_moments(rec, ret_col, idx, mb, self._mom_scratch, self._moments)
+                if self.world_size > 1:
+                    dist_utils.allreduce_(self._moments)
             ops.valuenorm_update(vn.state, self._moments, vn.beta)  # BEFORE normalize (ppo.py:190-195)
             vn_state = vn.state
         ev = getattr(self, "profile_events", None)
@@ -123,6 +130,9 @@ class PPOAlgorithm(BaseAlgorithm):
     def train_ppo(self, buffer, turn_on: bool = True) -> Dict[str, float]:
         self._advantages_and_records(buffer)
         M = buffer.episode_length * buffer.n_rollout_threads * buffer.num_agents
+        self._full_batch_moments = self.num_mini_batch == 1
+        if self._full_batch_moments:
+            self._moments.copy_(self._adv_stats[self._mom_sel])  # {sum ret, sum ret^2, count}
         self._info.zero_()
         self.last_indices = []
         for _ in range(self.ppo_epoch):

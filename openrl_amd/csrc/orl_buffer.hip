@@ -344,32 +344,43 @@ __global__ __launch_bounds__(256) void gather_kernel(orl_gather_desc d, const in
 
 // ------------------------------------------------------------------------------------------------
 // Keyed permutation of [0,n): balanced Feistel network over 2*hb bits (2^(2hb) >= n) with
-// cycle walking; round function = one Philox4x32-10 block of (half, round) under the key.
+// cycle walking.  The four 32-bit round keys come from ONE Philox4x32-10 block of (stream_id) under
+// `seed`; the round function is the murmur3 32-bit finaliser of (half ^ key) - a bijection-preserving
+// Feistel needs no more than a well-mixed round function, and this keeps the kernel store-bound.
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline uint64_t feistel_perm(uint64_t i, uint64_t n, int hb, uint64_t seed, uint64_t stream_id) {
-  const uint64_t hmask = ((uint64_t)1 << hb) - 1;
+__host__ __device__ inline uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+
+__host__ __device__ inline uint64_t feistel_perm(uint64_t i, uint64_t n, int hb, const u4& keys) {
+  const uint32_t hmask = (uint32_t)(((uint64_t)1 << hb) - 1);
+  const uint32_t k[4] = {keys.x, keys.y, keys.z, keys.w};
   uint64_t x = i;
   do {
-    uint64_t lft = x >> hb, rgt = x & hmask;
+    uint32_t lft = (uint32_t)(x >> hb), rgt = (uint32_t)x & hmask;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const u4 f = philox4x32_10(seed, (uint32_t)rgt, (uint32_t)(rgt >> 32), (uint32_t)stream_id,
-                                 (uint32_t)(stream_id >> 32) * 4u + (uint32_t)r);
-      const uint64_t fv = (((uint64_t)f.y << 32) | f.x) & hmask;
-      const uint64_t nl = rgt;
+      const uint32_t fv = fmix32(rgt ^ k[r]) & hmask;
+      const uint32_t nl = rgt;
       rgt = lft ^ fv;
       lft = nl;
     }
-    x = (lft << hb) | rgt;
+    x = ((uint64_t)lft << hb) | rgt;
   } while (x >= n);
   return x;
 }
 
 __global__ __launch_bounds__(256) void perm_feistel_kernel(int64_t* __restrict__ idx, long long n, int hb,
                                                            uint64_t seed, uint64_t stream_id) {
+  const u4 keys = philox4x32_10(seed, (uint32_t)stream_id, (uint32_t)(stream_id >> 32), 0x5EED5EEDu, 0u);
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    idx[i] = (int64_t)feistel_perm((uint64_t)i, (uint64_t)n, hb, seed, stream_id);
+    idx[i] = (int64_t)feistel_perm((uint64_t)i, (uint64_t)n, hb, keys);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -594,6 +605,7 @@ int orl_gather_minibatch(const orl_gather_desc* desc, const int64_t* idx, int n_
 
 int orl_perm_feistel(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
   ORL_REQUIRE(idx && n > 0, "orl_perm_feistel: bad arguments");
+  ORL_REQUIRE(n <= ((int64_t)1 << 62), "orl_perm_feistel: n too large");
   int bits = 1;
   while (((int64_t)1 << bits) < n) ++bits;
   const int hb = (bits + 1) / 2;

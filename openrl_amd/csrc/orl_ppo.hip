@@ -494,11 +494,23 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
 // ---- reduce: column sums over workgroup partials -------------------------------------------------
 __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partials, int n_blocks, int width,
                                                          float* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= width) return;
-  float s = 0.f;
-  for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * width + c];
-  sums[c] = s;
+  // block = 64 columns x 4 row groups: coalesced 256-byte row segments, 4-way split of the row walk,
+  // fixed summation order (deterministic): rows rg, rg+4, ... then groups 0..3.
+  __shared__ float sh[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < width) {
+    int b = rg;
+    for (; b + 4 < n_blocks; b += 8) {
+      s0 += partials[(size_t)b * width + col];
+      s1 += partials[(size_t)(b + 4) * width + col];
+    }
+    if (b < n_blocks) s0 += partials[(size_t)b * width + col];
+  }
+  sh[rg][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && col < width) sums[col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 // ---- apply: raw sums -> grads -> clip -> Adam; one workgroup of 1024 threads ------------------------
@@ -709,7 +721,7 @@ int orl_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net
 
 int orl_ppo_reduce(const float* partials, int n_blocks, int width, float* sums, void* stream) {
   ORL_REQUIRE(partials && sums && n_blocks > 0 && width > 0, "orl_ppo_reduce: bad arguments");
-  const int grid = (width + 255) / 256;
+  const int grid = (width + 63) / 64;
   hipLaunchKernelGGL(ppo_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partials, n_blocks, width, sums);
   return launch_status("orl_ppo_reduce");
 }

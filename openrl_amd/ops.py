@@ -137,7 +137,7 @@ def perm_feistel(n: int, seed: int, stream_id: int, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------ K1-K4
 def act_step(pnet: NetDesc, ptheta, cnet: Optional[NetDesc], ctheta, policy_obs, critic_obs, action_masks, B: int,
              deterministic: bool, seed: int, row0: int, rng_step: int, forced_u, values, actions, logp) -> None:
-    dev = _dev(policy_obs)
+    dev = _dev(policy_obs if policy_obs is not None else critic_obs)
     rc = _lib().orl_act_step(C.byref(pnet), fptr(ptheta), C.byref(cnet) if cnet is not None else None, fptr(ctheta),
                              fptr(policy_obs), fptr(critic_obs), fptr(action_masks), B, int(bool(deterministic)),
                              seed & (2 ** 64 - 1), row0, rng_step, fptr(forced_u), fptr(values), fptr(actions),

@@ -63,24 +63,34 @@ def box_muller(x0, x1):
     return (rad * np.cos(ang)).astype(np.float32), (rad * np.sin(ang)).astype(np.float32)
 
 
+def _fmix32(x):
+    x = x & MASK32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & MASK32
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & MASK32
+    x ^= x >> np.uint64(16)
+    return x
+
+
 def feistel_perm(n: int, seed: int, stream_id: int) -> np.ndarray:
-    """Device ``orl_perm_feistel``: 4-round balanced Feistel with cycle walking over ceil(log2 n) bits."""
+    """Device ``orl_perm_feistel``: 4-round balanced Feistel over ceil(log2 n) bits with cycle walking; round
+    keys = one Philox block of (stream_id) under ``seed``; round function = murmur3 fmix32(half ^ key)."""
     bits = 1
     while (1 << bits) < n:
         bits += 1
     hb = (bits + 1) // 2
-    hmask = (1 << hb) - 1
-    x = np.arange(n, dtype=np.uint64)
+    hmask = np.uint64((1 << hb) - 1)
+    keys = [np.uint64(int(k)) for k in philox4x32_10(seed, stream_id & 0xFFFFFFFF, (stream_id >> 32) & 0xFFFFFFFF,
+                                                     0x5EED5EED, 0)]
     out = np.empty(n, dtype=np.int64)
     pending = np.arange(n)
-    cur = x.copy()
+    cur = np.arange(n, dtype=np.uint64)
     while pending.size:
         lft = cur >> np.uint64(hb)
-        rgt = cur & np.uint64(hmask)
+        rgt = cur & hmask
         for r in range(4):
-            fx, fy, _, _ = philox4x32_10(seed, rgt & MASK32, rgt >> np.uint64(32), stream_id & 0xFFFFFFFF,
-                                         ((stream_id >> 32) * 4 + r) & 0xFFFFFFFF)
-            fv = ((fy.astype(np.uint64) << np.uint64(32)) | fx.astype(np.uint64)) & np.uint64(hmask)
+            fv = _fmix32(rgt ^ keys[r]) & hmask
             lft, rgt = rgt, lft ^ fv
         cur = (lft << np.uint64(hb)) | rgt
         done = cur < np.uint64(n)
