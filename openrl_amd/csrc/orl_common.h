@@ -116,6 +116,26 @@ __host__ __device__ inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0
 __host__ __device__ inline float u01_open0(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
 
 // ---- wave helpers ------------------------------------------------------------------------------
+// Sum over the 4 lanes {l, l^16, l^32, l^48} that share a batch row of a 16-row MFMA tile, result in all
+// of them.  gfx950 v_permlane16_swap / v_permlane32_swap are plain VALU ops (no LDS round trip like
+// ds_bpermute): swapping a value with a copy of itself and adding the two results is x + x[lane^16]
+// (resp. x + x[lane^32]).
+__device__ inline float row_allsum(float s) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  // Written as inline asm on purpose: with ROCm 7.2's hipcc the __builtin_amdgcn_permlane{16,32}_swap
+  // pair-result is mis-lowered inside larger kernels (the add after the swap reads the FIRST result twice:
+  // `v_permlane16_swap v12, v13 ; v_add_f32 v12, v12, v12`), which silently turns the sum into 2*x.
+  // The swap rewrites both operands in place, hence the two "+v" copies; the s_nop's are the VALU-write ->
+  // permlane-read wait states hipcc itself inserts (it pads nothing inside an asm statement).
+  float a = s, b = s;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  const float t = a + b;
+  a = t;
+  b = t;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

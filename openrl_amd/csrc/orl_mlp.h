@@ -123,8 +123,7 @@ __device__ inline float feat_sum(const f32x4 (&x)[4]) {
   float s = 0.f;
 #pragma unroll
   for (int m = 0; m < 4; ++m) s += (x[m][0] + x[m][1]) + (x[m][2] + x[m][3]);
-  s += __shfl_xor(s, 16);
-  s += __shfl_xor(s, 32);
+  s = row_allsum(s);
   return s;
 }
 
@@ -137,8 +136,7 @@ __device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd) {
     x[m] = x[m] - mean;
     v += (x[m][0] * x[m][0] + x[m][1] * x[m][1]) + (x[m][2] * x[m][2] + x[m][3] * x[m][3]);
   }
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
+  v = row_allsum(v);
   rstd = 1.0f / sqrtf(v * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
   for (int m = 0; m < 4; ++m) x[m] = x[m] * rstd;
@@ -177,8 +175,7 @@ __device__ inline void head_T(const float* __restrict__ W3s, const float* __rest
         const f32x4 w = *(const f32x4*)(W3s + c * HID + 16 * m + 4 * q);
         p += (w[0] * n2[m][0] + w[1] * n2[m][1]) + (w[2] * n2[m][2] + w[3] * n2[m][3]);
       }
-      p += __shfl_xor(p, 16);
-      p += __shfl_xor(p, 32);
+      p = row_allsum(p);
       p += b3s[c];
     }
     out[c] = p;

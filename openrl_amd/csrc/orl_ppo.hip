@@ -69,9 +69,10 @@ __device__ inline void load_slab_T(const float* __restrict__ slab, f32x4 (&x)[4]
 // make LDS writes of this wave visible to its own later reads (single wave, in-order LDS queue);
 // only the compiler must be kept from reordering.
 __device__ inline void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // LDS operations of one wave execute in issue order, so a later ds_read observes an earlier ds_write of
+  // ANY lane of the same wave; the compiler still inserts the lgkmcnt wait before a read's first use.
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // LayerNorm backward in T layout, in place: d <- rstd * (d*g - mean(d*g) - xhat * mean(d*g*xhat))
@@ -87,8 +88,8 @@ __device__ inline void ln_bwd_T(f32x4 (&d)[4], const f32x4 (&xhat)[4], const flo
     s1 += (d[m][0] + d[m][1]) + (d[m][2] + d[m][3]);
     s2 += (t[m][0] + t[m][1]) + (t[m][2] + t[m][3]);
   }
-  s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-  s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+  s1 = row_allsum(s1);
+  s2 = row_allsum(s2);
   const float c1 = s1 * (1.0f / 64.0f), c2 = s2 * (1.0f / 64.0f);
 #pragma unroll
   for (int m = 0; m < 4; ++m) d[m] = (d[m] - c1 - xhat[m] * c2) * rstd;
@@ -108,13 +109,14 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
   const int n_out = A.net.n_out;
   constexpr int NOP = (NO + 3) & ~3;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
-  const int per_wave = 3 * SLAB + TILE_B * DP + TILE_B * NOP;
+  const int rts = (((A.R >> 2) + 3) >> 2) * 256;  // floats per record-ring slot
+  const int per_wave = 3 * SLAB + 2 * rts + TILE_B * NOP;
   float* wl = smem + tw.total + wave * per_wave;
   float* X1 = wl;              // xhat1 slab
   float* X2 = wl + SLAB;       // xhat2 slab
   float* SS = wl + 2 * SLAB;   // scratch slab (dn2 -> dz2 -> dn1 -> dz1)
-  float* XT = wl + 3 * SLAB;   // x tile [16][DP]
-  float* DH = XT + TILE_B * DP;  // dhead [16][NOP]
+  float* XT = wl + 3 * SLAB;   // record ring: 2 slots of [chunk][16 rows][4 floats]
+  float* DH = XT + 2 * rts;    // dhead [16][NOP]
   __syncthreads();
 
   const float* lw = smem;
@@ -150,28 +152,52 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
   }
 
   const int n_tiles = (A.mb + TILE_B - 1) / TILE_B;
-  const int wave_g = blockIdx.x * PPO_WAVES + wave;
-  const int n_waves = gridDim.x * PPO_WAVES;
+  const int nwv = blockDim.x >> 6;  // waves in this workgroup (8 unless LDS forces fewer)
+  const int wave_g = blockIdx.x * nwv + wave;
+  const int n_waves = gridDim.x * nwv;
+
+  // ---- record tile pipeline -----------------------------------------------------------------------
+  // The 16 records of a tile are DMA'd global -> LDS (global_load_lds, 16 B per lane, no VGPRs) one tile
+  // AHEAD into a 2-deep ring; layout RT[chunk][row][4 floats] (the DMA writes wave-base + lane*16 B with
+  // lane = row + 16*q handling chunk 4g+q).  Minibatch indices are fetched two tiles ahead.
+  const int nch = A.R >> 2;
+  const int RTS = ((nch + 3) >> 2) * 256;  // floats per ring slot
+  auto row_of = [&](int t) -> long long {
+    const int ii = t * TILE_B + j;
+    if (t >= n_tiles || ii >= A.mb) return 0;  // invalid lanes read row 0 (finite data, weight 0)
+    return (A.idx != nullptr) ? A.idx[ii] : (long long)ii;
+  };
+  auto issue_dma = [&](float* slot, long long row) {
+    const float* src = A.records + (size_t)row * A.R;
+    for (int g = 0; 4 * g < nch; ++g) {
+      const int c = 4 * g + q;
+      if (c < nch)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * c),
+                                         (__attribute__((address_space(3))) void*)(slot + g * 256), 16, 0, 0);
+    }
+  };
+  long long row_next = row_of(wave_g);
+  issue_dma(XT, row_next);
+  row_next = row_of(wave_g + n_waves);
+  int ring = 0;
 
   for (int tile = wave_g; tile < n_tiles; tile += n_waves) {
     const int i = tile * TILE_B + j;
     const bool valid = i < A.mb;
-    long long row = 0;
-    if (valid) row = (A.idx != nullptr) ? A.idx[i] : (long long)i;
-    const float* rec = A.records + (size_t)row * A.R;
-
-    // x tile -> LDS (B operand of fc1 and of the dW1 pass)
-    for (int s = 0; s < (DP >> 2); ++s) {
-      const int k = 4 * s + q;
-      XT[j * DP + k] = (valid && k < D) ? rec[A.o_x + k] : 0.f;
-    }
-    wave_lds_fence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's records have landed in LDS
+    const float* RT = XT + ring * RTS;
+    issue_dma(XT + (ring ^ 1) * RTS, row_next);        // next tile's records, hidden behind this tile
+    row_next = row_of(tile + 2 * n_waves);
+    ring ^= 1;
+#define REC(col) RT[(((col) >> 2) << 6) + (j << 2) + ((col) & 3)]
+#define REC_R(r, col) RT[(((col) >> 2) << 6) + ((r) << 2) + ((col) & 3)]
 
     // ---------------- forward ----------------
     f32x4 z[4], xh1[4], n1[4], xh2[4];
     float rstd1, rstd2;
     load_vec_T(lw + tw.b1, q, z);
-    fc1_T(lw + tw.W1, DP, [&](int s) -> float { return XT[j * DP + 4 * s + q]; }, z, j, q);
+    // columns >= D of a record are other (finite) fields; W1's LDS image is zero-padded there
+    fc1_T(lw + tw.W1, DP, [&](int s) -> float { return REC(A.o_x + 4 * s + q); }, z, j, q);
     unsigned relu_bits = 0u;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -195,12 +221,12 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
     float dh[NO];
 #pragma unroll
     for (int c = 0; c < NO; ++c) dh[c] = 0.f;
-    const float active = valid ? rec[A.o_am] : 0.f;
+    const float active = valid ? REC(A.o_am) : 0.f;
     if (HEAD == ORL_HEAD_VALUE) {
       const float w = valid ? (hp.use_value_active_masks ? active : 1.f) : 0.f;
       const float v = hd[0];
-      const float vp = valid ? rec[A.o_vp] : 0.f;
-      float rt = valid ? rec[A.o_rt] : 0.f;
+      const float vp = valid ? REC(A.o_vp) : 0.f;
+      float rt = valid ? REC(A.o_rt) : 0.f;
       if (hp.use_valuenorm) rt = (rt - vn_mean) / vn_sd;
       // cal_value_loss (ppo.py:178-220)
       const float dv = v - vp;
@@ -225,12 +251,14 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
       if (q == 0 && valid) { st_active += active; st_rows += 1.f; st_loss += vl * w; }
     } else {
       const float w = valid ? (hp.use_policy_active_masks ? active : 1.f) : 0.f;
-      const float adv = valid ? rec[A.o_adv] : 0.f;
+      const float adv = valid ? REC(A.o_adv) : 0.f;
       if (HEAD == ORL_HEAD_CATEGORICAL) {
-        const float* am = (A.K > 0 && valid) ? rec + A.o_mk : nullptr;
-        const float lse = cat_lse<NO>(hd, n_out, am);
-        const int act = valid ? (int)rec[A.o_act] : 0;
-        const float old_lp = valid ? rec[A.o_lp] : 0.f;
+        float mk[NO];  // action mask of this row (1 = legal)
+#pragma unroll
+        for (int c = 0; c < NO; ++c) mk[c] = (A.K > 0 && valid && c < n_out) ? REC(A.o_mk + c) : 1.f;
+        const float lse = cat_lse<NO>(hd, n_out, mk);
+        const int act = valid ? (int)REC(A.o_act) : 0;
+        const float old_lp = valid ? REC(A.o_lp) : 0.f;
         const float lp = pick<NO>(hd, act) - lse;
         float ent = 0.f;
         float p[NO];
@@ -257,7 +285,7 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
 #pragma unroll
         for (int c = 0; c < NO; ++c) {
           if (c < n_out) {
-            const bool masked = (am != nullptr) && (am[c] == 0.f);
+            const bool masked = mk[c] == 0.f;
             const float ell = hd[c] - lse;
             const float d = gl * ((c == act ? 1.f : 0.f) - p[c]) + hp.entropy_coef * p[c] * (ell + ent);
             dh[c] = masked ? 0.f : w * d;
@@ -275,8 +303,8 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
           if (c < n_out) {
             const float ls = lw[tw.logstd + c];
             const float sd = expf(ls);
-            const float av = valid ? rec[A.o_act + c] : 0.f;
-            const float old_lp = valid ? rec[A.o_lp + c] : 0.f;
+            const float av = valid ? REC(A.o_act + c) : 0.f;
+            const float old_lp = valid ? REC(A.o_lp + c) : 0.f;
             const float dmu = av - hd[c];
             const float var = sd * sd;
             const float lp = -(dmu * dmu) / (2.f * var) - ls - 0.91893853320467274178f;
@@ -413,7 +441,7 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
       if (ND == 0) {
         for (int r = 0; r < TILE_B; ++r) {
           const float dzv = SS[r * TS + f];
-          const f32x4 xv = *(const f32x4*)(XT + r * 4);
+          const f32x4 xv = *(const f32x4*)(&REC_R(r, A.o_x));  // o_x % 4 == 0 on this path
           w1v[0] += dzv * xv[0]; w1v[1] += dzv * xv[1]; w1v[2] += dzv * xv[2]; w1v[3] += dzv * xv[3];
         }
       } else {
@@ -423,7 +451,7 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) av[m] = SS[(4 * s + q) * TS + 16 * m + j];
 #pragma unroll
-          for (int mk = 0; mk < NDA; ++mk) bv[mk] = (16 * mk + j < DP) ? XT[(4 * s + q) * DP + 16 * mk + j] : 0.f;
+          for (int mk = 0; mk < NDA; ++mk) bv[mk] = (16 * mk + j < D) ? REC_R(4 * s + q, A.o_x + 16 * mk + j) : 0.f;
 #pragma unroll
           for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
@@ -434,6 +462,8 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
     wave_lds_fence();
   }
 
+#undef REC
+#undef REC_R
   // ---- workgroup reduction of the 8 waves' accumulators, deterministic order -----------------------
   __syncthreads();
   float* acc = smem + tw.total;  // reuse the slab area: [rl.total + ORL_N_STATS]
@@ -442,7 +472,7 @@ __global__ __launch_bounds__(PPO_THREADS, 2) void ppo_tower_kernel(PpoArgs A) {
   __syncthreads();
   st_active = wave_sum(st_active); st_rows = wave_sum(st_rows); st_loss = wave_sum(st_loss);
   st_ent = wave_sum(st_ent); st_ratio = wave_sum(st_ratio);
-  for (int w = 0; w < PPO_WAVES; ++w) {
+  for (int w = 0; w < nwv; ++w) {
     if (wave == w) {
       // G tiles: lane (c = j, q), reg r -> G[o = 16mo+4q+r][i = 16mi+c]
 #pragma unroll
@@ -638,23 +668,30 @@ template <int HEAD, int NO, int ND>
 static int launch_tower(const PpoArgs& A, int grid, hipStream_t s) {
   const TowerLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, true);
   constexpr int NOP = (NO + 3) & ~3;
-  const int per_wave = 3 * SLAB + TILE_B * tw.DP + TILE_B * NOP;
+  const int rts = (((A.R >> 2) + 3) >> 2) * 256;
+  const int per_wave = 3 * SLAB + 2 * rts + TILE_B * NOP;
   const RawLayout rl(A.net);
-  size_t fl = (size_t)tw.total + (size_t)PPO_WAVES * per_wave;
+  // as many waves per workgroup (8, 6, 4, 2) as fit the 160 KiB of LDS next to the tower's weights
   const size_t need_acc = (size_t)tw.total + rl.total + ORL_N_STATS;
-  if (need_acc > fl) fl = need_acc;
+  int waves = PPO_WAVES;
+  size_t fl = 0;
+  for (; waves >= 2; waves -= 2) {
+    fl = (size_t)tw.total + (size_t)waves * per_wave;
+    if (need_acc > fl) fl = need_acc;
+    if (fl * sizeof(float) <= 160 * 1024) break;
+  }
   const size_t lds = fl * sizeof(float);
-  if (lds > 160 * 1024) return fail(ORL_E_UNSUPPORTED, "orl_ppo_fwd_bwd: tower needs %zu B of LDS (> 160 KiB)", lds);
+  if (waves < 2) return fail(ORL_E_UNSUPPORTED, "orl_ppo_fwd_bwd: tower needs %zu B of LDS (> 160 KiB)", lds);
   (void)hipFuncSetAttribute((const void*)ppo_tower_kernel<HEAD, NO, ND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  hipLaunchKernelGGL((ppo_tower_kernel<HEAD, NO, ND>), dim3(grid), dim3(PPO_THREADS), lds, s, A);
+  hipLaunchKernelGGL((ppo_tower_kernel<HEAD, NO, ND>), dim3(grid), dim3(waves * 64), lds, s, A);
   return launch_status("orl_ppo_fwd_bwd");
 }
 
 template <int HEAD, int NO>
 static int launch_tower_nd(const PpoArgs& A, int grid, hipStream_t s) {
   const int D = A.net.obs_dim;
-  if (D <= 4) return launch_tower<HEAD, NO, 0>(A, grid, s);
+  if (D <= 4 && (A.o_x & 3) == 0) return launch_tower<HEAD, NO, 0>(A, grid, s);
   if (D <= 16) return launch_tower<HEAD, NO, 1>(A, grid, s);
   if (D <= 32) return launch_tower<HEAD, NO, 2>(A, grid, s);
   return launch_tower<HEAD, NO, 4>(A, grid, s);
