@@ -210,6 +210,7 @@ int orl_ppo_max_blocks(void); /* upper bound of workgroups => rows of `partials`
 /* partials: float32 device scratch of orl_ppo_max_blocks() * (raw_p + ORL_N_STATS + raw_c + ORL_N_STATS)
  * floats: policy rows [n_blocks][raw_p + ORL_N_STATS] start at 0, critic rows
  * [n_blocks][raw_c + ORL_N_STATS] start at orl_ppo_max_blocks() * (raw_p + ORL_N_STATS).
+ * n_blocks_out (host int[2], optional) receives the rows written to the two regions.
  * idx may be NULL (identity order).  vn_state is read AFTER the caller applied
  * orl_valuenorm_update for this minibatch (ppo.py:190-195 order). */
 int orl_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,

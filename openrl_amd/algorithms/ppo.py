@@ -96,14 +96,14 @@ class PPOAlgorithm(BaseAlgorithm):
         if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel pair
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        nb = ops.ppo_fwd_bwd(p.net, p.theta, c.net, c.theta, rec, idx, mb, vn_state, self.hp, self._partials)
+        nb_p, nb_c = ops.ppo_fwd_bwd(p.net, p.theta, c.net, c.theta, rec, idx, mb, vn_state, self.hp, self._partials)
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
         base = self._partials.data_ptr()
         sums = self._sums.data_ptr()
-        ops.ppo_reduce(base, nb, self._raw_p, sums, self.device)
-        ops.ppo_reduce(base + 4 * ops.ppo_max_blocks() * self._raw_p, nb, self._raw_c, sums + 4 * self._raw_p,
+        ops.ppo_reduce(base, nb_p, self._raw_p, sums, self.device)
+        ops.ppo_reduce(base + 4 * ops.ppo_max_blocks() * self._raw_p, nb_c, self._raw_c, sums + 4 * self._raw_p,
                        self.device)
         if self.world_size > 1:
             dist_utils.allreduce_(self._sums)  # ONE small collective per optimiser step

@@ -48,9 +48,14 @@ struct TowerLayout {
 // Raw gradient-sum vector of one tower (what the fused backward accumulates; see orl_ppo.hip):
 //   G[H*H]   = sum_r dz2[r][o] * xhat1[r][i]          (dW2 = g1[i]*G + be1[i]*db2[o])
 //   S3[n_out*H] = sum_r dhead[r][c] * xhat2[r][f]     (dW3 = g2[f]*S3 + be2[f]*db3[c])
-//   db3[n_out], dg2[H], dbe2[H], db2[H], dg1[H], dbe1[H], dW1[H*D], db1[H], dlogstd[n_out]
+//   db3[n_out], db2[H], dW1[H*D], db1[H], dlogstd[n_out]
+// The LayerNorm affine gradients need NO accumulator of their own - they are linear images of the above:
+//   dn2 = W3^T dhead  =>  dg2[f]  = sum_r dn2[r][f] xhat2[r][f] = sum_c W3[c][f] * S3[c][f],
+//                         dbe2[f] = sum_r dn2[r][f]             = sum_c W3[c][f] * db3[c];
+//   dn1 = W2^T dz2    =>  dg1[i]  = sum_o W2[o][i] * G[o][i],     dbe1[i] = sum_o W2[o][i] * db2[o].
+// orl_ppo_apply evaluates them (fp32 dot products of <= 64 terms) from the reduced sums.
 struct RawLayout {
-  int oG, oS3, odb3, odg2, odbe2, odb2, odg1, odbe1, odW1, odb1, odlogstd, total;
+  int oG, oS3, odb3, odb2, odW1, odb1, odlogstd, total;
   __host__ __device__ RawLayout() {}
   __host__ __device__ explicit RawLayout(const orl_net_desc& n) {
     const int H = n.hidden, D = n.obs_dim, K = n.n_out;
@@ -58,11 +63,7 @@ struct RawLayout {
     oG = o; o += H * H;
     oS3 = o; o += K * H;
     odb3 = o; o += K;
-    odg2 = o; o += H;
-    odbe2 = o; o += H;
     odb2 = o; o += H;
-    odg1 = o; o += H;
-    odbe1 = o; o += H;
     odW1 = o; o += H * D;
     odb1 = o; o += H;
     odlogstd = o; o += (n.head_kind == ORL_HEAD_GAUSSIAN ? K : 0);

@@ -1,0 +1,526 @@
+// orl_ppo_tower.h - the fused per-tower PPO forward + loss + backward kernel (K9-K12) for gfx950.
+//
+// A wavefront owns 16-row tiles of the minibatch (stride = all waves of the grid).  Per tile, out of
+// registers + two private 16x64 LDS slabs, with fp32 MFMA 16x16x4 in the T layout of orl_mlp.h:
+//
+//   forward   x -> fc1 -> relu -> LN1 (xhat1 -> slab X1) -> n1 -> W2 (64 MFMA) -> LN2 (xhat2) -> n2 -> head
+//   loss      PPO clipped surrogate + entropy / clipped huber value loss  ->  dhead   (per batch row)
+//   backward  dn2 = W3^T dhead -> LN2' -> dz2 -> slab SS
+//             G  += dz2^T xhat1        (wgrad, 64 MFMA, operands read from SS / X1 in F layout), db2
+//             dn1 = W2^T dz2           (dgrad, 64 MFMA, A operand = W2 columns) -> LN1' -> relu' -> dz1 -> SS
+//             dW1 += dz1^T x, db1
+//
+// Only xhat1, xhat2, dz2 and dz1 are bounced through LDS (T-layout 16-byte row stores, F-layout 4-byte
+// column reads); the LayerNorm-affine gradients are NOT accumulated here at all - they are linear images
+// of G / S3 / db2 / db3 and are evaluated once per update in orl_ppo_apply (see RawLayout).
+//
+// Records arrive through a 2-deep global->LDS DMA ring (global_load_lds, no VGPRs) one tile ahead.
+// Occupancy: WPS waves per SIMD (3 when the LDS budget allows: 12 waves / CU, <= 168 VGPRs).
+#pragma once
+#include "orl_common.h"
+#include "orl_mlp.h"
+
+namespace orl {
+
+constexpr int PPO_MAX_BLOCKS = 256;  // one workgroup per CU
+constexpr int TS = 68;               // slab row stride (floats): 16-byte rows, bank-skewed
+constexpr int SLAB = TILE_B * TS;
+
+struct PpoArgs {
+  orl_net_desc net;
+  const float* theta;
+  const float* records;
+  const int64_t* idx;  // may be NULL (identity)
+  const float* vn_state;
+  float* partials;     // [gridDim][raw.total + ORL_N_STATS]
+  orl_ppo_hparams hp;
+  int R;               // record width
+  int o_x;             // column of this tower's observation inside a record
+  int o_act, o_lp, o_adv, o_vp, o_rt, o_am, o_mk;  // record columns
+  int a_w;             // stored action width
+  int K;               // action-mask width (0 = none)
+  int mb;              // rows in this minibatch
+};
+
+__device__ inline float huber_or_mse(float e, float d, int use_huber, float& de) {
+  if (use_huber) {
+    const float ae = fabsf(e);
+    if (ae <= d) { de = e; return e * e * 0.5f; }
+    de = e > 0.f ? d : -d;
+    return d * (ae - d * 0.5f);
+  }
+  de = e;
+  return e * e * 0.5f;
+}
+
+// T-layout 16x64 register tile <-> LDS slab rows (lane (j,q) owns 4 x 16 bytes of row j)
+__device__ inline void store_slab_T(float* __restrict__ slab, const f32x4 (&x)[4], int j, int q) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) *(f32x4*)(slab + j * TS + 16 * m + 4 * q) = x[m];
+}
+__device__ inline void load_slab_T(const float* __restrict__ slab, f32x4 (&x)[4], int j, int q) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(slab + j * TS + 16 * m + 4 * q);
+}
+
+// LDS operations of one wave execute in issue order, so a later ds_read observes an earlier ds_write of
+// ANY lane of the same wave; only the compiler has to be kept from reordering across this point (it still
+// inserts the lgkmcnt wait before a read's first use).
+__device__ inline void wave_lds_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// LayerNorm backward in T layout, in place: d <- rstd * (d*g - mean(d*g) - xhat * mean(d*g*xhat))
+__device__ inline void ln_bwd_T(f32x4 (&d)[4], const f32x4 (&xhat)[4], const float* __restrict__ g, float rstd,
+                                int q) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const f32x4 gg = *(const f32x4*)(g + 16 * m + 4 * q);
+    d[m] = d[m] * gg;
+    const f32x4 t = d[m] * xhat[m];
+    s1 += (d[m][0] + d[m][1]) + (d[m][2] + d[m][3]);
+    s2 += (t[0] + t[1]) + (t[2] + t[3]);
+  }
+  s1 = row_allsum(s1);
+  s2 = row_allsum(s2);
+  const float c1 = s1 * (1.0f / 64.0f), c2 = s2 * (1.0f / 64.0f);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) d[m] = (d[m] - c1 - xhat[m] * c2) * rstd;
+}
+
+// acc[mo] += sum_o W[o][16mo + j-th column] * in[o]   i.e.  acc = W^T in  with W row-major [64][W2S]:
+// the dgrad GEMM reads W2 by columns instead of keeping a transposed copy in LDS (rows 4q apart hit
+// banks 16 apart, so the 4-byte column reads are conflict free).
+__device__ inline void mm64_T_wt(const float* __restrict__ Ws, const f32x4 (&in)[4], f32x4 (&acc)[4], int j, int q) {
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row = Ws + (16 * mi + 4 * q + r) * W2S + j;
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(row[16 * mo], in[mi][r], acc[mo]);
+    }
+  }
+}
+
+// HEAD: ORL_HEAD_VALUE / _CATEGORICAL / _GAUSSIAN; NO: padded head width; ND: ceil(D/16) for the MFMA
+// dW1 path, 0 = VALU path (D <= 4, 16-byte aligned obs column); WPS: waves per SIMD the kernel is built for.
+template <int HEAD, int NO, int ND, int WPS>
+__global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const TowerLayout tl(A.net);
+  const RawLayout rl(A.net);
+  const TowerLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, false);
+  stage_tower(smem, A.theta, tl, tw, false, threadIdx.x, blockDim.x);
+  const int DP = tw.DP;
+  const int D = A.net.obs_dim;
+  const int n_out = A.net.n_out;
+  constexpr int NOP = (NO + 3) & ~3;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int nch = A.R >> 2;
+  const int rts = ((nch + 3) >> 2) * 256;  // floats per record-ring slot
+  const int per_wave = 2 * SLAB + 2 * rts + TILE_B * NOP;
+  float* wl = smem + tw.total + wave * per_wave;
+  float* X1 = wl;              // xhat1 slab (forward -> wgrad / LN1 backward)
+  float* SS = wl + SLAB;       // scratch slab: xhat2 -> dz2 -> dz1
+  float* RR = wl + 2 * SLAB;   // record ring: 2 slots of [chunk][16 rows][4 floats]
+  float* DH = RR + 2 * rts;    // dhead [16][NOP]
+  __syncthreads();
+
+  const float* lw = smem;
+  const orl_ppo_hparams hp = A.hp;
+
+  // ---- persistent accumulators (live across all tiles of this wave) -----------------------------------
+  f32x4 G[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NDA = ND > 0 ? ND : 1;
+  f32x4 G1[4][NDA];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < NDA; ++b) G1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float w1v[4] = {0.f, 0.f, 0.f, 0.f};  // VALU dW1 (ND == 0): lane f, k = 0..3
+  float a_db2 = 0.f, a_db1 = 0.f, a_db3 = 0.f, a_dls = 0.f;
+  float a_S3[NO];
+#pragma unroll
+  for (int c = 0; c < NO; ++c) a_S3[c] = 0.f;
+  float st_active = 0.f, st_rows = 0.f, st_loss = 0.f, st_ent = 0.f, st_ratio = 0.f;
+
+  // ValueNorm.normalize coefficients (valuenorm.py:79-91)
+  float vn_mean = 0.f, vn_sd = 1.f;
+  if (HEAD == ORL_HEAD_VALUE && hp.use_valuenorm && A.vn_state != nullptr) {
+    const float deb = fmaxf(A.vn_state[2], 1e-5f);
+    vn_mean = A.vn_state[0] / deb;
+    const float msq = A.vn_state[1] / deb;
+    vn_sd = sqrtf(fmaxf(msq - vn_mean * vn_mean, 1e-2f));
+  }
+
+  const int n_tiles = (A.mb + TILE_B - 1) / TILE_B;
+  const int nwv = blockDim.x >> 6;
+  const int wave_g = blockIdx.x * nwv + wave;
+  const int n_waves = gridDim.x * nwv;
+
+  // ---- record tile pipeline: DMA global -> LDS one tile ahead, indices two tiles ahead ----------------
+  auto row_of = [&](int t) -> long long {
+    const int ii = t * TILE_B + j;
+    if (t >= n_tiles || ii >= A.mb) return 0;  // invalid lanes read row 0 (finite data, weight 0)
+    return (A.idx != nullptr) ? A.idx[ii] : (long long)ii;
+  };
+  auto issue_dma = [&](float* slot, long long row) {
+    const float* src = A.records + (size_t)row * A.R;
+    for (int g = 0; 4 * g < nch; ++g) {
+      const int c = 4 * g + q;
+      if (c < nch)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * c),
+                                         (__attribute__((address_space(3))) void*)(slot + g * 256), 16, 0, 0);
+    }
+  };
+  long long row_next = row_of(wave_g);
+  issue_dma(RR, row_next);
+  row_next = row_of(wave_g + n_waves);
+  int ring = 0;
+
+  for (int tile = wave_g; tile < n_tiles; tile += n_waves) {
+    const int i = tile * TILE_B + j;
+    const bool valid = i < A.mb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's records have landed in LDS
+    const float* RT = RR + ring * rts;
+    issue_dma(RR + (ring ^ 1) * rts, row_next);       // next tile's records, hidden behind this tile
+    row_next = row_of(tile + 2 * n_waves);
+    ring ^= 1;
+#define REC(col) RT[(((col) >> 2) << 6) + (j << 2) + ((col) & 3)]
+#define REC_R(r, col) RT[(((col) >> 2) << 6) + ((r) << 2) + ((col) & 3)]
+
+    // ---------------- forward ----------------
+    f32x4 xh2[4];
+    float rstd1, rstd2;
+    unsigned relu_bits = 0u;
+    float hd[NO];
+    {
+      f32x4 z[4], n1[4];
+      load_vec_T(lw + tw.b1, q, z);
+      // columns >= D of a record are other (finite) fields; W1's LDS image is zero-padded there
+      fc1_T(lw + tw.W1, DP, [&](int s) -> float { return REC(A.o_x + 4 * s + q); }, z, j, q);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (z[m][r] > 0.f) relu_bits |= 1u << (4 * m + r);
+          z[m][r] = fmaxf(z[m][r], 0.f);
+        }
+      ln_normalize_T(z, rstd1);  // z = xhat1
+      store_slab_T(X1, z, j, q);
+      ln_affine_T(z, lw + tw.g1, lw + tw.be1, q, n1);
+      load_vec_T(lw + tw.b2, q, xh2);
+      mm64_T(lw + tw.W2, n1, xh2, j, q);
+      ln_normalize_T(xh2, rstd2);
+      ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, z);  // z = n2
+      head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, z, q, hd);
+    }
+
+    // ---------------- loss + dhead (per batch row; the 4 lanes of a row compute identically) --------
+    float dh[NO];
+#pragma unroll
+    for (int c = 0; c < NO; ++c) dh[c] = 0.f;
+    const float active = valid ? REC(A.o_am) : 0.f;
+    if (HEAD == ORL_HEAD_VALUE) {
+      const float w = valid ? (hp.use_value_active_masks ? active : 1.f) : 0.f;
+      const float v = hd[0];
+      const float vp = valid ? REC(A.o_vp) : 0.f;
+      float rt = valid ? REC(A.o_rt) : 0.f;
+      if (hp.use_valuenorm) rt = (rt - vn_mean) / vn_sd;
+      // cal_value_loss (ppo.py:178-220)
+      const float dv = v - vp;
+      const float dvc = fminf(fmaxf(dv, -hp.clip_param), hp.clip_param);
+      const bool inside = (dv >= -hp.clip_param) && (dv <= hp.clip_param);
+      const float e_c = rt - (vp + dvc);
+      const float e_o = rt - v;
+      float de_c, de_o;
+      const float l_c = huber_or_mse(e_c, hp.huber_delta, hp.use_huber_loss, de_c);
+      const float l_o = huber_or_mse(e_o, hp.huber_delta, hp.use_huber_loss, de_o);
+      float vl, g;  // g = d vl / d v
+      if (hp.use_clipped_value_loss) {
+        vl = fmaxf(l_o, l_c);
+        if (l_o > l_c) g = -de_o;
+        else if (l_o < l_c) g = inside ? -de_c : 0.f;
+        else g = -0.5f * de_o + (inside ? -0.5f * de_c : 0.f);  // torch.max splits ties
+      } else {
+        vl = l_o;
+        g = -de_o;
+      }
+      dh[0] = w * g * hp.value_loss_coef;
+      if (q == 0 && valid) { st_active += active; st_rows += 1.f; st_loss += vl * w; }
+    } else {
+      const float w = valid ? (hp.use_policy_active_masks ? active : 1.f) : 0.f;
+      const float adv = valid ? REC(A.o_adv) : 0.f;
+      if (HEAD == ORL_HEAD_CATEGORICAL) {
+        float mk[NO];  // action mask of this row (1 = legal)
+#pragma unroll
+        for (int c = 0; c < NO; ++c) mk[c] = (A.K > 0 && valid && c < n_out) ? REC(A.o_mk + c) : 1.f;
+        const float lse = cat_lse<NO>(hd, n_out, mk);
+        const int act = valid ? (int)REC(A.o_act) : 0;
+        const float old_lp = valid ? REC(A.o_lp) : 0.f;
+        const float lp = pick<NO>(hd, act) - lse;
+        float ent = 0.f;
+        float p[NO];
+#pragma unroll
+        for (int c = 0; c < NO; ++c) {
+          p[c] = 0.f;
+          if (c < n_out) {
+            const float ell = hd[c] - lse;
+            p[c] = expf(ell);
+            ent -= p[c] * ell;
+          }
+        }
+        float ratio = expf(lp - old_lp);
+        const float ratio_raw = ratio;
+        float dr_eff = 1.f;
+        if (hp.dual_clip_ppo) {
+          if (ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }
+        }
+        const float s1 = ratio * adv;
+        const float s2 = fminf(fmaxf(ratio, 1.f - hp.clip_param), 1.f + hp.clip_param) * adv;
+        const float surr = fminf(s1, s2);
+        const float dsurr_dr = (s1 <= s2) ? adv : 0.f;
+        const float gl = -dsurr_dr * dr_eff * ratio_raw;  // d(-surr)/d logp
+#pragma unroll
+        for (int c = 0; c < NO; ++c) {
+          if (c < n_out) {
+            const bool masked = mk[c] == 0.f;
+            const float ell = hd[c] - lse;
+            const float d = gl * ((c == act ? 1.f : 0.f) - p[c]) + hp.entropy_coef * p[c] * (ell + ent);
+            dh[c] = masked ? 0.f : w * d;
+          }
+        }
+        if (q == 0 && valid) {
+          st_active += active; st_rows += 1.f; st_loss += -surr * w; st_ent += ent * w; st_ratio += ratio;
+        }
+      } else {
+        // DiagGaussian, everything per action dimension (distributions.py:34-43, ppo.py:302-317)
+        const float ent_scale = hp.use_policy_active_masks ? 1.f : 1.f / (float)n_out;
+        float surr_sum = 0.f, ent_sum = 0.f, ratio_sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NO; ++c) {
+          if (c < n_out) {
+            const float ls = lw[tw.logstd + c];
+            const float sd = expf(ls);
+            const float av = valid ? REC(A.o_act + c) : 0.f;
+            const float old_lp = valid ? REC(A.o_lp + c) : 0.f;
+            const float dmu = av - hd[c];
+            const float var = sd * sd;
+            const float lp = -(dmu * dmu) / (2.f * var) - ls - 0.91893853320467274178f;
+            float ratio = expf(lp - old_lp);
+            const float ratio_raw = ratio;
+            float dr_eff = 1.f;
+            if (hp.dual_clip_ppo && ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }
+            const float s1 = ratio * adv;
+            const float s2 = fminf(fmaxf(ratio, 1.f - hp.clip_param), 1.f + hp.clip_param) * adv;
+            surr_sum += fminf(s1, s2);
+            const float gl = -((s1 <= s2) ? adv : 0.f) * dr_eff * ratio_raw;
+            dh[c] = w * gl * dmu / var;
+            // dlogstd contribution of this row, column-summed through DH right below
+            const float dls = w * (gl * (dmu * dmu / var - 1.f) - hp.entropy_coef * ent_scale);
+            if (q == 1) DH[j * NOP + c] = dls;
+            ent_sum += 1.41893853320467274178f + ls;
+            ratio_sum += ratio;
+          }
+        }
+        if (q == 0 && valid) {
+          st_active += active; st_rows += 1.f; st_loss += -surr_sum * w; st_ent += ent_sum * w;
+          st_ratio += ratio_sum;
+        }
+        wave_lds_fence();
+        if (l < n_out) {
+          float s = 0.f;
+          for (int r = 0; r < TILE_B; ++r) s += DH[r * NOP + l];
+          a_dls += s;
+        }
+        wave_lds_fence();
+      }
+    }
+
+    // ---------------- backward ----------------
+    // S3 += dhead^T xhat2, db3 (F layout: lane = feature f); xhat2 goes through the scratch slab
+    store_slab_T(SS, xh2, j, q);
+    if (q == 0) {
+#pragma unroll
+      for (int c = 0; c < NO; ++c) DH[j * NOP + c] = dh[c];
+    }
+    wave_lds_fence();
+    {
+      const int f = l;
+      float s3[NO];
+#pragma unroll
+      for (int c = 0; c < NO; ++c) s3[c] = 0.f;
+      float s_db3 = 0.f;
+      for (int r = 0; r < TILE_B; ++r) {
+        const float xh = SS[r * TS + f];
+#pragma unroll
+        for (int c = 0; c < NO; ++c) s3[c] += DH[r * NOP + c] * xh;
+        s_db3 += DH[r * NOP + (f < NO ? f : 0)];
+      }
+#pragma unroll
+      for (int c = 0; c < NO; ++c) a_S3[c] += s3[c];
+      a_db3 += s_db3;
+    }
+    // dn2 = W3^T dhead (T layout), LN2 backward -> dz2
+    f32x4 d2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) d2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NO; ++c) {
+      if (c < n_out) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) d2[m] += *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q) * dh[c];
+      }
+    }
+    ln_bwd_T(d2, xh2, lw + tw.g2, rstd2, q);
+    wave_lds_fence();
+    store_slab_T(SS, d2, j, q);
+    wave_lds_fence();
+    // wgrad: G += dz2^T xhat1 (operands straight from the slabs in F layout), db2
+    {
+      float s_db = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          av[m] = SS[(4 * s + q) * TS + 16 * m + j];
+          bv[m] = X1[(4 * s + q) * TS + 16 * m + j];
+        }
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) G[mo][mi] = ORL_MFMA(av[mo], bv[mi], G[mo][mi]);
+      }
+      const int f = l;
+      for (int r = 0; r < TILE_B; ++r) s_db += SS[r * TS + f];
+      a_db2 += s_db;
+    }
+    // dgrad: dn1 = W2^T dz2, LN1 backward, relu backward -> dz1
+    f32x4 d1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mm64_T_wt(lw + tw.W2, d2, d1, j, q);
+    {
+      f32x4 xh1[4];
+      load_slab_T(X1, xh1, j, q);
+      ln_bwd_T(d1, xh1, lw + tw.g1, rstd1, q);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (!((relu_bits >> (4 * m + r)) & 1u)) d1[m][r] = 0.f;
+    wave_lds_fence();
+    store_slab_T(SS, d1, j, q);
+    wave_lds_fence();
+    // dW1 += dz1^T x, db1
+    {
+      const int f = l;
+      float s_db = 0.f;
+      if (ND == 0) {
+        for (int r = 0; r < TILE_B; ++r) {
+          const float dzv = SS[r * TS + f];
+          const f32x4 xv = *(const f32x4*)(&REC_R(r, A.o_x));  // o_x % 4 == 0 on this path
+          s_db += dzv;
+          w1v[0] += dzv * xv[0]; w1v[1] += dzv * xv[1]; w1v[2] += dzv * xv[2]; w1v[3] += dzv * xv[3];
+        }
+      } else {
+        for (int r = 0; r < TILE_B; ++r) s_db += SS[r * TS + f];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float av[4], bv[NDA];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) av[m] = SS[(4 * s + q) * TS + 16 * m + j];
+#pragma unroll
+          for (int mk = 0; mk < NDA; ++mk) bv[mk] = (16 * mk + j < D) ? REC_R(4 * s + q, A.o_x + 16 * mk + j) : 0.f;
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int mk = 0; mk < NDA; ++mk) G1[mf][mk] = ORL_MFMA(av[mf], bv[mk], G1[mf][mk]);
+        }
+      }
+      a_db1 += s_db;
+    }
+    wave_lds_fence();
+  }
+#undef REC
+#undef REC_R
+
+  // ---- workgroup reduction of the waves' accumulators, fixed order (deterministic) ---------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before LDS is reused
+  __syncthreads();
+  float* acc = smem + tw.total;  // reuse the slab area: [rl.total + ORL_N_STATS]
+  const int PW = rl.total + ORL_N_STATS;
+  for (int e = threadIdx.x; e < PW; e += blockDim.x) acc[e] = 0.f;
+  __syncthreads();
+  st_active = wave_sum(st_active); st_rows = wave_sum(st_rows); st_loss = wave_sum(st_loss);
+  st_ent = wave_sum(st_ent); st_ratio = wave_sum(st_ratio);
+  for (int w = 0; w < nwv; ++w) {
+    if (wave == w) {
+      // G tiles: lane (c = j, q), reg r -> G[o = 16mo+4q+r][i = 16mi+c]
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j] += G[mo][mi][r];
+      const int f = l;
+      acc[rl.odb2 + f] += a_db2;
+      acc[rl.odb1 + f] += a_db1;
+#pragma unroll
+      for (int c = 0; c < NO; ++c)
+        if (c < n_out) acc[rl.oS3 + c * HID + f] += a_S3[c];
+      if (f < n_out) acc[rl.odb3 + f] += a_db3;
+      if (HEAD == ORL_HEAD_GAUSSIAN && f < n_out) acc[rl.odlogstd + f] += a_dls;
+      if (ND == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < D) acc[rl.odW1 + f * D + k] += w1v[k];
+      } else {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+          for (int mk = 0; mk < NDA; ++mk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kk = 16 * mk + j;
+              if (kk < D) acc[rl.odW1 + (16 * mf + 4 * q + r) * D + kk] += G1[mf][mk][r];
+            }
+      }
+      if (l == 0) {
+        acc[rl.total + ST_ACTIVE_SUM] += st_active;
+        acc[rl.total + ST_ROWS] += st_rows;
+        if (HEAD == ORL_HEAD_VALUE) acc[rl.total + ST_VLOSS_SUM] += st_loss;
+        else {
+          acc[rl.total + ST_PLOSS_SUM] += st_loss;
+          acc[rl.total + ST_ENT_SUM] += st_ent;
+          acc[rl.total + ST_RATIO_SUM] += st_ratio;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = A.partials + (size_t)blockIdx.x * PW;
+  for (int e = threadIdx.x; e < PW; e += blockDim.x) out[e] = acc[e];
+}
+
+// LDS bytes needed by `waves` waves of this tower
+inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian) {
+  const TowerLds tw(net.obs_dim, net.n_out, gaussian, false);
+  const RawLayout rl(net);
+  const int rts = (((R >> 2) + 3) >> 2) * 256;
+  const size_t per_wave = 2 * SLAB + 2 * rts + TILE_B * nop;
+  size_t fl = (size_t)tw.total + (size_t)waves * per_wave;
+  const size_t need_acc = (size_t)tw.total + rl.total + ORL_N_STATS;
+  return fl > need_acc ? fl : need_acc;
+}
+
+}  // namespace orl

@@ -146,14 +146,15 @@ def act_step(pnet: NetDesc, ptheta, cnet: Optional[NetDesc], ctheta, policy_obs,
 
 
 # ------------------------------------------------------------------------------------------------ K9-K14
-def ppo_fwd_bwd(pnet, ptheta, cnet, ctheta, records, idx, mb: int, vn_state, hp: PPOHParams, partials) -> int:
+def ppo_fwd_bwd(pnet, ptheta, cnet, ctheta, records, idx, mb: int, vn_state, hp: PPOHParams, partials):
+    """Returns (policy workgroups, critic workgroups) = rows of the two partial regions."""
     dev = _dev(records)
-    nb = C.c_int(0)
+    nb = (C.c_int * 2)(0, 0)
     rc = _lib().orl_ppo_fwd_bwd(C.byref(pnet), fptr(ptheta), C.byref(cnet), fptr(ctheta), fptr(records),
                                 records.shape[1], ptr(idx), mb, fptr(vn_state), C.byref(hp), fptr(partials),
-                                C.byref(nb), stream_ptr(dev))
+                                nb, stream_ptr(dev))
     nat.check(rc, "orl_ppo_fwd_bwd")
-    return nb.value
+    return nb[0], nb[1]
 
 
 def ppo_reduce(partials_ptr: int, n_blocks: int, width: int, sums_ptr: int, dev) -> None:
