@@ -64,7 +64,11 @@ class _YamlConfigAction(argparse.Action):
             text = jinja2.Template(text).render(**head["globals"])
         data = yaml.safe_load(text) or {}
         data.pop("globals", None)
+        types = {a.dest: a.type for a in parser._actions if a.type is not None}
         for k, v in _flatten(data).items():
+            conv = types.get(k)
+            if conv is not None and isinstance(v, (str, int, float, bool)) and v is not None:
+                v = conv(v)  # e.g. YAML 1.1 reads "7e-4" as a string
             setattr(namespace, k, v)
         setattr(namespace, self.dest, values)
 

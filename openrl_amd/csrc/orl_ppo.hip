@@ -181,19 +181,21 @@ static int launch_tower_w(const PpoArgs& A, int waves, size_t lds, hipStream_t s
 template <int HEAD, int NO, int ND>
 static int launch_tower(const PpoArgs& A, hipStream_t s) {
   constexpr int NOP = (NO + 3) & ~3;
-  // as many waves per workgroup (12, 8, 6, 4, 2) as fit the 160 KiB of LDS next to the tower's weights
-  static const int kWaves[5] = {12, 8, 6, 4, 2};
-  static const int max_waves = []() {  // tuning knob for A/B runs: ORL_PPO_WAVES=8 caps the workgroup size
+  // as many waves per workgroup (8, 6, 4, 2) as fit the 160 KiB of LDS next to the tower's weights.
+  // 12 waves (3 per SIMD, <= 168 VGPRs) fit the LDS budget too but were measured SLOWER on MI355X
+  // (5.94 vs 5.21 ms per iteration): at 168 VGPRs hipcc spills 260 B per lane around the 64 wgrad
+  // accumulators, so the kernel is built for 2 waves per SIMD.
+  static const int kWaves[4] = {8, 6, 4, 2};
+  static const int max_waves = []() {  // tuning knob for A/B runs: ORL_PPO_WAVES=4 caps the workgroup size
     const char* e = getenv("ORL_PPO_WAVES");
-    return e ? atoi(e) : 12;
+    return e ? atoi(e) : 8;
   }();
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < 4; ++k) {
     const int waves = kWaves[k];
     if (waves > max_waves) continue;
     const size_t lds = tower_lds_floats(A.net, A.R, NOP, waves, HEAD == ORL_HEAD_GAUSSIAN) * sizeof(float);
     if (lds > 160 * 1024) continue;
-    const int grid = waves == 12 ? launch_tower_w<HEAD, NO, ND, 3>(A, waves, lds, s)
-                                 : launch_tower_w<HEAD, NO, ND, 2>(A, waves, lds, s);
+    const int grid = launch_tower_w<HEAD, NO, ND, 2>(A, waves, lds, s);
     const int rc = launch_status("orl_ppo_fwd_bwd");
     return rc ? -1000 - rc : grid;
   }

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
   };
   auto issue_dma = [&](float* slot, long long row) {
     const float* src = A.records + (size_t)row * A.R;
+#pragma unroll 1
     for (int g = 0; 4 * g < nch; ++g) {
       const int c = 4 * g + q;
       if (c < nch)
@@ -197,12 +198,11 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
 #define REC_R(r, col) RT[(((col) >> 2) << 6) + ((r) << 2) + ((col) & 3)]
 
     // ---------------- forward ----------------
-    f32x4 xh2[4];
     float rstd1, rstd2;
     unsigned relu_bits = 0u;
     float hd[NO];
     {
-      f32x4 z[4], n1[4];
+      f32x4 z[4], n1[4], xh2[4];
       load_vec_T(lw + tw.b1, q, z);
       // columns >= D of a record are other (finite) fields; W1's LDS image is zero-padded there
       fc1_T(lw + tw.W1, DP, [&](int s) -> float { return REC(A.o_x + 4 * s + q); }, z, j, q);
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       load_vec_T(lw + tw.b2, q, xh2);
       mm64_T(lw + tw.W2, n1, xh2, j, q);
       ln_normalize_T(xh2, rstd2);
+      store_slab_T(SS, xh2, j, q);  // parked in the scratch slab: read back in F layout (S3) and T layout (LN2')
       ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, z);  // z = n2
       head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, z, q, hd);
     }
@@ -345,8 +346,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     }
 
     // ---------------- backward ----------------
-    // S3 += dhead^T xhat2, db3 (F layout: lane = feature f); xhat2 goes through the scratch slab
-    store_slab_T(SS, xh2, j, q);
+    // S3 += dhead^T xhat2, db3 (F layout: lane = feature f); xhat2 comes from the scratch slab
     if (q == 0) {
 #pragma unroll
       for (int c = 0; c < NO; ++c) DH[j * NOP + c] = dh[c];
@@ -379,7 +379,11 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
         for (int m = 0; m < 4; ++m) d2[m] += *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q) * dh[c];
       }
     }
-    ln_bwd_T(d2, xh2, lw + tw.g2, rstd2, q);
+    {
+      f32x4 xh2[4];
+      load_slab_T(SS, xh2, j, q);
+      ln_bwd_T(d2, xh2, lw + tw.g2, rstd2, q);
+    }
     wave_lds_fence();
     store_slab_T(SS, d2, j, q);
     wave_lds_fence();
@@ -407,7 +411,11 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     f32x4 d1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mm64_T_wt(lw + tw.W2, d2, d1, j, q);
+    {
+      f32x4 dz2[4];  // re-read from the slab (T layout) instead of keeping 16 VGPRs live across the wgrad block
+      load_slab_T(SS, dz2, j, q);
+      mm64_T_wt(lw + tw.W2, dz2, d1, j, q);
+    }
     {
       f32x4 xh1[4];
       load_slab_T(X1, xh1, j, q);
