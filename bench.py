@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--perm", default="device", choices=["device", "reference"],
                     help="minibatch permutation source; 'reference' = host torch.randperm (bit-exact stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rollout-len", type=int, default=128, help="rollout length of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
     from openrl_amd import distributed as du
@@ -124,9 +124,15 @@ def main():
     achieved_tf = flops_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     gae_ms = sum(a.elapsed_time(b) for a, b in gae_events) / max(len(gae_events), 1)
     gae_bytes = 16 * M  # S_gae: 3 reads + 1 write per sample
+    traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_hbm.json)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
+            traffic = json.load(fh)["orl_ppo_fwd_bwd_pair"]["hbm_bytes_per_launch_raw"]
+    except Exception:
+        pass
     roofline = {"kernel": "orl_ppo_fwd_bwd (ppo_tower_kernel policy+critic)", "bound": "mfma",
                 "achieved": round(achieved_tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launch_ms": round(k_ms, 4), "launches_timed": len(ev),
                 "flops_per_launch": flops_per_launch,
                 "gae_scan": {"bound": "hbm", "achieved": round(gae_bytes / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else 0,
@@ -144,15 +150,15 @@ def main():
            "roofline": roofline}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.cpu_trainer import time_cpu_baseline
+        from oracle.cpu_trainer import time_cpu_baseline_bounded
 
-        cb = time_cpu_baseline(n_envs=N_ENVS, T=args.cpu_rollout_len, ppo_epoch=PPO_EPOCH, iters=1)
+        cb = time_cpu_baseline_bounded(n_envs=N_ENVS, ppo_epoch=PPO_EPOCH, target_seconds=args.cpu_seconds)
         out["cpu_baseline"] = {"value": round(cb["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": cb["cores"],
                                "kind": "port",
-                               "sample": "1 iteration: %d envs x %d-step rollout + %d epochs (%.1f s; act %.1f s, "
-                                         "insert %.1f s, update %.1f s)" % (N_ENVS, args.cpu_rollout_len, PPO_EPOCH,
-                                                                           cb["seconds"], cb["phase_act"],
-                                                                           cb["phase_insert"], cb["phase_update"])}
+                               "sample": "1 iteration of the oracle port: %d envs x %d-step rollout + %d full-batch "
+                                         "epochs (%.1f s; act %.1f s, insert %.1f s, update %.1f s)"
+                                         % (N_ENVS, cb["T"], PPO_EPOCH, cb["seconds"], cb["phase_act"],
+                                            cb["phase_insert"], cb["phase_update"])}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -40,6 +40,9 @@ def prepare_action_masks(infos, agent_num: int):
 
 
 class OnPolicyDriver:
+    #: the buffer this driver works on (device-resident); see INTEGRATION.md section 2
+    from ..buffers import NormalReplayBuffer as buffer_class
+
     def __init__(self, config: Dict[str, Any], trainer, buffer, agent, rank: int = 0, world_size: int = 1, client=None,
                  logger: Optional[Logger] = None, callback=None) -> None:
         self.trainer = trainer

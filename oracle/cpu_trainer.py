@@ -172,6 +172,23 @@ class CPUTrainer:
         return self.update()
 
 
+def time_cpu_baseline_bounded(n_envs=4096, ppo_epoch=10, target_seconds=15.0, max_threads=16) -> Dict[str, float]:
+    """Bounded CPU sample for bench.py: a short probe (T=8) sizes the rollout length T in {8,...,128} so that
+    one iteration (T-step rollout of ``n_envs`` + ``ppo_epoch`` full-batch epochs) takes about
+    ``target_seconds``.  Threads are capped: with hundreds of host cores torch's intra-op pool makes these
+    small ops SLOWER (measured 900 env-steps/s at 256 threads vs 2.9e4 at 8)."""
+    import os
+
+    threads = max(1, min(os.cpu_count() or 1, max_threads))
+    probe = time_cpu_baseline(n_envs=n_envs, T=8, ppo_epoch=ppo_epoch, iters=1, threads=threads)
+    T = 8
+    while T < 128 and probe["seconds"] * (2 * T / 8.0) <= target_seconds:
+        T *= 2
+    res = probe if T == 8 else time_cpu_baseline(n_envs=n_envs, T=T, ppo_epoch=ppo_epoch, iters=1, threads=threads)
+    res["T"] = T
+    return res
+
+
 def time_cpu_baseline(n_envs=4096, T=16, ppo_epoch=10, iters=1, warmup=0, threads=None) -> Dict[str, float]:
     """Bounded sample of the cfg-2 workload: ``iters`` iterations of (T-step rollout of n_envs + ppo_epoch
     full-batch epochs).  Returns env-steps/s and the per-phase split."""
