@@ -35,9 +35,11 @@ def init_from_env(backend: str = None) -> int:
     """Initialise from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*); returns local rank."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        lr = lr % torch.cuda.device_count()  # several ranks may share one GPU in tests (gloo backend)
     if ws > 1 and not is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("ORL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(lr)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
