@@ -238,6 +238,10 @@ typedef struct orl_adam_state {
 } orl_adam_state;
 
 int orl_ppo_reduce(const float* partials, int n_blocks, int width, float* sums, void* stream);
+/* Same, both regions of an orl_ppo_fwd_bwd `partials` buffer in ONE launch:
+ * sums[0 .. width_policy) <- policy region, sums[width_policy .. +width_critic) <- critic region. */
+int orl_ppo_reduce_pair(const float* partials, int n_blocks_policy, int width_policy, int n_blocks_critic,
+                        int width_critic, float* sums, void* stream);
 int orl_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums,
                   const orl_ppo_hparams* hp, const orl_adam_state* padam, const orl_adam_state* cadam,
                   float* train_info_accum, void* stream);

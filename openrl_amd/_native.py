@@ -94,6 +94,7 @@ _SIGNATURES = {
     "orl_ppo_fwd_bwd": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, C.c_int, _P, C.c_int, _P,
                                   C.POINTER(PPOHParams), _P, C.POINTER(C.c_int), _P]),
     "orl_ppo_reduce": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "orl_ppo_reduce_pair": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "orl_ppo_apply": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
                                 C.POINTER(AdamState), C.POINTER(AdamState), _P, _P]),
     "orl_valuenorm_update": (C.c_int, [_P, _P, C.c_double, _P]),

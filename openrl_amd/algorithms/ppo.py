@@ -100,11 +100,7 @@ class PPOAlgorithm(BaseAlgorithm):
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
-        base = self._partials.data_ptr()
-        sums = self._sums.data_ptr()
-        ops.ppo_reduce(base, nb_p, self._raw_p, sums, self.device)
-        ops.ppo_reduce(base + 4 * ops.ppo_max_blocks() * self._raw_p, nb_c, self._raw_c, sums + 4 * self._raw_p,
-                       self.device)
+        ops.ppo_reduce_pair(self._partials, nb_p, self._raw_p, nb_c, self._raw_c, self._sums)
         if self.world_size > 1:
             dist_utils.allreduce_(self._sums)  # ONE small collective per optimiser step
         po.step_count += 1 if turn_on else 0

@@ -231,8 +231,48 @@ struct RolloutArgs {
   float* next_value;  // [N] bootstrap value of slot T (may be NULL)
 };
 
+// Trunk forward of ONE 16-row tile split over the 4 waves of a tower group: wave `gw` owns M-tile gw (16 of the
+// 64 hidden features) of both GEMMs, the pre-LayerNorm activations are all-gathered through LDS (one
+// workgroup barrier each), and every wave then normalises the full tile itself, so the result in each wave is
+// bit-identical to trunk_fwd_T (same k order per output element).  Per step this shortens the dependent MFMA
+// chain from 68 to 17 instructions: the rollout is a latency problem (one 16-env tile per 8-wave workgroup),
+// not a throughput one.  Every wave of the workgroup must call this the same number of times (barriers).
+constexpr int GS = 68;  // gather-slab row stride (floats)
+template <class XB>
+__device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const TowerLds& tw, XB xb, float* __restrict__ gA,
+                                      float* __restrict__ gB, int gw, int j, int q, f32x4 (&n2)[4]) {
+  f32x4 acc = *(const f32x4*)(lds + tw.b1 + 16 * gw + 4 * q);
+  for (int s = 0; s < (tw.DP >> 2); ++s) {
+    const float a = lds[tw.W1 + (16 * gw + j) * tw.DP + 4 * s + q];
+    acc = ORL_MFMA(a, xb(s), acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+  *(f32x4*)(gA + j * GS + 16 * gw + 4 * q) = acc;
+  __syncthreads();
+  f32x4 x[4], n1[4];
+  float rstd;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(gA + j * GS + 16 * m + 4 * q);
+  ln_normalize_T(x, rstd);
+  ln_affine_T(x, lds + tw.g1, lds + tw.be1, q, n1);
+  acc = *(const f32x4*)(lds + tw.b2 + 16 * gw + 4 * q);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const f32x4 a4 = *(const f32x4*)(lds + tw.W2 + (16 * gw + j) * W2S + 16 * mi + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = ORL_MFMA(a4[r], n1[mi][r], acc);
+  }
+  *(f32x4*)(gB + j * GS + 16 * gw + 4 * q) = acc;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(gB + j * GS + 16 * m + 4 * q);
+  ln_normalize_T(x, rstd);
+  ln_affine_T(x, lds + tw.g2, lds + tw.be2, q, n2);
+}
+
 template <int NO, int HEAD, int ENV>
-__global__ __launch_bounds__(128) void rollout_kernel(RolloutArgs A) {
+__global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const orl_buffer_ptrs& b = A.r.buf;
   const int D = A.pnet.obs_dim;
@@ -244,8 +284,15 @@ __global__ __launch_bounds__(128) void rollout_kernel(RolloutArgs A) {
   stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x);
   const int DP = twp.DP;
   float* s_obs = smem + twp.total + twc.total;  // [2][16][DP]
+  float* s_gather = s_obs + 2 * TILE_B * DP;    // [2 towers][2 slabs][16][GS]
 
+  // waves 0-3: policy tower (wave 0 also samples and steps the env); waves 4-7: critic tower
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int grp = wave >> 2, gw = wave & 3;
+  const float* tlds = grp == 0 ? smem : smem + twp.total;
+  const TowerLds& tww = grp == 0 ? twp : twc;
+  float* gA = s_gather + grp * 2 * TILE_B * GS;
+  float* gB = gA + TILE_B * GS;
   const int n = blockIdx.x * TILE_B + j;
   const bool ok = n < N;
   const int n_out = A.pnet.n_out;
@@ -275,9 +322,9 @@ __global__ __launch_bounds__(128) void rollout_kernel(RolloutArgs A) {
     float* nxt = s_obs + ((t + 1) & 1) * TILE_B * DP;
     auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
     const uint64_t tg = A.r.rng_step0 + (uint64_t)t;
+    f32x4 n2[4];
+    trunk_fwd_coop(tlds, tww, xb, gA, gB, gw, j, q, n2);
     if (wave == 0) {
-      f32x4 n2[4];
-      trunk_fwd_T(smem, twp, xb, j, q, n2);
       float hd[NO];
       head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);
       float act_o[NO], lp_o[NO];
@@ -357,26 +404,27 @@ __global__ __launch_bounds__(128) void rollout_kernel(RolloutArgs A) {
       if (b.action_masks != nullptr && ok && q == 0) {
         for (int c = 0; c < b.K; ++c) b.action_masks[s1 * b.K + c] = 1.f;
       }
-    } else {
-      f32x4 n2[4];
+    } else if (wave == 4) {
       const float* lc = smem + twp.total;
-      trunk_fwd_T(lc, twc, xb, j, q, n2);
       float v[1];
       head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
       if (ok && q == 0) A.r.value_preds[(size_t)t * N + n] = v[0];
     }
     __syncthreads();
   }
-  // bootstrap value of the last observation (OnPolicyDriver.compute_returns, onpolicy_driver.py:205-233)
-  if (wave == 1 && A.next_value != nullptr) {
+  // bootstrap value of the last observation (OnPolicyDriver.compute_returns, onpolicy_driver.py:205-233);
+  // all waves walk the cooperative trunk once more (barriers), only the critic leader uses the result
+  if (A.next_value != nullptr) {
     const float* cur = s_obs + (T & 1) * TILE_B * DP;
     auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
     f32x4 n2[4];
-    const float* lc = smem + twp.total;
-    trunk_fwd_T(lc, twc, xb, j, q, n2);
-    float v[1];
-    head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
-    if (ok && q == 0) A.next_value[n] = v[0];
+    trunk_fwd_coop(tlds, tww, xb, gA, gB, gw, j, q, n2);
+    if (wave == 4) {
+      const float* lc = smem + twp.total;
+      float v[1];
+      head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
+      if (ok && q == 0) A.next_value[n] = v[0];
+    }
   }
   if (wave == 0 && q == 0 && ok) {
 #pragma unroll
@@ -569,7 +617,7 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
                 "orl_rollout_fused: CartPole needs Discrete(2) and 4-d obs");
   const TowerLds twp(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false);
   const TowerLds twc(cnet->obs_dim, 1, false, false);
-  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP) * sizeof(float);
+  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP + 4 * TILE_B * GS) * sizeof(float);
   ORL_REQUIRE(lds <= 160 * 1024, "orl_rollout_fused: needs %zu B of LDS", lds);
   RolloutArgs A;
   A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.r = *args; A.next_value = next_value;
@@ -579,7 +627,7 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
     if (lds > 48 * 1024)                                                                                            \
       (void)hipFuncSetAttribute((const void*)rollout_kernel<NO, HD, EV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                          \
-    hipLaunchKernelGGL((rollout_kernel<NO, HD, EV>), dim3(grid), dim3(128), lds, (hipStream_t)stream, A);          \
+    hipLaunchKernelGGL((rollout_kernel<NO, HD, EV>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A);          \
   } while (0)
   if (args->env_kind == ORL_ENV_SYNTH) {
 #define ORL_RO_LAUNCH(NO, HD) ORL_RO_LAUNCH2(NO, HD, ORL_ENV_SYNTH)

@@ -87,8 +87,11 @@ __device__ inline float raw_to_grad(const float* __restrict__ raw, const float* 
   return g * inv_den;
 }
 
+// One workgroup per tower (blockIdx.x = 0 policy, 1 critic).  The tower's raw sums and parameters are
+// staged in LDS first so the 64-term LayerNorm-affine dot products of raw_to_grad run out of LDS.
 __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTower Cc, const float* __restrict__ sums,
                                                          orl_ppo_hparams hp, float* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) float s_apply[];
   __shared__ float sh[16];
   const TowerLayout tlp(P.net), tlc(Cc.net);
   const RawLayout rlp(P.net), rlc(Cc.net);
@@ -98,22 +101,35 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
   const float* stc = rawc + rlc.total;
   const float den_p = hp.use_policy_active_masks ? stp[ST_ACTIVE_SUM] : stp[ST_ROWS];
   const float den_v = hp.use_value_active_masks ? stc[ST_ACTIVE_SUM] : stc[ST_ROWS];
-  float norms[2];
-  for (int t = 0; t < 2; ++t) {
+  float norms[2] = {0.f, 0.f};
+  {
+    const int t = blockIdx.x;
     const ApplyTower& W = t == 0 ? P : Cc;
     const TowerLayout& tl = t == 0 ? tlp : tlc;
     const RawLayout& rl = t == 0 ? rlp : rlc;
-    const float* raw = t == 0 ? rawp : rawc;
+    const float* raw_g = t == 0 ? rawp : rawc;
     const float inv_den = 1.0f / (t == 0 ? den_p : den_v);
     if (t == 0 && (hp.reserved & 1)) {
       // turn_on == False: the policy loss is not in the loss list (ppo.py:226-236) -> no gradient, no step
       for (int p = threadIdx.x; p < tl.total; p += blockDim.x) W.ad.grad[p] = 0.f;
-      norms[0] = 0.f;
-      continue;
+      if (threadIdx.x == 0 && info != nullptr) {
+        info[1] += stp[ST_PLOSS_SUM] / den_p;
+        float ent_den0 = den_p;
+        if (!hp.use_policy_active_masks && P.net.head_kind == ORL_HEAD_GAUSSIAN) ent_den0 = den_p * (float)P.net.n_out;
+        info[2] += stp[ST_ENT_SUM] / ent_den0;
+        const float aw0 = P.net.head_kind == ORL_HEAD_GAUSSIAN ? (float)P.net.n_out : 1.f;
+        info[5] += stp[ST_RATIO_SUM] / (stp[ST_ROWS] * aw0);
+      }
+      return;
     }
+    float* raw = s_apply;
+    float* th_s = s_apply + rl.total;
+    for (int e = threadIdx.x; e < rl.total; e += blockDim.x) raw[e] = raw_g[e];
+    for (int e = threadIdx.x; e < tl.total; e += blockDim.x) th_s[e] = W.ad.theta[e];
+    __syncthreads();
     float ss = 0.f;
     for (int p = threadIdx.x; p < tl.total; p += blockDim.x) {
-      float g = raw_to_grad(raw, W.ad.theta, tl, rl, p, inv_den);
+      float g = raw_to_grad(raw, th_s, tl, rl, p, inv_den);
       W.ad.grad[p] = g;
       ss += g * g;
     }
@@ -142,20 +158,47 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
       th = th - step_size * (m / denom);
       W.ad.m[p] = m; W.ad.v[p] = v; W.ad.theta[p] = th;
     }
-    __syncthreads();
   }
   if (threadIdx.x == 0 && info != nullptr) {
-    const float ploss = stp[ST_PLOSS_SUM] / den_p;
-    float ent_den = den_p;
-    if (!hp.use_policy_active_masks && P.net.head_kind == ORL_HEAD_GAUSSIAN) ent_den = den_p * (float)P.net.n_out;
-    info[0] += stc[ST_VLOSS_SUM] / den_v;                 // value_loss
-    info[1] += ploss;                                     // policy_loss
-    info[2] += stp[ST_ENT_SUM] / ent_den;                 // dist_entropy
-    info[3] += norms[0];                                  // actor_grad_norm
-    info[4] += norms[1];                                  // critic_grad_norm
-    const float a_w = P.net.head_kind == ORL_HEAD_GAUSSIAN ? (float)P.net.n_out : 1.f;
-    info[5] += stp[ST_RATIO_SUM] / (stp[ST_ROWS] * a_w);  // ratio.mean()
+    if (blockIdx.x == 0) {
+      float ent_den = den_p;
+      if (!hp.use_policy_active_masks && P.net.head_kind == ORL_HEAD_GAUSSIAN) ent_den = den_p * (float)P.net.n_out;
+      info[1] += stp[ST_PLOSS_SUM] / den_p;                 // policy_loss
+      info[2] += stp[ST_ENT_SUM] / ent_den;                 // dist_entropy
+      info[3] += norms[0];                                  // actor_grad_norm
+      const float a_w = P.net.head_kind == ORL_HEAD_GAUSSIAN ? (float)P.net.n_out : 1.f;
+      info[5] += stp[ST_RATIO_SUM] / (stp[ST_ROWS] * a_w);  // ratio.mean()
+    } else {
+      info[0] += stc[ST_VLOSS_SUM] / den_v;                 // value_loss
+      info[4] += norms[1];                                  // critic_grad_norm
+    }
   }
+}
+
+// both towers' partial regions in one launch: blocks [0, gp) reduce the policy region, the rest the critic's
+__global__ __launch_bounds__(256) void ppo_reduce_pair_kernel(const float* __restrict__ pp, int nb_p, int wp, int gp,
+                                                              const float* __restrict__ pc, int nb_c, int wc,
+                                                              float* __restrict__ sums) {
+  __shared__ float sh[4][64];
+  const bool pol = (int)blockIdx.x < gp;
+  const float* partials = pol ? pp : pc;
+  const int n_blocks = pol ? nb_p : nb_c, width = pol ? wp : wc;
+  float* out = pol ? sums : sums + wp;
+  const int col = (pol ? blockIdx.x : blockIdx.x - gp) * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < width) {
+    int b = rg;
+    for (; b + 4 < n_blocks; b += 8) {
+      s0 += partials[(size_t)b * width + col];
+      s1 += partials[(size_t)(b + 4) * width + col];
+    }
+    if (b < n_blocks) s0 += partials[(size_t)b * width + col];
+  }
+  sh[rg][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && col < width)
+    out[col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 static int check_tower(const orl_net_desc* n, const char* who) {
@@ -290,8 +333,24 @@ int orl_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const floa
   ApplyTower P, Cc;
   P.net = *pnet; P.ad = *padam; P.sums_off = 0;
   Cc.net = *cnet; Cc.ad = *cadam; Cc.sums_off = RawLayout(*pnet).total + ORL_N_STATS;
-  hipLaunchKernelGGL(ppo_apply_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, P, Cc, sums, *hp, train_info_accum);
+  const size_t lp = (size_t)(RawLayout(*pnet).total + TowerLayout(*pnet).total) * sizeof(float);
+  const size_t lc = (size_t)(RawLayout(*cnet).total + TowerLayout(*cnet).total) * sizeof(float);
+  const size_t lds = lp > lc ? lp : lc;
+  (void)hipFuncSetAttribute((const void*)ppo_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ppo_apply_kernel, dim3(2), dim3(1024), lds, (hipStream_t)stream, P, Cc, sums, *hp,
+                     train_info_accum);
   return launch_status("orl_ppo_apply");
+}
+
+int orl_ppo_reduce_pair(const float* partials, int n_blocks_policy, int width_policy, int n_blocks_critic,
+                        int width_critic, float* sums, void* stream) {
+  ORL_REQUIRE(partials && sums && n_blocks_policy > 0 && n_blocks_critic > 0 && width_policy > 0 && width_critic > 0,
+              "orl_ppo_reduce_pair: bad arguments");
+  const int gp = (width_policy + 63) / 64, gc = (width_critic + 63) / 64;
+  hipLaunchKernelGGL(ppo_reduce_pair_kernel, dim3(gp + gc), dim3(256), 0, (hipStream_t)stream, partials,
+                     n_blocks_policy, width_policy, gp, partials + (size_t)PPO_MAX_BLOCKS * width_policy,
+                     n_blocks_critic, width_critic, sums);
+  return launch_status("orl_ppo_reduce_pair");
 }
 
 }  // extern "C"

@@ -162,6 +162,12 @@ def ppo_reduce(partials_ptr: int, n_blocks: int, width: int, sums_ptr: int, dev)
     nat.check(rc, "orl_ppo_reduce")
 
 
+def ppo_reduce_pair(partials, nb_p: int, width_p: int, nb_c: int, width_c: int, sums) -> None:
+    dev = _dev(sums)
+    rc = _lib().orl_ppo_reduce_pair(fptr(partials), nb_p, width_p, nb_c, width_c, fptr(sums), stream_ptr(dev))
+    nat.check(rc, "orl_ppo_reduce_pair")
+
+
 def ppo_apply(pnet, cnet, sums, hp: PPOHParams, padam: AdamState, cadam: AdamState, train_info_accum) -> None:
     dev = _dev(sums)
     rc = _lib().orl_ppo_apply(C.byref(pnet), C.byref(cnet), fptr(sums), C.byref(hp), C.byref(padam), C.byref(cadam),
