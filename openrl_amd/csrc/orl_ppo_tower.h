@@ -22,6 +22,13 @@
 
 namespace orl {
 
+// A/B knob: raise the wave's issue priority around MFMA bursts (cdna guide T5).
+#ifdef ORL_USE_SETPRIO
+#define ORL_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define ORL_PRIO(x) ((void)0)
+#endif
+
 constexpr int PPO_MAX_BLOCKS = 256;  // one workgroup per CU
 constexpr int TS = 68;               // slab row stride (floats): 16-byte rows, bank-skewed
 constexpr int SLAB = TILE_B * TS;
@@ -217,7 +224,9 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       store_slab_T(X1, z, j, q);
       ln_affine_T(z, lw + tw.g1, lw + tw.be1, q, n1);
       load_vec_T(lw + tw.b2, q, xh2);
+      ORL_PRIO(1);
       mm64_T(lw + tw.W2, n1, xh2, j, q);
+      ORL_PRIO(0);
       ln_normalize_T(xh2, rstd2);
       store_slab_T(SS, xh2, j, q);  // parked in the scratch slab: read back in F layout (S3) and T layout (LN2')
       ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, z);  // z = n2
@@ -414,7 +423,9 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     {
       f32x4 dz2[4];  // re-read from the slab (T layout) instead of keeping 16 VGPRs live across the wgrad block
       load_slab_T(SS, dz2, j, q);
+      ORL_PRIO(1);
       mm64_T_wt(lw + tw.W2, dz2, d1, j, q);
+      ORL_PRIO(0);
     }
     {
       f32x4 xh1[4];
