@@ -178,6 +178,16 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
                  uint64_t rng_step, const float* forced_u, float* values, float* actions, float* logp,
                  void* stream);
 
+/* Forward-only evaluation of GIVEN actions = PPOModule.evaluate_actions (openrl/modules/ppo_module.py:149-193,
+ * PolicyNetwork.eval_actions networks/policy_network.py:164-203, ACTLayer.evaluate_actions utils/act.py:102-172):
+ * values [B,1], action_log_probs [B,a], dist_entropy [1] (device) = masked mean with active_masks [B,1] when
+ * given, else the plain mean; entropy_rows [B] is scratch (entropy * weight per row).  ctheta may be NULL. */
+int orl_evaluate_actions(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,
+                         const float* ctheta, const float* policy_obs, const float* critic_obs,
+                         const float* actions, const float* action_masks, const float* active_masks, int B,
+                         float* values, float* action_log_probs, float* entropy_rows, float* dist_entropy,
+                         void* stream);
+
 /* ---- K9-K12: fused PPO minibatch forward + loss + backward ----------------------------------------
  * Replaces PPOAlgorithm.prepare_loss + loss.backward() x2 (openrl/algorithms/ppo.py:238-361,
  * 123-124) with PPOModule.evaluate_actions (modules/ppo_module.py:149-193), cal_value_loss

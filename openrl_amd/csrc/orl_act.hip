@@ -491,6 +491,120 @@ __global__ __launch_bounds__(256) void env_step_kernel(float* __restrict__ env_s
   }
 }
 
+// --------------------------------------------------------------------------------------------------
+// evaluate_actions (forward only): log-prob of GIVEN actions, per-row entropy, values.
+// --------------------------------------------------------------------------------------------------
+struct EvalArgs {
+  orl_net_desc pnet, cnet;
+  const float* ptheta;
+  const float* ctheta;
+  const float* pobs;
+  const float* cobs;
+  const float* actions;  // [B, a]
+  const float* amask;    // [B, n_out] or NULL
+  const float* active;   // [B] or NULL
+  float* values;         // [B]
+  float* logp;           // [B, a]
+  float* ent_w;          // [B]: entropy(row) * weight(row)
+  int B;
+};
+
+template <int NO, int HEAD>
+__global__ __launch_bounds__(128) void eval_actions_kernel(EvalArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const TowerLayout tlp(A.pnet);
+  const TowerLds twp(A.pnet.obs_dim, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false);
+  TowerLds twc;
+  const bool has_c = A.ctheta != nullptr;
+  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x);
+  if (has_c) {
+    const TowerLayout tlc(A.cnet);
+    twc = TowerLds(A.cnet.obs_dim, 1, false, false);
+    stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int row = blockIdx.x * TILE_B + j;
+  const bool ok = row < A.B;
+  if (wave == 0) {
+    const int D = A.pnet.obs_dim, n_out = A.pnet.n_out;
+    const float* xrow = A.pobs + (size_t)row * D;
+    auto xb = [&](int s) -> float {
+      const int k = 4 * s + q;
+      return (ok && k < D) ? xrow[k] : 0.f;
+    };
+    f32x4 n2[4];
+    trunk_fwd_T(smem, twp, xb, j, q, n2);
+    float hd[NO];
+    head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);
+    const float w = (A.active != nullptr && ok) ? A.active[row] : 1.f;
+    if (HEAD == ORL_HEAD_CATEGORICAL) {
+      const float* am = (A.amask != nullptr && ok) ? A.amask + (size_t)row * n_out : nullptr;
+      const float lse = cat_lse<NO>(hd, n_out, am);
+      const int act = ok ? (int)A.actions[row] : 0;
+      float ent = 0.f;
+#pragma unroll
+      for (int c = 0; c < NO; ++c) {
+        if (c < n_out) {
+          const float ell = hd[c] - lse;
+          ent -= expf(ell) * ell;
+        }
+      }
+      if (ok && q == 0) {
+        A.logp[row] = pick<NO>(hd, act) - lse;
+        A.ent_w[row] = ent * w;
+      }
+    } else {
+      float ent = 0.f;
+#pragma unroll
+      for (int c = 0; c < NO; ++c) {
+        if (c < n_out) {
+          const float ls = smem[twp.logstd + c];
+          const float sd = expf(ls);
+          const float d = (ok ? A.actions[(size_t)row * n_out + c] : 0.f) - hd[c];
+          if (ok && q == 0) A.logp[(size_t)row * n_out + c] = -(d * d) / (2.f * (sd * sd)) - ls - 0.91893853320467274178f;
+          ent += 1.41893853320467274178f + ls;
+        }
+      }
+      if (ok && q == 0) A.ent_w[row] = ent * w;
+    }
+  } else if (has_c) {
+    const int D = A.cnet.obs_dim;
+    const float* xrow = A.cobs + (size_t)row * D;
+    auto xb = [&](int s) -> float {
+      const int k = 4 * s + q;
+      return (ok && k < D) ? xrow[k] : 0.f;
+    };
+    f32x4 n2[4];
+    const float* lc = smem + twp.total;
+    trunk_fwd_T(lc, twc, xb, j, q, n2);
+    float v[1];
+    head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
+    if (ok && q == 0) A.values[row] = v[0];
+  }
+}
+
+// dist_entropy = sum(ent_w) / (sum(active) | B | B*a)   (act.py:151-168)
+__global__ __launch_bounds__(256) void eval_entropy_kernel(const float* __restrict__ ent_w,
+                                                           const float* __restrict__ active, int B, float den_scale,
+                                                           float* __restrict__ out) {
+  __shared__ double sh[4][2];
+  double s = 0, d = 0;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    s += (double)ent_w[i];
+    d += active != nullptr ? (double)active[i] : 1.0;
+  }
+  s = wave_sum(s);
+  d = wave_sum(d);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = s; sh[threadIdx.x >> 6][1] = d; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ss = 0, dd = 0;
+    for (int k = 0; k < 4; ++k) { ss += sh[k][0]; dd += sh[k][1]; }
+    out[0] = (float)(ss / (dd * (double)den_scale));
+  }
+}
+
 static int check_net(const orl_net_desc* n, const char* who, bool is_critic) {
   if (!n) return fail(ORL_E_INVALID, "%s: null net descriptor", who);
   if (n->hidden != HID) return fail(ORL_E_UNSUPPORTED, "%s: hidden_size %d not built (only 64)", who, n->hidden);
@@ -560,6 +674,44 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
   ORL_DISPATCH_HEAD(ORL_ACT_LAUNCH);
 #undef ORL_ACT_LAUNCH
   return launch_status("orl_act_step");
+}
+
+int orl_evaluate_actions(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                         const float* policy_obs, const float* critic_obs, const float* actions,
+                         const float* action_masks, const float* active_masks, int B, float* values,
+                         float* action_log_probs, float* entropy_rows, float* dist_entropy, void* stream) {
+  int rc = check_net(pnet, "orl_evaluate_actions(policy)", false);
+  if (rc) return rc;
+  ORL_REQUIRE(ptheta && policy_obs && actions && action_log_probs && entropy_rows && dist_entropy && B > 0,
+              "orl_evaluate_actions: bad arguments");
+  size_t lds = TowerLds(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false).total;
+  if (ctheta) {
+    rc = check_net(cnet, "orl_evaluate_actions(critic)", true);
+    if (rc) return rc;
+    ORL_REQUIRE(critic_obs && values, "orl_evaluate_actions: critic given without critic_obs/values");
+    lds += TowerLds(cnet->obs_dim, 1, false, false).total;
+  }
+  lds *= sizeof(float);
+  ORL_REQUIRE(lds <= 160 * 1024, "orl_evaluate_actions: towers need %zu B of LDS", lds);
+  EvalArgs A;
+  A.pnet = *pnet; A.cnet = ctheta ? *cnet : *pnet; A.ptheta = ptheta; A.ctheta = ctheta; A.pobs = policy_obs;
+  A.cobs = critic_obs; A.actions = actions; A.amask = action_masks; A.active = active_masks; A.values = values;
+  A.logp = action_log_probs; A.ent_w = entropy_rows; A.B = B;
+  const int grid = (B + TILE_B - 1) / TILE_B;
+#define ORL_EVAL_LAUNCH(NO, HD)                                                                                     \
+  do {                                                                                                              \
+    if (lds > 48 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)eval_actions_kernel<NO, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                          \
+    hipLaunchKernelGGL((eval_actions_kernel<NO, HD>), dim3(grid), dim3(128), lds, (hipStream_t)stream, A);          \
+  } while (0)
+  ORL_DISPATCH_HEAD(ORL_EVAL_LAUNCH);
+#undef ORL_EVAL_LAUNCH
+  // masked mean: sum(ent*active)/sum(active); unmasked: mean over rows (categorical) or rows*dims (Gaussian)
+  const float den_scale = (active_masks == nullptr && pnet->head_kind == ORL_HEAD_GAUSSIAN) ? (float)pnet->n_out : 1.f;
+  hipLaunchKernelGGL(eval_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, entropy_rows, active_masks, B,
+                     den_scale, dist_entropy);
+  return launch_status("orl_evaluate_actions");
 }
 
 int orl_env_state_width(int env_kind) {

@@ -303,9 +303,23 @@ class PPOModule:
 
     def evaluate_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, action, masks, action_masks=None,
                          active_masks=None, critic_masks_batch=None):
-        raise NotImplementedError(
-            "evaluate_actions is fused into orl_ppo_fwd_bwd (loss + backward) in the MI355X engine; "
-            "use PPOAlgorithm.train or ops.ppo_fwd_bwd")
+        """Forward-only (no autograd graph: the training path fuses loss + backward in ``orl_ppo_fwd_bwd``).
+        Returns ``(values, action_log_probs, dist_entropy, policy_values=None)`` like ppo_module.py:149-193;
+        the entropy is the active-mask weighted mean when ``cfg.use_policy_active_masks`` (policy_network.py:199)."""
+        p, c = self.models["policy"], self.models["critic"]
+        x = self._dev(obs, p.net.obs_dim)
+        xc = self._dev(critic_obs, c.net.obs_dim)
+        B = x.shape[0]
+        act = self._dev(action, self.act_width)
+        am = self._dev(action_masks, p.net.n_out) if (action_masks is not None and p.net.head_kind ==
+                                                       ops.HEAD_CATEGORICAL) else None
+        active = None
+        if active_masks is not None and self.cfg.use_policy_active_masks:
+            active = self._dev(active_masks, 1)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+        values, logp, ent_rows, ent = f(B, 1), f(B, self.act_width), f(B), f(1)
+        ops.evaluate_actions(p.net, p.theta, c.net, c.theta, x, xc, act, am, active, B, values, logp, ent_rows, ent)
+        return values, logp, ent[0], None
 
     def act(self, obs, rnn_states_actor, masks, action_masks=None, deterministic=False):
         _, actions, _ = self._forward(None, obs, action_masks, deterministic, want_value=False)

@@ -145,6 +145,16 @@ def act_step(pnet: NetDesc, ptheta, cnet: Optional[NetDesc], ctheta, policy_obs,
     nat.check(rc, "orl_act_step")
 
 
+def evaluate_actions(pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, actions, action_masks, active_masks, B: int,
+                     values, logp, ent_rows, dist_entropy) -> None:
+    dev = _dev(policy_obs)
+    rc = _lib().orl_evaluate_actions(C.byref(pnet), fptr(ptheta), C.byref(cnet) if cnet is not None else None,
+                                     fptr(ctheta), fptr(policy_obs), fptr(critic_obs), fptr(actions),
+                                     fptr(action_masks), fptr(active_masks), B, fptr(values), fptr(logp),
+                                     fptr(ent_rows), fptr(dist_entropy), stream_ptr(dev))
+    nat.check(rc, "orl_evaluate_actions")
+
+
 # ------------------------------------------------------------------------------------------------ K9-K14
 def ppo_fwd_bwd(pnet, ptheta, cnet, ctheta, records, idx, mb: int, vn_state, hp: PPOHParams, partials):
     """Returns (policy workgroups, critic workgroups) = rows of the two partial regions."""

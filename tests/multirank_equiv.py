@@ -1,0 +1,92 @@
+"""Worker for tests/test_multirank_gpu.py (launched with torch.distributed.run, 2 ranks, gloo, one GPU).
+
+"G ranks == 1 rank on the concatenated batch" (SURVEY.md section 8e): a global buffer of 2*Nl env lanes is split
+by env between the ranks; every rank runs PPOAlgorithm.train on its shard with the all-reduces of
+openrl_amd/distributed.py in the loop; rank 0 also runs the same update single-process on the whole buffer and
+compares weights, ValueNorm state and train_info."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build(cfg, N, D, n_act, world_size, dev, seed=0):
+    from openrl_amd import spaces
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers.replay_data import ReplayData
+    from openrl_amd.modules.ppo_module import PPOModule
+
+    cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = N, 1, cfg.hidden_size
+    obs_space, act_space = spaces.Box(-np.inf, np.inf, (D,)), spaces.Discrete(n_act)
+    torch.manual_seed(seed)
+    module = PPOModule(cfg, obs_space, obs_space, act_space, device=dev, rank=0, world_size=world_size)
+    buf = ReplayData(cfg, 1, obs_space, act_space, device=dev)
+    return module, buf, PPOAlgorithm(cfg, module, agent_num=1, device=dev)
+
+
+def fill(buf, host, lo, hi, nv):
+    for k, v in host.items():
+        getattr(buf, k).copy_(torch.tensor(v[:, lo:hi]))
+    return torch.tensor(nv[lo:hi])
+
+
+def main():
+    from openrl_amd import distributed as du
+    from openrl_amd.configs.config import default_cfg
+
+    du.init_from_env(backend="gloo")
+    rank, world = du.rank(), du.world_size()
+    dev = "cuda:0"
+    T, Nl, D, n_act = 12, 24, 4, 2
+    N = Nl * world
+    rs = np.random.RandomState(5)
+    host = dict(policy_obs=rs.randn(T + 1, N, 1, D).astype(np.float32), rewards=rs.rand(T, N, 1, 1).astype(np.float32),
+                value_preds=(0.3 * rs.randn(T + 1, N, 1, 1)).astype(np.float32),
+                masks=(rs.rand(T + 1, N, 1, 1) > 0.05).astype(np.float32),
+                active_masks=(rs.rand(T + 1, N, 1, 1) > 0.1).astype(np.float32),
+                actions=rs.randint(0, n_act, (T, N, 1, 1)).astype(np.float32),
+                action_log_probs=(np.log(0.5) + 0.05 * rs.randn(T, N, 1, 1)).astype(np.float32))
+    nv = (0.3 * rs.randn(N, 1, 1)).astype(np.float32)
+    argv = ["--episode_length", str(T), "--ppo_epoch", "3", "--num_mini_batch", "1", "--amd_perm_mode", "device"]
+
+    # sharded run (all ranks)
+    cfg = default_cfg(argv)
+    module, buf, algo = build(cfg, Nl, D, n_act, world, dev)
+    lo, hi = du.shard_range(N, rank, world)
+    buf.compute_returns(fill(buf, host, lo, hi, nv), module.get_critic_value_normalizer())
+    info = algo.train(buf)
+    torch.cuda.synchronize()
+    ok = True
+    if rank == 0:
+        cfg1 = default_cfg(argv)
+        m1, b1, a1 = build(cfg1, N, D, n_act, 1, dev)
+        b1.compute_returns(fill(b1, host, 0, N, nv), m1.get_critic_value_normalizer())
+        info1 = a1.train(b1)
+        for k in ("policy", "critic"):
+            got, want = module.models[k].theta.cpu().numpy(), m1.models[k].theta.cpu().numpy()
+            err = np.abs(got - want).max()
+            print("theta %s max|diff| %.3e" % (k, err))
+            ok &= bool(np.allclose(got, want, rtol=1e-4, atol=2e-6))
+        vs, vs1 = module.get_critic_value_normalizer().state.cpu().numpy(), m1.get_critic_value_normalizer().state.cpu().numpy()
+        ok &= bool(np.allclose(vs, vs1, rtol=1e-6))
+        for k in info1:
+            ok &= bool(np.isclose(info[k], info1[k], rtol=2e-4, atol=2e-6))
+        print("info", info, info1)
+        print("MULTIRANK_EQUIV_OK" if ok else "MULTIRANK_EQUIV_FAIL")
+    # all ranks must end with bit-identical weights (same reduced vector, same Adam step)
+    th = module.models["policy"].theta.clone()
+    gathered = [torch.zeros_like(th) for _ in range(world)]
+    torch.distributed.all_gather(gathered, th)
+    if rank == 0:
+        same = all(torch.equal(gathered[0], g) for g in gathered)
+        print("REPLICAS_IDENTICAL" if same else "REPLICAS_DIVERGED")
+    torch.distributed.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -269,3 +269,30 @@ def test_act_step_philox_stream_matches_oracle(ops):
     ops.act_step(pnet, dev(g["theta_p1"]), cnet, dev(g["theta_c1"]), dev(obs), dev(obs), None, B, False, seed, row0,
                  step, None, values, actions, logp)
     assert (actions.cpu().numpy()[:, 0] == want_a[:, 0]).mean() >= 0.995
+
+
+@pytest.mark.parametrize("case", H.TRAIN_CASES)
+def test_evaluate_actions_vs_oracle(ops, case):
+    """PPOModule.evaluate_actions (ppo_module.py:149-193): log-prob of stored actions, masked-mean entropy, values."""
+    g = H.load_golden(case)
+    cfg = H.case_cfg(g)
+    pspec, cspec = H.case_specs(g)
+    b = H.case_buffer(g)
+    fr = po.flat_rows
+    obs, act, active = fr(b["policy_obs"][:-1]), fr(b["actions"]), fr(b["active_masks"][:-1])
+    am = None if b["action_masks"] is None else fr(b["action_masks"][:-1])
+    t = lambda a: None if a is None else torch.as_tensor(a, dtype=torch.float32)
+    with torch.no_grad():
+        want_lp, want_ent = po.evaluate_actions(pspec, torch.tensor(g["theta_p1"]), t(obs), t(act), t(am), t(active),
+                                                cfg.use_policy_active_masks)
+        want_v = po.tower_forward(cspec, torch.tensor(g["theta_c1"]), t(obs))
+    B, a_w = obs.shape[0], act.shape[1]
+    pnet, cnet = ops.net_desc(pspec.obs_dim, pspec.n_out, pspec.head), ops.net_desc(cspec.obs_dim, 1, ops.HEAD_VALUE)
+    values, logp = torch.empty(B, 1, device=DEV), torch.empty(B, a_w, device=DEV)
+    ent_rows, ent = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
+    ops.evaluate_actions(pnet, dev(g["theta_p1"]), cnet, dev(g["theta_c1"]), dev(obs), dev(obs), dev(act),
+                         None if am is None else dev(am), dev(active) if cfg.use_policy_active_masks else None, B,
+                         values, logp, ent_rows, ent)
+    np.testing.assert_allclose(logp.cpu().numpy(), want_lp.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(values.cpu().numpy(), want_v.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ent.item(), want_ent.item(), rtol=1e-5, atol=1e-6)

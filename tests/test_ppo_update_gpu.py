@@ -121,3 +121,78 @@ def test_device_permutation_mode_trains_and_is_deterministic():
         assert len(set(idx.tolist())) == idx.size  # a permutation, not a resample
     assert np.array_equal(outs[0][0], outs[1][0]), "same seed must give bit-identical weights"
     assert np.isfinite(list(outs[0][1].values())).all()
+
+
+def _random_case(D, act_space_kind, n_act, N, T, seed, masks=False):
+    """Synthetic buffer at an arbitrary shape: one full-batch update, engine vs oracle autograd."""
+    from openrl_amd import spaces
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers.replay_data import ReplayData
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.modules.ppo_module import PPOModule
+
+    rs = np.random.RandomState(seed)
+    cfg = default_cfg(["--seed", str(seed), "--episode_length", str(T), "--ppo_epoch", "1"])
+    cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = N, 1, cfg.hidden_size
+    obs_space = spaces.Box(-np.inf, np.inf, (D,))
+    act_space = spaces.Discrete(n_act) if act_space_kind == "discrete" else spaces.Box(-1, 1, (n_act,))
+    torch.manual_seed(seed)
+    module = PPOModule(cfg, obs_space, obs_space, act_space, device=DEV, rank=0, world_size=1)
+    buf = ReplayData(cfg, 1, obs_space, act_space, device=DEV)
+    a_w = 1 if act_space_kind == "discrete" else n_act
+    host = dict(policy_obs=rs.randn(T + 1, N, 1, D).astype(np.float32),
+                rewards=rs.rand(T, N, 1, 1).astype(np.float32),
+                value_preds=(0.3 * rs.randn(T + 1, N, 1, 1)).astype(np.float32),
+                masks=(rs.rand(T + 1, N, 1, 1) > 0.05).astype(np.float32),
+                active_masks=(rs.rand(T + 1, N, 1, 1) > 0.1).astype(np.float32))
+    if act_space_kind == "discrete":
+        host["actions"] = rs.randint(0, n_act, (T, N, 1, 1)).astype(np.float32)
+        host["action_log_probs"] = np.log(np.full((T, N, 1, 1), 1.0 / n_act, np.float32)) + 0.05 * rs.randn(T, N, 1, 1).astype(np.float32)
+        if masks:
+            am = (rs.rand(T + 1, N, 1, n_act) > 0.3).astype(np.float32)
+            am[np.arange(T)[:, None], np.arange(N)[None, :], 0, host["actions"][..., 0, 0].astype(int)] = 1.0
+            host["action_masks"] = am
+    else:
+        host["actions"] = rs.randn(T, N, 1, n_act).astype(np.float32)
+        host["action_log_probs"] = (-0.5 * host["actions"] ** 2 - 0.9189385 + 0.05 * rs.randn(T, N, 1, n_act)).astype(np.float32)
+    for k, v in host.items():
+        getattr(buf, k).copy_(torch.tensor(v))
+    host["critic_obs"] = host["policy_obs"]
+    host.setdefault("action_masks", None if act_space_kind != "discrete" else np.ones((T + 1, N, 1, n_act), np.float32))
+    buf.compute_returns(torch.tensor(0.3 * rs.randn(N, 1, 1).astype(np.float32)), module.get_critic_value_normalizer())
+    host["returns"], host["value_preds"] = buf.returns.cpu().numpy(), buf.value_preds.cpu().numpy()
+    return cfg, module, buf, PPOAlgorithm(cfg, module, agent_num=1, device=DEV), host, a_w
+
+
+@pytest.mark.parametrize("D,kind,n_act,N,T,masks", [
+    (17, "gaussian", 6, 64, 25, False),    # config 3 shape: HalfCheetah obs 17, Box(6)
+    (18, "discrete", 9, 64, 25, True),     # config 5 shape: tictactoe obs 18, Discrete(9) + action masks
+    (18, "discrete", 5, 48, 25, False),    # MPE simple_spread policy obs 18, Discrete(5) (feed-forward part)
+    (4, "discrete", 2, 1024, 32, False),   # config 2 shape, 2048 tiles
+    (3, "discrete", 3, 7, 5, False),       # ragged: 35 rows, obs not a multiple of 4
+])
+def test_single_update_at_baseline_shapes_vs_oracle(D, kind, n_act, N, T, masks):
+    cfg, module, buf, algo, host, a_w = _random_case(D, kind, n_act, N, T, seed=D + n_act, masks=masks)
+    hp = po.hyper_from_cfg(cfg)
+    head = po.HEAD_CATEGORICAL if kind == "discrete" else po.HEAD_GAUSSIAN
+    pspec, cspec = po.TowerSpec(D, n_act, head), po.TowerSpec(D, 1, po.HEAD_VALUE)
+    ptheta, ctheta = module.models["policy"].theta.cpu().clone(), module.models["critic"].theta.cpu().clone()
+    padam, cadam = po.AdamOracle(ptheta.numel(), cfg.lr), po.AdamOracle(ctheta.numel(), cfg.critic_lr)
+    vn = po.ValueNormOracle()
+    adv = po.advantages(host["returns"], host["value_preds"], host["active_masks"], vn, False)
+    fr = po.flat_rows
+    sample = (fr(host["critic_obs"][:-1]), fr(host["policy_obs"][:-1]), fr(host["actions"]),
+              fr(host["value_preds"][:-1]), fr(host["returns"][:-1]), fr(host["active_masks"][:-1]),
+              fr(host["action_log_probs"]), adv.reshape(-1, 1),
+              None if host["action_masks"] is None else fr(host["action_masks"][:-1]))
+    info_o, gp, gc = po.ppo_update(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, sample)
+    algo._advantages_and_records(buf)
+    np.testing.assert_allclose(buf.advantages.cpu().numpy(), adv, rtol=5e-5, atol=5e-5)
+    algo._info.zero_()
+    algo._update_minibatch(buf, None, adv.size, True)
+    got_p, got_c = module.models["policy"].grad.cpu().numpy(), module.models["critic"].grad.cpu().numpy()
+    np.testing.assert_allclose(got_p, gp, rtol=2e-3, atol=3e-5 * np.abs(gp).max() + 1e-7)
+    np.testing.assert_allclose(got_c, gc, rtol=2e-3, atol=3e-5 * np.abs(gc).max() + 1e-7)
+    want = np.array([info_o[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
+                                         "critic_grad_norm", "ratio")])
+    np.testing.assert_allclose(algo._info[:6].cpu().numpy(), want, rtol=3e-4, atol=3e-5)
