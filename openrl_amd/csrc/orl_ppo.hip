@@ -209,14 +209,15 @@ static int check_tower(const orl_net_desc* n, const char* who) {
   return 0;
 }
 
-template <int HEAD, int NO, int ND, int WPS>
+template <int HEAD, int NO, int ND, int WPS, bool PC>
 static int launch_tower_w(const PpoArgs& A, int waves, size_t lds, hipStream_t s) {
   const int n_tiles = (A.mb + TILE_B - 1) / TILE_B;
-  int grid = (n_tiles + waves - 1) / waves;
+  const int walkers = PC ? 8 : waves;  // waves per workgroup that walk tiles
+  int grid = (n_tiles + walkers - 1) / walkers;
   if (grid > PPO_MAX_BLOCKS) grid = PPO_MAX_BLOCKS;
-  (void)hipFuncSetAttribute((const void*)ppo_tower_kernel<HEAD, NO, ND, WPS>,
+  (void)hipFuncSetAttribute((const void*)ppo_tower_kernel<HEAD, NO, ND, WPS, PC>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((ppo_tower_kernel<HEAD, NO, ND, WPS>), dim3(grid), dim3(waves * 64), lds, s, A);
+  hipLaunchKernelGGL((ppo_tower_kernel<HEAD, NO, ND, WPS, PC>), dim3(grid), dim3(waves * 64), lds, s, A);
   return grid;
 }
 
@@ -231,14 +232,22 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
   static const int kWaves[4] = {8, 6, 4, 2};
   static const int max_waves = []() {  // tuning knob for A/B runs: ORL_PPO_WAVES=4 caps the workgroup size
     const char* e = getenv("ORL_PPO_WAVES");
-    return e ? atoi(e) : 8;
+    return e ? atoi(e) : 8;  // 12 = producer/consumer build: correct but measured slower (0.408 vs 0.384 ms)
   }();
+  if (max_waves >= 12) {  // producer / consumer build: 8 producers + 4 consumers, 3 waves per SIMD
+    const size_t lds = tower_lds_floats(A.net, A.R, NOP, 12, HEAD == ORL_HEAD_GAUSSIAN, true) * sizeof(float);
+    if (lds <= 160 * 1024) {
+      const int grid = launch_tower_w<HEAD, NO, ND, 3, true>(A, 12, lds, s);
+      const int rc = launch_status("orl_ppo_fwd_bwd");
+      return rc ? -1000 - rc : grid;
+    }
+  }
   for (int k = 0; k < 4; ++k) {
     const int waves = kWaves[k];
     if (waves > max_waves) continue;
     const size_t lds = tower_lds_floats(A.net, A.R, NOP, waves, HEAD == ORL_HEAD_GAUSSIAN) * sizeof(float);
     if (lds > 160 * 1024) continue;
-    const int grid = launch_tower_w<HEAD, NO, ND, 2>(A, waves, lds, s);
+    const int grid = launch_tower_w<HEAD, NO, ND, 2, false>(A, waves, lds, s);
     const int rc = launch_status("orl_ppo_fwd_bwd");
     return rc ? -1000 - rc : grid;
   }
