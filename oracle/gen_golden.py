@@ -190,6 +190,108 @@ def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, s
     print(name + ".npz", {k: float(info[k]) for k in info})
 
 
+def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=0):
+    """use_recurrent_policy: hand-driven rollout (rnn states zeroed on env-done, onpolicy_driver.py:91-108),
+    then PPOAlgorithm.train with recurrent_generator (ppo.py:363-372, replay_data.py:1062-1258)."""
+    from gymnasium.spaces import Box, Dict as DictSpace
+    from openrl.algorithms.ppo import PPOAlgorithm
+    from openrl.buffers import NormalReplayBuffer
+    from openrl.modules.ppo_module import PPOModule
+    from openrl.utils.util import set_seed
+
+    cfg = _cfg(["--use_recurrent_policy", "true"] + argv, N, T)
+    cfg.num_agents = A
+    cfg.seed = seed
+    act_space = act_space_fn()
+    if Dp == Dc:
+        obs_space = Box(-np.inf, np.inf, (Dp,))
+    else:
+        obs_space = DictSpace({"policy": Box(-np.inf, np.inf, (Dp,)), "critic": Box(-np.inf, np.inf, (Dc,))})
+    set_seed(cfg.seed)
+    module = PPOModule(cfg, policy_input_space=obs_space, critic_input_space=obs_space, act_space=act_space,
+                       share_model=False, rank=0, world_size=1)
+    out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"])}
+    buffer = NormalReplayBuffer(cfg, A, obs_space, act_space, data_client=None)
+    algo = PPOAlgorithm(cfg, module, agent_num=A)
+    rs = np.random.RandomState(200 + seed)
+
+    def draw_obs():
+        if Dp == Dc:
+            return rs.randn(N, A, Dp).astype(np.float32)
+        return {"policy": rs.randn(N, A, Dp).astype(np.float32), "critic": rs.randn(N, A, Dc).astype(np.float32)}
+
+    buffer.init_buffer(draw_obs())
+    algo.prep_rollout()
+    d = buffer.data
+    H = cfg.hidden_size
+    for step in range(T):
+        with torch.no_grad():
+            value, action, logp, rs_a, rs_c = module.get_actions(
+                d.get_batch_data("critic_obs", step), d.get_batch_data("policy_obs", step),
+                d.get_batch_data("rnn_states", step), d.get_batch_data("rnn_states_critic", step),
+                d.get_batch_data("masks", step), action_masks=d.get_batch_data("action_masks", step))
+        split = lambda x: np.array(np.split(x.detach().cpu().numpy(), N))
+        values, actions, logps, rnn_a, rnn_c = split(value), split(action), split(logp), split(rs_a), split(rs_c)
+        rewards = rs.rand(N, A, 1).astype(np.float32)
+        dones = rs.rand(N, A) < 0.2
+        dones[rs.randint(N)] = True
+        dones_env = np.all(dones, axis=1)
+        rnn_a[dones_env] = 0.0
+        rnn_c[dones_env] = 0.0
+        masks = np.ones((N, A, 1), np.float32)
+        masks[dones_env] = 0.0
+        active = np.ones((N, A, 1), np.float32)
+        active[dones] = 0.0
+        active[dones_env] = 1.0
+        bad = np.ones((N, A, 1), np.float32)
+        buffer.insert(draw_obs(), rnn_a, rnn_c, actions, logps, values, rewards, masks, active_masks=active,
+                      bad_masks=bad, action_masks=None)
+    with torch.no_grad():
+        nv = module.get_values(d.get_batch_data("critic_obs", -1), np.concatenate(d.rnn_states_critic[-1]),
+                               np.concatenate(d.masks[-1]))
+    next_values = np.array(np.split(nv.detach().cpu().numpy(), N))
+    vn = module.get_critic_value_normalizer()
+    buffer.compute_returns(next_values, vn)
+    for f in ("policy_obs", "critic_obs"):
+        v = getattr(d, f)
+        out["buf_" + f] = (v["policy" if f == "policy_obs" else "critic"] if isinstance(v, dict) else v).copy()
+    for f in ("actions", "action_log_probs", "value_preds", "returns", "rewards", "masks", "bad_masks",
+              "active_masks", "rnn_states", "rnn_states_critic"):
+        out["buf_" + f] = getattr(d, f).copy()
+    if d.action_masks is not None:
+        out["buf_action_masks"] = d.action_masks.copy()
+    out["next_values"] = next_values
+    torch.manual_seed(4321 + seed)
+    algo.prep_training()
+    info = algo.train(d)
+    out["train_info"] = np.array([float(info[k]) for k in
+                                  ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
+                                   "ratio")], np.float64)
+    out["theta_p1"] = _flat(module.models["policy"])
+    out["theta_c1"] = _flat(module.models["critic"])
+    if vn is not None:
+        out["vn_state1"] = np.array([vn.running_mean.item(), vn.running_mean_sq.item(), vn.debiasing_term.item()],
+                                    np.float32)
+    out["argv"] = np.array(" ".join(["--use_recurrent_policy", "true"] + argv))
+    out["perm_seed"] = np.array(4321 + seed)
+    # deterministic probe with non-trivial states and a zero mask on theta1
+    B = 12
+    pp, pc = rs.randn(B, Dp).astype(np.float32), rs.randn(B, Dc).astype(np.float32)
+    ha, hc = (0.5 * rs.randn(B, 1, H)).astype(np.float32), (0.5 * rs.randn(B, 1, H)).astype(np.float32)
+    pm = np.ones((B, 1), np.float32)
+    pm[::3] = 0.0
+    algo.prep_rollout()
+    with torch.no_grad():
+        if Dp == Dc:
+            pp = pc
+        v, a, lp, ha1, hc1 = module.get_actions(pc, pp, ha, hc, pm, deterministic=True)
+    out["probe_policy_obs"], out["probe_critic_obs"], out["probe_h"], out["probe_hc"], out["probe_masks"] = pp, pc, ha, hc, pm
+    out["probe_values"], out["probe_actions"], out["probe_logp"] = v.numpy(), a.numpy().astype(np.float32), lp.numpy()
+    out["probe_h1"], out["probe_hc1"] = ha1.numpy(), hc1.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: float(info[k]) for k in info})
+
+
 def perm_case():
     from torch.utils.data.sampler import BatchSampler, SubsetRandomSampler
 
@@ -204,21 +306,40 @@ def perm_case():
 
 
 def main():
+    """``python -m oracle.gen_golden [name ...]`` - without names every fixture is regenerated."""
     ref_stubs.install()
     os.makedirs(OUT, exist_ok=True)
     from gymnasium.spaces import Box, Discrete
 
-    gae_cases()
-    perm_case()
-    _train_case("train_discrete", ["--ppo_epoch", "3", "--num_mini_batch", "2"], 4, lambda: Discrete(2))
-    _train_case("train_discrete_masks", ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_adv_normalize", "true",
-                                         "--use_huber_loss"], 6, lambda: Discrete(5), use_masks=True, seed=1)
-    _train_case("train_gaussian", ["--ppo_epoch", "2", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"],
-                5, lambda: Box(-1, 1, (3,)), seed=2)
-    _train_case("train_novn_proper", ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_valuenorm", "false",
-                                      "--use_proper_time_limits", "true", "--dual_clip_ppo", "true",
-                                      "--use_clipped_value_loss", "--use_value_active_masks", "false",
-                                      "--use_policy_active_masks"], 4, lambda: Discrete(2), seed=3)
+    only = set(sys.argv[1:])
+    want = lambda name: not only or name in only
+    if want("gae"):
+        gae_cases()
+    if want("perm"):
+        perm_case()
+    cases = {
+        "train_discrete": lambda n: _train_case(n, ["--ppo_epoch", "3", "--num_mini_batch", "2"], 4, lambda: Discrete(2)),
+        "train_discrete_masks": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_adv_normalize", "true", "--use_huber_loss"], 6,
+            lambda: Discrete(5), use_masks=True, seed=1),
+        "train_gaussian": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 5,
+            lambda: Box(-1, 1, (3,)), seed=2),
+        "train_novn_proper": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_valuenorm", "false", "--use_proper_time_limits",
+                "true", "--dual_clip_ppo", "true", "--use_clipped_value_loss", "--use_value_active_masks", "false",
+                "--use_policy_active_masks"], 4, lambda: Discrete(2), seed=3),
+        # recurrent (GRU) branch: T=7 is odd, so chunks of 2 straddle lanes like cfg4's T=25
+        "train_recurrent": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 18, 54,
+            lambda: Discrete(5), N=6, A=3, T=7, seed=5),
+        "train_recurrent_chunk5": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--data_chunk_length", "5"], 6, 6,
+            lambda: Box(-1, 1, (2,)), N=5, A=1, T=10, seed=6),
+    }
+    for name, fn in cases.items():
+        if want(name):
+            fn(name)
 
 
 if __name__ == "__main__":

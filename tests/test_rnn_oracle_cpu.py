@@ -1,0 +1,67 @@
+"""The recurrent (GRU) oracle against vectors minted from the REAL reference classes (oracle/gen_golden.py):
+PPOModule with use_recurrent_policy, NormalReplayBuffer.recurrent_generator, PPOAlgorithm.train."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as po
+from oracle import rnn_oracle as ro
+from tests import helpers as H
+from tests import rnn_helpers as RH
+
+KEYS = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
+
+
+@pytest.mark.parametrize("case,seed", [("train_recurrent", 5), ("train_recurrent_chunk5", 6)])
+def test_recurrent_init_matches_reference_rng_order(case, seed):
+    g = H.load_golden(case)
+    cfg = H.case_cfg(g)
+    pspec, cspec = RH.rnn_specs(g)
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    tp = ro.init_rnn_tower(pspec, cfg.gain, cfg.use_orthogonal, cfg.activation_id)
+    tc = ro.init_rnn_tower(cspec, 1.0, cfg.use_orthogonal, cfg.activation_id)
+    assert np.array_equal(tp.numpy(), g["theta_p0"])
+    assert np.array_equal(tc.numpy(), g["theta_c0"])
+
+
+@pytest.mark.parametrize("case", RH.RNN_CASES)
+def test_recurrent_train_replay_matches_reference(case):
+    g = H.load_golden(case)
+    r = RH.rnn_oracle_replay(g)
+    np.testing.assert_allclose(r["ptheta"], g["theta_p1"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(r["ctheta"], g["theta_c1"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(np.array([r["info"][k] for k in KEYS]), g["train_info"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r["vn"], g["vn_state1"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("case", RH.RNN_CASES)
+def test_recurrent_probe_matches_reference(case):
+    g = H.load_golden(case)
+    pspec, cspec = RH.rnn_specs(g)
+    v, a, lp, h1, hc1 = ro.get_actions(pspec, torch.tensor(g["theta_p1"]), cspec, torch.tensor(g["theta_c1"]),
+                                       g["probe_policy_obs"], g["probe_critic_obs"], g["probe_h"], g["probe_hc"],
+                                       g["probe_masks"], deterministic=True)
+    np.testing.assert_allclose(v, g["probe_values"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a, g["probe_actions"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lp, g["probe_logp"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(h1, g["probe_h1"].reshape(h1.shape), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(hc1, g["probe_hc1"].reshape(hc1.shape), rtol=1e-5, atol=1e-6)
+
+
+def test_rollout_states_in_the_golden_buffer_follow_the_oracle_cell():
+    """rnn_states[t+1] = GRU(base(obs[t]), rnn_states[t] * masks[t]), zeroed where the env finished."""
+    g = H.load_golden("train_recurrent")
+    pspec, _ = RH.rnn_specs(g)
+    th = torch.tensor(g["theta_p0"])
+    T = g["buf_actions"].shape[0]
+    for t in range(T):
+        x = torch.tensor(g["buf_policy_obs"][t].reshape(-1, pspec.obs_dim))
+        h = torch.tensor(g["buf_rnn_states"][t].reshape(-1, 64))
+        m = torch.tensor(g["buf_masks"][t].reshape(-1, 1))
+        _, h1 = ro.rnn_tower_forward(pspec, th, x, h, m)
+        want = g["buf_rnn_states"][t + 1].reshape(-1, 64)
+        keep = g["buf_masks"][t + 1].reshape(-1) == 1.0
+        np.testing.assert_allclose(h1.numpy()[keep], want[keep], rtol=1e-5, atol=1e-6)
+        assert np.all(want[~keep] == 0.0)
