@@ -300,6 +300,59 @@ int orl_env_step(int env_kind, float* env_state, float* ep_stats, const float* a
 int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,
                       const float* ctheta, const orl_rollout_args* args, float* next_value, void* stream);
 
+/* ---- recurrent (GRU) towers: use_recurrent_policy -------------------------
+ * Tower = MLPBase (as above) -> RNNLayer = one-layer nn.GRU(H,H) + LayerNorm(H) (openrl/modules/networks/utils/
+ * rnn.py:5-99, recurrent_N = 1) -> head.  The orl_net_desc fields keep their meaning; `theta` is the reference's
+ * parameter order for that network (policy_network.py:60-118, value_network.py:60-111):
+ *   W1 b1 g1 be1 W2 b2 g2 be2 | weight_ih_l0[3H*H] weight_hh_l0[3H*H] bias_ih_l0[3H] bias_hh_l0[3H] (gates r,z,n)
+ *   | g3[H] be3[H] (rnn.norm) | W3 b3 (logstd).
+ * Step semantics (rnn.py:39-49): h' = GRU(base(obs), h * mask); features = LayerNorm(h').
+ */
+int orl_rnn_param_count(const orl_net_desc* net);
+int orl_rnn_raw_grad_count(const orl_net_desc* net);
+
+/* PPOModule.get_actions with recurrent networks (ppo_module.py:102-138): like orl_act_step plus the hidden
+ * states h_*_in [B,H] (multiplied by masks [B] first) and the new states h_*_out [B,H] (may alias the inputs).
+ * NULL ptheta = value-only call (get_values, :140-147); NULL ctheta = policy only. */
+int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                     const float* policy_obs, const float* critic_obs, const float* h_policy_in,
+                     const float* h_critic_in, const float* masks, const float* action_masks, int B,
+                     int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const float* forced_u,
+                     float* values, float* actions, float* logp, float* h_policy_out, float* h_critic_out,
+                     void* stream);
+
+/* ReplayData.recurrent_generator's index arithmetic (buffers/replay_data.py:1062-1258): chunk c covers the rows
+ * c*L .. c*L+L-1 of the [lane][t]-ordered flat batch (lane = n*A+a; chunks may straddle lanes when T % L != 0).
+ * rows[l*n_chunks + i] = record row (t*lanes + lane) of step l of chunk chunk_idx[i] (NULL = identity) - the same
+ * index addresses masks [T+1,lanes] and, scaled by H, the stored rnn states [T+1,lanes,H]. */
+int orl_rnn_chunk_rows(const int64_t* chunk_idx, int n_chunks, int L, int T, int lanes, int64_t* rows, void* stream);
+
+typedef struct orl_rnn_batch {
+  const float* records;  /* packed update records (orl_adv_normalize_pack), row = t*lanes + lane */
+  const int64_t* rows;   /* [L][n_chunks] from orl_rnn_chunk_rows */
+  const float* masks;    /* [T+1, lanes] */
+  const float* h_policy; /* [T+1, lanes, H] rnn_states          */
+  const float* h_critic; /* [T+1, lanes, H] rnn_states_critic   */
+  int32_t rec_width, n_chunks, L, reserved;
+} orl_rnn_batch;
+
+/* float32 scratch the update needs (activation tapes + per-workgroup partials), in floats */
+int64_t orl_rnn_workspace_floats(const orl_net_desc* pnet, const orl_net_desc* cnet, int n_chunks, int L);
+
+/* PPOAlgorithm.prepare_loss + 2x backward (ppo.py:98-124, 238-361) on one recurrent minibatch: per tower a
+ * row kernel (forward over the L steps, loss, back-propagation through time; activation gradients go to a tape)
+ * and a weight-gradient GEMM kernel over the tape, then the deterministic reduction into
+ *   sums[raw_p + ORL_N_STATS + raw_c + ORL_N_STATS]   (raw_* = orl_rnn_raw_grad_count)
+ * - the vector a multi-GPU run all-reduces. */
+int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                        const orl_rnn_batch* batch, const float* vn_state, const orl_ppo_hparams* hp,
+                        float* workspace, float* sums, void* stream);
+
+/* orl_ppo_apply for recurrent towers; `scratch` holds 512 floats. */
+int orl_rnn_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums, const orl_ppo_hparams* hp,
+                      const orl_adam_state* padam, const orl_adam_state* cadam, float* train_info_accum,
+                      float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

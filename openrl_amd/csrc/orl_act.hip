@@ -11,6 +11,7 @@
 // rollout step is a dependent-latency chain, not a throughput problem.
 #include "orl_common.h"
 #include "orl_mlp.h"
+#include "orl_heads.h"
 
 namespace orl {
 
@@ -29,63 +30,6 @@ struct ActArgs {
   int deterministic;
   uint64_t seed, row0, rng_step;
 };
-
-// Sample / evaluate the action head for batch row `row` of this lane (all 4 lanes of a row agree).
-// Returns through act_out/logp_out (arrays of NO; categorical uses slot 0).
-template <int NO, int HEAD>
-__device__ inline void sample_head(float (&hd)[NO], int n_out, const float* lds_logstd, const float* amask_row,
-                                   const float* forced_row, int deterministic, uint64_t seed, uint64_t grow,
-                                   uint64_t rng_step, float (&act_out)[NO], float (&logp_out)[NO]) {
-  if (HEAD == ORL_HEAD_CATEGORICAL) {
-    const float lse = cat_lse<NO>(hd, n_out, amask_row);
-    int a;
-    if (deterministic) {
-      a = cat_mode<NO>(hd, n_out);
-    } else {
-      float u;
-      if (forced_row != nullptr) u = forced_row[0];
-      else {
-        const u4 r = philox4x32_10(seed, (uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)rng_step,
-                                   (uint32_t)(rng_step >> 32) << 8);
-        u = u01(r.x);
-      }
-      a = cat_sample<NO>(hd, n_out, lse, u);
-    }
-    act_out[0] = (float)a;
-    logp_out[0] = pick<NO>(hd, a) - lse;
-  } else {
-    // DiagGaussian: std = exp(logstd), per-dimension log-prob (distributions.py:34-43, 75-98)
-#pragma unroll
-    for (int b = 0; b < (NO + 3) / 4; ++b) {
-      float e[4] = {0.f, 0.f, 0.f, 0.f};
-      if (!deterministic && forced_row == nullptr && 4 * b < n_out) {
-        const u4 r = philox4x32_10(seed, (uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)rng_step,
-                                   ((uint32_t)(rng_step >> 32) << 8) | (uint32_t)b);
-        box_muller(r.x, r.y, e[0], e[1]);
-        box_muller(r.z, r.w, e[2], e[3]);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = 4 * b + k;
-        if (c < NO) {
-          float av = 0.f, lp = 0.f;
-          if (c < n_out) {
-            const float ls = lds_logstd[c];
-            const float sd = expf(ls);
-            float eps = e[k];
-            if (forced_row != nullptr && !deterministic) eps = forced_row[c];
-            av = deterministic ? hd[c] : hd[c] + sd * eps;
-            const float d = av - hd[c];
-            // Normal.log_prob: -(x-mu)^2/(2 var) - log(sd) - log(sqrt(2 pi))
-            lp = -(d * d) / (2.f * (sd * sd)) - ls - 0.91893853320467274178f;
-          }
-          act_out[c] = av;
-          logp_out[c] = lp;
-        }
-      }
-    }
-  }
-}
 
 template <int NO, int HEAD>
 __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {

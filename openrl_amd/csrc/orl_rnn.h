@@ -1,0 +1,259 @@
+// orl_rnn.h - layouts and wave-level primitives of the recurrent (GRU) towers for gfx950
+// (use_recurrent_policy: openrl/modules/networks/utils/rnn.py:5-99).
+//
+// Everything stays in the T layout of orl_mlp.h (16 batch rows per wavefront, features down the MFMA M
+// dimension), so the GRU's six 64x64 GEMMs chain straight off the trunk's C fragments:
+//   r = sigma(Wir x + bir + Whr h + bhr),  z = sigma(Wiz x + biz + Whz h + bhz),
+//   n = tanh(Win x + bin + r * (Whn h + bhn)),  h' = (1 - z) * n + z * h          (torch.nn.GRU, gates r,z,n)
+#pragma once
+#include "orl_common.h"
+#include "orl_mlp.h"
+
+namespace orl {
+
+// ---- parameter order of a recurrent tower (reference model.parameters()) ---------------------------------
+struct RnnLayout {
+  int D, H, n_out, head;
+  int oW1, ob1, og1, obe1, oW2, ob2, og2, obe2, oWih, oWhh, obih, obhh, og3, obe3, oW3, ob3, ologstd, total;
+  __host__ __device__ RnnLayout() {}
+  __host__ __device__ explicit RnnLayout(const orl_net_desc& n) {
+    D = n.obs_dim; H = n.hidden; n_out = n.n_out; head = n.head_kind;
+    int o = 0;
+    oW1 = o; o += H * D;
+    ob1 = o; o += H;
+    og1 = o; o += H;
+    obe1 = o; o += H;
+    oW2 = o; o += H * H;
+    ob2 = o; o += H;
+    og2 = o; o += H;
+    obe2 = o; o += H;
+    oWih = o; o += 3 * H * H;
+    oWhh = o; o += 3 * H * H;
+    obih = o; o += 3 * H;
+    obhh = o; o += 3 * H;
+    og3 = o; o += H;
+    obe3 = o; o += H;
+    oW3 = o; o += n_out * H;
+    ob3 = o; o += n_out;
+    ologstd = o;
+    if (head == ORL_HEAD_GAUSSIAN) o += n_out;
+    total = o;
+  }
+};
+
+// Raw sums the update accumulates for one recurrent tower (delta = gradient w.r.t. a pre-activation):
+//   P1[H*D]   = sum dz1 (x) obs                     = dW1
+//   S2[H*H]   = sum dz2 (x) xhat1                   (dW2 = g1*S2 + be1*db2;  dg1 = sum_o W2*S2, dbe1 = W2^T db2)
+//   S3[3H*H]  = sum [dr,dz,dn] (x) xhat2            (dWih = g2*S3 + be2*dbih; dg2 = sum_o Wih*S3, dbe2 = Wih^T dbih)
+//   P4[3H*H]  = sum [dr,dz,dghn] (x) h_in           = dWhh
+//   S5[K*H]   = sum dhead (x) xhat3                 (dW3 = g3*S5 + be3*db3;  dg3 = sum_c W3*S5, dbe3 = W3^T db3)
+//   db1[H] db2[H] dbih[3H] dbhh[3H] db3[K] | dlogstd[K]
+// The LayerNorm-affine gradients are linear images of these (same argument as RawLayout in orl_common.h).
+struct RnnRaw {
+  int oP1, oS2, oS3, oP4, oS5, odb1, odb2, odbih, odbhh, odb3, odlogstd, total, n_logstd;
+  __host__ __device__ RnnRaw() {}
+  __host__ __device__ explicit RnnRaw(const orl_net_desc& n) {
+    const int H = n.hidden, D = n.obs_dim, K = n.n_out;
+    int o = 0;
+    oP1 = o; o += H * D;
+    oS2 = o; o += H * H;
+    oS3 = o; o += 3 * H * H;
+    oP4 = o; o += 3 * H * H;
+    oS5 = o; o += K * H;
+    odb1 = o; o += H;
+    odb2 = o; o += H;
+    odbih = o; o += 3 * H;
+    odbhh = o; o += 3 * H;
+    odb3 = o; o += K;
+    odlogstd = o;
+    n_logstd = (n.head_kind == ORL_HEAD_GAUSSIAN ? K : 0);
+    o += n_logstd;
+    total = o;
+  }
+};
+
+// ---- LDS image of a recurrent tower (row kernel): 64x64 blocks padded to W2S columns ----------------------
+struct RnnLds {
+  int DP, W1, b1, g1, be1, W2, b2, g2, be2, Wih, Whh, bih, bhh, g3, be3, W3, b3, logstd, total;
+  __host__ __device__ RnnLds() {}
+  __host__ __device__ RnnLds(int D, int n_out, bool gaussian) {
+    DP = (D + 3) & ~3;
+    const int no4 = (n_out + 3) & ~3;
+    int o = 0;
+    W1 = o; o += HID * DP;
+    b1 = o; o += HID;
+    g1 = o; o += HID;
+    be1 = o; o += HID;
+    W2 = o; o += HID * W2S;
+    b2 = o; o += HID;
+    g2 = o; o += HID;
+    be2 = o; o += HID;
+    Wih = o; o += 3 * HID * W2S;
+    Whh = o; o += 3 * HID * W2S;
+    bih = o; o += 3 * HID;
+    bhh = o; o += 3 * HID;
+    g3 = o; o += HID;
+    be3 = o; o += HID;
+    W3 = o; o += no4 * HID;
+    b3 = o; o += no4;
+    logstd = o; o += gaussian ? no4 : 0;
+    total = o;
+  }
+};
+
+__device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __restrict__ theta, const RnnLayout& tl,
+                                       const RnnLds& tw, int tid, int nthreads) {
+  const int D = tl.D;
+  for (int e = tid; e < HID * tw.DP; e += nthreads) {
+    const int f = e / tw.DP, k = e - f * tw.DP;
+    lds[tw.W1 + e] = (k < D) ? theta[tl.oW1 + f * D + k] : 0.f;
+  }
+  for (int e = tid; e < HID; e += nthreads) {
+    lds[tw.b1 + e] = theta[tl.ob1 + e];
+    lds[tw.g1 + e] = theta[tl.og1 + e];
+    lds[tw.be1 + e] = theta[tl.obe1 + e];
+    lds[tw.b2 + e] = theta[tl.ob2 + e];
+    lds[tw.g2 + e] = theta[tl.og2 + e];
+    lds[tw.be2 + e] = theta[tl.obe2 + e];
+    lds[tw.g3 + e] = theta[tl.og3 + e];
+    lds[tw.be3 + e] = theta[tl.obe3 + e];
+  }
+  for (int e = tid; e < 3 * HID; e += nthreads) {
+    lds[tw.bih + e] = theta[tl.obih + e];
+    lds[tw.bhh + e] = theta[tl.obhh + e];
+  }
+  for (int e = tid; e < HID * HID; e += nthreads) lds[tw.W2 + (e >> 6) * W2S + (e & 63)] = theta[tl.oW2 + e];
+  for (int e = tid; e < 3 * HID * HID; e += nthreads) {
+    lds[tw.Wih + (e >> 6) * W2S + (e & 63)] = theta[tl.oWih + e];
+    lds[tw.Whh + (e >> 6) * W2S + (e & 63)] = theta[tl.oWhh + e];
+  }
+  const int no4 = (tl.n_out + 3) & ~3;
+  for (int e = tid; e < no4 * HID; e += nthreads) lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] : 0.f;
+  for (int e = tid; e < no4; e += nthreads) {
+    lds[tw.b3 + e] = (e < tl.n_out) ? theta[tl.ob3 + e] : 0.f;
+    if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = (e < tl.n_out) ? theta[tl.ologstd + e] : 0.f;
+  }
+}
+
+// acc += W[64 x 64, row stride S] * in   (T layout; S = W2S for the LDS image, 64 for weights read from global)
+template <int S>
+__device__ inline void mm64_S(const float* __restrict__ Ws, const f32x4 (&in)[4], f32x4 (&acc)[4], int j, int q) {
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    f32x4 a4[4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) a4[mo] = *(const f32x4*)(Ws + (16 * mo + j) * S + 16 * mi + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(a4[mo][r], in[mi][r], acc[mo]);
+    }
+  }
+}
+
+// acc += W^T in  with W row-major [64][S] read by columns (dgrad)
+template <int S>
+__device__ inline void mm64_S_wt(const float* __restrict__ Ws, const f32x4 (&in)[4], f32x4 (&acc)[4], int j, int q) {
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row = Ws + (16 * mi + 4 * q + r) * S + j;
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(row[16 * mo], in[mi][r], acc[mo]);
+    }
+  }
+}
+
+// fc1 with W1 read from GLOBAL memory (row stride D, no padding)
+template <class XB>
+__device__ inline void fc1_g(const float* __restrict__ W1, int D, XB xb, f32x4 (&acc)[4], int j, int q) {
+  for (int s = 0; 4 * s < D; ++s) {
+    const float b = xb(s);
+    const int k = 4 * s + q;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float a = (k < D) ? W1[(16 * m + j) * D + k] : 0.f;
+      acc[m] = ORL_MFMA(a, b, acc[m]);
+    }
+  }
+}
+
+__device__ inline float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// LayerNorm backward in T layout, in place: d <- rstd * (d*g - mean(d*g) - xhat * mean(d*g*xhat))
+__device__ inline void ln_bwd_rnn(f32x4 (&d)[4], const f32x4 (&xhat)[4], const float* __restrict__ g, float rstd,
+                                  int q) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const f32x4 gg = *(const f32x4*)(g + 16 * m + 4 * q);
+    d[m] = d[m] * gg;
+    const f32x4 t = d[m] * xhat[m];
+    s1 += (d[m][0] + d[m][1]) + (d[m][2] + d[m][3]);
+    s2 += (t[0] + t[1]) + (t[2] + t[3]);
+  }
+  s1 = row_allsum(s1);
+  s2 = row_allsum(s2);
+  const float c1 = s1 * (1.0f / 64.0f), c2 = s2 * (1.0f / 64.0f);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) d[m] = (d[m] - c1 - xhat[m] * c2) * rstd;
+}
+
+// One GRU step in T layout.  Wih/Whh: three stacked 64 x 64 blocks (r, z, n) with row stride S; bih/bhh [192].
+// Outputs the gates (needed by the backward pass) and h' = (1-z)*n + z*hin.
+template <int S>
+__device__ inline void gru_fwd_T(const float* __restrict__ Wih, const float* __restrict__ Whh,
+                                 const float* __restrict__ bih, const float* __restrict__ bhh, const f32x4 (&x)[4],
+                                 const f32x4 (&hin)[4], f32x4 (&r)[4], f32x4 (&z)[4], f32x4 (&n)[4], f32x4 (&ghn)[4],
+                                 f32x4 (&hnew)[4], int j, int q) {
+  f32x4 t[4];
+  load_vec_T(bih, q, r);
+  load_vec_T(bhh, q, t);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) r[m] += t[m];
+  mm64_S<S>(Wih, x, r, j, q);
+  mm64_S<S>(Whh, hin, r, j, q);
+  load_vec_T(bih + HID, q, z);
+  load_vec_T(bhh + HID, q, t);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) z[m] += t[m];
+  mm64_S<S>(Wih + HID * S, x, z, j, q);
+  mm64_S<S>(Whh + HID * S, hin, z, j, q);
+  load_vec_T(bih + 2 * HID, q, n);
+  mm64_S<S>(Wih + 2 * HID * S, x, n, j, q);
+  load_vec_T(bhh + 2 * HID, q, ghn);
+  mm64_S<S>(Whh + 2 * HID * S, hin, ghn, j, q);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float rr = sigmoid_f(r[m][k]);
+      const float zz = sigmoid_f(z[m][k]);
+      const float nn = tanhf(n[m][k] + rr * ghn[m][k]);
+      r[m][k] = rr;
+      z[m][k] = zz;
+      n[m][k] = nn;
+      hnew[m][k] = (1.0f - zz) * nn + zz * hin[m][k];
+    }
+}
+
+// ---- wgrad tape ---------------------------------------------------------------------------------------------
+// One block per (tile, step): 10 activation vectors of 16 rows x 64 features, the head deltas (16 x 16) and the
+// observation tile (16 x 16*ND).  Element (row, feature f = 16m + 4qq + r) of a 64-wide vector sits at float
+//     ((m*4 + qq)*16 + ((row + 4*qq) & 15))*4 + r
+// i.e. the writer's own register layout with the 16 rows of each qq group rotated by 4*qq: the row kernel's
+// stores stay 1 KiB-contiguous per m, and the wgrad kernel's 4-byte MFMA operand reads (16 consecutive features
+// x 4 rows per instruction) fall on 32 distinct LDS banks.
+constexpr int TV = 1024;  // floats per 64-wide vector
+enum { TV_DZ1 = 0, TV_DZ2, TV_DR, TV_DZ, TV_DN, TV_DGHN, TV_XH1, TV_XH2, TV_HIN, TV_XH3, TV_NVEC };
+constexpr int TAPE_HEAD = TV_NVEC * TV;  // head deltas: 256 floats
+constexpr int TAPE_X = TAPE_HEAD + 256;  // observation m-blocks: ND * 256 floats
+__host__ __device__ inline int tape_block_floats(int D) { return TAPE_X + ((D + 15) >> 4) * 256; }
+
+__device__ inline void tape_store(float* __restrict__ v, const f32x4 (&x)[4], int j, int q) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) *(f32x4*)(v + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4) = x[m];
+}
+
+}  // namespace orl

@@ -1,0 +1,872 @@
+// orl_rnn.hip - recurrent (GRU) branch of the hot path for gfx950 (use_recurrent_policy):
+//   orl_rnn_act_step    : policy + value forward with hidden states and action sampling (rollout)
+//   orl_rnn_chunk_rows  : recurrent_generator index arithmetic (chunks of data_chunk_length rows)
+//   orl_rnn_ppo_fwd_bwd : per tower  (1) ROW kernel - forward over the L steps of 16 chunks per wavefront, PPO /
+//                         value loss, back-propagation through time with the forward recomputed per step; every
+//                         pre-activation gradient and layer input goes to a TAPE in HBM;  (2) WGRAD kernel - all
+//                         weight gradients as one K = rows GEMM sweep over the tape (fp32 MFMA, accumulators in
+//                         registers, 8 waves own disjoint output tiles);  then deterministic reductions
+//   orl_rnn_ppo_apply   : raw sums -> gradients (LayerNorm-affine grads as dot products), clip, Adam
+//
+// Why a tape instead of the register-resident wgrad of orl_ppo_tower.h: the GRU adds 2 x 192 x 64 weights, i.e.
+// 384 accumulator registers per lane on top of the 64 of W2 - they do not fit a wavefront.  Spread over the 8
+// waves of a workgroup they do (<= 80 each), but then every wave needs every row's deltas: the tape is that
+// exchange, sized for HBM3E (2.9 KB per row-step, written and read once per epoch).
+#include <stdlib.h>
+#include "orl_common.h"
+#include "orl_mlp.h"
+#include "orl_heads.h"
+#include "orl_loss.h"
+#include "orl_rnn.h"
+
+namespace orl {
+
+// =====================================================================================================
+// rollout step
+// =====================================================================================================
+struct RnnActArgs {
+  orl_net_desc pnet, cnet;
+  const float *ptheta, *ctheta, *pobs, *cobs, *hp_in, *hc_in, *masks, *amask, *forced;
+  float *values, *actions, *logp, *hp_out, *hc_out;
+  int B, deterministic;
+  uint64_t seed, row0, rng_step;
+};
+
+// base -> GRU -> LayerNorm with every weight read straight from global memory (L2 resident; a rollout step
+// touches each weight once per 16-row tile, staging 140 KB into LDS first would cost the same traffic)
+template <class XB>
+__device__ inline void rnn_tower_fwd_g(const float* __restrict__ th, const RnnLayout& tl, XB xb, const f32x4 (&hin)[4],
+                                       f32x4 (&hnew)[4], f32x4 (&n3)[4], int j, int q) {
+  f32x4 z[4], n1[4], n2[4];
+  float rstd;
+  load_vec_T(th + tl.ob1, q, z);
+  fc1_g(th + tl.oW1, tl.D, xb, z, j, q);
+  relu_T(z);
+  ln_normalize_T(z, rstd);
+  ln_affine_T(z, th + tl.og1, th + tl.obe1, q, n1);
+  load_vec_T(th + tl.ob2, q, z);
+  mm64_S<64>(th + tl.oW2, n1, z, j, q);
+  ln_normalize_T(z, rstd);
+  ln_affine_T(z, th + tl.og2, th + tl.obe2, q, n2);
+  f32x4 r[4], zz[4], n[4], g[4];
+  gru_fwd_T<64>(th + tl.oWih, th + tl.oWhh, th + tl.obih, th + tl.obhh, n2, hin, r, zz, n, g, hnew, j, q);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) z[m] = hnew[m];
+  ln_normalize_T(z, rstd);
+  ln_affine_T(z, th + tl.og3, th + tl.obe3, q, n3);
+}
+
+template <int NO, int HEAD>
+__global__ __launch_bounds__(128) void rnn_act_kernel(RnnActArgs A) {
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int row = blockIdx.x * TILE_B + j;
+  const bool row_ok = row < A.B;
+  const int rr = row_ok ? row : 0;
+  const float mk = A.masks[rr];
+  const bool pol = wave == 0;
+  if (pol ? (A.ptheta == nullptr) : (A.ctheta == nullptr)) return;
+  const RnnLayout tl(pol ? A.pnet : A.cnet);
+  const float* th = pol ? A.ptheta : A.ctheta;
+  const float* xrow = (pol ? A.pobs : A.cobs) + (size_t)rr * tl.D;
+  const float* hrow = (pol ? A.hp_in : A.hc_in) + (size_t)rr * HID;
+  float* hout = (pol ? A.hp_out : A.hc_out) + (size_t)rr * HID;
+  const int D = tl.D;
+  auto xb = [&](int s) -> float {
+    const int k = 4 * s + q;
+    return (k < D) ? xrow[k] : 0.f;
+  };
+  f32x4 hin[4], hnew[4], n3[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) hin[m] = *(const f32x4*)(hrow + 16 * m + 4 * q) * mk;
+  rnn_tower_fwd_g(th, tl, xb, hin, hnew, n3, j, q);
+  if (row_ok) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) *(f32x4*)(hout + 16 * m + 4 * q) = hnew[m];
+  }
+  if (pol) {
+    float hd[NO];
+    head_T<NO>(th + tl.oW3, th + tl.ob3, tl.n_out, n3, q, hd);
+    const int n_out = tl.n_out;
+    const int a_w = (HEAD == ORL_HEAD_CATEGORICAL) ? 1 : n_out;
+    float act_o[NO], lp_o[NO];
+    const float* am = (A.amask != nullptr && row_ok) ? A.amask + (size_t)row * n_out : nullptr;
+    const float* fr = (A.forced != nullptr && row_ok) ? A.forced + (size_t)row * a_w : nullptr;
+    sample_head<NO, HEAD>(hd, n_out, th + tl.ologstd, am, fr, A.deterministic, A.seed, A.row0 + (uint64_t)row,
+                          A.rng_step, act_o, lp_o);
+    if (row_ok && q == 0) {
+#pragma unroll
+      for (int c = 0; c < NO; ++c) {
+        if (c < a_w) {
+          A.actions[(size_t)row * a_w + c] = act_o[c];
+          A.logp[(size_t)row * a_w + c] = lp_o[c];
+        }
+      }
+    }
+  } else {
+    float v[1];
+    head_T<1>(th + tl.oW3, th + tl.ob3, 1, n3, q, v);
+    if (row_ok && q == 0) A.values[row] = v[0];
+  }
+}
+
+// =====================================================================================================
+// recurrent_generator rows
+// =====================================================================================================
+__global__ void rnn_chunk_rows_kernel(const int64_t* __restrict__ chunk_idx, int n_chunks, int L, int T, int lanes,
+                                      int64_t* __restrict__ rows) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_chunks * L) return;
+  const int l = e / n_chunks, i = e - l * n_chunks;
+  const int64_t c = chunk_idx ? chunk_idx[i] : (int64_t)i;
+  const int64_t r = c * L + l;  // row of the [lane][t]-ordered flat batch (_cast, buffers/utils/util.py:96-97)
+  const int64_t lane = r / T, t = r - lane * T;
+  rows[e] = t * lanes + lane;
+}
+
+// =====================================================================================================
+// update: row kernel
+// =====================================================================================================
+constexpr int RNN_ROW_BLOCKS = 256;
+constexpr int RNN_WG_BLOCKS = 512;
+
+struct RnnRowArgs {
+  orl_net_desc net;
+  const float* theta;
+  const float* records;
+  const int64_t* rows;  // [L][Nc]
+  const float* masks;
+  const float* hbuf;    // [T+1, lanes, H] stored states of this tower
+  const float* vn_state;
+  float* htape;         // [n_tiles*L][1024]   pre-mask input state of every step
+  float* tape;          // [n_tiles*L][tape_block_floats]
+  float* partials;      // [gridDim][n_logstd + ORL_N_STATS]
+  orl_ppo_hparams hp;
+  LossCols cols;
+  int R, o_x, Nc, L;
+};
+
+template <int HEAD, int NO>
+__global__ __launch_bounds__(512, 2) void rnn_row_kernel(RnnRowArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const RnnLayout tl(A.net);
+  const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN);
+  stage_rnn_tower(smem, A.theta, tl, tw, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const float* lw = smem;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int D = A.net.obs_dim, n_out = A.net.n_out, DP = tw.DP;
+  const int Nc = A.Nc, L = A.L;
+  const orl_ppo_hparams hp = A.hp;
+  const int BLK = tape_block_floats(D);
+  const int ND = (D + 15) >> 4;
+
+  float vn_mean = 0.f, vn_sd = 1.f;
+  if (HEAD == ORL_HEAD_VALUE && hp.use_valuenorm && A.vn_state != nullptr) {
+    const float deb = fmaxf(A.vn_state[2], 1e-5f);
+    vn_mean = A.vn_state[0] / deb;
+    const float msq = A.vn_state[1] / deb;
+    vn_sd = sqrtf(fmaxf(msq - vn_mean * vn_mean, 1e-2f));
+  }
+  LossStats st = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float a_dls[NO];
+#pragma unroll
+  for (int c = 0; c < NO; ++c) a_dls[c] = 0.f;
+
+  const int n_tiles = (Nc + TILE_B - 1) / TILE_B;
+  const int nwv = blockDim.x >> 6;
+  for (int tile = blockIdx.x * nwv + wave; tile < n_tiles; tile += gridDim.x * nwv) {
+    const int ci = tile * TILE_B + j;
+    const bool valid = ci < Nc;
+    const int cis = valid ? ci : 0;  // padding lanes shadow chunk 0: finite data, zero loss weight
+    // trunk forward of one record row; keeps what the backward pass needs when KEEP
+    auto trunk = [&](const float* rec, f32x4 (&xh1)[4], float& rstd1, unsigned& relu_bits, f32x4 (&xh2)[4],
+                     float& rstd2, f32x4 (&n2)[4]) {
+      f32x4 n1[4];
+      load_vec_T(lw + tw.b1, q, xh1);
+      fc1_T(lw + tw.W1, DP, [&](int s) -> float {
+        const int k = 4 * s + q;
+        return k < D ? rec[A.o_x + k] : 0.f;
+      }, xh1, j, q);
+      relu_bits = 0u;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (xh1[m][r] > 0.f) relu_bits |= 1u << (4 * m + r);
+          xh1[m][r] = fmaxf(xh1[m][r], 0.f);
+        }
+      ln_normalize_T(xh1, rstd1);
+      ln_affine_T(xh1, lw + tw.g1, lw + tw.be1, q, n1);
+      load_vec_T(lw + tw.b2, q, xh2);
+      mm64_T(lw + tw.W2, n1, xh2, j, q);
+      ln_normalize_T(xh2, rstd2);
+      ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, n2);
+    };
+
+    // ---------------- forward sweep: hidden state entering every step -> htape ----------------
+    {
+      f32x4 h[4];
+      const float* h0 = A.hbuf + (size_t)A.rows[cis] * HID;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(h0 + 16 * m + 4 * q);
+      for (int s = 0; s < L; ++s) {
+        float* ht = A.htape + ((size_t)tile * L + s) * TV;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) *(f32x4*)(ht + (m * 64 + l) * 4) = h[m];
+        if (s == L - 1) break;
+        const long long row = A.rows[(size_t)s * Nc + cis];
+        const float mk = A.masks[row];
+        f32x4 hin[4], xh1[4], xh2[4], n2[4], r[4], z[4], n[4], g[4];
+        float r1, r2;
+        unsigned rb;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hin[m] = h[m] * mk;
+        trunk(A.records + (size_t)row * A.R, xh1, r1, rb, xh2, r2, n2);
+        gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin, r, z, n, g, h, j, q);
+      }
+    }
+
+    // ---------------- backward sweep (BPTT), forward recomputed per step ----------------
+    f32x4 carry[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) carry[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = L - 1; s >= 0; --s) {
+      const long long row = A.rows[(size_t)s * Nc + cis];
+      const float* rec = A.records + (size_t)row * A.R;
+      const float mk = A.masks[row];
+      float* tb = A.tape + ((size_t)tile * L + s) * BLK;
+      f32x4 hin[4];
+      {
+        const float* ht = A.htape + ((size_t)tile * L + s) * TV;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hin[m] = *(const f32x4*)(ht + (m * 64 + l) * 4) * mk;
+      }
+      tape_store(tb + TV_HIN * TV, hin, j, q);
+      float rstd1, rstd2, rstd3;
+      unsigned relu_bits;
+      f32x4 gr[4], gz[4], gn[4], ghn[4];
+      float dh[NO], dls[NO];
+      {
+        f32x4 xh1[4], xh2[4], n2[4], hnew[4];
+        trunk(rec, xh1, rstd1, relu_bits, xh2, rstd2, n2);
+        tape_store(tb + TV_XH1 * TV, xh1, j, q);
+        tape_store(tb + TV_XH2 * TV, xh2, j, q);
+        gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin, gr, gz, gn, ghn, hnew, j, q);
+        ln_normalize_T(hnew, rstd3);  // hnew = xhat3
+        tape_store(tb + TV_XH3 * TV, hnew, j, q);
+        f32x4 n3[4];
+        ln_affine_T(hnew, lw + tw.g3, lw + tw.be3, q, n3);
+        float hd[NO];
+        head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, n3, q, hd);
+        ppo_row_loss<HEAD, NO>(hd, n_out, valid, [&](int col) -> float { return rec[col]; }, A.cols, hp, vn_mean,
+                               vn_sd, lw + tw.logstd, dh, dls, st, q == 0);
+        if (q == 0) {
+#pragma unroll
+          for (int c = 0; c < NO; ++c) a_dls[c] += dls[c];
+        }
+      }
+      // head deltas -> tape (16-wide vector: lane (j,q) owns columns 4q..4q+3)
+      {
+        f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NO; ++c)
+          if ((c >> 2) == q) dv[c & 3] = dh[c];
+        *(f32x4*)(tb + TAPE_HEAD + (q * 16 + ((j + 4 * q) & 15)) * 4) = dv;
+      }
+      // observation tile -> tape
+      for (int m = 0; m < ND; ++m) {
+        f32x4 xv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * m + 4 * q + r;
+          xv[r] = f < D ? rec[A.o_x + f] : 0.f;
+        }
+        *(f32x4*)(tb + TAPE_X + m * 256 + (q * 16 + ((j + 4 * q) & 15)) * 4) = xv;
+      }
+      // d(features) = W3^T dhead, LN3 backward, + gradient carried from step s+1
+      f32x4 dt[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) dt[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NO; ++c) {
+        if (c < n_out) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) dt[m] += *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q) * dh[c];
+        }
+      }
+      {
+        f32x4 xh3[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xh3[m] = *(const f32x4*)(tb + TV_XH3 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        ln_bwd_rnn(dt, xh3, lw + tw.g3, rstd3, q);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) dt[m] += carry[m];
+      // GRU cell backward (elementwise part); gr/gz/gn/ghn become dr/dz/dn/dghn, carry collects dt*z
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float rr = gr[m][k], zz = gz[m][k], nn = gn[m][k], gg = ghn[m][k], d = dt[m][k], hh = hin[m][k];
+          const float dn_pre = d * (1.0f - zz) * (1.0f - nn * nn);
+          const float dz_pre = d * (hh - nn) * zz * (1.0f - zz);
+          const float dr_pre = dn_pre * gg * rr * (1.0f - rr);
+          gr[m][k] = dr_pre;
+          gz[m][k] = dz_pre;
+          gn[m][k] = dn_pre;
+          ghn[m][k] = dn_pre * rr;
+          carry[m][k] = d * zz;
+        }
+      tape_store(tb + TV_DR * TV, gr, j, q);
+      tape_store(tb + TV_DZ * TV, gz, j, q);
+      tape_store(tb + TV_DN * TV, gn, j, q);
+      tape_store(tb + TV_DGHN * TV, ghn, j, q);
+      // dgrad through the hidden-to-hidden weights -> carry ; through the input weights -> dn2
+      mm64_S_wt<W2S>(lw + tw.Whh, gr, carry, j, q);
+      mm64_S_wt<W2S>(lw + tw.Whh + HID * W2S, gz, carry, j, q);
+      mm64_S_wt<W2S>(lw + tw.Whh + 2 * HID * W2S, ghn, carry, j, q);
+      f32x4 d2[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) d2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mm64_S_wt<W2S>(lw + tw.Wih, gr, d2, j, q);
+      mm64_S_wt<W2S>(lw + tw.Wih + HID * W2S, gz, d2, j, q);
+      mm64_S_wt<W2S>(lw + tw.Wih + 2 * HID * W2S, gn, d2, j, q);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) carry[m] = carry[m] * mk;  // h_in = h * mask
+      // LN2 backward -> dz2
+      {
+        f32x4 xh2[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xh2[m] = *(const f32x4*)(tb + TV_XH2 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        ln_bwd_rnn(d2, xh2, lw + tw.g2, rstd2, q);
+      }
+      tape_store(tb + TV_DZ2 * TV, d2, j, q);
+      // dn1 = W2^T dz2, LN1 backward, relu backward -> dz1
+      f32x4 d1[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mm64_S_wt<W2S>(lw + tw.W2, d2, d1, j, q);
+      {
+        f32x4 xh1[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xh1[m] = *(const f32x4*)(tb + TV_XH1 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        ln_bwd_rnn(d1, xh1, lw + tw.g1, rstd1, q);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (!((relu_bits >> (4 * m + r)) & 1u)) d1[m][r] = 0.f;
+      tape_store(tb + TV_DZ1 * TV, d1, j, q);
+    }
+  }
+
+  // ---- workgroup reduction of {dlogstd, stats}: fixed order ------------------------------------------
+  __syncthreads();
+  float* acc = smem;  // weights are dead
+  const int PW = RnnRaw(A.net).n_logstd + ORL_N_STATS;
+  const int nls = PW - ORL_N_STATS;
+  for (int e = threadIdx.x; e < PW; e += blockDim.x) acc[e] = 0.f;
+  __syncthreads();
+  st.active = wave_sum(st.active); st.rows = wave_sum(st.rows); st.loss = wave_sum(st.loss);
+  st.ent = wave_sum(st.ent); st.ratio = wave_sum(st.ratio);
+#pragma unroll
+  for (int c = 0; c < NO; ++c) a_dls[c] = wave_sum(a_dls[c]);
+  for (int w = 0; w < nwv; ++w) {
+    if (wave == w && l == 0) {
+#pragma unroll
+      for (int c = 0; c < NO; ++c)
+        if (c < nls) acc[c] += a_dls[c];
+      acc[nls + ST_ACTIVE_SUM] += st.active;
+      acc[nls + ST_ROWS] += st.rows;
+      if (HEAD == ORL_HEAD_VALUE) acc[nls + ST_VLOSS_SUM] += st.loss;
+      else {
+        acc[nls + ST_PLOSS_SUM] += st.loss;
+        acc[nls + ST_ENT_SUM] += st.ent;
+        acc[nls + ST_RATIO_SUM] += st.ratio;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < PW; e += blockDim.x) A.partials[(size_t)blockIdx.x * PW + e] = acc[e];
+}
+
+// =====================================================================================================
+// update: weight-gradient GEMM over the tape
+// =====================================================================================================
+struct RnnWgArgs {
+  orl_net_desc net;
+  const float* tape;
+  float* partials;  // [gridDim][raw.total - n_logstd]
+  int n_blocks;     // tape blocks (tile-steps)
+};
+
+// MFMA operand of feature tile `m` of a staged 64-wide vector for k-step s (rows 4s..4s+3), lane (c, q)
+__device__ inline float tape_opnd(const float* __restrict__ v, int m, int s, int c, int q) {
+  const int qq = c >> 2;
+  return v[((m * 4 + qq) * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3)];
+}
+
+__global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float blk[];
+  const RnnRaw rl(A.net);
+  const int D = A.net.obs_dim, K = A.net.n_out;
+  const int ND = (D + 15) >> 4;
+  const int BLK = tape_block_floats(D);
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 15, q = l >> 4;
+  // waves 0-6: one 64 x 64 product each; wave 7: dz1 x obs (4 x ND tiles) and dhead x xhat3 (1 x 4 tiles)
+  //   wave   0        1        2        3        4        5          6
+  //   delta  dr       dz       dn       dr       dz       dghn       dz2
+  //   input  xhat2    xhat2    xhat2    h_in     h_in     h_in       xhat1
+  const int g3 = wave < 3 ? wave : wave - 3;  // gate block of waves 0-5
+  const int dv = wave == 6 ? TV_DZ2 : wave == 7 ? TV_DZ1 : (g3 == 0 ? TV_DR : g3 == 1 ? TV_DZ : wave == 2 ? TV_DN : TV_DGHN);
+  const int iv = wave == 6 ? TV_XH1 : wave < 3 ? TV_XH2 : TV_HIN;
+  f32x4 G[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 G5[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) G5[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;  // column sum of delta column `threadIdx.x` (threads 0..399)
+
+  for (int b = blockIdx.x; b < A.n_blocks; b += gridDim.x) {
+    const f32x4* src = (const f32x4*)(A.tape + (size_t)b * BLK);
+    __syncthreads();  // previous block fully consumed
+    for (int e = threadIdx.x; e < (BLK >> 2); e += blockDim.x) ((f32x4*)blk)[e] = src[e];
+    __syncthreads();
+    if (wave < 7) {
+      const float* dvp = blk + dv * TV;
+      const float* ivp = blk + iv * TV;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          av[m] = tape_opnd(dvp, m, s, c, q);
+          bv[m] = tape_opnd(ivp, m, s, c, q);
+        }
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) G[mo][mi] = ORL_MFMA(av[mo], bv[mi], G[mo][mi]);
+      }
+    } else {
+      const float* dvp = blk + TV_DZ1 * TV;
+      const float* xp = blk + TAPE_X;       // ND m-blocks of 256 floats, same (qq,row,r) layout
+      const float* hp = blk + TAPE_HEAD;    // one m-block
+      const float* x3 = blk + TV_XH3 * TV;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float av[4], bv[4], b3[4];
+        const int qq = c >> 2;
+        const int off = (qq * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          av[m] = tape_opnd(dvp, m, s, c, q);
+          bv[m] = m < ND ? xp[m * 256 + off] : 0.f;
+          b3[m] = tape_opnd(x3, m, s, c, q);
+        }
+        const float ah = hp[off];
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            if (mi < ND) G[mo][mi] = ORL_MFMA(av[mo], bv[mi], G[mo][mi]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) G5[mi] = ORL_MFMA(ah, b3[mi], G5[mi]);
+      }
+    }
+    // bias gradients: column sums of the six delta vectors (384 columns) and of the head deltas (16)
+    if (threadIdx.x < 400) {
+      const int t = threadIdx.x;
+      const float* base;
+      int f;
+      if (t < 384) { base = blk + (t >> 6) * TV; f = t & 63; }
+      else { base = blk + TAPE_HEAD; f = t - 384; }
+      const float* p = base + (((f >> 4) * 4 + ((f >> 2) & 3)) * 16) * 4 + (f & 3);
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += p[4 * r];
+      bsum += s;
+    }
+  }
+
+  // ---- write this workgroup's partial row: every wave owns disjoint outputs --------------------------
+  const int PW = rl.total - rl.n_logstd;
+  float* out = A.partials + (size_t)blockIdx.x * PW;
+  // C fragment: lane (c, q), reg r -> out row 16*mo + 4q + r, in column 16*mi + c
+  if (wave < 7) {
+    float* o = out + (wave == 6 ? rl.oS2 : (wave < 3 ? rl.oS3 : rl.oP4) + g3 * 64 * 64);
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(16 * mo + 4 * q + r) * HID + 16 * mi + c] = G[mo][mi][r];
+  } else {
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * mi + c;
+          if (mi < ND && k < D) out[rl.oP1 + (16 * mo + 4 * q + r) * D + k] = G[mo][mi][r];
+        }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cc = 4 * q + r;
+        if (cc < K) out[rl.oS5 + cc * HID + 16 * mi + c] = G5[mi][r];
+      }
+  }
+  // bias sums: thread t < 384 holds column (vec = t/64, f = t%64); t in [384,400) head column
+  __syncthreads();
+  float* sh = blk;
+  if (threadIdx.x < 400) sh[threadIdx.x] = bsum;
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+    out[rl.odb1 + e] = sh[TV_DZ1 * 64 + e];
+    out[rl.odb2 + e] = sh[TV_DZ2 * 64 + e];
+  }
+  for (int e = threadIdx.x; e < 192; e += blockDim.x) {
+    const int g = e >> 6, f = e & 63;
+    const float rz = sh[(g == 0 ? TV_DR : TV_DZ) * 64 + f];
+    out[rl.odbih + e] = g < 2 ? rz : sh[TV_DN * 64 + f];
+    out[rl.odbhh + e] = g < 2 ? rz : sh[TV_DGHN * 64 + f];
+  }
+  for (int e = threadIdx.x; e < K; e += blockDim.x) out[rl.odb3 + e] = sh[384 + e];
+}
+
+// =====================================================================================================
+// apply
+// =====================================================================================================
+struct RnnApplyTower {
+  orl_net_desc net;
+  orl_adam_state ad;
+  const float* raw;  // reduced raw sums of this tower, followed by the ORL_N_STATS stats
+};
+
+__device__ inline float rnn_raw_to_grad(const float* __restrict__ raw, const float* __restrict__ th, const RnnLayout& tl,
+                                        const RnnRaw& rl, int p, float inv_den) {
+  const int H = HID;
+  float g = 0.f;
+  if (p < tl.ob1) g = raw[rl.oP1 + (p - tl.oW1)];
+  else if (p < tl.og1) g = raw[rl.odb1 + (p - tl.ob1)];
+  else if (p < tl.obe1) {
+    const int i = p - tl.og1;
+    for (int o = 0; o < H; ++o) g += th[tl.oW2 + o * H + i] * raw[rl.oS2 + o * H + i];
+  } else if (p < tl.oW2) {
+    const int i = p - tl.obe1;
+    for (int o = 0; o < H; ++o) g += th[tl.oW2 + o * H + i] * raw[rl.odb2 + o];
+  } else if (p < tl.ob2) {
+    const int e = p - tl.oW2, o = e / H, i = e - o * H;
+    g = th[tl.og1 + i] * raw[rl.oS2 + e] + th[tl.obe1 + i] * raw[rl.odb2 + o];
+  } else if (p < tl.og2) g = raw[rl.odb2 + (p - tl.ob2)];
+  else if (p < tl.obe2) {
+    const int f = p - tl.og2;
+    for (int o = 0; o < 3 * H; ++o) g += th[tl.oWih + o * H + f] * raw[rl.oS3 + o * H + f];
+  } else if (p < tl.oWih) {
+    const int f = p - tl.obe2;
+    for (int o = 0; o < 3 * H; ++o) g += th[tl.oWih + o * H + f] * raw[rl.odbih + o];
+  } else if (p < tl.oWhh) {
+    const int e = p - tl.oWih, o = e / H, f = e - o * H;
+    g = th[tl.og2 + f] * raw[rl.oS3 + e] + th[tl.obe2 + f] * raw[rl.odbih + o];
+  } else if (p < tl.obih) g = raw[rl.oP4 + (p - tl.oWhh)];
+  else if (p < tl.obhh) g = raw[rl.odbih + (p - tl.obih)];
+  else if (p < tl.og3) g = raw[rl.odbhh + (p - tl.obhh)];
+  else if (p < tl.obe3) {
+    const int f = p - tl.og3;
+    for (int cc = 0; cc < tl.n_out; ++cc) g += th[tl.oW3 + cc * H + f] * raw[rl.oS5 + cc * H + f];
+  } else if (p < tl.oW3) {
+    const int f = p - tl.obe3;
+    for (int cc = 0; cc < tl.n_out; ++cc) g += th[tl.oW3 + cc * H + f] * raw[rl.odb3 + cc];
+  } else if (p < tl.ob3) {
+    const int e = p - tl.oW3, cc = e / H, f = e - cc * H;
+    g = th[tl.og3 + f] * raw[rl.oS5 + e] + th[tl.obe3 + f] * raw[rl.odb3 + cc];
+  } else if (p < tl.ologstd) g = raw[rl.odb3 + (p - tl.ob3)];
+  else g = raw[rl.odlogstd + (p - tl.ologstd)];
+  return g * inv_den;
+}
+
+// blockIdx.y = tower (0 policy, 1 critic); grad[p] and per-block sums of squares -> scratch[tower*256 + block]
+__global__ __launch_bounds__(256) void rnn_grad_kernel(RnnApplyTower P, RnnApplyTower Cc, orl_ppo_hparams hp,
+                                                       float* __restrict__ scratch) {
+  __shared__ float sh[4];
+  const RnnApplyTower& W = blockIdx.y == 0 ? P : Cc;
+  const RnnLayout tl(W.net);
+  const RnnRaw rl(W.net);
+  const float* stv = W.raw + rl.total;
+  const bool use_active = blockIdx.y == 0 ? hp.use_policy_active_masks : hp.use_value_active_masks;
+  const float inv_den = 1.0f / (use_active ? stv[ST_ACTIVE_SUM] : stv[ST_ROWS]);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  float g = 0.f;
+  if (p < tl.total) {
+    if (!(blockIdx.y == 0 && (hp.reserved & 1))) g = rnn_raw_to_grad(W.raw, W.ad.theta, tl, rl, p, inv_den);
+    W.ad.grad[p] = g;
+  }
+  float ss = wave_sum(g * g);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) scratch[blockIdx.y * 256 + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void rnn_adam_kernel(RnnApplyTower P, RnnApplyTower Cc, orl_ppo_hparams hp,
+                                                       const float* __restrict__ scratch, int nb_p, int nb_c,
+                                                       float* __restrict__ info) {
+  const int t = blockIdx.y;
+  const RnnApplyTower& W = t == 0 ? P : Cc;
+  const RnnLayout tl(W.net);
+  const RnnRaw rl(W.net);
+  const float* stv = W.raw + rl.total;
+  const int nb = t == 0 ? nb_p : nb_c;
+  if ((int)blockIdx.x >= nb) return;
+  float ss = 0.f;
+  for (int b = 0; b < nb; ++b) ss += scratch[t * 256 + b];  // same order in every block: identical norm
+  const float total = sqrtf(ss);
+  const bool off = t == 0 && (hp.reserved & 1);  // turn_on == False: no policy step (ppo.py:226-236)
+  if (!off) {
+    float coef = 1.f;
+    if (hp.use_max_grad_norm) coef = fminf(hp.max_grad_norm / (total + 1e-6f), 1.f);
+    const double b1d = 0.9, b2d = 0.999;
+    const float b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
+    const double bc1 = 1.0 - pow(b1d, (double)W.ad.step);
+    const double bc2 = 1.0 - pow(b2d, (double)W.ad.step);
+    const float step_size = (float)((double)W.ad.lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < tl.total) {
+      float g = W.ad.grad[p] * coef;
+      W.ad.grad[p] = g;
+      float th = W.ad.theta[p];
+      if (W.ad.weight_decay != 0.f) g += W.ad.weight_decay * th;
+      float m = W.ad.m[p], v = W.ad.v[p];
+      m = m + (g - m) * omb1;
+      v = v * b2 + omb2 * (g * g);
+      const float denom = sqrtf(v) / bc2_sqrt + W.ad.eps;
+      th = th - step_size * (m / denom);
+      W.ad.m[p] = m; W.ad.v[p] = v; W.ad.theta[p] = th;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && info != nullptr) {
+    if (t == 0) {
+      const float den_p = hp.use_policy_active_masks ? stv[ST_ACTIVE_SUM] : stv[ST_ROWS];
+      const bool gauss = P.net.head_kind == ORL_HEAD_GAUSSIAN;
+      float ent_den = den_p;
+      if (!hp.use_policy_active_masks && gauss) ent_den = den_p * (float)P.net.n_out;
+      info[1] += stv[ST_PLOSS_SUM] / den_p;
+      info[2] += stv[ST_ENT_SUM] / ent_den;
+      if (!off) info[3] += total;
+      info[5] += stv[ST_RATIO_SUM] / (stv[ST_ROWS] * (gauss ? (float)P.net.n_out : 1.f));
+    } else {
+      const float den_v = hp.use_value_active_masks ? stv[ST_ACTIVE_SUM] : stv[ST_ROWS];
+      info[0] += stv[ST_VLOSS_SUM] / den_v;
+      info[4] += total;
+    }
+  }
+}
+
+// ---- host helpers ------------------------------------------------------------------------------------
+static int check_rnn_net(const orl_net_desc* n, const char* who, bool value) {
+  if (!n) return fail(ORL_E_INVALID, "%s: null net descriptor", who);
+  if (n->hidden != HID) return fail(ORL_E_UNSUPPORTED, "%s: hidden_size %d not built (only 64)", who, n->hidden);
+  if (n->obs_dim < 1 || n->obs_dim > 64) return fail(ORL_E_UNSUPPORTED, "%s: obs_dim %d outside [1,64]", who, n->obs_dim);
+  if (n->n_out < 1 || n->n_out > 16) return fail(ORL_E_UNSUPPORTED, "%s: n_out %d outside [1,16]", who, n->n_out);
+  if (value && !(n->head_kind == ORL_HEAD_VALUE && n->n_out == 1)) return fail(ORL_E_INVALID, "%s: not a value head", who);
+  if (!value && n->head_kind != ORL_HEAD_CATEGORICAL && n->head_kind != ORL_HEAD_GAUSSIAN)
+    return fail(ORL_E_INVALID, "%s: policy head kind %d not built", who, n->head_kind);
+  return 0;
+}
+
+struct RnnWs {  // workspace carve-up (floats) for one tower
+  size_t htape, tape, rpart, wpart, total;
+  int n_tiles, n_blocks, grid_row, grid_wg, rpw, wpw;
+  RnnWs(const orl_net_desc& n, int n_chunks, int L) {
+    const RnnRaw rl(n);
+    n_tiles = (n_chunks + TILE_B - 1) / TILE_B;
+    n_blocks = n_tiles * L;
+    grid_row = (n_tiles + 7) / 8;
+    if (grid_row > RNN_ROW_BLOCKS) grid_row = RNN_ROW_BLOCKS;
+    grid_wg = n_blocks < RNN_WG_BLOCKS ? n_blocks : RNN_WG_BLOCKS;
+    rpw = rl.n_logstd + ORL_N_STATS;
+    wpw = rl.total - rl.n_logstd;
+    size_t o = 0;
+    htape = o; o += (size_t)n_blocks * TV;
+    tape = o; o += (size_t)n_blocks * tape_block_floats(n.obs_dim);
+    rpart = o; o += (size_t)RNN_ROW_BLOCKS * rpw;
+    wpart = o; o += (size_t)RNN_WG_BLOCKS * wpw;
+    total = (o + 63) & ~(size_t)63;
+  }
+};
+
+template <int HEAD, int NO>
+static int launch_rnn_row(const RnnRowArgs& A, int grid, hipStream_t s) {
+  const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN);
+  const size_t lds = (size_t)tw.total * sizeof(float);
+  if (lds > 160 * 1024) return fail(ORL_E_UNSUPPORTED, "orl_rnn_ppo_fwd_bwd: tower needs %zu B of LDS", lds);
+  (void)hipFuncSetAttribute((const void*)rnn_row_kernel<HEAD, NO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((rnn_row_kernel<HEAD, NO>), dim3(grid), dim3(512), lds, s, A);
+  return launch_status("orl_rnn_ppo_fwd_bwd(row)");
+}
+
+}  // namespace orl
+
+using namespace orl;
+
+extern "C" {
+
+int orl_rnn_param_count(const orl_net_desc* net) {
+  if (!net) return fail(ORL_E_INVALID, "orl_rnn_param_count: null");
+  return RnnLayout(*net).total;
+}
+
+int orl_rnn_raw_grad_count(const orl_net_desc* net) {
+  if (!net) return fail(ORL_E_INVALID, "orl_rnn_raw_grad_count: null");
+  return RnnRaw(*net).total;
+}
+
+int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                     const float* policy_obs, const float* critic_obs, const float* h_policy_in,
+                     const float* h_critic_in, const float* masks, const float* action_masks, int B,
+                     int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const float* forced_u,
+                     float* values, float* actions, float* logp, float* h_policy_out, float* h_critic_out,
+                     void* stream) {
+  ORL_REQUIRE(ptheta || ctheta, "orl_rnn_act_step: neither tower given");
+  ORL_REQUIRE(B > 0 && masks, "orl_rnn_act_step: B=%d / null masks", B);
+  int rc;
+  if (ptheta) {
+    rc = check_rnn_net(pnet, "orl_rnn_act_step(policy)", false);
+    if (rc) return rc;
+    ORL_REQUIRE(policy_obs && actions && logp && h_policy_in && h_policy_out, "orl_rnn_act_step: null policy pointer");
+  }
+  if (ctheta) {
+    rc = check_rnn_net(cnet, "orl_rnn_act_step(critic)", true);
+    if (rc) return rc;
+    ORL_REQUIRE(critic_obs && values && h_critic_in && h_critic_out, "orl_rnn_act_step: null critic pointer");
+  }
+  RnnActArgs A;
+  A.pnet = ptheta ? *pnet : *cnet;
+  A.cnet = ctheta ? *cnet : *pnet;
+  A.ptheta = ptheta; A.ctheta = ctheta; A.pobs = policy_obs; A.cobs = critic_obs; A.hp_in = h_policy_in;
+  A.hc_in = h_critic_in; A.masks = masks; A.amask = action_masks; A.forced = forced_u; A.values = values;
+  A.actions = actions; A.logp = logp; A.hp_out = h_policy_out; A.hc_out = h_critic_out; A.B = B;
+  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step;
+  const int grid = (B + TILE_B - 1) / TILE_B;
+  hipStream_t s = (hipStream_t)stream;
+  const int no = A.pnet.n_out;
+#define ORL_RNN_ACT(NO, HD) hipLaunchKernelGGL((rnn_act_kernel<NO, HD>), dim3(grid), dim3(128), 0, s, A)
+  if (!ptheta || A.pnet.head_kind == ORL_HEAD_VALUE) ORL_RNN_ACT(2, ORL_HEAD_CATEGORICAL);  // value-only: wave 0 exits
+  else if (A.pnet.head_kind == ORL_HEAD_CATEGORICAL) {
+    if (no <= 2) ORL_RNN_ACT(2, ORL_HEAD_CATEGORICAL);
+    else if (no <= 8) ORL_RNN_ACT(8, ORL_HEAD_CATEGORICAL);
+    else ORL_RNN_ACT(16, ORL_HEAD_CATEGORICAL);
+  } else {
+    if (no <= 2) ORL_RNN_ACT(2, ORL_HEAD_GAUSSIAN);
+    else if (no <= 8) ORL_RNN_ACT(8, ORL_HEAD_GAUSSIAN);
+    else ORL_RNN_ACT(16, ORL_HEAD_GAUSSIAN);
+  }
+#undef ORL_RNN_ACT
+  return launch_status("orl_rnn_act_step");
+}
+
+int orl_rnn_chunk_rows(const int64_t* chunk_idx, int n_chunks, int L, int T, int lanes, int64_t* rows, void* stream) {
+  ORL_REQUIRE(rows && n_chunks > 0 && L > 0 && T > 0 && lanes > 0, "orl_rnn_chunk_rows: bad arguments");
+  const int n = n_chunks * L;
+  hipLaunchKernelGGL(rnn_chunk_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunk_idx,
+                     n_chunks, L, T, lanes, rows);
+  return launch_status("orl_rnn_chunk_rows");
+}
+
+int64_t orl_rnn_workspace_floats(const orl_net_desc* pnet, const orl_net_desc* cnet, int n_chunks, int L) {
+  if (!pnet || !cnet || n_chunks <= 0 || L <= 0) return fail(ORL_E_INVALID, "orl_rnn_workspace_floats: bad arguments");
+  return (int64_t)(RnnWs(*pnet, n_chunks, L).total + RnnWs(*cnet, n_chunks, L).total);
+}
+
+int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                        const orl_rnn_batch* batch, const float* vn_state, const orl_ppo_hparams* hp,
+                        float* workspace, float* sums, void* stream) {
+  int rc = check_rnn_net(pnet, "orl_rnn_ppo_fwd_bwd(policy)", false);
+  if (rc) return rc;
+  rc = check_rnn_net(cnet, "orl_rnn_ppo_fwd_bwd(critic)", true);
+  if (rc) return rc;
+  ORL_REQUIRE(ptheta && ctheta && batch && hp && workspace && sums, "orl_rnn_ppo_fwd_bwd: null pointer");
+  ORL_REQUIRE(batch->records && batch->rows && batch->masks && batch->h_policy && batch->h_critic,
+              "orl_rnn_ppo_fwd_bwd: null batch pointer");
+  ORL_REQUIRE(batch->n_chunks > 0 && batch->L > 0, "orl_rnn_ppo_fwd_bwd: empty minibatch");
+  const int a_w = pnet->head_kind == ORL_HEAD_CATEGORICAL ? 1 : pnet->n_out;
+  const int Dp = pnet->obs_dim, Dc = cnet->obs_dim;
+  const int K = pnet->head_kind == ORL_HEAD_CATEGORICAL ? pnet->n_out : 0;
+  ORL_REQUIRE(orl_record_width(Dp, Dc, a_w, K) == batch->rec_width, "orl_rnn_ppo_fwd_bwd: record width %d != %d",
+              batch->rec_width, orl_record_width(Dp, Dc, a_w, K));
+  hipStream_t s = (hipStream_t)stream;
+  const int o_co = Dp, o_ac = o_co + Dc, o_lp = o_ac + a_w, o_adv = o_lp + a_w;
+  RnnRowArgs A;
+  A.records = batch->records; A.rows = batch->rows; A.masks = batch->masks; A.vn_state = vn_state; A.hp = *hp;
+  A.R = batch->rec_width; A.Nc = batch->n_chunks; A.L = batch->L;
+  A.cols.o_act = o_ac; A.cols.o_lp = o_lp; A.cols.o_adv = o_adv; A.cols.o_vp = o_adv + 1; A.cols.o_rt = o_adv + 2;
+  A.cols.o_am = o_adv + 3; A.cols.o_mk = o_adv + 4; A.cols.K = K;
+  const RnnWs wp(*pnet, batch->n_chunks, batch->L), wc(*cnet, batch->n_chunks, batch->L);
+  float* sums_t = sums;
+  for (int t = 0; t < 2; ++t) {
+    const orl_net_desc& net = t == 0 ? *pnet : *cnet;
+    const RnnWs& w = t == 0 ? wp : wc;
+    float* base = workspace + (t == 0 ? 0 : wp.total);
+    const RnnRaw rl(net);
+    A.net = net; A.theta = t == 0 ? ptheta : ctheta; A.hbuf = t == 0 ? batch->h_policy : batch->h_critic;
+    A.o_x = t == 0 ? 0 : o_co;
+    A.htape = base + w.htape; A.tape = base + w.tape; A.partials = base + w.rpart;
+    if (t == 1) rc = launch_rnn_row<ORL_HEAD_VALUE, 1>(A, w.grid_row, s);
+    else if (net.head_kind == ORL_HEAD_CATEGORICAL) {
+      if (net.n_out <= 2) rc = launch_rnn_row<ORL_HEAD_CATEGORICAL, 2>(A, w.grid_row, s);
+      else if (net.n_out <= 8) rc = launch_rnn_row<ORL_HEAD_CATEGORICAL, 8>(A, w.grid_row, s);
+      else rc = launch_rnn_row<ORL_HEAD_CATEGORICAL, 16>(A, w.grid_row, s);
+    } else {
+      if (net.n_out <= 8) rc = launch_rnn_row<ORL_HEAD_GAUSSIAN, 8>(A, w.grid_row, s);
+      else rc = launch_rnn_row<ORL_HEAD_GAUSSIAN, 16>(A, w.grid_row, s);
+    }
+    if (rc) return rc;
+    RnnWgArgs G;
+    G.net = net; G.tape = base + w.tape; G.partials = base + w.wpart; G.n_blocks = w.n_blocks;
+    const size_t lds = (size_t)tape_block_floats(net.obs_dim) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)rnn_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(rnn_wgrad_kernel, dim3(w.grid_wg), dim3(512), lds, s, G);
+    rc = launch_status("orl_rnn_ppo_fwd_bwd(wgrad)");
+    if (rc) return rc;
+    // sums of this tower: [raw without logstd | dlogstd | stats]
+    rc = orl_ppo_reduce(base + w.wpart, w.grid_wg, w.wpw, sums_t, stream);
+    if (rc) return rc;
+    rc = orl_ppo_reduce(base + w.rpart, w.grid_row, w.rpw, sums_t + w.wpw, stream);
+    if (rc) return rc;
+    sums_t += rl.total + ORL_N_STATS;
+  }
+  return 0;
+}
+
+int orl_rnn_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums, const orl_ppo_hparams* hp,
+                      const orl_adam_state* padam, const orl_adam_state* cadam, float* train_info_accum,
+                      float* scratch, void* stream) {
+  int rc = check_rnn_net(pnet, "orl_rnn_ppo_apply(policy)", false);
+  if (rc) return rc;
+  rc = check_rnn_net(cnet, "orl_rnn_ppo_apply(critic)", true);
+  if (rc) return rc;
+  ORL_REQUIRE(sums && hp && padam && cadam && scratch, "orl_rnn_ppo_apply: null pointer");
+  ORL_REQUIRE(padam->theta && padam->grad && padam->m && padam->v && cadam->theta && cadam->grad && cadam->m && cadam->v,
+              "orl_rnn_ppo_apply: null optimizer buffer");
+  ORL_REQUIRE(padam->step >= 1 && cadam->step >= 1, "orl_rnn_ppo_apply: Adam step counts are 1-based");
+  RnnApplyTower P, Cc;
+  P.net = *pnet; P.ad = *padam; P.raw = sums;
+  Cc.net = *cnet; Cc.ad = *cadam; Cc.raw = sums + RnnRaw(*pnet).total + ORL_N_STATS;
+  const int nb_p = (RnnLayout(*pnet).total + 255) / 256, nb_c = (RnnLayout(*cnet).total + 255) / 256;
+  ORL_REQUIRE(nb_p <= 256 && nb_c <= 256, "orl_rnn_ppo_apply: tower too large");
+  const int nb = nb_p > nb_c ? nb_p : nb_c;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rnn_grad_kernel, dim3(nb, 2), dim3(256), 0, s, P, Cc, *hp, scratch);
+  hipLaunchKernelGGL(rnn_adam_kernel, dim3(nb, 2), dim3(256), 0, s, P, Cc, *hp, scratch, nb_p, nb_c,
+                     train_info_accum);
+  return launch_status("orl_rnn_ppo_apply");
+}
+
+}  // extern "C"

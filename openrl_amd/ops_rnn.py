@@ -1,0 +1,78 @@
+"""Tensor-level wrappers over the recurrent (GRU) part of the C ABI (``include/orl_hip.h``, ``orl_rnn_*``).
+Same contract as ``ops.py``: checks, raw pointers, current stream; nothing is computed in Python."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as nat
+from ._native import AdamState, NetDesc, PPOHParams, RnnBatch, fptr, ptr, stream_ptr
+
+
+def _lib():
+    return nat.load()
+
+
+def _dev(t: torch.Tensor):
+    nat.require_gpu(t.device)
+    return t.device
+
+
+def rnn_param_count(net: NetDesc) -> int:
+    n = _lib().orl_rnn_param_count(C.byref(net))
+    if n < 0:
+        nat.check(n, "orl_rnn_param_count")
+    return n
+
+
+def rnn_raw_grad_count(net: NetDesc) -> int:
+    n = _lib().orl_rnn_raw_grad_count(C.byref(net))
+    if n < 0:
+        nat.check(n, "orl_rnn_raw_grad_count")
+    return n
+
+
+def rnn_act_step(pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, h_policy_in, h_critic_in, masks, action_masks,
+                 B: int, deterministic: bool, seed: int, row0: int, rng_step: int, forced_u, values, actions, logp,
+                 h_policy_out, h_critic_out) -> None:
+    dev = _dev(masks)
+    rc = _lib().orl_rnn_act_step(C.byref(pnet) if pnet is not None else None, fptr(ptheta),
+                                 C.byref(cnet) if cnet is not None else None, fptr(ctheta), fptr(policy_obs),
+                                 fptr(critic_obs), fptr(h_policy_in), fptr(h_critic_in), fptr(masks),
+                                 fptr(action_masks), B, int(bool(deterministic)), seed & (2 ** 64 - 1), row0, rng_step,
+                                 fptr(forced_u), fptr(values), fptr(actions), fptr(logp), fptr(h_policy_out),
+                                 fptr(h_critic_out), stream_ptr(dev))
+    nat.check(rc, "orl_rnn_act_step")
+
+
+def rnn_chunk_rows(chunk_idx, n_chunks: int, L: int, T: int, lanes: int, rows: torch.Tensor) -> None:
+    dev = _dev(rows)
+    assert rows.dtype == torch.int64 and rows.numel() >= n_chunks * L
+    rc = _lib().orl_rnn_chunk_rows(ptr(chunk_idx), n_chunks, L, T, lanes, ptr(rows), stream_ptr(dev))
+    nat.check(rc, "orl_rnn_chunk_rows")
+
+
+def rnn_workspace_floats(pnet, cnet, n_chunks: int, L: int) -> int:
+    n = _lib().orl_rnn_workspace_floats(C.byref(pnet), C.byref(cnet), n_chunks, L)
+    if n < 0:
+        nat.check(int(n), "orl_rnn_workspace_floats")
+    return int(n)
+
+
+def rnn_ppo_fwd_bwd(pnet, ptheta, cnet, ctheta, records, rows, masks, h_policy, h_critic, n_chunks: int, L: int,
+                    vn_state, hp: PPOHParams, workspace, sums) -> None:
+    dev = _dev(records)
+    b = RnnBatch(fptr(records), ptr(rows), fptr(masks), fptr(h_policy), fptr(h_critic), records.shape[1], n_chunks, L,
+                 0)
+    rc = _lib().orl_rnn_ppo_fwd_bwd(C.byref(pnet), fptr(ptheta), C.byref(cnet), fptr(ctheta), C.byref(b),
+                                    fptr(vn_state), C.byref(hp), fptr(workspace), fptr(sums), stream_ptr(dev))
+    nat.check(rc, "orl_rnn_ppo_fwd_bwd")
+
+
+def rnn_ppo_apply(pnet, cnet, sums, hp: PPOHParams, padam: AdamState, cadam: AdamState, train_info_accum,
+                  scratch) -> None:
+    dev = _dev(sums)
+    rc = _lib().orl_rnn_ppo_apply(C.byref(pnet), C.byref(cnet), fptr(sums), C.byref(hp), C.byref(padam),
+                                  C.byref(cadam), fptr(train_info_accum), fptr(scratch), stream_ptr(dev))
+    nat.check(rc, "orl_rnn_ppo_apply")

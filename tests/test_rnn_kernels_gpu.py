@@ -1,0 +1,157 @@
+"""Recurrent (GRU) HIP kernels against the oracle / the golden vectors minted from the real reference
+(SURVEY.md section 8a row a26): orl_rnn_act_step, orl_rnn_chunk_rows, orl_rnn_ppo_fwd_bwd, orl_rnn_ppo_apply."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as po
+from oracle import rnn_oracle as ro
+from tests import helpers as H
+from tests import rnn_helpers as RH
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+KEYS = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
+
+
+def _nets(pspec, cspec):
+    from openrl_amd import ops
+
+    head = ops.HEAD_CATEGORICAL if pspec.head == po.HEAD_CATEGORICAL else ops.HEAD_GAUSSIAN
+    return ops.net_desc(pspec.obs_dim, pspec.n_out, head), ops.net_desc(cspec.obs_dim, 1, ops.HEAD_VALUE)
+
+
+def _t(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(DEV)
+
+
+@pytest.mark.parametrize("case", RH.RNN_CASES)
+def test_rnn_param_counts_and_probe_vs_reference(case):
+    from openrl_amd import ops_rnn
+
+    g = H.load_golden(case)
+    pspec, cspec = RH.rnn_specs(g)
+    pnet, cnet = _nets(pspec, cspec)
+    assert ops_rnn.rnn_param_count(pnet) == g["theta_p1"].size == pspec.n_params()
+    assert ops_rnn.rnn_param_count(cnet) == g["theta_c1"].size
+    B = g["probe_policy_obs"].shape[0]
+    a_w = g["probe_actions"].shape[1]
+    values, actions, logp = torch.zeros(B, 1, device=DEV), torch.zeros(B, a_w, device=DEV), torch.zeros(B, a_w, device=DEV)
+    hp1, hc1 = torch.zeros(B, 64, device=DEV), torch.zeros(B, 64, device=DEV)
+    ops_rnn.rnn_act_step(pnet, _t(g["theta_p1"]), cnet, _t(g["theta_c1"]), _t(g["probe_policy_obs"]),
+                         _t(g["probe_critic_obs"]), _t(g["probe_h"].reshape(B, 64)), _t(g["probe_hc"].reshape(B, 64)),
+                         _t(g["probe_masks"].reshape(B)), None, B, True, 0, 0, 0, None, values, actions, logp, hp1, hc1)
+    np.testing.assert_allclose(values.cpu().numpy(), g["probe_values"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(actions.cpu().numpy(), g["probe_actions"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["probe_logp"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(hp1.cpu().numpy(), g["probe_h1"].reshape(B, 64), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(hc1.cpu().numpy(), g["probe_hc1"].reshape(B, 64), rtol=2e-4, atol=2e-5)
+    # value-only call (PPOModule.get_values) and sampled call with forced uniforms vs the oracle's sampler
+    v2, hc2 = torch.zeros(B, 1, device=DEV), torch.zeros(B, 64, device=DEV)
+    ops_rnn.rnn_act_step(None, None, cnet, _t(g["theta_c1"]), None, _t(g["probe_critic_obs"]), None,
+                         _t(g["probe_hc"].reshape(B, 64)), _t(g["probe_masks"].reshape(B)), None, B, True, 0, 0, 0, None,
+                         v2, None, None, None, hc2)
+    assert torch.equal(v2, values) and torch.equal(hc2, hc1)
+    rs = np.random.RandomState(3)
+    u = rs.rand(B, a_w).astype(np.float32) if pspec.head == po.HEAD_CATEGORICAL else rs.randn(B, a_w).astype(np.float32)
+    ops_rnn.rnn_act_step(pnet, _t(g["theta_p1"]), cnet, _t(g["theta_c1"]), _t(g["probe_policy_obs"]),
+                         _t(g["probe_critic_obs"]), _t(g["probe_h"].reshape(B, 64)), _t(g["probe_hc"].reshape(B, 64)),
+                         _t(g["probe_masks"].reshape(B)), None, B, False, 0, 0, 0, _t(u), values, actions, logp, hp1, hc1)
+    v_o, a_o, lp_o, _, _ = ro.get_actions(pspec, torch.tensor(g["theta_p1"]), cspec, torch.tensor(g["theta_c1"]),
+                                          g["probe_policy_obs"], g["probe_critic_obs"], g["probe_h"], g["probe_hc"],
+                                          g["probe_masks"], deterministic=False, forced_u=u)
+    np.testing.assert_allclose(actions.cpu().numpy(), a_o, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp_o, rtol=2e-4, atol=3e-5)
+
+
+def test_chunk_rows_match_the_recurrent_generator_order():
+    from openrl_amd import ops_rnn
+
+    T, lanes, L = 7, 5, 2  # chunks straddle lanes (T odd)
+    n_chunks = (T * lanes) // L
+    chunks = torch.randperm(n_chunks)
+    rows = torch.zeros(L * n_chunks, dtype=torch.int64, device=DEV)
+    ops_rnn.rnn_chunk_rows(chunks.to(DEV), n_chunks, L, T, lanes, rows)
+    # cast order row r = lane*T + t  ->  record row t*lanes + lane
+    r = (chunks.numpy()[None, :] * L + np.arange(L)[:, None])
+    want = (r % T) * lanes + (r // T)
+    assert np.array_equal(rows.cpu().numpy().reshape(L, n_chunks), want)
+    ops_rnn.rnn_chunk_rows(None, n_chunks, L, T, lanes, rows)
+    r = (np.arange(n_chunks)[None, :] * L + np.arange(L)[:, None])
+    assert np.array_equal(rows.cpu().numpy().reshape(L, n_chunks), (r % T) * lanes + (r // T))
+
+
+def _records(buf, adv, K):
+    fl = lambda x: x.reshape(-1, x.shape[-1])
+    cols = [fl(buf["policy_obs"][:-1]), fl(buf["critic_obs"][:-1]), fl(buf["actions"]), fl(buf["action_log_probs"]),
+            adv.reshape(-1, 1), fl(buf["value_preds"][:-1]), fl(buf["returns"][:-1]), fl(buf["active_masks"][:-1])]
+    if K:
+        cols.append(fl(buf["action_masks"][:-1]))
+    rec = np.concatenate(cols, 1).astype(np.float32)
+    pad = (-rec.shape[1]) % 4
+    return np.pad(rec, ((0, 0), (0, pad)))
+
+
+@pytest.mark.parametrize("case", RH.RNN_CASES)
+def test_rnn_update_gradients_and_adam_step_vs_oracle(case):
+    """First minibatch of the golden case: raw sums -> gradients, clip, Adam, train_info vs oracle autograd."""
+    from openrl_amd import ops, ops_rnn
+
+    g = H.load_golden(case)
+    cfg = H.case_cfg(g)
+    hp_o = po.hyper_from_cfg(cfg)
+    pspec, cspec = RH.rnn_specs(g)
+    pnet, cnet = _nets(pspec, cspec)
+    buf = H.case_buffer(g)
+    T, N, A = buf["rewards"].shape[:3]
+    lanes, L = N * A, cfg.data_chunk_length
+    vn = po.ValueNormOracle()
+    adv = po.advantages(buf["returns"], buf["value_preds"], buf["active_masks"], vn, hp_o.use_adv_normalize)
+    rows_o = ro.buffer_rows(buf, adv)
+    torch.manual_seed(int(g["perm_seed"]))
+    chunks = ro.recurrent_chunk_order(T * lanes, L, cfg.num_mini_batch)[0]
+    ptheta, ctheta = torch.tensor(g["theta_p0"]).clone(), torch.tensor(g["theta_c0"]).clone()
+    padam = po.AdamOracle(ptheta.numel(), cfg.lr, cfg.opti_eps, cfg.weight_decay)
+    cadam = po.AdamOracle(ctheta.numel(), cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)
+    info_o, gp, gc, raw_p, raw_c = ro.ppo_update(hp_o, pspec, ptheta, cspec, ctheta, padam, cadam, vn,
+                                                  ro.chunk_sample(rows_o, chunks, L))
+    # ---- engine
+    K = pspec.n_out if pspec.head == po.HEAD_CATEGORICAL else 0
+    rec = _t(_records(buf, adv, K))
+    assert rec.shape[1] == ops.record_width(pspec.obs_dim, cspec.obs_dim, buf["actions"].shape[-1], K)
+    n_chunks = len(chunks)
+    rows = torch.zeros(L * n_chunks, dtype=torch.int64, device=DEV)
+    ops_rnn.rnn_chunk_rows(_t(chunks, torch.int64), n_chunks, L, T, lanes, rows)
+    vn_state = torch.zeros(3, device=DEV)
+    mom, scratch = torch.zeros(3, dtype=torch.float64, device=DEV), torch.zeros(512, dtype=torch.float64, device=DEV)
+    ret_col = pspec.obs_dim + cspec.obs_dim + 2 * buf["actions"].shape[-1] + 2
+    ops.minibatch_moments(rec, ret_col, rows, L * n_chunks, scratch, mom)
+    ops.valuenorm_update(vn_state, mom, 0.99999)
+    np.testing.assert_allclose(vn_state.cpu().numpy(), vn.state(), rtol=1e-6)
+    hp = ops.make_hparams(cfg)
+    th_p, th_c = _t(g["theta_p0"]), _t(g["theta_c0"])
+    ws = torch.zeros(ops_rnn.rnn_workspace_floats(pnet, cnet, n_chunks, L), device=DEV)
+    raw_np, raw_nc = ops_rnn.rnn_raw_grad_count(pnet), ops_rnn.rnn_raw_grad_count(cnet)
+    sums = torch.zeros(raw_np + raw_nc + 2 * ops.N_STATS, device=DEV)
+    masks = _t(buf["masks"].reshape(T + 1, lanes))
+    h_p, h_c = _t(buf["rnn_states"].reshape(T + 1, lanes, 64)), _t(buf["rnn_states_critic"].reshape(T + 1, lanes, 64))
+    ops_rnn.rnn_ppo_fwd_bwd(pnet, th_p, cnet, th_c, rec, rows, masks, h_p, h_c, n_chunks, L, vn_state, hp, ws, sums)
+    st_p = sums[raw_np:raw_np + ops.N_STATS].cpu().numpy()
+    assert st_p[1] == L * n_chunks  # rows counted
+    from openrl_amd._native import AdamState, fptr
+
+    gr_p, gr_c = torch.zeros_like(th_p), torch.zeros_like(th_c)
+    m_p, v_p, m_c, v_c = (torch.zeros_like(th_p), torch.zeros_like(th_p), torch.zeros_like(th_c), torch.zeros_like(th_c))
+    info = torch.zeros(8, device=DEV)
+    ops_rnn.rnn_ppo_apply(pnet, cnet, sums, hp,
+                          AdamState(fptr(th_p), fptr(gr_p), fptr(m_p), fptr(v_p), cfg.lr, cfg.opti_eps, cfg.weight_decay, 1),
+                          AdamState(fptr(th_c), fptr(gr_c), fptr(m_c), fptr(v_c), cfg.critic_lr, cfg.opti_eps,
+                                    cfg.weight_decay, 1), info, torch.zeros(512, device=DEV))
+    np.testing.assert_allclose(gr_p.cpu().numpy(), gp, rtol=3e-3, atol=3e-5 * np.abs(gp).max() + 1e-7)
+    np.testing.assert_allclose(gr_c.cpu().numpy(), gc, rtol=3e-3, atol=3e-5 * np.abs(gc).max() + 1e-7)
+    np.testing.assert_allclose(info[:6].cpu().numpy(), np.array([info_o[k] for k in KEYS]), rtol=3e-4, atol=3e-5)
+    # Adam: the oracle's step applied to the ENGINE's clipped gradients must land on the engine's parameters
+    for th_e, gr_e, th0, lr in ((th_p, gr_p, g["theta_p0"], cfg.lr), (th_c, gr_c, g["theta_c0"], cfg.critic_lr)):
+        th = torch.tensor(th0).clone()
+        po.AdamOracle(th.numel(), lr, cfg.opti_eps, cfg.weight_decay).step(th, gr_e.cpu())
+        np.testing.assert_allclose(th_e.cpu().numpy(), th.numpy(), rtol=1e-5, atol=1e-7)
