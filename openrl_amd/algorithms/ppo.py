@@ -22,7 +22,7 @@ import torch
 
 from .. import _native as nat
 from .. import distributed as dist_utils
-from .. import ops
+from .. import ops, ops_rnn
 from .base_algorithm import BaseAlgorithm
 
 INFO_KEYS = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
@@ -32,17 +32,23 @@ class PPOAlgorithm(BaseAlgorithm):
     def __init__(self, cfg, init_module, agent_num: int = 1, device: Union[str, torch.device] = "cuda:0") -> None:
         if cfg.use_share_model or cfg.use_joint_action_loss or cfg.use_deepspeed or cfg.use_amp:
             raise NotImplementedError("share_model / joint_action_loss / deepspeed / amp are not built in this engine")
-        if cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy:
-            raise NotImplementedError("recurrent generators are not built in this engine yet")
+        if cfg.use_naive_recurrent_policy:
+            raise NotImplementedError("naive_recurrent_generator is not built in this engine (use_recurrent_policy is)")
         super().__init__(cfg, init_module, agent_num, device)
         self.train_list = [self.train_ppo]
         self.hp = ops.make_hparams(cfg)
         p, c = self.algo_module.models["policy"], self.algo_module.models["critic"]
-        self._raw_p = ops.raw_grad_count(p.net) + ops.N_STATS
-        self._raw_c = ops.raw_grad_count(c.net) + ops.N_STATS
+        self.recurrent = bool(getattr(self.algo_module, "recurrent", False))
+        raw = ops_rnn.rnn_raw_grad_count if self.recurrent else ops.raw_grad_count
+        self._raw_p = raw(p.net) + ops.N_STATS
+        self._raw_c = raw(c.net) + ops.N_STATS
         mb = ops.ppo_max_blocks()
         dev = self.device
-        self._partials = torch.empty(mb * (self._raw_p + self._raw_c), dtype=torch.float32, device=dev)
+        self._partials = None if self.recurrent else torch.empty(mb * (self._raw_p + self._raw_c), dtype=torch.float32,
+                                                                 device=dev)
+        self._rnn_ws = None      # activation tapes + partials of the recurrent update, sized on first use
+        self._rnn_rows = None    # [L, n_chunks] record rows of the current minibatch
+        self._rnn_scratch = torch.zeros(512, dtype=torch.float32, device=dev) if self.recurrent else None
         self._sums = torch.zeros(self._raw_p + self._raw_c, dtype=torch.float32, device=dev)
         self._info = torch.zeros(8, dtype=torch.float32, device=dev)
         self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
@@ -112,6 +118,55 @@ class PPOAlgorithm(BaseAlgorithm):
         ops.ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
                       co.native_state(co.step_count), self._info)
 
+    # ------------------------------------------------------------------------------------------ recurrent
+    def _update_minibatch_rnn(self, buffer, chunks, n_chunks: int, turn_on: bool) -> None:
+        """One recurrent_generator minibatch (replay_data.py:1062-1258): ``chunks`` = chunk ids (device int64)."""
+        mod = self.algo_module
+        p, c = mod.models["policy"], mod.models["critic"]
+        po, co = mod.optimizers["policy"], mod.optimizers["critic"]
+        T, lanes, L = buffer.episode_length, buffer.n_rollout_threads * buffer.num_agents, self.data_chunk_length
+        rec = buffer.records
+        if self._rnn_rows is None or self._rnn_rows.numel() < n_chunks * L:
+            self._rnn_rows = torch.empty(n_chunks * L, dtype=torch.int64, device=self.device)
+        rows = self._rnn_rows
+        ops_rnn.rnn_chunk_rows(chunks, n_chunks, L, T, lanes, rows)
+        vn = mod.get_critic_value_normalizer() if self._use_valuenorm else None
+        vn_state = None
+        if vn is not None:
+            ret_col = buffer.Dp + buffer.Dc + 2 * buffer.act_shape + 2
+            ops.minibatch_moments(rec, ret_col, rows, n_chunks * L, self._mom_scratch, self._moments)
+            if self.world_size > 1:
+                dist_utils.allreduce_(self._moments)
+            ops.valuenorm_update(vn.state, self._moments, vn.beta)
+            vn_state = vn.state
+        need = ops_rnn.rnn_workspace_floats(p.net, c.net, n_chunks, L)
+        if self._rnn_ws is None or self._rnn_ws.numel() < need:
+            self._rnn_ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        ops_rnn.rnn_ppo_fwd_bwd(p.net, p.theta, c.net, c.theta, rec, rows, buffer.masks, buffer.rnn_states,
+                                buffer.rnn_states_critic, n_chunks, L, vn_state, self.hp, self._rnn_ws, self._sums)
+        if self.world_size > 1:
+            dist_utils.allreduce_(self._sums)
+        po.step_count += 1 if turn_on else 0
+        co.step_count += 1
+        hp = self.hp
+        if not turn_on:
+            hp = nat.PPOHParams.from_buffer_copy(self.hp)
+            hp.reserved = 1
+        ops_rnn.rnn_ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
+                              co.native_state(co.step_count), self._info, self._rnn_scratch)
+
+    def _chunk_batches(self, M: int):
+        L = self.data_chunk_length
+        assert M >= L, "PPO requires n_rollout_threads * num_agents * episode_length >= data_chunk_length"
+        data_chunks = M // L
+        mbs = data_chunks // self.num_mini_batch
+        if self.perm_mode == "device":
+            self._perm_counter += 1
+            rand = ops.perm_feistel(data_chunks, int(self.cfg.seed), self._perm_counter, self.device)
+        else:
+            rand = torch.randperm(data_chunks).to(self.device, non_blocking=True)  # replay_data.py:1078
+        return [rand[i * mbs:(i + 1) * mbs] for i in range(self.num_mini_batch)], mbs
+
     def _minibatch_indices(self, M: int):
         mbs = M // self.num_mini_batch
         n_batches = M // mbs  # drop_last=True (replay_data.py:578-580)
@@ -126,12 +181,18 @@ class PPOAlgorithm(BaseAlgorithm):
     def train_ppo(self, buffer, turn_on: bool = True) -> Dict[str, float]:
         self._advantages_and_records(buffer)
         M = buffer.episode_length * buffer.n_rollout_threads * buffer.num_agents
-        self._full_batch_moments = self.num_mini_batch == 1
+        self._full_batch_moments = self.num_mini_batch == 1 and not self.recurrent
         if self._full_batch_moments:
             self._moments.copy_(self._adv_stats[self._mom_sel])  # {sum ret, sum ret^2, count}
         self._info.zero_()
         self.last_indices = []
         for _ in range(self.ppo_epoch):
+            if self.recurrent:  # get_data_generator (ppo.py:363-372)
+                batches, mbs = self._chunk_batches(M)
+                for chunks in batches:
+                    self.last_indices.append(chunks)
+                    self._update_minibatch_rnn(buffer, chunks, mbs, turn_on)
+                continue
             batches, mbs = self._minibatch_indices(M)
             for idx in batches:
                 self.last_indices.append(idx)

@@ -74,7 +74,10 @@ class OnPolicyDriver:
         dev_env = bool(getattr(self.envs, "is_device_env", False))
         if mode == "fused" and not dev_env:
             raise ValueError("amd_rollout_mode=fused needs a device-resident env")
-        self.fused = dev_env and mode in ("auto", "fused") and not self.callback.needs_per_step
+        recurrent = bool(getattr(self.trainer.algo_module, "recurrent", False))
+        if mode == "fused" and recurrent:
+            raise ValueError("amd_rollout_mode=fused is not built for recurrent policies (stepwise rollout only)")
+        self.fused = dev_env and mode in ("auto", "fused") and not self.callback.needs_per_step and not recurrent
         d = self.buffer.data
         self._next_value = torch.zeros(d.n_rollout_threads, d.num_agents, 1, dtype=torch.float32, device=self.device)
         self._have_next_value = False
@@ -188,6 +191,16 @@ class OnPolicyDriver:
         mod = self.trainer.algo_module
         out = (d.value_preds[step].view(-1, 1), d.actions[step].view(-1, d.act_shape),
                d.action_log_probs[step].view(-1, d.act_shape))
+        if getattr(mod, "recurrent", False):
+            # new hidden states go straight into slot step+1 (ReplayData.insert, replay_data.py:262-263);
+            # add2buffer zeroes them where the env finished (onpolicy_driver.py:91-108)
+            H = d.hidden_size
+            mod._forward_rnn(d.get_batch_data("critic_obs", step), d.get_batch_data("policy_obs", step),
+                             d.rnn_states[step].view(-1, H), d.rnn_states_critic[step].view(-1, H),
+                             d.masks[step].view(-1), d.get_batch_data("action_masks", step), False, out=out,
+                             h_out=(d.rnn_states[step + 1].view(-1, H), d.rnn_states_critic[step + 1].view(-1, H)))
+            return (d.value_preds[step], d.actions[step], d.action_log_probs[step], d.rnn_states[step + 1],
+                    d.rnn_states_critic[step + 1])
         mod._forward(d.get_batch_data("critic_obs", step), d.get_batch_data("policy_obs", step),
                      d.get_batch_data("action_masks", step), False, out=out)
         return d.value_preds[step], d.actions[step], d.action_log_probs[step], None, None
@@ -215,6 +228,10 @@ class OnPolicyDriver:
         ops.buffer_insert(d.buffer_ptrs(), step, p_obs, c_obs, self._as_dev(data["rewards"]),
                           self._as_dev(data["dones"], torch.uint8), bad,
                           None if amask is None else self._as_dev(amask))
+        if d.rnn_states.stride(0) != 0:  # recurrent: rnn_states[dones_env] = 0 (masks[step+1] is 0 exactly there)
+            m = d.masks[step + 1].unsqueeze(-1)
+            d.rnn_states[step + 1].mul_(m)
+            d.rnn_states_critic[step + 1].mul_(m)
         d.step = (step + 1) % d.episode_length
         d._adv_fresh = False
 
@@ -227,6 +244,9 @@ class OnPolicyDriver:
             next_values = self._next_value
             self._have_next_value = False
         else:
-            next_values = mod.get_values(d.get_batch_data("critic_obs", -1), None, None).view(
+            rec = getattr(mod, "recurrent", False)
+            next_values = mod.get_values(d.get_batch_data("critic_obs", -1),
+                                         d.rnn_states_critic[-1].reshape(-1, d.hidden_size) if rec else None,
+                                         d.masks[-1].reshape(-1, 1) if rec else None).view(
                 d.n_rollout_threads, d.num_agents, 1)
         self.buffer.compute_returns(next_values, mod.get_critic_value_normalizer())

@@ -48,6 +48,15 @@ class PPONet:
 
     def act(self, observation, action_masks: Optional[np.ndarray] = None, deterministic: bool = False,
             episode_starts: Optional[np.ndarray] = None) -> Tuple[torch.Tensor, Any]:
+        if episode_starts is not None and self.rnn_states_actor is not None:
+            # reset_rnn_states (ppo_net.py:33-47): zero the state of every agent of an env that starts an episode
+            starts = np.repeat(np.asarray(episode_starts, dtype=np.float32).reshape(-1), self.env.agent_num)
+            mask = 1.0 - starts[:, None, None]
+            if isinstance(self.rnn_states_actor, torch.Tensor):
+                self.rnn_states_actor = self.rnn_states_actor * torch.as_tensor(mask, dtype=torch.float32,
+                                                                                device=self.rnn_states_actor.device)
+            else:
+                self.rnn_states_actor = self.rnn_states_actor * mask
         actions, self.rnn_states_actor = self.module.act(obs=observation, rnn_states_actor=self.rnn_states_actor,
                                                          masks=self.masks, action_masks=action_masks,
                                                          deterministic=deterministic)

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from .. import ops, spaces
+from .. import ops, ops_rnn, spaces
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -84,11 +84,14 @@ class ValueNorm:
 
 
 # ---------------------------------------------------------------------------------------------------------
-def _tower_entries(prefix_head: str, D: int, H: int, K: int, gaussian: bool):
+def _tower_entries(prefix_head: str, D: int, H: int, K: int, gaussian: bool, recurrent: bool = False):
     """(state_dict key, shape) in the reference's registration order."""
     e = [("base.mlp.fc1.0.weight", (H, D)), ("base.mlp.fc1.0.bias", (H,)), ("base.mlp.fc1.2.weight", (H,)),
          ("base.mlp.fc1.2.bias", (H,)), ("base.mlp.fc3.0.weight", (H, H)), ("base.mlp.fc3.0.bias", (H,)),
          ("base.mlp.fc3.1.weight", (H,)), ("base.mlp.fc3.1.bias", (H,))]
+    if recurrent:  # RNNLayer (networks/utils/rnn.py:5-27): one-layer GRU + LayerNorm
+        e += [("rnn.rnn.weight_ih_l0", (3 * H, H)), ("rnn.rnn.weight_hh_l0", (3 * H, H)), ("rnn.rnn.bias_ih_l0", (3 * H,)),
+              ("rnn.rnn.bias_hh_l0", (3 * H,)), ("rnn.norm.weight", (H,)), ("rnn.norm.bias", (H,))]
     if prefix_head == "critic":
         e += [("v_out.weight", (K, H)), ("v_out.bias", (K,))]
     elif gaussian:
@@ -103,15 +106,17 @@ class Tower:
     """One MLP tower = flat parameter vector ``theta`` + descriptor; quacks enough like a torch module
     (``parameters / state_dict / load_state_dict / train / eval``) for the reference's callers."""
 
-    def __init__(self, role: str, obs_dim: int, n_out: int, head_kind: int, hidden: int, device, theta_host):
+    def __init__(self, role: str, obs_dim: int, n_out: int, head_kind: int, hidden: int, device, theta_host,
+                 recurrent: bool = False):
         self.role = role
         self.device = device
+        self.recurrent = recurrent
         self.net = ops.net_desc(obs_dim, n_out, head_kind, hidden)
-        self.n_params = ops.param_count(self.net)
+        self.n_params = ops_rnn.rnn_param_count(self.net) if recurrent else ops.param_count(self.net)
         assert theta_host.numel() == self.n_params, (theta_host.numel(), self.n_params)
         self.theta = theta_host.to(device=device, dtype=torch.float32).contiguous()
         self.grad = torch.zeros_like(self.theta)
-        self._entries = _tower_entries(role, obs_dim, hidden, n_out, head_kind == ops.HEAD_GAUSSIAN)
+        self._entries = _tower_entries(role, obs_dim, hidden, n_out, head_kind == ops.HEAD_GAUSSIAN, recurrent)
         self.training = False
         self.value_normalizer: Optional[ValueNorm] = None
 
@@ -184,19 +189,28 @@ class FusedAdam:
 
 
 def _host_init_tower(D: int, H: int, K: int, gaussian: bool, gain_head: float, use_orthogonal: bool,
-                     activation_id: int) -> torch.Tensor:
-    """Host-side initial parameters with the reference's generator consumption (see module docstring)."""
+                     activation_id: int, recurrent: bool = False) -> torch.Tensor:
+    """Host-side initial parameters with the reference's generator consumption (see module docstring).
+    Recurrent towers draw the nn.GRU default init and then the orthogonal / xavier init of weight_ih_l0,
+    weight_hh_l0 (gain 1, biases 0 - rnn.py:14-26) between the trunk and the head."""
     init_method = torch.nn.init.orthogonal_ if use_orthogonal else torch.nn.init.xavier_uniform_
     gain = torch.nn.init.calculate_gain(["tanh", "relu", "leaky_relu", "selu"][activation_id])
     fc1 = torch.nn.Linear(D, H)
     init_method(fc1.weight.data, gain=gain)
     fc3 = torch.nn.Linear(H, H)
     init_method(fc3.weight.data, gain=gain)
+    rnn_parts = []
+    if recurrent:
+        gru = torch.nn.GRU(H, H, num_layers=1)
+        init_method(gru.weight_ih_l0.data)
+        init_method(gru.weight_hh_l0.data)
+        rnn_parts = [gru.weight_ih_l0.data.reshape(-1), gru.weight_hh_l0.data.reshape(-1), torch.zeros(3 * H),
+                     torch.zeros(3 * H), torch.ones(H), torch.zeros(H)]
     head = torch.nn.Linear(H, K)
     init_method(head.weight.data, gain=gain_head)
     zeros, ones = torch.zeros(H), torch.ones(H)
-    parts = [fc1.weight.data.reshape(-1), zeros, ones, zeros, fc3.weight.data.reshape(-1), zeros, ones, zeros,
-             head.weight.data.reshape(-1), torch.zeros(K)]
+    parts = [fc1.weight.data.reshape(-1), zeros, ones, zeros, fc3.weight.data.reshape(-1), zeros, ones, zeros] + \
+        rnn_parts + [head.weight.data.reshape(-1), torch.zeros(K)]
     if gaussian:
         parts.append(torch.zeros(K))
     return torch.cat(parts).clone()
@@ -210,7 +224,7 @@ class PPOModule:
             raise NotImplementedError("use_share_model (PolicyValueNetwork) is not built in the MI355X engine")
         if model_dict:
             raise NotImplementedError("custom model_dict towers are not built: the engine runs fixed MFMA towers")
-        for flag in ("use_recurrent_policy", "use_naive_recurrent_policy", "use_influence_policy", "use_popart",
+        for flag in ("use_naive_recurrent_policy", "use_influence_policy", "use_popart",
                      "use_feature_normalization", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp",
                      "use_deepspeed", "use_joint_action_loss", "use_single_network"):
             if getattr(cfg, flag, False):
@@ -218,6 +232,9 @@ class PPOModule:
         if cfg.layer_N != 1 or cfg.hidden_size != 64 or cfg.activation_id != 1:
             raise NotImplementedError("MI355X towers are built for layer_N=1, hidden_size=64, ReLU (got %d, %d, %d)"
                                       % (cfg.layer_N, cfg.hidden_size, cfg.activation_id))
+        self.recurrent = bool(cfg.use_recurrent_policy)
+        if self.recurrent and (cfg.recurrent_N != 1 or getattr(cfg, "rnn_type", "gru") != "gru"):
+            raise NotImplementedError("recurrent towers are built for a one-layer GRU (recurrent_N=1, rnn_type=gru)")
         self.cfg = cfg
         self.device = nat.require_gpu(device)
         self.lr, self.critic_lr = cfg.lr, cfg.critic_lr
@@ -237,10 +254,11 @@ class PPOModule:
             raise NotImplementedError("action space %s not built (Discrete / Box only)" % kind)
         H = cfg.hidden_size
         # RNG order: policy tower first, then critic (ppo_module.py:58-89 -> rl_module.py:65-87)
-        tp = _host_init_tower(Dp, H, K, head == ops.HEAD_GAUSSIAN, cfg.gain, cfg.use_orthogonal, cfg.activation_id)
-        tc = _host_init_tower(Dc, H, 1, False, 1.0, cfg.use_orthogonal, cfg.activation_id)
-        policy = Tower("policy", Dp, K, head, H, self.device, tp)
-        critic = Tower("critic", Dc, 1, ops.HEAD_VALUE, H, self.device, tc)
+        rec = self.recurrent
+        tp = _host_init_tower(Dp, H, K, head == ops.HEAD_GAUSSIAN, cfg.gain, cfg.use_orthogonal, cfg.activation_id, rec)
+        tc = _host_init_tower(Dc, H, 1, False, 1.0, cfg.use_orthogonal, cfg.activation_id, rec)
+        policy = Tower("policy", Dp, K, head, H, self.device, tp, rec)
+        critic = Tower("critic", Dc, 1, ops.HEAD_VALUE, H, self.device, tc, rec)
         if cfg.use_valuenorm:
             critic.value_normalizer = ValueNorm(1, device=self.device)
         self.models = {"policy": policy, "critic": critic}
@@ -261,6 +279,35 @@ class PPOModule:
         if width is not None:
             t = t.reshape(-1, width)
         return t.contiguous()
+
+    def _forward_rnn(self, critic_obs, obs, h_policy, h_critic, masks, action_masks, deterministic, want_value=True,
+                     want_action=True, forced_u=None, out=None, h_out=None):
+        """Recurrent get_actions / get_values / act: states [B, (1,) H] in, new states out (``h_out`` = pair of
+        destination tensors, e.g. the buffer's next slot; default fresh tensors)."""
+        p, c = self.models["policy"], self.models["critic"]
+        H = p.net.hidden
+        x = self._dev(obs, p.net.obs_dim) if want_action else None
+        xc = self._dev(critic_obs, c.net.obs_dim) if want_value else None
+        B = (x if x is not None else xc).shape[0]
+        mk = self._dev(masks, 1).reshape(B)
+        hp_in = self._dev(h_policy, H) if want_action else None
+        hc_in = self._dev(h_critic, H) if want_value else None
+        am = self._dev(action_masks, p.net.n_out) if (want_action and action_masks is not None and p.net.head_kind ==
+                                                       ops.HEAD_CATEGORICAL) else None
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=self.device)
+        if out is None:
+            values = f(B, 1) if want_value else None
+            actions, logp = (f(B, self.act_width), f(B, self.act_width)) if want_action else (None, None)
+        else:
+            values, actions, logp = out
+        hp_out, hc_out = h_out if h_out is not None else (f(B, H) if want_action else None, f(B, H) if want_value else None)
+        ops_rnn.rnn_act_step(p.net if want_action else None, p.theta if want_action else None,
+                             c.net if want_value else None, c.theta if want_value else None, x, xc, hp_in, hc_in, mk, am,
+                             B, deterministic, self.act_seed, 0, self.rng_step, self._dev(forced_u, self.act_width),
+                             values, actions, logp, hp_out, hc_out)
+        if want_action and not deterministic:
+            self.rng_step += 1
+        return values, actions, logp, hp_out, hc_out
 
     def _forward(self, critic_obs, obs, action_masks, deterministic, want_value=True, want_action=True,
                  forced_u=None, out=None):
@@ -291,10 +338,16 @@ class PPOModule:
 
     def get_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks=None,
                     deterministic=False):
+        if self.recurrent:
+            v, a, lp, hp, hc = self._forward_rnn(critic_obs, obs, rnn_states_actor, rnn_states_critic, masks,
+                                                 action_masks, deterministic)
+            return v, a, lp, hp.unsqueeze(1), hc.unsqueeze(1)  # [B, recurrent_N, H] like rnn.py:49
         values, actions, logp = self._forward(critic_obs, obs, action_masks, deterministic)
         return values, actions, logp, rnn_states_actor, rnn_states_critic
 
     def get_values(self, critic_obs, rnn_states_critic, masks):
+        if self.recurrent:
+            return self._forward_rnn(critic_obs, None, None, rnn_states_critic, masks, None, True, want_action=False)[0]
         p, c = self.models["policy"], self.models["critic"]
         xc = self._dev(critic_obs, c.net.obs_dim)
         values = torch.empty(xc.shape[0], 1, dtype=torch.float32, device=self.device)
@@ -306,6 +359,8 @@ class PPOModule:
         """Forward-only (no autograd graph: the training path fuses loss + backward in ``orl_ppo_fwd_bwd``).
         Returns ``(values, action_log_probs, dist_entropy, policy_values=None)`` like ppo_module.py:149-193;
         the entropy is the active-mask weighted mean when ``cfg.use_policy_active_masks`` (policy_network.py:199)."""
+        if self.recurrent:
+            raise NotImplementedError("evaluate_actions over recurrent chunks runs inside orl_rnn_ppo_fwd_bwd only")
         p, c = self.models["policy"], self.models["critic"]
         x = self._dev(obs, p.net.obs_dim)
         xc = self._dev(critic_obs, c.net.obs_dim)
@@ -322,6 +377,10 @@ class PPOModule:
         return values, logp, ent[0], None
 
     def act(self, obs, rnn_states_actor, masks, action_masks=None, deterministic=False):
+        if self.recurrent:
+            _, actions, _, hp, _ = self._forward_rnn(None, obs, rnn_states_actor, None, masks, action_masks,
+                                                     deterministic, want_value=False)
+            return actions, hp.unsqueeze(1)
         _, actions, _ = self._forward(None, obs, action_masks, deterministic, want_value=False)
         return actions, rnn_states_actor
 

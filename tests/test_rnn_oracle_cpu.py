@@ -26,6 +26,21 @@ def test_recurrent_init_matches_reference_rng_order(case, seed):
     assert np.array_equal(tc.numpy(), g["theta_c0"])
 
 
+@pytest.mark.parametrize("case,seed", [("train_recurrent", 5), ("train_recurrent_chunk5", 6)])
+def test_engine_host_init_of_recurrent_towers_matches_reference(case, seed):
+    """The product's own initialiser (openrl_amd/modules/ppo_module.py) - host code, runs without a GPU."""
+    from openrl_amd.modules.ppo_module import _host_init_tower
+
+    g = H.load_golden(case)
+    cfg = H.case_cfg(g)
+    pspec, cspec = RH.rnn_specs(g)
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    tp = _host_init_tower(pspec.obs_dim, 64, pspec.n_out, pspec.head == po.HEAD_GAUSSIAN, cfg.gain, cfg.use_orthogonal,
+                          cfg.activation_id, recurrent=True)
+    tc = _host_init_tower(cspec.obs_dim, 64, 1, False, 1.0, cfg.use_orthogonal, cfg.activation_id, recurrent=True)
+    assert np.array_equal(tp.numpy(), g["theta_p0"]) and np.array_equal(tc.numpy(), g["theta_c0"])
+
+
 @pytest.mark.parametrize("case", RH.RNN_CASES)
 def test_recurrent_train_replay_matches_reference(case):
     g = H.load_golden(case)

@@ -1,0 +1,136 @@
+"""Recurrent (GRU) path through the host mirror of the reference API: PPOModule / ReplayData / PPOAlgorithm /
+OnPolicyDriver with ``use_recurrent_policy`` (the way examples/mpe/mpe_ppo.yaml runs cfg4), replaying the golden
+cases minted from the real reference.  Needs a MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as po
+from oracle import rnn_oracle as ro
+from tests import helpers as H
+from tests import rnn_helpers as RH
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+THETA_RTOL, THETA_ATOL = 2e-3, 4e-5
+INFO_RTOL, INFO_ATOL = 3e-4, 3e-5
+KEYS = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
+
+
+def _spaces(g):
+    from openrl_amd import spaces
+
+    Dp, Dc = g["buf_policy_obs"].shape[-1], g["buf_critic_obs"].shape[-1]
+    box = lambda d: spaces.Box(-np.inf, np.inf, (d,))
+    obs_space = box(Dp) if Dp == Dc else spaces.Dict({"policy": box(Dp), "critic": box(Dc)})
+    if "buf_action_masks" in g:
+        act_space = spaces.Discrete(g["buf_action_masks"].shape[-1])
+    else:
+        act_space = spaces.Box(-1, 1, (g["buf_actions"].shape[-1],))
+    return obs_space, act_space
+
+
+def build_engine(g, seed=None):
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers.replay_data import ReplayData
+    from openrl_amd.modules.ppo_module import PPOModule
+
+    cfg = H.case_cfg(g)
+    T, N, A = g["buf_actions"].shape[:3]
+    cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents = T, N, A
+    cfg.rnn_hidden_size = cfg.hidden_size
+    obs_space, act_space = _spaces(g)
+    if seed is not None:
+        import random
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    module = PPOModule(cfg, obs_space, obs_space, act_space, device=DEV, rank=0, world_size=1)
+    buf = ReplayData(cfg, A, obs_space, act_space, device=DEV)
+    algo = PPOAlgorithm(cfg, module, agent_num=A, device=DEV)
+    return cfg, module, buf, algo
+
+
+@pytest.mark.parametrize("case,seed", [("train_recurrent", 5), ("train_recurrent_chunk5", 6)])
+def test_recurrent_module_init_is_the_reference_init(case, seed):
+    g = H.load_golden(case)
+    _, module, _, _ = build_engine(g, seed=seed)
+    # same generator stream; the orthogonal init's QR runs in this host's LAPACK, hence allclose and not array_equal
+    # (bit-equality on the authoring host is asserted by tests/test_rnn_oracle_cpu.py for the same code path)
+    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p0"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c0"], rtol=1e-4, atol=3e-5)
+    sd = module.models["policy"].state_dict()
+    assert sd["rnn.rnn.weight_ih_l0"].shape == (192, 64) and sd["rnn.norm.bias"].shape == (64,)
+
+
+@pytest.mark.parametrize("case", RH.RNN_CASES)
+def test_recurrent_train_matches_reference_golden(case):
+    g = H.load_golden(case)
+    cfg, module, buf, algo = build_engine(g)
+    module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+    module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+    for f in ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks",
+              "bad_masks", "active_masks", "action_masks", "rnn_states", "rnn_states_critic"):
+        if "buf_" + f in g and getattr(buf, f) is not None:
+            getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    info = algo.train(buf)
+    r = RH.rnn_oracle_replay(g)
+    assert len(algo.last_indices) == len(r["used"])
+    for got, want in zip(algo.last_indices, r["used"]):  # torch.randperm(data_chunks) stream of replay_data.py:1078
+        assert np.array_equal(got.cpu().numpy(), want)
+    np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
+    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
+
+
+def test_recurrent_stepwise_rollout_reproduces_the_reference_buffer():
+    """Teacher-forced stepwise rollout (golden actions are deterministic functions of obs, states and the sampler's
+    uniforms, which the reference drew from torch.multinomial - so compare what does not depend on the sample:
+    hidden states and values slot by slot, given the golden observations / masks)."""
+    g = H.load_golden("train_recurrent")
+    cfg, module, buf, algo = build_engine(g)
+    module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+    module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+    T, N, A = g["buf_actions"].shape[:3]
+    for f in ("policy_obs", "critic_obs", "masks"):
+        getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+    for t in range(T):
+        v, a, lp, hp, hc = module.get_actions(buf.get_batch_data("critic_obs", t), buf.get_batch_data("policy_obs", t),
+                                              buf.get_batch_data("rnn_states", t), buf.get_batch_data("rnn_states_critic", t),
+                                              buf.get_batch_data("masks", t))
+        assert hp.shape == (N * A, 1, 64) and a.shape == (N * A, 1)
+        m = buf.masks[t + 1].unsqueeze(-1)
+        buf.rnn_states[t + 1].copy_(hp.view(N, A, 1, 64) * m)      # driver: zero where the env finished
+        buf.rnn_states_critic[t + 1].copy_(hc.view(N, A, 1, 64) * m)
+        np.testing.assert_allclose(v.cpu().numpy().reshape(N, A, 1), g["buf_value_preds"][t], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(buf.rnn_states.cpu().numpy(), g["buf_rnn_states"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(buf.rnn_states_critic.cpu().numpy(), g["buf_rnn_states_critic"], rtol=3e-4, atol=3e-5)
+    nv = module.get_values(buf.get_batch_data("critic_obs", -1), buf.rnn_states_critic[-1].reshape(-1, 64),
+                           buf.masks[-1].reshape(-1, 1))
+    np.testing.assert_allclose(nv.cpu().numpy().reshape(N, A, 1), g["next_values"], rtol=3e-4, atol=3e-5)
+
+
+def test_recurrent_agent_trains_on_a_host_multiagent_env():
+    """make-less end to end: PPONet + PPOAgent.train with use_recurrent_policy on the duck-typed host env."""
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.modules.common import PPONet
+    from openrl_amd.runners.common import PPOAgent
+    from tests.test_multiagent_gpu import ToyMultiAgentEnv
+
+    N, A, T = 8, 3, 25
+    cfg = default_cfg(["--episode_length", str(T), "--ppo_epoch", "2", "--use_recurrent_policy", "true", "--seed", "1"])
+    env = ToyMultiAgentEnv(N, A)
+    net = PPONet(env, cfg=cfg, device=DEV)
+    agent = PPOAgent(net)
+    th0 = net.module.models["policy"].theta.clone()
+    agent.train(total_time_steps=2 * N * T)
+    d = agent.driver.buffer.data
+    assert d.rnn_states.shape == (T + 1, N, A, 1, 64) and d.rnn_states.abs().max() > 0
+    assert torch.all(d.rnn_states[1:, 0] == 0)          # env 0 finishes every step -> its stored states are zero
+    assert torch.isfinite(net.module.models["policy"].theta).all()
+    assert (net.module.models["policy"].theta - th0).abs().max() > 0
+    obs = {"policy": np.zeros((N, A, 18), np.float32), "critic": np.zeros((N, A, 54), np.float32)}
+    agent.reset()
+    action, _ = agent.act(obs)
+    assert action.shape == (N, A, 1)
