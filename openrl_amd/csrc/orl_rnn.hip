@@ -127,7 +127,7 @@ __global__ void rnn_chunk_rows_kernel(const int64_t* __restrict__ chunk_idx, int
 // update: row kernel
 // =====================================================================================================
 constexpr int RNN_ROW_BLOCKS = 256;
-constexpr int RNN_WG_BLOCKS = 512;
+constexpr int RNN_WG_BLOCKS = 512;  // both towers together: 2 workgroups per CU
 
 struct RnnRowArgs {
   orl_net_desc net;
@@ -145,8 +145,11 @@ struct RnnRowArgs {
   int R, o_x, Nc, L;
 };
 
+// Body of the row kernel for one tower; `bid` / `nblk` = this workgroup's index / count within its tower's share
+// of the launch (both towers run in ONE launch so that 2 x n_tiles work units spread over all CUs - with cfg4's
+// 4800 tiles per tower a per-tower launch leaves 22 % of the wave slots idle in the last round).
 template <int HEAD, int NO>
-__global__ __launch_bounds__(512, 2) void rnn_row_kernel(RnnRowArgs A) {
+__device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const RnnLayout tl(A.net);
   const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN);
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void rnn_row_kernel(RnnRowArgs A) {
 
   const int n_tiles = (Nc + TILE_B - 1) / TILE_B;
   const int nwv = blockDim.x >> 6;
-  for (int tile = blockIdx.x * nwv + wave; tile < n_tiles; tile += gridDim.x * nwv) {
+  for (int tile = bid * nwv + wave; tile < n_tiles; tile += nblk * nwv) {
     const int ci = tile * TILE_B + j;
     const bool valid = ci < Nc;
     const int cis = valid ? ci : 0;  // padding lanes shadow chunk 0: finite data, zero loss weight
@@ -388,7 +391,14 @@ __global__ __launch_bounds__(512, 2) void rnn_row_kernel(RnnRowArgs A) {
     }
     __syncthreads();
   }
-  for (int e = threadIdx.x; e < PW; e += blockDim.x) A.partials[(size_t)blockIdx.x * PW + e] = acc[e];
+  for (int e = threadIdx.x; e < PW; e += blockDim.x) A.partials[(size_t)bid * PW + e] = acc[e];
+}
+
+// blocks [0, split) = policy tower, [split, gridDim) = critic tower
+template <int HEADP, int NOP>
+__global__ __launch_bounds__(512, 2) void rnn_row_pair_kernel(RnnRowArgs P, RnnRowArgs Cc, int split) {
+  if ((int)blockIdx.x < split) rnn_row_body<HEADP, NOP>(P, blockIdx.x, split);
+  else rnn_row_body<ORL_HEAD_VALUE, 1>(Cc, blockIdx.x - split, gridDim.x - split);
 }
 
 // =====================================================================================================
@@ -407,8 +417,13 @@ __device__ inline float tape_opnd(const float* __restrict__ v, int m, int s, int
   return v[((m * 4 + qq) * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3)];
 }
 
-__global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs A) {
+__global__ __launch_bounds__(512, 4) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArgs Cc, int split) {
   extern __shared__ __attribute__((aligned(16))) float blk[];
+  // blocks [0, split) sweep the policy tower's tape, the rest the critic's (one launch for both)
+  const bool pol = (int)blockIdx.x < split;
+  const RnnWgArgs& A = pol ? P : Cc;
+  const int bid = pol ? blockIdx.x : blockIdx.x - split;
+  const int nblk = pol ? split : gridDim.x - split;
   const RnnRaw rl(A.net);
   const int D = A.net.obs_dim, K = A.net.n_out;
   const int ND = (D + 15) >> 4;
@@ -426,16 +441,32 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs A) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 G5[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) G5[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 G5 = {0.f, 0.f, 0.f, 0.f};  // waves 0-3: dhead x xhat3 tile `wave` (S5 columns 16*wave .. +15)
   float bsum = 0.f;  // column sum of delta column `threadIdx.x` (threads 0..399)
 
-  for (int b = blockIdx.x; b < A.n_blocks; b += gridDim.x) {
+  // Tape blocks travel HBM -> registers -> LDS; the NEXT block's loads are issued before the MFMAs of the
+  // current one, so the HBM latency hides behind the GEMM (a block is <= 2880 float4 = 6 per thread).
+  constexpr int PRE = 6;
+  const int n4 = BLK >> 2;
+  f32x4 pre[PRE];
+  auto fetch = [&](int b) {
     const f32x4* src = (const f32x4*)(A.tape + (size_t)b * BLK);
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int e = threadIdx.x + k * 512;
+      if (e < n4) pre[k] = src[e];
+    }
+  };
+  if (bid < A.n_blocks) fetch(bid);
+  for (int b = bid; b < A.n_blocks; b += nblk) {
     __syncthreads();  // previous block fully consumed
-    for (int e = threadIdx.x; e < (BLK >> 2); e += blockDim.x) ((f32x4*)blk)[e] = src[e];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int e = threadIdx.x + k * 512;
+      if (e < n4) ((f32x4*)blk)[e] = pre[k];
+    }
     __syncthreads();
+    if (b + nblk < A.n_blocks) fetch(b + nblk);
     if (wave < 7) {
       const float* dvp = blk + dv * TV;
       const float* ivp = blk + iv * TV;
@@ -451,31 +482,30 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs A) {
         for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi) G[mo][mi] = ORL_MFMA(av[mo], bv[mi], G[mo][mi]);
+        if (wave < 4) {
+          const int qq = c >> 2;
+          const float ah = blk[TAPE_HEAD + (qq * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3)];
+          G5 = ORL_MFMA(ah, tape_opnd(blk + TV_XH3 * TV, wave, s, c, q), G5);
+        }
       }
     } else {
       const float* dvp = blk + TV_DZ1 * TV;
       const float* xp = blk + TAPE_X;       // ND m-blocks of 256 floats, same (qq,row,r) layout
-      const float* hp = blk + TAPE_HEAD;    // one m-block
-      const float* x3 = blk + TV_XH3 * TV;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        float av[4], bv[4], b3[4];
+        float av[4], bv[4];
         const int qq = c >> 2;
         const int off = (qq * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           av[m] = tape_opnd(dvp, m, s, c, q);
           bv[m] = m < ND ? xp[m * 256 + off] : 0.f;
-          b3[m] = tape_opnd(x3, m, s, c, q);
         }
-        const float ah = hp[off];
 #pragma unroll
         for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
             if (mi < ND) G[mo][mi] = ORL_MFMA(av[mo], bv[mi], G[mo][mi]);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) G5[mi] = ORL_MFMA(ah, b3[mi], G5[mi]);
       }
     }
     // bias gradients: column sums of the six delta vectors (384 columns) and of the head deltas (16)
@@ -495,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs A) {
 
   // ---- write this workgroup's partial row: every wave owns disjoint outputs --------------------------
   const int PW = rl.total - rl.n_logstd;
-  float* out = A.partials + (size_t)blockIdx.x * PW;
+  float* out = A.partials + (size_t)bid * PW;
   // C fragment: lane (c, q), reg r -> out row 16*mo + 4q + r, in column 16*mi + c
   if (wave < 7) {
     float* o = out + (wave == 6 ? rl.oS2 : (wave < 3 ? rl.oS3 : rl.oP4) + g3 * 64 * 64);
@@ -505,6 +535,13 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs A) {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[(16 * mo + 4 * q + r) * HID + 16 * mi + c] = G[mo][mi][r];
+    if (wave < 4) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cc = 4 * q + r;
+        if (cc < K) out[rl.oS5 + cc * HID + 16 * wave + c] = G5[r];
+      }
+    }
   } else {
 #pragma unroll
     for (int mo = 0; mo < 4; ++mo)
@@ -515,13 +552,6 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs A) {
           const int k = 16 * mi + c;
           if (mi < ND && k < D) out[rl.oP1 + (16 * mo + 4 * q + r) * D + k] = G[mo][mi][r];
         }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cc = 4 * q + r;
-        if (cc < K) out[rl.oS5 + cc * HID + 16 * mi + c] = G5[mi][r];
-      }
   }
   // bias sums: thread t < 384 holds column (vec = t/64, f = t%64); t in [384,400) head column
   __syncthreads();
@@ -669,6 +699,39 @@ __global__ __launch_bounds__(256) void rnn_adam_kernel(RnnApplyTower P, RnnApply
   }
 }
 
+// column sums of two partial regions in one launch (fixed order => deterministic), each to its own output
+__global__ __launch_bounds__(256) void rnn_reduce_pair_kernel(const float* __restrict__ pa, int nb_a, int wa, int ga,
+                                                              float* __restrict__ oa, const float* __restrict__ pb,
+                                                              int nb_b, int wb, float* __restrict__ ob) {
+  __shared__ float sh[4][64];
+  const bool first = (int)blockIdx.x < ga;
+  const float* partials = first ? pa : pb;
+  const int n_blocks = first ? nb_a : nb_b, width = first ? wa : wb;
+  float* out = first ? oa : ob;
+  const int col = (first ? blockIdx.x : blockIdx.x - ga) * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < width) {
+    int b = rg;
+    for (; b + 4 < n_blocks; b += 8) {
+      s0 += partials[(size_t)b * width + col];
+      s1 += partials[(size_t)(b + 4) * width + col];
+    }
+    if (b < n_blocks) s0 += partials[(size_t)b * width + col];
+  }
+  sh[rg][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && col < width)
+    out[col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+static int orl_ppo_reduce_pair2(const float* pa, int nb_a, int wa, float* oa, const float* pb, int nb_b, int wb,
+                                float* ob, hipStream_t s) {
+  const int ga = (wa + 63) / 64, gb = (wb + 63) / 64;
+  hipLaunchKernelGGL(rnn_reduce_pair_kernel, dim3(ga + gb), dim3(256), 0, s, pa, nb_a, wa, ga, oa, pb, nb_b, wb, ob);
+  return launch_status("orl_rnn_ppo_fwd_bwd(reduce)");
+}
+
 // ---- host helpers ------------------------------------------------------------------------------------
 static int check_rnn_net(const orl_net_desc* n, const char* who, bool value) {
   if (!n) return fail(ORL_E_INVALID, "%s: null net descriptor", who);
@@ -688,9 +751,10 @@ struct RnnWs {  // workspace carve-up (floats) for one tower
     const RnnRaw rl(n);
     n_tiles = (n_chunks + TILE_B - 1) / TILE_B;
     n_blocks = n_tiles * L;
+    // each tower gets half of the CUs: its twin runs in the same launch
     grid_row = (n_tiles + 7) / 8;
-    if (grid_row > RNN_ROW_BLOCKS) grid_row = RNN_ROW_BLOCKS;
-    grid_wg = n_blocks < RNN_WG_BLOCKS ? n_blocks : RNN_WG_BLOCKS;
+    if (grid_row > RNN_ROW_BLOCKS / 2) grid_row = RNN_ROW_BLOCKS / 2;
+    grid_wg = n_blocks < RNN_WG_BLOCKS / 2 ? n_blocks : RNN_WG_BLOCKS / 2;
     rpw = rl.n_logstd + ORL_N_STATS;
     wpw = rl.total - rl.n_logstd;
     size_t o = 0;
@@ -703,12 +767,13 @@ struct RnnWs {  // workspace carve-up (floats) for one tower
 };
 
 template <int HEAD, int NO>
-static int launch_rnn_row(const RnnRowArgs& A, int grid, hipStream_t s) {
-  const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN);
-  const size_t lds = (size_t)tw.total * sizeof(float);
+static int launch_rnn_rows(const RnnRowArgs& P, const RnnRowArgs& Cc, int grid_p, int grid_c, hipStream_t s) {
+  const RnnLds twp(P.net.obs_dim, P.net.n_out, HEAD == ORL_HEAD_GAUSSIAN), twc(Cc.net.obs_dim, 1, false);
+  const size_t lds = (size_t)(twp.total > twc.total ? twp.total : twc.total) * sizeof(float);
   if (lds > 160 * 1024) return fail(ORL_E_UNSUPPORTED, "orl_rnn_ppo_fwd_bwd: tower needs %zu B of LDS", lds);
-  (void)hipFuncSetAttribute((const void*)rnn_row_kernel<HEAD, NO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((rnn_row_kernel<HEAD, NO>), dim3(grid), dim3(512), lds, s, A);
+  (void)hipFuncSetAttribute((const void*)rnn_row_pair_kernel<HEAD, NO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((rnn_row_pair_kernel<HEAD, NO>), dim3(grid_p + grid_c), dim3(512), lds, s, P, Cc, grid_p);
   return launch_status("orl_rnn_ppo_fwd_bwd(row)");
 }
 
@@ -809,40 +874,40 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
   A.cols.o_act = o_ac; A.cols.o_lp = o_lp; A.cols.o_adv = o_adv; A.cols.o_vp = o_adv + 1; A.cols.o_rt = o_adv + 2;
   A.cols.o_am = o_adv + 3; A.cols.o_mk = o_adv + 4; A.cols.K = K;
   const RnnWs wp(*pnet, batch->n_chunks, batch->L), wc(*cnet, batch->n_chunks, batch->L);
-  float* sums_t = sums;
-  for (int t = 0; t < 2; ++t) {
-    const orl_net_desc& net = t == 0 ? *pnet : *cnet;
-    const RnnWs& w = t == 0 ? wp : wc;
-    float* base = workspace + (t == 0 ? 0 : wp.total);
-    const RnnRaw rl(net);
-    A.net = net; A.theta = t == 0 ? ptheta : ctheta; A.hbuf = t == 0 ? batch->h_policy : batch->h_critic;
-    A.o_x = t == 0 ? 0 : o_co;
-    A.htape = base + w.htape; A.tape = base + w.tape; A.partials = base + w.rpart;
-    if (t == 1) rc = launch_rnn_row<ORL_HEAD_VALUE, 1>(A, w.grid_row, s);
-    else if (net.head_kind == ORL_HEAD_CATEGORICAL) {
-      if (net.n_out <= 2) rc = launch_rnn_row<ORL_HEAD_CATEGORICAL, 2>(A, w.grid_row, s);
-      else if (net.n_out <= 8) rc = launch_rnn_row<ORL_HEAD_CATEGORICAL, 8>(A, w.grid_row, s);
-      else rc = launch_rnn_row<ORL_HEAD_CATEGORICAL, 16>(A, w.grid_row, s);
-    } else {
-      if (net.n_out <= 8) rc = launch_rnn_row<ORL_HEAD_GAUSSIAN, 8>(A, w.grid_row, s);
-      else rc = launch_rnn_row<ORL_HEAD_GAUSSIAN, 16>(A, w.grid_row, s);
-    }
-    if (rc) return rc;
-    RnnWgArgs G;
-    G.net = net; G.tape = base + w.tape; G.partials = base + w.wpart; G.n_blocks = w.n_blocks;
-    const size_t lds = (size_t)tape_block_floats(net.obs_dim) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)rnn_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(rnn_wgrad_kernel, dim3(w.grid_wg), dim3(512), lds, s, G);
-    rc = launch_status("orl_rnn_ppo_fwd_bwd(wgrad)");
-    if (rc) return rc;
-    // sums of this tower: [raw without logstd | dlogstd | stats]
-    rc = orl_ppo_reduce(base + w.wpart, w.grid_wg, w.wpw, sums_t, stream);
-    if (rc) return rc;
-    rc = orl_ppo_reduce(base + w.rpart, w.grid_row, w.rpw, sums_t + w.wpw, stream);
-    if (rc) return rc;
-    sums_t += rl.total + ORL_N_STATS;
+  float* base_p = workspace;
+  float* base_c = workspace + wp.total;
+  RnnRowArgs C2 = A;
+  A.net = *pnet; A.theta = ptheta; A.hbuf = batch->h_policy; A.o_x = 0;
+  A.htape = base_p + wp.htape; A.tape = base_p + wp.tape; A.partials = base_p + wp.rpart;
+  C2.net = *cnet; C2.theta = ctheta; C2.hbuf = batch->h_critic; C2.o_x = o_co;
+  C2.htape = base_c + wc.htape; C2.tape = base_c + wc.tape; C2.partials = base_c + wc.rpart;
+  // (1) row kernels of both towers, one launch
+  const int no = pnet->n_out;
+  if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
+    if (no <= 2) rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 2>(A, C2, wp.grid_row, wc.grid_row, s);
+    else if (no <= 8) rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 8>(A, C2, wp.grid_row, wc.grid_row, s);
+    else rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 16>(A, C2, wp.grid_row, wc.grid_row, s);
+  } else {
+    if (no <= 8) rc = launch_rnn_rows<ORL_HEAD_GAUSSIAN, 8>(A, C2, wp.grid_row, wc.grid_row, s);
+    else rc = launch_rnn_rows<ORL_HEAD_GAUSSIAN, 16>(A, C2, wp.grid_row, wc.grid_row, s);
   }
-  return 0;
+  if (rc) return rc;
+  // (2) weight-gradient GEMMs over both tapes, one launch
+  RnnWgArgs Gp, Gc;
+  Gp.net = *pnet; Gp.tape = A.tape; Gp.partials = base_p + wp.wpart; Gp.n_blocks = wp.n_blocks;
+  Gc.net = *cnet; Gc.tape = C2.tape; Gc.partials = base_c + wc.wpart; Gc.n_blocks = wc.n_blocks;
+  const int bp = tape_block_floats(pnet->obs_dim), bc = tape_block_floats(cnet->obs_dim);
+  const size_t lds = (size_t)(bp > bc ? bp : bc) * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)rnn_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(rnn_wgrad_kernel, dim3(wp.grid_wg + wc.grid_wg), dim3(512), lds, s, Gp, Gc, wp.grid_wg);
+  rc = launch_status("orl_rnn_ppo_fwd_bwd(wgrad)");
+  if (rc) return rc;
+  // (3) sums of each tower: [raw without logstd | dlogstd | stats]
+  float* sums_c = sums + RnnRaw(*pnet).total + ORL_N_STATS;
+  rc = orl_ppo_reduce_pair2(Gp.partials, wp.grid_wg, wp.wpw, sums, Gc.partials, wc.grid_wg, wc.wpw, sums_c, s);
+  if (rc) return rc;
+  return orl_ppo_reduce_pair2(A.partials, wp.grid_row, wp.rpw, sums + wp.wpw, C2.partials, wc.grid_row, wc.rpw,
+                              sums_c + wc.wpw, s);
 }
 
 int orl_rnn_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums, const orl_ppo_hparams* hp,
