@@ -300,6 +300,20 @@ int orl_env_step(int env_kind, float* env_state, float* ep_stats, const float* a
 int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,
                       const float* ctheta, const orl_rollout_args* args, float* next_value, void* stream);
 
+/* ---- device-resident MPE simple_spread (BASELINE config 4's env) ------------------
+ * 3 agents, 3 landmarks, Discrete(5) actions: World.step physics (openrl/envs/mpe/core.py:216-323), rewards and
+ * observations of scenarios/simple_spread.py:84-125, shared reward and done-at-world_length of
+ * multiagent_env.py:167-260, auto-reset of envs/vec_env/sync_venv.py:217-222.  One env = 3 buffer lanes.
+ *   env_state [N, orl_mpe_state_width()]; actions [N,3] (action index as float32, the layout orl_*act_step writes);
+ *   obs_policy [N,3,18]; obs_critic [N,3,54] (all agents' obs concatenated, may be NULL); rewards [N,3]; dones
+ *   uint8 [N,3]; ep_stats [N,4] as for the other device envs (may be NULL).  Reset positions come from Philox keyed
+ *   (env_seed, env, episode) instead of numpy's PCG64 (documented deviation; physics is generator-free). */
+int orl_mpe_state_width(void);
+int orl_mpe_reset(float* env_state, float* ep_stats, float* obs_policy, float* obs_critic, int N, uint64_t env_seed,
+                  void* stream);
+int orl_mpe_step(float* env_state, float* ep_stats, const float* actions, float* obs_policy, float* obs_critic,
+                 float* rewards, uint8_t* dones, int N, uint64_t env_seed, int world_length, void* stream);
+
 /* ---- recurrent (GRU) towers: use_recurrent_policy -------------------------
  * Tower = MLPBase (as above) -> RNNLayer = one-layer nn.GRU(H,H) + LayerNorm(H) (openrl/modules/networks/utils/
  * rnn.py:5-99, recurrent_N = 1) -> head.  The orl_net_desc fields keep their meaning; `theta` is the reference's

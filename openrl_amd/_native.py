@@ -112,6 +112,9 @@ _SIGNATURES = {
     "orl_env_step": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                C.c_uint64, _P]),
     "orl_rollout_fused": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, C.POINTER(RolloutArgs), _P, _P]),
+    "orl_mpe_state_width": (C.c_int, []),
+    "orl_mpe_reset": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
+    "orl_mpe_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.c_int, _P]),
     "orl_rnn_param_count": (C.c_int, [C.POINTER(NetDesc)]),
     "orl_rnn_raw_grad_count": (C.c_int, [C.POINTER(NetDesc)]),
     "orl_rnn_act_step": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int,

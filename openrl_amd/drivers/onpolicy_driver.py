@@ -77,7 +77,10 @@ class OnPolicyDriver:
         recurrent = bool(getattr(self.trainer.algo_module, "recurrent", False))
         if mode == "fused" and recurrent:
             raise ValueError("amd_rollout_mode=fused is not built for recurrent policies (stepwise rollout only)")
-        self.fused = dev_env and mode in ("auto", "fused") and not self.callback.needs_per_step and not recurrent
+        can_fuse = dev_env and bool(getattr(self.envs, "supports_fused_rollout", True)) and not recurrent
+        if mode == "fused" and not can_fuse:
+            raise ValueError("amd_rollout_mode=fused is not built for env %r" % getattr(self.envs, "env_name", "?"))
+        self.fused = can_fuse and mode in ("auto", "fused") and not self.callback.needs_per_step
         d = self.buffer.data
         self._next_value = torch.zeros(d.n_rollout_threads, d.num_agents, 1, dtype=torch.float32, device=self.device)
         self._have_next_value = False

@@ -33,7 +33,11 @@ def make(id: str, env_num: int = 1, asynchronous: bool = False, add_monitor: boo
         act = kwargs.pop("action_space", spaces.Discrete(2))
         return DeviceVecEnv("synthetic", env_num, obs_dim, act, id, kwargs.pop("episode_limit", 200), device=device,
                             seed=seed)
+    if id == "simple_spread":  # openrl/envs/mpe (registration.py:76-81 -> make_mpe_envs)
+        from ..vec_env.mpe_env import MpeSpreadVecEnv
+
+        return MpeSpreadVecEnv(env_num, id, kwargs.pop("world_length", 25), device=device, seed=seed)
     raise NotImplementedError(
-        "env id %r is not a device-resident env of the MI355X engine (built: 'CartPole-v1', '%s-v0'); "
+        "env id %r is not a device-resident env of the MI355X engine (built: 'CartPole-v1', 'simple_spread', '%s-v0'); "
         "pass make_custom_envs=... returning a duck-typed VecEnv (gymnasium is not part of this engine)"
         % (id, _SYNTH_PREFIX))

@@ -76,3 +76,23 @@ def rnn_ppo_apply(pnet, cnet, sums, hp: PPOHParams, padam: AdamState, cadam: Ada
     rc = _lib().orl_rnn_ppo_apply(C.byref(pnet), C.byref(cnet), fptr(sums), C.byref(hp), C.byref(padam),
                                   C.byref(cadam), fptr(train_info_accum), fptr(scratch), stream_ptr(dev))
     nat.check(rc, "orl_rnn_ppo_apply")
+
+
+# ------------------------------------------------------------------------------------------------ MPE device env
+def mpe_state_width() -> int:
+    return _lib().orl_mpe_state_width()
+
+
+def mpe_reset(env_state, ep_stats, obs_policy, obs_critic, N: int, seed: int) -> None:
+    dev = _dev(env_state)
+    rc = _lib().orl_mpe_reset(fptr(env_state), fptr(ep_stats), fptr(obs_policy), fptr(obs_critic), N,
+                              seed & (2 ** 64 - 1), stream_ptr(dev))
+    nat.check(rc, "orl_mpe_reset")
+
+
+def mpe_step(env_state, ep_stats, actions, obs_policy, obs_critic, rewards, dones, N: int, seed: int,
+             world_length: int) -> None:
+    dev = _dev(env_state)
+    rc = _lib().orl_mpe_step(fptr(env_state), fptr(ep_stats), fptr(actions), fptr(obs_policy), fptr(obs_critic),
+                             fptr(rewards), ptr(dones), N, seed & (2 ** 64 - 1), world_length, stream_ptr(dev))
+    nat.check(rc, "orl_mpe_step")

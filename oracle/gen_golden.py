@@ -292,6 +292,56 @@ def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=
     print(name + ".npz", {k: float(info[k]) for k in info})
 
 
+def mpe_case():
+    """Trajectories of the reference's MPE simple_spread: its own ``World`` / ``Scenario`` classes (core.py,
+    scenarios/simple_spread.py - numpy only) stepped with the action decoding of multiagent_env.py:268-310 restated
+    by hand (MultiAgentEnv itself needs gymnasium.core / seeding, absent here)."""
+    import importlib
+    import types
+
+    ref = "/root/reference/openrl/envs"
+    for name, path in (("openrl.envs", ref), ("openrl.envs.mpe", ref + "/mpe"),
+                       ("openrl.envs.mpe.scenarios", ref + "/mpe/scenarios")):
+        if name not in sys.modules:  # package shells: skip the __init__ files that pull gymnasium wrappers in
+            m = types.ModuleType(name)
+            m.__path__ = [path]
+            sys.modules[name] = m
+    Scenario = importlib.import_module("openrl.envs.mpe.scenarios.simple_spread").Scenario
+    out = {}
+    rs = np.random.RandomState(11)
+    E, S = 6, 30
+    pos0, lm0, acts = np.zeros((E, 3, 2)), np.zeros((E, 3, 2)), rs.randint(0, 5, (E, S, 3))
+    traj_pos, traj_vel = np.zeros((E, S, 3, 2)), np.zeros((E, S, 3, 2))
+    traj_rew, traj_obs = np.zeros((E, S, 3)), np.zeros((E, S, 3, 18))
+    for e in range(E):
+        sc = Scenario()
+        world = sc.make_world()
+        sc.reset_world(world, np.random.default_rng(100 + e))
+        if e >= 3:  # start some worlds crowded so that the contact forces are exercised
+            for i, ag in enumerate(world.agents):
+                ag.state.p_pos = np.array([0.05 * i, 0.12 * i]) + 0.01 * rs.randn(2)
+        pos0[e] = np.stack([a.state.p_pos for a in world.agents])
+        lm0[e] = np.stack([l.state.p_pos for l in world.landmarks])
+        for s in range(S):
+            for i, ag in enumerate(world.agents):  # _set_action, discrete_action_space branch
+                onehot = np.zeros(5)
+                onehot[acts[e, s, i]] = 1
+                ag.action.u = np.zeros(2)
+                ag.action.c = np.zeros(2)
+                ag.action.u[0] += onehot[1] - onehot[2]
+                ag.action.u[1] += onehot[3] - onehot[4]
+                ag.action.u *= 5.0
+            world.step()
+            traj_pos[e, s] = np.stack([a.state.p_pos for a in world.agents])
+            traj_vel[e, s] = np.stack([a.state.p_vel for a in world.agents])
+            ind = [sc.reward(a, world) for a in world.agents]
+            traj_rew[e, s] = np.sum(ind)  # shared_reward (multiagent_env.py:191-194)
+            traj_obs[e, s] = np.stack([sc.observation(a, world) for a in world.agents])
+    out.update(pos0=pos0, lm0=lm0, actions=acts, pos=traj_pos, vel=traj_vel, rewards=traj_rew, obs=traj_obs)
+    np.savez_compressed(os.path.join(OUT, "mpe_spread.npz"), **out)
+    print("mpe_spread.npz", traj_rew.mean())
+
+
 def perm_case():
     from torch.utils.data.sampler import BatchSampler, SubsetRandomSampler
 
@@ -317,6 +367,8 @@ def main():
         gae_cases()
     if want("perm"):
         perm_case()
+    if want("mpe_spread"):
+        mpe_case()
     cases = {
         "train_discrete": lambda n: _train_case(n, ["--ppo_epoch", "3", "--num_mini_batch", "2"], 4, lambda: Discrete(2)),
         "train_discrete_masks": lambda n: _train_case(

@@ -1,0 +1,104 @@
+"""Device-resident MPE simple_spread (csrc/orl_mpe.hip) vs the reference trajectories / the oracle restatement, and
+BASELINE config 4 end to end: make("simple_spread") + PPONet + PPOAgent.train with use_recurrent_policy."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpe_oracle as mo
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _state(pos, vel, lm, step=0.0):
+    E = pos.shape[0]
+    st = np.zeros((E, 24), np.float32)
+    st[:, 0:6], st[:, 6:12], st[:, 12:18], st[:, 18] = pos.reshape(E, 6), vel.reshape(E, 6), lm.reshape(E, 6), step
+    return torch.tensor(st, device=DEV)
+
+
+def test_mpe_step_matches_reference_trajectories_teacher_forced():
+    """One device step from every golden state (the reference integrates in float64; fp32 tolerance stated here)."""
+    from openrl_amd import ops_rnn
+
+    g = H.load_golden("mpe_spread")
+    E, S = g["actions"].shape[:2]
+    assert ops_rnn.mpe_state_width() == 24
+    obs_p, obs_c = torch.zeros(E, 3, 18, device=DEV), torch.zeros(E, 3, 54, device=DEV)
+    rew, done = torch.zeros(E, 3, device=DEV), torch.zeros(E, 3, dtype=torch.uint8, device=DEV)
+    for s in range(S):
+        pos = g["pos0"] if s == 0 else g["pos"][:, s - 1]
+        vel = np.zeros_like(pos) if s == 0 else g["vel"][:, s - 1]
+        st = _state(pos, vel, g["lm0"], step=float(s % 20))
+        ops_rnn.mpe_step(st, None, torch.tensor(g["actions"][:, s], dtype=torch.float32, device=DEV), obs_p, obs_c, rew,
+                         done, E, 0, 25)
+        stn = st.cpu().numpy()
+        np.testing.assert_allclose(stn[:, 0:6].reshape(E, 3, 2), g["pos"][:, s], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(stn[:, 6:12].reshape(E, 3, 2), g["vel"][:, s], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(obs_p.cpu().numpy(), g["obs"][:, s], rtol=1e-4, atol=2e-5)
+        # rewards are discontinuous at contact (|d - 0.3| < 1e-6 could flip a collision count): none in the fixture
+        np.testing.assert_allclose(rew.cpu().numpy(), g["rewards"][:, s], rtol=1e-5, atol=1e-5)
+        oc = obs_c.cpu().numpy()
+        assert np.array_equal(oc[:, 0], obs_p.cpu().numpy().reshape(E, 54)) and np.array_equal(oc[:, 1], oc[:, 0])
+        assert not done.any() and np.all(stn[:, 18] == float(s % 20) + 1)
+
+
+def test_mpe_reset_done_and_autoreset():
+    from openrl_amd.envs.common import make
+
+    N = 70
+    env = make("simple_spread", env_num=N, seed=4)
+    assert env.agent_num == 3 and env.parallel_env_num == N and env.action_space.n == 5
+    obs = env.reset_device(seed=4)
+    for n in (0, 13, 69):
+        ag, lm = mo.device_reset_positions(4, n, 0)
+        p, c = mo.observations(ag.astype(np.float64), np.zeros((3, 2)), lm.astype(np.float64))
+        np.testing.assert_allclose(obs["policy"][n].cpu().numpy(), p, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(obs["critic"][n].cpu().numpy(), c, rtol=1e-6, atol=1e-6)
+    a = torch.zeros(N, 3, 1, device=DEV)
+    total = torch.zeros(N, device=DEV)
+    for t in range(25):
+        obs, rew, done = env.step_device(a)
+        total += rew[:, 0, 0]
+        assert rew.shape == (N, 3, 1) and done.shape == (N, 3)
+        assert bool(done.all()) == (t == 24)
+    # auto-reset: the observation returned with done is the first one of episode 1 (sync_venv.py:217-222)
+    ag, lm = mo.device_reset_positions(4, 13, 1)
+    p, _ = mo.observations(ag.astype(np.float64), np.zeros((3, 2)), lm.astype(np.float64))
+    np.testing.assert_allclose(obs["policy"][13].cpu().numpy(), p, rtol=1e-6, atol=1e-6)
+    s = env.episode_statistics()
+    assert s["episodes_finished"] == N
+    np.testing.assert_allclose(s["episode_return_mean"], total.mean().item(), rtol=1e-5)
+    # no-op actions from rest: nothing moves, so the reward is constant over the episode
+    o2, r2, d2, _ = env.step(np.zeros((N, 3, 1)))
+    assert o2["policy"].shape == (N, 3, 18) and r2.shape == (N, 3, 1) and d2.dtype == bool
+
+
+def test_config4_end_to_end_recurrent_mappo_on_device_mpe():
+    """examples/mpe/mpe_ppo.yaml (use_recurrent_policy, episode_length 25, lr 7e-4) on the device MPE env."""
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+    from openrl_amd.runners.common import PPOAgent
+
+    N, T = 128, 25
+    cfg = default_cfg(["--seed", "0", "--lr", "7e-4", "--critic_lr", "7e-4", "--episode_length", str(T),
+                       "--use_recurrent_policy", "true", "--use_valuenorm", "true", "--use_adv_normalize", "true",
+                       "--ppo_epoch", "5", "--log_interval", "1"])
+    env = make("simple_spread", env_num=N)
+    net = PPONet(env, cfg=cfg, device=DEV)
+    agent = PPOAgent(net)
+    agent.train(total_time_steps=3 * N * T)
+    drv = agent.driver
+    assert not drv.fused and agent.num_time_steps == 3 * N * T
+    d = drv.buffer.data
+    assert d.policy_obs.shape == (T + 1, N, 3, 18) and d.critic_obs.shape == (T + 1, N, 3, 54)
+    # episodes are exactly one rollout long: slot 0 (= previous slot T) starts an episode: mask 0, states 0
+    assert torch.all(d.masks[0] == 0) and torch.all(d.masks[1:T] == 1)
+    assert torch.all(d.rnn_states[0] == 0) and d.rnn_states[1:T].abs().max() > 0
+    assert torch.isfinite(d.rewards).all() and d.rewards.max() < 0
+    for m in net.module.models.values():
+        assert torch.isfinite(m.theta).all()
+    st = env.episode_statistics()
+    assert st["episodes_finished"] == 3 * N and -400 < st["episode_return_mean"] < -50
