@@ -52,6 +52,11 @@ def main():
                 action_log_probs=(np.log(0.5) + 0.05 * rs.randn(T, N, 1, 1)).astype(np.float32))
     nv = (0.3 * rs.randn(N, 1, 1)).astype(np.float32)
     argv = ["--episode_length", str(T), "--ppo_epoch", "3", "--num_mini_batch", "1", "--amd_perm_mode", "device"]
+    recurrent = "rnn" in sys.argv[1:]
+    if recurrent:  # T is even: chunks of 2 never straddle env lanes, so shards see the same chunks as one process
+        argv += ["--use_recurrent_policy", "true", "--data_chunk_length", "2"]
+        host["rnn_states"] = (0.3 * rs.randn(T + 1, N, 1, 1, 64)).astype(np.float32)
+        host["rnn_states_critic"] = (0.3 * rs.randn(T + 1, N, 1, 1, 64)).astype(np.float32)
 
     # sharded run (all ranks)
     cfg = default_cfg(argv)

@@ -19,9 +19,10 @@ def _free_port():
     return p
 
 
-def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
+@pytest.mark.parametrize("mode", ["mlp", "rnn"])
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(mode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multirank_equiv.py")]
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multirank_equiv.py"), mode]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     out = res.stdout + res.stderr
     assert "MULTIRANK_EQUIV_OK" in out, out[-3000:]
