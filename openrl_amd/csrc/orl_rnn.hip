@@ -181,15 +181,26 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
     const int ci = tile * TILE_B + j;
     const bool valid = ci < Nc;
     const int cis = valid ? ci : 0;  // padding lanes shadow chunk 0: finite data, zero loss weight
-    // trunk forward of one record row; keeps what the backward pass needs when KEEP
-    auto trunk = [&](const float* rec, f32x4 (&xh1)[4], float& rstd1, unsigned& relu_bits, f32x4 (&xh2)[4],
+    // observation B operands of one record row: xv[k] = x[4k + q] (zero beyond D), k < DP/4 <= 16
+    auto load_x = [&](const float* rec, float (&xv)[16]) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int c = 4 * k + q;
+        xv[k] = (4 * k < DP && c < D) ? rec[A.o_x + c] : 0.f;
+      }
+    };
+    // trunk forward of one row; returns what the backward pass needs
+    auto trunk = [&](const float (&xv)[16], f32x4 (&xh1)[4], float& rstd1, unsigned& relu_bits, f32x4 (&xh2)[4],
                      float& rstd2, f32x4 (&n2)[4]) {
       f32x4 n1[4];
       load_vec_T(lw + tw.b1, q, xh1);
-      fc1_T(lw + tw.W1, DP, [&](int s) -> float {
-        const int k = 4 * s + q;
-        return k < D ? rec[A.o_x + k] : 0.f;
-      }, xh1, j, q);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (4 * k < DP) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) xh1[m] = ORL_MFMA(lw[tw.W1 + (16 * m + j) * DP + 4 * k + q], xv[k], xh1[m]);
+        }
+      }
       relu_bits = 0u;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -206,26 +217,35 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, n2);
     };
 
+    // The row index and mask of a step are fetched ONE STEP AHEAD (row -> record -> obs is a chain of three dependent
+    // global loads when started inside the step; this way the observation loads can start at once).
+    long long row_c = A.rows[cis];
+    float mk_c = A.masks[row_c];
+
     // ---------------- forward sweep: hidden state entering every step -> htape ----------------
     {
       f32x4 h[4];
-      const float* h0 = A.hbuf + (size_t)A.rows[cis] * HID;
+      const float* h0 = A.hbuf + (size_t)row_c * HID;
 #pragma unroll
       for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(h0 + 16 * m + 4 * q);
       for (int s = 0; s < L; ++s) {
         float* ht = A.htape + ((size_t)tile * L + s) * TV;
 #pragma unroll
         for (int m = 0; m < 4; ++m) *(f32x4*)(ht + (m * 64 + l) * 4) = h[m];
-        if (s == L - 1) break;
-        const long long row = A.rows[(size_t)s * Nc + cis];
-        const float mk = A.masks[row];
+        if (s == L - 1) break;  // row_c / mk_c / xv_c now describe step L-1: the first step of the backward sweep
+        float xv_c[16];
+        load_x(A.records + (size_t)row_c * A.R, xv_c);
+        const long long row_n = A.rows[(size_t)(s + 1) * Nc + cis];
+        const float mk_n = A.masks[row_n];
         f32x4 hin[4], xh1[4], xh2[4], n2[4], r[4], z[4], n[4], g[4];
         float r1, r2;
         unsigned rb;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) hin[m] = h[m] * mk;
-        trunk(A.records + (size_t)row * A.R, xh1, r1, rb, xh2, r2, n2);
+        for (int m = 0; m < 4; ++m) hin[m] = h[m] * mk_c;
+        trunk(xv_c, xh1, r1, rb, xh2, r2, n2);
         gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin, r, z, n, g, h, j, q);
+        row_c = row_n;
+        mk_c = mk_n;
       }
     }
 
@@ -234,15 +254,21 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
 #pragma unroll
     for (int m = 0; m < 4; ++m) carry[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = L - 1; s >= 0; --s) {
-      const long long row = A.rows[(size_t)s * Nc + cis];
+      const long long row = row_c;
       const float* rec = A.records + (size_t)row * A.R;
-      const float mk = A.masks[row];
+      const float mk = mk_c;
+      float xv[16];
+      load_x(rec, xv);
       float* tb = A.tape + ((size_t)tile * L + s) * BLK;
       f32x4 hin[4];
       {
         const float* ht = A.htape + ((size_t)tile * L + s) * TV;
 #pragma unroll
         for (int m = 0; m < 4; ++m) hin[m] = *(const f32x4*)(ht + (m * 64 + l) * 4) * mk;
+      }
+      if (s > 0) {  // next (earlier) step's inputs
+        row_c = A.rows[(size_t)(s - 1) * Nc + cis];
+        mk_c = A.masks[row_c];
       }
       tape_store(tb + TV_HIN * TV, hin, j, q);
       float rstd1, rstd2, rstd3;
@@ -251,7 +277,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       float dh[NO], dls[NO];
       {
         f32x4 xh1[4], xh2[4], n2[4], hnew[4];
-        trunk(rec, xh1, rstd1, relu_bits, xh2, rstd2, n2);
+        trunk(xv, xh1, rstd1, relu_bits, xh2, rstd2, n2);
         tape_store(tb + TV_XH1 * TV, xh1, j, q);
         tape_store(tb + TV_XH2 * TV, xh2, j, q);
         gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin, gr, gz, gn, ghn, hnew, j, q);
@@ -338,9 +364,13 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       for (int m = 0; m < 4; ++m) carry[m] = carry[m] * mk;  // h_in = h * mask
       // LN2 backward -> dz2
       {
+        // xhat2 / xhat1 come back from the tape through a laundered pointer: otherwise the compiler forwards the
+        // stored registers to these loads and keeps 32 VGPRs live across the GRU (-> scratch spills)
+        const float* tbr = tb;
+        asm volatile("" : "+v"(tbr));
         f32x4 xh2[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xh2[m] = *(const f32x4*)(tb + TV_XH2 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        for (int m = 0; m < 4; ++m) xh2[m] = *(const f32x4*)(tbr + TV_XH2 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
         ln_bwd_rnn(d2, xh2, lw + tw.g2, rstd2, q);
       }
       tape_store(tb + TV_DZ2 * TV, d2, j, q);
@@ -350,9 +380,11 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       mm64_S_wt<W2S>(lw + tw.W2, d2, d1, j, q);
       {
+        const float* tbr = tb;
+        asm volatile("" : "+v"(tbr));
         f32x4 xh1[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xh1[m] = *(const f32x4*)(tb + TV_XH1 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        for (int m = 0; m < 4; ++m) xh1[m] = *(const f32x4*)(tbr + TV_XH1 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
         ln_bwd_rnn(d1, xh1, lw + tw.g1, rstd1, q);
       }
 #pragma unroll
