@@ -209,7 +209,8 @@ typedef struct orl_ppo_hparams {
   int32_t use_valuenorm; /* normalise returns with vn_state inside the value loss */
   int32_t dual_clip_ppo;
   int32_t use_max_grad_norm;
-  int32_t reserved;
+  int32_t reserved; /* flag bits: 1 = critic-only update (turn_on == False, ppo.py:226-236);
+                     * 2 = A2C policy loss -adv*logp instead of the clipped surrogate (algorithms/a2c.py:88-98) */
 } orl_ppo_hparams;
 
 /* size (floats) of the raw gradient-sum vector of one tower and of the stats vector */

@@ -114,7 +114,7 @@ class PPOAlgorithm(BaseAlgorithm):
         hp = self.hp
         if not turn_on:
             hp = nat.PPOHParams.from_buffer_copy(self.hp)
-            hp.reserved = 1  # critic-only update (construct_loss_list, ppo.py:226-236)
+            hp.reserved |= 1  # critic-only update (construct_loss_list, ppo.py:226-236)
         ops.ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
                       co.native_state(co.step_count), self._info)
 
@@ -151,7 +151,7 @@ class PPOAlgorithm(BaseAlgorithm):
         hp = self.hp
         if not turn_on:
             hp = nat.PPOHParams.from_buffer_copy(self.hp)
-            hp.reserved = 1
+            hp.reserved |= 1
         ops_rnn.rnn_ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
                               co.native_state(co.step_count), self._info, self._rnn_scratch)
 

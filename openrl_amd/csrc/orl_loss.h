@@ -95,8 +95,13 @@ __device__ inline void ppo_row_loss(float (&hd)[NO], int n_out, bool valid, REC 
       if (hp.dual_clip_ppo && ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }
       const float s1 = ratio * adv;
       const float s2 = fminf(fmaxf(ratio, 1.f - hp.clip_param), 1.f + hp.clip_param) * adv;
-      const float surr = fminf(s1, s2);
-      const float gl = -((s1 <= s2) ? adv : 0.f) * dr_eff * ratio_raw;  // d(-surr)/d logp
+      float surr = fminf(s1, s2);
+      float gl = -((s1 <= s2) ? adv : 0.f) * dr_eff * ratio_raw;  // d(-surr)/d logp
+      if (hp.reserved & 2) {  // A2C (algorithms/a2c.py:88-98): loss = -adv * logp, train_info ratio = 0
+        surr = adv * lp;
+        gl = -adv;
+        ratio = 0.f;
+      }
 #pragma unroll
       for (int c = 0; c < NO; ++c) {
         if (c < n_out) {
@@ -127,8 +132,14 @@ __device__ inline void ppo_row_loss(float (&hd)[NO], int n_out, bool valid, REC 
           if (hp.dual_clip_ppo && ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }
           const float s1 = ratio * adv;
           const float s2 = fminf(fmaxf(ratio, 1.f - hp.clip_param), 1.f + hp.clip_param) * adv;
-          surr_sum += fminf(s1, s2);
-          const float gl = -((s1 <= s2) ? adv : 0.f) * dr_eff * ratio_raw;
+          float surr_c = fminf(s1, s2);
+          float gl = -((s1 <= s2) ? adv : 0.f) * dr_eff * ratio_raw;
+          if (hp.reserved & 2) {  // A2C
+            surr_c = adv * lp;
+            gl = -adv;
+            ratio = 0.f;
+          }
+          surr_sum += surr_c;
           dh[c] = w * gl * dmu / var;
           dls[c] = w * (gl * (dmu * dmu / var - 1.f) - hp.entropy_coef * ent_scale);
           ent_sum += 1.41893853320467274178f + ls;

@@ -1,4 +1,5 @@
 from ...modules.common.ppo_net import PPONet  # BASELINE.json names it under runners.common as well
+from .a2c_agent import A2CAgent
 from .ppo_agent import PPOAgent
 
-__all__ = ["PPOAgent", "PPONet"]
+__all__ = ["A2CAgent", "PPOAgent", "PPONet"]

@@ -91,7 +91,7 @@ def gae_cases():
     print("gae.npz", len(out))
 
 
-def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, seed=0):
+def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, seed=0, a2c=False):
     """Fill a reference buffer with a hand-driven rollout of the reference module, then run
     PPOAlgorithm.train and record everything needed to replay it."""
     from gymnasium.spaces import Box
@@ -109,7 +109,13 @@ def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, s
                        share_model=False, rank=0, world_size=1)
     out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"])}
     buffer = NormalReplayBuffer(cfg, 1, obs_space, act_space, data_client=None)
-    algo = PPOAlgorithm(cfg, module, agent_num=1)
+    if a2c:
+        from openrl.algorithms.a2c import A2CAlgorithm
+
+        algo = A2CAlgorithm(cfg, module, agent_num=1)
+        out["a2c"] = np.array(1)
+    else:
+        algo = PPOAlgorithm(cfg, module, agent_num=1)
     rs = np.random.RandomState(100 + seed)
     obs = rs.randn(N, 1, obs_dim).astype(np.float32)
     K = act_space.n if act_space.__class__.__name__ == "Discrete" else 0
@@ -162,7 +168,7 @@ def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, s
     torch.manual_seed(1234 + seed)
     algo.prep_training()
     info = algo.train(d)
-    out["train_info"] = np.array([float(info[k]) for k in
+    out["train_info"] = np.array([float(info.get(k, 0.0)) for k in
                                   ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
                                    "ratio")], np.float64)
     out["theta_p1"] = _flat(module.models["policy"])
@@ -381,6 +387,9 @@ def main():
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_valuenorm", "false", "--use_proper_time_limits",
                 "true", "--dual_clip_ppo", "true", "--use_clipped_value_loss", "--use_value_active_masks", "false",
                 "--use_policy_active_masks"], 4, lambda: Discrete(2), seed=3),
+        # A2CAlgorithm (algorithms/a2c.py): policy-gradient loss, one minibatch per epoch
+        "train_a2c": lambda n: _train_case(n, ["--ppo_epoch", "3", "--num_mini_batch", "4"], 4, lambda: Discrete(3),
+                                           seed=7, a2c=True),
         # recurrent (GRU) branch: T=7 is odd, so chunks of 2 straddle lanes like cfg4's T=25
         "train_recurrent": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 18, 54,

@@ -303,6 +303,7 @@ class PPOHyper:
     dual_clip_ppo: bool = False
     use_max_grad_norm: bool = True
     use_adv_normalize: bool = False
+    a2c: bool = False  # A2CAlgorithm.prepare_loss (algorithms/a2c.py:88-98): -adv * logp, no ratio / clip
 
 
 def huber_loss(e, d):  # modules/utils/util.py:20-23
@@ -365,6 +366,9 @@ def prepare_loss(hp: PPOHyper, pspec, ptheta, cspec, ctheta, vn, sample):
     surr1 = ratio * adv
     surr2 = torch.clamp(ratio, 1.0 - hp.clip_param, 1.0 + hp.clip_param) * adv
     surr_final = torch.min(surr1, surr2)
+    if hp.a2c:
+        surr_final = adv * logp  # policy_gradient_loss = -adv.detach() * action_log_probs
+        ratio = torch.zeros(1)   # a2c.py:139
     if hp.use_policy_active_masks:
         policy_loss = (-torch.sum(surr_final, dim=-1, keepdim=True) * active).sum() / active.sum()
     else:

@@ -173,6 +173,8 @@ def prepare_loss(hp: po.PPOHyper, pspec, ptheta, cspec, ctheta, vn, s: Dict[str,
     if hp.dual_clip_ppo:
         ratio = torch.min(ratio, torch.tensor(hp.dual_clip_coeff))
     surr_final = torch.min(ratio * adv, torch.clamp(ratio, 1.0 - hp.clip_param, 1.0 + hp.clip_param) * adv)
+    if getattr(hp, "a2c", False):
+        surr_final, ratio = adv * logp, torch.zeros(1)
     if hp.use_policy_active_masks:
         policy_loss = (-torch.sum(surr_final, dim=-1, keepdim=True) * active).sum() / active.sum()
     else:

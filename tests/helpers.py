@@ -41,6 +41,9 @@ def oracle_replay(g):
     """Replay the golden case's PPOAlgorithm.train with the oracle; returns final thetas, info, vn state."""
     cfg = case_cfg(g)
     hp = po.hyper_from_cfg(cfg)
+    nmb = cfg.num_mini_batch
+    if "a2c" in g:  # A2CAlgorithm: policy-gradient loss, num_mini_batch forced to 1 (a2c.py:37)
+        hp.a2c, nmb = True, 1
     pspec, cspec = case_specs(g)
     ptheta = torch.tensor(g["theta_p0"]).clone()
     ctheta = torch.tensor(g["theta_c0"]).clone()
@@ -49,7 +52,6 @@ def oracle_replay(g):
     vn = po.ValueNormOracle() if cfg.use_valuenorm else None
     buf = case_buffer(g)
     torch.manual_seed(int(g["perm_seed"]))
-    info, adv, used = po.train_ppo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, buf, cfg.ppo_epoch,
-                                   cfg.num_mini_batch)
+    info, adv, used = po.train_ppo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, buf, cfg.ppo_epoch, nmb)
     return dict(ptheta=ptheta.numpy(), ctheta=ctheta.numpy(), info=info, adv=adv, used=used,
                 vn=None if vn is None else vn.state(), cfg=cfg, hp=hp, pspec=pspec, cspec=cspec)
