@@ -127,7 +127,7 @@ __global__ void rnn_chunk_rows_kernel(const int64_t* __restrict__ chunk_idx, int
 // update: row kernel
 // =====================================================================================================
 constexpr int RNN_ROW_BLOCKS = 256;
-constexpr int RNN_WG_BLOCKS = 512;  // both towers together: 2 workgroups per CU
+constexpr int RNN_WG_BLOCKS = 256;  // both towers together: 1 workgroup per CU (3-slot DMA ring in LDS)
 
 struct RnnRowArgs {
   orl_net_desc net;
@@ -449,8 +449,8 @@ __device__ inline float tape_opnd(const float* __restrict__ v, int m, int s, int
   return v[((m * 4 + qq) * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3)];
 }
 
-__global__ __launch_bounds__(512, 4) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArgs Cc, int split) {
-  extern __shared__ __attribute__((aligned(16))) float blk[];
+__global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArgs Cc, int split) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];  // 3 slots of one tape block each
   // blocks [0, split) sweep the policy tower's tape, the rest the critic's (one launch for both)
   const bool pol = (int)blockIdx.x < split;
   const RnnWgArgs& A = pol ? P : Cc;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512, 4) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
   const int ND = (D + 15) >> 4;
   const int BLK = tape_block_floats(D);
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 15, q = l >> 4;
-  // waves 0-6: one 64 x 64 product each; wave 7: dz1 x obs (4 x ND tiles) and dhead x xhat3 (1 x 4 tiles)
+  // waves 0-6: one 64 x 64 product each; wave 7: dz1 x obs (4 x ND tiles); waves 0-3 also one dhead x xhat3 tile
   //   wave   0        1        2        3        4        5          6
   //   delta  dr       dz       dn       dr       dz       dghn       dz2
   //   input  xhat2    xhat2    xhat2    h_in     h_in     h_in       xhat1
@@ -476,29 +476,34 @@ __global__ __launch_bounds__(512, 4) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
   f32x4 G5 = {0.f, 0.f, 0.f, 0.f};  // waves 0-3: dhead x xhat3 tile `wave` (S5 columns 16*wave .. +15)
   float bsum = 0.f;  // column sum of delta column `threadIdx.x` (threads 0..399)
 
-  // Tape blocks travel HBM -> registers -> LDS; the NEXT block's loads are issued before the MFMAs of the
-  // current one, so the HBM latency hides behind the GEMM (a block is <= 2880 float4 = 6 per thread).
-  constexpr int PRE = 6;
-  const int n4 = BLK >> 2;
-  f32x4 pre[PRE];
-  auto fetch = [&](int b) {
-    const f32x4* src = (const f32x4*)(A.tape + (size_t)b * BLK);
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-      const int e = threadIdx.x + k * 512;
-      if (e < n4) pre[k] = src[e];
-    }
+  // Tape blocks stream HBM -> LDS by DMA (global_load_lds: no VGPRs, 1 KiB per wave instruction) through a ring of
+  // three slots: while block i is multiplied, blocks i+1 and i+2 are in flight - two blocks (<= 90 KB) per CU keep
+  // HBM busy, where a one-deep register prefetch left the memory pipe idle during commit + barriers (2.96 TB/s).
+  const int n_inst = BLK >> 8;                       // 1 KiB DMA instructions per block (BLK is a multiple of 256)
+  const int my_inst = (n_inst - wave + 7) >> 3;      // instructions k = wave, wave + 8, ... issued by this wave
+  auto issue = [&](int b, int slot) {
+    const float* src = A.tape + (size_t)b * BLK + l * 4;
+    float* dst = ring + (size_t)slot * BLK;
+    for (int k = wave; k < n_inst; k += 8)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 256),
+                                       (__attribute__((address_space(3))) void*)(dst + k * 256), 16, 0, 0);
   };
-  if (bid < A.n_blocks) fetch(bid);
+  if (bid < A.n_blocks) issue(bid, 0);
+  if (bid + nblk < A.n_blocks) issue(bid + nblk, 1);
+  int slot = 0;
   for (int b = bid; b < A.n_blocks; b += nblk) {
-    __syncthreads();  // previous block fully consumed
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-      const int e = threadIdx.x + k * 512;
-      if (e < n4) ((f32x4*)blk)[e] = pre[k];
+    // this wave's DMA for block b has landed when at most the younger block's instructions are outstanding
+    if (b + nblk < A.n_blocks) {
+      if (my_inst == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (my_inst == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
-    if (b + nblk < A.n_blocks) fetch(b + nblk);
+    __syncthreads();  // block b complete for every wave; slot (slot+2)%3 (block b - nblk) fully consumed
+    if (b + 2 * nblk < A.n_blocks) issue(b + 2 * nblk, slot == 0 ? 2 : slot - 1);
+    const float* blk = ring + (size_t)slot * BLK;
+    slot = slot == 2 ? 0 : slot + 1;
     if (wave < 7) {
       const float* dvp = blk + dv * TV;
       const float* ivp = blk + iv * TV;
@@ -547,10 +552,12 @@ __global__ __launch_bounds__(512, 4) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
       int f;
       if (t < 384) { base = blk + (t >> 6) * TV; f = t & 63; }
       else { base = blk + TAPE_HEAD; f = t - 384; }
-      const float* p = base + (((f >> 4) * 4 + ((f >> 2) & 3)) * 16) * 4 + (f & 3);
+      const int g = f >> 2;  // (m, qq) group of 16 row slots; lanes of a wave start at different slots so that the
+                             // 64 reads of one instruction spread over all LDS banks ((slot*4 + r) mod 32)
+      const float* p = base + g * 64 + (f & 3);
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += p[4 * r];
+      for (int i = 0; i < 16; ++i) s += p[((i + g) & 15) * 4];
       bsum += s;
     }
   }
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(512, 4) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
   }
   // bias sums: thread t < 384 holds column (vec = t/64, f = t%64); t in [384,400) head column
   __syncthreads();
-  float* sh = blk;
+  float* sh = ring;
   if (threadIdx.x < 400) sh[threadIdx.x] = bsum;
   __syncthreads();
   for (int e = threadIdx.x; e < 64; e += blockDim.x) {
@@ -929,7 +936,7 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
   Gp.net = *pnet; Gp.tape = A.tape; Gp.partials = base_p + wp.wpart; Gp.n_blocks = wp.n_blocks;
   Gc.net = *cnet; Gc.tape = C2.tape; Gc.partials = base_c + wc.wpart; Gc.n_blocks = wc.n_blocks;
   const int bp = tape_block_floats(pnet->obs_dim), bc = tape_block_floats(cnet->obs_dim);
-  const size_t lds = (size_t)(bp > bc ? bp : bc) * sizeof(float);
+  const size_t lds = 3 * (size_t)(bp > bc ? bp : bc) * sizeof(float);
   (void)hipFuncSetAttribute((const void*)rnn_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(rnn_wgrad_kernel, dim3(wp.grid_wg + wc.grid_wg), dim3(512), lds, s, Gp, Gc, wp.grid_wg);
   rc = launch_status("orl_rnn_ppo_fwd_bwd(wgrad)");
