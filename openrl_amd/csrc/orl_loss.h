@@ -85,11 +85,11 @@ __device__ inline void ppo_row_loss(float (&hd)[NO], int n_out, bool valid, REC 
         p[c] = 0.f;
         if (c < n_out) {
           const float ell = hd[c] - lse;
-          p[c] = expf(ell);
+          p[c] = __expf(ell);
           ent -= p[c] * ell;
         }
       }
-      float ratio = expf(lp - old_lp);
+      float ratio = __expf(lp - old_lp);
       const float ratio_raw = ratio;
       float dr_eff = 1.f;
       if (hp.dual_clip_ppo && ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }
@@ -126,7 +126,7 @@ __device__ inline void ppo_row_loss(float (&hd)[NO], int n_out, bool valid, REC 
           const float dmu = av - hd[c];
           const float var = sd * sd;
           const float lp = -(dmu * dmu) / (2.f * var) - ls - 0.91893853320467274178f;
-          float ratio = expf(lp - old_lp);
+          float ratio = __expf(lp - old_lp);
           const float ratio_raw = ratio;
           float dr_eff = 1.f;
           if (hp.dual_clip_ppo && ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }

@@ -137,7 +137,8 @@ __device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd) {
     v += (x[m][0] * x[m][0] + x[m][1] * x[m][1]) + (x[m][2] * x[m][2] + x[m][3] * x[m][3]);
   }
   v = row_allsum(v);
-  rstd = 1.0f / sqrtf(v * (1.0f / 64.0f) + 1e-5f);
+  // v_rsq_f32 (1 ulp) instead of the ~20-instruction correctly-rounded sqrt + IEEE division sequence
+  rstd = __builtin_amdgcn_rsqf(v * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
   for (int m = 0; m < 4; ++m) x[m] = x[m] * rstd;
 }
@@ -215,9 +216,9 @@ __device__ inline float cat_lse(float (&lg)[NO], int n_out, const float* __restr
   float se = 0.f;
 #pragma unroll
   for (int c = 0; c < NO; ++c) {
-    if (c < n_out) se += expf(lg[c] - mx);
+    if (c < n_out) se += __expf(lg[c] - mx);  // v_exp_f32 / v_log_f32: 1-ulp hardware transcendentals
   }
-  return mx + logf(se);
+  return mx + __logf(se);
 }
 
 // inverse-CDF sample of softmax(lg) with uniform u in [0,1)
@@ -227,7 +228,7 @@ __device__ inline int cat_sample(const float (&lg)[NO], int n_out, float lse, fl
   float tot = 0.f;
 #pragma unroll
   for (int c = 0; c < NO; ++c) {
-    p[c] = (c < n_out) ? expf(lg[c] - lse) : 0.f;
+    p[c] = (c < n_out) ? __expf(lg[c] - lse) : 0.f;
     tot += p[c];
   }
   const float ut = u * tot;

@@ -308,11 +308,11 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
           p[c] = 0.f;
           if (c < n_out) {
             const float ell = hd[c] - lse;
-            p[c] = expf(ell);
+            p[c] = __expf(ell);
             ent -= p[c] * ell;
           }
         }
-        float ratio = expf(lp - old_lp);
+        float ratio = __expf(lp - old_lp);
         const float ratio_raw = ratio;
         float dr_eff = 1.f;
         if (hp.dual_clip_ppo) {
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
             const float dmu = av - hd[c];
             const float var = sd * sd;
             const float lp = -(dmu * dmu) / (2.f * var) - ls - 0.91893853320467274178f;
-            float ratio = expf(lp - old_lp);
+            float ratio = __expf(lp - old_lp);
             const float ratio_raw = ratio;
             float dr_eff = 1.f;
             if (hp.dual_clip_ppo && ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }

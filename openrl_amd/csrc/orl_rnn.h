@@ -179,14 +179,15 @@ __device__ inline void fc1_g(const float* __restrict__ W1, int D, XB xb, f32x4 (
   }
 }
 
-// Gate non-linearities on the hardware transcendental units: v_exp_f32 / v_rcp_f32 are 1-ulp instructions, so
+// Gate non-linearities on the hardware transcendental units (v_exp_f32, v_rcp_f32 via __builtin_amdgcn_rcpf -
+// __frcp_rn still expands to the IEEE division sequence): 1-ulp instructions, so
 // sigma and tanh cost ~5 VALU ops instead of the ~25-35 of libm's expf + IEEE division / tanhf (the GRU evaluates
 // 3 x 64 of them per row and step, forward and recomputed forward).  Absolute error <= 3e-7, far inside the
 // stated fp32 tolerance of the parity tests.
-__device__ inline float sigmoid_f(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ inline float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ inline float tanh_f(float x) {
   const float xc = fminf(fmaxf(x, -15.0f), 15.0f);  // tanh(15) == 1 in fp32; keeps exp finite
-  return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * xc));
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * xc));
 }
 
 // LayerNorm backward in T layout, in place: d <- rstd * (d*g - mean(d*g) - xhat * mean(d*g*xhat))
