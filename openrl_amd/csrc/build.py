@@ -36,7 +36,7 @@ def _digest() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str:
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP):
@@ -45,15 +45,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 return LIB
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
            "-o", LIB] + srcs
+    if prof:  # phase-timing build of the tower kernel (orl_debug_prof); never the shipped configuration
+        cmd.insert(1, "-DORL_PROF")
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
     with open(STAMP, "w") as fh:
-        fh.write(dig)
+        fh.write(dig + ("-prof" if prof else ""))
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv or "--prof" in sys.argv, verbose=True, prof="--prof" in sys.argv))

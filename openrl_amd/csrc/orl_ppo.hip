@@ -273,6 +273,17 @@ extern "C" {
 
 int orl_ppo_max_blocks(void) { return PPO_MAX_BLOCKS; }
 
+#ifdef ORL_PROF
+// debug build only: cumulative per-phase cycle counts of wave 0 / workgroup 0 of every tower launch; reset on read
+int orl_debug_prof(unsigned long long* out16) {
+  unsigned long long zero[16] = {0};
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_orl_prof), sizeof(zero));
+  hipMemcpyToSymbol(HIP_SYMBOL(g_orl_prof), zero, sizeof(zero));
+  return 0;
+}
+#endif
+
 int orl_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                     const float* records, int rec_width, const int64_t* idx, int mb, const float* vn_state,
                     const orl_ppo_hparams* hp, float* partials, int* n_blocks_out, void* stream) {

@@ -29,6 +29,24 @@ namespace orl {
 #define ORL_PRIO(x) ((void)0)
 #endif
 
+#ifdef ORL_PROF
+// Phase timing build (python -m openrl_amd.csrc.build --prof; tools/tower_phase_prof.py): wave 0 of workgroup 0 reads
+// s_memtime after each phase of its tile loop and lane 0 adds the delta to an LDS counter (ds_add, no return value:
+// nothing on the vmcnt path - register accumulators were spilled to scratch by hipcc and global atomics sit in front
+// of the tile's own s_waitcnt vmcnt(0), both of which distorted the phases being measured).
+__device__ unsigned long long g_orl_prof[16];
+#define ORL_T(k)                                                                  \
+  do {                                                                            \
+    if (prof_on) {                                                                \
+      const unsigned long long t_now = __builtin_readcyclecounter();              \
+      if (l == 0) atomicAdd(&prof_lds[k], t_now - t_last);                        \
+      t_last = t_now;                                                             \
+    }                                                                             \
+  } while (0)
+#else
+#define ORL_T(k) ((void)0)
+#endif
+
 constexpr int PPO_MAX_BLOCKS = 256;  // one workgroup per CU
 constexpr int TS = 68;               // slab row stride (floats): 16-byte rows, bank-skewed
 constexpr int SLAB = TILE_B * TS;
@@ -214,6 +232,12 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     row_next = row_of(wave_g + n_waves);
   }
 
+#ifdef ORL_PROF
+  __shared__ unsigned long long prof_lds[16];
+  const bool prof_on = blockIdx.x == 0 && wave == 0;
+  if (prof_on && l < 16) prof_lds[l] = 0ull;
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
   for (int tile = consumer ? n_tiles : wave_g; tile < n_tiles; tile += n_waves) {
     const int i = tile * TILE_B + j;
     const bool valid = i < A.mb;
@@ -225,6 +249,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
 #define REC(col) RT[(((col) >> 2) << 6) + (j << 2) + ((col) & 3)]
 #define REC_R(r, col) RT[(((col) >> 2) << 6) + ((r) << 2) + ((col) & 3)]
 
+    ORL_T(0);  // record DMA wait + next issue
     // ---------------- forward ----------------
     float rstd1, rstd2;
     unsigned relu_bits = 0u;
@@ -249,15 +274,18 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       store_slab_T(X1, z, j, q);
       ln_affine_T(z, lw + tw.g1, lw + tw.be1, q, n1);
       load_vec_T(lw + tw.b2, q, xh2);
+      ORL_T(1);  // fc1, relu, LN1, slab store, affine
       ORL_PRIO(1);
       mm64_T(lw + tw.W2, n1, xh2, j, q);
       ORL_PRIO(0);
+      ORL_T(2);  // fc2: 64 MFMA
       ln_normalize_T(xh2, rstd2);
       store_slab_T(SS, xh2, j, q);  // parked in the scratch slab: read back in F layout (S3) and T layout (LN2')
       ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, z);  // z = n2
       head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, z, q, hd);
     }
 
+    ORL_T(3);  // LN2, slab store, affine, head
     // ---------------- loss + dhead (per batch row; the 4 lanes of a row compute identically) --------
     float dh[NO];
 #pragma unroll
@@ -390,6 +418,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       }
     }
 
+    ORL_T(4);  // loss
     // ---------------- backward ----------------
     // S3 += dhead^T xhat2, db3 (F layout: lane = feature f); xhat2 comes from the scratch slab
     if (q == 0) {
@@ -413,6 +442,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       for (int c = 0; c < NO; ++c) a_S3[c] += s3[c];
       a_db3 += s_db3;
     }
+    ORL_T(5);  // dhead store, S3 / db3 column sums
     // dn2 = W3^T dhead (T layout), LN2 backward -> dz2
     f32x4 d2[4];
 #pragma unroll
@@ -432,6 +462,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     wave_lds_fence();
     store_slab_T(SS, d2, j, q);
     wave_lds_fence();
+    ORL_T(6);  // dn2, LN2 backward, dz2 slab store
     if (PC) {
       // hand dz2 (SS) + xhat1 (X1) to the consumer wave; all LDS stores of this wave precede the flag store
       ++tiles_done;
@@ -456,6 +487,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       for (int r = 0; r < TILE_B; ++r) s_db += SS[r * TS + f];
       a_db2 += s_db;
     }
+    ORL_T(7);  // wgrad: 64 MFMA from F-layout slab reads, db2
     // dgrad: dn1 = W2^T dz2, LN1 backward, relu backward -> dz1
     f32x4 d1[4];
 #pragma unroll
@@ -467,6 +499,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       mm64_T_wt(lw + tw.W2, dz2, d1, j, q);
       ORL_PRIO(0);
     }
+    ORL_T(8);  // dgrad: 64 MFMA
     {
       f32x4 xh1[4];
       load_slab_T(X1, xh1, j, q);
@@ -484,6 +517,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     }
     store_slab_T(SS, d1, j, q);
     wave_lds_fence();
+    ORL_T(9);  // LN1 backward, relu backward, dz1 slab store
     // dW1 += dz1^T x, db1
     {
       const int f = l;
@@ -513,7 +547,12 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       a_db1 += s_db;
     }
     wave_lds_fence();
+    ORL_T(10);  // dW1 / db1
   }
+#ifdef ORL_PROF
+  if (prof_on && l < 12) atomicAdd(&g_orl_prof[l], prof_lds[l]);
+  if (prof_on && l == 12) atomicAdd(&g_orl_prof[12], 1ull);
+#endif
 #undef REC
 #undef REC_R
 
