@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["orl_buffer.hip", "orl_act.hip", "orl_ppo.hip", "orl_rnn.hip", "orl_mpe.hip"]
-HEADERS = ["orl_common.h", "orl_mlp.h", "orl_ppo_tower.h", "orl_heads.h", "orl_loss.h", "orl_rnn.h", os.path.join("..", "..", "include", "orl_hip.h")]
+HEADERS = ["orl_common.h", "orl_mlp.h", "orl_ppo_tower.h", "orl_ppo_tower_mt.h", "orl_heads.h", "orl_loss.h", "orl_rnn.h", os.path.join("..", "..", "include", "orl_hip.h")]
 LIB = os.path.join(HERE, "liborl_hip.so")
 STAMP = os.path.join(HERE, ".liborl_hip.stamp")
 ARCH = "gfx950"

@@ -8,6 +8,7 @@
 #include "orl_common.h"
 #include "orl_mlp.h"
 #include "orl_ppo_tower.h"
+#include "orl_ppo_tower_mt.h"
 
 namespace orl {
 
@@ -234,6 +235,25 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
     const char* e = getenv("ORL_PPO_WAVES");
     return e ? atoi(e) : 8;  // 12 = producer/consumer build: correct but measured slower (0.408 vs 0.384 ms)
   }();
+  static const int mt = []() {  // ORL_PPO_MT=2: A/B knob for the multi-tile kernel (2 tiles per wave, 1 wave / SIMD)
+    const char* e = getenv("ORL_PPO_MT");
+    return e ? atoi(e) : 0;
+  }();
+  if constexpr (ND == 0) {
+    if (mt == 2) {  // measured SLOWER than the default (0.457 vs 0.367 ms per pair), kept for A/B runs: DESIGN.md 6
+      const size_t lds = tower_mt_lds_floats(A.net, A.R, NOP, 2, HEAD == ORL_HEAD_GAUSSIAN) * sizeof(float);
+      if (lds <= 160 * 1024) {
+        const int n_tiles = (A.mb + TILE_B - 1) / TILE_B;
+        int grid = (n_tiles + 7) / 8;
+        if (grid > PPO_MAX_BLOCKS) grid = PPO_MAX_BLOCKS;
+        (void)hipFuncSetAttribute((const void*)ppo_tower_mt_kernel<HEAD, NO, ND, 2>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ppo_tower_mt_kernel<HEAD, NO, ND, 2>), dim3(grid), dim3(256), lds, s, A);
+        const int rc = launch_status("orl_ppo_fwd_bwd(mt)");
+        return rc ? -1000 - rc : grid;
+      }
+    }
+  }
   if (max_waves >= 12) {  // producer / consumer build: 8 producers + 4 consumers, 3 waves per SIMD
     const size_t lds = tower_lds_floats(A.net, A.R, NOP, 12, HEAD == ORL_HEAD_GAUSSIAN, true) * sizeof(float);
     if (lds <= 160 * 1024) {
