@@ -264,32 +264,47 @@ __global__ __launch_bounds__(256) void adv_normalize_pack_kernel(float* __restri
   const int Dp = src.Dp, Dc = src.Dc, a = src.a, K = src.K;
   const int o_co = Dp, o_ac = o_co + Dc, o_lp = o_ac + a, o_adv = o_lp + a, o_vp = o_adv + 1, o_rt = o_vp + 1,
             o_am = o_rt + 1, o_mk = o_am + 1, o_end = o_mk + K;
-  const long long total = M * (long long)R;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const long long row = e / R;
-    const int col = (int)(e - row * R);
-    float v;
-    if (col < o_co) v = src.policy_obs[row * Dp + col];
-    else if (col < o_ac) v = src.critic_obs[row * Dc + (col - o_co)];
-    else if (col < o_lp) v = src.actions[row * a + (col - o_ac)];
-    else if (col < o_adv) v = src.action_log_probs[row * a + (col - o_lp)];
-    else if (col == o_adv) {
+  // one 16-byte chunk of a record per thread and step (R is a multiple of 4): 32-bit index arithmetic, float4 stores
+  auto fetch = [&](long long row, int col) -> float {
+    if (col < o_co) return src.policy_obs[row * Dp + col];
+    if (col < o_ac) return src.critic_obs[row * Dc + (col - o_co)];
+    if (col < o_lp) return src.actions[row * a + (col - o_ac)];
+    if (col < o_adv) return src.action_log_probs[row * a + (col - o_lp)];
+    if (col == o_adv) {
       float x = adv[row];
       if (use_adv_normalize) x = (x - c.m1) / c.s1;
-      v = (x - c.m2) / c.s2;
+      const float v = (x - c.m2) / c.s2;
       adv[row] = v;
-    } else if (col == o_vp) v = src.value_preds[row];
-    else if (col == o_rt) v = src.returns[row];
-    else if (col == o_am) v = src.active_masks[row];
-    else if (col < o_end) v = (src.action_masks != nullptr) ? src.action_masks[row * K + (col - o_mk)] : 1.f;
-    else v = 0.f;
-    records[e] = v;
+      return v;
+    }
+    if (col == o_vp) return src.value_preds[row];
+    if (col == o_rt) return src.returns[row];
+    if (col == o_am) return src.active_masks[row];
+    if (col < o_end) return (src.action_masks != nullptr) ? src.action_masks[row * K + (col - o_mk)] : 1.f;
+    return 0.f;
+  };
+  const unsigned nch = (unsigned)R >> 2;
+  const long long chunks = M * (long long)nch;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < chunks; e += stride) {
+    long long row;
+    unsigned ch;
+    if (chunks < (1ll << 31)) {
+      const unsigned e32 = (unsigned)e;
+      row = e32 / nch;
+      ch = e32 - (unsigned)row * nch;
+    } else {
+      row = e / nch;
+      ch = (unsigned)(e - row * nch);
+    }
+    float4 v;
+    v.x = fetch(row, 4 * ch + 0);
+    v.y = fetch(row, 4 * ch + 1);
+    v.z = fetch(row, 4 * ch + 2);
+    v.w = fetch(row, 4 * ch + 3);
+    *(float4*)(records + row * R + 4 * ch) = v;
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K5: insert + mask construction for one step.
-// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void buffer_insert_kernel(orl_buffer_ptrs b, int step,
                                                             const float* __restrict__ nobs_p,
                                                             const float* __restrict__ nobs_c,
@@ -561,9 +576,9 @@ int orl_adv_normalize_pack(float* adv, const double* stat_partials, int n_partia
     R = orl_record_width(s0.Dp, s0.Dc, s0.a, s0.K);
   }
   const long long M = (long long)T * L;
-  long long work = records ? M * R : M;
+  long long work = records ? M * (R >> 2) : M;
   int grid = (int)((work + 255) / 256);
-  if (grid > 2048) grid = 2048;
+  if (grid > 8192) grid = 8192;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(adv_normalize_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, adv, stat_partials,
                      n_partials, M, L, use_adv_normalize, stats_out, s0, records, R);
