@@ -126,6 +126,21 @@ __global__ void rnn_chunk_rows_kernel(const int64_t* __restrict__ chunk_idx, int
 // =====================================================================================================
 // update: row kernel
 // =====================================================================================================
+#ifdef ORL_PROF
+// phase timing build (see orl_ppo_tower.h): wave 0 of workgroup 0 (policy tower), LDS-atomic accumulation;
+// read with orl_debug_rnn_prof (tools/rnn_phase_prof.py)
+__device__ unsigned long long g_rnn_prof[16];
+#define RNN_T(k)                                                      \
+  do {                                                                \
+    if (prof_on) {                                                    \
+      const unsigned long long t_now = __builtin_readcyclecounter();  \
+      if (l == 0) atomicAdd(&rprof_lds[k], t_now - t_last);           \
+      t_last = t_now;                                                 \
+    }                                                                 \
+  } while (0)
+#else
+#define RNN_T(k) ((void)0)
+#endif
 constexpr int RNN_ROW_BLOCKS = 256;
 constexpr int RNN_WG_BLOCKS = 256;  // both towers together: 1 workgroup per CU (3-slot DMA ring in LDS)
 
@@ -177,6 +192,12 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
 
   const int n_tiles = (Nc + TILE_B - 1) / TILE_B;
   const int nwv = blockDim.x >> 6;
+#ifdef ORL_PROF
+  __shared__ unsigned long long rprof_lds[16];
+  const bool prof_on = blockIdx.x == 0 && wave == 0;
+  if (prof_on && l < 16) rprof_lds[l] = 0ull;
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
   for (int tile = bid * nwv + wave; tile < n_tiles; tile += nblk * nwv) {
     const int ci = tile * TILE_B + j;
     const bool valid = ci < Nc;
@@ -249,6 +270,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       }
     }
 
+    RNN_T(0);  // forward sweep (L-1 forward-only steps + state tape)
     // ---------------- backward sweep (BPTT), forward recomputed per step ----------------
     f32x4 carry[4];
 #pragma unroll
@@ -270,6 +292,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
         row_c = A.rows[(size_t)(s - 1) * Nc + cis];
         mk_c = A.masks[row_c];
       }
+      RNN_T(1);  // step inputs: record / state-tape loads
       tape_store(tb + TV_HIN * TV, hin, j, q);
       float rstd1, rstd2, rstd3;
       unsigned relu_bits;
@@ -280,7 +303,9 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
         trunk(xv, xh1, rstd1, relu_bits, xh2, rstd2, n2);
         tape_store(tb + TV_XH1 * TV, xh1, j, q);
         tape_store(tb + TV_XH2 * TV, xh2, j, q);
+        RNN_T(2);  // trunk recompute (fc1 + 64 MFMA) + tape stores
         gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin, gr, gz, gn, ghn, hnew, j, q);
+        RNN_T(3);  // GRU forward: 384 MFMA + gates
         ln_normalize_T(hnew, rstd3);  // hnew = xhat3
         tape_store(tb + TV_XH3 * TV, hnew, j, q);
         f32x4 n3[4];
@@ -294,6 +319,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
           for (int c = 0; c < NO; ++c) a_dls[c] += dls[c];
         }
       }
+      RNN_T(4);  // LN3, head, loss
       // head deltas -> tape (16-wide vector: lane (j,q) owns columns 4q..4q+3)
       {
         f32x4 dv = {0.f, 0.f, 0.f, 0.f};
@@ -331,6 +357,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m) dt[m] += carry[m];
+      RNN_T(5);  // dhead / obs tape, W3^T dhead, LN3 backward
       // GRU cell backward (elementwise part); gr/gz/gn/ghn become dr/dz/dn/dghn, carry collects dt*z
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -350,6 +377,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       tape_store(tb + TV_DZ * TV, gz, j, q);
       tape_store(tb + TV_DN * TV, gn, j, q);
       tape_store(tb + TV_DGHN * TV, ghn, j, q);
+      RNN_T(6);  // GRU elementwise backward + 4 tape vectors
       // dgrad through the hidden-to-hidden weights -> carry ; through the input weights -> dn2
       mm64_S_wt<W2S>(lw + tw.Whh, gr, carry, j, q);
       mm64_S_wt<W2S>(lw + tw.Whh + HID * W2S, gz, carry, j, q);
@@ -362,6 +390,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       mm64_S_wt<W2S>(lw + tw.Wih + 2 * HID * W2S, gn, d2, j, q);
 #pragma unroll
       for (int m = 0; m < 4; ++m) carry[m] = carry[m] * mk;  // h_in = h * mask
+      RNN_T(7);  // GRU dgrad: 384 MFMA (column reads)
       // LN2 backward -> dz2
       {
         // xhat2 / xhat1 come back from the tape through a laundered pointer: otherwise the compiler forwards the
@@ -393,8 +422,13 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
         for (int r = 0; r < 4; ++r)
           if (!((relu_bits >> (4 * m + r)) & 1u)) d1[m][r] = 0.f;
       tape_store(tb + TV_DZ1 * TV, d1, j, q);
+      RNN_T(8);  // LN2 backward, W2 dgrad (64 MFMA), LN1 / relu backward, tapes
     }
   }
+#ifdef ORL_PROF
+  if (prof_on && l < 12) atomicAdd(&g_rnn_prof[l], rprof_lds[l]);
+  if (prof_on && l == 12) atomicAdd(&g_rnn_prof[12], 1ull);
+#endif
 
   // ---- workgroup reduction of {dlogstd, stats}: fixed order ------------------------------------------
   __syncthreads();
@@ -821,6 +855,16 @@ static int launch_rnn_rows(const RnnRowArgs& P, const RnnRowArgs& Cc, int grid_p
 using namespace orl;
 
 extern "C" {
+
+#ifdef ORL_PROF
+int orl_debug_rnn_prof(unsigned long long* out16) {
+  unsigned long long zero[16] = {0};
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rnn_prof), sizeof(zero));
+  hipMemcpyToSymbol(HIP_SYMBOL(g_rnn_prof), zero, sizeof(zero));
+  return 0;
+}
+#endif
 
 int orl_rnn_param_count(const orl_net_desc* net) {
   if (!net) return fail(ORL_E_INVALID, "orl_rnn_param_count: null");
