@@ -102,3 +102,37 @@ def test_config4_end_to_end_recurrent_mappo_on_device_mpe():
         assert torch.isfinite(m.theta).all()
     st = env.episode_statistics()
     assert st["episodes_finished"] == 3 * N and -400 < st["episode_return_mean"] < -50
+
+
+def test_recurrent_mappo_learns_on_device_mpe():
+    """Learning sanity for config 4: the shared episode reward of simple_spread improves markedly within 150
+    iterations of recurrent MAPPO (tools/mpe_learning_curve.py: -218 -> -123 after 600 iterations of 1024 envs)."""
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+
+    N, T, iters = 512, 25, 150
+    cfg = default_cfg(["--seed", "0", "--lr", "7e-4", "--critic_lr", "7e-4", "--episode_length", str(T),
+                       "--use_recurrent_policy", "true", "--use_valuenorm", "true", "--use_adv_normalize", "true",
+                       "--amd_perm_mode", "device", "--log_interval", "1000000"])
+    env = make("simple_spread", env_num=N, device=DEV)
+    net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+    cfg.num_env_steps = N * T * iters
+
+    class _Agent:
+        num_time_steps = 0
+
+    trainer = PPOAlgorithm(cfg, net.module, agent_num=3, device=DEV)
+    buf = NormalReplayBuffer(cfg, 3, env.observation_space, env.action_space, device=DEV)
+    drv = OnPolicyDriver({"cfg": cfg, "num_agents": 3, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, _Agent())
+    drv.reset_and_buffer_init()
+    curve = []
+    for i in range(iters):
+        drv.episode = i
+        drv._inner_loop()
+        curve.append(float(buf.data.rewards[:, :, 0, 0].sum(0).mean()))
+    first, last = np.mean(curve[:3]), np.mean(curve[-10:])
+    assert last > first + 40.0, (first, last)
