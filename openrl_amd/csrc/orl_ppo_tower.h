@@ -146,8 +146,8 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
   const RawLayout rl(A.net);
   // On the ND == 0 path the padded obs width is 4 and for NO <= 4 the padded head width is 4: every LDS
   // offset of the tower image becomes a compile-time constant (immediate offsets instead of address VGPRs).
-  const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, false);
-  stage_tower(smem, A.theta, tl, tw, false, threadIdx.x, blockDim.x);
+  const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, !PC);
+  stage_tower(smem, A.theta, tl, tw, !PC, threadIdx.x, blockDim.x);
   const int DP = tw.DP;
   const int D = A.net.obs_dim;
   const int n_out = A.net.n_out;
@@ -496,7 +496,10 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       f32x4 dz2[4];  // re-read from the slab (T layout) instead of keeping 16 VGPRs live across the wgrad block
       load_slab_T(SS, dz2, j, q);
       ORL_PRIO(1);
-      mm64_T_wt(lw + tw.W2, dz2, d1, j, q);
+      // dgrad A operand: a transposed copy of W2 in LDS read by 16-byte rows (16 reads per 64 MFMA); reading W2 by
+      // columns (64 four-byte reads, one per MFMA) made this the slowest phase of the tile: 5 100 vs 3 100 cycles
+      if (PC) mm64_T_wt(lw + tw.W2, dz2, d1, j, q);
+      else mm64_T(lw + tw.W2T, dz2, d1, j, q);
       ORL_PRIO(0);
     }
     ORL_T(8);  // dgrad: 64 MFMA
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
 
 // LDS bytes needed by `waves` waves of this tower
 inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian, bool pc = false) {
-  const TowerLds tw(net.obs_dim, net.n_out, gaussian, false);
+  const TowerLds tw(net.obs_dim, net.n_out, gaussian, !pc);
   const RawLayout rl(net);
   const int rts = (((R >> 2) + 3) >> 2) * 256;
   const size_t per_wave = 2 * SLAB + 2 * rts + TILE_B * nop;
