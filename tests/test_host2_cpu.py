@@ -1,0 +1,80 @@
+"""Host-side logic added with the recurrent / MPE / A2C work - runs without a GPU: loud failures of the product
+path, host queries of the new C entry points, recurrent parameter bookkeeping, example configs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from openrl_amd import _native as nat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_recurrent_host_queries_match_the_reference_parameter_count():
+    lib = nat.load()
+    for D, K, head in ((18, 5, nat.ORL_HEAD_CATEGORICAL), (54, 1, nat.ORL_HEAD_VALUE), (6, 2, nat.ORL_HEAD_GAUSSIAN)):
+        net = nat.NetDesc(D, 64, K, head)
+        H = 64
+        want = H * D + 3 * H + H * H + 3 * H + 2 * 3 * H * H + 2 * 3 * H + 2 * H + K * H + K
+        want += K if head == nat.ORL_HEAD_GAUSSIAN else 0
+        assert lib.orl_rnn_param_count(C.byref(net)) == want
+        # same count as torch's own modules in the reference's registration order
+        gru = torch.nn.GRU(H, H)
+        n_ref = sum(p.numel() for p in gru.parameters()) + sum(
+            p.numel() for m in (torch.nn.Linear(D, H), torch.nn.LayerNorm(H), torch.nn.Linear(H, H), torch.nn.LayerNorm(H),
+                                torch.nn.LayerNorm(H), torch.nn.Linear(H, K)) for p in m.parameters())
+        assert want - (K if head == nat.ORL_HEAD_GAUSSIAN else 0) == n_ref
+        raw = lib.orl_rnn_raw_grad_count(C.byref(net))
+        assert raw == H * D + H * H + 2 * 3 * H * H + K * H + 2 * H + 2 * 3 * H + K + (K if head == nat.ORL_HEAD_GAUSSIAN else 0)
+    assert lib.orl_mpe_state_width() == 24
+    pn, cn = nat.NetDesc(18, 64, 5, nat.ORL_HEAD_CATEGORICAL), nat.NetDesc(54, 64, 1, nat.ORL_HEAD_VALUE)
+    ws = lib.orl_rnn_workspace_floats(C.byref(pn), C.byref(cn), 76800, 2)
+    assert 200e6 < ws * 4 < 2e9  # two 442 MB tapes + state tapes + partial rows at the cfg4 shape
+
+
+def test_recurrent_entry_points_validate_before_launching():
+    lib = nat.load()
+    net = nat.NetDesc(18, 64, 5, nat.ORL_HEAD_CATEGORICAL)
+    assert lib.orl_rnn_chunk_rows(None, 0, 2, 25, 8, None, None) == -1
+    assert b"orl_rnn_chunk_rows" in lib.orl_last_error_string()
+    assert lib.orl_mpe_step(None, None, None, None, None, None, None, 4, 0, 25, None) == -1
+    bad = nat.NetDesc(18, 128, 5, nat.ORL_HEAD_CATEGORICAL)
+    assert lib.orl_rnn_ppo_apply(C.byref(bad), C.byref(net), None, None, None, None, None, None, None) == -2  # hidden 128
+    assert b"hidden_size 128" in lib.orl_last_error_string()
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the loud failure on a box without a HIP device")
+def test_new_product_paths_fail_loudly_without_a_gpu():
+    from openrl_amd.envs.common import make
+
+    with pytest.raises(nat.NativeError):
+        make("simple_spread", env_num=4)
+    with pytest.raises(NotImplementedError):
+        make("HalfCheetah-v4", env_num=4)
+
+
+def test_a2c_and_example_configs():
+    from openrl_amd.algorithms.a2c import A2CAlgorithm
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.configs.config import create_config_parser
+    from openrl_amd.runners.common import A2CAgent, PPOAgent
+
+    assert issubclass(A2CAlgorithm, PPOAlgorithm) and issubclass(A2CAgent, PPOAgent)
+    cfg = create_config_parser().parse_args(["--config", os.path.join(ROOT, "examples", "mpe", "mpe_ppo.yaml")])
+    assert cfg.use_recurrent_policy is True and cfg.episode_length == 25 and cfg.lr == pytest.approx(7e-4)
+    assert cfg.data_chunk_length == 2 and cfg.recurrent_N == 1  # reference defaults (config.py:578-589)
+
+
+def test_recurrent_tower_state_dict_keys_follow_the_reference():
+    from openrl_amd.modules.ppo_module import _tower_entries
+
+    keys = [k for k, _ in _tower_entries("policy", 18, 64, 5, False, True)]
+    assert keys[8:14] == ["rnn.rnn.weight_ih_l0", "rnn.rnn.weight_hh_l0", "rnn.rnn.bias_ih_l0", "rnn.rnn.bias_hh_l0",
+                          "rnn.norm.weight", "rnn.norm.bias"]
+    assert keys[-2:] == ["act.action_out.linear.weight", "act.action_out.linear.bias"]
+    n = sum(int(np.prod(s)) for _, s in _tower_entries("critic", 54, 64, 1, False, True))
+    lib = nat.load()
+    assert n == lib.orl_rnn_param_count(C.byref(nat.NetDesc(54, 64, 1, nat.ORL_HEAD_VALUE)))
