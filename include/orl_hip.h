@@ -178,6 +178,12 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
                  uint64_t rng_step, const float* forced_u, float* values, float* actions, float* logp,
                  void* stream);
 
+/* Optional device-side addend of `rng_step` for orl_act_step / orl_rnn_act_step launched afterwards from this host
+ * thread (NULL switches it off): rng_step_effective = rng_step + *dev_counter, read by the kernel at run time.  It
+ * exists so that a stepwise rollout can be captured ONCE into a hipGraph (kernel arguments are frozen at capture)
+ * and replayed every iteration with fresh Philox counters - the caller advances the counter on the device. */
+int orl_act_rng_offset(const uint64_t* dev_counter);
+
 /* Forward-only evaluation of GIVEN actions = PPOModule.evaluate_actions (openrl/modules/ppo_module.py:149-193,
  * PolicyNetwork.eval_actions networks/policy_network.py:164-203, ACTLayer.evaluate_actions utils/act.py:102-172):
  * values [B,1], action_log_probs [B,a], dist_entropy [1] (device) = masked mean with active_masks [B,1] when

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "orl_env_step": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                C.c_uint64, _P]),
     "orl_rollout_fused": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, C.POINTER(RolloutArgs), _P, _P]),
+    "orl_act_rng_offset": (C.c_int, [_P]),
     "orl_mpe_state_width": (C.c_int, []),
     "orl_mpe_reset": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "orl_mpe_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.c_int, _P]),
@@ -179,9 +180,16 @@ def stream_ptr(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_GPU_OK = None  # torch.cuda.is_available() costs ~18 us per call (device-count query); the answer cannot change
+
+
 def require_gpu(device) -> torch.device:
-    device = torch.device(device)
-    if device.type != "cuda" or not torch.cuda.is_available():
+    global _GPU_OK
+    if not isinstance(device, torch.device):
+        device = torch.device(device)
+    if _GPU_OK is None:
+        _GPU_OK = bool(torch.cuda.is_available())
+    if device.type != "cuda" or not _GPU_OK:
         raise NativeError(
             "openrl_amd is a MI355X (ROCm) engine: device %r has no HIP runtime behind it and there is no CPU "
             "fallback. Use the reference on CPU, or run on a gfx950 device." % (str(device),))

@@ -29,6 +29,7 @@ struct ActArgs {
   int B;
   int deterministic;
   uint64_t seed, row0, rng_step;
+  const unsigned long long* rng_dev;  // optional device-side addend of rng_step (orl_act_rng_offset)
 };
 
 template <int NO, int HEAD>
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
     const float* am = (A.amask != nullptr && row_ok) ? A.amask + (size_t)row * n_out : nullptr;
     const float* fr = (A.forced != nullptr && row_ok) ? A.forced + (size_t)row * a_w : nullptr;
     sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, am, fr, A.deterministic, A.seed, A.row0 + (uint64_t)row,
-                          A.rng_step, act_o, lp_o);
+                          A.rng_step + (A.rng_dev ? *A.rng_dev : 0ull), act_o, lp_o);
     if (row_ok && q == 0) {
 #pragma unroll
       for (int c = 0; c < NO; ++c) {
@@ -606,7 +607,7 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
   A.cnet = ctheta ? *cnet : *pnet;
   A.ptheta = ptheta; A.ctheta = ctheta; A.pobs = policy_obs; A.cobs = critic_obs; A.amask = action_masks;
   A.forced = forced_u; A.values = values; A.actions = actions; A.logp = logp; A.B = B;
-  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step;
+  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step; A.rng_dev = g_rng_dev;
   const int grid = (B + TILE_B - 1) / TILE_B;
 #define ORL_ACT_LAUNCH(NO, HD)                                                                                  \
   do {                                                                                                          \

@@ -10,6 +10,7 @@
 namespace orl {
 
 thread_local char g_err[512] = {0};
+thread_local const unsigned long long* g_rng_dev = nullptr;
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -553,6 +554,11 @@ int orl_adv_stats(const float* returns, const float* value_preds, const float* a
                      active_masks, vn_state, M, adv_raw, stat_partials);
   if (n_partials) *n_partials = grid;
   return launch_status("orl_adv_stats");
+}
+
+int orl_act_rng_offset(const uint64_t* dev_counter) {
+  g_rng_dev = (const unsigned long long*)dev_counter;
+  return 0;
 }
 
 int orl_record_width(int Dp, int Dc, int a, int K) {

@@ -30,6 +30,7 @@ struct RnnActArgs {
   float *values, *actions, *logp, *hp_out, *hc_out;
   int B, deterministic;
   uint64_t seed, row0, rng_step;
+  const unsigned long long* rng_dev;  // optional device-side addend of rng_step (orl_act_rng_offset)
 };
 
 // base -> GRU -> LayerNorm with every weight read straight from global memory (L2 resident; a rollout step
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(128) void rnn_act_kernel(RnnActArgs A) {
     const float* am = (A.amask != nullptr && row_ok) ? A.amask + (size_t)row * n_out : nullptr;
     const float* fr = (A.forced != nullptr && row_ok) ? A.forced + (size_t)row * a_w : nullptr;
     sample_head<NO, HEAD>(hd, n_out, th + tl.ologstd, am, fr, A.deterministic, A.seed, A.row0 + (uint64_t)row,
-                          A.rng_step, act_o, lp_o);
+                          A.rng_step + (A.rng_dev ? *A.rng_dev : 0ull), act_o, lp_o);
     if (row_ok && q == 0) {
 #pragma unroll
       for (int c = 0; c < NO; ++c) {
@@ -106,6 +107,90 @@ __global__ __launch_bounds__(128) void rnn_act_kernel(RnnActArgs A) {
     float v[1];
     head_T<1>(th + tl.oW3, th + tl.ob3, 1, n3, q, v);
     if (row_ok && q == 0) A.values[row] = v[0];
+  }
+}
+
+// Large batches: one workgroup = one tower (blocks [0, split) policy, the rest critic), its 142 KB of weights staged
+// into LDS once, 4 waves x 16-row tiles.  At the cfg4 rollout batch (6144 rows) this replaces 768 waves that each pull
+// every weight through L2 with global loads in front of the MFMAs (37 us) by 192 workgroups of LDS-fed GEMMs.
+template <int NO, int HEAD>
+__global__ __launch_bounds__(256, 1) void rnn_act_lds_kernel(RnnActArgs A, int split, int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const bool pol = (int)blockIdx.x < split;
+  const int bid = pol ? blockIdx.x : blockIdx.x - split;
+  const orl_net_desc net = pol ? A.pnet : A.cnet;
+  const float* th = pol ? A.ptheta : A.ctheta;
+  const RnnLayout tl(net);
+  const RnnLds tw(net.obs_dim, net.n_out, pol && HEAD == ORL_HEAD_GAUSSIAN);
+  stage_rnn_tower(smem, th, tl, tw, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const float* lw = smem;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int D = tl.D, DP = tw.DP;
+  const int n_tiles = (A.B + TILE_B - 1) / TILE_B;
+  for (int k = wave; k < tiles_per_wg; k += 4) {
+    const int tile = bid * tiles_per_wg + k;
+    if (tile >= n_tiles) break;
+    const int row = tile * TILE_B + j;
+    const bool row_ok = row < A.B;
+    const int rr = row_ok ? row : 0;
+    const float mk = A.masks[rr];
+    const float* xrow = (pol ? A.pobs : A.cobs) + (size_t)rr * D;
+    const float* hrow = (pol ? A.hp_in : A.hc_in) + (size_t)rr * HID;
+    float* hout = (pol ? A.hp_out : A.hc_out) + (size_t)rr * HID;
+    f32x4 hin[4], hnew[4], n3[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hin[m] = *(const f32x4*)(hrow + 16 * m + 4 * q) * mk;
+    {
+      f32x4 z[4], n1[4], n2[4];
+      float rstd;
+      load_vec_T(lw + tw.b1, q, z);
+      fc1_T(lw + tw.W1, DP, [&](int s) -> float {
+        const int c = 4 * s + q;
+        return c < D ? xrow[c] : 0.f;
+      }, z, j, q);
+      relu_T(z);
+      ln_normalize_T(z, rstd);
+      ln_affine_T(z, lw + tw.g1, lw + tw.be1, q, n1);
+      load_vec_T(lw + tw.b2, q, z);
+      mm64_T(lw + tw.W2, n1, z, j, q);
+      ln_normalize_T(z, rstd);
+      ln_affine_T(z, lw + tw.g2, lw + tw.be2, q, n2);
+      f32x4 r[4], zz[4], n[4], g[4];
+      gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin, r, zz, n, g, hnew, j, q);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) z[m] = hnew[m];
+      ln_normalize_T(z, rstd);
+      ln_affine_T(z, lw + tw.g3, lw + tw.be3, q, n3);
+    }
+    if (row_ok) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) *(f32x4*)(hout + 16 * m + 4 * q) = hnew[m];
+    }
+    if (pol) {
+      float hd[NO];
+      head_T<NO>(lw + tw.W3, lw + tw.b3, tl.n_out, n3, q, hd);
+      const int n_out = tl.n_out;
+      const int a_w = (HEAD == ORL_HEAD_CATEGORICAL) ? 1 : n_out;
+      float act_o[NO], lp_o[NO];
+      const float* am = (A.amask != nullptr && row_ok) ? A.amask + (size_t)row * n_out : nullptr;
+      const float* fr = (A.forced != nullptr && row_ok) ? A.forced + (size_t)row * a_w : nullptr;
+      sample_head<NO, HEAD>(hd, n_out, lw + tw.logstd, am, fr, A.deterministic, A.seed, A.row0 + (uint64_t)row,
+                            A.rng_step + (A.rng_dev ? *A.rng_dev : 0ull), act_o, lp_o);
+      if (row_ok && q == 0) {
+#pragma unroll
+        for (int c = 0; c < NO; ++c) {
+          if (c < a_w) {
+            A.actions[(size_t)row * a_w + c] = act_o[c];
+            A.logp[(size_t)row * a_w + c] = lp_o[c];
+          }
+        }
+      }
+    } else {
+      float v[1];
+      head_T<1>(lw + tw.W3, lw + tw.b3, 1, n3, q, v);
+      if (row_ok && q == 0) A.values[row] = v[0];
+    }
   }
 }
 
@@ -901,10 +986,36 @@ int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_ne
   A.ptheta = ptheta; A.ctheta = ctheta; A.pobs = policy_obs; A.cobs = critic_obs; A.hp_in = h_policy_in;
   A.hc_in = h_critic_in; A.masks = masks; A.amask = action_masks; A.forced = forced_u; A.values = values;
   A.actions = actions; A.logp = logp; A.hp_out = h_policy_out; A.hc_out = h_critic_out; A.B = B;
-  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step;
+  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step; A.rng_dev = g_rng_dev;
   const int grid = (B + TILE_B - 1) / TILE_B;
   hipStream_t s = (hipStream_t)stream;
   const int no = A.pnet.n_out;
+  if (ptheta && ctheta && grid >= 128) {  // big batch, both towers: LDS-staged workgroups (rnn_act_lds_kernel)
+    int tpw = (grid + 95) / 96;           // tiles per workgroup: ~96 workgroups per tower, 4 waves each
+    if (tpw < 4) tpw = 4;
+    const int gw = (grid + tpw - 1) / tpw;
+    const RnnLds twp(A.pnet.obs_dim, A.pnet.n_out, A.pnet.head_kind == ORL_HEAD_GAUSSIAN), twc(A.cnet.obs_dim, 1, false);
+    const size_t lds = (size_t)(twp.total > twc.total ? twp.total : twc.total) * sizeof(float);
+    if (lds <= 160 * 1024) {
+#define ORL_RNN_ACT_LDS(NO, HD)                                                                                   \
+  do {                                                                                                            \
+    (void)hipFuncSetAttribute((const void*)rnn_act_lds_kernel<NO, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                          \
+    hipLaunchKernelGGL((rnn_act_lds_kernel<NO, HD>), dim3(2 * gw), dim3(256), lds, s, A, gw, tpw);                \
+  } while (0)
+      if (A.pnet.head_kind == ORL_HEAD_CATEGORICAL) {
+        if (no <= 2) ORL_RNN_ACT_LDS(2, ORL_HEAD_CATEGORICAL);
+        else if (no <= 8) ORL_RNN_ACT_LDS(8, ORL_HEAD_CATEGORICAL);
+        else ORL_RNN_ACT_LDS(16, ORL_HEAD_CATEGORICAL);
+      } else {
+        if (no <= 2) ORL_RNN_ACT_LDS(2, ORL_HEAD_GAUSSIAN);
+        else if (no <= 8) ORL_RNN_ACT_LDS(8, ORL_HEAD_GAUSSIAN);
+        else ORL_RNN_ACT_LDS(16, ORL_HEAD_GAUSSIAN);
+      }
+#undef ORL_RNN_ACT_LDS
+      return launch_status("orl_rnn_act_step");
+    }
+  }
 #define ORL_RNN_ACT(NO, HD) hipLaunchKernelGGL((rnn_act_kernel<NO, HD>), dim3(grid), dim3(128), 0, s, A)
   if (!ptheta || A.pnet.head_kind == ORL_HEAD_VALUE) ORL_RNN_ACT(2, ORL_HEAD_CATEGORICAL);  // value-only: wave 0 exits
   else if (A.pnet.head_kind == ORL_HEAD_CATEGORICAL) {

@@ -81,6 +81,13 @@ class OnPolicyDriver:
         if mode == "fused" and not can_fuse:
             raise ValueError("amd_rollout_mode=fused is not built for env %r" % getattr(self.envs, "env_name", "?"))
         self.fused = can_fuse and mode in ("auto", "fused") and not self.callback.needs_per_step
+        # stepwise rollouts of device envs whose step takes no per-call host scalar are captured once into a hipGraph
+        # (T x {act, env.step, insert} ~ 125 launches) and replayed; the Philox step counter lives on the device
+        self._graph_ok = (dev_env and not self.fused and bool(getattr(cfg, "amd_use_graph", True))
+                          and bool(getattr(self.envs, "supports_graph_rollout", False))
+                          and not self.callback.needs_per_step)
+        self._graph = None
+        self._rng_ctr = None
         d = self.buffer.data
         self._next_value = torch.zeros(d.n_rollout_threads, d.num_agents, 1, dtype=torch.float32, device=self.device)
         self._have_next_value = False
@@ -133,6 +140,8 @@ class OnPolicyDriver:
         self.trainer.prep_rollout()
         if self.fused:
             self._fused_rollout()
+        elif self._graph_ok and self.episode >= 1:  # the first rollout runs eagerly (allocations, module loads)
+            self._graph_rollout()
         else:
             for step in range(self.episode_length):
                 if not self._rollout_step(step):
@@ -168,6 +177,31 @@ class OnPolicyDriver:
         d.step = 0
         d._adv_fresh = False
         self.agent.num_time_steps += env.parallel_env_num * self.episode_length
+
+    def _graph_rollout(self) -> None:
+        mod = self.trainer.algo_module
+        T = self.episode_length
+        if self._graph is None:
+            self._rng_ctr = torch.full((1,), int(mod.rng_step), dtype=torch.int64, device=self.device)
+            saved_steps, saved_rng = self.agent.num_time_steps, mod.rng_step
+            mod.rng_step = 0  # the captured launches carry rng_step = 0 .. T-1; the device counter is the base
+            ops.act_rng_offset(self._rng_ctr)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    for step in range(T):
+                        self._rollout_step(step)
+                    self._rng_ctr.add_(T)
+            finally:
+                ops.act_rng_offset(None)
+                self.agent.num_time_steps, mod.rng_step = saved_steps, saved_rng
+            self._graph = graph
+        self._graph.replay()
+        mod.rng_step += T
+        self.agent.num_time_steps += self.envs.parallel_env_num * T
+        d = self.buffer.data
+        d.step = 0
+        d._adv_fresh = False
 
     def _rollout_step(self, step: int) -> bool:
         d = self.buffer.data

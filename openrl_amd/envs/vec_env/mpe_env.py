@@ -45,6 +45,7 @@ class MpeSpreadVecEnv(DeviceVecEnv):
         self._infos = [{} for _ in range(self._n)]
         self.is_device_env = True
         self.supports_fused_rollout = False
+        self.supports_graph_rollout = True  # orl_mpe_step takes no per-call host scalar: capturable
 
     @property
     def agent_num(self) -> int:

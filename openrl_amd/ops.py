@@ -145,6 +145,11 @@ def act_step(pnet: NetDesc, ptheta, cnet: Optional[NetDesc], ctheta, policy_obs,
     nat.check(rc, "orl_act_step")
 
 
+def act_rng_offset(dev_counter: Optional[torch.Tensor]) -> None:
+    """Device-side addend of ``rng_step`` for the act-step launches that follow (None switches it off)."""
+    nat.check(_lib().orl_act_rng_offset(ptr(dev_counter)), "orl_act_rng_offset")
+
+
 def evaluate_actions(pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, actions, action_masks, active_masks, B: int,
                      values, logp, ent_rows, dist_entropy) -> None:
     dev = _dev(policy_obs)

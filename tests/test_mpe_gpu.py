@@ -136,3 +136,46 @@ def test_recurrent_mappo_learns_on_device_mpe():
         curve.append(float(buf.data.rewards[:, :, 0, 0].sum(0).mean()))
     first, last = np.mean(curve[:3]), np.mean(curve[-10:])
     assert last > first + 40.0, (first, last)
+
+
+def test_graph_captured_rollout_equals_eager_rollout():
+    """amd_use_graph: the stepwise rollout is captured once into a hipGraph and replayed, with the Philox step counter
+    on the device (orl_act_rng_offset).  Same kernels, same counters -> the buffers are bit-identical to eager."""
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+
+    def run(use_graph):
+        N, T, iters = 96, 25, 4
+        cfg = default_cfg(["--seed", "3", "--episode_length", str(T), "--use_recurrent_policy", "true", "--ppo_epoch", "2",
+                           "--amd_perm_mode", "device", "--amd_use_graph", str(use_graph), "--log_interval", "1000000"])
+        env = make("simple_spread", env_num=N, device=DEV, seed=3)
+        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+        cfg.num_env_steps = N * T * iters
+
+        class _Agent:
+            num_time_steps = 0
+
+        agent = _Agent()
+        trainer = PPOAlgorithm(cfg, net.module, agent_num=3, device=DEV)
+        buf = NormalReplayBuffer(cfg, 3, env.observation_space, env.action_space, device=DEV)
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 3, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, agent)
+        drv.reset_and_buffer_init()
+        for i in range(iters):
+            drv.episode = i
+            drv._inner_loop()
+        assert (drv._graph is not None) == use_graph and agent.num_time_steps == N * T * iters
+        d = buf.data
+        return {k: getattr(d, k).clone() for k in ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds",
+                                                     "rewards", "masks", "active_masks", "rnn_states", "returns")}, \
+            net.module.models["policy"].theta.clone(), net.module.rng_step
+
+    a, tha, ra = run(True)
+    b, thb, rb = run(False)
+    assert ra == rb
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(tha, thb)

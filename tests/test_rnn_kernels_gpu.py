@@ -155,3 +155,30 @@ def test_rnn_update_gradients_and_adam_step_vs_oracle(case):
         th = torch.tensor(th0).clone()
         po.AdamOracle(th.numel(), lr, cfg.opti_eps, cfg.weight_decay).step(th, gr_e.cpu())
         np.testing.assert_allclose(th_e.cpu().numpy(), th.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_rnn_act_step_large_batch_path_equals_small_batch_path():
+    """>= 128 tiles with both towers runs the LDS-staged workgroup kernel; the same rows in chunks of 64 tiles run
+    the per-tile kernel that reads weights through L2.  Same arithmetic order -> identical results."""
+    from openrl_amd import ops, ops_rnn
+
+    B, Dp, Dc, K = 4099, 18, 54, 5  # ragged: last tile partly filled
+    pnet, cnet = ops.net_desc(Dp, K, ops.HEAD_CATEGORICAL), ops.net_desc(Dc, 1, ops.HEAD_VALUE)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    thp, thc = 0.2 * r(ops_rnn.rnn_param_count(pnet)), 0.2 * r(ops_rnn.rnn_param_count(cnet))
+    po_, co_, hp, hc = r(B, Dp), r(B, Dc), 0.5 * r(B, 64), 0.5 * r(B, 64)
+    mk = (torch.rand(B, device=DEV, generator=g) > 0.2).float()
+    u = torch.rand(B, 1, device=DEV, generator=g)
+    out = lambda: (torch.zeros(B, 1, device=DEV), torch.zeros(B, 1, device=DEV), torch.zeros(B, 1, device=DEV),
+                   torch.zeros(B, 64, device=DEV), torch.zeros(B, 64, device=DEV))
+    v1, a1, l1, hp1, hc1 = out()
+    ops_rnn.rnn_act_step(pnet, thp, cnet, thc, po_, co_, hp, hc, mk, None, B, False, 0, 0, 0, u, v1, a1, l1, hp1, hc1)
+    v2, a2, l2, hp2, hc2 = out()
+    for lo in range(0, B, 1024):
+        hi = min(lo + 1024, B)
+        ops_rnn.rnn_act_step(pnet, thp, cnet, thc, po_[lo:hi], co_[lo:hi], hp[lo:hi], hc[lo:hi], mk[lo:hi], None, hi - lo,
+                             False, 0, 0, 0, u[lo:hi], v2[lo:hi], a2[lo:hi], l2[lo:hi], hp2[lo:hi], hc2[lo:hi])
+    for x, y in ((v1, v2), (l1, l2), (hp1, hp2), (hc1, hc2)):
+        torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
+    assert (a1 == a2).float().mean() > 0.999 and a1.max() <= K - 1
