@@ -138,7 +138,8 @@ def test_recurrent_mappo_learns_on_device_mpe():
     assert last > first + 40.0, (first, last)
 
 
-def test_graph_captured_rollout_equals_eager_rollout():
+@pytest.mark.parametrize("recurrent", ["true", "false"])
+def test_graph_captured_rollout_equals_eager_rollout(recurrent):
     """amd_use_graph: the stepwise rollout is captured once into a hipGraph and replayed, with the Philox step counter
     on the device (orl_act_rng_offset).  Same kernels, same counters -> the buffers are bit-identical to eager."""
     from openrl_amd.algorithms.ppo import PPOAlgorithm
@@ -150,7 +151,7 @@ def test_graph_captured_rollout_equals_eager_rollout():
 
     def run(use_graph):
         N, T, iters = 96, 25, 4
-        cfg = default_cfg(["--seed", "3", "--episode_length", str(T), "--use_recurrent_policy", "true", "--ppo_epoch", "2",
+        cfg = default_cfg(["--seed", "3", "--episode_length", str(T), "--use_recurrent_policy", recurrent, "--ppo_epoch", "2",
                            "--amd_perm_mode", "device", "--amd_use_graph", str(use_graph), "--log_interval", "1000000"])
         env = make("simple_spread", env_num=N, device=DEV, seed=3)
         net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
