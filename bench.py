@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--perm", default="device", choices=["device", "reference"],
+    ap.add_argument("--perm", default="device", choices=["device", "reference", "identity"],
                     help="minibatch permutation source; 'reference' = host torch.randperm (bit-exact stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")

@@ -157,6 +157,10 @@ int orl_gather_minibatch(const orl_gather_desc* desc, const int64_t* idx, int n_
  * torch.randperm used by BatchSampler(SubsetRandomSampler) (replay_data.py:578-580); NOT
  * bit-identical to it (documented in DESIGN.md). */
 int orl_perm_feistel(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+/* Same permutation plus, in the same launch, orl_valuenorm_update(vn_state, moments, beta): the per-epoch pair when
+ * the minibatch is the whole batch (num_mini_batch = 1: moments come from the GAE pass, ppo.py:190-195). */
+int orl_perm_feistel_vn(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id, float* vn_state,
+                        const double* moments, double beta, void* stream);
 
 /* ---- K1-K4: rollout forward + sampling -------------------------------------------------------------
  * Replaces PPOModule.get_actions (openrl/modules/ppo_module.py:102-138) =

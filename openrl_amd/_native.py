@@ -94,6 +94,7 @@ _SIGNATURES = {
     "orl_buffer_insert": (C.c_int, [C.POINTER(BufferPtrs), C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "orl_gather_minibatch": (C.c_int, [C.POINTER(GatherDesc), _P, C.c_int, _P]),
     "orl_perm_feistel": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
+    "orl_perm_feistel_vn": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, C.c_double, _P]),
     "orl_act_step": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, C.c_int, C.c_int,
                                C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
     "orl_evaluate_actions": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, C.c_int, _P,

@@ -58,6 +58,7 @@ class PPOAlgorithm(BaseAlgorithm):
         self._full_batch_moments = False
         self.perm_mode = getattr(cfg, "amd_perm_mode", "reference")
         self._perm_counter = 0
+        self._vn_in_perm = False
         self.last_indices = None  # minibatch index tensors of the last train() (tests / inspection)
 
     # ------------------------------------------------------------------------------------------ advantages
@@ -96,7 +97,10 @@ class PPOAlgorithm(BaseAlgorithm):
                 ops.minibatch_moments(rec, ret_col, idx, mb, self._mom_scratch, self._moments)
                 if self.world_size > 1:
                     dist_utils.allreduce_(self._moments)
-            ops.valuenorm_update(vn.state, self._moments, vn.beta)  # BEFORE normalize (ppo.py:190-195)
+            if self._vn_in_perm:
+                self._vn_in_perm = False  # this epoch's update already ran inside the permutation launch
+            else:
+                ops.valuenorm_update(vn.state, self._moments, vn.beta)  # BEFORE normalize (ppo.py:190-195)
             vn_state = vn.state
         ev = getattr(self, "profile_events", None)
         if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel pair
@@ -170,9 +174,15 @@ class PPOAlgorithm(BaseAlgorithm):
     def _minibatch_indices(self, M: int):
         mbs = M // self.num_mini_batch
         n_batches = M // mbs  # drop_last=True (replay_data.py:578-580)
-        if self.perm_mode == "device":
+        if self.perm_mode == "identity" and self.num_mini_batch == 1:
+            return [None], mbs
+        if self.perm_mode in ("device", "identity"):
             self._perm_counter += 1
-            perm = ops.perm_feistel(M, int(self.cfg.seed), self._perm_counter, self.device)
+            vn = None
+            if self._full_batch_moments and self._use_valuenorm:  # one launch: permutation + this epoch's ValueNorm.update
+                v = self.algo_module.get_critic_value_normalizer()
+                vn, self._vn_in_perm = (v.state, self._moments, v.beta), True
+            perm = ops.perm_feistel(M, int(self.cfg.seed), self._perm_counter, self.device, vn)
         else:
             perm = torch.randperm(M).to(self.device, non_blocking=True)  # CPU generator, like the reference
         return [perm[b * mbs:(b + 1) * mbs] for b in range(n_batches)], mbs

@@ -19,7 +19,7 @@ from ._flag_table import FLAGS
 AMD_FLAGS = [
     # minibatch permutation source: "reference" = host torch.randperm on the CPU generator, bit-exact
     # with replay_data.py:578-580; "device" = keyed Feistel bijection generated on the GPU.
-    ("amd_perm_mode", "str", "reference", "opt", ["reference", "device"]),
+    ("amd_perm_mode", "str", "reference", "opt", ["reference", "device", "identity"]),
     # rollout engine: "auto" picks the fused persistent kernel for device-resident envs.
     ("amd_rollout_mode", "str", "auto", "opt", ["auto", "fused", "stepwise"]),
     # capture the PPO update epoch in a hipGraph.

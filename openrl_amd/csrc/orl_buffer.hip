@@ -391,20 +391,11 @@ __host__ __device__ inline uint64_t feistel_perm(uint64_t i, uint64_t n, int hb,
   return x;
 }
 
-__global__ __launch_bounds__(256) void perm_feistel_kernel(int64_t* __restrict__ idx, long long n, int hb,
-                                                           uint64_t seed, uint64_t stream_id) {
-  const u4 keys = philox4x32_10(seed, (uint32_t)stream_id, (uint32_t)(stream_id >> 32), 0x5EED5EEDu, 0u);
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    idx[i] = (int64_t)feistel_perm((uint64_t)i, (uint64_t)n, hb, keys);
-}
-
 // ------------------------------------------------------------------------------------------------
 // ValueNorm.update (valuenorm.py:58-77) from batch sums, and minibatch return moments.
 // ------------------------------------------------------------------------------------------------
-__global__ void valuenorm_update_kernel(float* __restrict__ vn, const double* __restrict__ mom, float beta, float omw) {
+__device__ __forceinline__ void valuenorm_update_body(float* __restrict__ vn, const double* __restrict__ mom, float beta, float omw) {
 #pragma clang fp contract(off)
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double cnt = mom[2];
   const float bm = (float)(mom[0] / cnt);
   const float bsq = (float)(mom[1] / cnt);
@@ -414,6 +405,27 @@ __global__ void valuenorm_update_kernel(float* __restrict__ vn, const double* __
   vn[0] = vn[0] * beta + t0;
   vn[1] = vn[1] * beta + t1;
   vn[2] = vn[2] * beta + omw;
+}
+
+__global__ void valuenorm_update_kernel(float* __restrict__ vn, const double* __restrict__ mom, float beta, float omw) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  valuenorm_update_body(vn, mom, beta, omw);
+}
+
+// One launch per PPO epoch when the minibatch is the whole batch: the permutation of that epoch and, on one extra
+// workgroup, the ValueNorm.update that precedes its loss (ppo.py:190-195) - the two are independent.
+__global__ __launch_bounds__(256) void perm_feistel_kernel(int64_t* __restrict__ idx, long long n, int hb,
+                                                           uint64_t seed, uint64_t stream_id, float* __restrict__ vn,
+                                                           const double* __restrict__ mom, float beta, float omw) {
+  if (vn != nullptr && blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x == 0) valuenorm_update_body(vn, mom, beta, omw);
+    return;
+  }
+  const int nb = (int)gridDim.x - (vn != nullptr ? 1 : 0);
+  const u4 keys = philox4x32_10(seed, (uint32_t)stream_id, (uint32_t)(stream_id >> 32), 0x5EED5EEDu, 0u);
+  const long long stride = (long long)nb * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    idx[i] = (int64_t)feistel_perm((uint64_t)i, (uint64_t)n, hb, keys);
 }
 
 __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ records, int R, int col,
@@ -624,17 +636,28 @@ int orl_gather_minibatch(const orl_gather_desc* desc, const int64_t* idx, int n_
   return launch_status("orl_gather_minibatch");
 }
 
-int orl_perm_feistel(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
-  ORL_REQUIRE(idx && n > 0, "orl_perm_feistel: bad arguments");
-  ORL_REQUIRE(n <= ((int64_t)1 << 62), "orl_perm_feistel: n too large");
+static int launch_perm(const char* what, int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id, float* vn,
+                       const double* mom, double beta, void* stream) {
+  ORL_REQUIRE(idx && n > 0, "%s: bad arguments", what);
+  ORL_REQUIRE(n <= ((int64_t)1 << 62), "%s: n too large", what);
   int bits = 1;
   while (((int64_t)1 << bits) < n) ++bits;
   const int hb = (bits + 1) / 2;
   int grid = (int)((n + 255) / 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(perm_feistel_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, (long long)n, hb, seed,
-                     stream_id);
-  return launch_status("orl_perm_feistel");
+  hipLaunchKernelGGL(perm_feistel_kernel, dim3(grid + (vn ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, idx,
+                     (long long)n, hb, seed, stream_id, vn, mom, (float)beta, (float)(1.0 - beta));
+  return launch_status(what);
+}
+
+int orl_perm_feistel(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+  return launch_perm("orl_perm_feistel", idx, n, seed, stream_id, nullptr, nullptr, 0.0, stream);
+}
+
+int orl_perm_feistel_vn(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_id, float* vn_state,
+                        const double* moments, double beta, void* stream) {
+  ORL_REQUIRE(vn_state && moments, "orl_perm_feistel_vn: null pointer");
+  return launch_perm("orl_perm_feistel_vn", idx, n, seed, stream_id, vn_state, moments, beta, stream);
 }
 
 int orl_valuenorm_update(float* vn_state, const double* moments, double beta, void* stream) {

@@ -126,10 +126,15 @@ def gather_minibatch(srcs: Sequence[torch.Tensor], idx: torch.Tensor) -> List[to
     return outs
 
 
-def perm_feistel(n: int, seed: int, stream_id: int, device) -> torch.Tensor:
+def perm_feistel(n: int, seed: int, stream_id: int, device, vn=None) -> torch.Tensor:
+    """``vn`` = (state, moments, beta): also run ValueNorm.update in the same launch (orl_perm_feistel_vn)."""
     dev = nat.require_gpu(device)
     idx = torch.empty(n, dtype=torch.int64, device=dev)
-    rc = _lib().orl_perm_feistel(ptr(idx), n, seed & (2 ** 64 - 1), stream_id & (2 ** 64 - 1), stream_ptr(dev))
+    if vn is None:
+        rc = _lib().orl_perm_feistel(ptr(idx), n, seed & (2 ** 64 - 1), stream_id & (2 ** 64 - 1), stream_ptr(dev))
+    else:
+        rc = _lib().orl_perm_feistel_vn(ptr(idx), n, seed & (2 ** 64 - 1), stream_id & (2 ** 64 - 1), fptr(vn[0]),
+                                        ptr(vn[1]), float(vn[2]), stream_ptr(dev))
     nat.check(rc, "orl_perm_feistel")
     return idx
 

@@ -195,6 +195,20 @@ def test_perm_feistel_matches_oracle_and_is_bijective(ops, n):
         assert np.array_equal(got, px.feistel_perm(n, 77, 3))
 
 
+def test_perm_feistel_vn_equals_the_two_separate_launches(ops):
+    """orl_perm_feistel_vn = orl_perm_feistel + orl_valuenorm_update in one launch (bit-exact both ways)."""
+    n = 70_001
+    mom = torch.tensor([1234.5, 98765.25, 4096.0], dtype=torch.float64, device=DEV)
+    a = torch.tensor([0.3, 1.7, 0.25], device=DEV)
+    b = a.clone()
+    for k in range(3):
+        pa = ops.perm_feistel(n, 5, 10 + k, DEV, vn=(a, mom, 0.99999))
+        pb = ops.perm_feistel(n, 5, 10 + k, DEV)
+        ops.valuenorm_update(b, mom, 0.99999)
+        assert torch.equal(pa, pb) and torch.equal(a, b)
+    assert not torch.equal(a, torch.tensor([0.3, 1.7, 0.25], device=DEV))
+
+
 # --------------------------------------------------------------------------------------------- K1-K4
 @pytest.mark.parametrize("case", H.TRAIN_CASES)
 def test_act_step_deterministic_probe_vs_reference(ops, case):
