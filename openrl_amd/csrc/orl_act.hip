@@ -184,9 +184,31 @@ struct RolloutArgs {
 // chain from 68 to 17 instructions: the rollout is a latency problem (one 16-env tile per 8-wave workgroup),
 // not a throughput one.  Every wave of the workgroup must call this the same number of times (barriers).
 constexpr int GS = 68;  // gather-slab row stride (floats)
+#ifdef ORL_PROF
+// Phase timing build (tools/rollout_phase_prof.py): waves 0 and 1 of workgroup 0 stamp the shader clock after each
+// phase of a rollout step; slots 0-7 = wave 0 (policy leader), 8-15 = wave 1 (env wave of the synthetic env).
+__device__ unsigned long long g_roll_prof[16];
+struct RollProf {
+  unsigned long long* lds;
+  unsigned long long t_last;
+  bool on;
+  int base;
+};
+#define RO_T(rp, k)                                                             \
+  do {                                                                          \
+    if ((rp).on) {                                                              \
+      const unsigned long long t_now = __builtin_readcyclecounter();            \
+      if ((threadIdx.x & 63) == 0) atomicAdd(&(rp).lds[(rp).base + (k)], t_now - (rp).t_last); \
+      (rp).t_last = t_now;                                                      \
+    }                                                                           \
+  } while (0)
+#else
+struct RollProf {};
+#define RO_T(rp, k) do {} while (0)
+#endif
 template <class XB>
 __device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const TowerLds& tw, XB xb, float* __restrict__ gA,
-                                      float* __restrict__ gB, int gw, int j, int q, f32x4 (&n2)[4]) {
+                                      float* __restrict__ gB, int gw, int j, int q, f32x4 (&n2)[4], RollProf& rp) {
   f32x4 acc = *(const f32x4*)(lds + tw.b1 + 16 * gw + 4 * q);
   for (int s = 0; s < (tw.DP >> 2); ++s) {
     const float a = lds[tw.W1 + (16 * gw + j) * tw.DP + 4 * s + q];
@@ -195,7 +217,9 @@ __device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const Tower
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
   *(f32x4*)(gA + j * GS + 16 * gw + 4 * q) = acc;
+  RO_T(rp, 0);
   __syncthreads();
+  RO_T(rp, 1);
   f32x4 x[4], n1[4];
   float rstd;
 #pragma unroll
@@ -210,11 +234,14 @@ __device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const Tower
     for (int r = 0; r < 4; ++r) acc = ORL_MFMA(a4[r], n1[mi][r], acc);
   }
   *(f32x4*)(gB + j * GS + 16 * gw + 4 * q) = acc;
+  RO_T(rp, 2);
   __syncthreads();
+  RO_T(rp, 3);
 #pragma unroll
   for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(gB + j * GS + 16 * m + 4 * q);
   ln_normalize_T(x, rstd);
   ln_affine_T(x, lds + tw.g2, lds + tw.be2, q, n2);
+  RO_T(rp, 4);
 }
 
 template <int NO, int HEAD, int ENV>
@@ -231,6 +258,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   const int DP = twp.DP;
   float* s_obs = smem + twp.total + twc.total;  // [2][16][DP]
   float* s_gather = s_obs + 2 * TILE_B * DP;    // [2 towers][2 slabs][16][GS]
+  float* s_noise = s_gather + 4 * TILE_B * GS;  // [2][16][16]: sampling noise of steps t (parity) drawn one step ahead
 
   // waves 0-3: policy tower (wave 0 also samples and steps the env); waves 4-7: critic tower
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
@@ -264,7 +292,34 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     ep_ret = A.r.ep_stats[n * 4 + 0]; ep_len = A.r.ep_stats[n * 4 + 1];
     fin_ret = A.r.ep_stats[n * 4 + 2]; fin_cnt = A.r.ep_stats[n * 4 + 3];
   }
+  // The sampling noise does not depend on the network output: wave 3 (idle while wave 0 runs the head) draws the
+  // NEXT step's uniforms / normals into LDS with the same Philox counters sample_head would use, and wave 0 consumes
+  // them through sample_head's forced-noise argument - bit-identical actions, Philox off the critical path.
+  constexpr int NOISE_WAVE = 3, OBS_WAVE = (ENV == ORL_ENV_SYNTH) ? 2 : 0;
+  auto draw_noise = [&](uint64_t tg, float* dst) {
+    if (HEAD == ORL_HEAD_CATEGORICAL) {
+      const u4 r = philox4x32_10(A.r.act_seed, (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)tg,
+                                 (uint32_t)(tg >> 32) << 8);
+      if (q == 0) dst[j * 16] = u01(r.x);
+    } else if (4 * q < n_out) {
+      const u4 r = philox4x32_10(A.r.act_seed, (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)tg,
+                                 ((uint32_t)(tg >> 32) << 8) | (uint32_t)q);
+      float e[4];
+      box_muller(r.x, r.y, e[0], e[1]);
+      box_muller(r.z, r.w, e[2], e[3]);
+      *(f32x4*)(dst + j * 16 + 4 * q) = f32x4{e[0], e[1], e[2], e[3]};
+    }
+  };
+  if (wave == NOISE_WAVE) draw_noise(A.r.rng_step0, s_noise);
   __syncthreads();
+  RollProf rp;
+#ifdef ORL_PROF
+  __shared__ unsigned long long prof_lds[16];
+  if (threadIdx.x < 16) prof_lds[threadIdx.x] = 0ull;
+  __syncthreads();
+  rp.lds = prof_lds; rp.on = blockIdx.x == 0 && wave < 2; rp.base = 8 * wave;
+  rp.t_last = __builtin_readcyclecounter();
+#endif
 
   for (int t = 0; t < T; ++t) {
     const float* cur = s_obs + (t & 1) * TILE_B * DP;
@@ -272,15 +327,15 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
     const uint64_t tg = A.r.rng_step0 + (uint64_t)t;
     f32x4 n2[4];
-    trunk_fwd_coop(tlds, tww, xb, gA, gB, gw, j, q, n2);
+    trunk_fwd_coop(tlds, tww, xb, gA, gB, gw, j, q, n2, rp);
     float act_o[NO];
     if (wave == 0) {
       float hd[NO], lp_o[NO];
       head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);
       // the built-in device envs never mask actions (their action_masks rows stay all-ones), so the mask is
       // not re-read from HBM on the per-step critical path
-      sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, nullptr, nullptr, 0, A.r.act_seed, (uint64_t)n, tg, act_o,
-                            lp_o);
+      sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, nullptr, s_noise + (t & 1) * TILE_B * 16 + j * 16, 0,
+                            A.r.act_seed, (uint64_t)n, tg, act_o, lp_o);
       if (ok && q == 0) {
 #pragma unroll
         for (int c = 0; c < NO; ++c) {
@@ -291,11 +346,29 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
         }
       }
     }
+    RO_T(rp, 5);
+    if (wave == NOISE_WAVE) draw_noise(tg + 1, s_noise + ((t + 1) & 1) * TILE_B * 16);
+    if (ENV == ORL_ENV_SYNTH && wave == OBS_WAVE) {
+      // synthetic observations of slot t+1: every lane of the row generates obs blocks b = q, q+4, ...
+      const size_t s1 = (size_t)(t + 1) * N + n;
+      for (int bb = q; bb < (D + 3) / 4; bb += 4) {
+        float o[4];
+        synth_obs_block(A.r.env_seed, (uint32_t)n, tg + 1, (uint32_t)bb, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = 4 * bb + k;
+          if (d < DP) nxt[j * DP + d] = (d < D) ? o[k] : 0.f;
+          if (ok && d < D) {
+            b.policy_obs[s1 * D + d] = o[k];
+            if (sep_c) b.critic_obs[s1 * D + d] = o[k];
+          }
+        }
+      }
+    }
     if (wave == ENV_WAVE) {
       // ---- env.step + insert (slot t+1) ----
       const size_t s1 = (size_t)(t + 1) * N + n;
       if (ENV == ORL_ENV_SYNTH) {
-        // every lane of the row helps generating obs blocks b = q, q+4, ...
         bool done = false;
         if (q == 0 && ok) {
           const float rew = synth_reward(A.r.env_seed, (uint32_t)n, tg);
@@ -308,19 +381,6 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
           b.bad_masks[s1] = 1.f;
           ep_ret += rew; ep_len += 1.f;
           if (done) { fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f; }
-        }
-        for (int bb = q; bb < (D + 3) / 4; bb += 4) {
-          float o[4];
-          synth_obs_block(A.r.env_seed, (uint32_t)n, tg + 1, (uint32_t)bb, o);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int d = 4 * bb + k;
-            if (d < DP) nxt[j * DP + d] = (d < D) ? o[k] : 0.f;
-            if (ok && d < D) {
-              b.policy_obs[s1 * D + d] = o[k];
-              if (sep_c) b.critic_obs[s1 * D + d] = o[k];
-            }
-          }
         }
       } else {
         if (q == 0 && ok) {
@@ -364,15 +424,21 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
       head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
       if (ok && q == 0) A.r.value_preds[(size_t)t * N + n] = v[0];
     }
+    RO_T(rp, 6);
     __syncthreads();
+    RO_T(rp, 7);
   }
+#ifdef ORL_PROF
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < 16) atomicAdd(&g_roll_prof[threadIdx.x], prof_lds[threadIdx.x]);
+#endif
   // bootstrap value of the last observation (OnPolicyDriver.compute_returns, onpolicy_driver.py:205-233);
   // all waves walk the cooperative trunk once more (barriers), only the critic leader uses the result
   if (A.next_value != nullptr) {
     const float* cur = s_obs + (T & 1) * TILE_B * DP;
     auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
     f32x4 n2[4];
-    trunk_fwd_coop(tlds, tww, xb, gA, gB, gw, j, q, n2);
+    trunk_fwd_coop(tlds, tww, xb, gA, gB, gw, j, q, n2, rp);
     if (wave == 4) {
       const float* lc = smem + twp.total;
       float v[1];
@@ -703,6 +769,17 @@ int orl_env_step(int env_kind, float* env_state, float* ep_stats, const float* a
   return launch_status("orl_env_step");
 }
 
+#ifdef ORL_PROF
+// debug build only: cumulative per-phase cycle counts of waves 0/1 of workgroup 0 of every fused rollout; reset on read
+int orl_debug_rollout_prof(unsigned long long* out16) {
+  unsigned long long zero[16] = {0};
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_roll_prof), sizeof(zero));
+  hipMemcpyToSymbol(HIP_SYMBOL(g_roll_prof), zero, sizeof(zero));
+  return 0;
+}
+#endif
+
 int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                       const orl_rollout_args* args, float* next_value, void* stream) {
   int rc = check_net(pnet, "orl_rollout_fused(policy)", false);
@@ -723,7 +800,7 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
                 "orl_rollout_fused: CartPole needs Discrete(2) and 4-d obs");
   const TowerLds twp(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false);
   const TowerLds twc(cnet->obs_dim, 1, false, false);
-  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP + 4 * TILE_B * GS) * sizeof(float);
+  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 2 * TILE_B * 16) * sizeof(float);
   ORL_REQUIRE(lds <= 160 * 1024, "orl_rollout_fused: needs %zu B of LDS", lds);
   RolloutArgs A;
   A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.r = *args; A.next_value = next_value;
