@@ -35,9 +35,9 @@ int launch_status(const char* what) {
 // several independent 256-byte-row loads in flight, then wave 0 runs the sequential recurrence out
 // of LDS and writes returns / raw advantages as coalesced 256-byte rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int GAE_LANES = 64;
-constexpr int GAE_TC = 32;  // time chunk
-constexpr int GAE_THREADS = 256;
+constexpr int GAE_LANES = 16;   // lanes (env x agent columns) per workgroup: 4096 lanes -> 256 workgroups
+constexpr int GAE_TC = 128;     // time chunk held in LDS
+constexpr int GAE_THREADS = 512;
 
 struct VnCoef {
   float sd, mean;
@@ -69,6 +69,13 @@ __device__ inline float vn_denorm(const VnCoef& c, float v) {
   return t + c.mean;
 }
 
+// Three phases per time chunk, because only the carry is sequential:
+//   A  (all 256 threads, one (t, lane) element each per pass): global loads, ValueNorm denormalisation, delta and the
+//      per-step coefficient -> LDS.  Everything that does not depend on the carry happens here, in parallel.
+//   B  (GAE_LANES threads): the reverse recurrence proper - 2-5 dependent fp32 operations per step, operands from LDS,
+//      in exactly the reference's operation order (bit-exact, contraction off).
+//   C  (all threads, same element mapping as A so V'(t) and the active mask are still in registers): returns, raw
+//      advantages, the statistics sums.
 template <bool USE_GAE, bool PROPER>
 __global__ __launch_bounds__(GAE_THREADS) void gae_scan_kernel(
     const float* __restrict__ rewards, float* __restrict__ value_preds, const float* __restrict__ masks,
@@ -76,97 +83,122 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_scan_kernel(
     float* __restrict__ returns, int T, int L, float gamma, float gl, const float* __restrict__ active_masks,
     float* __restrict__ adv_raw, double* __restrict__ stat_partials) {
 #pragma clang fp contract(off)
-  // LDS tiles: index [tt][lane]; v has TC+1 rows (needs V[t+1]), m/bad rows are for t+1.
-  __shared__ float s_r[GAE_TC][GAE_LANES];
-  __shared__ float s_v[GAE_TC + 1][GAE_LANES];
-  __shared__ float s_m[GAE_TC][GAE_LANES];
-  __shared__ float s_b[GAE_TC][GAE_LANES];
-  __shared__ float s_a[GAE_TC][GAE_LANES];
+  // LDS tiles, index [tt][lane].  GAE: d = delta, c = gamma*lambda*m(t+1).  Returns: d = r, c = m(t+1), y = (1-bad)*V'.
+  __shared__ float s_d[GAE_TC][GAE_LANES];
+  __shared__ float s_c[GAE_TC][GAE_LANES];
+  __shared__ float s_b[PROPER ? GAE_TC : 1][GAE_LANES];
+  __shared__ float s_y[(PROPER && !USE_GAE) ? GAE_TC : 1][GAE_LANES];
+  __shared__ double s_red[GAE_THREADS / 64][8];
+  constexpr int PASSES = GAE_TC * GAE_LANES / GAE_THREADS;  // elements per thread and chunk
+  constexpr int TSTEP = GAE_THREADS / GAE_LANES;            // tt stride between a thread's elements
 
   const int lane0 = blockIdx.x * GAE_LANES;
   const int tid = threadIdx.x;
-  const int ln = tid & 63;
-  const int l = lane0 + ln;
+  const int la = tid % GAE_LANES, tg = tid / GAE_LANES;
+  const int l = lane0 + la;
   const bool lane_ok = l < L;
   const VnCoef vc = vn_coef(vn_state);
   const bool want_stats = stat_partials != nullptr;
 
   // slot T gets next_value first (replay_data.py:323/360/384/418)
+  float nv = 0.f;
+  if (lane_ok) nv = next_value[l];
   if (tid < GAE_LANES && lane_ok) {
-    const float nv = next_value[l];
     if (USE_GAE) value_preds[(size_t)T * L + l] = nv;
     else returns[(size_t)T * L + l] = nv;
   }
 
-  float carry = 0.f;  // gae (USE_GAE) or returns[t+1] (otherwise)
-  if (!USE_GAE && tid < GAE_LANES && lane_ok) carry = next_value[l];
+  float carry = USE_GAE ? 0.f : nv;  // gae (USE_GAE) or returns[t+1] (otherwise); live in threads < GAE_LANES
   double s_all = 0, q_all = 0, n_all = 0, s_act = 0, q_act = 0, n_act = 0, s_ret = 0, q_ret = 0;
 
   for (int t_hi = T; t_hi > 0; t_hi -= GAE_TC) {
     const int t_lo = (t_hi - GAE_TC > 0) ? t_hi - GAE_TC : 0;
     const int nt = t_hi - t_lo;
-    __syncthreads();
-    // cooperative staged load: element e -> (tt = e / 64, lane = e % 64)
-    for (int e = tid; e < nt * GAE_LANES; e += GAE_THREADS) {
-      const int tt = e >> 6, la = e & 63;
-      const int gl_ = lane0 + la;
-      if (gl_ < L) {
+    float v_cur[PASSES], act[PASSES];
+    // ---- A ----
+    float r_[PASSES], v_[PASSES], m_[PASSES], vn_[PASSES], b_[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int tt = tg + p * TSTEP;
+      r_[p] = v_[p] = m_[p] = vn_[p] = 0.f; b_[p] = 1.f; act[p] = 0.f;
+      if (tt < nt && lane_ok) {
         const size_t t = (size_t)(t_lo + tt);
-        s_r[tt][la] = rewards[t * L + gl_];
-        s_v[tt][la] = value_preds[t * L + gl_];
-        s_m[tt][la] = masks[(t + 1) * L + gl_];
-        if (PROPER) s_b[tt][la] = bad_masks[(t + 1) * L + gl_];
-        if (want_stats) s_a[tt][la] = active_masks[t * L + gl_];
+        r_[p] = rewards[t * L + l];
+        v_[p] = value_preds[t * L + l];
+        m_[p] = masks[(t + 1) * L + l];
+        // V[t+1]: slot T is next_value (written above by another thread - read the source instead)
+        if (USE_GAE) vn_[p] = ((int)t + 1 == T) ? nv : value_preds[(t + 1) * L + l];
+        if (PROPER) b_[p] = bad_masks[(t + 1) * L + l];
+        if (want_stats) act[p] = active_masks[t * L + l];
       }
     }
-    if (tid < GAE_LANES && lane_ok) {
-      // V[t_hi]: slot T is next_value (just written by this thread - read the source instead)
-      s_v[nt][ln] = (t_hi == T) ? (USE_GAE ? next_value[l] : 0.f) : value_preds[(size_t)t_hi * L + l];
-    }
-    __syncthreads();
-    if (tid < GAE_LANES && lane_ok) {
-      for (int tt = nt - 1; tt >= 0; --tt) {
-        const size_t t = (size_t)(t_lo + tt);
-        const float r = s_r[tt][ln];
-        const float m = s_m[tt][ln];
-        const float v_cur = vn_denorm(vc, s_v[tt][ln]);
-        float ret;
+    __syncthreads();  // the previous chunk's phase C is done with s_d
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int tt = tg + p * TSTEP;
+      v_cur[p] = vn_denorm(vc, v_[p]);
+      if (tt < nt) {
         if (USE_GAE) {
-          const float v_nxt = vn_denorm(vc, s_v[tt + 1][ln]);
+          const float v_nxt = vn_denorm(vc, vn_[p]);
           // delta = r + gamma * V'(t+1) * m(t+1) - V'(t)      (replay_data.py:390-396)
           const float a0 = gamma * v_nxt;
-          const float a1 = a0 * m;
-          const float a2 = r + a1;
-          const float delta = a2 - v_cur;
+          const float a1 = a0 * m_[p];
+          const float a2 = r_[p] + a1;
+          s_d[tt][la] = a2 - v_cur[p];
+          s_c[tt][la] = gl * m_[p];
+          if (PROPER) s_b[tt][la] = b_[p];
+        } else {
+          s_d[tt][la] = r_[p];
+          s_c[tt][la] = m_[p];
+          if (PROPER) {
+            s_b[tt][la] = b_[p];
+            s_y[tt][la] = (1.f - b_[p]) * v_cur[p];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- B ----
+    if (tid < GAE_LANES) {
+#pragma unroll 8
+      for (int tt = nt - 1; tt >= 0; --tt) {
+        if (USE_GAE) {
           // gae = delta + gamma*lambda * m(t+1) * gae        (:397-400)
-          const float b0 = gl * m;
-          const float b1 = b0 * carry;
-          float gae = delta + b1;
-          if (PROPER) gae = gae * s_b[tt][ln];  // (:341/357)
+          const float b1 = s_c[tt][la] * carry;
+          float gae = s_d[tt][la] + b1;
+          if (PROPER) gae = gae * s_b[tt][la];  // (:341/357)
           carry = gae;
-          ret = gae + v_cur;
         } else {
           // returns[t] = returns[t+1]*gamma*m(t+1) + r  [ *bad + (1-bad)*V'(t) ]  (:365-381, :420-423)
           const float c0 = carry * gamma;
-          const float c1 = c0 * m;
-          float x = c1 + r;
+          const float c1 = c0 * s_c[tt][la];
+          float x = c1 + s_d[tt][la];
           if (PROPER) {
-            const float b = s_b[tt][ln];
-            const float y0 = x * b;
-            const float y1 = (1.f - b) * v_cur;
-            x = y0 + y1;
+            const float y0 = x * s_b[tt][la];
+            x = y0 + s_y[tt][la];
           }
           carry = x;
-          ret = x;
         }
+        s_d[tt][la] = carry;
+      }
+    }
+    __syncthreads();
+    // ---- C ----
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int tt = tg + p * TSTEP;
+      if (tt < nt && lane_ok) {
+        const size_t t = (size_t)(t_lo + tt);
+        const float g = s_d[tt][la];
+        const float ret = USE_GAE ? g + v_cur[p] : g;
         returns[t * L + l] = ret;
         if (adv_raw != nullptr || want_stats) {
-          const float adv = ret - v_cur;  // ppo.py:394-400
+          const float adv = ret - v_cur[p];  // ppo.py:394-400
           if (adv_raw != nullptr) adv_raw[t * L + l] = adv;
           if (want_stats) {
             const double a = (double)adv;
             s_all += a; q_all += a * a; n_all += 1.0;
-            if (s_a[tt][ln] != 0.f) { s_act += a; q_act += a * a; n_act += 1.0; }
+            if (act[p] != 0.f) { s_act += a; q_act += a * a; n_act += 1.0; }
             const double rr = (double)ret;
             s_ret += rr; q_ret += rr * rr;
           }
@@ -174,13 +206,19 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_scan_kernel(
       }
     }
   }
-  if (want_stats && tid < GAE_LANES) {
+  if (want_stats) {
     s_all = wave_sum(s_all); q_all = wave_sum(q_all); n_all = wave_sum(n_all);
     s_act = wave_sum(s_act); q_act = wave_sum(q_act); n_act = wave_sum(n_act);
     s_ret = wave_sum(s_ret); q_ret = wave_sum(q_ret);
-    if (tid == 0) {
-      double* p = stat_partials + (size_t)blockIdx.x * 8;
+    if ((tid & 63) == 0) {
+      double* p = s_red[tid >> 6];
       p[0] = s_all; p[1] = q_all; p[2] = n_all; p[3] = s_act; p[4] = q_act; p[5] = n_act; p[6] = s_ret; p[7] = q_ret;
+    }
+    __syncthreads();
+    if (tid < 8) {
+      double x = 0;
+      for (int w = 0; w < GAE_THREADS / 64; ++w) x += s_red[w][tid];
+      stat_partials[(size_t)blockIdx.x * 8 + tid] = x;
     }
   }
 }
