@@ -634,7 +634,7 @@ int orl_adv_normalize_pack(float* adv, const double* stat_partials, int n_partia
   const long long M = (long long)T * L;
   long long work = records ? M * (R >> 2) : M;
   int grid = (int)((work + 255) / 256);
-  if (grid > 8192) grid = 8192;
+  if (grid > 4096) grid = 4096;  // every workgroup re-reduces the GAE partial rows first: few, longer workgroups (measured)
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(adv_normalize_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, adv, stat_partials,
                      n_partials, M, L, use_adv_normalize, stats_out, s0, records, R);
