@@ -53,6 +53,18 @@ __device__ inline float block_sum_1024(float v, float* sh) {
   return t;
 }
 
+// beta ** step for the Adam bias corrections: square-and-multiply in double (a dozen multiplies; libm's pow is a few
+// hundred cold instructions in a kernel whose run time is instruction fetch).  Agrees with pow() to ~1e-15 relative.
+__device__ inline double powi_d(double b, long long n) {
+  double r = 1.0;
+  while (n > 0) {
+    if (n & 1) r *= b;
+    b *= b;
+    n >>= 1;
+  }
+  return r;
+}
+
 // gradient of parameter p (parameter order) from the raw sums of one tower, already divided by den
 __device__ inline float raw_to_grad(const float* __restrict__ raw, const float* __restrict__ theta,
                                     const TowerLayout& tl, const RawLayout& rl, int p, float inv_den) {
@@ -125,13 +137,36 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     }
     float* raw = s_apply;
     float* th_s = s_apply + rl.total;
+    // latency plan for a one-shot, two-workgroup kernel: everything that comes from HBM (raw sums, parameters, Adam
+    // moments) is requested up front into LDS, the double-precision bias corrections are evaluated while those loads
+    // are in flight, gradients stay in LDS between the norm and the Adam pass, and every loop stays ROLLED - the code
+    // is fetched cold on each launch, so instruction bytes cost more than loop overhead (an unrolled variant of this
+    // body measured 17.2 us against 13.3 us).
+    float* m_s = th_s + tl.total;
+    float* v_s = m_s + tl.total;
+    float* g_s = v_s + tl.total;
+#pragma unroll 1
     for (int e = threadIdx.x; e < rl.total; e += blockDim.x) raw[e] = raw_g[e];
-    for (int e = threadIdx.x; e < tl.total; e += blockDim.x) th_s[e] = W.ad.theta[e];
+#pragma unroll 1
+    for (int e = threadIdx.x; e < tl.total; e += blockDim.x) {
+      th_s[e] = W.ad.theta[e];
+      m_s[e] = W.ad.m[e];
+      v_s[e] = W.ad.v[e];
+    }
+    // torch.optim.Adam (single tensor math, betas (0.9, 0.999), amsgrad off)
+    // scalar coefficients are python doubles in torch/optim/adam.py; only tensor math is fp32
+    const double b1d = 0.9, b2d = 0.999;
+    const float b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
+    const double bc1 = 1.0 - powi_d(b1d, (long long)W.ad.step);
+    const double bc2 = 1.0 - powi_d(b2d, (long long)W.ad.step);
+    const float step_size = (float)((double)W.ad.lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
     __syncthreads();
     float ss = 0.f;
+#pragma unroll 1
     for (int p = threadIdx.x; p < tl.total; p += blockDim.x) {
-      float g = raw_to_grad(raw, th_s, tl, rl, p, inv_den);
-      W.ad.grad[p] = g;
+      const float g = raw_to_grad(raw, th_s, tl, rl, p, inv_den);
+      g_s[p] = g;
       ss += g * g;
     }
     const float total = sqrtf(block_sum_1024(ss, sh));
@@ -139,20 +174,13 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
     float coef = 1.f;
     if (hp.use_max_grad_norm) coef = fminf(hp.max_grad_norm / (total + 1e-6f), 1.f);
-    // torch.optim.Adam (single tensor math, betas (0.9, 0.999), amsgrad off)
-    // scalar coefficients are python doubles in torch/optim/adam.py; only tensor math is fp32
-    const double b1d = 0.9, b2d = 0.999;
-    const float b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
-    const double bc1 = 1.0 - pow(b1d, (double)W.ad.step);
-    const double bc2 = 1.0 - pow(b2d, (double)W.ad.step);
-    const float step_size = (float)((double)W.ad.lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+#pragma unroll 1
     for (int p = threadIdx.x; p < tl.total; p += blockDim.x) {
-      float g = W.ad.grad[p] * coef;
+      float g = g_s[p] * coef;
       W.ad.grad[p] = g;
-      float th = W.ad.theta[p];
+      float th = th_s[p];
       if (W.ad.weight_decay != 0.f) g += W.ad.weight_decay * th;
-      float m = W.ad.m[p], v = W.ad.v[p];
+      float m = m_s[p], v = v_s[p];
       m = m + (g - m) * omb1;          // exp_avg.lerp_(grad, 1 - beta1)
       v = v * b2 + omb2 * (g * g);     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
       const float denom = sqrtf(v) / bc2_sqrt + W.ad.eps;
@@ -177,29 +205,37 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
 }
 
 // both towers' partial regions in one launch: blocks [0, gp) reduce the policy region, the rest the critic's
-__global__ __launch_bounds__(256) void ppo_reduce_pair_kernel(const float* __restrict__ pp, int nb_p, int wp, int gp,
-                                                              const float* __restrict__ pc, int nb_c, int wc,
-                                                              float* __restrict__ sums) {
-  __shared__ float sh[4][64];
+__global__ __launch_bounds__(1024) void ppo_reduce_pair_kernel(const float* __restrict__ pp, int nb_p, int wp, int gp,
+                                                               const float* __restrict__ pc, int nb_c, int wc,
+                                                               float* __restrict__ sums) {
+  // 64 columns x 16 row groups per workgroup: at 256 partial rows every thread has 16 independent loads in flight
+  __shared__ float sh[16][64];
   const bool pol = (int)blockIdx.x < gp;
   const float* partials = pol ? pp : pc;
   const int n_blocks = pol ? nb_p : nb_c, width = pol ? wp : wc;
   float* out = pol ? sums : sums + wp;
-  const int col = (pol ? blockIdx.x : blockIdx.x - gp) * 64 + (threadIdx.x & 63);
+  const int lc = threadIdx.x & 63;
+  const int col = (pol ? blockIdx.x : blockIdx.x - gp) * 64 + lc;
   const int rg = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (col < width) {
     int b = rg;
-    for (; b + 4 < n_blocks; b += 8) {
+    for (; b + 48 < n_blocks; b += 64) {
       s0 += partials[(size_t)b * width + col];
-      s1 += partials[(size_t)(b + 4) * width + col];
+      s1 += partials[(size_t)(b + 16) * width + col];
+      s2 += partials[(size_t)(b + 32) * width + col];
+      s3 += partials[(size_t)(b + 48) * width + col];
     }
-    if (b < n_blocks) s0 += partials[(size_t)b * width + col];
+    for (; b < n_blocks; b += 16) s0 += partials[(size_t)b * width + col];
   }
-  sh[rg][threadIdx.x & 63] = s0 + s1;
+  sh[rg][lc] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (rg == 0 && col < width)
-    out[col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  if (rg == 0 && col < width) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (sh[4 * k][lc] + sh[4 * k + 1][lc]) + (sh[4 * k + 2][lc] + sh[4 * k + 3][lc]);
+    out[col] = (t[0] + t[1]) + (t[2] + t[3]);
+  }
 }
 
 static int check_tower(const orl_net_desc* n, const char* who) {
@@ -373,8 +409,8 @@ int orl_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const floa
   ApplyTower P, Cc;
   P.net = *pnet; P.ad = *padam; P.sums_off = 0;
   Cc.net = *cnet; Cc.ad = *cadam; Cc.sums_off = RawLayout(*pnet).total + ORL_N_STATS;
-  const size_t lp = (size_t)(RawLayout(*pnet).total + TowerLayout(*pnet).total) * sizeof(float);
-  const size_t lc = (size_t)(RawLayout(*cnet).total + TowerLayout(*cnet).total) * sizeof(float);
+  const size_t lp = (size_t)(RawLayout(*pnet).total + 4 * TowerLayout(*pnet).total) * sizeof(float);  // raw | theta m v g
+  const size_t lc = (size_t)(RawLayout(*cnet).total + 4 * TowerLayout(*cnet).total) * sizeof(float);
   const size_t lds = lp > lc ? lp : lc;
   (void)hipFuncSetAttribute((const void*)ppo_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(ppo_apply_kernel, dim3(2), dim3(1024), lds, (hipStream_t)stream, P, Cc, sums, *hp,
@@ -387,7 +423,7 @@ int orl_ppo_reduce_pair(const float* partials, int n_blocks_policy, int width_po
   ORL_REQUIRE(partials && sums && n_blocks_policy > 0 && n_blocks_critic > 0 && width_policy > 0 && width_critic > 0,
               "orl_ppo_reduce_pair: bad arguments");
   const int gp = (width_policy + 63) / 64, gc = (width_critic + 63) / 64;
-  hipLaunchKernelGGL(ppo_reduce_pair_kernel, dim3(gp + gc), dim3(256), 0, (hipStream_t)stream, partials,
+  hipLaunchKernelGGL(ppo_reduce_pair_kernel, dim3(gp + gc), dim3(1024), 0, (hipStream_t)stream, partials,
                      n_blocks_policy, width_policy, gp, partials + (size_t)PPO_MAX_BLOCKS * width_policy,
                      n_blocks_critic, width_critic, sums);
   return launch_status("orl_ppo_reduce_pair");
