@@ -266,6 +266,13 @@ int orl_ppo_reduce_pair(const float* partials, int n_blocks_policy, int width_po
 int orl_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums,
                   const orl_ppo_hparams* hp, const orl_adam_state* padam, const orl_adam_state* cadam,
                   float* train_info_accum, void* stream);
+/* orl_ppo_apply plus, on otherwise idle workgroups of the same launch, the NEXT epoch's minibatch permutation
+ * (orl_perm_feistel(next_idx, n, seed, stream_id)) and - when vn_state != NULL - its ValueNorm.update
+ * (orl_valuenorm_update(vn_state, moments, beta)); neither depends on this optimiser step. */
+int orl_ppo_apply_perm(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums,
+                       const orl_ppo_hparams* hp, const orl_adam_state* padam, const orl_adam_state* cadam,
+                       float* train_info_accum, int64_t* next_idx, int64_t n, uint64_t seed, uint64_t stream_id,
+                       float* vn_state, const double* moments, double beta, void* stream);
 
 /* ValueNorm.update (openrl/modules/utils/valuenorm.py:58-77) from reduced batch sums:
  * moments = {sum(x), sum(x^2), count} as doubles on the device; beta = 0.99999. */

@@ -106,6 +106,9 @@ _SIGNATURES = {
     "orl_ppo_reduce_pair": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "orl_ppo_apply": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
                                 C.POINTER(AdamState), C.POINTER(AdamState), _P, _P]),
+    "orl_ppo_apply_perm": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
+                                     C.POINTER(AdamState), C.POINTER(AdamState), _P, _P, C.c_int64, C.c_uint64,
+                                     C.c_uint64, _P, _P, C.c_double, _P]),
     "orl_valuenorm_update": (C.c_int, [_P, _P, C.c_double, _P]),
     "orl_minibatch_moments": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
     "orl_env_state_width": (C.c_int, [C.c_int]),

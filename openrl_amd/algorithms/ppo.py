@@ -59,6 +59,7 @@ class PPOAlgorithm(BaseAlgorithm):
         self.perm_mode = getattr(cfg, "amd_perm_mode", "reference")
         self._perm_counter = 0
         self._vn_in_perm = False
+        self.fuse_next_perm = True  # device permutation of epoch e+1 rides in epoch e's optimiser-step launch
         self.last_indices = None  # minibatch index tensors of the last train() (tests / inspection)
 
     # ------------------------------------------------------------------------------------------ advantages
@@ -80,7 +81,7 @@ class PPOAlgorithm(BaseAlgorithm):
         buffer._adv_fresh = False  # advantages are now normalised in place
 
     # ------------------------------------------------------------------------------------------ one minibatch
-    def _update_minibatch(self, buffer, idx, mb: int, turn_on: bool) -> None:
+    def _update_minibatch(self, buffer, idx, mb: int, turn_on: bool, next_perm=None):
         mod = self.algo_module
         p, c = mod.models["policy"], mod.models["critic"]
         po, co = mod.optimizers["policy"], mod.optimizers["critic"]
@@ -119,8 +120,8 @@ class PPOAlgorithm(BaseAlgorithm):
         if not turn_on:
             hp = nat.PPOHParams.from_buffer_copy(self.hp)
             hp.reserved |= 1  # critic-only update (construct_loss_list, ppo.py:226-236)
-        ops.ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
-                      co.native_state(co.step_count), self._info)
+        return ops.ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
+                             co.native_state(co.step_count), self._info, next_perm)
 
     # ------------------------------------------------------------------------------------------ recurrent
     def _update_minibatch_rnn(self, buffer, chunks, n_chunks: int, turn_on: bool) -> None:
@@ -171,18 +172,27 @@ class PPOAlgorithm(BaseAlgorithm):
             rand = torch.randperm(data_chunks).to(self.device, non_blocking=True)  # replay_data.py:1078
         return [rand[i * mbs:(i + 1) * mbs] for i in range(self.num_mini_batch)], mbs
 
-    def _minibatch_indices(self, M: int):
+    def _perm_job(self, M: int):
+        """Arguments of the next device permutation (and the ValueNorm.update that rides with it)."""
+        self._perm_counter += 1
+        vn = None
+        if self._full_batch_moments and self._use_valuenorm:  # one launch: permutation + this epoch's ValueNorm.update
+            v = self.algo_module.get_critic_value_normalizer()
+            vn = (v.state, self._moments, v.beta)
+        return M, int(self.cfg.seed), self._perm_counter, vn
+
+    def _minibatch_indices(self, M: int, perm=None):
+        """``perm``: this epoch's permutation if the previous epoch's optimiser-step launch already produced it."""
         mbs = M // self.num_mini_batch
         n_batches = M // mbs  # drop_last=True (replay_data.py:578-580)
         if self.perm_mode == "identity" and self.num_mini_batch == 1:
             return [None], mbs
-        if self.perm_mode in ("device", "identity"):
-            self._perm_counter += 1
-            vn = None
-            if self._full_batch_moments and self._use_valuenorm:  # one launch: permutation + this epoch's ValueNorm.update
-                v = self.algo_module.get_critic_value_normalizer()
-                vn, self._vn_in_perm = (v.state, self._moments, v.beta), True
-            perm = ops.perm_feistel(M, int(self.cfg.seed), self._perm_counter, self.device, vn)
+        if perm is not None:
+            self._vn_in_perm = self._full_batch_moments and self._use_valuenorm
+        elif self.perm_mode in ("device", "identity"):
+            n, seed, sid, vn = self._perm_job(M)
+            self._vn_in_perm = vn is not None
+            perm = ops.perm_feistel(n, seed, sid, self.device, vn)
         else:
             perm = torch.randperm(M).to(self.device, non_blocking=True)  # CPU generator, like the reference
         return [perm[b * mbs:(b + 1) * mbs] for b in range(n_batches)], mbs
@@ -196,17 +206,24 @@ class PPOAlgorithm(BaseAlgorithm):
             self._moments.copy_(self._adv_stats[self._mom_sel])  # {sum ret, sum ret^2, count}
         self._info.zero_()
         self.last_indices = []
-        for _ in range(self.ppo_epoch):
+        next_perm = None
+        for epoch in range(self.ppo_epoch):
             if self.recurrent:  # get_data_generator (ppo.py:363-372)
                 batches, mbs = self._chunk_batches(M)
                 for chunks in batches:
                     self.last_indices.append(chunks)
                     self._update_minibatch_rnn(buffer, chunks, mbs, turn_on)
                 continue
-            batches, mbs = self._minibatch_indices(M)
-            for idx in batches:
+            batches, mbs = self._minibatch_indices(M, next_perm)
+            next_perm = None
+            for k, idx in enumerate(batches):
                 self.last_indices.append(idx)
-                self._update_minibatch(buffer, idx, mbs, turn_on)
+                # the last optimiser step of an epoch also produces the next epoch's permutation (same launch)
+                job = None
+                if (self.fuse_next_perm and k == len(batches) - 1 and epoch + 1 < self.ppo_epoch
+                        and self.perm_mode == "device"):
+                    job = self._perm_job(M)
+                next_perm = self._update_minibatch(buffer, idx, mbs, turn_on, job)
         num_updates = self.ppo_epoch * self.num_mini_batch
         vals = (self._info[:6] / float(num_updates)).cpu().tolist()  # the only device->host sync of train()
         return {k: v for k, v in zip(INFO_KEYS, vals)}

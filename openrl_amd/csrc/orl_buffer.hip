@@ -6,6 +6,7 @@
 // accesses over the [T(+1), N*A] lane grid, LDS staging for the time scan, wave64 shuffles for
 // reductions.  No MFMA here by design.
 #include "orl_common.h"
+#include "orl_perm.h"
 
 namespace orl {
 
@@ -397,74 +398,14 @@ __global__ __launch_bounds__(256) void gather_kernel(orl_gather_desc d, const in
 }
 
 // ------------------------------------------------------------------------------------------------
-// Keyed permutation of [0,n): balanced Feistel network over 2*hb bits (2^(2hb) >= n) with
-// cycle walking.  The four 32-bit round keys come from ONE Philox4x32-10 block of (stream_id) under
-// `seed`; the round function is the murmur3 32-bit finaliser of (half ^ key) - a bijection-preserving
-// Feistel needs no more than a well-mixed round function, and this keeps the kernel store-bound.
-// ------------------------------------------------------------------------------------------------
-__host__ __device__ inline uint32_t fmix32(uint32_t x) {
-  x ^= x >> 16;
-  x *= 0x85EBCA6Bu;
-  x ^= x >> 13;
-  x *= 0xC2B2AE35u;
-  x ^= x >> 16;
-  return x;
-}
-
-__host__ __device__ inline uint64_t feistel_perm(uint64_t i, uint64_t n, int hb, const u4& keys) {
-  const uint32_t hmask = (uint32_t)(((uint64_t)1 << hb) - 1);
-  const uint32_t k[4] = {keys.x, keys.y, keys.z, keys.w};
-  uint64_t x = i;
-  do {
-    uint32_t lft = (uint32_t)(x >> hb), rgt = (uint32_t)x & hmask;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t fv = fmix32(rgt ^ k[r]) & hmask;
-      const uint32_t nl = rgt;
-      rgt = lft ^ fv;
-      lft = nl;
-    }
-    x = ((uint64_t)lft << hb) | rgt;
-  } while (x >= n);
-  return x;
-}
-
-// ------------------------------------------------------------------------------------------------
 // ValueNorm.update (valuenorm.py:58-77) from batch sums, and minibatch return moments.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void valuenorm_update_body(float* __restrict__ vn, const double* __restrict__ mom, float beta, float omw) {
-#pragma clang fp contract(off)
-  const double cnt = mom[2];
-  const float bm = (float)(mom[0] / cnt);
-  const float bsq = (float)(mom[1] / cnt);
-  // omw = float32(1.0 - weight) with the subtraction done in double on the host (python float semantics)
-  const float t0 = bm * omw;
-  const float t1 = bsq * omw;
-  vn[0] = vn[0] * beta + t0;
-  vn[1] = vn[1] * beta + t1;
-  vn[2] = vn[2] * beta + omw;
-}
-
 __global__ void valuenorm_update_kernel(float* __restrict__ vn, const double* __restrict__ mom, float beta, float omw) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   valuenorm_update_body(vn, mom, beta, omw);
 }
 
-// One launch per PPO epoch when the minibatch is the whole batch: the permutation of that epoch and, on one extra
-// workgroup, the ValueNorm.update that precedes its loss (ppo.py:190-195) - the two are independent.
-__global__ __launch_bounds__(256) void perm_feistel_kernel(int64_t* __restrict__ idx, long long n, int hb,
-                                                           uint64_t seed, uint64_t stream_id, float* __restrict__ vn,
-                                                           const double* __restrict__ mom, float beta, float omw) {
-  if (vn != nullptr && blockIdx.x == gridDim.x - 1) {
-    if (threadIdx.x == 0) valuenorm_update_body(vn, mom, beta, omw);
-    return;
-  }
-  const int nb = (int)gridDim.x - (vn != nullptr ? 1 : 0);
-  const u4 keys = philox4x32_10(seed, (uint32_t)stream_id, (uint32_t)(stream_id >> 32), 0x5EED5EEDu, 0u);
-  const long long stride = (long long)nb * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    idx[i] = (int64_t)feistel_perm((uint64_t)i, (uint64_t)n, hb, keys);
-}
+__global__ __launch_bounds__(256) void perm_feistel_kernel(PermJob J) { perm_job_block(J, blockIdx.x, gridDim.x); }
 
 __global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ records, int R, int col,
                                                               const int64_t* __restrict__ idx, int mb,
@@ -678,13 +619,10 @@ static int launch_perm(const char* what, int64_t* idx, int64_t n, uint64_t seed,
                        const double* mom, double beta, void* stream) {
   ORL_REQUIRE(idx && n > 0, "%s: bad arguments", what);
   ORL_REQUIRE(n <= ((int64_t)1 << 62), "%s: n too large", what);
-  int bits = 1;
-  while (((int64_t)1 << bits) < n) ++bits;
-  const int hb = (bits + 1) / 2;
+  const PermJob J = make_perm_job(idx, n, seed, stream_id, vn, mom, beta);
   int grid = (int)((n + 255) / 256);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(perm_feistel_kernel, dim3(grid + (vn ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, idx,
-                     (long long)n, hb, seed, stream_id, vn, mom, (float)beta, (float)(1.0 - beta));
+  hipLaunchKernelGGL(perm_feistel_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, J);
   return launch_status(what);
 }
 

@@ -2,8 +2,7 @@
 //   orl_ppo_fwd_bwd : K9-K12 fused tower forward + PPO/value/entropy loss + full backward, one launch
 //                     per tower (kernel in orl_ppo_tower.h), producing per-workgroup partial sums of the
 //                     RAW gradient
-//   orl_ppo_reduce  : deterministic column sums of the partials (the vector a multi-GPU run all-reduces)
-//   orl_ppo_apply   : raw sums -> parameter gradients, grad-norm clip (K13), Adam (K14), train_info
+// (the reduction of those partials and the optimiser step live in orl_apply.hip, built WITHOUT -ffast-math)
 #include <stdlib.h>
 #include "orl_common.h"
 #include "orl_mlp.h"
@@ -11,232 +10,6 @@
 #include "orl_ppo_tower_mt.h"
 
 namespace orl {
-
-// ---- reduce: column sums over workgroup partials -------------------------------------------------
-__global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partials, int n_blocks, int width,
-                                                         float* __restrict__ sums) {
-  // block = 64 columns x 4 row groups: coalesced 256-byte row segments, 4-way split of the row walk,
-  // fixed summation order (deterministic): rows rg, rg+4, ... then groups 0..3.
-  __shared__ float sh[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rg = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f;
-  if (col < width) {
-    int b = rg;
-    for (; b + 4 < n_blocks; b += 8) {
-      s0 += partials[(size_t)b * width + col];
-      s1 += partials[(size_t)(b + 4) * width + col];
-    }
-    if (b < n_blocks) s0 += partials[(size_t)b * width + col];
-  }
-  sh[rg][threadIdx.x & 63] = s0 + s1;
-  __syncthreads();
-  if (rg == 0 && col < width)
-    sums[col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-}
-
-// ---- apply: raw sums -> grads -> clip -> Adam; one workgroup of 1024 threads ------------------------
-struct ApplyTower {
-  orl_net_desc net;
-  orl_adam_state ad;
-  int sums_off;  // offset of this tower's raw vector in `sums`
-};
-
-__device__ inline float block_sum_1024(float v, float* sh) {
-  v = wave_sum(v);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) sh[w] = v;
-  __syncthreads();
-  float t = 0.f;
-  for (int k = 0; k < 16; ++k) t += sh[k];
-  __syncthreads();
-  return t;
-}
-
-// beta ** step for the Adam bias corrections: square-and-multiply in double (a dozen multiplies; libm's pow is a few
-// hundred cold instructions in a kernel whose run time is instruction fetch).  Agrees with pow() to ~1e-15 relative.
-__device__ inline double powi_d(double b, long long n) {
-  double r = 1.0;
-  while (n > 0) {
-    if (n & 1) r *= b;
-    b *= b;
-    n >>= 1;
-  }
-  return r;
-}
-
-// gradient of parameter p (parameter order) from the raw sums of one tower, already divided by den
-__device__ inline float raw_to_grad(const float* __restrict__ raw, const float* __restrict__ theta,
-                                    const TowerLayout& tl, const RawLayout& rl, int p, float inv_den) {
-  const int H = HID;
-  float g;
-  if (p < tl.ob1) g = raw[rl.odW1 + (p - tl.oW1)];
-  else if (p < tl.og1) g = raw[rl.odb1 + (p - tl.ob1)];
-  else if (p < tl.obe1) {  // LN1 weight: dg1[i] = sum_o W2[o][i] * G[o][i]
-    const int i = p - tl.og1;
-    g = 0.f;
-    for (int o = 0; o < H; ++o) g += theta[tl.oW2 + o * H + i] * raw[rl.oG + o * H + i];
-  } else if (p < tl.oW2) {  // LN1 bias: dbe1[i] = sum_o W2[o][i] * db2[o]
-    const int i = p - tl.obe1;
-    g = 0.f;
-    for (int o = 0; o < H; ++o) g += theta[tl.oW2 + o * H + i] * raw[rl.odb2 + o];
-  } else if (p < tl.ob2) {
-    const int e = p - tl.oW2, o = e / H, i = e - o * H;
-    g = theta[tl.og1 + i] * raw[rl.oG + e] + theta[tl.obe1 + i] * raw[rl.odb2 + o];
-  } else if (p < tl.og2) g = raw[rl.odb2 + (p - tl.ob2)];
-  else if (p < tl.obe2) {  // LN2 weight: dg2[f] = sum_c W3[c][f] * S3[c][f]
-    const int f = p - tl.og2;
-    g = 0.f;
-    for (int c = 0; c < tl.n_out; ++c) g += theta[tl.oW3 + c * H + f] * raw[rl.oS3 + c * H + f];
-  } else if (p < tl.oW3) {  // LN2 bias: dbe2[f] = sum_c W3[c][f] * db3[c]
-    const int f = p - tl.obe2;
-    g = 0.f;
-    for (int c = 0; c < tl.n_out; ++c) g += theta[tl.oW3 + c * H + f] * raw[rl.odb3 + c];
-  } else if (p < tl.ob3) {
-    const int e = p - tl.oW3, c = e / H, f = e - c * H;
-    g = theta[tl.og2 + f] * raw[rl.oS3 + e] + theta[tl.obe2 + f] * raw[rl.odb3 + c];
-  } else if (p < tl.ologstd) g = raw[rl.odb3 + (p - tl.ob3)];
-  else g = raw[rl.odlogstd + (p - tl.ologstd)];
-  return g * inv_den;
-}
-
-// One workgroup per tower (blockIdx.x = 0 policy, 1 critic).  The tower's raw sums and parameters are
-// staged in LDS first so the 64-term LayerNorm-affine dot products of raw_to_grad run out of LDS.
-__global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTower Cc, const float* __restrict__ sums,
-                                                         orl_ppo_hparams hp, float* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) float s_apply[];
-  __shared__ float sh[16];
-  const TowerLayout tlp(P.net), tlc(Cc.net);
-  const RawLayout rlp(P.net), rlc(Cc.net);
-  const float* rawp = sums + P.sums_off;
-  const float* stp = rawp + rlp.total;
-  const float* rawc = sums + Cc.sums_off;
-  const float* stc = rawc + rlc.total;
-  const float den_p = hp.use_policy_active_masks ? stp[ST_ACTIVE_SUM] : stp[ST_ROWS];
-  const float den_v = hp.use_value_active_masks ? stc[ST_ACTIVE_SUM] : stc[ST_ROWS];
-  float norms[2] = {0.f, 0.f};
-  {
-    const int t = blockIdx.x;
-    const ApplyTower& W = t == 0 ? P : Cc;
-    const TowerLayout& tl = t == 0 ? tlp : tlc;
-    const RawLayout& rl = t == 0 ? rlp : rlc;
-    const float* raw_g = t == 0 ? rawp : rawc;
-    const float inv_den = 1.0f / (t == 0 ? den_p : den_v);
-    if (t == 0 && (hp.reserved & 1)) {
-      // turn_on == False: the policy loss is not in the loss list (ppo.py:226-236) -> no gradient, no step
-      for (int p = threadIdx.x; p < tl.total; p += blockDim.x) W.ad.grad[p] = 0.f;
-      if (threadIdx.x == 0 && info != nullptr) {
-        info[1] += stp[ST_PLOSS_SUM] / den_p;
-        float ent_den0 = den_p;
-        if (!hp.use_policy_active_masks && P.net.head_kind == ORL_HEAD_GAUSSIAN) ent_den0 = den_p * (float)P.net.n_out;
-        info[2] += stp[ST_ENT_SUM] / ent_den0;
-        const float aw0 = P.net.head_kind == ORL_HEAD_GAUSSIAN ? (float)P.net.n_out : 1.f;
-        info[5] += stp[ST_RATIO_SUM] / (stp[ST_ROWS] * aw0);
-      }
-      return;
-    }
-    float* raw = s_apply;
-    float* th_s = s_apply + rl.total;
-    // latency plan for a one-shot, two-workgroup kernel: everything that comes from HBM (raw sums, parameters, Adam
-    // moments) is requested up front into LDS, the double-precision bias corrections are evaluated while those loads
-    // are in flight, gradients stay in LDS between the norm and the Adam pass, and every loop stays ROLLED - the code
-    // is fetched cold on each launch, so instruction bytes cost more than loop overhead (an unrolled variant of this
-    // body measured 17.2 us against 13.3 us).
-    float* m_s = th_s + tl.total;
-    float* v_s = m_s + tl.total;
-    float* g_s = v_s + tl.total;
-#pragma unroll 1
-    for (int e = threadIdx.x; e < rl.total; e += blockDim.x) raw[e] = raw_g[e];
-#pragma unroll 1
-    for (int e = threadIdx.x; e < tl.total; e += blockDim.x) {
-      th_s[e] = W.ad.theta[e];
-      m_s[e] = W.ad.m[e];
-      v_s[e] = W.ad.v[e];
-    }
-    // torch.optim.Adam (single tensor math, betas (0.9, 0.999), amsgrad off)
-    // scalar coefficients are python doubles in torch/optim/adam.py; only tensor math is fp32
-    const double b1d = 0.9, b2d = 0.999;
-    const float b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
-    const double bc1 = 1.0 - powi_d(b1d, (long long)W.ad.step);
-    const double bc2 = 1.0 - powi_d(b2d, (long long)W.ad.step);
-    const float step_size = (float)((double)W.ad.lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    __syncthreads();
-    float ss = 0.f;
-#pragma unroll 1
-    for (int p = threadIdx.x; p < tl.total; p += blockDim.x) {
-      const float g = raw_to_grad(raw, th_s, tl, rl, p, inv_den);
-      g_s[p] = g;
-      ss += g * g;
-    }
-    const float total = sqrtf(block_sum_1024(ss, sh));
-    norms[t] = total;
-    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
-    float coef = 1.f;
-    if (hp.use_max_grad_norm) coef = fminf(hp.max_grad_norm / (total + 1e-6f), 1.f);
-#pragma unroll 1
-    for (int p = threadIdx.x; p < tl.total; p += blockDim.x) {
-      float g = g_s[p] * coef;
-      W.ad.grad[p] = g;
-      float th = th_s[p];
-      if (W.ad.weight_decay != 0.f) g += W.ad.weight_decay * th;
-      float m = m_s[p], v = v_s[p];
-      m = m + (g - m) * omb1;          // exp_avg.lerp_(grad, 1 - beta1)
-      v = v * b2 + omb2 * (g * g);     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-      const float denom = sqrtf(v) / bc2_sqrt + W.ad.eps;
-      th = th - step_size * (m / denom);
-      W.ad.m[p] = m; W.ad.v[p] = v; W.ad.theta[p] = th;
-    }
-  }
-  if (threadIdx.x == 0 && info != nullptr) {
-    if (blockIdx.x == 0) {
-      float ent_den = den_p;
-      if (!hp.use_policy_active_masks && P.net.head_kind == ORL_HEAD_GAUSSIAN) ent_den = den_p * (float)P.net.n_out;
-      info[1] += stp[ST_PLOSS_SUM] / den_p;                 // policy_loss
-      info[2] += stp[ST_ENT_SUM] / ent_den;                 // dist_entropy
-      info[3] += norms[0];                                  // actor_grad_norm
-      const float a_w = P.net.head_kind == ORL_HEAD_GAUSSIAN ? (float)P.net.n_out : 1.f;
-      info[5] += stp[ST_RATIO_SUM] / (stp[ST_ROWS] * a_w);  // ratio.mean()
-    } else {
-      info[0] += stc[ST_VLOSS_SUM] / den_v;                 // value_loss
-      info[4] += norms[1];                                  // critic_grad_norm
-    }
-  }
-}
-
-// both towers' partial regions in one launch: blocks [0, gp) reduce the policy region, the rest the critic's
-__global__ __launch_bounds__(1024) void ppo_reduce_pair_kernel(const float* __restrict__ pp, int nb_p, int wp, int gp,
-                                                               const float* __restrict__ pc, int nb_c, int wc,
-                                                               float* __restrict__ sums) {
-  // 64 columns x 16 row groups per workgroup: at 256 partial rows every thread has 16 independent loads in flight
-  __shared__ float sh[16][64];
-  const bool pol = (int)blockIdx.x < gp;
-  const float* partials = pol ? pp : pc;
-  const int n_blocks = pol ? nb_p : nb_c, width = pol ? wp : wc;
-  float* out = pol ? sums : sums + wp;
-  const int lc = threadIdx.x & 63;
-  const int col = (pol ? blockIdx.x : blockIdx.x - gp) * 64 + lc;
-  const int rg = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (col < width) {
-    int b = rg;
-    for (; b + 48 < n_blocks; b += 64) {
-      s0 += partials[(size_t)b * width + col];
-      s1 += partials[(size_t)(b + 16) * width + col];
-      s2 += partials[(size_t)(b + 32) * width + col];
-      s3 += partials[(size_t)(b + 48) * width + col];
-    }
-    for (; b < n_blocks; b += 16) s0 += partials[(size_t)b * width + col];
-  }
-  sh[rg][lc] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (rg == 0 && col < width) {
-    float t[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = (sh[4 * k][lc] + sh[4 * k + 1][lc]) + (sh[4 * k + 2][lc] + sh[4 * k + 3][lc]);
-    out[col] = (t[0] + t[1]) + (t[2] + t[3]);
-  }
-}
 
 static int check_tower(const orl_net_desc* n, const char* who) {
   if (!n) return fail(ORL_E_INVALID, "%s: null net descriptor", who);
@@ -387,46 +160,6 @@ int orl_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net
   if (gc <= 0) return gc <= -1000 ? -(gc + 1000) : gc;
   if (n_blocks_out) { n_blocks_out[0] = gp; n_blocks_out[1] = gc; }
   return 0;
-}
-
-int orl_ppo_reduce(const float* partials, int n_blocks, int width, float* sums, void* stream) {
-  ORL_REQUIRE(partials && sums && n_blocks > 0 && width > 0, "orl_ppo_reduce: bad arguments");
-  const int grid = (width + 63) / 64;
-  hipLaunchKernelGGL(ppo_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partials, n_blocks, width, sums);
-  return launch_status("orl_ppo_reduce");
-}
-
-int orl_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums, const orl_ppo_hparams* hp,
-                  const orl_adam_state* padam, const orl_adam_state* cadam, float* train_info_accum, void* stream) {
-  int rc = check_tower(pnet, "orl_ppo_apply(policy)");
-  if (rc) return rc;
-  rc = check_tower(cnet, "orl_ppo_apply(critic)");
-  if (rc) return rc;
-  ORL_REQUIRE(sums && hp && padam && cadam, "orl_ppo_apply: null pointer");
-  ORL_REQUIRE(padam->theta && padam->grad && padam->m && padam->v && cadam->theta && cadam->grad && cadam->m && cadam->v,
-              "orl_ppo_apply: null optimizer buffer");
-  ORL_REQUIRE(padam->step >= 1 && cadam->step >= 1, "orl_ppo_apply: Adam step counts are 1-based");
-  ApplyTower P, Cc;
-  P.net = *pnet; P.ad = *padam; P.sums_off = 0;
-  Cc.net = *cnet; Cc.ad = *cadam; Cc.sums_off = RawLayout(*pnet).total + ORL_N_STATS;
-  const size_t lp = (size_t)(RawLayout(*pnet).total + 4 * TowerLayout(*pnet).total) * sizeof(float);  // raw | theta m v g
-  const size_t lc = (size_t)(RawLayout(*cnet).total + 4 * TowerLayout(*cnet).total) * sizeof(float);
-  const size_t lds = lp > lc ? lp : lc;
-  (void)hipFuncSetAttribute((const void*)ppo_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(ppo_apply_kernel, dim3(2), dim3(1024), lds, (hipStream_t)stream, P, Cc, sums, *hp,
-                     train_info_accum);
-  return launch_status("orl_ppo_apply");
-}
-
-int orl_ppo_reduce_pair(const float* partials, int n_blocks_policy, int width_policy, int n_blocks_critic,
-                        int width_critic, float* sums, void* stream) {
-  ORL_REQUIRE(partials && sums && n_blocks_policy > 0 && n_blocks_critic > 0 && width_policy > 0 && width_critic > 0,
-              "orl_ppo_reduce_pair: bad arguments");
-  const int gp = (width_policy + 63) / 64, gc = (width_critic + 63) / 64;
-  hipLaunchKernelGGL(ppo_reduce_pair_kernel, dim3(gp + gc), dim3(1024), 0, (hipStream_t)stream, partials,
-                     n_blocks_policy, width_policy, gp, partials + (size_t)PPO_MAX_BLOCKS * width_policy,
-                     n_blocks_critic, width_critic, sums);
-  return launch_status("orl_ppo_reduce_pair");
 }
 
 }  // extern "C"

@@ -188,11 +188,24 @@ def ppo_reduce_pair(partials, nb_p: int, width_p: int, nb_c: int, width_c: int, 
     nat.check(rc, "orl_ppo_reduce_pair")
 
 
-def ppo_apply(pnet, cnet, sums, hp: PPOHParams, padam: AdamState, cadam: AdamState, train_info_accum) -> None:
+def ppo_apply(pnet, cnet, sums, hp: PPOHParams, padam: AdamState, cadam: AdamState, train_info_accum,
+              next_perm=None):
+    """``next_perm`` = (n, seed, stream_id, vn | None): also produce the next epoch's permutation (returned) and, with
+    vn = (state, moments, beta), its ValueNorm.update, on idle workgroups of the same launch (orl_ppo_apply_perm)."""
     dev = _dev(sums)
-    rc = _lib().orl_ppo_apply(C.byref(pnet), C.byref(cnet), fptr(sums), C.byref(hp), C.byref(padam), C.byref(cadam),
-                              fptr(train_info_accum), stream_ptr(dev))
-    nat.check(rc, "orl_ppo_apply")
+    if next_perm is None:
+        rc = _lib().orl_ppo_apply(C.byref(pnet), C.byref(cnet), fptr(sums), C.byref(hp), C.byref(padam),
+                                  C.byref(cadam), fptr(train_info_accum), stream_ptr(dev))
+        nat.check(rc, "orl_ppo_apply")
+        return None
+    n, seed, stream_id, vn = next_perm
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    rc = _lib().orl_ppo_apply_perm(C.byref(pnet), C.byref(cnet), fptr(sums), C.byref(hp), C.byref(padam),
+                                   C.byref(cadam), fptr(train_info_accum), ptr(idx), n, seed & (2 ** 64 - 1),
+                                   stream_id & (2 ** 64 - 1), fptr(vn[0]) if vn else None, ptr(vn[1]) if vn else None,
+                                   float(vn[2]) if vn else 0.0, stream_ptr(dev))
+    nat.check(rc, "orl_ppo_apply_perm")
+    return idx
 
 
 def valuenorm_update(vn_state, moments, beta: float = 0.99999) -> None:

@@ -55,7 +55,7 @@ def test_host_side_queries(lib):
     assert lib.orl_record_width(4, 4, 1, 2) == 16  # one 64-byte record per sample at config 2
     assert lib.orl_record_width(17, 17, 6, 0) == 52
     assert lib.orl_ppo_max_blocks() == 256
-    assert lib.orl_gae_max_partials(128, 4096) == 64
+    assert lib.orl_gae_max_partials(128, 4096) == 256  # 16 lanes per workgroup
     assert lib.orl_env_state_width(n.ORL_ENV_SYNTH) == 4 and lib.orl_env_state_width(n.ORL_ENV_CARTPOLE) == 8
 
 

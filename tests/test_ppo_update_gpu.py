@@ -123,6 +123,25 @@ def test_device_permutation_mode_trains_and_is_deterministic():
     assert np.isfinite(list(outs[0][1].values())).all()
 
 
+@pytest.mark.parametrize("case", ["train_discrete", "train_discrete_masks"])
+def test_next_epoch_permutation_in_the_apply_launch_changes_nothing(case):
+    """orl_ppo_apply_perm: epoch e+1's permutation (+ ValueNorm.update when the minibatch is the whole batch) produced
+    by idle workgroups of epoch e's optimiser step == the stand-alone launches, bit for bit."""
+    g = H.load_golden(case)
+    outs = []
+    for fuse in (True, False):
+        cfg, module, buf, algo = build_engine(g)
+        algo.perm_mode, algo.fuse_next_perm = "device", fuse
+        algo.train(buf)
+        vn = module.get_critic_value_normalizer()
+        outs.append((module.models["policy"].theta.clone(), module.models["critic"].theta.clone(),
+                     None if vn is None else vn.state.clone(), [i.clone() for i in algo.last_indices]))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert (a[2] is None and b[2] is None) or torch.equal(a[2], b[2])
+    assert len(a[3]) == len(b[3]) and all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+
+
 def _random_case(D, act_space_kind, n_act, N, T, seed, masks=False):
     """Synthetic buffer at an arbitrary shape: one full-batch update, engine vs oracle autograd."""
     from openrl_amd import spaces
