@@ -137,6 +137,13 @@ typedef struct orl_buffer_ptrs {
 int orl_buffer_insert(const orl_buffer_ptrs* buf, int step, const float* next_policy_obs,
                       const float* next_critic_obs, const float* rewards, const uint8_t* dones,
                       const uint8_t* bad_transition, const float* next_action_masks, void* stream);
+/* orl_buffer_insert for recurrent policies: additionally multiplies the hidden states the act step left in slot
+ * step+1 (h_*_next = rnn_states[step+1], [N*A, hidden], in place; h_critic_next may be NULL) by masks[step+1], i.e.
+ * rnn_states[dones_env == True] = 0 (onpolicy_driver.py:100-109) without two extra elementwise launches. */
+int orl_buffer_insert_rnn(const orl_buffer_ptrs* buf, int step, const float* next_policy_obs,
+                          const float* next_critic_obs, const float* rewards, const uint8_t* dones,
+                          const uint8_t* bad_transition, const float* next_action_masks, float* h_policy_next,
+                          float* h_critic_next, int hidden, void* stream);
 
 /* ---- K8: minibatch gather ------------------------------------------------------------------------
  * Replaces the fancy-index gathers of ReplayData.feed_forward_generator

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "orl_record_width": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "orl_adv_normalize_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(PackSrc), _P, _P]),
     "orl_buffer_insert": (C.c_int, [C.POINTER(BufferPtrs), C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "orl_buffer_insert_rnn": (C.c_int, [C.POINTER(BufferPtrs), C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "orl_gather_minibatch": (C.c_int, [C.POINTER(GatherDesc), _P, C.c_int, _P]),
     "orl_perm_feistel": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "orl_perm_feistel_vn": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, C.c_double, _P]),

@@ -138,11 +138,17 @@ class PPOAlgorithm(BaseAlgorithm):
         vn = mod.get_critic_value_normalizer() if self._use_valuenorm else None
         vn_state = None
         if vn is not None:
-            ret_col = buffer.Dp + buffer.Dc + 2 * buffer.act_shape + 2
-            ops.minibatch_moments(rec, ret_col, rows, n_chunks * L, self._mom_scratch, self._moments)
-            if self.world_size > 1:
-                dist_utils.allreduce_(self._moments)
-            ops.valuenorm_update(vn.state, self._moments, vn.beta)
+            if self._full_batch_moments:
+                pass  # every chunk is in the minibatch: the GAE pass already summed these returns (train_ppo)
+            else:
+                ret_col = buffer.Dp + buffer.Dc + 2 * buffer.act_shape + 2
+                ops.minibatch_moments(rec, ret_col, rows, n_chunks * L, self._mom_scratch, self._moments)
+                if self.world_size > 1:
+                    dist_utils.allreduce_(self._moments)
+            if self._vn_in_perm:
+                self._vn_in_perm = False  # ran inside the permutation launch
+            else:
+                ops.valuenorm_update(vn.state, self._moments, vn.beta)
             vn_state = vn.state
         need = ops_rnn.rnn_workspace_floats(p.net, c.net, n_chunks, L)
         if self._rnn_ws is None or self._rnn_ws.numel() < need:
@@ -166,8 +172,9 @@ class PPOAlgorithm(BaseAlgorithm):
         data_chunks = M // L
         mbs = data_chunks // self.num_mini_batch
         if self.perm_mode == "device":
-            self._perm_counter += 1
-            rand = ops.perm_feistel(data_chunks, int(self.cfg.seed), self._perm_counter, self.device)
+            n, seed, sid, vn = self._perm_job(data_chunks)
+            self._vn_in_perm = vn is not None
+            rand = ops.perm_feistel(n, seed, sid, self.device, vn)
         else:
             rand = torch.randperm(data_chunks).to(self.device, non_blocking=True)  # replay_data.py:1078
         return [rand[i * mbs:(i + 1) * mbs] for i in range(self.num_mini_batch)], mbs
@@ -201,7 +208,8 @@ class PPOAlgorithm(BaseAlgorithm):
     def train_ppo(self, buffer, turn_on: bool = True) -> Dict[str, float]:
         self._advantages_and_records(buffer)
         M = buffer.episode_length * buffer.n_rollout_threads * buffer.num_agents
-        self._full_batch_moments = self.num_mini_batch == 1 and not self.recurrent
+        # one minibatch == every sample (recurrent: every chunk, when the chunks tile the batch exactly)
+        self._full_batch_moments = self.num_mini_batch == 1 and (not self.recurrent or M % self.data_chunk_length == 0)
         if self._full_batch_moments:
             self._moments.copy_(self._adv_stats[self._mom_sel])  # {sum ret, sum ret^2, count}
         self._info.zero_()

@@ -55,18 +55,6 @@ __device__ inline float block_sum_1024(float v, float* sh) {
   return t;
 }
 
-// beta ** step for the Adam bias corrections: square-and-multiply in double (a dozen multiplies; libm's pow is a few
-// hundred cold instructions in a kernel whose run time is instruction fetch).  Agrees with pow() to ~1e-15 relative.
-__device__ inline double powi_d(double b, long long n) {
-  double r = 1.0;
-  while (n > 0) {
-    if (n & 1) r *= b;
-    b *= b;
-    n >>= 1;
-  }
-  return r;
-}
-
 // gradient of parameter p (parameter order) from the raw sums of one tower, already divided by den
 __device__ inline float raw_to_grad(const float* __restrict__ raw, const float* __restrict__ theta,
                                     const TowerLayout& tl, const RawLayout& rl, int p, float inv_den) {

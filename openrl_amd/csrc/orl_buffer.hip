@@ -351,7 +351,9 @@ __global__ __launch_bounds__(256) void buffer_insert_kernel(orl_buffer_ptrs b, i
                                                             const float* __restrict__ rew,
                                                             const uint8_t* __restrict__ dones,
                                                             const uint8_t* __restrict__ bad,
-                                                            const float* __restrict__ namask) {
+                                                            const float* __restrict__ namask,
+                                                            float* __restrict__ h_policy, float* __restrict__ h_critic,
+                                                            int H) {
   const int LA = b.N * b.A;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -372,6 +374,18 @@ __global__ __launch_bounds__(256) void buffer_insert_kernel(orl_buffer_ptrs b, i
     b.masks[s1 * LA + i] = all_done ? 0.f : 1.f;                 // onpolicy_driver.py:110-113
     b.active_masks[s1 * LA + i] = (d && !all_done) ? 0.f : 1.f;  // :119-125
     b.bad_masks[s1 * LA + i] = (bad != nullptr && bad[i] != 0) ? 0.f : 1.f;  // :126-138
+  }
+  // recurrent: rnn_states[dones_env == True] = 0 (onpolicy_driver.py:100-109) as the product with masks[step+1],
+  // in place on slot step+1 where the act kernel left the new hidden states
+  if (h_policy != nullptr) {
+    for (long long i = i0; i < (long long)LA * H; i += stride) {
+      const int n = (int)((i / H) / b.A);
+      bool all_done = true;
+      for (int a = 0; a < b.A; ++a) all_done = all_done && (dones[n * b.A + a] != 0);
+      const float m = all_done ? 0.f : 1.f;
+      h_policy[i] = h_policy[i] * m;
+      if (h_critic != nullptr) h_critic[i] = h_critic[i] * m;
+    }
   }
 }
 
@@ -585,16 +599,29 @@ int orl_adv_normalize_pack(float* adv, const double* stat_partials, int n_partia
 int orl_buffer_insert(const orl_buffer_ptrs* buf, int step, const float* next_policy_obs,
                       const float* next_critic_obs, const float* rewards, const uint8_t* dones,
                       const uint8_t* bad_transition, const float* next_action_masks, void* stream) {
+  return orl_buffer_insert_rnn(buf, step, next_policy_obs, next_critic_obs, rewards, dones, bad_transition,
+                               next_action_masks, nullptr, nullptr, 0, stream);
+}
+
+int orl_buffer_insert_rnn(const orl_buffer_ptrs* buf, int step, const float* next_policy_obs,
+                          const float* next_critic_obs, const float* rewards, const uint8_t* dones,
+                          const uint8_t* bad_transition, const float* next_action_masks, float* h_policy_next,
+                          float* h_critic_next, int hidden, void* stream) {
   ORL_REQUIRE(buf && next_policy_obs && next_critic_obs && rewards && dones, "orl_buffer_insert: null pointer");
+  ORL_REQUIRE(!h_policy_next || hidden > 0, "orl_buffer_insert_rnn: hidden size %d", hidden);
+  ORL_REQUIRE(h_policy_next || !h_critic_next, "orl_buffer_insert_rnn: critic states without policy states");
   ORL_REQUIRE(step >= 0 && step < buf->T, "orl_buffer_insert: step %d outside [0,%d)", step, buf->T);
   ORL_REQUIRE(buf->policy_obs && buf->critic_obs && buf->rewards && buf->masks && buf->bad_masks && buf->active_masks,
               "orl_buffer_insert: null buffer array");
-  const long long work = (long long)buf->N * buf->A * (buf->Dp > buf->Dc ? buf->Dp : buf->Dc);
+  int wmax = buf->Dp > buf->Dc ? buf->Dp : buf->Dc;
+  if (h_policy_next && hidden > wmax) wmax = hidden;
+  const long long work = (long long)buf->N * buf->A * wmax;
   int grid = (int)((work + 255) / 256);
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(buffer_insert_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *buf, step,
-                     next_policy_obs, next_critic_obs, rewards, dones, bad_transition, next_action_masks);
+                     next_policy_obs, next_critic_obs, rewards, dones, bad_transition, next_action_masks,
+                     h_policy_next, h_critic_next, hidden);
   return launch_status("orl_buffer_insert");
 }
 

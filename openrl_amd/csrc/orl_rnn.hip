@@ -821,8 +821,8 @@ __global__ __launch_bounds__(256) void rnn_adam_kernel(RnnApplyTower P, RnnApply
     if (hp.use_max_grad_norm) coef = fminf(hp.max_grad_norm / (total + 1e-6f), 1.f);
     const double b1d = 0.9, b2d = 0.999;
     const float b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
-    const double bc1 = 1.0 - pow(b1d, (double)W.ad.step);
-    const double bc2 = 1.0 - pow(b2d, (double)W.ad.step);
+    const double bc1 = 1.0 - powi_d(b1d, (long long)W.ad.step);
+    const double bc2 = 1.0 - powi_d(b2d, (long long)W.ad.step);
     const float step_size = (float)((double)W.ad.lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -858,35 +858,43 @@ __global__ __launch_bounds__(256) void rnn_adam_kernel(RnnApplyTower P, RnnApply
 }
 
 // column sums of two partial regions in one launch (fixed order => deterministic), each to its own output
-__global__ __launch_bounds__(256) void rnn_reduce_pair_kernel(const float* __restrict__ pa, int nb_a, int wa, int ga,
-                                                              float* __restrict__ oa, const float* __restrict__ pb,
-                                                              int nb_b, int wb, float* __restrict__ ob) {
-  __shared__ float sh[4][64];
+__global__ __launch_bounds__(1024) void rnn_reduce_pair_kernel(const float* __restrict__ pa, int nb_a, int wa, int ga,
+                                                               float* __restrict__ oa, const float* __restrict__ pb,
+                                                               int nb_b, int wb, float* __restrict__ ob) {
+  // 64 columns x 16 row groups per workgroup (same shape as ppo_reduce_pair_kernel, orl_apply.hip)
+  __shared__ float sh[16][64];
   const bool first = (int)blockIdx.x < ga;
   const float* partials = first ? pa : pb;
   const int n_blocks = first ? nb_a : nb_b, width = first ? wa : wb;
   float* out = first ? oa : ob;
-  const int col = (first ? blockIdx.x : blockIdx.x - ga) * 64 + (threadIdx.x & 63);
+  const int lc = threadIdx.x & 63;
+  const int col = (first ? blockIdx.x : blockIdx.x - ga) * 64 + lc;
   const int rg = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (col < width) {
     int b = rg;
-    for (; b + 4 < n_blocks; b += 8) {
+    for (; b + 48 < n_blocks; b += 64) {
       s0 += partials[(size_t)b * width + col];
-      s1 += partials[(size_t)(b + 4) * width + col];
+      s1 += partials[(size_t)(b + 16) * width + col];
+      s2 += partials[(size_t)(b + 32) * width + col];
+      s3 += partials[(size_t)(b + 48) * width + col];
     }
-    if (b < n_blocks) s0 += partials[(size_t)b * width + col];
+    for (; b < n_blocks; b += 16) s0 += partials[(size_t)b * width + col];
   }
-  sh[rg][threadIdx.x & 63] = s0 + s1;
+  sh[rg][lc] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (rg == 0 && col < width)
-    out[col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  if (rg == 0 && col < width) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (sh[4 * k][lc] + sh[4 * k + 1][lc]) + (sh[4 * k + 2][lc] + sh[4 * k + 3][lc]);
+    out[col] = (t[0] + t[1]) + (t[2] + t[3]);
+  }
 }
 
 static int orl_ppo_reduce_pair2(const float* pa, int nb_a, int wa, float* oa, const float* pb, int nb_b, int wb,
                                 float* ob, hipStream_t s) {
   const int ga = (wa + 63) / 64, gb = (wb + 63) / 64;
-  hipLaunchKernelGGL(rnn_reduce_pair_kernel, dim3(ga + gb), dim3(256), 0, s, pa, nb_a, wa, ga, oa, pb, nb_b, wb, ob);
+  hipLaunchKernelGGL(rnn_reduce_pair_kernel, dim3(ga + gb), dim3(1024), 0, s, pa, nb_a, wa, ga, oa, pb, nb_b, wb, ob);
   return launch_status("orl_rnn_ppo_fwd_bwd(reduce)");
 }
 

@@ -262,13 +262,11 @@ class OnPolicyDriver:
                             for i in infos], dtype=np.uint8)
             bad = self._as_dev(bad, torch.uint8)
         amask = prepare_action_masks(infos, self.num_agents)
+        rec = d.rnn_states.stride(0) != 0  # recurrent: rnn_states[dones_env] = 0, folded into the insert launch
         ops.buffer_insert(d.buffer_ptrs(), step, p_obs, c_obs, self._as_dev(data["rewards"]),
                           self._as_dev(data["dones"], torch.uint8), bad,
-                          None if amask is None else self._as_dev(amask))
-        if d.rnn_states.stride(0) != 0:  # recurrent: rnn_states[dones_env] = 0 (masks[step+1] is 0 exactly there)
-            m = d.masks[step + 1].unsqueeze(-1)
-            d.rnn_states[step + 1].mul_(m)
-            d.rnn_states_critic[step + 1].mul_(m)
+                          None if amask is None else self._as_dev(amask),
+                          d.rnn_states[step + 1] if rec else None, d.rnn_states_critic[step + 1] if rec else None)
         d.step = (step + 1) % d.episode_length
         d._adv_fresh = False
 

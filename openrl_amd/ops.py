@@ -96,12 +96,19 @@ def adv_normalize_pack(adv, stat_partials, n_partials: int, T: int, L: int, use_
 
 # ------------------------------------------------------------------------------------------------ K5 / K8
 def buffer_insert(buf: BufferPtrs, step: int, next_policy_obs, next_critic_obs, rewards, dones, bad_transition=None,
-                  next_action_masks=None) -> None:
+                  next_action_masks=None, h_policy_next=None, h_critic_next=None) -> None:
+    """``h_*_next`` (recurrent): rnn_states[step+1] views, multiplied in place by masks[step+1] in the same launch."""
     dev = _dev(rewards)
     if dones.dtype != torch.uint8:
         raise nat.NativeError("dones must be uint8")
-    rc = _lib().orl_buffer_insert(C.byref(buf), step, fptr(next_policy_obs), fptr(next_critic_obs), fptr(rewards),
-                                  ptr(dones), ptr(bad_transition), fptr(next_action_masks), stream_ptr(dev))
+    if h_policy_next is None:
+        rc = _lib().orl_buffer_insert(C.byref(buf), step, fptr(next_policy_obs), fptr(next_critic_obs), fptr(rewards),
+                                      ptr(dones), ptr(bad_transition), fptr(next_action_masks), stream_ptr(dev))
+    else:
+        rc = _lib().orl_buffer_insert_rnn(C.byref(buf), step, fptr(next_policy_obs), fptr(next_critic_obs),
+                                          fptr(rewards), ptr(dones), ptr(bad_transition), fptr(next_action_masks),
+                                          fptr(h_policy_next), fptr(h_critic_next), int(h_policy_next.shape[-1]),
+                                          stream_ptr(dev))
     nat.check(rc, "orl_buffer_insert")
 
 
