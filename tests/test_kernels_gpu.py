@@ -63,7 +63,8 @@ def test_gae_known_answer_vector(ops):
         assert np.array_equal(ret.cpu().numpy(), g["kat_proper%d_returns" % proper])
 
 
-@pytest.mark.parametrize("T,L", [(1, 1), (37, 70), (128, 4096)])
+# T > 128 crosses the kernel's LDS time-chunk boundary (configs 3 and 5 roll out 200 steps); L not a multiple of 16
+@pytest.mark.parametrize("T,L", [(1, 1), (37, 70), (128, 4096), (200, 1024), (129, 17), (300, 33)])
 def test_gae_ragged_and_full_size(ops, T, L):
     rs = np.random.RandomState(T * 1000 + L)
     rewards = rs.randn(T, L, 1, 1).astype(np.float32)
@@ -77,12 +78,38 @@ def test_gae_ragged_and_full_size(ops, T, L):
     assert np.array_equal(d_vp.cpu().numpy(), want_vp)
 
 
+@pytest.mark.parametrize("use_gae", [True, False])
+@pytest.mark.parametrize("proper", [False, True])
+@pytest.mark.parametrize("use_vn", [False, True])
+def test_gae_long_rollout_all_variants(ops, use_gae, proper, use_vn):
+    """All four compute_returns variants across the 128-step LDS chunk boundary (T = 200, ragged lane count), against
+    the restatement that the golden vectors pin (tests/test_oracle_cpu.py)."""
+    T, L = 200, 50
+    rs = np.random.RandomState(77 + 2 * use_gae + proper)
+    rewards = rs.randn(T, L, 1, 1).astype(np.float32)
+    vp = rs.randn(T + 1, L, 1, 1).astype(np.float32)
+    masks = (rs.rand(T + 1, L, 1, 1) > 0.05).astype(np.float32)
+    bad = (rs.rand(T + 1, L, 1, 1) > 0.05).astype(np.float32)
+    nv = rs.randn(L, 1, 1).astype(np.float32)
+    vn = None
+    if use_vn:
+        vn = po.ValueNormOracle()
+        vn.set_state([0.3e-3, 2.5e-3, 1.2e-3])
+    want, want_vp = po.compute_returns(rewards, vp, masks, bad if proper else None, nv, 0.99, 0.95, use_gae, proper, vn)
+    d_vp, ret = dev(vp), torch.zeros(T + 1, L, 1, 1, device=DEV)
+    ops.gae_scan(dev(rewards), d_vp, dev(masks), dev(bad) if proper else None, dev(nv),
+                 dev(vn.state()) if use_vn else None, ret, 0.99, 0.95, use_gae, proper)
+    assert np.array_equal(ret.cpu().numpy(), want)
+    assert np.array_equal(d_vp.cpu().numpy(), want_vp)
+
+
 # --------------------------------------------------------------------------------------------- K7
+@pytest.mark.parametrize("T", [11, 150])
 @pytest.mark.parametrize("use_adv_norm", [False, True])
 @pytest.mark.parametrize("use_vn", [False, True])
-def test_advantage_normalisation_and_record_packing(ops, use_adv_norm, use_vn):
+def test_advantage_normalisation_and_record_packing(ops, use_adv_norm, use_vn, T):
     rs = np.random.RandomState(5)
-    T, N, A, Dp, Dc, K = 11, 13, 2, 3, 5, 4
+    N, A, Dp, Dc, K = 13, 2, 3, 5, 4
     L = N * A
     rewards = rs.randn(T, N, A, 1).astype(np.float32)
     vp = rs.randn(T + 1, N, A, 1).astype(np.float32)
