@@ -30,9 +30,11 @@ constexpr int TILE_B = 16; // batch rows per wave tile
 
 // LDS image of one tower (offsets in floats, all multiples of 4 => 16-byte aligned).
 struct TowerLds {
-  int DP, n_out, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, logstd, W2T, total;
+  int DP, n_out, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, logstd, W2T, W3P, total;
   __host__ __device__ TowerLds() {}
-  __host__ __device__ TowerLds(int D, int n_out_, bool gaussian, bool with_w2t) {
+  // with_w3p: a second image of W3, zero padded to 16 rows at the conflict-free stride W2S - the MFMA operand of the
+  // head GEMMs of wide heads (orl_ppo_tower.h, NO > 4)
+  __host__ __device__ TowerLds(int D, int n_out_, bool gaussian, bool with_w2t, bool with_w3p = false) {
     DP = (D + 3) & ~3;
     n_out = n_out_;
     const int no4 = (n_out + 3) & ~3;
@@ -49,6 +51,7 @@ struct TowerLds {
     b3 = o; o += no4;
     logstd = o; o += gaussian ? no4 : 0;
     W2T = o; o += with_w2t ? HID * W2S : 0;
+    W3P = o; o += with_w3p ? 16 * W2S : 0;
     total = o;
   }
 };
@@ -56,7 +59,13 @@ struct TowerLds {
 // Cooperative global -> LDS staging of a tower (any thread count).  W1 is zero padded to DP
 // columns, W2 re-strided to W2S, optionally also stored transposed (for the backward GEMM).
 __device__ inline void stage_tower(float* __restrict__ lds, const float* __restrict__ theta, const TowerLayout& tl,
-                                   const TowerLds& tw, bool with_w2t, int tid, int nthreads) {
+                                   const TowerLds& tw, bool with_w2t, int tid, int nthreads, bool with_w3p = false) {
+  if (with_w3p) {
+    for (int e = tid; e < 16 * W2S; e += nthreads) {
+      const int c = e / W2S, i = e - c * W2S;
+      lds[tw.W3P + e] = (c < tl.n_out && i < HID) ? theta[tl.oW3 + c * HID + i] : 0.f;
+    }
+  }
   const int D = tl.D;
   for (int e = tid; e < HID * tw.DP; e += nthreads) {
     const int f = e / tw.DP, k = e - f * tw.DP;

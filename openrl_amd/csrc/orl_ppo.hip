@@ -34,7 +34,7 @@ static int launch_tower_w(const PpoArgs& A, int waves, size_t lds, hipStream_t s
 // Launch one tower; returns the number of workgroups (> 0) or a negative error code.
 template <int HEAD, int NO, int ND>
 static int launch_tower(const PpoArgs& A, hipStream_t s) {
-  constexpr int NOP = (NO + 3) & ~3;
+  constexpr int NOP = NO > 4 ? 16 : ((NO + 3) & ~3);  // wide heads: 16-wide dhead tile + W3 MFMA image
   // as many waves per workgroup (8, 6, 4, 2) as fit the 160 KiB of LDS next to the tower's weights.
   // 12 waves (3 per SIMD, <= 168 VGPRs) fit the LDS budget too but were measured SLOWER on MI355X
   // (5.94 vs 5.21 ms per iteration): at 168 VGPRs hipcc spills 260 B per lane around the 64 wgrad

@@ -146,12 +146,15 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
   const RawLayout rl(A.net);
   // On the ND == 0 path the padded obs width is 4 and for NO <= 4 the padded head width is 4: every LDS
   // offset of the tower image becomes a compile-time constant (immediate offsets instead of address VGPRs).
-  const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, !PC);
-  stage_tower(smem, A.theta, tl, tw, !PC, threadIdx.x, blockDim.x);
+  // wide heads (NO > 4: Discrete(5..16), Box(5..16)) run their three head GEMMs - logits, dn2 = W3^T dhead,
+  // S3 += dhead^T xhat2 - on MFMA; with NO x 64 scalar FMAs per lane they were 2/3 of the tile and spilled 360 VGPRs
+  constexpr bool HMM = NO > 4;
+  const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, !PC, HMM);
+  stage_tower(smem, A.theta, tl, tw, !PC, threadIdx.x, blockDim.x, HMM);
   const int DP = tw.DP;
   const int D = A.net.obs_dim;
   const int n_out = A.net.n_out;
-  constexpr int NOP = (NO + 3) & ~3;
+  constexpr int NOP = HMM ? 16 : ((NO + 3) & ~3);  // width of the dhead tile in LDS
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
   const int nch = A.R >> 2;
   const int rts = ((nch + 3) >> 2) * 256;  // floats per record-ring slot
@@ -187,9 +190,13 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     for (int b = 0; b < NDA; ++b) G1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float w1v[4] = {0.f, 0.f, 0.f, 0.f};  // VALU dW1 (ND == 0): lane f, k = 0..3
   float a_db2 = 0.f, a_db1 = 0.f, a_db3 = 0.f, a_dls = 0.f;
-  float a_S3[NO];
+  constexpr int NS3 = HMM ? 1 : NO;
+  float a_S3[NS3];  // narrow heads: S3[c][f = lane] sums on the VALU
 #pragma unroll
-  for (int c = 0; c < NO; ++c) a_S3[c] = 0.f;
+  for (int c = 0; c < NS3; ++c) a_S3[c] = 0.f;
+  f32x4 S3acc[4];   // wide heads: MFMA tiles, lane (j, q) reg r -> S3[c = 4q+r][f = 16mi+j]
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) S3acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
   float st_active = 0.f, st_rows = 0.f, st_loss = 0.f, st_ent = 0.f, st_ratio = 0.f;
 
   // ValueNorm.normalize coefficients (valuenorm.py:79-91)
@@ -282,7 +289,30 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       ln_normalize_T(xh2, rstd2);
       store_slab_T(SS, xh2, j, q);  // parked in the scratch slab: read back in F layout (S3) and T layout (LN2')
       ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, z);  // z = n2
-      head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, z, q, hd);
+      if constexpr (HMM) {
+        // logits^T[16 c x 16 rows] = W3p[16 x 64] n2^T: 16 MFMAs; lane (j, q) gets logits 4q..4q+3 of row j, the tile
+        // goes through DH so that every lane of a row holds all of them (the loss below is written per row)
+        const int no4 = (n_out + 3) & ~3;
+        f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (4 * q < no4) hacc = *(const f32x4*)(lw + tw.b3 + 4 * q);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const f32x4 a4 = *(const f32x4*)(lw + tw.W3P + j * W2S + 16 * mi + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hacc = ORL_MFMA(a4[r], z[mi][r], hacc);
+        }
+        *(f32x4*)(DH + j * NOP + 4 * q) = hacc;
+        wave_lds_fence();
+#pragma unroll
+        for (int b = 0; b < NO / 4; ++b) {
+          const f32x4 v = *(const f32x4*)(DH + j * NOP + 4 * b);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hd[4 * b + r] = v[r];
+        }
+        wave_lds_fence();
+      } else {
+        head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, z, q, hd);
+      }
     }
 
     ORL_T(3);  // LN2, slab store, affine, head
@@ -423,10 +453,21 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     // S3 += dhead^T xhat2, db3 (F layout: lane = feature f); xhat2 comes from the scratch slab
     if (q == 0) {
 #pragma unroll
-      for (int c = 0; c < NO; ++c) DH[j * NOP + c] = dh[c];
+      for (int c = 0; c < NOP; ++c) DH[j * NOP + c] = c < NO ? dh[c < NO ? c : 0] : 0.f;
     }
     wave_lds_fence();
-    {
+    if constexpr (HMM) {
+      // K = 16 rows: A = dhead[row = 4s+q][c = j], B = xhat2[row = 4s+q][f = 16mi+j], both straight from LDS
+      float s_db3 = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float a = DH[(4 * s + q) * NOP + j];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) S3acc[mi] = ORL_MFMA(a, SS[(4 * s + q) * TS + 16 * mi + j], S3acc[mi]);
+      }
+      for (int r = 0; r < TILE_B; ++r) s_db3 += DH[r * NOP + (l & 15)];
+      a_db3 += s_db3;
+    } else {
       const int f = l;
       float s3[NO];
 #pragma unroll
@@ -439,7 +480,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
         s_db3 += DH[r * NOP + (f < NO ? f : 0)];
       }
 #pragma unroll
-      for (int c = 0; c < NO; ++c) a_S3[c] += s3[c];
+      for (int c = 0; c < NO; ++c) a_S3[c < NS3 ? c : 0] += s3[c];
       a_db3 += s_db3;
     }
     ORL_T(5);  // dhead store, S3 / db3 column sums
@@ -447,11 +488,21 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     f32x4 d2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) d2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (HMM) {
+      // dn2^T[64 f x 16 rows] = W3p^T[64 x 16 c] dhead^T: the dhead tile is this lane's B operand in T layout
+      const f32x4 dv = *(const f32x4*)(DH + j * NOP + 4 * q);
 #pragma unroll
-    for (int c = 0; c < NO; ++c) {
-      if (c < n_out) {
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) d2[m] += *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q) * dh[c];
+        for (int mo = 0; mo < 4; ++mo)
+          d2[mo] = ORL_MFMA(lw[tw.W3P + (4 * q + r) * W2S + 16 * mo + j], dv[r], d2[mo]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NO; ++c) {
+        if (c < n_out) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) d2[m] += *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q) * dh[c];
+        }
       }
     }
     {
@@ -628,9 +679,17 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       const int f = l;
       acc[rl.odb2 + f] += a_db2;  // PC: only consumers hold db2 / G, producers hold the rest (zeros otherwise)
       acc[rl.odb1 + f] += a_db1;
+      if constexpr (HMM) {
 #pragma unroll
-      for (int c = 0; c < NO; ++c)
-        if (c < n_out) acc[rl.oS3 + c * HID + f] += a_S3[c];
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * q + r < n_out) acc[rl.oS3 + (4 * q + r) * HID + 16 * mi + j] += S3acc[mi][r];
+      } else {
+#pragma unroll
+        for (int c = 0; c < NO; ++c)
+          if (c < n_out) acc[rl.oS3 + c * HID + f] += a_S3[c < NS3 ? c : 0];
+      }
       if (f < n_out) acc[rl.odb3 + f] += a_db3;
       if (HEAD == ORL_HEAD_GAUSSIAN && f < n_out) acc[rl.odlogstd + f] += a_dls;
       if (ND == 0) {
@@ -667,7 +726,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
 
 // LDS bytes needed by `waves` waves of this tower
 inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian, bool pc = false) {
-  const TowerLds tw(net.obs_dim, net.n_out, gaussian, !pc);
+  const TowerLds tw(net.obs_dim, net.n_out, gaussian, !pc, nop == 16);
   const RawLayout rl(net);
   const int rts = (((R >> 2) + 3) >> 2) * 256;
   const size_t per_wave = 2 * SLAB + 2 * rts + TILE_B * nop;
