@@ -36,12 +36,13 @@ template <int NO, int HEAD>
 __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const TowerLayout tlp(A.pnet);
-  const TowerLds twp(A.pnet.obs_dim, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false);
+  constexpr bool HMM = NO > 4;  // wide heads on MFMA (head_mfma_T): same logits in the rollout, act and update kernels
+  const TowerLds twp(A.pnet.obs_dim, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false, HMM);
   TowerLayout tlc;
   TowerLds twc;
   const bool has_c = A.ctheta != nullptr;
   const bool has_p = A.ptheta != nullptr;
-  if (has_p) stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x);
+  if (has_p) stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
   if (has_c) {
     tlc = TowerLayout(A.cnet);
     twc = TowerLds(A.cnet.obs_dim, 1, false, false);
@@ -63,7 +64,12 @@ __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
     f32x4 n2[4];
     trunk_fwd_T(smem, twp, xb, j, q, n2);
     float hd[NO];
-    head_T<NO>(smem + twp.W3, smem + twp.b3, A.pnet.n_out, n2, q, hd);
+    if constexpr (HMM) {
+      float* tile = smem + twp.total + (has_c ? TowerLds(A.cnet.obs_dim, 1, false, false).total : 0);  // [16][16]
+      head_mfma_T<NO>(smem + twp.W3P, smem + twp.b3, A.pnet.n_out, n2, tile, j, q, hd);
+    } else {
+      head_T<NO>(smem + twp.W3, smem + twp.b3, A.pnet.n_out, n2, q, hd);
+    }
     const int n_out = A.pnet.n_out;
     const int a_w = (HEAD == ORL_HEAD_CATEGORICAL) ? 1 : n_out;
     float act_o[NO], lp_o[NO];
@@ -251,14 +257,16 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   const int D = A.pnet.obs_dim;
   const int N = b.N, T = b.T;
   const TowerLayout tlp(A.pnet), tlc(A.cnet);
-  const TowerLds twp(D, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false);
+  constexpr bool HMM = NO > 4;  // wide heads on MFMA (head_mfma_T)
+  const TowerLds twp(D, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false, HMM);
   const TowerLds twc(D, 1, false, false);
-  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x);
+  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
   stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x);
   const int DP = twp.DP;
   float* s_obs = smem + twp.total + twc.total;  // [2][16][DP]
   float* s_gather = s_obs + 2 * TILE_B * DP;    // [2 towers][2 slabs][16][GS]
   float* s_noise = s_gather + 4 * TILE_B * GS;  // [2][16][16]: sampling noise of steps t (parity) drawn one step ahead
+  float* s_logits = s_noise + 2 * TILE_B * 16;  // [16][16] logits tile of head_mfma_T (wide heads only)
 
   // waves 0-3: policy tower (wave 0 also samples and steps the env); waves 4-7: critic tower
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
@@ -331,7 +339,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     float act_o[NO];
     if (wave == 0) {
       float hd[NO], lp_o[NO];
-      head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);
+      if constexpr (HMM) head_mfma_T<NO>(smem + twp.W3P, smem + twp.b3, n_out, n2, s_logits, j, q, hd);
+      else head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);
       // the built-in device envs never mask actions (their action_masks rows stay all-ones), so the mask is
       // not re-read from HBM on the per-step critical path
       sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, nullptr, s_noise + (t & 1) * TILE_B * 16 + j * 16, 0,
@@ -659,13 +668,15 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
   ORL_REQUIRE(ptheta || ctheta, "orl_act_step: neither tower given");
   if (ptheta) ORL_REQUIRE(policy_obs && actions && logp, "orl_act_step: null policy pointer");
   ORL_REQUIRE(B > 0, "orl_act_step: B=%d", B);
-  size_t lds = TowerLds(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false).total;
+  const bool wide = pnet->n_out > 2;  // = the NO > 4 instantiations of ORL_DISPATCH_HEAD: padded W3 image + logits tile
+  size_t lds = TowerLds(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false, wide).total;
   if (ctheta) {
     rc = check_net(cnet, "orl_act_step(critic)", true);
     if (rc) return rc;
     ORL_REQUIRE(critic_obs && values, "orl_act_step: critic given without critic_obs/values");
     lds += TowerLds(cnet->obs_dim, 1, false, false).total;
   }
+  if (wide) lds += TILE_B * 16;
   lds *= sizeof(float);
   ORL_REQUIRE(lds <= 160 * 1024, "orl_act_step: towers need %zu B of LDS (> 160 KiB)", lds);
   ActArgs A;
@@ -798,9 +809,9 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   if (args->env_kind == ORL_ENV_CARTPOLE)
     ORL_REQUIRE(pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 2 && b.Dp == 4,
                 "orl_rollout_fused: CartPole needs Discrete(2) and 4-d obs");
-  const TowerLds twp(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false);
+  const TowerLds twp(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false, pnet->n_out > 2);
   const TowerLds twc(cnet->obs_dim, 1, false, false);
-  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 2 * TILE_B * 16) * sizeof(float);
+  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 3 * TILE_B * 16) * sizeof(float);
   ORL_REQUIRE(lds <= 160 * 1024, "orl_rollout_fused: needs %zu B of LDS", lds);
   RolloutArgs A;
   A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.r = *args; A.next_value = next_value;

@@ -192,6 +192,40 @@ __device__ inline void head_T(const float* __restrict__ W3s, const float* __rest
   }
 }
 
+// LDS operations of one wave execute in issue order, so a later ds_read observes an earlier ds_write of
+// ANY lane of the same wave; only the compiler has to be kept from reordering across this point (it still
+// inserts the lgkmcnt wait before a read's first use).
+__device__ inline void wave_lds_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Wide heads (5..16 outputs) on MFMA: logits^T[16 c x 16 rows] = W3p[16 x 64] n2^T in 16 MFMAs, where W3p is the
+// zero-padded [16][W2S] image TowerLds::W3P.  Lane (j, q) receives logits 4q..4q+3 of row j; the tile takes one trip
+// through a wave-private [16][16] LDS scratch so that every lane of a row ends up with all of them, as head_T does.
+template <int NO>
+__device__ inline void head_mfma_T(const float* __restrict__ W3p, const float* __restrict__ b3s, int n_out,
+                                   const f32x4 (&n2)[4], float* __restrict__ tile, int j, int q, float (&out)[NO]) {
+  const int no4 = (n_out + 3) & ~3;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (4 * q < no4) acc = *(const f32x4*)(b3s + 4 * q);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const f32x4 a4 = *(const f32x4*)(W3p + j * W2S + 16 * mi + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = ORL_MFMA(a4[r], n2[mi][r], acc);
+  }
+  *(f32x4*)(tile + j * 16 + 4 * q) = acc;
+  wave_lds_fence();
+#pragma unroll
+  for (int b = 0; b < NO / 4; ++b) {
+    const f32x4 v = *(const f32x4*)(tile + j * 16 + 4 * b);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[4 * b + r] = v[r];
+  }
+  wave_lds_fence();
+}
+
 // Whole trunk forward for one tile: returns n2 (post-LN2 activations) in T layout.
 template <class XB>
 __device__ inline void trunk_fwd_T(const float* __restrict__ lds, const TowerLds& tw, XB xb, int j, int q,

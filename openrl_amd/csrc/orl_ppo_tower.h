@@ -88,14 +88,6 @@ __device__ inline void load_slab_T(const float* __restrict__ slab, f32x4 (&x)[4]
   for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(slab + j * TS + 16 * m + 4 * q);
 }
 
-// LDS operations of one wave execute in issue order, so a later ds_read observes an earlier ds_write of
-// ANY lane of the same wave; only the compiler has to be kept from reordering across this point (it still
-// inserts the lgkmcnt wait before a read's first use).
-__device__ inline void wave_lds_fence() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // LayerNorm backward in T layout, in place: d <- rstd * (d*g - mean(d*g) - xhat * mean(d*g*xhat))
 __device__ inline void ln_bwd_T(f32x4 (&d)[4], const f32x4 (&xhat)[4], const float* __restrict__ g, float rstd,
                                 int q) {
@@ -290,26 +282,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       store_slab_T(SS, xh2, j, q);  // parked in the scratch slab: read back in F layout (S3) and T layout (LN2')
       ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, z);  // z = n2
       if constexpr (HMM) {
-        // logits^T[16 c x 16 rows] = W3p[16 x 64] n2^T: 16 MFMAs; lane (j, q) gets logits 4q..4q+3 of row j, the tile
-        // goes through DH so that every lane of a row holds all of them (the loss below is written per row)
-        const int no4 = (n_out + 3) & ~3;
-        f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (4 * q < no4) hacc = *(const f32x4*)(lw + tw.b3 + 4 * q);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const f32x4 a4 = *(const f32x4*)(lw + tw.W3P + j * W2S + 16 * mi + 4 * q);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) hacc = ORL_MFMA(a4[r], z[mi][r], hacc);
-        }
-        *(f32x4*)(DH + j * NOP + 4 * q) = hacc;
-        wave_lds_fence();
-#pragma unroll
-        for (int b = 0; b < NO / 4; ++b) {
-          const f32x4 v = *(const f32x4*)(DH + j * NOP + 4 * b);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) hd[4 * b + r] = v[r];
-        }
-        wave_lds_fence();
+        head_mfma_T<NO>(lw + tw.W3P, lw + tw.b3, n_out, z, DH, j, q, hd);  // NOP == 16: DH is the [16][16] scratch tile
       } else {
         head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, z, q, hd);
       }
