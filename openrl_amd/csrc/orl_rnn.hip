@@ -738,41 +738,33 @@ struct RnnApplyTower {
   const float* raw;  // reduced raw sums of this tower, followed by the ORL_N_STATS stats
 };
 
+// Parameters whose gradient is a single raw sum or a two-term product.  The six LayerNorm-affine vectors
+// (g1 be1 g2 be2 g3 be3) are 64-/192-/n_out-term dot products over the raw sums and are computed by the dedicated
+// "dot" workgroups of rnn_grad_kernel; this function is never called for them.
+__device__ inline bool rnn_is_dot_param(const RnnLayout& tl, int p) {
+  return (p >= tl.og1 && p < tl.oW2) || (p >= tl.og2 && p < tl.oWih) || (p >= tl.og3 && p < tl.oW3);
+}
+
 __device__ inline float rnn_raw_to_grad(const float* __restrict__ raw, const float* __restrict__ th, const RnnLayout& tl,
                                         const RnnRaw& rl, int p, float inv_den) {
   const int H = HID;
   float g = 0.f;
   if (p < tl.ob1) g = raw[rl.oP1 + (p - tl.oW1)];
   else if (p < tl.og1) g = raw[rl.odb1 + (p - tl.ob1)];
-  else if (p < tl.obe1) {
-    const int i = p - tl.og1;
-    for (int o = 0; o < H; ++o) g += th[tl.oW2 + o * H + i] * raw[rl.oS2 + o * H + i];
-  } else if (p < tl.oW2) {
-    const int i = p - tl.obe1;
-    for (int o = 0; o < H; ++o) g += th[tl.oW2 + o * H + i] * raw[rl.odb2 + o];
-  } else if (p < tl.ob2) {
+  else if (p < tl.oW2) g = 0.f;  // g1, be1: dot workgroups
+  else if (p < tl.ob2) {
     const int e = p - tl.oW2, o = e / H, i = e - o * H;
     g = th[tl.og1 + i] * raw[rl.oS2 + e] + th[tl.obe1 + i] * raw[rl.odb2 + o];
   } else if (p < tl.og2) g = raw[rl.odb2 + (p - tl.ob2)];
-  else if (p < tl.obe2) {
-    const int f = p - tl.og2;
-    for (int o = 0; o < 3 * H; ++o) g += th[tl.oWih + o * H + f] * raw[rl.oS3 + o * H + f];
-  } else if (p < tl.oWih) {
-    const int f = p - tl.obe2;
-    for (int o = 0; o < 3 * H; ++o) g += th[tl.oWih + o * H + f] * raw[rl.odbih + o];
-  } else if (p < tl.oWhh) {
+  else if (p < tl.oWih) g = 0.f;  // g2, be2
+  else if (p < tl.oWhh) {
     const int e = p - tl.oWih, o = e / H, f = e - o * H;
     g = th[tl.og2 + f] * raw[rl.oS3 + e] + th[tl.obe2 + f] * raw[rl.odbih + o];
   } else if (p < tl.obih) g = raw[rl.oP4 + (p - tl.oWhh)];
   else if (p < tl.obhh) g = raw[rl.odbih + (p - tl.obih)];
   else if (p < tl.og3) g = raw[rl.odbhh + (p - tl.obhh)];
-  else if (p < tl.obe3) {
-    const int f = p - tl.og3;
-    for (int cc = 0; cc < tl.n_out; ++cc) g += th[tl.oW3 + cc * H + f] * raw[rl.oS5 + cc * H + f];
-  } else if (p < tl.oW3) {
-    const int f = p - tl.obe3;
-    for (int cc = 0; cc < tl.n_out; ++cc) g += th[tl.oW3 + cc * H + f] * raw[rl.odb3 + cc];
-  } else if (p < tl.ob3) {
+  else if (p < tl.oW3) g = 0.f;  // g3, be3
+  else if (p < tl.ob3) {
     const int e = p - tl.oW3, cc = e / H, f = e - cc * H;
     g = th[tl.og3 + f] * raw[rl.oS5 + e] + th[tl.obe3 + f] * raw[rl.odb3 + cc];
   } else if (p < tl.ologstd) g = raw[rl.odb3 + (p - tl.ob3)];
@@ -780,26 +772,62 @@ __device__ inline float rnn_raw_to_grad(const float* __restrict__ raw, const flo
   return g * inv_den;
 }
 
-// blockIdx.y = tower (0 policy, 1 critic); grad[p] and per-block sums of squares -> scratch[tower*256 + block]
+// blockIdx.y = tower (0 policy, 1 critic); grad[p] and per-block sums of squares -> scratch[tower*256 + block].
+// Workgroups [0, nbm) take one parameter per thread; workgroups nbm + e, e = 0..5, are the "dot" workgroups of the
+// LayerNorm-affine vectors g1 be1 g2 be2 g3 be3: lane f owns element f, the 4 waves split the reduction index (up to
+// 192 terms, coalesced rows of W and of the raw sums) and combine through LDS - as one thread per element these loops
+// were the critical path of the launch (18 us).  Their sums of squares go to scratch[tower*256 + nb_tower + e].
 __global__ __launch_bounds__(256) void rnn_grad_kernel(RnnApplyTower P, RnnApplyTower Cc, orl_ppo_hparams hp,
-                                                       float* __restrict__ scratch) {
-  __shared__ float sh[4];
-  const RnnApplyTower& W = blockIdx.y == 0 ? P : Cc;
+                                                       float* __restrict__ scratch, int nbm, int nb_p, int nb_c) {
+  __shared__ float sh[4][64];
+  const int t = blockIdx.y;
+  const RnnApplyTower& W = t == 0 ? P : Cc;
   const RnnLayout tl(W.net);
   const RnnRaw rl(W.net);
   const float* stv = W.raw + rl.total;
-  const bool use_active = blockIdx.y == 0 ? hp.use_policy_active_masks : hp.use_value_active_masks;
+  const bool use_active = t == 0 ? hp.use_policy_active_masks : hp.use_value_active_masks;
   const float inv_den = 1.0f / (use_active ? stv[ST_ACTIVE_SUM] : stv[ST_ROWS]);
+  const bool off = t == 0 && (hp.reserved & 1);
+  const int nb_t = t == 0 ? nb_p : nb_c;
+  if ((int)blockIdx.x >= nbm) {
+    const int e = (int)blockIdx.x - nbm, w = threadIdx.x >> 6, f = threadIdx.x & 63;
+    const int p0 = e == 0 ? tl.og1 : e == 1 ? tl.obe1 : e == 2 ? tl.og2 : e == 3 ? tl.obe2 : e == 4 ? tl.og3 : tl.obe3;
+    const int th0 = e < 2 ? tl.oW2 : e < 4 ? tl.oWih : tl.oW3;
+    const int len = e < 2 ? HID : e < 4 ? 3 * HID : tl.n_out;
+    const int mat = e == 0 ? rl.oS2 : e == 2 ? rl.oS3 : rl.oS5;          // even e: elementwise against a raw matrix
+    const int vec = e == 1 ? rl.odb2 : e == 3 ? rl.odbih : rl.odb3;      // odd e : against a raw bias-sum vector
+    const float* th = W.ad.theta;
+    float s = 0.f;
+    if (!off) {
+      if (e & 1) {
+#pragma unroll 4
+        for (int o = w; o < len; o += 4) s += th[th0 + o * HID + f] * W.raw[vec + o];
+      } else {
+#pragma unroll 4
+        for (int o = w; o < len; o += 4) s += th[th0 + o * HID + f] * W.raw[mat + o * HID + f];
+      }
+    }
+    sh[w][f] = s;
+    __syncthreads();
+    if (w == 0) {
+      const float g = ((sh[0][f] + sh[1][f]) + (sh[2][f] + sh[3][f])) * inv_den;
+      W.ad.grad[p0 + f] = g;
+      const float ss = wave_sum(g * g);
+      if (f == 0) scratch[t * 256 + nb_t + e] = ss;
+    }
+    return;
+  }
+  if ((int)blockIdx.x >= nb_t) return;  // padding workgroups of the smaller tower
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   float g = 0.f;
-  if (p < tl.total) {
-    if (!(blockIdx.y == 0 && (hp.reserved & 1))) g = rnn_raw_to_grad(W.raw, W.ad.theta, tl, rl, p, inv_den);
+  if (p < tl.total && !rnn_is_dot_param(tl, p)) {
+    if (!off) g = rnn_raw_to_grad(W.raw, W.ad.theta, tl, rl, p, inv_den);
     W.ad.grad[p] = g;
   }
   float ss = wave_sum(g * g);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+  if ((threadIdx.x & 63) == 0) sh[0][threadIdx.x >> 6] = ss;
   __syncthreads();
-  if (threadIdx.x == 0) scratch[blockIdx.y * 256 + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (threadIdx.x == 0) scratch[t * 256 + blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
 }
 
 __global__ __launch_bounds__(256) void rnn_adam_kernel(RnnApplyTower P, RnnApplyTower Cc, orl_ppo_hparams hp,
@@ -813,7 +841,7 @@ __global__ __launch_bounds__(256) void rnn_adam_kernel(RnnApplyTower P, RnnApply
   const int nb = t == 0 ? nb_p : nb_c;
   if ((int)blockIdx.x >= nb) return;
   float ss = 0.f;
-  for (int b = 0; b < nb; ++b) ss += scratch[t * 256 + b];  // same order in every block: identical norm
+  for (int b = 0; b < nb + 6; ++b) ss += scratch[t * 256 + b];  // same order in every block: identical norm (+6 dot groups)
   const float total = sqrtf(ss);
   const bool off = t == 0 && (hp.reserved & 1);  // turn_on == False: no policy step (ppo.py:226-236)
   if (!off) {
@@ -1127,10 +1155,10 @@ int orl_rnn_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const 
   P.net = *pnet; P.ad = *padam; P.raw = sums;
   Cc.net = *cnet; Cc.ad = *cadam; Cc.raw = sums + RnnRaw(*pnet).total + ORL_N_STATS;
   const int nb_p = (RnnLayout(*pnet).total + 255) / 256, nb_c = (RnnLayout(*cnet).total + 255) / 256;
-  ORL_REQUIRE(nb_p <= 256 && nb_c <= 256, "orl_rnn_ppo_apply: tower too large");
+  ORL_REQUIRE(nb_p + 6 <= 256 && nb_c + 6 <= 256, "orl_rnn_ppo_apply: tower too large");
   const int nb = nb_p > nb_c ? nb_p : nb_c;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(rnn_grad_kernel, dim3(nb, 2), dim3(256), 0, s, P, Cc, *hp, scratch);
+  hipLaunchKernelGGL(rnn_grad_kernel, dim3(nb + 6, 2), dim3(256), 0, s, P, Cc, *hp, scratch, nb, nb_p, nb_c);
   hipLaunchKernelGGL(rnn_adam_kernel, dim3(nb, 2), dim3(256), 0, s, P, Cc, *hp, scratch, nb_p, nb_c,
                      train_info_accum);
   return launch_status("orl_rnn_ppo_apply");
