@@ -47,7 +47,7 @@ struct TowerLds {
     b2 = o; o += HID;
     g2 = o; o += HID;
     be2 = o; o += HID;
-    W3 = o; o += no4 * HID;
+    W3 = o; o += with_w3p ? 0 : no4 * HID;  // wide heads read the padded image W3P only
     b3 = o; o += no4;
     logstd = o; o += gaussian ? no4 : 0;
     W2T = o; o += with_w2t ? HID * W2S : 0;
@@ -86,7 +86,8 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
     if (with_w2t) lds[tw.W2T + i * W2S + o] = w;
   }
   const int no4 = (tl.n_out + 3) & ~3;
-  for (int e = tid; e < no4 * HID; e += nthreads) lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] : 0.f;
+  if (!with_w3p)
+    for (int e = tid; e < no4 * HID; e += nthreads) lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] : 0.f;
   for (int e = tid; e < no4; e += nthreads) {
     lds[tw.b3 + e] = (e < tl.n_out) ? theta[tl.ob3 + e] : 0.f;
     if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = (e < tl.n_out) ? theta[tl.ologstd + e] : 0.f;

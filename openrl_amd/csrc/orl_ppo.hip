@@ -74,11 +74,16 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
   for (int k = 0; k < 4; ++k) {
     const int waves = kWaves[k];
     if (waves > max_waves) continue;
-    const size_t lds = tower_lds_floats(A.net, A.R, NOP, waves, HEAD == ORL_HEAD_GAUSSIAN) * sizeof(float);
-    if (lds > 160 * 1024) continue;
-    const int grid = launch_tower_w<HEAD, NO, ND, 2, false>(A, waves, lds, s);
-    const int rc = launch_status("orl_ppo_fwd_bwd");
-    return rc ? -1000 - rc : grid;
+    // the transposed W2 copy (17 KB, +2 % on the dgrad GEMM) is the first thing to go when it would cost a pair of waves
+    for (int w2t = 1; w2t >= (ND == 0 ? 1 : 0); --w2t) {
+      const size_t lds = tower_lds_floats(A.net, A.R, NOP, waves, HEAD == ORL_HEAD_GAUSSIAN, false, w2t != 0) * sizeof(float);
+      if (lds > 160 * 1024) continue;
+      PpoArgs B = A;
+      B.use_w2t = w2t;
+      const int grid = launch_tower_w<HEAD, NO, ND, 2, false>(B, waves, lds, s);
+      const int rc = launch_status("orl_ppo_fwd_bwd");
+      return rc ? -1000 - rc : grid;
+    }
   }
   fail(ORL_E_UNSUPPORTED, "orl_ppo_fwd_bwd: tower (obs %d, record %d floats) does not fit 160 KiB of LDS", A.net.obs_dim,
        A.R);
@@ -132,7 +137,7 @@ int orl_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net
   PpoArgs A;
   A.records = records; A.idx = idx; A.vn_state = vn_state; A.hp = *hp; A.R = rec_width;
   A.o_act = o_ac; A.o_lp = o_lp; A.o_adv = o_adv; A.o_vp = o_adv + 1; A.o_rt = o_adv + 2; A.o_am = o_adv + 3;
-  A.o_mk = o_adv + 4; A.a_w = a_w; A.mb = mb;
+  A.o_mk = o_adv + 4; A.a_w = a_w; A.mb = mb; A.use_w2t = 1;
   // action-mask width: categorical records always carry n_out mask floats (ReplayData keeps ones)
   A.K = pnet->head_kind == ORL_HEAD_CATEGORICAL ? pnet->n_out : 0;
   ORL_REQUIRE(orl_record_width(Dp, Dc, a_w, A.K) == rec_width, "orl_ppo_fwd_bwd: record width %d != %d", rec_width,

@@ -65,6 +65,7 @@ struct PpoArgs {
   int a_w;             // stored action width
   int K;               // action-mask width (0 = none)
   int mb;              // rows in this minibatch
+  int use_w2t;         // keep a transposed LDS copy of W2 for the dgrad GEMM (dropped when it costs a pair of waves)
 };
 
 __device__ inline float huber_or_mse(float e, float d, int use_huber, float& de) {
@@ -141,15 +142,18 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
   // wide heads (NO > 4: Discrete(5..16), Box(5..16)) run their three head GEMMs - logits, dn2 = W3^T dhead,
   // S3 += dhead^T xhat2 - on MFMA; with NO x 64 scalar FMAs per lane they were 2/3 of the tile and spilled 360 VGPRs
   constexpr bool HMM = NO > 4;
-  const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, !PC, HMM);
-  stage_tower(smem, A.theta, tl, tw, !PC, threadIdx.x, blockDim.x, HMM);
+  const bool w2t = !PC && (ND == 0 || A.use_w2t);  // compile-time true on the small-observation path
+  const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, w2t, HMM);
+  stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM);
   const int DP = tw.DP;
   const int D = A.net.obs_dim;
   const int n_out = A.net.n_out;
   constexpr int NOP = HMM ? 16 : ((NO + 3) & ~3);  // width of the dhead tile in LDS
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
   const int nch = A.R >> 2;
-  const int rts = ((nch + 3) >> 2) * 256;  // floats per record-ring slot
+  // floats per record-ring slot (chunk c of row r at c*64 + r*4); the small-observation path keeps the form that is
+  // visibly a multiple of 256 (measured: 1.2 % faster tower at config 2), wider records are sized exactly
+  const int rts = ND == 0 ? ((nch + 3) >> 2) * 256 : nch * 64;
   const int per_wave = 2 * SLAB + 2 * rts + TILE_B * NOP;
   constexpr int NPROD = 8;                         // producers per workgroup in PC mode
   const bool consumer = PC && wave >= NPROD;
@@ -522,8 +526,8 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       ORL_PRIO(1);
       // dgrad A operand: a transposed copy of W2 in LDS read by 16-byte rows (16 reads per 64 MFMA); reading W2 by
       // columns (64 four-byte reads, one per MFMA) made this the slowest phase of the tile: 5 100 vs 3 100 cycles
-      if (PC) mm64_T_wt(lw + tw.W2, dz2, d1, j, q);
-      else mm64_T(lw + tw.W2T, dz2, d1, j, q);
+      if (w2t) mm64_T(lw + tw.W2T, dz2, d1, j, q);
+      else mm64_T_wt(lw + tw.W2, dz2, d1, j, q);
       ORL_PRIO(0);
     }
     ORL_T(8);  // dgrad: 64 MFMA
@@ -698,10 +702,11 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
 }
 
 // LDS bytes needed by `waves` waves of this tower
-inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian, bool pc = false) {
-  const TowerLds tw(net.obs_dim, net.n_out, gaussian, !pc, nop == 16);
+inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian, bool pc = false,
+                               bool w2t = true) {
+  const TowerLds tw(net.obs_dim, net.n_out, gaussian, !pc && w2t, nop == 16);
   const RawLayout rl(net);
-  const int rts = (((R >> 2) + 3) >> 2) * 256;
+  const int rts = net.obs_dim <= 4 ? (((R >> 2) + 3) >> 2) * 256 : (R >> 2) * 64;  // >= what the kernel uses
   const size_t per_wave = 2 * SLAB + 2 * rts + TILE_B * nop;
   size_t fl = (size_t)tw.total + (size_t)(pc ? 8 : waves) * per_wave + (pc ? 16 : 0);
   const size_t need_acc = (size_t)tw.total + rl.total + ORL_N_STATS;
