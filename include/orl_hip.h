@@ -320,6 +320,11 @@ int orl_env_step(int env_kind, float* env_state, float* ep_stats, const float* a
                  float* obs, float* rewards, uint8_t* dones, int N, int obs_dim, uint64_t env_seed,
                  int episode_limit, uint64_t global_step, void* stream);
 
+/* V(obs) of `rows` stored observations [rows, obs_dim] in one persistent launch (PPOModule.get_values,
+ * ppo_module.py:140-147, for a whole rollout at once); the same per-row arithmetic as orl_act_step's critic. */
+int orl_critic_values(const orl_net_desc* cnet, const float* ctheta, const float* critic_obs, int64_t rows,
+                      float* values, void* stream);
+
 /* next_value [N] (optional): critic value of the observation in slot T, i.e. the bootstrap value
  * OnPolicyDriver.compute_returns feeds ReplayData.compute_returns (onpolicy_driver.py:205-233). */
 int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,

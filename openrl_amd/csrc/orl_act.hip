@@ -250,7 +250,11 @@ __device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const Tower
   RO_T(rp, 4);
 }
 
-template <int NO, int HEAD, int ENV>
+// WC = false: policy-only rollout with 4 waves (one per SIMD); the values of all T+1 slots are then computed by ONE
+// batched launch of critic_values_kernel over the stored observations - same parameters, same per-row arithmetic
+// (trunk_fwd_coop is bit-identical to trunk_fwd_T), but throughput-bound instead of sharing the SIMDs of a
+// latency-bound step loop with the policy.
+template <int NO, int HEAD, int ENV, bool WC>
 __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const orl_buffer_ptrs& b = A.r.buf;
@@ -261,9 +265,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   const TowerLds twp(D, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false, HMM);
   const TowerLds twc(D, 1, false, false);
   stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
-  stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x);
+  if (WC) stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x);
   const int DP = twp.DP;
-  float* s_obs = smem + twp.total + twc.total;  // [2][16][DP]
+  float* s_obs = smem + twp.total + (WC ? twc.total : 0);  // [2][16][DP]
   float* s_gather = s_obs + 2 * TILE_B * DP;    // [2 towers][2 slabs][16][GS]
   float* s_noise = s_gather + 4 * TILE_B * GS;  // [2][16][16]: sampling noise of steps t (parity) drawn one step ahead
   float* s_logits = s_noise + 2 * TILE_B * 16;  // [16][16] logits tile of head_mfma_T (wide heads only)
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
         for (int c = 0; c < b.K; ++c) b.action_masks[s1 * b.K + c] = 1.f;
       }
     }
-    if (wave == 4) {
+    if (WC && wave == 4) {
       const float* lc = smem + twp.total;
       float v[1];
       head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
 #endif
   // bootstrap value of the last observation (OnPolicyDriver.compute_returns, onpolicy_driver.py:205-233);
   // all waves walk the cooperative trunk once more (barriers), only the critic leader uses the result
-  if (A.next_value != nullptr) {
+  if (WC && A.next_value != nullptr) {
     const float* cur = s_obs + (T & 1) * TILE_B * DP;
     auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
     f32x4 n2[4];
@@ -461,6 +465,52 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
       if (k < SW) A.r.env_state[(size_t)n * SW + k] = est[k];
     A.r.ep_stats[n * 4 + 0] = ep_ret; A.r.ep_stats[n * 4 + 1] = ep_len;
     A.r.ep_stats[n * 4 + 2] = fin_ret; A.r.ep_stats[n * 4 + 3] = fin_cnt;
+  }
+}
+
+// V(obs) for a large batch of stored observations (all T+1 slots of a rollout in one launch): persistent workgroups
+// of 8 waves, the critic tower staged once per workgroup, one 16-row tile per wave and trip, the next tile's
+// observation fragments prefetched into registers.  Per-row arithmetic = act_step_kernel's critic wave (trunk_fwd_T).
+__global__ __launch_bounds__(512) void critic_values_kernel(orl_net_desc cnet, const float* __restrict__ ctheta,
+                                                            const float* __restrict__ obs, long long rows,
+                                                            float* __restrict__ values) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const TowerLayout tl(cnet);
+  const TowerLds tw(cnet.obs_dim, 1, false, false);
+  stage_tower(smem, ctheta, tl, tw, false, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int D = cnet.obs_dim, nk = tw.DP >> 2, nwv = blockDim.x >> 6;
+  const long long n_tiles = (rows + TILE_B - 1) / TILE_B;
+  const long long stride = (long long)gridDim.x * nwv;
+  float xr[16];
+  auto fetch = [&](long long tile) {
+    const long long row = tile * TILE_B + j;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int k = 4 * s + q;
+      xr[s] = (s < nk && tile < n_tiles && row < rows && k < D) ? obs[row * D + k] : 0.f;
+    }
+  };
+  long long tile = (long long)blockIdx.x * nwv + wave;
+  fetch(tile);
+  for (; tile < n_tiles; tile += stride) {
+    float xc[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xc[s] = xr[s];
+    fetch(tile + stride);
+    auto xb = [&](int s) -> float {
+      float v = xc[0];
+#pragma unroll
+      for (int t = 1; t < 16; ++t) v = (s == t) ? xc[t] : v;
+      return v;
+    };
+    f32x4 n2[4];
+    trunk_fwd_T(smem, tw, xb, j, q, n2);
+    float v[1];
+    head_T<1>(smem + tw.W3, smem + tw.b3, 1, n2, q, v);
+    const long long row = tile * TILE_B + j;
+    if (row < rows && q == 0) values[row] = v[0];
   }
 }
 
@@ -791,6 +841,22 @@ int orl_debug_rollout_prof(unsigned long long* out16) {
 }
 #endif
 
+int orl_critic_values(const orl_net_desc* cnet, const float* ctheta, const float* critic_obs, int64_t rows,
+                      float* values, void* stream) {
+  int rc = check_net(cnet, "orl_critic_values", true);
+  if (rc) return rc;
+  ORL_REQUIRE(ctheta && critic_obs && values && rows > 0, "orl_critic_values: bad arguments");
+  const size_t lds = (size_t)TowerLds(cnet->obs_dim, 1, false, false).total * sizeof(float);
+  const long long n_tiles = (rows + TILE_B - 1) / TILE_B;
+  int grid = (int)((n_tiles + 7) / 8);
+  if (grid > 512) grid = 512;  // two 8-wave workgroups per CU
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)critic_values_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(critic_values_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, *cnet, ctheta, critic_obs,
+                     (long long)rows, values);
+  return launch_status("orl_critic_values");
+}
+
 int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                       const orl_rollout_args* args, float* next_value, void* stream) {
   int rc = check_net(pnet, "orl_rollout_fused(policy)", false);
@@ -811,17 +877,26 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
                 "orl_rollout_fused: CartPole needs Discrete(2) and 4-d obs");
   const TowerLds twp(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false, pnet->n_out > 2);
   const TowerLds twc(cnet->obs_dim, 1, false, false);
-  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 3 * TILE_B * 16) * sizeof(float);
+  // ORL_ROLLOUT_SPLIT=1 (A/B knob): policy-only step loop + one batched orl_critic_values launch over all T+1 slots.
+  // Measured at config 2: the step loop drops only 271 -> 237 us (the policy's own latency chain is the step), the
+  // value launch costs 60 us - so the critic stays inside the loop by default.
+  static const bool split = getenv("ORL_ROLLOUT_SPLIT") != nullptr;
+  const size_t lds = (size_t)(twp.total + (split ? 0 : twc.total) + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 3 * TILE_B * 16) * sizeof(float);
   ORL_REQUIRE(lds <= 160 * 1024, "orl_rollout_fused: needs %zu B of LDS", lds);
   RolloutArgs A;
   A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.r = *args; A.next_value = next_value;
   const int grid = (b.N + TILE_B - 1) / TILE_B;
-#define ORL_RO_LAUNCH2(NO, HD, EV)                                                                                  \
+#define ORL_RO_LAUNCH3(NO, HD, EV, WC, THREADS)                                                                      \
   do {                                                                                                              \
     if (lds > 48 * 1024)                                                                                            \
-      (void)hipFuncSetAttribute((const void*)rollout_kernel<NO, HD, EV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                          \
-    hipLaunchKernelGGL((rollout_kernel<NO, HD, EV>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A);          \
+      (void)hipFuncSetAttribute((const void*)rollout_kernel<NO, HD, EV, WC>,                                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+    hipLaunchKernelGGL((rollout_kernel<NO, HD, EV, WC>), dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, A);   \
+  } while (0)
+#define ORL_RO_LAUNCH2(NO, HD, EV)                                                                                  \
+  do {                                                                                                              \
+    if (split) ORL_RO_LAUNCH3(NO, HD, EV, false, 256);                                                              \
+    else ORL_RO_LAUNCH3(NO, HD, EV, true, 512);                                                                     \
   } while (0)
   if (args->env_kind == ORL_ENV_SYNTH) {
 #define ORL_RO_LAUNCH(NO, HD) ORL_RO_LAUNCH2(NO, HD, ORL_ENV_SYNTH)
@@ -833,7 +908,16 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
     return fail(ORL_E_INVALID, "orl_rollout_fused: unknown env kind %d", args->env_kind);
   }
 #undef ORL_RO_LAUNCH2
-  return launch_status("orl_rollout_fused");
+#undef ORL_RO_LAUNCH3
+  rc = launch_status("orl_rollout_fused");
+  if (rc || !split) return rc;
+  // values of every slot 0..T from the stored critic observations; slot T doubles as the bootstrap value
+  rc = orl_critic_values(cnet, ctheta, b.critic_obs, (int64_t)(b.T + 1) * b.N, args->value_preds, stream);
+  if (rc) return rc;
+  if (next_value != nullptr)
+    (void)hipMemcpyAsync(next_value, args->value_preds + (size_t)b.T * b.N, sizeof(float) * b.N, hipMemcpyDeviceToDevice,
+                         (hipStream_t)stream);
+  return launch_status("orl_rollout_fused(values)");
 }
 
 }  // extern "C"

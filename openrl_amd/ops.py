@@ -162,6 +162,14 @@ def act_rng_offset(dev_counter: Optional[torch.Tensor]) -> None:
     nat.check(_lib().orl_act_rng_offset(ptr(dev_counter)), "orl_act_rng_offset")
 
 
+def critic_values(cnet: NetDesc, ctheta, critic_obs, values) -> None:
+    """values[rows] = V(critic_obs[rows, D]) in one persistent launch (orl_critic_values)."""
+    dev = _dev(critic_obs)
+    rows = critic_obs.numel() // cnet.obs_dim
+    rc = _lib().orl_critic_values(C.byref(cnet), fptr(ctheta), fptr(critic_obs), rows, fptr(values), stream_ptr(dev))
+    nat.check(rc, "orl_critic_values")
+
+
 def evaluate_actions(pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, actions, action_masks, active_masks, B: int,
                      values, logp, ent_rows, dist_entropy) -> None:
     dev = _dev(policy_obs)

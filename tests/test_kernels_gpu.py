@@ -103,6 +103,21 @@ def test_gae_long_rollout_all_variants(ops, use_gae, proper, use_vn):
     assert np.array_equal(d_vp.cpu().numpy(), want_vp)
 
 
+@pytest.mark.parametrize("D,B", [(4, 1000), (18, 4099), (54, 33)])
+def test_batched_critic_values_equal_the_act_step_critic(ops, D, B):
+    """orl_critic_values (the fused rollout's value pass over all T+1 slots) == orl_act_step's critic wave, bit for bit."""
+    rs = np.random.RandomState(D)
+    cnet = ops.net_desc(D, 1, ops.HEAD_VALUE)
+    n_par = D * 64 + 64 * 3 + 64 * 64 + 64 * 3 + 64 + 1
+    theta = dev((0.2 * rs.randn(n_par)).astype(np.float32))
+    obs = dev(rs.randn(B, D).astype(np.float32))
+    want, got = torch.empty(B, 1, device=DEV), torch.full((B,), np.nan, device=DEV)
+    pnet = ops.net_desc(D, 2, ops.HEAD_CATEGORICAL)  # descriptor only: no policy parameters are passed
+    ops.act_step(pnet, None, cnet, theta, None, obs, None, B, True, 0, 0, 0, None, want, None, None)
+    ops.critic_values(cnet, theta, obs, got)
+    assert torch.equal(got, want.view(-1))
+
+
 # --------------------------------------------------------------------------------------------- K7
 @pytest.mark.parametrize("T", [11, 150])
 @pytest.mark.parametrize("use_adv_norm", [False, True])
