@@ -138,6 +138,17 @@ __device__ inline float row_allsum(float s) {
   return a + b;
 }
 
+// max over the same 4 lanes, result in all of them
+__device__ inline float row_allmax(float s) {
+  float a = s, b = s;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  const float t = fmaxf(a, b);
+  a = t;
+  b = t;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     float rstd1, rstd2;
     unsigned relu_bits = 0u;
     float hd[NO];
+    f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};  // wide heads: this lane's 4 logits
     {
       f32x4 z[4], n1[4], xh2[4];
       load_vec_T(lw + tw.b1, q, z);
@@ -286,7 +287,17 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       store_slab_T(SS, xh2, j, q);  // parked in the scratch slab: read back in F layout (S3) and T layout (LN2')
       ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, z);  // z = n2
       if constexpr (HMM) {
-        head_mfma_T<NO>(lw + tw.W3P, lw + tw.b3, n_out, z, DH, j, q, hd);  // NOP == 16: DH is the [16][16] scratch tile
+        // logits^T[16 c x 16 rows] = W3p n2^T: lane (j, q) keeps logits c = 4q..4q+3 of row j - the layout the loss,
+        // the dhead tile and the dn2 GEMM below all work in (no redistribution)
+        const int no4 = (n_out + 3) & ~3;
+        hv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (4 * q < no4) hv = *(const f32x4*)(lw + tw.b3 + 4 * q);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const f32x4 a4 = *(const f32x4*)(lw + tw.W3P + j * W2S + 16 * mi + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv = ORL_MFMA(a4[r], z[mi][r], hv);
+        }
       } else {
         head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, z, q, hd);
       }
@@ -297,7 +308,127 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     float dh[NO];
 #pragma unroll
     for (int c = 0; c < NO; ++c) dh[c] = 0.f;
+    f32x4 dhv = f32x4{0.f, 0.f, 0.f, 0.f};  // wide heads: d loss / d logit of this lane's 4 classes / dimensions
     const float active = valid ? REC(A.o_am) : 0.f;
+    if constexpr (HMM) {
+      // Each lane owns classes / action dimensions c = 4q + r; row-wide quantities are in-lane partials combined
+      // over the 4 lanes of the row (row_allsum / row_allmax).  Same formulas as the narrow-head code below.
+      const float w = valid ? (hp.use_policy_active_masks ? active : 1.f) : 0.f;
+      const float adv = valid ? REC(A.o_adv) : 0.f;
+      if (HEAD == ORL_HEAD_CATEGORICAL) {
+        float lg[4], mk[4];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * q + r;
+          mk[r] = (A.K > 0 && valid && c < n_out) ? REC(A.o_mk + c) : 1.f;
+          lg[r] = (mk[r] == 0.f) ? -6e4f : hv[r];
+          if (c < n_out) mx = fmaxf(mx, lg[r]);
+        }
+        mx = row_allmax(mx);
+        float se = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * q + r < n_out) se += __expf(lg[r] - mx);
+        se = row_allsum(se);
+        const float lse = mx + __logf(se);
+        const int act = valid ? (int)REC(A.o_act) : 0;
+        const float old_lp = valid ? REC(A.o_lp) : 0.f;
+        float pk = 0.f, entp = 0.f;
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * q + r;
+          p[r] = 0.f;
+          if (c < n_out) {
+            const float ell = lg[r] - lse;
+            p[r] = __expf(ell);
+            entp -= p[r] * ell;
+            if (c == act) pk = lg[r];
+          }
+        }
+        const float lp = row_allsum(pk) - lse;
+        const float ent = row_allsum(entp);
+        float ratio = __expf(lp - old_lp);
+        const float ratio_raw = ratio;
+        float dr_eff = 1.f;
+        if (hp.dual_clip_ppo) {
+          if (ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }
+        }
+        const float s1 = ratio * adv;
+        const float s2 = fminf(fmaxf(ratio, 1.f - hp.clip_param), 1.f + hp.clip_param) * adv;
+        float surr = fminf(s1, s2);
+        float gl = -((s1 <= s2) ? adv : 0.f) * dr_eff * ratio_raw;  // d(-surr)/d logp
+        if (hp.reserved & 2) {  // A2C
+          surr = adv * lp;
+          gl = -adv;
+          ratio = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * q + r;
+          if (c < n_out) {
+            const float ell = lg[r] - lse;
+            const float d = gl * ((c == act ? 1.f : 0.f) - p[r]) + hp.entropy_coef * p[r] * (ell + ent);
+            dhv[r] = (mk[r] == 0.f) ? 0.f : w * d;
+          }
+        }
+        if (q == 0 && valid) {
+          st_active += active; st_rows += 1.f; st_loss += -surr * w; st_ent += ent * w; st_ratio += ratio;
+        }
+      } else {
+        const float ent_scale = hp.use_policy_active_masks ? 1.f : 1.f / (float)n_out;
+        float surr_sum = 0.f, ent_sum = 0.f, ratio_sum = 0.f;
+        f32x4 dlsv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * q + r;
+          if (c < n_out) {
+            const float ls = lw[tw.logstd + c];
+            const float sd = expf(ls);
+            const float av = valid ? REC(A.o_act + c) : 0.f;
+            const float old_lp = valid ? REC(A.o_lp + c) : 0.f;
+            const float dmu = av - hv[r];
+            const float var = sd * sd;
+            const float lp = -(dmu * dmu) / (2.f * var) - ls - 0.91893853320467274178f;
+            float ratio = __expf(lp - old_lp);
+            const float ratio_raw = ratio;
+            float dr_eff = 1.f;
+            if (hp.dual_clip_ppo && ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }
+            const float s1 = ratio * adv;
+            const float s2 = fminf(fmaxf(ratio, 1.f - hp.clip_param), 1.f + hp.clip_param) * adv;
+            float surr_c = fminf(s1, s2);
+            float gl = -((s1 <= s2) ? adv : 0.f) * dr_eff * ratio_raw;
+            if (hp.reserved & 2) {  // A2C
+              surr_c = adv * lp;
+              gl = -adv;
+              ratio = 0.f;
+            }
+            surr_sum += surr_c;
+            dhv[r] = w * gl * dmu / var;
+            dlsv[r] = w * (gl * (dmu * dmu / var - 1.f) - hp.entropy_coef * ent_scale);
+            ent_sum += 1.41893853320467274178f + ls;
+            ratio_sum += ratio;
+          }
+        }
+        surr_sum = row_allsum(surr_sum);
+        ent_sum = row_allsum(ent_sum);
+        ratio_sum = row_allsum(ratio_sum);
+        if (q == 0 && valid) {
+          st_active += active; st_rows += 1.f; st_loss += -surr_sum * w; st_ent += ent_sum * w;
+          st_ratio += ratio_sum;
+        }
+        // dlogstd: column sums of the [16 rows][16 dims] tile
+        *(f32x4*)(DH + j * NOP + 4 * q) = dlsv;
+        wave_lds_fence();
+        if (l < n_out) {
+          float s = 0.f;
+          for (int r = 0; r < TILE_B; ++r) s += DH[r * NOP + l];
+          a_dls += s;
+        }
+        wave_lds_fence();
+      }
+    } else
     if (HEAD == ORL_HEAD_VALUE) {
       const float w = valid ? (hp.use_value_active_masks ? active : 1.f) : 0.f;
       const float v = hd[0];
@@ -428,7 +559,9 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     ORL_T(4);  // loss
     // ---------------- backward ----------------
     // S3 += dhead^T xhat2, db3 (F layout: lane = feature f); xhat2 comes from the scratch slab
-    if (q == 0) {
+    if constexpr (HMM) {
+      *(f32x4*)(DH + j * NOP + 4 * q) = dhv;
+    } else if (q == 0) {
 #pragma unroll
       for (int c = 0; c < NOP; ++c) DH[j * NOP + c] = c < NO ? dh[c < NO ? c : 0] : 0.f;
     }
@@ -467,7 +600,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     for (int m = 0; m < 4; ++m) d2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (HMM) {
       // dn2^T[64 f x 16 rows] = W3p^T[64 x 16 c] dhead^T: the dhead tile is this lane's B operand in T layout
-      const f32x4 dv = *(const f32x4*)(DH + j * NOP + 4 * q);
+      const f32x4 dv = dhv;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
