@@ -344,6 +344,17 @@ int orl_mpe_reset(float* env_state, float* ep_stats, float* obs_policy, float* o
 int orl_mpe_step(float* env_state, float* ep_stats, const float* actions, float* obs_policy, float* obs_critic,
                  float* rewards, uint8_t* dones, int N, uint64_t env_seed, int world_length, void* stream);
 
+/* ---- device-resident tic-tac-toe vs a uniformly random opponent (BASELINE config 5's env) ---------------------
+ * examples/selfplay: PettingZoo tictactoe_v3 behind RandomOpponentWrapper (selfplay/wrappers/
+ * base_multiplayer_wrapper.py:85-150, random_opponent_wrapper.py:27-43).  One env = one game; a step is the agent's
+ * move plus the opponent's reply; rewards +1 / -1 / 0 (illegal move: -1, game over); obs [N, 18], action masks
+ * [N, 9] (1 = empty cell), rewards [N], dones uint8 [N]; finished games restart in the same step (auto-reset). */
+int orl_ttt_state_width(void);
+int orl_ttt_reset(float* env_state, float* ep_stats, float* obs, float* action_masks, int N, uint64_t env_seed,
+                  void* stream);
+int orl_ttt_step(float* env_state, float* ep_stats, const float* actions, float* obs, float* action_masks,
+                 float* rewards, uint8_t* dones, int N, uint64_t env_seed, void* stream);
+
 /* ---- recurrent (GRU) towers: use_recurrent_policy -------------------------
  * Tower = MLPBase (as above) -> RNNLayer = one-layer nn.GRU(H,H) + LayerNorm(H) (openrl/modules/networks/utils/
  * rnn.py:5-99, recurrent_N = 1) -> head.  The orl_net_desc fields keep their meaning; `theta` is the reference's

@@ -1,0 +1,157 @@
+// orl_ttt.hip - device-resident batched tic-tac-toe against a uniformly random legal-move opponent, for gfx950:
+// BASELINE config 5's env (examples/selfplay: PettingZoo tictactoe_v3 behind RandomOpponentWrapper,
+// openrl/selfplay/wrappers/base_multiplayer_wrapper.py:85-150 + random_opponent_wrapper.py:27-43).
+//
+// One lane owns one game.  The learning agent is "player 1" of the state; at every reset a Philox bit decides whether
+// it moves first or second (BaseMultiPlayerWrapper.reset picks self_player at random and lets the opponent move until
+// it is the agent's turn).  A step = the agent's move, then - if the game is still open - the opponent's reply.
+// Rewards are PettingZoo's: +1 win, -1 loss, 0 draw, -1 for an illegal move (which also ends the game).  Observation:
+// 18 floats, obs[2*cell] = agent's mark, obs[2*cell+1] = opponent's mark (the two 3x3 planes of tictactoe_v3 in
+// action-index order); action mask: 9 floats, 1 = empty cell.  Finished games restart in the same step (auto-reset,
+// envs/vec_env/sync_venv.py:217-222): the returned observation / mask are the first ones of the next game.
+// Integer work throughout; Philox streams: start bit (seed, env, 0x77C7FFFF, episode), opponent move k of an episode
+// (seed, env, 0x77C70000 + k, episode).
+#include "orl_common.h"
+
+namespace orl {
+
+constexpr int TTT_STATE_W = 12;  // board[9] (0 empty, 1 agent, 2 opponent), opponent moves this episode, episode, -
+
+__device__ inline bool ttt_wins(const int (&b)[9], int p) {
+  return (b[0] == p && b[1] == p && b[2] == p) || (b[3] == p && b[4] == p && b[5] == p) ||
+         (b[6] == p && b[7] == p && b[8] == p) || (b[0] == p && b[3] == p && b[6] == p) ||
+         (b[1] == p && b[4] == p && b[7] == p) || (b[2] == p && b[5] == p && b[8] == p) ||
+         (b[0] == p && b[4] == p && b[8] == p) || (b[2] == p && b[4] == p && b[6] == p);
+}
+
+__device__ inline int ttt_empty(const int (&b)[9]) {
+  int n = 0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) n += b[c] == 0;
+  return n;
+}
+
+// uniformly random legal move: the k-th empty cell, k = floor(u * n_empty)
+__device__ inline void ttt_opponent_move(int (&b)[9], uint64_t seed, uint32_t env, uint32_t episode, uint32_t move) {
+  const int n = ttt_empty(b);
+  const u4 r = philox4x32_10(seed, env, 0x77C70000u + move, episode, 0u);
+  int k = (int)(u01(r.x) * (float)n);
+  k = k < n - 1 ? k : n - 1;
+  int seen = 0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    if (b[c] == 0) {
+      if (seen == k) b[c] = 2;
+      ++seen;
+    }
+  }
+}
+
+// empty board; if the agent plays second the opponent opens.  Returns the number of opponent moves made (0 / 1).
+__device__ inline int ttt_begin(int (&b)[9], uint64_t seed, uint32_t env, uint32_t episode) {
+#pragma unroll
+  for (int c = 0; c < 9; ++c) b[c] = 0;
+  const u4 r = philox4x32_10(seed, env, 0x77C7FFFFu, episode, 0u);
+  if (r.x & 1u) {
+    ttt_opponent_move(b, seed, env, episode, 0u);
+    return 1;
+  }
+  return 0;
+}
+
+__device__ inline void ttt_write(const int (&b)[9], int moves, int episode, float* __restrict__ st, float* __restrict__ obs,
+                                 float* __restrict__ amask) {
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    st[c] = (float)b[c];
+    obs[2 * c] = b[c] == 1 ? 1.f : 0.f;
+    obs[2 * c + 1] = b[c] == 2 ? 1.f : 0.f;
+    amask[c] = b[c] == 0 ? 1.f : 0.f;
+  }
+  st[9] = (float)moves; st[10] = (float)episode; st[11] = 0.f;
+}
+
+__global__ void ttt_reset_kernel(float* __restrict__ st, float* __restrict__ ep_stats, float* __restrict__ obs,
+                                 float* __restrict__ amask, int N, uint64_t seed) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int b[9];
+  const int moves = ttt_begin(b, seed, (uint32_t)n, 0u);
+  ttt_write(b, moves, 0, st + (size_t)n * TTT_STATE_W, obs + (size_t)n * 18, amask + (size_t)n * 9);
+  if (ep_stats != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ep_stats[(size_t)n * 4 + k] = 0.f;
+  }
+}
+
+__global__ void ttt_step_kernel(float* __restrict__ st, float* __restrict__ ep_stats, const float* __restrict__ actions,
+                                float* __restrict__ obs, float* __restrict__ amask, float* __restrict__ rewards,
+                                uint8_t* __restrict__ dones, int N, uint64_t seed) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float* s = st + (size_t)n * TTT_STATE_W;
+  int b[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) b[c] = (int)s[c];
+  int moves = (int)s[9], episode = (int)s[10];
+  const int a = (int)actions[n];
+  float rew = 0.f;
+  bool done = false;
+  bool legal = false;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) legal = legal || (c == a && b[c] == 0);
+  if (!legal) {  // TerminateIllegalWrapper: the mover loses
+    rew = -1.f;
+    done = true;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+      if (c == a) b[c] = 1;
+    if (ttt_wins(b, 1)) { rew = 1.f; done = true; }
+    else if (ttt_empty(b) == 0) done = true;
+    else {
+      ttt_opponent_move(b, seed, (uint32_t)n, (uint32_t)episode, (uint32_t)moves);
+      ++moves;
+      if (ttt_wins(b, 2)) { rew = -1.f; done = true; }
+      else if (ttt_empty(b) == 0) done = true;
+    }
+  }
+  if (ep_stats != nullptr) {
+    float* e = ep_stats + (size_t)n * 4;
+    e[0] += rew; e[1] += 1.f;
+    if (done) { e[2] += e[0]; e[3] += 1.f; e[0] = 0.f; e[1] = 0.f; }
+  }
+  if (done) {
+    ++episode;
+    moves = ttt_begin(b, seed, (uint32_t)n, (uint32_t)episode);
+  }
+  ttt_write(b, moves, episode, s, obs + (size_t)n * 18, amask + (size_t)n * 9);
+  rewards[n] = rew;
+  dones[n] = done ? 1 : 0;
+}
+
+}  // namespace orl
+
+using namespace orl;
+
+extern "C" {
+
+int orl_ttt_state_width(void) { return TTT_STATE_W; }
+
+int orl_ttt_reset(float* env_state, float* ep_stats, float* obs, float* action_masks, int N, uint64_t env_seed,
+                  void* stream) {
+  ORL_REQUIRE(env_state && obs && action_masks && N > 0, "orl_ttt_reset: bad arguments");
+  hipLaunchKernelGGL(ttt_reset_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_state, ep_stats,
+                     obs, action_masks, N, env_seed);
+  return launch_status("orl_ttt_reset");
+}
+
+int orl_ttt_step(float* env_state, float* ep_stats, const float* actions, float* obs, float* action_masks,
+                 float* rewards, uint8_t* dones, int N, uint64_t env_seed, void* stream) {
+  ORL_REQUIRE(env_state && actions && obs && action_masks && rewards && dones && N > 0, "orl_ttt_step: bad arguments");
+  hipLaunchKernelGGL(ttt_step_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_state, ep_stats,
+                     actions, obs, action_masks, rewards, dones, N, env_seed);
+  return launch_status("orl_ttt_step");
+}
+
+}  // extern "C"

@@ -97,6 +97,10 @@ class OnPolicyDriver:
         if getattr(self.envs, "is_device_env", False):
             obs = self.envs.reset_device(seed=getattr(self.envs, "seed", None))
             info = None
+            dev_masks = getattr(self.envs, "action_mask_device", None)  # legal-move masks that never leave the device
+            if dev_masks is not None:
+                self.buffer.init_buffer(obs, action_masks=dev_masks)
+                return
         else:
             returns = self.envs.reset()
             if isinstance(returns, tuple):
@@ -217,7 +221,8 @@ class OnPolicyDriver:
         self.callback.update_locals(locals())
         if self.callback.on_step() is False:
             return False
-        self.add2buffer({"obs": obs, "rewards": rewards, "dones": dones, "infos": infos, "step": step})
+        self.add2buffer({"obs": obs, "rewards": rewards, "dones": dones, "infos": infos, "step": step,
+                         "action_masks": getattr(self.envs, "action_mask_device", None)})
         return True
 
     @torch.no_grad()
@@ -261,7 +266,9 @@ class OnPolicyDriver:
             bad = np.array([[bool(i.get("bad_transition", [False] * self.num_agents)[a]) for a in range(self.num_agents)]
                             for i in infos], dtype=np.uint8)
             bad = self._as_dev(bad, torch.uint8)
-        amask = prepare_action_masks(infos, self.num_agents)
+        amask = data.get("action_masks")  # device envs: already a device tensor [N, A, K]
+        if amask is None:
+            amask = prepare_action_masks(infos, self.num_agents)
         rec = d.rnn_states.stride(0) != 0  # recurrent: rnn_states[dones_env] = 0, folded into the insert launch
         ops.buffer_insert(d.buffer_ptrs(), step, p_obs, c_obs, self._as_dev(data["rewards"]),
                           self._as_dev(data["dones"], torch.uint8), bad,

@@ -37,7 +37,11 @@ def make(id: str, env_num: int = 1, asynchronous: bool = False, add_monitor: boo
         from ..vec_env.mpe_env import MpeSpreadVecEnv
 
         return MpeSpreadVecEnv(env_num, id, kwargs.pop("world_length", 25), device=device, seed=seed)
+    if id == "tictactoe_v3":  # openrl/envs/PettingZoo + selfplay RandomOpponentWrapper (examples/selfplay)
+        from ..vec_env.tictactoe_env import TicTacToeVecEnv
+
+        return TicTacToeVecEnv(env_num, id, device=device, seed=seed)
     raise NotImplementedError(
-        "env id %r is not a device-resident env of the MI355X engine (built: 'CartPole-v1', 'simple_spread', '%s-v0'); "
+        "env id %r is not a device-resident env of the MI355X engine (built: 'CartPole-v1', 'simple_spread', 'tictactoe_v3', '%s-v0'); "
         "pass make_custom_envs=... returning a duck-typed VecEnv (gymnasium is not part of this engine)"
         % (id, _SYNTH_PREFIX))

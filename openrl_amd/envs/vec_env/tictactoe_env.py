@@ -1,0 +1,74 @@
+"""Device-resident batched tic-tac-toe against a uniformly random opponent (BASELINE config 5's env; SURVEY.md
+section 8f rank 3) behind the VecEnv duck-type of ``device_env.DeviceVecEnv``.
+
+Reference: ``examples/selfplay`` - ``make("tictactoe_v3", opponent_wrappers=[RandomOpponentWrapper], ...)`` wraps a
+PettingZoo game so that the learning agent sees a single-agent env whose step contains the opponent's reply
+(``selfplay/wrappers/base_multiplayer_wrapper.py:85-150``), with the legal moves delivered as ``info["action_masks"]``
+(``MoveActionMask2InfoWrapper``).  Here one HIP launch (``orl_ttt_step``) advances every game, and the legal-move masks
+stay on the device (``action_mask_device``: the driver hands them to ``orl_buffer_insert`` / ``orl_act_step``).
+The opponent-pool variant of the reference (``OpponentPoolWrapper``: opponents are earlier checkpoints served by a
+selfplay API) is not built."""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ... import _native as nat
+from ... import ops_rnn, spaces
+from .device_env import DeviceVecEnv
+
+
+class TicTacToeVecEnv(DeviceVecEnv):
+    OBS, N_ACT = 18, 9
+
+    def __init__(self, env_num: int, env_name: str = "tictactoe_v3", device="cuda:0", seed: int = 0):
+        self.kind = "tictactoe_random_opponent"
+        self.env_kind = None  # not a kind the fused rollout kernel steps in-kernel
+        self.device = nat.require_gpu(device)
+        self._n = int(env_num)
+        self._env_name = env_name
+        self.episode_limit = 5  # a game lasts at most 5 agent moves
+        self.seed = int(seed)
+        self._observation_space = spaces.Box(0.0, 1.0, (self.OBS,), np.float32)
+        self._action_space = spaces.Discrete(self.N_ACT)
+        z = lambda *s, **k: torch.zeros(*s, device=self.device, **k)
+        self.env_state = z(self._n, ops_rnn.ttt_state_width())
+        self.ep_stats = z(self._n, 4)
+        self.obs = z(self._n, 1, self.OBS)
+        self.action_mask_device = z(self._n, 1, self.N_ACT)  # 1 = legal; read by the driver after reset / step
+        self._rew = z(self._n, 1, 1)
+        self._done = z(self._n, 1, dtype=torch.uint8)
+        self.global_step = 0
+        self.start_time = time.time()
+        self.total_step = 0
+        self._infos = [{} for _ in range(self._n)]
+        self.is_device_env = True
+        self.supports_fused_rollout = False
+        self.supports_graph_rollout = True  # orl_ttt_step takes no per-call host scalar: capturable
+
+    def reset_device(self, seed: Optional[int] = None):
+        if seed is not None:
+            self.seed = int(seed)
+        ops_rnn.ttt_reset(self.env_state, self.ep_stats, self.obs, self.action_mask_device, self._n, self.seed)
+        self.global_step = 0
+        return self.obs
+
+    def reset(self, seed: Optional[int] = None, options=None):
+        obs = self.reset_device(seed)
+        return obs.cpu().numpy(), {"action_masks": self.action_mask_device.cpu().numpy()}
+
+    def step_device(self, actions: torch.Tensor):
+        a = actions.to(self.device, torch.float32).reshape(self._n).contiguous()
+        ops_rnn.ttt_step(self.env_state, self.ep_stats, a, self.obs, self.action_mask_device, self._rew, self._done,
+                         self._n, self.seed)
+        self.global_step += 1
+        return self.obs, self._rew, self._done
+
+    def step(self, actions, extra_data=None):
+        obs, rew, done = self.step_device(torch.as_tensor(np.asarray(actions), dtype=torch.float32))
+        masks = self.action_mask_device.cpu().numpy()
+        infos = [{"action_masks": masks[n]} for n in range(self._n)]
+        return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool), infos

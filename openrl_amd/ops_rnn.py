@@ -96,3 +96,22 @@ def mpe_step(env_state, ep_stats, actions, obs_policy, obs_critic, rewards, done
     rc = _lib().orl_mpe_step(fptr(env_state), fptr(ep_stats), fptr(actions), fptr(obs_policy), fptr(obs_critic),
                              fptr(rewards), ptr(dones), N, seed & (2 ** 64 - 1), world_length, stream_ptr(dev))
     nat.check(rc, "orl_mpe_step")
+
+
+# ------------------------------------------------------------------------------------------------ device tic-tac-toe
+def ttt_state_width() -> int:
+    return int(_lib().orl_ttt_state_width())
+
+
+def ttt_reset(env_state, ep_stats, obs, action_masks, N: int, seed: int) -> None:
+    dev = _dev(env_state)
+    rc = _lib().orl_ttt_reset(fptr(env_state), fptr(ep_stats), fptr(obs), fptr(action_masks), N, seed & (2 ** 64 - 1),
+                              stream_ptr(dev))
+    nat.check(rc, "orl_ttt_reset")
+
+
+def ttt_step(env_state, ep_stats, actions, obs, action_masks, rewards, dones, N: int, seed: int) -> None:
+    dev = _dev(env_state)
+    rc = _lib().orl_ttt_step(fptr(env_state), fptr(ep_stats), fptr(actions), fptr(obs), fptr(action_masks),
+                             fptr(rewards), ptr(dones), N, seed & (2 ** 64 - 1), stream_ptr(dev))
+    nat.check(rc, "orl_ttt_step")
