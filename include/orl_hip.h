@@ -295,6 +295,7 @@ int orl_minibatch_moments(const float* records, int rec_width, int ret_col, cons
  */
 #define ORL_ENV_SYNTH 0    /* fixed-step synthetic env: obs ~ N(0,1) keyed (seed, env, t), reward U(0,1) */
 #define ORL_ENV_CARTPOLE 1 /* CartPole-v1 dynamics (gymnasium classic_control cartpole.py) */
+#define ORL_ENV_TTT 2      /* tic-tac-toe vs a uniformly random opponent (orl_ttt_*): obs 18, Discrete(9), legal-move masks */
 
 typedef struct orl_rollout_args {
   orl_buffer_ptrs buf;

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liborl_hip.so")
 
 ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
-ORL_ENV_SYNTH, ORL_ENV_CARTPOLE = 0, 1
+ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT = 0, 1, 2
 ORL_GATHER_MAX = 12
 ORL_N_STATS = 16
 

@@ -12,6 +12,7 @@
 #include "orl_common.h"
 #include "orl_mlp.h"
 #include "orl_heads.h"
+#include "orl_ttt.h"
 
 namespace orl {
 
@@ -251,8 +252,8 @@ __device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const Tower
 }
 
 // WC = false: policy-only rollout with 4 waves (one per SIMD); the values of all T+1 slots are then computed by ONE
-// batched launch of critic_values_kernel over the stored observations - same parameters, same per-row arithmetic
-// (trunk_fwd_coop is bit-identical to trunk_fwd_T), but throughput-bound instead of sharing the SIMDs of a
+// batched launch of critic_values_kernel over the stored observations - same parameters, the same arithmetic up to
+// the few-ulp contraction differences between the cooperative and the per-wave trunk, but throughput-bound instead of sharing the SIMDs of a
 // latency-bound step loop with the policy.
 template <int NO, int HEAD, int ENV, bool WC>
 __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
@@ -295,12 +296,18 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   // the action, so its step runs on wave 1 concurrently with wave 0's head + sampling; CartPole needs the action
   // and stays on wave 0.
   constexpr int ENV_WAVE = (ENV == ORL_ENV_SYNTH) ? 1 : 0;
-  float est[8];
-  const int SW = (ENV == ORL_ENV_SYNTH) ? SYNTH_STATE_W : CARTPOLE_STATE_W;
+  constexpr int ESW = (ENV == ORL_ENV_TTT) ? TTT_STATE_W : 8;
+  float est[ESW];
+  const int SW = (ENV == ORL_ENV_SYNTH) ? SYNTH_STATE_W : (ENV == ORL_ENV_TTT) ? TTT_STATE_W : CARTPOLE_STATE_W;
   float ep_ret = 0.f, ep_len = 0.f, fin_ret = 0.f, fin_cnt = 0.f;
+  // tic-tac-toe: the legal-move mask of the current step lives in LDS (written with the board one step earlier)
+  float* s_mask = s_logits + TILE_B * 16;  // [16][16]
+  if (ENV == ORL_ENV_TTT && wave == 0 && q == 0) {
+    for (int c = 0; c < 16; ++c) s_mask[j * 16 + c] = (ok && c < 9) ? b.action_masks[(size_t)n * 9 + c] : (c == 0 ? 1.f : 0.f);
+  }
   if (wave == ENV_WAVE && q == 0 && ok) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) est[k] = (k < SW) ? A.r.env_state[(size_t)n * SW + k] : 0.f;
+    for (int k = 0; k < ESW; ++k) est[k] = (k < SW) ? A.r.env_state[(size_t)n * SW + k] : 0.f;
     ep_ret = A.r.ep_stats[n * 4 + 0]; ep_len = A.r.ep_stats[n * 4 + 1];
     fin_ret = A.r.ep_stats[n * 4 + 2]; fin_cnt = A.r.ep_stats[n * 4 + 3];
   }
@@ -347,8 +354,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
       else head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);
       // the built-in device envs never mask actions (their action_masks rows stay all-ones), so the mask is
       // not re-read from HBM on the per-step critical path
-      sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, nullptr, s_noise + (t & 1) * TILE_B * 16 + j * 16, 0,
-                            A.r.act_seed, (uint64_t)n, tg, act_o, lp_o);
+      sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, ENV == ORL_ENV_TTT ? s_mask + j * 16 : nullptr,
+                            s_noise + (t & 1) * TILE_B * 16 + j * 16, 0, A.r.act_seed, (uint64_t)n, tg, act_o, lp_o);
       if (ok && q == 0) {
 #pragma unroll
         for (int c = 0; c < NO; ++c) {
@@ -395,6 +402,72 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
           ep_ret += rew; ep_len += 1.f;
           if (done) { fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f; }
         }
+      } else if (ENV == ORL_ENV_TTT) {
+        // orl_ttt_step's game logic on the owning lane; the new observation / mask rows go through LDS and leave as
+        // coalesced rows of the [T+1, N, 18] / [T+1, N, 9] arrays (all 64 lanes store)
+        if (q == 0) {
+          int bd[9];
+#pragma unroll
+          for (int c = 0; c < 9; ++c) bd[c] = (int)est[c];
+          int moves = (int)est[9], episode = (int)est[10];
+          if (ok) {
+            const int a = (int)act_o[0];
+            float rew = 0.f;
+            bool done = false, legal = false;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) legal = legal || (c == a && bd[c] == 0);
+            if (!legal) { rew = -1.f; done = true; }
+            else {
+#pragma unroll
+              for (int c = 0; c < 9; ++c)
+                if (c == a) bd[c] = 1;
+              if (ttt_wins(bd, 1)) { rew = 1.f; done = true; }
+              else if (ttt_empty(bd) == 0) done = true;
+              else {
+                ttt_opponent_move(bd, A.r.env_seed, (uint32_t)n, (uint32_t)episode, (uint32_t)moves);
+                ++moves;
+                if (ttt_wins(bd, 2)) { rew = -1.f; done = true; }
+                else if (ttt_empty(bd) == 0) done = true;
+              }
+            }
+            b.rewards[(size_t)t * N + n] = rew;
+            b.masks[s1] = done ? 0.f : 1.f;
+            b.active_masks[s1] = 1.f;
+            b.bad_masks[s1] = 1.f;
+            ep_ret += rew; ep_len += 1.f;
+            if (done) {
+              fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f;
+              ++episode;
+              moves = ttt_begin(bd, A.r.env_seed, (uint32_t)n, (uint32_t)episode);
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) est[c] = (float)bd[c];
+            est[9] = (float)moves; est[10] = (float)episode;
+          }
+#pragma unroll
+          for (int c = 0; c < 9; ++c) {
+            nxt[j * DP + 2 * c] = (ok && bd[c] == 1) ? 1.f : 0.f;
+            nxt[j * DP + 2 * c + 1] = (ok && bd[c] == 2) ? 1.f : 0.f;
+            s_mask[j * 16 + c] = (!ok && c == 0) ? 1.f : ((ok && bd[c] == 0) ? 1.f : 0.f);
+          }
+          for (int d = 18; d < DP; ++d) nxt[j * DP + d] = 0.f;
+        }
+        wave_lds_fence();
+        {
+          const int row0 = blockIdx.x * TILE_B;
+          const int nrow = (N - row0) < TILE_B ? (N - row0) : TILE_B;
+          const size_t base = (size_t)(t + 1) * N + row0;
+          for (int e = l; e < nrow * 18; e += 64) {
+            const int rr = e / 18, d = e - rr * 18;
+            const float v = nxt[rr * DP + d];
+            b.policy_obs[base * 18 + e] = v;
+            if (sep_c) b.critic_obs[base * 18 + e] = v;
+          }
+          for (int e = l; e < nrow * 9; e += 64) {
+            const int rr = e / 9, c = e - rr * 9;
+            b.action_masks[base * 9 + e] = s_mask[rr * 16 + c];
+          }
+        }
       } else {
         if (q == 0 && ok) {
           float s[4] = {est[0], est[1], est[2], est[3]};
@@ -427,7 +500,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
           for (int k = 0; k < 4; ++k) nxt[j * DP + k] = 0.f;
         }
       }
-      if (b.action_masks != nullptr && ok && q == 0) {
+      if (ENV != ORL_ENV_TTT && b.action_masks != nullptr && ok && q == 0) {
         for (int c = 0; c < b.K; ++c) b.action_masks[s1 * b.K + c] = 1.f;
       }
     }
@@ -461,7 +534,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   }
   if (wave == ENV_WAVE && q == 0 && ok) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < ESW; ++k)
       if (k < SW) A.r.env_state[(size_t)n * SW + k] = est[k];
     A.r.ep_stats[n * 4 + 0] = ep_ret; A.r.ep_stats[n * 4 + 1] = ep_len;
     A.r.ep_stats[n * 4 + 2] = fin_ret; A.r.ep_stats[n * 4 + 3] = fin_cnt;
@@ -875,13 +948,16 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   if (args->env_kind == ORL_ENV_CARTPOLE)
     ORL_REQUIRE(pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 2 && b.Dp == 4,
                 "orl_rollout_fused: CartPole needs Discrete(2) and 4-d obs");
+  if (args->env_kind == ORL_ENV_TTT)
+    ORL_REQUIRE(pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 9 && b.Dp == 18 && b.K == 9 && b.action_masks,
+                "orl_rollout_fused: tic-tac-toe needs Discrete(9), 18-d obs and the action-mask array");
   const TowerLds twp(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false, pnet->n_out > 2);
   const TowerLds twc(cnet->obs_dim, 1, false, false);
   // ORL_ROLLOUT_SPLIT=1 (A/B knob): policy-only step loop + one batched orl_critic_values launch over all T+1 slots.
   // Measured at config 2: the step loop drops only 271 -> 237 us (the policy's own latency chain is the step), the
   // value launch costs 60 us - so the critic stays inside the loop by default.
   static const bool split = getenv("ORL_ROLLOUT_SPLIT") != nullptr;
-  const size_t lds = (size_t)(twp.total + (split ? 0 : twc.total) + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 3 * TILE_B * 16) * sizeof(float);
+  const size_t lds = (size_t)(twp.total + (split ? 0 : twc.total) + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 4 * TILE_B * 16) * sizeof(float);
   ORL_REQUIRE(lds <= 160 * 1024, "orl_rollout_fused: needs %zu B of LDS", lds);
   RolloutArgs A;
   A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.r = *args; A.next_value = next_value;
@@ -904,6 +980,8 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
 #undef ORL_RO_LAUNCH
   } else if (args->env_kind == ORL_ENV_CARTPOLE) {
     ORL_RO_LAUNCH2(2, ORL_HEAD_CATEGORICAL, ORL_ENV_CARTPOLE);
+  } else if (args->env_kind == ORL_ENV_TTT) {
+    ORL_RO_LAUNCH2(16, ORL_HEAD_CATEGORICAL, ORL_ENV_TTT);
   } else {
     return fail(ORL_E_INVALID, "orl_rollout_fused: unknown env kind %d", args->env_kind);
   }

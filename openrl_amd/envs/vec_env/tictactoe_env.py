@@ -26,7 +26,7 @@ class TicTacToeVecEnv(DeviceVecEnv):
 
     def __init__(self, env_num: int, env_name: str = "tictactoe_v3", device="cuda:0", seed: int = 0):
         self.kind = "tictactoe_random_opponent"
-        self.env_kind = None  # not a kind the fused rollout kernel steps in-kernel
+        self.env_kind = nat.ORL_ENV_TTT  # the fused rollout kernel plays the game in-kernel (orl_rollout_fused)
         self.device = nat.require_gpu(device)
         self._n = int(env_num)
         self._env_name = env_name
@@ -46,8 +46,8 @@ class TicTacToeVecEnv(DeviceVecEnv):
         self.total_step = 0
         self._infos = [{} for _ in range(self._n)]
         self.is_device_env = True
-        self.supports_fused_rollout = False
-        self.supports_graph_rollout = True  # orl_ttt_step takes no per-call host scalar: capturable
+        self.supports_fused_rollout = True
+        self.supports_graph_rollout = True  # stepwise mode: orl_ttt_step takes no per-call host scalar, capturable
 
     def reset_device(self, seed: Optional[int] = None):
         if seed is not None:

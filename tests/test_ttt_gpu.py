@@ -43,8 +43,8 @@ def test_ttt_step_matches_oracle_bit_for_bit():
     assert st["episodes_finished"] == n_done and n_done > 2 * N
 
 
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_config5_end_to_end_masks_stay_on_device(use_graph):
+@pytest.mark.parametrize("mode", ["fused", "graph", "eager"])
+def test_config5_end_to_end_masks_stay_on_device(mode):
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers import NormalReplayBuffer
     from openrl_amd.configs.config import default_cfg
@@ -54,7 +54,8 @@ def test_config5_end_to_end_masks_stay_on_device(use_graph):
 
     N, T, iters = 256, 8, 3
     cfg = default_cfg(["--seed", "2", "--episode_length", str(T), "--ppo_epoch", "2", "--amd_perm_mode", "device",
-                       "--amd_use_graph", str(use_graph), "--log_interval", "1000000"])
+                       "--amd_use_graph", str(mode == "graph"), "--amd_rollout_mode",
+                       "fused" if mode == "fused" else "stepwise", "--log_interval", "1000000"])
     env = make("tictactoe_v3", env_num=N, device=DEV, seed=2)
     net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
     cfg.num_env_steps = N * T * iters
@@ -78,9 +79,55 @@ def test_config5_end_to_end_masks_stay_on_device(use_graph):
         occ = d.policy_obs[:, :, 0, 0::2] + d.policy_obs[:, :, 0, 1::2]
         assert torch.equal(1.0 - occ, d.action_masks[:, :, 0, :])
         assert torch.all(d.rewards.abs() <= 1) and torch.isfinite(d.returns).all()
-    assert (drv._graph is not None) == use_graph and not drv.fused
+    assert (drv._graph is not None) == (mode == "graph") and drv.fused == (mode == "fused")
     for m in net.module.models.values():
         assert torch.isfinite(m.theta).all()
+
+
+def test_fused_rollout_equals_stepwise_rollout_on_tictactoe():
+    """The in-kernel game of orl_rollout_fused (ORL_ENV_TTT) and the stepwise orl_act_step + orl_ttt_step +
+    orl_buffer_insert path fill the buffer identically (same Philox streams for sampling and for the opponent)."""
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+
+    def run(mode):
+        N, T = 150, 12   # N not a multiple of the 16-env tile
+        cfg = default_cfg(["--seed", "5", "--episode_length", str(T), "--ppo_epoch", "1", "--amd_perm_mode", "device",
+                           "--amd_use_graph", "false", "--amd_rollout_mode", mode, "--log_interval", "1000000"])
+        env = make("tictactoe_v3", env_num=N, device=DEV, seed=5)
+        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+        cfg.num_env_steps = N * T * 2
+
+        class _Agent:
+            num_time_steps = 0
+
+        trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=DEV)
+        buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=DEV)
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, _Agent())
+        drv.reset_and_buffer_init()
+        out = []
+        for i in range(2):
+            drv.episode = i
+            drv.actor_rollout()
+            drv.compute_returns()
+            d = buf.data
+            out.append({k: getattr(d, k).clone() for k in ("policy_obs", "actions", "action_log_probs", "value_preds",
+                                                           "rewards", "masks", "action_masks", "returns")})
+            drv.buffer.after_update()
+        return out, env.ep_stats.clone(), env.env_state.clone()
+
+    (fa, sa, ea), (fb, sb, eb) = run("fused"), run("stepwise")
+    for a, b in zip(fa, fb):
+        for k in ("policy_obs", "actions", "rewards", "masks", "action_masks"):
+            assert torch.equal(a[k], b[k]), k
+        # the two kernels' float arithmetic is contracted differently by hipcc: a few ulp, not bitwise
+        for k in ("action_log_probs", "value_preds", "returns"):
+            torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-6, msg=k)
+    assert torch.equal(sa, sb) and torch.equal(ea, eb)
 
 
 def test_ppo_beats_the_random_opponent():
