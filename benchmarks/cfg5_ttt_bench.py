@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--T", type=int, default=200)
+    ap.add_argument("--opponent", default="random", choices=["random", "pool"],
+                    help="pool: self-play against 4 frozen snapshots of the learner (stepwise rollout, hipGraph)")
     a = ap.parse_args()
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers import NormalReplayBuffer
@@ -34,7 +36,10 @@ def main():
 
     dev, N, T = "cuda:0", a.envs, a.T
     cfg = default_cfg(["--seed", "0", "--episode_length", str(T), "--amd_perm_mode", "device", "--log_interval", "1000000"])
-    env = make("tictactoe_v3", env_num=N, device=dev)
+    env = make("tictactoe_v3", env_num=N, device=dev, opponent=a.opponent)
+    if a.opponent == "pool":
+        torch.manual_seed(1)
+        env.opp_thetas.copy_(0.1 * torch.randn_like(env.opp_thetas))  # non-trivial opponents from the start
     net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=N)
     cfg.num_env_steps = N * T * (a.steps + a.warmup)
 
@@ -65,7 +70,7 @@ def main():
         t_upd += tc - tb
     dt = time.perf_counter() - t0
     st = env.episode_statistics()
-    print(json.dumps({"bench": "cfg5_tictactoe_random_opponent", "envs": N, "episode_length": T, "ppo_epoch": cfg.ppo_epoch,
+    print(json.dumps({"bench": "cfg5_tictactoe_%s_opponent" % a.opponent, "envs": N, "episode_length": T, "ppo_epoch": cfg.ppo_epoch,
                       "env_steps_per_s": N * T * a.steps / dt, "ms_per_iteration": dt / a.steps * 1e3,
                       "ms_rollout": t_roll / a.steps * 1e3, "ms_update": t_upd / a.steps * 1e3,
                       "games_finished": st["episodes_finished"], "mean_game_result": st["episode_return_mean"]}))

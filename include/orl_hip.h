@@ -355,6 +355,15 @@ int orl_ttt_reset(float* env_state, float* ep_stats, float* obs, float* action_m
                   void* stream);
 int orl_ttt_step(float* env_state, float* ep_stats, const float* actions, float* obs, float* action_masks,
                  float* rewards, uint8_t* dones, int N, uint64_t env_seed, void* stream);
+/* The same step in two launches, for an opponent that is a POLICY (self-play; OpponentPoolWrapper of the reference
+ * plays earlier checkpoints): orl_ttt_agent_move applies the agent's moves and writes, for every game still open, the
+ * board from the opponent's side (opp_obs [N, 18], opp_masks [N, 9]); the caller samples opp_actions [N] from the
+ * opponent's policy (orl_act_step); orl_ttt_opponent_move applies them, settles rewards / dones, auto-resets and
+ * writes the agent's next observation / mask.  An opening move of the opponent after a reset stays uniform. */
+int orl_ttt_agent_move(float* env_state, const float* actions, float* opp_obs, float* opp_masks, float* rewards,
+                       uint8_t* dones, int N, void* stream);
+int orl_ttt_opponent_move(float* env_state, float* ep_stats, const float* opp_actions, float* obs, float* action_masks,
+                          float* rewards, uint8_t* dones, int N, uint64_t env_seed, void* stream);
 
 /* ---- recurrent (GRU) towers: use_recurrent_policy -------------------------
  * Tower = MLPBase (as above) -> RNNLayer = one-layer nn.GRU(H,H) + LayerNorm(H) (openrl/modules/networks/utils/

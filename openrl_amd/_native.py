@@ -101,6 +101,8 @@ _SIGNATURES = {
     "orl_ttt_state_width": (C.c_int, []),
     "orl_ttt_reset": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "orl_ttt_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
+    "orl_ttt_agent_move": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "orl_ttt_opponent_move": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "orl_critic_values": (C.c_int, [C.POINTER(NetDesc), _P, _P, C.c_int64, _P, _P]),
     "orl_evaluate_actions": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, C.c_int, _P,
                                        _P, _P, _P, _P]),

@@ -87,6 +87,90 @@ __global__ void ttt_step_kernel(float* __restrict__ st, float* __restrict__ ep_s
   dones[n] = done ? 1 : 0;
 }
 
+// ---- two-phase step for a LEARNED opponent (self-play): the agent's move, then - after the caller has run the
+// opponent's policy on `opp_obs` / `opp_masks` (the board from the opponent's side) - the opponent's move.
+// state[11]: 0 = agent to move, 1 = waiting for the opponent's reply, 2 = game ended by the agent's move.
+__global__ void ttt_agent_move_kernel(float* __restrict__ st, const float* __restrict__ actions,
+                                      float* __restrict__ opp_obs, float* __restrict__ opp_masks,
+                                      float* __restrict__ rewards, uint8_t* __restrict__ dones, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float* s = st + (size_t)n * TTT_STATE_W;
+  int b[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) b[c] = (int)s[c];
+  const int a = (int)actions[n];
+  float rew = 0.f;
+  int phase = 1;
+  bool legal = false;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) legal = legal || (c == a && b[c] == 0);
+  if (!legal) { rew = -1.f; phase = 2; }
+  else {
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+      if (c == a) b[c] = 1;
+    if (ttt_wins(b, 1)) { rew = 1.f; phase = 2; }
+    else if (ttt_empty(b) == 0) phase = 2;
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    s[c] = (float)b[c];
+    opp_obs[(size_t)n * 18 + 2 * c] = (phase == 1 && b[c] == 2) ? 1.f : 0.f;      // the opponent's own marks
+    opp_obs[(size_t)n * 18 + 2 * c + 1] = (phase == 1 && b[c] == 1) ? 1.f : 0.f;  // the agent's marks
+    opp_masks[(size_t)n * 9 + c] = phase == 1 ? (b[c] == 0 ? 1.f : 0.f) : (c == 0 ? 1.f : 0.f);
+  }
+  s[11] = (float)phase;
+  rewards[n] = rew;
+  dones[n] = phase == 2 ? 1 : 0;
+}
+
+__global__ void ttt_opponent_move_kernel(float* __restrict__ st, float* __restrict__ ep_stats,
+                                         const float* __restrict__ opp_actions, float* __restrict__ obs,
+                                         float* __restrict__ amask, float* __restrict__ rewards,
+                                         uint8_t* __restrict__ dones, int N, uint64_t seed) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float* s = st + (size_t)n * TTT_STATE_W;
+  int b[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) b[c] = (int)s[c];
+  int moves = (int)s[9], episode = (int)s[10];
+  const int phase = (int)s[11];
+  float rew = rewards[n];
+  bool done = phase == 2;
+  if (phase == 1) {
+    int a = (int)opp_actions[n];
+    bool legal = false;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) legal = legal || (c == a && b[c] == 0);
+    if (!legal) {  // cannot happen under the mask; keep the game well-defined: first empty cell
+      a = -1;
+#pragma unroll
+      for (int c = 8; c >= 0; --c)
+        if (b[c] == 0) a = c;
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+      if (c == a) b[c] = 2;
+    ++moves;
+    if (ttt_wins(b, 2)) { rew = -1.f; done = true; }
+    else if (ttt_empty(b) == 0) done = true;
+  }
+  if (ep_stats != nullptr) {
+    float* e = ep_stats + (size_t)n * 4;
+    e[0] += rew; e[1] += 1.f;
+    if (done) { e[2] += e[0]; e[3] += 1.f; e[0] = 0.f; e[1] = 0.f; }
+  }
+  if (done) {
+    ++episode;
+    moves = ttt_begin(b, seed, (uint32_t)n, (uint32_t)episode);  // an opening move of the opponent stays uniform
+  }
+  ttt_write(b, moves, episode, s, obs + (size_t)n * 18, amask + (size_t)n * 9);
+  rewards[n] = rew;
+  dones[n] = done ? 1 : 0;
+}
+
 }  // namespace orl
 
 using namespace orl;
@@ -109,6 +193,23 @@ int orl_ttt_step(float* env_state, float* ep_stats, const float* actions, float*
   hipLaunchKernelGGL(ttt_step_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_state, ep_stats,
                      actions, obs, action_masks, rewards, dones, N, env_seed);
   return launch_status("orl_ttt_step");
+}
+
+int orl_ttt_agent_move(float* env_state, const float* actions, float* opp_obs, float* opp_masks, float* rewards,
+                       uint8_t* dones, int N, void* stream) {
+  ORL_REQUIRE(env_state && actions && opp_obs && opp_masks && rewards && dones && N > 0, "orl_ttt_agent_move: bad arguments");
+  hipLaunchKernelGGL(ttt_agent_move_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_state, actions,
+                     opp_obs, opp_masks, rewards, dones, N);
+  return launch_status("orl_ttt_agent_move");
+}
+
+int orl_ttt_opponent_move(float* env_state, float* ep_stats, const float* opp_actions, float* obs, float* action_masks,
+                          float* rewards, uint8_t* dones, int N, uint64_t env_seed, void* stream) {
+  ORL_REQUIRE(env_state && opp_actions && obs && action_masks && rewards && dones && N > 0,
+              "orl_ttt_opponent_move: bad arguments");
+  hipLaunchKernelGGL(ttt_opponent_move_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_state,
+                     ep_stats, opp_actions, obs, action_masks, rewards, dones, N, env_seed);
+  return launch_status("orl_ttt_opponent_move");
 }
 
 }  // extern "C"

@@ -38,8 +38,10 @@ def make(id: str, env_num: int = 1, asynchronous: bool = False, add_monitor: boo
 
         return MpeSpreadVecEnv(env_num, id, kwargs.pop("world_length", 25), device=device, seed=seed)
     if id == "tictactoe_v3":  # openrl/envs/PettingZoo + selfplay RandomOpponentWrapper (examples/selfplay)
-        from ..vec_env.tictactoe_env import TicTacToeVecEnv
+        from ..vec_env.tictactoe_env import TicTacToeSelfPlayVecEnv, TicTacToeVecEnv
 
+        if kwargs.pop("opponent", "random") == "pool":  # self-play against frozen snapshots of the learner
+            return TicTacToeSelfPlayVecEnv(env_num, id, device=device, seed=seed, pool_size=kwargs.pop("pool_size", 4))
         return TicTacToeVecEnv(env_num, id, device=device, seed=seed)
     raise NotImplementedError(
         "env id %r is not a device-resident env of the MI355X engine (built: 'CartPole-v1', 'simple_spread', 'tictactoe_v3', '%s-v0'); "

@@ -72,3 +72,54 @@ class TicTacToeVecEnv(DeviceVecEnv):
         masks = self.action_mask_device.cpu().numpy()
         infos = [{"action_masks": masks[n]} for n in range(self._n)]
         return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool), infos
+
+
+class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
+    """Self-play variant: the opponent is a POLICY - one of ``pool_size`` frozen snapshots of the learner
+    (``openrl/selfplay/wrappers/opponent_pool_wrapper.py:37-120`` plays earlier checkpoints).
+
+    Env group g (the g-th contiguous block of N / pool_size envs) plays snapshot g.  A step is three device stages:
+    ``orl_ttt_agent_move`` -> one ``orl_act_step`` per snapshot on the opponent-side boards (sampled under the legal-
+    move masks) -> ``orl_ttt_opponent_move``; all of them capturable, so the stepwise rollout still replays as one
+    hipGraph.  Snapshots are refreshed in place with ``push_opponent(theta)`` (round-robin), e.g. by
+    ``SelfPlayCallback``.  Until the first push every slot holds all-zero parameters = the uniformly random opponent.
+    Not the reference's selfplay API / per-reset opponent sampling: the assignment of snapshots to envs is static."""
+
+    def __init__(self, env_num: int, env_name: str = "tictactoe_v3", device="cuda:0", seed: int = 0, pool_size: int = 4):
+        super().__init__(env_num, env_name, device=device, seed=seed)
+        from ... import ops
+
+        self.kind = "tictactoe_selfplay_pool"
+        self.env_kind = None
+        self.supports_fused_rollout = False  # the in-kernel game of orl_rollout_fused only has the random opponent
+        self.pool_size = max(1, min(int(pool_size), self._n))
+        self.opp_net = nat.NetDesc(self.OBS, 64, self.N_ACT, nat.ORL_HEAD_CATEGORICAL)
+        self.opp_thetas = torch.zeros(self.pool_size, ops.param_count(self.opp_net), device=self.device)
+        self.opp_seed = (self.seed * 2654435761 + 0x5E1F) & (2 ** 63 - 1)
+        self.pushes = 0
+        z = lambda *s, **k: torch.zeros(*s, device=self.device, **k)
+        self._opp_obs, self._opp_mask = z(self._n, self.OBS), z(self._n, self.N_ACT)
+        self._opp_act, self._opp_lp = z(self._n, 1), z(self._n, 1)
+        b = [round(g * self._n / self.pool_size) for g in range(self.pool_size + 1)]
+        self._groups = [(b[g], b[g + 1]) for g in range(self.pool_size) if b[g + 1] > b[g]]
+
+    def push_opponent(self, theta: torch.Tensor) -> int:
+        """Store a snapshot of the learner's policy parameters in the next pool slot (in place: graph-safe)."""
+        slot = self.pushes % self.pool_size
+        self.opp_thetas[slot].copy_(theta.detach().to(self.device).reshape(-1))
+        self.pushes += 1
+        return slot
+
+    def step_device(self, actions: torch.Tensor):
+        from ... import ops
+
+        a = actions.to(self.device, torch.float32).reshape(self._n).contiguous()
+        ops_rnn.ttt_agent_move(self.env_state, a, self._opp_obs, self._opp_mask, self._rew, self._done, self._n)
+        for g, (r0, r1) in enumerate(self._groups):
+            ops.act_step(self.opp_net, self.opp_thetas[g], None, None, self._opp_obs[r0:r1], None, self._opp_mask[r0:r1],
+                         r1 - r0, False, self.opp_seed, r0, self.global_step, None, None, self._opp_act[r0:r1],
+                         self._opp_lp[r0:r1])
+        ops_rnn.ttt_opponent_move(self.env_state, self.ep_stats, self._opp_act, self.obs, self.action_mask_device,
+                                  self._rew, self._done, self._n, self.seed)
+        self.global_step += 1
+        return self.obs, self._rew, self._done

@@ -115,3 +115,17 @@ def ttt_step(env_state, ep_stats, actions, obs, action_masks, rewards, dones, N:
     rc = _lib().orl_ttt_step(fptr(env_state), fptr(ep_stats), fptr(actions), fptr(obs), fptr(action_masks),
                              fptr(rewards), ptr(dones), N, seed & (2 ** 64 - 1), stream_ptr(dev))
     nat.check(rc, "orl_ttt_step")
+
+
+def ttt_agent_move(env_state, actions, opp_obs, opp_masks, rewards, dones, N: int) -> None:
+    dev = _dev(env_state)
+    rc = _lib().orl_ttt_agent_move(fptr(env_state), fptr(actions), fptr(opp_obs), fptr(opp_masks), fptr(rewards),
+                                   ptr(dones), N, stream_ptr(dev))
+    nat.check(rc, "orl_ttt_agent_move")
+
+
+def ttt_opponent_move(env_state, ep_stats, opp_actions, obs, action_masks, rewards, dones, N: int, seed: int) -> None:
+    dev = _dev(env_state)
+    rc = _lib().orl_ttt_opponent_move(fptr(env_state), fptr(ep_stats), fptr(opp_actions), fptr(obs), fptr(action_masks),
+                                      fptr(rewards), ptr(dones), N, seed & (2 ** 64 - 1), stream_ptr(dev))
+    nat.check(rc, "orl_ttt_opponent_move")

@@ -73,6 +73,22 @@ class NoopCallback(BaseCallback):
     needs_per_step = False
 
 
+class SelfPlayCallback(BaseCallback):
+    """Every ``push_every`` rollouts, store a snapshot of the learner's policy in the env's opponent pool
+    (``TicTacToeSelfPlayVecEnv.push_opponent``) - the role of the reference's selfplay callbacks / OpponentPoolWrapper."""
+    needs_per_step = False
+
+    def __init__(self, push_every: int = 10, verbose: int = 0):
+        super().__init__(verbose)
+        self.push_every, self.rollouts = int(push_every), 0
+
+    def _on_rollout_start(self) -> None:
+        env = self.agent.net.env if getattr(self.agent, "net", None) is not None else None
+        if env is not None and hasattr(env, "push_opponent") and self.rollouts % self.push_every == 0 and self.rollouts:
+            env.push_opponent(self.agent.net.module.models["policy"].theta)
+        self.rollouts += 1
+
+
 class ConvertCallback(BaseCallback):
     def __init__(self, callback: Callable[[Dict[str, Any], Dict[str, Any]], bool], verbose: int = 0):
         super().__init__(verbose)

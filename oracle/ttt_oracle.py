@@ -78,3 +78,44 @@ class Game:
             self.episode += 1
             self.board, self.moves = begin(self.seed, self.env, self.episode)
         return rew, done
+
+    # ---- two-phase step (orl_ttt_agent_move / orl_ttt_opponent_move): the opponent's reply is supplied by the caller
+    def agent_move(self, a: int):
+        """Returns (reward, done, pending): pending = the game is open and waits for the opponent's reply."""
+        self._rew, self._phase = 0.0, 1
+        if not (0 <= a < 9) or self.board[a] != 0:
+            self._rew, self._phase = -1.0, 2
+        else:
+            self.board[a] = 1
+            if wins(self.board, 1):
+                self._rew, self._phase = 1.0, 2
+            elif 0 not in self.board:
+                self._phase = 2
+        return self._rew, self._phase == 2, self._phase == 1
+
+    def opponent_view(self):
+        o, m = np.zeros(18, np.float32), np.zeros(9, np.float32)
+        if self._phase == 1:
+            for c in range(9):
+                o[2 * c] = self.board[c] == 2
+                o[2 * c + 1] = self.board[c] == 1
+                m[c] = self.board[c] == 0
+        else:
+            m[0] = 1.0
+        return o, m
+
+    def opponent_move(self, a: int):
+        rew, done = self._rew, self._phase == 2
+        if self._phase == 1:
+            if not (0 <= a < 9) or self.board[a] != 0:
+                a = min(c for c in range(9) if self.board[c] == 0)
+            self.board[a] = 2
+            self.moves += 1
+            if wins(self.board, 2):
+                rew, done = -1.0, True
+            elif 0 not in self.board:
+                done = True
+        if done:
+            self.episode += 1
+            self.board, self.moves = begin(self.seed, self.env, self.episode)
+        return rew, done

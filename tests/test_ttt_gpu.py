@@ -163,3 +163,71 @@ def test_ppo_beats_the_random_opponent():
         curve.append(float(d.rewards.sum() / ends))  # mean result of the games finished in this rollout
     first, last = np.mean(curve[:3]), np.mean(curve[-10:])
     assert abs(first) < 0.25 and last > first + 0.4, (first, last)
+
+
+def test_two_phase_step_matches_oracle_with_scripted_opponent():
+    """orl_ttt_agent_move + orl_ttt_opponent_move (the self-play step) against the oracle, the opponent's replies drawn
+    by the test from the opponent-side masks the first kernel wrote."""
+    from openrl_amd import ops_rnn
+
+    N, S, seed = 200, 30, 9
+    z = lambda *s, **k: torch.zeros(*s, device=DEV, **k)
+    st, eps, obs, mask = z(N, ops_rnn.ttt_state_width()), z(N, 4), z(N, 18), z(N, 9)
+    oobs, omask, rew, done = z(N, 18), z(N, 9), z(N), z(N, dtype=torch.uint8)
+    ops_rnn.ttt_reset(st, eps, obs, mask, N, seed)
+    games = [to.Game(seed, n) for n in range(N)]
+    rs = np.random.RandomState(1)
+    for s in range(S):
+        m = mask.cpu().numpy()
+        acts = np.array([rs.choice(np.flatnonzero(m[n])) for n in range(N)], np.float32)
+        ops_rnn.ttt_agent_move(st, torch.tensor(acts, device=DEV), oobs, omask, rew, done, N)
+        oo, om, r1, d1 = oobs.cpu().numpy(), omask.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        opp = np.zeros(N, np.float32)
+        for n in range(N):
+            wr, wd, pending = games[n].agent_move(int(acts[n]))
+            wo, wm = games[n].opponent_view()
+            assert (r1[n], bool(d1[n])) == (wr, wd) and np.array_equal(oo[n], wo) and np.array_equal(om[n], wm), (s, n)
+            opp[n] = rs.choice(np.flatnonzero(wm))
+        ops_rnn.ttt_opponent_move(st, eps, torch.tensor(opp, device=DEV), obs, mask, rew, done, N, seed)
+        r2, d2, o2, m2 = rew.cpu().numpy(), done.cpu().numpy(), obs.cpu().numpy(), mask.cpu().numpy()
+        for n in range(N):
+            wr, wd = games[n].opponent_move(int(opp[n]))
+            assert (r2[n], bool(d2[n])) == (wr, wd), (s, n)
+            assert np.array_equal(o2[n], games[n].obs()) and np.array_equal(m2[n], games[n].mask())
+    assert float(eps[:, 3].sum()) > N  # games were finished and counted
+
+
+def test_selfplay_pool_env_and_callback_end_to_end():
+    """make("tictactoe_v3", opponent="pool"): opponents are frozen snapshots of the learner, refreshed by
+    SelfPlayCallback through PPOAgent.train; afterwards the learner beats the uniformly random opponent."""
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+    from openrl_amd.runners.common import PPOAgent
+    from openrl_amd.utils.callbacks import SelfPlayCallback
+
+    N, T = 1024, 10
+    cfg = default_cfg(["--seed", "0", "--lr", "1e-3", "--critic_lr", "1e-3", "--episode_length", str(T), "--ppo_epoch", "5",
+                       "--amd_perm_mode", "device", "--log_interval", "1000000"])
+    env = make("tictactoe_v3", env_num=N, device=DEV, opponent="pool", pool_size=3)
+    # before any snapshot: all-zero parameters = uniform over the legal moves (log-prob = -log(#empty cells))
+    env.reset_device(seed=0)
+    env.step_device(torch.zeros(N, 1, 1, device=DEV))
+    lp = env._opp_lp.view(-1).cpu().numpy()
+    n_legal = env._opp_mask.sum(-1).cpu().numpy()
+    np.testing.assert_allclose(lp, -np.log(n_legal), rtol=1e-5, atol=1e-6)
+    net = PPONet(env, cfg=cfg, device=DEV)
+    agent = PPOAgent(net)
+    agent.train(total_time_steps=N * T * 80, callback=SelfPlayCallback(push_every=10))
+    assert env.pushes == 7 and not agent.driver.fused and agent.driver._graph is not None
+    assert env.opp_thetas.abs().sum(dim=1).min() > 0  # every slot holds a real snapshot by now
+    for m in net.module.models.values():
+        assert torch.isfinite(m.theta).all()
+    # evaluation against the uniformly random opponent
+    ev = make("tictactoe_v3", env_num=2048, device=DEV, seed=123)
+    obs = ev.reset_device(seed=123)
+    for _ in range(40):
+        a, _ = net.module.act(obs.view(2048, 18), None, None, action_masks=ev.action_mask_device.view(2048, 9), deterministic=True)
+        obs, _, _ = ev.step_device(a.view(2048, 1, 1))
+    st = ev.episode_statistics()
+    assert st["episodes_finished"] > 2048 * 5 and st["episode_return_mean"] > 0.5, st
