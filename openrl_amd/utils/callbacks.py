@@ -137,6 +137,100 @@ class CallbackList(BaseCallback):
             c.update_locals(locals_)
 
 
+class EveryNTimesteps(BaseCallback):
+    """Trigger ``callback`` every ``n_steps`` timesteps (openrl/utils/callbacks/callbacks.py EveryNTimesteps)."""
+
+    def __init__(self, n_steps: int, callback: BaseCallback):
+        super().__init__()
+        self.n_steps, self.last_time_trigger, self.callback = int(n_steps), 0, callback
+
+    def _init_callback(self) -> None:
+        self.callback.parent = self
+        self.callback.init_callback(self.agent)
+
+    def _on_step(self) -> bool:
+        if (self.num_time_steps - self.last_time_trigger) >= self.n_steps:
+            self.last_time_trigger = self.num_time_steps
+            return self.callback.on_step()
+        return True
+
+    def update_child_locals(self, locals_: Dict[str, Any]) -> None:
+        self.callback.update_locals(locals_)
+
+
+class CheckpointCallback(BaseCallback):
+    """``agent.save(save_path/{name_prefix}_{num_time_steps}_steps)`` every ``save_freq`` calls
+    (openrl/utils/callbacks/checkpoint_callback.py:28-100; replay-buffer checkpoints are not built)."""
+
+    def __init__(self, save_freq: int, save_path: str, name_prefix: str = "rl_model", save_replay_buffer: bool = False,
+                 verbose: int = 0):
+        super().__init__(verbose)
+        self.save_freq, self.save_path, self.name_prefix = int(save_freq), str(save_path), name_prefix
+        self.saved: List[str] = []
+
+    def _init_callback(self) -> None:
+        import os
+
+        os.makedirs(self.save_path, exist_ok=True)
+
+    def _on_step(self) -> bool:
+        if self.n_calls % self.save_freq == 0:
+            import os
+
+            path = os.path.join(self.save_path, "%s_%d_steps" % (self.name_prefix, self.num_time_steps))
+            self.agent.save(path)
+            self.saved.append(path)
+            if self.verbose >= 2:
+                print("Saving model checkpoint to %s" % path)
+        return True
+
+
+class StopTrainingOnMaxEpisodes(BaseCallback):
+    """Stop once ``max_episodes`` episodes per env have finished (stop_callback.py:60-100): counts ``dones`` of the
+    driver's locals, so it forces the stepwise rollout."""
+
+    def __init__(self, max_episodes: int, verbose: int = 0):
+        super().__init__(verbose)
+        self.max_episodes, self.n_episodes, self._total = int(max_episodes), 0, int(max_episodes)
+
+    def _init_callback(self) -> None:
+        env = getattr(getattr(self.agent, "net", None), "env", None) or getattr(self.agent, "_env", None)
+        self._total = self.max_episodes * int(getattr(env, "parallel_env_num", 1))
+
+    def _on_step(self) -> bool:
+        assert "dones" in self.locals, "`dones` variable is not defined next to callback.on_step()"
+        d = self.locals["dones"]
+        self.n_episodes += int(d.sum().item() if hasattr(d, "sum") else sum(d))
+        return self.n_episodes < self._total
+
+
+class ProgressBarCallback(BaseCallback):
+    """Placeholder for the reference's rich progress bar (processbar_callback.py): counts steps, draws nothing."""
+    needs_per_step = False
+
+
+CALLBACKS = {"CheckpointCallback": CheckpointCallback, "StopTrainingOnMaxEpisodes": StopTrainingOnMaxEpisodes,
+             "ProgressBarCallback": ProgressBarCallback, "EveryNTimesteps": EveryNTimesteps,
+             "SelfPlayCallback": SelfPlayCallback}
+
+
+class CallbackFactory:
+    """``cfg.callbacks`` entries ``{"id": ..., "args": {...}}`` -> callback objects (callbacks_factory.py:14-60).
+    EvalCallback / StopTrainingOnRewardThreshold / StopTrainingOnNoModelImprovement / SelfplayAPI are not built."""
+
+    @staticmethod
+    def get_callback(spec: Dict[str, Any]) -> BaseCallback:
+        if spec["id"] not in CALLBACKS:
+            raise ValueError("Callback %s not found (built: %s)" % (spec["id"], ", ".join(sorted(CALLBACKS))))
+        return CALLBACKS[spec["id"]](**spec.get("args", {}))
+
+    @staticmethod
+    def get_callbacks(specs) -> "CallbackList":
+        if isinstance(specs, dict):
+            specs = [specs]
+        return CallbackList([CallbackFactory.get_callback(s) for s in specs])
+
+
 MaybeCallback = Union[None, Callable, List[BaseCallback], BaseCallback]
 
 

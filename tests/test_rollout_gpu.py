@@ -170,6 +170,34 @@ def test_agent_train_api_and_callbacks():
     assert o.shape == (9, 1, 4) and r.shape == (9, 1, 1) and d.shape == (9, 1)
 
 
+def test_callback_factory_checkpoint_and_stop_on_max_episodes(tmp_path):
+    """cfg.callbacks-style specs (examples/cartpole/callbacks.yaml) through CallbackFactory: training stops after
+    max_episodes per env, checkpoints land where asked and load back."""
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import PPOAgent as Agent
+    from openrl_amd.utils.callbacks import CallbackFactory
+
+    cfg = _cfg(["--episode_length", "16", "--ppo_epoch", "1"])
+    env = make("CartPole-v1", env_num=8, device=DEV)
+    agent = Agent(Net(env, cfg=cfg, device=DEV))
+    cbs = CallbackFactory.get_callbacks([
+        {"id": "ProgressBarCallback"},
+        {"id": "StopTrainingOnMaxEpisodes", "args": {"max_episodes": 3, "verbose": 1}},
+        {"id": "CheckpointCallback", "args": {"save_freq": 20, "save_path": str(tmp_path / "ck"), "name_prefix": "ppo"}}])
+    agent.train(total_time_steps=8 * 16 * 400, callback=cbs)
+    stop, ck = cbs.callbacks[1], cbs.callbacks[2]
+    assert 8 * 3 <= stop.n_episodes < 8 * 3 + 8 and agent.num_time_steps < 8 * 16 * 400  # stopped early
+    assert len(ck.saved) == agent.num_time_steps // 8 // 20 and len(ck.saved) >= 1
+    theta = agent.net.module.models["policy"].theta.clone()
+    agent.net.module.models["policy"].theta.zero_()
+    agent.load(ck.saved[-1])
+    assert agent.net.module.models["policy"].theta.abs().sum() > 0
+    with pytest.raises(ValueError):
+        CallbackFactory.get_callback({"id": "EvalCallback"})
+    del theta
+
+
 def test_cartpole_learns_like_the_reference_recipe(tmp_path):
     """The reference's behavioural test (tests/test_examples/test_train_cartpole.py:39-54): default cfg, 9 envs,
     20 000 steps, then a deterministic rollout.  Its own >= 450 bar is on the FIRST termination among the 9
