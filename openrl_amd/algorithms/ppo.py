@@ -28,6 +28,81 @@ from .base_algorithm import BaseAlgorithm
 INFO_KEYS = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
 
 
+class DeviceTrainInfo(dict):
+    """The train_info dict of ``PPOAlgorithm.train`` (ppo.py:445-458) whose values are still on the device: the one
+    device->host copy happens on first access (any read of the dict), not at the end of every update."""
+
+    def __init__(self, keys, device_values: torch.Tensor):
+        super().__init__()
+        self._keys, self._dev = tuple(keys), device_values
+
+    def _materialize(self) -> None:
+        if self._dev is not None:
+            vals, self._dev = self._dev.cpu().tolist(), None
+            for k, v in zip(self._keys, vals):
+                super().__setitem__(k, v)
+
+    def __getitem__(self, k):
+        self._materialize()
+        return super().__getitem__(k)
+
+    def __iter__(self):
+        self._materialize()
+        return super().__iter__()
+
+    def __len__(self):
+        self._materialize()
+        return super().__len__()
+
+    def __contains__(self, k):
+        self._materialize()
+        return super().__contains__(k)
+
+    def __repr__(self):
+        self._materialize()
+        return super().__repr__()
+
+    def __eq__(self, other):
+        self._materialize()
+        return super().__eq__(other)
+
+    def get(self, k, default=None):
+        self._materialize()
+        return super().get(k, default)
+
+    def keys(self):
+        self._materialize()
+        return super().keys()
+
+    def values(self):
+        self._materialize()
+        return super().values()
+
+    def items(self):
+        self._materialize()
+        return super().items()
+
+    def copy(self):
+        self._materialize()
+        return dict(self)
+
+    def pop(self, *a):
+        self._materialize()
+        return super().pop(*a)
+
+    def update(self, *a, **k):
+        self._materialize()
+        return super().update(*a, **k)
+
+    def __setitem__(self, k, v):
+        self._materialize()
+        super().__setitem__(k, v)
+
+    def __delitem__(self, k):
+        self._materialize()
+        super().__delitem__(k)
+
+
 class PPOAlgorithm(BaseAlgorithm):
     def __init__(self, cfg, init_module, agent_num: int = 1, device: Union[str, torch.device] = "cuda:0") -> None:
         if cfg.use_share_model or cfg.use_joint_action_loss or cfg.use_deepspeed or cfg.use_amp:
@@ -233,10 +308,13 @@ class PPOAlgorithm(BaseAlgorithm):
                     job = self._perm_job(M)
                 next_perm = self._update_minibatch(buffer, idx, mbs, turn_on, job)
         num_updates = self.ppo_epoch * self.num_mini_batch
-        vals = (self._info[:6] / float(num_updates)).cpu().tolist()  # the only device->host sync of train()
-        return {k: v for k, v in zip(INFO_KEYS, vals)}
+        # no device->host sync here: the averages stay on the device until somebody reads the dict (logging every
+        # log_interval iterations, tests), so the host can enqueue the next rollout while this update still runs
+        return DeviceTrainInfo(INFO_KEYS, self._info[:6] / float(num_updates))
 
     def train(self, buffer, turn_on: bool = True) -> Dict[str, float]:
+        if len(self.train_list) == 1:
+            return self.train_list[0](buffer, turn_on)  # keeps a DeviceTrainInfo lazy
         train_info = {}
         for train_func in self.train_list:
             train_info.update(train_func(buffer, turn_on))
