@@ -145,6 +145,17 @@ int orl_buffer_insert_rnn(const orl_buffer_ptrs* buf, int step, const float* nex
                           const uint8_t* bad_transition, const float* next_action_masks, float* h_policy_next,
                           float* h_critic_next, int hidden, void* stream);
 
+/* ReplayData.after_update (openrl/buffers/replay_data.py:286-318): dst[k][0..n[k]) = src[k][0..n[k]) for up to 8
+ * float arrays in one launch (slot T -> slot 0 of the per-step arrays). */
+#define ORL_COPY_MAX 8
+typedef struct orl_copy_desc {
+  const float* src[ORL_COPY_MAX];
+  float* dst[ORL_COPY_MAX];
+  int64_t n[ORL_COPY_MAX];
+  int32_t count;
+} orl_copy_desc;
+int orl_multi_copy(const orl_copy_desc* desc, void* stream);
+
 /* ---- K8: minibatch gather ------------------------------------------------------------------------
  * Replaces the fancy-index gathers of ReplayData.feed_forward_generator
  * (openrl/buffers/replay_data.py:615-646): dst[i, :] = src[idx[i], :] for up to 12 arrays at once.

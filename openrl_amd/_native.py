@@ -46,6 +46,10 @@ class BufferPtrs(C.Structure):
                 ("K", C.c_int32)]
 
 
+class CopyDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p * 8), ("dst", C.c_void_p * 8), ("n", C.c_int64 * 8), ("count", C.c_int32)]
+
+
 class GatherDesc(C.Structure):
     _fields_ = [("src", C.c_void_p * ORL_GATHER_MAX), ("dst", C.c_void_p * ORL_GATHER_MAX),
                 ("width", C.c_int32 * ORL_GATHER_MAX), ("count", C.c_int32)]
@@ -93,6 +97,7 @@ _SIGNATURES = {
     "orl_adv_normalize_pack": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(PackSrc), _P, _P]),
     "orl_buffer_insert": (C.c_int, [C.POINTER(BufferPtrs), C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "orl_buffer_insert_rnn": (C.c_int, [C.POINTER(BufferPtrs), C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "orl_multi_copy": (C.c_int, [C.POINTER(CopyDesc), _P]),
     "orl_gather_minibatch": (C.c_int, [C.POINTER(GatherDesc), _P, C.c_int, _P]),
     "orl_perm_feistel": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "orl_perm_feistel_vn": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, C.c_double, _P]),

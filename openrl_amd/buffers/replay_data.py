@@ -136,17 +136,16 @@ class ReplayData(object):
 
     def after_update(self):
         assert self.step == 0, "step:{} episode:{}".format(self.step, self.episode_length)
-        self.policy_obs[0].copy_(self.policy_obs[-1])
+        pairs = [(self.policy_obs[0], self.policy_obs[-1])]
         if self.critic_obs is not self.policy_obs:
-            self.critic_obs[0].copy_(self.critic_obs[-1])
+            pairs.append((self.critic_obs[0], self.critic_obs[-1]))
         if self.rnn_states.stride(0) != 0:
-            self.rnn_states[0].copy_(self.rnn_states[-1])
-            self.rnn_states_critic[0].copy_(self.rnn_states_critic[-1])
-        self.masks[0].copy_(self.masks[-1])
-        self.bad_masks[0].copy_(self.bad_masks[-1])
-        self.active_masks[0].copy_(self.active_masks[-1])
+            pairs += [(self.rnn_states[0], self.rnn_states[-1]), (self.rnn_states_critic[0], self.rnn_states_critic[-1])]
+        pairs += [(self.masks[0], self.masks[-1]), (self.bad_masks[0], self.bad_masks[-1]),
+                  (self.active_masks[0], self.active_masks[-1])]
         if self.action_masks is not None:
-            self.action_masks[0].copy_(self.action_masks[-1])
+            pairs.append((self.action_masks[0], self.action_masks[-1]))
+        ops.multi_copy(pairs)  # one launch (orl_multi_copy) instead of one copy per array
 
     def compute_returns(self, next_value, value_normalizer=None):
         """K6 on the device (replay_data.py:320-423) + the fused advantage statistics (K7a)."""

@@ -390,6 +390,20 @@ __global__ __launch_bounds__(256) void buffer_insert_kernel(orl_buffer_ptrs b, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// ReplayData.after_update (replay_data.py:286-318): slot T -> slot 0 of every per-step array, one launch instead of
+// one copy per array.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void multi_copy_kernel(orl_copy_desc d) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = 0; k < d.count; ++k) {
+    const float* __restrict__ src = d.src[k];
+    float* __restrict__ dst = d.dst[k];
+    for (long long i = i0; i < d.n[k]; i += stride) dst[i] = src[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K8: multi-array row gather.  One thread per output float; descriptors live in kernel args.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_kernel(orl_gather_desc d, const int64_t* __restrict__ idx, int n_rows,
@@ -623,6 +637,20 @@ int orl_buffer_insert_rnn(const orl_buffer_ptrs* buf, int step, const float* nex
                      next_policy_obs, next_critic_obs, rewards, dones, bad_transition, next_action_masks,
                      h_policy_next, h_critic_next, hidden);
   return launch_status("orl_buffer_insert");
+}
+
+int orl_multi_copy(const orl_copy_desc* desc, void* stream) {
+  ORL_REQUIRE(desc && desc->count >= 0 && desc->count <= ORL_COPY_MAX, "orl_multi_copy: bad descriptor");
+  long long most = 0;
+  for (int k = 0; k < desc->count; ++k) {
+    ORL_REQUIRE(desc->src[k] && desc->dst[k] && desc->n[k] >= 0, "orl_multi_copy: bad entry %d", k);
+    if (desc->n[k] > most) most = desc->n[k];
+  }
+  if (desc->count == 0 || most == 0) return 0;
+  int grid = (int)((most + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *desc);
+  return launch_status("orl_multi_copy");
 }
 
 int orl_gather_minibatch(const orl_gather_desc* desc, const int64_t* idx, int n_rows, void* stream) {

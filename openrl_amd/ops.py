@@ -112,6 +112,16 @@ def buffer_insert(buf: BufferPtrs, step: int, next_policy_obs, next_critic_obs, 
     nat.check(rc, "orl_buffer_insert")
 
 
+def multi_copy(pairs) -> None:
+    """dst.copy_(src) for up to 8 (dst, src) pairs of contiguous float32 tensors in ONE launch (orl_multi_copy)."""
+    d = nat.CopyDesc()
+    d.count = len(pairs)
+    for k, (dst, src) in enumerate(pairs):
+        d.dst[k], d.src[k], d.n[k] = dst.data_ptr(), src.data_ptr(), src.numel()
+    rc = _lib().orl_multi_copy(C.byref(d), stream_ptr(_dev(pairs[0][0])))
+    nat.check(rc, "orl_multi_copy")
+
+
 def gather_minibatch(srcs: Sequence[torch.Tensor], idx: torch.Tensor) -> List[torch.Tensor]:
     """dst[k][i, :] = srcs[k][idx[i], :] for up to 12 row-major 2-D float32 arrays in one launch."""
     dev = _dev(idx)
