@@ -91,7 +91,8 @@ int orl_adv_stats(const float* returns, const float* value_preds, const float* a
  * Replaces openrl/algorithms/ppo.py:402-409: optional global (x-mean)/(std+1e-5) (use_adv_normalize)
  * followed - always - by the same transform with nanmean/nanstd over entries whose active mask != 0.
  * Reads the partials of orl_gae_scan; writes adv [T*L] in place over adv_raw (may alias).
- * stats_out (device, 8 doubles, optional): the reduced sums, for logging / all-reduce.
+ * stats_out (device, 11 doubles, optional): the 8 reduced sums, then {sum ret, sum ret^2, count} = the moments
+ * orl_valuenorm_update takes when one minibatch is the whole batch (no extra pass, no gather).
  * When `records` != NULL also packs the per-sample update record (see orl_record_width):
  *   [policy_obs Dp | critic_obs Dc | action a | old_logp a | adv | value_pred | return | active | action_mask K]
  * in flat row order (t*N+n)*A+a, i.e. the row order of feed_forward_generator

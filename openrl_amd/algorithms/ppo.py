@@ -128,8 +128,8 @@ class PPOAlgorithm(BaseAlgorithm):
         self._info = torch.zeros(8, dtype=torch.float32, device=dev)
         self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
         self._mom_scratch = torch.zeros(512, dtype=torch.float64, device=dev)
-        self._adv_stats = torch.zeros(8, dtype=torch.float64, device=dev)
-        self._mom_sel = torch.tensor([6, 7, 2], dtype=torch.int64, device=dev)
+        self._adv_stats = torch.zeros(11, dtype=torch.float64, device=dev)  # 8 sums + the full-batch return moments
+        self._moments_mb = self._moments
         self._full_batch_moments = False
         self.perm_mode = getattr(cfg, "amd_perm_mode", "reference")
         self._perm_counter = 0
@@ -285,8 +285,8 @@ class PPOAlgorithm(BaseAlgorithm):
         M = buffer.episode_length * buffer.n_rollout_threads * buffer.num_agents
         # one minibatch == every sample (recurrent: every chunk, when the chunks tile the batch exactly)
         self._full_batch_moments = self.num_mini_batch == 1 and (not self.recurrent or M % self.data_chunk_length == 0)
-        if self._full_batch_moments:
-            self._moments.copy_(self._adv_stats[self._mom_sel])  # {sum ret, sum ret^2, count}
+        # full batch: {sum ret, sum ret^2, count} are already in the statistics row the pack kernel wrote (a view, no copy)
+        self._moments = self._adv_stats[8:11] if self._full_batch_moments else self._moments_mb
         self._info.zero_()
         self.last_indices = []
         next_perm = None

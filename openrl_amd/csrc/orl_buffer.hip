@@ -266,6 +266,8 @@ __global__ __launch_bounds__(256) void adv_normalize_pack_kernel(float* __restri
   reduce_partials(partials, n_partials, st);
   if (blockIdx.x == 0 && threadIdx.x == 0 && stats_out != nullptr) {
     for (int k = 0; k < 8; ++k) stats_out[k] = st[k];
+    // {sum ret, sum ret^2, count}: the moments ValueNorm.update takes when one minibatch is the whole batch
+    stats_out[8] = st[6]; stats_out[9] = st[7]; stats_out[10] = st[2];
   }
   AdvCoef c;
   // stage 1 (optional): numpy mean()/std() over ALL entries (ppo.py:402-403)

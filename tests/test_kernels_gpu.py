@@ -157,7 +157,7 @@ def test_advantage_normalisation_and_record_packing(ops, use_adv_norm, use_vn, T
 
     src = PackSrc(fptr(d_pobs), fptr(d_cobs), fptr(d_act), fptr(d_lp), fptr(d_vp), fptr(d_ret), fptr(d_active),
                   fptr(d_am), Dp, Dc, 1, K)
-    stats = torch.zeros(8, dtype=torch.float64, device=DEV)
+    stats = torch.zeros(11, dtype=torch.float64, device=DEV)
     ops.adv_normalize_pack(adv, partials, n_part, T, L, use_adv_norm, stats, src, rec)
     got_adv = adv.cpu().numpy()
     # fp32 tolerance: reductions differ in order (double tree on device vs numpy pairwise fp32)
