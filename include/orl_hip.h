@@ -200,6 +200,12 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
                  const float* action_masks, int B, int deterministic, uint64_t seed, uint64_t row0,
                  uint64_t rng_step, const float* forced_u, float* values, float* actions, float* logp,
                  void* stream);
+/* orl_act_step (policy only) for a POOL of policies of one architecture in one launch: rows
+ * [g*rows_per_group, (g+1)*rows_per_group) are evaluated with the parameters pthetas + g*theta_stride
+ * (rows_per_group a multiple of 16).  The self-play env uses it for the opponents' moves. */
+int orl_act_step_grouped(const orl_net_desc* pnet, const float* pthetas, int64_t theta_stride, int rows_per_group,
+                         const float* policy_obs, const float* action_masks, int B, int deterministic, uint64_t seed,
+                         uint64_t row0, uint64_t rng_step, float* actions, float* logp, void* stream);
 
 /* Optional device-side addend of `rng_step` for orl_act_step / orl_rnn_act_step launched afterwards from this host
  * thread (NULL switches it off): rng_step_effective = rng_step + *dev_counter, read by the kernel at run time.  It

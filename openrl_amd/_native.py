@@ -109,6 +109,8 @@ _SIGNATURES = {
     "orl_ttt_agent_move": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "orl_ttt_opponent_move": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "orl_critic_values": (C.c_int, [C.POINTER(NetDesc), _P, _P, C.c_int64, _P, _P]),
+    "orl_act_step_grouped": (C.c_int, [C.POINTER(NetDesc), _P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64,
+                                       C.c_uint64, C.c_uint64, _P, _P, _P]),
     "orl_evaluate_actions": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, C.c_int, _P,
                                        _P, _P, _P, _P]),
     "orl_ppo_max_blocks": (C.c_int, []),

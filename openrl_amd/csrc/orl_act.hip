@@ -31,6 +31,8 @@ struct ActArgs {
   int deterministic;
   uint64_t seed, row0, rng_step;
   const unsigned long long* rng_dev;  // optional device-side addend of rng_step (orl_act_rng_offset)
+  int group_rows;          // > 0: rows [g*group_rows, (g+1)*group_rows) use the policy parameters ptheta + g*theta_stride
+  long long theta_stride;  //      (orl_act_step_grouped: one launch for a pool of policies); a multiple of 16 rows
 };
 
 template <int NO, int HEAD>
@@ -43,7 +45,9 @@ __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
   TowerLds twc;
   const bool has_c = A.ctheta != nullptr;
   const bool has_p = A.ptheta != nullptr;
-  if (has_p) stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
+  const float* ptheta = A.ptheta;
+  if (has_p && A.group_rows > 0) ptheta += (size_t)((blockIdx.x * TILE_B) / A.group_rows) * A.theta_stride;
+  if (has_p) stage_tower(smem, ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
   if (has_c) {
     tlc = TowerLayout(A.cnet);
     twc = TowerLds(A.cnet.obs_dim, 1, false, false);
@@ -782,7 +786,7 @@ using namespace orl;
 
 extern "C" {
 
-int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+static int act_step_impl(const char* what, int group_rows, long long theta_stride, const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                  const float* policy_obs, const float* critic_obs, const float* action_masks, int B,
                  int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const float* forced_u,
                  float* values, float* actions, float* logp, void* stream) {
@@ -808,6 +812,7 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
   A.ptheta = ptheta; A.ctheta = ctheta; A.pobs = policy_obs; A.cobs = critic_obs; A.amask = action_masks;
   A.forced = forced_u; A.values = values; A.actions = actions; A.logp = logp; A.B = B;
   A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step; A.rng_dev = g_rng_dev;
+  A.group_rows = group_rows; A.theta_stride = theta_stride;
   const int grid = (B + TILE_B - 1) / TILE_B;
 #define ORL_ACT_LAUNCH(NO, HD)                                                                                  \
   do {                                                                                                          \
@@ -818,7 +823,24 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
   } while (0)
   ORL_DISPATCH_HEAD(ORL_ACT_LAUNCH);
 #undef ORL_ACT_LAUNCH
-  return launch_status("orl_act_step");
+  return launch_status(what);
+}
+
+int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                 const float* policy_obs, const float* critic_obs, const float* action_masks, int B, int deterministic,
+                 uint64_t seed, uint64_t row0, uint64_t rng_step, const float* forced_u, float* values, float* actions,
+                 float* logp, void* stream) {
+  return act_step_impl("orl_act_step", 0, 0, pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, action_masks, B, deterministic, seed, row0, rng_step, forced_u, values, actions, logp, stream);
+}
+
+int orl_act_step_grouped(const orl_net_desc* pnet, const float* pthetas, int64_t theta_stride, int rows_per_group,
+                         const float* policy_obs, const float* action_masks, int B, int deterministic, uint64_t seed,
+                         uint64_t row0, uint64_t rng_step, float* actions, float* logp, void* stream) {
+  ORL_REQUIRE(pthetas && rows_per_group > 0 && rows_per_group % TILE_B == 0 && theta_stride >= 0,
+              "orl_act_step_grouped: rows_per_group must be a positive multiple of %d", TILE_B);
+  return act_step_impl("orl_act_step_grouped", rows_per_group, theta_stride, pnet, pthetas, nullptr, nullptr, policy_obs,
+                       nullptr, action_masks, B, deterministic, seed, row0, rng_step, nullptr, nullptr, actions, logp,
+                       stream);
 }
 
 int orl_evaluate_actions(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,

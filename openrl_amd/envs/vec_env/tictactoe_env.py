@@ -79,8 +79,8 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
     (``openrl/selfplay/wrappers/opponent_pool_wrapper.py:37-120`` plays earlier checkpoints).
 
     Env group g (the g-th contiguous block of N / pool_size envs) plays snapshot g.  A step is three device stages:
-    ``orl_ttt_agent_move`` -> one ``orl_act_step`` per snapshot on the opponent-side boards (sampled under the legal-
-    move masks) -> ``orl_ttt_opponent_move``; all of them capturable, so the stepwise rollout still replays as one
+    ``orl_ttt_agent_move`` -> ONE ``orl_act_step_grouped`` launch that evaluates every snapshot on its group's
+    opponent-side boards (sampled under the legal-move masks) -> ``orl_ttt_opponent_move``; all of them capturable, so the stepwise rollout still replays as one
     hipGraph.  Snapshots are refreshed in place with ``push_opponent(theta)`` (round-robin), e.g. by
     ``SelfPlayCallback``.  Until the first push every slot holds all-zero parameters = the uniformly random opponent.
     Not the reference's selfplay API / per-reset opponent sampling: the assignment of snapshots to envs is static."""
@@ -100,8 +100,10 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
         z = lambda *s, **k: torch.zeros(*s, device=self.device, **k)
         self._opp_obs, self._opp_mask = z(self._n, self.OBS), z(self._n, self.N_ACT)
         self._opp_act, self._opp_lp = z(self._n, 1), z(self._n, 1)
-        b = [round(g * self._n / self.pool_size) for g in range(self.pool_size + 1)]
-        self._groups = [(b[g], b[g + 1]) for g in range(self.pool_size) if b[g + 1] > b[g]]
+        # contiguous env groups of a multiple of 16 rows (one MFMA tile never mixes two snapshots)
+        self._group_rows = -(-self._n // self.pool_size)
+        self._group_rows = -(-self._group_rows // 16) * 16
+        self.pool_size = -(-self._n // self._group_rows)  # groups that actually receive envs
 
     def push_opponent(self, theta: torch.Tensor) -> int:
         """Store a snapshot of the learner's policy parameters in the next pool slot (in place: graph-safe)."""
@@ -115,10 +117,8 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
 
         a = actions.to(self.device, torch.float32).reshape(self._n).contiguous()
         ops_rnn.ttt_agent_move(self.env_state, a, self._opp_obs, self._opp_mask, self._rew, self._done, self._n)
-        for g, (r0, r1) in enumerate(self._groups):
-            ops.act_step(self.opp_net, self.opp_thetas[g], None, None, self._opp_obs[r0:r1], None, self._opp_mask[r0:r1],
-                         r1 - r0, False, self.opp_seed, r0, self.global_step, None, None, self._opp_act[r0:r1],
-                         self._opp_lp[r0:r1])
+        ops.act_step_grouped(self.opp_net, self.opp_thetas, self._group_rows, self._opp_obs, self._opp_mask, self._n, False,
+                             self.opp_seed, 0, self.global_step, self._opp_act, self._opp_lp)
         ops_rnn.ttt_opponent_move(self.env_state, self.ep_stats, self._opp_act, self.obs, self.action_mask_device,
                                   self._rew, self._done, self._n, self.seed)
         self.global_step += 1

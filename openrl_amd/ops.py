@@ -167,6 +167,16 @@ def act_step(pnet: NetDesc, ptheta, cnet: Optional[NetDesc], ctheta, policy_obs,
     nat.check(rc, "orl_act_step")
 
 
+def act_step_grouped(pnet: NetDesc, pthetas, rows_per_group: int, policy_obs, action_masks, B: int, deterministic: bool,
+                     seed: int, row0: int, rng_step: int, actions, logp) -> None:
+    """One launch for a pool of policies: row group g is evaluated with ``pthetas[g]`` (orl_act_step_grouped)."""
+    dev = _dev(policy_obs)
+    rc = _lib().orl_act_step_grouped(C.byref(pnet), fptr(pthetas), pthetas.stride(0), rows_per_group, fptr(policy_obs),
+                                     fptr(action_masks), B, int(bool(deterministic)), seed & (2 ** 64 - 1), row0,
+                                     rng_step, fptr(actions), fptr(logp), stream_ptr(dev))
+    nat.check(rc, "orl_act_step_grouped")
+
+
 def act_rng_offset(dev_counter: Optional[torch.Tensor]) -> None:
     """Device-side addend of ``rng_step`` for the act-step launches that follow (None switches it off)."""
     nat.check(_lib().orl_act_rng_offset(ptr(dev_counter)), "orl_act_rng_offset")

@@ -103,6 +103,27 @@ def test_gae_long_rollout_all_variants(ops, use_gae, proper, use_vn):
     assert np.array_equal(d_vp.cpu().numpy(), want_vp)
 
 
+def test_grouped_act_step_equals_one_launch_per_policy(ops):
+    """orl_act_step_grouped (a pool of policies in one launch) == orl_act_step per row group, bit for bit."""
+    rs = np.random.RandomState(3)
+    D, K, B, G = 18, 9, 100, 32          # 4 groups: 32 + 32 + 32 + 4 rows
+    pnet = ops.net_desc(D, K, ops.HEAD_CATEGORICAL)
+    thetas = dev((0.3 * rs.randn(4, ops.param_count(pnet))).astype(np.float32))
+    obs = dev(rs.randn(B, D).astype(np.float32))
+    masks = (rs.rand(B, K) > 0.4).astype(np.float32)
+    masks[:, 0] = 1.0
+    masks = dev(masks)
+    a1, l1 = torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV)
+    a2, l2 = torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV)
+    ops.act_step_grouped(pnet, thetas, G, obs, masks, B, False, 77, 0, 5, a1, l1)
+    for g in range(4):
+        r0, r1 = g * G, min((g + 1) * G, B)
+        ops.act_step(pnet, thetas[g], None, None, obs[r0:r1], None, masks[r0:r1], r1 - r0, False, 77, r0, 5, None, None,
+                     a2[r0:r1], l2[r0:r1])
+    assert torch.equal(a1, a2) and torch.equal(l1, l2)
+    assert len(torch.unique(a1)) > 3
+
+
 @pytest.mark.parametrize("D,B", [(4, 1000), (18, 4099), (54, 33)])
 def test_batched_critic_values_equal_the_act_step_critic(ops, D, B):
     """orl_critic_values (the fused rollout's value pass over all T+1 slots) == orl_act_step's critic wave, bit for bit."""
