@@ -314,6 +314,7 @@ int orl_minibatch_moments(const float* records, int rec_width, int ret_col, cons
 #define ORL_ENV_SYNTH 0    /* fixed-step synthetic env: obs ~ N(0,1) keyed (seed, env, t), reward U(0,1) */
 #define ORL_ENV_CARTPOLE 1 /* CartPole-v1 dynamics (gymnasium classic_control cartpole.py) */
 #define ORL_ENV_TTT 2      /* tic-tac-toe vs a uniformly random opponent (orl_ttt_*): obs 18, Discrete(9), legal-move masks */
+#define ORL_ENV_TTT_POOL 3 /* the same game, the opponent of env group g is policy g of a pool (orl_rollout_args.opp_*) */
 
 typedef struct orl_rollout_args {
   orl_buffer_ptrs buf;
@@ -327,6 +328,13 @@ typedef struct orl_rollout_args {
   uint64_t env_seed;
   uint64_t act_seed;
   uint64_t rng_step0;      /* global step counter at the first step of this rollout */
+  /* ORL_ENV_TTT_POOL only: a pool of opponent policies with the policy tower's architecture (orl_act_step_grouped) */
+  const float* opp_thetas; /* parameters of policy g at opp_thetas + g*opp_theta_stride */
+  int64_t opp_theta_stride;
+  int32_t opp_group_rows;  /* envs [g*opp_group_rows, ...) play policy g; a multiple of 16 */
+  int32_t opp_reserved;
+  uint64_t opp_seed;       /* Philox seed of the opponents' sampling; counter = (env, opp_rng_step0 + t) */
+  uint64_t opp_rng_step0;
 } orl_rollout_args;
 
 int orl_env_state_width(int env_kind);

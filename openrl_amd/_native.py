@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liborl_hip.so")
 
 ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
-ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT = 0, 1, 2
+ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL = 0, 1, 2, 3
 ORL_GATHER_MAX = 12
 ORL_N_STATS = 16
 
@@ -73,7 +73,9 @@ class RolloutArgs(C.Structure):
     _fields_ = [("buf", BufferPtrs), ("value_preds", C.c_void_p), ("actions", C.c_void_p),
                 ("action_log_probs", C.c_void_p), ("env_state", C.c_void_p), ("ep_stats", C.c_void_p),
                 ("env_kind", C.c_int32), ("episode_limit", C.c_int32), ("env_seed", C.c_uint64),
-                ("act_seed", C.c_uint64), ("rng_step0", C.c_uint64)]
+                ("act_seed", C.c_uint64), ("rng_step0", C.c_uint64), ("opp_thetas", C.c_void_p),
+                ("opp_theta_stride", C.c_int64), ("opp_group_rows", C.c_int32), ("opp_reserved", C.c_int32),
+                ("opp_seed", C.c_uint64), ("opp_rng_step0", C.c_uint64)]
 
 
 class RnnBatch(C.Structure):

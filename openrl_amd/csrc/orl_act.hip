@@ -300,13 +300,22 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   // the action, so its step runs on wave 1 concurrently with wave 0's head + sampling; CartPole needs the action
   // and stays on wave 0.
   constexpr int ENV_WAVE = (ENV == ORL_ENV_SYNTH) ? 1 : 0;
-  constexpr int ESW = (ENV == ORL_ENV_TTT) ? TTT_STATE_W : 8;
+  constexpr bool IS_TTT = ENV == ORL_ENV_TTT || ENV == ORL_ENV_TTT_POOL;
+  constexpr int ESW = IS_TTT ? TTT_STATE_W : 8;
   float est[ESW];
-  const int SW = (ENV == ORL_ENV_SYNTH) ? SYNTH_STATE_W : (ENV == ORL_ENV_TTT) ? TTT_STATE_W : CARTPOLE_STATE_W;
+  const int SW = (ENV == ORL_ENV_SYNTH) ? SYNTH_STATE_W : IS_TTT ? TTT_STATE_W : CARTPOLE_STATE_W;
   float ep_ret = 0.f, ep_len = 0.f, fin_ret = 0.f, fin_cnt = 0.f;
   // tic-tac-toe: the legal-move mask of the current step lives in LDS (written with the board one step earlier)
   float* s_mask = s_logits + TILE_B * 16;  // [16][16]
-  if (ENV == ORL_ENV_TTT && wave == 0 && q == 0) {
+  // self-play (ORL_ENV_TTT_POOL): the opponent's tower image, the opponent-side boards and masks of the current step
+  float* s_opp = s_mask + TILE_B * 16;                         // TowerLds image of this tile's opponent policy
+  float* s_oobs = s_opp + (ENV == ORL_ENV_TTT_POOL ? twp.total : 0);  // [16][DP]
+  float* s_omask = s_oobs + TILE_B * DP;                       // [16][16]
+  if constexpr (ENV == ORL_ENV_TTT_POOL) {
+    const float* oth = A.r.opp_thetas + (size_t)((blockIdx.x * TILE_B) / A.r.opp_group_rows) * A.r.opp_theta_stride;
+    stage_tower(s_opp, oth, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
+  }
+  if (IS_TTT && wave == 0 && q == 0) {
     for (int c = 0; c < 16; ++c) s_mask[j * 16 + c] = (ok && c < 9) ? b.action_masks[(size_t)n * 9 + c] : (c == 0 ? 1.f : 0.f);
   }
   if (wave == ENV_WAVE && q == 0 && ok) {
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
       else head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);
       // the built-in device envs never mask actions (their action_masks rows stay all-ones), so the mask is
       // not re-read from HBM on the per-step critical path
-      sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, ENV == ORL_ENV_TTT ? s_mask + j * 16 : nullptr,
+      sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, IS_TTT ? s_mask + j * 16 : nullptr,
                             s_noise + (t & 1) * TILE_B * 16 + j * 16, 0, A.r.act_seed, (uint64_t)n, tg, act_o, lp_o);
       if (ok && q == 0) {
 #pragma unroll
@@ -366,6 +375,124 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
           if (c < a_w) {
             A.r.actions[((size_t)t * N + n) * a_w + c] = act_o[c];
             A.r.action_log_probs[((size_t)t * N + n) * a_w + c] = lp_o[c];
+          }
+        }
+      }
+    }
+    if constexpr (ENV == ORL_ENV_TTT_POOL) {
+      // ---- phase A (orl_ttt_agent_move): the agent's move on the owning lanes of wave 0; boards from the opponent's
+      // side go to LDS for the opponent's policy
+      int ph = 2;
+      float rew_a = 0.f;
+      if (wave == 0 && q == 0) {
+        int bd[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) bd[c] = (int)est[c];
+        if (ok) {
+          const int a = (int)act_o[0];
+          bool legal = false;
+#pragma unroll
+          for (int c = 0; c < 9; ++c) legal = legal || (c == a && bd[c] == 0);
+          ph = 1;
+          if (!legal) { rew_a = -1.f; ph = 2; }
+          else {
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+              if (c == a) bd[c] = 1;
+            if (ttt_wins(bd, 1)) { rew_a = 1.f; ph = 2; }
+            else if (ttt_empty(bd) == 0) ph = 2;
+          }
+#pragma unroll
+          for (int c = 0; c < 9; ++c) est[c] = (float)bd[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+          s_oobs[j * DP + 2 * c] = (ph == 1 && bd[c] == 2) ? 1.f : 0.f;
+          s_oobs[j * DP + 2 * c + 1] = (ph == 1 && bd[c] == 1) ? 1.f : 0.f;
+          s_omask[j * 16 + c] = ph == 1 ? (bd[c] == 0 ? 1.f : 0.f) : (c == 0 ? 1.f : 0.f);
+        }
+        for (int d = 18; d < DP; ++d) s_oobs[j * DP + d] = 0.f;
+      }
+      __syncthreads();
+      // ---- the opponent's policy: cooperative trunk of the policy group on the opponent-side boards (the critic
+      // group only keeps the barrier count)
+      f32x4 o2[4];
+      if (grp == 0) {
+        auto xo = [&](int s) -> float { return s_oobs[j * DP + 4 * s + q]; };
+        trunk_fwd_coop(s_opp, twp, xo, gA, gB, gw, j, q, o2, rp);
+      } else {
+        __syncthreads();
+        __syncthreads();
+      }
+      if (wave == 0) {
+        float ohd[NO], oact[NO], olp[NO];
+        head_mfma_T<NO>(s_opp + twp.W3P, s_opp + twp.b3, n_out, o2, s_logits, j, q, ohd);
+        sample_head<NO, HEAD>(ohd, n_out, nullptr, s_omask + j * 16, nullptr, 0, A.r.opp_seed, (uint64_t)n,
+                              A.r.opp_rng_step0 + (uint64_t)t, oact, olp);
+        // ---- phase B (orl_ttt_opponent_move) ----
+        if (q == 0) {
+          const size_t s1 = (size_t)(t + 1) * N + n;
+          int bd[9];
+#pragma unroll
+          for (int c = 0; c < 9; ++c) bd[c] = (int)est[c];
+          int moves = (int)est[9], episode = (int)est[10];
+          if (ok) {
+            float rew = rew_a;
+            bool done = ph == 2;
+            if (ph == 1) {
+              int a = (int)oact[0];
+              bool legal = false;
+#pragma unroll
+              for (int c = 0; c < 9; ++c) legal = legal || (c == a && bd[c] == 0);
+              if (!legal) {
+                a = -1;
+#pragma unroll
+                for (int c = 8; c >= 0; --c)
+                  if (bd[c] == 0) a = c;
+              }
+#pragma unroll
+              for (int c = 0; c < 9; ++c)
+                if (c == a) bd[c] = 2;
+              ++moves;
+              if (ttt_wins(bd, 2)) { rew = -1.f; done = true; }
+              else if (ttt_empty(bd) == 0) done = true;
+            }
+            b.rewards[(size_t)t * N + n] = rew;
+            b.masks[s1] = done ? 0.f : 1.f;
+            b.active_masks[s1] = 1.f;
+            b.bad_masks[s1] = 1.f;
+            ep_ret += rew; ep_len += 1.f;
+            if (done) {
+              fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f;
+              ++episode;
+              moves = ttt_begin(bd, A.r.env_seed, (uint32_t)n, (uint32_t)episode);
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) est[c] = (float)bd[c];
+            est[9] = (float)moves; est[10] = (float)episode;
+          }
+#pragma unroll
+          for (int c = 0; c < 9; ++c) {
+            nxt[j * DP + 2 * c] = (ok && bd[c] == 1) ? 1.f : 0.f;
+            nxt[j * DP + 2 * c + 1] = (ok && bd[c] == 2) ? 1.f : 0.f;
+            s_mask[j * 16 + c] = (!ok && c == 0) ? 1.f : ((ok && bd[c] == 0) ? 1.f : 0.f);
+          }
+          for (int d = 18; d < DP; ++d) nxt[j * DP + d] = 0.f;
+        }
+        wave_lds_fence();
+        {
+          const int row0 = blockIdx.x * TILE_B;
+          const int nrow = (N - row0) < TILE_B ? (N - row0) : TILE_B;
+          const size_t base = (size_t)(t + 1) * N + row0;
+          for (int e = l; e < nrow * 18; e += 64) {
+            const int rr = e / 18, d = e - rr * 18;
+            const float v = nxt[rr * DP + d];
+            b.policy_obs[base * 18 + e] = v;
+            if (sep_c) b.critic_obs[base * 18 + e] = v;
+          }
+          for (int e = l; e < nrow * 9; e += 64) {
+            const int rr = e / 9, c = e - rr * 9;
+            b.action_masks[base * 9 + e] = s_mask[rr * 16 + c];
           }
         }
       }
@@ -472,7 +599,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
             b.action_masks[base * 9 + e] = s_mask[rr * 16 + c];
           }
         }
-      } else {
+      } else if (ENV == ORL_ENV_CARTPOLE) {
         if (q == 0 && ok) {
           float s[4] = {est[0], est[1], est[2], est[3]};
           const int action = (int)act_o[0];
@@ -504,7 +631,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
           for (int k = 0; k < 4; ++k) nxt[j * DP + k] = 0.f;
         }
       }
-      if (ENV != ORL_ENV_TTT && b.action_masks != nullptr && ok && q == 0) {
+      if (!IS_TTT && b.action_masks != nullptr && ok && q == 0) {
         for (int c = 0; c < b.K; ++c) b.action_masks[s1 * b.K + c] = 1.f;
       }
     }
@@ -970,7 +1097,12 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   if (args->env_kind == ORL_ENV_CARTPOLE)
     ORL_REQUIRE(pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 2 && b.Dp == 4,
                 "orl_rollout_fused: CartPole needs Discrete(2) and 4-d obs");
-  if (args->env_kind == ORL_ENV_TTT)
+  const bool pool = args->env_kind == ORL_ENV_TTT_POOL;
+  if (pool)
+    ORL_REQUIRE(args->opp_thetas && args->opp_group_rows > 0 && args->opp_group_rows % TILE_B == 0 &&
+                    args->opp_theta_stride >= 0,
+                "orl_rollout_fused: the opponent pool needs opp_thetas and opp_group_rows (a multiple of %d)", TILE_B);
+  if (args->env_kind == ORL_ENV_TTT || pool)
     ORL_REQUIRE(pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 9 && b.Dp == 18 && b.K == 9 && b.action_masks,
                 "orl_rollout_fused: tic-tac-toe needs Discrete(9), 18-d obs and the action-mask array");
   const TowerLds twp(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false, pnet->n_out > 2);
@@ -979,7 +1111,8 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   // Measured at config 2: the step loop drops only 271 -> 237 us (the policy's own latency chain is the step), the
   // value launch costs 60 us - so the critic stays inside the loop by default.
   static const bool split = getenv("ORL_ROLLOUT_SPLIT") != nullptr;
-  const size_t lds = (size_t)(twp.total + (split ? 0 : twc.total) + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 4 * TILE_B * 16) * sizeof(float);
+  const size_t lds = (size_t)(twp.total + (split ? 0 : twc.total) + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 4 * TILE_B * 16 +
+                                 (pool ? twp.total + TILE_B * twp.DP + TILE_B * 16 : 0)) * sizeof(float);
   ORL_REQUIRE(lds <= 160 * 1024, "orl_rollout_fused: needs %zu B of LDS", lds);
   RolloutArgs A;
   A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.r = *args; A.next_value = next_value;
@@ -1004,6 +1137,8 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
     ORL_RO_LAUNCH2(2, ORL_HEAD_CATEGORICAL, ORL_ENV_CARTPOLE);
   } else if (args->env_kind == ORL_ENV_TTT) {
     ORL_RO_LAUNCH2(16, ORL_HEAD_CATEGORICAL, ORL_ENV_TTT);
+  } else if (pool) {
+    ORL_RO_LAUNCH2(16, ORL_HEAD_CATEGORICAL, ORL_ENV_TTT_POOL);
   } else {
     return fail(ORL_E_INVALID, "orl_rollout_fused: unknown env kind %d", args->env_kind);
   }

@@ -174,6 +174,8 @@ class OnPolicyDriver:
         args = nat.RolloutArgs(d.buffer_ptrs(), f(d.value_preds), f(d.actions), f(d.action_log_probs), f(env.env_state),
                                f(env.ep_stats), env.env_kind, env.episode_limit, env.seed & (2 ** 64 - 1),
                                mod.act_seed & (2 ** 64 - 1), env.global_step)
+        if hasattr(env, "fill_rollout_args"):  # env-specific extras (the self-play opponent pool)
+            env.fill_rollout_args(args)
         ops.rollout_fused(p.net, p.theta, c.net, c.theta, args, self._next_value)
         env.global_step += self.episode_length
         mod.rng_step += self.episode_length

@@ -78,7 +78,8 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
     """Self-play variant: the opponent is a POLICY - one of ``pool_size`` frozen snapshots of the learner
     (``openrl/selfplay/wrappers/opponent_pool_wrapper.py:37-120`` plays earlier checkpoints).
 
-    Env group g (the g-th contiguous block of N / pool_size envs) plays snapshot g.  A step is three device stages:
+    Env group g (the g-th contiguous block of N / pool_size envs) plays snapshot g.  In stepwise mode a step is three device stages
+    (the fused rollout kernel does the same in-kernel, ``ORL_ENV_TTT_POOL``):
     ``orl_ttt_agent_move`` -> ONE ``orl_act_step_grouped`` launch that evaluates every snapshot on its group's
     opponent-side boards (sampled under the legal-move masks) -> ``orl_ttt_opponent_move``; all of them capturable, so the stepwise rollout still replays as one
     hipGraph.  Snapshots are refreshed in place with ``push_opponent(theta)`` (round-robin), e.g. by
@@ -90,8 +91,8 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
         from ... import ops
 
         self.kind = "tictactoe_selfplay_pool"
-        self.env_kind = None
-        self.supports_fused_rollout = False  # the in-kernel game of orl_rollout_fused only has the random opponent
+        self.env_kind = nat.ORL_ENV_TTT_POOL  # orl_rollout_fused plays both sides in-kernel (fill_rollout_args)
+        self.supports_fused_rollout = True
         self.pool_size = max(1, min(int(pool_size), self._n))
         self.opp_net = nat.NetDesc(self.OBS, 64, self.N_ACT, nat.ORL_HEAD_CATEGORICAL)
         self.opp_thetas = torch.zeros(self.pool_size, ops.param_count(self.opp_net), device=self.device)
@@ -104,6 +105,14 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
         self._group_rows = -(-self._n // self.pool_size)
         self._group_rows = -(-self._group_rows // 16) * 16
         self.pool_size = -(-self._n // self._group_rows)  # groups that actually receive envs
+
+    def fill_rollout_args(self, args) -> None:
+        """The opponent-pool fields of orl_rollout_args (fused rollout); same Philox keys as the stepwise path."""
+        args.opp_thetas = self.opp_thetas.data_ptr()
+        args.opp_theta_stride = self.opp_thetas.stride(0)
+        args.opp_group_rows = self._group_rows
+        args.opp_seed = self.opp_seed & (2 ** 64 - 1)
+        args.opp_rng_step0 = self.global_step
 
     def push_opponent(self, theta: torch.Tensor) -> int:
         """Store a snapshot of the learner's policy parameters in the next pool slot (in place: graph-safe)."""

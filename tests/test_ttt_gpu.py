@@ -130,6 +130,55 @@ def test_fused_rollout_equals_stepwise_rollout_on_tictactoe():
     assert torch.equal(sa, sb) and torch.equal(ea, eb)
 
 
+def test_fused_selfplay_rollout_equals_stepwise():
+    """ORL_ENV_TTT_POOL inside orl_rollout_fused (both players' policies in-kernel) fills the buffer like the stepwise
+    orl_act_step + orl_ttt_agent_move + orl_act_step_grouped + orl_ttt_opponent_move + orl_buffer_insert path."""
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+
+    def run(mode):
+        N, T = 150, 12
+        cfg = default_cfg(["--seed", "5", "--episode_length", str(T), "--ppo_epoch", "1", "--amd_perm_mode", "device",
+                           "--amd_use_graph", "false", "--amd_rollout_mode", mode, "--log_interval", "1000000"])
+        env = make("tictactoe_v3", env_num=N, device=DEV, seed=5, opponent="pool", pool_size=3)
+        torch.manual_seed(4)
+        env.opp_thetas.copy_(0.5 * torch.randn_like(env.opp_thetas))  # three different non-trivial opponents
+        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+        cfg.num_env_steps = N * T * 2
+
+        class _Agent:
+            num_time_steps = 0
+
+        trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=DEV)
+        buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=DEV)
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, _Agent())
+        assert drv.fused == (mode == "fused")
+        drv.reset_and_buffer_init()
+        out = []
+        for i in range(2):
+            drv.episode = i
+            drv.actor_rollout()
+            drv.compute_returns()
+            d = buf.data
+            out.append({k: getattr(d, k).clone() for k in ("policy_obs", "actions", "action_log_probs", "value_preds",
+                                                           "rewards", "masks", "action_masks", "returns")})
+            drv.buffer.after_update()
+        return out, env.ep_stats.clone(), env.env_state[:, :11].clone()
+
+    (fa, sa, ea), (fb, sb, eb) = run("fused"), run("stepwise")
+    for a, b in zip(fa, fb):
+        for k in ("policy_obs", "actions", "rewards", "masks", "action_masks"):
+            assert torch.equal(a[k], b[k]), k
+        for k in ("action_log_probs", "value_preds", "returns"):
+            torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-6, msg=k)
+    assert torch.equal(sa, sb) and torch.equal(ea, eb)
+    assert (fa[0]["rewards"] != 0).sum() > 50  # games were decided both ways
+
+
 def test_ppo_beats_the_random_opponent():
     """Learning sanity for config 5's env: the mean game result against the uniformly random opponent (0 for a random
     agent by symmetry) rises clearly within 120 iterations of masked PPO."""
@@ -219,7 +268,7 @@ def test_selfplay_pool_env_and_callback_end_to_end():
     net = PPONet(env, cfg=cfg, device=DEV)
     agent = PPOAgent(net)
     agent.train(total_time_steps=N * T * 80, callback=SelfPlayCallback(push_every=10))
-    assert env.pushes == 7 and not agent.driver.fused and agent.driver._graph is not None
+    assert env.pushes == 7 and agent.driver.fused
     assert env.opp_thetas.abs().sum(dim=1).min() > 0  # every slot holds a real snapshot by now
     for m in net.module.models.values():
         assert torch.isfinite(m.theta).all()
