@@ -78,3 +78,22 @@ def test_recurrent_tower_state_dict_keys_follow_the_reference():
     n = sum(int(np.prod(s)) for _, s in _tower_entries("critic", 54, 64, 1, False, True))
     lib = nat.load()
     assert n == lib.orl_rnn_param_count(C.byref(nat.NetDesc(54, 64, 1, nat.ORL_HEAD_VALUE)))
+
+
+def test_device_train_info_is_a_dict_that_copies_on_first_read():
+    """PPOAlgorithm.train returns its six averages without a device->host sync; any read materialises them."""
+    from openrl_amd.algorithms.ppo import INFO_KEYS, DeviceTrainInfo
+
+    vals = torch.tensor([0.5, -0.25, 1.5, 2.0, 3.0, 1.0])
+    d = DeviceTrainInfo(INFO_KEYS, vals)
+    assert isinstance(d, dict) and d._dev is not None
+    assert d["value_loss"] == 0.5 and d._dev is None           # first read copies
+    assert list(d.keys()) == list(INFO_KEYS) and len(d) == 6 and "ratio" in d
+    assert dict(DeviceTrainInfo(INFO_KEYS, vals)) == {k: float(v) for k, v in zip(INFO_KEYS, vals)}
+    e = DeviceTrainInfo(INFO_KEYS, vals)
+    e.pop("ratio", None)                                        # A2CAlgorithm.train drops the ratio
+    assert "ratio" not in e and len(e) == 5
+    f = {}
+    f.update(DeviceTrainInfo(INFO_KEYS, vals))
+    assert f["dist_entropy"] == 1.5
+    assert bool(DeviceTrainInfo(INFO_KEYS, vals)) and np.isfinite(list(DeviceTrainInfo(INFO_KEYS, vals).values())).all()
