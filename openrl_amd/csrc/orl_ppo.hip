@@ -94,8 +94,10 @@ template <int HEAD, int NO>
 static int launch_tower_nd(const PpoArgs& A, hipStream_t s) {
   const int D = A.net.obs_dim;
   if (D <= 4 && (A.o_x & 3) == 0) return launch_tower<HEAD, NO, 0>(A, s);
-  if (D <= 16) return launch_tower<HEAD, NO, 1>(A, s);
-  if (D <= 32) return launch_tower<HEAD, NO, 2>(A, s);
+  // ND = 16-column MFMA blocks of the dW1 accumulator; up to 4 remainder columns go to the VALU (17..20, 33..36)
+  static const bool rem = getenv("ORL_PPO_NOREM") == nullptr;
+  if (D <= (rem ? 20 : 16)) return launch_tower<HEAD, NO, 1>(A, s);
+  if (D <= (rem ? 36 : 32)) return launch_tower<HEAD, NO, 2>(A, s);
   return launch_tower<HEAD, NO, 4>(A, s);
 }
 

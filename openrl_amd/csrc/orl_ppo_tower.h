@@ -694,7 +694,20 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
           w1v[0] += dzv * xv[0]; w1v[1] += dzv * xv[1]; w1v[2] += dzv * xv[2]; w1v[3] += dzv * xv[3];
         }
       } else {
-        for (int r = 0; r < TILE_B; ++r) s_db += SS[r * TS + f];
+        // columns [0, 16 ND) of dW1 on MFMA; a remainder of up to 4 columns (D = 17..20, 33..36: launch_tower_nd) on
+        // the VALU like the ND == 0 path instead of a whole extra 16-column accumulator block
+        const int n_rem = D - 16 * ND;
+        if (n_rem > 0) {
+          for (int r = 0; r < TILE_B; ++r) {
+            const float dzv = SS[r * TS + f];
+            s_db += dzv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (k < n_rem) w1v[k] += dzv * REC_R(r, A.o_x + 16 * ND + k);
+          }
+        } else {
+          for (int r = 0; r < TILE_B; ++r) s_db += SS[r * TS + f];
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           float av[4], bv[NDA];
@@ -816,6 +829,9 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
               const int kk = 16 * mk + j;
               if (kk < D) acc[rl.odW1 + (16 * mf + 4 * q + r) * D + kk] += G1[mf][mk][r];
             }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (16 * ND + k < D) acc[rl.odW1 + f * D + 16 * ND + k] += w1v[k];
       }
       if (l == 0) {
         acc[rl.total + ST_ACTIVE_SUM] += st_active;
