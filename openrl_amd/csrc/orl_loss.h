@@ -153,4 +153,74 @@ __device__ inline void ppo_row_loss(float (&hd)[NO], int n_out, bool valid, REC 
   }
 }
 
+// Categorical PPO loss on logits DISTRIBUTED over the 4 lanes of a batch row: lane q holds classes 4q..4q+3 (the
+// layout the MFMA head GEMM leaves them in); row-wide maxima / sums by permlane swaps.  Same formulas as
+// ppo_row_loss<ORL_HEAD_CATEGORICAL>; dhv[r] = d(loss numerator)/d logit[4q+r].
+template <class REC>
+__device__ inline void ppo_cat_loss_dist(const f32x4& hv, int n_out, int q, bool valid, REC rec, const LossCols& C,
+                                         const orl_ppo_hparams& hp, f32x4& dhv, LossStats& st, bool count) {
+  dhv = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float active = valid ? rec(C.o_am) : 0.f;
+  const float w = valid ? (hp.use_policy_active_masks ? active : 1.f) : 0.f;
+  const float adv = valid ? rec(C.o_adv) : 0.f;
+  float lg[4], mk[4];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = 4 * q + r;
+    mk[r] = (C.K > 0 && valid && c < n_out) ? rec(C.o_mk + c) : 1.f;
+    lg[r] = (mk[r] == 0.f) ? -6e4f : hv[r];
+    if (c < n_out) mx = fmaxf(mx, lg[r]);
+  }
+  mx = row_allmax(mx);
+  float se = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (4 * q + r < n_out) se += __expf(lg[r] - mx);
+  se = row_allsum(se);
+  const float lse = mx + __logf(se);
+  const int act = valid ? (int)rec(C.o_act) : 0;
+  const float old_lp = valid ? rec(C.o_lp) : 0.f;
+  float pk = 0.f, entp = 0.f;
+  float p[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = 4 * q + r;
+    p[r] = 0.f;
+    if (c < n_out) {
+      const float ell = lg[r] - lse;
+      p[r] = __expf(ell);
+      entp -= p[r] * ell;
+      if (c == act) pk = lg[r];
+    }
+  }
+  const float lp = row_allsum(pk) - lse;
+  const float ent = row_allsum(entp);
+  float ratio = __expf(lp - old_lp);
+  const float ratio_raw = ratio;
+  float dr_eff = 1.f;
+  if (hp.dual_clip_ppo && ratio > hp.dual_clip_coeff) { ratio = hp.dual_clip_coeff; dr_eff = 0.f; }
+  const float s1 = ratio * adv;
+  const float s2 = fminf(fmaxf(ratio, 1.f - hp.clip_param), 1.f + hp.clip_param) * adv;
+  float surr = fminf(s1, s2);
+  float gl = -((s1 <= s2) ? adv : 0.f) * dr_eff * ratio_raw;  // d(-surr)/d logp
+  if (hp.reserved & 2) {  // A2C
+    surr = adv * lp;
+    gl = -adv;
+    ratio = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = 4 * q + r;
+    if (c < n_out) {
+      const float ell = lg[r] - lse;
+      const float d = gl * ((c == act ? 1.f : 0.f) - p[r]) + hp.entropy_coef * p[r] * (ell + ent);
+      dhv[r] = (mk[r] == 0.f) ? 0.f : w * d;
+    }
+  }
+  if (count && valid) {
+    st.active += active; st.rows += 1.f; st.loss += -surr * w; st.ent += ent * w; st.ratio += ratio;
+  }
+}
+
 }  // namespace orl

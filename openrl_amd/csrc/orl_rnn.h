@@ -74,9 +74,10 @@ struct RnnRaw {
 
 // ---- LDS image of a recurrent tower (row kernel): 64x64 blocks padded to W2S columns ----------------------
 struct RnnLds {
-  int DP, W1, b1, g1, be1, W2, b2, g2, be2, Wih, Whh, bih, bhh, g3, be3, W3, b3, logstd, total;
+  int DP, W1, b1, g1, be1, W2, b2, g2, be2, Wih, Whh, bih, bhh, g3, be3, W3, b3, logstd, W3P, total;
   __host__ __device__ RnnLds() {}
-  __host__ __device__ RnnLds(int D, int n_out, bool gaussian) {
+  // with_w3p: W3 zero padded to [16][W2S] - the MFMA operand of the wide categorical head in the row kernel
+  __host__ __device__ RnnLds(int D, int n_out, bool gaussian, bool with_w3p = false) {
     DP = (D + 3) & ~3;
     const int no4 = (n_out + 3) & ~3;
     int o = 0;
@@ -97,13 +98,20 @@ struct RnnLds {
     W3 = o; o += no4 * HID;
     b3 = o; o += no4;
     logstd = o; o += gaussian ? no4 : 0;
+    W3P = o; o += with_w3p ? 16 * W2S : 0;
     total = o;
   }
 };
 
 __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __restrict__ theta, const RnnLayout& tl,
-                                       const RnnLds& tw, int tid, int nthreads) {
+                                       const RnnLds& tw, int tid, int nthreads, bool with_w3p = false) {
   const int D = tl.D;
+  if (with_w3p) {
+    for (int e = tid; e < 16 * W2S; e += nthreads) {
+      const int c = e / W2S, i = e - c * W2S;
+      lds[tw.W3P + e] = (c < tl.n_out && i < HID) ? theta[tl.oW3 + c * HID + i] : 0.f;
+    }
+  }
   for (int e = tid; e < HID * tw.DP; e += nthreads) {
     const int f = e / tw.DP, k = e - f * tw.DP;
     lds[tw.W1 + e] = (k < D) ? theta[tl.oW1 + f * D + k] : 0.f;

@@ -252,8 +252,10 @@ template <int HEAD, int NO>
 __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const RnnLayout tl(A.net);
-  const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN);
-  stage_rnn_tower(smem, A.theta, tl, tw, threadIdx.x, blockDim.x);
+  // wide categorical heads: logits and W3^T dhead as 16-MFMA GEMMs, the loss on the 4 logits the MFMA leaves per lane
+  constexpr bool HMM = HEAD == ORL_HEAD_CATEGORICAL && NO > 4;
+  const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HMM);
+  stage_rnn_tower(smem, A.theta, tl, tw, threadIdx.x, blockDim.x, HMM);
   __syncthreads();
   const float* lw = smem;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
@@ -366,6 +368,29 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       const float mk = mk_c;
       float xv[16];
       load_x(rec, xv);
+      // the scalar record fields the loss needs, requested NOW with the observation: read lazily inside the loss they
+      // were a chain of exposed L2 round trips in the middle of the step
+      const float rf_am = rec[A.cols.o_am], rf_adv = rec[A.cols.o_adv], rf_act = rec[A.cols.o_act];
+      const float rf_lp = rec[A.cols.o_lp], rf_vp = rec[A.cols.o_vp], rf_rt = rec[A.cols.o_rt];
+      float rf_mk[4] = {1.f, 1.f, 1.f, 1.f};  // wide categorical head: the masks of this lane's 4 classes
+      if (HEAD == ORL_HEAD_CATEGORICAL && NO > 4 && A.cols.K > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * q + r < n_out) rf_mk[r] = rec[A.cols.o_mk + 4 * q + r];
+      }
+      auto recf = [&](int col) -> float {
+        if (col == A.cols.o_am) return rf_am;
+        if (col == A.cols.o_adv) return rf_adv;
+        if (col == A.cols.o_act) return rf_act;
+        if (col == A.cols.o_lp) return rf_lp;
+        if (col == A.cols.o_vp) return rf_vp;
+        if (col == A.cols.o_rt) return rf_rt;
+        if (HEAD == ORL_HEAD_CATEGORICAL && NO > 4) {
+          const int d = col - (A.cols.o_mk + 4 * q);
+          if (d >= 0 && d < 4) return d == 0 ? rf_mk[0] : d == 1 ? rf_mk[1] : d == 2 ? rf_mk[2] : rf_mk[3];
+        }
+        return rec[col];
+      };
       float* tb = A.tape + ((size_t)tile * L + s) * BLK;
       f32x4 hin[4];
       {
@@ -383,6 +408,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       unsigned relu_bits;
       f32x4 gr[4], gz[4], gn[4], ghn[4];
       float dh[NO], dls[NO];
+      f32x4 dhv = f32x4{0.f, 0.f, 0.f, 0.f};  // wide categorical head: this lane's 4 head deltas
       {
         f32x4 xh1[4], xh2[4], n2[4], hnew[4];
         trunk(xv, xh1, rstd1, relu_bits, xh2, rstd2, n2);
@@ -395,22 +421,37 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
         tape_store(tb + TV_XH3 * TV, hnew, j, q);
         f32x4 n3[4];
         ln_affine_T(hnew, lw + tw.g3, lw + tw.be3, q, n3);
-        float hd[NO];
-        head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, n3, q, hd);
-        ppo_row_loss<HEAD, NO>(hd, n_out, valid, [&](int col) -> float { return rec[col]; }, A.cols, hp, vn_mean,
-                               vn_sd, lw + tw.logstd, dh, dls, st, q == 0);
-        if (q == 0) {
+        if constexpr (HMM) {
+          const int no4 = (n_out + 3) & ~3;
+          f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (4 * q < no4) hv = *(const f32x4*)(lw + tw.b3 + 4 * q);
 #pragma unroll
-          for (int c = 0; c < NO; ++c) a_dls[c] += dls[c];
+          for (int mi = 0; mi < 4; ++mi) {
+            const f32x4 a4 = *(const f32x4*)(lw + tw.W3P + j * W2S + 16 * mi + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv = ORL_MFMA(a4[r], n3[mi][r], hv);
+          }
+          ppo_cat_loss_dist(hv, n_out, q, valid, recf, A.cols, hp, dhv, st, q == 0);
+        } else {
+          float hd[NO];
+          head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, n3, q, hd);
+          ppo_row_loss<HEAD, NO>(hd, n_out, valid, recf, A.cols, hp, vn_mean, vn_sd, lw + tw.logstd, dh, dls, st, q == 0);
+          if (q == 0) {
+#pragma unroll
+            for (int c = 0; c < NO; ++c) a_dls[c] += dls[c];
+          }
         }
       }
       RNN_T(4);  // LN3, head, loss
       // head deltas -> tape (16-wide vector: lane (j,q) owns columns 4q..4q+3)
       {
         f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (HMM) dv = dhv;
+        else {
 #pragma unroll
-        for (int c = 0; c < NO; ++c)
-          if ((c >> 2) == q) dv[c & 3] = dh[c];
+          for (int c = 0; c < NO; ++c)
+            if ((c >> 2) == q) dv[c & 3] = dh[c];
+        }
         *(f32x4*)(tb + TAPE_HEAD + (q * 16 + ((j + 4 * q) & 15)) * 4) = dv;
       }
       // observation tile -> tape
@@ -427,11 +468,19 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       f32x4 dt[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) dt[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (HMM) {
 #pragma unroll
-      for (int c = 0; c < NO; ++c) {
-        if (c < n_out) {
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int m = 0; m < 4; ++m) dt[m] += *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q) * dh[c];
+          for (int mo = 0; mo < 4; ++mo)
+            dt[mo] = ORL_MFMA(lw[tw.W3P + (4 * q + r) * W2S + 16 * mo + j], dhv[r], dt[mo]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < NO; ++c) {
+          if (c < n_out) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) dt[m] += *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q) * dh[c];
+          }
         }
       }
       {
@@ -962,7 +1011,8 @@ struct RnnWs {  // workspace carve-up (floats) for one tower
 
 template <int HEAD, int NO>
 static int launch_rnn_rows(const RnnRowArgs& P, const RnnRowArgs& Cc, int grid_p, int grid_c, hipStream_t s) {
-  const RnnLds twp(P.net.obs_dim, P.net.n_out, HEAD == ORL_HEAD_GAUSSIAN), twc(Cc.net.obs_dim, 1, false);
+  const RnnLds twp(P.net.obs_dim, P.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HEAD == ORL_HEAD_CATEGORICAL && NO > 4);
+  const RnnLds twc(Cc.net.obs_dim, 1, false);
   const size_t lds = (size_t)(twp.total > twc.total ? twp.total : twc.total) * sizeof(float);
   if (lds > 160 * 1024) return fail(ORL_E_UNSUPPORTED, "orl_rnn_ppo_fwd_bwd: tower needs %zu B of LDS", lds);
   (void)hipFuncSetAttribute((const void*)rnn_row_pair_kernel<HEAD, NO>, hipFuncAttributeMaxDynamicSharedMemorySize,
