@@ -95,7 +95,8 @@ __device__ inline float raw_to_grad(const float* __restrict__ raw, const float* 
 // Workgroups >= 2 (orl_ppo_apply_perm only) produce the NEXT epoch's minibatch permutation and ValueNorm.update in the
 // same launch: both are independent of this optimiser step, and the two apply workgroups leave 254 CUs idle.
 __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTower Cc, const float* __restrict__ sums,
-                                                         orl_ppo_hparams hp, float* __restrict__ info, PermJob J) {
+                                                         orl_ppo_hparams hp, float* __restrict__ info, PermJob J,
+                                                         int stage_mv) {
   extern __shared__ __attribute__((aligned(16))) float s_apply[];
   if (blockIdx.x >= 2) {
     perm_job_block(J, (int)blockIdx.x - 2, (int)gridDim.x - 2);
@@ -138,16 +139,18 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     // are in flight, gradients stay in LDS between the norm and the Adam pass, and every loop stays ROLLED - the code
     // is fetched cold on each launch, so instruction bytes cost more than loop overhead (an unrolled variant of this
     // body measured 17.2 us against 13.3 us).
-    float* m_s = th_s + tl.total;
+    float* g_s = th_s + tl.total;
+    float* m_s = g_s + tl.total;  // Adam moments: staged too when everything fits 160 KiB (stage_mv), else read from HBM
     float* v_s = m_s + tl.total;
-    float* g_s = v_s + tl.total;
 #pragma unroll 1
     for (int e = threadIdx.x; e < rl.total; e += blockDim.x) raw[e] = raw_g[e];
 #pragma unroll 1
     for (int e = threadIdx.x; e < tl.total; e += blockDim.x) {
       th_s[e] = W.ad.theta[e];
-      m_s[e] = W.ad.m[e];
-      v_s[e] = W.ad.v[e];
+      if (stage_mv) {
+        m_s[e] = W.ad.m[e];
+        v_s[e] = W.ad.v[e];
+      }
     }
     // torch.optim.Adam (single tensor math, betas (0.9, 0.999), amsgrad off)
     // scalar coefficients are python doubles in torch/optim/adam.py; only tensor math is fp32
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
       W.ad.grad[p] = g;
       float th = th_s[p];
       if (W.ad.weight_decay != 0.f) g += W.ad.weight_decay * th;
-      float m = m_s[p], v = v_s[p];
+      float m = stage_mv ? m_s[p] : W.ad.m[p], v = stage_mv ? v_s[p] : W.ad.v[p];
       m = m + (g - m) * omb1;          // exp_avg.lerp_(grad, 1 - beta1)
       v = v * b2 + omb2 * (g * g);     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
       const float denom = sqrtf(v) / bc2_sqrt + W.ad.eps;
@@ -270,9 +273,16 @@ static int launch_apply(const char* what, const orl_net_desc* pnet, const orl_ne
   ApplyTower P, Cc;
   P.net = *pnet; P.ad = *padam; P.sums_off = 0;
   Cc.net = *cnet; Cc.ad = *cadam; Cc.sums_off = RawLayout(*pnet).total + ORL_N_STATS;
-  const size_t lp = (size_t)(RawLayout(*pnet).total + 4 * TowerLayout(*pnet).total) * sizeof(float);  // raw | theta m v g
-  const size_t lc = (size_t)(RawLayout(*cnet).total + 4 * TowerLayout(*cnet).total) * sizeof(float);
-  const size_t lds = lp > lc ? lp : lc;
+  // raw | theta g [| m v]: the Adam moments are staged with the rest when that fits 160 KiB (every tower up to obs ~40),
+  // the widest towers (obs 64 x 16 outputs: 191 KB) read them from HBM in the Adam pass
+  auto need = [&](int k) {
+    const size_t lp = (size_t)(RawLayout(*pnet).total + k * TowerLayout(*pnet).total) * sizeof(float);
+    const size_t lc = (size_t)(RawLayout(*cnet).total + k * TowerLayout(*cnet).total) * sizeof(float);
+    return lp > lc ? lp : lc;
+  };
+  const int stage_mv = need(4) <= 160 * 1024;
+  const size_t lds = need(stage_mv ? 4 : 2);
+  ORL_REQUIRE(lds <= 160 * 1024, "%s: tower needs %zu B of LDS", what, lds);
   int perm_blocks = 0;
   if (J.idx != nullptr) {
     perm_blocks = (int)((J.n + 1023) / 1024);
@@ -280,7 +290,7 @@ static int launch_apply(const char* what, const orl_net_desc* pnet, const orl_ne
   }
   (void)hipFuncSetAttribute((const void*)ppo_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(ppo_apply_kernel, dim3(2 + perm_blocks), dim3(1024), lds, (hipStream_t)stream, P, Cc, sums, *hp,
-                     train_info_accum, J);
+                     train_info_accum, J, stage_mv);
   return launch_status(what);
 }
 

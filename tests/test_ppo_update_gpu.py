@@ -189,6 +189,10 @@ def _random_case(D, act_space_kind, n_act, N, T, seed, masks=False):
     (18, "discrete", 5, 48, 25, False),    # MPE simple_spread policy obs 18, Discrete(5) (feed-forward part)
     (4, "discrete", 2, 1024, 32, False),   # config 2 shape, 2048 tiles
     (3, "discrete", 3, 7, 5, False),       # ragged: 35 rows, obs not a multiple of 4
+    (64, "discrete", 16, 40, 9, True),     # the widest tower the kernels admit: obs 64, 16 classes, masks
+    (33, "gaussian", 16, 20, 7, False),    # obs 33: two 16-column dW1 blocks + a 1-column remainder; Box(16)
+    (20, "discrete", 4, 33, 6, False),     # obs 20: one dW1 block + a 4-column remainder; narrow head at NO = 8
+    (54, "gaussian", 1, 18, 5, False),     # MPE critic-sized obs with a one-dimensional Gaussian head
 ])
 def test_single_update_at_baseline_shapes_vs_oracle(D, kind, n_act, N, T, masks):
     cfg, module, buf, algo, host, a_w = _random_case(D, kind, n_act, N, T, seed=D + n_act, masks=masks)

@@ -228,3 +228,26 @@ def test_cartpole_learns_like_the_reference_recipe(tmp_path):
         if not alive.any():
             break
     assert total.mean() >= 350, total
+
+
+@pytest.mark.parametrize("obs_dim,act", [(64, ("discrete", 16)), (33, ("box", 16)), (1, ("discrete", 2))])
+def test_extreme_tower_shapes_train_end_to_end(obs_dim, act):
+    """The widest (obs 64, 16 outputs) and narrowest towers the kernels admit through make / PPONet / PPOAgent.train on
+    the synthetic env: fused rollout, GAE, update - finite parameters, permutation and buffers consistent."""
+    from openrl_amd import spaces
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import PPOAgent as Agent
+
+    space = spaces.Discrete(act[1]) if act[0] == "discrete" else spaces.Box(-1.0, 1.0, (act[1],))
+    cfg = _cfg(["--episode_length", "12", "--ppo_epoch", "2", "--amd_perm_mode", "device"])
+    env = make("SyntheticFixedStep-v0", env_num=40, obs_dim=obs_dim, action_space=space, episode_limit=5, device=DEV)
+    agent = Agent(Net(env, cfg=cfg, device=DEV))
+    agent.train(total_time_steps=40 * 12 * 3)
+    assert agent.driver.fused and agent.num_time_steps == 40 * 12 * 3
+    d = agent.driver.buffer.data
+    assert torch.isfinite(d.returns).all() and torch.isfinite(d.action_log_probs).all()
+    if act[0] == "discrete":
+        assert d.actions.min() >= 0 and d.actions.max() <= act[1] - 1 and len(torch.unique(d.actions)) > 1
+    for m in agent.net.module.models.values():
+        assert torch.isfinite(m.theta).all() and torch.isfinite(m.grad).all()
