@@ -142,6 +142,26 @@ def test_next_epoch_permutation_in_the_apply_launch_changes_nothing(case):
     assert len(a[3]) == len(b[3]) and all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
 
 
+@pytest.mark.parametrize("case", ["train_discrete", "train_gaussian"])
+def test_turn_on_false_updates_only_the_critic(case):
+    """PPOAlgorithm.train(buffer, turn_on=False) (ppo.py:226-236: the policy loss is not in the loss list): the policy
+    parameters and its Adam state do not move, the critic gets exactly the update it gets with turn_on=True."""
+    g = H.load_golden(case)
+    res = []
+    for turn_on in (True, False):
+        cfg, module, buf, algo = build_engine(g)
+        algo.perm_mode = "device"
+        p0 = module.models["policy"].theta.clone()
+        info = algo.train(buf, turn_on=turn_on)
+        res.append((module.models["policy"].theta.clone(), module.models["critic"].theta.clone(), dict(info), p0,
+                    module.optimizers["policy"].step_count))
+    on, off = res
+    assert torch.equal(off[0], off[3]) and off[4] == 0 and not torch.equal(on[0], on[3])
+    assert torch.equal(on[1], off[1])  # the critic tower never sees the policy
+    assert off[2]["actor_grad_norm"] == 0.0 and np.isfinite(list(off[2].values())).all()
+    assert off[2]["value_loss"] == on[2]["value_loss"]
+
+
 def _random_case(D, act_space_kind, n_act, N, T, seed, masks=False):
     """Synthetic buffer at an arbitrary shape: one full-batch update, engine vs oracle autograd."""
     from openrl_amd import spaces

@@ -84,6 +84,30 @@ def test_recurrent_train_matches_reference_golden(case):
     np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("case", ["train_recurrent", "train_recurrent_chunk5"])
+def test_recurrent_turn_on_false_updates_only_the_critic(case):
+    """turn_on=False through the recurrent update: the policy tower (incl. its LayerNorm-affine dot workgroups) gets no
+    gradient and no Adam step, the critic gets exactly its usual update."""
+    g = H.load_golden(case)
+    res = []
+    for turn_on in (True, False):
+        cfg, module, buf, algo = build_engine(g)
+        module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+        module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+        for f in ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks",
+                  "bad_masks", "active_masks", "action_masks", "rnn_states", "rnn_states_critic"):
+            if "buf_" + f in g and getattr(buf, f) is not None:
+                getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+        algo.perm_mode = "device"
+        info = algo.train(buf, turn_on=turn_on)
+        res.append((module.models["policy"].theta.clone(), module.models["critic"].theta.clone(), dict(info),
+                    module.models["policy"].grad.clone()))
+    on, off = res
+    assert torch.equal(off[0], torch.tensor(g["theta_p0"], device=DEV)) and not torch.equal(on[0], off[0])
+    assert torch.equal(on[1], off[1]) and torch.all(off[3] == 0)
+    assert off[2]["actor_grad_norm"] == 0.0 and off[2]["value_loss"] == on[2]["value_loss"]
+
+
 def test_recurrent_stepwise_rollout_reproduces_the_reference_buffer():
     """Teacher-forced stepwise rollout (golden actions are deterministic functions of obs, states and the sampler's
     uniforms, which the reference drew from torch.multinomial - so compare what does not depend on the sample:
