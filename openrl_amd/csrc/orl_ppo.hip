@@ -90,6 +90,32 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
   return ORL_E_UNSUPPORTED;
 }
 
+// Both towers in one launch (ppo_tower_pair_kernel) when both take the small-observation build (ND == 0) with 8 waves
+// and the transposed W2 copy - configuration 2's shape.  Returns 0 when the pair launch does not apply (the caller then
+// launches the towers one by one), > 0 = launched (gp, gc through the out arguments), < 0 = error.
+template <int HEADP, int NOP_>
+static int try_launch_pair(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int* gc_out, hipStream_t s) {
+  static const bool off = getenv("ORL_PPO_NOPAIR") != nullptr || getenv("ORL_PPO_WAVES") != nullptr ||
+                          getenv("ORL_PPO_MT") != nullptr;
+  if (off) return 0;
+  if (!(P.net.obs_dim <= 4 && (P.o_x & 3) == 0 && Cc.net.obs_dim <= 4 && (Cc.o_x & 3) == 0)) return 0;
+  constexpr int NOPP = NOP_ > 4 ? 16 : ((NOP_ + 3) & ~3);
+  const size_t lp = tower_lds_floats(P.net, P.R, NOPP, 8, HEADP == ORL_HEAD_GAUSSIAN) * sizeof(float);
+  const size_t lc = tower_lds_floats(Cc.net, Cc.R, 4, 8, false) * sizeof(float);
+  const size_t lds = lp > lc ? lp : lc;
+  if (lds > 160 * 1024) return 0;
+  const int n_tiles = (P.mb + TILE_B - 1) / TILE_B;
+  int g = (n_tiles + 7) / 8;
+  if (g > PPO_MAX_BLOCKS) g = PPO_MAX_BLOCKS;
+  (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, 0>), dim3(2 * g), dim3(512), lds, s, P, Cc, g);
+  const int rc = launch_status("orl_ppo_fwd_bwd(pair)");
+  if (rc) return -1000 - rc;
+  *gp_out = g; *gc_out = g;
+  return 1;
+}
+
 template <int HEAD, int NO>
 static int launch_tower_nd(const PpoArgs& A, hipStream_t s) {
   const int D = A.net.obs_dim;
@@ -147,6 +173,28 @@ int orl_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net
   hipStream_t s = (hipStream_t)stream;
   const RawLayout rlp(*pnet);
 
+  // both towers in one launch where that build applies
+  {
+    PpoArgs P = A, Cc = A;
+    P.net = *pnet; P.theta = ptheta; P.o_x = 0; P.partials = partials;
+    Cc.net = *cnet; Cc.theta = ctheta; Cc.o_x = o_co;
+    Cc.partials = partials + (size_t)PPO_MAX_BLOCKS * (rlp.total + ORL_N_STATS);
+    int g1 = 0, g2 = 0, pr = 0;
+    const int no_ = pnet->n_out;
+    if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
+      if (no_ <= 2) pr = try_launch_pair<ORL_HEAD_CATEGORICAL, 2>(P, Cc, &g1, &g2, s);
+      else if (no_ <= 8) pr = try_launch_pair<ORL_HEAD_CATEGORICAL, 8>(P, Cc, &g1, &g2, s);
+      else pr = try_launch_pair<ORL_HEAD_CATEGORICAL, 16>(P, Cc, &g1, &g2, s);
+    } else {
+      if (no_ <= 8) pr = try_launch_pair<ORL_HEAD_GAUSSIAN, 8>(P, Cc, &g1, &g2, s);
+      else pr = try_launch_pair<ORL_HEAD_GAUSSIAN, 16>(P, Cc, &g1, &g2, s);
+    }
+    if (pr < 0) return -(pr + 1000);
+    if (pr > 0) {
+      if (n_blocks_out) { n_blocks_out[0] = g1; n_blocks_out[1] = g2; }
+      return 0;
+    }
+  }
   // policy tower
   A.net = *pnet; A.theta = ptheta; A.o_x = 0; A.partials = partials;
   const int no = pnet->n_out;

@@ -133,7 +133,7 @@ __device__ inline void mm64_T_wt(const float* __restrict__ Ws, const f32x4 (&in)
 // 32 MFMA operands into registers, frees the slabs and runs the 64 wgrad MFMAs.  Fixed service order, so the
 // summation order - and therefore the result - is deterministic.
 template <int HEAD, int NO, int ND, int WPS, bool PC>
-__global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
+__device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const TowerLayout tl(A.net);
   const RawLayout rl(A.net);
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
   const int n_tiles = (A.mb + TILE_B - 1) / TILE_B;
   const int nwv = blockDim.x >> 6;
   const int nprod = PC ? NPROD : nwv;             // waves of this workgroup that walk tiles
-  const int wave_g = blockIdx.x * nprod + wave;
-  const int n_waves = gridDim.x * nprod;
+  const int wave_g = bid * nprod + wave;
+  const int n_waves = nblk * nprod;
   int tiles_done = 0;                              // PC: tiles this producer has handed to its consumer
 
   // ---- record tile pipeline: DMA global -> LDS one tile ahead, indices two tiles ahead ----------------
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
 
 #ifdef ORL_PROF
   __shared__ unsigned long long prof_lds[16];
-  const bool prof_on = blockIdx.x == 0 && wave == 0;
+  const bool prof_on = bid == 0 && wave == 0;
   if (prof_on && l < 16) prof_lds[l] = 0ull;
   unsigned long long t_last = __builtin_readcyclecounter();
 #endif
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
       for (int b = 0; b < 4; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int c = wave - NPROD;
     auto tiles_of = [&](int p) -> int {
-      const int first = blockIdx.x * NPROD + p;
+      const int first = bid * NPROD + p;
       return first < n_tiles ? (n_tiles - first + n_waves - 1) / n_waves : 0;
     };
     const int cnt0 = tiles_of(c), cnt1 = tiles_of(c + 4);
@@ -846,8 +846,22 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
     }
     __syncthreads();
   }
-  float* out = A.partials + (size_t)blockIdx.x * PW;
+  float* out = A.partials + (size_t)bid * PW;
   for (int e = threadIdx.x; e < PW; e += blockDim.x) out[e] = acc[e];
+}
+
+template <int HEAD, int NO, int ND, int WPS, bool PC>
+__global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
+  ppo_tower_body<HEAD, NO, ND, WPS, PC>(A, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Both towers of one minibatch in ONE launch (the default 8-wave build): workgroups [0, gp) are the policy tower,
+// the rest the critic tower.  No kernel boundary between the two: critic workgroups start on a CU as soon as its
+// policy workgroup retires instead of waiting for the slowest policy workgroup of the whole chip.
+template <int HEADP, int NOP_, int ND>
+__global__ __launch_bounds__(512, 2) void ppo_tower_pair_kernel(PpoArgs P, PpoArgs Cc, int gp) {
+  if ((int)blockIdx.x < gp) ppo_tower_body<HEADP, NOP_, ND, 2, false>(P, (int)blockIdx.x, gp);
+  else ppo_tower_body<ORL_HEAD_VALUE, 1, ND, 2, false>(Cc, (int)blockIdx.x - gp, (int)gridDim.x - gp);
 }
 
 // LDS bytes needed by `waves` waves of this tower
