@@ -51,8 +51,7 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str
     base = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
     if prof:  # phase-timing build of the tower kernels (orl_debug_prof); never the shipped configuration
         base.append("-DORL_PROF")
-    objs = []
-    for src in srcs:
+    def compile_one(src):
         obj = os.path.splitext(src)[0] + ".o"
         cmd = base + (["-ffast-math"] if os.path.basename(src) in FAST_MATH else []) + ["-c", src, "-o", obj]
         if verbose:
@@ -60,7 +59,13 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-        objs.append(obj)
+        return obj
+
+    # the translation units are independent: compile them side by side (wall time = the slowest one, orl_ppo.hip)
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, srcs))
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -93,27 +93,48 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
 // Both towers in one launch (ppo_tower_pair_kernel) when both take the small-observation build (ND == 0) with 8 waves
 // and the transposed W2 copy - configuration 2's shape.  Returns 0 when the pair launch does not apply (the caller then
 // launches the towers one by one), > 0 = launched (gp, gc through the out arguments), < 0 = error.
+template <int HEADP, int NOP_, int ND>
+static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int* gc_out, hipStream_t s) {
+  constexpr int NOPP = NOP_ > 4 ? 16 : ((NOP_ + 3) & ~3);
+  for (int w2t = 1; w2t >= (ND == 0 ? 1 : 0); --w2t) {  // same LDS policy as launch_tower: W2^T goes before a pair of waves
+    const size_t lp = tower_lds_floats(P.net, P.R, NOPP, 8, HEADP == ORL_HEAD_GAUSSIAN, false, w2t != 0) * sizeof(float);
+    const size_t lc = tower_lds_floats(Cc.net, Cc.R, 4, 8, false, false, w2t != 0) * sizeof(float);
+    const size_t lds = lp > lc ? lp : lc;
+    if (lds > 160 * 1024) continue;
+    PpoArgs P2 = P, C2 = Cc;
+    P2.use_w2t = w2t; C2.use_w2t = w2t;
+    const int n_tiles = (P.mb + TILE_B - 1) / TILE_B;
+    int g = (n_tiles + 7) / 8;
+    if (g > PPO_MAX_BLOCKS) g = PPO_MAX_BLOCKS;
+    (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND>), dim3(2 * g), dim3(512), lds, s, P2, C2, g);
+    const int rc = launch_status("orl_ppo_fwd_bwd(pair)");
+    if (rc) return -1000 - rc;
+    *gp_out = g; *gc_out = g;
+    return 1;
+  }
+  return 0;  // 8 waves do not fit: the one-by-one launches pick fewer waves
+}
+
+// Both towers in one launch (ppo_tower_pair_kernel) when both take the same build (same ND, 8 waves).  Returns 0 when the
+// pair launch does not apply (the caller then launches the towers one by one), > 0 = launched (workgroups per tower
+// through the out arguments), < 0 = error.
 template <int HEADP, int NOP_>
 static int try_launch_pair(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int* gc_out, hipStream_t s) {
   static const bool off = getenv("ORL_PPO_NOPAIR") != nullptr || getenv("ORL_PPO_WAVES") != nullptr ||
-                          getenv("ORL_PPO_MT") != nullptr;
+                          getenv("ORL_PPO_MT") != nullptr || getenv("ORL_PPO_NOREM") != nullptr;
   if (off) return 0;
-  if (!(P.net.obs_dim <= 4 && (P.o_x & 3) == 0 && Cc.net.obs_dim <= 4 && (Cc.o_x & 3) == 0)) return 0;
-  constexpr int NOPP = NOP_ > 4 ? 16 : ((NOP_ + 3) & ~3);
-  const size_t lp = tower_lds_floats(P.net, P.R, NOPP, 8, HEADP == ORL_HEAD_GAUSSIAN) * sizeof(float);
-  const size_t lc = tower_lds_floats(Cc.net, Cc.R, 4, 8, false) * sizeof(float);
-  const size_t lds = lp > lc ? lp : lc;
-  if (lds > 160 * 1024) return 0;
-  const int n_tiles = (P.mb + TILE_B - 1) / TILE_B;
-  int g = (n_tiles + 7) / 8;
-  if (g > PPO_MAX_BLOCKS) g = PPO_MAX_BLOCKS;
-  (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-  hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, 0>), dim3(2 * g), dim3(512), lds, s, P, Cc, g);
-  const int rc = launch_status("orl_ppo_fwd_bwd(pair)");
-  if (rc) return -1000 - rc;
-  *gp_out = g; *gc_out = g;
-  return 1;
+  auto nd_of = [](const PpoArgs& A) {  // = launch_tower_nd's choice
+    const int D = A.net.obs_dim;
+    return (D <= 4 && (A.o_x & 3) == 0) ? 0 : D <= 20 ? 1 : D <= 36 ? 2 : 4;
+  };
+  const int nd = nd_of(P);
+  if (nd != nd_of(Cc)) return 0;
+  if (nd == 0) return launch_pair_nd<HEADP, NOP_, 0>(P, Cc, gp_out, gc_out, s);
+  if (nd == 1) return launch_pair_nd<HEADP, NOP_, 1>(P, Cc, gp_out, gc_out, s);
+  if (nd == 2) return launch_pair_nd<HEADP, NOP_, 2>(P, Cc, gp_out, gc_out, s);
+  return 0;  // obs > 36 (ND == 4): rare, one launch per tower
 }
 
 template <int HEAD, int NO>
