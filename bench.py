@@ -130,7 +130,7 @@ def main():
             traffic = json.load(fh)["orl_ppo_fwd_bwd_pair"]["hbm_bytes_per_launch_raw"]
     except Exception:
         pass
-    roofline = {"kernel": "orl_ppo_fwd_bwd (ppo_tower_kernel policy+critic)", "bound": "mfma",
+    roofline = {"kernel": "orl_ppo_fwd_bwd (ppo_tower_pair_kernel: policy + critic towers in one launch)", "bound": "mfma",
                 "achieved": round(achieved_tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launch_ms": round(k_ms, 4), "launches_timed": len(ev),

@@ -9,10 +9,6 @@ OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 
-# 1. the default bench line (includes the bounded CPU baseline)
-timeout 600 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err
-tail -c 600 $OUT/${TAG}_bench_line.json
-
 # 2. per-kernel time of the same command (no CPU leg: it is not GPU work)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- \
     python bench.py --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
@@ -26,6 +22,11 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/summarize_pmc.py $OUT/${TAG}_pmc_FETCH_SIZE.csv $OUT/${TAG}_pmc_WRITE_SIZE.csv > $OUT/${TAG}_pmc_hbm.json
 cat $OUT/${TAG}_pmc_hbm.json | head -50
+cp $OUT/${TAG}_pmc_hbm.json profiles/${TAG}_pmc_hbm.json  # bench.py quotes roofline.traffic from the committed path
+
+# 1. the default bench line (includes the bounded CPU baseline); after the PMC summary so that roofline.traffic is this run's
+timeout 600 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err
+tail -c 600 $OUT/${TAG}_bench_line.json
 
 # 4. recurrent (cfg4 shape) update micro-benchmark + its kernel stats
 timeout 600 python benchmarks/rnn_update_bench.py > $OUT/${TAG}_rnn_update_line.json 2>/dev/null

@@ -14,6 +14,7 @@ from collections import defaultdict
 # bench.py's workload (configs[1]): rows per launch and bytes per record, for the algorithmic figure
 ROWS, REC_BYTES = 4096 * 128, 64
 KEYS = [("gae_scan", "gae_scan_kernel"), ("adv_normalize_pack", "adv_normalize_pack_kernel"),
+        ("ppo_tower_pair", "ppo_tower_pair_kernel"),  # both towers in one launch (the default build)
         ("ppo_tower_policy", "ppo_tower_kernel<1,"), ("ppo_tower_critic", "ppo_tower_kernel<0,"),
         ("rollout_fused", "rollout_kernel"), ("ppo_apply", "ppo_apply_kernel"), ("ppo_reduce_pair", "ppo_reduce_pair_kernel")]
 
@@ -40,9 +41,10 @@ def main():
             f, w = fetch.get(key, []), write.get(key, [])
             out[key] = {"FETCH_SIZE_KB_mean": round(sum(f) / max(len(f), 1), 1), "launches_fetch": len(f),
                         "WRITE_SIZE_KB_mean": round(sum(w) / max(len(w), 1), 1), "launches_write": len(w)}
-    if "ppo_tower_policy" in out and "ppo_tower_critic" in out:
-        raw = sum(out[k]["FETCH_SIZE_KB_mean"] + out[k]["WRITE_SIZE_KB_mean"] for k in ("ppo_tower_policy", "ppo_tower_critic"))
-        x2 = sum(2 * out[k]["FETCH_SIZE_KB_mean"] + out[k]["WRITE_SIZE_KB_mean"] for k in ("ppo_tower_policy", "ppo_tower_critic"))
+    towers = ("ppo_tower_pair",) if "ppo_tower_pair" in out else ("ppo_tower_policy", "ppo_tower_critic")
+    if all(k in out for k in towers):
+        raw = sum(out[k]["FETCH_SIZE_KB_mean"] + out[k]["WRITE_SIZE_KB_mean"] for k in towers)
+        x2 = sum(2 * out[k]["FETCH_SIZE_KB_mean"] + out[k]["WRITE_SIZE_KB_mean"] for k in towers)
         out["orl_ppo_fwd_bwd_pair"] = {
             "hbm_bytes_per_launch_raw": int(raw * 1024), "hbm_bytes_per_launch_fetch_x2": int(x2 * 1024),
             "algorithmic_bytes_per_launch": 2 * ROWS * REC_BYTES + 2 * ROWS * 8 + 256 * 4 * (4626 + 4561),
