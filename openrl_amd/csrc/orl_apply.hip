@@ -168,6 +168,9 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
       g_s[p] = g;
       ss += g * g;
     }
+    // one Adam loop for both cases: generic pointers to the staged copies (LDS) or to the moments in HBM
+    const float* mp = stage_mv ? (const float*)m_s : (const float*)W.ad.m;
+    const float* vp = stage_mv ? (const float*)v_s : (const float*)W.ad.v;
     const float total = sqrtf(block_sum_1024(ss, sh));
     norms[t] = total;
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
       W.ad.grad[p] = g;
       float th = th_s[p];
       if (W.ad.weight_decay != 0.f) g += W.ad.weight_decay * th;
-      float m = stage_mv ? m_s[p] : W.ad.m[p], v = stage_mv ? v_s[p] : W.ad.v[p];
+      float m = mp[p], v = vp[p];
       m = m + (g - m) * omb1;          // exp_avg.lerp_(grad, 1 - beta1)
       v = v * b2 + omb2 * (g * g);     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
       const float denom = sqrtf(v) / bc2_sqrt + W.ad.eps;
@@ -286,7 +289,7 @@ static int launch_apply(const char* what, const orl_net_desc* pnet, const orl_ne
   int perm_blocks = 0;
   if (J.idx != nullptr) {
     perm_blocks = (int)((J.n + 1023) / 1024);
-    if (perm_blocks > 512) perm_blocks = 512;
+    if (perm_blocks > 254) perm_blocks = 254;  // one workgroup per CU next to the two apply workgroups (their LDS footprint is per launch)
   }
   (void)hipFuncSetAttribute((const void*)ppo_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(ppo_apply_kernel, dim3(2 + perm_blocks), dim3(1024), lds, (hipStream_t)stream, P, Cc, sums, *hp,
