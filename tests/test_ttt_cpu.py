@@ -41,3 +41,29 @@ def test_random_games_terminate_with_consistent_rewards_and_masks():
         g.step(4)
         taken = 4 if g.board[4] != 0 else int(np.flatnonzero(g.mask() == 0)[0])
     assert g.step(taken) == (-1.0, True)
+
+
+def test_two_phase_step_with_the_random_reply_equals_the_one_phase_step():
+    """Oracle self-consistency: agent_move + opponent_move(reply) == step when the reply is the uniformly random legal
+    move step() itself would draw (same Philox key) - ties the self-play restatement to the random-opponent one."""
+    import copy
+
+    from oracle import philox as px
+
+    rs = np.random.RandomState(5)
+    for env in range(60):
+        a_game, b_game = to.Game(seed=8, env=env), to.Game(seed=8, env=env)
+        for _ in range(30):
+            assert a_game.board == b_game.board and a_game.episode == b_game.episode
+            act = int(rs.choice(np.flatnonzero(a_game.mask())))
+            want = a_game.step(act)
+            rew, done, pending = b_game.agent_move(act)
+            reply = 0
+            if pending:
+                empty = [c for c in range(9) if b_game.board[c] == 0]
+                x, _, _, _ = px.philox4x32_10(8, env, 0x77C70000 + b_game.moves, b_game.episode, 0)
+                k = int(np.float32(px.u01(x)) * np.float32(len(empty)))
+                reply = empty[min(k, len(empty) - 1)]
+            got = b_game.opponent_move(reply)
+            assert got == want and a_game.board == b_game.board and a_game.moves == b_game.moves
+    del copy
