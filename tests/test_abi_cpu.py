@@ -101,3 +101,16 @@ def test_product_package_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c():
+    """include/orl_hip.h is the C ABI: it must compile as C99 on its own (no C++ / torch / HIP types in the signatures)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this machine")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "orl_hip.h")
+    res = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
