@@ -209,14 +209,117 @@ class ProgressBarCallback(BaseCallback):
     needs_per_step = False
 
 
-CALLBACKS = {"CheckpointCallback": CheckpointCallback, "StopTrainingOnMaxEpisodes": StopTrainingOnMaxEpisodes,
+class StopTrainingOnRewardThreshold(BaseCallback):
+    """Child of ``EvalCallback`` (``callbacks_on_new_best``): stop once the best mean evaluation reward reaches the
+    threshold (stop_callback.py:25-57)."""
+
+    def __init__(self, reward_threshold: float, verbose: int = 0):
+        super().__init__(verbose)
+        self.reward_threshold = float(reward_threshold)
+
+    def _on_step(self) -> bool:
+        assert self.parent is not None, "StopTrainingOnRewardThreshold must be used with an EvalCallback"
+        return bool(self.parent.best_mean_reward < self.reward_threshold)
+
+
+class EvalCallback(BaseCallback):
+    """Every ``eval_freq`` calls, play ``n_eval_episodes`` episodes per env of a separate DEVICE-RESIDENT evaluation env
+    with the current policy (greedy by default), track the best mean episode return, save the best model and run the
+    ``callbacks_on_new_best`` / ``callbacks_after_eval`` children (openrl/utils/callbacks/eval_callback.py:73-246).
+    ``eval_env``: a device VecEnv of this package or the ``{"id": ..., "env_num": ...}`` spec ``make`` takes.  Episode
+    returns come from the env's in-kernel episode statistics, so the evaluation itself never leaves the device."""
+
+    def __init__(self, eval_env, callbacks_on_new_best=None, callbacks_after_eval=None, n_eval_episodes: int = 5,
+                 eval_freq: int = 10000, log_path: Optional[str] = None, best_model_save_path: Optional[str] = None,
+                 deterministic: bool = True, render: bool = False, verbose: int = 1, stop_logic: str = "OR",
+                 max_eval_steps: int = 100000):
+        super().__init__(verbose)
+        self.eval_env_spec, self.eval_env = eval_env, None
+        mk = lambda c: None if c is None else (CallbackFactory.get_callbacks(c) if isinstance(c, (dict, list)) else c)
+        self.on_new_best, self.after_eval = mk(callbacks_on_new_best), mk(callbacks_after_eval)
+        self.n_eval_episodes, self.eval_freq, self.deterministic = int(n_eval_episodes), int(eval_freq), bool(deterministic)
+        self.best_model_save_path, self.max_eval_steps = best_model_save_path, int(max_eval_steps)
+        self.best_mean_reward, self.last_mean_reward = -float("inf"), -float("inf")
+        self.evaluations = []  # (num_time_steps, mean episode return, episodes)
+
+    def _init_callback(self) -> None:
+        if isinstance(self.eval_env_spec, dict):
+            from ..envs.common import make
+
+            spec = dict(self.eval_env_spec)
+            self.eval_env = make(spec.pop("id"), **spec)
+        else:
+            self.eval_env = self.eval_env_spec
+        if not getattr(self.eval_env, "is_device_env", False):
+            raise NotImplementedError("EvalCallback evaluates on the device-resident envs of this package")
+        for child in (self.on_new_best, self.after_eval):
+            if child is not None:
+                child.parent = self
+                for c in getattr(child, "callbacks", [child]):
+                    c.parent = self
+                child.init_callback(self.agent)
+
+    def evaluate(self):
+        import torch
+
+        env, module = self.eval_env, self.agent.net.module
+        n, a = env.parallel_env_num, env.agent_num
+        obs = env.reset_device(seed=getattr(env, "seed", 0))
+        env.ep_stats.zero_()
+        target = self.n_eval_episodes * n
+        h = torch.zeros(n * a, module.cfg.hidden_size, device=env.device) if getattr(module, "recurrent", False) else None
+        masks = torch.ones(n * a, 1, device=env.device)
+        for step in range(self.max_eval_steps):
+            p_obs = obs["policy"] if isinstance(obs, dict) else obs
+            am = getattr(env, "action_mask_device", None)
+            act, h2 = module.act(p_obs.reshape(n * a, -1), h, masks, action_masks=None if am is None else am.reshape(n * a, -1),
+                                 deterministic=self.deterministic)
+            obs, _, done = env.step_device(act.view(n, a, -1))
+            if h is not None:
+                masks = 1.0 - done.reshape(n * a, 1).float()
+                h = h2.reshape(n * a, -1)
+            if step % 8 == 7 and env.episode_statistics()["episodes_finished"] >= target:
+                break
+        st = env.episode_statistics()
+        return st["episode_return_mean"], int(st["episodes_finished"])
+
+    def _on_step(self) -> bool:
+        if self.eval_freq <= 0 or self.n_calls % self.eval_freq != 0:
+            return True
+        mean_reward, episodes = self.evaluate()
+        self.last_mean_reward = float(mean_reward)
+        self.evaluations.append((self.num_time_steps, self.last_mean_reward, episodes))
+        if self.verbose >= 1:
+            print("Eval num_time_steps=%d, episode_reward=%.2f over %d episodes" % (self.num_time_steps, mean_reward, episodes))
+        keep = True
+        if self.last_mean_reward > self.best_mean_reward:
+            self.best_mean_reward = self.last_mean_reward
+            if self.best_model_save_path is not None:
+                import os
+
+                os.makedirs(self.best_model_save_path, exist_ok=True)
+                self.agent.save(os.path.join(self.best_model_save_path, "best_model"))
+            if self.on_new_best is not None:
+                keep = self.on_new_best.on_step() and keep
+        if self.after_eval is not None:
+            keep = self.after_eval.on_step() and keep
+        return keep
+
+    def update_child_locals(self, locals_: Dict[str, Any]) -> None:
+        for child in (self.on_new_best, self.after_eval):
+            if child is not None:
+                child.update_locals(locals_)
+
+
+CALLBACKS = {"CheckpointCallback": CheckpointCallback, "EvalCallback": EvalCallback,
+             "StopTrainingOnRewardThreshold": StopTrainingOnRewardThreshold, "StopTrainingOnMaxEpisodes": StopTrainingOnMaxEpisodes,
              "ProgressBarCallback": ProgressBarCallback, "EveryNTimesteps": EveryNTimesteps,
              "SelfPlayCallback": SelfPlayCallback}
 
 
 class CallbackFactory:
     """``cfg.callbacks`` entries ``{"id": ..., "args": {...}}`` -> callback objects (callbacks_factory.py:14-60).
-    EvalCallback / StopTrainingOnRewardThreshold / StopTrainingOnNoModelImprovement / SelfplayAPI are not built."""
+    StopTrainingOnNoModelImprovement / SelfplayAPI are not built."""
 
     @staticmethod
     def get_callback(spec: Dict[str, Any]) -> BaseCallback:

@@ -194,8 +194,29 @@ def test_callback_factory_checkpoint_and_stop_on_max_episodes(tmp_path):
     agent.load(ck.saved[-1])
     assert agent.net.module.models["policy"].theta.abs().sum() > 0
     with pytest.raises(ValueError):
-        CallbackFactory.get_callback({"id": "EvalCallback"})
+        CallbackFactory.get_callback({"id": "StopTrainingOnNoModelImprovement"})
     del theta
+
+
+def test_eval_callback_with_reward_threshold_stops_training(tmp_path):
+    """examples/cartpole/callbacks.yaml's EvalCallback + StopTrainingOnRewardThreshold on a device-resident eval env."""
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import PPOAgent as Agent
+    from openrl_amd.utils.callbacks import CallbackFactory
+
+    cfg = _cfg(["--episode_length", "32", "--ppo_epoch", "4", "--lr", "1e-3", "--critic_lr", "1e-3"])
+    env = make("CartPole-v1", env_num=64, device=DEV)
+    agent = Agent(Net(env, cfg=cfg, device=DEV))
+    cb = CallbackFactory.get_callback({"id": "EvalCallback", "args": {
+        "eval_env": {"id": "CartPole-v1", "env_num": 16, "device": DEV}, "n_eval_episodes": 2, "eval_freq": 64,
+        "best_model_save_path": str(tmp_path / "best"), "verbose": 0,
+        "callbacks_on_new_best": [{"id": "StopTrainingOnRewardThreshold", "args": {"reward_threshold": 150.0}}]}})
+    agent.train(total_time_steps=64 * 32 * 400, callback=cb)
+    assert len(cb.evaluations) >= 1 and cb.best_mean_reward >= 150.0, cb.evaluations
+    assert agent.num_time_steps < 64 * 32 * 400, "training did not stop at the threshold"
+    assert all(e[2] >= 32 for e in cb.evaluations) and (tmp_path / "best").exists()
+    assert cb.evaluations[-1][1] == cb.best_mean_reward  # the evaluation that crossed the threshold ended the run
 
 
 def test_cartpole_learns_like_the_reference_recipe(tmp_path):
