@@ -31,3 +31,18 @@ def test_cartpole_example_train_and_evaluate():
     agent = ex.train(env_num=9, total_time_steps=9 * 200 * 2)
     steps, total_reward = ex.evaluation(agent, env_num=9)
     assert steps >= 8 and total_reward > 0
+
+
+def test_selfplay_and_callback_examples_run(tmp_path, monkeypatch, capsys):
+    import sys
+
+    monkeypatch.chdir(tmp_path)  # the callbacks example writes ./results/
+    sp = _load(os.path.join(ROOT, "examples", "selfplay", "train_selfplay.py"))
+    monkeypatch.setattr(sys, "argv", ["train_selfplay.py", "--envs", "512", "--steps", str(512 * 20 * 30)])
+    sp.main()
+    out = capsys.readouterr().out
+    assert "vs random opponent" in out and float(out.strip().split()[-1]) > 0.2
+    cb = _load(os.path.join(ROOT, "examples", "cartpole", "train_ppo_callbacks.py"))
+    cb.main()
+    out = capsys.readouterr().out
+    assert "stopped after" in out and os.path.isdir(tmp_path / "results" / "best_model")
