@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 100 /* 0.1.0 */
+#define ORL_VERSION 200 /* 0.2.0: rng_step_dev arguments (no thread-local state), orl_abi_struct_size, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -54,6 +54,12 @@ typedef struct orl_net_desc {
   int32_t n_out;     /* head width */
   int32_t head_kind; /* ORL_HEAD_* */
 } orl_net_desc;
+
+/* ABI guard for bindings: sizeof() of the structs of this header AS THE LIBRARY WAS BUILT, so that a stale shared
+ * object with the same symbol names but another struct layout is refused at load time instead of corrupting device
+ * memory.  which: 0 orl_net_desc, 1 orl_pack_src, 2 orl_buffer_ptrs, 3 orl_copy_desc, 4 orl_gather_desc,
+ * 5 orl_ppo_hparams, 6 orl_adam_state, 7 orl_rollout_args, 8 orl_rnn_batch; anything else returns ORL_E_INVALID. */
+int orl_abi_struct_size(int which);
 
 /* number of float32 parameters of a tower (== sum of reference state_dict numels) */
 int orl_param_count(const orl_net_desc* net);
@@ -198,20 +204,21 @@ int orl_perm_feistel_vn(int64_t* idx, int64_t n, uint64_t seed, uint64_t stream_
 int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet,
                  const float* ctheta, const float* policy_obs, const float* critic_obs,
                  const float* action_masks, int B, int deterministic, uint64_t seed, uint64_t row0,
-                 uint64_t rng_step, const float* forced_u, float* values, float* actions, float* logp,
-                 void* stream);
+                 uint64_t rng_step, const uint64_t* rng_step_dev, const float* forced_u, float* values,
+                 float* actions, float* logp, void* stream);
 /* orl_act_step (policy only) for a POOL of policies of one architecture in one launch: rows
  * [g*rows_per_group, (g+1)*rows_per_group) are evaluated with the parameters pthetas + g*theta_stride
  * (rows_per_group a multiple of 16).  The self-play env uses it for the opponents' moves. */
 int orl_act_step_grouped(const orl_net_desc* pnet, const float* pthetas, int64_t theta_stride, int rows_per_group,
                          const float* policy_obs, const float* action_masks, int B, int deterministic, uint64_t seed,
-                         uint64_t row0, uint64_t rng_step, float* actions, float* logp, void* stream);
+                         uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev, float* actions, float* logp,
+                         void* stream);
 
-/* Optional device-side addend of `rng_step` for orl_act_step / orl_rnn_act_step launched afterwards from this host
- * thread (NULL switches it off): rng_step_effective = rng_step + *dev_counter, read by the kernel at run time.  It
- * exists so that a stepwise rollout can be captured ONCE into a hipGraph (kernel arguments are frozen at capture)
- * and replayed every iteration with fresh Philox counters - the caller advances the counter on the device. */
-int orl_act_rng_offset(const uint64_t* dev_counter);
+/* `rng_step_dev` (orl_act_step / orl_act_step_grouped / orl_rnn_act_step; may be NULL): optional DEVICE-side addend
+ * of `rng_step`: rng_step_effective = rng_step + *rng_step_dev, read by the kernel at run time.  It exists so that a
+ * stepwise rollout can be captured ONCE into a hipGraph (kernel arguments are frozen at capture) and replayed every
+ * iteration with fresh Philox counters - the caller advances the counter on the device.  An explicit argument: the
+ * library keeps no per-thread or global state besides the last-error string. */
 
 /* Forward-only evaluation of GIVEN actions = PPOModule.evaluate_actions (openrl/modules/ppo_module.py:149-193,
  * PolicyNetwork.eval_actions networks/policy_network.py:164-203, ACTLayer.evaluate_actions utils/act.py:102-172):
@@ -408,9 +415,9 @@ int orl_rnn_raw_grad_count(const orl_net_desc* net);
 int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                      const float* policy_obs, const float* critic_obs, const float* h_policy_in,
                      const float* h_critic_in, const float* masks, const float* action_masks, int B,
-                     int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const float* forced_u,
-                     float* values, float* actions, float* logp, float* h_policy_out, float* h_critic_out,
-                     void* stream);
+                     int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
+                     const float* forced_u, float* values, float* actions, float* logp, float* h_policy_out,
+                     float* h_critic_out, void* stream);
 
 /* ReplayData.recurrent_generator's index arithmetic (buffers/replay_data.py:1062-1258): chunk c covers the rows
  * c*L .. c*L+L-1 of the [lane][t]-ordered flat batch (lane = n*A+a; chunks may straddle lanes when T % L != 0).

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liborl_hip.so")
 ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL = 0, 1, 2, 3
 ORL_GATHER_MAX = 12
+ORL_VERSION = 200  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -84,10 +85,14 @@ class RnnBatch(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+# order of orl_abi_struct_size(which)
+_ABI_STRUCTS = (NetDesc, PackSrc, BufferPtrs, CopyDesc, GatherDesc, PPOHParams, AdamState, RolloutArgs, RnnBatch)
+
 # name -> (restype, argtypes); must list EVERY symbol of include/orl_hip.h (tests check this)
 _P = C.c_void_p
 _SIGNATURES = {
     "orl_version": (C.c_int, []),
+    "orl_abi_struct_size": (C.c_int, [C.c_int]),
     "orl_last_error_string": (C.c_char_p, []),
     "orl_param_count": (C.c_int, [C.POINTER(NetDesc)]),
     "orl_raw_grad_count": (C.c_int, [C.POINTER(NetDesc)]),
@@ -104,7 +109,7 @@ _SIGNATURES = {
     "orl_perm_feistel": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "orl_perm_feistel_vn": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, C.c_double, _P]),
     "orl_act_step": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, C.c_int, C.c_int,
-                               C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
+                               C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P]),
     "orl_ttt_state_width": (C.c_int, []),
     "orl_ttt_reset": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "orl_ttt_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
@@ -112,7 +117,7 @@ _SIGNATURES = {
     "orl_ttt_opponent_move": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "orl_critic_values": (C.c_int, [C.POINTER(NetDesc), _P, _P, C.c_int64, _P, _P]),
     "orl_act_step_grouped": (C.c_int, [C.POINTER(NetDesc), _P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64,
-                                       C.c_uint64, C.c_uint64, _P, _P, _P]),
+                                       C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "orl_evaluate_actions": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, C.c_int, _P,
                                        _P, _P, _P, _P]),
     "orl_ppo_max_blocks": (C.c_int, []),
@@ -132,14 +137,13 @@ _SIGNATURES = {
     "orl_env_step": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                C.c_uint64, _P]),
     "orl_rollout_fused": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, C.POINTER(RolloutArgs), _P, _P]),
-    "orl_act_rng_offset": (C.c_int, [_P]),
     "orl_mpe_state_width": (C.c_int, []),
     "orl_mpe_reset": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "orl_mpe_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.c_int, _P]),
     "orl_rnn_param_count": (C.c_int, [C.POINTER(NetDesc)]),
     "orl_rnn_raw_grad_count": (C.c_int, [C.POINTER(NetDesc)]),
     "orl_rnn_act_step": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int,
-                                   C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P]),
+                                   C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "orl_rnn_chunk_rows": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "orl_rnn_workspace_floats": (C.c_int64, [C.POINTER(NetDesc), C.POINTER(NetDesc), C.c_int, C.c_int]),
     "orl_rnn_ppo_fwd_bwd": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, C.POINTER(RnnBatch), _P,
@@ -160,17 +164,27 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    from .csrc import build as _b
+
     if not os.path.exists(LIB_PATH):
         if not build_if_missing:
             raise NativeError("%s is missing - run `python -m openrl_amd.csrc.build`" % LIB_PATH)
-        from .csrc import build as _b
-
         _b.build()
+    elif build_if_missing and _b.have_hipcc():
+        _b.build()  # no-op when the source digest matches the stamp; rebuilds a stale shared object
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale -> loud failure
         fn.restype = res
         fn.argtypes = args
+    # a stale build can export the same names with another struct layout: refuse it instead of corrupting memory
+    if lib.orl_version() != ORL_VERSION:
+        raise NativeError("%s is version %d, the bindings are %d - rebuild with `python -m openrl_amd.csrc.build "
+                          "--force`" % (LIB_PATH, lib.orl_version(), ORL_VERSION))
+    for which, st in enumerate(_ABI_STRUCTS):
+        if lib.orl_abi_struct_size(which) != C.sizeof(st):
+            raise NativeError("ABI mismatch: %s is %d bytes in %s, %d in the bindings" %
+                              (st.__name__, lib.orl_abi_struct_size(which), LIB_PATH, C.sizeof(st)))
     _lib = lib
     return lib
 

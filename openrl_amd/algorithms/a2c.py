@@ -7,16 +7,13 @@ from typing import Union
 
 import torch
 
-from .ppo import PPOAlgorithm
+from .ppo import INFO_KEYS, PPOAlgorithm
 
 
 class A2CAlgorithm(PPOAlgorithm):
+    info_keys = INFO_KEYS[:5]  # no "ratio" (a2c.py:142-145); the dict stays lazy - nothing is popped on the host
+
     def __init__(self, cfg, init_module, agent_num: int = 1, device: Union[str, torch.device] = "cuda:0") -> None:
         super().__init__(cfg, init_module, agent_num, device)
         self.num_mini_batch = 1  # a2c.py:37
         self.hp.reserved |= 2    # policy-gradient loss
-
-    def train(self, buffer, turn_on: bool = True):
-        train_info = super().train(buffer, turn_on)
-        train_info.pop("ratio", None)  # a2c.py:142-145
-        return train_info

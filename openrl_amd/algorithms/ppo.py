@@ -104,6 +104,9 @@ class DeviceTrainInfo(dict):
 
 
 class PPOAlgorithm(BaseAlgorithm):
+    #: train_info keys in the order of the device accumulator (a prefix of INFO_KEYS; A2C drops the trailing "ratio")
+    info_keys = INFO_KEYS
+
     def __init__(self, cfg, init_module, agent_num: int = 1, device: Union[str, torch.device] = "cuda:0") -> None:
         if cfg.use_share_model or cfg.use_joint_action_loss or cfg.use_deepspeed or cfg.use_amp:
             raise NotImplementedError("share_model / joint_action_loss / deepspeed / amp are not built in this engine")
@@ -250,6 +253,8 @@ class PPOAlgorithm(BaseAlgorithm):
             n, seed, sid, vn = self._perm_job(data_chunks)
             self._vn_in_perm = vn is not None
             rand = ops.perm_feistel(n, seed, sid, self.device, vn)
+        elif self.perm_mode == "identity":  # chunks in buffer order (parity debugging / determinism)
+            rand = torch.arange(data_chunks, dtype=torch.int64, device=self.device)
         else:
             rand = torch.randperm(data_chunks).to(self.device, non_blocking=True)  # replay_data.py:1078
         return [rand[i * mbs:(i + 1) * mbs] for i in range(self.num_mini_batch)], mbs
@@ -267,11 +272,14 @@ class PPOAlgorithm(BaseAlgorithm):
         """``perm``: this epoch's permutation if the previous epoch's optimiser-step launch already produced it."""
         mbs = M // self.num_mini_batch
         n_batches = M // mbs  # drop_last=True (replay_data.py:578-580)
-        if self.perm_mode == "identity" and self.num_mini_batch == 1:
-            return [None], mbs
+        if self.perm_mode == "identity":  # buffer order: the whole batch, or contiguous slices of it
+            if self.num_mini_batch == 1:
+                return [None], mbs
+            order = torch.arange(M, dtype=torch.int64, device=self.device)
+            return [order[b * mbs:(b + 1) * mbs] for b in range(n_batches)], mbs
         if perm is not None:
             self._vn_in_perm = self._full_batch_moments and self._use_valuenorm
-        elif self.perm_mode in ("device", "identity"):
+        elif self.perm_mode == "device":
             n, seed, sid, vn = self._perm_job(M)
             self._vn_in_perm = vn is not None
             perm = ops.perm_feistel(n, seed, sid, self.device, vn)
@@ -310,7 +318,8 @@ class PPOAlgorithm(BaseAlgorithm):
         num_updates = self.ppo_epoch * self.num_mini_batch
         # no device->host sync here: the averages stay on the device until somebody reads the dict (logging every
         # log_interval iterations, tests), so the host can enqueue the next rollout while this update still runs
-        return DeviceTrainInfo(INFO_KEYS, self._info[:6] / float(num_updates))
+        keys = self.info_keys
+        return DeviceTrainInfo(keys, self._info[:len(keys)] / float(num_updates))
 
     def train(self, buffer, turn_on: bool = True) -> Dict[str, float]:
         if len(self.train_list) == 1:

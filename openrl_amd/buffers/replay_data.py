@@ -59,6 +59,8 @@ class ReplayData(object):
         self.value_preds = z(T + 1, N, A, 1)
         self.returns = z(T + 1, N, A, 1)
         self.act_kind = spaces.kind(act_space)
+        #: actions are integer indices stored as floats (what a host env must be handed as int64)
+        self.act_is_index = self.act_kind in ("Discrete", "MultiDiscrete", "MultiBinary")
         self.K = int(act_space.n) if self.act_kind == "Discrete" else 0
         self.action_masks = o(T + 1, N, A, self.K) if self.K else None
         self.act_shape = a = spaces.act_shape(act_space)

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["orl_buffer.hip", "orl_act.hip", "orl_ppo.hip", "orl_apply.hip", "orl_rnn.hip", "orl_mpe.hip", "orl_ttt.hip"]
-HEADERS = ["orl_common.h", "orl_mlp.h", "orl_ppo_tower.h", "orl_ppo_tower_mt.h", "orl_heads.h", "orl_loss.h", "orl_rnn.h", "orl_perm.h", "orl_ttt.h", os.path.join("..", "..", "include", "orl_hip.h")]
+HEADERS = ["orl_common.h", "orl_mlp.h", "orl_ppo_tower.h", "orl_heads.h", "orl_loss.h", "orl_rnn.h", "orl_perm.h", "orl_ttt.h", os.path.join("..", "..", "include", "orl_hip.h")]
 FAST_MATH = {"orl_ppo.hip", "orl_rnn.hip", "orl_act.hip"}
 LIB = os.path.join(HERE, "liborl_hip.so")
 STAMP = os.path.join(HERE, ".liborl_hip.stamp")
@@ -25,6 +25,10 @@ def _hipcc() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found; cannot build the gfx950 extension")
+
+
+def have_hipcc() -> bool:
+    return bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
 
 
 def _digest() -> str:

@@ -30,7 +30,7 @@ struct ActArgs {
   int B;
   int deterministic;
   uint64_t seed, row0, rng_step;
-  const unsigned long long* rng_dev;  // optional device-side addend of rng_step (orl_act_rng_offset)
+  const unsigned long long* rng_dev;  // optional device-side addend of rng_step (rng_step_dev argument)
   int group_rows;          // > 0: rows [g*group_rows, (g+1)*group_rows) use the policy parameters ptheta + g*theta_stride
   long long theta_stride;  //      (orl_act_step_grouped: one launch for a pool of policies); a multiple of 16 rows
 };
@@ -915,8 +915,8 @@ extern "C" {
 
 static int act_step_impl(const char* what, int group_rows, long long theta_stride, const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                  const float* policy_obs, const float* critic_obs, const float* action_masks, int B,
-                 int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const float* forced_u,
-                 float* values, float* actions, float* logp, void* stream) {
+                 int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
+                 const float* forced_u, float* values, float* actions, float* logp, void* stream) {
   int rc = check_net(pnet, "orl_act_step(policy)", false);
   if (rc) return rc;
   ORL_REQUIRE(ptheta || ctheta, "orl_act_step: neither tower given");
@@ -938,7 +938,7 @@ static int act_step_impl(const char* what, int group_rows, long long theta_strid
   A.cnet = ctheta ? *cnet : *pnet;
   A.ptheta = ptheta; A.ctheta = ctheta; A.pobs = policy_obs; A.cobs = critic_obs; A.amask = action_masks;
   A.forced = forced_u; A.values = values; A.actions = actions; A.logp = logp; A.B = B;
-  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step; A.rng_dev = g_rng_dev;
+  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step; A.rng_dev = (const unsigned long long*)rng_step_dev;
   A.group_rows = group_rows; A.theta_stride = theta_stride;
   const int grid = (B + TILE_B - 1) / TILE_B;
 #define ORL_ACT_LAUNCH(NO, HD)                                                                                  \
@@ -955,19 +955,21 @@ static int act_step_impl(const char* what, int group_rows, long long theta_strid
 
 int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                  const float* policy_obs, const float* critic_obs, const float* action_masks, int B, int deterministic,
-                 uint64_t seed, uint64_t row0, uint64_t rng_step, const float* forced_u, float* values, float* actions,
-                 float* logp, void* stream) {
-  return act_step_impl("orl_act_step", 0, 0, pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, action_masks, B, deterministic, seed, row0, rng_step, forced_u, values, actions, logp, stream);
+                 uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev, const float* forced_u,
+                 float* values, float* actions, float* logp, void* stream) {
+  return act_step_impl("orl_act_step", 0, 0, pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, action_masks, B,
+                       deterministic, seed, row0, rng_step, rng_step_dev, forced_u, values, actions, logp, stream);
 }
 
 int orl_act_step_grouped(const orl_net_desc* pnet, const float* pthetas, int64_t theta_stride, int rows_per_group,
                          const float* policy_obs, const float* action_masks, int B, int deterministic, uint64_t seed,
-                         uint64_t row0, uint64_t rng_step, float* actions, float* logp, void* stream) {
+                         uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev, float* actions, float* logp,
+                         void* stream) {
   ORL_REQUIRE(pthetas && rows_per_group > 0 && rows_per_group % TILE_B == 0 && theta_stride >= 0,
               "orl_act_step_grouped: rows_per_group must be a positive multiple of %d", TILE_B);
   return act_step_impl("orl_act_step_grouped", rows_per_group, theta_stride, pnet, pthetas, nullptr, nullptr, policy_obs,
-                       nullptr, action_masks, B, deterministic, seed, row0, rng_step, nullptr, nullptr, actions, logp,
-                       stream);
+                       nullptr, action_masks, B, deterministic, seed, row0, rng_step, rng_step_dev, nullptr, nullptr, actions,
+                       logp, stream);
 }
 
 int orl_evaluate_actions(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
@@ -1107,11 +1109,9 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
                 "orl_rollout_fused: tic-tac-toe needs Discrete(9), 18-d obs and the action-mask array");
   const TowerLds twp(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false, pnet->n_out > 2);
   const TowerLds twc(cnet->obs_dim, 1, false, false);
-  // ORL_ROLLOUT_SPLIT=1 (A/B knob): policy-only step loop + one batched orl_critic_values launch over all T+1 slots.
-  // Measured at config 2: the step loop drops only 271 -> 237 us (the policy's own latency chain is the step), the
-  // value launch costs 60 us - so the critic stays inside the loop by default.
-  static const bool split = getenv("ORL_ROLLOUT_SPLIT") != nullptr;
-  const size_t lds = (size_t)(twp.total + (split ? 0 : twc.total) + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 4 * TILE_B * 16 +
+  // The critic stays inside the step loop: a policy-only loop + one batched orl_critic_values launch over all T+1
+  // slots was measured slower at config 2 (271 -> 237 us step loop, +60 us value launch).
+  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 4 * TILE_B * 16 +
                                  (pool ? twp.total + TILE_B * twp.DP + TILE_B * 16 : 0)) * sizeof(float);
   ORL_REQUIRE(lds <= 160 * 1024, "orl_rollout_fused: needs %zu B of LDS", lds);
   RolloutArgs A;
@@ -1124,11 +1124,7 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
     hipLaunchKernelGGL((rollout_kernel<NO, HD, EV, WC>), dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, A);   \
   } while (0)
-#define ORL_RO_LAUNCH2(NO, HD, EV)                                                                                  \
-  do {                                                                                                              \
-    if (split) ORL_RO_LAUNCH3(NO, HD, EV, false, 256);                                                              \
-    else ORL_RO_LAUNCH3(NO, HD, EV, true, 512);                                                                     \
-  } while (0)
+#define ORL_RO_LAUNCH2(NO, HD, EV) ORL_RO_LAUNCH3(NO, HD, EV, true, 512)
   if (args->env_kind == ORL_ENV_SYNTH) {
 #define ORL_RO_LAUNCH(NO, HD) ORL_RO_LAUNCH2(NO, HD, ORL_ENV_SYNTH)
     ORL_DISPATCH_HEAD(ORL_RO_LAUNCH);
@@ -1144,15 +1140,7 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   }
 #undef ORL_RO_LAUNCH2
 #undef ORL_RO_LAUNCH3
-  rc = launch_status("orl_rollout_fused");
-  if (rc || !split) return rc;
-  // values of every slot 0..T from the stored critic observations; slot T doubles as the bootstrap value
-  rc = orl_critic_values(cnet, ctheta, b.critic_obs, (int64_t)(b.T + 1) * b.N, args->value_preds, stream);
-  if (rc) return rc;
-  if (next_value != nullptr)
-    (void)hipMemcpyAsync(next_value, args->value_preds + (size_t)b.T * b.N, sizeof(float) * b.N, hipMemcpyDeviceToDevice,
-                         (hipStream_t)stream);
-  return launch_status("orl_rollout_fused(values)");
+  return launch_status("orl_rollout_fused");
 }
 
 }  // extern "C"

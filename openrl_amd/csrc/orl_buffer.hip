@@ -11,7 +11,6 @@
 namespace orl {
 
 thread_local char g_err[512] = {0};
-thread_local const unsigned long long* g_rng_dev = nullptr;
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -530,6 +529,21 @@ using namespace orl;
 extern "C" {
 
 int orl_version(void) { return ORL_VERSION; }
+
+int orl_abi_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(orl_net_desc);
+    case 1: return (int)sizeof(orl_pack_src);
+    case 2: return (int)sizeof(orl_buffer_ptrs);
+    case 3: return (int)sizeof(orl_copy_desc);
+    case 4: return (int)sizeof(orl_gather_desc);
+    case 5: return (int)sizeof(orl_ppo_hparams);
+    case 6: return (int)sizeof(orl_adam_state);
+    case 7: return (int)sizeof(orl_rollout_args);
+    case 8: return (int)sizeof(orl_rnn_batch);
+    default: return ORL_E_INVALID;
+  }
+}
 const char* orl_last_error_string(void) { return g_err; }
 
 int orl_param_count(const orl_net_desc* net) {
@@ -585,11 +599,6 @@ int orl_adv_stats(const float* returns, const float* value_preds, const float* a
                      active_masks, vn_state, M, adv_raw, stat_partials);
   if (n_partials) *n_partials = grid;
   return launch_status("orl_adv_stats");
-}
-
-int orl_act_rng_offset(const uint64_t* dev_counter) {
-  g_rng_dev = (const unsigned long long*)dev_counter;
-  return 0;
 }
 
 int orl_record_width(int Dp, int Dc, int a, int K) {

@@ -13,7 +13,6 @@ namespace orl {
 
 // ---- error reporting -----------------------------------------------------------------------
 extern thread_local char g_err[512];
-extern thread_local const unsigned long long* g_rng_dev;  // orl_act_rng_offset: device-side addend of rng_step
 int fail(int code, const char* fmt, ...);
 int launch_status(const char* what);  // hipGetLastError -> return code (+message)
 

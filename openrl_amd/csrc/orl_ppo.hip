@@ -3,11 +3,9 @@
 //                     per tower (kernel in orl_ppo_tower.h), producing per-workgroup partial sums of the
 //                     RAW gradient
 // (the reduction of those partials and the optimiser step live in orl_apply.hip, built WITHOUT -ffast-math)
-#include <stdlib.h>
 #include "orl_common.h"
 #include "orl_mlp.h"
 #include "orl_ppo_tower.h"
-#include "orl_ppo_tower_mt.h"
 
 namespace orl {
 
@@ -19,15 +17,14 @@ static int check_tower(const orl_net_desc* n, const char* who) {
   return 0;
 }
 
-template <int HEAD, int NO, int ND, int WPS, bool PC>
+template <int HEAD, int NO, int ND>
 static int launch_tower_w(const PpoArgs& A, int waves, size_t lds, hipStream_t s) {
   const int n_tiles = (A.mb + TILE_B - 1) / TILE_B;
-  const int walkers = PC ? 8 : waves;  // waves per workgroup that walk tiles
-  int grid = (n_tiles + walkers - 1) / walkers;
+  int grid = (n_tiles + waves - 1) / waves;
   if (grid > PPO_MAX_BLOCKS) grid = PPO_MAX_BLOCKS;
-  (void)hipFuncSetAttribute((const void*)ppo_tower_kernel<HEAD, NO, ND, WPS, PC>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((ppo_tower_kernel<HEAD, NO, ND, WPS, PC>), dim3(grid), dim3(waves * 64), lds, s, A);
+  (void)hipFuncSetAttribute((const void*)ppo_tower_kernel<HEAD, NO, ND>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((ppo_tower_kernel<HEAD, NO, ND>), dim3(grid), dim3(waves * 64), lds, s, A);
   return grid;
 }
 
@@ -35,52 +32,19 @@ static int launch_tower_w(const PpoArgs& A, int waves, size_t lds, hipStream_t s
 template <int HEAD, int NO, int ND>
 static int launch_tower(const PpoArgs& A, hipStream_t s) {
   constexpr int NOP = NO > 4 ? 16 : ((NO + 3) & ~3);  // wide heads: 16-wide dhead tile + W3 MFMA image
-  // as many waves per workgroup (8, 6, 4, 2) as fit the 160 KiB of LDS next to the tower's weights.
-  // 12 waves (3 per SIMD, <= 168 VGPRs) fit the LDS budget too but were measured SLOWER on MI355X
-  // (5.94 vs 5.21 ms per iteration): at 168 VGPRs hipcc spills 260 B per lane around the 64 wgrad
-  // accumulators, so the kernel is built for 2 waves per SIMD.
+  // as many waves per workgroup (8, 6, 4, 2) as fit the 160 KiB of LDS next to the tower's weights; the kernel is
+  // built for 2 waves per SIMD (3 per SIMD at <= 168 VGPRs spills around the 64 wgrad accumulators and a producer /
+  // consumer split of the wgrad were both measured slower: DESIGN.md section 6)
   static const int kWaves[4] = {8, 6, 4, 2};
-  static const int max_waves = []() {  // tuning knob for A/B runs: ORL_PPO_WAVES=4 caps the workgroup size
-    const char* e = getenv("ORL_PPO_WAVES");
-    return e ? atoi(e) : 8;  // 12 = producer/consumer build: correct but measured slower (0.408 vs 0.384 ms)
-  }();
-  static const int mt = []() {  // ORL_PPO_MT=2: A/B knob for the multi-tile kernel (2 tiles per wave, 1 wave / SIMD)
-    const char* e = getenv("ORL_PPO_MT");
-    return e ? atoi(e) : 0;
-  }();
-  if constexpr (ND == 0) {
-    if (mt == 2) {  // measured SLOWER than the default (0.457 vs 0.367 ms per pair), kept for A/B runs: DESIGN.md 6
-      const size_t lds = tower_mt_lds_floats(A.net, A.R, NOP, 2, HEAD == ORL_HEAD_GAUSSIAN) * sizeof(float);
-      if (lds <= 160 * 1024) {
-        const int n_tiles = (A.mb + TILE_B - 1) / TILE_B;
-        int grid = (n_tiles + 7) / 8;
-        if (grid > PPO_MAX_BLOCKS) grid = PPO_MAX_BLOCKS;
-        (void)hipFuncSetAttribute((const void*)ppo_tower_mt_kernel<HEAD, NO, ND, 2>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ppo_tower_mt_kernel<HEAD, NO, ND, 2>), dim3(grid), dim3(256), lds, s, A);
-        const int rc = launch_status("orl_ppo_fwd_bwd(mt)");
-        return rc ? -1000 - rc : grid;
-      }
-    }
-  }
-  if (max_waves >= 12) {  // producer / consumer build: 8 producers + 4 consumers, 3 waves per SIMD
-    const size_t lds = tower_lds_floats(A.net, A.R, NOP, 12, HEAD == ORL_HEAD_GAUSSIAN, true) * sizeof(float);
-    if (lds <= 160 * 1024) {
-      const int grid = launch_tower_w<HEAD, NO, ND, 3, true>(A, 12, lds, s);
-      const int rc = launch_status("orl_ppo_fwd_bwd");
-      return rc ? -1000 - rc : grid;
-    }
-  }
   for (int k = 0; k < 4; ++k) {
     const int waves = kWaves[k];
-    if (waves > max_waves) continue;
     // the transposed W2 copy (17 KB, +2 % on the dgrad GEMM) is the first thing to go when it would cost a pair of waves
     for (int w2t = 1; w2t >= (ND == 0 ? 1 : 0); --w2t) {
-      const size_t lds = tower_lds_floats(A.net, A.R, NOP, waves, HEAD == ORL_HEAD_GAUSSIAN, false, w2t != 0) * sizeof(float);
+      const size_t lds = tower_lds_floats(A.net, A.R, NOP, waves, HEAD == ORL_HEAD_GAUSSIAN, w2t != 0) * sizeof(float);
       if (lds > 160 * 1024) continue;
       PpoArgs B = A;
       B.use_w2t = w2t;
-      const int grid = launch_tower_w<HEAD, NO, ND, 2, false>(B, waves, lds, s);
+      const int grid = launch_tower_w<HEAD, NO, ND>(B, waves, lds, s);
       const int rc = launch_status("orl_ppo_fwd_bwd");
       return rc ? -1000 - rc : grid;
     }
@@ -97,8 +61,8 @@ template <int HEADP, int NOP_, int ND>
 static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int* gc_out, hipStream_t s) {
   constexpr int NOPP = NOP_ > 4 ? 16 : ((NOP_ + 3) & ~3);
   for (int w2t = 1; w2t >= (ND == 0 ? 1 : 0); --w2t) {  // same LDS policy as launch_tower: W2^T goes before a pair of waves
-    const size_t lp = tower_lds_floats(P.net, P.R, NOPP, 8, HEADP == ORL_HEAD_GAUSSIAN, false, w2t != 0) * sizeof(float);
-    const size_t lc = tower_lds_floats(Cc.net, Cc.R, 4, 8, false, false, w2t != 0) * sizeof(float);
+    const size_t lp = tower_lds_floats(P.net, P.R, NOPP, 8, HEADP == ORL_HEAD_GAUSSIAN, w2t != 0) * sizeof(float);
+    const size_t lc = tower_lds_floats(Cc.net, Cc.R, 4, 8, false, w2t != 0) * sizeof(float);
     const size_t lds = lp > lc ? lp : lc;
     if (lds > 160 * 1024) continue;
     PpoArgs P2 = P, C2 = Cc;
@@ -122,9 +86,6 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
 // through the out arguments), < 0 = error.
 template <int HEADP, int NOP_>
 static int try_launch_pair(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int* gc_out, hipStream_t s) {
-  static const bool off = getenv("ORL_PPO_NOPAIR") != nullptr || getenv("ORL_PPO_WAVES") != nullptr ||
-                          getenv("ORL_PPO_MT") != nullptr || getenv("ORL_PPO_NOREM") != nullptr;
-  if (off) return 0;
   auto nd_of = [](const PpoArgs& A) {  // = launch_tower_nd's choice
     const int D = A.net.obs_dim;
     return (D <= 4 && (A.o_x & 3) == 0) ? 0 : D <= 20 ? 1 : D <= 36 ? 2 : 4;
@@ -142,9 +103,8 @@ static int launch_tower_nd(const PpoArgs& A, hipStream_t s) {
   const int D = A.net.obs_dim;
   if (D <= 4 && (A.o_x & 3) == 0) return launch_tower<HEAD, NO, 0>(A, s);
   // ND = 16-column MFMA blocks of the dW1 accumulator; up to 4 remainder columns go to the VALU (17..20, 33..36)
-  static const bool rem = getenv("ORL_PPO_NOREM") == nullptr;
-  if (D <= (rem ? 20 : 16)) return launch_tower<HEAD, NO, 1>(A, s);
-  if (D <= (rem ? 36 : 32)) return launch_tower<HEAD, NO, 2>(A, s);
+  if (D <= 20) return launch_tower<HEAD, NO, 1>(A, s);
+  if (D <= 36) return launch_tower<HEAD, NO, 2>(A, s);
   return launch_tower<HEAD, NO, 4>(A, s);
 }
 

@@ -15,7 +15,7 @@
 // of G / S3 / db2 / db3 and are evaluated once per update in orl_ppo_apply (see RawLayout).
 //
 // Records arrive through a 2-deep global->LDS DMA ring (global_load_lds, no VGPRs) one tile ahead.
-// Occupancy: WPS waves per SIMD (3 when the LDS budget allows: 12 waves / CU, <= 168 VGPRs).
+// Occupancy: 2 waves per SIMD (8-wave workgroups, <= 256 VGPRs; the 64 wgrad accumulators keep a third wave out).
 #pragma once
 #include "orl_common.h"
 #include "orl_mlp.h"
@@ -124,15 +124,8 @@ __device__ inline void mm64_T_wt(const float* __restrict__ Ws, const f32x4 (&in)
 }
 
 // HEAD: ORL_HEAD_VALUE / _CATEGORICAL / _GAUSSIAN; NO: padded head width; ND: ceil(D/16) for the MFMA
-// dW1 path, 0 = VALU path (D <= 4, 16-byte aligned obs column); WPS: waves per SIMD the kernel is built for.
-//
-// PC = true is the producer / consumer build (3 waves per SIMD): waves 0-7 of the 12-wave workgroup are
-// PRODUCERS that run everything except the wgrad GEMM (without the 64 wgrad accumulators they fit 168 VGPRs),
-// waves 8-11 are CONSUMERS that own the accumulators: consumer c picks the dz2 / xhat1 slabs of producers c and
-// c+4 out of LDS (monotonic ready/freed counters per producer, workgroup-scope release/acquire), copies the
-// 32 MFMA operands into registers, frees the slabs and runs the 64 wgrad MFMAs.  Fixed service order, so the
-// summation order - and therefore the result - is deterministic.
-template <int HEAD, int NO, int ND, int WPS, bool PC>
+// dW1 path, 0 = VALU path (D <= 4, 16-byte aligned obs column).
+template <int HEAD, int NO, int ND>
 __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const TowerLayout tl(A.net);
@@ -142,7 +135,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // wide heads (NO > 4: Discrete(5..16), Box(5..16)) run their three head GEMMs - logits, dn2 = W3^T dhead,
   // S3 += dhead^T xhat2 - on MFMA; with NO x 64 scalar FMAs per lane they were 2/3 of the tile and spilled 360 VGPRs
   constexpr bool HMM = NO > 4;
-  const bool w2t = !PC && (ND == 0 || A.use_w2t);  // compile-time true on the small-observation path
+  const bool w2t = ND == 0 || A.use_w2t;  // compile-time true on the small-observation path
   const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, w2t, HMM);
   stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM);
   const int DP = tw.DP;
@@ -155,11 +148,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // visibly a multiple of 256 (measured: 1.2 % faster tower at config 2), wider records are sized exactly
   const int rts = ND == 0 ? ((nch + 3) >> 2) * 256 : nch * 64;
   const int per_wave = 2 * SLAB + 2 * rts + TILE_B * NOP;
-  constexpr int NPROD = 8;                         // producers per workgroup in PC mode
-  const bool consumer = PC && wave >= NPROD;
-  int* flags = (int*)(smem + tw.total + NPROD * per_wave);  // PC: ready[8], freed[8]
-  if (PC && threadIdx.x < 2 * NPROD) flags[threadIdx.x] = 0;
-  float* wl = smem + tw.total + (consumer ? 0 : wave) * per_wave;
+  float* wl = smem + tw.total + wave * per_wave;
   float* X1 = wl;              // xhat1 slab (forward -> wgrad / LN1 backward)
   float* SS = wl + SLAB;       // scratch slab: xhat2 -> dz2 -> dz1
   float* RR = wl + 2 * SLAB;   // record ring: 2 slots of [chunk][16 rows][4 floats]
@@ -171,13 +160,10 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 
   // ---- persistent accumulators (live across all tiles of this wave) -----------------------------------
   f32x4 G[4][4];
-  if (!PC) {  // PC: only consumers own G; it is zeroed at the top of the consumer section so that the 64
-              // registers are not live across the producers' tile loop
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+    for (int b = 0; b < 4; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int NDA = ND > 0 ? ND : 1;
   f32x4 G1[4][NDA];
 #pragma unroll
@@ -206,10 +192,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 
   const int n_tiles = (A.mb + TILE_B - 1) / TILE_B;
   const int nwv = blockDim.x >> 6;
-  const int nprod = PC ? NPROD : nwv;             // waves of this workgroup that walk tiles
-  const int wave_g = bid * nprod + wave;
-  const int n_waves = nblk * nprod;
-  int tiles_done = 0;                              // PC: tiles this producer has handed to its consumer
+  const int wave_g = bid * nwv + wave;
+  const int n_waves = nblk * nwv;
 
   // ---- record tile pipeline: DMA global -> LDS one tile ahead, indices two tiles ahead ----------------
   auto row_of = [&](int t) -> long long {
@@ -229,11 +213,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   };
   long long row_next = 0;
   int ring = 0;
-  if (!consumer) {
-    row_next = row_of(wave_g);
-    issue_dma(RR, row_next);
-    row_next = row_of(wave_g + n_waves);
-  }
+  row_next = row_of(wave_g);
+  issue_dma(RR, row_next);
+  row_next = row_of(wave_g + n_waves);
 
 #ifdef ORL_PROF
   __shared__ unsigned long long prof_lds[16];
@@ -241,7 +223,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   if (prof_on && l < 16) prof_lds[l] = 0ull;
   unsigned long long t_last = __builtin_readcyclecounter();
 #endif
-  for (int tile = consumer ? n_tiles : wave_g; tile < n_tiles; tile += n_waves) {
+  for (int tile = wave_g; tile < n_tiles; tile += n_waves) {
     const int i = tile * TILE_B + j;
     const bool valid = i < A.mb;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's records have landed in LDS
@@ -271,10 +253,6 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
           z[m][r] = fmaxf(z[m][r], 0.f);
         }
       ln_normalize_T(z, rstd1);  // z = xhat1
-      if (PC) {  // the consumer must have copied the previous tile's xhat1 / dz2 out of the slabs
-        while (__hip_atomic_load(&flags[NPROD + wave], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < tiles_done)
-          __builtin_amdgcn_s_sleep(1);
-      }
       store_slab_T(X1, z, j, q);
       ln_affine_T(z, lw + tw.g1, lw + tw.be1, q, n1);
       load_vec_T(lw + tw.b2, q, xh2);
@@ -624,11 +602,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     store_slab_T(SS, d2, j, q);
     wave_lds_fence();
     ORL_T(6);  // dn2, LN2 backward, dz2 slab store
-    if (PC) {
-      // hand dz2 (SS) + xhat1 (X1) to the consumer wave; all LDS stores of this wave precede the flag store
-      ++tiles_done;
-      if (l == 0) __hip_atomic_store(&flags[wave], tiles_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
+    {
       // wgrad: G += dz2^T xhat1 (operands straight from the slabs in F layout), db2
       float s_db = 0.f;
 #pragma unroll
@@ -675,10 +649,6 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       for (int r = 0; r < 4; ++r)
         if (!((relu_bits >> (4 * m + r)) & 1u)) d1[m][r] = 0.f;
     wave_lds_fence();
-    if (PC) {  // dz1 overwrites the slab the consumer reads dz2 from
-      while (__hip_atomic_load(&flags[NPROD + wave], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < tiles_done)
-        __builtin_amdgcn_s_sleep(1);
-    }
     store_slab_T(SS, d1, j, q);
     wave_lds_fence();
     ORL_T(9);  // LN1 backward, relu backward, dz1 slab store
@@ -733,52 +703,6 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #undef REC
 #undef REC_R
 
-  // ---- consumer waves: wgrad GEMM + db2 for the tiles of producers c and c+4 ------------------------------
-  if (consumer) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int c = wave - NPROD;
-    auto tiles_of = [&](int p) -> int {
-      const int first = bid * NPROD + p;
-      return first < n_tiles ? (n_tiles - first + n_waves - 1) / n_waves : 0;
-    };
-    const int cnt0 = tiles_of(c), cnt1 = tiles_of(c + 4);
-    const int rounds = cnt0 > cnt1 ? cnt0 : cnt1;
-    for (int k = 1; k <= rounds; ++k) {
-#pragma unroll
-      for (int which = 0; which < 2; ++which) {
-        const int p = c + 4 * which;
-        if (k > (which ? cnt1 : cnt0)) continue;
-        const float* pX1 = smem + tw.total + p * per_wave;
-        const float* pSS = pX1 + SLAB;
-        while (__hip_atomic_load(&flags[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k)
-          __builtin_amdgcn_s_sleep(1);
-        float av[4][4], bv[4][4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            av[s][m] = pSS[(4 * s + q) * TS + 16 * m + j];
-            bv[s][m] = pX1[(4 * s + q) * TS + 16 * m + j];
-          }
-        float s_db = 0.f;
-        for (int r = 0; r < TILE_B; ++r) s_db += pSS[r * TS + l];
-        a_db2 += s_db;
-        // operands are in registers: release the producer's slabs (the release waits for the LDS reads)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (l == 0) __hip_atomic_store(&flags[NPROD + p], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) G[mo][mi] = ORL_MFMA(av[s][mo], bv[s][mi], G[mo][mi]);
-      }
-    }
-  }
-
   // ---- workgroup reduction of the waves' accumulators, fixed order (deterministic) ---------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before LDS is reused
   __syncthreads();
@@ -790,17 +714,15 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   st_ent = wave_sum(st_ent); st_ratio = wave_sum(st_ratio);
   for (int w = 0; w < nwv; ++w) {
     if (wave == w) {
-      // G tiles: lane (c = j, q), reg r -> G[o = 16mo+4q+r][i = 16mi+c]   (PC: consumer waves only)
-      if (!PC || consumer) {
+      // G tiles: lane (c = j, q), reg r -> G[o = 16mo+4q+r][i = 16mi+c]
 #pragma unroll
-        for (int mo = 0; mo < 4; ++mo)
+      for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j] += G[mo][mi][r];
-      }
+          for (int r = 0; r < 4; ++r) acc[rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j] += G[mo][mi][r];
       const int f = l;
-      acc[rl.odb2 + f] += a_db2;  // PC: only consumers hold db2 / G, producers hold the rest (zeros otherwise)
+      acc[rl.odb2 + f] += a_db2;
       acc[rl.odb1 + f] += a_db1;
       if constexpr (HMM) {
 #pragma unroll
@@ -850,9 +772,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   for (int e = threadIdx.x; e < PW; e += blockDim.x) out[e] = acc[e];
 }
 
-template <int HEAD, int NO, int ND, int WPS, bool PC>
-__global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
-  ppo_tower_body<HEAD, NO, ND, WPS, PC>(A, (int)blockIdx.x, (int)gridDim.x);
+template <int HEAD, int NO, int ND>
+__global__ __launch_bounds__(512, 2) void ppo_tower_kernel(PpoArgs A) {
+  ppo_tower_body<HEAD, NO, ND>(A, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Both towers of one minibatch in ONE launch (the default 8-wave build): workgroups [0, gp) are the policy tower,
@@ -860,18 +782,17 @@ __global__ __launch_bounds__(WPS * 256, WPS) void ppo_tower_kernel(PpoArgs A) {
 // policy workgroup retires instead of waiting for the slowest policy workgroup of the whole chip.
 template <int HEADP, int NOP_, int ND>
 __global__ __launch_bounds__(512, 2) void ppo_tower_pair_kernel(PpoArgs P, PpoArgs Cc, int gp) {
-  if ((int)blockIdx.x < gp) ppo_tower_body<HEADP, NOP_, ND, 2, false>(P, (int)blockIdx.x, gp);
-  else ppo_tower_body<ORL_HEAD_VALUE, 1, ND, 2, false>(Cc, (int)blockIdx.x - gp, (int)gridDim.x - gp);
+  if ((int)blockIdx.x < gp) ppo_tower_body<HEADP, NOP_, ND>(P, (int)blockIdx.x, gp);
+  else ppo_tower_body<ORL_HEAD_VALUE, 1, ND>(Cc, (int)blockIdx.x - gp, (int)gridDim.x - gp);
 }
 
 // LDS bytes needed by `waves` waves of this tower
-inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian, bool pc = false,
-                               bool w2t = true) {
-  const TowerLds tw(net.obs_dim, net.n_out, gaussian, !pc && w2t, nop == 16);
+inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian, bool w2t = true) {
+  const TowerLds tw(net.obs_dim, net.n_out, gaussian, w2t, nop == 16);
   const RawLayout rl(net);
   const int rts = net.obs_dim <= 4 ? (((R >> 2) + 3) >> 2) * 256 : (R >> 2) * 64;  // >= what the kernel uses
   const size_t per_wave = 2 * SLAB + 2 * rts + TILE_B * nop;
-  size_t fl = (size_t)tw.total + (size_t)(pc ? 8 : waves) * per_wave + (pc ? 16 : 0);
+  size_t fl = (size_t)tw.total + (size_t)waves * per_wave;
   const size_t need_acc = (size_t)tw.total + rl.total + ORL_N_STATS;
   return fl > need_acc ? fl : need_acc;
 }

@@ -30,7 +30,7 @@ struct RnnActArgs {
   float *values, *actions, *logp, *hp_out, *hc_out;
   int B, deterministic;
   uint64_t seed, row0, rng_step;
-  const unsigned long long* rng_dev;  // optional device-side addend of rng_step (orl_act_rng_offset)
+  const unsigned long long* rng_dev;  // optional device-side addend of rng_step (rng_step_dev argument)
 };
 
 // base -> GRU -> LayerNorm with every weight read straight from global memory (L2 resident; a rollout step
@@ -1050,9 +1050,9 @@ int orl_rnn_raw_grad_count(const orl_net_desc* net) {
 int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                      const float* policy_obs, const float* critic_obs, const float* h_policy_in,
                      const float* h_critic_in, const float* masks, const float* action_masks, int B,
-                     int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const float* forced_u,
-                     float* values, float* actions, float* logp, float* h_policy_out, float* h_critic_out,
-                     void* stream) {
+                     int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
+                     const float* forced_u, float* values, float* actions, float* logp, float* h_policy_out,
+                     float* h_critic_out, void* stream) {
   ORL_REQUIRE(ptheta || ctheta, "orl_rnn_act_step: neither tower given");
   ORL_REQUIRE(B > 0 && masks, "orl_rnn_act_step: B=%d / null masks", B);
   int rc;
@@ -1072,7 +1072,7 @@ int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_ne
   A.ptheta = ptheta; A.ctheta = ctheta; A.pobs = policy_obs; A.cobs = critic_obs; A.hp_in = h_policy_in;
   A.hc_in = h_critic_in; A.masks = masks; A.amask = action_masks; A.forced = forced_u; A.values = values;
   A.actions = actions; A.logp = logp; A.hp_out = h_policy_out; A.hc_out = h_critic_out; A.B = B;
-  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step; A.rng_dev = g_rng_dev;
+  A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step; A.rng_dev = (const unsigned long long*)rng_step_dev;
   const int grid = (B + TILE_B - 1) / TILE_B;
   hipStream_t s = (hipStream_t)stream;
   const int no = A.pnet.n_out;

@@ -24,7 +24,7 @@ import torch
 
 from .. import _native as nat
 from .. import ops
-from ..utils.callbacks import as_callback
+from ..utils.callbacks import as_callback, callback_needs_per_step
 from ..utils.logger import Logger
 
 
@@ -56,8 +56,9 @@ class OnPolicyDriver:
         self.device = nat.require_gpu(config["device"])
         self.callback = as_callback(callback)
         self.agent = agent
-        if self.callback.agent is None:
+        if getattr(self.callback, "agent", None) is None:
             self.callback.init_callback(agent)
+        per_step_cb = callback_needs_per_step(self.callback)
         self.num_agents = config["num_agents"]
         self.num_env_steps = cfg.num_env_steps
         self.episode_length = cfg.episode_length
@@ -80,12 +81,12 @@ class OnPolicyDriver:
         can_fuse = dev_env and bool(getattr(self.envs, "supports_fused_rollout", True)) and not recurrent
         if mode == "fused" and not can_fuse:
             raise ValueError("amd_rollout_mode=fused is not built for env %r" % getattr(self.envs, "env_name", "?"))
-        self.fused = can_fuse and mode in ("auto", "fused") and not self.callback.needs_per_step
+        self.fused = can_fuse and mode in ("auto", "fused") and not per_step_cb
         # stepwise rollouts of device envs whose step takes no per-call host scalar are captured once into a hipGraph
         # (T x {act, env.step, insert} ~ 125 launches) and replayed; the Philox step counter lives on the device
         self._graph_ok = (dev_env and not self.fused and bool(getattr(cfg, "amd_use_graph", True))
                           and bool(getattr(self.envs, "supports_graph_rollout", False))
-                          and not self.callback.needs_per_step)
+                          and not per_step_cb)
         self._graph = None
         self._rng_ctr = None
         d = self.buffer.data
@@ -191,7 +192,8 @@ class OnPolicyDriver:
             self._rng_ctr = torch.full((1,), int(mod.rng_step), dtype=torch.int64, device=self.device)
             saved_steps, saved_rng = self.agent.num_time_steps, mod.rng_step
             mod.rng_step = 0  # the captured launches carry rng_step = 0 .. T-1; the device counter is the base
-            ops.act_rng_offset(self._rng_ctr)
+            mod.rng_step_dev = self._rng_ctr  # explicit argument of every act launch captured below
+            self.envs.rng_step_dev = self._rng_ctr  # ... including the opponents' launches of a self-play env
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph):
@@ -199,7 +201,8 @@ class OnPolicyDriver:
                         self._rollout_step(step)
                     self._rng_ctr.add_(T)
             finally:
-                ops.act_rng_offset(None)
+                mod.rng_step_dev = None
+                self.envs.rng_step_dev = None
                 self.agent.num_time_steps, mod.rng_step = saved_steps, saved_rng
             self._graph = graph
         self._graph.replay()
@@ -218,7 +221,10 @@ class OnPolicyDriver:
             obs, rewards, dones = self.envs.step_device(actions)
             infos = None
         else:
-            obs, rewards, dones, infos = self.envs.step(actions.cpu().numpy(), extra_data)
+            # host envs get the reference's action dtype: integer indices for Discrete / MultiDiscrete spaces (the
+            # reference's ACTLayer samples int64, act.py:59-83), float32 for Box; the buffer keeps them as floats
+            host_actions = actions.long().cpu().numpy() if self.buffer.data.act_is_index else actions.cpu().numpy()
+            obs, rewards, dones, infos = self.envs.step(host_actions, extra_data)
         self.agent.num_time_steps += self.envs.parallel_env_num
         self.callback.update_locals(locals())
         if self.callback.on_step() is False:

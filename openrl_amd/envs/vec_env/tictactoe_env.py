@@ -127,7 +127,8 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
         a = actions.to(self.device, torch.float32).reshape(self._n).contiguous()
         ops_rnn.ttt_agent_move(self.env_state, a, self._opp_obs, self._opp_mask, self._rew, self._done, self._n)
         ops.act_step_grouped(self.opp_net, self.opp_thetas, self._group_rows, self._opp_obs, self._opp_mask, self._n, False,
-                             self.opp_seed, 0, self.global_step, self._opp_act, self._opp_lp)
+                             self.opp_seed, 0, self.global_step, self._opp_act, self._opp_lp,
+                             rng_step_dev=getattr(self, "rng_step_dev", None))
         ops_rnn.ttt_opponent_move(self.env_state, self.ep_stats, self._opp_act, self.obs, self.action_mask_device,
                                   self._rew, self._done, self._n, self.seed)
         self.global_step += 1

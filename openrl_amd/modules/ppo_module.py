@@ -267,6 +267,7 @@ class PPOModule:
         self.act_width = 1 if head == ops.HEAD_CATEGORICAL else K
         self.act_seed = int(cfg.seed)
         self.rng_step = 0  # advances by one per sampled batch; part of the Philox counter
+        self.rng_step_dev = None  # optional device-side addend (int64 scalar): set while a rollout hipGraph is captured
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, x, width: Optional[int] = None) -> Optional[torch.Tensor]:
@@ -304,7 +305,7 @@ class PPOModule:
         ops_rnn.rnn_act_step(p.net if want_action else None, p.theta if want_action else None,
                              c.net if want_value else None, c.theta if want_value else None, x, xc, hp_in, hc_in, mk, am,
                              B, deterministic, self.act_seed, 0, self.rng_step, self._dev(forced_u, self.act_width),
-                             values, actions, logp, hp_out, hc_out)
+                             values, actions, logp, hp_out, hc_out, rng_step_dev=self.rng_step_dev)
         if want_action and not deterministic:
             self.rng_step += 1
         return values, actions, logp, hp_out, hc_out
@@ -325,7 +326,7 @@ class PPOModule:
             values, actions, logp = out
         ops.act_step(p.net, p.theta, c.net if want_value else None, c.theta if want_value else None, x, xc, am, B,
                      deterministic, self.act_seed, 0, self.rng_step, self._dev(forced_u, self.act_width), values,
-                     actions, logp)
+                     actions, logp, rng_step_dev=self.rng_step_dev)
         if not deterministic:
             self.rng_step += 1
         return values, actions, logp

@@ -158,28 +158,25 @@ def perm_feistel(n: int, seed: int, stream_id: int, device, vn=None) -> torch.Te
 
 # ------------------------------------------------------------------------------------------------ K1-K4
 def act_step(pnet: NetDesc, ptheta, cnet: Optional[NetDesc], ctheta, policy_obs, critic_obs, action_masks, B: int,
-             deterministic: bool, seed: int, row0: int, rng_step: int, forced_u, values, actions, logp) -> None:
+             deterministic: bool, seed: int, row0: int, rng_step: int, forced_u, values, actions, logp,
+             rng_step_dev=None) -> None:
+    """``rng_step_dev``: optional int64 device scalar added to ``rng_step`` by the kernel (hipGraph replays)."""
     dev = _dev(policy_obs if policy_obs is not None else critic_obs)
     rc = _lib().orl_act_step(C.byref(pnet), fptr(ptheta), C.byref(cnet) if cnet is not None else None, fptr(ctheta),
                              fptr(policy_obs), fptr(critic_obs), fptr(action_masks), B, int(bool(deterministic)),
-                             seed & (2 ** 64 - 1), row0, rng_step, fptr(forced_u), fptr(values), fptr(actions),
-                             fptr(logp), stream_ptr(dev))
+                             seed & (2 ** 64 - 1), row0, rng_step, ptr(rng_step_dev), fptr(forced_u), fptr(values),
+                             fptr(actions), fptr(logp), stream_ptr(dev))
     nat.check(rc, "orl_act_step")
 
 
 def act_step_grouped(pnet: NetDesc, pthetas, rows_per_group: int, policy_obs, action_masks, B: int, deterministic: bool,
-                     seed: int, row0: int, rng_step: int, actions, logp) -> None:
+                     seed: int, row0: int, rng_step: int, actions, logp, rng_step_dev=None) -> None:
     """One launch for a pool of policies: row group g is evaluated with ``pthetas[g]`` (orl_act_step_grouped)."""
     dev = _dev(policy_obs)
     rc = _lib().orl_act_step_grouped(C.byref(pnet), fptr(pthetas), pthetas.stride(0), rows_per_group, fptr(policy_obs),
                                      fptr(action_masks), B, int(bool(deterministic)), seed & (2 ** 64 - 1), row0,
-                                     rng_step, fptr(actions), fptr(logp), stream_ptr(dev))
+                                     rng_step, ptr(rng_step_dev), fptr(actions), fptr(logp), stream_ptr(dev))
     nat.check(rc, "orl_act_step_grouped")
-
-
-def act_rng_offset(dev_counter: Optional[torch.Tensor]) -> None:
-    """Device-side addend of ``rng_step`` for the act-step launches that follow (None switches it off)."""
-    nat.check(_lib().orl_act_rng_offset(ptr(dev_counter)), "orl_act_rng_offset")
 
 
 def critic_values(cnet: NetDesc, ctheta, critic_obs, values) -> None:

@@ -35,13 +35,13 @@ def rnn_raw_grad_count(net: NetDesc) -> int:
 
 def rnn_act_step(pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, h_policy_in, h_critic_in, masks, action_masks,
                  B: int, deterministic: bool, seed: int, row0: int, rng_step: int, forced_u, values, actions, logp,
-                 h_policy_out, h_critic_out) -> None:
+                 h_policy_out, h_critic_out, rng_step_dev=None) -> None:
     dev = _dev(masks)
     rc = _lib().orl_rnn_act_step(C.byref(pnet) if pnet is not None else None, fptr(ptheta),
                                  C.byref(cnet) if cnet is not None else None, fptr(ctheta), fptr(policy_obs),
                                  fptr(critic_obs), fptr(h_policy_in), fptr(h_critic_in), fptr(masks),
                                  fptr(action_masks), B, int(bool(deterministic)), seed & (2 ** 64 - 1), row0, rng_step,
-                                 fptr(forced_u), fptr(values), fptr(actions), fptr(logp), fptr(h_policy_out),
+                                 nat.ptr(rng_step_dev), fptr(forced_u), fptr(values), fptr(actions), fptr(logp), fptr(h_policy_out),
                                  fptr(h_critic_out), stream_ptr(dev))
     nat.check(rc, "orl_rnn_act_step")
 

@@ -104,7 +104,7 @@ class CallbackList(BaseCallback):
     def __init__(self, callbacks: List[BaseCallback]):
         super().__init__()
         self.callbacks = callbacks
-        self.needs_per_step = any(c.needs_per_step for c in callbacks)
+        self.needs_per_step = any(callback_needs_per_step(c) for c in callbacks)
 
     def _init_callback(self) -> None:
         for c in self.callbacks:
@@ -337,12 +337,38 @@ class CallbackFactory:
 MaybeCallback = Union[None, Callable, List[BaseCallback], BaseCallback]
 
 
-def as_callback(callback: MaybeCallback) -> BaseCallback:
-    """rl_agent.py:132-164: list -> CallbackList, function -> ConvertCallback, None -> no-op."""
+_HOOKS = ("init_callback", "on_rollout_start", "update_locals", "on_step", "on_rollout_end")
+
+
+def is_callback_object(cb) -> bool:
+    """Duck type of a callback OBJECT: this package's ``BaseCallback`` or a foreign one with the same hooks - e.g. the
+    reference's own ``openrl.utils.callbacks.callbacks.{CallbackList,ConvertCallback}`` that ``RLAgent._init_callback``
+    (rl_agent.py:137-164) always hands a driver injected through ``driver_class``, even for ``callback=None``."""
+    return isinstance(cb, BaseCallback) or all(callable(getattr(cb, h, None)) for h in _HOOKS)
+
+
+def callback_needs_per_step(cb) -> bool:
+    """Does this callback object need host control at every env step (forces the stepwise rollout)?  Foreign objects
+    carry no ``needs_per_step`` attribute: the reference's wrappers around "no callback" (``ConvertCallback(None)``,
+    an empty or all-no-op ``CallbackList``) do not, anything else is assumed to."""
+    flag = getattr(cb, "needs_per_step", None)
+    if flag is not None and not isinstance(cb, CallbackList):
+        return bool(flag)
+    children = getattr(cb, "callbacks", None)
+    if isinstance(children, (list, tuple)):  # CallbackList (ours or foreign)
+        return any(callback_needs_per_step(c) for c in children)
+    if type(cb).__name__ == "ConvertCallback" and getattr(cb, "callback", 0) is None:
+        return False
+    return True if flag is None else bool(flag)
+
+
+def as_callback(callback: MaybeCallback):
+    """rl_agent.py:132-164: list -> CallbackList, function -> ConvertCallback, None -> no-op; a callback object
+    (ours or a foreign duck type, see ``is_callback_object``) is used as it is."""
     if callback is None:
         return NoopCallback()
     if isinstance(callback, list):
         return CallbackList(callback)
-    if not isinstance(callback, BaseCallback):
-        return ConvertCallback(callback)
-    return callback
+    if is_callback_object(callback):
+        return callback
+    return ConvertCallback(callback)

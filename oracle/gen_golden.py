@@ -196,6 +196,57 @@ def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, s
     print(name + ".npz", {k: float(info[k]) for k in info})
 
 
+def _train_case_full(name, argv, N, T, D, n_act, seed=0):
+    """A full-size update (BASELINE.json configs[1]: 4096 envs x 128 steps, obs 4, Discrete(2), ppo_epoch 10, one
+    minibatch): the buffer comes from ``oracle.fixtures.synth_update_buffer`` (regenerated from the seed by the
+    test), only the reference's outputs are stored.  ``ReplayData.compute_returns`` + ``PPOAlgorithm.train``
+    (algorithms/ppo.py:383-458, buffers/replay_data.py:320-423, 553-646) are the reference's own."""
+    from gymnasium.spaces import Box, Discrete
+    from openrl.algorithms.ppo import PPOAlgorithm
+    from openrl.buffers import NormalReplayBuffer
+    from openrl.modules.ppo_module import PPOModule
+    from openrl.utils.util import set_seed
+
+    from .fixtures import synth_update_buffer
+
+    cfg = _cfg(argv, N, T)
+    cfg.seed = seed
+    obs_space, act_space = Box(-np.inf, np.inf, (D,)), Discrete(n_act)
+    set_seed(cfg.seed)
+    module = PPOModule(cfg, policy_input_space=obs_space, critic_input_space=obs_space, act_space=act_space,
+                       share_model=False, rank=0, world_size=1)
+    out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"])}
+    buffer = NormalReplayBuffer(cfg, 1, obs_space, act_space, data_client=None)
+    algo = PPOAlgorithm(cfg, module, agent_num=1)
+    d = buffer.data
+    src = synth_update_buffer(1000 + seed, N, T, D, n_act)
+    d.policy_obs[:] = src["policy_obs"]
+    d.critic_obs[:] = src["policy_obs"]
+    for f in ("rewards", "value_preds", "masks", "active_masks", "bad_masks", "actions", "action_log_probs",
+              "action_masks"):
+        getattr(d, f)[:] = src[f]
+    vn = module.get_critic_value_normalizer()
+    buffer.compute_returns(src["next_value"].copy(), vn)
+    out["returns_probe_idx"] = np.array([[0, 0], [T // 2, N // 3], [T - 1, N - 1], [17, 5], [T - 2, 11]])
+    out["returns_probe"] = np.array([d.returns[t, n, 0, 0] for t, n in out["returns_probe_idx"]], np.float32)
+    out["returns_sum"] = np.array(d.returns[:-1].astype(np.float64).sum())
+    torch.manual_seed(1234 + seed)
+    algo.prep_training()
+    info = algo.train(d)
+    out["train_info"] = np.array([float(info.get(k, 0.0)) for k in
+                                  ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
+                                   "ratio")], np.float64)
+    out["theta_p1"] = _flat(module.models["policy"])
+    out["theta_c1"] = _flat(module.models["critic"])
+    out["vn_state1"] = np.array([vn.running_mean.item(), vn.running_mean_sq.item(), vn.debiasing_term.item()],
+                                np.float32)
+    out["argv"] = np.array(" ".join(argv))
+    out["perm_seed"] = np.array(1234 + seed)
+    out["shape"] = np.array([N, T, D, n_act, 1000 + seed])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: float(info[k]) for k in info})
+
+
 def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=0):
     """use_recurrent_policy: hand-driven rollout (rnn states zeroed on env-done, onpolicy_driver.py:91-108),
     then PPOAlgorithm.train with recurrent_generator (ppo.py:363-372, replay_data.py:1062-1258)."""
@@ -394,6 +445,8 @@ def main():
         "train_recurrent": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 18, 54,
             lambda: Discrete(5), N=6, A=3, T=7, seed=5),
+        # BASELINE.json configs[1] at full size (what bench.py runs): only outputs are stored, inputs come from a seed
+        "train_cfg2_full": lambda n: _train_case_full(n, ["--ppo_epoch", "10", "--num_mini_batch", "1"], 4096, 128, 4, 2),
         "train_recurrent_chunk5": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--data_chunk_length", "5"], 6, 6,
             lambda: Box(-1, 1, (2,)), N=5, A=1, T=10, seed=6),

@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_host_side_queries(lib):
     from openrl_amd import _native as n
 
-    assert lib.orl_version() == 100
+    assert lib.orl_version() == n.ORL_VERSION == 200
     pol = n.NetDesc(4, 64, 2, n.ORL_HEAD_CATEGORICAL)
     cri = n.NetDesc(4, 64, 1, n.ORL_HEAD_VALUE)
     gau = n.NetDesc(17, 64, 6, n.ORL_HEAD_GAUSSIAN)
@@ -68,7 +68,7 @@ def test_argument_validation_happens_before_any_launch(lib):
     rc = lib.orl_perm_feistel(None, 0, 0, 0, None)
     assert rc == -1
     bad = n.NetDesc(4, 128, 2, n.ORL_HEAD_CATEGORICAL)  # hidden_size 128 is not built
-    rc = lib.orl_act_step(C.byref(bad), None, None, None, None, None, None, 1, 0, 0, 0, 0, None, None, None, None, None)
+    rc = lib.orl_act_step(C.byref(bad), None, None, None, None, None, None, 1, 0, 0, 0, 0, None, None, None, None, None, None)
     assert rc == -2 and b"hidden_size" in lib.orl_last_error_string()
     assert lib.orl_env_state_width(77) == -1
 

@@ -97,3 +97,65 @@ def test_device_train_info_is_a_dict_that_copies_on_first_read():
     f.update(DeviceTrainInfo(INFO_KEYS, vals))
     assert f["dist_entropy"] == 1.5
     assert bool(DeviceTrainInfo(INFO_KEYS, vals)) and np.isfinite(list(DeviceTrainInfo(INFO_KEYS, vals).values())).all()
+
+
+# ---- foreign callback objects (HipDriver injected into the reference's PPOAgent) ----------
+class _ForeignBase:
+    """Shape of the reference's ``openrl.utils.callbacks.callbacks.BaseCallback`` - NOT a subclass of this package's."""
+
+    def __init__(self):
+        self.agent, self.n_calls, self.locals, self.started = None, 0, {}, 0
+
+    def init_callback(self, agent):
+        self.agent = agent
+
+    def on_rollout_start(self):
+        self.started += 1
+
+    def update_locals(self, locals_):
+        self.locals.update(locals_)
+
+    def on_step(self):
+        self.n_calls += 1
+        return self._on_step()
+
+    def _on_step(self):
+        return True
+
+    def on_rollout_end(self):
+        pass
+
+
+def _foreign(name, **attrs):
+    cls = type(name, (_ForeignBase,), {})
+    obj = cls()
+    for k, v in attrs.items():
+        setattr(obj, k, v)
+    return obj
+
+
+def test_foreign_callback_objects_are_used_as_they_are():
+    """rl_agent._init_callback (reference rl_agent.py:137-164) hands a driver its OWN CallbackList / ConvertCallback
+    object even for ``callback=None``; it must be driven through its hooks, not wrapped and called as a function."""
+    from openrl_amd.utils import callbacks as cb
+
+    none_cb = _foreign("ConvertCallback", callback=None)          # what callback=None becomes in the reference
+    got = cb.as_callback(none_cb)
+    assert got is none_cb                                          # not wrapped into this package's ConvertCallback
+    assert cb.callback_needs_per_step(none_cb) is False            # -> the fused rollout stays available
+    fn_cb = _foreign("ConvertCallback", callback=lambda l, g: True)
+    assert cb.as_callback(fn_cb) is fn_cb and cb.callback_needs_per_step(fn_cb) is True
+    lst = _foreign("CallbackList", callbacks=[none_cb, _foreign("CallbackList", callbacks=[])])
+    assert cb.as_callback(lst) is lst and cb.callback_needs_per_step(lst) is False
+    lst2 = _foreign("CallbackList", callbacks=[none_cb, _foreign("CheckpointCallback")])
+    assert cb.callback_needs_per_step(lst2) is True
+    # a plain function is still converted, and a mixed list of ours + foreign objects is a CallbackList of ours
+    conv = cb.as_callback(lambda l, g: False)
+    assert isinstance(conv, cb.ConvertCallback) and conv.needs_per_step
+    mixed = cb.CallbackList([cb.NoopCallback(), none_cb])
+    assert mixed.needs_per_step is False
+    # the hooks are called on the foreign object itself
+    got.init_callback("agent")
+    got.on_rollout_start()
+    got.update_locals({"obs": 1})
+    assert got.on_step() is True and got.n_calls == 1 and got.locals["obs"] == 1 and got.started == 1

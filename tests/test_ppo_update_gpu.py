@@ -71,6 +71,74 @@ def test_train_matches_reference_golden(case):
                                    rtol=1e-5)
 
 
+def _assert_golden_outputs(g, module, info):
+    got = np.array([info[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
+                                      "critic_grad_norm", "ratio")])
+    np.testing.assert_allclose(got, g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
+    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL,
+                               atol=THETA_ATOL)
+    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL,
+                               atol=THETA_ATOL)
+    if "vn_state1" in g:
+        np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"],
+                                   rtol=1e-5)
+
+
+@pytest.mark.parametrize("perm_mode", ["device", "identity"])
+@pytest.mark.parametrize("case", [c for c in H.TRAIN_CASES if "--num_mini_batch 1" in str(H.load_golden(c)["argv"])])
+def test_device_and_identity_permutation_land_on_the_reference_golden(case, perm_mode):
+    """What bench.py runs (``amd_perm_mode=device``) against the REFERENCE's outputs: with one minibatch per epoch the
+    permutation only changes the fp32 summation order, so the reference's final weights / train_info / ValueNorm
+    state (reached with its own torch.randperm stream) must be hit at the same tolerances as in reference mode."""
+    g = H.load_golden(case)
+    cfg, module, buf, algo = build_engine(g)
+    assert cfg.num_mini_batch == 1
+    algo.perm_mode = perm_mode
+    algo.prep_training()
+    info = algo.train(buf)
+    _assert_golden_outputs(g, module, info)
+
+
+@pytest.mark.parametrize("perm_mode", ["device", "identity", "reference"])
+def test_full_size_update_matches_reference_golden(perm_mode):
+    """BASELINE.json configs[1] at FULL size - 4096 envs x 128 steps = 524 288 rows, obs 4, Discrete(2), ppo_epoch 10,
+    one minibatch, ValueNorm on: 256 workgroups x 128 tiles per tower launch, the partial-reduce depth and the
+    ``gae_max_partials`` regime of the bench.  The buffer is regenerated from the seed (oracle/fixtures.py); the
+    expected outputs are the REAL reference's ``compute_returns`` + ``PPOAlgorithm.train`` (oracle/gen_golden.py,
+    case train_cfg2_full; reference algorithms/ppo.py:383-458, buffers/replay_data.py:320-423,553-646)."""
+    from openrl_amd import spaces
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers.replay_data import ReplayData
+    from openrl_amd.modules.ppo_module import PPOModule
+    from oracle.fixtures import synth_update_buffer
+
+    g = H.load_golden("train_cfg2_full")
+    N, T, D, n_act, seed = (int(x) for x in g["shape"])
+    cfg = H.case_cfg(g)
+    cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = T, N, 1, cfg.hidden_size
+    obs_space, act_space = spaces.Box(-np.inf, np.inf, (D,)), spaces.Discrete(n_act)
+    torch.manual_seed(0)
+    module = PPOModule(cfg, obs_space, obs_space, act_space, device=DEV, rank=0, world_size=1)
+    module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+    module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+    buf = ReplayData(cfg, 1, obs_space, act_space, device=DEV)
+    src = synth_update_buffer(seed, N, T, D, n_act)
+    for f in ("policy_obs", "rewards", "value_preds", "masks", "active_masks", "bad_masks", "actions",
+              "action_log_probs", "action_masks"):
+        getattr(buf, f).copy_(torch.tensor(src[f]))
+    buf.compute_returns(torch.tensor(src["next_value"]), module.get_critic_value_normalizer())
+    ret = buf.returns.cpu().numpy()
+    probe = np.array([ret[t, n, 0, 0] for t, n in g["returns_probe_idx"]])
+    np.testing.assert_allclose(probe, g["returns_probe"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ret[:-1].astype(np.float64).sum(), float(g["returns_sum"]), rtol=1e-6)
+    algo = PPOAlgorithm(cfg, module, agent_num=1, device=DEV)
+    algo.perm_mode = perm_mode
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    info = algo.train(buf)
+    _assert_golden_outputs(g, module, info)
+
+
 @pytest.mark.parametrize("case", H.TRAIN_CASES)
 def test_single_update_gradients_vs_oracle(case):
     """One minibatch: clipped parameter gradients of both towers against torch autograd on the oracle."""

@@ -75,11 +75,15 @@ def _build(env_id, N, T, seed=3, **kw):
     return cfg, env, net, trainer, buf, _Agent()
 
 
-@pytest.mark.parametrize("env_id,kw", [("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=7)), ("CartPole-v1", {})])
-def test_fused_rollout_equals_stepwise_rollout(env_id, kw):
+@pytest.mark.parametrize("env_id,kw,N,T", [
+    ("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=7), 50, 23),
+    ("CartPole-v1", {}, 50, 23),
+    # the headline size (bench.py: BASELINE.json configs[1]): 256 workgroups x 128 steps of the fused kernel
+    ("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=200), 4096, 128),
+])
+def test_fused_rollout_equals_stepwise_rollout(env_id, kw, N, T):
     from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
 
-    N, T = 50, 23
     bufs = []
     for mode in ("fused", "stepwise"):
         cfg, env, net, trainer, buf, agent = _build(env_id, N, T, **kw)
