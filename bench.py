@@ -1,19 +1,25 @@
 #!/usr/bin/env python
 """bench.py - env-steps/sec (collect + GAE + PPO update) of the MI355X engine on BASELINE.json's
-config 2: CartPole-shaped PPO, 4096 envs x 128-step rollout per GPU, obs 4, Discrete(2), hidden 64,
+config 2: CartPole-shaped PPO, 4096 envs x 128-step rollout, obs 4, Discrete(2), hidden 64,
 ppo_epoch 10, num_mini_batch 1, ValueNorm on (reference defaults).
 
-A "step" = ONE training iteration of the hot path over one batch: a 128-step rollout of 4096 envs on the
+A "step" = ONE training iteration of the hot path over one batch: a 128-step rollout of the 4096 envs on the
 synthetic fixed-step env + bootstrap value + GAE/advantages + 10 PPO epochs
-(forward, loss, backward, grad-clip, Adam for both towers).  Weak scaling: every rank runs 4096 envs;
-gradients / statistics are summed over ranks with one small RCCL all-reduce per optimiser step.
+(forward, loss, backward, grad-clip, Adam for both towers).
+
+Multi-GPU = the metric's "4096-env CartPole at 1/2/4/8 GPUs" (SURVEY.md section 8e): STRONG scaling - the 4096 global
+envs are sharded 4096/G per rank (one process per GPU; rollout, buffer shard and GAE are local), gradients /
+statistics are summed over ranks once per optimiser step by the one-shot xGMI all-reduce fused into the
+optimiser-step launches (``orl_comm``; ``--collective rccl`` = one RCCL all-reduce instead).  ``--scaling weak`` keeps
+4096 envs on EVERY rank.
 
     python bench.py [--gpus N --steps K --warmup W]           (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel pair (``orl_ppo_fwd_bwd`` =
 ppo_tower_kernel policy + critic, fp32 MFMA bound) timed live with HIP events on the launch stream;
 ``cpu_baseline`` times the oracle port of the reference's CPU path (oracle/cpu_trainer.py) on the host
-cores - a reported baseline, not the target.
+cores and cites the committed run of the REAL reference objects (oracle/ref_cpu_baseline.py,
+profiles/r02_ref_cpu_line.json) - a reported baseline, not the target.
 """
 from __future__ import annotations
 
@@ -41,6 +47,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--perm", default="device", choices=["device", "reference", "identity"],
                     help="minibatch permutation source; 'reference' = host torch.randperm (bit-exact stream)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: 4096 GLOBAL envs sharded over the ranks (the metric); weak: 4096 envs per rank")
+    ap.add_argument("--collective", default="p2p", choices=["p2p", "rccl"],
+                    help="gradient exchange: fused one-shot xGMI push all-reduce (orl_comm) or one RCCL all-reduce")
+    ap.add_argument("--envs", type=int, default=N_ENVS, help="global env count (default: the metric's 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -63,11 +74,18 @@ def main():
     torch.cuda.set_device(local_rank)
 
     cfg = default_cfg(["--episode_length", str(T_ROLL), "--ppo_epoch", str(PPO_EPOCH), "--amd_perm_mode", args.perm,
-                       "--log_interval", "1000000"])
-    env = make("SyntheticFixedStep-v0", env_num=N_ENVS, obs_dim=OBS_DIM, episode_limit=200, device=dev,
+                       "--log_interval", "1000000", "--amd_collective", args.collective])
+    if args.scaling == "strong":  # the metric: the global envs shard contiguously, N/G per GPU
+        lo, hi = du.shard_range(args.envs, rank, world)
+        n_local = hi - lo
+    else:
+        n_local = args.envs
+    if n_local < 1:
+        raise SystemExit("%d envs cannot be sharded over %d ranks" % (args.envs, world))
+    env = make("SyntheticFixedStep-v0", env_num=n_local, obs_dim=OBS_DIM, episode_limit=200, device=dev,
                seed=cfg.seed + 10086 * rank)
-    net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=N_ENVS)
-    cfg.num_env_steps = N_ENVS * T_ROLL * (args.steps + args.warmup)
+    net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=n_local)
+    cfg.num_env_steps = n_local * T_ROLL * (args.steps + args.warmup)
 
     class _Agent:
         num_time_steps = 0
@@ -112,11 +130,12 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
-    steps_total = N_ENVS * T_ROLL * args.steps * world
+    global_envs = args.envs if args.scaling == "strong" else args.envs * world
+    steps_total = global_envs * T_ROLL * args.steps
     value = steps_total / dt
 
     # ---- roofline of the dominant kernel pair
-    M = N_ENVS * T_ROLL
+    M = n_local * T_ROLL  # rows of one tower-pair launch on this rank
     f_fwd = 2 * ((OBS_DIM + OBS_DIM) * 64 + 2 * 64 * 64 + 64 * (N_ACT + 1))  # 17 792 flop / row
     flops_per_launch = 3 * f_fwd * M                                          # fwd + dgrad + wgrad, both towers
     ev = trainer.profile_events
@@ -124,37 +143,57 @@ def main():
     achieved_tf = flops_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     gae_ms = sum(a.elapsed_time(b) for a, b in gae_events) / max(len(gae_events), 1)
     gae_bytes = 16 * M  # S_gae: 3 reads + 1 write per sample
-    traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_hbm.json)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
-            traffic = json.load(fh)["orl_ppo_fwd_bwd_pair"]["hbm_bytes_per_launch_raw"]
-    except Exception:
-        pass
+    # HBM bytes per launch: NOT measured in this process (PMC needs rocprofv3) - read from the committed summary of the
+    # separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, and only quoted for the shape it was taken at
+    traffic, traffic_source = None, None
+    for name in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                blob = json.load(fh)["orl_ppo_fwd_bwd_pair"]
+            if M == N_ENVS * T_ROLL:
+                traffic = blob.get("hbm_bytes_per_launch", blob.get("hbm_bytes_per_launch_raw"))
+                traffic_source = "profiles/" + name
+            break
+        except Exception:
+            continue
     roofline = {"kernel": "orl_ppo_fwd_bwd (ppo_tower_pair_kernel: policy + critic towers in one launch)", "bound": "mfma",
                 "achieved": round(achieved_tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_source,
                 "launch_ms": round(k_ms, 4), "launches_timed": len(ev),
                 "flops_per_launch": flops_per_launch,
                 "gae_scan": {"bound": "hbm", "achieved": round(gae_bytes / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else 0,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "launch_ms": round(gae_ms, 4),
-                             "note": "8.4 MB per launch: latency-bound, includes adv statistics"}}
+                             "note": "%.1f MB per launch: latency-bound, includes adv statistics" % (gae_bytes / 1e6)}}
 
     out = {"metric": "env-steps/sec (collect+PPO update), 4096-env CartPole-shape", "value": round(value, 1),
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "configs[1]: PPO, 4096 envs x 128-step rollout per GPU, obs 4, Discrete(2), "
-                                  "MLP 64x64, ppo_epoch 10, num_mini_batch 1, ValueNorm on; synthetic fixed-step env",
-                      "global_envs": N_ENVS * world, "rollout_len": T_ROLL, "ppo_epoch": PPO_EPOCH,
-                      "perm_mode": args.perm, "parallelism": "env-shard dp%d" % world},
+           "config": {"workload": "configs[1]: PPO, %d global envs x 128-step rollout (%d envs per GPU), obs 4, "
+                                  "Discrete(2), MLP 64x64, ppo_epoch 10, num_mini_batch 1, ValueNorm on; synthetic "
+                                  "fixed-step env" % (global_envs, n_local),
+                      "global_envs": global_envs, "envs_per_gpu": n_local, "rollout_len": T_ROLL,
+                      "ppo_epoch": PPO_EPOCH, "perm_mode": args.perm, "parallelism": "env-shard dp%d" % world,
+                      "collective": ("none" if world == 1 else
+                                     "orl_comm one-shot xGMI push, fused into reduce+apply" if trainer._comm is not None
+                                     else "torch.distributed all_reduce (%s)" % torch.distributed.get_backend())},
            "roofline": roofline}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_trainer import time_cpu_baseline_bounded
 
         cb = time_cpu_baseline_bounded(n_envs=N_ENVS, ppo_epoch=PPO_EPOCH, target_seconds=args.cpu_seconds)
+        kind = "port"
+        try:  # the REAL reference objects, timed where /root/reference exists (oracle/ref_cpu_baseline.py), committed
+            with open(os.path.join(ROOT, "profiles", "r02_ref_cpu_line.json")) as fh:
+                ref = json.loads(fh.readline())
+            kind = ("port (reference-run: %.0f env-steps/s on %d cores, 1 warm-up + %d iterations of the full "
+                    "configs[1] workload, profiles/r02_ref_cpu_line.json)" % (ref["value"], ref["cores"], ref["iters"]))
+        except Exception:
+            pass
         out["cpu_baseline"] = {"value": round(cb["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": cb["cores"],
-                               "kind": "port",
+                               "kind": kind,
                                "sample": "1 iteration of the oracle port: %d envs x %d-step rollout + %d full-batch "
                                          "epochs (%.1f s; act %.1f s, insert %.1f s, update %.1f s)"
                                          % (N_ENVS, cb["T"], PPO_EPOCH, cb["seconds"], cb["phase_act"],

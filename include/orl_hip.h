@@ -306,6 +306,40 @@ int orl_ppo_apply_perm(const orl_net_desc* pnet, const orl_net_desc* cnet, const
                        float* train_info_accum, int64_t* next_idx, int64_t n, uint64_t seed, uint64_t stream_id,
                        float* vn_state, const double* moments, double beta, void* stream);
 
+/* ---- multi-GPU: one-shot small-message SUM all-reduce over xGMI peer memory ----------
+ * The PPO path shards env lanes over the GPUs of one node (one process per GPU); the only data-path exchange is ONE
+ * flat fp32 vector per optimiser step (both towers' raw gradient sums + denominators + logging sums, 38.9 KB at
+ * configuration 2) - the generalisation of the reference's only live collective, the sum-all-reduce of
+ * openrl/modules/networks/utils/distributed_utils.py:22-26, and of the DDP hook left empty at
+ * openrl/algorithms/ppo.py:437-443.  At that size a ring is latency-bound, so every rank PUSHES its vector to every
+ * peer's inbox (hipIpc-mapped device memory, one hop) as 8-byte {fp32, sequence tag} granules and sums the G
+ * contributions in RANK ORDER: all ranks compute the bit-identical result, independent of arrival order.
+ *
+ * An orl_comm is the one object of this ABI that owns memory (its inbox, 2 x world x capacity granules, and the
+ * mapped peer inboxes).  Set-up: every rank calls orl_comm_create (-> its 64-byte IPC handle), the caller exchanges
+ * the handles out of band (e.g. torch.distributed.all_gather), every rank calls orl_comm_connect with all of them
+ * ([world][64] bytes, rank order).  All ranks must issue the same sequence of collectives on a comm.  A peer that
+ * does not arrive within 10 s sets an error word (orl_comm_error; it synchronises the stream) instead of hanging. */
+typedef struct orl_comm orl_comm;
+#define ORL_IPC_HANDLE_BYTES 64
+int orl_comm_create(int rank, int world, int64_t capacity_floats, orl_comm** comm_out, unsigned char* handle_out);
+int orl_comm_connect(orl_comm* comm, const unsigned char* all_handles);
+int orl_comm_destroy(orl_comm* comm);
+int orl_comm_error(orl_comm* comm, void* stream);
+/* data[0..n) <- sum over ranks of data[0..n), in place, n <= capacity; no-op for world == 1. */
+int orl_allreduce_small(orl_comm* comm, float* data, int n, void* stream);
+/* The same collective fused into the optimiser step, so that a multi-GPU step is the same TWO launches as a
+ * single-GPU one: orl_ppo_reduce_pair_comm = orl_ppo_reduce_pair whose workgroups also push every column sum they
+ * produce to the peers (opens a collective); orl_ppo_apply_comm = orl_ppo_apply(_perm when next_idx != NULL) that sums
+ * the G contributions in rank order while it stages the raw sums (closes it) and writes the global sums back to
+ * `sums`.  The two calls must come in this order, once each per optimiser step. */
+int orl_ppo_reduce_pair_comm(orl_comm* comm, const float* partials, int n_blocks_policy, int width_policy,
+                             int n_blocks_critic, int width_critic, float* sums, void* stream);
+int orl_ppo_apply_comm(orl_comm* comm, const orl_net_desc* pnet, const orl_net_desc* cnet, float* sums,
+                       const orl_ppo_hparams* hp, const orl_adam_state* padam, const orl_adam_state* cadam,
+                       float* train_info_accum, int64_t* next_idx, int64_t n, uint64_t seed, uint64_t stream_id,
+                       float* vn_state, const double* moments, double beta, void* stream);
+
 /* ValueNorm.update (openrl/modules/utils/valuenorm.py:58-77) from reduced batch sums:
  * moments = {sum(x), sum(x^2), count} as doubles on the device; beta = 0.99999. */
 int orl_valuenorm_update(float* vn_state, const double* moments, double beta, void* stream);

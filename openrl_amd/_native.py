@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liborl_hip.so")
 ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL = 0, 1, 2, 3
 ORL_GATHER_MAX = 12
+ORL_IPC_HANDLE_BYTES = 64
 ORL_VERSION = 200  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
@@ -128,6 +129,15 @@ _SIGNATURES = {
     "orl_ppo_apply": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
                                 C.POINTER(AdamState), C.POINTER(AdamState), _P, _P]),
     "orl_ppo_apply_perm": (C.c_int, [C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
+                                     C.POINTER(AdamState), C.POINTER(AdamState), _P, _P, C.c_int64, C.c_uint64,
+                                     C.c_uint64, _P, _P, C.c_double, _P]),
+    "orl_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.POINTER(_P), _P]),
+    "orl_comm_connect": (C.c_int, [_P, _P]),
+    "orl_comm_destroy": (C.c_int, [_P]),
+    "orl_comm_error": (C.c_int, [_P, _P]),
+    "orl_allreduce_small": (C.c_int, [_P, _P, C.c_int, _P]),
+    "orl_ppo_reduce_pair_comm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "orl_ppo_apply_comm": (C.c_int, [_P, C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
                                      C.POINTER(AdamState), C.POINTER(AdamState), _P, _P, C.c_int64, C.c_uint64,
                                      C.c_uint64, _P, _P, C.c_double, _P]),
     "orl_valuenorm_update": (C.c_int, [_P, _P, C.c_double, _P]),

@@ -128,6 +128,10 @@ class PPOAlgorithm(BaseAlgorithm):
         self._rnn_rows = None    # [L, n_chunks] record rows of the current minibatch
         self._rnn_scratch = torch.zeros(512, dtype=torch.float32, device=dev) if self.recurrent else None
         self._sums = torch.zeros(self._raw_p + self._raw_c, dtype=torch.float32, device=dev)
+        # multi-GPU: the one-shot xGMI all-reduce of the sums vector, fused into the optimiser-step launches (MLP towers)
+        # or as its own launch (recurrent); None = single process or amd_collective=rccl -> torch.distributed
+        self._comm = dist_utils.make_small_allreduce(self._sums.numel(), dev, getattr(cfg, "amd_collective", "p2p")) \
+            if self.world_size > 1 else None
         self._info = torch.zeros(8, dtype=torch.float32, device=dev)
         self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
         self._mom_scratch = torch.zeros(512, dtype=torch.float64, device=dev)
@@ -189,9 +193,12 @@ class PPOAlgorithm(BaseAlgorithm):
         if ev is not None:
             e1.record()
             ev.append((e0, e1))
-        ops.ppo_reduce_pair(self._partials, nb_p, self._raw_p, nb_c, self._raw_c, self._sums)
-        if self.world_size > 1:
-            dist_utils.allreduce_(self._sums)  # ONE small collective per optimiser step
+        # ONE small collective per optimiser step: pushed by the reduce launch, summed by the apply
+        # launch (orl_comm), or one RCCL all-reduce between them
+        comm = self._comm
+        ops.ppo_reduce_pair(self._partials, nb_p, self._raw_p, nb_c, self._raw_c, self._sums, comm=comm)
+        if self.world_size > 1 and comm is None:
+            dist_utils.allreduce_(self._sums)
         po.step_count += 1 if turn_on else 0
         co.step_count += 1
         hp = self.hp
@@ -199,7 +206,7 @@ class PPOAlgorithm(BaseAlgorithm):
             hp = nat.PPOHParams.from_buffer_copy(self.hp)
             hp.reserved |= 1  # critic-only update (construct_loss_list, ppo.py:226-236)
         return ops.ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
-                             co.native_state(co.step_count), self._info, next_perm)
+                             co.native_state(co.step_count), self._info, next_perm, comm=comm)
 
     # ------------------------------------------------------------------------------------------ recurrent
     def _update_minibatch_rnn(self, buffer, chunks, n_chunks: int, turn_on: bool) -> None:
@@ -234,7 +241,10 @@ class PPOAlgorithm(BaseAlgorithm):
         ops_rnn.rnn_ppo_fwd_bwd(p.net, p.theta, c.net, c.theta, rec, rows, buffer.masks, buffer.rnn_states,
                                 buffer.rnn_states_critic, n_chunks, L, vn_state, self.hp, self._rnn_ws, self._sums)
         if self.world_size > 1:
-            dist_utils.allreduce_(self._sums)
+            if self._comm is not None:
+                self._comm.allreduce_(self._sums)
+            else:
+                dist_utils.allreduce_(self._sums)
         po.step_count += 1 if turn_on else 0
         co.step_count += 1
         hp = self.hp

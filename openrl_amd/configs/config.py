@@ -24,6 +24,10 @@ AMD_FLAGS = [
     ("amd_rollout_mode", "str", "auto", "opt", ["auto", "fused", "stepwise"]),
     # capture the PPO update epoch in a hipGraph.
     ("amd_use_graph", "bool", True, "opt", None),
+    # multi-GPU gradient exchange: "p2p" = the one-shot xGMI push all-reduce fused into the optimiser-step launches
+    # (orl_ppo_reduce_pair_comm / orl_ppo_apply_comm, falls back to "rccl" if peer memory cannot be mapped);
+    # "rccl" = one torch.distributed all-reduce (RCCL) per optimiser step.
+    ("amd_collective", "str", "p2p", "opt", ["p2p", "rccl"]),
 ]
 
 

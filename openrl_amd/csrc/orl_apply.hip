@@ -4,10 +4,14 @@
 //                                          (the vector a multi-GPU run all-reduces)
 //   orl_ppo_apply                        : raw sums -> parameter gradients, grad-norm clip (K13), Adam (K14), train_info
 //   orl_ppo_apply_perm                   : the same launch also produces the next epoch's permutation / ValueNorm.update
+//   orl_ppo_reduce_pair_comm / orl_ppo_apply_comm : the multi-GPU optimiser step in the SAME two launches - the reduce
+//                                          pushes every column sum it produces to the peers' inboxes, the apply sums
+//                                          the G contributions in rank order while it stages them (orl_comm.h)
 #include <stdlib.h>
 #include <string.h>
 #include "orl_common.h"
 #include "orl_perm.h"
+#include "orl_comm.h"
 #include "orl_mlp.h"
 #undef ORL_PROF  // the phase-timing symbols of the tower header belong to orl_ppo.hip
 #include "orl_ppo_tower.h"
@@ -94,9 +98,9 @@ __device__ inline float raw_to_grad(const float* __restrict__ raw, const float* 
 // staged in LDS first so the 64-term LayerNorm-affine dot products of raw_to_grad run out of LDS.
 // Workgroups >= 2 (orl_ppo_apply_perm only) produce the NEXT epoch's minibatch permutation and ValueNorm.update in the
 // same launch: both are independent of this optimiser step, and the two apply workgroups leave 254 CUs idle.
-__global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTower Cc, const float* __restrict__ sums,
+__global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTower Cc, float* __restrict__ sums,
                                                          orl_ppo_hparams hp, float* __restrict__ info, PermJob J,
-                                                         int stage_mv) {
+                                                         int stage_mv, CommDev CM, int use_comm) {
   extern __shared__ __attribute__((aligned(16))) float s_apply[];
   if (blockIdx.x >= 2) {
     perm_job_block(J, (int)blockIdx.x - 2, (int)gridDim.x - 2);
@@ -105,21 +109,37 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
   __shared__ float sh[16];
   const TowerLayout tlp(P.net), tlc(Cc.net);
   const RawLayout rlp(P.net), rlc(Cc.net);
-  const float* rawp = sums + P.sums_off;
-  const float* stp = rawp + rlp.total;
-  const float* rawc = sums + Cc.sums_off;
-  const float* stc = rawc + rlc.total;
-  const float den_p = hp.use_policy_active_masks ? stp[ST_ACTIVE_SUM] : stp[ST_ROWS];
-  const float den_v = hp.use_value_active_masks ? stc[ST_ACTIVE_SUM] : stc[ST_ROWS];
   float norms[2] = {0.f, 0.f};
+  const int t = blockIdx.x;
+  // this tower's raw sums + statistics, staged in LDS first.  Multi-GPU (use_comm): every element is the sum over
+  // ranks, in rank order, of the local column sum and the peers' pushed granules (orl_ppo_reduce_pair_comm); the
+  // reduced vector is also written back to `sums` so the caller observes the global sums.
+  float* raw = s_apply;
+  const float* st;  // this tower's statistics (ST_*), in LDS
+  float den_p = 1.f, den_v = 1.f;
   {
-    const int t = blockIdx.x;
+    const RawLayout& rl0 = t == 0 ? rlp : rlc;
+    const int off = t == 0 ? P.sums_off : Cc.sums_off;
+    const int nraw = rl0.total + ORL_N_STATS;
+#pragma unroll 1
+    for (int e = threadIdx.x; e < nraw; e += blockDim.x) {
+      float v = sums[off + e];
+      if (use_comm) {
+        v = comm_sum(CM, off + e, v);
+        sums[off + e] = v;
+      }
+      raw[e] = v;
+    }
+    st = raw + rl0.total;
+  }
+  {
     const ApplyTower& W = t == 0 ? P : Cc;
     const TowerLayout& tl = t == 0 ? tlp : tlc;
     const RawLayout& rl = t == 0 ? rlp : rlc;
-    const float* raw_g = t == 0 ? rawp : rawc;
-    const float inv_den = 1.0f / (t == 0 ? den_p : den_v);
     if (t == 0 && (hp.reserved & 1)) {
+      __syncthreads();
+      den_p = hp.use_policy_active_masks ? st[ST_ACTIVE_SUM] : st[ST_ROWS];
+      const float* stp = st;
       // turn_on == False: the policy loss is not in the loss list (ppo.py:226-236) -> no gradient, no step
       for (int p = threadIdx.x; p < tl.total; p += blockDim.x) W.ad.grad[p] = 0.f;
       if (threadIdx.x == 0 && info != nullptr) {
@@ -132,8 +152,7 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
       }
       return;
     }
-    float* raw = s_apply;
-    float* th_s = s_apply + rl.total;
+    float* th_s = s_apply + rl.total + ORL_N_STATS;
     // latency plan for a one-shot, two-workgroup kernel: everything that comes from HBM (raw sums, parameters, Adam
     // moments) is requested up front into LDS, the double-precision bias corrections are evaluated while those loads
     // are in flight, gradients stay in LDS between the norm and the Adam pass, and every loop stays ROLLED - the code
@@ -142,8 +161,6 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     float* g_s = th_s + tl.total;
     float* m_s = g_s + tl.total;  // Adam moments: staged too when everything fits 160 KiB (stage_mv), else read from HBM
     float* v_s = m_s + tl.total;
-#pragma unroll 1
-    for (int e = threadIdx.x; e < rl.total; e += blockDim.x) raw[e] = raw_g[e];
 #pragma unroll 1
     for (int e = threadIdx.x; e < tl.total; e += blockDim.x) {
       th_s[e] = W.ad.theta[e];
@@ -161,6 +178,9 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     const float step_size = (float)((double)W.ad.lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     __syncthreads();
+    den_p = hp.use_policy_active_masks ? st[ST_ACTIVE_SUM] : st[ST_ROWS];
+    den_v = hp.use_value_active_masks ? st[ST_ACTIVE_SUM] : st[ST_ROWS];
+    const float inv_den = 1.0f / (t == 0 ? den_p : den_v);
     float ss = 0.f;
 #pragma unroll 1
     for (int p = threadIdx.x; p < tl.total; p += blockDim.x) {
@@ -191,6 +211,8 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     }
   }
   if (threadIdx.x == 0 && info != nullptr) {
+    const float* stp = st;
+    const float* stc = st;
     if (blockIdx.x == 0) {
       float ent_den = den_p;
       if (!hp.use_policy_active_masks && P.net.head_kind == ORL_HEAD_GAUSSIAN) ent_den = den_p * (float)P.net.n_out;
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
 // both towers' partial regions in one launch: blocks [0, gp) reduce the policy region, the rest the critic's
 __global__ __launch_bounds__(1024) void ppo_reduce_pair_kernel(const float* __restrict__ pp, int nb_p, int wp, int gp,
                                                                const float* __restrict__ pc, int nb_c, int wc,
-                                                               float* __restrict__ sums) {
+                                                               float* __restrict__ sums, CommDev CM, int use_comm) {
   // 64 columns x 16 row groups per workgroup: at 256 partial rows every thread has 16 independent loads in flight
   __shared__ float sh[16][64];
   const bool pol = (int)blockIdx.x < gp;
@@ -236,7 +258,13 @@ __global__ __launch_bounds__(1024) void ppo_reduce_pair_kernel(const float* __re
     float t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) t[k] = (sh[4 * k][lc] + sh[4 * k + 1][lc]) + (sh[4 * k + 2][lc] + sh[4 * k + 3][lc]);
-    out[col] = (t[0] + t[1]) + (t[2] + t[3]);
+    const float v = (t[0] + t[1]) + (t[2] + t[3]);
+    out[col] = v;
+    if (use_comm) {  // multi-GPU: the column sum goes straight to every peer's inbox (one 8-byte granule each)
+      const int e = pol ? col : wp + col;
+      for (int p = 0; p < CM.world; ++p)
+        if (p != CM.rank) comm_push(CM, p, e, v);
+    }
   }
 }
 
@@ -262,9 +290,9 @@ int orl_ppo_reduce(const float* partials, int n_blocks, int width, float* sums, 
   return launch_status("orl_ppo_reduce");
 }
 
-static int launch_apply(const char* what, const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums,
+static int launch_apply(const char* what, const orl_net_desc* pnet, const orl_net_desc* cnet, float* sums,
                         const orl_ppo_hparams* hp, const orl_adam_state* padam, const orl_adam_state* cadam,
-                        float* train_info_accum, const PermJob& J, void* stream) {
+                        float* train_info_accum, const PermJob& J, void* stream, orl_comm* comm = nullptr) {
   int rc = check_tower(pnet, what);
   if (rc) return rc;
   rc = check_tower(cnet, what);
@@ -279,8 +307,8 @@ static int launch_apply(const char* what, const orl_net_desc* pnet, const orl_ne
   // raw | theta g [| m v]: the Adam moments are staged with the rest when that fits 160 KiB (every tower up to obs ~40),
   // the widest towers (obs 64 x 16 outputs: 191 KB) read them from HBM in the Adam pass
   auto need = [&](int k) {
-    const size_t lp = (size_t)(RawLayout(*pnet).total + k * TowerLayout(*pnet).total) * sizeof(float);
-    const size_t lc = (size_t)(RawLayout(*cnet).total + k * TowerLayout(*cnet).total) * sizeof(float);
+    const size_t lp = (size_t)(RawLayout(*pnet).total + ORL_N_STATS + k * TowerLayout(*pnet).total) * sizeof(float);
+    const size_t lc = (size_t)(RawLayout(*cnet).total + ORL_N_STATS + k * TowerLayout(*cnet).total) * sizeof(float);
     return lp > lc ? lp : lc;
   };
   const int stage_mv = need(4) <= 160 * 1024;
@@ -291,9 +319,20 @@ static int launch_apply(const char* what, const orl_net_desc* pnet, const orl_ne
     perm_blocks = (int)((J.n + 1023) / 1024);
     if (perm_blocks > 254) perm_blocks = 254;  // one workgroup per CU next to the two apply workgroups (their LDS footprint is per launch)
   }
+  CommDev CM;
+  memset(&CM, 0, sizeof(CM));
+  int use_comm = 0;
+  if (comm != nullptr) {  // the push half ran in orl_ppo_reduce_pair_comm under the SAME sequence number
+    const int total = Cc.sums_off + RawLayout(*cnet).total + ORL_N_STATS;
+    ORL_REQUIRE(total <= orl_comm_capacity(comm), "%s: the sums vector (%d floats) exceeds the comm's capacity %d", what,
+                total, orl_comm_capacity(comm));
+    rc = orl_comm_current(comm, &CM);
+    if (rc) return rc;
+    use_comm = CM.world > 1;
+  }
   (void)hipFuncSetAttribute((const void*)ppo_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(ppo_apply_kernel, dim3(2 + perm_blocks), dim3(1024), lds, (hipStream_t)stream, P, Cc, sums, *hp,
-                     train_info_accum, J, stage_mv);
+                     train_info_accum, J, stage_mv, CM, use_comm);
   return launch_status(what);
 }
 
@@ -301,7 +340,22 @@ int orl_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const floa
                   const orl_adam_state* padam, const orl_adam_state* cadam, float* train_info_accum, void* stream) {
   PermJob J;
   memset(&J, 0, sizeof(J));
-  return launch_apply("orl_ppo_apply", pnet, cnet, sums, hp, padam, cadam, train_info_accum, J, stream);
+  return launch_apply("orl_ppo_apply", pnet, cnet, (float*)sums, hp, padam, cadam, train_info_accum, J, stream);
+}
+
+int orl_ppo_apply_comm(orl_comm* comm, const orl_net_desc* pnet, const orl_net_desc* cnet, float* sums,
+                       const orl_ppo_hparams* hp, const orl_adam_state* padam, const orl_adam_state* cadam,
+                       float* train_info_accum, int64_t* next_idx, int64_t n, uint64_t seed, uint64_t stream_id,
+                       float* vn_state, const double* moments, double beta, void* stream) {
+  ORL_REQUIRE(comm, "orl_ppo_apply_comm: null comm");
+  PermJob J;
+  memset(&J, 0, sizeof(J));
+  if (next_idx != nullptr) {
+    ORL_REQUIRE(n > 0 && n <= ((int64_t)1 << 62), "orl_ppo_apply_comm: bad permutation arguments");
+    ORL_REQUIRE(!vn_state || moments, "orl_ppo_apply_comm: vn_state needs moments");
+    J = make_perm_job(next_idx, n, seed, stream_id, vn_state, moments, beta);
+  }
+  return launch_apply("orl_ppo_apply_comm", pnet, cnet, sums, hp, padam, cadam, train_info_accum, J, stream, comm);
 }
 
 int orl_ppo_apply_perm(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums, const orl_ppo_hparams* hp,
@@ -311,18 +365,41 @@ int orl_ppo_apply_perm(const orl_net_desc* pnet, const orl_net_desc* cnet, const
   ORL_REQUIRE(next_idx && n > 0 && n <= ((int64_t)1 << 62), "orl_ppo_apply_perm: bad permutation arguments");
   ORL_REQUIRE(!vn_state || moments, "orl_ppo_apply_perm: vn_state needs moments");
   const PermJob J = make_perm_job(next_idx, n, seed, stream_id, vn_state, moments, beta);
-  return launch_apply("orl_ppo_apply_perm", pnet, cnet, sums, hp, padam, cadam, train_info_accum, J, stream);
+  return launch_apply("orl_ppo_apply_perm", pnet, cnet, (float*)sums, hp, padam, cadam, train_info_accum, J, stream);
+}
+
+static int launch_reduce_pair(const char* what, orl_comm* comm, const float* partials, int n_blocks_policy,
+                              int width_policy, int n_blocks_critic, int width_critic, float* sums, void* stream) {
+  ORL_REQUIRE(partials && sums && n_blocks_policy > 0 && n_blocks_critic > 0 && width_policy > 0 && width_critic > 0,
+              "%s: bad arguments", what);
+  CommDev CM;
+  memset(&CM, 0, sizeof(CM));
+  int use_comm = 0;
+  if (comm != nullptr) {
+    ORL_REQUIRE(width_policy + width_critic <= orl_comm_capacity(comm), "%s: %d floats exceed the comm's capacity %d",
+                what, width_policy + width_critic, orl_comm_capacity(comm));
+    const int rc = orl_comm_next(comm, &CM);  // a new collective: its poll half is orl_ppo_apply_comm
+    if (rc) return rc;
+    use_comm = CM.world > 1;
+  }
+  const int gp = (width_policy + 63) / 64, gc = (width_critic + 63) / 64;
+  hipLaunchKernelGGL(ppo_reduce_pair_kernel, dim3(gp + gc), dim3(1024), 0, (hipStream_t)stream, partials,
+                     n_blocks_policy, width_policy, gp, partials + (size_t)PPO_MAX_BLOCKS * width_policy,
+                     n_blocks_critic, width_critic, sums, CM, use_comm);
+  return launch_status(what);
 }
 
 int orl_ppo_reduce_pair(const float* partials, int n_blocks_policy, int width_policy, int n_blocks_critic,
                         int width_critic, float* sums, void* stream) {
-  ORL_REQUIRE(partials && sums && n_blocks_policy > 0 && n_blocks_critic > 0 && width_policy > 0 && width_critic > 0,
-              "orl_ppo_reduce_pair: bad arguments");
-  const int gp = (width_policy + 63) / 64, gc = (width_critic + 63) / 64;
-  hipLaunchKernelGGL(ppo_reduce_pair_kernel, dim3(gp + gc), dim3(1024), 0, (hipStream_t)stream, partials,
-                     n_blocks_policy, width_policy, gp, partials + (size_t)PPO_MAX_BLOCKS * width_policy,
-                     n_blocks_critic, width_critic, sums);
-  return launch_status("orl_ppo_reduce_pair");
+  return launch_reduce_pair("orl_ppo_reduce_pair", nullptr, partials, n_blocks_policy, width_policy, n_blocks_critic,
+                            width_critic, sums, stream);
+}
+
+int orl_ppo_reduce_pair_comm(orl_comm* comm, const float* partials, int n_blocks_policy, int width_policy,
+                             int n_blocks_critic, int width_critic, float* sums, void* stream) {
+  ORL_REQUIRE(comm, "orl_ppo_reduce_pair_comm: null comm");
+  return launch_reduce_pair("orl_ppo_reduce_pair_comm", comm, partials, n_blocks_policy, width_policy, n_blocks_critic,
+                            width_critic, sums, stream);
 }
 
 }  // extern "C"

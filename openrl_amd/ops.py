@@ -214,17 +214,34 @@ def ppo_reduce(partials_ptr: int, n_blocks: int, width: int, sums_ptr: int, dev)
     nat.check(rc, "orl_ppo_reduce")
 
 
-def ppo_reduce_pair(partials, nb_p: int, width_p: int, nb_c: int, width_c: int, sums) -> None:
+def ppo_reduce_pair(partials, nb_p: int, width_p: int, nb_c: int, width_c: int, sums, comm=None) -> None:
+    """``comm`` (a ``distributed.SmallAllreduce``): also push every column sum to the peers (opens the collective
+    that ``ppo_apply(..., comm=comm)`` closes)."""
     dev = _dev(sums)
-    rc = _lib().orl_ppo_reduce_pair(fptr(partials), nb_p, width_p, nb_c, width_c, fptr(sums), stream_ptr(dev))
+    if comm is None:
+        rc = _lib().orl_ppo_reduce_pair(fptr(partials), nb_p, width_p, nb_c, width_c, fptr(sums), stream_ptr(dev))
+    else:
+        rc = _lib().orl_ppo_reduce_pair_comm(comm.handle, fptr(partials), nb_p, width_p, nb_c, width_c, fptr(sums),
+                                             stream_ptr(dev))
     nat.check(rc, "orl_ppo_reduce_pair")
 
 
 def ppo_apply(pnet, cnet, sums, hp: PPOHParams, padam: AdamState, cadam: AdamState, train_info_accum,
-              next_perm=None):
+              next_perm=None, comm=None):
     """``next_perm`` = (n, seed, stream_id, vn | None): also produce the next epoch's permutation (returned) and, with
     vn = (state, moments, beta), its ValueNorm.update, on idle workgroups of the same launch (orl_ppo_apply_perm)."""
     dev = _dev(sums)
+    if comm is not None:  # multi-GPU: sum the ranks' contributions (pushed by ppo_reduce_pair) while staging them
+        idx, n, seed, stream_id, vn = None, 0, 0, 0, None
+        if next_perm is not None:
+            n, seed, stream_id, vn = next_perm
+            idx = torch.empty(n, dtype=torch.int64, device=dev)
+        rc = _lib().orl_ppo_apply_comm(comm.handle, C.byref(pnet), C.byref(cnet), fptr(sums), C.byref(hp),
+                                       C.byref(padam), C.byref(cadam), fptr(train_info_accum), ptr(idx), n,
+                                       seed & (2 ** 64 - 1), stream_id & (2 ** 64 - 1), fptr(vn[0]) if vn else None,
+                                       ptr(vn[1]) if vn else None, float(vn[2]) if vn else 0.0, stream_ptr(dev))
+        nat.check(rc, "orl_ppo_apply_comm")
+        return idx
     if next_perm is None:
         rc = _lib().orl_ppo_apply(C.byref(pnet), C.byref(cnet), fptr(sums), C.byref(hp), C.byref(padam),
                                   C.byref(cadam), fptr(train_info_accum), stream_ptr(dev))

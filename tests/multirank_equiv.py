@@ -34,6 +34,37 @@ def fill(buf, host, lo, hi, nv):
     return torch.tensor(nv[lo:hi])
 
 
+def comm_main(du, rank, world, dev):
+    """orl_allreduce_small (one-shot P2P push over hipIpc-mapped peer memory; both ranks share cuda:0 here) against
+    torch.distributed's all_reduce: bit-identical for 2 ranks (a + b is commutative in fp32), over many
+    back-to-back collectives of different sizes (exercises the parity double-buffering of the inboxes)."""
+    comm = du.make_small_allreduce(20000, dev)
+    ok = comm is not None
+    if ok:
+        rs = np.random.RandomState(100 + rank)
+        for k, n in enumerate([1, 63, 64, 9702, 20000, 7, 9702, 9702, 4096, 1]):
+            x = torch.tensor(rs.randn(n).astype(np.float32) * (1 + k), device=dev)
+            want = x.clone()
+            torch.distributed.all_reduce(want)  # gloo on CUDA tensors
+            got = comm.allreduce_(x.clone())
+            torch.cuda.synchronize()
+            if not torch.equal(got, want):
+                ok = False
+                print("rank %d: collective %d (n=%d) differs: max|d| %.3e" % (rank, k, n, (got - want).abs().max().item()))
+        comm.check()
+        # every rank holds the identical vector
+        g = [torch.zeros_like(got) for _ in range(world)]
+        torch.distributed.all_gather(g, got)
+        ok &= all(torch.equal(g[0], t) for t in g)
+        comm.close()
+    flag = torch.tensor([1.0 if ok else 0.0])
+    torch.distributed.all_reduce(flag)
+    if rank == 0:
+        print("COMM_OK" if flag.item() == world else "COMM_FAIL")
+    torch.distributed.destroy_process_group()
+    sys.exit(0 if flag.item() == world else 1)
+
+
 def main():
     from openrl_amd import distributed as du
     from openrl_amd.configs.config import default_cfg
@@ -41,6 +72,9 @@ def main():
     du.init_from_env(backend="gloo")
     rank, world = du.rank(), du.world_size()
     dev = "cuda:0"
+    if "comm" in sys.argv[1:]:
+        return comm_main(du, rank, world, dev)
+    collective = "rccl" if "rccl" in sys.argv[1:] else "p2p"
     T, Nl, D, n_act = 12, 24, 4, 2
     N = Nl * world
     rs = np.random.RandomState(5)
@@ -51,7 +85,8 @@ def main():
                 actions=rs.randint(0, n_act, (T, N, 1, 1)).astype(np.float32),
                 action_log_probs=(np.log(0.5) + 0.05 * rs.randn(T, N, 1, 1)).astype(np.float32))
     nv = (0.3 * rs.randn(N, 1, 1)).astype(np.float32)
-    argv = ["--episode_length", str(T), "--ppo_epoch", "3", "--num_mini_batch", "1", "--amd_perm_mode", "device"]
+    argv = ["--episode_length", str(T), "--ppo_epoch", "3", "--num_mini_batch", "1", "--amd_perm_mode", "device",
+            "--amd_collective", collective]
     recurrent = "rnn" in sys.argv[1:]
     if recurrent:  # T is even: chunks of 2 never straddle env lanes, so shards see the same chunks as one process
         argv += ["--use_recurrent_policy", "true", "--data_chunk_length", "2"]
@@ -63,9 +98,26 @@ def main():
     module, buf, algo = build(cfg, Nl, D, n_act, world, dev)
     lo, hi = du.shard_range(N, rank, world)
     buf.compute_returns(fill(buf, host, lo, hi, nv), module.get_critic_value_normalizer())
+    assert (algo._comm is not None) == (collective == "p2p"), "the fused orl_comm path must be the one that runs"
     info = algo.train(buf)
     torch.cuda.synchronize()
+    if algo._comm is not None:
+        algo._comm.check()
     ok = True
+    # the other collective on the same shard: the fused one-shot push (orl_comm) and the torch.distributed all-reduce
+    # add the same two fp32 vectors -> bit-identical weights for 2 ranks
+    other = "rccl" if collective == "p2p" else "p2p"
+    cfg2 = default_cfg([a if a != collective else other for a in argv])
+    m2, b2, a2 = build(cfg2, Nl, D, n_act, world, dev)
+    b2.compute_returns(fill(b2, host, lo, hi, nv), m2.get_critic_value_normalizer())
+    a2.train(b2)
+    torch.cuda.synchronize()
+    same_coll = all(torch.equal(module.models[k].theta, m2.models[k].theta) for k in ("policy", "critic"))
+    flag = torch.tensor([1.0 if same_coll else 0.0])
+    torch.distributed.all_reduce(flag)
+    if rank == 0:
+        print("COLLECTIVES_BITWISE_EQUAL" if flag.item() == world else "COLLECTIVES_DIFFER")
+    ok &= flag.item() == world
     if rank == 0:
         cfg1 = default_cfg(argv)
         m1, b1, a1 = build(cfg1, N, D, n_act, 1, dev)
