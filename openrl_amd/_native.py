@@ -180,7 +180,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         if not build_if_missing:
             raise NativeError("%s is missing - run `python -m openrl_amd.csrc.build`" % LIB_PATH)
         _b.build()
-    elif build_if_missing and _b.have_hipcc():
+    elif build_if_missing and _b.have_hipcc() and not os.environ.get("ORL_KEEP_BUILD"):
+        # (ORL_KEEP_BUILD=1: measurement tools that load a deliberately different build, e.g. --prof)
         _b.build()  # no-op when the source digest matches the stamp; rebuilds a stale shared object
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():

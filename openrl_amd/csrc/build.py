@@ -53,6 +53,9 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str
     # the bench iteration, every parity test unchanged); the buffer kernels are NOT (the GAE scan is bit-exact with
     # the reference's operation order) and neither is the MPE physics (compared with a float64 reference).
     base = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    # build-time A/B switches for kernel experiments (e.g. ORL_BUILD_DEFS="-DORL_TOWER_ILV"); never read at run time
+    extra = os.environ.get("ORL_BUILD_DEFS", "").split()
+    base += extra
     if prof:  # phase-timing build of the tower kernels (orl_debug_prof); never the shipped configuration
         base.append("-DORL_PROF")
     def compile_one(src):
@@ -80,7 +83,7 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str
     if res.returncode != 0:
         raise RuntimeError("hipcc (link) failed:\n" + res.stdout + res.stderr)
     with open(STAMP, "w") as fh:
-        fh.write(dig + ("-prof" if prof else ""))
+        fh.write(dig + ("-prof" if prof else "") + ("".join(extra)))
     return LIB
 
 

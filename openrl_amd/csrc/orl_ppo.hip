@@ -38,6 +38,9 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
   static const int kWaves[4] = {8, 6, 4, 2};
   for (int k = 0; k < 4; ++k) {
     const int waves = kWaves[k];
+#ifdef ORL_TOWER_MAXWAVES  // build-time experiment switch (occupancy A/B), never defined in the shipped build
+    if (waves > ORL_TOWER_MAXWAVES) continue;
+#endif
     // the transposed W2 copy (17 KB, +2 % on the dgrad GEMM) is the first thing to go when it would cost a pair of waves
     for (int w2t = 1; w2t >= (ND == 0 ? 1 : 0); --w2t) {
       const size_t lds = tower_lds_floats(A.net, A.R, NOP, waves, HEAD == ORL_HEAD_GAUSSIAN, w2t != 0) * sizeof(float);
@@ -86,6 +89,9 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
 // through the out arguments), < 0 = error.
 template <int HEADP, int NOP_>
 static int try_launch_pair(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int* gc_out, hipStream_t s) {
+#ifdef ORL_TOWER_MAXWAVES
+  return 0;
+#endif
   auto nd_of = [](const PpoArgs& A) {  // = launch_tower_nd's choice
     const int D = A.net.obs_dim;
     return (D <= 4 && (A.o_x & 3) == 0) ? 0 : D <= 20 ? 1 : D <= 36 ? 2 : 4;

@@ -602,6 +602,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     store_slab_T(SS, d2, j, q);
     wave_lds_fence();
     ORL_T(6);  // dn2, LN2 backward, dz2 slab store
+#ifndef ORL_TOWER_ILV
     {
       // wgrad: G += dz2^T xhat1 (operands straight from the slabs in F layout), db2
       float s_db = 0.f;
@@ -651,6 +652,54 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     wave_lds_fence();
     store_slab_T(SS, d1, j, q);
     wave_lds_fence();
+#else
+    // Interleaved backward (ORL_TOWER_ILV): the 64 wgrad MFMAs have no consumer inside the tile, so they are issued
+    // UNDER the VALU / LDS chain LN1' -> relu' -> dz1 store (and the dW1 loop below) instead of as a burst of their
+    // own during which the wave's VALU idles.  Their 32 operands are read from the slabs first (the dz1 store below
+    // overwrites the dz2 slab; LDS operations of a wave execute in program order).
+    float av[4][4], bv[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        av[s][m] = SS[(4 * s + q) * TS + 16 * m + j];
+        bv[s][m] = X1[(4 * s + q) * TS + 16 * m + j];
+      }
+    {
+      float s_db = 0.f;
+      const int f = l;
+      for (int r = 0; r < TILE_B; ++r) s_db += SS[r * TS + f];
+      a_db2 += s_db;
+    }
+    ORL_T(7);  // wgrad operand reads, db2
+    // dgrad: dn1 = W2^T dz2 straight from the LN2' output registers
+    f32x4 d1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (w2t) mm64_T(lw + tw.W2T, d2, d1, j, q);
+    else mm64_T_wt(lw + tw.W2, d2, d1, j, q);
+    ORL_T(8);  // dgrad: 64 MFMA
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      f32x4 xh1[4];
+      load_slab_T(X1, xh1, j, q);
+      ln_bwd_T(d1, xh1, lw + tw.g1, rstd1, q);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (!((relu_bits >> (4 * m + r)) & 1u)) d1[m][r] = 0.f;
+    wave_lds_fence();
+    store_slab_T(SS, d1, j, q);
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) G[mo][mi] = ORL_MFMA(av[s][mo], bv[s][mi], G[mo][mi]);
+#endif
     ORL_T(9);  // LN1 backward, relu backward, dz1 slab store
     // dW1 += dz1^T x, db1
     {
@@ -693,6 +742,16 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       }
       a_db1 += s_db;
     }
+#ifdef ORL_TOWER_ILV
+    // one wgrad MFMA per ~5 VALU / LDS instructions of the chain above (the pipe takes one fp32 MFMA per 32 cycles)
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     wave_lds_fence();
     ORL_T(10);  // dW1 / db1
   }

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--obs", type=int, default=4, help="observation width (4 = config 2; 17 / 18 = configs 3 / 5)")
     ap.add_argument("--act", type=int, default=2, help="Discrete(n)")
     a = ap.parse_args()
-    os.environ["ORL_PPO_WAVES"] = str(a.waves)
+    os.environ["ORL_KEEP_BUILD"] = "1"  # load the --prof build as it is
     from openrl_amd import _native as nat
     from openrl_amd import spaces
     from openrl_amd.algorithms.ppo import PPOAlgorithm
@@ -56,7 +56,7 @@ def main():
         algo.train(buf)
         lib.orl_debug_prof(out)  # resets; keep the last iteration
     launches = out[12]
-    tiles = launches * (N * T // 16) // (256 * a.waves)
+    tiles = launches * (N * T // 16) // (256 * a.waves)  # --waves must match the build (ORL_TOWER_MAXWAVES)
     tot = sum(out[k] for k in range(11))
     print("waves/workgroup %d: %d launches, %d tiles by the probe wave, %.0f cycles per tile" % (a.waves, launches, tiles,
                                                                                           tot / tiles))
