@@ -137,6 +137,20 @@ __device__ inline float row_allsum(float s) {
   return a + b;
 }
 
+// Two independent row sums in one go: the swaps of the two values share their wait states and the dependent
+// add -> swap -> add chain of one value hides behind the other's (LayerNorm needs its two statistics together).
+__device__ inline void row_allsum2(float& x, float& y) {
+  float a = x, b = x, c = y, d = y;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  const float t = a + b, u = c + d;
+  a = t; b = t; c = u; d = u;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  x = a + b;
+  y = c + d;
+}
+
 // max over the same 4 lanes, result in all of them
 __device__ inline float row_allmax(float s) {
   float a = s, b = s;

@@ -101,11 +101,11 @@ __device__ inline void ln_bwd_T(f32x4 (&d)[4], const f32x4 (&xhat)[4], const flo
     s1 += (d[m][0] + d[m][1]) + (d[m][2] + d[m][3]);
     s2 += (t[0] + t[1]) + (t[2] + t[3]);
   }
-  s1 = row_allsum(s1);
-  s2 = row_allsum(s2);
-  const float c1 = s1 * (1.0f / 64.0f), c2 = s2 * (1.0f / 64.0f);
+  row_allsum2(s1, s2);
+  // rstd * (d*g - c1 - xhat*c2) as two FMAs per element
+  const float k1 = -s1 * (1.0f / 64.0f) * rstd, k2 = -s2 * (1.0f / 64.0f) * rstd;
 #pragma unroll
-  for (int m = 0; m < 4; ++m) d[m] = (d[m] - c1 - xhat[m] * c2) * rstd;
+  for (int m = 0; m < 4; ++m) d[m] = xhat[m] * k2 + (d[m] * rstd + k1);
 }
 
 // acc[mo] += sum_o W[o][16mo + j-th column] * in[o]   i.e.  acc = W^T in  with W row-major [64][W2S]:
@@ -201,14 +201,27 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     if (t >= n_tiles || ii >= A.mb) return 0;  // invalid lanes read row 0 (finite data, weight 0)
     return (A.idx != nullptr) ? A.idx[ii] : (long long)ii;
   };
+  // The DMA is issued from an asm statement on purpose.  hipcc counts __builtin_amdgcn_global_load_lds in vmcnt and,
+  // having no alias information for it, drains it (s_waitcnt vmcnt(0)) before the next LDS read of the wave - i.e.
+  // right after the issue, a full HBM round trip per tile with nothing overlapped (2 900 of a tile's 24 000 cycles in
+  // the phase profile).  An asm statement is invisible to that bookkeeping; the one wait this pipeline needs is the
+  // explicit vmcnt(0) at the top of the tile loop, a whole tile after the issue (guide section 5.7: M0 is written in
+  // the same statement that reads it; the s_nop covers the SALU-write -> M0 use hazard).
   auto issue_dma = [&](float* slot, long long row) {
     const float* src = A.records + (size_t)row * A.R;
 #pragma unroll 1
     for (int g = 0; 4 * g < nch; ++g) {
       const int c = 4 * g + q;
-      if (c < nch)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * c),
-                                         (__attribute__((address_space(3))) void*)(slot + g * 256), 16, 0, 0);
+      const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
+          (unsigned)(size_t)(__attribute__((address_space(3))) float*)(slot + g * 256));
+      if (c < nch) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src + 4 * c), "s"(lds_dst)
+                     : "memory");
+      }
     }
   };
   long long row_next = 0;
@@ -228,8 +241,12 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     const bool valid = i < A.mb;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's records have landed in LDS
     const float* RT = RR + ring * rts;
-    issue_dma(RR + (ring ^ 1) * rts, row_next);       // next tile's records, hidden behind this tile
+    // Order matters: the index prefetch (a load hipcc counts) is re-issued BEFORE the DMA (which it cannot see).  The
+    // other way round, hipcc's own "previous load into these registers must have landed" wait sits behind the DMA
+    // and drains it.
+    const long long row_cur = row_next;
     row_next = row_of(tile + 2 * n_waves);
+    issue_dma(RR + (ring ^ 1) * rts, row_cur);        // next tile's records, hidden behind this tile
     ring ^= 1;
 #define REC(col) RT[(((col) >> 2) << 6) + (j << 2) + ((col) & 3)]
 #define REC_R(r, col) RT[(((col) >> 2) << 6) + ((r) << 2) + ((col) & 3)]
@@ -237,7 +254,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     ORL_T(0);  // record DMA wait + next issue
     // ---------------- forward ----------------
     float rstd1, rstd2;
-    unsigned relu_bits = 0u;
+    // relu'(z1) as 16 wave-wide lane masks (one v_cmp each, kept in SGPR pairs) instead of a per-lane bit field that
+    // costs an or per element here and an and + compare per element in the backward pass
+    unsigned long long relu_mask[16];
     float hd[NO];
     f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};  // wide heads: this lane's 4 logits
     {
@@ -249,7 +268,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (z[m][r] > 0.f) relu_bits |= 1u << (4 * m + r);
+          relu_mask[4 * m + r] = __builtin_amdgcn_ballot_w64(z[m][r] > 0.f);
           z[m][r] = fmaxf(z[m][r], 0.f);
         }
       ln_normalize_T(z, rstd1);  // z = xhat1
@@ -602,9 +621,11 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     store_slab_T(SS, d2, j, q);
     wave_lds_fence();
     ORL_T(6);  // dn2, LN2 backward, dz2 slab store
-#ifndef ORL_TOWER_ILV
     {
-      // wgrad: G += dz2^T xhat1 (operands straight from the slabs in F layout), db2
+      // wgrad: G += dz2^T xhat1 (operands straight from the slabs in F layout), db2.  Issued as a burst of its own:
+      // an fp32 MFMA blocks the issuing wave's VALU for its whole 32 cycles on gfx950 (tools/mfma_valu_overlap.hip),
+      // so interleaving these MFMAs with the LN1' chain below buys nothing (measured: 4 862 cycles interleaved vs
+      // 2 986 + 1 884 as two phases).
       float s_db = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -624,62 +645,16 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       a_db2 += s_db;
     }
     ORL_T(7);  // wgrad: 64 MFMA from F-layout slab reads, db2
-    // dgrad: dn1 = W2^T dz2, LN1 backward, relu backward -> dz1
+    // dgrad: dn1 = W2^T dz2 straight from the LN2' output registers (no T-layout re-read of the slab), then LN1
+    // backward and relu backward -> dz1
     f32x4 d1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-      f32x4 dz2[4];  // re-read from the slab (T layout) instead of keeping 16 VGPRs live across the wgrad block
-      load_slab_T(SS, dz2, j, q);
-      ORL_PRIO(1);
-      // dgrad A operand: a transposed copy of W2 in LDS read by 16-byte rows (16 reads per 64 MFMA); reading W2 by
-      // columns (64 four-byte reads, one per MFMA) made this the slowest phase of the tile: 5 100 vs 3 100 cycles
-      if (w2t) mm64_T(lw + tw.W2T, dz2, d1, j, q);
-      else mm64_T_wt(lw + tw.W2, dz2, d1, j, q);
-      ORL_PRIO(0);
-    }
-    ORL_T(8);  // dgrad: 64 MFMA
-    {
-      f32x4 xh1[4];
-      load_slab_T(X1, xh1, j, q);
-      ln_bwd_T(d1, xh1, lw + tw.g1, rstd1, q);
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (!((relu_bits >> (4 * m + r)) & 1u)) d1[m][r] = 0.f;
-    wave_lds_fence();
-    store_slab_T(SS, d1, j, q);
-    wave_lds_fence();
-#else
-    // Interleaved backward (ORL_TOWER_ILV): the 64 wgrad MFMAs have no consumer inside the tile, so they are issued
-    // UNDER the VALU / LDS chain LN1' -> relu' -> dz1 store (and the dW1 loop below) instead of as a burst of their
-    // own during which the wave's VALU idles.  Their 32 operands are read from the slabs first (the dz1 store below
-    // overwrites the dz2 slab; LDS operations of a wave execute in program order).
-    float av[4][4], bv[4][4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        av[s][m] = SS[(4 * s + q) * TS + 16 * m + j];
-        bv[s][m] = X1[(4 * s + q) * TS + 16 * m + j];
-      }
-    {
-      float s_db = 0.f;
-      const int f = l;
-      for (int r = 0; r < TILE_B; ++r) s_db += SS[r * TS + f];
-      a_db2 += s_db;
-    }
-    ORL_T(7);  // wgrad operand reads, db2
-    // dgrad: dn1 = W2^T dz2 straight from the LN2' output registers
-    f32x4 d1[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // dgrad A operand: a transposed copy of W2 in LDS read by 16-byte rows (16 reads per 64 MFMA); reading W2 by
+    // columns (64 four-byte reads, one per MFMA) made this the slowest phase of the tile: 5 100 vs 3 100 cycles
     if (w2t) mm64_T(lw + tw.W2T, d2, d1, j, q);
     else mm64_T_wt(lw + tw.W2, d2, d1, j, q);
     ORL_T(8);  // dgrad: 64 MFMA
-    __builtin_amdgcn_sched_barrier(0);
     {
       f32x4 xh1[4];
       load_slab_T(X1, xh1, j, q);
@@ -689,17 +664,10 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (!((relu_bits >> (4 * m + r)) & 1u)) d1[m][r] = 0.f;
+        d1[m][r] = __builtin_amdgcn_inverse_ballot_w64(relu_mask[4 * m + r]) ? d1[m][r] : 0.f;
     wave_lds_fence();
     store_slab_T(SS, d1, j, q);
     wave_lds_fence();
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) G[mo][mi] = ORL_MFMA(av[s][mo], bv[s][mi], G[mo][mi]);
-#endif
     ORL_T(9);  // LN1 backward, relu backward, dz1 slab store
     // dW1 += dz1^T x, db1
     {
@@ -742,16 +710,6 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       }
       a_db1 += s_db;
     }
-#ifdef ORL_TOWER_ILV
-    // one wgrad MFMA per ~5 VALU / LDS instructions of the chain above (the pipe takes one fp32 MFMA per 32 cycles)
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     wave_lds_fence();
     ORL_T(10);  // dW1 / db1
   }

@@ -38,7 +38,7 @@ __device__ __forceinline__ void mfma_bf16(f32x4& acc, bf16x8 a, bf16x8 b) {
 
 // MODE: 0 mfma only, 1 valu only, 2 mixed in one wave, 3 split by wave half.  BF: 0 fp32 MFMA, 1 bf16 MFMA
 template <int MODE, int K, int BF>
-__global__ __launch_bounds__(512) void probe(float* out, long long* cycles, float seed) {
+__global__ __launch_bounds__(1024) void probe(float* out, long long* cycles, float seed) {
   const int wave = threadIdx.x >> 6;
   const bool do_mfma = MODE == 0 || MODE == 2 || (MODE == 3 && wave < 4);
   const bool do_valu = MODE == 1 || MODE == 2 || (MODE == 3 && wave >= 4);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) void probe(float* out, long long* cycles, floa
 
 template <int MODE, int K, int BF>
 static void run(const char* name, int threads, float* out, long long* cyc) {
-  long long h[8] = {0};
+  long long h[16] = {0};
   for (int rep = 0; rep < 3; ++rep) {
     hipLaunchKernelGGL((probe<MODE, K, BF>), dim3(1), dim3(threads), 0, 0, out, cyc, 1.0f + rep);
     hipDeviceSynchronize();
@@ -100,21 +100,27 @@ static void run(const char* name, int threads, float* out, long long* cyc) {
   hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
   const double slots = (double)ITERS * NACC;
   printf("%-34s waves %d: wave0 %7.1f cyc/slot", name, threads / 64, h[0] / slots);
-  if (threads == 512) printf("   wave4 %7.1f cyc/slot", h[4] / slots);
+  if (threads >= 512) printf("   wave4 %7.1f cyc/slot", h[4] / slots);
   printf("\n");
 }
 
 int main() {
   float* out;
   long long* cyc;
-  hipMalloc(&out, 512 * sizeof(float));
-  hipMalloc(&cyc, 8 * sizeof(long long));
+  hipMalloc(&out, 1024 * sizeof(float));
+  hipMalloc(&cyc, 16 * sizeof(long long));
   printf("one slot = 1 MFMA and/or K v_fma_f32 (wave64); s_memtime ticks = shader cycles\n");
   printf("---- fp32 MFMA v_mfma_f32_16x16x4_f32, K = 4\n");
   run<0, 4, 0>("A mfma only (1 wave/SIMD)", 256, out, cyc);
   run<1, 4, 0>("B valu only (1 wave/SIMD)", 256, out, cyc);
   run<2, 4, 0>("C mfma+valu in ONE wave", 256, out, cyc);
   run<3, 4, 0>("D mfma waves 0-3 | valu waves 4-7", 512, out, cyc);
+  printf("---- VALU pipe occupancy: the same v_fma stream on 1 / 2 / 4 waves per SIMD (K = 4 and 8 independent chains)\n");
+  run<1, 4, 0>("B valu only, 2 waves/SIMD", 512, out, cyc);
+  run<1, 4, 0>("B valu only, 4 waves/SIMD", 1024, out, cyc);
+  run<1, 8, 0>("B valu only K=8, 2 waves/SIMD", 512, out, cyc);
+  run<1, 8, 0>("B valu only K=8, 4 waves/SIMD", 1024, out, cyc);
+  run<0, 4, 0>("A mfma only, 2 waves/SIMD", 512, out, cyc);
   printf("---- fp32 MFMA, K = 8\n");
   run<1, 8, 0>("B valu only", 256, out, cyc);
   run<2, 8, 0>("C mfma+valu in ONE wave", 256, out, cyc);
