@@ -485,6 +485,79 @@ int orl_rnn_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const 
                       const orl_adam_state* padam, const orl_adam_state* cadam, float* train_info_accum,
                       float* scratch, void* stream);
 
+/* ==== general tower path (csrc/orl_gen.hip) ==========================================================================
+ * The fused kernels above are built for the reference's DEFAULT tower (hidden_size 64, layer_N 1, ReLU, no feature
+ * LayerNorm) - what every BASELINE.json configuration runs.  Everything else MLPBase / MLPLayer
+ * (openrl/modules/networks/utils/mlp.py:8-46,100-180), PolicyValueNetwork (use_share_model,
+ * openrl/modules/networks/policy_value_network.py:34-230) and ACTLayer's MultiDiscrete branch
+ * (openrl/modules/networks/utils/act.py:26-34,60-72,136-151) can express runs layer by layer through these entry
+ * points, activations in caller-owned device buffers; the layer loop is host code (modules/generic_net.py), where the
+ * reference has it (nn.Module.forward). */
+#define ORL_ACT_NONE (-1)
+#define ORL_ACT_TANH 0 /* = cfg.activation_id (mlp.py:13) */
+#define ORL_ACT_RELU 1
+#define ORL_ACT_LEAKY_RELU 2
+#define ORL_ACT_ELU 3
+#define ORL_HEAD_MULTI_DISCRETE 3 /* MultiDiscrete(nvec): n_heads Categoricals over one concatenated logits row */
+#define ORL_MAX_HEADS 8
+typedef struct orl_head_desc {
+  int32_t kind;    /* ORL_HEAD_CATEGORICAL / _GAUSSIAN / _MULTI_DISCRETE */
+  int32_t n_out;   /* logits per row (MultiDiscrete: sum of nvec) */
+  int32_t n_heads; /* MultiDiscrete: components, else 1 */
+  int32_t nvec[ORL_MAX_HEADS];
+} orl_head_desc;
+
+/* C[M,N] = sum_k A(m,k) * B(k,n) in fp32 on MFMA; element (m,k) of A sits at A + m*sam + k*sak, (k,n) of B at
+ * B + k*sbk + n*sbn, so the same kernel is x W^T (nn.Linear forward), dz W (input gradient) and dz^T x (weight
+ * gradient: K = batch rows).  n_split > 1 splits K into that many slices whose partial products go to
+ * partials[n_split][M*N] and are summed in slice order (deterministic). */
+int orl_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int64_t ldc,
+             int M, int N, int K, int n_split, float* partials, void* stream);
+/* One layer of MLPLayer below its Linear: a = act(z + bias); with gamma/beta also LayerNorm (eps 1e-5):
+ * xhat = (a - mean) * rstd, y = xhat * gamma + beta; without them y = a.  z, a, xhat, y are [B, H] (H <= 512), rstd [B];
+ * every output pointer may be NULL.  Also used with z = observations, act NONE, bias NULL for MLPBase.feature_norm. */
+int orl_row_fwd(const float* z, const float* bias, int act, const float* gamma, const float* beta, int B, int H,
+                float* a_out, float* xhat_out, float* rstd_out, float* y_out, void* stream);
+/* Its backward: dy [B,H] -> dz [B,H] (gradient at the Linear's output; may be NULL) and per-workgroup partial rows
+ * col_partials[n_blocks][3H] = [d gamma | d beta | d bias] to be column-summed with orl_ppo_reduce. */
+int orl_row_bwd(const float* dy, const float* gamma, const float* xhat, const float* rstd, const float* a, int act, int B,
+                int H, float* dz_out, float* col_partials, int max_blocks, int* n_blocks_out, void* stream);
+/* out[i, :] = records[idx[i] (or i), col0 : col0+width] */
+int orl_gather_cols(const float* records, int rec_width, int col0, int width, const int64_t* idx, int mb, float* out,
+                    void* stream);
+/* den[0] = sum of the active column over the minibatch rows, den[1] = rows: the masked-mean denominators of
+ * PPOAlgorithm.prepare_loss (ppo.py:319-361); a multi-GPU run all-reduces these two floats. */
+int orl_gen_denoms(const float* records, int rec_width, int Dp, int Dc, int a_w, const int64_t* idx, int mb, float* den,
+                   void* stream);
+/* Policy part of prepare_loss + ACTLayer.evaluate_actions for rows idx[0..mb) given the head's logits [mb, n_out]:
+ * training (dlogits != NULL): dlogits = d(policy_loss - entropy_coef * dist_entropy) / d logits, ALREADY divided by
+ * the denominators in den; partials[n_blocks][20] = {policy-loss sum, entropy sum, ratio sum, -, dlogstd[16]}.
+ * evaluation (dlogits == NULL): logp_out [mb, a_w] and ent_out [mb] only. */
+int orl_gen_policy_loss(const orl_head_desc* head, const float* logits, const float* logstd, const float* records,
+                        int rec_width, int Dp, int Dc, int a_w, int K, const int64_t* idx, int mb, const float* den,
+                        const orl_ppo_hparams* hp, float* dlogits, float* partials, int max_blocks, int* n_blocks_out,
+                        float* logp_out, float* ent_out, void* stream);
+/* cal_value_loss (ppo.py:178-220): dvalues [mb] (already * value_loss_coef / denominator), partials[n_blocks][1]. */
+int orl_gen_value_loss(const float* values, const float* records, int rec_width, int Dp, int Dc, int a_w, int K,
+                       const int64_t* idx, int mb, const float* vn_state, const float* den, const orl_ppo_hparams* hp,
+                       float* dvalues, float* partials, int max_blocks, int* n_blocks_out, void* stream);
+/* ACTLayer.forward from logits: actions / log-probs [B, a_w]; Philox counters as orl_act_step (MultiDiscrete component
+ * h takes word h of the stream). */
+int orl_gen_sample(const orl_head_desc* head, const float* logits, const float* logstd, const float* action_masks, int B,
+                   int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
+                   const float* forced_u, int a_w, float* actions, float* logp, void* stream);
+/* clip_grad_norm_ (n_clips = 2: twice, as ppo.py:127-145 does for the shared model) + torch.optim.Adam on one flat
+ * vector; train_info_accum[slot_first] += norm before the first clip, [slot_second] += norm before the second
+ * (slots < 0 are skipped); scratch holds 256 floats. */
+int orl_gen_adam(const orl_adam_state* adam, int64_t n, float max_grad_norm, int use_max_grad_norm, int n_clips,
+                 float* scratch, float* train_info_accum, int slot_first, int slot_second, void* stream);
+/* dst[0..n) += src[0..n): gradient accumulation when a shared trunk is back-propagated twice (policy and critic
+ * observations differ) or two heads feed one feature gradient. */
+int orl_vec_add(float* dst, const float* src, int64_t n, void* stream);
+/* train_info_accum {value_loss, policy_loss, dist_entropy, -, -, ratio} += the reduced loss sums / denominators. */
+int orl_gen_info(const float* policy_sums, const float* value_sums, const float* den, const orl_ppo_hparams* hp,
+                 float entropy_div, float ratio_div, float* train_info_accum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

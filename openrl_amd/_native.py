@@ -86,6 +86,13 @@ class RnnBatch(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class HeadDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_out", C.c_int32), ("n_heads", C.c_int32), ("nvec", C.c_int32 * 8)]
+
+
+ORL_ACT_NONE, ORL_ACT_TANH, ORL_ACT_RELU, ORL_ACT_LEAKY_RELU, ORL_ACT_ELU = -1, 0, 1, 2, 3
+ORL_HEAD_MULTI_DISCRETE = 3
+
 # order of orl_abi_struct_size(which)
 _ABI_STRUCTS = (NetDesc, PackSrc, BufferPtrs, CopyDesc, GatherDesc, PPOHParams, AdamState, RolloutArgs, RnnBatch)
 
@@ -140,6 +147,23 @@ _SIGNATURES = {
     "orl_ppo_apply_comm": (C.c_int, [_P, C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
                                      C.POINTER(AdamState), C.POINTER(AdamState), _P, _P, C.c_int64, C.c_uint64,
                                      C.c_uint64, _P, _P, C.c_double, _P]),
+    "orl_gemm": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
+                           C.c_int, _P, _P]),
+    "orl_row_fwd": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "orl_row_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int), _P]),
+    "orl_gather_cols": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "orl_gen_denoms": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "orl_gen_policy_loss": (C.c_int, [C.POINTER(HeadDesc), _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P,
+                                      C.c_int, _P, C.POINTER(PPOHParams), _P, _P, C.c_int, C.POINTER(C.c_int), _P, _P,
+                                      _P]),
+    "orl_gen_value_loss": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P,
+                                     C.POINTER(PPOHParams), _P, _P, C.c_int, C.POINTER(C.c_int), _P]),
+    "orl_gen_sample": (C.c_int, [C.POINTER(HeadDesc), _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
+                                 _P, _P, C.c_int, _P, _P, _P]),
+    "orl_gen_adam": (C.c_int, [C.POINTER(AdamState), C.c_int64, C.c_float, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
+                               _P]),
+    "orl_vec_add": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "orl_gen_info": (C.c_int, [_P, _P, _P, C.POINTER(PPOHParams), C.c_float, C.c_float, _P, _P]),
     "orl_valuenorm_update": (C.c_int, [_P, _P, C.c_double, _P]),
     "orl_minibatch_moments": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
     "orl_env_state_width": (C.c_int, [C.c_int]),

@@ -108,13 +108,31 @@ class PPOAlgorithm(BaseAlgorithm):
     info_keys = INFO_KEYS
 
     def __init__(self, cfg, init_module, agent_num: int = 1, device: Union[str, torch.device] = "cuda:0") -> None:
-        if cfg.use_share_model or cfg.use_joint_action_loss or cfg.use_deepspeed or cfg.use_amp:
-            raise NotImplementedError("share_model / joint_action_loss / deepspeed / amp are not built in this engine")
+        if cfg.use_joint_action_loss or cfg.use_deepspeed or cfg.use_amp:
+            raise NotImplementedError("joint_action_loss / deepspeed / amp are not built in this engine")
         if cfg.use_naive_recurrent_policy:
             raise NotImplementedError("naive_recurrent_generator is not built in this engine (use_recurrent_policy is)")
         super().__init__(cfg, init_module, agent_num, device)
         self.train_list = [self.train_ppo]
         self.hp = ops.make_hparams(cfg)
+        self.generic = bool(getattr(self.algo_module, "generic", False))
+        self.perm_mode = getattr(cfg, "amd_perm_mode", "reference")
+        self._perm_counter = 0
+        self._vn_in_perm = False
+        self.last_indices = None
+        self._info = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self._moments = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self._mom_scratch = torch.zeros(512, dtype=torch.float64, device=self.device)
+        self._adv_stats = torch.zeros(11, dtype=torch.float64, device=self.device)
+        self._moments_mb = self._moments
+        self._full_batch_moments = False
+        if self.generic:  # general towers (modules/generic_net.py): layer-wise update, algorithms/ppo_generic.py
+            self.recurrent = False
+            self.fuse_next_perm = False
+            self._comm = None
+            self._gen_den = torch.zeros(2, dtype=torch.float32, device=self.device)
+            self._gen_scratch = torch.zeros(256, dtype=torch.float32, device=self.device)
+            return
         p, c = self.algo_module.models["policy"], self.algo_module.models["critic"]
         self.recurrent = bool(getattr(self.algo_module, "recurrent", False))
         raw = ops_rnn.rnn_raw_grad_count if self.recurrent else ops.raw_grad_count
@@ -132,17 +150,7 @@ class PPOAlgorithm(BaseAlgorithm):
         # or as its own launch (recurrent); None = single process or amd_collective=rccl -> torch.distributed
         self._comm = dist_utils.make_small_allreduce(self._sums.numel(), dev, getattr(cfg, "amd_collective", "p2p")) \
             if self.world_size > 1 else None
-        self._info = torch.zeros(8, dtype=torch.float32, device=dev)
-        self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
-        self._mom_scratch = torch.zeros(512, dtype=torch.float64, device=dev)
-        self._adv_stats = torch.zeros(11, dtype=torch.float64, device=dev)  # 8 sums + the full-batch return moments
-        self._moments_mb = self._moments
-        self._full_batch_moments = False
-        self.perm_mode = getattr(cfg, "amd_perm_mode", "reference")
-        self._perm_counter = 0
-        self._vn_in_perm = False
         self.fuse_next_perm = True  # device permutation of epoch e+1 rides in epoch e's optimiser-step launch
-        self.last_indices = None  # minibatch index tensors of the last train() (tests / inspection)
 
     # ------------------------------------------------------------------------------------------ advantages
     def _advantages_and_records(self, buffer) -> None:
@@ -164,6 +172,10 @@ class PPOAlgorithm(BaseAlgorithm):
 
     # ------------------------------------------------------------------------------------------ one minibatch
     def _update_minibatch(self, buffer, idx, mb: int, turn_on: bool, next_perm=None):
+        if self.generic:
+            from .ppo_generic import update_minibatch_generic
+
+            return update_minibatch_generic(self, buffer, idx, mb, turn_on)
         mod = self.algo_module
         p, c = mod.models["policy"], mod.models["critic"]
         po, co = mod.optimizers["policy"], mod.optimizers["critic"]

@@ -1,0 +1,137 @@
+"""One PPO minibatch on the GENERAL towers (``modules/generic_net.py``): ``PPOAlgorithm.ppo_update``
+(openrl/algorithms/ppo.py:46-176) = prepare_loss (:238-361) -> backward of every loss in the loss list (:112-124)
+-> clip_grad_norm_ per parameter group (:127-145) -> optimizer.step() for every optimizer (:160-164), as a chain of
+HIP launches per layer (``ops_gen``).  Separate policy / critic networks take one trunk pass each; the shared
+``PolicyValueNetwork`` takes ONE pass when policy and critic observations are the same array (the reference runs
+``obs_prep`` + ``common`` twice on the same data and sums the gradients - identical up to fp32 summation order),
+two passes otherwise, and is clipped twice exactly as the reference clips ``get_actor_para()`` and then
+``get_critic_para()`` (both = all parameters, base_value_policy_network.py:58-62).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _native as nat
+from .. import distributed as dist_utils
+from .. import ops, ops_gen
+from ..modules import generic_net as gn
+
+
+def _loss_sums(ws, name: str, nb: int, width: int):
+    ops.ppo_reduce(ws.loss_partials.data_ptr(), nb, width, ws.loss_sums[name].data_ptr(), ws.loss_sums[name].device)
+    return ws.loss_sums[name]
+
+
+def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool) -> None:
+    mod = algo.algo_module
+    rec = buffer.records
+    Dp, Dc, a_w, K = buffer.Dp, buffer.Dc, buffer.act_shape, buffer.K
+    hp = algo.hp
+    vn = mod.get_critic_value_normalizer() if algo._use_valuenorm else None
+    vn_state = None
+    if vn is not None:
+        if not algo._full_batch_moments:
+            ret_col = Dp + Dc + 2 * a_w + 2
+            ops.minibatch_moments(rec, ret_col, idx, mb, algo._mom_scratch, algo._moments)
+            if algo.world_size > 1:
+                dist_utils.allreduce_(algo._moments)
+        if algo._vn_in_perm:
+            algo._vn_in_perm = False  # this epoch's update already ran inside the permutation launch
+        else:
+            ops.valuenorm_update(vn.state, algo._moments, vn.beta)  # BEFORE normalize (ppo.py:190-195)
+        vn_state = vn.state
+    den = algo._gen_den
+    ops_gen.denoms(rec, Dp, Dc, a_w, idx, mb, den)
+    if algo.world_size > 1:
+        dist_utils.allreduce_(den)  # global masked-mean denominators
+    pn, cn = mod.policy_net, mod.critic_net
+    shared = mod.share_model
+    one_pass = shared and buffer.critic_obs is buffer.policy_obs
+
+    # ---- forward
+    wp = mod.workspace(pn, mb, True, "p")
+    xp = wp.v(wp.x0, mb, Dp)
+    ops_gen.gather_cols(rec, 0, Dp, idx, mb, xp)
+    feats_p = gn.trunk_forward(pn, wp, xp, True)
+    logits = gn.head_forward(pn, wp, "act", feats_p)
+    if one_pass:
+        wc, feats_c = wp, feats_p
+    else:
+        wc = mod.workspace(cn, mb, True, "c")
+        xc = wc.v(wc.x0, mb, Dc)
+        ops_gen.gather_cols(rec, Dp, Dc, idx, mb, xc)
+        feats_c = gn.trunk_forward(cn, wc, xc, True)
+    values = gn.head_forward(cn, wc, "v_out", feats_c)
+
+    # ---- losses: d loss / d head outputs (already divided by the denominators) + statistics
+    head = pn.head_desc
+    dlogits = wp.v(wp.dhead["act"], mb, head.n_out)
+    nb = ops_gen.policy_loss(head, logits, mod._logstd(), rec, Dp, Dc, a_w, K, idx, mb, den, hp, dlogits,
+                             wp.loss_partials)
+    psums = _loss_sums(wp, "act", nb, 20)
+    dvalues = wc.v(wc.dhead["v_out"], mb, 1)
+    nb = ops_gen.value_loss(values.view(-1), rec, Dp, Dc, a_w, K, idx, mb, vn_state, den, hp, dvalues.view(-1),
+                            wc.loss_partials)
+    vsums = _loss_sums(wc, "v_out", nb, 1)
+
+    # ---- backward + optimiser
+    def step(net, opt, n_clips, slot_first, slot_second):
+        if algo.world_size > 1:
+            dist_utils.allreduce_(net.grad)
+        opt.step_count += 1
+        ops_gen.adam(opt.native_state(opt.step_count), net.n_params, hp.max_grad_norm, bool(hp.use_max_grad_norm), n_clips,
+                     algo._gen_scratch, algo._info, slot_first, slot_second, algo.device)
+
+    def logstd_grad(net):
+        h = net.heads["act"]
+        if "logstd" in h:
+            ops.multi_copy([(net.v(h["logstd"], h["n"], grad=True), psums[4:4 + h["n"]])])
+
+    if shared:
+        model, opt = mod.models["model"], mod.optimizers["model"]
+        model.grad.zero_()
+        if one_pass:
+            dfeat = wp.v(wp.dfeat, mb, model.H)
+            gn.head_backward(model, wp, "v_out", feats_c, dvalues, dfeat, False)
+            if turn_on:
+                gn.head_backward(model, wp, "act", feats_p, dlogits, dfeat, True)
+                logstd_grad(model)
+            gn.trunk_backward(model, wp, dfeat)
+        else:
+            dfeat = wc.v(wc.dfeat, mb, model.H)
+            gn.head_backward(model, wc, "v_out", feats_c, dvalues, dfeat, False)
+            gn.trunk_backward(model, wc, dfeat)
+            if turn_on:
+                g1 = model.grad.clone()
+                dfeat = wp.v(wp.dfeat, mb, model.H)
+                gn.head_backward(model, wp, "act", feats_p, dlogits, dfeat, False)
+                logstd_grad(model)
+                gn.trunk_backward(model, wp, dfeat)  # rewrites the trunk slots; head slots of the other pass stay
+                hv = model.heads["v_out"]
+                lo, hi = hv["W"], hv["b"] + 1
+                g1[lo:hi] = 0.0  # v_out's gradient is already in model.grad (the second pass did not touch it)
+                ops_gen.vec_add(model.grad, g1)
+        step(model, opt, 2, 3, 4)  # actor_grad_norm, then critic_grad_norm of the once-clipped gradient
+    else:
+        popt, copt = mod.optimizers["policy"], mod.optimizers["critic"]
+        if turn_on:
+            pn.grad.zero_()
+            dfeat = wp.v(wp.dfeat, mb, pn.H)
+            gn.head_backward(pn, wp, "act", feats_p, dlogits, dfeat, False)
+            logstd_grad(pn)
+            gn.trunk_backward(pn, wp, dfeat)
+            step(pn, popt, 1, 3, -1)
+        cn.grad.zero_()
+        dfeat = wc.v(wc.dfeat, mb, cn.H)
+        gn.head_backward(cn, wc, "v_out", feats_c, dvalues, dfeat, False)
+        gn.trunk_backward(cn, wc, dfeat)
+        step(cn, copt, 1, 4, -1)
+
+    # ---- train_info (device-side accumulation; the sums are global in a multi-GPU run)
+    if algo.world_size > 1:
+        dist_utils.allreduce_(psums)
+        dist_utils.allreduce_(vsums)
+    gauss = head.kind == ops_gen.HEAD_GAUSSIAN
+    ent_div = float(head.n_out) if (gauss and not hp.use_policy_active_masks) else 1.0
+    ratio_div = float(a_w) if head.kind != ops_gen.HEAD_CATEGORICAL else 1.0
+    ops_gen.info(psums, vsums, den, hp, ent_div, ratio_div, algo._info)

@@ -78,7 +78,11 @@ class OnPolicyDriver:
         recurrent = bool(getattr(self.trainer.algo_module, "recurrent", False))
         if mode == "fused" and recurrent:
             raise ValueError("amd_rollout_mode=fused is not built for recurrent policies (stepwise rollout only)")
-        can_fuse = dev_env and bool(getattr(self.envs, "supports_fused_rollout", True)) and not recurrent
+        generic = bool(getattr(self.trainer.algo_module, "generic", False))  # general towers roll out stepwise
+        if mode == "fused" and generic:
+            raise ValueError("amd_rollout_mode=fused is built for the default tower only (hidden 64, layer_N 1, ReLU)")
+        can_fuse = (dev_env and bool(getattr(self.envs, "supports_fused_rollout", True)) and not recurrent
+                    and not generic)
         if mode == "fused" and not can_fuse:
             raise ValueError("amd_rollout_mode=fused is not built for env %r" % getattr(self.envs, "env_name", "?"))
         self.fused = can_fuse and mode in ("auto", "fused") and not per_step_cb

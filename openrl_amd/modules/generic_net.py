@@ -1,0 +1,509 @@
+"""General towers: any ``hidden_size`` / ``layer_N`` / ``activation_id`` / ``use_feature_normalization``, the shared
+``PolicyValueNetwork`` (``use_share_model``) and MultiDiscrete action heads.
+
+The fused MFMA kernels (``orl_act_step`` / ``orl_ppo_fwd_bwd``) are built for the reference's DEFAULT tower.  Anything
+else ``MLPBase`` / ``MLPLayer`` (openrl/modules/networks/utils/mlp.py:8-46,100-180), ``PolicyValueNetwork``
+(openrl/modules/networks/policy_value_network.py:34-230) and ``ACTLayer``'s MultiDiscrete branch
+(openrl/modules/networks/utils/act.py:26-34,60-72,136-151) describe runs here layer by layer on the HIP primitives of
+``ops_gen`` (fp32 MFMA GEMM, fused bias/activation/LayerNorm rows, loss, Adam) with the activations in HBM.  The layer
+loop is host code - the place the reference has it (``nn.Module.forward``); there is still no torch.nn module, no
+autograd and no CPU path.
+
+Parameters are ONE flat float32 vector per network.  ``GenNet.entries`` lists (state_dict key, shape, offset) in the
+reference's registration order (so checkpoints and the golden vectors of ``oracle/gen_golden.py`` map one to one),
+including the quirks that matter for parity: ``MLPLayer.fc_h`` is registered next to its clones ``fc2`` and never
+used in ``forward`` (its parameters receive no gradient and never move), and the shared model's ``critic_obs_prep``
+is the same module object as ``obs_prep``.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .. import ops, ops_gen, spaces
+from .ppo_module import FusedAdam, PPOModule, ValueNorm
+
+GAINS = ["tanh", "relu", "leaky_relu", "selu"]  # calculate_gain names per activation_id (mlp.py:15-17)
+
+
+def needs_generic(cfg, act_space, share_model: bool) -> bool:
+    """Does this configuration fall outside the fused default-tower kernels?"""
+    kind = spaces.kind(act_space)
+    return bool(share_model or cfg.use_share_model or cfg.layer_N != 1 or cfg.hidden_size != 64
+                or cfg.activation_id != 1 or cfg.use_feature_normalization or kind == "MultiDiscrete")
+
+
+def _act_head(act_space):
+    kind = spaces.kind(act_space)
+    if kind == "Discrete":
+        return ops_gen.HEAD_CATEGORICAL, [int(act_space.n)]
+    if kind == "Box":
+        return ops_gen.HEAD_GAUSSIAN, [int(act_space.shape[0])]
+    if kind == "MultiDiscrete":
+        nvec = [int(h - l + 1) for h, l in zip(np.asarray(act_space.high).reshape(-1), np.asarray(act_space.low).reshape(-1))]
+        return ops_gen.HEAD_MULTI_DISCRETE, nvec
+    raise NotImplementedError("action space %s not built (Discrete / Box / MultiDiscrete)" % kind)
+
+
+class GenNet:
+    """One reference network (``PolicyNetwork`` / ``ValueNetwork`` / ``PolicyValueNetwork``) as a flat vector."""
+
+    def __init__(self, role: str, cfg, obs_dim: int, act_space, device) -> None:
+        assert role in ("policy", "critic", "model")
+        self.role, self.device = role, device
+        self.H = H = int(cfg.hidden_size)
+        if H % 4 or H > 512:
+            raise NotImplementedError("hidden_size %d: the general towers take multiples of 4 up to 512" % H)
+        self.D = int(obs_dim)
+        self.act_id = int(cfg.activation_id)
+        if not 0 <= self.act_id <= 3:
+            raise NotImplementedError("activation_id %d" % self.act_id)
+        layer_N = 0 if getattr(cfg, "use_single_network", False) else int(cfg.layer_N)
+        self.entries: List = []   # (key, shape, offset) in the reference's registration order
+        self.layers: List[Dict] = []
+        self.ctor: List = []      # construction order of the Linear layers: ("layer", L) / ("dead", fc_h, [clones])
+        self.fn: Optional[Dict] = None
+        self._o = 0
+        base = "obs_prep" if role == "model" else "base"
+        if cfg.use_feature_normalization:
+            self.fn = dict(g=self._add(base + ".feature_norm.weight", (self.D,)),
+                           be=self._add(base + ".feature_norm.bias", (self.D,)), dim=self.D)
+        self._mlp_layer(base + ".mlp", self.D, H, layer_N)
+        if role == "model":  # self.common = MLPLayer(H, H, layer_N=0, ...)  (policy_value_network.py:78-84)
+            self._mlp_layer("common", H, H, 0)
+        self.heads: Dict[str, Dict] = OrderedDict()
+        if role in ("critic", "model"):
+            self.heads["v_out"] = dict(W=self._add("v_out.weight", (1, H)), b=self._add("v_out.bias", (1,)), n=1,
+                                       gain=1.0, parts=[1])
+        if role in ("policy", "model"):
+            kind, nvec = _act_head(act_space)
+            n = sum(nvec)
+            oW, ob = self._o, self._o + n * H
+            self._o += n * H + n
+            if kind == ops_gen.HEAD_MULTI_DISCRETE:
+                r = 0
+                for i, k in enumerate(nvec):  # act.action_outs.{i}.linear.{weight,bias}: interleaved in the reference
+                    self.entries.append(("act.action_outs.%d.linear.weight" % i, (k, H), oW + r * H))
+                    self.entries.append(("act.action_outs.%d.linear.bias" % i, (k,), ob + r))
+                    r += k
+            elif kind == ops_gen.HEAD_GAUSSIAN:
+                self.entries.append(("act.action_out.fc_mean.weight", (n, H), oW))
+                self.entries.append(("act.action_out.fc_mean.bias", (n,), ob))
+            else:
+                self.entries.append(("act.action_out.linear.weight", (n, H), oW))
+                self.entries.append(("act.action_out.linear.bias", (n,), ob))
+            self.heads["act"] = dict(W=oW, b=ob, n=n, gain=float(cfg.gain), parts=nvec, kind=kind)
+            if kind == ops_gen.HEAD_GAUSSIAN:
+                self.heads["act"]["logstd"] = self._add("act.action_out.logstd._bias", (n, 1))
+            self.head_desc = ops_gen.head_desc(kind, n, nvec if kind == ops_gen.HEAD_MULTI_DISCRETE else None)
+            self.act_kind, self.nvec = kind, nvec
+            self.act_width = 1 if kind == ops_gen.HEAD_CATEGORICAL else len(nvec) if kind == ops_gen.HEAD_MULTI_DISCRETE else n
+        self.n_params = self._o
+        self.theta = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.theta)
+        self.training = False
+        self.value_normalizer: Optional[ValueNorm] = None
+        self.max_width = max([self.D, H] + [h["n"] for h in self.heads.values()])
+
+    # ------------------------------------------------------------------ layout
+    def _add(self, key: str, shape) -> int:
+        off = self._o
+        self.entries.append((key, tuple(shape), off))
+        self._o += int(np.prod(shape))
+        return off
+
+    def _seq(self, prefix: str, n_in: int, n_out: int, act: int, dead: bool = False) -> Dict:
+        ln = 2 if act != ops_gen.ACT_NONE else 1  # nn.Sequential(Linear, act, LayerNorm) / (Linear, LayerNorm)
+        d = dict(n_in=n_in, n_out=n_out, act=act, dead=dead,
+                 W=self._add(prefix + ".0.weight", (n_out, n_in)), b=self._add(prefix + ".0.bias", (n_out,)),
+                 g=self._add(prefix + ".%d.weight" % ln, (n_out,)), be=self._add(prefix + ".%d.bias" % ln, (n_out,)))
+        return d
+
+    def _mlp_layer(self, prefix: str, n_in: int, H: int, layer_N: int) -> None:
+        """MLPLayer.__init__ (mlp.py:8-39): fc1, [fc_h + (layer_N-1) clones in fc2], fc3."""
+        fc1 = self._seq(prefix + ".fc1", n_in, H, self.act_id)
+        self.layers.append(fc1)
+        self.ctor.append(("layer", fc1))
+        if layer_N > 1:
+            fc_h = self._seq(prefix + ".fc_h", H, H, self.act_id, dead=True)  # registered, never run in forward
+            clones = [self._seq(prefix + ".fc2.%d" % i, H, H, self.act_id) for i in range(layer_N - 1)]
+            self.layers.extend(clones)
+            self.ctor.append(("dead", fc_h, clones))
+        fc3 = self._seq(prefix + ".fc3", H, H, ops_gen.ACT_NONE)
+        self.layers.append(fc3)
+        self.ctor.append(("layer", fc3))
+
+    def v(self, off: int, *shape, grad: bool = False) -> torch.Tensor:
+        t = self.grad if grad else self.theta
+        return t[off:off + int(np.prod(shape))].view(*shape)
+
+    # ------------------------------------------------------------------ reference-order views
+    def named_parameters(self):
+        return [(k, self.v(o, *s)) for k, s, o in self.entries]
+
+    def parameters(self):
+        return [t for _, t in self.named_parameters()]
+
+    def reference_flat(self) -> torch.Tensor:
+        """``torch.cat([p.reshape(-1) for p in model.parameters() if p.requires_grad])`` of the reference model."""
+        return torch.cat([t.reshape(-1) for _, t in self.named_parameters()])
+
+    def load_reference_flat(self, flat) -> None:
+        flat = torch.as_tensor(flat, dtype=torch.float32).reshape(-1)
+        assert flat.numel() == self.n_params, (flat.numel(), self.n_params)
+        o = 0
+        for _, t in self.named_parameters():
+            t.copy_(flat[o:o + t.numel()].reshape(t.shape).to(self.device))
+            o += t.numel()
+
+    def reference_grad_flat(self) -> torch.Tensor:
+        return torch.cat([self.v(o, *s, grad=True).reshape(-1) for _, s, o in self.entries])
+
+    def state_dict(self):
+        sd = OrderedDict()
+        if self.value_normalizer is not None:
+            sd["value_normalizer.running_mean"] = self.value_normalizer.state[0:1]
+            sd["value_normalizer.running_mean_sq"] = self.value_normalizer.state[1:2]
+            sd["value_normalizer.debiasing_term"] = self.value_normalizer.state[2]
+        for k, t in self.named_parameters():
+            sd[k] = t
+            if k.startswith("obs_prep."):  # the same module object under a second name (policy_value_network.py:75)
+                sd["critic_" + k] = t
+        return sd
+
+    def load_state_dict(self, sd):
+        for k, t in self.named_parameters():
+            t.copy_(torch.as_tensor(sd[k]).to(self.device, torch.float32).reshape(t.shape))
+        if self.value_normalizer is not None and "value_normalizer.running_mean" in sd:
+            self.value_normalizer.state[0] = float(torch.as_tensor(sd["value_normalizer.running_mean"]).reshape(-1)[0])
+            self.value_normalizer.state[1] = float(torch.as_tensor(sd["value_normalizer.running_mean_sq"]).reshape(-1)[0])
+            self.value_normalizer.state[2] = float(torch.as_tensor(sd["value_normalizer.debiasing_term"]))
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ------------------------------------------------------------------ initial weights (reference RNG order)
+    def host_init(self, cfg) -> None:
+        """Draw the initial parameters on the HOST with the generator consumption of the reference constructors:
+        per Linear the nn.Linear default init, then orthogonal_/xavier_uniform_ with gain (mlp.py:14-39, act.py,
+        distributions.py:58-98, value_network.py:103-109, policy_value_network.py:78-113); LayerNorm draws nothing;
+        ``fc2`` clones are deepcopies of ``fc_h``."""
+        init_method = torch.nn.init.orthogonal_ if cfg.use_orthogonal else torch.nn.init.xavier_uniform_
+        gain = torch.nn.init.calculate_gain(GAINS[self.act_id])
+
+        def linear(n_in, n_out, g):
+            m = torch.nn.Linear(n_in, n_out)
+            init_method(m.weight.data, gain=g)
+            return m.weight.data.reshape(-1)
+
+        def fill(layer, w):
+            self.v(layer["W"], layer["n_out"] * layer["n_in"]).copy_(w)
+            self.v(layer["b"], layer["n_out"]).zero_()
+            self.v(layer["g"], layer["n_out"]).fill_(1.0)
+            self.v(layer["be"], layer["n_out"]).zero_()
+
+        if self.fn is not None:
+            self.v(self.fn["g"], self.D).fill_(1.0)
+            self.v(self.fn["be"], self.D).zero_()
+        for item in self.ctor:
+            if item[0] == "layer":
+                fill(item[1], linear(item[1]["n_in"], item[1]["n_out"], gain))
+            else:  # fc_h is constructed and initialised once; get_clones deep-copies it (no generator use)
+                w = linear(item[1]["n_in"], item[1]["n_out"], gain)
+                for L in [item[1]] + item[2]:
+                    fill(L, w)
+        for name, h in self.heads.items():
+            if name == "v_out":
+                self.v(h["W"], self.H).copy_(linear(self.H, 1, h["gain"]))
+                self.v(h["b"], 1).zero_()
+            else:
+                r = 0
+                for k in h["parts"]:
+                    self.v(h["W"] + r * self.H, k * self.H).copy_(linear(self.H, k, h["gain"]))
+                    r += k
+                self.v(h["b"], h["n"]).zero_()
+                if "logstd" in h:
+                    self.v(h["logstd"], h["n"]).zero_()
+
+
+class GenWorkspace:
+    """Activation / gradient buffers of one trunk pass over up to ``rows`` rows (allocated once, reused)."""
+
+    def __init__(self, net: GenNet, rows: int, training: bool) -> None:
+        dev, f = net.device, torch.float32
+        e = lambda *s: torch.empty(*s, dtype=f, device=dev)
+        self.rows = rows
+        W = net.max_width
+        self.z = e(rows, W)
+        self.x0 = e(rows, net.D)
+        self.fn = dict(xhat=e(rows, net.D), rstd=e(rows), y=e(rows, net.D)) if net.fn is not None else None
+        self.layers = []
+        for L in net.layers:
+            self.layers.append(dict(a=e(rows, L["n_out"]) if (training and L["act"] != ops_gen.ACT_NONE) else None,
+                                    xhat=e(rows, L["n_out"]) if training else None, rstd=e(rows) if training else None,
+                                    y=e(rows, L["n_out"])))
+        self.head_out = {k: e(rows, h["n"]) for k, h in net.heads.items()}
+        if training:
+            self.dhead = {k: e(rows, h["n"]) for k, h in net.heads.items()}
+            self.da, self.db2, self.dz, self.dfeat = e(rows, W), e(rows, W), e(rows, W), e(rows, W)
+            self.col_partials = e(ops_gen.MAX_BLOCKS * 3 * W)
+            self.colsum = e(3 * W)
+            self.wgrad_partials = e(max(4 * W * W, 1 << 22))
+            self.loss_partials = e(ops_gen.MAX_BLOCKS * 20)
+            self.loss_sums = {"act": e(20), "v_out": e(20)}
+
+    def v(self, t: torch.Tensor, rows: int, width: int) -> torch.Tensor:
+        return t.view(-1)[:rows * width].view(rows, width)
+
+
+def trunk_forward(net: GenNet, ws: GenWorkspace, x: torch.Tensor, save: bool) -> torch.Tensor:
+    """MLPBase.forward (+ the shared model's ``common`` layers): features [B, H]."""
+    B = x.shape[0]
+    if net.fn is not None:
+        f = ws.fn
+        y = ws.v(f["y"], B, net.D)
+        ops_gen.row_fwd(x, None, ops_gen.ACT_NONE, net.v(net.fn["g"], net.D), net.v(net.fn["be"], net.D), None,
+                        ws.v(f["xhat"], B, net.D) if save else None, f["rstd"][:B] if save else None, y)
+        x = y
+    for L, w in zip(net.layers, ws.layers):
+        n_in, n_out = L["n_in"], L["n_out"]
+        z = ws.v(ws.z, B, n_out)
+        ops_gen.linear_fwd(x, net.v(L["W"], n_out, n_in), z)
+        y = ws.v(w["y"], B, n_out)
+        ops_gen.row_fwd(z, net.v(L["b"], n_out), L["act"], net.v(L["g"], n_out), net.v(L["be"], n_out),
+                        ws.v(w["a"], B, n_out) if (save and w["a"] is not None) else None,
+                        ws.v(w["xhat"], B, n_out) if save else None, w["rstd"][:B] if save else None, y)
+        w["x_in"] = x
+        x = y
+    return x
+
+
+def head_forward(net: GenNet, ws: GenWorkspace, name: str, feats: torch.Tensor) -> torch.Tensor:
+    h = net.heads[name]
+    B, n = feats.shape[0], h["n"]
+    z = ws.v(ws.z, B, n)
+    ops_gen.linear_fwd(feats, net.v(h["W"], n, net.H), z)
+    out = ws.v(ws.head_out[name], B, n)
+    ops_gen.row_fwd(z, net.v(h["b"], n), ops_gen.ACT_NONE, None, None, None, None, None, out)
+    return out
+
+
+def _colsums(net: GenNet, ws: GenWorkspace, nb: int, width: int, targets) -> None:
+    """Column-sum the [nb][3*width] partial rows and copy the three blocks to their places in ``net.grad``."""
+    ops.ppo_reduce(ws.col_partials.data_ptr(), nb, 3 * width, ws.colsum.data_ptr(), net.device)
+    pairs = [(net.v(off, width, grad=True), ws.colsum[k * width:(k + 1) * width]) for k, off in enumerate(targets)
+             if off is not None]
+    ops.multi_copy(pairs)
+
+
+def head_backward(net: GenNet, ws: GenWorkspace, name: str, feats: torch.Tensor, dout: torch.Tensor,
+                  dfeat: torch.Tensor, accumulate: bool) -> None:
+    """nn.Linear backward of one head: dW, db into ``net.grad``; dfeat (+)= dout @ W."""
+    h = net.heads[name]
+    B, n, H = feats.shape[0], h["n"], net.H
+    ops_gen.linear_wgrad(dout, feats, net.v(h["W"], n, H, grad=True), ws.wgrad_partials)
+    nb = ops_gen.row_bwd(dout, None, None, None, None, ops_gen.ACT_NONE, None, ws.col_partials)
+    _colsums(net, ws, nb, n, [None, None, h["b"]])
+    if accumulate:
+        tmp = ws.v(ws.dz, B, H)
+        ops_gen.linear_dgrad(dout, net.v(h["W"], n, H), tmp)
+        ops_gen.vec_add(dfeat, tmp)
+    else:
+        ops_gen.linear_dgrad(dout, net.v(h["W"], n, H), dfeat)
+
+
+def trunk_backward(net: GenNet, ws: GenWorkspace, dfeat: torch.Tensor) -> None:
+    """Backward of ``trunk_forward``: every trunk parameter's gradient is WRITTEN into ``net.grad``."""
+    B = dfeat.shape[0]
+    dy = dfeat
+    bufs = [ws.da, ws.db2]
+    for k in range(len(net.layers) - 1, -1, -1):
+        L, w = net.layers[k], ws.layers[k]
+        n_in, n_out = L["n_in"], L["n_out"]
+        dz = ws.v(ws.dz, B, n_out)
+        nb = ops_gen.row_bwd(dy, net.v(L["g"], n_out), ws.v(w["xhat"], B, n_out), w["rstd"][:B],
+                             ws.v(w["a"], B, n_out) if w["a"] is not None else None, L["act"], dz, ws.col_partials)
+        _colsums(net, ws, nb, n_out, [L["g"], L["be"], L["b"]])
+        ops_gen.linear_wgrad(dz, w["x_in"], net.v(L["W"], n_out, n_in, grad=True), ws.wgrad_partials)
+        if k > 0 or net.fn is not None:
+            dx = ws.v(bufs[k & 1], B, n_in)
+            ops_gen.linear_dgrad(dz, net.v(L["W"], n_out, n_in), dx)
+            dy = dx
+    if net.fn is not None:
+        f = ws.fn
+        nb = ops_gen.row_bwd(dy, net.v(net.fn["g"], net.D), ws.v(f["xhat"], B, net.D), f["rstd"][:B], None,
+                             ops_gen.ACT_NONE, None, ws.col_partials)
+        _colsums(net, ws, nb, net.D, [net.fn["g"], net.fn["be"], None])
+
+
+class GenAdam(FusedAdam):
+    """Adam state of one general network; the step is ``orl_gen_adam`` (norm, clip, Adam in two launches)."""
+
+
+class GenericPPOModule(PPOModule):
+    """``PPOModule`` for everything outside the fused default tower (see the module docstring)."""
+
+    generic = True
+
+    def __init__(self, cfg, policy_input_space, critic_input_space, act_space, share_model: bool = False,
+                 device="cuda:0", rank=None, world_size=None, model_dict=None):
+        if model_dict:
+            raise NotImplementedError("custom model_dict networks are not built")
+        for flag in ("use_recurrent_policy", "use_naive_recurrent_policy", "use_influence_policy", "use_popart",
+                     "use_policy_vhead", "use_attn", "use_conv1d", "use_amp", "use_deepspeed", "use_joint_action_loss"):
+            if getattr(cfg, flag, False):
+                raise NotImplementedError("cfg.%s=True is not built for the general towers" % flag)
+        self.cfg = cfg
+        self.device = nat.require_gpu(device)
+        self.recurrent = False
+        self.lr, self.critic_lr = cfg.lr, cfg.critic_lr
+        self.opti_eps, self.weight_decay = cfg.opti_eps, cfg.weight_decay
+        self.act_space = act_space
+        self.rank, self.world_size = rank, world_size
+        self.share_model = bool(share_model or cfg.use_share_model)
+        self.policy_input_space, self.critic_input_space = policy_input_space, critic_input_space
+        self.Dp = spaces.obs_dim(spaces.policy_obs_space(policy_input_space))
+        self.Dc = spaces.obs_dim(spaces.critic_obs_space(critic_input_space))
+        if self.share_model:
+            if self.Dc != self.Dp:
+                raise NotImplementedError("use_share_model: critic observations go through the policy's obs_prep "
+                                          "(policy_value_network.py:75) and must have the same width")
+            model = GenNet("model", cfg, self.Dp, act_space, self.device)
+            model.host_init(cfg)
+            if cfg.use_valuenorm:
+                model.value_normalizer = ValueNorm(1, device=self.device)
+            self.models = {"model": model}
+            self.optimizers = {"model": GenAdam(model, cfg.lr, cfg.opti_eps, cfg.weight_decay)}
+            pol = model
+        else:
+            policy = GenNet("policy", cfg, self.Dp, act_space, self.device)
+            policy.host_init(cfg)  # RNG order: policy first, then critic (rl_module.py:65-87)
+            critic = GenNet("critic", cfg, self.Dc, act_space, self.device)
+            critic.host_init(cfg)
+            if cfg.use_valuenorm:
+                critic.value_normalizer = ValueNorm(1, device=self.device)
+            self.models = {"policy": policy, "critic": critic}
+            self.optimizers = {"policy": GenAdam(policy, cfg.lr, cfg.opti_eps, cfg.weight_decay),
+                               "critic": GenAdam(critic, cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)}
+            pol = policy
+        self.act_width = pol.act_width
+        self.act_kind = pol.act_kind
+        self.n_logits = pol.heads["act"]["n"]
+        self.K = self.n_logits if pol.act_kind == ops_gen.HEAD_CATEGORICAL else 0
+        self.act_seed = int(cfg.seed)
+        self.rng_step = 0
+        self.rng_step_dev = None
+        self._ws: Dict = {}
+
+    # ------------------------------------------------------------------ nets
+    @property
+    def policy_net(self) -> GenNet:
+        return self.models["model" if self.share_model else "policy"]
+
+    @property
+    def critic_net(self) -> GenNet:
+        return self.models["model" if self.share_model else "critic"]
+
+    def workspace(self, net: GenNet, rows: int, training: bool, tag: str = "") -> GenWorkspace:
+        key = (id(net), training, tag)
+        ws = self._ws.get(key)
+        if ws is None or ws.rows < rows:
+            ws = self._ws[key] = GenWorkspace(net, rows, training)
+        return ws
+
+    def _logstd(self):
+        h = self.policy_net.heads["act"]
+        return self.policy_net.v(h["logstd"], h["n"]) if "logstd" in h else None
+
+    # ------------------------------------------------------------------ rollout side
+    @torch.no_grad()
+    def _forward(self, critic_obs, obs, action_masks, deterministic, want_value=True, want_action=True, forced_u=None,
+                 out=None):
+        pn, cn = self.policy_net, self.critic_net
+        x = self._dev(obs, self.Dp) if want_action else None
+        xc = self._dev(critic_obs, self.Dc) if want_value else None
+        B = (x if x is not None else xc).shape[0]
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=self.device)
+        if out is None:
+            values = f(B, 1) if want_value else None
+            actions, logp = (f(B, self.act_width), f(B, self.act_width)) if want_action else (None, None)
+        else:
+            values, actions, logp = out
+        feats_p = None
+        if want_action:
+            ws = self.workspace(pn, B, False, "p")
+            feats_p = trunk_forward(pn, ws, x, False)
+            logits = head_forward(pn, ws, "act", feats_p)
+            am = self._dev(action_masks, self.n_logits) if (action_masks is not None and self.K) else None
+            ops_gen.sample(pn.head_desc, logits, self._logstd(), am, B, deterministic, self.act_seed, 0, self.rng_step,
+                           self.rng_step_dev, self._dev(forced_u, self.act_width), self.act_width, actions, logp)
+            if not deterministic:
+                self.rng_step += 1
+        if want_value:
+            if self.share_model and want_action and xc.data_ptr() == x.data_ptr():
+                ws, feats_c = self.workspace(pn, B, False, "p"), feats_p
+            else:
+                ws = self.workspace(cn, B, False, "c")
+                feats_c = trunk_forward(cn, ws, xc, False)
+            v = head_forward(cn, ws, "v_out", feats_c)
+            values.copy_(v)
+        return values, actions, logp
+
+    def get_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks=None,
+                    deterministic=False):
+        values, actions, logp = self._forward(critic_obs, obs, action_masks, deterministic)
+        return values, actions, logp, rnn_states_actor, rnn_states_critic
+
+    def get_values(self, critic_obs, rnn_states_critic, masks):
+        return self._forward(critic_obs, None, None, True, want_action=False)[0]
+
+    def act(self, obs, rnn_states_actor, masks, action_masks=None, deterministic=False):
+        _, actions, _ = self._forward(None, obs, action_masks, deterministic, want_value=False)
+        return actions, rnn_states_actor
+
+    @torch.no_grad()
+    def evaluate_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, action, masks, action_masks=None,
+                         active_masks=None, critic_masks_batch=None):
+        """Forward-only ``PPOModule.evaluate_actions`` (ppo_module.py:149-193): values, log-probs, dist_entropy."""
+        pn = self.policy_net
+        x = self._dev(obs, self.Dp)
+        B = x.shape[0]
+        values = self.get_values(critic_obs, None, None)
+        ws = self.workspace(pn, B, False, "p")
+        logits = head_forward(pn, ws, "act", trunk_forward(pn, ws, x, False))
+        a_w, K = self.act_width, self.K
+        R = ops.record_width(self.Dp, self.Dc, a_w, K)
+        rec = torch.zeros(B, R, dtype=torch.float32, device=self.device)
+        o_act = self.Dp + self.Dc
+        rec[:, o_act:o_act + a_w] = self._dev(action, a_w)
+        if K:
+            o_mk = o_act + 2 * a_w + 4
+            rec[:, o_mk:o_mk + K] = 1.0 if action_masks is None else self._dev(action_masks, K)
+        logp = torch.empty(B, a_w, dtype=torch.float32, device=self.device)
+        ent = torch.empty(B, dtype=torch.float32, device=self.device)
+        ops_gen.policy_eval(pn.head_desc, logits, self._logstd(), rec, self.Dp, self.Dc, a_w, K, B,
+                            ops.make_hparams(self.cfg), logp, ent)
+        if active_masks is not None:
+            am = self._dev(active_masks, 1).reshape(-1)
+            dist_entropy = (ent * am).sum() / am.sum()
+        else:
+            dist_entropy = ent.mean() / (self.n_logits if self.act_kind == ops_gen.HEAD_GAUSSIAN else 1)
+        return values, logp, dist_entropy, None
+
+    # ------------------------------------------------------------------ reference interface
+    def lr_decay(self, episode, episodes):
+        if self.share_model:
+            self.optimizers["model"].param_groups[0]["lr"] = self.lr - (self.lr * (episode / float(episodes)))
+        else:
+            super().lr_decay(episode, episodes)
+
+    def get_critic_value_normalizer(self):
+        return self.critic_net.value_normalizer

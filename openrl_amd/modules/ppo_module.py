@@ -217,6 +217,20 @@ def _host_init_tower(D: int, H: int, K: int, gaussian: bool, gain_head: float, u
 
 
 class PPOModule:
+    #: False = the fused default-tower kernels; True = the layer-wise general path (modules/generic_net.py)
+    generic = False
+
+    def __new__(cls, cfg, policy_input_space=None, critic_input_space=None, act_space=None, share_model: bool = False,
+                *args, **kwargs):
+        # Configurations outside the fused default tower (hidden_size / layer_N / activation / feature norm / shared
+        # model / MultiDiscrete) are served by GenericPPOModule behind the same constructor.
+        if cls is PPOModule and act_space is not None:
+            from .generic_net import GenericPPOModule, needs_generic
+
+            if needs_generic(cfg, act_space, share_model) and not cfg.use_recurrent_policy:
+                return object.__new__(GenericPPOModule)
+        return object.__new__(cls)
+
     def __init__(self, cfg, policy_input_space, critic_input_space, act_space, share_model: bool = False,
                  device: Union[str, torch.device] = "cuda:0", rank: Optional[int] = None,
                  world_size: Optional[int] = None, model_dict: Optional[Dict[str, Any]] = None):

@@ -1,0 +1,157 @@
+"""Tensor-level wrappers over the general tower path of the C ABI (``include/orl_hip.h``, csrc/orl_gen.hip).
+
+Same contract as ``ops.py``: shape/dtype checks, raw pointers, current stream; nothing is computed in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _native as nat
+from ._native import AdamState, HeadDesc, PPOHParams, fptr, ptr, stream_ptr
+
+ACT_NONE, ACT_TANH, ACT_RELU, ACT_LEAKY_RELU, ACT_ELU = (nat.ORL_ACT_NONE, nat.ORL_ACT_TANH, nat.ORL_ACT_RELU,
+                                                         nat.ORL_ACT_LEAKY_RELU, nat.ORL_ACT_ELU)
+HEAD_CATEGORICAL, HEAD_GAUSSIAN, HEAD_MULTI_DISCRETE = nat.ORL_HEAD_CATEGORICAL, nat.ORL_HEAD_GAUSSIAN, nat.ORL_HEAD_MULTI_DISCRETE
+MAX_BLOCKS = 1024  # rows of every per-workgroup partial buffer of this path
+
+
+def _lib():
+    return nat.load()
+
+
+def head_desc(kind: int, n_out: int, nvec: Optional[Sequence[int]] = None) -> HeadDesc:
+    h = HeadDesc()
+    h.kind, h.n_out, h.n_heads = int(kind), int(n_out), 1 if nvec is None else len(nvec)
+    for k, v in enumerate(nvec or []):
+        h.nvec[k] = int(v)
+    return h
+
+
+def gemm(A: torch.Tensor, sam: int, sak: int, B: torch.Tensor, sbk: int, sbn: int, Cmat: torch.Tensor, ldc: int, M: int,
+         N: int, K: int, n_split: int = 1, partials: Optional[torch.Tensor] = None) -> None:
+    """Cmat[m*ldc + n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] (fp32 MFMA); split-K through ``partials``."""
+    dev = nat.require_gpu(Cmat.device)
+    if n_split > 1:
+        assert partials is not None and partials.numel() >= n_split * M * N
+    rc = _lib().orl_gemm(fptr(A), sam, sak, fptr(B), sbk, sbn, fptr(Cmat), ldc, M, N, K, n_split, fptr(partials),
+                         stream_ptr(dev))
+    nat.check(rc, "orl_gemm")
+
+
+def linear_fwd(x: torch.Tensor, W: torch.Tensor, z: torch.Tensor) -> None:
+    """z[B, out] = x[B, in] @ W[out, in]^T (nn.Linear without the bias)."""
+    Bn, K = x.shape
+    N = W.shape[0]
+    gemm(x, K, 1, W, 1, K, z, N, Bn, N, K)
+
+
+def linear_dgrad(dz: torch.Tensor, W: torch.Tensor, dx: torch.Tensor) -> None:
+    """dx[B, in] = dz[B, out] @ W[out, in]."""
+    Bn, K = dz.shape
+    N = W.shape[1]
+    gemm(dz, K, 1, W, N, 1, dx, N, Bn, N, K)
+
+
+def linear_wgrad(dz: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, partials: torch.Tensor) -> None:
+    """dW[out, in] = dz[B, out]^T @ x[B, in]; the batch rows are the K dimension (deterministic split-K)."""
+    Bn, M = dz.shape
+    N = x.shape[1]
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    n_split = max(1, min(Bn // 512, max(1, 1024 // tiles), partials.numel() // (M * N)))
+    gemm(dz, 1, M, x, N, 1, dW, N, M, N, Bn, n_split, partials)
+
+
+def row_fwd(z, bias, act: int, gamma, beta, a_out, xhat_out, rstd_out, y_out) -> None:
+    dev = nat.require_gpu(z.device)
+    Bn, H = z.shape
+    rc = _lib().orl_row_fwd(fptr(z), fptr(bias), act, fptr(gamma), fptr(beta), Bn, H, fptr(a_out), fptr(xhat_out),
+                            fptr(rstd_out), fptr(y_out), stream_ptr(dev))
+    nat.check(rc, "orl_row_fwd")
+
+
+def row_bwd(dy, gamma, xhat, rstd, a, act: int, dz_out, col_partials) -> int:
+    """Returns the number of partial rows written to ``col_partials`` ([rows][3H])."""
+    dev = nat.require_gpu(dy.device)
+    Bn, H = dy.shape
+    nb = C.c_int(0)
+    max_blocks = min(MAX_BLOCKS, col_partials.numel() // (3 * H))
+    rc = _lib().orl_row_bwd(fptr(dy), fptr(gamma), fptr(xhat), fptr(rstd), fptr(a), act, Bn, H, fptr(dz_out),
+                            fptr(col_partials), max_blocks, C.byref(nb), stream_ptr(dev))
+    nat.check(rc, "orl_row_bwd")
+    return nb.value
+
+
+def gather_cols(records, col0: int, width: int, idx, mb: int, out) -> None:
+    dev = nat.require_gpu(records.device)
+    rc = _lib().orl_gather_cols(fptr(records), records.shape[1], col0, width, ptr(idx), mb, fptr(out), stream_ptr(dev))
+    nat.check(rc, "orl_gather_cols")
+
+
+def denoms(records, Dp: int, Dc: int, a_w: int, idx, mb: int, den) -> None:
+    dev = nat.require_gpu(records.device)
+    rc = _lib().orl_gen_denoms(fptr(records), records.shape[1], Dp, Dc, a_w, ptr(idx), mb, fptr(den), stream_ptr(dev))
+    nat.check(rc, "orl_gen_denoms")
+
+
+def policy_loss(head: HeadDesc, logits, logstd, records, Dp: int, Dc: int, a_w: int, K: int, idx, mb: int, den,
+                hp: PPOHParams, dlogits, partials) -> int:
+    dev = nat.require_gpu(records.device)
+    nb = C.c_int(0)
+    rc = _lib().orl_gen_policy_loss(C.byref(head), fptr(logits), fptr(logstd), fptr(records), records.shape[1], Dp, Dc,
+                                    a_w, K, ptr(idx), mb, fptr(den), C.byref(hp), fptr(dlogits), fptr(partials),
+                                    min(MAX_BLOCKS, partials.numel() // 20), C.byref(nb), None, None, stream_ptr(dev))
+    nat.check(rc, "orl_gen_policy_loss")
+    return nb.value
+
+
+def policy_eval(head: HeadDesc, logits, logstd, records, Dp: int, Dc: int, a_w: int, K: int, mb: int, hp: PPOHParams,
+                logp_out, ent_out) -> None:
+    """ACTLayer.evaluate_actions on dense rows (records in identity order): log-probs [mb, a_w], entropy [mb]."""
+    dev = nat.require_gpu(records.device)
+    rc = _lib().orl_gen_policy_loss(C.byref(head), fptr(logits), fptr(logstd), fptr(records), records.shape[1], Dp, Dc,
+                                    a_w, K, None, mb, None, C.byref(hp), None, None, 0, None, fptr(logp_out),
+                                    fptr(ent_out), stream_ptr(dev))
+    nat.check(rc, "orl_gen_policy_loss(eval)")
+
+
+def value_loss(values, records, Dp: int, Dc: int, a_w: int, K: int, idx, mb: int, vn_state, den, hp: PPOHParams, dvalues,
+               partials) -> int:
+    dev = nat.require_gpu(records.device)
+    nb = C.c_int(0)
+    rc = _lib().orl_gen_value_loss(fptr(values), fptr(records), records.shape[1], Dp, Dc, a_w, K, ptr(idx), mb,
+                                   fptr(vn_state), fptr(den), C.byref(hp), fptr(dvalues), fptr(partials),
+                                   min(MAX_BLOCKS, partials.numel()), C.byref(nb), stream_ptr(dev))
+    nat.check(rc, "orl_gen_value_loss")
+    return nb.value
+
+
+def sample(head: HeadDesc, logits, logstd, action_masks, Bn: int, deterministic: bool, seed: int, row0: int,
+           rng_step: int, rng_step_dev, forced_u, a_w: int, actions, logp) -> None:
+    dev = nat.require_gpu(logits.device)
+    rc = _lib().orl_gen_sample(C.byref(head), fptr(logits), fptr(logstd), fptr(action_masks), Bn,
+                               int(bool(deterministic)), seed & (2 ** 64 - 1), row0, rng_step, ptr(rng_step_dev),
+                               fptr(forced_u), a_w, fptr(actions), fptr(logp), stream_ptr(dev))
+    nat.check(rc, "orl_gen_sample")
+
+
+def adam(state: AdamState, n: int, max_grad_norm: float, use_max_grad_norm: bool, n_clips: int, scratch, info,
+         slot_first: int, slot_second: int, device) -> None:
+    rc = _lib().orl_gen_adam(C.byref(state), n, float(max_grad_norm), int(bool(use_max_grad_norm)), n_clips,
+                             fptr(scratch), fptr(info), slot_first, slot_second, stream_ptr(device))
+    nat.check(rc, "orl_gen_adam")
+
+
+def vec_add(dst: torch.Tensor, src: torch.Tensor) -> None:
+    assert dst.numel() == src.numel()
+    rc = _lib().orl_vec_add(fptr(dst), fptr(src), dst.numel(), stream_ptr(nat.require_gpu(dst.device)))
+    nat.check(rc, "orl_vec_add")
+
+
+def info(policy_sums, value_sums, den, hp: PPOHParams, entropy_div: float, ratio_div: float, info_accum) -> None:
+    dev = nat.require_gpu(info_accum.device)
+    rc = _lib().orl_gen_info(fptr(policy_sums), fptr(value_sums), fptr(den), C.byref(hp), float(entropy_div),
+                             float(ratio_div), fptr(info_accum), stream_ptr(dev))
+    nat.check(rc, "orl_gen_info")

@@ -41,6 +41,19 @@ class Discrete(Space):
         return "Discrete(%d)" % self.n
 
 
+class MultiDiscrete(Space):
+    """gymnasium.spaces.MultiDiscrete(nvec): the reference reads ``high - low + 1`` per component (act.py:28)."""
+
+    def __init__(self, nvec):
+        self.nvec = np.asarray(nvec, dtype=np.int64).reshape(-1)
+        super().__init__(self.nvec.shape, np.int64)
+        self.low = np.zeros_like(self.nvec)
+        self.high = self.nvec - 1
+
+    def __repr__(self):
+        return "MultiDiscrete(%s)" % self.nvec.tolist()
+
+
 class Dict(Space):  # noqa: A001 - the name is the contract
     def __init__(self, spaces=None, **kw):
         super().__init__(None, None)
@@ -90,4 +103,6 @@ def act_shape(space) -> int:
         return 1
     if k == "Box":
         return int(space.shape[0])
-    raise NotImplementedError("action space type %s not built in the MI355X engine (Discrete / Box only)" % k)
+    if k == "MultiDiscrete":  # one stored column per component (buffers/utils/util.py:80-81: space.shape)
+        return int(np.asarray(space.shape).reshape(-1)[0])
+    raise NotImplementedError("action space type %s not built in the MI355X engine (Discrete / Box / MultiDiscrete)" % k)

@@ -91,7 +91,7 @@ def gae_cases():
     print("gae.npz", len(out))
 
 
-def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, seed=0, a2c=False):
+def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, seed=0, a2c=False, share=False):
     """Fill a reference buffer with a hand-driven rollout of the reference module, then run
     PPOAlgorithm.train and record everything needed to replay it."""
     from gymnasium.spaces import Box
@@ -106,8 +106,11 @@ def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, s
     obs_space = Box(-np.inf, np.inf, (obs_dim,))
     set_seed(cfg.seed)
     module = PPOModule(cfg, policy_input_space=obs_space, critic_input_space=obs_space, act_space=act_space,
-                       share_model=False, rank=0, world_size=1)
-    out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"])}
+                       share_model=share, rank=0, world_size=1)
+    if share:  # PolicyValueNetwork: one network, one optimizer (ppo_module.py:58-69)
+        out = {"theta_m0": _flat(module.models["model"])}
+    else:
+        out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"])}
     buffer = NormalReplayBuffer(cfg, 1, obs_space, act_space, data_client=None)
     if a2c:
         from openrl.algorithms.a2c import A2CAlgorithm
@@ -171,8 +174,11 @@ def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, s
     out["train_info"] = np.array([float(info.get(k, 0.0)) for k in
                                   ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
                                    "ratio")], np.float64)
-    out["theta_p1"] = _flat(module.models["policy"])
-    out["theta_c1"] = _flat(module.models["critic"])
+    if share:
+        out["theta_m1"] = _flat(module.models["model"])
+    else:
+        out["theta_p1"] = _flat(module.models["policy"])
+        out["theta_c1"] = _flat(module.models["critic"])
     if vn is not None:
         out["vn_state1"] = np.array([vn.running_mean.item(), vn.running_mean_sq.item(), vn.debiasing_term.item()],
                                     np.float32)
@@ -187,13 +193,46 @@ def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, s
             pm = (rs.rand(16, K) > 0.3).astype(np.float32)
             pm[:, 0] = 1.0
             out["probe_masks"] = pm
-        v, a, lp, _, _ = module.get_actions(probe, probe, np.zeros((16, 1, 64), np.float32),
-                                            np.zeros((16, 1, 64), np.float32), np.ones((16, 1), np.float32),
+        Hh = cfg.hidden_size
+        v, a, lp, _, _ = module.get_actions(probe, probe, np.zeros((16, 1, Hh), np.float32),
+                                            np.zeros((16, 1, Hh), np.float32), np.ones((16, 1), np.float32),
                                             action_masks=pm, deterministic=True)
     out["probe_obs"], out["probe_values"] = probe, v.numpy()
     out["probe_actions"], out["probe_logp"] = a.numpy().astype(np.float32), lp.numpy()
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name + ".npz", {k: float(info[k]) for k in info})
+
+
+def actlayer_multidiscrete_case():
+    """ACTLayer with a MultiDiscrete space (act.py:26-34, 60-72, 136-151): per-component Categoricals over the same
+    features.  The reference's ReplayData cannot hold MultiDiscrete actions (np.zeros((T, N, A, act_space.shape)),
+    replay_data.py:161-168, raises TypeError), so parity for this head is pinned at the ACTLayer level: deterministic
+    actions, log-probs of given actions, the (detached) entropy, and the gradient of sum(log-probs) w.r.t. the
+    features and the head parameters."""
+    from gymnasium.spaces import MultiDiscrete
+    from openrl.modules.networks.utils.act import ACTLayer
+
+    torch.manual_seed(21)
+    nvec, H, B = [3, 2, 5], 64, 24
+    layer = ACTLayer(MultiDiscrete(nvec), H, True, 0.01)
+    rs = np.random.RandomState(21)
+    for lin in layer.action_outs:  # non-trivial weights (the constructor's gain 0.01 makes every head almost uniform)
+        lin.linear.weight.data.copy_(torch.tensor(0.4 * rs.randn(*lin.linear.weight.shape).astype(np.float32)))
+        lin.linear.bias.data.copy_(torch.tensor(0.1 * rs.randn(*lin.linear.bias.shape).astype(np.float32)))
+    x = torch.tensor(rs.randn(B, H).astype(np.float32), requires_grad=True)
+    actions = torch.tensor(np.stack([rs.randint(0, k, B) for k in nvec], 1).astype(np.int64))
+    active = torch.tensor((rs.rand(B, 1) > 0.2).astype(np.float32))
+    logp, ent = layer.evaluate_actions(x, actions, None, active)
+    logp.sum().backward()
+    det_a, det_lp = layer(x.detach(), None, True)
+    out = dict(nvec=np.array(nvec), x=x.detach().numpy(), actions=actions.numpy().astype(np.float32),
+               active=active.numpy(), logp=logp.detach().numpy(), entropy=np.array(float(ent)),
+               dx=x.grad.numpy(), det_actions=det_a.numpy().astype(np.float32), det_logp=det_lp.detach().numpy())
+    for i, lin in enumerate(layer.action_outs):
+        out["W%d" % i], out["b%d" % i] = lin.linear.weight.detach().numpy(), lin.linear.bias.detach().numpy()
+        out["dW%d" % i], out["db%d" % i] = lin.linear.weight.grad.numpy(), lin.linear.bias.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "actlayer_multidiscrete.npz"), **out)
+    print("actlayer_multidiscrete.npz", float(ent))
 
 
 def _train_case_full(name, argv, N, T, D, n_act, seed=0):
@@ -426,6 +465,8 @@ def main():
         perm_case()
     if want("mpe_spread"):
         mpe_case()
+    if want("actlayer_multidiscrete"):
+        actlayer_multidiscrete_case()
     cases = {
         "train_discrete": lambda n: _train_case(n, ["--ppo_epoch", "3", "--num_mini_batch", "2"], 4, lambda: Discrete(2)),
         "train_discrete_masks": lambda n: _train_case(
@@ -441,6 +482,23 @@ def main():
         # A2CAlgorithm (algorithms/a2c.py): policy-gradient loss, one minibatch per epoch
         "train_a2c": lambda n: _train_case(n, ["--ppo_epoch", "3", "--num_mini_batch", "4"], 4, lambda: Discrete(3),
                                            seed=7, a2c=True),
+        # general towers (MLPBase / MLPLayer beyond the default: mlp.py:8-46,100-180) and the shared PolicyValueNetwork
+        "train_gen_h128_l2_tanh_fn": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--hidden_size", "128", "--layer_N", "2", "--activation_id",
+                "0", "--use_feature_normalization", "true"], 6, lambda: Discrete(3), seed=11),
+        "train_gen_elu_box": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--hidden_size", "32", "--activation_id", "3"], 5,
+            lambda: Box(-1, 1, (2,)), seed=12),
+        "train_gen_leaky_l3": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--layer_N", "3", "--activation_id", "2",
+                "--use_adv_normalize", "true"], 4, lambda: Discrete(2), use_masks=True, seed=13),
+        "train_share": lambda n: _train_case(
+            n, ["--ppo_epoch", "3", "--num_mini_batch", "2", "--use_share_model", "true"], 5, lambda: Discrete(4),
+            seed=14, share=True),
+        "train_share_box_fn": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_share_model", "true",
+                "--use_feature_normalization", "true", "--hidden_size", "48", "--layer_N", "2"], 7,
+            lambda: Box(-1, 1, (3,)), seed=15, share=True),
         # recurrent (GRU) branch: T=7 is odd, so chunks of 2 straddle lanes like cfg4's T=25
         "train_recurrent": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 18, 54,

@@ -1,0 +1,187 @@
+"""General towers (modules/generic_net.py + csrc/orl_gen.hip) against the REAL reference: hidden_size / layer_N /
+activation_id / use_feature_normalization outside the fused default tower, the shared PolicyValueNetwork, and the
+MultiDiscrete ACTLayer.  Golden vectors: oracle/gen_golden.py (reference mlp.py:8-46,100-180,
+policy_value_network.py:34-230, act.py:14-172, algorithms/ppo.py:46-176).  Needs a MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GEN_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_share", "train_share_box_fn"]
+# fp32 tolerances of the update path (MFMA k-order, tile-wise gradient sums); same as tests/test_ppo_update_gpu.py
+THETA_RTOL, THETA_ATOL = 2e-3, 3e-5
+INFO_RTOL, INFO_ATOL = 3e-4, 3e-5
+
+
+def build(g, load_theta0=True):
+    from openrl_amd import spaces
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers.replay_data import ReplayData
+    from openrl_amd.modules.ppo_module import PPOModule
+    from openrl_amd.utils.util import set_seed
+
+    cfg = H.case_cfg(g)
+    cfg.seed = int(g["perm_seed"]) - 1234  # gen_golden._train_case: cfg.seed = seed, perm_seed = 1234 + seed
+    T, N, D = g["buf_policy_obs"].shape[0] - 1, g["buf_policy_obs"].shape[1], g["buf_policy_obs"].shape[-1]
+    cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = T, N, 1, cfg.hidden_size
+    obs_space = spaces.Box(-np.inf, np.inf, (D,))
+    if "buf_action_masks" in g:
+        act_space = spaces.Discrete(g["buf_action_masks"].shape[-1])
+    else:
+        act_space = spaces.Box(-1, 1, (g["buf_actions"].shape[-1],))
+    set_seed(cfg.seed)
+    module = PPOModule(cfg, obs_space, obs_space, act_space, share_model=cfg.use_share_model, device=DEV, rank=0,
+                       world_size=1)
+    assert module.generic, "these configurations must take the general path"
+    return cfg, module, obs_space, act_space, ReplayData, PPOAlgorithm
+
+
+def nets(module, g):
+    if "theta_m0" in g:
+        return [("model", "theta_m0", "theta_m1")]
+    return [("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")]
+
+
+@pytest.mark.parametrize("case", GEN_CASES)
+def test_initial_weights_reproduce_the_reference(case):
+    """Same seed -> same generator consumption as PolicyNetwork / ValueNetwork / PolicyValueNetwork construction
+    (feature norm, fc1, fc_h + its clones, fc3, common, v_out, act heads), including the never-used fc_h block.
+    Bit-exact on the host that generated the goldens (tests/test_generic_cpu.py); another host's LAPACK QR inside
+    orthogonal_ differs in the last bits, hence the 1e-5 here."""
+    g = H.load_golden(case)
+    cfg, module, *_ = build(g)
+    for name, k0, _ in nets(module, g):
+        got = module.models[name].reference_flat().cpu().numpy()
+        assert got.shape == g[k0].shape
+        np.testing.assert_allclose(got, g[k0], rtol=0, atol=1e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("case", GEN_CASES)
+def test_train_matches_reference_golden(case):
+    g = H.load_golden(case)
+    cfg, module, obs_space, act_space, ReplayData, PPOAlgorithm = build(g)
+    for name, k0, _ in nets(module, g):
+        module.models[name].load_reference_flat(g[k0])
+    buf = ReplayData(cfg, 1, obs_space, act_space, device=DEV)
+    for f in ("policy_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks", "bad_masks",
+              "active_masks", "action_masks"):
+        if "buf_" + f in g:
+            getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+    algo = PPOAlgorithm(cfg, module, agent_num=1, device=DEV)
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    info = algo.train(buf)
+    got = np.array([info[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
+                                      "critic_grad_norm", "ratio")])
+    np.testing.assert_allclose(got, g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
+    for name, _, k1 in nets(module, g):
+        np.testing.assert_allclose(module.models[name].reference_flat().cpu().numpy(), g[k1], rtol=THETA_RTOL,
+                                   atol=THETA_ATOL, err_msg=name)
+    if "vn_state1" in g:
+        np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"],
+                                   rtol=1e-5)
+    # deterministic probe on the trained weights: values, greedy / mean actions, their log-probs
+    module2 = module
+    for name, _, k1 in nets(module, g):
+        module2.models[name].load_reference_flat(g[k1])
+    pm = g["probe_masks"] if "probe_masks" in g else None
+    v, a, lp, _, _ = module2.get_actions(g["probe_obs"], g["probe_obs"], None, None, None, action_masks=pm,
+                                         deterministic=True)
+    np.testing.assert_allclose(v.cpu().numpy(), g["probe_values"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(a.cpu().numpy(), g["probe_actions"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(lp.cpu().numpy(), g["probe_logp"], rtol=2e-4, atol=2e-5)
+
+
+def test_dead_fc_h_block_never_moves():
+    """MLPLayer registers fc_h next to its clones fc2 and never runs it (mlp.py:28-34,41-46): no gradient, no Adam
+    step - its parameters stay at their initial values through an update, as in the reference golden."""
+    g = H.load_golden("train_gen_leaky_l3")
+    cfg, module, *_ = build(g)
+    net = module.models["policy"]
+    keys = [k for k, _, _ in net.entries if ".fc_h." in k]
+    assert keys, "layer_N = 3 must register an fc_h block"
+    flat0, flat1 = g["theta_p0"], g["theta_p1"]
+    o = 0
+    for k, t in net.named_parameters():
+        n = t.numel()
+        if ".fc_h." in k:
+            assert np.array_equal(flat0[o:o + n], flat1[o:o + n]), k  # the reference itself never moves it
+        o += n
+
+
+def test_multidiscrete_actlayer_vs_reference():
+    """ACTLayer with MultiDiscrete([3, 2, 5]) (act.py:26-34,60-72,136-151): log-probs of given actions, the detached
+    mean entropy, greedy actions, and the gradient of sum(log-probs) through the head."""
+    from openrl_amd import ops, ops_gen, spaces
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.modules import generic_net as gn
+
+    g = H.load_golden("actlayer_multidiscrete")
+    nvec = [int(k) for k in g["nvec"]]
+    cfg = default_cfg([])
+    net = gn.GenNet("policy", cfg, 4, spaces.MultiDiscrete(nvec), DEV)
+    sd = {"act.action_outs.%d.linear.weight" % i: g["W%d" % i] for i in range(len(nvec))}
+    sd.update({"act.action_outs.%d.linear.bias" % i: g["b%d" % i] for i in range(len(nvec))})
+    for k, t in net.named_parameters():
+        if k in sd:
+            t.copy_(torch.tensor(sd[k]).reshape(t.shape))
+    B = g["x"].shape[0]
+    feats = torch.tensor(g["x"], device=DEV)
+    ws = gn.GenWorkspace(net, B, True)
+    logits = gn.head_forward(net, ws, "act", feats)
+    a_w, n_tot = len(nvec), sum(nvec)
+    R = ops.record_width(4, 4, a_w, 0)
+    rec = torch.zeros(B, R, device=DEV)
+    rec[:, 8:8 + a_w] = torch.tensor(g["actions"], device=DEV)
+    rec[:, 8 + 2 * a_w + 3] = torch.tensor(g["active"][:, 0], device=DEV)
+    logp, ent = torch.empty(B, a_w, device=DEV), torch.empty(B, device=DEV)
+    hp = ops.make_hparams(cfg)
+    ops_gen.policy_eval(net.head_desc, logits, None, rec, 4, 4, a_w, 0, B, hp, logp, ent)
+    np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-6)
+    act = torch.tensor(g["active"][:, 0], device=DEV)
+    np.testing.assert_allclose(float((ent * act).sum() / act.sum()), float(g["entropy"]), rtol=1e-5)
+    # greedy actions + their log-probs
+    a = torch.empty(B, a_w, device=DEV)
+    lp = torch.empty(B, a_w, device=DEV)
+    ops_gen.sample(net.head_desc, logits, None, None, B, True, 0, 0, 0, None, None, a_w, a, lp)
+    assert np.array_equal(a.cpu().numpy(), g["det_actions"])
+    np.testing.assert_allclose(lp.cpu().numpy(), g["det_logp"], rtol=1e-5, atol=1e-6)
+    # gradient of sum(logp) w.r.t. features and head parameters: d logp_h / d logits = onehot - softmax
+    dl = torch.zeros(B, n_tot, device=DEV)
+    off = 0
+    for h, k in enumerate(nvec):
+        p = torch.softmax(logits[:, off:off + k], -1)
+        dl[:, off:off + k] = -p
+        dl[torch.arange(B), off + torch.tensor(g["actions"][:, h], device=DEV).long()] += 1.0
+        off += k
+    dfeat = torch.empty(B, net.H, device=DEV)
+    net.grad.zero_()
+    gn.head_backward(net, ws, "act", feats, dl.contiguous(), dfeat, False)
+    np.testing.assert_allclose(dfeat.cpu().numpy(), g["dx"], rtol=1e-4, atol=1e-6)
+    grads = {k: net.v(o, *s, grad=True).cpu().numpy() for k, s, o in net.entries}
+    for i in range(len(nvec)):
+        np.testing.assert_allclose(grads["act.action_outs.%d.linear.weight" % i], g["dW%d" % i], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(grads["act.action_outs.%d.linear.bias" % i], g["db%d" % i], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(70, 33, 50, 1), (64, 64, 16, 1), (5, 130, 1000, 4), (128, 6, 4096, 8),
+                                           (1000, 48, 48, 1)])
+def test_gemm_against_torch_fp32(M, N, K, split):
+    """orl_gemm (fp32 MFMA, arbitrary strides, split-K) vs a plain torch fp32 reference of the same product."""
+    from openrl_amd import ops_gen
+
+    rs = np.random.RandomState(M + N + K)
+    A, Bm = rs.randn(M, K).astype(np.float32), rs.randn(K, N).astype(np.float32)
+    want = torch.tensor(A, dtype=torch.float64) @ torch.tensor(Bm, dtype=torch.float64)
+    a, b = torch.tensor(A, device=DEV), torch.tensor(Bm, device=DEV)
+    part = torch.empty(split * M * N, device=DEV)
+    for at in (False, True):        # A stored [M,K] or transposed [K,M]
+        for bt in (False, True):    # B stored [K,N] or transposed [N,K]
+            aa = a.t().contiguous() if at else a
+            bb = b.t().contiguous() if bt else b
+            c = torch.zeros(M, N, device=DEV)
+            ops_gen.gemm(aa, 1 if at else K, M if at else 1, bb, 1 if bt else N, K if bt else 1, c, N, M, N, K, split, part)
+            np.testing.assert_allclose(c.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-4 * np.sqrt(K))
