@@ -169,10 +169,16 @@ class GenNet:
             sd["value_normalizer.running_mean"] = self.value_normalizer.state[0:1]
             sd["value_normalizer.running_mean_sq"] = self.value_normalizer.state[1:2]
             sd["value_normalizer.debiasing_term"] = self.value_normalizer.state[2]
-        for k, t in self.named_parameters():
-            sd[k] = t
-            if k.startswith("obs_prep."):  # the same module object under a second name (policy_value_network.py:75)
+        named = self.named_parameters()
+        for k, t in named:
+            if k.startswith("obs_prep."):
+                sd[k] = t
+        for k, t in named:  # the same module object registered under a second name (policy_value_network.py:75)
+            if k.startswith("obs_prep."):
                 sd["critic_" + k] = t
+        for k, t in named:
+            if not k.startswith("obs_prep."):
+                sd[k] = t
         return sd
 
     def load_state_dict(self, sd):

@@ -222,6 +222,34 @@ class StopTrainingOnRewardThreshold(BaseCallback):
         return bool(self.parent.best_mean_reward < self.reward_threshold)
 
 
+class StopTrainingOnNoModelImprovement(BaseCallback):
+    """Child of ``EvalCallback`` (``callbacks_after_eval``): stop when ``max_no_improvement_evals`` consecutive
+    evaluations brought no new best mean reward, counting only after ``min_evals`` evaluations
+    (stop_callback.py:107-154)."""
+
+    def __init__(self, max_no_improvement_evals: int, min_evals: int = 0, verbose: int = 1):
+        super().__init__(verbose)
+        self.max_no_improvement_evals, self.min_evals = int(max_no_improvement_evals), int(min_evals)
+        self.last_best_mean_reward = -float("inf")
+        self.no_improvement_evals = 0
+
+    def _on_step(self) -> bool:
+        assert self.parent is not None, "StopTrainingOnNoModelImprovement must be used with an EvalCallback"
+        continue_training = True
+        if self.n_calls > self.min_evals:
+            if self.parent.best_mean_reward > self.last_best_mean_reward:
+                self.no_improvement_evals = 0
+            else:
+                self.no_improvement_evals += 1
+                if self.no_improvement_evals > self.max_no_improvement_evals:
+                    continue_training = False
+        self.last_best_mean_reward = self.parent.best_mean_reward
+        if self.verbose >= 1 and not continue_training:
+            print("Stopping training because there was no new best model in the last %d evaluations"
+                  % self.no_improvement_evals)
+        return continue_training
+
+
 class EvalCallback(BaseCallback):
     """Every ``eval_freq`` calls, play ``n_eval_episodes`` episodes per env of a separate DEVICE-RESIDENT evaluation env
     with the current policy (greedy by default), track the best mean episode return, save the best model and run the
@@ -313,13 +341,14 @@ class EvalCallback(BaseCallback):
 
 CALLBACKS = {"CheckpointCallback": CheckpointCallback, "EvalCallback": EvalCallback,
              "StopTrainingOnRewardThreshold": StopTrainingOnRewardThreshold, "StopTrainingOnMaxEpisodes": StopTrainingOnMaxEpisodes,
+             "StopTrainingOnNoModelImprovement": StopTrainingOnNoModelImprovement,
              "ProgressBarCallback": ProgressBarCallback, "EveryNTimesteps": EveryNTimesteps,
              "SelfPlayCallback": SelfPlayCallback}
 
 
 class CallbackFactory:
     """``cfg.callbacks`` entries ``{"id": ..., "args": {...}}`` -> callback objects (callbacks_factory.py:14-60).
-    StopTrainingOnNoModelImprovement / SelfplayAPI are not built."""
+    The SelfplayAPI callbacks (they talk to the reference's self-play HTTP service) are not built."""
 
     @staticmethod
     def get_callback(spec: Dict[str, Any]) -> BaseCallback:

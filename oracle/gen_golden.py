@@ -235,6 +235,49 @@ def actlayer_multidiscrete_case():
     print("actlayer_multidiscrete.npz", float(ent))
 
 
+def state_dict_case():
+    """``state_dict()`` of the reference's own PolicyNetwork / ValueNetwork / PolicyValueNetwork (the content of the
+    checkpoints ``RLAgent.save`` pickles, rl_agent.py:187-213, rl_module.py:155-192) for three configurations, plus a
+    deterministic probe through ``PPOModule.get_actions`` - the engine must load these dicts by key and reproduce
+    the probe."""
+    from gymnasium.spaces import Box, Discrete
+    from openrl.modules.ppo_module import PPOModule
+    from openrl.utils.util import set_seed
+
+    out = {}
+    confs = {"default": ([], 4, Discrete(2), False),
+             "general": (["--hidden_size", "32", "--layer_N", "2", "--activation_id", "0",
+                          "--use_feature_normalization", "true"], 6, Box(-1, 1, (3,)), False),
+             "shared": (["--use_share_model", "true"], 5, Discrete(3), True)}
+    rs = np.random.RandomState(77)
+    for tag, (argv, D, act, share) in confs.items():
+        cfg = _cfg(argv, 4, 8)
+        cfg.seed = 77
+        set_seed(cfg.seed)
+        obs_space = Box(-np.inf, np.inf, (D,))
+        module = PPOModule(cfg, policy_input_space=obs_space, critic_input_space=obs_space, act_space=act,
+                           share_model=share, rank=0, world_size=1)
+        for name, model in module.models.items():
+            # move every tensor off its initial value so that a key mix-up cannot go unnoticed
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.add_(torch.tensor(np.abs(np.asarray(0.05 * rs.randn(*p_.shape), np.float32)) if p_.dim() == 0
+                                         else np.asarray(0.05 * rs.randn(*p_.shape), np.float32)))
+            for k, v in model.state_dict().items():
+                out["%s/%s/%s" % (tag, name, k)] = v.detach().numpy().copy()
+        probe = rs.randn(12, D).astype(np.float32)
+        H_ = cfg.hidden_size
+        with torch.no_grad():
+            v, a, lp, _, _ = module.get_actions(probe, probe, np.zeros((12, 1, H_), np.float32),
+                                                np.zeros((12, 1, H_), np.float32), np.ones((12, 1), np.float32),
+                                                deterministic=True)
+        out[tag + "/argv"] = np.array(" ".join(argv))
+        out[tag + "/probe_obs"], out[tag + "/probe_values"] = probe, v.numpy()
+        out[tag + "/probe_actions"], out[tag + "/probe_logp"] = a.numpy().astype(np.float32), lp.numpy()
+    np.savez_compressed(os.path.join(OUT, "state_dicts.npz"), **out)
+    print("state_dicts.npz", len(out))
+
+
 def _train_case_full(name, argv, N, T, D, n_act, seed=0):
     """A full-size update (BASELINE.json configs[1]: 4096 envs x 128 steps, obs 4, Discrete(2), ppo_epoch 10, one
     minibatch): the buffer comes from ``oracle.fixtures.synth_update_buffer`` (regenerated from the seed by the
@@ -465,6 +508,8 @@ def main():
         perm_case()
     if want("mpe_spread"):
         mpe_case()
+    if want("state_dicts"):
+        state_dict_case()
     if want("actlayer_multidiscrete"):
         actlayer_multidiscrete_case()
     cases = {

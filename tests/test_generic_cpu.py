@@ -67,3 +67,48 @@ def test_dispatch_rule_and_state_dict_keys():
     for _, shape, off in net.entries:
         cover[off:off + int(np.prod(shape))] += 1
     assert (cover == 1).all()
+
+
+@pytest.mark.parametrize("tag", ["default", "general", "shared"])
+def test_state_dict_keys_and_shapes_equal_the_reference_networks(tag):
+    """Keys (in order) and shapes of ``state_dict()`` against state dicts SAVED BY THE REFERENCE's own PolicyNetwork /
+    ValueNetwork / PolicyValueNetwork (tests/golden/state_dicts.npz, oracle/gen_golden.py::state_dict_case), and a
+    load -> state_dict round trip of those tensors."""
+    from openrl_amd.modules import ppo_module as pm
+    from openrl_amd import ops
+
+    g = H.load_golden("state_dicts")
+    cfg = H.case_cfg({"argv": g[tag + "/argv"]})
+    D = g[tag + "/probe_obs"].shape[1]
+    names = sorted({k.split("/")[1] for k in g if k.startswith(tag + "/") and k.count("/") == 2})
+    for name in names:
+        ref = OrderedDictFrom(g, tag + "/" + name + "/")
+        if tag == "default":
+            K, head = (2, ops.HEAD_CATEGORICAL) if name == "policy" else (1, ops.HEAD_VALUE)
+            net = pm.Tower(name, D, K, head, 64, "cpu", torch.zeros(4866 if name == "policy" else 4801))
+        else:
+            act = spaces.Box(-1, 1, (3,)) if tag == "general" else spaces.Discrete(3)
+            net = gn.GenNet(name, cfg, D, act, "cpu")
+        if cfg.use_valuenorm and name in ("critic", "model"):
+            net.value_normalizer = _HostValueNorm()
+        ours = net.state_dict()
+        assert list(ours.keys()) == list(ref.keys()), (name, list(ours.keys()), list(ref.keys()))
+        for k in ref:
+            assert tuple(ours[k].shape) == tuple(ref[k].shape), (k, ours[k].shape, ref[k].shape)
+        net.load_state_dict({k: torch.tensor(v) for k, v in ref.items()})
+        for k, v in net.state_dict().items():
+            assert np.array_equal(np.asarray(v), ref[k]), k
+
+
+def OrderedDictFrom(g, prefix):
+    from collections import OrderedDict
+
+    return OrderedDict((k[len(prefix):], g[k]) for k in g.files if k.startswith(prefix)) if hasattr(g, "files") else \
+        OrderedDict((k[len(prefix):], v) for k, v in g.items() if k.startswith(prefix))
+
+
+class _HostValueNorm:
+    """state holder with the device ValueNorm's interface (a CPU stand-in for the key / shape checks)."""
+
+    def __init__(self):
+        self.state = torch.zeros(3)

@@ -278,3 +278,36 @@ def test_general_towers_train_cartpole_end_to_end_and_checkpoint(argv, tmp_path)
     ep = [v for k, v in stats.items() if "episode" in k.lower() and "len" in k.lower()]
     if ep:
         assert float(np.mean(ep)) > 60, stats
+
+
+@pytest.mark.parametrize("tag", ["default", "general", "shared"])
+def test_loading_a_state_dict_saved_by_the_reference_reproduces_its_outputs(tag):
+    """Checkpoint compatibility in the direction that matters for a drop-in: ``state_dict()`` tensors produced by the
+    REFERENCE's networks (tests/golden/state_dicts.npz) are loaded by key into the engine's networks (fused default
+    tower, general tower, shared model) and the deterministic ``get_actions`` probe must come out as the reference's."""
+    from collections import OrderedDict
+
+    from openrl_amd import spaces
+    from openrl_amd.modules.ppo_module import PPOModule
+
+    g = H.load_golden("state_dicts")
+    cfg = H.case_cfg({"argv": g[tag + "/argv"]})
+    D = g[tag + "/probe_obs"].shape[1]
+    cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = 4, 1, cfg.hidden_size
+    act = {"default": spaces.Discrete(2), "general": spaces.Box(-1, 1, (3,)), "shared": spaces.Discrete(3)}[tag]
+    obs_space = spaces.Box(-np.inf, np.inf, (D,))
+    module = PPOModule(cfg, obs_space, obs_space, act, share_model=cfg.use_share_model, device=DEV, rank=0, world_size=1)
+    assert module.generic == (tag != "default")
+    for name, model in module.models.items():
+        pre = "%s/%s/" % (tag, name)
+        model.load_state_dict(OrderedDict((k[len(pre):], torch.tensor(v)) for k, v in g.items() if k.startswith(pre)))
+    obs = g[tag + "/probe_obs"]
+    v, a, lp, _, _ = module.get_actions(obs, obs, None, None, None, deterministic=True)
+    np.testing.assert_allclose(v.cpu().numpy(), g[tag + "/probe_values"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(a.cpu().numpy(), g[tag + "/probe_actions"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(lp.cpu().numpy(), g[tag + "/probe_logp"], rtol=2e-4, atol=2e-5)
+    vn = module.get_critic_value_normalizer()
+    cname = "model" if tag == "shared" else "critic"
+    np.testing.assert_allclose(vn.state.cpu().numpy(),
+                               [float(g["%s/%s/value_normalizer.%s" % (tag, cname, k)].reshape(-1)[0])
+                                for k in ("running_mean", "running_mean_sq", "debiasing_term")], rtol=1e-6)

@@ -159,3 +159,53 @@ def test_foreign_callback_objects_are_used_as_they_are():
     got.on_rollout_start()
     got.update_locals({"obs": 1})
     assert got.on_step() is True and got.n_calls == 1 and got.locals["obs"] == 1 and got.started == 1
+
+
+def test_stop_training_on_no_model_improvement_counts_like_the_reference():
+    """stop_callback.py:107-154: improvements reset the counter, the (max+1)-th stale evaluation stops training,
+    evaluations up to ``min_evals`` are not counted."""
+    from openrl_amd.utils import callbacks as cb
+
+    class _Parent:
+        best_mean_reward = -float("inf")
+
+    c = cb.CallbackFactory.get_callback({"id": "StopTrainingOnNoModelImprovement",
+                                         "args": {"max_no_improvement_evals": 2, "min_evals": 1, "verbose": 0}})
+    c.parent = _Parent()
+    c.init_callback(type("A", (), {"num_time_steps": 0})())
+    seq = [1.0, 1.0, 2.0, 2.0, 2.0, 2.0]   # best_mean_reward after each evaluation
+    out = []
+    for r in seq:
+        c.parent.best_mean_reward = r
+        out.append(c.on_step())
+    # call 1 (<= min_evals) not counted; call 2 stale (1); call 3 improves; calls 4, 5 stale (1, 2); call 6 stale (3) -> stop
+    assert out == [True, True, True, True, True, False]
+
+
+def test_logger_run_dirs_and_file_scalar_backend(tmp_path):
+    """logger.py:64-151,185-207: <log_path>/<project>/<scenario>/<exp>/run<k>, log.txt, and every log_info key reaching
+    the scalar back-end (tensorboardX when importable, else the scalars.jsonl / scalars.csv writer)."""
+    import json
+
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.utils.logger import Logger
+
+    cfg = default_cfg([])
+    for k in (1, 2):
+        lg = Logger(cfg, project_name="proj", scenario_name="scen", exp_name="exp", log_path=str(tmp_path),
+                    use_tensorboard=True)
+        assert lg.run_dir == tmp_path / "proj" / "scen" / "exp" / ("run%d" % k)
+        lg.log_info({"value_loss": torch.tensor(0.5), "FPS": 123, "rewards": [1.0, 3.0]}, step=64 * k)
+        lg.log_learner_info(0, {"lr": 5e-4}, step=64 * k)
+        lg.info("hello")
+        lg.close()
+        assert (lg.run_dir / "log.txt").exists() and "value_loss: 0.5" in (lg.run_dir / "log.txt").read_text()
+        assert lg.history[-1] == (64 * k, {"value_loss": 0.5, "FPS": 123.0, "rewards": 2.0})
+        jl = lg.run_dir / "logs" / "scalars.jsonl"
+        if jl.exists():  # tensorboardX absent: the file back-end
+            rows = [json.loads(l) for l in jl.read_text().splitlines()]
+            assert {r["key"] for r in rows} == {"value_loss", "FPS", "rewards", "Learner_0/lr"}
+            assert all(r["step"] == 64 * k for r in rows)
+    quiet = Logger(cfg)  # no log_path: nothing on disk, history only
+    quiet.log_info({"a": 1}, 1)
+    assert quiet.run_dir is None and quiet.history == [(1, {"a": 1.0})]
