@@ -214,6 +214,21 @@ int orl_act_step_grouped(const orl_net_desc* pnet, const float* pthetas, int64_t
                          uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev, float* actions, float* logp,
                          void* stream);
 
+/* orl_act_step (policy only) for a pool of K policies with a PER-ROW assignment: row i is evaluated with the
+ * parameters pthetas + opp_index[i]*theta_stride.  A 16-row tile runs the tower once per distinct index it contains
+ * (exact for any assignment; K x the work in the worst case) - the opponents of the self-play env when every env
+ * draws its opponent at reset (openrl/selfplay/wrappers/opponent_pool_wrapper.py:37-66). */
+int orl_act_step_pool(const orl_net_desc* pnet, const float* pthetas, int64_t theta_stride, int n_policies,
+                      const int32_t* opp_index, const float* policy_obs, const float* action_masks, int B,
+                      int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
+                      float* actions, float* logp, void* stream);
+/* Opponent sampling of the self-play pool (openrl/selfplay/sample_strategy/{random,last}_opponent.py): for every env n
+ * with dones[n] != 0 (dones == NULL: every env) opp_index[n] <- strategy 0: uniform over [0, n_filled) from Philox
+ * keyed (seed, n, draw_id); strategy 1: last_slot (the newest snapshot).  per_tile != 0: one draw per 16-env tile,
+ * written to all of its envs (what the fused rollout kernel can consume). */
+int orl_opponent_sample(int32_t* opp_index, const uint8_t* dones, int N, int n_filled, int last_slot, int strategy,
+                        int per_tile, uint64_t seed, uint64_t draw_id, const uint64_t* draw_id_dev, void* stream);
+
 /* `rng_step_dev` (orl_act_step / orl_act_step_grouped / orl_rnn_act_step; may be NULL): optional DEVICE-side addend
  * of `rng_step`: rng_step_effective = rng_step + *rng_step_dev, read by the kernel at run time.  It exists so that a
  * stepwise rollout can be captured ONCE into a hipGraph (kernel arguments are frozen at capture) and replayed every
@@ -376,6 +391,8 @@ typedef struct orl_rollout_args {
   int32_t opp_reserved;
   uint64_t opp_seed;       /* Philox seed of the opponents' sampling; counter = (env, opp_rng_step0 + t) */
   uint64_t opp_rng_step0;
+  const int32_t* opp_index; /* optional [N]: env n plays pool policy opp_index[n] instead of n / opp_group_rows; the
+                             * fused kernel needs it uniform over each 16-env tile (orl_opponent_sample, per_tile) */
 } orl_rollout_args;
 
 int orl_env_state_width(int env_kind);

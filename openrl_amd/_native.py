@@ -77,7 +77,7 @@ class RolloutArgs(C.Structure):
                 ("env_kind", C.c_int32), ("episode_limit", C.c_int32), ("env_seed", C.c_uint64),
                 ("act_seed", C.c_uint64), ("rng_step0", C.c_uint64), ("opp_thetas", C.c_void_p),
                 ("opp_theta_stride", C.c_int64), ("opp_group_rows", C.c_int32), ("opp_reserved", C.c_int32),
-                ("opp_seed", C.c_uint64), ("opp_rng_step0", C.c_uint64)]
+                ("opp_seed", C.c_uint64), ("opp_rng_step0", C.c_uint64), ("opp_index", C.c_void_p)]
 
 
 class RnnBatch(C.Structure):
@@ -126,6 +126,10 @@ _SIGNATURES = {
     "orl_critic_values": (C.c_int, [C.POINTER(NetDesc), _P, _P, C.c_int64, _P, _P]),
     "orl_act_step_grouped": (C.c_int, [C.POINTER(NetDesc), _P, C.c_int64, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64,
                                        C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
+    "orl_act_step_pool": (C.c_int, [C.POINTER(NetDesc), _P, C.c_int64, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64,
+                                    C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
+    "orl_opponent_sample": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P,
+                                      _P]),
     "orl_evaluate_actions": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, C.c_int, _P,
                                        _P, _P, _P, _P]),
     "orl_ppo_max_blocks": (C.c_int, []),

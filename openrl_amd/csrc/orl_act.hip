@@ -33,6 +33,8 @@ struct ActArgs {
   const unsigned long long* rng_dev;  // optional device-side addend of rng_step (rng_step_dev argument)
   int group_rows;          // > 0: rows [g*group_rows, (g+1)*group_rows) use the policy parameters ptheta + g*theta_stride
   long long theta_stride;  //      (orl_act_step_grouped: one launch for a pool of policies); a multiple of 16 rows
+  const int* opp_index;    // orl_act_step_pool: per-row policy index (NULL otherwise)
+  int n_policies;
 };
 
 template <int NO, int HEAD>
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
   const bool has_p = A.ptheta != nullptr;
   const float* ptheta = A.ptheta;
   if (has_p && A.group_rows > 0) ptheta += (size_t)((blockIdx.x * TILE_B) / A.group_rows) * A.theta_stride;
-  if (has_p) stage_tower(smem, ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
+  if (has_p && A.opp_index == nullptr) stage_tower(smem, ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
   if (has_c) {
     tlc = TowerLayout(A.cnet);
     twc = TowerLds(A.cnet.obs_dim, 1, false, false);
@@ -58,6 +60,17 @@ __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
   const int row = blockIdx.x * TILE_B + j;
   const bool row_ok = row < A.B;
+  // orl_act_step_pool: every row names its own policy.  The tile runs the tower once per distinct index it holds
+  // (workgroup-uniform loop: stage policy k, evaluate, rows whose index is k keep the result).
+  const int my_k = (A.opp_index != nullptr && row_ok) ? A.opp_index[row] : -1;
+  const int n_pass = A.opp_index != nullptr ? A.n_policies : 1;
+  for (int pass = 0; pass < n_pass; ++pass) {
+  if (A.opp_index != nullptr) {
+    if (!__syncthreads_or(my_k == pass)) continue;  // also orders the previous pass's LDS reads before restaging
+    stage_tower(smem, A.ptheta + (size_t)pass * A.theta_stride, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
+    __syncthreads();
+  }
+  const bool keep = A.opp_index == nullptr || my_k == pass;
   if (wave == 0) {
     if (!has_p) return;
     const int D = A.pnet.obs_dim;
@@ -82,7 +95,7 @@ __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
     const float* fr = (A.forced != nullptr && row_ok) ? A.forced + (size_t)row * a_w : nullptr;
     sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, am, fr, A.deterministic, A.seed, A.row0 + (uint64_t)row,
                           A.rng_step + (A.rng_dev ? *A.rng_dev : 0ull), act_o, lp_o);
-    if (row_ok && q == 0) {
+    if (row_ok && q == 0 && keep) {
 #pragma unroll
       for (int c = 0; c < NO; ++c) {
         if (c < a_w) {
@@ -105,6 +118,25 @@ __global__ __launch_bounds__(128) void act_step_kernel(ActArgs A) {
     head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
     if (row_ok && q == 0) A.values[row] = v[0];
   }
+  }  // pass
+}
+
+// Opponent sampling for the self-play pool (see orl_opponent_sample in include/orl_hip.h)
+__global__ void opponent_sample_kernel(int* __restrict__ opp_index, const uint8_t* __restrict__ dones, int N,
+                                       int n_filled, int last_slot, int strategy, int per_tile, uint64_t seed,
+                                       uint64_t draw_id, const unsigned long long* __restrict__ draw_id_dev) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  if (dones != nullptr && dones[n] == 0) return;
+  const uint64_t id = draw_id + (draw_id_dev ? *draw_id_dev : 0ull);
+  const uint32_t key = per_tile ? (uint32_t)(n / TILE_B) : (uint32_t)n;
+  int k = last_slot;
+  if (strategy == 0) {
+    const u4 r = philox4x32_10(seed, key, 0x0FF05A3Fu, (uint32_t)id, (uint32_t)(id >> 32));
+    k = (int)(u01(r.x) * (float)n_filled);
+    k = k < n_filled - 1 ? k : n_filled - 1;
+  }
+  opp_index[n] = k < 0 ? 0 : k;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -312,7 +344,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   float* s_oobs = s_opp + (ENV == ORL_ENV_TTT_POOL ? twp.total : 0);  // [16][DP]
   float* s_omask = s_oobs + TILE_B * DP;                       // [16][16]
   if constexpr (ENV == ORL_ENV_TTT_POOL) {
-    const float* oth = A.r.opp_thetas + (size_t)((blockIdx.x * TILE_B) / A.r.opp_group_rows) * A.r.opp_theta_stride;
+    const int first = blockIdx.x * TILE_B;  // opp_index: uniform over the tile (orl_opponent_sample per_tile)
+    const int og = A.r.opp_index != nullptr ? A.r.opp_index[first < N ? first : N - 1] : first / A.r.opp_group_rows;
+    const float* oth = A.r.opp_thetas + (size_t)og * A.r.opp_theta_stride;
     stage_tower(s_opp, oth, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
   }
   if (IS_TTT && wave == 0 && q == 0) {
@@ -913,7 +947,8 @@ using namespace orl;
 
 extern "C" {
 
-static int act_step_impl(const char* what, int group_rows, long long theta_stride, const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+static int act_step_impl(const char* what, int group_rows, long long theta_stride, const int* opp_index, int n_policies,
+                         const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                  const float* policy_obs, const float* critic_obs, const float* action_masks, int B,
                  int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
                  const float* forced_u, float* values, float* actions, float* logp, void* stream) {
@@ -940,6 +975,7 @@ static int act_step_impl(const char* what, int group_rows, long long theta_strid
   A.forced = forced_u; A.values = values; A.actions = actions; A.logp = logp; A.B = B;
   A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step; A.rng_dev = (const unsigned long long*)rng_step_dev;
   A.group_rows = group_rows; A.theta_stride = theta_stride;
+  A.opp_index = opp_index; A.n_policies = n_policies;
   const int grid = (B + TILE_B - 1) / TILE_B;
 #define ORL_ACT_LAUNCH(NO, HD)                                                                                  \
   do {                                                                                                          \
@@ -957,7 +993,7 @@ int orl_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_de
                  const float* policy_obs, const float* critic_obs, const float* action_masks, int B, int deterministic,
                  uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev, const float* forced_u,
                  float* values, float* actions, float* logp, void* stream) {
-  return act_step_impl("orl_act_step", 0, 0, pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, action_masks, B,
+  return act_step_impl("orl_act_step", 0, 0, nullptr, 0, pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, action_masks, B,
                        deterministic, seed, row0, rng_step, rng_step_dev, forced_u, values, actions, logp, stream);
 }
 
@@ -967,9 +1003,29 @@ int orl_act_step_grouped(const orl_net_desc* pnet, const float* pthetas, int64_t
                          void* stream) {
   ORL_REQUIRE(pthetas && rows_per_group > 0 && rows_per_group % TILE_B == 0 && theta_stride >= 0,
               "orl_act_step_grouped: rows_per_group must be a positive multiple of %d", TILE_B);
-  return act_step_impl("orl_act_step_grouped", rows_per_group, theta_stride, pnet, pthetas, nullptr, nullptr, policy_obs,
+  return act_step_impl("orl_act_step_grouped", rows_per_group, theta_stride, nullptr, 0, pnet, pthetas, nullptr, nullptr, policy_obs,
                        nullptr, action_masks, B, deterministic, seed, row0, rng_step, rng_step_dev, nullptr, nullptr, actions,
                        logp, stream);
+}
+
+int orl_act_step_pool(const orl_net_desc* pnet, const float* pthetas, int64_t theta_stride, int n_policies,
+                      const int32_t* opp_index, const float* policy_obs, const float* action_masks, int B,
+                      int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
+                      float* actions, float* logp, void* stream) {
+  ORL_REQUIRE(pthetas && opp_index && n_policies >= 1 && theta_stride >= 0, "orl_act_step_pool: bad pool arguments");
+  return act_step_impl("orl_act_step_pool", 0, theta_stride, (const int*)opp_index, n_policies, pnet, pthetas, nullptr,
+                       nullptr, policy_obs, nullptr, action_masks, B, deterministic, seed, row0, rng_step, rng_step_dev,
+                       nullptr, nullptr, actions, logp, stream);
+}
+
+int orl_opponent_sample(int32_t* opp_index, const uint8_t* dones, int N, int n_filled, int last_slot, int strategy,
+                        int per_tile, uint64_t seed, uint64_t draw_id, const uint64_t* draw_id_dev, void* stream) {
+  ORL_REQUIRE(opp_index && N > 0 && n_filled >= 1 && (strategy == 0 || strategy == 1),
+              "orl_opponent_sample: bad arguments (n_filled=%d, strategy=%d)", n_filled, strategy);
+  hipLaunchKernelGGL(opponent_sample_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int*)opp_index,
+                     dones, N, n_filled, last_slot, strategy, per_tile, seed, draw_id,
+                     (const unsigned long long*)draw_id_dev);
+  return launch_status("orl_opponent_sample");
 }
 
 int orl_evaluate_actions(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,

@@ -146,6 +146,8 @@ class OnPolicyDriver:
 
     def actor_rollout(self) -> Tuple[Dict[str, Any], bool]:
         self.callback.on_rollout_start()
+        if hasattr(self.envs, "on_rollout_start"):  # e.g. the self-play env's per-rollout opponent draw
+            self.envs.on_rollout_start()
         self.trainer.prep_rollout()
         if self.fused:
             self._fused_rollout()

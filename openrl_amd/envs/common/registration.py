@@ -40,8 +40,22 @@ def make(id: str, env_num: int = 1, asynchronous: bool = False, add_monitor: boo
     if id == "tictactoe_v3":  # openrl/envs/PettingZoo + selfplay RandomOpponentWrapper (examples/selfplay)
         from ..vec_env.tictactoe_env import TicTacToeSelfPlayVecEnv, TicTacToeVecEnv
 
-        if kwargs.pop("opponent", "random") == "pool":  # self-play against frozen snapshots of the learner
-            return TicTacToeSelfPlayVecEnv(env_num, id, device=device, seed=seed, pool_size=kwargs.pop("pool_size", 4))
+        opponent = kwargs.pop("opponent", "random")
+        # the reference selects the opponent with wrapper classes (examples/selfplay/train_selfplay.py:26,51:
+        # opponent_wrappers=[RecordWinner, OpponentPoolWrapper] / [..., RandomOpponentWrapper]); their NAMES (classes or
+        # strings) are honoured here, the wrappers' work itself (opponent moves, winner records) is in-kernel
+        names = [w if isinstance(w, str) else getattr(w, "__name__", str(w)) for w in kwargs.pop("opponent_wrappers", [])]
+        unknown = [n for n in names if n not in ("OpponentPoolWrapper", "RandomOpponentWrapper", "RecordWinner")]
+        if unknown:
+            raise NotImplementedError("opponent_wrappers %s are not built for the device tic-tac-toe env" % unknown)
+        if "OpponentPoolWrapper" in names:
+            opponent = "pool"
+        elif "RandomOpponentWrapper" in names:
+            opponent = "random"
+        if opponent == "pool":  # self-play against frozen snapshots of the learner
+            return TicTacToeSelfPlayVecEnv(env_num, id, device=device, seed=seed, pool_size=kwargs.pop("pool_size", 4),
+                                           opponent_sampling=kwargs.pop("opponent_sampling", "per_reset"),
+                                           opponent_strategy=kwargs.pop("opponent_strategy", "RandomOpponent"))
         return TicTacToeVecEnv(env_num, id, device=device, seed=seed)
     raise NotImplementedError(
         "env id %r is not a device-resident env of the MI355X engine (built: 'CartPole-v1', 'simple_spread', 'tictactoe_v3', '%s-v0'); "

@@ -84,15 +84,36 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
     opponent-side boards (sampled under the legal-move masks) -> ``orl_ttt_opponent_move``; all of them capturable, so the stepwise rollout still replays as one
     hipGraph.  Snapshots are refreshed in place with ``push_opponent(theta)`` (round-robin), e.g. by
     ``SelfPlayCallback``.  Until the first push every slot holds all-zero parameters = the uniformly random opponent.
-    Not the reference's selfplay API / per-reset opponent sampling: the assignment of snapshots to envs is static."""
 
-    def __init__(self, env_num: int, env_name: str = "tictactoe_v3", device="cuda:0", seed: int = 0, pool_size: int = 4):
+    Which snapshot an env plays (``opponent_sampling``; the reference asks its self-play service for an opponent at
+    EVERY ``reset``, opponent_pool_wrapper.py:37-66, and the service applies a sample strategy):
+
+    * ``"per_reset"`` (the reference's semantics, exact): every env draws a pool slot whenever its game ends
+      (``orl_opponent_sample`` on the dones of the step, in the same stepwise launch chain) - ``opponent_strategy``
+      ``"RandomOpponent"`` = uniform over the filled slots, ``"LastOpponent"`` = the newest
+      (selfplay/sample_strategy/{random,last}_opponent.py); the opponents' moves come from ``orl_act_step_pool``, which
+      runs a 16-env tile once per distinct slot it holds.  Stepwise / hipGraph rollout only.
+    * ``"per_rollout"``: one draw per 16-env tile at every rollout start - the same marginal distribution of
+      opponents, coarser in time, and the fused one-launch rollout still applies (a tile shares one opponent image).
+    * ``"static"``: env group g always plays slot g (round 1's behaviour)."""
+
+    STRATEGIES = {"RandomOpponent": 0, "LastOpponent": 1}
+
+    def __init__(self, env_num: int, env_name: str = "tictactoe_v3", device="cuda:0", seed: int = 0, pool_size: int = 4,
+                 opponent_sampling: str = "per_reset", opponent_strategy: str = "RandomOpponent"):
         super().__init__(env_num, env_name, device=device, seed=seed)
         from ... import ops
 
+        if opponent_sampling not in ("per_reset", "per_rollout", "static"):
+            raise ValueError("opponent_sampling must be per_reset / per_rollout / static, got %r" % opponent_sampling)
+        if opponent_strategy not in self.STRATEGIES:
+            raise ValueError("opponent_strategy must be one of %s" % sorted(self.STRATEGIES))
+        self.opponent_sampling, self.opponent_strategy = opponent_sampling, opponent_strategy
         self.kind = "tictactoe_selfplay_pool"
         self.env_kind = nat.ORL_ENV_TTT_POOL  # orl_rollout_fused plays both sides in-kernel (fill_rollout_args)
-        self.supports_fused_rollout = True
+        self.supports_fused_rollout = opponent_sampling != "per_reset"
+        self.opp_index = torch.zeros(self._n, dtype=torch.int32, device=self.device)
+        self._draws = 0
         self.pool_size = max(1, min(int(pool_size), self._n))
         self.opp_net = nat.NetDesc(self.OBS, 64, self.N_ACT, nat.ORL_HEAD_CATEGORICAL)
         self.opp_thetas = torch.zeros(self.pool_size, ops.param_count(self.opp_net), device=self.device)
@@ -113,6 +134,32 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
         args.opp_group_rows = self._group_rows
         args.opp_seed = self.opp_seed & (2 ** 64 - 1)
         args.opp_rng_step0 = self.global_step
+        if self.opponent_sampling == "per_rollout":
+            args.opp_index = self.opp_index.data_ptr()
+
+    @property
+    def n_filled(self) -> int:
+        return max(1, min(self.pushes, self.pool_size))
+
+    def sample_opponents(self, dones, per_tile: bool = False) -> None:
+        """Draw a pool slot for every env in ``dones`` (None: all) with the configured strategy - on the device."""
+        from ... import ops
+
+        last = (self.pushes - 1) % self.pool_size if self.pushes else 0
+        ops.opponent_sample(self.opp_index, dones, self.n_filled, last, self.STRATEGIES[self.opponent_strategy], per_tile,
+                            self.opp_seed ^ 0x0B0E, self._draws, getattr(self, "rng_step_dev", None))
+        self._draws += 1
+
+    def reset_device(self, seed=None):
+        obs = super().reset_device(seed)
+        if self.opponent_sampling == "per_reset":
+            self.sample_opponents(None)
+        return obs
+
+    def on_rollout_start(self) -> None:
+        """Driver hook (fused and stepwise rollouts alike): the per-rollout draw of one pool slot per 16-env tile."""
+        if self.opponent_sampling == "per_rollout":
+            self.sample_opponents(None, per_tile=True)
 
     def push_opponent(self, theta: torch.Tensor) -> int:
         """Store a snapshot of the learner's policy parameters in the next pool slot (in place: graph-safe)."""
@@ -126,10 +173,16 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
 
         a = actions.to(self.device, torch.float32).reshape(self._n).contiguous()
         ops_rnn.ttt_agent_move(self.env_state, a, self._opp_obs, self._opp_mask, self._rew, self._done, self._n)
-        ops.act_step_grouped(self.opp_net, self.opp_thetas, self._group_rows, self._opp_obs, self._opp_mask, self._n, False,
-                             self.opp_seed, 0, self.global_step, self._opp_act, self._opp_lp,
-                             rng_step_dev=getattr(self, "rng_step_dev", None))
+        rdev = getattr(self, "rng_step_dev", None)
+        if self.opponent_sampling == "static":
+            ops.act_step_grouped(self.opp_net, self.opp_thetas, self._group_rows, self._opp_obs, self._opp_mask, self._n,
+                                 False, self.opp_seed, 0, self.global_step, self._opp_act, self._opp_lp, rng_step_dev=rdev)
+        else:  # every env (per_reset) / tile (per_rollout) names its own pool slot
+            ops.act_step_pool(self.opp_net, self.opp_thetas, self.opp_index, self._opp_obs, self._opp_mask, self._n, False,
+                              self.opp_seed, 0, self.global_step, self._opp_act, self._opp_lp, rng_step_dev=rdev)
         ops_rnn.ttt_opponent_move(self.env_state, self.ep_stats, self._opp_act, self.obs, self.action_mask_device,
                                   self._rew, self._done, self._n, self.seed)
+        if self.opponent_sampling == "per_reset":  # a finished game -> a fresh opponent for the next one
+            self.sample_opponents(self._done)
         self.global_step += 1
         return self.obs, self._rew, self._done

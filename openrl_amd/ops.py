@@ -179,6 +179,29 @@ def act_step_grouped(pnet: NetDesc, pthetas, rows_per_group: int, policy_obs, ac
     nat.check(rc, "orl_act_step_grouped")
 
 
+def act_step_pool(pnet: NetDesc, pthetas, opp_index, policy_obs, action_masks, B: int, deterministic: bool, seed: int,
+                  row0: int, rng_step: int, actions, logp, rng_step_dev=None) -> None:
+    """Row i is evaluated with policy ``pthetas[opp_index[i]]`` (orl_act_step_pool: exact per-row assignment)."""
+    dev = _dev(policy_obs)
+    assert opp_index.dtype == torch.int32
+    rc = _lib().orl_act_step_pool(C.byref(pnet), fptr(pthetas), pthetas.stride(0), pthetas.shape[0], ptr(opp_index),
+                                  fptr(policy_obs), fptr(action_masks), B, int(bool(deterministic)),
+                                  seed & (2 ** 64 - 1), row0, rng_step, ptr(rng_step_dev), fptr(actions), fptr(logp),
+                                  stream_ptr(dev))
+    nat.check(rc, "orl_act_step_pool")
+
+
+def opponent_sample(opp_index, dones, n_filled: int, last_slot: int, strategy: int, per_tile: bool, seed: int,
+                    draw_id: int, draw_id_dev=None) -> None:
+    """opp_index[n] <- a pool slot for every env with dones[n] (None: all): strategy 0 uniform over the filled slots,
+    1 the newest (openrl/selfplay/sample_strategy/{random,last}_opponent.py)."""
+    dev = _dev(opp_index)
+    rc = _lib().orl_opponent_sample(ptr(opp_index), ptr(dones), opp_index.numel(), n_filled, last_slot, strategy,
+                                    int(bool(per_tile)), seed & (2 ** 64 - 1), draw_id, ptr(draw_id_dev),
+                                    stream_ptr(dev))
+    nat.check(rc, "orl_opponent_sample")
+
+
 def critic_values(cnet: NetDesc, ctheta, critic_obs, values) -> None:
     """values[rows] = V(critic_obs[rows, D]) in one persistent launch (orl_critic_values)."""
     dev = _dev(critic_obs)

@@ -130,7 +130,8 @@ def test_fused_rollout_equals_stepwise_rollout_on_tictactoe():
     assert torch.equal(sa, sb) and torch.equal(ea, eb)
 
 
-def test_fused_selfplay_rollout_equals_stepwise():
+@pytest.mark.parametrize("sampling", ["static", "per_rollout"])
+def test_fused_selfplay_rollout_equals_stepwise(sampling):
     """ORL_ENV_TTT_POOL inside orl_rollout_fused (both players' policies in-kernel) fills the buffer like the stepwise
     orl_act_step + orl_ttt_agent_move + orl_act_step_grouped + orl_ttt_opponent_move + orl_buffer_insert path."""
     from openrl_amd.algorithms.ppo import PPOAlgorithm
@@ -144,9 +145,11 @@ def test_fused_selfplay_rollout_equals_stepwise():
         N, T = 150, 12
         cfg = default_cfg(["--seed", "5", "--episode_length", str(T), "--ppo_epoch", "1", "--amd_perm_mode", "device",
                            "--amd_use_graph", "false", "--amd_rollout_mode", mode, "--log_interval", "1000000"])
-        env = make("tictactoe_v3", env_num=N, device=DEV, seed=5, opponent="pool", pool_size=3)
+        env = make("tictactoe_v3", env_num=N, device=DEV, seed=5, opponent="pool", pool_size=3,
+                   opponent_sampling=sampling)
         torch.manual_seed(4)
         env.opp_thetas.copy_(0.5 * torch.randn_like(env.opp_thetas))  # three different non-trivial opponents
+        env.pushes = 3  # all three slots count as filled for the per-rollout draw
         net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
         cfg.num_env_steps = N * T * 2
 
@@ -258,7 +261,8 @@ def test_selfplay_pool_env_and_callback_end_to_end():
     N, T = 1024, 10
     cfg = default_cfg(["--seed", "0", "--lr", "1e-3", "--critic_lr", "1e-3", "--episode_length", str(T), "--ppo_epoch", "5",
                        "--amd_perm_mode", "device", "--log_interval", "1000000"])
-    env = make("tictactoe_v3", env_num=N, device=DEV, opponent="pool", pool_size=3)
+    env = make("tictactoe_v3", env_num=N, device=DEV, opponent_wrappers=["RecordWinner", "OpponentPoolWrapper"],
+               pool_size=3, opponent_sampling="per_rollout")
     # before any snapshot: all-zero parameters = uniform over the legal moves (log-prob = -log(#empty cells))
     env.reset_device(seed=0)
     env.step_device(torch.zeros(N, 1, 1, device=DEV))
@@ -280,3 +284,66 @@ def test_selfplay_pool_env_and_callback_end_to_end():
         obs, _, _ = ev.step_device(a.view(2048, 1, 1))
     st = ev.episode_statistics()
     assert st["episodes_finished"] > 2048 * 5 and st["episode_return_mean"] > 0.5, st
+
+
+def test_act_step_pool_equals_one_launch_per_policy():
+    """orl_act_step_pool (every row names its pool slot; a tile runs once per distinct slot it holds) against K plain
+    orl_act_step launches over the whole batch with the rows picked afterwards: same Philox counters, same towers."""
+    from openrl_amd import ops
+
+    B, K, D, NA = 200, 4, 18, 9
+    pnet = ops.net_desc(D, NA, ops.HEAD_CATEGORICAL)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    thetas = 0.3 * torch.randn(K, ops.param_count(pnet), device=DEV, generator=g)
+    obs = torch.randn(B, D, device=DEV, generator=g)
+    masks = (torch.rand(B, NA, device=DEV, generator=g) > 0.3).float()
+    masks[:, 0] = 1.0
+    idx = torch.randint(0, K, (B,), device=DEV, generator=g).int()
+    idx[:16] = 2           # a tile with a single slot
+    idx[16:32] = torch.arange(16, device=DEV).int() % K  # a tile with every slot
+    a, lp = torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV)
+    ops.act_step_pool(pnet, thetas, idx, obs, masks, B, False, 99, 7, 5, a, lp)
+    want_a, want_lp = torch.empty_like(a), torch.empty_like(lp)
+    for k in range(K):
+        ak, lk = torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV)
+        ops.act_step(pnet, thetas[k], None, None, obs, None, masks, B, False, 99, 7, 5, None, None, ak, lk)
+        sel = idx == k
+        want_a[sel], want_lp[sel] = ak[sel], lk[sel]
+    assert torch.equal(a, want_a)
+    assert torch.equal(lp, want_lp)
+
+
+@pytest.mark.parametrize("strategy", ["RandomOpponent", "LastOpponent"])
+def test_per_reset_opponent_sampling(strategy):
+    """opponent_sampling="per_reset" (opponent_pool_wrapper.py:37-66): an env draws a new pool slot exactly when its
+    game ends - uniform over the FILLED slots (RandomOpponent) or the newest slot (LastOpponent) - and keeps it
+    through the game; the rollout runs stepwise (also as a replayed hipGraph)."""
+    from openrl_amd.envs.common import make
+
+    N = 2048
+    env = make("tictactoe_v3", env_num=N, device=DEV, seed=9, opponent="pool", pool_size=4,
+               opponent_sampling="per_reset", opponent_strategy=strategy)
+    assert not env.supports_fused_rollout
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for k in range(3):  # three snapshots pushed: slots 0..2 filled, 3 empty
+        env.push_opponent(0.3 * torch.randn(env.opp_thetas.shape[1], device=DEV, generator=g))
+    env.reset_device(seed=9)
+    idx0 = env.opp_index.clone()
+    assert int(idx0.max()) <= 2
+    changed_total, seen = 0, []
+    for t in range(12):
+        prev = env.opp_index.clone()
+        am = env.action_mask_device.view(N, 9)
+        a = torch.multinomial(am + 1e-6, 1, generator=g).float().view(N, 1, 1)  # a random legal move
+        _, _, done = env.step_device(a)
+        now = env.opp_index
+        assert torch.equal(now[done.view(-1) == 0], prev[done.view(-1) == 0]), "an open game keeps its opponent"
+        seen.append(now[done.view(-1) != 0].clone())
+        changed_total += int((done.view(-1) != 0).sum())
+    drawn = torch.cat(seen)
+    assert changed_total > N and int(drawn.max()) <= 2
+    if strategy == "LastOpponent":
+        assert bool((drawn == 2).all())  # the newest snapshot sits in slot 2
+    else:
+        freq = torch.bincount(drawn, minlength=3).float() / drawn.numel()
+        assert float((freq - 1 / 3).abs().max()) < 0.03, freq
