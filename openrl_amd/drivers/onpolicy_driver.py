@@ -39,6 +39,40 @@ def prepare_action_masks(infos, agent_num: int):
     return np.stack([np.asarray(i["action_masks"]).reshape(agent_num, -1) for i in infos])
 
 
+class HostStaging:
+    """Pinned-memory staging for HOST envs (gymnasium / PettingZoo / Isaac wrappers behind the VecEnv duck type):
+    every array that crosses PCIe per step - observations, rewards, dones, masks in; actions out - goes through a
+    page-locked buffer allocated once per (name, shape, dtype), so the copies are DMA transfers queued on the launch
+    stream instead of pageable staged copies that block the host.  Safe to reuse the
+    buffers step after step: a step ends with the synchronising device -> host copy of the actions, which orders every
+    earlier host -> device copy of the stream before the host touches the pinned arrays again."""
+
+    def __init__(self, device) -> None:
+        self.device = device
+        self._in, self._out = {}, {}
+
+    def to_device(self, name: str, arr, dtype: torch.dtype) -> torch.Tensor:
+        a = np.asarray(arr)
+        key = (name, a.shape, dtype)
+        pair = self._in.get(key)
+        if pair is None:
+            pin = torch.empty(a.shape, dtype=dtype).pin_memory()
+            pair = self._in[key] = (pin, pin.numpy(), torch.empty(a.shape, dtype=dtype, device=self.device))
+        pin, view, dev = pair
+        np.copyto(view, a, casting="unsafe")  # one host pass: dtype conversion straight into the pinned pages
+        dev.copy_(pin, non_blocking=True)
+        return dev
+
+    def to_host(self, name: str, t: torch.Tensor) -> np.ndarray:
+        key = (name, tuple(t.shape), t.dtype)
+        pin = self._out.get(key)
+        if pin is None:
+            pin = self._out[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        pin.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return pin.numpy()
+
+
 class OnPolicyDriver:
     #: the buffer this driver works on (device-resident); see INTEGRATION.md section 2
     from ..buffers import NormalReplayBuffer as buffer_class
@@ -93,6 +127,7 @@ class OnPolicyDriver:
                           and not per_step_cb)
         self._graph = None
         self._rng_ctr = None
+        self._staging = None if dev_env else HostStaging(self.device)
         d = self.buffer.data
         self._next_value = torch.zeros(d.n_rollout_threads, d.num_agents, 1, dtype=torch.float32, device=self.device)
         self._have_next_value = False
@@ -229,7 +264,7 @@ class OnPolicyDriver:
         else:
             # host envs get the reference's action dtype: integer indices for Discrete / MultiDiscrete spaces (the
             # reference's ACTLayer samples int64, act.py:59-83), float32 for Box; the buffer keeps them as floats
-            host_actions = actions.long().cpu().numpy() if self.buffer.data.act_is_index else actions.cpu().numpy()
+            host_actions = self._staging.to_host("actions", actions.long() if self.buffer.data.act_is_index else actions)
             obs, rewards, dones, infos = self.envs.step(host_actions, extra_data)
         self.agent.num_time_steps += self.envs.parallel_env_num
         self.callback.update_locals(locals())
@@ -261,9 +296,11 @@ class OnPolicyDriver:
                      d.get_batch_data("action_masks", step), False, out=out)
         return d.value_preds[step], d.actions[step], d.action_log_probs[step], None, None
 
-    def _as_dev(self, x, dtype=torch.float32):
+    def _as_dev(self, x, dtype=torch.float32, name: str = ""):
         if isinstance(x, torch.Tensor):
             return x.to(self.device, dtype).contiguous()
+        if self._staging is not None and name:  # host env: through the pinned staging buffers
+            return self._staging.to_device(name, x, dtype)
         return torch.as_tensor(np.ascontiguousarray(x)).to(self.device, dtype).contiguous()
 
     def add2buffer(self, data):
@@ -272,21 +309,21 @@ class OnPolicyDriver:
         step = data["step"] if "step" in data else d.step
         obs = data["obs"]
         p_obs, c_obs = (obs.get("policy", obs), obs.get("critic", obs)) if isinstance(obs, dict) else (obs, obs)
-        p_obs = self._as_dev(p_obs)
-        c_obs = p_obs if c_obs is obs or d.critic_obs is d.policy_obs else self._as_dev(c_obs)
+        p_obs = self._as_dev(p_obs, name="policy_obs")
+        c_obs = p_obs if c_obs is obs or d.critic_obs is d.policy_obs else self._as_dev(c_obs, name="critic_obs")
         infos = data["infos"]
         bad = None
         if infos is not None and len(infos) and isinstance(infos[0], dict) and any("bad_transition" in i for i in infos):
             bad = np.array([[bool(i.get("bad_transition", [False] * self.num_agents)[a]) for a in range(self.num_agents)]
                             for i in infos], dtype=np.uint8)
-            bad = self._as_dev(bad, torch.uint8)
+            bad = self._as_dev(bad, torch.uint8, "bad_transition")
         amask = data.get("action_masks")  # device envs: already a device tensor [N, A, K]
         if amask is None:
             amask = prepare_action_masks(infos, self.num_agents)
         rec = d.rnn_states.stride(0) != 0  # recurrent: rnn_states[dones_env] = 0, folded into the insert launch
-        ops.buffer_insert(d.buffer_ptrs(), step, p_obs, c_obs, self._as_dev(data["rewards"]),
-                          self._as_dev(data["dones"], torch.uint8), bad,
-                          None if amask is None else self._as_dev(amask),
+        ops.buffer_insert(d.buffer_ptrs(), step, p_obs, c_obs, self._as_dev(data["rewards"], name="rewards"),
+                          self._as_dev(data["dones"], torch.uint8, "dones"), bad,
+                          None if amask is None else self._as_dev(amask, name="action_masks"),
                           d.rnn_states[step + 1] if rec else None, d.rnn_states_critic[step + 1] if rec else None)
         d.step = (step + 1) % d.episode_length
         d._adv_fresh = False
