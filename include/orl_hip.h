@@ -470,11 +470,33 @@ int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_ne
                      const float* forced_u, float* values, float* actions, float* logp, float* h_policy_out,
                      float* h_critic_out, void* stream);
 
+/* One step of PPOModule.evaluate_actions with recurrent networks (ppo_module.py:149-193, rnn.py:39-99): like
+ * orl_rnn_act_step, but the GIVEN actions [B, a] are evaluated - log-probs [B, a], per-row entropy [B] - instead of
+ * sampled.  A sequence of L steps is L calls that hand h_*_out to the next call's h_*_in. */
+int orl_rnn_eval_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                      const float* policy_obs, const float* critic_obs, const float* h_policy_in,
+                      const float* h_critic_in, const float* masks, const float* action_masks, const float* actions,
+                      int B, float* values, float* logp, float* entropy, float* h_policy_out, float* h_critic_out,
+                      void* stream);
+
 /* ReplayData.recurrent_generator's index arithmetic (buffers/replay_data.py:1062-1258): chunk c covers the rows
  * c*L .. c*L+L-1 of the [lane][t]-ordered flat batch (lane = n*A+a; chunks may straddle lanes when T % L != 0).
  * rows[l*n_chunks + i] = record row (t*lanes + lane) of step l of chunk chunk_idx[i] (NULL = identity) - the same
  * index addresses masks [T+1,lanes] and, scaled by H, the stored rnn states [T+1,lanes,H]. */
 int orl_rnn_chunk_rows(const int64_t* chunk_idx, int n_chunks, int L, int T, int lanes, int64_t* rows, void* stream);
+
+/* recurrent_generator_v3 (buffers/replay_data.py:425-551, use_joint_action_loss): chunk c = positions c*L .. c*L+L-1
+ * of the (n*T + t)-ordered batch with the agent axis kept; rows[l*(n_chunks*A) + i*A + a] = record row of agent a at
+ * step l of chunk chunk_idx[i] (agent0_only: rows[l*n_chunks + i], a = 0 - the critic's sequences). */
+int orl_rnn_chunk_rows_v3(const int64_t* chunk_idx, int n_chunks, int L, int T, int n_envs, int n_agents, int agent0_only,
+                          int64_t* rows, void* stream);
+/* Joint-action loss (JRPO, algorithms/ppo.py:254-300): given the CURRENT policy's log-probs logp_new [L][n_chunks*A][a]
+ * of the minibatch rows (orl_rnn_eval_step), write to records_out (a full copy of `records`) the old log-probs shifted
+ * so that exp(logp - old') is the JOINT ratio over agents and action dims, adv' = A * agent 0's advantage and
+ * active' = agent 0's active mask for every agent row of a (step, chunk); the per-row PPO loss of
+ * orl_rnn_ppo_fwd_bwd on records_out then has exactly the joint-action gradient. */
+int orl_rnn_jrpo_records(const float* records, float* records_out, int rec_width, int Dp, int Dc, int a_w,
+                         const int64_t* rows, int n_chunks, int L, int n_agents, const float* logp_new, void* stream);
 
 typedef struct orl_rnn_batch {
   const float* records;  /* packed update records (orl_adv_normalize_pack), row = t*lanes + lane */
@@ -482,7 +504,9 @@ typedef struct orl_rnn_batch {
   const float* masks;    /* [T+1, lanes] */
   const float* h_policy; /* [T+1, lanes, H] rnn_states          */
   const float* h_critic; /* [T+1, lanes, H] rnn_states_critic   */
-  int32_t rec_width, n_chunks, L, reserved;
+  int32_t rec_width, n_chunks, L, n_chunks_critic;
+  const int64_t* rows_critic; /* optional [L][n_chunks_critic]: the critic tower's own sequences (joint-action loss:
+                               * agent 0 of every chunk); NULL = the policy's rows */
 } orl_rnn_batch;
 
 /* float32 scratch the update needs (activation tapes + per-workgroup partials), in floats */

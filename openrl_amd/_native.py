@@ -83,7 +83,7 @@ class RolloutArgs(C.Structure):
 class RnnBatch(C.Structure):
     _fields_ = [("records", C.c_void_p), ("rows", C.c_void_p), ("masks", C.c_void_p), ("h_policy", C.c_void_p),
                 ("h_critic", C.c_void_p), ("rec_width", C.c_int32), ("n_chunks", C.c_int32), ("L", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("n_chunks_critic", C.c_int32), ("rows_critic", C.c_void_p)]
 
 
 class HeadDesc(C.Structure):
@@ -182,7 +182,11 @@ _SIGNATURES = {
     "orl_rnn_raw_grad_count": (C.c_int, [C.POINTER(NetDesc)]),
     "orl_rnn_act_step": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                    C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "orl_rnn_eval_step": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P,
+                                    _P, _P, _P, _P, _P]),
     "orl_rnn_chunk_rows": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "orl_rnn_chunk_rows_v3": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "orl_rnn_jrpo_records": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "orl_rnn_workspace_floats": (C.c_int64, [C.POINTER(NetDesc), C.POINTER(NetDesc), C.c_int, C.c_int]),
     "orl_rnn_ppo_fwd_bwd": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, C.POINTER(RnnBatch), _P,
                                       C.POINTER(PPOHParams), _P, _P, _P]),

@@ -108,14 +108,18 @@ class PPOAlgorithm(BaseAlgorithm):
     info_keys = INFO_KEYS
 
     def __init__(self, cfg, init_module, agent_num: int = 1, device: Union[str, torch.device] = "cuda:0") -> None:
-        if cfg.use_joint_action_loss or cfg.use_deepspeed or cfg.use_amp:
-            raise NotImplementedError("joint_action_loss / deepspeed / amp are not built in this engine")
+        if cfg.use_deepspeed or cfg.use_amp:
+            raise NotImplementedError("deepspeed / amp are not built in this engine")
+        if cfg.use_joint_action_loss and not cfg.use_recurrent_policy:
+            raise NotImplementedError("use_joint_action_loss is built for recurrent policies (recurrent_generator_v3, "
+                                      "the only generator the reference pairs it with, ppo.py:363-372)")
         if cfg.use_naive_recurrent_policy:
             raise NotImplementedError("naive_recurrent_generator is not built in this engine (use_recurrent_policy is)")
         super().__init__(cfg, init_module, agent_num, device)
         self.train_list = [self.train_ppo]
         self.hp = ops.make_hparams(cfg)
         self.generic = bool(getattr(self.algo_module, "generic", False))
+        self.use_joint_action_loss = bool(cfg.use_joint_action_loss)
         self.perm_mode = getattr(cfg, "amd_perm_mode", "reference")
         self._perm_counter = 0
         self._vn_in_perm = False
@@ -221,8 +225,89 @@ class PPOAlgorithm(BaseAlgorithm):
                              co.native_state(co.step_count), self._info, next_perm, comm=comm)
 
     # ------------------------------------------------------------------------------------------ recurrent
+    def _update_minibatch_jrpo(self, buffer, chunks, n_chunks: int, turn_on: bool) -> None:
+        """One recurrent_generator_v3 minibatch with the joint-action loss (JRPO: ppo.py:254-300,
+        replay_data.py:425-551).  The joint ratio over agents needs every agent's CURRENT log-prob before any row's
+        loss can be evaluated, so the step is: (1) forward-only evaluation of the minibatch's policy sequences
+        (``orl_rnn_eval_step`` per chunk step), (2) ``orl_rnn_jrpo_records`` folds the joint log-ratio, agent 0's
+        advantage (x A) and agent 0's active mask into a copy of the records, (3) the ordinary fused recurrent update on
+        that copy - policy tower over all (chunk, agent) sequences, critic tower over agent 0's only."""
+        mod = self.algo_module
+        p, c = mod.models["policy"], mod.models["critic"]
+        po, co = mod.optimizers["policy"], mod.optimizers["critic"]
+        T, N, A, L = buffer.episode_length, buffer.n_rollout_threads, buffer.num_agents, self.data_chunk_length
+        lanes, H = N * A, p.net.hidden
+        rec = buffer.records
+        Dp, Dc, a_w, K = buffer.Dp, buffer.Dc, buffer.act_shape, buffer.K
+        ns = n_chunks * A
+        dev = self.device
+        if getattr(self, "_jr", None) is None or self._jr["ns"] < ns or self._jr["L"] != L:
+            f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+            self._jr = dict(ns=ns, L=L, rows_p=torch.empty(L * ns, dtype=torch.int64, device=dev),
+                            rows_c=torch.empty(L * n_chunks, dtype=torch.int64, device=dev), x=f(ns, Dp), act=f(ns, a_w),
+                            mk=f(ns), am=f(ns, K) if K else None, h=f(ns, H), logp=f(L * ns, a_w), rec2=torch.empty_like(rec))
+        j = self._jr
+        rows_p, rows_c = j["rows_p"][:L * ns], j["rows_c"][:L * n_chunks]
+        ops_rnn.rnn_chunk_rows_v3(chunks, n_chunks, L, T, N, A, False, rows_p)
+        ops_rnn.rnn_chunk_rows_v3(chunks, n_chunks, L, T, N, A, True, rows_c)
+        vn = mod.get_critic_value_normalizer() if self._use_valuenorm else None
+        vn_state = None
+        if vn is not None:  # ValueNorm.update(return_batch): the returns of agent 0's rows (to_single_np, ppo.py:258)
+            ret_col = Dp + Dc + 2 * a_w + 2
+            ops.minibatch_moments(rec, ret_col, rows_c, n_chunks * L, self._mom_scratch, self._moments_mb)
+            if self.world_size > 1:
+                dist_utils.allreduce_(self._moments_mb)
+            ops.valuenorm_update(vn.state, self._moments_mb, vn.beta)
+            self._vn_in_perm = False
+            vn_state = vn.state
+        # (1) current log-probs of every (step, chunk, agent) row
+        from .. import ops_gen
+
+        x, act, mk, am, h = j["x"][:ns], j["act"][:ns], j["mk"][:ns], (j["am"][:ns] if K else None), j["h"][:ns]
+        o_act = Dp + Dc
+        masks_flat = buffer.masks.view(-1, 1)
+        hflat = buffer.rnn_states.view(-1, H)
+        ops_gen.gather_cols(hflat, 0, H, rows_p[:ns], ns, h)  # the state entering each sequence (replay_data.py:519)
+        for s in range(L):
+            r = rows_p[s * ns:(s + 1) * ns]
+            ops_gen.gather_cols(rec, 0, Dp, r, ns, x)
+            ops_gen.gather_cols(rec, o_act, a_w, r, ns, act)
+            ops_gen.gather_cols(masks_flat, 0, 1, r, ns, mk.view(ns, 1))
+            if K:
+                ops_gen.gather_cols(rec, o_act + 2 * a_w + 4, K, r, ns, am)
+            ops_rnn.rnn_eval_step(p.net, p.theta, None, None, x, None, h, None, mk, am, act, ns, None,
+                                  j["logp"][s * ns:(s + 1) * ns], None, h, None)
+        # (2) joint-ratio records
+        rec2 = j["rec2"]
+        if self._jr.get("stamp") is not buffer.records or self._jr.get("fresh") != self._jrpo_epoch_id:
+            rec2.copy_(rec)
+            self._jr["stamp"], self._jr["fresh"] = buffer.records, self._jrpo_epoch_id
+        ops_rnn.rnn_jrpo_records(rec, rec2, Dp, Dc, a_w, rows_p, n_chunks, L, A, j["logp"])
+        # (3) fused recurrent update on the adjusted records
+        need = ops_rnn.rnn_workspace_floats(p.net, c.net, ns, L)
+        if self._rnn_ws is None or self._rnn_ws.numel() < need:
+            self._rnn_ws = torch.empty(need, dtype=torch.float32, device=dev)
+        ops_rnn.rnn_ppo_fwd_bwd(p.net, p.theta, c.net, c.theta, rec2, rows_p, buffer.masks, buffer.rnn_states,
+                                buffer.rnn_states_critic, ns, L, vn_state, self.hp, self._rnn_ws, self._sums,
+                                rows_critic=rows_c, n_chunks_critic=n_chunks)
+        if self.world_size > 1:
+            if self._comm is not None:
+                self._comm.allreduce_(self._sums)
+            else:
+                dist_utils.allreduce_(self._sums)
+        po.step_count += 1 if turn_on else 0
+        co.step_count += 1
+        hp = self.hp
+        if not turn_on:
+            hp = nat.PPOHParams.from_buffer_copy(self.hp)
+            hp.reserved |= 1
+        ops_rnn.rnn_ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
+                              co.native_state(co.step_count), self._info, self._rnn_scratch)
+
     def _update_minibatch_rnn(self, buffer, chunks, n_chunks: int, turn_on: bool) -> None:
         """One recurrent_generator minibatch (replay_data.py:1062-1258): ``chunks`` = chunk ids (device int64)."""
+        if self.use_joint_action_loss:
+            return self._update_minibatch_jrpo(buffer, chunks, n_chunks, turn_on)
         mod = self.algo_module
         p, c = mod.models["policy"], mod.models["critic"]
         po, co = mod.optimizers["policy"], mod.optimizers["critic"]
@@ -268,6 +353,8 @@ class PPOAlgorithm(BaseAlgorithm):
 
     def _chunk_batches(self, M: int):
         L = self.data_chunk_length
+        if self.use_joint_action_loss:  # recurrent_generator_v3 chunks (env, time) positions, the agent axis is kept
+            M = M // self.agent_num
         assert M >= L, "PPO requires n_rollout_threads * num_agents * episode_length >= data_chunk_length"
         data_chunks = M // L
         mbs = data_chunks // self.num_mini_batch
@@ -320,6 +407,10 @@ class PPOAlgorithm(BaseAlgorithm):
         self._info.zero_()
         self.last_indices = []
         next_perm = None
+        self._jrpo_epoch_id = getattr(self, "_jrpo_epoch_id", 0) + 1  # a fresh records copy per train() call
+        if self.use_joint_action_loss:
+            self._full_batch_moments = False  # ValueNorm sees agent 0's returns only (to_single_np)
+            self._moments = self._moments_mb
         for epoch in range(self.ppo_epoch):
             if self.recurrent:  # get_data_generator (ppo.py:363-372)
                 batches, mbs = self._chunk_batches(M)
@@ -341,7 +432,10 @@ class PPOAlgorithm(BaseAlgorithm):
         # no device->host sync here: the averages stay on the device until somebody reads the dict (logging every
         # log_interval iterations, tests), so the host can enqueue the next rollout while this update still runs
         keys = self.info_keys
-        return DeviceTrainInfo(keys, self._info[:len(keys)] / float(num_updates))
+        scale = torch.full((len(keys),), 1.0 / float(num_updates), dtype=torch.float32, device=self.device)
+        if self.use_joint_action_loss:  # every agent row (and action dim) of a (step, chunk) carried the joint term
+            scale[1] /= float(buffer.num_agents * buffer.act_shape)
+        return DeviceTrainInfo(keys, self._info[:len(keys)] * scale)
 
     def train(self, buffer, turn_on: bool = True) -> Dict[str, float]:
         if len(self.train_list) == 1:

@@ -62,4 +62,39 @@ __device__ inline void sample_head(float (&hd)[NO], int n_out, const float* lds_
   }
 }
 
+// Evaluate GIVEN actions on the head outputs of batch row `row` (ACTLayer.evaluate_actions, utils/act.py:153-172):
+// log-probs (categorical: slot 0; Gaussian: per dimension) and the row's entropy (Gaussian: summed over dimensions).
+template <int NO, int HEAD>
+__device__ inline void eval_head(float (&hd)[NO], int n_out, const float* lds_logstd, const float* amask_row,
+                                 const float* given_row, float (&logp_out)[NO], float& ent_out) {
+#pragma unroll
+  for (int c = 0; c < NO; ++c) logp_out[c] = 0.f;
+  if (HEAD == ORL_HEAD_CATEGORICAL) {
+    const float lse = cat_lse<NO>(hd, n_out, amask_row);
+    const int a = (int)given_row[0];
+    logp_out[0] = pick<NO>(hd, a) - lse;
+    float ent = 0.f;
+#pragma unroll
+    for (int c = 0; c < NO; ++c) {
+      if (c < n_out) {
+        const float ell = hd[c] - lse;
+        ent -= __expf(ell) * ell;
+      }
+    }
+    ent_out = ent;
+  } else {
+    float ent = 0.f;
+#pragma unroll
+    for (int c = 0; c < NO; ++c) {
+      if (c < n_out) {
+        const float ls = lds_logstd[c], sd = expf(ls);
+        const float d = given_row[c] - hd[c];
+        logp_out[c] = -(d * d) / (2.f * (sd * sd)) - ls - 0.91893853320467274178f;
+        ent += 1.41893853320467274178f + ls;
+      }
+    }
+    ent_out = ent;
+  }
+}
+
 }  // namespace orl

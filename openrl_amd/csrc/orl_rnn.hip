@@ -27,6 +27,8 @@ namespace orl {
 struct RnnActArgs {
   orl_net_desc pnet, cnet;
   const float *ptheta, *ctheta, *pobs, *cobs, *hp_in, *hc_in, *masks, *amask, *forced;
+  const float* given;  // orl_rnn_eval_step: evaluate these actions [B, a] instead of sampling (NULL otherwise)
+  float* ent_out;      //                    per-row entropy [B]
   float *values, *actions, *logp, *hp_out, *hc_out;
   int B, deterministic;
   uint64_t seed, row0, rng_step;
@@ -92,6 +94,16 @@ __global__ __launch_bounds__(128) void rnn_act_kernel(RnnActArgs A) {
     float act_o[NO], lp_o[NO];
     const float* am = (A.amask != nullptr && row_ok) ? A.amask + (size_t)row * n_out : nullptr;
     const float* fr = (A.forced != nullptr && row_ok) ? A.forced + (size_t)row * a_w : nullptr;
+    if (A.given != nullptr) {  // evaluate mode: log-probs + entropy of the given actions
+      float ent = 0.f;
+      eval_head<NO, HEAD>(hd, n_out, th + tl.ologstd, am, A.given + (size_t)rr * a_w, lp_o, ent);
+      if (row_ok && q == 0) {
+#pragma unroll
+        for (int c = 0; c < NO; ++c)
+          if (c < a_w) A.logp[(size_t)row * a_w + c] = lp_o[c];
+        if (A.ent_out) A.ent_out[row] = ent;
+      }
+    } else {
     sample_head<NO, HEAD>(hd, n_out, th + tl.ologstd, am, fr, A.deterministic, A.seed, A.row0 + (uint64_t)row,
                           A.rng_step + (A.rng_dev ? *A.rng_dev : 0ull), act_o, lp_o);
     if (row_ok && q == 0) {
@@ -102,6 +114,7 @@ __global__ __launch_bounds__(128) void rnn_act_kernel(RnnActArgs A) {
           A.logp[(size_t)row * a_w + c] = lp_o[c];
         }
       }
+    }
     }
   } else {
     float v[1];
@@ -175,6 +188,16 @@ __global__ __launch_bounds__(256, 1) void rnn_act_lds_kernel(RnnActArgs A, int s
       float act_o[NO], lp_o[NO];
       const float* am = (A.amask != nullptr && row_ok) ? A.amask + (size_t)row * n_out : nullptr;
       const float* fr = (A.forced != nullptr && row_ok) ? A.forced + (size_t)row * a_w : nullptr;
+      if (A.given != nullptr) {  // evaluate mode
+        float ent = 0.f;
+        eval_head<NO, HEAD>(hd, n_out, lw + tw.logstd, am, A.given + (size_t)rr * a_w, lp_o, ent);
+        if (row_ok && q == 0) {
+#pragma unroll
+          for (int c = 0; c < NO; ++c)
+            if (c < a_w) A.logp[(size_t)row * a_w + c] = lp_o[c];
+          if (A.ent_out) A.ent_out[row] = ent;
+        }
+      } else {
       sample_head<NO, HEAD>(hd, n_out, lw + tw.logstd, am, fr, A.deterministic, A.seed, A.row0 + (uint64_t)row,
                             A.rng_step + (A.rng_dev ? *A.rng_dev : 0ull), act_o, lp_o);
       if (row_ok && q == 0) {
@@ -185,6 +208,7 @@ __global__ __launch_bounds__(256, 1) void rnn_act_lds_kernel(RnnActArgs A, int s
             A.logp[(size_t)row * a_w + c] = lp_o[c];
           }
         }
+      }
       }
     } else {
       float v[1];
@@ -206,6 +230,57 @@ __global__ void rnn_chunk_rows_kernel(const int64_t* __restrict__ chunk_idx, int
   const int64_t r = c * L + l;  // row of the [lane][t]-ordered flat batch (_cast, buffers/utils/util.py:96-97)
   const int64_t lane = r / T, t = r - lane * T;
   rows[e] = t * lanes + lane;
+}
+
+// recurrent_generator_v3 (buffers/replay_data.py:425-551, the joint-action loss): chunk c covers positions
+// c*L .. c*L+L-1 of the (n*T + t)-ordered batch with the AGENT AXIS KEPT (_cast_v3, buffers/utils/util.py:100-101);
+// a minibatch flattens [L, chunks, A], i.e. sequence (i, a) -> i*A + a.  agent0_only: one sequence per chunk (a = 0),
+// what the critic of the joint-action loss evaluates (ppo.py:254-262, to_single_np).
+__global__ void rnn_chunk_rows_v3_kernel(const int64_t* __restrict__ chunk_idx, int n_chunks, int L, int T, int A,
+                                         int lanes, int agent0_only, int64_t* __restrict__ rows) {
+  const int AA = agent0_only ? 1 : A;
+  const int ns = n_chunks * AA;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ns * L) return;
+  const int l = e / ns, sq = e - l * ns;
+  const int i = sq / AA, a = sq - i * AA;
+  const int64_t c = chunk_idx ? chunk_idx[i] : (int64_t)i;
+  const int64_t p = c * L + l;
+  const int64_t n = p / T, t = p - n * T;
+  rows[e] = t * lanes + n * A + a;
+}
+
+// Joint-action (JRPO) records: for every (step l, chunk i) of the minibatch the joint log-ratio
+//   S = sum over agents a and action dims d of (logp_new[l, i*A+a, d] - old_logp[row(l,i,a), d])
+// (ppo.py:281-300) is folded into the per-row fields the row kernel already reads, in a COPY of the records:
+//   old_logp'[a, d] = old_logp[a, d] - (S - (logp_new[a, d] - old_logp[a, d]))   => exp(lp - old') = exp(S), d/dlp = ratio
+//   adv'  = A * adv of agent 0,  active' = active of agent 0   (adv_targ[:, 0], active_masks_batch[:, 0]; the factor
+//   A cancels the A-fold denominator the row kernel accumulates over the agent rows).
+__global__ void rnn_jrpo_records_kernel(const float* __restrict__ rec, float* __restrict__ out, int R,
+                                        const int64_t* __restrict__ rows /*[L][n_chunks*A]*/, int n_chunks, int L, int A,
+                                        const float* __restrict__ logp_new /*[L][n_chunks*A][a_w]*/, int a_w, int o_lp,
+                                        int o_adv, int o_am) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_chunks * L) return;
+  const int l = e / n_chunks, i = e - l * n_chunks;
+  const int ns = n_chunks * A;
+  float S = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const int64_t r = rows[(size_t)l * ns + i * A + a];
+    for (int d = 0; d < a_w; ++d) S += logp_new[((size_t)l * ns + i * A + a) * a_w + d] - rec[(size_t)r * R + o_lp + d];
+  }
+  const int64_t r0 = rows[(size_t)l * ns + i * A];
+  const float adv0 = rec[(size_t)r0 * R + o_adv], act0 = rec[(size_t)r0 * R + o_am];
+  for (int a = 0; a < A; ++a) {
+    const int64_t r = rows[(size_t)l * ns + i * A + a];
+    for (int d = 0; d < a_w; ++d) {
+      const float old = rec[(size_t)r * R + o_lp + d];
+      const float own = logp_new[((size_t)l * ns + i * A + a) * a_w + d] - old;
+      out[(size_t)r * R + o_lp + d] = old - (S - own);
+    }
+    out[(size_t)r * R + o_adv] = (float)A * adv0;
+    out[(size_t)r * R + o_am] = act0;
+  }
 }
 
 // =====================================================================================================
@@ -1047,19 +1122,20 @@ int orl_rnn_raw_grad_count(const orl_net_desc* net) {
   return RnnRaw(*net).total;
 }
 
-int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
-                     const float* policy_obs, const float* critic_obs, const float* h_policy_in,
-                     const float* h_critic_in, const float* masks, const float* action_masks, int B,
-                     int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
-                     const float* forced_u, float* values, float* actions, float* logp, float* h_policy_out,
-                     float* h_critic_out, void* stream) {
+static int rnn_act_impl(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                        const float* policy_obs, const float* critic_obs, const float* h_policy_in,
+                        const float* h_critic_in, const float* masks, const float* action_masks, int B,
+                        int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
+                        const float* forced_u, const float* given, float* ent_out, float* values, float* actions,
+                        float* logp, float* h_policy_out, float* h_critic_out, void* stream) {
   ORL_REQUIRE(ptheta || ctheta, "orl_rnn_act_step: neither tower given");
   ORL_REQUIRE(B > 0 && masks, "orl_rnn_act_step: B=%d / null masks", B);
   int rc;
   if (ptheta) {
     rc = check_rnn_net(pnet, "orl_rnn_act_step(policy)", false);
     if (rc) return rc;
-    ORL_REQUIRE(policy_obs && actions && logp && h_policy_in && h_policy_out, "orl_rnn_act_step: null policy pointer");
+    ORL_REQUIRE(policy_obs && (actions || given) && logp && h_policy_in && h_policy_out,
+                "orl_rnn_act_step: null policy pointer");
   }
   if (ctheta) {
     rc = check_rnn_net(cnet, "orl_rnn_act_step(critic)", true);
@@ -1071,6 +1147,7 @@ int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_ne
   A.cnet = ctheta ? *cnet : *pnet;
   A.ptheta = ptheta; A.ctheta = ctheta; A.pobs = policy_obs; A.cobs = critic_obs; A.hp_in = h_policy_in;
   A.hc_in = h_critic_in; A.masks = masks; A.amask = action_masks; A.forced = forced_u; A.values = values;
+  A.given = given; A.ent_out = ent_out;
   A.actions = actions; A.logp = logp; A.hp_out = h_policy_out; A.hc_out = h_critic_out; A.B = B;
   A.deterministic = deterministic; A.seed = seed; A.row0 = row0; A.rng_step = rng_step; A.rng_dev = (const unsigned long long*)rng_step_dev;
   const int grid = (B + TILE_B - 1) / TILE_B;
@@ -1117,12 +1194,54 @@ int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_ne
   return launch_status("orl_rnn_act_step");
 }
 
+int orl_rnn_act_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                     const float* policy_obs, const float* critic_obs, const float* h_policy_in,
+                     const float* h_critic_in, const float* masks, const float* action_masks, int B,
+                     int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step, const uint64_t* rng_step_dev,
+                     const float* forced_u, float* values, float* actions, float* logp, float* h_policy_out,
+                     float* h_critic_out, void* stream) {
+  return rnn_act_impl(pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, h_policy_in, h_critic_in, masks, action_masks,
+                      B, deterministic, seed, row0, rng_step, rng_step_dev, forced_u, nullptr, nullptr, values, actions,
+                      logp, h_policy_out, h_critic_out, stream);
+}
+
+int orl_rnn_eval_step(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                      const float* policy_obs, const float* critic_obs, const float* h_policy_in,
+                      const float* h_critic_in, const float* masks, const float* action_masks, const float* actions,
+                      int B, float* values, float* logp, float* entropy, float* h_policy_out, float* h_critic_out,
+                      void* stream) {
+  ORL_REQUIRE(!ptheta || actions, "orl_rnn_eval_step: the policy tower needs the actions to evaluate");
+  return rnn_act_impl(pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, h_policy_in, h_critic_in, masks, action_masks,
+                      B, 1, 0, 0, 0, nullptr, nullptr, actions, entropy, values, nullptr, logp, h_policy_out,
+                      h_critic_out, stream);
+}
+
 int orl_rnn_chunk_rows(const int64_t* chunk_idx, int n_chunks, int L, int T, int lanes, int64_t* rows, void* stream) {
   ORL_REQUIRE(rows && n_chunks > 0 && L > 0 && T > 0 && lanes > 0, "orl_rnn_chunk_rows: bad arguments");
   const int n = n_chunks * L;
   hipLaunchKernelGGL(rnn_chunk_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunk_idx,
                      n_chunks, L, T, lanes, rows);
   return launch_status("orl_rnn_chunk_rows");
+}
+
+int orl_rnn_chunk_rows_v3(const int64_t* chunk_idx, int n_chunks, int L, int T, int n_envs, int n_agents, int agent0_only,
+                          int64_t* rows, void* stream) {
+  ORL_REQUIRE(rows && n_chunks > 0 && L > 0 && T > 0 && n_envs > 0 && n_agents > 0, "orl_rnn_chunk_rows_v3: bad arguments");
+  const int n = n_chunks * (agent0_only ? 1 : n_agents) * L;
+  hipLaunchKernelGGL(rnn_chunk_rows_v3_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunk_idx,
+                     n_chunks, L, T, n_agents, n_envs * n_agents, agent0_only, rows);
+  return launch_status("orl_rnn_chunk_rows_v3");
+}
+
+int orl_rnn_jrpo_records(const float* records, float* records_out, int rec_width, int Dp, int Dc, int a_w,
+                         const int64_t* rows, int n_chunks, int L, int n_agents, const float* logp_new, void* stream) {
+  ORL_REQUIRE(records && records_out && rows && logp_new && n_chunks > 0 && L > 0 && n_agents > 0 && a_w > 0,
+              "orl_rnn_jrpo_records: bad arguments");
+  const int o_lp = Dp + Dc + a_w, o_adv = o_lp + a_w;
+  const int n = n_chunks * L;
+  hipLaunchKernelGGL(rnn_jrpo_records_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, records,
+                     records_out, rec_width, rows, n_chunks, L, n_agents, logp_new, a_w, o_lp, o_adv, o_adv + 3);
+  return launch_status("orl_rnn_jrpo_records");
 }
 
 int64_t orl_rnn_workspace_floats(const orl_net_desc* pnet, const orl_net_desc* cnet, int n_chunks, int L) {
@@ -1153,13 +1272,16 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
   A.R = batch->rec_width; A.Nc = batch->n_chunks; A.L = batch->L;
   A.cols.o_act = o_ac; A.cols.o_lp = o_lp; A.cols.o_adv = o_adv; A.cols.o_vp = o_adv + 1; A.cols.o_rt = o_adv + 2;
   A.cols.o_am = o_adv + 3; A.cols.o_mk = o_adv + 4; A.cols.K = K;
-  const RnnWs wp(*pnet, batch->n_chunks, batch->L), wc(*cnet, batch->n_chunks, batch->L);
+  const int nc_c = batch->rows_critic ? batch->n_chunks_critic : batch->n_chunks;  // joint-action loss: agent 0 only
+  ORL_REQUIRE(nc_c > 0 && nc_c <= batch->n_chunks, "orl_rnn_ppo_fwd_bwd: %d critic sequences", nc_c);
+  const RnnWs wp(*pnet, batch->n_chunks, batch->L), wc(*cnet, nc_c, batch->L);
   float* base_p = workspace;
   float* base_c = workspace + wp.total;
   RnnRowArgs C2 = A;
   A.net = *pnet; A.theta = ptheta; A.hbuf = batch->h_policy; A.o_x = 0;
   A.htape = base_p + wp.htape; A.tape = base_p + wp.tape; A.partials = base_p + wp.rpart;
   C2.net = *cnet; C2.theta = ctheta; C2.hbuf = batch->h_critic; C2.o_x = o_co;
+  if (batch->rows_critic) { C2.rows = batch->rows_critic; C2.Nc = nc_c; }
   C2.htape = base_c + wc.htape; C2.tape = base_c + wc.tape; C2.partials = base_c + wc.rpart;
   // (1) row kernels of both towers, one launch
   const int no = pnet->n_out;

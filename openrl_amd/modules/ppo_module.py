@@ -234,17 +234,19 @@ class PPOModule:
     def __init__(self, cfg, policy_input_space, critic_input_space, act_space, share_model: bool = False,
                  device: Union[str, torch.device] = "cuda:0", rank: Optional[int] = None,
                  world_size: Optional[int] = None, model_dict: Optional[Dict[str, Any]] = None):
+        # this class = the fused default-tower kernels (feed-forward or GRU); every other feed-forward configuration was
+        # routed to GenericPPOModule by __new__, so what is refused here is a RECURRENT policy outside the default tower
         if share_model or cfg.use_share_model:
-            raise NotImplementedError("use_share_model (PolicyValueNetwork) is not built in the MI355X engine")
+            raise NotImplementedError("use_share_model with use_recurrent_policy is not built (feed-forward only)")
         if model_dict:
-            raise NotImplementedError("custom model_dict towers are not built: the engine runs fixed MFMA towers")
+            raise NotImplementedError("custom model_dict towers are not built: the engine runs its own towers")
         for flag in ("use_naive_recurrent_policy", "use_influence_policy", "use_popart",
                      "use_feature_normalization", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp",
-                     "use_deepspeed", "use_joint_action_loss", "use_single_network"):
+                     "use_deepspeed", "use_single_network"):
             if getattr(cfg, flag, False):
                 raise NotImplementedError("cfg.%s=True is not built in the MI355X engine yet" % flag)
         if cfg.layer_N != 1 or cfg.hidden_size != 64 or cfg.activation_id != 1:
-            raise NotImplementedError("MI355X towers are built for layer_N=1, hidden_size=64, ReLU (got %d, %d, %d)"
+            raise NotImplementedError("recurrent towers are built for layer_N=1, hidden_size=64, ReLU (got %d, %d, %d)"
                                       % (cfg.layer_N, cfg.hidden_size, cfg.activation_id))
         self.recurrent = bool(cfg.use_recurrent_policy)
         if self.recurrent and (cfg.recurrent_N != 1 or getattr(cfg, "rnn_type", "gru") != "gru"):
@@ -375,7 +377,8 @@ class PPOModule:
         Returns ``(values, action_log_probs, dist_entropy, policy_values=None)`` like ppo_module.py:149-193;
         the entropy is the active-mask weighted mean when ``cfg.use_policy_active_masks`` (policy_network.py:199)."""
         if self.recurrent:
-            raise NotImplementedError("evaluate_actions over recurrent chunks runs inside orl_rnn_ppo_fwd_bwd only")
+            return self._evaluate_actions_rnn(critic_obs, obs, rnn_states_actor, rnn_states_critic, action, masks,
+                                              action_masks, active_masks, critic_masks_batch)
         p, c = self.models["policy"], self.models["critic"]
         x = self._dev(obs, p.net.obs_dim)
         xc = self._dev(critic_obs, c.net.obs_dim)
@@ -390,6 +393,50 @@ class PPOModule:
         values, logp, ent_rows, ent = f(B, 1), f(B, self.act_width), f(B), f(1)
         ops.evaluate_actions(p.net, p.theta, c.net, c.theta, x, xc, act, am, active, B, values, logp, ent_rows, ent)
         return values, logp, ent[0], None
+
+    @torch.no_grad()
+    def _evaluate_actions_rnn(self, critic_obs, obs, h_policy, h_critic, action, masks, action_masks, active_masks,
+                              critic_masks=None, critic_states_rows=None):
+        """Recurrent evaluate_actions (policy_network.py:164-203 + RNNLayer.forward, rnn.py:39-99), forward only:
+        the rows are ``L`` steps of ``N`` sequences flattened as [L*N, ...] (the layout of recurrent_generator,
+        replay_data.py:1207-1256), the states [N, (1,) H] enter step 0; every step multiplies the carried state by that
+        step's mask.  ``critic_*`` may describe FEWER sequences than the policy's (the joint-action loss evaluates the
+        critic on agent 0 only): sizes are taken from the state tensors.  One orl_rnn_eval_step per step and tower."""
+        p, c = self.models["policy"], self.models["critic"]
+        H = p.net.hidden
+        x, act = self._dev(obs, p.net.obs_dim), self._dev(action, self.act_width)
+        hp = self._dev(h_policy, H)
+        Np, Bp = hp.shape[0], x.shape[0]
+        assert Bp % Np == 0, "rows must be L steps of the %d policy sequences" % Np
+        L = Bp // Np
+        mk = self._dev(masks, 1).reshape(-1)
+        am = self._dev(action_masks, p.net.n_out) if (action_masks is not None and p.net.head_kind ==
+                                                       ops.HEAD_CATEGORICAL) else None
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=self.device)
+        logp, ent = f(Bp, self.act_width), f(Bp)
+        hp = hp.clone()
+        for s in range(L):
+            r = slice(s * Np, (s + 1) * Np)
+            ops_rnn.rnn_eval_step(p.net, p.theta, None, None, x[r], None, hp, None, mk[r], None if am is None else am[r],
+                                  act[r], Np, None, logp[r], ent[r], hp, None)
+        values = None
+        if critic_obs is not None:
+            xc = self._dev(critic_obs, c.net.obs_dim)
+            hc = self._dev(h_critic, H).clone()
+            Nc = hc.shape[0]
+            assert xc.shape[0] == L * Nc, "critic rows must be the same L steps of its %d sequences" % Nc
+            mkc = mk if critic_masks is None else self._dev(critic_masks, 1).reshape(-1)
+            values = f(L * Nc, 1)
+            for s in range(L):
+                r = slice(s * Nc, (s + 1) * Nc)
+                ops_rnn.rnn_eval_step(None, None, c.net, c.theta, None, xc[r], None, hc, mkc[r], None, None, Nc, values[r],
+                                      None, None, None, hc)
+        if active_masks is not None and self.cfg.use_policy_active_masks:
+            w = self._dev(active_masks, 1).reshape(-1)
+            dist_entropy = (ent * w).sum() / w.sum()
+        else:
+            dist_entropy = ent.mean() / (p.net.n_out if p.net.head_kind == ops.HEAD_GAUSSIAN else 1)
+        return values, logp, dist_entropy, None
 
     def act(self, obs, rnn_states_actor, masks, action_masks=None, deterministic=False):
         if self.recurrent:

@@ -46,6 +46,18 @@ def rnn_act_step(pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, h_policy_in
     nat.check(rc, "orl_rnn_act_step")
 
 
+def rnn_eval_step(pnet, ptheta, cnet, ctheta, policy_obs, critic_obs, h_policy_in, h_critic_in, masks, action_masks,
+                  actions, B: int, values, logp, entropy, h_policy_out, h_critic_out) -> None:
+    """One recurrent step of evaluate_actions: log-probs / entropy of the GIVEN actions, values, new hidden states."""
+    dev = _dev(masks)
+    rc = _lib().orl_rnn_eval_step(C.byref(pnet) if pnet is not None else None, fptr(ptheta),
+                                  C.byref(cnet) if cnet is not None else None, fptr(ctheta), fptr(policy_obs),
+                                  fptr(critic_obs), fptr(h_policy_in), fptr(h_critic_in), fptr(masks),
+                                  fptr(action_masks), fptr(actions), B, fptr(values), fptr(logp), fptr(entropy),
+                                  fptr(h_policy_out), fptr(h_critic_out), stream_ptr(dev))
+    nat.check(rc, "orl_rnn_eval_step")
+
+
 def rnn_chunk_rows(chunk_idx, n_chunks: int, L: int, T: int, lanes: int, rows: torch.Tensor) -> None:
     dev = _dev(rows)
     assert rows.dtype == torch.int64 and rows.numel() >= n_chunks * L
@@ -60,11 +72,30 @@ def rnn_workspace_floats(pnet, cnet, n_chunks: int, L: int) -> int:
     return int(n)
 
 
+def rnn_chunk_rows_v3(chunk_idx, n_chunks: int, L: int, T: int, n_envs: int, n_agents: int, agent0_only: bool,
+                      rows: torch.Tensor) -> None:
+    """recurrent_generator_v3 rows (agent axis kept): rows[l, i*A + a] (or rows[l, i] for agent 0 only)."""
+    dev = _dev(rows)
+    assert rows.dtype == torch.int64 and rows.numel() >= n_chunks * L * (1 if agent0_only else n_agents)
+    rc = _lib().orl_rnn_chunk_rows_v3(ptr(chunk_idx), n_chunks, L, T, n_envs, n_agents, int(bool(agent0_only)), ptr(rows),
+                                      stream_ptr(dev))
+    nat.check(rc, "orl_rnn_chunk_rows_v3")
+
+
+def rnn_jrpo_records(records, records_out, Dp: int, Dc: int, a_w: int, rows, n_chunks: int, L: int, n_agents: int,
+                     logp_new) -> None:
+    dev = _dev(records)
+    rc = _lib().orl_rnn_jrpo_records(fptr(records), fptr(records_out), records.shape[1], Dp, Dc, a_w, ptr(rows), n_chunks,
+                                     L, n_agents, fptr(logp_new), stream_ptr(dev))
+    nat.check(rc, "orl_rnn_jrpo_records")
+
+
 def rnn_ppo_fwd_bwd(pnet, ptheta, cnet, ctheta, records, rows, masks, h_policy, h_critic, n_chunks: int, L: int,
-                    vn_state, hp: PPOHParams, workspace, sums) -> None:
+                    vn_state, hp: PPOHParams, workspace, sums, rows_critic=None, n_chunks_critic: int = 0) -> None:
+    """``rows_critic`` / ``n_chunks_critic``: the critic tower's own sequences (joint-action loss: agent 0 only)."""
     dev = _dev(records)
     b = RnnBatch(fptr(records), ptr(rows), fptr(masks), fptr(h_policy), fptr(h_critic), records.shape[1], n_chunks, L,
-                 0)
+                 n_chunks_critic, ptr(rows_critic))
     rc = _lib().orl_rnn_ppo_fwd_bwd(C.byref(pnet), fptr(ptheta), C.byref(cnet), fptr(ctheta), C.byref(b),
                                     fptr(vn_state), C.byref(hp), fptr(workspace), fptr(sums), stream_ptr(dev))
     nat.check(rc, "orl_rnn_ppo_fwd_bwd")

@@ -550,6 +550,11 @@ def main():
             lambda: Discrete(5), N=6, A=3, T=7, seed=5),
         # BASELINE.json configs[1] at full size (what bench.py runs): only outputs are stored, inputs come from a seed
         "train_cfg2_full": lambda n: _train_case_full(n, ["--ppo_epoch", "10", "--num_mini_batch", "1"], 4096, 128, 4, 2),
+        # JRPO: use_joint_action_loss -> recurrent_generator_v3 (agent axis kept) + joint ratio, critic on agent 0 only
+        # (algorithms/ppo.py:254-300, buffers/replay_data.py:425-551)
+        "train_recurrent_jrpo": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--use_joint_action_loss", "true", "--lr", "7e-4",
+                "--critic_lr", "7e-4"], 18, 54, lambda: Discrete(5), N=6, A=3, T=8, seed=8),
         "train_recurrent_chunk5": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--data_chunk_length", "5"], 6, 6,
             lambda: Box(-1, 1, (2,)), N=5, A=1, T=10, seed=6),

@@ -241,3 +241,112 @@ def train_ppo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, buf: Dict[str,
                 info[k] += step_info[k]
     n_upd = ppo_epoch * num_mini_batch
     return {k: v / n_upd for k, v in info.items()}, adv, used
+
+
+# ------------------------------------------------------------------------------------------ joint-action loss (JRPO)
+def cast_v3(x: np.ndarray) -> np.ndarray:
+    """``_cast_v3`` (buffers/utils/util.py:100-101): [T, N, A, w] -> [N*T, A, w], position = n*T + t."""
+    return np.ascontiguousarray(x.transpose(1, 0, 2, 3)).reshape(-1, *x.shape[2:])
+
+
+def buffer_rows_v3(buf: Dict[str, np.ndarray], adv: np.ndarray) -> Dict[str, Optional[np.ndarray]]:
+    """The views of recurrent_generator_v3 (replay_data.py:446-472): the agent axis is kept."""
+    H = buf["rnn_states"].shape[-1]
+    cs = lambda x: np.ascontiguousarray(x[:-1].transpose(1, 0, 2, 3, 4)).reshape(-1, x.shape[2], H)
+    return {
+        "critic_obs": cast_v3(buf["critic_obs"][:-1]), "policy_obs": cast_v3(buf["policy_obs"][:-1]),
+        "actions": cast_v3(buf["actions"]), "value_preds": cast_v3(buf["value_preds"][:-1]),
+        "returns": cast_v3(buf["returns"][:-1]), "masks": cast_v3(buf["masks"][:-1]),
+        "active_masks": cast_v3(buf["active_masks"][:-1]), "action_log_probs": cast_v3(buf["action_log_probs"]),
+        "adv": cast_v3(adv),
+        "action_masks": cast_v3(buf["action_masks"][:-1]) if buf.get("action_masks") is not None else None,
+        "rnn_states": cs(buf["rnn_states"]), "rnn_states_critic": cs(buf["rnn_states_critic"]),
+    }
+
+
+def chunk_sample_v3(rows: Dict[str, Optional[np.ndarray]], chunks: np.ndarray, L: int):
+    """One minibatch of replay_data.py:474-551: [L, Nc, A, w] flattened to [L*Nc*A, w] (row = (l*Nc + i)*A + a);
+    rnn states [Nc*A, H] from each chunk's first position."""
+    first = np.asarray(chunks, dtype=np.int64) * L
+    pidx = first[None, :] + np.arange(L, dtype=np.int64)[:, None]  # [L, Nc] positions
+    out = {}
+    for k, v in rows.items():
+        if v is None:
+            out[k] = None
+        elif k in ("rnn_states", "rnn_states_critic"):
+            out[k] = v[first].reshape(-1, v.shape[-1])
+        else:
+            out[k] = v[pidx].reshape(-1, v.shape[-1])
+    return out
+
+
+def prepare_loss_jrpo(hp: po.PPOHyper, pspec, ptheta, cspec, ctheta, vn, s: Dict[str, torch.Tensor], A: int):
+    """PPOAlgorithm.prepare_loss with use_joint_action_loss (ppo.py:254-361): the critic sees agent 0's rows only
+    (to_single_np), the ratio is the exponential of the log-ratio summed over agents and action dimensions, the
+    advantage and the active mask are agent 0's; the entropy still averages over every agent row."""
+    single = lambda x: x.reshape(-1, A, *x.shape[1:])[:, 0, ...]
+    critic_obs, h_c, critic_masks = single(s["critic_obs"]), single(s["rnn_states_critic"]), single(s["masks"])
+    value_preds, returns = single(s["value_preds"]), single(s["returns"])
+    adv = s["adv"].reshape(-1, A, 1)[:, 0, :]
+    values, _ = rnn_tower_forward(cspec, ctheta, critic_obs, h_c, critic_masks)
+    out, _ = rnn_tower_forward(pspec, ptheta, s["policy_obs"], s["rnn_states"], s["masks"])
+    active_all, old_logp, action = s["active_masks"], s["action_log_probs"], s["actions"]
+    am = active_all if hp.use_policy_active_masks else None
+    if pspec.head == HEAD_CATEGORICAL:
+        dist = torch.distributions.Categorical(logits=po.masked_logits(out, s["action_masks"]))
+        logp = dist.log_prob(action.squeeze(-1).long()).view(action.size(0), -1).sum(-1).unsqueeze(-1)
+        ent = dist.entropy()
+        dist_entropy = (ent * am.squeeze(-1)).sum() / am.sum() if am is not None else ent.mean()
+    else:
+        std = pspec.split(ptheta)["logstd"].exp()
+        dist = torch.distributions.Normal(out, std.expand_as(out))
+        logp = dist.log_prob(action)
+        ent = dist.entropy()
+        dist_entropy = (ent * am).sum() / am.sum() if am is not None else ent.mean()
+    joint = lambda x: x.reshape(-1, A, x.shape[-1]).sum(dim=(1, -1), keepdim=True).reshape(-1, 1)
+    ratio = torch.exp(joint(logp) - joint(old_logp))
+    active = active_all.reshape(-1, A, 1)[:, 0, :]
+    if hp.dual_clip_ppo:
+        ratio = torch.min(ratio, torch.tensor(hp.dual_clip_coeff))
+    surr_final = torch.min(ratio * adv, torch.clamp(ratio, 1.0 - hp.clip_param, 1.0 + hp.clip_param) * adv)
+    if hp.use_policy_active_masks:
+        policy_loss = (-torch.sum(surr_final, dim=-1, keepdim=True) * active).sum() / active.sum()
+    else:
+        policy_loss = -torch.sum(surr_final, dim=-1, keepdim=True).mean()
+    value_loss = po.cal_value_loss(hp, vn, values, value_preds, returns, active)
+    return [policy_loss - dist_entropy * hp.entropy_coef, value_loss * hp.value_loss_coef], value_loss, policy_loss, \
+        dist_entropy, ratio
+
+
+def train_ppo_jrpo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, buf: Dict[str, np.ndarray], ppo_epoch: int,
+                   num_mini_batch: int, data_chunk_length: int):
+    """train_ppo (ppo.py:383-458) with recurrent_generator_v3 + the joint-action loss."""
+    adv = po.advantages(buf["returns"], buf["value_preds"], buf["active_masks"], vn if hp.use_valuenorm else None,
+                        hp.use_adv_normalize)
+    rows = buffer_rows_v3(buf, adv)
+    A = buf["actions"].shape[2]
+    positions = rows["adv"].shape[0]  # N*T
+    keys = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
+    info = {k: 0.0 for k in keys}
+    used = []
+    t = lambda a: None if a is None else torch.as_tensor(a, dtype=torch.float32)
+    for _ in range(ppo_epoch):
+        for chunks in recurrent_chunk_order(positions, data_chunk_length, num_mini_batch):
+            used.append(np.asarray(chunks).copy())
+            s = {k: t(v) for k, v in chunk_sample_v3(rows, chunks, data_chunk_length).items()}
+            pth = ptheta.detach().clone().requires_grad_(True)
+            cth = ctheta.detach().clone().requires_grad_(True)
+            loss_list, value_loss, policy_loss, dist_entropy, ratio = prepare_loss_jrpo(
+                hp, pspec, pth, cspec, cth, vn if hp.use_valuenorm else None, s, A)
+            for loss in loss_list:
+                loss.backward()
+            gp, an = po.clip_grad_norm(pth.grad, hp.max_grad_norm) if hp.use_max_grad_norm else (pth.grad, float(pth.grad.norm(2)))
+            gc, cn = po.clip_grad_norm(cth.grad, hp.max_grad_norm) if hp.use_max_grad_norm else (cth.grad, float(cth.grad.norm(2)))
+            padam.step(ptheta, gp)
+            cadam.step(ctheta, gc)
+            step = dict(value_loss=value_loss.item(), policy_loss=policy_loss.item(), dist_entropy=dist_entropy.item(),
+                        actor_grad_norm=an, critic_grad_norm=cn, ratio=ratio.mean().item())
+            for k in keys:
+                info[k] += step[k]
+    n_upd = ppo_epoch * num_mini_batch
+    return {k: v / n_upd for k, v in info.items()}, adv, used

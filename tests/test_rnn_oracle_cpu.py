@@ -80,3 +80,27 @@ def test_rollout_states_in_the_golden_buffer_follow_the_oracle_cell():
         keep = g["buf_masks"][t + 1].reshape(-1) == 1.0
         np.testing.assert_allclose(h1.numpy()[keep], want[keep], rtol=1e-5, atol=1e-6)
         assert np.all(want[~keep] == 0.0)
+
+
+def test_jrpo_oracle_replays_the_reference_golden():
+    """use_joint_action_loss: recurrent_generator_v3 (agent axis kept, replay_data.py:425-551) + the joint ratio over
+    agents with agent 0's advantage / active mask and the critic on agent 0's rows only (ppo.py:254-300), against the
+    golden replay of the REAL reference (oracle/gen_golden.py, case train_recurrent_jrpo)."""
+    g = H.load_golden("train_recurrent_jrpo")
+    cfg = H.case_cfg(g)
+    assert cfg.use_joint_action_loss and cfg.use_recurrent_policy
+    hp = po.hyper_from_cfg(cfg)
+    pspec, cspec = RH.rnn_specs(g)
+    pt, ct = torch.tensor(g["theta_p0"]).clone(), torch.tensor(g["theta_c0"]).clone()
+    pa = po.AdamOracle(pt.numel(), cfg.lr, cfg.opti_eps, cfg.weight_decay)
+    ca = po.AdamOracle(ct.numel(), cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)
+    vn = po.ValueNormOracle()
+    torch.manual_seed(int(g["perm_seed"]))
+    info, _, used = ro.train_ppo_jrpo(hp, pspec, pt, cspec, ct, pa, ca, vn, H.case_buffer(g), cfg.ppo_epoch,
+                                      cfg.num_mini_batch, cfg.data_chunk_length)
+    T, N, A = g["buf_actions"].shape[:3]
+    assert len(used) == cfg.ppo_epoch * cfg.num_mini_batch and used[0].size == (N * T // cfg.data_chunk_length) // cfg.num_mini_batch
+    np.testing.assert_allclose([info[k] for k in KEYS], g["train_info"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(pt.numpy(), g["theta_p1"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(ct.numpy(), g["theta_c1"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(vn.state(), g["vn_state1"], rtol=1e-6)

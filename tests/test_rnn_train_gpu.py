@@ -158,3 +158,68 @@ def test_recurrent_agent_trains_on_a_host_multiagent_env():
     agent.reset()
     action, _ = agent.act(obs)
     assert action.shape == (N, A, 1)
+
+
+def _fill(buf, g):
+    for f in ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks",
+              "bad_masks", "active_masks", "action_masks", "rnn_states", "rnn_states_critic"):
+        if "buf_" + f in g and getattr(buf, f) is not None:
+            getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+
+
+@pytest.mark.parametrize("perm_mode", ["reference", "device"])
+def test_jrpo_train_matches_reference_golden(perm_mode):
+    """use_joint_action_loss (JRPO): recurrent_generator_v3 + joint ratio over agents, critic on agent 0 only
+    (algorithms/ppo.py:254-300, buffers/replay_data.py:425-551) - the engine's pre-pass + adjusted-records update against
+    the REAL reference's PPOAlgorithm.train (golden train_recurrent_jrpo)."""
+    g = H.load_golden("train_recurrent_jrpo")
+    cfg, module, buf, algo = build_engine(g)
+    assert algo.use_joint_action_loss and algo.recurrent
+    module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+    module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+    _fill(buf, g)
+    algo.perm_mode = perm_mode
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    info = algo.train(buf)
+    T, N, A = g["buf_actions"].shape[:3]
+    n_chunks = (N * T // cfg.data_chunk_length) // cfg.num_mini_batch
+    assert len(algo.last_indices) == cfg.ppo_epoch * cfg.num_mini_batch and algo.last_indices[0].numel() == n_chunks
+    if perm_mode == "reference":  # with two minibatches per epoch only the reference's own chunk order is comparable
+        np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
+        np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+        np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+        np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
+    else:
+        assert np.isfinite([info[k] for k in KEYS]).all()
+        assert abs(info["ratio"] - 1.0) < 0.05 and 0.5 < info["dist_entropy"] < 1.7
+
+
+def test_recurrent_evaluate_actions_vs_oracle():
+    """PPOModule.evaluate_actions with recurrent networks outside the update (ppo_module.py:149-193, rnn.py:39-99):
+    L steps of N sequences flattened [L*N, ...], states [N, H] entering step 0 - values, log-probs and the masked mean
+    entropy against the oracle's unrolled GRU towers on a golden chunk sample."""
+    g = H.load_golden("train_recurrent")
+    cfg, module, buf, algo = build_engine(g)
+    module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+    module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+    pspec, cspec = RH.rnn_specs(g)
+    b = H.case_buffer(g)
+    adv = np.zeros_like(b["rewards"])
+    rows = ro.buffer_rows(b, adv)
+    L = 2
+    chunks = np.arange(rows["adv"].shape[0] // L)[::3]
+    s = ro.chunk_sample(rows, chunks, L)
+    t = lambda a: None if a is None else torch.as_tensor(a, dtype=torch.float32)
+    pth, cth = torch.tensor(g["theta_p0"]), torch.tensor(g["theta_c0"])
+    want_v, _ = ro.rnn_tower_forward(cspec, cth, t(s["critic_obs"]), t(s["rnn_states_critic"]), t(s["masks"]))
+    out, _ = ro.rnn_tower_forward(pspec, pth, t(s["policy_obs"]), t(s["rnn_states"]), t(s["masks"]))
+    dist = torch.distributions.Categorical(logits=po.masked_logits(out, t(s["action_masks"])))
+    want_lp = dist.log_prob(t(s["actions"]).squeeze(-1).long()).unsqueeze(-1)
+    am = t(s["active_masks"])
+    want_ent = (dist.entropy() * am.squeeze(-1)).sum() / am.sum()
+    v, lp, ent, _ = module.evaluate_actions(s["critic_obs"], s["policy_obs"], s["rnn_states"], s["rnn_states_critic"],
+                                            s["actions"], s["masks"], s["action_masks"], s["active_masks"])
+    np.testing.assert_allclose(v.cpu().numpy(), want_v.detach().numpy(), rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(lp.cpu().numpy(), want_lp.detach().numpy(), rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(float(ent), float(want_ent), rtol=1e-4)
