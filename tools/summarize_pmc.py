@@ -2,10 +2,13 @@
 
     python tools/summarize_pmc.py fetch.csv write.csv > profiles/rNN_pmc_hbm.json
 
-Units: the counters are KB per dispatch.  gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B
-per 128-B request for wide coalesced streams, i.e. it under-reports such streams by 2x - calibrated here on the
-GAE scan whose read set is known exactly (3 arrays of T*L floats + the value bootstrap).  Both the raw and the x2
-figures are reported for the tower kernels; `bench.py` quotes the raw sum as `roofline.traffic`."""
+Units: the counters are KiB per dispatch.  Calibration on gfx950 (tools/pmc_calibrate.hip, 512 MiB per pattern,
+profiles/r02_pmc_calibration.json): WRITE_SIZE is exact; FETCH_SIZE reports exactly 1/2 of a COALESCED stream at 16 B,
+4 B per lane and for the 16-B global_load_lds DMA alike (128-B requests tallied at 64 B, MI355X_MICROARCH.md), and is
+EXACT for 64-byte rows gathered at scattered positions (one 64-B request per row).  Hence per kernel:
+  streaming kernels (gae_scan, adv_normalize_pack, ppo_reduce_pair, rollout): bytes = 2 * FETCH + WRITE
+  tower kernels: records are 64-B rows at permuted positions (exact), the int64 index stream is coalesced (1/2):
+                 bytes = FETCH + (index bytes) / 2 + WRITE."""
 import csv
 import json
 import sys
@@ -41,18 +44,22 @@ def main():
             f, w = fetch.get(key, []), write.get(key, [])
             out[key] = {"FETCH_SIZE_KB_mean": round(sum(f) / max(len(f), 1), 1), "launches_fetch": len(f),
                         "WRITE_SIZE_KB_mean": round(sum(w) / max(len(w), 1), 1), "launches_write": len(w)}
+    for key in ("gae_scan", "adv_normalize_pack", "ppo_reduce_pair", "rollout_fused"):
+        if key in out:  # coalesced streams: FETCH_SIZE is half the bytes (calibration above)
+            out[key]["hbm_bytes_per_launch"] = int((2 * out[key]["FETCH_SIZE_KB_mean"] + out[key]["WRITE_SIZE_KB_mean"]) * 1024)
     towers = ("ppo_tower_pair",) if "ppo_tower_pair" in out else ("ppo_tower_policy", "ppo_tower_critic")
     if all(k in out for k in towers):
         raw = sum(out[k]["FETCH_SIZE_KB_mean"] + out[k]["WRITE_SIZE_KB_mean"] for k in towers)
-        x2 = sum(2 * out[k]["FETCH_SIZE_KB_mean"] + out[k]["WRITE_SIZE_KB_mean"] for k in towers)
+        idx_bytes = 2 * ROWS * 8  # both towers stream the int64 permutation
         out["orl_ppo_fwd_bwd_pair"] = {
-            "hbm_bytes_per_launch_raw": int(raw * 1024), "hbm_bytes_per_launch_fetch_x2": int(x2 * 1024),
-            "algorithmic_bytes_per_launch": 2 * ROWS * REC_BYTES + 2 * ROWS * 8 + 256 * 4 * (4626 + 4561),
-            "note": "FETCH_SIZE/WRITE_SIZE from separate rocprofv3 --pmc passes (KB). gfx950 FETCH_SIZE counts 64 B per "
-                    "128-B request for wide coalesced streams (exact x2 on the GAE stream); the tower kernels gather "
-                    "64-B records by 16-B-per-lane DMA, uncalibrated, so both raw and x2 are given. Algorithmic = "
-                    "records + int64 indices read by both towers + the 256 per-workgroup partial rows written "
-                    "(4626 / 4561 floats per row for the policy / critic tower of configs[1])."}
+            "hbm_bytes_per_launch": int(raw * 1024) + idx_bytes // 2, "hbm_bytes_per_launch_raw": int(raw * 1024),
+            "algorithmic_bytes_per_launch": 2 * ROWS * REC_BYTES + idx_bytes + 256 * 4 * (4626 + 4561),
+            "note": "FETCH_SIZE / WRITE_SIZE (KiB) from separate rocprofv3 --pmc passes. Calibrated (tools/pmc_calibrate.hip, "
+                    "profiles/r02_pmc_calibration.json): WRITE_SIZE exact; FETCH_SIZE exact for the 64-B records gathered "
+                    "at permuted rows, 1/2 for the coalesced int64 index stream - hbm_bytes_per_launch adds the missing "
+                    "half of the index bytes to the raw sum. Algorithmic = records + indices read by both towers + the "
+                    "256 per-workgroup partial rows written (4626 / 4561 floats per row for the policy / critic tower of "
+                    "configs[1]); the second tower finds part of the shared record lines in L2 / Infinity Cache."}
     json.dump(out, sys.stdout, indent=1)
 
 
