@@ -723,41 +723,54 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // ---- workgroup reduction of the waves' accumulators, fixed order (deterministic) ---------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before LDS is reused
   __syncthreads();
-  float* acc = smem + tw.total;  // reuse the slab area: [rl.total + ORL_N_STATS]
+  // The waves' accumulators are combined in a few PARALLEL rounds instead of one serial round per wave: the slab area
+  // holds up to NREG full images of the partial row; in round p waves [p*NREG, (p+1)*NREG) each write (p == 0) or add
+  // (p > 0) their accumulators into image (wave % NREG), and the images are then summed element-wise in image order.
+  // Every element is produced by the same fixed sequence of additions on every launch (deterministic), the 8 serial
+  // read-modify-write rounds + zero fill of the first version become 2 rounds + one pass at configuration 2.
   const int PW = rl.total + ORL_N_STATS;
-  for (int e = threadIdx.x; e < PW; e += blockDim.x) acc[e] = 0.f;
+  float* img0 = smem + tw.total;  // reuse the slab area
+  int NREG = (nwv * per_wave) / PW;
+  NREG = NREG > 4 ? 4 : NREG < 1 ? 1 : NREG;
+  while (nwv % NREG) --NREG;
+  // only the statistics tail has slots no wave writes: zero it in every image, the rest is written by round 0
+  for (int e = threadIdx.x; e < NREG * ORL_N_STATS; e += blockDim.x)
+    img0[(size_t)(e / ORL_N_STATS) * PW + rl.total + (e % ORL_N_STATS)] = 0.f;
   __syncthreads();
   st_active = wave_sum(st_active); st_rows = wave_sum(st_rows); st_loss = wave_sum(st_loss);
   st_ent = wave_sum(st_ent); st_ratio = wave_sum(st_ratio);
-  for (int w = 0; w < nwv; ++w) {
-    if (wave == w) {
+  float* acc = img0 + (size_t)(wave % NREG) * PW;
+  for (int p = 0; p < nwv / NREG; ++p) {
+    if (wave / NREG == p) {
+      const bool first = p == 0;
+      auto put = [&](int idx, float v) { acc[idx] = first ? v : acc[idx] + v; };
       // G tiles: lane (c = j, q), reg r -> G[o = 16mo+4q+r][i = 16mi+c]
 #pragma unroll
       for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j] += G[mo][mi][r];
+          for (int r = 0; r < 4; ++r) put(rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j, G[mo][mi][r]);
       const int f = l;
-      acc[rl.odb2 + f] += a_db2;
-      acc[rl.odb1 + f] += a_db1;
+      put(rl.odb2 + f, a_db2);
+      put(rl.odb1 + f, a_db1);
       if constexpr (HMM) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (4 * q + r < n_out) acc[rl.oS3 + (4 * q + r) * HID + 16 * mi + j] += S3acc[mi][r];
+            if (4 * q + r < n_out) put(rl.oS3 + (4 * q + r) * HID + 16 * mi + j, S3acc[mi][r]);
       } else {
 #pragma unroll
         for (int c = 0; c < NO; ++c)
-          if (c < n_out) acc[rl.oS3 + c * HID + f] += a_S3[c < NS3 ? c : 0];
+          if (c < n_out) put(rl.oS3 + c * HID + f, a_S3[c < NS3 ? c : 0]);
       }
-      if (f < n_out) acc[rl.odb3 + f] += a_db3;
-      if (HEAD == ORL_HEAD_GAUSSIAN && f < n_out) acc[rl.odlogstd + f] += a_dls;
+      if (f < n_out) put(rl.odb3 + f, a_db3);
+      if (HEAD == ORL_HEAD_GAUSSIAN && f < n_out) put(rl.odlogstd + f, a_dls);
       if (ND == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (k < D) acc[rl.odW1 + f * D + k] += w1v[k];
+          if (k < D) put(rl.odW1 + f * D + k, w1v[k]);
       } else {
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf)
@@ -766,27 +779,31 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int kk = 16 * mk + j;
-              if (kk < D) acc[rl.odW1 + (16 * mf + 4 * q + r) * D + kk] += G1[mf][mk][r];
+              if (kk < D) put(rl.odW1 + (16 * mf + 4 * q + r) * D + kk, G1[mf][mk][r]);
             }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (16 * ND + k < D) acc[rl.odW1 + f * D + 16 * ND + k] += w1v[k];
+          if (16 * ND + k < D) put(rl.odW1 + f * D + 16 * ND + k, w1v[k]);
       }
       if (l == 0) {
-        acc[rl.total + ST_ACTIVE_SUM] += st_active;
-        acc[rl.total + ST_ROWS] += st_rows;
-        if (HEAD == ORL_HEAD_VALUE) acc[rl.total + ST_VLOSS_SUM] += st_loss;
+        put(rl.total + ST_ACTIVE_SUM, st_active);
+        put(rl.total + ST_ROWS, st_rows);
+        if (HEAD == ORL_HEAD_VALUE) put(rl.total + ST_VLOSS_SUM, st_loss);
         else {
-          acc[rl.total + ST_PLOSS_SUM] += st_loss;
-          acc[rl.total + ST_ENT_SUM] += st_ent;
-          acc[rl.total + ST_RATIO_SUM] += st_ratio;
+          put(rl.total + ST_PLOSS_SUM, st_loss);
+          put(rl.total + ST_ENT_SUM, st_ent);
+          put(rl.total + ST_RATIO_SUM, st_ratio);
         }
       }
     }
     __syncthreads();
   }
   float* out = A.partials + (size_t)bid * PW;
-  for (int e = threadIdx.x; e < PW; e += blockDim.x) out[e] = acc[e];
+  for (int e = threadIdx.x; e < PW; e += blockDim.x) {
+    float t = img0[e];
+    for (int g = 1; g < NREG; ++g) t += img0[(size_t)g * PW + e];
+    out[e] = t;
+  }
 }
 
 template <int HEAD, int NO, int ND>
