@@ -115,15 +115,23 @@ __device__ inline void fc1_T(const float* __restrict__ W1s, int DP, XB xb, f32x4
 
 // acc += Ws[64 x 64 (stride W2S)] * in   (both T layout).  64 MFMAs, 16 ds_read_b128.
 __device__ inline void mm64_T(const float* __restrict__ Ws, const f32x4 (&in)[4], f32x4 (&acc)[4], int j, int q) {
+  // A operands double-buffered: the four 16-byte reads of k-block mi+1 are issued BEFORE the 16 MFMAs of k-block mi,
+  // otherwise every block opens with an exposed LDS round trip (measured: a 64-MFMA phase took ~2 500 cycles of its
+  // 2 048-cycle floor on a wave running alone)
+  f32x4 a4[2][4];
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) a4[0][mo] = *(const f32x4*)(Ws + (16 * mo + j) * W2S + 4 * q);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    f32x4 a4[4];
+    if (mi < 3) {
 #pragma unroll
-    for (int mo = 0; mo < 4; ++mo) a4[mo] = *(const f32x4*)(Ws + (16 * mo + j) * W2S + 16 * mi + 4 * q);
+      for (int mo = 0; mo < 4; ++mo)
+        a4[(mi + 1) & 1][mo] = *(const f32x4*)(Ws + (16 * mo + j) * W2S + 16 * (mi + 1) + 4 * q);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(a4[mo][r], in[mi][r], acc[mo]);
+      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(a4[mi & 1][mo][r], in[mi][r], acc[mo]);
     }
   }
 }

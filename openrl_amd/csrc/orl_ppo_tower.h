@@ -627,18 +627,26 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       // so interleaving these MFMAs with the LN1' chain below buys nothing (measured: 4 862 cycles interleaved vs
       // 2 986 + 1 884 as two phases).
       float s_db = 0.f;
+      // operands of k-step s+1 are read before the 16 MFMAs of k-step s (same double buffering as mm64_T)
+      float av[2][4], bv[2][4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        av[0][m] = SS[q * TS + 16 * m + j];
+        bv[0][m] = X1[q * TS + 16 * m + j];
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        float av[4], bv[4];
+        if (s < 3) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          av[m] = SS[(4 * s + q) * TS + 16 * m + j];
-          bv[m] = X1[(4 * s + q) * TS + 16 * m + j];
+          for (int m = 0; m < 4; ++m) {
+            av[(s + 1) & 1][m] = SS[(4 * (s + 1) + q) * TS + 16 * m + j];
+            bv[(s + 1) & 1][m] = X1[(4 * (s + 1) + q) * TS + 16 * m + j];
+          }
         }
 #pragma unroll
         for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi) G[mo][mi] = ORL_MFMA(av[mo], bv[mi], G[mo][mi]);
+          for (int mi = 0; mi < 4; ++mi) G[mo][mi] = ORL_MFMA(av[s & 1][mo], bv[s & 1][mi], G[mo][mi]);
       }
       const int f = l;
       for (int r = 0; r < TILE_B; ++r) s_db += SS[r * TS + f];
