@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 200 /* 0.2.0: rng_step_dev arguments (no thread-local state), orl_abi_struct_size, collectives */
+#define ORL_VERSION 201 /* 0.2.1: + orl_rnn_rollout_fused; 0.2.0: rng_step_dev arguments, orl_abi_struct_size, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -58,7 +58,8 @@ typedef struct orl_net_desc {
 /* ABI guard for bindings: sizeof() of the structs of this header AS THE LIBRARY WAS BUILT, so that a stale shared
  * object with the same symbol names but another struct layout is refused at load time instead of corrupting device
  * memory.  which: 0 orl_net_desc, 1 orl_pack_src, 2 orl_buffer_ptrs, 3 orl_copy_desc, 4 orl_gather_desc,
- * 5 orl_ppo_hparams, 6 orl_adam_state, 7 orl_rollout_args, 8 orl_rnn_batch; anything else returns ORL_E_INVALID. */
+ * 5 orl_ppo_hparams, 6 orl_adam_state, 7 orl_rollout_args, 8 orl_rnn_batch, 9 orl_rnn_rollout_args; anything else
+ * returns ORL_E_INVALID. */
 int orl_abi_struct_size(int which);
 
 /* number of float32 parameters of a tower (== sum of reference state_dict numels) */
@@ -525,6 +526,34 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
 int orl_rnn_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums, const orl_ppo_hparams* hp,
                       const orl_adam_state* padam, const orl_adam_state* cadam, float* train_info_accum,
                       float* scratch, void* stream);
+
+/* OnPolicyDriver.actor_rollout (openrl/drivers/onpolicy_driver.py:154-233) of a recurrent policy on a device-resident
+ * multi-agent env, fused: ONE policy + env launch steps all T = buf.T steps (hidden states in registers, worlds stepped
+ * in-kernel like orl_mpe_step, every per-step buffer field written from the kernel incl. masks[t+1] and
+ * rnn_states[dones_env] = 0 of add2buffer, :80-152), then ONE critic sweep over the stored share_obs fills
+ * value_preds[0..T), rnn_states_critic[1..T] and `next_value` (the bootstrap value compute_returns needs, :205-233).
+ * Reads slot 0 of obs / masks / rnn_states* (ReplayData.after_update / init_buffer put them there).  Same per-row
+ * arithmetic and Philox counters (act_seed, row, rng_step0 + t [+ *rng_step_dev]) as T x {orl_rnn_act_step,
+ * orl_mpe_step, orl_buffer_insert_rnn}.  Built for env_kind ORL_ENV_MPE_SPREAD (3 agents, obs 18 / 54, Discrete(5)). */
+#define ORL_ENV_MPE_SPREAD 4
+typedef struct orl_rnn_rollout_args {
+  orl_buffer_ptrs buf;
+  float* value_preds;        /* [T+1, N, A, 1] */
+  float* actions;            /* [T, N, A, 1]   */
+  float* action_log_probs;   /* [T, N, A, 1]   */
+  float* rnn_states;         /* [T+1, N, A, H] */
+  float* rnn_states_critic;  /* [T+1, N, A, H] */
+  float* env_state;          /* [N, orl_mpe_state_width()] */
+  float* ep_stats;           /* [N, 4] or NULL */
+  float* obs_policy_out;     /* optional [N, A, Dp]: the env's own observation arrays, left as after the last step */
+  float* obs_critic_out;     /* optional [N, A, Dc] */
+  float* next_value;         /* optional [N*A] */
+  int32_t env_kind, world_length, deterministic, reserved;
+  uint64_t env_seed, act_seed, rng_step0;
+  const uint64_t* rng_step_dev; /* optional device-side addend of rng_step0 (see orl_act_step) */
+} orl_rnn_rollout_args;
+int orl_rnn_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                          const orl_rnn_rollout_args* args, void* stream);
 
 /* ==== general tower path (csrc/orl_gen.hip) ==========================================================================
  * The fused kernels above are built for the reference's DEFAULT tower (hidden_size 64, layer_N 1, ReLU, no feature

@@ -16,10 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liborl_hip.so")
 
 ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
-ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL = 0, 1, 2, 3
+ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL, ORL_ENV_MPE_SPREAD = 0, 1, 2, 3, 4
 ORL_GATHER_MAX = 12
 ORL_IPC_HANDLE_BYTES = 64
-ORL_VERSION = 200  # must equal include/orl_hip.h; checked against the loaded library
+ORL_VERSION = 201  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -86,6 +86,16 @@ class RnnBatch(C.Structure):
                 ("n_chunks_critic", C.c_int32), ("rows_critic", C.c_void_p)]
 
 
+class RnnRolloutArgs(C.Structure):
+    _fields_ = [("buf", BufferPtrs), ("value_preds", C.c_void_p), ("actions", C.c_void_p),
+                ("action_log_probs", C.c_void_p), ("rnn_states", C.c_void_p), ("rnn_states_critic", C.c_void_p),
+                ("env_state", C.c_void_p), ("ep_stats", C.c_void_p), ("obs_policy_out", C.c_void_p),
+                ("obs_critic_out", C.c_void_p), ("next_value", C.c_void_p), ("env_kind", C.c_int32),
+                ("world_length", C.c_int32), ("deterministic", C.c_int32), ("reserved", C.c_int32),
+                ("env_seed", C.c_uint64), ("act_seed", C.c_uint64), ("rng_step0", C.c_uint64),
+                ("rng_step_dev", C.c_void_p)]
+
+
 class HeadDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_out", C.c_int32), ("n_heads", C.c_int32), ("nvec", C.c_int32 * 8)]
 
@@ -94,7 +104,8 @@ ORL_ACT_NONE, ORL_ACT_TANH, ORL_ACT_RELU, ORL_ACT_LEAKY_RELU, ORL_ACT_ELU = -1, 
 ORL_HEAD_MULTI_DISCRETE = 3
 
 # order of orl_abi_struct_size(which)
-_ABI_STRUCTS = (NetDesc, PackSrc, BufferPtrs, CopyDesc, GatherDesc, PPOHParams, AdamState, RolloutArgs, RnnBatch)
+_ABI_STRUCTS = (NetDesc, PackSrc, BufferPtrs, CopyDesc, GatherDesc, PPOHParams, AdamState, RolloutArgs, RnnBatch,
+                RnnRolloutArgs)
 
 # name -> (restype, argtypes); must list EVERY symbol of include/orl_hip.h (tests check this)
 _P = C.c_void_p
@@ -184,6 +195,7 @@ _SIGNATURES = {
                                    C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "orl_rnn_eval_step": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P,
                                     _P, _P, _P, _P, _P]),
+    "orl_rnn_rollout_fused": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, C.POINTER(RnnRolloutArgs), _P]),
     "orl_rnn_chunk_rows": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "orl_rnn_chunk_rows_v3": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "orl_rnn_jrpo_records": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

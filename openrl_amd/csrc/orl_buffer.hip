@@ -541,6 +541,7 @@ int orl_abi_struct_size(int which) {
     case 6: return (int)sizeof(orl_adam_state);
     case 7: return (int)sizeof(orl_rollout_args);
     case 8: return (int)sizeof(orl_rnn_batch);
+    case 9: return (int)sizeof(orl_rnn_rollout_args);
     default: return ORL_E_INVALID;
   }
 }

@@ -255,6 +255,30 @@ __device__ inline void gru_fwd_T(const float* __restrict__ Wih, const float* __r
     }
 }
 
+// base -> GRU -> LayerNorm of one 16-row tile with the tower's LDS image (RnnLds): the rollout-side forward shared by
+// rnn_act_lds_kernel and the fused recurrent rollout (orl_rnn_rollout.hip).  xb(s) = obs column 4s + q of this lane's row.
+template <class XB>
+__device__ inline void rnn_tower_fwd_lds(const float* __restrict__ lw, const RnnLds& tw, XB xb, const f32x4 (&hin)[4],
+                                         f32x4 (&hnew)[4], f32x4 (&n3)[4], int j, int q) {
+  f32x4 z[4], n1[4], n2[4];
+  float rstd;
+  load_vec_T(lw + tw.b1, q, z);
+  fc1_T(lw + tw.W1, tw.DP, xb, z, j, q);
+  relu_T(z);
+  ln_normalize_T(z, rstd);
+  ln_affine_T(z, lw + tw.g1, lw + tw.be1, q, n1);
+  load_vec_T(lw + tw.b2, q, z);
+  mm64_T(lw + tw.W2, n1, z, j, q);
+  ln_normalize_T(z, rstd);
+  ln_affine_T(z, lw + tw.g2, lw + tw.be2, q, n2);
+  f32x4 r[4], zz[4], n[4], g[4];
+  gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin, r, zz, n, g, hnew, j, q);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) z[m] = hnew[m];
+  ln_normalize_T(z, rstd);
+  ln_affine_T(z, lw + tw.g3, lw + tw.be3, q, n3);
+}
+
 // ---- wgrad tape ---------------------------------------------------------------------------------------------
 // One block per (tile, step): 10 activation vectors of 16 rows x 64 features, the head deltas (16 x 16) and the
 // observation tile (16 x 16*ND).  Element (row, feature f = 16m + 4qq + r) of a 64-wide vector sits at float

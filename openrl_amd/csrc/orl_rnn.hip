@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void rnn_act_lds_kernel(RnnActArgs A, int s
   __syncthreads();
   const float* lw = smem;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
-  const int D = tl.D, DP = tw.DP;
+  const int D = tl.D;
   const int n_tiles = (A.B + TILE_B - 1) / TILE_B;
   for (int k = wave; k < tiles_per_wg; k += 4) {
     const int tile = bid * tiles_per_wg + k;
@@ -154,28 +154,10 @@ __global__ __launch_bounds__(256, 1) void rnn_act_lds_kernel(RnnActArgs A, int s
     f32x4 hin[4], hnew[4], n3[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) hin[m] = *(const f32x4*)(hrow + 16 * m + 4 * q) * mk;
-    {
-      f32x4 z[4], n1[4], n2[4];
-      float rstd;
-      load_vec_T(lw + tw.b1, q, z);
-      fc1_T(lw + tw.W1, DP, [&](int s) -> float {
-        const int c = 4 * s + q;
-        return c < D ? xrow[c] : 0.f;
-      }, z, j, q);
-      relu_T(z);
-      ln_normalize_T(z, rstd);
-      ln_affine_T(z, lw + tw.g1, lw + tw.be1, q, n1);
-      load_vec_T(lw + tw.b2, q, z);
-      mm64_T(lw + tw.W2, n1, z, j, q);
-      ln_normalize_T(z, rstd);
-      ln_affine_T(z, lw + tw.g2, lw + tw.be2, q, n2);
-      f32x4 r[4], zz[4], n[4], g[4];
-      gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin, r, zz, n, g, hnew, j, q);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) z[m] = hnew[m];
-      ln_normalize_T(z, rstd);
-      ln_affine_T(z, lw + tw.g3, lw + tw.be3, q, n3);
-    }
+    rnn_tower_fwd_lds(lw, tw, [&](int s) -> float {
+      const int c = 4 * s + q;
+      return c < D ? xrow[c] : 0.f;
+    }, hin, hnew, n3, j, q);
     if (row_ok) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) *(f32x4*)(hout + 16 * m + 4 * q) = hnew[m];

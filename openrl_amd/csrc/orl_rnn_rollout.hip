@@ -1,0 +1,285 @@
+// orl_rnn_rollout.hip - fused rollout of a recurrent (GRU) MAPPO policy on the device-resident MPE `simple_spread`
+// (BASELINE config 4): the whole episode_length-step actor_rollout
+// (openrl/drivers/onpolicy_driver.py:154-233 with use_recurrent_policy) in TWO launches instead of
+// T x {orl_rnn_act_step, orl_mpe_step, orl_buffer_insert}.
+//
+//   rnn_rollout_mpe_policy_kernel : one workgroup = 16 worlds; wave a = agent a of those worlds (a 16-row tile of the
+//       policy tower, weights staged into LDS once).  Hidden states stay in registers for all T steps, the worlds in
+//       the registers of 16 lanes; actions reach the world lanes and the new observations reach the towers through
+//       LDS.  Every per-step buffer field (obs / share_obs, actions, log-probs, rewards, masks, rnn_states) is written
+//       from here, the observations as coalesced copies of the LDS tile.
+//   rnn_rollout_critic_kernel     : the critic has no influence on the trajectory, so it sweeps the stored share_obs
+//       afterwards: one wave per 16-row tile, T + 1 steps with its hidden state in registers (the last step is the
+//       bootstrap value of compute_returns), next step's observation prefetched behind the current step's GEMMs.
+//
+// Both use the per-tile arithmetic of the stepwise kernels (rnn_tower_fwd_lds, sample_head, mpe_advance) and the same
+// Philox counters (act_seed, row, rng_step0 + t), so a fused rollout reproduces the stepwise one.
+#include "orl_common.h"
+#include "orl_mlp.h"
+#include "orl_heads.h"
+#include "orl_rnn.h"
+#include "orl_mpe.h"
+
+namespace orl {
+
+struct RnnRolloutArgs {
+  orl_net_desc pnet, cnet;
+  const float *ptheta, *ctheta;
+  orl_buffer_ptrs buf;
+  float *value_preds, *actions, *logp, *hp, *hc;
+  float *env_state, *ep_stats, *obs_p_out, *obs_c_out, *next_value;
+  int world_length, deterministic;
+  uint64_t env_seed, act_seed, rng_step0;
+  const unsigned long long* rng_dev;
+};
+
+constexpr int OBS_S = 20;  // padded LDS row of one agent's observation (18 -> 20 floats: fc1's k-steps of 4)
+
+template <int NO>
+__global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_policy_kernel(RnnRolloutArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const orl_buffer_ptrs& b = A.buf;
+  const RnnLayout tl(A.pnet);
+  const RnnLds tw(MPE_OBS, A.pnet.n_out, false);
+  stage_rnn_tower(smem, A.ptheta, tl, tw, threadIdx.x, blockDim.x);
+  const float* lw = smem;
+  float* s_obs = smem + tw.total;                    // [3 agents][16 worlds][OBS_S]
+  float* s_act = s_obs + MPE_A * TILE_B * OBS_S;     // [3][16]
+  float* s_rew = s_act + MPE_A * TILE_B;             // [16]
+  float* s_done = s_rew + TILE_B;                    // [16]
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int N = b.N, T = b.T;
+  const int LA = N * MPE_A;
+  const int e0 = blockIdx.x * TILE_B;
+  const int env = e0 + j;
+  const bool ok = env < N;
+  const int row = (ok ? env : 0) * MPE_A + wave;  // this lane's buffer row (world, agent = wave)
+  const int n_here = (N - e0) < TILE_B ? (N - e0) : TILE_B;
+  const uint64_t rng0 = A.rng_step0 + (A.rng_dev ? *A.rng_dev : 0ull);
+
+  for (int e = threadIdx.x; e < MPE_A * TILE_B * OBS_S; e += blockDim.x) {
+    const int i = e / (TILE_B * OBS_S), r = e - i * (TILE_B * OBS_S), jj = r / OBS_S, k = r - jj * OBS_S;
+    s_obs[e] = (jj < n_here && k < MPE_OBS) ? b.policy_obs[((size_t)(e0 + jj) * MPE_A + i) * MPE_OBS + k] : 0.f;
+  }
+  f32x4 h[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(A.hp + (size_t)row * HID + 16 * m + 4 * q);
+  float mk = b.masks[row];
+  const bool world_lane = wave == 0 && q == 0 && ok;
+  MpeWorld w;
+  float est[4] = {0.f, 0.f, 0.f, 0.f};
+  if (world_lane) {
+    mpe_load(A.env_state + (size_t)env * MPE_STATE_W, w);
+    if (A.ep_stats != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) est[k] = A.ep_stats[(size_t)env * 4 + k];
+    }
+  }
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    f32x4 hin[4], hnew[4], n3[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hin[m] = h[m] * mk;
+    const float* xrow = s_obs + (wave * TILE_B + j) * OBS_S;
+    rnn_tower_fwd_lds(lw, tw, [&](int s) -> float { return xrow[4 * s + q]; }, hin, hnew, n3, j, q);
+    float hd[NO], act_o[NO], lp_o[NO];
+    head_T<NO>(lw + tw.W3, lw + tw.b3, tl.n_out, n3, q, hd);
+    sample_head<NO, ORL_HEAD_CATEGORICAL>(hd, tl.n_out, nullptr, nullptr, nullptr, A.deterministic, A.act_seed,
+                                          (uint64_t)row, rng0 + (uint64_t)t, act_o, lp_o);
+    if (q == 0) {
+      s_act[wave * TILE_B + j] = act_o[0];
+      if (ok) {
+        A.actions[(size_t)t * LA + row] = act_o[0];
+        A.logp[(size_t)t * LA + row] = lp_o[0];
+      }
+    }
+    __syncthreads();  // actions of the 3 agents visible; every wave is done reading this step's observations
+    if (world_lane) {
+      int act[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) act[i] = (int)s_act[i * TILE_B + j];
+      float rew;
+      bool done;
+      mpe_advance(w, act, A.env_seed, (uint32_t)env, A.world_length, rew, done);
+      mpe_ep_stats(est, rew, done);
+      s_rew[j] = rew;
+      s_done[j] = done ? 1.f : 0.f;
+      float o[3][MPE_OBS];
+      mpe_obs(w, o);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < MPE_OBS; ++k) s_obs[(i * TILE_B + j) * OBS_S + k] = o[i][k];
+    }
+    __syncthreads();  // next observations, rewards and done flags visible
+    // masks[t+1] = 0 where the world finished (every agent of a world finishes together), and
+    // rnn_states[dones_env] = 0 (onpolicy_driver.py:100-113) applied to the registers and the stored slot
+    mk = s_done[j] != 0.f ? 0.f : 1.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) h[m] = hnew[m] * mk;
+    if (ok) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) *(f32x4*)(A.hp + ((size_t)(t + 1) * LA + row) * HID + 16 * m + 4 * q) = h[m];
+    }
+    // per-step scalars of the 16 worlds x 3 agents: rows e0*3 .. e0*3 + 3*n_here - 1 are contiguous
+    if ((int)threadIdx.x < MPE_A * n_here) {
+      const int jj = threadIdx.x / MPE_A;
+      const size_t r1 = (size_t)(t + 1) * LA + (size_t)e0 * MPE_A + threadIdx.x;
+      b.rewards[(size_t)t * LA + (size_t)e0 * MPE_A + threadIdx.x] = s_rew[jj];
+      b.masks[r1] = s_done[jj] != 0.f ? 0.f : 1.f;
+      b.active_masks[r1] = 1.f;  // (done && !all_done) never holds: the agents of a world share the done flag
+      b.bad_masks[r1] = 1.f;
+    }
+    // observations of slot t+1 as coalesced copies of the LDS tile: policy [world][agent][18], critic
+    // [world][agent][3 x 18] (every agent's share_obs is the concatenation of all three observations)
+    {
+      float* dp = b.policy_obs + ((size_t)(t + 1) * LA + (size_t)e0 * MPE_A) * MPE_OBS;
+      for (int e = threadIdx.x; e < n_here * MPE_A * MPE_OBS; e += blockDim.x) {
+        const int jj = e / (MPE_A * MPE_OBS), r = e - jj * (MPE_A * MPE_OBS), i = r / MPE_OBS, k = r - i * MPE_OBS;
+        const float v = s_obs[(i * TILE_B + jj) * OBS_S + k];
+        dp[e] = v;
+        if (t == T - 1 && A.obs_p_out != nullptr) A.obs_p_out[(size_t)e0 * MPE_A * MPE_OBS + e] = v;
+      }
+      float* dc = b.critic_obs + ((size_t)(t + 1) * LA + (size_t)e0 * MPE_A) * MPE_COBS;
+      for (int e = threadIdx.x; e < n_here * MPE_A * MPE_COBS; e += blockDim.x) {
+        const int jj = e / (MPE_A * MPE_COBS), r = e - jj * (MPE_A * MPE_COBS), c = r % MPE_COBS;
+        const int i2 = c / MPE_OBS, k = c - i2 * MPE_OBS;
+        const float v = s_obs[(i2 * TILE_B + jj) * OBS_S + k];
+        dc[e] = v;
+        if (t == T - 1 && A.obs_c_out != nullptr) A.obs_c_out[(size_t)e0 * MPE_A * MPE_COBS + e] = v;
+      }
+    }
+  }
+  if (world_lane) {
+    mpe_store(A.env_state + (size_t)env * MPE_STATE_W, w);
+    if (A.ep_stats != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) A.ep_stats[(size_t)env * 4 + k] = est[k];
+    }
+  }
+}
+
+// Critic sweep over the stored observations: rows [0, N*A) of every slot; tile = 16 consecutive rows per wave.
+__global__ __launch_bounds__(128, 1) void rnn_rollout_critic_kernel(RnnRolloutArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const orl_buffer_ptrs& b = A.buf;
+  const RnnLayout tl(A.cnet);
+  const RnnLds tw(A.cnet.obs_dim, 1, false);
+  stage_rnn_tower(smem, A.ctheta, tl, tw, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const float* lw = smem;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int D = tl.D, T = b.T;
+  const int LA = b.N * b.A;
+  const int n_tiles = (LA + TILE_B - 1) / TILE_B;
+  const int nwv = blockDim.x >> 6;
+  constexpr int XK = 16;  // k-steps of 4 observation columns held per lane (D <= 64)
+  float* slab = smem + tw.total + wave * TILE_B * 64;  // this wave's observation tile [16][DP]
+  for (int tile = blockIdx.x * nwv + wave; tile < n_tiles; tile += gridDim.x * nwv) {
+    const int row = tile * TILE_B + j;
+    const bool ok = row < LA;
+    const int rr = ok ? row : 0;
+    f32x4 h[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(A.hc + (size_t)rr * HID + 16 * m + 4 * q);
+    float xv[XK], mk = b.masks[rr];
+    auto load_x = [&](int t, float (&x)[XK]) {
+      const float* xr = b.critic_obs + ((size_t)t * LA + rr) * D;
+#pragma unroll
+      for (int s = 0; s < XK; ++s) {
+        const int c = 4 * s + q;
+        x[s] = (4 * s < D && c < D) ? xr[c] : 0.f;
+      }
+    };
+    load_x(0, xv);
+    for (int t = 0; t <= T; ++t) {
+      float xn[XK], mkn = 0.f;
+      if (t < T) {  // next slot's inputs (written by the policy launch), in flight behind this step's GEMMs
+        load_x(t + 1, xn);
+        mkn = b.masks[(size_t)(t + 1) * LA + rr];
+      }
+      f32x4 hin[4], hnew[4], n3[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) hin[m] = h[m] * mk;
+      // fc1's k-loop has a run-time trip count: the prefetched registers go through this lane's own slots of the
+      // wave's LDS slab (written and read by the same lane, no cross-lane ordering involved)
+#pragma unroll
+      for (int s = 0; s < XK; ++s)
+        if (4 * s < tw.DP) slab[j * tw.DP + 4 * s + q] = xv[s];
+      rnn_tower_fwd_lds(lw, tw, [&](int s) -> float { return slab[j * tw.DP + 4 * s + q]; }, hin, hnew, n3, j, q);
+      float v[1];
+      head_T<1>(lw + tw.W3, lw + tw.b3, 1, n3, q, v);
+      if (t == T) {
+        if (ok && q == 0 && A.next_value != nullptr) A.next_value[row] = v[0];
+        break;
+      }
+      if (ok && q == 0) A.value_preds[(size_t)t * LA + row] = v[0];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) h[m] = hnew[m] * mkn;  // rnn_states_critic[dones_env] = 0
+      if (ok) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) *(f32x4*)(A.hc + ((size_t)(t + 1) * LA + row) * HID + 16 * m + 4 * q) = h[m];
+      }
+      mk = mkn;
+#pragma unroll
+      for (int s = 0; s < XK; ++s) xv[s] = xn[s];
+    }
+  }
+}
+
+}  // namespace orl
+
+using namespace orl;
+
+extern "C" {
+
+int orl_rnn_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
+                          const orl_rnn_rollout_args* a, void* stream) {
+  ORL_REQUIRE(pnet && ptheta && cnet && ctheta && a, "orl_rnn_rollout_fused: null argument");
+  ORL_REQUIRE(a->env_kind == ORL_ENV_MPE_SPREAD, "orl_rnn_rollout_fused: env kind %d not built (MPE simple_spread only)",
+              a->env_kind);
+  const orl_buffer_ptrs& b = a->buf;
+  ORL_REQUIRE(b.A == MPE_A && b.Dp == MPE_OBS && b.Dc == MPE_COBS && b.N > 0 && b.T > 0,
+              "orl_rnn_rollout_fused: buffer (A %d, Dp %d, Dc %d) is not simple_spread's (3, 18, 54)", b.A, b.Dp, b.Dc);
+  ORL_REQUIRE(pnet->hidden == HID && cnet->hidden == HID && pnet->obs_dim == MPE_OBS && cnet->obs_dim == MPE_COBS &&
+                  pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 5 && cnet->n_out == 1,
+              "orl_rnn_rollout_fused: towers do not match simple_spread (obs 18 / 54, Discrete(5), hidden 64)");
+  ORL_REQUIRE(b.policy_obs && b.critic_obs && b.critic_obs != b.policy_obs && b.rewards && b.masks && b.bad_masks &&
+                  b.active_masks && a->value_preds && a->actions && a->action_log_probs && a->rnn_states &&
+                  a->rnn_states_critic && a->env_state && a->world_length > 0,
+              "orl_rnn_rollout_fused: null buffer / env pointer");
+  RnnRolloutArgs A;
+  A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.buf = b;
+  A.value_preds = a->value_preds; A.actions = a->actions; A.logp = a->action_log_probs; A.hp = a->rnn_states;
+  A.hc = a->rnn_states_critic; A.env_state = a->env_state; A.ep_stats = a->ep_stats; A.obs_p_out = a->obs_policy_out;
+  A.obs_c_out = a->obs_critic_out; A.next_value = a->next_value; A.world_length = a->world_length;
+  A.deterministic = a->deterministic; A.env_seed = a->env_seed; A.act_seed = a->act_seed; A.rng_step0 = a->rng_step0;
+  A.rng_dev = (const unsigned long long*)a->rng_step_dev;
+  hipStream_t s = (hipStream_t)stream;
+  {
+    const RnnLds tw(MPE_OBS, 5, false);
+    const size_t lds = (size_t)(tw.total + MPE_A * TILE_B * OBS_S + MPE_A * TILE_B + 2 * TILE_B) * sizeof(float);
+    ORL_REQUIRE(lds <= 160 * 1024, "orl_rnn_rollout_fused: policy image %zu B exceeds the LDS", lds);
+    (void)hipFuncSetAttribute((const void*)rnn_rollout_mpe_policy_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    const int grid = (b.N + TILE_B - 1) / TILE_B;
+    hipLaunchKernelGGL((rnn_rollout_mpe_policy_kernel<8>), dim3(grid), dim3(192), lds, s, A);
+    const int rc = launch_status("orl_rnn_rollout_fused(policy)");
+    if (rc) return rc;
+  }
+  {
+    const RnnLds tw(MPE_COBS, 1, false);
+    const size_t lds = (size_t)(tw.total + 2 * TILE_B * 64) * sizeof(float);
+    ORL_REQUIRE(lds <= 160 * 1024, "orl_rnn_rollout_fused: critic image %zu B exceeds the LDS", lds);
+    (void)hipFuncSetAttribute((const void*)rnn_rollout_critic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    const int n_tiles = (b.N * b.A + TILE_B - 1) / TILE_B;
+    int grid = (n_tiles + 1) / 2;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(rnn_rollout_critic_kernel, dim3(grid), dim3(128), lds, s, A);
+  }
+  return launch_status("orl_rnn_rollout_fused(critic)");
+}
+
+}  // extern "C"

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from .. import ops
+from .. import ops, ops_rnn
 from ..utils.callbacks import as_callback, callback_needs_per_step
 from ..utils.logger import Logger
 
@@ -110,13 +110,16 @@ class OnPolicyDriver:
         if mode == "fused" and not dev_env:
             raise ValueError("amd_rollout_mode=fused needs a device-resident env")
         recurrent = bool(getattr(self.trainer.algo_module, "recurrent", False))
-        if mode == "fused" and recurrent:
-            raise ValueError("amd_rollout_mode=fused is not built for recurrent policies (stepwise rollout only)")
         generic = bool(getattr(self.trainer.algo_module, "generic", False))  # general towers roll out stepwise
         if mode == "fused" and generic:
             raise ValueError("amd_rollout_mode=fused is built for the default tower only (hidden 64, layer_N 1, ReLU)")
-        can_fuse = (dev_env and bool(getattr(self.envs, "supports_fused_rollout", True)) and not recurrent
-                    and not generic)
+        # recurrent policies: fused on envs orl_rnn_rollout_fused steps in-kernel (the device MPE simple_spread)
+        self.fused_rnn = (dev_env and recurrent and not generic
+                          and bool(getattr(self.envs, "supports_fused_rnn_rollout", False)))
+        if mode == "fused" and recurrent and not self.fused_rnn:
+            raise ValueError("amd_rollout_mode=fused with a recurrent policy is built for the device MPE env only")
+        can_fuse = self.fused_rnn or (dev_env and bool(getattr(self.envs, "supports_fused_rollout", True))
+                                      and not recurrent and not generic)
         if mode == "fused" and not can_fuse:
             raise ValueError("amd_rollout_mode=fused is not built for env %r" % getattr(self.envs, "env_name", "?"))
         self.fused = can_fuse and mode in ("auto", "fused") and not per_step_cb
@@ -213,6 +216,25 @@ class OnPolicyDriver:
         p, c = mod.models["policy"], mod.models["critic"]
         env = self.envs
         f = nat.fptr
+        if self.fused_rnn:  # recurrent policy: policy + env launch, then the critic sweep (orl_rnn_rollout_fused)
+            a = nat.RnnRolloutArgs()
+            a.buf = d.buffer_ptrs()
+            a.value_preds, a.actions, a.action_log_probs = f(d.value_preds), f(d.actions), f(d.action_log_probs)
+            a.rnn_states, a.rnn_states_critic = f(d.rnn_states), f(d.rnn_states_critic)
+            a.env_state, a.ep_stats = f(env.env_state), f(env.ep_stats)
+            a.obs_policy_out, a.obs_critic_out = f(env.obs["policy"]), f(env.obs["critic"])
+            a.next_value = f(self._next_value)
+            a.env_kind, a.world_length, a.deterministic = env.env_kind, env.episode_limit, 0
+            a.env_seed, a.act_seed = env.seed & (2 ** 64 - 1), mod.act_seed & (2 ** 64 - 1)
+            a.rng_step0 = int(mod.rng_step)
+            ops_rnn.rnn_rollout_fused(p.net, p.theta, c.net, c.theta, a, self.device)
+            env.global_step += self.episode_length
+            mod.rng_step += self.episode_length
+            self._have_next_value = True
+            d.step = 0
+            d._adv_fresh = False
+            self.agent.num_time_steps += env.parallel_env_num * self.episode_length
+            return
         args = nat.RolloutArgs(d.buffer_ptrs(), f(d.value_preds), f(d.actions), f(d.action_log_probs), f(env.env_state),
                                f(env.ep_stats), env.env_kind, env.episode_limit, env.seed & (2 ** 64 - 1),
                                mod.act_seed & (2 ** 64 - 1), env.global_step)

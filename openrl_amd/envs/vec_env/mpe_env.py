@@ -24,7 +24,7 @@ class MpeSpreadVecEnv(DeviceVecEnv):
     def __init__(self, env_num: int, env_name: str = "simple_spread", world_length: int = 25, device="cuda:0",
                  seed: int = 0):
         self.kind = "mpe_simple_spread"
-        self.env_kind = None  # not one of the single-agent kinds the fused rollout kernel steps in-kernel
+        self.env_kind = nat.ORL_ENV_MPE_SPREAD  # stepped in-kernel by orl_rnn_rollout_fused (recurrent policies)
         self.device = nat.require_gpu(device)
         self._n = int(env_num)
         self._env_name = env_name
@@ -44,7 +44,8 @@ class MpeSpreadVecEnv(DeviceVecEnv):
         self.total_step = 0
         self._infos = [{} for _ in range(self._n)]
         self.is_device_env = True
-        self.supports_fused_rollout = False
+        self.supports_fused_rollout = False     # the MLP rollout kernel steps single-agent envs only
+        self.supports_fused_rnn_rollout = True  # recurrent MAPPO: orl_rnn_rollout_fused
         self.supports_graph_rollout = True  # orl_mpe_step takes no per-call host scalar: capturable
 
     @property

@@ -129,6 +129,13 @@ def mpe_step(env_state, ep_stats, actions, obs_policy, obs_critic, rewards, done
     nat.check(rc, "orl_mpe_step")
 
 
+def rnn_rollout_fused(pnet, ptheta, cnet, ctheta, args: "nat.RnnRolloutArgs", device) -> None:
+    """The whole recurrent actor_rollout on the device MPE env: one policy + env launch, one critic sweep."""
+    rc = _lib().orl_rnn_rollout_fused(C.byref(pnet), fptr(ptheta), C.byref(cnet), fptr(ctheta), C.byref(args),
+                                      stream_ptr(nat.require_gpu(device)))
+    nat.check(rc, "orl_rnn_rollout_fused")
+
+
 # ------------------------------------------------------------------------------------------------ device tic-tac-toe
 def ttt_state_width() -> int:
     return int(_lib().orl_ttt_state_width())

@@ -91,7 +91,7 @@ def test_config4_end_to_end_recurrent_mappo_on_device_mpe():
     agent = PPOAgent(net)
     agent.train(total_time_steps=3 * N * T)
     drv = agent.driver
-    assert not drv.fused and agent.num_time_steps == 3 * N * T
+    assert drv.fused and drv.fused_rnn and agent.num_time_steps == 3 * N * T  # orl_rnn_rollout_fused
     d = drv.buffer.data
     assert d.policy_obs.shape == (T + 1, N, 3, 18) and d.critic_obs.shape == (T + 1, N, 3, 54)
     # episodes are exactly one rollout long: slot 0 (= previous slot T) starts an episode: mask 0, states 0
@@ -152,7 +152,8 @@ def test_graph_captured_rollout_equals_eager_rollout(recurrent):
     def run(use_graph):
         N, T, iters = 96, 25, 4
         cfg = default_cfg(["--seed", "3", "--episode_length", str(T), "--use_recurrent_policy", recurrent, "--ppo_epoch", "2",
-                           "--amd_perm_mode", "device", "--amd_use_graph", str(use_graph), "--log_interval", "1000000"])
+                           "--amd_perm_mode", "device", "--amd_use_graph", str(use_graph), "--amd_rollout_mode", "stepwise",
+                           "--log_interval", "1000000"])
         env = make("simple_spread", env_num=N, device=DEV, seed=3)
         net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
         cfg.num_env_steps = N * T * iters
@@ -180,3 +181,68 @@ def test_graph_captured_rollout_equals_eager_rollout(recurrent):
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert torch.equal(tha, thb)
+
+
+@pytest.mark.parametrize("N", [96, 50])
+def test_fused_recurrent_rollout_equals_stepwise_rollout(N):
+    """orl_rnn_rollout_fused (policy + MPE world in one launch, critic sweep in a second) against the stepwise
+    T x {orl_rnn_act_step, orl_mpe_step, orl_buffer_insert_rnn} rollout: same per-tile arithmetic and Philox counters,
+    so actions / rewards / masks agree exactly and the float fields to fp32 round-off; 4 iterations with updates in
+    between, so slot 0 hand-over (after_update), auto-reset and the bootstrap value are covered.  N = 50 leaves a
+    ragged last tile of 2 worlds."""
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+
+    def run(mode):
+        T, iters = 25, 4
+        cfg = default_cfg(["--seed", "3", "--episode_length", str(T), "--use_recurrent_policy", "true", "--ppo_epoch", "2",
+                           "--amd_perm_mode", "device", "--amd_use_graph", "false", "--amd_rollout_mode", mode,
+                           "--log_interval", "1000000"])
+        env = make("simple_spread", env_num=N, device=DEV, seed=3)
+        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+        cfg.num_env_steps = N * T * iters
+
+        class _Agent:
+            num_time_steps = 0
+
+        agent = _Agent()
+        trainer = PPOAlgorithm(cfg, net.module, agent_num=3, device=DEV)
+        buf = NormalReplayBuffer(cfg, 3, env.observation_space, env.action_space, device=DEV)
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 3, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, agent)
+        assert drv.fused == (mode == "fused")
+        drv.reset_and_buffer_init()
+        snaps = []
+        for i in range(iters):
+            drv.episode = i
+            drv.actor_rollout()
+            drv.learner_update()  # compute_returns (consumes the fused launch's bootstrap value) + train
+            d = buf.data
+            snaps.append({k: getattr(d, k).clone() for k in (
+                "policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "rewards", "masks",
+                "active_masks", "bad_masks", "rnn_states", "rnn_states_critic", "returns")})
+            snaps[-1]["env_obs_p"], snaps[-1]["env_obs_c"] = env.obs["policy"].clone(), env.obs["critic"].clone()
+            snaps[-1]["env_state"], snaps[-1]["ep_stats"] = env.env_state.clone(), env.ep_stats.clone()
+            buf.after_update()
+        assert agent.num_time_steps == N * T * iters
+        return snaps, net.module.models["policy"].theta.clone(), net.module.rng_step, env.global_step
+
+    a, tha, ra, ga = run("fused")
+    b, thb, rb, gb = run("stepwise")
+    assert ra == rb and ga == gb
+    exact = ("actions", "rewards", "masks", "active_masks", "bad_masks", "policy_obs", "critic_obs", "env_obs_p", "env_obs_c",
+             "env_state", "ep_stats")
+    # iteration 0 starts from identical weights; later iterations inherit fp32 round-off through the updates, where a
+    # sampled action may flip - compare them on the first iteration exactly and on all iterations statistically
+    for k in exact:
+        assert torch.equal(a[0][k], b[0][k]), k
+    for k in ("action_log_probs", "value_preds", "rnn_states", "rnn_states_critic", "returns"):
+        torch.testing.assert_close(a[0][k], b[0][k], rtol=2e-5, atol=2e-6, msg=k)
+    for i in range(1, len(a)):
+        same = (a[i]["actions"] == b[i]["actions"]).float().mean().item()
+        assert same > 0.99, (i, same)
+        assert torch.equal(a[i]["masks"], b[i]["masks"])
+    torch.testing.assert_close(tha, thb, rtol=1e-3, atol=1e-4)
