@@ -137,7 +137,6 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   constexpr bool HMM = NO > 4;
   const bool w2t = ND == 0 || A.use_w2t;  // compile-time true on the small-observation path
   const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, w2t, HMM);
-  stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM);
   const int DP = tw.DP;
   const int D = A.net.obs_dim;
   const int n_out = A.net.n_out;
@@ -153,7 +152,6 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   float* SS = wl + SLAB;       // scratch slab: xhat2 -> dz2 -> dz1
   float* RR = wl + 2 * SLAB;   // record ring: 2 slots of [chunk][16 rows][4 floats]
   float* DH = RR + 2 * rts;    // dhead [16][NOP]
-  __syncthreads();
 
   const float* lw = smem;
   const orl_ppo_hparams hp = A.hp;
@@ -229,6 +227,11 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   row_next = row_of(wave_g);
   issue_dma(RR, row_next);
   row_next = row_of(wave_g + n_waves);
+  // the tower image is staged AFTER the first tile's index loads and record DMA are in flight (their latency chain -
+  // index -> record rows -> LDS - overlaps the parameter loads instead of following them); the record ring and the
+  // image are disjoint LDS regions
+  stage_tower_flat(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM);
+  __syncthreads();
 
 #ifdef ORL_PROF
   __shared__ unsigned long long prof_lds[16];

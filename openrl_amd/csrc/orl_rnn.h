@@ -146,15 +146,21 @@ __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __r
 // acc += W[64 x 64, row stride S] * in   (T layout; S = W2S for the LDS image, 64 for weights read from global)
 template <int S>
 __device__ inline void mm64_S(const float* __restrict__ Ws, const f32x4 (&in)[4], f32x4 (&acc)[4], int j, int q) {
+  // A operands double-buffered like mm64_T: k-block mi+1's four 16-byte reads are issued before k-block mi's MFMAs
+  f32x4 a4[2][4];
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) a4[0][mo] = *(const f32x4*)(Ws + (16 * mo + j) * S + 4 * q);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    f32x4 a4[4];
+    if (mi < 3) {
 #pragma unroll
-    for (int mo = 0; mo < 4; ++mo) a4[mo] = *(const f32x4*)(Ws + (16 * mo + j) * S + 16 * mi + 4 * q);
+      for (int mo = 0; mo < 4; ++mo)
+        a4[(mi + 1) & 1][mo] = *(const f32x4*)(Ws + (16 * mo + j) * S + 16 * (mi + 1) + 4 * q);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(a4[mo][r], in[mi][r], acc[mo]);
+      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(a4[mi & 1][mo][r], in[mi][r], acc[mo]);
     }
   }
 }
