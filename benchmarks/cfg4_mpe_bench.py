@@ -1,7 +1,8 @@
 """BASELINE config 4 end to end on one MI355X: MPE simple_spread, 2048 envs x 3 agents, episode_length 25, recurrent
 (GRU) MAPPO as examples/mpe/mpe_ppo.yaml runs it (use_recurrent_policy, data_chunk_length 2 and ppo_epoch from the
-reference defaults), device-resident env, stepwise rollout (orl_rnn_act_step + orl_mpe_step + orl_buffer_insert per
-step) + GAE + recurrent PPO update.
+reference defaults), device-resident env, fused recurrent rollout (orl_rnn_rollout_fused: policy + worlds in one
+launch, critic sweep in a second; --rollout stepwise = orl_rnn_act_step + orl_mpe_step + orl_buffer_insert per step as
+a hipGraph) + GAE + recurrent PPO update.
 
     python benchmarks/cfg4_mpe_bench.py [--steps 10 --warmup 2 --envs 2048]
 
@@ -23,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--envs", type=int, default=2048)
+    ap.add_argument("--rollout", default="auto", choices=["auto", "fused", "stepwise"])
     a = ap.parse_args()
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers import NormalReplayBuffer
@@ -34,7 +36,7 @@ def main():
     dev, N, T = "cuda:0", a.envs, 25
     cfg = default_cfg(["--seed", "0", "--lr", "7e-4", "--critic_lr", "7e-4", "--episode_length", str(T),
                        "--use_recurrent_policy", "true", "--use_valuenorm", "true", "--use_adv_normalize", "true",
-                       "--amd_perm_mode", "device", "--log_interval", "1000000"])
+                       "--amd_perm_mode", "device", "--amd_rollout_mode", a.rollout, "--log_interval", "1000000"])
     env = make("simple_spread", env_num=N, device=dev)
     net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=N)
     cfg.num_env_steps = N * T * (a.steps + a.warmup)
@@ -69,6 +71,7 @@ def main():
     st = env.episode_statistics()
     print(json.dumps({"bench": "cfg4_mpe_recurrent_mappo", "envs": N, "agents": 3, "episode_length": T,
                       "ppo_epoch": cfg.ppo_epoch, "data_chunk_length": cfg.data_chunk_length,
+                      "rollout": "fused" if drv.fused else "stepwise (hipGraph)",
                       "env_steps_per_s": N * T * a.steps / dt, "agent_steps_per_s": 3 * N * T * a.steps / dt,
                       "ms_per_iteration": dt / a.steps * 1e3, "ms_rollout": t_roll / a.steps * 1e3,
                       "ms_update": t_upd / a.steps * 1e3, "episode_return_mean": st["episode_return_mean"]}))

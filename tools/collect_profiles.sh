@@ -34,5 +34,29 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_
     python benchmarks/rnn_update_bench.py --iters 3 --warmup 1 > $OUT/${TAG}_rnn_stats.log 2>&1
 find $OUT/${TAG}_rnn_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/${TAG}_rnn_update_kernel_stats.csv
 cat $OUT/${TAG}_rnn_update_line.json
+# 5. the other BASELINE configurations / shapes (builder-run lines beside the headline) + their kernel stats
+stats() {  # stats <name> <command...>: kernel-trace summary of a command -> $OUT/${TAG}_<name>_kernel_stats.csv
+  local name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_st_$name -- "$@" > $OUT/${TAG}_st_$name.log 2>&1
+  find $OUT/${TAG}_st_$name -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/${TAG}_${name}_kernel_stats.csv
+  rm -rf $OUT/${TAG}_st_$name
+}
+timeout 600 python benchmarks/cfg4_mpe_bench.py > $OUT/${TAG}_cfg4_mpe_line.json 2>/dev/null
+stats cfg4_mpe python benchmarks/cfg4_mpe_bench.py --steps 4 --warmup 2
+timeout 600 python benchmarks/cfg5_ttt_bench.py > $OUT/${TAG}_cfg5_ttt_line.json 2>/dev/null
+stats cfg5_ttt python benchmarks/cfg5_ttt_bench.py --steps 4 --warmup 2
+timeout 600 python benchmarks/shape_sweep.py > $OUT/${TAG}_shape_sweep.jsonl 2>/dev/null
+stats cfg3_shape python benchmarks/shape_sweep.py --only cfg3_halfcheetah_shape
+timeout 600 python benchmarks/host_env_bench.py > $OUT/${TAG}_host_env_line.json 2>/dev/null
+# 6. the per-rank shard of the strong-scaling bench at 8 and 2 GPUs (512 / 2048 of the 4096 envs), on one GPU
+for E in 512 2048; do
+  timeout 600 python bench.py --no-cpu-baseline --envs $E > $OUT/${TAG}_bench_envs${E}_line.json 2>/dev/null
+done
+stats bench_envs512 python bench.py --no-cpu-baseline --envs 512
+# 7. issue / wait counters of the tower kernel
+bash tools/pmc_tower.sh > $OUT/${TAG}_pmc_tower.txt 2>&1
+# 8. the GPU test suite
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/${TAG}_pytest_gpu.log
+tail -3 $OUT/${TAG}_pytest_gpu.log
 # keep the merge small: the raw rocprof trees are not needed
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_rnn_stats

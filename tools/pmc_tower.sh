@@ -13,7 +13,7 @@ acc=defaultdict(list)
 try:
     for r in csv.DictReader(open(sys.argv[1])):
         k=r["Kernel_Name"]
-        if "ppo_tower_kernel<1" in k:
+        if "ppo_tower_pair_kernel" in k:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in sorted(acc.items()): print(k, round(sum(v)/len(v),1), len(v))
 except Exception as e: print("ERR", e)

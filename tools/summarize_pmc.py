@@ -53,12 +53,12 @@ def main():
         idx_bytes = 2 * ROWS * 8  # both towers stream the int64 permutation
         out["orl_ppo_fwd_bwd_pair"] = {
             "hbm_bytes_per_launch": int(raw * 1024) + idx_bytes // 2, "hbm_bytes_per_launch_raw": int(raw * 1024),
-            "algorithmic_bytes_per_launch": 2 * ROWS * REC_BYTES + idx_bytes + 256 * 4 * (4626 + 4561),
+            "algorithmic_bytes_per_launch": 2 * ROWS * REC_BYTES + idx_bytes + 128 * 4 * (4626 + 4561),
             "note": "FETCH_SIZE / WRITE_SIZE (KiB) from separate rocprofv3 --pmc passes. Calibrated (tools/pmc_calibrate.hip, "
                     "profiles/r02_pmc_calibration.json): WRITE_SIZE exact; FETCH_SIZE exact for the 64-B records gathered "
                     "at permuted rows, 1/2 for the coalesced int64 index stream - hbm_bytes_per_launch adds the missing "
                     "half of the index bytes to the raw sum. Algorithmic = records + indices read by both towers + the "
-                    "256 per-workgroup partial rows written (4626 / 4561 floats per row for the policy / critic tower of "
+                    "2 x 128 per-workgroup partial rows written (4626 / 4561 floats per row for the policy / critic tower of "
                     "configs[1]); the second tower finds part of the shared record lines in L2 / Infinity Cache."}
     json.dump(out, sys.stdout, indent=1)
 
