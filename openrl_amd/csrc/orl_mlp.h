@@ -94,68 +94,6 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
   }
 }
 
-// stage_tower with ONE global round trip: every thread first loads its share of the flat parameter vector (coalesced,
-// all loads in flight together), then scatters the values to their places in the LDS image.  stage_tower above walks
-// the image segment by segment - six dependent load -> wait -> store stages, i.e. six L2 round trips in front of the
-// first tile of every workgroup; the update launches one such workgroup per CU and minibatch, so at small batches
-// (strong scaling: 2 tiles per wave at 512 envs per GPU) that prologue is a visible part of the launch.
-__device__ inline void stage_tower_flat(float* __restrict__ lds, const float* __restrict__ theta, const TowerLayout& tl,
-                                        const TowerLds& tw, bool with_w2t, int tid, int nthreads, bool with_w3p = false) {
-  constexpr int KC = 12;  // parameters per thread and round (config 2: 4 866 parameters / 512 threads -> one round)
-  const int D = tl.D, DP = tw.DP;
-  const int no4 = (tl.n_out + 3) & ~3;
-  // padding slots no parameter maps to
-  if (DP != D) {
-    const int pw = DP - D;
-    for (int e = tid; e < HID * pw; e += nthreads) lds[tw.W1 + (e / pw) * DP + D + (e % pw)] = 0.f;
-  }
-  if (with_w3p) {
-    for (int e = tid + tl.n_out * W2S; e < 16 * W2S; e += nthreads) lds[tw.W3P + e] = 0.f;
-    for (int e = tid; e < tl.n_out * (W2S - HID); e += nthreads)
-      lds[tw.W3P + (e / (W2S - HID)) * W2S + HID + e % (W2S - HID)] = 0.f;
-  } else {
-    for (int e = tid + tl.n_out * HID; e < no4 * HID; e += nthreads) lds[tw.W3 + e] = 0.f;
-  }
-  for (int e = tid + tl.n_out; e < no4; e += nthreads) {
-    lds[tw.b3 + e] = 0.f;
-    if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = 0.f;
-  }
-  for (int base = 0; base < tl.total; base += KC * nthreads) {
-    float v[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const int e = base + k * nthreads + tid;
-      v[k] = e < tl.total ? theta[e] : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const int e = base + k * nthreads + tid;
-      if (e >= tl.total) continue;
-      const float w = v[k];
-      if (e < tl.ob1) {
-        const int f = e / D;
-        lds[tw.W1 + f * DP + (e - f * D)] = w;
-      } else if (e < tl.oW2) {
-        lds[tw.b1 + (e - tl.ob1)] = w;  // b1 | g1 | be1 are consecutive in both layouts
-      } else if (e < tl.ob2) {
-        const int r = e - tl.oW2, o = r >> 6, i = r & 63;
-        lds[tw.W2 + o * W2S + i] = w;
-        if (with_w2t) lds[tw.W2T + i * W2S + o] = w;
-      } else if (e < tl.oW3) {
-        lds[tw.b2 + (e - tl.ob2)] = w;  // b2 | g2 | be2
-      } else if (e < tl.ob3) {
-        const int r = e - tl.oW3;
-        if (with_w3p) lds[tw.W3P + (r >> 6) * W2S + (r & 63)] = w;
-        else lds[tw.W3 + r] = w;
-      } else if (e < tl.ologstd) {
-        lds[tw.b3 + (e - tl.ob3)] = w;
-      } else {
-        lds[tw.logstd + (e - tl.ologstd)] = w;
-      }
-    }
-  }
-}
-
 // acc[m] <- vec[16m+4q .. +3]   (bias init of an accumulator in T layout)
 __device__ inline void load_vec_T(const float* __restrict__ v, int q, f32x4 (&acc)[4]) {
 #pragma unroll

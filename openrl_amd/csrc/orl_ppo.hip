@@ -70,14 +70,37 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
     PpoArgs P2 = P, C2 = Cc;
     P2.use_w2t = w2t; C2.use_w2t = w2t;
     const int n_tiles = (P.mb + TILE_B - 1) / TILE_B;
-    // One workgroup fits a CU (LDS).  When the two towers together need more workgroups than there are CUs, each gets
-    // HALF the CUs and its waves loop over twice as many tiles: both towers are resident from the first cycle and the
-    // per-workgroup prologue / epilogue (~12 us: staging, first record DMA, accumulator reduction) is paid once per
-    // launch instead of once per tower back to back.  Measured against 256 + 256 workgroups (the critic's starting as
-    // the policy's retire): pair launch 63.7 -> 55.2 us at 512 envs, 100.4 -> 94.3 us at 1024, 323.9 -> 319.8 us at
-    // 4096; giving the policy tower 53 % / 56 % of the CUs was slower at every size (tiles per wave quantise).
+    // One workgroup fits a CU (LDS).  Two ways to run 2 x g workgroups on 256 CUs:
+    //  * back to back: 256 + 256 workgroups, a critic workgroup starts on a CU when its policy workgroup retires - exact
+    //    load balance, but the per-workgroup prologue / epilogue (~12 us: staging, first record DMA, accumulator
+    //    reduction) is paid twice in sequence;
+    //  * side by side: the CUs are split between the towers (both resident from the first cycle, one prologue /
+    //    epilogue per launch), each wave loops over about twice as many tiles.  The split follows the towers' cost per
+    //    tile (single-tower launches at the three BASELINE shapes: policy / critic = 1.05 with a narrow head, 1.24 with
+    //    the wide-head MFMA path of either distribution) and minimises the later tower's finish in whole tiles per wave.
+    // Measured pair launch, back to back -> side by side: configuration 2's towers 63.7 -> 55.2 us at 512 envs,
+    // 100.4 -> 94.3 us at 1024, 323.9 -> 319.8 us at 4096; cfg3 shape (12 800 tiles) 198 -> 186 us; cfg5 shape (51 200
+    // tiles, wide head) 678 -> 694 us.  Hence side by side when the towers are nearly equal or the launch is short.
     int gp = (n_tiles + 7) / 8, gc = gp;
-    if (gp + gc > PPO_MAX_BLOCKS) gp = gc = PPO_MAX_BLOCKS / 2;
+    if (gp > PPO_MAX_BLOCKS) gp = gc = PPO_MAX_BLOCKS;
+    const double w_p = NOP_ > 4 ? 1.24 : 1.05;
+    const bool side_by_side = w_p < 1.1 || n_tiles <= 12 * 8 * PPO_MAX_BLOCKS;
+    if (gp + gc > PPO_MAX_BLOCKS && side_by_side) {
+      double best = 1e30;
+      int best_g = PPO_MAX_BLOCKS / 2;
+      for (int d = 0; d <= PPO_MAX_BLOCKS / 4; ++d) {  // nearest to an even split first: ties keep it
+        for (int sgn = 1; sgn >= -1; sgn -= 2) {
+          const int g = PPO_MAX_BLOCKS / 2 + sgn * d;
+          const double tp = (double)((n_tiles + 8 * g - 1) / (8 * g)) * w_p;
+          const double tc = (double)((n_tiles + 8 * (PPO_MAX_BLOCKS - g) - 1) / (8 * (PPO_MAX_BLOCKS - g)));
+          const double t = tp > tc ? tp : tc;
+          if (t < best - 1e-9) { best = t; best_g = g; }
+          if (d == 0) break;
+        }
+      }
+      gp = best_g;
+      gc = PPO_MAX_BLOCKS - best_g;
+    }
     (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND>), dim3(gp + gc), dim3(512), lds, s, P2, C2, gp);

@@ -230,7 +230,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // the tower image is staged AFTER the first tile's index loads and record DMA are in flight (their latency chain -
   // index -> record rows -> LDS - overlaps the parameter loads instead of following them); the record ring and the
   // image are disjoint LDS regions
-  stage_tower_flat(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM);
+  stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM);
   __syncthreads();
 
 #ifdef ORL_PROF
