@@ -528,10 +528,11 @@ int orl_rnn_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const 
                       float* scratch, void* stream);
 
 /* OnPolicyDriver.actor_rollout (openrl/drivers/onpolicy_driver.py:154-233) of a recurrent policy on a device-resident
- * multi-agent env, fused: ONE policy + env launch steps all T = buf.T steps (hidden states in registers, worlds stepped
+ * multi-agent env, fused: policy + env workgroups step all T = buf.T steps (hidden states in registers, worlds stepped
  * in-kernel like orl_mpe_step, every per-step buffer field written from the kernel incl. masks[t+1] and
- * rnn_states[dones_env] = 0 of add2buffer, :80-152), then ONE critic sweep over the stored share_obs fills
- * value_preds[0..T), rnn_states_critic[1..T] and `next_value` (the bootstrap value compute_returns needs, :205-233).
+ * rnn_states[dones_env] = 0 of add2buffer, :80-152), critic workgroups sweep the stored share_obs and fill
+ * value_preds[0..T), rnn_states_critic[1..T] and `next_value` (the bootstrap value compute_returns needs, :205-233) -
+ * in the same launch when `sync_flags` is given, as a second launch otherwise.
  * Reads slot 0 of obs / masks / rnn_states* (ReplayData.after_update / init_buffer put them there).  Same per-row
  * arithmetic and Philox counters (act_seed, row, rng_step0 + t [+ *rng_step_dev]) as T x {orl_rnn_act_step,
  * orl_mpe_step, orl_buffer_insert_rnn}.  Built for env_kind ORL_ENV_MPE_SPREAD (3 agents, obs 18 / 54, Discrete(5)). */
@@ -551,6 +552,9 @@ typedef struct orl_rnn_rollout_args {
   int32_t env_kind, world_length, deterministic, reserved;
   uint64_t env_seed, act_seed, rng_step0;
   const uint64_t* rng_step_dev; /* optional device-side addend of rng_step0 (see orl_act_step) */
+  int32_t* sync_flags;       /* optional [ceil(N/16) + 1] int32 scratch: with it the critic workgroups run in the SAME
+                              * launch, one step behind their policy workgroups (per-group step counters; the last word
+                              * is set to 1 if a critic's bounded wait ever timed out); NULL = two launches */
 } orl_rnn_rollout_args;
 int orl_rnn_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                           const orl_rnn_rollout_args* args, void* stream);

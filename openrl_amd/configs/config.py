@@ -28,6 +28,9 @@ AMD_FLAGS = [
     # (orl_ppo_reduce_pair_comm / orl_ppo_apply_comm, falls back to "rccl" if peer memory cannot be mapped);
     # "rccl" = one torch.distributed all-reduce (RCCL) per optimiser step.
     ("amd_collective", "str", "p2p", "opt", ["p2p", "rccl"]),
+    # fused recurrent rollout (orl_rnn_rollout_fused): critic workgroups in the same launch, one step behind their
+    # policy workgroups (true), or a second launch after the policy's (false).
+    ("amd_rnn_rollout_chase", "bool", True, "opt", None),
 ]
 
 

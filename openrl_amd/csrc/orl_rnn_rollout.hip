@@ -1,16 +1,21 @@
 // orl_rnn_rollout.hip - fused rollout of a recurrent (GRU) MAPPO policy on the device-resident MPE `simple_spread`
 // (BASELINE config 4): the whole episode_length-step actor_rollout
-// (openrl/drivers/onpolicy_driver.py:154-233 with use_recurrent_policy) in TWO launches instead of
+// (openrl/drivers/onpolicy_driver.py:154-233 with use_recurrent_policy) in ONE launch instead of
 // T x {orl_rnn_act_step, orl_mpe_step, orl_buffer_insert}.
 //
-//   rnn_rollout_mpe_policy_kernel : one workgroup = 16 worlds; wave a = agent a of those worlds (a 16-row tile of the
-//       policy tower, weights staged into LDS once).  Hidden states stay in registers for all T steps, the worlds in
-//       the registers of 16 lanes; actions reach the world lanes and the new observations reach the towers through
-//       LDS.  Every per-step buffer field (obs / share_obs, actions, log-probs, rewards, masks, rnn_states) is written
-//       from here, the observations as coalesced copies of the LDS tile.
-//   rnn_rollout_critic_kernel     : the critic has no influence on the trajectory, so it sweeps the stored share_obs
-//       afterwards: one wave per 16-row tile, T + 1 steps with its hidden state in registers (the last step is the
-//       bootstrap value of compute_returns), next step's observation prefetched behind the current step's GEMMs.
+//   policy workgroups : 16 worlds each; wave a = agent a of those worlds (a 16-row tile of the policy tower, weights
+//       staged into LDS once).  Hidden states stay in registers for all T steps, the worlds in the registers of 16
+//       lanes; actions reach the world lanes and the new observations reach the towers through LDS.  Every per-step
+//       buffer field (obs / share_obs, actions, log-probs, rewards, masks, rnn_states) is written from here, the
+//       observations as coalesced copies of the LDS tile.
+//   critic workgroups : the critic has no influence on the trajectory, so it only consumes the stored share_obs:
+//       one wave per 16-row tile, T + 1 steps with its hidden state in registers (the last step is the bootstrap
+//       value of compute_returns).
+// The two kinds alternate in the grid (block 2b = policy of worlds 16b.., block 2b+1 = critic of the same 48 rows) and
+// the critic CHASES its policy workgroup one step behind through a per-pair step counter in global memory (release
+// store after slot t+1 is written, acquire spin before it is read; the spin is bounded by the wall clock and a
+// critic only ever waits for a LOWER-numbered block, which the dispatcher has already placed).  Without the counter
+// array (sync_flags == NULL) the two kinds run as two launches, critic after policy.
 //
 // Both use the per-tile arithmetic of the stepwise kernels (rnn_tower_fwd_lds, sample_head, mpe_advance) and the same
 // Philox counters (act_seed, row, rng_step0 + t), so a fused rollout reproduces the stepwise one.
@@ -31,12 +36,25 @@ struct RnnRolloutArgs {
   int world_length, deterministic;
   uint64_t env_seed, act_seed, rng_step0;
   const unsigned long long* rng_dev;
+  int* flags;  // [n_pairs + 1]: steps published by policy workgroup b; [n_pairs] = error word (chase timed out)
 };
+
+constexpr unsigned long long CHASE_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
+
+// Device-coherent accesses for the data a critic workgroup reads while its policy workgroup is still running (the two
+// may sit on different XCDs, whose L2s are not coherent for ordinary cached accesses): relaxed agent-scope atomics are
+// written through / read around the non-coherent levels, so no L2 write-back (an agent-scope RELEASE fence flushes the
+// whole L2: measured 2.3x on the policy's step) is needed - only program order plus the step counter.
+__device__ inline void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 constexpr int OBS_S = 20;  // padded LDS row of one agent's observation (18 -> 20 floats: fc1's k-steps of 4)
 
-template <int NO>
-__global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_policy_kernel(RnnRolloutArgs A) {
+// bid = index of the 16-world group; CHASE: publish the step counter for the critic workgroup of the same group
+template <int NO, bool CHASE>
+__device__ __forceinline__ void rnn_rollout_policy_body(const RnnRolloutArgs& A, const int bid) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const orl_buffer_ptrs& b = A.buf;
   const RnnLayout tl(A.pnet);
@@ -50,7 +68,7 @@ __global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_policy_kernel(RnnRollo
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
   const int N = b.N, T = b.T;
   const int LA = N * MPE_A;
-  const int e0 = blockIdx.x * TILE_B;
+  const int e0 = bid * TILE_B;
   const int env = e0 + j;
   const bool ok = env < N;
   const int row = (ok ? env : 0) * MPE_A + wave;  // this lane's buffer row (world, agent = wave)
@@ -127,7 +145,8 @@ __global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_policy_kernel(RnnRollo
       const int jj = threadIdx.x / MPE_A;
       const size_t r1 = (size_t)(t + 1) * LA + (size_t)e0 * MPE_A + threadIdx.x;
       b.rewards[(size_t)t * LA + (size_t)e0 * MPE_A + threadIdx.x] = s_rew[jj];
-      b.masks[r1] = s_done[jj] != 0.f ? 0.f : 1.f;
+      if (CHASE) st_agent(b.masks + r1, s_done[jj] != 0.f ? 0.f : 1.f);
+      else b.masks[r1] = s_done[jj] != 0.f ? 0.f : 1.f;
       b.active_masks[r1] = 1.f;  // (done && !all_done) never holds: the agents of a world share the done flag
       b.bad_masks[r1] = 1.f;
     }
@@ -146,9 +165,15 @@ __global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_policy_kernel(RnnRollo
         const int jj = e / (MPE_A * MPE_COBS), r = e - jj * (MPE_A * MPE_COBS), c = r % MPE_COBS;
         const int i2 = c / MPE_OBS, k = c - i2 * MPE_OBS;
         const float v = s_obs[(i2 * TILE_B + jj) * OBS_S + k];
-        dc[e] = v;
+        if (CHASE) st_agent(dc + e, v);
+        else dc[e] = v;
         if (t == T - 1 && A.obs_c_out != nullptr) A.obs_c_out[(size_t)e0 * MPE_A * MPE_COBS + e] = v;
       }
+    }
+    if (CHASE) {  // slot t+1 (share_obs, masks) is complete: publish it to the critic workgroup of this group
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have been acknowledged
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(A.flags + bid, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (world_lane) {
@@ -160,8 +185,10 @@ __global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_policy_kernel(RnnRollo
   }
 }
 
-// Critic sweep over the stored observations: rows [0, N*A) of every slot; tile = 16 consecutive rows per wave.
-__global__ __launch_bounds__(128, 1) void rnn_rollout_critic_kernel(RnnRolloutArgs A) {
+// Critic sweep over the stored observations, rows [0, N*A) of every slot; one 16-row tile per wave.  CHASE: tile =
+// 3 * bid + wave (the rows of policy group bid) and slot t is read only after that group has published step t.
+template <bool CHASE>
+__device__ __forceinline__ void rnn_rollout_critic_body(const RnnRolloutArgs& A, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const orl_buffer_ptrs& b = A.buf;
   const RnnLayout tl(A.cnet);
@@ -176,7 +203,7 @@ __global__ __launch_bounds__(128, 1) void rnn_rollout_critic_kernel(RnnRolloutAr
   const int nwv = blockDim.x >> 6;
   constexpr int XK = 16;  // k-steps of 4 observation columns held per lane (D <= 64)
   float* slab = smem + tw.total + wave * TILE_B * 64;  // this wave's observation tile [16][DP]
-  for (int tile = blockIdx.x * nwv + wave; tile < n_tiles; tile += gridDim.x * nwv) {
+  for (int tile = bid * nwv + wave; tile < n_tiles; tile += nblk * nwv) {
     const int row = tile * TILE_B + j;
     const bool ok = row < LA;
     const int rr = ok ? row : 0;
@@ -189,13 +216,25 @@ __global__ __launch_bounds__(128, 1) void rnn_rollout_critic_kernel(RnnRolloutAr
 #pragma unroll
       for (int s = 0; s < XK; ++s) {
         const int c = 4 * s + q;
-        x[s] = (4 * s < D && c < D) ? xr[c] : 0.f;
+        x[s] = (4 * s < D && c < D) ? (CHASE && t > 0 ? ld_agent(xr + c) : xr[c]) : 0.f;
+      }
+    };
+    // chase: bounded wait until the policy group has published `need` steps (all lanes of the wave spin together)
+    auto wait_for = [&](int need) {
+      if (__hip_atomic_load(A.flags + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(A.flags + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > CHASE_TIMEOUT_TICKS) {
+          A.flags[(b.N + TILE_B - 1) / TILE_B] = 1;  // error word: the rollout's critic outputs are not valid
+          break;
+        }
       }
     };
     load_x(0, xv);
     for (int t = 0; t <= T; ++t) {
       float xn[XK], mkn = 0.f;
-      if (t < T) {  // next slot's inputs (written by the policy launch), in flight behind this step's GEMMs
+      if (!CHASE && t < T) {  // next slot's inputs in flight behind this step's GEMMs
         load_x(t + 1, xn);
         mkn = b.masks[(size_t)(t + 1) * LA + rr];
       }
@@ -215,6 +254,11 @@ __global__ __launch_bounds__(128, 1) void rnn_rollout_critic_kernel(RnnRolloutAr
         break;
       }
       if (ok && q == 0) A.value_preds[(size_t)t * LA + row] = v[0];
+      if (CHASE) {  // slot t+1 exists once the policy group has finished step t; by now it usually has
+        wait_for(t + 1);
+        load_x(t + 1, xn);
+        mkn = ld_agent(b.masks + (size_t)(t + 1) * LA + rr);
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) h[m] = hnew[m] * mkn;  // rnn_states_critic[dones_env] = 0
       if (ok) {
@@ -226,6 +270,23 @@ __global__ __launch_bounds__(128, 1) void rnn_rollout_critic_kernel(RnnRolloutAr
       for (int s = 0; s < XK; ++s) xv[s] = xn[s];
     }
   }
+}
+
+template <int NO>
+__global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_policy_kernel(RnnRolloutArgs A) {
+  rnn_rollout_policy_body<NO, false>(A, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(128, 1) void rnn_rollout_critic_kernel(RnnRolloutArgs A) {
+  rnn_rollout_critic_body<false>(A, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// policy and critic workgroups interleaved, the critic one step behind its policy group
+template <int NO>
+__global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_chase_kernel(RnnRolloutArgs A) {
+  const int bid = (int)blockIdx.x >> 1;
+  if ((blockIdx.x & 1) == 0) rnn_rollout_policy_body<NO, true>(A, bid);
+  else rnn_rollout_critic_body<true>(A, bid, (int)gridDim.x >> 1);
 }
 
 }  // namespace orl
@@ -256,28 +317,36 @@ int orl_rnn_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const o
   A.obs_c_out = a->obs_critic_out; A.next_value = a->next_value; A.world_length = a->world_length;
   A.deterministic = a->deterministic; A.env_seed = a->env_seed; A.act_seed = a->act_seed; A.rng_step0 = a->rng_step0;
   A.rng_dev = (const unsigned long long*)a->rng_step_dev;
+  A.flags = a->sync_flags;
   hipStream_t s = (hipStream_t)stream;
-  {
-    const RnnLds tw(MPE_OBS, 5, false);
-    const size_t lds = (size_t)(tw.total + MPE_A * TILE_B * OBS_S + MPE_A * TILE_B + 2 * TILE_B) * sizeof(float);
-    ORL_REQUIRE(lds <= 160 * 1024, "orl_rnn_rollout_fused: policy image %zu B exceeds the LDS", lds);
-    (void)hipFuncSetAttribute((const void*)rnn_rollout_mpe_policy_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  const RnnLds twp(MPE_OBS, 5, false), twc(MPE_COBS, 1, false);
+  const size_t lds_p = (size_t)(twp.total + MPE_A * TILE_B * OBS_S + MPE_A * TILE_B + 2 * TILE_B) * sizeof(float);
+  const size_t lds_c = (size_t)(twc.total + 3 * TILE_B * 64) * sizeof(float);
+  ORL_REQUIRE(lds_p <= 160 * 1024 && lds_c <= 160 * 1024, "orl_rnn_rollout_fused: tower image exceeds the LDS");
+  const int n_groups = (b.N + TILE_B - 1) / TILE_B;
+  if (a->sync_flags != nullptr) {  // one launch, critic workgroups chase their policy workgroups
+    if (hipMemsetAsync(a->sync_flags, 0, (size_t)(n_groups + 1) * sizeof(int), s) != hipSuccess)
+      return fail(ORL_E_INVALID, "orl_rnn_rollout_fused: clearing the step counters failed");
+    const size_t lds = lds_p > lds_c ? lds_p : lds_c;
+    (void)hipFuncSetAttribute((const void*)rnn_rollout_mpe_chase_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    const int grid = (b.N + TILE_B - 1) / TILE_B;
-    hipLaunchKernelGGL((rnn_rollout_mpe_policy_kernel<8>), dim3(grid), dim3(192), lds, s, A);
+    hipLaunchKernelGGL((rnn_rollout_mpe_chase_kernel<8>), dim3(2 * n_groups), dim3(192), lds, s, A);
+    return launch_status("orl_rnn_rollout_fused(chase)");
+  }
+  {
+    (void)hipFuncSetAttribute((const void*)rnn_rollout_mpe_policy_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_p);
+    hipLaunchKernelGGL((rnn_rollout_mpe_policy_kernel<8>), dim3(n_groups), dim3(192), lds_p, s, A);
     const int rc = launch_status("orl_rnn_rollout_fused(policy)");
     if (rc) return rc;
   }
   {
-    const RnnLds tw(MPE_COBS, 1, false);
-    const size_t lds = (size_t)(tw.total + 2 * TILE_B * 64) * sizeof(float);
-    ORL_REQUIRE(lds <= 160 * 1024, "orl_rnn_rollout_fused: critic image %zu B exceeds the LDS", lds);
     (void)hipFuncSetAttribute((const void*)rnn_rollout_critic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+                              (int)lds_c);
     const int n_tiles = (b.N * b.A + TILE_B - 1) / TILE_B;
     int grid = (n_tiles + 1) / 2;
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(rnn_rollout_critic_kernel, dim3(grid), dim3(128), lds, s, A);
+    hipLaunchKernelGGL(rnn_rollout_critic_kernel, dim3(grid), dim3(128), lds_c, s, A);
   }
   return launch_status("orl_rnn_rollout_fused(critic)");
 }

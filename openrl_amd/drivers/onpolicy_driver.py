@@ -130,6 +130,7 @@ class OnPolicyDriver:
                           and not per_step_cb)
         self._graph = None
         self._rng_ctr = None
+        self._chase_flags = None  # orl_rnn_rollout_fused step counters (recurrent fused rollout)
         self._staging = None if dev_env else HostStaging(self.device)
         d = self.buffer.data
         self._next_value = torch.zeros(d.n_rollout_threads, d.num_agents, 1, dtype=torch.float32, device=self.device)
@@ -227,6 +228,11 @@ class OnPolicyDriver:
             a.env_kind, a.world_length, a.deterministic = env.env_kind, env.episode_limit, 0
             a.env_seed, a.act_seed = env.seed & (2 ** 64 - 1), mod.act_seed & (2 ** 64 - 1)
             a.rng_step0 = int(mod.rng_step)
+            if bool(getattr(self.cfg, "amd_rnn_rollout_chase", True)):  # critic in the same launch, one step behind
+                if self._chase_flags is None:
+                    self._chase_flags = torch.zeros((d.n_rollout_threads + 15) // 16 + 1, dtype=torch.int32,
+                                                    device=self.device)
+                a.sync_flags = nat.ptr(self._chase_flags)
             ops_rnn.rnn_rollout_fused(p.net, p.theta, c.net, c.theta, a, self.device)
             env.global_step += self.episode_length
             mod.rng_step += self.episode_length

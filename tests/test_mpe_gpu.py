@@ -183,8 +183,8 @@ def test_graph_captured_rollout_equals_eager_rollout(recurrent):
     assert torch.equal(tha, thb)
 
 
-@pytest.mark.parametrize("N", [96, 50])
-def test_fused_recurrent_rollout_equals_stepwise_rollout(N):
+@pytest.mark.parametrize("N,chase", [(96, "true"), (50, "true"), (96, "false"), (2048, "true")])
+def test_fused_recurrent_rollout_equals_stepwise_rollout(N, chase):
     """orl_rnn_rollout_fused (policy + MPE world in one launch, critic sweep in a second) against the stepwise
     T x {orl_rnn_act_step, orl_mpe_step, orl_buffer_insert_rnn} rollout: same per-tile arithmetic and Philox counters,
     so actions / rewards / masks agree exactly and the float fields to fp32 round-off; 4 iterations with updates in
@@ -201,7 +201,7 @@ def test_fused_recurrent_rollout_equals_stepwise_rollout(N):
         T, iters = 25, 4
         cfg = default_cfg(["--seed", "3", "--episode_length", str(T), "--use_recurrent_policy", "true", "--ppo_epoch", "2",
                            "--amd_perm_mode", "device", "--amd_use_graph", "false", "--amd_rollout_mode", mode,
-                           "--log_interval", "1000000"])
+                           "--amd_rnn_rollout_chase", chase, "--log_interval", "1000000"])
         env = make("simple_spread", env_num=N, device=DEV, seed=3)
         net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
         cfg.num_env_steps = N * T * iters
@@ -228,6 +228,8 @@ def test_fused_recurrent_rollout_equals_stepwise_rollout(N):
             snaps[-1]["env_state"], snaps[-1]["ep_stats"] = env.env_state.clone(), env.ep_stats.clone()
             buf.after_update()
         assert agent.num_time_steps == N * T * iters
+        if drv._chase_flags is not None:  # the last word is set when a critic's bounded wait timed out
+            assert int(drv._chase_flags[-1]) == 0 and int(drv._chase_flags[:-1].min()) == T
         return snaps, net.module.models["policy"].theta.clone(), net.module.rng_step, env.global_step
 
     a, tha, ra, ga = run("fused")
