@@ -113,9 +113,12 @@ class PPOAlgorithm(BaseAlgorithm):
         if cfg.use_joint_action_loss and not cfg.use_recurrent_policy:
             raise NotImplementedError("use_joint_action_loss is built for recurrent policies (recurrent_generator_v3, "
                                       "the only generator the reference pairs it with, ppo.py:363-372)")
-        if cfg.use_naive_recurrent_policy:
-            raise NotImplementedError("naive_recurrent_generator is not built in this engine (use_recurrent_policy is)")
         super().__init__(cfg, init_module, agent_num, device)
+        # use_naive_recurrent_policy (get_data_generator, ppo.py:365-372): naive_recurrent_generator samples whole
+        # trajectories per (env, agent) lane with randperm(lanes) - exactly recurrent_generator's chunks of length
+        # episode_length (one chunk per lane, the same permutation stream, the same (L, Nc) row order), so it runs
+        # through the chunked update with L = T (set per update from the buffer)
+        self.naive_recurrent = bool(cfg.use_naive_recurrent_policy) and not bool(cfg.use_recurrent_policy)
         self.train_list = [self.train_ppo]
         self.hp = ops.make_hparams(cfg)
         self.generic = bool(getattr(self.algo_module, "generic", False))
@@ -398,6 +401,8 @@ class PPOAlgorithm(BaseAlgorithm):
 
     # ------------------------------------------------------------------------------------------ reference API
     def train_ppo(self, buffer, turn_on: bool = True) -> Dict[str, float]:
+        if self.naive_recurrent:
+            self.data_chunk_length = buffer.episode_length
         self._advantages_and_records(buffer)
         M = buffer.episode_length * buffer.n_rollout_threads * buffer.num_agents
         # one minibatch == every sample (recurrent: every chunk, when the chunks tile the batch exactly)

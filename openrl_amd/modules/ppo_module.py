@@ -227,7 +227,8 @@ class PPOModule:
         if cls is PPOModule and act_space is not None:
             from .generic_net import GenericPPOModule, needs_generic
 
-            if needs_generic(cfg, act_space, share_model) and not cfg.use_recurrent_policy:
+            if needs_generic(cfg, act_space, share_model) and not (cfg.use_recurrent_policy
+                                                                    or cfg.use_naive_recurrent_policy):
                 return object.__new__(GenericPPOModule)
         return object.__new__(cls)
 
@@ -240,7 +241,7 @@ class PPOModule:
             raise NotImplementedError("use_share_model with use_recurrent_policy is not built (feed-forward only)")
         if model_dict:
             raise NotImplementedError("custom model_dict towers are not built: the engine runs its own towers")
-        for flag in ("use_naive_recurrent_policy", "use_influence_policy", "use_popart",
+        for flag in ("use_influence_policy", "use_popart",
                      "use_feature_normalization", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp",
                      "use_deepspeed", "use_single_network"):
             if getattr(cfg, flag, False):
@@ -248,7 +249,9 @@ class PPOModule:
         if cfg.layer_N != 1 or cfg.hidden_size != 64 or cfg.activation_id != 1:
             raise NotImplementedError("recurrent towers are built for layer_N=1, hidden_size=64, ReLU (got %d, %d, %d)"
                                       % (cfg.layer_N, cfg.hidden_size, cfg.activation_id))
-        self.recurrent = bool(cfg.use_recurrent_policy)
+        # use_naive_recurrent_policy builds the same RNNLayer towers (policy_network.py:82-90); only the update's data
+        # generator differs (PPOAlgorithm)
+        self.recurrent = bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy)
         if self.recurrent and (cfg.recurrent_N != 1 or getattr(cfg, "rnn_type", "gru") != "gru"):
             raise NotImplementedError("recurrent towers are built for a one-layer GRU (recurrent_N=1, rnn_type=gru)")
         self.cfg = cfg

@@ -329,7 +329,7 @@ def _train_case_full(name, argv, N, T, D, n_act, seed=0):
     print(name + ".npz", {k: float(info[k]) for k in info})
 
 
-def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=0):
+def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=0, naive=False):
     """use_recurrent_policy: hand-driven rollout (rnn states zeroed on env-done, onpolicy_driver.py:91-108),
     then PPOAlgorithm.train with recurrent_generator (ppo.py:363-372, replay_data.py:1062-1258)."""
     from gymnasium.spaces import Box, Dict as DictSpace
@@ -338,7 +338,10 @@ def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=
     from openrl.modules.ppo_module import PPOModule
     from openrl.utils.util import set_seed
 
-    cfg = _cfg(["--use_recurrent_policy", "true"] + argv, N, T)
+    # naive: use_naive_recurrent_policy -> the same RNNLayer towers, trained on whole-trajectory sequences through
+    # naive_recurrent_generator (ppo.py:365-372, replay_data.py:806-960)
+    rnn_flag = ["--use_naive_recurrent_policy", "true"] if naive else ["--use_recurrent_policy", "true"]
+    cfg = _cfg(rnn_flag + argv, N, T)
     cfg.num_agents = A
     cfg.seed = seed
     act_space = act_space_fn()
@@ -411,7 +414,7 @@ def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=
     if vn is not None:
         out["vn_state1"] = np.array([vn.running_mean.item(), vn.running_mean_sq.item(), vn.debiasing_term.item()],
                                     np.float32)
-    out["argv"] = np.array(" ".join(["--use_recurrent_policy", "true"] + argv))
+    out["argv"] = np.array(" ".join(rnn_flag + argv))
     out["perm_seed"] = np.array(4321 + seed)
     # deterministic probe with non-trivial states and a zero mask on theta1
     B = 12
@@ -555,6 +558,10 @@ def main():
         "train_recurrent_jrpo": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--use_joint_action_loss", "true", "--lr", "7e-4",
                 "--critic_lr", "7e-4"], 18, 54, lambda: Discrete(5), N=6, A=3, T=8, seed=8),
+        # use_naive_recurrent_policy: whole trajectories per lane (naive_recurrent_generator)
+        "train_naive_recurrent": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 7, 7,
+            lambda: Discrete(4), N=5, A=2, T=6, seed=9, naive=True),
         "train_recurrent_chunk5": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--data_chunk_length", "5"], 6, 6,
             lambda: Box(-1, 1, (2,)), N=5, A=1, T=10, seed=6),

@@ -6,7 +6,7 @@ from oracle import ppo_oracle as po
 from oracle import rnn_oracle as ro
 from tests import helpers as H
 
-RNN_CASES = ["train_recurrent", "train_recurrent_chunk5"]
+RNN_CASES = ["train_recurrent", "train_recurrent_chunk5", "train_naive_recurrent"]
 
 
 def rnn_specs(g):
@@ -28,7 +28,9 @@ def rnn_oracle_replay(g):
     vn = po.ValueNormOracle() if cfg.use_valuenorm else None
     buf = H.case_buffer(g)
     torch.manual_seed(int(g["perm_seed"]))
+    # naive_recurrent_generator (replay_data.py:806-960) = whole trajectories per lane: chunks of length T
+    L = g["buf_actions"].shape[0] if (cfg.use_naive_recurrent_policy and not cfg.use_recurrent_policy) else cfg.data_chunk_length
     info, adv, used = ro.train_ppo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, buf, cfg.ppo_epoch,
-                                   cfg.num_mini_batch, cfg.data_chunk_length)
+                                   cfg.num_mini_batch, L)
     return dict(ptheta=ptheta.numpy(), ctheta=ctheta.numpy(), info=info, adv=adv, used=used,
                 vn=None if vn is None else vn.state(), cfg=cfg, hp=hp, pspec=pspec, cspec=cspec)
