@@ -69,7 +69,15 @@ int orl_comm_create(int rank, int world, int64_t capacity_floats, orl_comm** com
   const int64_t cap = (capacity_floats + 63) & ~(int64_t)63;
   c->bytes = (size_t)2 * world * cap * sizeof(unsigned long long);
   hipError_t e = hipGetDevice(&c->device);
-  if (e == hipSuccess) e = hipMalloc(&c->local, c->bytes);
+  // fine-grained device memory: peers write it and the owner polls it WHILE kernels run on both sides, which is what
+  // fine-grained coherence is specified for (coarse-grained memory is only guaranteed coherent at kernel boundaries)
+  if (e == hipSuccess) {
+    e = hipExtMallocWithFlags(&c->local, c->bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      e = hipMalloc(&c->local, c->bytes);
+    }
+  }
   if (e == hipSuccess) e = hipMemset(c->local, 0, c->bytes);  // tag 0 is never a live sequence number
   if (e == hipSuccess) e = hipMalloc((void**)&c->err_dev, sizeof(int));
   if (e == hipSuccess) e = hipMemset(c->err_dev, 0, sizeof(int));

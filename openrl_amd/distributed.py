@@ -143,6 +143,21 @@ def make_small_allreduce(capacity_floats: int, device, mode: str = "p2p"):
         import warnings
 
         warnings.warn("orl_comm unavailable (%s): falling back to torch.distributed all-reduces" % (e,))
+    if ok:  # self-test on THIS node's links before anything depends on it: a known sum, both inbox parities
+        try:
+            W, r = dist.get_world_size(), dist.get_rank()
+            pat = (1 + torch.arange(comm.capacity, device=comm.device) % 7).to(torch.float32)
+            for _ in range(2):
+                t = pat * float(r + 1)
+                comm.allreduce_(t)
+                comm.check()
+                if not torch.equal(t, pat * float(W * (W + 1) // 2)):
+                    raise RuntimeError("orl_allreduce_small self-test: wrong sum on rank %d" % r)
+        except Exception as e:
+            ok = 0
+            import warnings
+
+            warnings.warn("orl_comm self-test failed (%s): falling back to torch.distributed all-reduces" % (e,))
     flags = [None] * dist.get_world_size()
     dist.all_gather_object(flags, ok)
     if not all(flags):
