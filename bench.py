@@ -130,6 +130,8 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
+    if getattr(trainer, "_comm", None) is not None:
+        trainer._comm.check()  # a peer that never arrived (device-side timeout) must fail the run, not shade the number
     global_envs = args.envs if args.scaling == "strong" else args.envs * world
     steps_total = global_envs * T_ROLL * args.steps
     value = steps_total / dt
