@@ -395,7 +395,36 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     f32x4 n2[4];
     trunk_fwd_coop(tlds, tww, xb, gA, gB, gw, j, q, n2, rp);
     float act_o[NO];
-    if (wave == 0) {
+    if constexpr (HMM && HEAD == ORL_HEAD_GAUSSIAN) {
+      // Wide Gaussian heads: the MFMA leaves means 4q..4q+3 of row j in lane (j, q) - each lane samples exactly those
+      // dimensions (same expressions as sample_head) and stores them, instead of every lane of a row walking all NO
+      // dimensions after a trip of the tile through LDS: this phase was 3 300 of the step's 7 900 cycles at Box(6).
+      if (wave == 0) {
+        const int no4 = (n_out + 3) & ~3;
+        f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (4 * q < no4) mu = *(const f32x4*)(smem + twp.b3 + 4 * q);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const f32x4 a4 = *(const f32x4*)(smem + twp.W3P + j * W2S + 16 * mi + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mu = ORL_MFMA(a4[r], n2[mi][r], mu);
+        }
+        const float* noise = s_noise + (t & 1) * TILE_B * 16 + j * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * q + r;
+          if (ok && c < n_out) {
+            const float ls = smem[twp.logstd + c];
+            const float sd = expf(ls);
+            const float av = mu[r] + sd * noise[c];
+            const float d = av - mu[r];
+            const float lp = -(d * d) / (2.f * (sd * sd)) - ls - 0.91893853320467274178f;
+            A.r.actions[((size_t)t * N + n) * a_w + c] = av;
+            A.r.action_log_probs[((size_t)t * N + n) * a_w + c] = lp;
+          }
+        }
+      }
+    } else if (wave == 0) {
       float hd[NO], lp_o[NO];
       if constexpr (HMM) head_mfma_T<NO>(smem + twp.W3P, smem + twp.b3, n_out, n2, s_logits, j, q, hd);
       else head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);

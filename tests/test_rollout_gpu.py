@@ -80,10 +80,20 @@ def _build(env_id, N, T, seed=3, **kw):
     ("CartPole-v1", {}, 50, 23),
     # the headline size (bench.py: BASELINE.json configs[1]): 256 workgroups x 128 steps of the fused kernel
     ("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=200), 4096, 128),
+    # wide Gaussian head (cfg3's HalfCheetah shape): the fused kernel samples per lane from the MFMA fragment
+    ("SyntheticFixedStep-v0", dict(obs_dim=17, episode_limit=9, action_space="box6"), 70, 21),
+    # narrow Gaussian head (scalar head path)
+    ("SyntheticFixedStep-v0", dict(obs_dim=5, episode_limit=9, action_space="box3"), 40, 11),
 ])
 def test_fused_rollout_equals_stepwise_rollout(env_id, kw, N, T):
     from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
 
+    box = None
+    if isinstance(kw.get("action_space"), str):  # "box<k>" -> Box(-1, 1, (k,))
+        from openrl_amd import spaces
+
+        box = int(kw["action_space"][3:])
+        kw = dict(kw, action_space=spaces.Box(-1.0, 1.0, (box,)))
     bufs = []
     for mode in ("fused", "stepwise"):
         cfg, env, net, trainer, buf, agent = _build(env_id, N, T, **kw)
@@ -101,7 +111,11 @@ def test_fused_rollout_equals_stepwise_rollout(env_id, kw, N, T):
     # output element) but hipcc contracts the LayerNorm / head arithmetic differently in the two kernels, so float
     # fields agree to a few ulp, not bitwise; a sampled action can flip only when its uniform sits on a CDF edge.
     act_a, act_b = a.actions.cpu().numpy(), b.actions.cpu().numpy()
-    same = act_a == act_b
+    if box is not None:  # continuous actions: mean + std * eps with the same Philox normals, to fp32 round-off
+        np.testing.assert_allclose(act_a, act_b, rtol=1e-5, atol=1e-6)
+        same = np.ones_like(act_a, dtype=bool)
+    else:
+        same = act_a == act_b
     assert same.mean() >= 0.999, same.mean()
     if env_id.startswith("Synthetic"):  # observations do not depend on actions: every step is comparable
         for f in ("policy_obs", "rewards", "masks", "active_masks", "bad_masks"):
