@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--T", type=int, default=200)
     ap.add_argument("--opponent", default="random", choices=["random", "pool"],
                     help="pool: self-play against 4 frozen snapshots of the learner (stepwise rollout, hipGraph)")
+    ap.add_argument("--sampling", default="per_rollout", choices=["per_reset", "per_rollout", "static"],
+                    help="pool opponent assignment: per_reset = the reference's per-episode draw (stepwise rollout as a "
+                         "hipGraph, per-env pool act launch); per_rollout / static keep one snapshot per 16-env tile, "
+                         "which the fused rollout kernel plays in-kernel")
     a = ap.parse_args()
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers import NormalReplayBuffer
@@ -36,7 +40,8 @@ def main():
 
     dev, N, T = "cuda:0", a.envs, a.T
     cfg = default_cfg(["--seed", "0", "--episode_length", str(T), "--amd_perm_mode", "device", "--log_interval", "1000000"])
-    env = make("tictactoe_v3", env_num=N, device=dev, opponent=a.opponent)
+    kw = dict(opponent_sampling=a.sampling) if a.opponent == "pool" else {}
+    env = make("tictactoe_v3", env_num=N, device=dev, opponent=a.opponent, **kw)
     if a.opponent == "pool":
         torch.manual_seed(1)
         env.opp_thetas.copy_(0.1 * torch.randn_like(env.opp_thetas))  # non-trivial opponents from the start
@@ -73,7 +78,9 @@ def main():
     print(json.dumps({"bench": "cfg5_tictactoe_%s_opponent" % a.opponent, "envs": N, "episode_length": T, "ppo_epoch": cfg.ppo_epoch,
                       "env_steps_per_s": N * T * a.steps / dt, "ms_per_iteration": dt / a.steps * 1e3,
                       "ms_rollout": t_roll / a.steps * 1e3, "ms_update": t_upd / a.steps * 1e3,
-                      "games_finished": st["episodes_finished"], "mean_game_result": st["episode_return_mean"]}))
+                      "games_finished": st["episodes_finished"], "mean_game_result": st["episode_return_mean"],
+                      "rollout": "fused" if drv.fused else "stepwise (hipGraph)",
+                      "opponent_sampling": a.sampling if a.opponent == "pool" else None}))
 
 
 if __name__ == "__main__":

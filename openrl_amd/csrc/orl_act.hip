@@ -424,6 +424,27 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
           }
         }
       }
+    } else if constexpr (HMM && HEAD == ORL_HEAD_CATEGORICAL) {
+      // Wide categorical heads: sampled on the MFMA fragment (sample_cat_frag) - no trip of the logits tile through
+      // LDS, 4 classes per lane instead of NO per lane: this phase was 4 200 of the step's 8 900 cycles at Discrete(9).
+      if (wave == 0) {
+        const int no4 = (n_out + 3) & ~3;
+        f32x4 lgv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (4 * q < no4) lgv = *(const f32x4*)(smem + twp.b3 + 4 * q);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const f32x4 a4 = *(const f32x4*)(smem + twp.W3P + j * W2S + 16 * mi + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lgv = ORL_MFMA(a4[r], n2[mi][r], lgv);
+        }
+        float av, lp;
+        sample_cat_frag(lgv, n_out, q, IS_TTT ? s_mask + j * 16 : nullptr, s_noise[(t & 1) * TILE_B * 16 + j * 16], av, lp);
+        act_o[0] = av;
+        if (ok && q == 0) {
+          A.r.actions[(size_t)t * N + n] = av;
+          A.r.action_log_probs[(size_t)t * N + n] = lp;
+        }
+      }
     } else if (wave == 0) {
       float hd[NO], lp_o[NO];
       if constexpr (HMM) head_mfma_T<NO>(smem + twp.W3P, smem + twp.b3, n_out, n2, s_logits, j, q, hd);
@@ -488,10 +509,22 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
         __syncthreads();
       }
       if (wave == 0) {
-        float ohd[NO], oact[NO], olp[NO];
-        head_mfma_T<NO>(s_opp + twp.W3P, s_opp + twp.b3, n_out, o2, s_logits, j, q, ohd);
-        sample_head<NO, HEAD>(ohd, n_out, nullptr, s_omask + j * 16, nullptr, 0, A.r.opp_seed, (uint64_t)n,
-                              A.r.opp_rng_step0 + (uint64_t)t, oact, olp);
+        float oact[NO], olp;
+        {  // the opponent samples on the fragment too, with its own Philox stream (sample_head's counter layout)
+          const int no4 = (n_out + 3) & ~3;
+          f32x4 lgv = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (4 * q < no4) lgv = *(const f32x4*)(s_opp + twp.b3 + 4 * q);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) {
+            const f32x4 a4 = *(const f32x4*)(s_opp + twp.W3P + j * W2S + 16 * mi + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lgv = ORL_MFMA(a4[r], o2[mi][r], lgv);
+          }
+          const uint64_t og = A.r.opp_rng_step0 + (uint64_t)t;
+          const u4 rr = philox4x32_10(A.r.opp_seed, (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)og,
+                                      (uint32_t)(og >> 32) << 8);
+          sample_cat_frag(lgv, n_out, q, s_omask + j * 16, u01(rr.x), oact[0], olp);
+        }
         // ---- phase B (orl_ttt_opponent_move) ----
         if (q == 0) {
           const size_t s1 = (size_t)(t + 1) * N + n;

@@ -151,6 +151,18 @@ __device__ inline void row_allsum2(float& x, float& y) {
   y = c + d;
 }
 
+// The 4 values of a row (lanes q = 0..3 of the tile row), in every one of its lanes: permlane16_swap of a value with
+// a copy of itself leaves the even-q value of each lane pair in one operand and the odd-q value in the other;
+// permlane32_swap of each of those with a copy of itself separates the two pairs.
+__device__ inline void row_gather4(float s, float (&o)[4]) {
+  float a = s, b = s;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  float c = a, d = a, e = b, f = b;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+               : "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+  o[0] = c; o[1] = e; o[2] = d; o[3] = f;
+}
+
 // max over the same 4 lanes, result in all of them
 __device__ inline float row_allmax(float s) {
   float a = s, b = s;

@@ -62,6 +62,62 @@ __device__ inline void sample_head(float (&hd)[NO], int n_out, const float* lds_
   }
 }
 
+// Categorical sampling on the MFMA fragment of a wide head (head_mfma_T's accumulator BEFORE its trip through LDS):
+// lane (j, q) holds the logits of classes 4q..4q+3 of row j and works on those four only; row-wide maxima / sums / the
+// class that crosses the uniform are combined over the row's 4 lanes with permlane swaps.  Same semantics as
+// cat_lse + cat_sample + pick (masked classes at -6e4, inverse CDF in class order, fall back to the last class of
+// non-zero probability); the sums associate per lane first, so results agree with sample_head to fp32 round-off.
+// Every lane of the row returns the action and its log-probability.
+__device__ inline void sample_cat_frag(const f32x4& lgv, int n_out, int q, const float* __restrict__ mask_row, float u,
+                                       float& act, float& logp) {
+  float lg[4];
+  bool val[4];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = 4 * q + r;
+    val[r] = c < n_out;
+    lg[r] = lgv[r];
+    if (val[r] && mask_row != nullptr && mask_row[c] == 0.f) lg[r] = -6e4f;
+    if (val[r]) mx = fmaxf(mx, lg[r]);
+  }
+  mx = row_allmax(mx);
+  float se = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (val[r]) se += __expf(lg[r] - mx);
+  se = row_allsum(se);
+  const float lse = mx + __logf(se);
+  float p[4], ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    p[r] = val[r] ? __expf(lg[r] - lse) : 0.f;
+    ps += p[r];
+  }
+  float s4[4];
+  row_gather4(ps, s4);
+  const float ut = u * (((s4[0] + s4[1]) + s4[2]) + s4[3]);
+  float cum = (q > 0 ? s4[0] : 0.f) + (q > 1 ? s4[1] : 0.f) + (q > 2 ? s4[2] : 0.f);
+  float cand = 999.f, last = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (val[r]) {
+      cum += p[r];
+      if (p[r] > 0.f) last = (float)(4 * q + r);
+      if (cand == 999.f && cum > ut) cand = (float)(4 * q + r);
+    }
+  }
+  const float first = -row_allmax(-cand);  // the lowest class whose cumulative probability exceeds u * total
+  last = row_allmax(last);
+  const float a = first == 999.f ? last : first;
+  float pk = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if ((float)(4 * q + r) == a) pk = lg[r];
+  act = a;
+  logp = row_allsum(pk) - lse;
+}
+
 // Evaluate GIVEN actions on the head outputs of batch row `row` (ACTLayer.evaluate_actions, utils/act.py:153-172):
 // log-probs (categorical: slot 0; Gaussian: per dimension) and the row's entropy (Gaussian: summed over dimensions).
 template <int NO, int HEAD>
