@@ -696,12 +696,15 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         // the VALU like the ND == 0 path instead of a whole extra 16-column accumulator block
         const int n_rem = D - 16 * ND;
         if (n_rem > 0) {
+          // all four remainder columns are read and accumulated unconditionally (columns >= D are other, finite or
+          // not, fields of the record: their accumulators are never written out) - with a per-column test on n_rem
+          // every read was its own branch + LDS round trip: 5 350 cycles of the tile's 30 100 at obs 18
+#pragma unroll
           for (int r = 0; r < TILE_B; ++r) {
             const float dzv = SS[r * TS + f];
             s_db += dzv;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (k < n_rem) w1v[k] += dzv * REC_R(r, A.o_x + 16 * ND + k);
+            for (int k = 0; k < 4; ++k) w1v[k] += dzv * REC_R(r, A.o_x + 16 * ND + k);
           }
         } else {
           for (int r = 0; r < TILE_B; ++r) s_db += SS[r * TS + f];
@@ -727,6 +730,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #ifdef ORL_PROF
   if (prof_on && l < 12) atomicAdd(&g_orl_prof[l], prof_lds[l]);
   if (prof_on && l == 12) atomicAdd(&g_orl_prof[12], 1ull);
+  if (prof_on && l == 13)  // tiles the probe wave walked (depends on how launch_pair_nd split the CUs)
+    atomicAdd(&g_orl_prof[13], (unsigned long long)((n_tiles - wave_g + n_waves - 1) / n_waves));
 #endif
 #undef REC
 #undef REC_R

@@ -56,7 +56,7 @@ def main():
         algo.train(buf)
         lib.orl_debug_prof(out)  # resets; keep the last iteration
     launches = out[12]
-    tiles = launches * (N * T // 16) // (256 * a.waves)  # --waves must match the build (ORL_TOWER_MAXWAVES)
+    tiles = out[13]  # counted by the probe wave itself (the CU split between the towers varies with the shape)
     tot = sum(out[k] for k in range(11))
     print("waves/workgroup %d: %d launches, %d tiles by the probe wave, %.0f cycles per tile" % (a.waves, launches, tiles,
                                                                                           tot / tiles))
