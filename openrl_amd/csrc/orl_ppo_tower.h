@@ -112,14 +112,20 @@ __device__ inline void ln_bwd_T(f32x4 (&d)[4], const f32x4 (&xhat)[4], const flo
 // the dgrad GEMM reads W2 by columns instead of keeping a transposed copy in LDS (rows 4q apart hit
 // banks 16 apart, so the 4-byte column reads are conflict free).
 __device__ inline void mm64_T_wt(const float* __restrict__ Ws, const f32x4 (&in)[4], f32x4 (&acc)[4], int j, int q) {
+  // column reads of k-step k+1 issued before the MFMAs of k-step k (see mm64_S_wt in orl_rnn.h)
+  float a[2][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mo = 0; mo < 4; ++mo) a[0][mo] = Ws[(4 * q) * W2S + j + 16 * mo];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* row = Ws + (16 * mi + 4 * q + r) * W2S + j;
+  for (int k = 0; k < 16; ++k) {
+    const int mi = k >> 2, r = k & 3;
+    if (k < 15) {
+      const float* row = Ws + (16 * ((k + 1) >> 2) + 4 * q + ((k + 1) & 3)) * W2S + j;
 #pragma unroll
-      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(row[16 * mo], in[mi][r], acc[mo]);
+      for (int mo = 0; mo < 4; ++mo) a[(k + 1) & 1][mo] = row[16 * mo];
     }
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(a[k & 1][mo], in[mi][r], acc[mo]);
   }
 }
 

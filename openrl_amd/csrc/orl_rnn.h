@@ -168,14 +168,22 @@ __device__ inline void mm64_S(const float* __restrict__ Ws, const f32x4 (&in)[4]
 // acc += W^T in  with W row-major [64][S] read by columns (dgrad)
 template <int S>
 __device__ inline void mm64_S_wt(const float* __restrict__ Ws, const f32x4 (&in)[4], f32x4 (&acc)[4], int j, int q) {
+  // the four column reads of k-step (mi, r) + 1 are issued before the four MFMAs of k-step (mi, r): read by columns
+  // every MFMA needs its own 4-byte LDS read, and without the look-ahead each group of 4 opened with an exposed LDS
+  // round trip (the GRU dgrad ran at 59 cycles per MFMA)
+  float a[2][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mo = 0; mo < 4; ++mo) a[0][mo] = Ws[(4 * q) * S + j + 16 * mo];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* row = Ws + (16 * mi + 4 * q + r) * S + j;
+  for (int k = 0; k < 16; ++k) {
+    const int mi = k >> 2, r = k & 3;
+    if (k < 15) {
+      const float* row = Ws + (16 * ((k + 1) >> 2) + 4 * q + ((k + 1) & 3)) * S + j;
 #pragma unroll
-      for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(row[16 * mo], in[mi][r], acc[mo]);
+      for (int mo = 0; mo < 4; ++mo) a[(k + 1) & 1][mo] = row[16 * mo];
     }
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) acc[mo] = ORL_MFMA(a[k & 1][mo], in[mi][r], acc[mo]);
   }
 }
 
