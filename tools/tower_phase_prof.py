@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--waves", type=int, default=8)
     ap.add_argument("--obs", type=int, default=4, help="observation width (4 = config 2; 17 / 18 = configs 3 / 5)")
     ap.add_argument("--act", type=int, default=2, help="Discrete(n)")
+    ap.add_argument("--box", type=int, default=0, help="Box(k) Gaussian policy instead of Discrete(--act)")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--T", type=int, default=128)
     a = ap.parse_args()
     os.environ["ORL_KEEP_BUILD"] = "1"  # load the --prof build as it is
     from openrl_amd import _native as nat
@@ -34,18 +37,23 @@ def main():
     from openrl_amd.configs.config import default_cfg
     from openrl_amd.modules.ppo_module import PPOModule
 
-    dev, N, T = "cuda:0", 4096, 128
+    dev, N, T = "cuda:0", a.envs, a.T
     cfg = default_cfg(["--episode_length", str(T), "--ppo_epoch", "10", "--amd_perm_mode", "device"])
     cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = N, 1, cfg.hidden_size
-    obs_space, act_space = spaces.Box(-np.inf, np.inf, (a.obs,)), spaces.Discrete(a.act)
+    obs_space = spaces.Box(-np.inf, np.inf, (a.obs,))
+    act_space = spaces.Box(-1.0, 1.0, (a.box,)) if a.box else spaces.Discrete(a.act)
     module = PPOModule(cfg, obs_space, obs_space, act_space, device=dev, rank=0, world_size=1)
     buf = ReplayData(cfg, 1, obs_space, act_space, device=dev)
     g = torch.Generator(device=dev).manual_seed(0)
     buf.policy_obs.copy_(torch.randn(T + 1, N, 1, a.obs, device=dev, generator=g))
     buf.rewards.copy_(torch.rand(T, N, 1, 1, device=dev, generator=g))
     buf.value_preds.copy_(0.3 * torch.randn(T + 1, N, 1, 1, device=dev, generator=g))
-    buf.actions.copy_(torch.randint(0, a.act, (T, N, 1, 1), device=dev, generator=g).float())
-    buf.action_log_probs.fill_(float(np.log(1.0 / a.act)))
+    if a.box:
+        buf.actions.copy_(torch.randn(T, N, 1, a.box, device=dev, generator=g))
+        buf.action_log_probs.fill_(-1.0)
+    else:
+        buf.actions.copy_(torch.randint(0, a.act, (T, N, 1, 1), device=dev, generator=g).float())
+        buf.action_log_probs.fill_(float(np.log(1.0 / a.act)))
     algo = PPOAlgorithm(cfg, module, agent_num=1, device=dev)
     lib = nat.load()
     if not hasattr(lib, "orl_debug_prof"):
