@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 201 /* 0.2.1: + orl_rnn_rollout_fused; 0.2.0: rng_step_dev arguments, orl_abi_struct_size, collectives */
+#define ORL_VERSION 202 /* 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -392,8 +392,21 @@ typedef struct orl_rollout_args {
   int32_t opp_reserved;
   uint64_t opp_seed;       /* Philox seed of the opponents' sampling; counter = (env, opp_rng_step0 + t) */
   uint64_t opp_rng_step0;
-  const int32_t* opp_index; /* optional [N]: env n plays pool policy opp_index[n] instead of n / opp_group_rows; the
-                             * fused kernel needs it uniform over each 16-env tile (orl_opponent_sample, per_tile) */
+  const int32_t* opp_index; /* optional [N]: env n plays pool policy opp_index[n] instead of n / opp_group_rows; unless
+                             * opp_per_reset is set the fused kernel needs it uniform over each 16-env tile
+                             * (orl_opponent_sample, per_tile) */
+  /* opp_per_reset != 0 (OpponentPoolWrapper.reset semantics, opponent_pool_wrapper.py:37-66, inside the fused kernel):
+   * every env names its own slot in opp_index, which is READ AND WRITTEN - a finished game draws its next opponent
+   * in-kernel exactly as orl_opponent_sample(per_tile = 0, draw_id = opp_draw_id0 + t) would.  All opp_n_policies
+   * (<= 4) snapshot images stay resident in LDS; the critic then runs as one batched launch after the step loop. */
+  int32_t opp_per_reset;
+  int32_t opp_n_policies;   /* pool slots (images at opp_thetas + k * opp_theta_stride) */
+  int32_t opp_n_filled;     /* slots a RandomOpponent draw may return: [0, opp_n_filled) */
+  int32_t opp_last_slot;    /* LastOpponent's slot */
+  int32_t opp_strategy;     /* 0 RandomOpponent, 1 LastOpponent (orl_opponent_sample) */
+  int32_t opp_pad;
+  uint64_t opp_sample_seed; /* orl_opponent_sample's seed */
+  uint64_t opp_draw_id0;    /* draw id of the rollout's first step */
 } orl_rollout_args;
 
 int orl_env_state_width(int env_kind);

@@ -19,7 +19,7 @@ ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL, ORL_ENV_MPE_SPREAD = 0, 1, 2, 3, 4
 ORL_GATHER_MAX = 12
 ORL_IPC_HANDLE_BYTES = 64
-ORL_VERSION = 201  # must equal include/orl_hip.h; checked against the loaded library
+ORL_VERSION = 202  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -77,7 +77,10 @@ class RolloutArgs(C.Structure):
                 ("env_kind", C.c_int32), ("episode_limit", C.c_int32), ("env_seed", C.c_uint64),
                 ("act_seed", C.c_uint64), ("rng_step0", C.c_uint64), ("opp_thetas", C.c_void_p),
                 ("opp_theta_stride", C.c_int64), ("opp_group_rows", C.c_int32), ("opp_reserved", C.c_int32),
-                ("opp_seed", C.c_uint64), ("opp_rng_step0", C.c_uint64), ("opp_index", C.c_void_p)]
+                ("opp_seed", C.c_uint64), ("opp_rng_step0", C.c_uint64), ("opp_index", C.c_void_p),
+                ("opp_per_reset", C.c_int32), ("opp_n_policies", C.c_int32), ("opp_n_filled", C.c_int32),
+                ("opp_last_slot", C.c_int32), ("opp_strategy", C.c_int32), ("opp_pad", C.c_int32),
+                ("opp_sample_seed", C.c_uint64), ("opp_draw_id0", C.c_uint64)]
 
 
 class RnnBatch(C.Structure):

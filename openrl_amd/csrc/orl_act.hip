@@ -291,6 +291,11 @@ __device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const Tower
 // batched launch of critic_values_kernel over the stored observations - same parameters, the same arithmetic up to
 // the few-ulp contraction differences between the cooperative and the per-wave trunk, but throughput-bound instead of sharing the SIMDs of a
 // latency-bound step loop with the policy.
+// internal variant of ORL_ENV_TTT_POOL (orl_rollout_args.opp_per_reset): every env names its own pool slot, up to 4
+// snapshot images stay resident in LDS (the critic then runs after the fact: WC = false), the opponent's tower is
+// walked once per distinct slot a tile holds, and a finished game draws its next opponent in-kernel with
+// orl_opponent_sample's Philox stream
+#define ORL_ENV_TTT_POOLK 100
 template <int NO, int HEAD, int ENV, bool WC>
 __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   const int DP = twp.DP;
   float* s_obs = smem + twp.total + (WC ? twc.total : 0);  // [2][16][DP]
   float* s_gather = s_obs + 2 * TILE_B * DP;    // [2 towers][2 slabs][16][GS]
-  float* s_noise = s_gather + 4 * TILE_B * GS;  // [2][16][16]: sampling noise of steps t (parity) drawn one step ahead
+  float* s_noise = s_gather + (WC ? 4 : 2) * TILE_B * GS;  // [2][16][16]: sampling noise of step t (parity), drawn one step ahead
   float* s_logits = s_noise + 2 * TILE_B * 16;  // [16][16] logits tile of head_mfma_T (wide heads only)
 
   // waves 0-3: policy tower (wave 0 also samples and steps the env); waves 4-7: critic tower
@@ -332,7 +337,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   // the action, so its step runs on wave 1 concurrently with wave 0's head + sampling; CartPole needs the action
   // and stays on wave 0.
   constexpr int ENV_WAVE = (ENV == ORL_ENV_SYNTH) ? 1 : 0;
-  constexpr bool IS_TTT = ENV == ORL_ENV_TTT || ENV == ORL_ENV_TTT_POOL;
+  constexpr bool PERK = ENV == ORL_ENV_TTT_POOLK;                         // per-env opponents (see above)
+  constexpr bool IS_POOL = ENV == ORL_ENV_TTT_POOL || PERK;
+  constexpr bool IS_TTT = ENV == ORL_ENV_TTT || IS_POOL;
   constexpr int ESW = IS_TTT ? TTT_STATE_W : 8;
   float est[ESW];
   const int SW = (ENV == ORL_ENV_SYNTH) ? SYNTH_STATE_W : IS_TTT ? TTT_STATE_W : CARTPOLE_STATE_W;
@@ -341,9 +348,17 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   float* s_mask = s_logits + TILE_B * 16;  // [16][16]
   // self-play (ORL_ENV_TTT_POOL): the opponent's tower image, the opponent-side boards and masks of the current step
   float* s_opp = s_mask + TILE_B * 16;                         // TowerLds image of this tile's opponent policy
-  float* s_oobs = s_opp + (ENV == ORL_ENV_TTT_POOL ? twp.total : 0);  // [16][DP]
+  const int n_img = PERK ? A.r.opp_n_policies : (IS_POOL ? 1 : 0);
+  float* s_oobs = s_opp + n_img * twp.total;                   // [16][DP]
   float* s_omask = s_oobs + TILE_B * DP;                       // [16][16]
-  if constexpr (ENV == ORL_ENV_TTT_POOL) {
+  float* s_oppk = s_omask + TILE_B * 16;                       // [16] PERK: slot of the row's opponent this step, -1 = none
+  int my_opp = 0;                                              // PERK: this env's pool slot (owning lanes)
+  if constexpr (PERK) {
+    for (int k = 0; k < n_img; ++k)
+      stage_tower(s_opp + k * twp.total, A.r.opp_thetas + (size_t)k * A.r.opp_theta_stride, tlp, twp, false, threadIdx.x,
+                  blockDim.x, HMM);
+    my_opp = ok ? A.r.opp_index[n] : 0;
+  } else if constexpr (IS_POOL) {
     const int first = blockIdx.x * TILE_B;  // opp_index: uniform over the tile (orl_opponent_sample per_tile)
     const int og = A.r.opp_index != nullptr ? A.r.opp_index[first < N ? first : N - 1] : first / A.r.opp_group_rows;
     const float* oth = A.r.opp_thetas + (size_t)og * A.r.opp_theta_stride;
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
         }
       }
     }
-    if constexpr (ENV == ORL_ENV_TTT_POOL) {
+    if constexpr (IS_POOL) {
       // ---- phase A (orl_ttt_agent_move): the agent's move on the owning lanes of wave 0; boards from the opponent's
       // side go to LDS for the opponent's policy
       int ph = 2;
@@ -496,35 +511,51 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
           s_omask[j * 16 + c] = ph == 1 ? (bd[c] == 0 ? 1.f : 0.f) : (c == 0 ? 1.f : 0.f);
         }
         for (int d = 18; d < DP; ++d) s_oobs[j * DP + d] = 0.f;
+        if (PERK) s_oppk[j] = (ok && ph == 1) ? (float)my_opp : -1.f;
       }
       __syncthreads();
       // ---- the opponent's policy: cooperative trunk of the policy group on the opponent-side boards (the critic
       // group only keeps the barrier count)
-      f32x4 o2[4];
-      if (grp == 0) {
-        auto xo = [&](int s) -> float { return s_oobs[j * DP + 4 * s + q]; };
-        trunk_fwd_coop(s_opp, twp, xo, gA, gB, gw, j, q, o2, rp);
-      } else {
-        __syncthreads();
-        __syncthreads();
-      }
+      // One walk of the opponent tower per image: PERK walks image k only if some row of the tile plays slot k this
+      // step (workgroup-uniform test), rows keep the action sampled from their own slot's logits.
+      float oact[NO], olp = 0.f;
+      oact[0] = 0.f;
+      float ou = 0.f;  // the opponent's uniform: its own Philox stream (sample_head's counter layout), one per row
       if (wave == 0) {
-        float oact[NO], olp;
-        {  // the opponent samples on the fragment too, with its own Philox stream (sample_head's counter layout)
+        const uint64_t og = A.r.opp_rng_step0 + (uint64_t)t;
+        const u4 rr = philox4x32_10(A.r.opp_seed, (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)og,
+                                    (uint32_t)(og >> 32) << 8);
+        ou = u01(rr.x);
+      }
+      for (int k = 0; k < (PERK ? n_img : 1); ++k) {
+        const float* img = s_opp + k * twp.total;
+        if (PERK) {
+          if (!__syncthreads_or(s_oppk[j] == (float)k)) continue;
+        }
+        f32x4 o2[4];
+        if (grp == 0) {
+          auto xo = [&](int s) -> float { return s_oobs[j * DP + 4 * s + q]; };
+          trunk_fwd_coop(img, twp, xo, gA, gB, gw, j, q, o2, rp);
+        } else {
+          __syncthreads();
+          __syncthreads();
+        }
+        if (wave == 0) {  // sampled on the MFMA fragment like the learner's action
           const int no4 = (n_out + 3) & ~3;
           f32x4 lgv = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (4 * q < no4) lgv = *(const f32x4*)(s_opp + twp.b3 + 4 * q);
+          if (4 * q < no4) lgv = *(const f32x4*)(img + twp.b3 + 4 * q);
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi) {
-            const f32x4 a4 = *(const f32x4*)(s_opp + twp.W3P + j * W2S + 16 * mi + 4 * q);
+            const f32x4 a4 = *(const f32x4*)(img + twp.W3P + j * W2S + 16 * mi + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) lgv = ORL_MFMA(a4[r], o2[mi][r], lgv);
           }
-          const uint64_t og = A.r.opp_rng_step0 + (uint64_t)t;
-          const u4 rr = philox4x32_10(A.r.opp_seed, (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)og,
-                                      (uint32_t)(og >> 32) << 8);
-          sample_cat_frag(lgv, n_out, q, s_omask + j * 16, u01(rr.x), oact[0], olp);
+          float ak, lk;
+          sample_cat_frag(lgv, n_out, q, s_omask + j * 16, ou, ak, lk);
+          if (!PERK || s_oppk[j] == (float)k) { oact[0] = ak; olp = lk; }
         }
+      }
+      if (wave == 0) {
         // ---- phase B (orl_ttt_opponent_move) ----
         if (q == 0) {
           const size_t s1 = (size_t)(t + 1) * N + n;
@@ -562,6 +593,16 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
               fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f;
               ++episode;
               moves = ttt_begin(bd, A.r.env_seed, (uint32_t)n, (uint32_t)episode);
+              if (PERK) {  // a finished game -> a fresh opponent for the next one (opponent_sample_kernel's draw)
+                int k = A.r.opp_last_slot;
+                if (A.r.opp_strategy == 0) {
+                  const uint64_t id = A.r.opp_draw_id0 + (uint64_t)t;
+                  const u4 r = philox4x32_10(A.r.opp_sample_seed, (uint32_t)n, 0x0FF05A3Fu, (uint32_t)id, (uint32_t)(id >> 32));
+                  k = (int)(u01(r.x) * (float)A.r.opp_n_filled);
+                  k = k < A.r.opp_n_filled - 1 ? k : A.r.opp_n_filled - 1;
+                }
+                my_opp = k < 0 ? 0 : k;
+              }
             }
 #pragma unroll
             for (int c = 0; c < 9; ++c) est[c] = (float)bd[c];
@@ -765,6 +806,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
       if (k < SW) A.r.env_state[(size_t)n * SW + k] = est[k];
     A.r.ep_stats[n * 4 + 0] = ep_ret; A.r.ep_stats[n * 4 + 1] = ep_len;
     A.r.ep_stats[n * 4 + 2] = fin_ret; A.r.ep_stats[n * 4 + 3] = fin_cnt;
+    if (PERK) const_cast<int32_t*>(A.r.opp_index)[n] = my_opp;  // the slots the next rollout / stepwise step starts from
   }
 }
 
@@ -1218,10 +1260,17 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
     ORL_REQUIRE(pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 2 && b.Dp == 4,
                 "orl_rollout_fused: CartPole needs Discrete(2) and 4-d obs");
   const bool pool = args->env_kind == ORL_ENV_TTT_POOL;
+  const bool perk = pool && args->opp_per_reset != 0;  // per-env opponents, re-drawn in-kernel at every auto-reset
   if (pool)
     ORL_REQUIRE(args->opp_thetas && args->opp_group_rows > 0 && args->opp_group_rows % TILE_B == 0 &&
                     args->opp_theta_stride >= 0,
                 "orl_rollout_fused: the opponent pool needs opp_thetas and opp_group_rows (a multiple of %d)", TILE_B);
+  if (perk)
+    ORL_REQUIRE(args->opp_index && args->opp_n_policies >= 1 && args->opp_n_filled >= 1 &&
+                    args->opp_n_filled <= args->opp_n_policies && args->opp_last_slot >= 0 &&
+                    args->opp_last_slot < args->opp_n_policies,
+                "orl_rollout_fused: opp_per_reset needs opp_index and 1 <= opp_n_filled <= opp_n_policies (got %d, %d)",
+                args->opp_n_filled, args->opp_n_policies);
   if (args->env_kind == ORL_ENV_TTT || pool)
     ORL_REQUIRE(pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 9 && b.Dp == 18 && b.K == 9 && b.action_masks,
                 "orl_rollout_fused: tic-tac-toe needs Discrete(9), 18-d obs and the action-mask array");
@@ -1229,8 +1278,16 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   const TowerLds twc(cnet->obs_dim, 1, false, false);
   // The critic stays inside the step loop: a policy-only loop + one batched orl_critic_values launch over all T+1
   // slots was measured slower at config 2 (271 -> 237 us step loop, +60 us value launch).
-  const size_t lds = (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 4 * TILE_B * 16 +
-                                 (pool ? twp.total + TILE_B * twp.DP + TILE_B * 16 : 0)) * sizeof(float);
+  // Per-env opponents keep every pool image resident instead of the critic (which then runs as ONE batched launch over
+  // the stored observations afterwards): 1 + K policy images fit the 160 KiB for K <= 4.
+  const size_t lds =
+      perk ? (size_t)(twp.total + 2 * TILE_B * twp.DP + 2 * TILE_B * GS + 4 * TILE_B * 16 +
+                      (size_t)args->opp_n_policies * twp.total + TILE_B * twp.DP + TILE_B * 16 + TILE_B) * sizeof(float)
+           : (size_t)(twp.total + twc.total + 2 * TILE_B * twp.DP + 4 * TILE_B * GS + 4 * TILE_B * 16 +
+                      (pool ? twp.total + TILE_B * twp.DP + TILE_B * 16 + TILE_B : 0)) * sizeof(float);
+  if (perk && lds > 160 * 1024)
+    return fail(ORL_E_UNSUPPORTED, "orl_rollout_fused: a pool of %d snapshots does not fit the LDS (%zu B; 4 do)",
+                args->opp_n_policies, lds);
   ORL_REQUIRE(lds <= 160 * 1024, "orl_rollout_fused: needs %zu B of LDS", lds);
   RolloutArgs A;
   A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.r = *args; A.next_value = next_value;
@@ -1251,6 +1308,8 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
     ORL_RO_LAUNCH2(2, ORL_HEAD_CATEGORICAL, ORL_ENV_CARTPOLE);
   } else if (args->env_kind == ORL_ENV_TTT) {
     ORL_RO_LAUNCH2(16, ORL_HEAD_CATEGORICAL, ORL_ENV_TTT);
+  } else if (perk) {
+    ORL_RO_LAUNCH3(16, ORL_HEAD_CATEGORICAL, ORL_ENV_TTT_POOLK, false, 256);
   } else if (pool) {
     ORL_RO_LAUNCH2(16, ORL_HEAD_CATEGORICAL, ORL_ENV_TTT_POOL);
   } else {
@@ -1258,7 +1317,17 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   }
 #undef ORL_RO_LAUNCH2
 #undef ORL_RO_LAUNCH3
-  return launch_status("orl_rollout_fused");
+  rc = launch_status("orl_rollout_fused");
+  if (rc || !perk) return rc;
+  // per-env opponents: values of every slot 0..T from the stored critic observations (the same per-row arithmetic as
+  // orl_act_step's critic); slot T doubles as the bootstrap value
+  rc = orl_critic_values(cnet, ctheta, b.critic_obs, (int64_t)(b.T + 1) * b.N, args->value_preds, stream);
+  if (rc) return rc;
+  if (next_value != nullptr &&
+      hipMemcpyAsync(next_value, args->value_preds + (size_t)b.T * b.N, sizeof(float) * b.N, hipMemcpyDeviceToDevice,
+                     (hipStream_t)stream) != hipSuccess)
+    return fail(ORL_E_INVALID, "orl_rollout_fused: copying the bootstrap values failed");
+  return launch_status("orl_rollout_fused(values)");
 }
 
 }  // extern "C"

@@ -247,6 +247,8 @@ class OnPolicyDriver:
         if hasattr(env, "fill_rollout_args"):  # env-specific extras (the self-play opponent pool)
             env.fill_rollout_args(args)
         ops.rollout_fused(p.net, p.theta, c.net, c.theta, args, self._next_value)
+        if hasattr(env, "after_fused_rollout"):
+            env.after_fused_rollout(self.episode_length)
         env.global_step += self.episode_length
         mod.rng_step += self.episode_length
         self._have_next_value = True

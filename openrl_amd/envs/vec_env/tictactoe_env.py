@@ -88,11 +88,11 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
     Which snapshot an env plays (``opponent_sampling``; the reference asks its self-play service for an opponent at
     EVERY ``reset``, opponent_pool_wrapper.py:37-66, and the service applies a sample strategy):
 
-    * ``"per_reset"`` (the reference's semantics, exact): every env draws a pool slot whenever its game ends
-      (``orl_opponent_sample`` on the dones of the step, in the same stepwise launch chain) - ``opponent_strategy``
-      ``"RandomOpponent"`` = uniform over the filled slots, ``"LastOpponent"`` = the newest
-      (selfplay/sample_strategy/{random,last}_opponent.py); the opponents' moves come from ``orl_act_step_pool``, which
-      runs a 16-env tile once per distinct slot it holds.  Stepwise / hipGraph rollout only.
+    * ``"per_reset"`` (default, the reference's ``OpponentPoolWrapper.reset``): a finished game draws a fresh slot for
+      its env from a Philox stream on the device (``orl_opponent_sample``).  Stepwise, the act launch takes the per-env
+      slot (``orl_act_step_pool``); the fused one-launch rollout keeps all (up to 4) snapshot images in LDS, walks the
+      opponent tower once per distinct slot a 16-env tile holds and makes the same draws in-kernel
+      (``orl_rollout_args.opp_per_reset``); larger pools roll out stepwise / as a hipGraph.
     * ``"per_rollout"``: one draw per 16-env tile at every rollout start - the same marginal distribution of
       opponents, coarser in time, and the fused one-launch rollout still applies (a tile shares one opponent image).
     * ``"static"``: env group g always plays slot g (round 1's behaviour)."""
@@ -111,7 +111,8 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
         self.opponent_sampling, self.opponent_strategy = opponent_sampling, opponent_strategy
         self.kind = "tictactoe_selfplay_pool"
         self.env_kind = nat.ORL_ENV_TTT_POOL  # orl_rollout_fused plays both sides in-kernel (fill_rollout_args)
-        self.supports_fused_rollout = opponent_sampling != "per_reset"
+        # per_reset inside the fused kernel keeps every snapshot image in LDS next to the learner's: up to 4 fit
+        self.supports_fused_rollout = opponent_sampling != "per_reset" or int(pool_size) <= 4
         self.opp_index = torch.zeros(self._n, dtype=torch.int32, device=self.device)
         self._draws = 0
         self.pool_size = max(1, min(int(pool_size), self._n))
@@ -136,6 +137,20 @@ class TicTacToeSelfPlayVecEnv(TicTacToeVecEnv):
         args.opp_rng_step0 = self.global_step
         if self.opponent_sampling == "per_rollout":
             args.opp_index = self.opp_index.data_ptr()
+        elif self.opponent_sampling == "per_reset":  # per-env slots, re-drawn in-kernel when a game ends
+            args.opp_index = self.opp_index.data_ptr()
+            args.opp_per_reset = 1
+            args.opp_n_policies = self.opp_thetas.shape[0]
+            args.opp_n_filled = self.n_filled
+            args.opp_last_slot = (self.pushes - 1) % self.pool_size if self.pushes else 0
+            args.opp_strategy = self.STRATEGIES[self.opponent_strategy]
+            args.opp_sample_seed = (self.opp_seed ^ 0x0B0E) & (2 ** 64 - 1)
+            args.opp_draw_id0 = self._draws
+
+    def after_fused_rollout(self, steps: int) -> None:
+        """Driver hook: the fused kernel consumed one opponent draw id per step (like ``steps`` stepwise steps)."""
+        if self.opponent_sampling == "per_reset":
+            self._draws += steps
 
     @property
     def n_filled(self) -> int:

@@ -130,7 +130,7 @@ def test_fused_rollout_equals_stepwise_rollout_on_tictactoe():
     assert torch.equal(sa, sb) and torch.equal(ea, eb)
 
 
-@pytest.mark.parametrize("sampling", ["static", "per_rollout"])
+@pytest.mark.parametrize("sampling", ["static", "per_rollout", "per_reset"])
 def test_fused_selfplay_rollout_equals_stepwise(sampling):
     """ORL_ENV_TTT_POOL inside orl_rollout_fused (both players' policies in-kernel) fills the buffer like the stepwise
     orl_act_step + orl_ttt_agent_move + orl_act_step_grouped + orl_ttt_opponent_move + orl_buffer_insert path."""
@@ -170,9 +170,14 @@ def test_fused_selfplay_rollout_equals_stepwise(sampling):
             out.append({k: getattr(d, k).clone() for k in ("policy_obs", "actions", "action_log_probs", "value_preds",
                                                            "rewards", "masks", "action_masks", "returns")})
             drv.buffer.after_update()
+        out[-1]["opp_index"] = env.opp_index.clone()  # per_reset: the slots the in-kernel draws ended on
+        out[-1]["draws"] = torch.tensor(env._draws)
         return out, env.ep_stats.clone(), env.env_state[:, :11].clone()
 
     (fa, sa, ea), (fb, sb, eb) = run("fused"), run("stepwise")
+    assert torch.equal(fa[-1]["opp_index"], fb[-1]["opp_index"]) and torch.equal(fa[-1]["draws"], fb[-1]["draws"])
+    if sampling == "per_reset":
+        assert len(torch.unique(fa[-1]["opp_index"])) == 3  # every slot is in play within a tile
     for a, b in zip(fa, fb):
         for k in ("policy_obs", "actions", "rewards", "masks", "action_masks"):
             assert torch.equal(a[k], b[k]), k
@@ -317,13 +322,16 @@ def test_act_step_pool_equals_one_launch_per_policy():
 def test_per_reset_opponent_sampling(strategy):
     """opponent_sampling="per_reset" (opponent_pool_wrapper.py:37-66): an env draws a new pool slot exactly when its
     game ends - uniform over the FILLED slots (RandomOpponent) or the newest slot (LastOpponent) - and keeps it
-    through the game; the rollout runs stepwise (also as a replayed hipGraph)."""
+    through the game (the stepwise step; test_fused_selfplay_rollout_equals_stepwise[per_reset] holds the fused kernel's
+    in-kernel draws to the same stream).  Pools of more than 4 snapshots do not fit the fused kernel's LDS."""
     from openrl_amd.envs.common import make
 
     N = 2048
     env = make("tictactoe_v3", env_num=N, device=DEV, seed=9, opponent="pool", pool_size=4,
                opponent_sampling="per_reset", opponent_strategy=strategy)
-    assert not env.supports_fused_rollout
+    assert env.supports_fused_rollout
+    assert not make("tictactoe_v3", env_num=N, device=DEV, seed=9, opponent="pool", pool_size=6,
+                    opponent_sampling="per_reset").supports_fused_rollout
     g = torch.Generator(device=DEV).manual_seed(1)
     for k in range(3):  # three snapshots pushed: slots 0..2 filled, 3 empty
         env.push_opponent(0.3 * torch.randn(env.opp_thetas.shape[1], device=DEV, generator=g))
