@@ -613,9 +613,10 @@ int orl_row_bwd(const float* dy, const float* gamma, const float* xhat, const fl
 int orl_gather_cols(const float* records, int rec_width, int col0, int width, const int64_t* idx, int mb, float* out,
                     void* stream);
 /* den[0] = sum of the active column over the minibatch rows, den[1] = rows: the masked-mean denominators of
- * PPOAlgorithm.prepare_loss (ppo.py:319-361); a multi-GPU run all-reduces these two floats. */
+ * PPOAlgorithm.prepare_loss (ppo.py:319-361); a multi-GPU run all-reduces these two floats.  `scratch`: 257 floats
+ * the caller zeroes ONCE (slice sums + a completion counter that every call leaves at zero again). */
 int orl_gen_denoms(const float* records, int rec_width, int Dp, int Dc, int a_w, const int64_t* idx, int mb, float* den,
-                   void* stream);
+                   float* scratch, void* stream);
 /* Policy part of prepare_loss + ACTLayer.evaluate_actions for rows idx[0..mb) given the head's logits [mb, n_out]:
  * training (dlogits != NULL): dlogits = d(policy_loss - entropy_coef * dist_entropy) / d logits, ALREADY divided by
  * the denominators in den; partials[n_blocks][20] = {policy-loss sum, entropy sum, ratio sum, -, dlogstd[16]}.

@@ -170,7 +170,7 @@ _SIGNATURES = {
     "orl_row_fwd": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "orl_row_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int), _P]),
     "orl_gather_cols": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
-    "orl_gen_denoms": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "orl_gen_denoms": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
     "orl_gen_policy_loss": (C.c_int, [C.POINTER(HeadDesc), _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                       C.c_int, _P, C.POINTER(PPOHParams), _P, _P, C.c_int, C.POINTER(C.c_int), _P, _P,
                                       _P]),

@@ -138,6 +138,7 @@ class PPOAlgorithm(BaseAlgorithm):
             self.fuse_next_perm = False
             self._comm = None
             self._gen_den = torch.zeros(2, dtype=torch.float32, device=self.device)
+            self._gen_den_scratch = torch.zeros(257, dtype=torch.float32, device=self.device)
             self._gen_scratch = torch.zeros(256, dtype=torch.float32, device=self.device)
             return
         p, c = self.algo_module.models["policy"], self.algo_module.models["critic"]

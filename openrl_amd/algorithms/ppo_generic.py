@@ -41,7 +41,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool) -> None:
             ops.valuenorm_update(vn.state, algo._moments, vn.beta)  # BEFORE normalize (ppo.py:190-195)
         vn_state = vn.state
     den = algo._gen_den
-    ops_gen.denoms(rec, Dp, Dc, a_w, idx, mb, den)
+    ops_gen.denoms(rec, Dp, Dc, a_w, idx, mb, den, algo._gen_den_scratch)
     if algo.world_size > 1:
         dist_utils.allreduce_(den)  # global masked-mean denominators
     pn, cn = mod.policy_net, mod.critic_net

@@ -90,9 +90,12 @@ def gather_cols(records, col0: int, width: int, idx, mb: int, out) -> None:
     nat.check(rc, "orl_gather_cols")
 
 
-def denoms(records, Dp: int, Dc: int, a_w: int, idx, mb: int, den) -> None:
+def denoms(records, Dp: int, Dc: int, a_w: int, idx, mb: int, den, scratch) -> None:
+    """``scratch``: 257 floats zeroed once by the caller (left zeroed by every call)."""
     dev = nat.require_gpu(records.device)
-    rc = _lib().orl_gen_denoms(fptr(records), records.shape[1], Dp, Dc, a_w, ptr(idx), mb, fptr(den), stream_ptr(dev))
+    assert scratch.numel() >= 257
+    rc = _lib().orl_gen_denoms(fptr(records), records.shape[1], Dp, Dc, a_w, ptr(idx), mb, fptr(den), fptr(scratch),
+                               stream_ptr(dev))
     nat.check(rc, "orl_gen_denoms")
 
 
