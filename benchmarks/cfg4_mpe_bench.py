@@ -72,6 +72,8 @@ def main():
     print(json.dumps({"bench": "cfg4_mpe_recurrent_mappo", "envs": N, "agents": 3, "episode_length": T,
                       "ppo_epoch": cfg.ppo_epoch, "data_chunk_length": cfg.data_chunk_length,
                       "rollout": "fused" if drv.fused else "stepwise (hipGraph)",
+                      # 0 unless a critic workgroup's bounded wait for its policy workgroup ever timed out
+                      "chase_error": int(drv._chase_flags[-1]) if getattr(drv, "_chase_flags", None) is not None else None,
                       "env_steps_per_s": N * T * a.steps / dt, "agent_steps_per_s": 3 * N * T * a.steps / dt,
                       "ms_per_iteration": dt / a.steps * 1e3, "ms_rollout": t_roll / a.steps * 1e3,
                       "ms_update": t_upd / a.steps * 1e3, "episode_return_mean": st["episode_return_mean"]}))
