@@ -163,6 +163,13 @@ class GenNet:
     def reference_grad_flat(self) -> torch.Tensor:
         return torch.cat([self.v(o, *s, grad=True).reshape(-1) for _, s, o in self.entries])
 
+    def enable_popart_entries(self):
+        """cfg.use_popart: four frozen PopArt entries after v_out.{weight,bias}; the arithmetic is untouched (see
+        ``ppo_module.Tower.enable_popart_entries``)."""
+        z = lambda v: torch.full((1,), v, dtype=torch.float32, device=self.device)
+        self.popart = OrderedDict([("v_out.stddev", z(1.0)), ("v_out.mean", z(0.0)), ("v_out.mean_sq", z(0.0)),
+                                   ("v_out.debiasing_term", torch.zeros((), dtype=torch.float32, device=self.device))])
+
     def state_dict(self):
         sd = OrderedDict()
         if self.value_normalizer is not None:
@@ -179,11 +186,17 @@ class GenNet:
         for k, t in named:
             if not k.startswith("obs_prep."):
                 sd[k] = t
+                if k == "v_out.bias" and getattr(self, "popart", None) is not None:
+                    sd.update(self.popart)
         return sd
 
     def load_state_dict(self, sd):
         for k, t in self.named_parameters():
             t.copy_(torch.as_tensor(sd[k]).to(self.device, torch.float32).reshape(t.shape))
+        if getattr(self, "popart", None) is not None:
+            for k, t in self.popart.items():
+                if k in sd:
+                    t.copy_(torch.as_tensor(sd[k]).to(self.device, torch.float32).reshape(t.shape))
         if self.value_normalizer is not None and "value_normalizer.running_mean" in sd:
             self.value_normalizer.state[0] = float(torch.as_tensor(sd["value_normalizer.running_mean"]).reshape(-1)[0])
             self.value_normalizer.state[1] = float(torch.as_tensor(sd["value_normalizer.running_mean_sq"]).reshape(-1)[0])
@@ -363,7 +376,7 @@ class GenericPPOModule(PPOModule):
                  device="cuda:0", rank=None, world_size=None, model_dict=None):
         if model_dict:
             raise NotImplementedError("custom model_dict networks are not built")
-        for flag in ("use_recurrent_policy", "use_naive_recurrent_policy", "use_influence_policy", "use_popart",
+        for flag in ("use_recurrent_policy", "use_naive_recurrent_policy", "use_influence_policy",
                      "use_policy_vhead", "use_attn", "use_conv1d", "use_amp", "use_deepspeed", "use_joint_action_loss"):
             if getattr(cfg, flag, False):
                 raise NotImplementedError("cfg.%s=True is not built for the general towers" % flag)
@@ -386,6 +399,8 @@ class GenericPPOModule(PPOModule):
             model.host_init(cfg)
             if cfg.use_valuenorm:
                 model.value_normalizer = ValueNorm(1, device=self.device)
+            if cfg.use_popart:
+                model.enable_popart_entries()
             self.models = {"model": model}
             self.optimizers = {"model": GenAdam(model, cfg.lr, cfg.opti_eps, cfg.weight_decay)}
             pol = model
@@ -396,6 +411,8 @@ class GenericPPOModule(PPOModule):
             critic.host_init(cfg)
             if cfg.use_valuenorm:
                 critic.value_normalizer = ValueNorm(1, device=self.device)
+            if cfg.use_popart:
+                critic.enable_popart_entries()
             self.models = {"policy": policy, "critic": critic}
             self.optimizers = {"policy": GenAdam(policy, cfg.lr, cfg.opti_eps, cfg.weight_decay),
                                "critic": GenAdam(critic, cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)}

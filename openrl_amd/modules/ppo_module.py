@@ -119,6 +119,15 @@ class Tower:
         self._entries = _tower_entries(role, obs_dim, hidden, n_out, head_kind == ops.HEAD_GAUSSIAN, recurrent)
         self.training = False
         self.value_normalizer: Optional[ValueNorm] = None
+        # cfg.use_popart: the reference swaps v_out for a PopArt layer (value_network.py:106-107) but never calls its
+        # update / normalize on this path (the algorithm's value_normalizer is ValueNorm or None, base_value_network.py:
+        # 29-34), so the flag leaves the arithmetic alone and adds four frozen entries after v_out.{weight,bias}
+        self.popart: Optional[OrderedDict] = None
+
+    def enable_popart_entries(self):
+        z = lambda v: torch.full((1,), v, dtype=torch.float32, device=self.device)
+        self.popart = OrderedDict([("v_out.stddev", z(1.0)), ("v_out.mean", z(0.0)), ("v_out.mean_sq", z(0.0)),
+                                   ("v_out.debiasing_term", torch.zeros((), dtype=torch.float32, device=self.device))])
 
     def parameters(self):
         return [v for _, v in self.named_parameters()]
@@ -139,11 +148,17 @@ class Tower:
             sd["value_normalizer.debiasing_term"] = self.value_normalizer.state[2]
         for k, v in self.named_parameters():
             sd[k] = v
+        if self.popart is not None:
+            sd.update(self.popart)
         return sd
 
     def load_state_dict(self, sd):
         for k, v in self.named_parameters():
             v.copy_(torch.as_tensor(sd[k]).to(self.device, torch.float32).reshape(v.shape))
+        if self.popart is not None:
+            for k, v in self.popart.items():
+                if k in sd:
+                    v.copy_(torch.as_tensor(sd[k]).to(self.device, torch.float32).reshape(v.shape))
         if self.value_normalizer is not None and "value_normalizer.running_mean" in sd:
             self.value_normalizer.state[0] = float(sd["value_normalizer.running_mean"].reshape(-1)[0])
             self.value_normalizer.state[1] = float(sd["value_normalizer.running_mean_sq"].reshape(-1)[0])
@@ -241,7 +256,7 @@ class PPOModule:
             raise NotImplementedError("use_share_model with use_recurrent_policy is not built (feed-forward only)")
         if model_dict:
             raise NotImplementedError("custom model_dict towers are not built: the engine runs its own towers")
-        for flag in ("use_influence_policy", "use_popart",
+        for flag in ("use_influence_policy",
                      "use_feature_normalization", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp",
                      "use_deepspeed", "use_single_network"):
             if getattr(cfg, flag, False):
@@ -280,6 +295,8 @@ class PPOModule:
         critic = Tower("critic", Dc, 1, ops.HEAD_VALUE, H, self.device, tc, rec)
         if cfg.use_valuenorm:
             critic.value_normalizer = ValueNorm(1, device=self.device)
+        if cfg.use_popart:
+            critic.enable_popart_entries()
         self.models = {"policy": policy, "critic": critic}
         self.optimizers = {"policy": FusedAdam(policy, cfg.lr, cfg.opti_eps, cfg.weight_decay),
                            "critic": FusedAdam(critic, cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)}

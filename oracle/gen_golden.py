@@ -527,6 +527,11 @@ def main():
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_valuenorm", "false", "--use_proper_time_limits",
                 "true", "--dual_clip_ppo", "true", "--use_clipped_value_loss", "--use_value_active_masks", "false",
                 "--use_policy_active_masks"], 4, lambda: Discrete(2), seed=3),
+        # use_popart without ValueNorm (the reference's tests/test_buffer/test_generator.py combination): v_out is a PopArt
+        # layer whose update / normalize are never called on this path; model.parameters() gains 4 frozen entries
+        "train_popart": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--use_popart", "true", "--use_valuenorm", "false"], 5,
+            lambda: Discrete(3), seed=16),
         # A2CAlgorithm (algorithms/a2c.py): policy-gradient loss, one minibatch per epoch
         "train_a2c": lambda n: _train_case(n, ["--ppo_epoch", "3", "--num_mini_batch", "4"], 4, lambda: Discrete(3),
                                            seed=7, a2c=True),

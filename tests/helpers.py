@@ -8,7 +8,7 @@ from openrl_amd.configs.config import default_cfg
 from oracle import ppo_oracle as po
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TRAIN_CASES = ["train_discrete", "train_discrete_masks", "train_gaussian", "train_novn_proper"]
+TRAIN_CASES = ["train_discrete", "train_discrete_masks", "train_gaussian", "train_novn_proper", "train_popart"]
 
 
 def load_golden(name):
