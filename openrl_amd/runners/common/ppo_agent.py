@@ -94,6 +94,15 @@ class PPOAgent:
     def reset(self):
         self.net.reset()
 
+    def get_env(self):
+        """base_agent.py:50-57."""
+        return self._env
+
+    @property
+    def logger(self):
+        """base_agent.py:58-61."""
+        return getattr(self, "_logger", None)
+
     def set_env(self, env):
         self.net.reset()
         if env is not None:

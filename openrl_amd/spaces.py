@@ -18,6 +18,12 @@ class Space:
     def shape(self):
         return self._shape
 
+    def contains(self, x) -> bool:
+        raise NotImplementedError
+
+    def __contains__(self, x) -> bool:
+        return self.contains(x)
+
     def __repr__(self):
         return "%s(%s)" % (self.__class__.__name__, self._shape)
 
@@ -30,12 +36,22 @@ class Box(Space):
         self.low = np.broadcast_to(np.asarray(low, dtype=dtype), self._shape).copy()
         self.high = np.broadcast_to(np.asarray(high, dtype=dtype), self._shape).copy()
 
+    def contains(self, x) -> bool:
+        """gymnasium.spaces.Box.contains: castable to the dtype, same shape, inside the bounds."""
+        x = np.asarray(x)
+        return bool(np.can_cast(x.dtype, self.dtype) and x.shape == self._shape
+                    and np.all(x >= self.low) and np.all(x <= self.high))
+
 
 class Discrete(Space):
     def __init__(self, n, start=0):
         super().__init__((), np.int64)
         self.n = int(n)
         self.start = int(start)
+
+    def contains(self, x) -> bool:
+        x = np.asarray(x)
+        return bool(x.shape == () and np.issubdtype(x.dtype, np.integer) and self.start <= int(x) < self.start + self.n)
 
     def __repr__(self):
         return "Discrete(%d)" % self.n
@@ -49,6 +65,11 @@ class MultiDiscrete(Space):
         super().__init__(self.nvec.shape, np.int64)
         self.low = np.zeros_like(self.nvec)
         self.high = self.nvec - 1
+
+    def contains(self, x) -> bool:
+        x = np.asarray(x)
+        return bool(x.shape == self.nvec.shape and np.issubdtype(x.dtype, np.integer) and np.all(x >= 0)
+                    and np.all(x < self.nvec))
 
     def __repr__(self):
         return "MultiDiscrete(%s)" % self.nvec.tolist()

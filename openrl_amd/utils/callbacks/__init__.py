@@ -12,6 +12,7 @@ class BaseCallback:
 
     def __init__(self, verbose: int = 0):
         self.agent = None
+        self.training_env = None
         self.n_calls = 0
         self.num_time_steps = 0
         self.verbose = verbose
@@ -21,6 +22,9 @@ class BaseCallback:
 
     def init_callback(self, agent) -> None:
         self.agent = agent
+        get_env = getattr(agent, "get_env", None)
+        self.training_env = get_env() if callable(get_env) else getattr(agent, "_env", None)
+        self.logger = getattr(agent, "logger", None)
         self._init_callback()
 
     def _init_callback(self) -> None:
@@ -67,6 +71,9 @@ class BaseCallback:
     def update_child_locals(self, locals_: Dict[str, Any]) -> None:
         pass
 
+    def set_parent(self, parent: "BaseCallback") -> None:
+        self.parent = parent
+
 
 class NoopCallback(BaseCallback):
     """Default when the user passes ``callback=None``: lets the driver use the fused rollout."""
@@ -101,9 +108,12 @@ class ConvertCallback(BaseCallback):
 
 
 class CallbackList(BaseCallback):
-    def __init__(self, callbacks: List[BaseCallback]):
+    def __init__(self, callbacks: List[BaseCallback], stop_logic: str = "OR"):
         super().__init__()
-        self.callbacks = callbacks
+        assert isinstance(callbacks, list)
+        if stop_logic not in ("OR", "AND"):
+            raise ValueError("Unknown stop logic %s, possible values are 'OR' or 'AND'" % (stop_logic,))
+        self.callbacks, self.stop_logic = callbacks, stop_logic
         self.needs_per_step = any(callback_needs_per_step(c) for c in callbacks)
 
     def _init_callback(self) -> None:
@@ -119,10 +129,9 @@ class CallbackList(BaseCallback):
             c.on_rollout_start()
 
     def _on_step(self) -> bool:
-        ok = True
-        for c in self.callbacks:
-            ok = c.on_step() and ok
-        return ok
+        # callbacks.py:200-222: "OR" stops when ANY child asks to, "AND" only when ALL do; every child always runs
+        stops = [not c.on_step() for c in self.callbacks]
+        return not (any(stops) if self.stop_logic == "OR" else all(stops))
 
     def _on_rollout_end(self) -> None:
         for c in self.callbacks:
@@ -136,26 +145,61 @@ class CallbackList(BaseCallback):
         for c in self.callbacks:
             c.update_locals(locals_)
 
+    def set_parent(self, parent: "BaseCallback") -> None:
+        self.parent = parent
+        for c in self.callbacks:
+            c.set_parent(parent)
 
-class EveryNTimesteps(BaseCallback):
-    """Trigger ``callback`` every ``n_steps`` timesteps (openrl/utils/callbacks/callbacks.py EveryNTimesteps)."""
+    def __repr__(self):
+        return str([type(c).__name__ for c in self.callbacks])
 
-    def __init__(self, n_steps: int, callback: BaseCallback):
-        super().__init__()
-        self.n_steps, self.last_time_trigger, self.callback = int(n_steps), 0, callback
 
-    def _init_callback(self) -> None:
-        self.callback.parent = self
-        self.callback.init_callback(self.agent)
+def _as_child(callbacks, stop_logic: str = "OR"):
+    """A child given as ``{"id": ...}`` / a list of such specs goes through the factory (callbacks.py:296-299,
+    eval_callback.py:102-114); a callback object is used as it is."""
+    if isinstance(callbacks, (dict, list)):
+        return CallbackFactory.get_callbacks(callbacks, stop_logic=stop_logic)
+    return callbacks
+
+
+class EventCallback(BaseCallback):
+    """Base of the callbacks that trigger a child ``callback`` on an event (callbacks.py:133-173)."""
+
+    def __init__(self, callback: Optional[BaseCallback] = None, verbose: int = 0):
+        super().__init__(verbose=verbose)
+        self.callback = callback
+        if callback is not None:
+            self.callback.set_parent(self)
+
+    def init_callback(self, agent) -> None:
+        super().init_callback(agent)
+        if self.callback is not None:
+            self.callback.init_callback(self.agent)
+
+    def _on_training_start(self) -> None:
+        if self.callback is not None:
+            self.callback.on_training_start(self.locals, self.globals)
+
+    def _on_event(self) -> bool:
+        return self.callback.on_step() if self.callback is not None else True
+
+    def update_child_locals(self, locals_: Dict[str, Any]) -> None:
+        if self.callback is not None:
+            self.callback.update_locals(locals_)
+
+
+class EveryNTimesteps(EventCallback):
+    """Trigger ``callbacks`` every ``n_steps`` timesteps (callbacks.py:282-308)."""
+
+    def __init__(self, n_steps: int, callbacks=None, stop_logic: str = "OR", callback: Optional[BaseCallback] = None):
+        super().__init__(_as_child(callbacks if callbacks is not None else callback, stop_logic))
+        self.n_steps, self.last_time_trigger = int(n_steps), 0
 
     def _on_step(self) -> bool:
         if (self.num_time_steps - self.last_time_trigger) >= self.n_steps:
             self.last_time_trigger = self.num_time_steps
-            return self.callback.on_step()
+            return self._on_event()
         return True
-
-    def update_child_locals(self, locals_: Dict[str, Any]) -> None:
-        self.callback.update_locals(locals_)
 
 
 class CheckpointCallback(BaseCallback):
@@ -250,44 +294,63 @@ class StopTrainingOnNoModelImprovement(BaseCallback):
         return continue_training
 
 
-class EvalCallback(BaseCallback):
+class EvalCallback(EventCallback):
     """Every ``eval_freq`` calls, play ``n_eval_episodes`` episodes per env of a separate DEVICE-RESIDENT evaluation env
     with the current policy (greedy by default), track the best mean episode return, save the best model and run the
-    ``callbacks_on_new_best`` / ``callbacks_after_eval`` children (openrl/utils/callbacks/eval_callback.py:73-246).
-    ``eval_env``: a device VecEnv of this package or the ``{"id": ..., "env_num": ...}`` spec ``make`` takes.  Episode
-    returns come from the env's in-kernel episode statistics, so the evaluation itself never leaves the device."""
+    ``callbacks_on_new_best`` / ``callbacks_after_eval`` children (openrl/utils/callbacks/eval_callback.py:38-283; same
+    constructor).  ``eval_env``: a device VecEnv of this package, an env id, or the ``{"id": ..., "env_num": ...}``
+    spec ``make`` takes.  Episode returns come from the env's in-kernel episode statistics, so the evaluation never
+    leaves the device; what ``log_path``/evaluations.npz holds per evaluation is therefore one mean return and one mean
+    length PER ENV LANE, not one entry per episode.  ``render`` / ``asynchronous`` / ``warn`` are accepted for signature
+    compatibility and have nothing to act on here (no renderer, no worker processes, no Monitor wrapper)."""
 
     def __init__(self, eval_env, callbacks_on_new_best=None, callbacks_after_eval=None, n_eval_episodes: int = 5,
-                 eval_freq: int = 10000, log_path: Optional[str] = None, best_model_save_path: Optional[str] = None,
-                 deterministic: bool = True, render: bool = False, verbose: int = 1, stop_logic: str = "OR",
-                 max_eval_steps: int = 100000):
-        super().__init__(verbose)
-        self.eval_env_spec, self.eval_env = eval_env, None
-        mk = lambda c: None if c is None else (CallbackFactory.get_callbacks(c) if isinstance(c, (dict, list)) else c)
-        self.on_new_best, self.after_eval = mk(callbacks_on_new_best), mk(callbacks_after_eval)
+                 eval_freq: int = 10000, log_path=None, best_model_save_path=None, deterministic: bool = True,
+                 render: bool = False, asynchronous: bool = True, verbose: int = 1, warn: bool = True,
+                 stop_logic: str = "OR", close_env_at_end: bool = True, max_eval_steps: int = 100000):
+        import os
+
+        super().__init__(_as_child(callbacks_after_eval, stop_logic), verbose=verbose)
+        self.stop_logic = stop_logic
+        self.callbacks_on_new_best = _as_child(callbacks_on_new_best, stop_logic)
+        if self.callbacks_on_new_best is not None:
+            self.callbacks_on_new_best.set_parent(self)
         self.n_eval_episodes, self.eval_freq, self.deterministic = int(n_eval_episodes), int(eval_freq), bool(deterministic)
-        self.best_model_save_path, self.max_eval_steps = best_model_save_path, int(max_eval_steps)
+        self.render, self.warn, self.close_env_at_end = render, warn, close_env_at_end
         self.best_mean_reward, self.last_mean_reward = -float("inf"), -float("inf")
+        self.eval_env_spec, self.eval_env = eval_env, None
+        self.best_model_save_path = None if best_model_save_path is None else str(best_model_save_path)
+        self.log_path = None if log_path is None else os.path.join(str(log_path), "evaluations")
+        self.max_eval_steps = int(max_eval_steps)
+        self.evaluations_results, self.evaluations_time_steps, self.evaluations_length = [], [], []
         self.evaluations = []  # (num_time_steps, mean episode return, episodes)
 
-    def _init_callback(self) -> None:
-        if isinstance(self.eval_env_spec, dict):
-            from ..envs.common import make
+    # the names used before the constructor followed the reference's
+    on_new_best = property(lambda self: self.callbacks_on_new_best)
+    after_eval = property(lambda self: self.callback)
 
-            spec = dict(self.eval_env_spec)
-            self.eval_env = make(spec.pop("id"), **spec)
-        else:
-            self.eval_env = self.eval_env_spec
+    def _init_callback(self) -> None:
+        import os
+
+        if self.eval_env is None:
+            if isinstance(self.eval_env_spec, (dict, str)):
+                from ...envs.common import make
+
+                spec = dict(self.eval_env_spec) if isinstance(self.eval_env_spec, dict) else {"id": self.eval_env_spec}
+                self.eval_env = make(spec.pop("id"), **spec)
+            else:
+                self.eval_env = self.eval_env_spec
         if not getattr(self.eval_env, "is_device_env", False):
             raise NotImplementedError("EvalCallback evaluates on the device-resident envs of this package")
-        for child in (self.on_new_best, self.after_eval):
-            if child is not None:
-                child.parent = self
-                for c in getattr(child, "callbacks", [child]):
-                    c.parent = self
-                child.init_callback(self.agent)
+        if self.best_model_save_path is not None:
+            os.makedirs(self.best_model_save_path, exist_ok=True)
+        if self.log_path is not None:
+            os.makedirs(os.path.dirname(self.log_path), exist_ok=True)
+        if self.callbacks_on_new_best is not None:
+            self.callbacks_on_new_best.init_callback(self.agent)
 
-    def evaluate(self):
+    def evaluate_lanes(self):
+        """-> (mean finished-episode return per lane [n], mean finished-episode length per lane [n], episodes)."""
         import torch
 
         env, module = self.eval_env, self.agent.net.module
@@ -297,46 +360,76 @@ class EvalCallback(BaseCallback):
         target = self.n_eval_episodes * n
         h = torch.zeros(n * a, module.cfg.hidden_size, device=env.device) if getattr(module, "recurrent", False) else None
         masks = torch.ones(n * a, 1, device=env.device)
+        run_len = torch.zeros(n, device=env.device)
+        fin_len = torch.zeros(n, device=env.device)
         for step in range(self.max_eval_steps):
             p_obs = obs["policy"] if isinstance(obs, dict) else obs
             am = getattr(env, "action_mask_device", None)
             act, h2 = module.act(p_obs.reshape(n * a, -1), h, masks, action_masks=None if am is None else am.reshape(n * a, -1),
                                  deterministic=self.deterministic)
             obs, _, done = env.step_device(act.view(n, a, -1))
+            d0 = done.reshape(n, -1)[:, 0].float()
+            run_len += 1.0
+            fin_len += run_len * d0
+            run_len *= 1.0 - d0
             if h is not None:
                 masks = 1.0 - done.reshape(n * a, 1).float()
                 h = h2.reshape(n * a, -1)
             if step % 8 == 7 and env.episode_statistics()["episodes_finished"] >= target:
                 break
-        st = env.episode_statistics()
-        return st["episode_return_mean"], int(st["episodes_finished"])
+        st = env.ep_stats.reshape(n, -1, 4)[:, 0].double().cpu()
+        cnt = st[:, 3].clamp_min(1.0)
+        return (st[:, 2] / cnt).numpy(), (fin_len.double().cpu() / cnt).numpy(), int(st[:, 3].sum().item())
+
+    def evaluate(self):
+        st = self.evaluate_lanes()
+        return self.eval_env.episode_statistics()["episode_return_mean"], st[2]
 
     def _on_step(self) -> bool:
         if self.eval_freq <= 0 or self.n_calls % self.eval_freq != 0:
             return True
-        mean_reward, episodes = self.evaluate()
-        self.last_mean_reward = float(mean_reward)
-        self.evaluations.append((self.num_time_steps, self.last_mean_reward, episodes))
-        if self.verbose >= 1:
-            print("Eval num_time_steps=%d, episode_reward=%.2f over %d episodes" % (self.num_time_steps, mean_reward, episodes))
-        keep = True
-        if self.last_mean_reward > self.best_mean_reward:
-            self.best_mean_reward = self.last_mean_reward
-            if self.best_model_save_path is not None:
-                import os
+        import os
 
-                os.makedirs(self.best_model_save_path, exist_ok=True)
+        import numpy as np
+
+        lane_ret, lane_len, episodes = self.evaluate_lanes()
+        mean_reward = float(self.eval_env.episode_statistics()["episode_return_mean"])
+        self.last_mean_reward = mean_reward
+        self.evaluations.append((self.num_time_steps, mean_reward, episodes))
+        if self.log_path is not None:
+            self.evaluations_time_steps.append(self.num_time_steps)
+            self.evaluations_results.append(lane_ret)
+            self.evaluations_length.append(lane_len)
+            np.savez(self.log_path, timesteps=self.evaluations_time_steps, results=self.evaluations_results,
+                     ep_lengths=self.evaluations_length)
+        if self.verbose >= 1:
+            print("Eval num_timesteps=%d, episode_reward=%.2f +/- %.2f over %d episodes"
+                  % (self.num_time_steps, mean_reward, float(np.std(lane_ret)), episodes))
+            print("Episode length: %.2f +/- %.2f" % (float(np.mean(lane_len)), float(np.std(lane_len))))
+        keep = True
+        if mean_reward > self.best_mean_reward:
+            if self.verbose >= 1:
+                print("New best mean reward!")
+            if self.best_model_save_path is not None:
                 self.agent.save(os.path.join(self.best_model_save_path, "best_model"))
-            if self.on_new_best is not None:
-                keep = self.on_new_best.on_step() and keep
-        if self.after_eval is not None:
-            keep = self.after_eval.on_step() and keep
+                with open(os.path.join(self.best_model_save_path, "best_model_info.txt"), "w") as f:
+                    f.write("best model at step: %d\n" % self.num_time_steps)
+                    f.write("best model reward: %s\n" % mean_reward)
+            self.best_mean_reward = mean_reward
+            if self.callbacks_on_new_best is not None:
+                keep = self.callbacks_on_new_best.on_step()
+        if self.callback is not None:
+            keep = keep and self._on_event()
         return keep
 
     def update_child_locals(self, locals_: Dict[str, Any]) -> None:
-        for child in (self.on_new_best, self.after_eval):
+        for child in (self.callbacks_on_new_best, self.callback):
             if child is not None:
                 child.update_locals(locals_)
+
+    def _on_training_end(self) -> None:
+        if self.close_env_at_end and self.eval_env is not None:
+            self.eval_env.close()
 
 
 CALLBACKS = {"CheckpointCallback": CheckpointCallback, "EvalCallback": EvalCallback,
@@ -344,6 +437,7 @@ CALLBACKS = {"CheckpointCallback": CheckpointCallback, "EvalCallback": EvalCallb
              "StopTrainingOnNoModelImprovement": StopTrainingOnNoModelImprovement,
              "ProgressBarCallback": ProgressBarCallback, "EveryNTimesteps": EveryNTimesteps,
              "SelfPlayCallback": SelfPlayCallback}
+callbacks_dict = CALLBACKS  # the reference's name for the registry (callbacks_factory.py:14)
 
 
 class CallbackFactory:
@@ -357,10 +451,14 @@ class CallbackFactory:
         return CALLBACKS[spec["id"]](**spec.get("args", {}))
 
     @staticmethod
-    def get_callbacks(specs) -> "CallbackList":
+    def get_callbacks(specs, stop_logic: str = "OR") -> "CallbackList":
         if isinstance(specs, dict):
             specs = [specs]
-        return CallbackList([CallbackFactory.get_callback(s) for s in specs])
+        return CallbackList([CallbackFactory.get_callback(s) for s in specs], stop_logic=stop_logic)
+
+    @staticmethod
+    def register(id: str, callback_class) -> None:
+        CALLBACKS[id] = callback_class
 
 
 MaybeCallback = Union[None, Callable, List[BaseCallback], BaseCallback]

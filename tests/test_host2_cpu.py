@@ -182,6 +182,47 @@ def test_stop_training_on_no_model_improvement_counts_like_the_reference():
     assert out == [True, True, True, True, True, False]
 
 
+def test_callback_tree_follows_the_reference_constructors():
+    """callbacks.py:133-308, eval_callback.py:81-146, callbacks_factory.py:28-66: children given as objects or as
+    ``{"id": ...}`` specs, ``set_parent`` through lists, OR / AND stop logic (every child runs either way), the
+    reference's import paths."""
+    from openrl_amd.utils.callbacks.callbacks import BaseCallback, CallbackList, EveryNTimesteps
+    from openrl_amd.utils.callbacks.callbacks_factory import CallbackFactory
+    from openrl_amd.utils.callbacks.checkpoint_callback import CheckpointCallback
+    from openrl_amd.utils.callbacks.eval_callback import EvalCallback
+    from openrl_amd.utils.callbacks.stop_callback import StopTrainingOnRewardThreshold
+
+    class _Ret(BaseCallback):
+        def __init__(self, ret):
+            super().__init__()
+            self.ret = ret
+
+        def _on_step(self):
+            return self.ret
+
+    agent = type("A", (), {"num_time_steps": 0, "get_env": lambda self: "env", "logger": "lg"})()
+    for logic, rets, want in (("OR", [True, False, True], False), ("OR", [True, True], True),
+                              ("AND", [True, False], True), ("AND", [False, False], False)):
+        kids = [_Ret(r) for r in rets]
+        lst = CallbackList(kids, stop_logic=logic)
+        lst.init_callback(agent)
+        assert lst.on_step() is want
+        assert all(k.n_calls == 1 and k.training_env == "env" and k.logger == "lg" for k in kids)
+    with pytest.raises(ValueError):
+        CallbackList([], stop_logic="XOR")
+
+    ev = EvalCallback({"id": "CartPole-v1", "env_num": 2},
+                      callbacks_on_new_best=[{"id": "StopTrainingOnRewardThreshold", "args": {"reward_threshold": 5}}],
+                      callbacks_after_eval=StopTrainingOnRewardThreshold(7), stop_logic="AND", log_path="/tmp/x",
+                      warn=False, render=False, asynchronous=False, close_env_at_end=False)
+    assert ev.callbacks_on_new_best.stop_logic == "AND" and ev.callbacks_on_new_best.callbacks[0].parent is ev
+    assert ev.callback.parent is ev and ev.log_path == os.path.join("/tmp/x", "evaluations")
+    every = EveryNTimesteps(n_steps=6, callbacks={"id": "CheckpointCallback", "args": {"save_freq": 1, "save_path": "/tmp/x"}})
+    assert isinstance(every.callback.callbacks[0], CheckpointCallback) and every.callback.callbacks[0].parent is every
+    CallbackFactory.register("Ret", _Ret)
+    assert isinstance(CallbackFactory.get_callback({"id": "Ret", "args": {"ret": True}}), _Ret)
+
+
 def test_logger_run_dirs_and_file_scalar_backend(tmp_path):
     """logger.py:64-151,185-207: <log_path>/<project>/<scenario>/<exp>/run<k>, log.txt, and every log_info key reaching
     the scalar back-end (tensorboardX when importable, else the scalars.jsonl / scalars.csv writer)."""

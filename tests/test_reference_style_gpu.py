@@ -128,3 +128,108 @@ def test_train_mpe(mpe_config, tmp_path):
             break
         step += 1
     env.close()
+
+
+# ---- tests/test_callbacks/test_callbacks.py:51-112, 188-203, imports swapped (the Pendulum / IdentityEnv / BitFlippingEnv
+# segments need envs this package does not build) ---------------------------------------------------------------------
+@pytest.fixture(scope="module", params=["--seed 0"])
+def cb_config(request):
+    from openrl_amd.configs.config import create_config_parser
+
+    cfg_parser = create_config_parser()
+    cfg = cfg_parser.parse_args(request.param.split())
+    return cfg
+
+
+def test_callbacks(tmp_path, cb_config):
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import PPOAgent as Agent
+    from openrl_amd.utils.callbacks import (CallbackList, CheckpointCallback, EvalCallback, EveryNTimesteps,
+                                            ProgressBarCallback, StopTrainingOnMaxEpisodes,
+                                            StopTrainingOnNoModelImprovement, StopTrainingOnRewardThreshold)
+
+    config = cb_config
+    log_folder = tmp_path / "logs/callbacks/"
+
+    env = make("CartPole-v1", env_num=3)
+    agent = Agent(Net(env, cfg=config))
+
+    checkpoint_callback = CheckpointCallback(save_freq=1000, save_path=log_folder)
+    # Stop training if the performance is good enough
+    callback_on_best = StopTrainingOnRewardThreshold(reward_threshold=-1200, verbose=1)
+    # Stop training if there is no model improvement after 2 evaluations
+    callback_no_model_improvement = StopTrainingOnNoModelImprovement(
+        max_no_improvement_evals=2, min_evals=1, verbose=1
+    )
+    eval_callback = EvalCallback(
+        {"id": "CartPole-v1", "env_num": 2},
+        callbacks_on_new_best=callback_on_best,
+        callbacks_after_eval=callback_no_model_improvement,
+        best_model_save_path=log_folder,
+        log_path=log_folder,
+        eval_freq=100,
+        warn=False,
+        close_env_at_end=False,
+    )
+
+    # Equivalent to the `checkpoint_callback`
+    # but here in an event-driven manner
+    checkpoint_on_event = CheckpointCallback(
+        save_freq=1, save_path=log_folder, name_prefix="event"
+    )
+    event_callback = EveryNTimesteps(n_steps=500, callbacks=checkpoint_on_event)
+
+    # Stop training if max number of episodes is reached
+    callback_max_episodes = StopTrainingOnMaxEpisodes(max_episodes=100, verbose=1)
+
+    callback = CallbackList(
+        [checkpoint_callback, eval_callback, event_callback, callback_max_episodes]
+    )
+
+    agent.train(total_time_steps=1000, callback=callback)
+
+    # Check access to local variables
+
+    # (deviation: the device envs hand the driver DEVICE tensors, so the observation is copied out before the check)
+    assert agent._env.observation_space.contains(callback.locals["obs"][0][0].cpu().numpy())
+    # Check that the child callback was called
+    assert checkpoint_callback.locals["obs"] is callback.locals["obs"]
+    assert event_callback.locals["obs"] is callback.locals["obs"]
+    assert checkpoint_on_event.locals["obs"] is callback.locals["obs"]
+    # Check that internal callback counters match models' counters
+    assert event_callback.num_time_steps == agent.num_time_steps
+    assert event_callback.n_calls * agent.env_num == agent.num_time_steps
+
+    agent.train(1000, callback=None)
+    # Use progress bar
+    pb_callback = ProgressBarCallback()
+    agent.train(1000, callback=[checkpoint_callback, eval_callback, pb_callback])
+    # Automatic wrapping, old way of doing callbacks
+    agent.train(1000, callback=lambda _locals, _globals: True)
+
+    env.close()
+
+
+def test_checkpoint_additional_info(tmp_path, cb_config):
+    import os
+
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import PPOAgent as Agent
+    from openrl_amd.utils.callbacks import CheckpointCallback
+
+    log_folder = tmp_path / "logs/callbacks/"
+
+    env = make("CartPole-v1", env_num=1)
+    agent = Agent(Net(env, cfg=cb_config))
+
+    checkpoint_callback = CheckpointCallback(
+        save_freq=200,
+        save_path=log_folder,
+        verbose=2,
+    )
+
+    agent.train(200, callback=checkpoint_callback)
+
+    assert os.path.exists(log_folder / "rl_model_200_steps")
