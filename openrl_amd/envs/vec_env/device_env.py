@@ -106,6 +106,22 @@ class DeviceVecEnv:
         obs, rew, done = self.step_device(a)
         return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy().astype(bool), self._infos
 
+    def random_action(self, infos=None):
+        """base_venv.py:312-336: one ``action_space.sample`` per (env, agent) -> [N, A, 1] for Discrete, [N, A, dim]
+        otherwise; ``infos`` (what ``reset`` / ``step`` returned) supply legal-move masks."""
+        from ...drivers.onpolicy_driver import prepare_action_masks
+
+        masks = prepare_action_masks(infos, self.agent_num)
+        sp, out = self.action_space, []
+        for n in range(self.parallel_env_num):
+            row = []
+            for a in range(self.agent_num):
+                m = None if masks is None else np.asarray(masks[n]).reshape(self.agent_num, -1)[a]
+                x = sp.sample(mask=m) if m is not None else sp.sample()
+                row.append(np.asarray(x).reshape(-1))
+            out.append(row)
+        return np.array(out)
+
     def batch_rewards(self, buffer) -> Dict[str, Any]:
         return {}
 

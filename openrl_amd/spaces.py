@@ -21,6 +21,19 @@ class Space:
     def contains(self, x) -> bool:
         raise NotImplementedError
 
+    def seed(self, seed=None):
+        self._np_random = np.random.default_rng(seed)
+        return [seed]
+
+    @property
+    def np_random(self):
+        if getattr(self, "_np_random", None) is None:
+            self.seed()
+        return self._np_random
+
+    def sample(self, mask=None):
+        raise NotImplementedError
+
     def __contains__(self, x) -> bool:
         return self.contains(x)
 
@@ -36,6 +49,16 @@ class Box(Space):
         self.low = np.broadcast_to(np.asarray(low, dtype=dtype), self._shape).copy()
         self.high = np.broadcast_to(np.asarray(high, dtype=dtype), self._shape).copy()
 
+    def sample(self, mask=None):
+        """Uniform inside finite bounds, standard normal where a side is unbounded (gymnasium's Box.sample uses
+        shifted exponentials for the half-bounded cases; only boundedness matters to the callers here)."""
+        lo, hi = self.low.astype(np.float64), self.high.astype(np.float64)
+        fin = np.isfinite(lo) & np.isfinite(hi)
+        x = self.np_random.normal(size=self._shape)
+        u = self.np_random.uniform(size=self._shape)
+        x = np.where(fin, np.where(fin, lo, 0.0) + u * np.where(fin, hi - lo, 0.0), np.clip(x, lo, hi))
+        return x.astype(self.dtype)
+
     def contains(self, x) -> bool:
         """gymnasium.spaces.Box.contains: castable to the dtype, same shape, inside the bounds."""
         x = np.asarray(x)
@@ -48,6 +71,15 @@ class Discrete(Space):
         super().__init__((), np.int64)
         self.n = int(n)
         self.start = int(start)
+
+    def sample(self, mask=None):
+        """gymnasium.spaces.Discrete.sample: uniform over the legal entries of ``mask`` (int8 [n]) when given."""
+        if mask is not None:
+            legal = np.flatnonzero(np.asarray(mask).reshape(-1)[: self.n])
+            if legal.size:
+                return int(self.start + self.np_random.choice(legal))
+            return int(self.start)
+        return int(self.start + self.np_random.integers(self.n))
 
     def contains(self, x) -> bool:
         x = np.asarray(x)
@@ -65,6 +97,9 @@ class MultiDiscrete(Space):
         super().__init__(self.nvec.shape, np.int64)
         self.low = np.zeros_like(self.nvec)
         self.high = self.nvec - 1
+
+    def sample(self, mask=None):
+        return (self.np_random.random(self.nvec.shape) * self.nvec).astype(np.int64)
 
     def contains(self, x) -> bool:
         x = np.asarray(x)

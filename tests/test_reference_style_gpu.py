@@ -233,3 +233,52 @@ def test_checkpoint_additional_info(tmp_path, cb_config):
     agent.train(200, callback=checkpoint_callback)
 
     assert os.path.exists(log_folder / "rl_model_200_steps")
+
+
+# ---- tests/test_env/test_mpe_env.py:27-35 and the loop of :38-55 (no renderer here), imports swapped -------------------
+def test_mpe():
+    from openrl_amd.envs.common import make
+
+    env_num = 3
+    env = make("simple_spread", env_num=env_num)
+    obs, info = env.reset()
+    obs, reward, done, info = env.step(env.random_action())
+    assert env.agent_num == 3
+    assert env.parallel_env_num == env_num
+    env.close()
+
+
+def test_mpe_random_episode():
+    from openrl_amd.envs.common import make
+
+    env_num = 2
+    env = make("simple_spread", env_num=env_num, asynchronous=False)
+
+    env.reset(seed=0)
+    done = False
+    step = 0
+    total_reward = 0
+    while not np.any(done):
+        obs, r, done, info = env.step(env.random_action())
+        step += 1
+        total_reward += np.mean(r)
+    assert step == 25 and np.all(done) and total_reward < 0  # world_length 25 (mpe_env.py:33), spread rewards are <= 0
+    env.close()
+
+
+# ---- the evaluation loop of tests/test_selfplay/test_train_selfplay.py:84-121 against the built-in random opponent ----
+def test_tictactoe_random_legal_play():
+    from openrl_amd.envs.common import make
+
+    env = make("tictactoe_v3", env_num=4)
+    obs, info = env.reset(seed=0)
+    finished = 0
+    for _ in range(40):
+        a = env.random_action(info)
+        masks = np.stack([np.asarray(i["action_masks"]).reshape(-1) for i in info]) if isinstance(info, list) \
+            else np.asarray(info["action_masks"]).reshape(4, -1)
+        assert all(masks[n, int(a[n, 0, 0])] == 1 for n in range(4))   # only legal moves are drawn
+        obs, r, done, info = env.step(a)
+        finished += int(np.sum(done))
+    assert finished >= 4
+    env.close()
