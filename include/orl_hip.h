@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 202 /* 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 203 /* 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -609,6 +609,27 @@ int orl_row_fwd(const float* z, const float* bias, int act, const float* gamma, 
  * col_partials[n_blocks][3H] = [d gamma | d beta | d bias] to be column-summed with orl_ppo_reduce. */
 int orl_row_bwd(const float* dy, const float* gamma, const float* xhat, const float* rstd, const float* a, int act, int B,
                 int H, float* dz_out, float* col_partials, int max_blocks, int* n_blocks_out, void* stream);
+/* Fused layer of MLPLayer (mlp.py:8-46), nn.Sequential(Linear, act, LayerNorm) in ONE launch: y = LN(act(x W^T + b))
+ * for x [B, n_in], W [n_out, n_in] (nn.Linear layout), n_out <= 512.  a_out [B, n_out] (post-activation, pre-LayerNorm)
+ * and stats_out [B, 2] = (mean, rstd) per row are what orl_gen_layer_bwd needs; either may be NULL (rollouts).  Without
+ * gamma / beta (action / value heads) y = act(x W^T + b) and stats_out is not written. */
+int orl_gen_layer_fwd(const float* x, int B, int n_in, const float* W, const float* bias, int act, const float* gamma,
+                      const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, void* stream);
+/* Its backward in one launch: dy [B, n_out] -> dz_out [B, n_out] (gradient at the Linear's output; may be NULL),
+ * col_partials[n_blocks][3 n_out] = [d gamma | d beta | d bias] per workgroup (sum them with orl_gen_colsum), and - for a
+ * square layer, when dx_out != NULL - the input gradient dx_out [B, n_in] = dz W of the same row tile without re-reading
+ * dz.  a / stats as written by orl_gen_layer_fwd (stats unused without gamma, a unused without gamma and activation). */
+int orl_gen_layer_bwd(const float* dy, const float* a, const float* stats, const float* gamma, int act, int B, int n_out,
+                      const float* W, int n_in, float* dz_out, float* dx_out, float* col_partials, int max_blocks,
+                      int* n_blocks_out, void* stream);
+/* dW [n_out, n_in] = dz [B, n_out]^T x [B, n_in]: persistent split-K over the batch rows (slice partial products in
+ * partials, summed in slice order: deterministic).  partials_floats >= n_out * n_in; more lets more workgroups run. */
+int orl_gen_wgrad(const float* dz, const float* x, int B, int n_out, int n_in, float* dW, float* partials,
+                  int64_t partials_floats, void* stream);
+/* Fixed-order column sums of partials[n_rows][width]; columns [0, w0) go to dst0, [w0, w0+w1) to dst1, the rest to
+ * dst2 (w0 + w1 + w2 == width; a NULL destination drops its segment). */
+int orl_gen_colsum(const float* partials, int n_rows, int width, float* dst0, int w0, float* dst1, int w1, float* dst2,
+                   int w2, void* stream);
 /* out[i, :] = records[idx[i] (or i), col0 : col0+width] */
 int orl_gather_cols(const float* records, int rec_width, int col0, int width, const int64_t* idx, int mb, float* out,
                     void* stream);

@@ -19,7 +19,7 @@ ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL, ORL_ENV_MPE_SPREAD = 0, 1, 2, 3, 4
 ORL_GATHER_MAX = 12
 ORL_IPC_HANDLE_BYTES = 64
-ORL_VERSION = 202  # must equal include/orl_hip.h; checked against the loaded library
+ORL_VERSION = 203  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -169,6 +169,11 @@ _SIGNATURES = {
                            C.c_int, _P, _P]),
     "orl_row_fwd": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "orl_row_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int), _P]),
+    "orl_gen_layer_fwd": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "orl_gen_layer_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int,
+                                    C.POINTER(C.c_int), _P]),
+    "orl_gen_wgrad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
+    "orl_gen_colsum": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "orl_gather_cols": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "orl_gen_denoms": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
     "orl_gen_policy_loss": (C.c_int, [C.POINTER(HeadDesc), _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P,

@@ -22,6 +22,7 @@
 #include <string.h>
 #include "orl_common.h"
 #include "orl_mlp.h"
+#include "orl_gen_act.h"
 
 namespace orl {
 
@@ -87,26 +88,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------- rows
-__device__ inline float act_fwd(float z, int act) {
-  switch (act) {
-    case ORL_ACT_TANH: return tanhf(z);
-    case ORL_ACT_RELU: return fmaxf(z, 0.f);
-    case ORL_ACT_LEAKY_RELU: return z > 0.f ? z : 0.01f * z;
-    case ORL_ACT_ELU: return z > 0.f ? z : expm1f(z);
-    default: return z;
-  }
-}
-// derivative expressed through the OUTPUT a = act(z) (what the forward stores)
-__device__ inline float act_bwd(float a, int act) {
-  switch (act) {
-    case ORL_ACT_TANH: return 1.f - a * a;
-    case ORL_ACT_RELU: return a > 0.f ? 1.f : 0.f;
-    case ORL_ACT_LEAKY_RELU: return a > 0.f ? 1.f : 0.01f;
-    case ORL_ACT_ELU: return a > 0.f ? 1.f : a + 1.f;
-    default: return 1.f;
-  }
-}
-
 constexpr int ROW_MAX_PER_LANE = 8;  // H <= 512
 
 // One wavefront per row; lane l owns columns l, l+64, ...

@@ -1,0 +1,571 @@
+// orl_gen_fused.hip - fused layer kernels of the GENERAL tower path for gfx950 (round 2b).
+//
+// orl_gen.hip runs nn.Sequential(Linear, act, LayerNorm) as GEMM + row kernel with z / a / xhat / y all round-tripping
+// HBM.  At hidden_size 128 and 524 288 minibatch rows every such array is 268 MB, so the layer-wise path is a stream of
+// HBM passes.  The kernels here keep a 64-row tile of a layer on the CU across the whole layer:
+//
+//   orl_gen_layer_fwd   y = LN(act(x W^T + b)): fp32 MFMA accumulators of a [64 x n_out] tile stay in registers,
+//                       bias / activation / LayerNorm run on the MFMA D fragment (a row = 16 lanes x NB registers),
+//                       stores a (post-activation) + (mean, rstd) per row for the backward and y.    [x | a y]
+//   orl_gen_layer_bwd   dy -> dz (LayerNorm affine + LayerNorm + activation backward on the fragment), dz goes to HBM
+//                       once (the wgrad needs it) and, transposed through a wave-private LDS slab, straight into the
+//                       dgrad dx = dz W of the same tile; d gamma / d beta / d bias column sums per workgroup. [dy a | dz dx]
+//   orl_gen_wgrad       dW = dz^T x with the batch rows as K: persistent split-K, both operands row-major so every
+//                       load is a coalesced float4, up to a 128 x 128 output block per workgroup (each operand is read
+//                       once at hidden 128).                                                          [dz x | partials]
+//   orl_gen_colsum      fixed-order column sums of per-workgroup partial rows, written to up to 3 destinations.
+//
+// mlp.py:8-46 (MLPLayer), torch.nn.LayerNorm (eps 1e-5, biased variance of the centred values) as in orl_gen.hip.
+// Shapes these kernels do not take (n_out > 512, misaligned rows) stay on the layer-wise kernels.
+#include <string.h>
+#include "orl_common.h"
+#include "orl_mlp.h"
+#include "orl_gen_act.h"
+
+namespace orl {
+
+constexpr int GF_KC = 16;
+
+// sum over the 16 lanes (i = lane & 15) that hold one row of an MFMA D fragment; result in all of them
+__device__ inline float sum16(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+__device__ inline bool aligned16(const void* p) { return (((unsigned long long)p) & 15ull) == 0; }
+
+// ------------------------------------------------------------------------------------------------ forward
+// Workgroup = WAVES waves, wave w owns rows [16 w, 16 w + 16) of the tile and ALL n_out <= 16 NB columns.
+// D fragment: lane (i = l & 15, q = l >> 4), tile t, register r  ->  row 4 q + r, column 16 t + i.
+template <int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
+    const float* __restrict__ x, int B, int n_in, const float* __restrict__ W, const float* __restrict__ bias, int act,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int n_out, float* __restrict__ a_out,
+    float* __restrict__ stats_out, float* __restrict__ y_out) {
+  constexpr int BM = 16 * WAVES, NP = 16 * NB, XLD = BM + 16, WLD = NP + 16, NTH = 64 * WAVES;
+  constexpr int WU = (4 * NP + NTH - 1) / NTH;  // float4 units of the W chunk per thread
+  extern __shared__ float sh_gf[];
+  float* xs = sh_gf;                    // [2][KC][XLD]   xs[k][m]
+  float* ws = sh_gf + 2 * GF_KC * XLD;  // [2][KC][WLD]   ws[k][n]
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const bool vx = (n_in & 3) == 0 && aligned16(x), vw = (n_in & 3) == 0 && aligned16(W);
+
+  f32x4 rx;
+  f32x4 rw[WU];
+  auto load = [&](int k0) {
+    {
+      const int m = tid >> 2, k = k0 + 4 * (tid & 3);
+      rx = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m0 + m < B && k < n_in) {
+        const float* p = x + (m0 + m) * n_in + k;
+        if (vx) rx = *(const f32x4*)p;
+        else
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (k + j < n_in) rx[j] = p[j];
+      }
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < WU; ++u0) {
+      const int u = tid + NTH * u0, n = u >> 2, k = k0 + 4 * (u & 3);
+      rw[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < 4 * NP && n < n_out && k < n_in) {
+        const float* p = W + (long long)n * n_in + k;
+        if (vw) rw[u0] = *(const f32x4*)p;
+        else
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (k + j < n_in) rw[u0][j] = p[j];
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    float* xb = xs + buf * GF_KC * XLD;
+    float* wb = ws + buf * GF_KC * WLD;
+    {
+      const int m = tid >> 2, kq = 4 * (tid & 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xb[(kq + j) * XLD + m] = rx[j];
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < WU; ++u0) {
+      const int u = tid + NTH * u0, n = u >> 2, kq = 4 * (u & 3);
+      if (u < 4 * NP)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wb[(kq + j) * WLD + n] = rw[u0][j];
+    }
+  };
+
+  f32x4 acc[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nch = (n_in + GF_KC - 1) / GF_KC;
+  load(0);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) load((c + 1) * GF_KC);
+    const float* xb = xs + (c & 1) * GF_KC * XLD + 16 * wave + i;
+    const float* wb = ws + (c & 1) * GF_KC * WLD + i;
+#pragma unroll
+    for (int kk = 0; kk < GF_KC; kk += 4) {
+      const float av = xb[(kk + q) * XLD];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) acc[t] = ORL_MFMA(av, wb[(kk + q) * WLD + 16 * t], acc[t]);
+    }
+    if (c + 1 < nch) stash((c + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue on the fragment
+  float bs[NB], gm[NB], bt[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    const int col = 16 * t + i;
+    const bool cv = col < n_out;
+    bs[t] = (cv && bias) ? bias[col] : 0.f;
+    gm[t] = (cv && gamma) ? gamma[col] : 0.f;
+    bt[t] = (cv && gamma) ? beta[col] : 0.f;
+  }
+  const float inv_n = 1.0f / (float)n_out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long row = m0 + 16 * wave + 4 * q + r;
+    const bool rv = row < B;
+    float v[NB];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const bool cv = 16 * t + i < n_out;
+      v[t] = cv ? act_fwd(acc[t][r] + bs[t], act) : 0.f;
+      s += v[t];
+      if (rv && cv && a_out) a_out[row * n_out + 16 * t + i] = v[t];
+    }
+    if (gamma == nullptr) {
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+        if (rv && 16 * t + i < n_out && y_out) y_out[row * n_out + 16 * t + i] = v[t];
+      continue;
+    }
+    const float mean = sum16(s) * inv_n;
+    float v2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      v[t] = 16 * t + i < n_out ? v[t] - mean : 0.f;
+      v2 += v[t] * v[t];
+    }
+    const float rstd = 1.0f / sqrtf(sum16(v2) * inv_n + 1e-5f);
+    if (rv && stats_out && i == 0) {
+      stats_out[2 * row] = mean;
+      stats_out[2 * row + 1] = rstd;
+    }
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+      if (rv && 16 * t + i < n_out && y_out) y_out[row * n_out + 16 * t + i] = v[t] * rstd * gm[t] + bt[t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Persistent over 16*WAVES-row tiles.  dx (dgrad) only for square layers (n_in == n_out), which is every hidden layer
+// below the first; W == nullptr skips it.
+template <int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ stats,
+    const float* __restrict__ gamma, int act, int B, int n_out, const float* __restrict__ W, float* __restrict__ dz_out,
+    float* __restrict__ dx_out, float* __restrict__ partials) {
+  constexpr int BM = 16 * WAVES, NP = 16 * NB, WLD = NP + 16, NTH = 64 * WAVES, DLD = 17;
+  constexpr int WU = (4 * NP + NTH - 1) / NTH;
+  extern __shared__ float sh_gb[];
+  float* dzs = sh_gb;                     // [WAVES][NP][DLD]  dzs[w][c][m]   (wave-private)
+  float* ws = sh_gb + WAVES * NP * DLD;   // [2][KC][WLD]      ws[k = c][n]
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
+  const int n_in = n_out;
+  const bool do_dx = W != nullptr && dx_out != nullptr;
+  const bool vw = (n_in & 3) == 0 && aligned16(W);
+  float* dzw = dzs + wave * NP * DLD;
+
+  float gm[NB], cg[NB], cb[NB], cz[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    gm[t] = (gamma && 16 * t + i < n_out) ? gamma[16 * t + i] : 0.f;
+    cg[t] = cb[t] = cz[t] = 0.f;
+  }
+  const float inv_n = 1.0f / (float)n_out;
+  const long long ntiles = ((long long)B + BM - 1) / BM;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long m0 = tile * BM;
+    // ---- phase 1: dy -> dz on the fragment layout
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long row = m0 + 16 * wave + 4 * q + r;
+      const bool rv = row < B;
+      float d[NB], xh[NB], av[NB];
+      float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 1.f;
+      if (gamma && rv) { mean = stats[2 * row]; rstd = stats[2 * row + 1]; }
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const bool ok = rv && 16 * t + i < n_out;
+        const float g = ok ? dy[row * n_out + 16 * t + i] : 0.f;
+        av[t] = (ok && a) ? a[row * n_out + 16 * t + i] : 0.f;
+        if (gamma) {
+          xh[t] = ok ? (av[t] - mean) * rstd : 0.f;
+          cg[t] += g * xh[t];
+          cb[t] += g;
+          d[t] = g * gm[t];
+          s1 += d[t];
+          s2 += d[t] * xh[t];
+        } else {
+          d[t] = g;
+          xh[t] = 0.f;
+        }
+      }
+      float c1 = 0.f, c2 = 0.f;
+      if (gamma) { c1 = sum16(s1) * inv_n; c2 = sum16(s2) * inv_n; }
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const bool ok = rv && 16 * t + i < n_out;
+        float da = gamma ? (d[t] - c1 - xh[t] * c2) * rstd : d[t];
+        if (act != ORL_ACT_NONE) da *= act_bwd(av[t], act);
+        if (!ok) da = 0.f;
+        cz[t] += da;
+        if (ok && dz_out) dz_out[row * n_out + 16 * t + i] = da;
+        if (do_dx) dzw[(16 * t + i) * DLD + 4 * q + r] = da;
+      }
+    }
+    if (!do_dx) continue;
+    // ---- phase 2: dx[m][n] = sum_c dz[m][c] W[c][n]
+    f32x4 acc[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 rw[WU];
+    auto load = [&](int c0) {
+#pragma unroll
+      for (int u0 = 0; u0 < WU; ++u0) {
+        const int u = tid + NTH * u0, k = u / (NP / 4), n = 4 * (u % (NP / 4));
+        rw[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < 4 * NP && c0 + k < n_out && n < n_in) {
+          const float* p = W + (long long)(c0 + k) * n_in + n;
+          if (vw) rw[u0] = *(const f32x4*)p;
+          else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n + j < n_in) rw[u0][j] = p[j];
+        }
+      }
+    };
+    auto stash = [&](int buf) {
+      float* wb = ws + buf * GF_KC * WLD;
+#pragma unroll
+      for (int u0 = 0; u0 < WU; ++u0) {
+        const int u = tid + NTH * u0, k = u / (NP / 4), n = 4 * (u % (NP / 4));
+        if (u < 4 * NP) *(f32x4*)(wb + k * WLD + n) = rw[u0];
+      }
+    };
+    const int nch = (n_out + GF_KC - 1) / GF_KC;
+    load(0);
+    __syncthreads();  // the previous tile's MFMA loop is done with both ws buffers
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      if (c + 1 < nch) load((c + 1) * GF_KC);
+      const float* wb = ws + (c & 1) * GF_KC * WLD + i;
+      const float* ab = dzw + (c * GF_KC) * DLD + i;
+#pragma unroll
+      for (int kk = 0; kk < GF_KC; kk += 4) {
+        const float av = ab[(kk + q) * DLD];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) acc[t] = ORL_MFMA(av, wb[(kk + q) * WLD + 16 * t], acc[t]);
+      }
+      if (c + 1 < nch) stash((c + 1) & 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long row = m0 + 16 * wave + 4 * q + r;
+      if (row < B)
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+          if (16 * t + i < n_in) dx_out[row * n_in + 16 * t + i] = acc[t][r];
+    }
+  }
+  // ---- column sums of this workgroup: lanes sharing i (4 q groups) -> waves -> one partial row [dg | dbeta | dbias]
+  __syncthreads();
+  float* cs = sh_gb;  // [WAVES][3 NP]
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    const float g = row_allsum(cg[t]), b = row_allsum(cb[t]), z = row_allsum(cz[t]);
+    if (q == 0) {
+      cs[wave * 3 * NP + 16 * t + i] = g;
+      cs[wave * 3 * NP + NP + 16 * t + i] = b;
+      cs[wave * 3 * NP + 2 * NP + 16 * t + i] = z;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * NP; e += NTH) {
+    const int k = e / NP, col = e % NP;
+    if (col < n_out) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) s += cs[w * 3 * NP + e];
+      partials[(size_t)blockIdx.x * 3 * n_out + (size_t)k * n_out + col] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// partials[z][m][n] = sum over the rows k of split z of dz[k][m0 + m] * x[k][n0 + n];  block = (64 MT) x (16 NT).
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gen_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x, int B,
+                                                        int n_out, int n_in, int rows_per_split,
+                                                        float* __restrict__ partials) {
+  constexpr int BM = 64 * MT, BN = 16 * NT, ALD = BM + 16, BLD = BN + 16;
+  constexpr int AU = (4 * BM + 255) / 256, BU = (4 * BN + 255) / 256;
+  extern __shared__ float sh_gw[];
+  float* As = sh_gw;                     // [2][KC][ALD]  As[k][m]
+  float* Bs = sh_gw + 2 * GF_KC * ALD;   // [2][KC][BLD]  Bs[k][n]
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const long long kb = (long long)blockIdx.z * rows_per_split;
+  const long long ke = min((long long)B, kb + rows_per_split);
+  const bool va = (n_out & 3) == 0 && aligned16(dz), vb = (n_in & 3) == 0 && aligned16(x);
+  f32x4 ra[AU], rb[BU];
+  auto load = [&](long long k0) {
+#pragma unroll
+    for (int u0 = 0; u0 < AU; ++u0) {
+      const int u = tid + 256 * u0, k = u / (BM / 4), m = m0 + 4 * (u % (BM / 4));
+      ra[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < 4 * BM && k0 + k < ke && m < n_out) {
+        const float* p = dz + (k0 + k) * n_out + m;
+        if (va) ra[u0] = *(const f32x4*)p;
+        else
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (m + j < n_out) ra[u0][j] = p[j];
+      }
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < BU; ++u0) {
+      const int u = tid + 256 * u0, k = u / (BN / 4), n = n0 + 4 * (u % (BN / 4));
+      rb[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < 4 * BN && k0 + k < ke && n < n_in) {
+        const float* p = x + (k0 + k) * n_in + n;
+        if (vb) rb[u0] = *(const f32x4*)p;
+        else
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (n + j < n_in) rb[u0][j] = p[j];
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    float* ab = As + buf * GF_KC * ALD;
+    float* bb = Bs + buf * GF_KC * BLD;
+#pragma unroll
+    for (int u0 = 0; u0 < AU; ++u0) {
+      const int u = tid + 256 * u0;
+      if (u < 4 * BM) *(f32x4*)(ab + (u / (BM / 4)) * ALD + 4 * (u % (BM / 4))) = ra[u0];
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < BU; ++u0) {
+      const int u = tid + 256 * u0;
+      if (u < 4 * BN) *(f32x4*)(bb + (u / (BN / 4)) * BLD + 4 * (u % (BN / 4))) = rb[u0];
+    }
+  };
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long long nch = (ke - kb + GF_KC - 1) / GF_KC;
+  if (nch > 0) {
+    load(kb);
+    stash(0);
+  }
+  __syncthreads();
+  for (long long c = 0; c < nch; ++c) {
+    if (c + 1 < nch) load(kb + (c + 1) * GF_KC);
+    const float* ab = As + (c & 1) * GF_KC * ALD + 16 * MT * wave + i;
+    const float* bb = Bs + (c & 1) * GF_KC * BLD + i;
+#pragma unroll
+    for (int kk = 0; kk < GF_KC; kk += 4) {
+      float av[MT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) av[a] = ab[(kk + q) * ALD + 16 * a];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float bv = bb[(kk + q) * BLD + 16 * t];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a][t] = ORL_MFMA(av[a], bv, acc[a][t]);
+      }
+    }
+    if (c + 1 < nch) stash((c + 1) & 1);
+    __syncthreads();
+  }
+  float* out = partials + (size_t)blockIdx.z * (size_t)n_out * n_in;
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + 16 * (MT * wave + a) + 4 * q + r, gn = n0 + 16 * t + i;
+        if (gm < n_out && gn < n_in) out[(size_t)gm * n_in + gn] = acc[a][t][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+struct ColsumDst {
+  float* p[3];
+  int w[3];
+};
+// sums[col] = sum_b partials[b][col] in a fixed order (16 row groups of a strided walk, then the groups in index order);
+// column col of segment k (widths w[0..2]) goes to p[k][col - start_k] when p[k] != nullptr.
+__global__ __launch_bounds__(1024) void gen_colsum_kernel(const float* __restrict__ partials, int n_rows, int width,
+                                                          ColsumDst dst) {
+  __shared__ float sh[16][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < width) {
+    int b = rg;
+    for (; b + 48 < n_rows; b += 64) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += partials[(size_t)(b + 16 * j) * width + col];
+    }
+    for (int j = 0; b < n_rows; b += 16, ++j) s[j & 3] += partials[(size_t)b * width + col];
+  }
+  sh[rg][c] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (rg == 0 && col < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += sh[g][c];
+    int k = 0, start = 0;
+    while (k < 2 && col >= start + dst.w[k]) { start += dst.w[k]; ++k; }
+    if (dst.p[k]) dst.p[k][col - start] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+template <int NB, int WAVES>
+static int launch_fwd(const float* x, int B, int n_in, const float* W, const float* bias, int act, const float* gamma,
+                      const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, hipStream_t s) {
+  constexpr int BM = 16 * WAVES, NP = 16 * NB;
+  const size_t lds = (size_t)2 * GF_KC * ((BM + 16) + (NP + 16)) * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)gen_layer_fwd_kernel<NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const unsigned grid = (unsigned)(((long long)B + BM - 1) / BM);
+  hipLaunchKernelGGL((gen_layer_fwd_kernel<NB, WAVES>), dim3(grid), dim3(64 * WAVES), lds, s, x, B, n_in, W, bias, act, gamma,
+                     beta, n_out, a_out, stats_out, y_out);
+  return launch_status("orl_gen_layer_fwd");
+}
+
+template <int NB, int WAVES>
+static int launch_bwd(const float* dy, const float* a, const float* stats, const float* gamma, int act, int B, int n_out,
+                      const float* W, float* dz_out, float* dx_out, float* partials, int max_blocks, int* n_blocks_out,
+                      hipStream_t s) {
+  constexpr int BM = 16 * WAVES, NP = 16 * NB;
+  size_t fl = (size_t)WAVES * NP * 17 + (size_t)2 * GF_KC * (NP + 16);
+  if (fl < (size_t)WAVES * 3 * NP) fl = (size_t)WAVES * 3 * NP;
+  const size_t lds = fl * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)gen_layer_bwd_kernel<NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  long long grid = ((long long)B + BM - 1) / BM;
+  const int cap = max_blocks < 512 ? max_blocks : 512;  // 2 workgroups per CU
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL((gen_layer_bwd_kernel<NB, WAVES>), dim3((unsigned)grid), dim3(64 * WAVES), lds, s, dy, a, stats, gamma, act,
+                     B, n_out, W, dz_out, dx_out, partials);
+  *n_blocks_out = (int)grid;
+  return launch_status("orl_gen_layer_bwd");
+}
+
+template <int MT, int NT>
+static int launch_wgrad(const float* dz, const float* x, int B, int n_out, int n_in, int n_split, int rows_per_split,
+                        float* partials, hipStream_t s) {
+  constexpr int BM = 64 * MT, BN = 16 * NT;
+  const size_t lds = (size_t)2 * GF_KC * ((BM + 16) + (BN + 16)) * sizeof(float);
+  const dim3 grid((n_in + BN - 1) / BN, (n_out + BM - 1) / BM, n_split);
+  hipLaunchKernelGGL((gen_wgrad_kernel<MT, NT>), grid, dim3(256), lds, s, dz, x, B, n_out, n_in, rows_per_split, partials);
+  return launch_status("orl_gen_wgrad");
+}
+
+}  // namespace orl
+
+using namespace orl;
+
+extern "C" {
+
+int orl_gen_layer_fwd(const float* x, int B, int n_in, const float* W, const float* bias, int act, const float* gamma,
+                      const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, void* stream) {
+  ORL_REQUIRE(x && W && B > 0 && n_in > 0 && n_out > 0 && n_out <= 512, "orl_gen_layer_fwd: bad arguments (B=%d n_in=%d n_out=%d <= 512)",
+              B, n_in, n_out);
+  ORL_REQUIRE(act >= ORL_ACT_NONE && act <= ORL_ACT_ELU, "orl_gen_layer_fwd: activation id %d", act);
+  ORL_REQUIRE((gamma == nullptr) == (beta == nullptr), "orl_gen_layer_fwd: gamma and beta come together");
+  hipStream_t s = (hipStream_t)stream;
+#define ORL_GF_FWD(NB, WV) \
+  return launch_fwd<NB, WV>(x, B, n_in, W, bias, act, gamma, beta, n_out, a_out, stats_out, y_out, s)
+  if (n_out <= 16) ORL_GF_FWD(1, 4);
+  if (n_out <= 32) ORL_GF_FWD(2, 4);
+  if (n_out <= 64) ORL_GF_FWD(4, 4);
+  if (n_out <= 128) ORL_GF_FWD(8, 4);
+  if (n_out <= 256) ORL_GF_FWD(16, 4);
+  ORL_GF_FWD(32, 2);
+#undef ORL_GF_FWD
+}
+
+int orl_gen_layer_bwd(const float* dy, const float* a, const float* stats, const float* gamma, int act, int B, int n_out,
+                      const float* W, int n_in, float* dz_out, float* dx_out, float* col_partials, int max_blocks,
+                      int* n_blocks_out, void* stream) {
+  ORL_REQUIRE(dy && col_partials && n_blocks_out && B > 0 && n_out > 0 && n_out <= 512 && max_blocks > 0,
+              "orl_gen_layer_bwd: bad arguments (B=%d n_out=%d <= 512)", B, n_out);
+  ORL_REQUIRE(!gamma || (a && stats), "orl_gen_layer_bwd: LayerNorm backward needs the activations and the row statistics");
+  ORL_REQUIRE(act == ORL_ACT_NONE || a, "orl_gen_layer_bwd: activation backward needs the activations");
+  ORL_REQUIRE((dx_out == nullptr) || (W && n_in == n_out), "orl_gen_layer_bwd: the fused dgrad takes square layers (n_in %d, n_out %d)",
+              n_in, n_out);
+  hipStream_t s = (hipStream_t)stream;
+  const float* Wd = dx_out ? W : nullptr;
+#define ORL_GF_BWD(NB, WV) \
+  return launch_bwd<NB, WV>(dy, a, stats, gamma, act, B, n_out, Wd, dz_out, dx_out, col_partials, max_blocks, n_blocks_out, s)
+  if (n_out <= 16) ORL_GF_BWD(1, 4);
+  if (n_out <= 32) ORL_GF_BWD(2, 4);
+  if (n_out <= 64) ORL_GF_BWD(4, 4);
+  if (n_out <= 128) ORL_GF_BWD(8, 4);
+  if (n_out <= 256) ORL_GF_BWD(16, 4);
+  ORL_GF_BWD(32, 2);
+#undef ORL_GF_BWD
+}
+
+int orl_gen_colsum(const float* partials, int n_rows, int width, float* dst0, int w0, float* dst1, int w1, float* dst2,
+                   int w2, void* stream) {
+  ORL_REQUIRE(partials && n_rows > 0 && width > 0 && w0 >= 0 && w1 >= 0 && w2 >= 0 && w0 + w1 + w2 == width,
+              "orl_gen_colsum: bad arguments (rows %d, width %d = %d + %d + %d)", n_rows, width, w0, w1, w2);
+  ColsumDst d;
+  d.p[0] = dst0; d.p[1] = dst1; d.p[2] = dst2;
+  d.w[0] = w0; d.w[1] = w1; d.w[2] = w2;
+  hipLaunchKernelGGL(gen_colsum_kernel, dim3((width + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partials, n_rows, width, d);
+  return launch_status("orl_gen_colsum");
+}
+
+int orl_gen_wgrad(const float* dz, const float* x, int B, int n_out, int n_in, float* dW, float* partials,
+                  int64_t partials_floats, void* stream) {
+  ORL_REQUIRE(dz && x && dW && partials && B > 0 && n_out > 0 && n_in > 0, "orl_gen_wgrad: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const bool big = n_out > 64 && n_in > 64;
+  const int BM = big ? 128 : 64, BN = big ? 128 : (n_in <= 16 ? 16 : 64);
+  const int tiles = ((n_out + BM - 1) / BM) * ((n_in + BN - 1) / BN);
+  long long n_split = 512 / tiles;
+  if (n_split < 1) n_split = 1;
+  const long long by_rows = ((long long)B + 255) / 256;  // at least 256 rows per split
+  if (n_split > by_rows) n_split = by_rows;
+  const long long by_mem = partials_floats / ((long long)n_out * n_in);
+  ORL_REQUIRE(by_mem >= 1, "orl_gen_wgrad: the partials buffer (%lld floats) does not hold one %d x %d block",
+              (long long)partials_floats, n_out, n_in);
+  if (n_split > by_mem) n_split = by_mem;
+  long long rps = (((long long)B + n_split - 1) / n_split + GF_KC - 1) / GF_KC * GF_KC;
+  n_split = ((long long)B + rps - 1) / rps;
+  int rc;
+  if (big) rc = launch_wgrad<2, 8>(dz, x, B, n_out, n_in, (int)n_split, (int)rps, partials, s);
+  else if (n_in <= 16) rc = launch_wgrad<1, 1>(dz, x, B, n_out, n_in, (int)n_split, (int)rps, partials, s);
+  else rc = launch_wgrad<1, 4>(dz, x, B, n_out, n_in, (int)n_split, (int)rps, partials, s);
+  if (rc) return rc;
+  return orl_gen_colsum(partials, (int)n_split, n_out * n_in, dW, n_out * n_in, nullptr, 0, nullptr, 0, stream);
+}
+
+}  // extern "C"

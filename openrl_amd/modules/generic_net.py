@@ -254,28 +254,27 @@ class GenNet:
 
 
 class GenWorkspace:
-    """Activation / gradient buffers of one trunk pass over up to ``rows`` rows (allocated once, reused)."""
+    """Activation / gradient buffers of one trunk pass over up to ``rows`` rows (allocated once, reused).  Per layer the
+    forward keeps ``a`` (post-activation, pre-LayerNorm), the row statistics (mean, rstd) and ``y`` - what
+    ``orl_gen_layer_bwd`` and the next layer's weight gradient read."""
 
     def __init__(self, net: GenNet, rows: int, training: bool) -> None:
         dev, f = net.device, torch.float32
         e = lambda *s: torch.empty(*s, dtype=f, device=dev)
         self.rows = rows
         W = net.max_width
-        self.z = e(rows, W)
         self.x0 = e(rows, net.D)
         self.fn = dict(xhat=e(rows, net.D), rstd=e(rows), y=e(rows, net.D)) if net.fn is not None else None
         self.layers = []
         for L in net.layers:
-            self.layers.append(dict(a=e(rows, L["n_out"]) if (training and L["act"] != ops_gen.ACT_NONE) else None,
-                                    xhat=e(rows, L["n_out"]) if training else None, rstd=e(rows) if training else None,
-                                    y=e(rows, L["n_out"])))
+            self.layers.append(dict(a=e(rows, L["n_out"]) if training else None,
+                                    stats=e(rows, 2) if training else None, y=e(rows, L["n_out"])))
         self.head_out = {k: e(rows, h["n"]) for k, h in net.heads.items()}
         if training:
             self.dhead = {k: e(rows, h["n"]) for k, h in net.heads.items()}
             self.da, self.db2, self.dz, self.dfeat = e(rows, W), e(rows, W), e(rows, W), e(rows, W)
             self.col_partials = e(ops_gen.MAX_BLOCKS * 3 * W)
-            self.colsum = e(3 * W)
-            self.wgrad_partials = e(max(4 * W * W, 1 << 22))
+            self.wgrad_partials = e(max(4 * W * W, min(512 * W * W, 1 << 24)))
             self.loss_partials = e(ops_gen.MAX_BLOCKS * 20)
             self.loss_sums = {"act": e(20), "v_out": e(20)}
 
@@ -284,7 +283,8 @@ class GenWorkspace:
 
 
 def trunk_forward(net: GenNet, ws: GenWorkspace, x: torch.Tensor, save: bool) -> torch.Tensor:
-    """MLPBase.forward (+ the shared model's ``common`` layers): features [B, H]."""
+    """MLPBase.forward (+ the shared model's ``common`` layers): features [B, H].  One launch per layer
+    (``orl_gen_layer_fwd``: Linear + bias + activation + LayerNorm on the MFMA accumulators)."""
     B = x.shape[0]
     if net.fn is not None:
         f = ws.fn
@@ -294,12 +294,10 @@ def trunk_forward(net: GenNet, ws: GenWorkspace, x: torch.Tensor, save: bool) ->
         x = y
     for L, w in zip(net.layers, ws.layers):
         n_in, n_out = L["n_in"], L["n_out"]
-        z = ws.v(ws.z, B, n_out)
-        ops_gen.linear_fwd(x, net.v(L["W"], n_out, n_in), z)
         y = ws.v(w["y"], B, n_out)
-        ops_gen.row_fwd(z, net.v(L["b"], n_out), L["act"], net.v(L["g"], n_out), net.v(L["be"], n_out),
-                        ws.v(w["a"], B, n_out) if (save and w["a"] is not None) else None,
-                        ws.v(w["xhat"], B, n_out) if save else None, w["rstd"][:B] if save else None, y)
+        ops_gen.layer_fwd(x, net.v(L["W"], n_out, n_in), net.v(L["b"], n_out), L["act"], net.v(L["g"], n_out),
+                          net.v(L["be"], n_out), ws.v(w["a"], B, n_out) if save else None,
+                          ws.v(w["stats"], B, 2) if save else None, y)
         w["x_in"] = x
         x = y
     return x
@@ -308,19 +306,9 @@ def trunk_forward(net: GenNet, ws: GenWorkspace, x: torch.Tensor, save: bool) ->
 def head_forward(net: GenNet, ws: GenWorkspace, name: str, feats: torch.Tensor) -> torch.Tensor:
     h = net.heads[name]
     B, n = feats.shape[0], h["n"]
-    z = ws.v(ws.z, B, n)
-    ops_gen.linear_fwd(feats, net.v(h["W"], n, net.H), z)
     out = ws.v(ws.head_out[name], B, n)
-    ops_gen.row_fwd(z, net.v(h["b"], n), ops_gen.ACT_NONE, None, None, None, None, None, out)
+    ops_gen.layer_fwd(feats, net.v(h["W"], n, net.H), net.v(h["b"], n), ops_gen.ACT_NONE, None, None, None, None, out)
     return out
-
-
-def _colsums(net: GenNet, ws: GenWorkspace, nb: int, width: int, targets) -> None:
-    """Column-sum the [nb][3*width] partial rows and copy the three blocks to their places in ``net.grad``."""
-    ops.ppo_reduce(ws.col_partials.data_ptr(), nb, 3 * width, ws.colsum.data_ptr(), net.device)
-    pairs = [(net.v(off, width, grad=True), ws.colsum[k * width:(k + 1) * width]) for k, off in enumerate(targets)
-             if off is not None]
-    ops.multi_copy(pairs)
 
 
 def head_backward(net: GenNet, ws: GenWorkspace, name: str, feats: torch.Tensor, dout: torch.Tensor,
@@ -328,9 +316,9 @@ def head_backward(net: GenNet, ws: GenWorkspace, name: str, feats: torch.Tensor,
     """nn.Linear backward of one head: dW, db into ``net.grad``; dfeat (+)= dout @ W."""
     h = net.heads[name]
     B, n, H = feats.shape[0], h["n"], net.H
-    ops_gen.linear_wgrad(dout, feats, net.v(h["W"], n, H, grad=True), ws.wgrad_partials)
-    nb = ops_gen.row_bwd(dout, None, None, None, None, ops_gen.ACT_NONE, None, ws.col_partials)
-    _colsums(net, ws, nb, n, [None, None, h["b"]])
+    ops_gen.wgrad(dout, feats, net.v(h["W"], n, H, grad=True), ws.wgrad_partials)
+    nb = ops_gen.layer_bwd(dout, None, None, None, ops_gen.ACT_NONE, None, None, None, ws.col_partials)
+    ops_gen.colsum(ws.col_partials, nb, [(None, n), (None, n), (net.v(h["b"], n, grad=True), n)])
     if accumulate:
         tmp = ws.v(ws.dz, B, H)
         ops_gen.linear_dgrad(dout, net.v(h["W"], n, H), tmp)
@@ -340,7 +328,9 @@ def head_backward(net: GenNet, ws: GenWorkspace, name: str, feats: torch.Tensor,
 
 
 def trunk_backward(net: GenNet, ws: GenWorkspace, dfeat: torch.Tensor) -> None:
-    """Backward of ``trunk_forward``: every trunk parameter's gradient is WRITTEN into ``net.grad``."""
+    """Backward of ``trunk_forward``: every trunk parameter's gradient is WRITTEN into ``net.grad``.  Per layer:
+    ``orl_gen_layer_bwd`` (LayerNorm / activation backward + the input gradient of square layers), one column-sum
+    launch for d gamma / d beta / d bias, ``orl_gen_wgrad``."""
     B = dfeat.shape[0]
     dy = dfeat
     bufs = [ws.da, ws.db2]
@@ -348,19 +338,26 @@ def trunk_backward(net: GenNet, ws: GenWorkspace, dfeat: torch.Tensor) -> None:
         L, w = net.layers[k], ws.layers[k]
         n_in, n_out = L["n_in"], L["n_out"]
         dz = ws.v(ws.dz, B, n_out)
-        nb = ops_gen.row_bwd(dy, net.v(L["g"], n_out), ws.v(w["xhat"], B, n_out), w["rstd"][:B],
-                             ws.v(w["a"], B, n_out) if w["a"] is not None else None, L["act"], dz, ws.col_partials)
-        _colsums(net, ws, nb, n_out, [L["g"], L["be"], L["b"]])
-        ops_gen.linear_wgrad(dz, w["x_in"], net.v(L["W"], n_out, n_in, grad=True), ws.wgrad_partials)
-        if k > 0 or net.fn is not None:
-            dx = ws.v(bufs[k & 1], B, n_in)
-            ops_gen.linear_dgrad(dz, net.v(L["W"], n_out, n_in), dx)
+        want_dx = k > 0 or net.fn is not None
+        fused_dx = want_dx and n_in == n_out
+        dx = ws.v(bufs[k & 1], B, n_in) if want_dx else None
+        Wm = net.v(L["W"], n_out, n_in)
+        nb = ops_gen.layer_bwd(dy, ws.v(w["a"], B, n_out), ws.v(w["stats"], B, 2), net.v(L["g"], n_out), L["act"],
+                               Wm if fused_dx else None, dz, dx if fused_dx else None, ws.col_partials)
+        ops_gen.colsum(ws.col_partials, nb, [(net.v(L["g"], n_out, grad=True), n_out),
+                                             (net.v(L["be"], n_out, grad=True), n_out),
+                                             (net.v(L["b"], n_out, grad=True), n_out)])
+        ops_gen.wgrad(dz, w["x_in"], net.v(L["W"], n_out, n_in, grad=True), ws.wgrad_partials)
+        if want_dx:
+            if not fused_dx:
+                ops_gen.linear_dgrad(dz, Wm, dx)
             dy = dx
     if net.fn is not None:
         f = ws.fn
         nb = ops_gen.row_bwd(dy, net.v(net.fn["g"], net.D), ws.v(f["xhat"], B, net.D), f["rstd"][:B], None,
                              ops_gen.ACT_NONE, None, ws.col_partials)
-        _colsums(net, ws, nb, net.D, [net.fn["g"], net.fn["be"], None])
+        ops_gen.colsum(ws.col_partials, nb, [(net.v(net.fn["g"], net.D, grad=True), net.D),
+                                             (net.v(net.fn["be"], net.D, grad=True), net.D), (None, net.D)])
 
 
 class GenAdam(FusedAdam):

@@ -84,6 +84,53 @@ def row_bwd(dy, gamma, xhat, rstd, a, act: int, dz_out, col_partials) -> int:
     return nb.value
 
 
+def layer_fwd(x, W, bias, act: int, gamma, beta, a_out, stats_out, y_out) -> None:
+    """y = LN(act(x @ W^T + bias)) in one launch (``orl_gen_layer_fwd``); ``a_out`` [B, out] / ``stats_out`` [B, 2] feed
+    ``layer_bwd``."""
+    dev = nat.require_gpu(x.device)
+    Bn, n_in = x.shape
+    n_out = W.shape[0]
+    assert x.is_contiguous() and W.shape[1] == n_in
+    rc = _lib().orl_gen_layer_fwd(fptr(x), Bn, n_in, fptr(W), fptr(bias), act, fptr(gamma), fptr(beta), n_out,
+                                  fptr(a_out), fptr(stats_out), fptr(y_out), stream_ptr(dev))
+    nat.check(rc, "orl_gen_layer_fwd")
+
+
+def layer_bwd(dy, a, stats, gamma, act: int, W, dz_out, dx_out, col_partials) -> int:
+    """dy -> dz (+ dx = dz @ W for a square layer when ``dx_out`` is given) and the [d gamma | d beta | d bias] partial
+    rows; returns their count."""
+    dev = nat.require_gpu(dy.device)
+    Bn, n_out = dy.shape
+    n_in = W.shape[1] if W is not None else n_out
+    nb = C.c_int(0)
+    max_blocks = min(MAX_BLOCKS, col_partials.numel() // (3 * n_out))
+    rc = _lib().orl_gen_layer_bwd(fptr(dy), fptr(a), fptr(stats), fptr(gamma), act, Bn, n_out, fptr(W), n_in,
+                                  fptr(dz_out), fptr(dx_out), fptr(col_partials), max_blocks, C.byref(nb),
+                                  stream_ptr(dev))
+    nat.check(rc, "orl_gen_layer_bwd")
+    return nb.value
+
+
+def wgrad(dz, x, dW, partials) -> None:
+    """dW[out, in] = dz[B, out]^T @ x[B, in] (``orl_gen_wgrad``: persistent split-K, fixed summation order)."""
+    dev = nat.require_gpu(dz.device)
+    Bn, n_out = dz.shape
+    n_in = x.shape[1]
+    rc = _lib().orl_gen_wgrad(fptr(dz), fptr(x), Bn, n_out, n_in, fptr(dW), fptr(partials), partials.numel(),
+                              stream_ptr(dev))
+    nat.check(rc, "orl_gen_wgrad")
+
+
+def colsum(partials, n_rows: int, dsts) -> None:
+    """Column sums of ``partials[n_rows][sum(widths)]``; ``dsts`` = up to three (tensor or None, width) segments."""
+    dev = nat.require_gpu(partials.device)
+    dsts = list(dsts) + [(None, 0)] * (3 - len(dsts))
+    width = sum(w for _, w in dsts)
+    rc = _lib().orl_gen_colsum(fptr(partials), n_rows, width, fptr(dsts[0][0]), dsts[0][1], fptr(dsts[1][0]), dsts[1][1],
+                               fptr(dsts[2][0]), dsts[2][1], stream_ptr(dev))
+    nat.check(rc, "orl_gen_colsum")
+
+
 def gather_cols(records, col0: int, width: int, idx, mb: int, out) -> None:
     dev = nat.require_gpu(records.device)
     rc = _lib().orl_gather_cols(fptr(records), records.shape[1], col0, width, ptr(idx), mb, fptr(out), stream_ptr(dev))

@@ -187,6 +187,68 @@ def test_gemm_against_torch_fp32(M, N, K, split):
             np.testing.assert_allclose(c.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-4 * np.sqrt(K))
 
 
+_ACTS = {0: torch.tanh, 1: torch.relu, 2: torch.nn.functional.leaky_relu, 3: torch.nn.functional.elu}
+
+
+@pytest.mark.parametrize("B,n_in,n_out,act,ln", [(1000, 4, 128, 1, True), (777, 128, 128, 0, True), (300, 20, 36, 3, True),
+                                                 (530, 256, 256, 2, True), (200, 512, 512, 1, True), (999, 64, 64, -1, True),
+                                                 (640, 128, 5, -1, False), (333, 6, 100, 1, True), (64, 128, 1, -1, False)])
+def test_fused_layer_kernels_against_torch_fp64(B, n_in, n_out, act, ln):
+    """orl_gen_layer_fwd / orl_gen_layer_bwd / orl_gen_wgrad / orl_gen_colsum vs nn.Sequential(Linear, act, LayerNorm)
+    evaluated by torch autograd in fp64 (mlp.py:8-46).  Tolerances: fp32 accumulation over K <= 512 products and B rows."""
+    from openrl_amd import ops_gen
+
+    rs = np.random.RandomState(B + n_in + n_out)
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    x, W, b = t64(rs.randn(B, n_in)), t64(rs.randn(n_out, n_in) / np.sqrt(n_in)), t64(0.1 * rs.randn(n_out))
+    g, be = t64(1.0 + 0.1 * rs.randn(n_out)), t64(0.1 * rs.randn(n_out))
+    dy = torch.tensor(rs.randn(B, n_out), dtype=torch.float64)
+    a_ref = x @ W.t() + b
+    if act >= 0:
+        a_ref = _ACTS[act](a_ref)
+    y_ref = torch.nn.functional.layer_norm(a_ref, (n_out,), g, be, 1e-5) if ln else a_ref
+    (y_ref * dy).sum().backward()
+
+    dev = lambda t: t.detach().to(torch.float32).to(DEV).contiguous()
+    # the weights sit at an arbitrary (possibly 16-byte misaligned) offset of a flat vector, like GenNet.theta
+    flat = torch.zeros(3 + n_out * n_in, device=DEV)
+    flat[3:] = dev(W).view(-1)
+    for Wd in (dev(W), flat[3:].view(n_out, n_in)):
+        xd, a_out, stats, y = dev(x), torch.zeros(B, n_out, device=DEV), torch.zeros(B, 2, device=DEV), torch.zeros(B, n_out, device=DEV)
+        act_id = ops_gen.ACT_NONE if act < 0 else act
+        ops_gen.layer_fwd(xd, Wd, dev(b), act_id, dev(g) if ln else None, dev(be) if ln else None, a_out, stats if ln else None, y)
+        np.testing.assert_allclose(a_out.cpu().numpy(), a_ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+        # inference form: no a / stats
+        y2 = torch.zeros_like(y)
+        ops_gen.layer_fwd(xd, Wd, dev(b), act_id, dev(g) if ln else None, dev(be) if ln else None, None, None, y2)
+        assert torch.equal(y, y2)
+
+        part = torch.zeros(ops_gen.MAX_BLOCKS * 3 * n_out, device=DEV)
+        dz, dx = torch.zeros(B, n_out, device=DEV), torch.zeros(B, n_in, device=DEV)
+        square = n_in == n_out
+        nb = ops_gen.layer_bwd(dev(dy), a_out, stats if ln else None, dev(g) if ln else None, act_id,
+                               Wd if square else None, dz, dx if square else None, part)
+        dg, dbe, db = torch.zeros(n_out, device=DEV), torch.zeros(n_out, device=DEV), torch.zeros(n_out, device=DEV)
+        ops_gen.colsum(part, nb, [(dg if ln else None, n_out), (dbe if ln else None, n_out), (db, n_out)])
+        sB = np.sqrt(B)
+        np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=2e-5 * sB)
+        if ln:
+            np.testing.assert_allclose(dg.cpu().numpy(), g.grad.numpy(), rtol=1e-4, atol=2e-5 * sB)
+            np.testing.assert_allclose(dbe.cpu().numpy(), be.grad.numpy(), rtol=1e-4, atol=2e-5 * sB)
+        if not square:
+            ops_gen.linear_dgrad(dz, Wd.contiguous(), dx)
+        np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), rtol=1e-4, atol=1e-4)
+        dW = torch.zeros(n_out, n_in, device=DEV)
+        wp = torch.zeros(max(n_out * n_in, min(512 * n_out * n_in, 1 << 22)), device=DEV)
+        ops_gen.wgrad(dz, xd, dW, wp)
+        np.testing.assert_allclose(dW.cpu().numpy(), W.grad.numpy(), rtol=1e-4, atol=2e-5 * sB)
+        # deterministic: a second run is bit-identical
+        dW2 = torch.zeros_like(dW)
+        ops_gen.wgrad(dz, xd, dW2, wp)
+        assert torch.equal(dW, dW2)
+
+
 # ---- end to end through make / PPONet / PPOAgent ----------------------------------------------------------------------
 class MatchTargetEnv:
     """Host VecEnv (the duck type of examples/isaac/isaac2openrl.py:28-88) with a MultiDiscrete([3, 2]) action space:
