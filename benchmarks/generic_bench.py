@@ -68,6 +68,7 @@ def main():
     print(json.dumps({"bench": "generic_tower_path", "envs": N, "rollout_len": T, "hidden_size": a.hidden_size,
                       "layer_N": a.layer_N, "share_model": a.share, "generic": bool(getattr(net.module, "generic", False)),
                       "env_steps_per_s": N * T * a.steps / dt, "ms_per_iteration": dt / a.steps * 1e3,
+                      "rollout": "fused" if drv.fused else "graph" if drv._graph is not None else "stepwise",
                       "ms_rollout": t_roll / a.steps * 1e3, "ms_update": t_upd / a.steps * 1e3}))
 
 

@@ -418,6 +418,12 @@ int orl_env_reset(int env_kind, float* env_state, float* ep_stats, float* obs0, 
 int orl_env_step(int env_kind, float* env_state, float* ep_stats, const float* actions, int action_width,
                  float* obs, float* rewards, uint8_t* dones, int N, int obs_dim, uint64_t env_seed,
                  int episode_limit, uint64_t global_step, void* stream);
+/* The same step with the counter split in two: effective step = global_step + *global_step_dev (mod 2^64).  A stepwise
+ * rollout captured in a hipGraph freezes the host part; the device part (an int64 the graph itself advances) carries the
+ * progress from replay to replay.  global_step_dev == NULL is orl_env_step. */
+int orl_env_step_dev(int env_kind, float* env_state, float* ep_stats, const float* actions, int action_width,
+                     float* obs, float* rewards, uint8_t* dones, int N, int obs_dim, uint64_t env_seed,
+                     int episode_limit, uint64_t global_step, const int64_t* global_step_dev, void* stream);
 
 /* V(obs) of `rows` stored observations [rows, obs_dim] in one persistent launch (PPOModule.get_values,
  * ppo_module.py:140-147, for a whole rollout at once); the same per-row arithmetic as orl_act_step's critic. */

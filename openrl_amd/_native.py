@@ -193,6 +193,8 @@ _SIGNATURES = {
     "orl_env_reset": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int, _P]),
     "orl_env_step": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                C.c_uint64, _P]),
+    "orl_env_step_dev": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                                   C.c_uint64, _P, _P]),
     "orl_rollout_fused": (C.c_int, [C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, C.POINTER(RolloutArgs), _P, _P]),
     "orl_mpe_state_width": (C.c_int, []),
     "orl_mpe_reset": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_uint64, _P]),

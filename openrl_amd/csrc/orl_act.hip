@@ -863,9 +863,11 @@ __global__ __launch_bounds__(256) void env_step_kernel(float* __restrict__ env_s
                                                        const float* __restrict__ actions, int a_w,
                                                        float* __restrict__ obs, float* __restrict__ rew,
                                                        uint8_t* __restrict__ done, int N, int D, uint64_t seed,
-                                                       int episode_limit, uint64_t tg) {
+                                                       int episode_limit, uint64_t tg,
+                                                       const long long* __restrict__ tg_dev) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
+  if (tg_dev) tg += (uint64_t)*tg_dev;  // hipGraph replays: the host part is frozen, the device part advances
   float r;
   bool d;
   if (ENV == ORL_ENV_SYNTH) {
@@ -1196,18 +1198,25 @@ int orl_env_reset(int env_kind, float* env_state, float* ep_stats, float* obs0, 
 int orl_env_step(int env_kind, float* env_state, float* ep_stats, const float* actions, int action_width, float* obs,
                  float* rewards, uint8_t* dones, int N, int obs_dim, uint64_t env_seed, int episode_limit,
                  uint64_t global_step, void* stream) {
+  return orl_env_step_dev(env_kind, env_state, ep_stats, actions, action_width, obs, rewards, dones, N, obs_dim, env_seed,
+                          episode_limit, global_step, nullptr, stream);
+}
+
+int orl_env_step_dev(int env_kind, float* env_state, float* ep_stats, const float* actions, int action_width, float* obs,
+                     float* rewards, uint8_t* dones, int N, int obs_dim, uint64_t env_seed, int episode_limit,
+                     uint64_t global_step, const int64_t* global_step_dev, void* stream) {
   ORL_REQUIRE(env_state && obs && rewards && dones && N > 0 && obs_dim > 0 && episode_limit > 0,
               "orl_env_step: bad arguments");
   const int grid = (N + 255) / 256;
   if (env_kind == ORL_ENV_SYNTH) {
     hipLaunchKernelGGL((env_step_kernel<ORL_ENV_SYNTH>), dim3(grid), dim3(256), 0, (hipStream_t)stream, env_state,
                        ep_stats, actions, action_width, obs, rewards, dones, N, obs_dim, env_seed, episode_limit,
-                       global_step);
+                       global_step, (const long long*)global_step_dev);
   } else if (env_kind == ORL_ENV_CARTPOLE) {
     ORL_REQUIRE(actions && action_width >= 1 && obs_dim == 4, "orl_env_step: CartPole needs actions and 4-d obs");
     hipLaunchKernelGGL((env_step_kernel<ORL_ENV_CARTPOLE>), dim3(grid), dim3(256), 0, (hipStream_t)stream, env_state,
                        ep_stats, actions, action_width, obs, rewards, dones, N, obs_dim, env_seed, episode_limit,
-                       global_step);
+                       global_step, (const long long*)global_step_dev);
   } else {
     return fail(ORL_E_INVALID, "orl_env_step: unknown env kind %d", env_kind);
   }

@@ -37,6 +37,31 @@ __device__ inline float sum16(float v) {
 
 __device__ inline bool aligned16(const void* p) { return (((unsigned long long)p) & 15ull) == 0; }
 
+// Row layout of a 16-row wave slab of NP = 16 NB columns: LPR lanes (a power of two <= 64) walk one row in float4
+// slots s = lane % LPR + LPR j (j < VPL; valid while 4 s < n_out), 64 / LPR rows per pass, ITS passes per slab.  Loads
+// and stores are whole coalesced rows instead of the MFMA fragment's 64-byte column groups.
+template <int NB>
+struct RowLay {
+  static constexpr int VPRP = 4 * NB;
+  static constexpr int LPR = VPRP < 64 ? VPRP : 64;
+  static constexpr int VPL = VPRP / LPR;
+  static constexpr int RPI = 64 / LPR;
+  static constexpr int ITS = 16 / RPI;
+  static constexpr int UB = ITS < 4 ? ITS : 4;  // passes whose loads are issued together
+};
+template <int LPR>
+__device__ inline float sum_lanes(float v) {  // over the LPR lanes (aligned group) of one row
+#pragma unroll
+  for (int off = LPR >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+template <int LPR>
+__device__ inline float sum_groups(float v) {  // over the 64 / LPR row groups of the wave
+#pragma unroll
+  for (int off = 32; off >= LPR; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // Workgroup = WAVES waves, wave w owns rows [16 w, 16 w + 16) of the tile and ALL n_out <= 16 NB columns.
 // D fragment: lane (i = l & 15, q = l >> 4), tile t, register r  ->  row 4 q + r, column 16 t + i.
@@ -119,7 +144,77 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
     __syncthreads();
   }
 
-  // ---- epilogue on the fragment
+  // ---- epilogue
+  const float inv_n = 1.0f / (float)n_out;
+  if (gamma != nullptr && (n_out & 3) == 0 && aligned16(gamma) && aligned16(beta) && (!a_out || aligned16(a_out)) &&
+      (!y_out || aligned16(y_out))) {
+    // LayerNorm layers: bias + activation on the fragment, then through a wave-private LDS slab into the row layout
+    constexpr int LDR = NP + 4;
+    float* slab = sh_gf + wave * 16 * LDR;  // aliases xs / ws: the K loop ended with a barrier
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int col = 16 * t + i;
+      const float bv = (col < n_out && bias) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(4 * q + r) * LDR + col] = col < n_out ? act_fwd(acc[t][r] + bv, act) : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    using RL = RowLay<NB>;
+    const int ls = l % RL::LPR, VPR = n_out >> 2;
+    f32x4 g4[RL::VPL], b4[RL::VPL];
+#pragma unroll
+    for (int j = 0; j < RL::VPL; ++j) {
+      const int sl = ls + RL::LPR * j;
+      g4[j] = sl < VPR ? *(const f32x4*)(gamma + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+      b4[j] = sl < VPR ? *(const f32x4*)(beta + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < RL::ITS; ++it) {
+      const int rl = it * RL::RPI + l / RL::LPR;
+      const long long row = m0 + 16 * wave + rl;
+      const bool rv = row < B;
+      f32x4 v[RL::VPL];
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < RL::VPL; ++j) {
+        const int sl = ls + RL::LPR * j;
+        const bool ok = sl < VPR;
+        v[j] = ok ? *(const f32x4*)(slab + rl * LDR + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sm += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        if (ok && rv && a_out) *(f32x4*)(a_out + row * n_out + 4 * sl) = v[j];
+      }
+      const float mean = sum_lanes<RL::LPR>(sm) * inv_n;
+      float v2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < RL::VPL; ++j) {
+        const bool ok = ls + RL::LPR * j < VPR;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[j][e] = ok ? v[j][e] - mean : 0.f;
+          v2 += v[j][e] * v[j][e];
+        }
+      }
+      const float rstd = 1.0f / sqrtf(sum_lanes<RL::LPR>(v2) * inv_n + 1e-5f);
+      if (rv && stats_out && ls == 0) {
+        stats_out[2 * row] = mean;
+        stats_out[2 * row + 1] = rstd;
+      }
+#pragma unroll
+      for (int j = 0; j < RL::VPL; ++j) {
+        const int sl = ls + RL::LPR * j;
+        if (sl < VPR && rv && y_out) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = v[j][e] * rstd * g4[j][e] + b4[j][e];
+          *(f32x4*)(y_out + row * n_out + 4 * sl) = o;
+        }
+      }
+    }
+    return;
+  }
+  // any other shape (heads: no LayerNorm; odd widths): on the fragment
   float bs[NB], gm[NB], bt[NB];
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
@@ -129,7 +224,6 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
     gm[t] = (cv && gamma) ? gamma[col] : 0.f;
     bt[t] = (cv && gamma) ? beta[col] : 0.f;
   }
-  const float inv_n = 1.0f / (float)n_out;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const long long row = m0 + 16 * wave + 4 * q + r;
@@ -175,63 +269,139 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ stats,
     const float* __restrict__ gamma, int act, int B, int n_out, const float* __restrict__ W, float* __restrict__ dz_out,
     float* __restrict__ dx_out, float* __restrict__ partials) {
-  constexpr int BM = 16 * WAVES, NP = 16 * NB, WLD = NP + 16, NTH = 64 * WAVES, DLD = 17;
+  constexpr int BM = 16 * WAVES, NP = 16 * NB, WLD = NP + 16, NTH = 64 * WAVES, LDR = NP + 4;
   constexpr int WU = (4 * NP + NTH - 1) / NTH;
   extern __shared__ float sh_gb[];
-  float* dzs = sh_gb;                     // [WAVES][NP][DLD]  dzs[w][c][m]   (wave-private)
-  float* ws = sh_gb + WAVES * NP * DLD;   // [2][KC][WLD]      ws[k = c][n]
+  float* dzs = sh_gb;                      // [WAVES][16][LDR]  dzs[w][m][c]   (wave-private, row-major)
+  float* ws = sh_gb + WAVES * 16 * LDR;    // [2][KC][WLD]      ws[k = c][n]
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
   const int n_in = n_out;
   const bool do_dx = W != nullptr && dx_out != nullptr;
   const bool vw = (n_in & 3) == 0 && aligned16(W);
-  float* dzw = dzs + wave * NP * DLD;
+  float* dzw = dzs + wave * 16 * LDR;
+  // LayerNorm layers of aligned width walk phase 1 in the row layout (whole coalesced rows); anything else on the fragment
+  const bool rowlay = gamma != nullptr && (n_out & 3) == 0 && aligned16(gamma) && aligned16(dy) && aligned16(a) &&
+                      (!dz_out || aligned16(dz_out));
+  using RL = RowLay<NB>;
+  const int ls = l % RL::LPR, VPR = n_out >> 2;
 
   float gm[NB], cg[NB], cb[NB], cz[NB];
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
-    gm[t] = (gamma && 16 * t + i < n_out) ? gamma[16 * t + i] : 0.f;
+    gm[t] = (!rowlay && gamma && 16 * t + i < n_out) ? gamma[16 * t + i] : 0.f;
     cg[t] = cb[t] = cz[t] = 0.f;
+  }
+  f32x4 g4[RL::VPL], cg4[RL::VPL], cb4[RL::VPL], cz4[RL::VPL];
+#pragma unroll
+  for (int j = 0; j < RL::VPL; ++j) {
+    const int sl = ls + RL::LPR * j;
+    g4[j] = (rowlay && sl < VPR) ? *(const f32x4*)(gamma + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+    cg4[j] = cb4[j] = cz4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float inv_n = 1.0f / (float)n_out;
   const long long ntiles = ((long long)B + BM - 1) / BM;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long m0 = tile * BM;
-    // ---- phase 1: dy -> dz on the fragment layout
+    // ---- phase 1: dy -> dz
+    if (rowlay) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long row = m0 + 16 * wave + 4 * q + r;
-      const bool rv = row < B;
-      float d[NB], xh[NB], av[NB];
-      float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 1.f;
-      if (gamma && rv) { mean = stats[2 * row]; rstd = stats[2 * row + 1]; }
+      for (int it0 = 0; it0 < RL::ITS; it0 += RL::UB) {
+        // all loads of UB passes first: (UB x VPL x 2) float4 in flight per lane
+        f32x4 gy[RL::UB][RL::VPL], av[RL::UB][RL::VPL];
+        float mean[RL::UB], rstd[RL::UB];
 #pragma unroll
-      for (int t = 0; t < NB; ++t) {
-        const bool ok = rv && 16 * t + i < n_out;
-        const float g = ok ? dy[row * n_out + 16 * t + i] : 0.f;
-        av[t] = (ok && a) ? a[row * n_out + 16 * t + i] : 0.f;
-        if (gamma) {
-          xh[t] = ok ? (av[t] - mean) * rstd : 0.f;
-          cg[t] += g * xh[t];
-          cb[t] += g;
-          d[t] = g * gm[t];
-          s1 += d[t];
-          s2 += d[t] * xh[t];
-        } else {
-          d[t] = g;
-          xh[t] = 0.f;
+        for (int u = 0; u < RL::UB; ++u) {
+          const int rl = (it0 + u) * RL::RPI + l / RL::LPR;
+          const long long row = m0 + 16 * wave + rl;
+          const bool rv = row < B;
+          mean[u] = rv ? stats[2 * row] : 0.f;
+          rstd[u] = rv ? stats[2 * row + 1] : 1.f;
+#pragma unroll
+          for (int j = 0; j < RL::VPL; ++j) {
+            const int sl = ls + RL::LPR * j;
+            const bool ok = rv && sl < VPR;
+            gy[u][j] = ok ? *(const f32x4*)(dy + row * n_out + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+            av[u][j] = ok ? *(const f32x4*)(a + row * n_out + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RL::UB; ++u) {
+          const int rl = (it0 + u) * RL::RPI + l / RL::LPR;
+          const long long row = m0 + 16 * wave + rl;
+          const bool rv = row < B;
+          f32x4 d[RL::VPL], xh[RL::VPL];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < RL::VPL; ++j) {
+            const bool ok = rv && ls + RL::LPR * j < VPR;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              xh[j][e] = ok ? (av[u][j][e] - mean[u]) * rstd[u] : 0.f;
+              cg4[j][e] += gy[u][j][e] * xh[j][e];
+              cb4[j][e] += gy[u][j][e];
+              d[j][e] = gy[u][j][e] * g4[j][e];
+              s1 += d[j][e];
+              s2 += d[j][e] * xh[j][e];
+            }
+          }
+          const float c1 = sum_lanes<RL::LPR>(s1) * inv_n, c2 = sum_lanes<RL::LPR>(s2) * inv_n;
+#pragma unroll
+          for (int j = 0; j < RL::VPL; ++j) {
+            const int sl = ls + RL::LPR * j;
+            const bool sv = sl < VPR;
+            const bool ok = rv && sv;
+            f32x4 da;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = (d[j][e] - c1 - xh[j][e] * c2) * rstd[u];
+              if (act != ORL_ACT_NONE) t *= act_bwd(av[u][j][e], act);
+              da[e] = ok ? t : 0.f;
+              cz4[j][e] += da[e];
+            }
+            if (ok && dz_out) *(f32x4*)(dz_out + row * n_out + 4 * sl) = da;
+            if (do_dx && sv) *(f32x4*)(dzw + rl * LDR + 4 * sl) = da;
+          }
         }
       }
-      float c1 = 0.f, c2 = 0.f;
-      if (gamma) { c1 = sum16(s1) * inv_n; c2 = sum16(s2) * inv_n; }
+      if (do_dx)  // slab columns past n_out feed the MFMA K loop: keep them zero
+        for (int e = l; e < 16 * (NP - n_out); e += 64) dzw[(e / (NP - n_out)) * LDR + n_out + e % (NP - n_out)] = 0.f;
+    } else {
 #pragma unroll
-      for (int t = 0; t < NB; ++t) {
-        const bool ok = rv && 16 * t + i < n_out;
-        float da = gamma ? (d[t] - c1 - xh[t] * c2) * rstd : d[t];
-        if (act != ORL_ACT_NONE) da *= act_bwd(av[t], act);
-        if (!ok) da = 0.f;
-        cz[t] += da;
-        if (ok && dz_out) dz_out[row * n_out + 16 * t + i] = da;
-        if (do_dx) dzw[(16 * t + i) * DLD + 4 * q + r] = da;
+      for (int r = 0; r < 4; ++r) {
+        const long long row = m0 + 16 * wave + 4 * q + r;
+        const bool rv = row < B;
+        float d[NB], xh[NB], av[NB];
+        float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 1.f;
+        if (gamma && rv) { mean = stats[2 * row]; rstd = stats[2 * row + 1]; }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const bool ok = rv && 16 * t + i < n_out;
+          const float g = ok ? dy[row * n_out + 16 * t + i] : 0.f;
+          av[t] = (ok && a) ? a[row * n_out + 16 * t + i] : 0.f;
+          if (gamma) {
+            xh[t] = ok ? (av[t] - mean) * rstd : 0.f;
+            cg[t] += g * xh[t];
+            cb[t] += g;
+            d[t] = g * gm[t];
+            s1 += d[t];
+            s2 += d[t] * xh[t];
+          } else {
+            d[t] = g;
+            xh[t] = 0.f;
+          }
+        }
+        float c1 = 0.f, c2 = 0.f;
+        if (gamma) { c1 = sum16(s1) * inv_n; c2 = sum16(s2) * inv_n; }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const bool ok = rv && 16 * t + i < n_out;
+          float da = gamma ? (d[t] - c1 - xh[t] * c2) * rstd : d[t];
+          if (act != ORL_ACT_NONE) da *= act_bwd(av[t], act);
+          if (!ok) da = 0.f;
+          cz[t] += da;
+          if (ok && dz_out) dz_out[row * n_out + 16 * t + i] = da;
+          if (do_dx) dzw[(4 * q + r) * LDR + 16 * t + i] = da;
+        }
       }
     }
     if (!do_dx) continue;
@@ -270,10 +440,10 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
     for (int c = 0; c < nch; ++c) {
       if (c + 1 < nch) load((c + 1) * GF_KC);
       const float* wb = ws + (c & 1) * GF_KC * WLD + i;
-      const float* ab = dzw + (c * GF_KC) * DLD + i;
+      const float* ab = dzw + i * LDR + c * GF_KC + q;
 #pragma unroll
       for (int kk = 0; kk < GF_KC; kk += 4) {
-        const float av = ab[(kk + q) * DLD];
+        const float av = ab[kk];
 #pragma unroll
         for (int t = 0; t < NB; ++t) acc[t] = ORL_MFMA(av, wb[(kk + q) * WLD + 16 * t], acc[t]);
       }
@@ -289,16 +459,32 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
           if (16 * t + i < n_in) dx_out[row * n_in + 16 * t + i] = acc[t][r];
     }
   }
-  // ---- column sums of this workgroup: lanes sharing i (4 q groups) -> waves -> one partial row [dg | dbeta | dbias]
+  // ---- column sums of this workgroup: within the wave, then over the waves -> one partial row [dg | dbeta | dbias]
   __syncthreads();
   float* cs = sh_gb;  // [WAVES][3 NP]
+  if (rowlay) {
 #pragma unroll
-  for (int t = 0; t < NB; ++t) {
-    const float g = row_allsum(cg[t]), b = row_allsum(cb[t]), z = row_allsum(cz[t]);
-    if (q == 0) {
-      cs[wave * 3 * NP + 16 * t + i] = g;
-      cs[wave * 3 * NP + NP + 16 * t + i] = b;
-      cs[wave * 3 * NP + 2 * NP + 16 * t + i] = z;
+    for (int j = 0; j < RL::VPL; ++j) {
+      const int sl = ls + RL::LPR * j;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = sum_groups<RL::LPR>(cg4[j][e]), b = sum_groups<RL::LPR>(cb4[j][e]), z = sum_groups<RL::LPR>(cz4[j][e]);
+        if (l < RL::LPR && sl < VPR) {
+          cs[wave * 3 * NP + 4 * sl + e] = g;
+          cs[wave * 3 * NP + NP + 4 * sl + e] = b;
+          cs[wave * 3 * NP + 2 * NP + 4 * sl + e] = z;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const float g = row_allsum(cg[t]), b = row_allsum(cb[t]), z = row_allsum(cz[t]);
+      if (q == 0) {
+        cs[wave * 3 * NP + 16 * t + i] = g;
+        cs[wave * 3 * NP + NP + 16 * t + i] = b;
+        cs[wave * 3 * NP + 2 * NP + 16 * t + i] = z;
+      }
     }
   }
   __syncthreads();
@@ -450,7 +636,9 @@ template <int NB, int WAVES>
 static int launch_fwd(const float* x, int B, int n_in, const float* W, const float* bias, int act, const float* gamma,
                       const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, hipStream_t s) {
   constexpr int BM = 16 * WAVES, NP = 16 * NB;
-  const size_t lds = (size_t)2 * GF_KC * ((BM + 16) + (NP + 16)) * sizeof(float);
+  size_t fl = (size_t)2 * GF_KC * ((BM + 16) + (NP + 16));
+  if (fl < (size_t)WAVES * 16 * (NP + 4)) fl = (size_t)WAVES * 16 * (NP + 4);
+  const size_t lds = fl * sizeof(float);
   (void)hipFuncSetAttribute((const void*)gen_layer_fwd_kernel<NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const unsigned grid = (unsigned)(((long long)B + BM - 1) / BM);
   hipLaunchKernelGGL((gen_layer_fwd_kernel<NB, WAVES>), dim3(grid), dim3(64 * WAVES), lds, s, x, B, n_in, W, bias, act, gamma,
@@ -463,12 +651,12 @@ static int launch_bwd(const float* dy, const float* a, const float* stats, const
                       const float* W, float* dz_out, float* dx_out, float* partials, int max_blocks, int* n_blocks_out,
                       hipStream_t s) {
   constexpr int BM = 16 * WAVES, NP = 16 * NB;
-  size_t fl = (size_t)WAVES * NP * 17 + (size_t)2 * GF_KC * (NP + 16);
+  size_t fl = (size_t)WAVES * 16 * (NP + 4) + (size_t)2 * GF_KC * (NP + 16);
   if (fl < (size_t)WAVES * 3 * NP) fl = (size_t)WAVES * 3 * NP;
   const size_t lds = fl * sizeof(float);
   (void)hipFuncSetAttribute((const void*)gen_layer_bwd_kernel<NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   long long grid = ((long long)B + BM - 1) / BM;
-  const int cap = max_blocks < 512 ? max_blocks : 512;  // 2 workgroups per CU
+  const int cap = max_blocks < 768 ? max_blocks : 768;  // 3 workgroups per CU
   if (grid > cap) grid = cap;
   hipLaunchKernelGGL((gen_layer_bwd_kernel<NB, WAVES>), dim3((unsigned)grid), dim3(64 * WAVES), lds, s, dy, a, stats, gamma, act,
                      B, n_out, W, dz_out, dx_out, partials);
@@ -501,11 +689,13 @@ int orl_gen_layer_fwd(const float* x, int B, int n_in, const float* W, const flo
   hipStream_t s = (hipStream_t)stream;
 #define ORL_GF_FWD(NB, WV) \
   return launch_fwd<NB, WV>(x, B, n_in, W, bias, act, gamma, beta, n_out, a_out, stats_out, y_out, s)
-  if (n_out <= 16) ORL_GF_FWD(1, 4);
-  if (n_out <= 32) ORL_GF_FWD(2, 4);
-  if (n_out <= 64) ORL_GF_FWD(4, 4);
-  if (n_out <= 128) ORL_GF_FWD(8, 4);
-  if (n_out <= 256) ORL_GF_FWD(16, 4);
+  // rollout-sized batches: 16-row workgroups so that a few thousand rows still cover the chip
+  const bool skinny = B <= 16 * 1024;
+  if (n_out <= 16) { if (skinny) ORL_GF_FWD(1, 1); ORL_GF_FWD(1, 4); }
+  if (n_out <= 32) { if (skinny) ORL_GF_FWD(2, 1); ORL_GF_FWD(2, 4); }
+  if (n_out <= 64) { if (skinny) ORL_GF_FWD(4, 1); ORL_GF_FWD(4, 4); }
+  if (n_out <= 128) { if (skinny) ORL_GF_FWD(8, 1); ORL_GF_FWD(8, 4); }
+  if (n_out <= 256) { if (skinny) ORL_GF_FWD(16, 1); ORL_GF_FWD(16, 4); }
   ORL_GF_FWD(32, 2);
 #undef ORL_GF_FWD
 }
@@ -548,7 +738,7 @@ int orl_gen_wgrad(const float* dz, const float* x, int B, int n_out, int n_in, f
   ORL_REQUIRE(dz && x && dW && partials && B > 0 && n_out > 0 && n_in > 0, "orl_gen_wgrad: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const bool big = n_out > 64 && n_in > 64;
-  const int BM = big ? 128 : 64, BN = big ? 128 : (n_in <= 16 ? 16 : 64);
+  const int BM = big ? 128 : 64, BN = big ? 128 : (n_in <= 16 ? 16 : n_in > 64 ? 128 : 64);
   const int tiles = ((n_out + BM - 1) / BM) * ((n_in + BN - 1) / BN);
   long long n_split = 512 / tiles;
   if (n_split < 1) n_split = 1;
@@ -563,6 +753,7 @@ int orl_gen_wgrad(const float* dz, const float* x, int B, int n_out, int n_in, f
   int rc;
   if (big) rc = launch_wgrad<2, 8>(dz, x, B, n_out, n_in, (int)n_split, (int)rps, partials, s);
   else if (n_in <= 16) rc = launch_wgrad<1, 1>(dz, x, B, n_out, n_in, (int)n_split, (int)rps, partials, s);
+  else if (n_in > 64) rc = launch_wgrad<1, 8>(dz, x, B, n_out, n_in, (int)n_split, (int)rps, partials, s);
   else rc = launch_wgrad<1, 4>(dz, x, B, n_out, n_in, (int)n_split, (int)rps, partials, s);
   if (rc) return rc;
   return orl_gen_colsum(partials, (int)n_split, n_out * n_in, dW, n_out * n_in, nullptr, 0, nullptr, 0, stream);

@@ -265,6 +265,8 @@ class OnPolicyDriver:
             mod.rng_step = 0  # the captured launches carry rng_step = 0 .. T-1; the device counter is the base
             mod.rng_step_dev = self._rng_ctr  # explicit argument of every act launch captured below
             self.envs.rng_step_dev = self._rng_ctr  # ... including the opponents' launches of a self-play env
+            self.envs.rng_step_host = int(saved_rng)  # the counter's value now: envs with their own step count subtract it
+            env_step0 = getattr(self.envs, "global_step", None)
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph):
@@ -275,9 +277,13 @@ class OnPolicyDriver:
                 mod.rng_step_dev = None
                 self.envs.rng_step_dev = None
                 self.agent.num_time_steps, mod.rng_step = saved_steps, saved_rng
+                if env_step0 is not None:  # capturing ran the Python side of T steps without executing them
+                    self.envs.global_step = env_step0
             self._graph = graph
         self._graph.replay()
         mod.rng_step += T
+        if getattr(self.envs, "global_step", None) is not None:
+            self.envs.global_step += T
         self.agent.num_time_steps += self.envs.parallel_env_num * T
         d = self.buffer.data
         d.step = 0

@@ -54,6 +54,7 @@ class DeviceVecEnv:
         self.total_step = 0
         self._infos = [{} for _ in range(self._n)]
         self.is_device_env = True
+        self.supports_graph_rollout = True  # stepwise mode: the step counter has a device part (orl_env_step_dev)
 
     # ---- VecEnv contract
     @property
@@ -96,8 +97,13 @@ class DeviceVecEnv:
         a = None
         if actions is not None:
             a = actions.to(self.device, torch.float32).reshape(self._n, -1).contiguous()
+        # while the driver captures a stepwise rollout into a hipGraph it hands the env the graph's device step counter
+        # (``rng_step_dev``) and that counter's value at capture (``rng_step_host``): host part + device part == the
+        # env's own step count on every replay
+        rdev = getattr(self, "rng_step_dev", None)
+        host = self.global_step - (int(getattr(self, "rng_step_host", 0)) if rdev is not None else 0)
         ops.env_step(self.env_kind, self.env_state, self.ep_stats, a, self.obs, self._rew, self._done, self._n,
-                     self._obs_dim, self.seed, self.episode_limit, self.global_step)
+                     self._obs_dim, self.seed, self.episode_limit, host, rdev)
         self.global_step += 1
         return self.obs, self._rew.view(self._n, 1, 1), self._done.view(self._n, 1)
 

@@ -309,12 +309,13 @@ def env_reset(env_kind: int, env_state, ep_stats, obs0, N: int, obs_dim: int, en
 
 
 def env_step(env_kind: int, env_state, ep_stats, actions, obs, rewards, dones, N: int, obs_dim: int, env_seed: int,
-             episode_limit: int, global_step: int) -> None:
+             episode_limit: int, global_step: int, global_step_dev=None) -> None:
+    """``global_step_dev``: optional int64 device scalar added to ``global_step`` (mod 2^64) - see ``orl_env_step_dev``."""
     dev = _dev(env_state)
     a_w = 0 if actions is None else actions.shape[-1]
-    rc = _lib().orl_env_step(env_kind, fptr(env_state), fptr(ep_stats), fptr(actions), a_w, fptr(obs), fptr(rewards),
-                             ptr(dones), N, obs_dim, env_seed & (2 ** 64 - 1), episode_limit, global_step,
-                             stream_ptr(dev))
+    rc = _lib().orl_env_step_dev(env_kind, fptr(env_state), fptr(ep_stats), fptr(actions), a_w, fptr(obs), fptr(rewards),
+                                 ptr(dones), N, obs_dim, env_seed & (2 ** 64 - 1), episode_limit,
+                                 global_step & (2 ** 64 - 1), ptr(global_step_dev), stream_ptr(dev))
     nat.check(rc, "orl_env_step")
 
 

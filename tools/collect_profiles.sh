@@ -50,6 +50,11 @@ timeout 600 python benchmarks/cfg5_ttt_bench.py --opponent pool --sampling per_r
 timeout 600 python benchmarks/shape_sweep.py > $OUT/${TAG}_shape_sweep.jsonl 2>/dev/null
 stats cfg3_shape python benchmarks/shape_sweep.py --only cfg3_halfcheetah_shape
 timeout 600 python benchmarks/host_env_bench.py > $OUT/${TAG}_host_env_line.json 2>/dev/null
+# 5b. the general tower path (non-default towers): bench lines + kernel stats at hidden 128
+(python benchmarks/generic_bench.py --steps 5 --warmup 3; python benchmarks/generic_bench.py --steps 3 --warmup 3 --layer_N 4
+ python benchmarks/generic_bench.py --steps 3 --warmup 3 --hidden_size 256; python benchmarks/generic_bench.py --steps 3 --warmup 3 --share) \
+  2>/dev/null | grep generic_tower_path > $OUT/${TAG}_generic_lines.jsonl
+stats generic_h128 python benchmarks/generic_bench.py --steps 3 --warmup 3
 # 6. the per-rank shard of the strong-scaling bench at 8 and 2 GPUs (512 / 2048 of the 4096 envs), on one GPU
 for E in 512 2048; do
   timeout 600 python bench.py --no-cpu-baseline --envs $E > $OUT/${TAG}_bench_envs${E}_line.json 2>/dev/null
