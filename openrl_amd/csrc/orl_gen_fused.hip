@@ -25,6 +25,7 @@
 namespace orl {
 
 constexpr int GF_KC = 16;
+constexpr int WG_KC = 32;  // batch rows per wgrad chunk
 
 // sum over the 16 lanes (i = lane & 15) that hold one row of an MFMA D fragment; result in all of them
 __device__ inline float sum16(float v) {
@@ -499,6 +500,170 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------ resident-W backward
+// Square layers up to 128 x 128 on training-sized batches: the workgroup (8 waves, one per CU) loads W into LDS ONCE and
+// every wave then walks its own 16-row tiles with no workgroup barrier at all - dz reaches the MFMA A operand through a
+// wave-private row-major slab, so the memory phase of one wave overlaps the MFMA loop of the other wave of its SIMD
+// (fc3 backward at hidden 128: 500 -> 265 us, the HBM time of its four 268 MB passes).  The same structure was tried for
+// the forward and lost to the streaming kernel above (304 vs 270 us: with W resident only one 8-wave workgroup fits a
+// CU and its MFMA loop is bound by the LDS operand reads, 288 B per MFMA; blocking 32 rows per wave does not fit LDS).
+// square layer (n_in == n_out <= 128) with the input gradient: W row-major in LDS for the whole launch
+template <int NB>
+__global__ __launch_bounds__(512) void gen_layer_bwd_res_kernel(
+    const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ stats,
+    const float* __restrict__ gamma, int act, int B, int n_out, const float* __restrict__ W, float* __restrict__ dz_out,
+    float* __restrict__ dx_out, float* __restrict__ partials) {
+  constexpr int NP = 16 * NB, WLD = NP + 16, SLD = NP + 4;
+  using RL = RowLay<NB>;
+  extern __shared__ float sh_br[];
+  float* ws = sh_br;                // [NP][WLD]  ws[c][n] = W[c][n]
+  float* slabs = sh_br + NP * WLD;  // [8][16][SLD]
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
+  const int VPR = n_out >> 2;
+  for (int u = tid; u < n_out * VPR; u += 512) {
+    const int c = u / VPR, n = 4 * (u % VPR);
+    *(f32x4*)(ws + c * WLD + n) = *(const f32x4*)(W + (long long)c * n_out + n);
+  }
+  __syncthreads();
+  float* slab = slabs + wave * 16 * SLD;
+  const int ls = l % RL::LPR;
+  f32x4 g4[RL::VPL], cg4[RL::VPL], cb4[RL::VPL], cz4[RL::VPL];
+#pragma unroll
+  for (int j = 0; j < RL::VPL; ++j) {
+    const int sl = ls + RL::LPR * j;
+    g4[j] = sl < VPR ? *(const f32x4*)(gamma + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+    cg4[j] = cb4[j] = cz4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_n = 1.0f / (float)n_out;
+  const long long ntiles = ((long long)B + 15) / 16, stride = (long long)gridDim.x * 8;
+  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles; tile += stride) {
+    const long long m0 = tile * 16;
+    // ---- phase 1 (row layout): dy -> dz, to HBM and into the slab
+#pragma unroll
+    for (int it0 = 0; it0 < RL::ITS; it0 += RL::UB) {
+      f32x4 gy[RL::UB][RL::VPL], av[RL::UB][RL::VPL];
+      float mean[RL::UB], rstd[RL::UB];
+#pragma unroll
+      for (int u = 0; u < RL::UB; ++u) {
+        const int rl = (it0 + u) * RL::RPI + l / RL::LPR;
+        const long long row = m0 + rl;
+        const bool rv = row < B;
+        mean[u] = rv ? stats[2 * row] : 0.f;
+        rstd[u] = rv ? stats[2 * row + 1] : 1.f;
+#pragma unroll
+        for (int j = 0; j < RL::VPL; ++j) {
+          const int sl = ls + RL::LPR * j;
+          const bool ok = rv && sl < VPR;
+          gy[u][j] = ok ? *(const f32x4*)(dy + row * n_out + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+          av[u][j] = ok ? *(const f32x4*)(a + row * n_out + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < RL::UB; ++u) {
+        const int rl = (it0 + u) * RL::RPI + l / RL::LPR;
+        const long long row = m0 + rl;
+        const bool rv = row < B;
+        f32x4 d[RL::VPL], xh[RL::VPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < RL::VPL; ++j) {
+          const bool ok = rv && ls + RL::LPR * j < VPR;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xh[j][e] = ok ? (av[u][j][e] - mean[u]) * rstd[u] : 0.f;
+            cg4[j][e] += gy[u][j][e] * xh[j][e];
+            cb4[j][e] += gy[u][j][e];
+            d[j][e] = gy[u][j][e] * g4[j][e];
+            s1 += d[j][e];
+            s2 += d[j][e] * xh[j][e];
+          }
+        }
+        const float c1 = sum_lanes<RL::LPR>(s1) * inv_n, c2 = sum_lanes<RL::LPR>(s2) * inv_n;
+#pragma unroll
+        for (int j = 0; j < RL::VPL; ++j) {
+          const int sl = ls + RL::LPR * j;
+          const bool sv = sl < VPR;
+          const bool ok = rv && sv;
+          f32x4 da;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = (d[j][e] - c1 - xh[j][e] * c2) * rstd[u];
+            if (act != ORL_ACT_NONE) t *= act_bwd(av[u][j][e], act);
+            da[e] = ok ? t : 0.f;
+            cz4[j][e] += da[e];
+          }
+          if (ok && dz_out) *(f32x4*)(dz_out + row * n_out + 4 * sl) = da;
+          if (sv) *(f32x4*)(slab + rl * SLD + 4 * sl) = da;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- phase 2: dx = dz W on MFMA, no workgroup barrier
+    f32x4 acc[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ab = slab + i * SLD + q;
+    const float* wb = ws + q * WLD + i;
+#pragma unroll 4
+    for (int c0 = 0; c0 < n_out; c0 += 4) {
+      const float av = ab[c0];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) acc[t] = ORL_MFMA(av, wb[c0 * WLD + 16 * t], acc[t]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(4 * q + r) * SLD + 16 * t + i] = acc[t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < RL::ITS; ++it) {
+      const int rl = it * RL::RPI + l / RL::LPR;
+      const long long row = m0 + rl;
+#pragma unroll
+      for (int j = 0; j < RL::VPL; ++j) {
+        const int sl = ls + RL::LPR * j;
+        if (row < B && sl < VPR) *(f32x4*)(dx_out + row * n_out + 4 * sl) = *(const f32x4*)(slab + rl * SLD + 4 * sl);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // ---- column sums -> one partial row [dg | dbeta | dbias] per workgroup
+  __syncthreads();
+  float* cs = slabs;  // [8][3 NP]
+#pragma unroll
+  for (int j = 0; j < RL::VPL; ++j) {
+    const int sl = ls + RL::LPR * j;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = sum_groups<RL::LPR>(cg4[j][e]), b = sum_groups<RL::LPR>(cb4[j][e]), z = sum_groups<RL::LPR>(cz4[j][e]);
+      if (l < RL::LPR && sl < VPR) {
+        cs[wave * 3 * NP + 4 * sl + e] = g;
+        cs[wave * 3 * NP + NP + 4 * sl + e] = b;
+        cs[wave * 3 * NP + 2 * NP + 4 * sl + e] = z;
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * NP; e += 512) {
+    const int k = e / NP, col = e % NP;
+    if (col < n_out) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += cs[w * 3 * NP + e];
+      partials[(size_t)blockIdx.x * 3 * n_out + (size_t)k * n_out + col] = s;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ wgrad
 // partials[z][m][n] = sum over the rows k of split z of dz[k][m0 + m] * x[k][n0 + n];  block = (64 MT) x (16 NT).
 template <int MT, int NT>
@@ -506,10 +671,11 @@ __global__ __launch_bounds__(256) void gen_wgrad_kernel(const float* __restrict_
                                                         int n_out, int n_in, int rows_per_split,
                                                         float* __restrict__ partials) {
   constexpr int BM = 64 * MT, BN = 16 * NT, ALD = BM + 16, BLD = BN + 16;
-  constexpr int AU = (4 * BM + 255) / 256, BU = (4 * BN + 255) / 256;
+  constexpr int AUN = WG_KC * BM / 4, BUN = WG_KC * BN / 4;  // float4 units of one chunk
+  constexpr int AU = (AUN + 255) / 256, BU = (BUN + 255) / 256;
   extern __shared__ float sh_gw[];
   float* As = sh_gw;                     // [2][KC][ALD]  As[k][m]
-  float* Bs = sh_gw + 2 * GF_KC * ALD;   // [2][KC][BLD]  Bs[k][n]
+  float* Bs = sh_gw + 2 * WG_KC * ALD;   // [2][KC][BLD]  Bs[k][n]
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const long long kb = (long long)blockIdx.z * rows_per_split;
@@ -521,7 +687,7 @@ __global__ __launch_bounds__(256) void gen_wgrad_kernel(const float* __restrict_
     for (int u0 = 0; u0 < AU; ++u0) {
       const int u = tid + 256 * u0, k = u / (BM / 4), m = m0 + 4 * (u % (BM / 4));
       ra[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < 4 * BM && k0 + k < ke && m < n_out) {
+      if (u < AUN && k0 + k < ke && m < n_out) {
         const float* p = dz + (k0 + k) * n_out + m;
         if (va) ra[u0] = *(const f32x4*)p;
         else
@@ -533,7 +699,7 @@ __global__ __launch_bounds__(256) void gen_wgrad_kernel(const float* __restrict_
     for (int u0 = 0; u0 < BU; ++u0) {
       const int u = tid + 256 * u0, k = u / (BN / 4), n = n0 + 4 * (u % (BN / 4));
       rb[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < 4 * BN && k0 + k < ke && n < n_in) {
+      if (u < BUN && k0 + k < ke && n < n_in) {
         const float* p = x + (k0 + k) * n_in + n;
         if (vb) rb[u0] = *(const f32x4*)p;
         else
@@ -543,17 +709,17 @@ __global__ __launch_bounds__(256) void gen_wgrad_kernel(const float* __restrict_
     }
   };
   auto stash = [&](int buf) {
-    float* ab = As + buf * GF_KC * ALD;
-    float* bb = Bs + buf * GF_KC * BLD;
+    float* ab = As + buf * WG_KC * ALD;
+    float* bb = Bs + buf * WG_KC * BLD;
 #pragma unroll
     for (int u0 = 0; u0 < AU; ++u0) {
       const int u = tid + 256 * u0;
-      if (u < 4 * BM) *(f32x4*)(ab + (u / (BM / 4)) * ALD + 4 * (u % (BM / 4))) = ra[u0];
+      if (u < AUN) *(f32x4*)(ab + (u / (BM / 4)) * ALD + 4 * (u % (BM / 4))) = ra[u0];
     }
 #pragma unroll
     for (int u0 = 0; u0 < BU; ++u0) {
       const int u = tid + 256 * u0;
-      if (u < 4 * BN) *(f32x4*)(bb + (u / (BN / 4)) * BLD + 4 * (u % (BN / 4))) = rb[u0];
+      if (u < BUN) *(f32x4*)(bb + (u / (BN / 4)) * BLD + 4 * (u % (BN / 4))) = rb[u0];
     }
   };
   f32x4 acc[MT][NT];
@@ -561,18 +727,18 @@ __global__ __launch_bounds__(256) void gen_wgrad_kernel(const float* __restrict_
   for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const long long nch = (ke - kb + GF_KC - 1) / GF_KC;
+  const long long nch = (ke - kb + WG_KC - 1) / WG_KC;
   if (nch > 0) {
     load(kb);
     stash(0);
   }
   __syncthreads();
   for (long long c = 0; c < nch; ++c) {
-    if (c + 1 < nch) load(kb + (c + 1) * GF_KC);
-    const float* ab = As + (c & 1) * GF_KC * ALD + 16 * MT * wave + i;
-    const float* bb = Bs + (c & 1) * GF_KC * BLD + i;
+    if (c + 1 < nch) load(kb + (c + 1) * WG_KC);
+    const float* ab = As + (c & 1) * WG_KC * ALD + 16 * MT * wave + i;
+    const float* bb = Bs + (c & 1) * WG_KC * BLD + i;
 #pragma unroll
-    for (int kk = 0; kk < GF_KC; kk += 4) {
+    for (int kk = 0; kk < WG_KC; kk += 4) {
       float av[MT];
 #pragma unroll
       for (int a = 0; a < MT; ++a) av[a] = ab[(kk + q) * ALD + 16 * a];
@@ -664,11 +830,30 @@ static int launch_bwd(const float* dy, const float* a, const float* stats, const
   return launch_status("orl_gen_layer_bwd");
 }
 
+template <int NB>
+static int launch_bwd_res(const float* dy, const float* a, const float* stats, const float* gamma, int act, int B, int n_out,
+                          const float* W, float* dz_out, float* dx_out, float* partials, int max_blocks, int* n_blocks_out,
+                          hipStream_t s) {
+  constexpr int NP = 16 * NB;
+  const size_t lds = ((size_t)NP * (NP + 16) + (size_t)8 * 16 * (NP + 4)) * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)gen_layer_bwd_res_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  long long grid = (((long long)B + 15) / 16 + 7) / 8;
+  const int cap = max_blocks < 256 ? max_blocks : 256;
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL((gen_layer_bwd_res_kernel<NB>), dim3((unsigned)grid), dim3(512), lds, s, dy, a, stats, gamma, act, B,
+                     n_out, W, dz_out, dx_out, partials);
+  *n_blocks_out = (int)grid;
+  return launch_status("orl_gen_layer_bwd");
+}
+
+static inline bool al16(const void* p) { return p == nullptr || (((unsigned long long)p) & 15ull) == 0; }
+
 template <int MT, int NT>
 static int launch_wgrad(const float* dz, const float* x, int B, int n_out, int n_in, int n_split, int rows_per_split,
                         float* partials, hipStream_t s) {
   constexpr int BM = 64 * MT, BN = 16 * NT;
-  const size_t lds = (size_t)2 * GF_KC * ((BM + 16) + (BN + 16)) * sizeof(float);
+  const size_t lds = (size_t)2 * WG_KC * ((BM + 16) + (BN + 16)) * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)gen_wgrad_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const dim3 grid((n_in + BN - 1) / BN, (n_out + BM - 1) / BM, n_split);
   hipLaunchKernelGGL((gen_wgrad_kernel<MT, NT>), grid, dim3(256), lds, s, dz, x, B, n_out, n_in, rows_per_split, partials);
   return launch_status("orl_gen_wgrad");
@@ -711,6 +896,12 @@ int orl_gen_layer_bwd(const float* dy, const float* a, const float* stats, const
               n_in, n_out);
   hipStream_t s = (hipStream_t)stream;
   const float* Wd = dx_out ? W : nullptr;
+  if (dx_out && B > 16 * 1024 && gamma && n_out > 16 && n_out <= 128 && (n_out & 3) == 0 && al16(dy) && al16(a) && al16(W) &&
+      al16(gamma) && al16(dz_out) && al16(dx_out)) {
+    if (n_out <= 32) return launch_bwd_res<2>(dy, a, stats, gamma, act, B, n_out, W, dz_out, dx_out, col_partials, max_blocks, n_blocks_out, s);
+    if (n_out <= 64) return launch_bwd_res<4>(dy, a, stats, gamma, act, B, n_out, W, dz_out, dx_out, col_partials, max_blocks, n_blocks_out, s);
+    return launch_bwd_res<8>(dy, a, stats, gamma, act, B, n_out, W, dz_out, dx_out, col_partials, max_blocks, n_blocks_out, s);
+  }
 #define ORL_GF_BWD(NB, WV) \
   return launch_bwd<NB, WV>(dy, a, stats, gamma, act, B, n_out, Wd, dz_out, dx_out, col_partials, max_blocks, n_blocks_out, s)
   if (n_out <= 16) ORL_GF_BWD(1, 4);
@@ -748,7 +939,7 @@ int orl_gen_wgrad(const float* dz, const float* x, int B, int n_out, int n_in, f
   ORL_REQUIRE(by_mem >= 1, "orl_gen_wgrad: the partials buffer (%lld floats) does not hold one %d x %d block",
               (long long)partials_floats, n_out, n_in);
   if (n_split > by_mem) n_split = by_mem;
-  long long rps = (((long long)B + n_split - 1) / n_split + GF_KC - 1) / GF_KC * GF_KC;
+  long long rps = (((long long)B + n_split - 1) / n_split + WG_KC - 1) / WG_KC * WG_KC;
   n_split = ((long long)B + rps - 1) / rps;
   int rc;
   if (big) rc = launch_wgrad<2, 8>(dz, x, B, n_out, n_in, (int)n_split, (int)rps, partials, s);
