@@ -58,7 +58,7 @@ typedef struct orl_net_desc {
 /* ABI guard for bindings: sizeof() of the structs of this header AS THE LIBRARY WAS BUILT, so that a stale shared
  * object with the same symbol names but another struct layout is refused at load time instead of corrupting device
  * memory.  which: 0 orl_net_desc, 1 orl_pack_src, 2 orl_buffer_ptrs, 3 orl_copy_desc, 4 orl_gather_desc,
- * 5 orl_ppo_hparams, 6 orl_adam_state, 7 orl_rollout_args, 8 orl_rnn_batch, 9 orl_rnn_rollout_args; anything else
+ * 5 orl_ppo_hparams, 6 orl_adam_state, 7 orl_rollout_args, 8 orl_rnn_batch, 9 orl_rnn_rollout_args, 10 orl_gen_mlp_desc; anything else
  * returns ORL_E_INVALID. */
 int orl_abi_struct_size(int which);
 
@@ -621,6 +621,25 @@ int orl_row_bwd(const float* dy, const float* gamma, const float* xhat, const fl
  * gamma / beta (action / value heads) y = act(x W^T + b) and stats_out is not written. */
 int orl_gen_layer_fwd(const float* x, int B, int n_in, const float* W, const float* bias, int act, const float* gamma,
                       const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, void* stream);
+/* The whole tower of a rollout step in ONE launch (no activations stored): optional feature LayerNorm over the
+ * observation, n_layers x nn.Sequential(Linear, act, LayerNorm) with n_in(k) == n_out(k-1), widths multiples of 4 and
+ * <= 256, then n_heads (1 or 2) plain Linear heads on the trunk's features: entries layer[n_layers ..].  head_out0 /
+ * head_out1 are [B, n_out of that head].  All pointers are device pointers (typically into one flat parameter vector). */
+#define ORL_GEN_MLP_MAX_LAYERS 14
+typedef struct orl_gen_mlp_layer {
+  const float* W;      /* [n_out, n_in] */
+  const float* bias;   /* [n_out] or NULL */
+  const float* gamma;  /* LayerNorm weight [n_out]; NULL for a head */
+  const float* beta;
+  int32_t n_in, n_out, act, reserved;
+} orl_gen_mlp_layer;
+typedef struct orl_gen_mlp_desc {
+  int32_t n_layers, n_heads;
+  const float* fn_gamma; /* MLPBase.feature_norm over the n_in(0) observation columns, or NULL */
+  const float* fn_beta;
+  orl_gen_mlp_layer layer[ORL_GEN_MLP_MAX_LAYERS];
+} orl_gen_mlp_desc;
+int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* head_out0, float* head_out1, void* stream);
 /* Its backward in one launch: dy [B, n_out] -> dz_out [B, n_out] (gradient at the Linear's output; may be NULL),
  * col_partials[n_blocks][3 n_out] = [d gamma | d beta | d bias] per workgroup (sum them with orl_gen_colsum), and - for a
  * square layer, when dx_out != NULL - the input gradient dx_out [B, n_in] = dz W of the same row tile without re-reading

@@ -103,12 +103,25 @@ class HeadDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n_out", C.c_int32), ("n_heads", C.c_int32), ("nvec", C.c_int32 * 8)]
 
 
+ORL_GEN_MLP_MAX_LAYERS = 14
+
+
+class GenMlpLayer(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("n_in", C.c_int32), ("n_out", C.c_int32), ("act", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GenMlpDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("n_heads", C.c_int32), ("fn_gamma", C.c_void_p), ("fn_beta", C.c_void_p),
+                ("layer", GenMlpLayer * ORL_GEN_MLP_MAX_LAYERS)]
+
+
 ORL_ACT_NONE, ORL_ACT_TANH, ORL_ACT_RELU, ORL_ACT_LEAKY_RELU, ORL_ACT_ELU = -1, 0, 1, 2, 3
 ORL_HEAD_MULTI_DISCRETE = 3
 
 # order of orl_abi_struct_size(which)
 _ABI_STRUCTS = (NetDesc, PackSrc, BufferPtrs, CopyDesc, GatherDesc, PPOHParams, AdamState, RolloutArgs, RnnBatch,
-                RnnRolloutArgs)
+                RnnRolloutArgs, GenMlpDesc)
 
 # name -> (restype, argtypes); must list EVERY symbol of include/orl_hip.h (tests check this)
 _P = C.c_void_p
@@ -170,6 +183,7 @@ _SIGNATURES = {
     "orl_row_fwd": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "orl_row_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int), _P]),
     "orl_gen_layer_fwd": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "orl_gen_mlp_fwd": (C.c_int, [C.POINTER(GenMlpDesc), _P, C.c_int, _P, _P, _P]),
     "orl_gen_layer_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int,
                                     C.POINTER(C.c_int), _P]),
     "orl_gen_wgrad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),

@@ -664,6 +664,164 @@ __global__ __launch_bounds__(512) void gen_layer_bwd_res_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------ whole-MLP inference
+// Rollout side: the entire tower (optional feature LayerNorm, every MLPLayer, up to two heads) in ONE launch.  A 4-wave
+// workgroup owns 16 rows whose activations never leave an LDS slab; wave w computes the output tiles [w NBW, (w+1) NBW)
+// of every layer.  The B operand (weights) comes straight from L2 as one float4 per lane and 16-k block - lane (i, q)
+// reads W[16 t + i][k0 + 4 q .. + 3], i.e. the MFMA of sub-step s multiplies k = k0 + 4 q + s, and the A operand is read
+// from the slab with the same k permutation (a dot product does not care) - and ALL of a layer's weight loads (up to
+// 128 k) are issued at once, the next layer's right after this layer's MFMA loop, so the L2 latency hides behind the
+// bias / activation / LayerNorm phase: a rollout step is a latency chain, not a throughput problem.
+struct MlpArgs {
+  orl_gen_mlp_desc d;
+  const float* x;
+  int B;
+  float* head_out[2];
+};
+
+constexpr int MLP_KPRE = 8;  // 16-k blocks whose weights are in flight together
+
+template <int NBW>
+__global__ __launch_bounds__(256) void gen_mlp_fwd_kernel(MlpArgs A, int SLD) {
+  extern __shared__ float slab[];  // [16][SLD]
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
+  const long long m0 = (long long)blockIdx.x * 16;
+  const int B = A.B;
+  const int n_total = A.d.n_layers + A.d.n_heads;
+  f32x4 wr[MLP_KPRE][NBW];
+  // weights of entry L, k blocks [kb0, kb0 + MLP_KPRE), this wave's tiles
+  auto loadw = [&](int L, int kb0) {
+    const orl_gen_mlp_layer& ly = A.d.layer[L];
+    const int n_in = ly.n_in, n_out = ly.n_out;
+    const bool vec = (n_in & 3) == 0 && aligned16(ly.W);
+#pragma unroll
+    for (int kb = 0; kb < MLP_KPRE; ++kb)
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        wr[kb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int n = 16 * (wave * NBW + j) + i, k = 16 * (kb0 + kb) + 4 * q;
+        if (n < n_out && k < n_in) {
+          const float* p = ly.W + (long long)n * n_in + k;
+          if (vec) wr[kb][j] = *(const f32x4*)p;
+          else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (k + e < n_in) wr[kb][j][e] = p[e];
+        }
+      }
+  };
+  loadw(0, 0);
+  // ---- input rows (+ MLPBase.feature_norm) into the slab, zero-padded to a multiple of 16 columns
+  {
+    const int D = A.d.layer[0].n_in, DP = (D + 15) & ~15;
+    for (int e = tid; e < 16 * DP; e += 256) {
+      const int r = e / DP, c = e % DP;
+      slab[r * SLD + c] = (c < D && m0 + r < B) ? A.x[(m0 + r) * D + c] : 0.f;
+    }
+    __syncthreads();
+    if (A.d.fn_gamma != nullptr) {
+      if (tid < 16) {  // one lane per row: D is an observation width
+        float s = 0.f;
+        for (int c = 0; c < D; ++c) s += slab[tid * SLD + c];
+        const float mean = s / (float)D;
+        float v2 = 0.f;
+        for (int c = 0; c < D; ++c) { const float t = slab[tid * SLD + c] - mean; v2 += t * t; }
+        const float rstd = 1.0f / sqrtf(v2 / (float)D + 1e-5f);
+        for (int c = 0; c < D; ++c) slab[tid * SLD + c] = (slab[tid * SLD + c] - mean) * rstd * A.d.fn_gamma[c] + A.d.fn_beta[c];
+      }
+      __syncthreads();
+    }
+  }
+  for (int L = 0; L < n_total; ++L) {
+    const orl_gen_mlp_layer& ly = A.d.layer[L];
+    const bool is_head = L >= A.d.n_layers;
+    const int n_in = ly.n_in, n_out = ly.n_out;
+    f32x4 acc[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = (n_in + 15) >> 4;
+    for (int kb0 = 0; kb0 < nkb; kb0 += MLP_KPRE) {
+      if (kb0 > 0) loadw(L, kb0);
+#pragma unroll
+      for (int kb = 0; kb < MLP_KPRE; ++kb) {
+        if (kb0 + kb < nkb) {
+          const f32x4 a4 = *(const f32x4*)(slab + i * SLD + 16 * (kb0 + kb) + 4 * q);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) acc[j] = ORL_MFMA(a4[s], wr[kb][j][s], acc[j]);
+        }
+      }
+    }
+    if (L + 1 < n_total) loadw(L + 1, 0);  // in flight during this layer's epilogue
+    if (is_head) {  // heads read the trunk's features and leave the slab alone (a second head reads them again)
+      float* out = A.head_out[L - A.d.n_layers];
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        const int col = 16 * (wave * NBW + j) + i;
+        if (col < n_out) {
+          const float bv = ly.bias ? ly.bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (m0 + 4 * q + r < B) out[(m0 + 4 * q + r) * n_out + col] = acc[j][r] + bv;
+        }
+      }
+      continue;
+    }
+    __syncthreads();  // every wave is done reading this layer's input
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      const int col = 16 * (wave * NBW + j) + i;
+      if (col < ((n_out + 15) & ~15)) {
+        const float bv = (col < n_out && ly.bias) ? ly.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(4 * q + r) * SLD + col] = col < n_out ? act_fwd(acc[j][r] + bv, ly.act) : 0.f;
+      }
+    }
+    __syncthreads();
+    // LayerNorm in place: wave w takes rows 4 w .. 4 w + 3, 16 lanes x float4 slots per row (n_out % 4 == 0)
+    {
+      const int rl = 4 * wave + q, VPR = n_out >> 2;
+      const float inv_n = 1.0f / (float)n_out;
+      const bool gal = aligned16(ly.gamma) && aligned16(ly.beta);
+      f32x4 v[NBW];
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        const int sl = i + 16 * j;
+        v[j] = sl < VPR ? *(const f32x4*)(slab + rl * SLD + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sm += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+      }
+      const float mean = sum16(sm) * inv_n;
+      float v2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        const bool ok = i + 16 * j < VPR;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[j][e] = ok ? v[j][e] - mean : 0.f;
+          v2 += v[j][e] * v[j][e];
+        }
+      }
+      const float rstd = 1.0f / sqrtf(sum16(v2) * inv_n + 1e-5f);
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        const int sl = i + 16 * j;
+        if (sl < VPR) {
+          f32x4 g, b, o;
+          if (gal) { g = *(const f32x4*)(ly.gamma + 4 * sl); b = *(const f32x4*)(ly.beta + 4 * sl); }
+          else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g[e] = ly.gamma[4 * sl + e]; b[e] = ly.beta[4 * sl + e]; }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = v[j][e] * rstd * g[e] + b[e];
+          *(f32x4*)(slab + rl * SLD + 4 * sl) = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ wgrad
 // partials[z][m][n] = sum over the rows k of split z of dz[k][m0 + m] * x[k][n0 + n];  block = (64 MT) x (16 NT).
 template <int MT, int NT>
@@ -922,6 +1080,54 @@ int orl_gen_colsum(const float* partials, int n_rows, int width, float* dst0, in
   d.w[0] = w0; d.w[1] = w1; d.w[2] = w2;
   hipLaunchKernelGGL(gen_colsum_kernel, dim3((width + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partials, n_rows, width, d);
   return launch_status("orl_gen_colsum");
+}
+
+int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* head_out0, float* head_out1, void* stream) {
+  ORL_REQUIRE(desc && x && B > 0, "orl_gen_mlp_fwd: bad arguments");
+  ORL_REQUIRE(desc->n_layers >= 1 && desc->n_heads >= 1 && desc->n_heads <= 2 &&
+                  desc->n_layers + desc->n_heads <= ORL_GEN_MLP_MAX_LAYERS,
+              "orl_gen_mlp_fwd: %d layers + %d heads (at most %d entries, 1-2 heads)", desc->n_layers, desc->n_heads,
+              ORL_GEN_MLP_MAX_LAYERS);
+  ORL_REQUIRE(head_out0 && (desc->n_heads == 1 || head_out1), "orl_gen_mlp_fwd: a head has no output buffer");
+  ORL_REQUIRE((desc->fn_gamma == nullptr) == (desc->fn_beta == nullptr), "orl_gen_mlp_fwd: fn_gamma and fn_beta come together");
+  int wmax = 0, width = (desc->layer[0].n_in + 15) & ~15;
+  for (int L = 0; L < desc->n_layers + desc->n_heads; ++L) {
+    const orl_gen_mlp_layer& ly = desc->layer[L];
+    const bool head = L >= desc->n_layers;
+    ORL_REQUIRE(ly.W && ly.n_in > 0 && ly.n_out > 0 && ly.n_out <= 256, "orl_gen_mlp_fwd: entry %d: n_in %d, n_out %d (<= 256)", L,
+                ly.n_in, ly.n_out);
+    ORL_REQUIRE(ly.act >= ORL_ACT_NONE && ly.act <= ORL_ACT_ELU, "orl_gen_mlp_fwd: entry %d: activation id %d", L, ly.act);
+    if (!head) {
+      ORL_REQUIRE(ly.gamma && ly.beta && (ly.n_out & 3) == 0, "orl_gen_mlp_fwd: layer %d needs LayerNorm parameters and a width that is a multiple of 4", L);
+      ORL_REQUIRE(L == 0 || ly.n_in == desc->layer[L - 1].n_out, "orl_gen_mlp_fwd: layer %d reads %d columns, layer %d writes %d", L, ly.n_in, L - 1, desc->layer[L - 1].n_out);
+    } else {
+      ORL_REQUIRE(ly.n_in == desc->layer[desc->n_layers - 1].n_out && ly.act == ORL_ACT_NONE && !ly.gamma,
+                  "orl_gen_mlp_fwd: head %d must be a plain Linear on the trunk's %d features", L - desc->n_layers,
+                  desc->layer[desc->n_layers - 1].n_out);
+    }
+    if (ly.n_out > wmax) wmax = ly.n_out;
+    const int w16 = (ly.n_out + 15) & ~15;
+    if (w16 > width) width = w16;
+  }
+  ORL_REQUIRE(width <= 1024, "orl_gen_mlp_fwd: %d columns do not fit the wave's LDS slab", width);
+  MlpArgs A;
+  A.d = *desc; A.x = x; A.B = B; A.head_out[0] = head_out0; A.head_out[1] = head_out1;
+  // NBW output tiles per wave, 4 waves: widths up to 64 NBW; a row's float4 slots are 16 NBW
+  const int NBW = wmax <= 64 ? 1 : wmax <= 128 ? 2 : 4;
+  if (width < 64 * NBW) width = 64 * NBW;
+  const int SLD = width + 4;
+  const size_t lds = (size_t)16 * SLD * sizeof(float);
+  const unsigned grid = (unsigned)(((long long)B + 15) / 16);
+#define ORL_MLP_LAUNCH(NBX)                                                                                          \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)gen_mlp_fwd_kernel<NBX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((gen_mlp_fwd_kernel<NBX>), dim3(grid), dim3(256), lds, (hipStream_t)stream, A, SLD);          \
+  } while (0)
+  if (NBW == 1) ORL_MLP_LAUNCH(1);
+  else if (NBW == 2) ORL_MLP_LAUNCH(2);
+  else ORL_MLP_LAUNCH(4);
+#undef ORL_MLP_LAUNCH
+  return launch_status("orl_gen_mlp_fwd");
 }
 
 int orl_gen_wgrad(const float* dz, const float* x, int B, int n_out, int n_in, float* dW, float* partials,

@@ -137,6 +137,36 @@ class GenNet:
         self.layers.append(fc3)
         self.ctor.append(("layer", fc3))
 
+    def mlp_desc(self, head_names):
+        """``orl_gen_mlp_desc`` of this network with the given heads (rollout side: the whole tower in one launch), or
+        None when a width is outside what ``orl_gen_mlp_fwd`` takes.  Cached per parameter vector."""
+        key = (self.theta.data_ptr(), tuple(head_names))
+        hit = getattr(self, "_mlp_desc", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        from .. import _native as nat
+
+        ok = (len(self.layers) + len(head_names) <= nat.ORL_GEN_MLP_MAX_LAYERS and 1 <= len(head_names) <= 2
+              and all(L["n_out"] <= 256 and L["n_out"] % 4 == 0 for L in self.layers)
+              and all(self.heads[h]["n"] <= 256 for h in head_names) and self.D <= 1024)
+        d = None
+        if ok:
+            base = self.theta.data_ptr()
+            at = lambda off: base + 4 * off
+            d = nat.GenMlpDesc()
+            d.n_layers, d.n_heads = len(self.layers), len(head_names)
+            if self.fn is not None:
+                d.fn_gamma, d.fn_beta = at(self.fn["g"]), at(self.fn["be"])
+            for k, L in enumerate(self.layers):
+                e = d.layer[k]
+                e.W, e.bias, e.gamma, e.beta = at(L["W"]), at(L["b"]), at(L["g"]), at(L["be"])
+                e.n_in, e.n_out, e.act = L["n_in"], L["n_out"], L["act"]
+            for k, name in enumerate(head_names):
+                h, e = self.heads[name], d.layer[len(self.layers) + k]
+                e.W, e.bias, e.n_in, e.n_out, e.act = at(h["W"]), at(h["b"]), self.H, h["n"], ops_gen.ACT_NONE
+        self._mlp_desc = (key, d)
+        return d
+
     def v(self, off: int, *shape, grad: bool = False) -> torch.Tensor:
         t = self.grad if grad else self.theta
         return t[off:off + int(np.prod(shape))].view(*shape)
@@ -458,23 +488,40 @@ class GenericPPOModule(PPOModule):
         else:
             values, actions, logp = out
         feats_p = None
+        shared_once = self.share_model and want_action and want_value and xc.data_ptr() == x.data_ptr()
         if want_action:
             ws = self.workspace(pn, B, False, "p")
-            feats_p = trunk_forward(pn, ws, x, False)
-            logits = head_forward(pn, ws, "act", feats_p)
+            logits = ws.v(ws.head_out["act"], B, pn.heads["act"]["n"])
+            desc = pn.mlp_desc(("act", "v_out") if shared_once else ("act",))
+            if desc is not None:  # the whole tower (+ the value head of a shared network) in one launch
+                vdst = None
+                if shared_once:
+                    vdst = values if values.is_contiguous() else ws.v(ws.head_out["v_out"], B, 1)
+                ops_gen.mlp_fwd(desc, x, logits, vdst)
+                if shared_once and vdst is not values:
+                    values.copy_(vdst)
+            else:
+                feats_p = trunk_forward(pn, ws, x, False)
+                logits = head_forward(pn, ws, "act", feats_p)
             am = self._dev(action_masks, self.n_logits) if (action_masks is not None and self.K) else None
             ops_gen.sample(pn.head_desc, logits, self._logstd(), am, B, deterministic, self.act_seed, 0, self.rng_step,
                            self.rng_step_dev, self._dev(forced_u, self.act_width), self.act_width, actions, logp)
             if not deterministic:
                 self.rng_step += 1
-        if want_value:
-            if self.share_model and want_action and xc.data_ptr() == x.data_ptr():
+        if want_value and not (shared_once and feats_p is None):
+            if shared_once:
                 ws, feats_c = self.workspace(pn, B, False, "p"), feats_p
+                v = head_forward(cn, ws, "v_out", feats_c)
             else:
                 ws = self.workspace(cn, B, False, "c")
-                feats_c = trunk_forward(cn, ws, xc, False)
-            v = head_forward(cn, ws, "v_out", feats_c)
-            values.copy_(v)
+                desc = cn.mlp_desc(("v_out",))
+                if desc is not None:
+                    v = values if values.is_contiguous() else ws.v(ws.head_out["v_out"], B, 1)
+                    ops_gen.mlp_fwd(desc, xc, v)
+                else:
+                    v = head_forward(cn, ws, "v_out", trunk_forward(cn, ws, xc, False))
+            if v is not values:
+                values.copy_(v)
         return values, actions, logp
 
     def get_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks=None,

@@ -96,6 +96,14 @@ def layer_fwd(x, W, bias, act: int, gamma, beta, a_out, stats_out, y_out) -> Non
     nat.check(rc, "orl_gen_layer_fwd")
 
 
+def mlp_fwd(desc, x, head_out0, head_out1=None) -> None:
+    """The whole tower of a rollout step in one launch (``orl_gen_mlp_fwd``); ``desc``: ``_native.GenMlpDesc``."""
+    dev = nat.require_gpu(x.device)
+    assert x.is_contiguous() and x.shape[1] == desc.layer[0].n_in
+    rc = _lib().orl_gen_mlp_fwd(C.byref(desc), fptr(x), x.shape[0], fptr(head_out0), fptr(head_out1), stream_ptr(dev))
+    nat.check(rc, "orl_gen_mlp_fwd")
+
+
 def layer_bwd(dy, a, stats, gamma, act: int, W, dz_out, dx_out, col_partials) -> int:
     """dy -> dz (+ dx = dz @ W for a square layer when ``dx_out`` is given) and the [d gamma | d beta | d bias] partial
     rows; returns their count."""

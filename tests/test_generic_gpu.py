@@ -252,6 +252,37 @@ def test_fused_layer_kernels_against_torch_fp64(B, n_in, n_out, act, ln):
         assert torch.equal(dW, dW2)
 
 
+@pytest.mark.parametrize("argv,D,B", [(["--hidden_size", "128"], 4, 4096), (["--hidden_size", "128", "--layer_N", "4", "--activation_id", "0"], 18, 1000),
+                                      (["--hidden_size", "36", "--layer_N", "2", "--use_feature_normalization", "true", "--activation_id", "3"], 7, 333),
+                                      (["--hidden_size", "256", "--layer_N", "2", "--activation_id", "2"], 54, 77),
+                                      (["--hidden_size", "64", "--use_share_model", "true", "--layer_N", "2"], 6, 500)])
+def test_whole_tower_launch_equals_the_layer_by_layer_forward(argv, D, B):
+    """orl_gen_mlp_fwd (the rollout's one-launch tower) against the per-layer kernels the update runs (which are checked
+    against torch above): logits / values agree to fp32 summation order (the K index is walked in a permuted order)."""
+    from openrl_amd import spaces
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.modules import generic_net as gn
+    from openrl_amd import ops_gen
+
+    cfg = default_cfg(argv)
+    share = bool(cfg.use_share_model)
+    mod = gn.GenericPPOModule(cfg, spaces.Box(-np.inf, np.inf, (D,)), spaces.Box(-np.inf, np.inf, (D,)), spaces.Discrete(5),
+                              share_model=share, device=DEV)
+    torch.manual_seed(B)
+    x = torch.randn(B, D, device=DEV)
+    for net, heads in ((mod.policy_net, ("act", "v_out") if share else ("act",)), (mod.critic_net, ("v_out",))):
+        net.theta.add_(0.05 * torch.randn_like(net.theta))  # biases / LayerNorm affine away from their 0 / 1 init
+        desc = net.mlp_desc(heads)
+        assert desc is not None
+        outs = [torch.zeros(B, net.heads[h]["n"], device=DEV) for h in heads]
+        ops_gen.mlp_fwd(desc, x, outs[0], outs[1] if len(outs) > 1 else None)
+        ws = gn.GenWorkspace(net, B, False)
+        feats = gn.trunk_forward(net, ws, x, False)
+        for h, got in zip(heads, outs):
+            want = gn.head_forward(net, ws, h, feats)
+            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
 # ---- end to end through make / PPONet / PPOAgent ----------------------------------------------------------------------
 class MatchTargetEnv:
     """Host VecEnv (the duck type of examples/isaac/isaac2openrl.py:28-88) with a MultiDiscrete([3, 2]) action space:
