@@ -250,3 +250,39 @@ def test_logger_run_dirs_and_file_scalar_backend(tmp_path):
     quiet = Logger(cfg)  # no log_path: nothing on disk, history only
     quiet.log_info({"a": 1}, 1)
     assert quiet.run_dir is None and quiet.history == [(1, {"a": 1.0})]
+
+
+# ---- tests/test_buffer/test_buffer.py:28-55 with the import swapped -------------------------------------------------
+def test_obs_data_basic():
+    from openrl_amd.buffers.utils.obs_data import ObsData
+
+    a_data = np.array([1, 2])
+    b_data = np.array([3, 4])
+    c_data = np.array([5, 6, 7])
+    obs = ObsData({"a": a_data, "b": b_data, "c": c_data})
+
+    assert np.all(obs["c"] == c_data)
+    obs["a"][0] = 99
+    a_data[0] = 99
+    assert np.all(obs["a"] == a_data)
+
+    assert np.all(obs.flatten() == np.concatenate([a_data, b_data, c_data]))
+
+
+def test_obs_data_step():
+    from openrl_amd.buffers.utils.obs_data import ObsData
+
+    obs_stepes = [
+        {"obs_a": np.array([[[0, 1]]]), "obs_b": np.array([[[3, 9]]])},
+        {"obs_a": np.array([[[2, 4]]]), "obs_b": np.array([[[6, 8]]])},
+    ]
+    obs = ObsData({"obs_a": np.zeros((2, 1, 1, 2)), "obs_b": np.zeros((2, 1, 1, 2))})
+    for step in range(len(obs_stepes)):
+        for key in obs.keys():
+            obs[key][step] = obs_stepes[step][key]
+
+    step_data = {"obs_a": np.array([[0.0, 1.0]]), "obs_b": np.array([[3.0, 9.0]])}
+    for key in obs[0]:
+        assert np.all(obs[0][key] == step_data[key])
+    assert obs.all_batch(0, 2)["obs_b"].shape == (2, 2) and np.all(obs.all_batch(1, 2)["obs_a"] == [[2.0, 4.0]])
+    assert np.all(ObsData.prepare_input({"p": np.zeros((3, 2, 5))})["p"].shape == (6, 5))
