@@ -72,7 +72,9 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, int n_out, float* __restrict__ a_out,
     float* __restrict__ stats_out, float* __restrict__ y_out) {
   constexpr int BM = 16 * WAVES, NP = 16 * NB, XLD = BM + 16, WLD = NP + 16, NTH = 64 * WAVES;
-  constexpr int WU = (4 * NP + NTH - 1) / NTH;  // float4 units of the W chunk per thread
+  constexpr int KQ = GF_KC / 4;                       // float4 units per chunk row
+  constexpr int XU = (BM * KQ + NTH - 1) / NTH;       // float4 units of the x chunk per thread
+  constexpr int WU = (NP * KQ + NTH - 1) / NTH;       // ... of the W chunk
   extern __shared__ float sh_gf[];
   float* xs = sh_gf;                    // [2][KC][XLD]   xs[k][m]
   float* ws = sh_gf + 2 * GF_KC * XLD;  // [2][KC][WLD]   ws[k][n]
@@ -80,25 +82,26 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
   const long long m0 = (long long)blockIdx.x * BM;
   const bool vx = (n_in & 3) == 0 && aligned16(x), vw = (n_in & 3) == 0 && aligned16(W);
 
-  f32x4 rx;
+  f32x4 rx[XU];
   f32x4 rw[WU];
   auto load = [&](int k0) {
-    {
-      const int m = tid >> 2, k = k0 + 4 * (tid & 3);
-      rx = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (m0 + m < B && k < n_in) {
+#pragma unroll
+    for (int u0 = 0; u0 < XU; ++u0) {
+      const int u = tid + NTH * u0, m = u / KQ, k = k0 + 4 * (u % KQ);
+      rx[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < BM * KQ && m0 + m < B && k < n_in) {
         const float* p = x + (m0 + m) * n_in + k;
-        if (vx) rx = *(const f32x4*)p;
+        if (vx) rx[u0] = *(const f32x4*)p;
         else
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (k + j < n_in) rx[j] = p[j];
+          for (int j = 0; j < 4; ++j) if (k + j < n_in) rx[u0][j] = p[j];
       }
     }
 #pragma unroll
     for (int u0 = 0; u0 < WU; ++u0) {
-      const int u = tid + NTH * u0, n = u >> 2, k = k0 + 4 * (u & 3);
+      const int u = tid + NTH * u0, n = u / KQ, k = k0 + 4 * (u % KQ);
       rw[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < 4 * NP && n < n_out && k < n_in) {
+      if (u < NP * KQ && n < n_out && k < n_in) {
         const float* p = W + (long long)n * n_in + k;
         if (vw) rw[u0] = *(const f32x4*)p;
         else
@@ -110,15 +113,17 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
   auto stash = [&](int buf) {
     float* xb = xs + buf * GF_KC * XLD;
     float* wb = ws + buf * GF_KC * WLD;
-    {
-      const int m = tid >> 2, kq = 4 * (tid & 3);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xb[(kq + j) * XLD + m] = rx[j];
+    for (int u0 = 0; u0 < XU; ++u0) {
+      const int u = tid + NTH * u0, m = u / KQ, kq = 4 * (u % KQ);
+      if (u < BM * KQ)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xb[(kq + j) * XLD + m] = rx[u0][j];
     }
 #pragma unroll
     for (int u0 = 0; u0 < WU; ++u0) {
-      const int u = tid + NTH * u0, n = u >> 2, kq = 4 * (u & 3);
-      if (u < 4 * NP)
+      const int u = tid + NTH * u0, n = u / KQ, kq = 4 * (u % KQ);
+      if (u < NP * KQ)
 #pragma unroll
         for (int j = 0; j < 4; ++j) wb[(kq + j) * WLD + n] = rw[u0][j];
     }
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
     const float* __restrict__ gamma, int act, int B, int n_out, const float* __restrict__ W, float* __restrict__ dz_out,
     float* __restrict__ dx_out, float* __restrict__ partials) {
   constexpr int BM = 16 * WAVES, NP = 16 * NB, WLD = NP + 16, NTH = 64 * WAVES, LDR = NP + 4;
-  constexpr int WU = (4 * NP + NTH - 1) / NTH;
+  constexpr int WU = (GF_KC * NP / 4 + NTH - 1) / NTH;
   extern __shared__ float sh_gb[];
   float* dzs = sh_gb;                      // [WAVES][16][LDR]  dzs[w][m][c]   (wave-private, row-major)
   float* ws = sh_gb + WAVES * 16 * LDR;    // [2][KC][WLD]      ws[k = c][n]
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
       for (int u0 = 0; u0 < WU; ++u0) {
         const int u = tid + NTH * u0, k = u / (NP / 4), n = 4 * (u % (NP / 4));
         rw[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (u < 4 * NP && c0 + k < n_out && n < n_in) {
+        if (u < GF_KC * NP / 4 && c0 + k < n_out && n < n_in) {
           const float* p = W + (long long)(c0 + k) * n_in + n;
           if (vw) rw[u0] = *(const f32x4*)p;
           else
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
 #pragma unroll
       for (int u0 = 0; u0 < WU; ++u0) {
         const int u = tid + NTH * u0, k = u / (NP / 4), n = 4 * (u % (NP / 4));
-        if (u < 4 * NP) *(f32x4*)(wb + k * WLD + n) = rw[u0];
+        if (u < GF_KC * NP / 4) *(f32x4*)(wb + k * WLD + n) = rw[u0];
       }
     };
     const int nch = (n_out + GF_KC - 1) / GF_KC;
