@@ -312,3 +312,52 @@ def test_extreme_recurrent_tower_shapes_train_end_to_end(obs_dim, n_act):
     assert d.actions.min() >= 0 and d.actions.max() <= n_act - 1
     for m in agent.net.module.models.values():
         assert torch.isfinite(m.theta).all() and torch.isfinite(m.grad).all()
+
+
+@pytest.mark.parametrize("env_id,argv", [("CartPole-v1", []), ("SyntheticFixedStep-v0", ["--hidden_size", "128", "--layer_N", "2"]),
+                                         ("CartPole-v1", ["--hidden_size", "32", "--use_share_model", "true"])])
+def test_graph_captured_rollout_on_the_base_device_envs_equals_eager(env_id, argv):
+    """The synthetic / CartPole env's step counter has a device part (orl_env_step_dev), so a stepwise rollout of these
+    envs is captured into a hipGraph too (fixed towers in stepwise mode, general towers always): buffers, weights and
+    the env's own counter are bit-identical to the eager stepwise run."""
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+
+    def run(use_graph):
+        N, T, iters = 80, 20, 4
+        cfg = default_cfg(["--seed", "5", "--episode_length", str(T), "--ppo_epoch", "2", "--amd_perm_mode", "device",
+                           "--amd_use_graph", str(use_graph), "--amd_rollout_mode", "stepwise", "--log_interval", "1000000"] + argv)
+        kw = dict(obs_dim=6, episode_limit=7) if env_id.startswith("Synthetic") else {}
+        env = make(env_id, env_num=N, device=DEV, **kw)
+        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+        cfg.num_env_steps = N * T * iters
+
+        class _Agent:
+            num_time_steps = 0
+
+        agent = _Agent()
+        trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=DEV)
+        buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=DEV)
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, agent)
+        drv.reset_and_buffer_init()
+        for i in range(iters):
+            drv.episode = i
+            drv._inner_loop()
+        assert (drv._graph is not None) == use_graph and agent.num_time_steps == N * T * iters
+        assert env.global_step == T * iters
+        d = buf.data
+        keep = {k: getattr(d, k).clone() for k in ("policy_obs", "actions", "action_log_probs", "value_preds", "rewards",
+                                                   "masks", "returns")}
+        theta = next(iter(net.module.models.values())).theta.clone()
+        return keep, theta, net.module.rng_step, env.env_state.clone()
+
+    a, tha, ra, ea = run(True)
+    b, thb, rb, eb = run(False)
+    assert ra == rb and torch.equal(ea, eb)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(tha, thb)
