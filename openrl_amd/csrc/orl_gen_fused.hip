@@ -1,22 +1,26 @@
-// orl_gen_fused.hip - fused layer kernels of the GENERAL tower path for gfx950 (round 2b).
+// orl_gen_fused.hip - fused kernels of the GENERAL tower path for gfx950 (any hidden_size <= 512 / layer_N / activation).
 //
 // orl_gen.hip runs nn.Sequential(Linear, act, LayerNorm) as GEMM + row kernel with z / a / xhat / y all round-tripping
-// HBM.  At hidden_size 128 and 524 288 minibatch rows every such array is 268 MB, so the layer-wise path is a stream of
-// HBM passes.  The kernels here keep a 64-row tile of a layer on the CU across the whole layer:
+// HBM.  At hidden_size 128 and 524 288 minibatch rows every such array is 268 MB, so that path is a stream of HBM
+// passes.  The kernels here keep a row tile of a layer on the CU across the whole layer (mlp.py:8-46, MLPLayer;
+// torch.nn.LayerNorm: eps 1e-5, biased variance of the centred values):
 //
-//   orl_gen_layer_fwd   y = LN(act(x W^T + b)): fp32 MFMA accumulators of a [64 x n_out] tile stay in registers,
-//                       bias / activation / LayerNorm run on the MFMA D fragment (a row = 16 lanes x NB registers),
-//                       stores a (post-activation) + (mean, rstd) per row for the backward and y.    [x | a y]
-//   orl_gen_layer_bwd   dy -> dz (LayerNorm affine + LayerNorm + activation backward on the fragment), dz goes to HBM
-//                       once (the wgrad needs it) and, transposed through a wave-private LDS slab, straight into the
-//                       dgrad dx = dz W of the same tile; d gamma / d beta / d bias column sums per workgroup. [dy a | dz dx]
+//   orl_gen_layer_fwd   y = LN(act(x W^T + b)): the fp32 MFMA accumulators of a [64 x n_out] tile stay in registers;
+//                       bias / activation on the MFMA D fragment, then through a wave-private LDS slab into a ROW layout
+//                       (a row = up to 64 lanes x float4) for the LayerNorm statistics; a (post-activation),
+//                       (mean, rstd) and y leave as whole coalesced rows.                               [x | a y]
+//   orl_gen_layer_bwd   dy -> dz in the row layout (LayerNorm affine + LayerNorm + activation backward, column sums of
+//                       d gamma / d beta / d bias in registers), dz to HBM once (the wgrad needs it) and through the
+//                       LDS slab straight into the input gradient dx = dz W of the same tile.  Square layers up to
+//                       128 x 128 keep W resident in LDS and run barrier-free (gen_layer_bwd_res_kernel). [dy a | dz dx]
 //   orl_gen_wgrad       dW = dz^T x with the batch rows as K: persistent split-K, both operands row-major so every
-//                       load is a coalesced float4, up to a 128 x 128 output block per workgroup (each operand is read
-//                       once at hidden 128).                                                          [dz x | partials]
+//                       load is a coalesced float4, up to a 128 x 128 output block per workgroup.   [dz x | partials]
 //   orl_gen_colsum      fixed-order column sums of per-workgroup partial rows, written to up to 3 destinations.
+//   orl_gen_mlp_fwd     rollout side: the WHOLE tower (feature norm, every layer, 1-2 heads) of a 16-row tile in one
+//                       launch, weights straight from L2 as the MFMA B operand.
 //
-// mlp.py:8-46 (MLPLayer), torch.nn.LayerNorm (eps 1e-5, biased variance of the centred values) as in orl_gen.hip.
-// Shapes these kernels do not take (n_out > 512, misaligned rows) stay on the layer-wise kernels.
+// Widths that are not a multiple of 4 or parameter vectors that are not 16-byte aligned take the same kernels on a
+// scalar / fragment-layout path; n_out > 512 is refused (GenNet refuses it first).
 #include <string.h>
 #include "orl_common.h"
 #include "orl_mlp.h"
