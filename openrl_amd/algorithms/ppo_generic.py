@@ -18,7 +18,7 @@ from ..modules import generic_net as gn
 
 
 def _loss_sums(ws, name: str, nb: int, width: int):
-    ops.ppo_reduce(ws.loss_partials.data_ptr(), nb, width, ws.loss_sums[name].data_ptr(), ws.loss_sums[name].device)
+    ops_gen.colsum(ws.loss_partials, nb, [(ws.loss_sums[name], width)])
     return ws.loss_sums[name]
 
 
