@@ -186,16 +186,18 @@ def main():
         from oracle.cpu_trainer import time_cpu_baseline_bounded
 
         cb = time_cpu_baseline_bounded(n_envs=N_ENVS, ppo_epoch=PPO_EPOCH, target_seconds=args.cpu_seconds)
-        kind = "port"
+        ref_run = None
         try:  # the REAL reference objects, timed where /root/reference exists (oracle/ref_cpu_baseline.py), committed
             with open(os.path.join(ROOT, "profiles", "r02_ref_cpu_line.json")) as fh:
                 ref = json.loads(fh.readline())
-            kind = ("port (reference-run: %.0f env-steps/s on %d cores, 1 warm-up + %d iterations of the full "
-                    "configs[1] workload, profiles/r02_ref_cpu_line.json)" % (ref["value"], ref["cores"], ref["iters"]))
+            ref_run = {"value": round(ref["value"], 1), "unit": "env-steps/s", "cores": ref["cores"],
+                       "sample": "1 warm-up + %d iterations of the full configs[1] workload with the reference's own "
+                                 "classes, timed in the build container" % ref["iters"],
+                       "source": "profiles/r02_ref_cpu_line.json"}
         except Exception:
             pass
         out["cpu_baseline"] = {"value": round(cb["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": cb["cores"],
-                               "kind": kind,
+                               "kind": "port", "reference_run": ref_run,
                                "sample": "1 iteration of the oracle port: %d envs x %d-step rollout + %d full-batch "
                                          "epochs (%.1f s; act %.1f s, insert %.1f s, update %.1f s)"
                                          % (N_ENVS, cb["T"], PPO_EPOCH, cb["seconds"], cb["phase_act"],
