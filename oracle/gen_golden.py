@@ -203,6 +203,84 @@ def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, s
     print(name + ".npz", {k: float(info[k]) for k in info})
 
 
+def _train_case_mat(name, argv, obs_dim, act_space_fn, N=6, A=3, T=10, seed=0):
+    """Multi-agent feed-forward buffer + the reference's ``MATAlgorithm.train`` on the MLP ``PPOModule`` (what its own
+    tests/test_algorithm/test_mat_algorithm.py builds): one summed loss, ``feed_forward_generator_transformer``
+    (algorithms/mat.py:21-38, buffers/replay_data.py:707-804).  A > 1, so that minibatches of (step, env) pairs with all
+    their agents differ from the row-wise generator's."""
+    from gymnasium.spaces import Box
+    from openrl.algorithms.mat import MATAlgorithm
+    from openrl.buffers import NormalReplayBuffer
+    from openrl.modules.ppo_module import PPOModule
+    from openrl.utils.util import set_seed
+
+    cfg = _cfg(argv, N, T)
+    cfg.seed = seed
+    act_space = act_space_fn()
+    obs_space = Box(-np.inf, np.inf, (obs_dim,))
+    set_seed(cfg.seed)
+    module = PPOModule(cfg, policy_input_space=obs_space, critic_input_space=obs_space, act_space=act_space,
+                       share_model=False, rank=0, world_size=1)
+    out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"]), "mat": np.array(1),
+           "agents": np.array(A)}
+    buffer = NormalReplayBuffer(cfg, A, obs_space, act_space, data_client=None)
+    algo = MATAlgorithm(cfg, module, agent_num=A)
+    rs = np.random.RandomState(300 + seed)
+    obs = rs.randn(N, A, obs_dim).astype(np.float32)
+    buffer.init_buffer(obs.copy())
+    algo.prep_rollout()
+    d = buffer.data
+    for step in range(T):  # onpolicy_driver.py:159-192
+        with torch.no_grad():
+            value, action, logp, rs_a, rs_c = module.get_actions(
+                d.get_batch_data("critic_obs", step), d.get_batch_data("policy_obs", step),
+                d.get_batch_data("rnn_states", step), d.get_batch_data("rnn_states_critic", step),
+                d.get_batch_data("masks", step), action_masks=d.get_batch_data("action_masks", step))
+        split = lambda x: np.array(np.split(x.detach().cpu().numpy(), N))
+        values, actions, logps = split(value), split(action), split(logp)
+        obs = rs.randn(N, A, obs_dim).astype(np.float32)
+        rewards = rs.rand(N, A, 1).astype(np.float32)
+        dones = rs.rand(N, A) < 0.2
+        if step % 4 == 1:
+            dones[rs.randint(N)] = True  # a whole env done: masks 0, active 1 (onpolicy_driver.py:118-140)
+        dones_env = np.all(dones, axis=1)
+        masks = np.ones((N, A, 1), np.float32)
+        masks[dones_env] = 0.0
+        active = np.ones((N, A, 1), np.float32)
+        active[dones] = 0.0
+        active[dones_env] = 1.0
+        bad = np.ones((N, A, 1), np.float32)
+        buffer.insert(obs, split(rs_a), split(rs_c), actions, logps, values, rewards, masks, active_masks=active,
+                      bad_masks=bad, action_masks=None)
+    with torch.no_grad():
+        nv = module.get_values(d.get_batch_data("critic_obs", -1), np.concatenate(d.rnn_states_critic[-1]),
+                               np.concatenate(d.masks[-1]))
+    next_values = np.array(np.split(nv.detach().cpu().numpy(), N))
+    vn = module.get_critic_value_normalizer()
+    buffer.compute_returns(next_values, vn)
+    for f in ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks",
+              "bad_masks", "active_masks"):
+        out["buf_" + f] = getattr(d, f).copy()
+    if d.action_masks is not None:
+        out["buf_action_masks"] = d.action_masks.copy()
+    out["next_values"] = next_values
+    torch.manual_seed(4321 + seed)
+    algo.prep_training()
+    info = algo.train(d)
+    out["train_info"] = np.array([float(info.get(k, 0.0)) for k in
+                                  ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
+                                   "ratio")], np.float64)
+    out["theta_p1"] = _flat(module.models["policy"])
+    out["theta_c1"] = _flat(module.models["critic"])
+    if vn is not None:
+        out["vn_state1"] = np.array([vn.running_mean.item(), vn.running_mean_sq.item(), vn.debiasing_term.item()],
+                                    np.float32)
+    out["argv"] = np.array(" ".join(argv))
+    out["perm_seed"] = np.array(4321 + seed)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: float(info[k]) for k in info})
+
+
 def actlayer_multidiscrete_case():
     """ACTLayer with a MultiDiscrete space (act.py:26-34, 60-72, 136-151): per-component Categoricals over the same
     features.  The reference's ReplayData cannot hold MultiDiscrete actions (np.zeros((T, N, A, act_space.shape)),
@@ -552,6 +630,13 @@ def main():
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_share_model", "true",
                 "--use_feature_normalization", "true", "--hidden_size", "48", "--layer_N", "2"], 7,
             lambda: Box(-1, 1, (3,)), seed=15, share=True),
+        # MATAlgorithm on the MLP PPOModule (algorithms/mat.py): summed loss, (step, env)-pair minibatches, 3 agents
+        "train_mat": lambda n: _train_case_mat(
+            n, ["--ppo_epoch", "3", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 6, lambda: Discrete(5),
+            N=6, A=3, T=10, seed=21),
+        "train_mat_box": lambda n: _train_case_mat(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--use_huber_loss"], 5, lambda: Box(-1, 1, (2,)), N=5, A=2,
+            T=9, seed=22),
         # recurrent (GRU) branch: T=7 is odd, so chunks of 2 straddle lanes like cfg4's T=25
         "train_recurrent": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 18, 54,

@@ -152,6 +152,20 @@ def feed_forward_indices(batch_size: int, num_mini_batch: int) -> List[np.ndarra
     return [perm[i * mbs:(i + 1) * mbs] for i in range(batch_size // mbs)]
 
 
+def transformer_indices(agent_num: int):
+    """``feed_forward_generator_transformer`` (replay_data.py:707-804, MATAlgorithm's generator): ``randperm(T * N)``
+    over (step, env) pairs, ``mini_batch_size = T * N // nmb`` pairs per minibatch, every pair expanded to the rows of
+    all its agents in agent order (``_shuffle_agent_grid`` keeps the agent axis).  Returns an ``index_fn`` for
+    ``train_ppo``."""
+    def index_fn(batch_rows: int, num_mini_batch: int) -> List[np.ndarray]:
+        pairs = batch_rows // agent_num
+        mbs = pairs // num_mini_batch
+        perm = torch.randperm(pairs).numpy()
+        a = np.arange(agent_num)
+        return [(perm[i * mbs:(i + 1) * mbs][:, None] * agent_num + a).reshape(-1) for i in range(num_mini_batch)]
+    return index_fn
+
+
 def flat_rows(x: np.ndarray) -> np.ndarray:
     """``x[:-1].reshape(-1, width)`` row order (t*N+n)*A+a (replay_data.py:594-613)."""
     return x.reshape(-1, x.shape[-1])

@@ -84,6 +84,32 @@ def test_a2c_algorithm(config, init_module, buffer_data):
     _check(info, init_module)
 
 
+def test_mat_algorithm(config, init_module, buffer_data):  # tests/test_algorithm/test_mat_algorithm.py:74-79
+    from openrl_amd.algorithms.mat import MATAlgorithm
+
+    mat_algo = MATAlgorithm(config, init_module)
+    info = mat_algo.train(buffer_data)
+    _check(info, init_module)
+
+
+def test_mat_agent_trains_mpe_with_the_mlp_module():
+    """``MATAgent`` (runners/common/mat_agent.py) with the MLP ``PPONet`` on the 3-agent MPE env: the driver, the
+    (step, env)-pair minibatches and the fused towers end to end."""
+    from openrl_amd.configs.config import create_config_parser
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import MATAgent as Agent
+
+    cfg = create_config_parser().parse_args("--episode_length 5 --num_mini_batch 2 --ppo_epoch 2".split())
+    env = make("simple_spread", env_num=4)
+    agent = Agent(Net(env, cfg=cfg))
+    agent.train(total_time_steps=100)
+    assert agent.driver.trainer.__class__.__name__ == "MATAlgorithm"
+    idx = agent.driver.trainer.last_indices[-1].cpu().numpy().reshape(-1, 3)
+    assert np.all(idx % 3 == np.arange(3)) and np.all(idx // 3 == idx[:, :1] // 3)  # whole (step, env) pairs
+    env.close()
+
+
 # ---- tests/test_examples/test_train_mpe.py:17-58, imports swapped (test_train_cartpole.py's >= 450 threshold after
 # 20 000 steps depends on the seed - 298 at seed 0 here, 292 for the CPU restatement of the reference on the same env,
 # 500 at seed 1; tests/test_rollout_gpu.py::test_cartpole_learns_like_the_reference_recipe pins that recipe) --------
