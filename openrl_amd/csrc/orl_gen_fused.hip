@@ -274,13 +274,13 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
 // ------------------------------------------------------------------------------------------------ backward
 // Persistent over 16*WAVES-row tiles.  dx (dgrad) only for square layers (n_in == n_out), which is every hidden layer
 // below the first; W == nullptr skips it.
-template <int NB, int WAVES>
+template <int NB, int WAVES, int KC = GF_KC>
 __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ stats,
     const float* __restrict__ gamma, int act, int B, int n_out, const float* __restrict__ W, float* __restrict__ dz_out,
     float* __restrict__ dx_out, float* __restrict__ partials) {
   constexpr int BM = 16 * WAVES, NP = 16 * NB, WLD = NP + 16, NTH = 64 * WAVES, LDR = NP + 4;
-  constexpr int WU = (GF_KC * NP / 4 + NTH - 1) / NTH;
+  constexpr int WU = (KC * NP / 4 + NTH - 1) / NTH;
   extern __shared__ float sh_gb[];
   float* dzs = sh_gb;                      // [WAVES][16][LDR]  dzs[w][m][c]   (wave-private, row-major)
   float* ws = sh_gb + WAVES * 16 * LDR;    // [2][KC][WLD]      ws[k = c][n]
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
       for (int u0 = 0; u0 < WU; ++u0) {
         const int u = tid + NTH * u0, k = u / (NP / 4), n = 4 * (u % (NP / 4));
         rw[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (u < GF_KC * NP / 4 && c0 + k < n_out && n < n_in) {
+        if (u < KC * NP / 4 && c0 + k < n_out && n < n_in) {
           const float* p = W + (long long)(c0 + k) * n_in + n;
           if (vw) rw[u0] = *(const f32x4*)p;
           else
@@ -435,24 +435,24 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_bwd_kernel(
       }
     };
     auto stash = [&](int buf) {
-      float* wb = ws + buf * GF_KC * WLD;
+      float* wb = ws + buf * KC * WLD;
 #pragma unroll
       for (int u0 = 0; u0 < WU; ++u0) {
         const int u = tid + NTH * u0, k = u / (NP / 4), n = 4 * (u % (NP / 4));
-        if (u < GF_KC * NP / 4) *(f32x4*)(wb + k * WLD + n) = rw[u0];
+        if (u < KC * NP / 4) *(f32x4*)(wb + k * WLD + n) = rw[u0];
       }
     };
-    const int nch = (n_out + GF_KC - 1) / GF_KC;
+    const int nch = (n_out + KC - 1) / KC;
     load(0);
     __syncthreads();  // the previous tile's MFMA loop is done with both ws buffers
     stash(0);
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
-      if (c + 1 < nch) load((c + 1) * GF_KC);
-      const float* wb = ws + (c & 1) * GF_KC * WLD + i;
-      const float* ab = dzw + i * LDR + c * GF_KC + q;
+      if (c + 1 < nch) load((c + 1) * KC);
+      const float* wb = ws + (c & 1) * KC * WLD + i;
+      const float* ab = dzw + i * LDR + c * KC + q;
 #pragma unroll
-      for (int kk = 0; kk < GF_KC; kk += 4) {
+      for (int kk = 0; kk < KC; kk += 4) {
         const float av = ab[kk];
 #pragma unroll
         for (int t = 0; t < NB; ++t) acc[t] = ORL_MFMA(av, wb[(kk + q) * WLD + 16 * t], acc[t]);
@@ -979,19 +979,19 @@ static int launch_fwd(const float* x, int B, int n_in, const float* W, const flo
   return launch_status("orl_gen_layer_fwd");
 }
 
-template <int NB, int WAVES>
+template <int NB, int WAVES, int KC = GF_KC>
 static int launch_bwd(const float* dy, const float* a, const float* stats, const float* gamma, int act, int B, int n_out,
                       const float* W, float* dz_out, float* dx_out, float* partials, int max_blocks, int* n_blocks_out,
                       hipStream_t s) {
   constexpr int BM = 16 * WAVES, NP = 16 * NB;
-  size_t fl = (size_t)WAVES * 16 * (NP + 4) + (size_t)2 * GF_KC * (NP + 16);
+  size_t fl = (size_t)WAVES * 16 * (NP + 4) + (size_t)2 * KC * (NP + 16);
   if (fl < (size_t)WAVES * 3 * NP) fl = (size_t)WAVES * 3 * NP;
   const size_t lds = fl * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)gen_layer_bwd_kernel<NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)gen_layer_bwd_kernel<NB, WAVES, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   long long grid = ((long long)B + BM - 1) / BM;
   const int cap = max_blocks < 768 ? max_blocks : 768;  // 3 workgroups per CU
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((gen_layer_bwd_kernel<NB, WAVES>), dim3((unsigned)grid), dim3(64 * WAVES), lds, s, dy, a, stats, gamma, act,
+  hipLaunchKernelGGL((gen_layer_bwd_kernel<NB, WAVES, KC>), dim3((unsigned)grid), dim3(64 * WAVES), lds, s, dy, a, stats, gamma, act,
                      B, n_out, W, dz_out, dx_out, partials);
   *n_blocks_out = (int)grid;
   return launch_status("orl_gen_layer_bwd");
@@ -1075,7 +1075,12 @@ int orl_gen_layer_bwd(const float* dy, const float* a, const float* stats, const
   if (n_out <= 32) ORL_GF_BWD(2, 4);
   if (n_out <= 64) ORL_GF_BWD(4, 4);
   if (n_out <= 128) ORL_GF_BWD(8, 4);
-  if (n_out <= 256) ORL_GF_BWD(16, 4);
+  if (n_out <= 256) {
+    // with the input gradient the 4-wave workgroup (101 KB of LDS, 253 registers) runs alone on its CU: 8 waves with
+    // 8-k weight chunks fit 150 KB and put two waves on every SIMD
+    if (dx_out) return launch_bwd<16, 8, 8>(dy, a, stats, gamma, act, B, n_out, Wd, dz_out, dx_out, col_partials, max_blocks, n_blocks_out, s);
+    ORL_GF_BWD(16, 4);
+  }
   ORL_GF_BWD(32, 2);
 #undef ORL_GF_BWD
 }
