@@ -26,6 +26,19 @@ def test_mpe_example_train_save_load_evaluate(tmp_path):
     assert steps == 25 and np.isfinite(total_reward) and total_reward < 0
 
 
+def test_mpe_jrpo_and_mat_examples(tmp_path):
+    ex = _load(os.path.join(ROOT, "examples", "mpe", "train_ppo.py"))
+    agent = ex.train(env_num=32, total_time_steps=32 * 25 * 2, save_dir=str(tmp_path / "jrpo_agent"),
+                     argv=["--config", os.path.join(ROOT, "examples", "mpe", "mpe_jrpo.yaml"), "--ppo_epoch", "2"])
+    assert agent.driver.trainer.use_joint_action_loss and agent.net.module.recurrent
+    mat = _load(os.path.join(ROOT, "examples", "mpe", "train_mat.py"))
+    agent = mat.train(env_num=32, total_time_steps=32 * 25 * 2,
+                      argv=["--config", os.path.join(ROOT, "examples", "mpe", "mpe_mat.yaml"), "--ppo_epoch", "2"])
+    assert agent.driver.trainer.__class__.__name__ == "MATAlgorithm" and not agent.net.module.recurrent
+    total_reward, steps = mat.evaluation(agent, env_num=9)
+    assert steps == 25 and np.isfinite(total_reward) and total_reward < 0
+
+
 def test_cartpole_example_train_and_evaluate():
     ex = _load(os.path.join(ROOT, "examples", "cartpole", "train_ppo.py"))
     agent = ex.train(env_num=9, total_time_steps=9 * 200 * 2)
