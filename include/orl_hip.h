@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 203 /* 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 204 /* 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -623,8 +623,10 @@ int orl_gen_layer_fwd(const float* x, int B, int n_in, const float* W, const flo
                       const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, void* stream);
 /* The whole tower of a rollout step in ONE launch (no activations stored): optional feature LayerNorm over the
  * observation, n_layers x nn.Sequential(Linear, act, LayerNorm) with n_in(k) == n_out(k-1), widths multiples of 4 and
- * <= 256, then n_heads (1 or 2) plain Linear heads on the trunk's features: entries layer[n_layers ..].  head_out0 /
- * head_out1 are [B, n_out of that head].  All pointers are device pointers (typically into one flat parameter vector). */
+ * <= 256, then n_heads (0, 1 or 2) plain Linear heads on the trunk's features: entries layer[n_layers ..].  head_out0 /
+ * head_out1 are [B, n_out of that head]; feats_out (or NULL) receives the trunk's features [B, n_out(n_layers-1)] - what
+ * a recurrent cell between trunk and head consumes.  All pointers are device pointers (typically into one flat
+ * parameter vector). */
 #define ORL_GEN_MLP_MAX_LAYERS 14
 typedef struct orl_gen_mlp_layer {
   const float* W;      /* [n_out, n_in] */
@@ -639,7 +641,8 @@ typedef struct orl_gen_mlp_desc {
   const float* fn_beta;
   orl_gen_mlp_layer layer[ORL_GEN_MLP_MAX_LAYERS];
 } orl_gen_mlp_desc;
-int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* head_out0, float* head_out1, void* stream);
+int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* head_out0, float* head_out1,
+                    float* feats_out, void* stream);
 /* Its backward in one launch: dy [B, n_out] -> dz_out [B, n_out] (gradient at the Linear's output; may be NULL),
  * col_partials[n_blocks][3 n_out] = [d gamma | d beta | d bias] per workgroup (sum them with orl_gen_colsum), and - for a
  * square layer, when dx_out != NULL - the input gradient dx_out [B, n_in] = dz W of the same row tile without re-reading
@@ -688,6 +691,20 @@ int orl_gen_adam(const orl_adam_state* adam, int64_t n, float max_grad_norm, int
 /* dst[0..n) += src[0..n): gradient accumulation when a shared trunk is back-propagated twice (policy and critic
  * observations differ) or two heads feed one feature gradient. */
 int orl_vec_add(float* dst, const float* src, int64_t n, void* stream);
+/* One step of torch.nn.GRU (one layer; RNNLayer, networks/utils/rnn.py:28-99) after its two projections
+ * gi = x W_ih^T + b_ih and gh = h_in W_hh^T + b_hh ([N, 3H], column blocks r | z | n): h_out = (1 - z) n + z h_in.
+ * save [N, 4H] = (r, z, n, gh_n) feeds orl_gen_gru_gate_bwd (may be NULL); h_in_next = h_out * mask_next[row] is the
+ * next step's masked input (both NULL or both given). */
+int orl_gen_gru_gate_fwd(const float* gi, const float* gh, const float* h_in, const float* mask_next, int N, int H,
+                         float* h_out, float* h_in_next, float* save, void* stream);
+/* Its backward: dh [N, H] at h_out -> dgi, dgh [N, 3H] at the projections' outputs and dh_in = z * dh, the direct path
+ * to h_in (the path through gh is dgh W_hh, a GEMM). */
+int orl_gen_gru_gate_bwd(const float* dh, const float* save, const float* h_in, int N, int H, float* dgi, float* dgh,
+                         float* dh_in, void* stream);
+/* out[row, :] = (a[row, :] + b[row, :]) * row_scale[row] + add[row, :]; b, row_scale, add may be NULL.  Masks on hidden
+ * states and the carry of back-propagation through time. */
+int orl_gen_row_affine(const float* a, const float* b, const float* row_scale, const float* add, int N, int H, float* out,
+                       void* stream);
 /* train_info_accum {value_loss, policy_loss, dist_entropy, -, -, ratio} += the reduced loss sums / denominators. */
 int orl_gen_info(const float* policy_sums, const float* value_sums, const float* den, const orl_ppo_hparams* hp,
                  float entropy_div, float ratio_div, float* train_info_accum, void* stream);

@@ -578,6 +578,75 @@ __global__ __launch_bounds__(256) void vec_add_kernel(float* __restrict__ dst, c
     dst[e] += src[e];
 }
 
+// ---------------------------------------------------------------------------------------------------- GRU cell
+// torch.nn.GRU (one layer) as RNNLayer runs it (networks/utils/rnn.py:28-99), with the two projections done as GEMMs:
+//   gi = x W_ih^T + b_ih, gh = h_in W_hh^T + b_hh, h_in = h_prev * mask;  column blocks [r | z | n] of width H.
+//   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h = (1 - z) * n + z * h_in.
+// The forward optionally stores (r, z, n, gh_n) for the backward and the NEXT step's masked input h * mask_next.
+__device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gru_gate_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                           const float* __restrict__ h_in,
+                                                           const float* __restrict__ mask_next, long long n_el, int H,
+                                                           float* __restrict__ h_out, float* __restrict__ h_in_next,
+                                                           float* __restrict__ save) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / H;
+    const int c = (int)(e % H);
+    const float* a = gi + row * 3 * H;
+    const float* b = gh + row * 3 * H;
+    const float r = sigmoidf_(a[c] + b[c]);
+    const float z = sigmoidf_(a[H + c] + b[H + c]);
+    const float ghn = b[2 * H + c];
+    const float n = tanhf(a[2 * H + c] + r * ghn);
+    const float h = (1.0f - z) * n + z * h_in[e];
+    h_out[e] = h;
+    if (h_in_next) h_in_next[e] = h * mask_next[row];
+    if (save) {
+      float* sv = save + row * 4 * H;
+      sv[c] = r; sv[H + c] = z; sv[2 * H + c] = n; sv[3 * H + c] = ghn;
+    }
+  }
+}
+
+// dh = gradient at h;  dgi / dgh = gradients at the two projections' outputs, dh_in = the direct path z * dh
+__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ save,
+                                                           const float* __restrict__ h_in, long long n_el, int H,
+                                                           float* __restrict__ dgi, float* __restrict__ dgh,
+                                                           float* __restrict__ dh_in) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / H;
+    const int c = (int)(e % H);
+    const float* sv = save + row * 4 * H;
+    const float r = sv[c], z = sv[H + c], n = sv[2 * H + c], ghn = sv[3 * H + c];
+    const float g = dh[e];
+    const float dn = g * (1.0f - z);
+    const float dz = g * (h_in[e] - n);
+    const float dpn = dn * (1.0f - n * n);
+    const float dpr = dpn * ghn * r * (1.0f - r);
+    const float dpz = dz * z * (1.0f - z);
+    float* a = dgi + row * 3 * H;
+    float* b = dgh + row * 3 * H;
+    a[c] = dpr; a[H + c] = dpz; a[2 * H + c] = dpn;
+    b[c] = dpr; b[H + c] = dpz; b[2 * H + c] = dpn * r;
+    dh_in[e] = g * z;
+  }
+}
+
+// out[row, :] = (a[row, :] + b[row, :]) * scale[row] + add[row, :]   (b, scale, add may be NULL): masks on hidden states
+// and the carry of back-propagation through time
+__global__ __launch_bounds__(256) void row_affine_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ scale, const float* __restrict__ add,
+                                                         long long n_el, int H, float* __restrict__ out) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (long long)gridDim.x * blockDim.x) {
+    float v = a[e];
+    if (b) v += b[e];
+    if (scale) v *= scale[e / H];
+    if (add) v += add[e];
+    out[e] = v;
+  }
+}
+
 // train_info accumulation from the reduced loss statistics (everything stays on the device)
 __global__ void gen_info_kernel(const float* __restrict__ psums, const float* __restrict__ vsums,
                                 const float* __restrict__ den, orl_ppo_hparams hp, float ent_div, float ratio_div,
@@ -780,6 +849,38 @@ int orl_vec_add(float* dst, const float* src, int64_t n, void* stream) {
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(vec_add_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dst, src, (long long)n);
   return launch_status("orl_vec_add");
+}
+
+static inline int ew_grid(long long n) {
+  long long g = (n + 255) / 256;
+  return (int)(g > 4096 ? 4096 : g);
+}
+
+int orl_gen_gru_gate_fwd(const float* gi, const float* gh, const float* h_in, const float* mask_next, int N, int H,
+                         float* h_out, float* h_in_next, float* save, void* stream) {
+  ORL_REQUIRE(gi && gh && h_in && h_out && N > 0 && H > 0, "orl_gen_gru_gate_fwd: bad arguments");
+  ORL_REQUIRE((h_in_next == nullptr) == (mask_next == nullptr), "orl_gen_gru_gate_fwd: h_in_next and mask_next come together");
+  const long long n = (long long)N * H;
+  hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, gi, gh, h_in, mask_next, n, H,
+                     h_out, h_in_next, save);
+  return launch_status("orl_gen_gru_gate_fwd");
+}
+
+int orl_gen_gru_gate_bwd(const float* dh, const float* save, const float* h_in, int N, int H, float* dgi, float* dgh,
+                         float* dh_in, void* stream) {
+  ORL_REQUIRE(dh && save && h_in && dgi && dgh && dh_in && N > 0 && H > 0, "orl_gen_gru_gate_bwd: bad arguments");
+  const long long n = (long long)N * H;
+  hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dh, save, h_in, n, H, dgi, dgh,
+                     dh_in);
+  return launch_status("orl_gen_gru_gate_bwd");
+}
+
+int orl_gen_row_affine(const float* a, const float* b, const float* row_scale, const float* add, int N, int H, float* out,
+                       void* stream) {
+  ORL_REQUIRE(a && out && N > 0 && H > 0, "orl_gen_row_affine: bad arguments");
+  const long long n = (long long)N * H;
+  hipLaunchKernelGGL(row_affine_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, row_scale, add, n, H, out);
+  return launch_status("orl_gen_row_affine");
 }
 
 int orl_gen_info(const float* policy_sums, const float* value_sums, const float* den, const orl_ppo_hparams* hp,

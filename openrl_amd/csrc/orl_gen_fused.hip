@@ -686,6 +686,7 @@ struct MlpArgs {
   const float* x;
   int B;
   float* head_out[2];
+  float* feats;  // [B, n_out of the last trunk layer] or NULL
 };
 
 constexpr int MLP_KPRE = 8;  // 16-k blocks whose weights are in flight together
@@ -824,6 +825,13 @@ __global__ __launch_bounds__(256) void gen_mlp_fwd_kernel(MlpArgs A, int SLD) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = v[j][e] * rstd * g[e] + b[e];
           *(f32x4*)(slab + rl * SLD + 4 * sl) = o;
+          if (A.feats && L == A.d.n_layers - 1 && m0 + rl < B) {  // the trunk's features (a recurrent cell follows)
+            float* fo = A.feats + (m0 + rl) * n_out + 4 * sl;
+            if (aligned16(A.feats)) *(f32x4*)fo = o;
+            else
+#pragma unroll
+              for (int e = 0; e < 4; ++e) fo[e] = o[e];
+          }
         }
       }
     }
@@ -1096,13 +1104,14 @@ int orl_gen_colsum(const float* partials, int n_rows, int width, float* dst0, in
   return launch_status("orl_gen_colsum");
 }
 
-int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* head_out0, float* head_out1, void* stream) {
+int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* head_out0, float* head_out1,
+                    float* feats_out, void* stream) {
   ORL_REQUIRE(desc && x && B > 0, "orl_gen_mlp_fwd: bad arguments");
-  ORL_REQUIRE(desc->n_layers >= 1 && desc->n_heads >= 1 && desc->n_heads <= 2 &&
+  ORL_REQUIRE(desc->n_layers >= 1 && desc->n_heads >= 0 && desc->n_heads <= 2 && (desc->n_heads >= 1 || feats_out) &&
                   desc->n_layers + desc->n_heads <= ORL_GEN_MLP_MAX_LAYERS,
-              "orl_gen_mlp_fwd: %d layers + %d heads (at most %d entries, 1-2 heads)", desc->n_layers, desc->n_heads,
-              ORL_GEN_MLP_MAX_LAYERS);
-  ORL_REQUIRE(head_out0 && (desc->n_heads == 1 || head_out1), "orl_gen_mlp_fwd: a head has no output buffer");
+              "orl_gen_mlp_fwd: %d layers + %d heads (at most %d entries, 0-2 heads, features or a head wanted)",
+              desc->n_layers, desc->n_heads, ORL_GEN_MLP_MAX_LAYERS);
+  ORL_REQUIRE((desc->n_heads < 1 || head_out0) && (desc->n_heads < 2 || head_out1), "orl_gen_mlp_fwd: a head has no output buffer");
   ORL_REQUIRE((desc->fn_gamma == nullptr) == (desc->fn_beta == nullptr), "orl_gen_mlp_fwd: fn_gamma and fn_beta come together");
   int wmax = 0, width = (desc->layer[0].n_in + 15) & ~15;
   for (int L = 0; L < desc->n_layers + desc->n_heads; ++L) {
@@ -1125,7 +1134,7 @@ int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* 
   }
   ORL_REQUIRE(width <= 1024, "orl_gen_mlp_fwd: %d columns do not fit the wave's LDS slab", width);
   MlpArgs A;
-  A.d = *desc; A.x = x; A.B = B; A.head_out[0] = head_out0; A.head_out[1] = head_out1;
+  A.d = *desc; A.x = x; A.B = B; A.head_out[0] = head_out0; A.head_out[1] = head_out1; A.feats = feats_out;
   // NBW output tiles per wave, 4 waves: widths up to 64 NBW; a row's float4 slots are 16 NBW
   const int NBW = wmax <= 64 ? 1 : wmax <= 128 ? 2 : 4;
   if (width < 64 * NBW) width = 64 * NBW;

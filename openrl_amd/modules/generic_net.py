@@ -52,9 +52,10 @@ def _act_head(act_space):
 class GenNet:
     """One reference network (``PolicyNetwork`` / ``ValueNetwork`` / ``PolicyValueNetwork``) as a flat vector."""
 
-    def __init__(self, role: str, cfg, obs_dim: int, act_space, device) -> None:
+    def __init__(self, role: str, cfg, obs_dim: int, act_space, device, recurrent: bool = False) -> None:
         assert role in ("policy", "critic", "model")
-        self.role, self.device = role, device
+        assert not (recurrent and role == "model")
+        self.role, self.device, self.recurrent = role, device, bool(recurrent)
         self.H = H = int(cfg.hidden_size)
         if H % 4 or H > 512:
             raise NotImplementedError("hidden_size %d: the general towers take multiples of 4 up to 512" % H)
@@ -75,6 +76,14 @@ class GenNet:
         self._mlp_layer(base + ".mlp", self.D, H, layer_N)
         if role == "model":  # self.common = MLPLayer(H, H, layer_N=0, ...)  (policy_value_network.py:78-84)
             self._mlp_layer("common", H, H, 0)
+        self.rnn: Optional[Dict] = None
+        if self.recurrent:  # RNNLayer (networks/utils/rnn.py:5-27): nn.GRU(H, H, num_layers=1) + LayerNorm(H)
+            if 3 * H > 512:
+                raise NotImplementedError("recurrent general towers take hidden_size <= 168 (the GRU's 3 H gate columns "
+                                          "go through the 512-column layer kernels), got %d" % H)
+            self.rnn = dict(Wih=self._add("rnn.rnn.weight_ih_l0", (3 * H, H)), Whh=self._add("rnn.rnn.weight_hh_l0", (3 * H, H)),
+                            bih=self._add("rnn.rnn.bias_ih_l0", (3 * H,)), bhh=self._add("rnn.rnn.bias_hh_l0", (3 * H,)),
+                            g=self._add("rnn.norm.weight", (H,)), be=self._add("rnn.norm.bias", (H,)))
         self.heads: Dict[str, Dict] = OrderedDict()
         if role in ("critic", "model"):
             self.heads["v_out"] = dict(W=self._add("v_out.weight", (1, H)), b=self._add("v_out.bias", (1,)), n=1,
@@ -107,7 +116,7 @@ class GenNet:
         self.grad = torch.zeros_like(self.theta)
         self.training = False
         self.value_normalizer: Optional[ValueNorm] = None
-        self.max_width = max([self.D, H] + [h["n"] for h in self.heads.values()])
+        self.max_width = max([self.D, H] + [h["n"] for h in self.heads.values()] + ([3 * H] if self.recurrent else []))
 
     # ------------------------------------------------------------------ layout
     def _add(self, key: str, shape) -> int:
@@ -146,7 +155,7 @@ class GenNet:
             return hit[1]
         from .. import _native as nat
 
-        ok = (len(self.layers) + len(head_names) <= nat.ORL_GEN_MLP_MAX_LAYERS and 1 <= len(head_names) <= 2
+        ok = (len(self.layers) + len(head_names) <= nat.ORL_GEN_MLP_MAX_LAYERS and 0 <= len(head_names) <= 2
               and all(L["n_out"] <= 256 and L["n_out"] % 4 == 0 for L in self.layers)
               and all(self.heads[h]["n"] <= 256 for h in head_names) and self.D <= 1024)
         d = None
@@ -269,6 +278,17 @@ class GenNet:
                 w = linear(item[1]["n_in"], item[1]["n_out"], gain)
                 for L in [item[1]] + item[2]:
                     fill(L, w)
+        if self.rnn is not None:  # nn.GRU's default init, then orthogonal_/xavier on both weights, biases 0 (rnn.py:14-26)
+            H = self.H
+            gru = torch.nn.GRU(H, H, num_layers=1)
+            init_method(gru.weight_ih_l0.data)
+            init_method(gru.weight_hh_l0.data)
+            self.v(self.rnn["Wih"], 3 * H * H).copy_(gru.weight_ih_l0.data.reshape(-1))
+            self.v(self.rnn["Whh"], 3 * H * H).copy_(gru.weight_hh_l0.data.reshape(-1))
+            self.v(self.rnn["bih"], 3 * H).zero_()
+            self.v(self.rnn["bhh"], 3 * H).zero_()
+            self.v(self.rnn["g"], H).fill_(1.0)
+            self.v(self.rnn["be"], H).zero_()
         for name, h in self.heads.items():
             if name == "v_out":
                 self.v(h["W"], self.H).copy_(linear(self.H, 1, h["gain"]))
@@ -388,6 +408,76 @@ def trunk_backward(net: GenNet, ws: GenWorkspace, dfeat: torch.Tensor) -> None:
                              ops_gen.ACT_NONE, None, ws.col_partials)
         ops_gen.colsum(ws.col_partials, nb, [(net.v(net.fn["g"], net.D, grad=True), net.D),
                                              (net.v(net.fn["be"], net.D, grad=True), net.D), (None, net.D)])
+
+
+class GruWorkspace:
+    """Buffers of the GRU between trunk and head over ``L`` steps of ``N`` sequences (rows ordered [L, N], the layout of
+    ``recurrent_generator``): projections, masked inputs, gate values and the LayerNorm after the cell."""
+
+    def __init__(self, net: GenNet, L: int, N: int, training: bool) -> None:
+        H, dev = net.H, net.device
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.L, self.N = L, N
+        self.gi, self.gh = e(L * N, 3 * H), e(L * N, 3 * H)
+        self.h_in, self.h = e(L * N, H), e(L * N, H)   # masked input / output state of every step
+        self.y = e(L * N, H)                            # LayerNorm(h): what the head reads
+        if training:
+            self.save = e(L * N, 4 * H)
+            self.xhat, self.rstd = e(L * N, H), e(L * N)
+            self.dh, self.dh_dir, self.carry, self.tmp = e(L * N, H), e(N, H), e(N, H), e(N, H)
+            self.dgi, self.dgh = e(L * N, 3 * H), e(L * N, 3 * H)
+            self.dfeat = e(L * N, H)
+            self.col_partials = e(ops_gen.MAX_BLOCKS * 3 * 3 * H)
+            self.wgrad_partials = e(max(4 * 3 * H * H, min(256 * 3 * H * H, 1 << 24)))
+
+
+def gru_forward(net: GenNet, gw: GruWorkspace, feats: torch.Tensor, h0: torch.Tensor, masks: torch.Tensor, L: int, N: int,
+                save: bool) -> torch.Tensor:
+    """RNNLayer.forward (rnn.py:39-99) on [L * N, H] features: h_t = GRU(feats_t, h_{t-1} * mask_t), y = LayerNorm(h).
+    One projection GEMM for all steps' inputs; per step one recurrent GEMM + one gate launch.  Returns y [L * N, H];
+    ``gw.h[(L-1) * N:]`` is the state after the last step."""
+    H, r = net.H, net.rnn
+    Wih, Whh = net.v(r["Wih"], 3 * H, H), net.v(r["Whh"], 3 * H, H)
+    bih, bhh = net.v(r["bih"], 3 * H), net.v(r["bhh"], 3 * H)
+    B = L * N
+    ops_gen.layer_fwd(feats, Wih, bih, ops_gen.ACT_NONE, None, None, None, None, gw.gi[:B])
+    ops_gen.row_affine(h0, None, masks[:N], None, gw.h_in[:N])
+    for t in range(L):
+        s, nx = slice(t * N, (t + 1) * N), slice((t + 1) * N, (t + 2) * N)
+        ops_gen.layer_fwd(gw.h_in[s], Whh, bhh, ops_gen.ACT_NONE, None, None, None, None, gw.gh[s])
+        last = t == L - 1
+        ops_gen.gru_gate_fwd(gw.gi[s], gw.gh[s], gw.h_in[s], None if last else masks[nx], gw.h[s],
+                             None if last else gw.h_in[nx], gw.save[s] if save else None)
+    ops_gen.row_fwd(gw.h[:B], None, ops_gen.ACT_NONE, net.v(r["g"], H), net.v(r["be"], H), None,
+                    gw.xhat[:B] if save else None, gw.rstd[:B] if save else None, gw.y[:B])
+    return gw.y[:B]
+
+
+def gru_backward(net: GenNet, gw: GruWorkspace, feats: torch.Tensor, masks: torch.Tensor, dy: torch.Tensor, L: int,
+                 N: int) -> torch.Tensor:
+    """Back-propagation through ``gru_forward``: writes the GRU's and its LayerNorm's gradients into ``net.grad`` and
+    returns d feats [L * N, H].  The chunk's initial state is data (rnn.py / recurrent_generator): no gradient leaves."""
+    H, r = net.H, net.rnn
+    Wih, Whh = net.v(r["Wih"], 3 * H, H), net.v(r["Whh"], 3 * H, H)
+    B = L * N
+    # LayerNorm after the cell: dy -> dh (all steps), d gamma / d beta
+    nb = ops_gen.row_bwd(dy, net.v(r["g"], H), gw.xhat[:B], gw.rstd[:B], None, ops_gen.ACT_NONE, gw.dh[:B], gw.col_partials)
+    ops_gen.colsum(gw.col_partials, nb, [(net.v(r["g"], H, grad=True), H), (net.v(r["be"], H, grad=True), H), (None, H)])
+    for t in range(L - 1, -1, -1):
+        s = slice(t * N, (t + 1) * N)
+        # gw.dh[s] already holds the total gradient at h_t (its LayerNorm path + the carry added below for t < L-1)
+        ops_gen.gru_gate_bwd(gw.dh[s], gw.save[s], gw.h_in[s], gw.dgi[s], gw.dgh[s], gw.dh_dir)
+        if t > 0:  # d h_{t-1} += (dgh W_hh + z * dh) * mask_t
+            p = slice((t - 1) * N, t * N)
+            ops_gen.linear_dgrad(gw.dgh[s], Whh, gw.tmp)
+            ops_gen.row_affine(gw.tmp, gw.dh_dir, masks[s], gw.dh[p], gw.dh[p])
+    ops_gen.wgrad(gw.dgi[:B], feats, net.v(r["Wih"], 3 * H, H, grad=True), gw.wgrad_partials)
+    ops_gen.wgrad(gw.dgh[:B], gw.h_in[:B], net.v(r["Whh"], 3 * H, H, grad=True), gw.wgrad_partials)
+    for d, off in ((gw.dgi, r["bih"]), (gw.dgh, r["bhh"])):
+        nb = ops_gen.layer_bwd(d[:B], None, None, None, ops_gen.ACT_NONE, None, None, None, gw.col_partials)
+        ops_gen.colsum(gw.col_partials, nb, [(None, 3 * H), (None, 3 * H), (net.v(off, 3 * H, grad=True), 3 * H)])
+    ops_gen.linear_dgrad(gw.dgi[:B], Wih, gw.dfeat[:B])
+    return gw.dfeat[:B]
 
 
 class GenAdam(FusedAdam):

@@ -96,11 +96,13 @@ def layer_fwd(x, W, bias, act: int, gamma, beta, a_out, stats_out, y_out) -> Non
     nat.check(rc, "orl_gen_layer_fwd")
 
 
-def mlp_fwd(desc, x, head_out0, head_out1=None) -> None:
-    """The whole tower of a rollout step in one launch (``orl_gen_mlp_fwd``); ``desc``: ``_native.GenMlpDesc``."""
+def mlp_fwd(desc, x, head_out0, head_out1=None, feats_out=None) -> None:
+    """The whole tower of a rollout step in one launch (``orl_gen_mlp_fwd``); ``desc``: ``_native.GenMlpDesc``;
+    ``feats_out`` [B, H]: the trunk's features (recurrent towers run their GRU cell on them)."""
     dev = nat.require_gpu(x.device)
     assert x.is_contiguous() and x.shape[1] == desc.layer[0].n_in
-    rc = _lib().orl_gen_mlp_fwd(C.byref(desc), fptr(x), x.shape[0], fptr(head_out0), fptr(head_out1), stream_ptr(dev))
+    rc = _lib().orl_gen_mlp_fwd(C.byref(desc), fptr(x), x.shape[0], fptr(head_out0), fptr(head_out1), fptr(feats_out),
+                                stream_ptr(dev))
     nat.check(rc, "orl_gen_mlp_fwd")
 
 
@@ -200,6 +202,29 @@ def adam(state: AdamState, n: int, max_grad_norm: float, use_max_grad_norm: bool
     rc = _lib().orl_gen_adam(C.byref(state), n, float(max_grad_norm), int(bool(use_max_grad_norm)), n_clips,
                              fptr(scratch), fptr(info), slot_first, slot_second, stream_ptr(device))
     nat.check(rc, "orl_gen_adam")
+
+
+def gru_gate_fwd(gi, gh, h_in, mask_next, h_out, h_in_next, save) -> None:
+    """GRU gates of one step after the two projections (``orl_gen_gru_gate_fwd``)."""
+    N, H = h_in.shape
+    rc = _lib().orl_gen_gru_gate_fwd(fptr(gi), fptr(gh), fptr(h_in), fptr(mask_next), N, H, fptr(h_out), fptr(h_in_next),
+                                     fptr(save), stream_ptr(nat.require_gpu(h_in.device)))
+    nat.check(rc, "orl_gen_gru_gate_fwd")
+
+
+def gru_gate_bwd(dh, save, h_in, dgi, dgh, dh_in) -> None:
+    N, H = h_in.shape
+    rc = _lib().orl_gen_gru_gate_bwd(fptr(dh), fptr(save), fptr(h_in), N, H, fptr(dgi), fptr(dgh), fptr(dh_in),
+                                     stream_ptr(nat.require_gpu(h_in.device)))
+    nat.check(rc, "orl_gen_gru_gate_bwd")
+
+
+def row_affine(a, b, row_scale, add, out) -> None:
+    """out = (a + b) * row_scale[:, None] + add; ``b`` / ``row_scale`` / ``add`` may be None."""
+    N, H = a.shape
+    rc = _lib().orl_gen_row_affine(fptr(a), fptr(b), fptr(row_scale), fptr(add), N, H, fptr(out),
+                                   stream_ptr(nat.require_gpu(a.device)))
+    nat.check(rc, "orl_gen_row_affine")
 
 
 def vec_add(dst: torch.Tensor, src: torch.Tensor) -> None:

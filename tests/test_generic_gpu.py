@@ -283,6 +283,56 @@ def test_whole_tower_launch_equals_the_layer_by_layer_forward(argv, D, B):
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("H,L,N", [(128, 5, 70), (36, 3, 200), (64, 10, 33), (168, 2, 50)])
+def test_gru_sequence_forward_backward_against_torch_fp64(H, L, N):
+    """generic_net.gru_forward / gru_backward (projection GEMMs + orl_gen_gru_gate_fwd/_bwd + the LayerNorm after the
+    cell) vs torch.nn.GRUCell + LayerNorm under autograd in fp64, with the reference's masking h_{t-1} * mask_t
+    (networks/utils/rnn.py:39-99)."""
+    from openrl_amd import spaces
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.modules import generic_net as gn
+
+    cfg = default_cfg(["--hidden_size", str(H), "--use_recurrent_policy", "true"])
+    net = gn.GenNet("policy", cfg, 6, spaces.Discrete(3), DEV, recurrent=True)
+    torch.manual_seed(H + L)
+    net.host_init(cfg)
+    net.theta.add_(0.05 * torch.randn_like(net.theta))
+    r = net.rnn
+    t64 = lambda off, *sh: net.v(off, *sh).detach().cpu().double().clone().requires_grad_(True)
+    Wih, Whh, bih, bhh = t64(r["Wih"], 3 * H, H), t64(r["Whh"], 3 * H, H), t64(r["bih"], 3 * H), t64(r["bhh"], 3 * H)
+    g, be = t64(r["g"], H), t64(r["be"], H)
+    feats = torch.randn(L * N, H, dtype=torch.float64, requires_grad=True)
+    h0 = torch.randn(N, H, dtype=torch.float64)
+    masks = (torch.rand(L * N) > 0.2).double()
+    dy = torch.randn(L * N, H, dtype=torch.float64)
+    h, ys = h0, []
+    for t in range(L):
+        s = slice(t * N, (t + 1) * N)
+        hin = h * masks[s, None]
+        gi, gh = feats[s] @ Wih.t() + bih, hin @ Whh.t() + bhh
+        rr = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        zz = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        nn_ = torch.tanh(gi[:, 2 * H:] + rr * gh[:, 2 * H:])
+        h = (1 - zz) * nn_ + zz * hin
+        ys.append(torch.nn.functional.layer_norm(h, (H,), g, be, 1e-5))
+    y_ref = torch.cat(ys)
+    (y_ref * dy).sum().backward()
+
+    gw = gn.GruWorkspace(net, L, N, True)
+    dev = lambda t: t.detach().float().to(DEV).contiguous()
+    fd, md = dev(feats), dev(masks)
+    y = gn.gru_forward(net, gw, fd, dev(h0), md, L, N, True)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(gw.h[(L - 1) * N:L * N].cpu().numpy(), h.detach().numpy(), rtol=1e-4, atol=1e-5)
+    net.grad.zero_()
+    dfeat = gn.gru_backward(net, gw, fd, md, dev(dy), L, N)
+    sB = np.sqrt(L * N)
+    np.testing.assert_allclose(dfeat.cpu().numpy(), feats.grad.numpy(), rtol=2e-4, atol=2e-4)
+    for off, ref, sh in ((r["Wih"], Wih, (3 * H, H)), (r["Whh"], Whh, (3 * H, H)), (r["bih"], bih, (3 * H,)),
+                         (r["bhh"], bhh, (3 * H,)), (r["g"], g, (H,)), (r["be"], be, (H,))):
+        np.testing.assert_allclose(net.v(off, *sh, grad=True).cpu().numpy(), ref.grad.numpy(), rtol=3e-4, atol=4e-5 * sB)
+
+
 # ---- end to end through make / PPONet / PPOAgent ----------------------------------------------------------------------
 class MatchTargetEnv:
     """Host VecEnv (the duck type of examples/isaac/isaac2openrl.py:28-88) with a MultiDiscrete([3, 2]) action space:
