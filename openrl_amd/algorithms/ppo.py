@@ -134,7 +134,8 @@ class PPOAlgorithm(BaseAlgorithm):
         self._moments_mb = self._moments
         self._full_batch_moments = False
         if self.generic:  # general towers (modules/generic_net.py): layer-wise update, algorithms/ppo_generic.py
-            self.recurrent = False
+            self.recurrent = bool(getattr(self.algo_module, "recurrent", False))
+            self._rnn_rows = None
             self.fuse_next_perm = False
             self._comm = None
             self._gen_den = torch.zeros(2, dtype=torch.float32, device=self.device)
@@ -312,6 +313,15 @@ class PPOAlgorithm(BaseAlgorithm):
         """One recurrent_generator minibatch (replay_data.py:1062-1258): ``chunks`` = chunk ids (device int64)."""
         if self.use_joint_action_loss:
             return self._update_minibatch_jrpo(buffer, chunks, n_chunks, turn_on)
+        if self.generic:  # general towers with a GRU: the layer-wise update over the chunks' rows in [L, n_chunks] order
+            from .ppo_generic import update_minibatch_generic
+
+            T, lanes, L = buffer.episode_length, buffer.n_rollout_threads * buffer.num_agents, self.data_chunk_length
+            if self._rnn_rows is None or self._rnn_rows.numel() < n_chunks * L:
+                self._rnn_rows = torch.empty(n_chunks * L, dtype=torch.int64, device=self.device)
+            rows = self._rnn_rows[:n_chunks * L]
+            ops_rnn.rnn_chunk_rows(chunks, n_chunks, L, T, lanes, rows)
+            return update_minibatch_generic(self, buffer, rows, n_chunks * L, turn_on, rnn=(L, n_chunks))
         mod = self.algo_module
         p, c = mod.models["policy"], mod.models["critic"]
         po, co = mod.optimizers["policy"], mod.optimizers["critic"]

@@ -22,7 +22,10 @@ def _loss_sums(ws, name: str, nb: int, width: int):
     return ws.loss_sums[name]
 
 
-def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool) -> None:
+def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None) -> None:
+    """``rnn = (L, n_chunks)``: recurrent towers - ``idx`` holds the chunks' record rows in [L, n_chunks] order
+    (``orl_rnn_chunk_rows``), the GRU between trunk and head runs over the L steps from the stored states at the chunk
+    starts (recurrent_generator, replay_data.py:1062-1258; RNNLayer, rnn.py:39-99)."""
     mod = algo.algo_module
     rec = buffer.records
     Dp, Dc, a_w, K = buffer.Dp, buffer.Dc, buffer.act_shape, buffer.K
@@ -53,6 +56,14 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool) -> None:
     xp = wp.v(wp.x0, mb, Dp)
     ops_gen.gather_cols(rec, 0, Dp, idx, mb, xp)
     feats_p = gn.trunk_forward(pn, wp, xp, True)
+    trunk_p = trunk_c = gp = gc = mrows = None
+    if rnn is not None:
+        L, Nc = rnn
+        H = pn.H
+        mrows = buffer.masks.reshape(-1)[idx]                    # mask of step l of chunk i: the same row index
+        h0p = buffer.rnn_states.reshape(-1, H)[idx[:Nc]]         # stored states at the chunk starts
+        gp = mod.gru_workspace(pn, L, Nc, True, "p")
+        trunk_p, feats_p = feats_p, gn.gru_forward(pn, gp, feats_p, h0p, mrows, L, Nc, True)
     logits = gn.head_forward(pn, wp, "act", feats_p)
     if one_pass:
         wc, feats_c = wp, feats_p
@@ -61,6 +72,10 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool) -> None:
         xc = wc.v(wc.x0, mb, Dc)
         ops_gen.gather_cols(rec, Dp, Dc, idx, mb, xc)
         feats_c = gn.trunk_forward(cn, wc, xc, True)
+        if rnn is not None:
+            h0c = buffer.rnn_states_critic.reshape(-1, cn.H)[idx[:Nc]]
+            gc = mod.gru_workspace(cn, L, Nc, True, "c")
+            trunk_c, feats_c = feats_c, gn.gru_forward(cn, gc, feats_c, h0c, mrows, L, Nc, True)
     values = gn.head_forward(cn, wc, "v_out", feats_c)
 
     # ---- losses: d loss / d head outputs (already divided by the denominators) + statistics
@@ -119,11 +134,15 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool) -> None:
             dfeat = wp.v(wp.dfeat, mb, pn.H)
             gn.head_backward(pn, wp, "act", feats_p, dlogits, dfeat, False)
             logstd_grad(pn)
+            if rnn is not None:
+                dfeat = gn.gru_backward(pn, gp, trunk_p, mrows, dfeat, L, Nc)
             gn.trunk_backward(pn, wp, dfeat)
             step(pn, popt, 1, 3, -1)
         cn.grad.zero_()
         dfeat = wc.v(wc.dfeat, mb, cn.H)
         gn.head_backward(cn, wc, "v_out", feats_c, dvalues, dfeat, False)
+        if rnn is not None:
+            dfeat = gn.gru_backward(cn, gc, trunk_c, mrows, dfeat, L, Nc)
         gn.trunk_backward(cn, wc, dfeat)
         step(cn, copt, 1, 4, -1)
 

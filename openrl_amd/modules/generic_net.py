@@ -493,13 +493,19 @@ class GenericPPOModule(PPOModule):
                  device="cuda:0", rank=None, world_size=None, model_dict=None):
         if model_dict:
             raise NotImplementedError("custom model_dict networks are not built")
-        for flag in ("use_recurrent_policy", "use_naive_recurrent_policy", "use_influence_policy",
-                     "use_policy_vhead", "use_attn", "use_conv1d", "use_amp", "use_deepspeed", "use_joint_action_loss"):
+        for flag in ("use_influence_policy", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp", "use_deepspeed",
+                     "use_joint_action_loss"):
             if getattr(cfg, flag, False):
                 raise NotImplementedError("cfg.%s=True is not built for the general towers" % flag)
         self.cfg = cfg
         self.device = nat.require_gpu(device)
-        self.recurrent = False
+        # use_naive_recurrent_policy builds the same RNNLayer towers (policy_network.py:82-90)
+        self.recurrent = bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy)
+        if self.recurrent:
+            if cfg.recurrent_N != 1 or getattr(cfg, "rnn_type", "gru") != "gru":
+                raise NotImplementedError("recurrent towers are built for a one-layer GRU (recurrent_N=1, rnn_type=gru)")
+            if share_model or cfg.use_share_model:
+                raise NotImplementedError("use_share_model with a recurrent policy is not built")
         self.lr, self.critic_lr = cfg.lr, cfg.critic_lr
         self.opti_eps, self.weight_decay = cfg.opti_eps, cfg.weight_decay
         self.act_space = act_space
@@ -522,9 +528,9 @@ class GenericPPOModule(PPOModule):
             self.optimizers = {"model": GenAdam(model, cfg.lr, cfg.opti_eps, cfg.weight_decay)}
             pol = model
         else:
-            policy = GenNet("policy", cfg, self.Dp, act_space, self.device)
+            policy = GenNet("policy", cfg, self.Dp, act_space, self.device, recurrent=self.recurrent)
             policy.host_init(cfg)  # RNG order: policy first, then critic (rl_module.py:65-87)
-            critic = GenNet("critic", cfg, self.Dc, act_space, self.device)
+            critic = GenNet("critic", cfg, self.Dc, act_space, self.device, recurrent=self.recurrent)
             critic.host_init(cfg)
             if cfg.use_valuenorm:
                 critic.value_normalizer = ValueNorm(1, device=self.device)
@@ -558,6 +564,13 @@ class GenericPPOModule(PPOModule):
         if ws is None or ws.rows < rows:
             ws = self._ws[key] = GenWorkspace(net, rows, training)
         return ws
+
+    def gru_workspace(self, net: GenNet, L: int, N: int, training: bool, tag: str = "") -> "GruWorkspace":
+        key = ("gru", id(net), training, tag)
+        gw = self._ws.get(key)
+        if gw is None or gw.L * gw.N < L * N or gw.N < N:
+            gw = self._ws[key] = GruWorkspace(net, L, N, training)
+        return gw
 
     def _logstd(self):
         h = self.policy_net.heads["act"]
@@ -614,28 +627,74 @@ class GenericPPOModule(PPOModule):
                 values.copy_(v)
         return values, actions, logp
 
+    def _tower_step(self, net: GenNet, tag: str, x, h_in, mk, B: int):
+        """Trunk + one GRU step of ``B`` rows: (LayerNorm(h_new) [B, H], h_new [B, H])."""
+        ws = self.workspace(net, B, False, tag)
+        desc = net.mlp_desc(())
+        if desc is not None:  # the whole trunk in one launch
+            feats = ws.v(ws.layers[-1]["y"], B, net.H)
+            ops_gen.mlp_fwd(desc, x, None, None, feats)
+        else:
+            feats = trunk_forward(net, ws, x, False)
+        gw = self.gru_workspace(net, 1, B, False, tag)
+        y = gru_forward(net, gw, feats, h_in, mk, 1, B, False)
+        return ws, y, gw.h[:B]
+
+    @torch.no_grad()
+    def _forward_rnn(self, critic_obs, obs, h_policy, h_critic, masks, action_masks, deterministic, want_value=True,
+                     want_action=True, forced_u=None, out=None, h_out=None):
+        """Recurrent get_actions / get_values / act (same contract as ``PPOModule._forward_rnn``): states [B, (1,) H] in,
+        new states out (``h_out`` = pair of destination tensors, e.g. the buffer's next slot)."""
+        pn, cn = self.policy_net, self.critic_net
+        H = pn.H
+        x = self._dev(obs, self.Dp) if want_action else None
+        xc = self._dev(critic_obs, self.Dc) if want_value else None
+        B = (x if x is not None else xc).shape[0]
+        mk = self._dev(masks, 1).reshape(B)
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=self.device)
+        if out is None:
+            values = f(B, 1) if want_value else None
+            actions, logp = (f(B, self.act_width), f(B, self.act_width)) if want_action else (None, None)
+        else:
+            values, actions, logp = out
+        hp_out, hc_out = h_out if h_out is not None else (f(B, H) if want_action else None, f(B, H) if want_value else None)
+        if want_action:
+            ws, y, h_new = self._tower_step(pn, "p", x, self._dev(h_policy, H), mk, B)
+            logits = head_forward(pn, ws, "act", y)
+            am = self._dev(action_masks, self.n_logits) if (action_masks is not None and self.K) else None
+            ops_gen.sample(pn.head_desc, logits, self._logstd(), am, B, deterministic, self.act_seed, 0, self.rng_step,
+                           self.rng_step_dev, self._dev(forced_u, self.act_width), self.act_width, actions, logp)
+            if not deterministic:
+                self.rng_step += 1
+            hp_out.copy_(h_new.view_as(hp_out))
+        if want_value:
+            ws, y, h_new = self._tower_step(cn, "c", xc, self._dev(h_critic, H), mk, B)
+            values.copy_(head_forward(cn, ws, "v_out", y))
+            hc_out.copy_(h_new.view_as(hc_out))
+        return values, actions, logp, hp_out, hc_out
+
     def get_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks=None,
                     deterministic=False):
+        if self.recurrent:
+            return PPOModule.get_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks,
+                                         deterministic)
         values, actions, logp = self._forward(critic_obs, obs, action_masks, deterministic)
         return values, actions, logp, rnn_states_actor, rnn_states_critic
 
     def get_values(self, critic_obs, rnn_states_critic, masks):
+        if self.recurrent:
+            return self._forward_rnn(critic_obs, None, None, rnn_states_critic, masks, None, True, want_action=False)[0]
         return self._forward(critic_obs, None, None, True, want_action=False)[0]
 
     def act(self, obs, rnn_states_actor, masks, action_masks=None, deterministic=False):
+        if self.recurrent:
+            return PPOModule.act(self, obs, rnn_states_actor, masks, action_masks, deterministic)
         _, actions, _ = self._forward(None, obs, action_masks, deterministic, want_value=False)
         return actions, rnn_states_actor
 
-    @torch.no_grad()
-    def evaluate_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, action, masks, action_masks=None,
-                         active_masks=None, critic_masks_batch=None):
-        """Forward-only ``PPOModule.evaluate_actions`` (ppo_module.py:149-193): values, log-probs, dist_entropy."""
+    def _logp_entropy(self, logits, action, action_masks, active_masks, B: int):
+        """ACTLayer.evaluate_actions on dense rows: log-probs [B, a_w] and the (masked) mean entropy."""
         pn = self.policy_net
-        x = self._dev(obs, self.Dp)
-        B = x.shape[0]
-        values = self.get_values(critic_obs, None, None)
-        ws = self.workspace(pn, B, False, "p")
-        logits = head_forward(pn, ws, "act", trunk_forward(pn, ws, x, False))
         a_w, K = self.act_width, self.K
         R = ops.record_width(self.Dp, self.Dc, a_w, K)
         rec = torch.zeros(B, R, dtype=torch.float32, device=self.device)
@@ -648,14 +707,60 @@ class GenericPPOModule(PPOModule):
         ent = torch.empty(B, dtype=torch.float32, device=self.device)
         ops_gen.policy_eval(pn.head_desc, logits, self._logstd(), rec, self.Dp, self.Dc, a_w, K, B,
                             ops.make_hparams(self.cfg), logp, ent)
-        if active_masks is not None:
+        if active_masks is not None and self.cfg.use_policy_active_masks:  # policy_network.py:196-201
             am = self._dev(active_masks, 1).reshape(-1)
             dist_entropy = (ent * am).sum() / am.sum()
         else:
             dist_entropy = ent.mean() / (self.n_logits if self.act_kind == ops_gen.HEAD_GAUSSIAN else 1)
+        return logp, dist_entropy
+
+    @torch.no_grad()
+    def evaluate_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, action, masks, action_masks=None,
+                         active_masks=None, critic_masks_batch=None):
+        """Forward-only ``PPOModule.evaluate_actions`` (ppo_module.py:149-193): values, log-probs, dist_entropy."""
+        if self.recurrent:
+            return self._evaluate_actions_rnn(critic_obs, obs, rnn_states_actor, rnn_states_critic, action, masks,
+                                              action_masks, active_masks, critic_masks_batch)
+        pn = self.policy_net
+        x = self._dev(obs, self.Dp)
+        B = x.shape[0]
+        values = self.get_values(critic_obs, None, None)
+        ws = self.workspace(pn, B, False, "p")
+        logits = head_forward(pn, ws, "act", trunk_forward(pn, ws, x, False))
+        logp, dist_entropy = self._logp_entropy(logits, action, action_masks, active_masks, B)
         return values, logp, dist_entropy, None
 
-    # ------------------------------------------------------------------ reference interface
+    @torch.no_grad()
+    def _evaluate_actions_rnn(self, critic_obs, obs, h_policy, h_critic, action, masks, action_masks, active_masks,
+                              critic_masks=None, critic_states_rows=None):
+        """Recurrent evaluate_actions (policy_network.py:164-203 + RNNLayer.forward): the rows are L steps of N sequences
+        flattened [L * N, ...] (recurrent_generator's layout), the states [N, (1,) H] enter step 0."""
+        pn, cn = self.policy_net, self.critic_net
+        H = pn.H
+        x = self._dev(obs, self.Dp)
+        hp = self._dev(h_policy, H)
+        Np, Bp = hp.shape[0], x.shape[0]
+        assert Bp % Np == 0, "rows must be L steps of the %d policy sequences" % Np
+        L = Bp // Np
+        mk = self._dev(masks, 1).reshape(-1)
+        ws = self.workspace(pn, Bp, False, "p")
+        feats = trunk_forward(pn, ws, x, False)
+        y = gru_forward(pn, self.gru_workspace(pn, L, Np, False, "pe"), feats, hp, mk, L, Np, False)
+        logits = head_forward(pn, ws, "act", y)
+        logp, dist_entropy = self._logp_entropy(logits, action, action_masks, active_masks, Bp)
+        values = None
+        if critic_obs is not None:
+            xc = self._dev(critic_obs, self.Dc)
+            hc = self._dev(h_critic, H)
+            Nc = hc.shape[0]
+            assert xc.shape[0] == L * Nc, "critic rows must be the same L steps of its %d sequences" % Nc
+            mkc = mk if critic_masks is None else self._dev(critic_masks, 1).reshape(-1)
+            wc = self.workspace(cn, L * Nc, False, "c")
+            fc = trunk_forward(cn, wc, xc, False)
+            yc = gru_forward(cn, self.gru_workspace(cn, L, Nc, False, "ce"), fc, hc, mkc, L, Nc, False)
+            values = head_forward(cn, wc, "v_out", yc).clone()
+        return values, logp, dist_entropy, None
+
     def lr_decay(self, episode, episodes):
         if self.share_model:
             self.optimizers["model"].param_groups[0]["lr"] = self.lr - (self.lr * (episode / float(episodes)))

@@ -242,8 +242,7 @@ class PPOModule:
         if cls is PPOModule and act_space is not None:
             from .generic_net import GenericPPOModule, needs_generic
 
-            if needs_generic(cfg, act_space, share_model) and not (cfg.use_recurrent_policy
-                                                                    or cfg.use_naive_recurrent_policy):
+            if needs_generic(cfg, act_space, share_model):  # recurrent or not: GenNet carries the GRU too
                 return object.__new__(GenericPPOModule)
         return object.__new__(cls)
 

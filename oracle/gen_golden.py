@@ -655,6 +655,15 @@ def main():
         "train_recurrent_chunk5": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--data_chunk_length", "5"], 6, 6,
             lambda: Box(-1, 1, (2,)), N=5, A=1, T=10, seed=6),
+        # recurrent GENERAL towers (any hidden_size / layer_N / activation + the GRU of rnn.py): hidden 128 at the MPE
+        # shape; a tanh tower with layer_N 2, feature norm, Box actions and chunks of 4 that straddle lanes (T = 10)
+        "train_recurrent_gen_h128": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--hidden_size", "128", "--lr", "7e-4", "--critic_lr", "7e-4"],
+            18, 54, lambda: Discrete(5), N=6, A=3, T=7, seed=31),
+        "train_recurrent_gen_l2_tanh_fn": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--hidden_size", "32", "--layer_N", "2", "--activation_id",
+                "0", "--use_feature_normalization", "true", "--data_chunk_length", "4"], 6, 6,
+            lambda: Box(-1, 1, (2,)), N=5, A=1, T=10, seed=32),
     }
     for name, fn in cases.items():
         if want(name):

@@ -223,3 +223,113 @@ def test_recurrent_evaluate_actions_vs_oracle():
     np.testing.assert_allclose(v.cpu().numpy(), want_v.detach().numpy(), rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(lp.cpu().numpy(), want_lp.detach().numpy(), rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(float(ent), float(want_ent), rtol=1e-4)
+
+
+# ---- recurrent GENERAL towers (hidden_size / layer_N / activation / feature norm + the GRU): modules/generic_net.py ----
+GEN_RNN_CASES = [("train_recurrent_gen_h128", 31), ("train_recurrent_gen_l2_tanh_fn", 32)]
+_BUF_FIELDS = ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks",
+               "bad_masks", "active_masks", "action_masks", "rnn_states", "rnn_states_critic")
+
+
+def _load_case(g, buf, module):
+    module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+    module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+    for f in _BUF_FIELDS:
+        if "buf_" + f in g and getattr(buf, f) is not None:
+            getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+
+
+@pytest.mark.parametrize("case,seed", GEN_RNN_CASES)
+def test_general_recurrent_towers_init_and_state_dict_are_the_reference_s(case, seed):
+    g = H.load_golden(case)
+    cfg, module, _, _ = build_engine(g, seed=seed)
+    assert module.generic and module.recurrent
+    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p0"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c0"], rtol=1e-4, atol=3e-5)
+    Hs = cfg.hidden_size
+    sd = module.models["critic"].state_dict()
+    assert sd["rnn.rnn.weight_hh_l0"].shape == (3 * Hs, Hs) and sd["rnn.norm.weight"].shape == (Hs,)
+    keys = [k for k in sd if not k.startswith("value_normalizer")]
+    assert keys.index("rnn.rnn.weight_ih_l0") < keys.index("v_out.weight") and keys[-1] == "v_out.bias"
+
+
+@pytest.mark.parametrize("case,seed", GEN_RNN_CASES)
+def test_general_recurrent_train_matches_reference_golden(case, seed):
+    """PPOAlgorithm.train on recurrent general towers (trunk layer kernels + GRU BPTT over the chunks) vs the reference's
+    own train(): the chunk permutation stream, the final weights of both towers, train_info and the ValueNorm state."""
+    g = H.load_golden(case)
+    cfg, module, buf, algo = build_engine(g)
+    _load_case(g, buf, module)
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    info = algo.train(buf)
+    T, N, A = g["buf_actions"].shape[:3]
+    chunks = T * N * A // cfg.data_chunk_length
+    torch.manual_seed(int(g["perm_seed"]))
+    mbs = chunks // cfg.num_mini_batch
+    want = []
+    for _ in range(cfg.ppo_epoch):  # replay_data.py:1078-1082
+        perm = torch.randperm(chunks).numpy()
+        want += [perm[i * mbs:(i + 1) * mbs] for i in range(cfg.num_mini_batch)]
+    assert len(algo.last_indices) == len(want)
+    for got, w in zip(algo.last_indices, want):
+        assert np.array_equal(got.cpu().numpy(), w)
+    np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
+    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("case,seed", GEN_RNN_CASES)
+def test_general_recurrent_stepwise_rollout_reproduces_the_reference_buffer(case, seed):
+    """Teacher-forced get_actions step by step: hidden states and values of every slot against the reference's buffer."""
+    g = H.load_golden(case)
+    cfg, module, buf, algo = build_engine(g)
+    _load_case(g, buf, module)
+    buf.rnn_states.zero_(); buf.rnn_states_critic.zero_()
+    T, N, A = g["buf_actions"].shape[:3]
+    Hs = cfg.hidden_size
+    for t in range(T):
+        v, a, lp, hp, hc = module.get_actions(buf.get_batch_data("critic_obs", t), buf.get_batch_data("policy_obs", t),
+                                              buf.get_batch_data("rnn_states", t), buf.get_batch_data("rnn_states_critic", t),
+                                              buf.get_batch_data("masks", t))
+        assert hp.shape == (N * A, 1, Hs)
+        m = buf.masks[t + 1].unsqueeze(-1)
+        buf.rnn_states[t + 1].copy_(hp.view(N, A, 1, Hs) * m)
+        buf.rnn_states_critic[t + 1].copy_(hc.view(N, A, 1, Hs) * m)
+        np.testing.assert_allclose(v.cpu().numpy().reshape(N, A, 1), g["buf_value_preds"][t], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(buf.rnn_states.cpu().numpy(), g["buf_rnn_states"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(buf.rnn_states_critic.cpu().numpy(), g["buf_rnn_states_critic"], rtol=3e-4, atol=3e-5)
+    nv = module.get_values(buf.get_batch_data("critic_obs", -1), buf.rnn_states_critic[-1].reshape(-1, Hs),
+                           buf.masks[-1].reshape(-1, 1))
+    np.testing.assert_allclose(nv.cpu().numpy().reshape(N, A, 1), g["next_values"], rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("argv", [["--hidden_size", "128"], ["--hidden_size", "32", "--layer_N", "2", "--activation_id", "0",
+                                                             "--use_naive_recurrent_policy", "true", "--use_recurrent_policy", "false"]])
+def test_general_recurrent_agent_trains_mpe_end_to_end(argv, tmp_path):
+    """make / PPONet / PPOAgent.train with a recurrent policy on NON-default towers on the device MPE env: the stepwise
+    rollout (captured into a hipGraph after the first iteration) carries the GRU states through the buffer, the update
+    runs the chunked BPTT; save / load round trip."""
+    from openrl_amd.configs.config import create_config_parser
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import PPOAgent as Agent
+
+    base = ["--episode_length", "25", "--ppo_epoch", "2", "--num_mini_batch", "2", "--use_recurrent_policy", "true"]
+    cfg = create_config_parser().parse_args(base + argv)
+    env = make("simple_spread", env_num=16)
+    agent = Agent(Net(env, cfg=cfg))
+    mod = agent.net.module
+    assert mod.generic and mod.recurrent
+    th0 = mod.models["policy"].theta.clone()
+    agent.train(total_time_steps=16 * 25 * 3)
+    assert agent.driver._graph is not None and not agent.driver.fused
+    assert not torch.equal(th0, mod.models["policy"].theta) and torch.isfinite(mod.models["policy"].theta).all()
+    assert float(agent.driver.buffer.data.rnn_states.abs().sum()) > 0
+    agent.save(str(tmp_path / "a"))
+    agent.load(str(tmp_path / "a"))
+    obs, info = env.reset(seed=1)
+    action, _ = agent.act(obs, deterministic=True)
+    assert action.shape == (16, 3, 1)
+    env.close()
