@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--envs", type=int, default=2048)
     ap.add_argument("--rollout", default="auto", choices=["auto", "fused", "stepwise"])
+    ap.add_argument("--hidden_size", type=int, default=64, help="!= 64: the recurrent GENERAL towers (modules/generic_net.py)")
+    ap.add_argument("--layer_N", type=int, default=1)
     a = ap.parse_args()
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers import NormalReplayBuffer
@@ -36,7 +38,8 @@ def main():
     dev, N, T = "cuda:0", a.envs, 25
     cfg = default_cfg(["--seed", "0", "--lr", "7e-4", "--critic_lr", "7e-4", "--episode_length", str(T),
                        "--use_recurrent_policy", "true", "--use_valuenorm", "true", "--use_adv_normalize", "true",
-                       "--amd_perm_mode", "device", "--amd_rollout_mode", a.rollout, "--log_interval", "1000000"])
+                       "--amd_perm_mode", "device", "--amd_rollout_mode", a.rollout, "--log_interval", "1000000",
+                       "--hidden_size", str(a.hidden_size), "--layer_N", str(a.layer_N)])
     env = make("simple_spread", env_num=N, device=dev)
     net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=N)
     cfg.num_env_steps = N * T * (a.steps + a.warmup)
@@ -71,6 +74,8 @@ def main():
     st = env.episode_statistics()
     print(json.dumps({"bench": "cfg4_mpe_recurrent_mappo", "envs": N, "agents": 3, "episode_length": T,
                       "ppo_epoch": cfg.ppo_epoch, "data_chunk_length": cfg.data_chunk_length,
+                      "hidden_size": a.hidden_size, "layer_N": a.layer_N,
+                      "towers": "general" if getattr(net.module, "generic", False) else "fused default",
                       "rollout": "fused" if drv.fused else "stepwise (hipGraph)",
                       # 0 unless a critic workgroup's bounded wait for its policy workgroup ever timed out
                       "chase_error": int(drv._chase_flags[-1]) if getattr(drv, "_chase_flags", None) is not None else None,

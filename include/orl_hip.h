@@ -691,6 +691,10 @@ int orl_gen_adam(const orl_adam_state* adam, int64_t n, float max_grad_norm, int
 /* dst[0..n) += src[0..n): gradient accumulation when a shared trunk is back-propagated twice (policy and critic
  * observations differ) or two heads feed one feature gradient. */
 int orl_vec_add(float* dst, const float* src, int64_t n, void* stream);
+/* dst[c] = sum over the n_rows rows of x[r][c] (a bias gradient from a tall [rows, width] gradient matrix), in a fixed
+ * order: row slabs into `partials` (>= width floats; up to 512 * width are used), then orl_gen_colsum. */
+int orl_gen_colsum_rows(const float* x, int n_rows, int width, float* dst, float* partials, int64_t partials_floats,
+                        void* stream);
 /* One step of torch.nn.GRU (one layer; RNNLayer, networks/utils/rnn.py:28-99) after its two projections
  * gi = x W_ih^T + b_ih and gh = h_in W_hh^T + b_hh ([N, 3H], column blocks r | z | n): h_out = (1 - z) n + z h_in.
  * save [N, 4H] = (r, z, n, gh_n) feeds orl_gen_gru_gate_bwd (may be NULL); h_in_next = h_out * mask_next[row] is the

@@ -74,7 +74,8 @@ template <int NB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
     const float* __restrict__ x, int B, int n_in, const float* __restrict__ W, const float* __restrict__ bias, int act,
     const float* __restrict__ gamma, const float* __restrict__ beta, int n_out, float* __restrict__ a_out,
-    float* __restrict__ stats_out, float* __restrict__ y_out) {
+    float* __restrict__ stats_out, float* __restrict__ y_out, int ldo) {
+  // ldo: row stride of a_out / y_out (== n_out except when a wide layer WITHOUT LayerNorm is computed in column blocks)
   constexpr int BM = 16 * WAVES, NP = 16 * NB, XLD = BM + 16, WLD = NP + 16, NTH = 64 * WAVES;
   constexpr int KQ = GF_KC / 4;                       // float4 units per chunk row
   constexpr int XU = (BM * KQ + NTH - 1) / NTH;       // float4 units of the x chunk per thread
@@ -245,12 +246,12 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
       const bool cv = 16 * t + i < n_out;
       v[t] = cv ? act_fwd(acc[t][r] + bs[t], act) : 0.f;
       s += v[t];
-      if (rv && cv && a_out) a_out[row * n_out + 16 * t + i] = v[t];
+      if (rv && cv && a_out) a_out[row * ldo + 16 * t + i] = v[t];
     }
     if (gamma == nullptr) {
 #pragma unroll
       for (int t = 0; t < NB; ++t)
-        if (rv && 16 * t + i < n_out && y_out) y_out[row * n_out + 16 * t + i] = v[t];
+        if (rv && 16 * t + i < n_out && y_out) y_out[row * ldo + 16 * t + i] = v[t];
       continue;
     }
     const float mean = sum16(s) * inv_n;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
     }
 #pragma unroll
     for (int t = 0; t < NB; ++t)
-      if (rv && 16 * t + i < n_out && y_out) y_out[row * n_out + 16 * t + i] = v[t] * rstd * gm[t] + bt[t];
+      if (rv && 16 * t + i < n_out && y_out) y_out[row * ldo + 16 * t + i] = v[t] * rstd * gm[t] + bt[t];
   }
 }
 
@@ -972,18 +973,35 @@ __global__ __launch_bounds__(1024) void gen_colsum_kernel(const float* __restric
   }
 }
 
+// partials[b][c] = sum of x[r][c] over the rows r = b, b + gridDim.x, ... (fixed order); gen_colsum_kernel finishes
+__global__ __launch_bounds__(256) void gen_rowslab_sum_kernel(const float* __restrict__ x, long long n_rows, int width,
+                                                              float* __restrict__ partials) {
+  for (int c = threadIdx.x; c < width; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    long long r = blockIdx.x;
+    for (; r + gridDim.x < n_rows; r += 2 * (long long)gridDim.x) {
+      s0 += x[r * width + c];
+      s1 += x[(r + gridDim.x) * width + c];
+    }
+    if (r < n_rows) s0 += x[r * width + c];
+    partials[(size_t)blockIdx.x * width + c] = s0 + s1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 template <int NB, int WAVES>
 static int launch_fwd(const float* x, int B, int n_in, const float* W, const float* bias, int act, const float* gamma,
-                      const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, hipStream_t s) {
+                      const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, hipStream_t s,
+                      int ldo = 0) {
   constexpr int BM = 16 * WAVES, NP = 16 * NB;
+  if (ldo == 0) ldo = n_out;
   size_t fl = (size_t)2 * GF_KC * ((BM + 16) + (NP + 16));
   if (fl < (size_t)WAVES * 16 * (NP + 4)) fl = (size_t)WAVES * 16 * (NP + 4);
   const size_t lds = fl * sizeof(float);
   (void)hipFuncSetAttribute((const void*)gen_layer_fwd_kernel<NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const unsigned grid = (unsigned)(((long long)B + BM - 1) / BM);
   hipLaunchKernelGGL((gen_layer_fwd_kernel<NB, WAVES>), dim3(grid), dim3(64 * WAVES), lds, s, x, B, n_in, W, bias, act, gamma,
-                     beta, n_out, a_out, stats_out, y_out);
+                     beta, n_out, a_out, stats_out, y_out, ldo);
   return launch_status("orl_gen_layer_fwd");
 }
 
@@ -1051,6 +1069,21 @@ int orl_gen_layer_fwd(const float* x, int B, int n_in, const float* W, const flo
   return launch_fwd<NB, WV>(x, B, n_in, W, bias, act, gamma, beta, n_out, a_out, stats_out, y_out, s)
   // rollout-sized batches: 16-row workgroups so that a few thousand rows still cover the chip
   const bool skinny = B <= 16 * 1024;
+  if (gamma == nullptr && n_out > 128) {
+    // no LayerNorm: output columns are independent, so a wide projection (the GRU's 3 H gate columns) runs as 128-column
+    // blocks of the 8-tile kernel instead of one 32-tile-per-wave launch (256 registers, 2 waves per workgroup)
+    for (int c0 = 0; c0 < n_out; c0 += 128) {
+      const int nb_cols = n_out - c0 < 128 ? n_out - c0 : 128;
+      const float* Wc = W + (size_t)c0 * n_in;
+      const float* bc = bias ? bias + c0 : nullptr;
+      float* ac = a_out ? a_out + c0 : nullptr;
+      float* yc = y_out ? y_out + c0 : nullptr;
+      const int rc = skinny ? launch_fwd<8, 1>(x, B, n_in, Wc, bc, act, nullptr, nullptr, nb_cols, ac, nullptr, yc, s, n_out)
+                            : launch_fwd<8, 4>(x, B, n_in, Wc, bc, act, nullptr, nullptr, nb_cols, ac, nullptr, yc, s, n_out);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if (n_out <= 16) { if (skinny) ORL_GF_FWD(1, 1); ORL_GF_FWD(1, 4); }
   if (n_out <= 32) { if (skinny) ORL_GF_FWD(2, 1); ORL_GF_FWD(2, 4); }
   if (n_out <= 64) { if (skinny) ORL_GF_FWD(4, 1); ORL_GF_FWD(4, 4); }
@@ -1151,6 +1184,21 @@ int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* 
   else ORL_MLP_LAUNCH(4);
 #undef ORL_MLP_LAUNCH
   return launch_status("orl_gen_mlp_fwd");
+}
+
+int orl_gen_colsum_rows(const float* x, int n_rows, int width, float* dst, float* partials, int64_t partials_floats,
+                        void* stream) {
+  ORL_REQUIRE(x && dst && partials && n_rows > 0 && width > 0, "orl_gen_colsum_rows: bad arguments");
+  long long nb = partials_floats / width;
+  if (nb > 512) nb = 512;
+  if (nb > n_rows) nb = n_rows;
+  ORL_REQUIRE(nb >= 1, "orl_gen_colsum_rows: the partials buffer (%lld floats) does not hold one row of %d columns",
+              (long long)partials_floats, width);
+  hipLaunchKernelGGL(gen_rowslab_sum_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long long)n_rows,
+                     width, partials);
+  int rc = launch_status("orl_gen_colsum_rows");
+  if (rc) return rc;
+  return orl_gen_colsum(partials, (int)nb, width, dst, width, nullptr, 0, nullptr, 0, stream);
 }
 
 int orl_gen_wgrad(const float* dz, const float* x, int B, int n_out, int n_in, float* dW, float* partials,

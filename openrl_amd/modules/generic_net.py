@@ -474,8 +474,7 @@ def gru_backward(net: GenNet, gw: GruWorkspace, feats: torch.Tensor, masks: torc
     ops_gen.wgrad(gw.dgi[:B], feats, net.v(r["Wih"], 3 * H, H, grad=True), gw.wgrad_partials)
     ops_gen.wgrad(gw.dgh[:B], gw.h_in[:B], net.v(r["Whh"], 3 * H, H, grad=True), gw.wgrad_partials)
     for d, off in ((gw.dgi, r["bih"]), (gw.dgh, r["bhh"])):
-        nb = ops_gen.layer_bwd(d[:B], None, None, None, ops_gen.ACT_NONE, None, None, None, gw.col_partials)
-        ops_gen.colsum(gw.col_partials, nb, [(None, 3 * H), (None, 3 * H), (net.v(off, 3 * H, grad=True), 3 * H)])
+        ops_gen.colsum_rows(d[:B], net.v(off, 3 * H, grad=True), gw.col_partials)
     ops_gen.linear_dgrad(gw.dgi[:B], Wih, gw.dfeat[:B])
     return gw.dfeat[:B]
 

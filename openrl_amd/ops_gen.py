@@ -204,6 +204,14 @@ def adam(state: AdamState, n: int, max_grad_norm: float, use_max_grad_norm: bool
     nat.check(rc, "orl_gen_adam")
 
 
+def colsum_rows(x, dst, partials) -> None:
+    """dst[c] = sum_r x[r, c] of a tall matrix (``orl_gen_colsum_rows``, fixed summation order)."""
+    n_rows, width = x.shape
+    rc = _lib().orl_gen_colsum_rows(fptr(x), n_rows, width, fptr(dst), fptr(partials), partials.numel(),
+                                    stream_ptr(nat.require_gpu(x.device)))
+    nat.check(rc, "orl_gen_colsum_rows")
+
+
 def gru_gate_fwd(gi, gh, h_in, mask_next, h_out, h_in_next, save) -> None:
     """GRU gates of one step after the two projections (``orl_gen_gru_gate_fwd``)."""
     N, H = h_in.shape

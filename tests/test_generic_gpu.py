@@ -195,7 +195,7 @@ _ACTS = {0: torch.tanh, 1: torch.relu, 2: torch.nn.functional.leaky_relu, 3: tor
                                                  (640, 128, 5, -1, False), (333, 6, 100, 1, True), (64, 128, 1, -1, False),
                                                  (20001, 128, 128, 1, True), (17000, 4, 64, 0, True), (16500, 256, 256, 1, True),
                                                  (16400, 64, 9, -1, False), (18000, 32, 32, 2, True), (17001, 96, 96, 3, True),
-                                                 (16390, 20, 128, 1, True)])
+                                                 (16390, 20, 128, 1, True), (700, 64, 384, -1, False), (17000, 128, 384, -1, False), (900, 36, 300, 0, False)])
 def test_fused_layer_kernels_against_torch_fp64(B, n_in, n_out, act, ln):
     """orl_gen_layer_fwd / orl_gen_layer_bwd / orl_gen_wgrad / orl_gen_colsum vs nn.Sequential(Linear, act, LayerNorm)
     evaluated by torch autograd in fp64 (mlp.py:8-46).  Tolerances: fp32 accumulation over K <= 512 products and B rows."""
