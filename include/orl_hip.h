@@ -691,6 +691,9 @@ int orl_gen_adam(const orl_adam_state* adam, int64_t n, float max_grad_norm, int
 /* dst[0..n) += src[0..n): gradient accumulation when a shared trunk is back-propagated twice (policy and critic
  * observations differ) or two heads feed one feature gradient. */
 int orl_vec_add(float* dst, const float* src, int64_t n, void* stream);
+/* y [B, N] = x [B, K] W [K, N] (all row-major, fp32 MFMA): an input gradient dz W with W in nn.Linear's [out, in] layout,
+ * through the tiled forward kernel (coalesced float4 loads of both operands, 128 output columns per launch). */
+int orl_gen_matmul(const float* x, int B, int K, const float* W, int N, float* y, void* stream);
 /* dst[c] = sum over the n_rows rows of x[r][c] (a bias gradient from a tall [rows, width] gradient matrix), in a fixed
  * order: row slabs into `partials` (>= width floats; up to 512 * width are used), then orl_gen_colsum. */
 int orl_gen_colsum_rows(const float* x, int n_rows, int width, float* dst, float* partials, int64_t partials_floats,

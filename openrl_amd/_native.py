@@ -199,6 +199,7 @@ _SIGNATURES = {
                                  _P, _P, C.c_int, _P, _P, _P]),
     "orl_gen_adam": (C.c_int, [C.POINTER(AdamState), C.c_int64, C.c_float, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
                                _P]),
+    "orl_gen_matmul": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "orl_gen_colsum_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "orl_gen_gru_gate_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "orl_gen_gru_gate_bwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -70,11 +70,12 @@ __device__ inline float sum_groups(float v) {  // over the 64 / LPR row groups o
 // ------------------------------------------------------------------------------------------------ forward
 // Workgroup = WAVES waves, wave w owns rows [16 w, 16 w + 16) of the tile and ALL n_out <= 16 NB columns.
 // D fragment: lane (i = l & 15, q = l >> 4), tile t, register r  ->  row 4 q + r, column 16 t + i.
-template <int NB, int WAVES>
+// WKN: W is [n_in, n_out'] with row stride ldw (k-major: y = x W, an input gradient dz W) instead of nn.Linear's [n_out, n_in]
+template <int NB, int WAVES, bool WKN = false>
 __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
     const float* __restrict__ x, int B, int n_in, const float* __restrict__ W, const float* __restrict__ bias, int act,
     const float* __restrict__ gamma, const float* __restrict__ beta, int n_out, float* __restrict__ a_out,
-    float* __restrict__ stats_out, float* __restrict__ y_out, int ldo) {
+    float* __restrict__ stats_out, float* __restrict__ y_out, int ldo, int ldw) {
   // ldo: row stride of a_out / y_out (== n_out except when a wide layer WITHOUT LayerNorm is computed in column blocks)
   constexpr int BM = 16 * WAVES, NP = 16 * NB, XLD = BM + 16, WLD = NP + 16, NTH = 64 * WAVES;
   constexpr int KQ = GF_KC / 4;                       // float4 units per chunk row
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
   float* ws = sh_gf + 2 * GF_KC * XLD;  // [2][KC][WLD]   ws[k][n]
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
   const long long m0 = (long long)blockIdx.x * BM;
-  const bool vx = (n_in & 3) == 0 && aligned16(x), vw = (n_in & 3) == 0 && aligned16(W);
+  const bool vx = (n_in & 3) == 0 && aligned16(x);
+  const bool vw = WKN ? ((ldw & 3) == 0 && aligned16(W)) : ((n_in & 3) == 0 && aligned16(W));
 
   f32x4 rx[XU];
   f32x4 rw[WU];
@@ -104,14 +106,26 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
     }
 #pragma unroll
     for (int u0 = 0; u0 < WU; ++u0) {
-      const int u = tid + NTH * u0, n = u / KQ, k = k0 + 4 * (u % KQ);
+      const int u = tid + NTH * u0;
       rw[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < NP * KQ && n < n_out && k < n_in) {
-        const float* p = W + (long long)n * n_in + k;
-        if (vw) rw[u0] = *(const f32x4*)p;
-        else
+      if (WKN) {  // rows of W are k: a unit is 4 consecutive output columns of one k
+        const int k = k0 + u / (NP / 4), n = 4 * (u % (NP / 4));
+        if (u < NP * KQ && k < n_in && n < n_out) {
+          const float* p = W + (long long)k * ldw + n;
+          if (vw && n + 3 < n_out) rw[u0] = *(const f32x4*)p;
+          else
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (k + j < n_in) rw[u0][j] = p[j];
+            for (int j = 0; j < 4; ++j) if (n + j < n_out) rw[u0][j] = p[j];
+        }
+      } else {
+        const int n = u / KQ, k = k0 + 4 * (u % KQ);
+        if (u < NP * KQ && n < n_out && k < n_in) {
+          const float* p = W + (long long)n * n_in + k;
+          if (vw) rw[u0] = *(const f32x4*)p;
+          else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (k + j < n_in) rw[u0][j] = p[j];
+        }
       }
     }
   };
@@ -127,10 +141,16 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
     }
 #pragma unroll
     for (int u0 = 0; u0 < WU; ++u0) {
-      const int u = tid + NTH * u0, n = u / KQ, kq = 4 * (u % KQ);
-      if (u < NP * KQ)
+      const int u = tid + NTH * u0;
+      if (u < NP * KQ) {
+        if (WKN) {
+          *(f32x4*)(wb + (u / (NP / 4)) * WLD + 4 * (u % (NP / 4))) = rw[u0];
+        } else {
+          const int n = u / KQ, kq = 4 * (u % KQ);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wb[(kq + j) * WLD + n] = rw[u0][j];
+          for (int j = 0; j < 4; ++j) wb[(kq + j) * WLD + n] = rw[u0][j];
+        }
+      }
     }
   };
 
@@ -976,32 +996,36 @@ __global__ __launch_bounds__(1024) void gen_colsum_kernel(const float* __restric
 // partials[b][c] = sum of x[r][c] over the rows r = b, b + gridDim.x, ... (fixed order); gen_colsum_kernel finishes
 __global__ __launch_bounds__(256) void gen_rowslab_sum_kernel(const float* __restrict__ x, long long n_rows, int width,
                                                               float* __restrict__ partials) {
+  const long long g = gridDim.x;
   for (int c = threadIdx.x; c < width; c += 256) {
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     long long r = blockIdx.x;
-    for (; r + gridDim.x < n_rows; r += 2 * (long long)gridDim.x) {
+    for (; r + 3 * g < n_rows; r += 4 * g) {  // four rows in flight per thread
       s0 += x[r * width + c];
-      s1 += x[(r + gridDim.x) * width + c];
+      s1 += x[(r + g) * width + c];
+      s2 += x[(r + 2 * g) * width + c];
+      s3 += x[(r + 3 * g) * width + c];
     }
-    if (r < n_rows) s0 += x[r * width + c];
-    partials[(size_t)blockIdx.x * width + c] = s0 + s1;
+    for (; r < n_rows; r += g) s0 += x[r * width + c];
+    partials[(size_t)blockIdx.x * width + c] = (s0 + s1) + (s2 + s3);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ host
-template <int NB, int WAVES>
+template <int NB, int WAVES, bool WKN = false>
 static int launch_fwd(const float* x, int B, int n_in, const float* W, const float* bias, int act, const float* gamma,
                       const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, hipStream_t s,
-                      int ldo = 0) {
+                      int ldo = 0, int ldw = 0) {
   constexpr int BM = 16 * WAVES, NP = 16 * NB;
   if (ldo == 0) ldo = n_out;
   size_t fl = (size_t)2 * GF_KC * ((BM + 16) + (NP + 16));
   if (fl < (size_t)WAVES * 16 * (NP + 4)) fl = (size_t)WAVES * 16 * (NP + 4);
   const size_t lds = fl * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)gen_layer_fwd_kernel<NB, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)gen_layer_fwd_kernel<NB, WAVES, WKN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
   const unsigned grid = (unsigned)(((long long)B + BM - 1) / BM);
-  hipLaunchKernelGGL((gen_layer_fwd_kernel<NB, WAVES>), dim3(grid), dim3(64 * WAVES), lds, s, x, B, n_in, W, bias, act, gamma,
-                     beta, n_out, a_out, stats_out, y_out, ldo);
+  hipLaunchKernelGGL((gen_layer_fwd_kernel<NB, WAVES, WKN>), dim3(grid), dim3(64 * WAVES), lds, s, x, B, n_in, W, bias, act,
+                     gamma, beta, n_out, a_out, stats_out, y_out, ldo, ldw);
   return launch_status("orl_gen_layer_fwd");
 }
 
@@ -1184,6 +1208,21 @@ int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* 
   else ORL_MLP_LAUNCH(4);
 #undef ORL_MLP_LAUNCH
   return launch_status("orl_gen_mlp_fwd");
+}
+
+int orl_gen_matmul(const float* x, int B, int K, const float* W, int N, float* y, void* stream) {
+  ORL_REQUIRE(x && W && y && B > 0 && K > 0 && N > 0, "orl_gen_matmul: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const bool skinny = B <= 16 * 1024;
+  for (int c0 = 0; c0 < N; c0 += 128) {  // 128 output columns per launch (8 accumulator tiles per wave)
+    const int nb_cols = N - c0 < 128 ? N - c0 : 128;
+    const int rc = skinny ? launch_fwd<8, 1, true>(x, B, K, W + c0, nullptr, ORL_ACT_NONE, nullptr, nullptr, nb_cols, nullptr,
+                                                   nullptr, y + c0, s, N, N)
+                          : launch_fwd<8, 4, true>(x, B, K, W + c0, nullptr, ORL_ACT_NONE, nullptr, nullptr, nb_cols, nullptr,
+                                                   nullptr, y + c0, s, N, N);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int orl_gen_colsum_rows(const float* x, int n_rows, int width, float* dst, float* partials, int64_t partials_floats,

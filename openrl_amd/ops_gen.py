@@ -49,10 +49,12 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, z: torch.Tensor) -> None:
 
 
 def linear_dgrad(dz: torch.Tensor, W: torch.Tensor, dx: torch.Tensor) -> None:
-    """dx[B, in] = dz[B, out] @ W[out, in]."""
+    """dx[B, in] = dz[B, out] @ W[out, in] (``orl_gen_matmul``: the tiled kernel with W read k-major)."""
     Bn, K = dz.shape
     N = W.shape[1]
-    gemm(dz, K, 1, W, N, 1, dx, N, Bn, N, K)
+    assert dz.is_contiguous() and W.is_contiguous() and dx.is_contiguous()
+    rc = _lib().orl_gen_matmul(fptr(dz), Bn, K, fptr(W), N, fptr(dx), stream_ptr(nat.require_gpu(dz.device)))
+    nat.check(rc, "orl_gen_matmul")
 
 
 def linear_wgrad(dz: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, partials: torch.Tensor) -> None:
