@@ -76,8 +76,17 @@ __global__ __launch_bounds__(64 * WAVES) void gen_layer_fwd_kernel(
     const float* __restrict__ x, int B, int n_in, const float* __restrict__ W, const float* __restrict__ bias, int act,
     const float* __restrict__ gamma, const float* __restrict__ beta, int n_out, float* __restrict__ a_out,
     float* __restrict__ stats_out, float* __restrict__ y_out, int ldo, int ldw) {
-  // ldo: row stride of a_out / y_out (== n_out except when a wide layer WITHOUT LayerNorm is computed in column blocks)
+  // ldo: row stride of a_out / y_out.  gridDim.y > 1: a wide layer WITHOUT LayerNorm computed in blocks of NP columns
+  // (columns are independent then): block y owns columns [y NP, y NP + NP) of the ldo-wide output.
   constexpr int BM = 16 * WAVES, NP = 16 * NB, XLD = BM + 16, WLD = NP + 16, NTH = 64 * WAVES;
+  if (gridDim.y > 1) {
+    const int c0 = blockIdx.y * NP;
+    W += WKN ? (long long)c0 : (long long)c0 * n_in;
+    if (bias) bias += c0;
+    if (a_out) a_out += c0;
+    if (y_out) y_out += c0;
+    n_out = n_out - c0 < NP ? n_out - c0 : NP;
+  }
   constexpr int KQ = GF_KC / 4;                       // float4 units per chunk row
   constexpr int XU = (BM * KQ + NTH - 1) / NTH;       // float4 units of the x chunk per thread
   constexpr int WU = (NP * KQ + NTH - 1) / NTH;       // ... of the W chunk
@@ -1015,7 +1024,7 @@ __global__ __launch_bounds__(256) void gen_rowslab_sum_kernel(const float* __res
 template <int NB, int WAVES, bool WKN = false>
 static int launch_fwd(const float* x, int B, int n_in, const float* W, const float* bias, int act, const float* gamma,
                       const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, hipStream_t s,
-                      int ldo = 0, int ldw = 0) {
+                      int ldo = 0, int ldw = 0, int col_blocks = 1) {
   constexpr int BM = 16 * WAVES, NP = 16 * NB;
   if (ldo == 0) ldo = n_out;
   size_t fl = (size_t)2 * GF_KC * ((BM + 16) + (NP + 16));
@@ -1024,8 +1033,8 @@ static int launch_fwd(const float* x, int B, int n_in, const float* W, const flo
   (void)hipFuncSetAttribute((const void*)gen_layer_fwd_kernel<NB, WAVES, WKN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   const unsigned grid = (unsigned)(((long long)B + BM - 1) / BM);
-  hipLaunchKernelGGL((gen_layer_fwd_kernel<NB, WAVES, WKN>), dim3(grid), dim3(64 * WAVES), lds, s, x, B, n_in, W, bias, act,
-                     gamma, beta, n_out, a_out, stats_out, y_out, ldo, ldw);
+  hipLaunchKernelGGL((gen_layer_fwd_kernel<NB, WAVES, WKN>), dim3(grid, col_blocks), dim3(64 * WAVES), lds, s, x, B, n_in, W,
+                     bias, act, gamma, beta, n_out, a_out, stats_out, y_out, ldo, ldw);
   return launch_status("orl_gen_layer_fwd");
 }
 
@@ -1084,8 +1093,8 @@ extern "C" {
 
 int orl_gen_layer_fwd(const float* x, int B, int n_in, const float* W, const float* bias, int act, const float* gamma,
                       const float* beta, int n_out, float* a_out, float* stats_out, float* y_out, void* stream) {
-  ORL_REQUIRE(x && W && B > 0 && n_in > 0 && n_out > 0 && n_out <= 512, "orl_gen_layer_fwd: bad arguments (B=%d n_in=%d n_out=%d <= 512)",
-              B, n_in, n_out);
+  ORL_REQUIRE(x && W && B > 0 && n_in > 0 && n_out > 0 && (n_out <= 512 || gamma == nullptr),
+              "orl_gen_layer_fwd: bad arguments (B=%d n_in=%d n_out=%d; <= 512 with LayerNorm)", B, n_in, n_out);
   ORL_REQUIRE(act >= ORL_ACT_NONE && act <= ORL_ACT_ELU, "orl_gen_layer_fwd: activation id %d", act);
   ORL_REQUIRE((gamma == nullptr) == (beta == nullptr), "orl_gen_layer_fwd: gamma and beta come together");
   hipStream_t s = (hipStream_t)stream;
@@ -1096,17 +1105,9 @@ int orl_gen_layer_fwd(const float* x, int B, int n_in, const float* W, const flo
   if (gamma == nullptr && n_out > 128) {
     // no LayerNorm: output columns are independent, so a wide projection (the GRU's 3 H gate columns) runs as 128-column
     // blocks of the 8-tile kernel instead of one 32-tile-per-wave launch (256 registers, 2 waves per workgroup)
-    for (int c0 = 0; c0 < n_out; c0 += 128) {
-      const int nb_cols = n_out - c0 < 128 ? n_out - c0 : 128;
-      const float* Wc = W + (size_t)c0 * n_in;
-      const float* bc = bias ? bias + c0 : nullptr;
-      float* ac = a_out ? a_out + c0 : nullptr;
-      float* yc = y_out ? y_out + c0 : nullptr;
-      const int rc = skinny ? launch_fwd<8, 1>(x, B, n_in, Wc, bc, act, nullptr, nullptr, nb_cols, ac, nullptr, yc, s, n_out)
-                            : launch_fwd<8, 4>(x, B, n_in, Wc, bc, act, nullptr, nullptr, nb_cols, ac, nullptr, yc, s, n_out);
-      if (rc) return rc;
-    }
-    return 0;
+    const int cb = (n_out + 127) / 128;
+    return skinny ? launch_fwd<8, 1>(x, B, n_in, W, bias, act, nullptr, nullptr, n_out, a_out, nullptr, y_out, s, n_out, 0, cb)
+                  : launch_fwd<8, 4>(x, B, n_in, W, bias, act, nullptr, nullptr, n_out, a_out, nullptr, y_out, s, n_out, 0, cb);
   }
   if (n_out <= 16) { if (skinny) ORL_GF_FWD(1, 1); ORL_GF_FWD(1, 4); }
   if (n_out <= 32) { if (skinny) ORL_GF_FWD(2, 1); ORL_GF_FWD(2, 4); }
@@ -1214,15 +1215,9 @@ int orl_gen_matmul(const float* x, int B, int K, const float* W, int N, float* y
   ORL_REQUIRE(x && W && y && B > 0 && K > 0 && N > 0, "orl_gen_matmul: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const bool skinny = B <= 16 * 1024;
-  for (int c0 = 0; c0 < N; c0 += 128) {  // 128 output columns per launch (8 accumulator tiles per wave)
-    const int nb_cols = N - c0 < 128 ? N - c0 : 128;
-    const int rc = skinny ? launch_fwd<8, 1, true>(x, B, K, W + c0, nullptr, ORL_ACT_NONE, nullptr, nullptr, nb_cols, nullptr,
-                                                   nullptr, y + c0, s, N, N)
-                          : launch_fwd<8, 4, true>(x, B, K, W + c0, nullptr, ORL_ACT_NONE, nullptr, nullptr, nb_cols, nullptr,
-                                                   nullptr, y + c0, s, N, N);
-    if (rc) return rc;
-  }
-  return 0;
+  const int cb = (N + 127) / 128;  // 128 output columns (8 accumulator tiles per wave) per block column
+  return skinny ? launch_fwd<8, 1, true>(x, B, K, W, nullptr, ORL_ACT_NONE, nullptr, nullptr, N, nullptr, nullptr, y, s, N, N, cb)
+                : launch_fwd<8, 4, true>(x, B, K, W, nullptr, ORL_ACT_NONE, nullptr, nullptr, N, nullptr, nullptr, y, s, N, N, cb);
 }
 
 int orl_gen_colsum_rows(const float* x, int n_rows, int width, float* dst, float* partials, int64_t partials_floats,

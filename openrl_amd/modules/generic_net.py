@@ -78,9 +78,6 @@ class GenNet:
             self._mlp_layer("common", H, H, 0)
         self.rnn: Optional[Dict] = None
         if self.recurrent:  # RNNLayer (networks/utils/rnn.py:5-27): nn.GRU(H, H, num_layers=1) + LayerNorm(H)
-            if 3 * H > 512:
-                raise NotImplementedError("recurrent general towers take hidden_size <= 168 (the GRU's 3 H gate columns "
-                                          "go through the 512-column layer kernels), got %d" % H)
             self.rnn = dict(Wih=self._add("rnn.rnn.weight_ih_l0", (3 * H, H)), Whh=self._add("rnn.rnn.weight_hh_l0", (3 * H, H)),
                             bih=self._add("rnn.rnn.bias_ih_l0", (3 * H,)), bhh=self._add("rnn.rnn.bias_hh_l0", (3 * H,)),
                             g=self._add("rnn.norm.weight", (H,)), be=self._add("rnn.norm.bias", (H,)))

@@ -283,7 +283,7 @@ def test_whole_tower_launch_equals_the_layer_by_layer_forward(argv, D, B):
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("H,L,N", [(128, 5, 70), (36, 3, 200), (64, 10, 33), (168, 2, 50)])
+@pytest.mark.parametrize("H,L,N", [(128, 5, 70), (36, 3, 200), (64, 10, 33), (168, 2, 50), (256, 3, 40), (512, 2, 20)])
 def test_gru_sequence_forward_backward_against_torch_fp64(H, L, N):
     """generic_net.gru_forward / gru_backward (projection GEMMs + orl_gen_gru_gate_fwd/_bwd + the LayerNorm after the
     cell) vs torch.nn.GRUCell + LayerNorm under autograd in fp64, with the reference's masking h_{t-1} * mask_t
