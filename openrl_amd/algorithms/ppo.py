@@ -237,6 +237,8 @@ class PPOAlgorithm(BaseAlgorithm):
         (``orl_rnn_eval_step`` per chunk step), (2) ``orl_rnn_jrpo_records`` folds the joint log-ratio, agent 0's
         advantage (x A) and agent 0's active mask into a copy of the records, (3) the ordinary fused recurrent update on
         that copy - policy tower over all (chunk, agent) sequences, critic tower over agent 0's only."""
+        if self.generic:
+            return self._update_minibatch_jrpo_generic(buffer, chunks, n_chunks, turn_on)
         mod = self.algo_module
         p, c = mod.models["policy"], mod.models["critic"]
         po, co = mod.optimizers["policy"], mod.optimizers["critic"]
@@ -308,6 +310,56 @@ class PPOAlgorithm(BaseAlgorithm):
             hp.reserved |= 1
         ops_rnn.rnn_ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
                               co.native_state(co.step_count), self._info, self._rnn_scratch)
+
+    def _update_minibatch_jrpo_generic(self, buffer, chunks, n_chunks: int, turn_on: bool) -> None:
+        """The joint-action loss on recurrent GENERAL towers: same three steps as ``_update_minibatch_jrpo`` - current
+        log-probs of every (step, chunk, agent) row, ``orl_rnn_jrpo_records``, then the layer-wise update with the critic
+        on agent 0's rows."""
+        from .. import ops_gen
+        from .ppo_generic import update_minibatch_generic
+
+        mod = self.algo_module
+        T, N, A, L = buffer.episode_length, buffer.n_rollout_threads, buffer.num_agents, self.data_chunk_length
+        H = mod.policy_net.H
+        rec = buffer.records
+        Dp, Dc, a_w, K = buffer.Dp, buffer.Dc, buffer.act_shape, buffer.K
+        ns, dev = n_chunks * A, self.device
+        if getattr(self, "_jr", None) is None or self._jr["ns"] < ns or self._jr["L"] != L:
+            f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+            self._jr = dict(ns=ns, L=L, rows_p=torch.empty(L * ns, dtype=torch.int64, device=dev),
+                            rows_c=torch.empty(L * n_chunks, dtype=torch.int64, device=dev), x=f(L * ns, Dp),
+                            act=f(L * ns, a_w), am=f(L * ns, K) if K else None, rec2=torch.empty_like(rec))
+        j = self._jr
+        rows_p, rows_c = j["rows_p"][:L * ns], j["rows_c"][:L * n_chunks]
+        ops_rnn.rnn_chunk_rows_v3(chunks, n_chunks, L, T, N, A, False, rows_p)
+        ops_rnn.rnn_chunk_rows_v3(chunks, n_chunks, L, T, N, A, True, rows_c)
+        vn = mod.get_critic_value_normalizer() if self._use_valuenorm else None
+        if vn is not None:  # ValueNorm.update(return_batch): the returns of agent 0's rows (to_single_np, ppo.py:258)
+            ret_col = Dp + Dc + 2 * a_w + 2
+            ops.minibatch_moments(rec, ret_col, rows_c, n_chunks * L, self._mom_scratch, self._moments_mb)
+            if self.world_size > 1:
+                dist_utils.allreduce_(self._moments_mb)
+            ops.valuenorm_update(vn.state, self._moments_mb, vn.beta)
+            self._vn_in_perm = False
+        # (1) current log-probs of every (step, chunk, agent) row
+        B = L * ns
+        x, act, am = j["x"][:B], j["act"][:B], (j["am"][:B] if K else None)
+        o_act = Dp + Dc
+        ops_gen.gather_cols(rec, 0, Dp, rows_p, B, x)
+        ops_gen.gather_cols(rec, o_act, a_w, rows_p, B, act)
+        if K:
+            ops_gen.gather_cols(rec, o_act + 2 * a_w + 4, K, rows_p, B, am)
+        h0 = buffer.rnn_states.reshape(-1, H)[rows_p[:ns]]
+        mk = buffer.masks.reshape(-1)[rows_p]
+        _, logp, _, _ = mod._evaluate_actions_rnn(None, x, h0, None, act, mk, am, None)
+        # (2) joint-ratio records
+        rec2 = j["rec2"]
+        if j.get("stamp") is not buffer.records or j.get("fresh") != self._jrpo_epoch_id:
+            rec2.copy_(rec)
+            j["stamp"], j["fresh"] = buffer.records, self._jrpo_epoch_id
+        ops_rnn.rnn_jrpo_records(rec, rec2, Dp, Dc, a_w, rows_p, n_chunks, L, A, logp)
+        # (3) the layer-wise recurrent update on the adjusted records; the critic sees agent 0's sequences
+        update_minibatch_generic(self, buffer, rows_p, B, turn_on, rnn=(L, ns), jrpo=(rec2, rows_c, n_chunks))
 
     def _update_minibatch_rnn(self, buffer, chunks, n_chunks: int, turn_on: bool) -> None:
         """One recurrent_generator minibatch (replay_data.py:1062-1258): ``chunks`` = chunk ids (device int64)."""

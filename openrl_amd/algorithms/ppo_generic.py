@@ -22,17 +22,25 @@ def _loss_sums(ws, name: str, nb: int, width: int):
     return ws.loss_sums[name]
 
 
-def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None) -> None:
+def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None, jrpo=None) -> None:
     """``rnn = (L, n_chunks)``: recurrent towers - ``idx`` holds the chunks' record rows in [L, n_chunks] order
     (``orl_rnn_chunk_rows``), the GRU between trunk and head runs over the L steps from the stored states at the chunk
-    starts (recurrent_generator, replay_data.py:1062-1258; RNNLayer, rnn.py:39-99)."""
+    starts (recurrent_generator, replay_data.py:1062-1258; RNNLayer, rnn.py:39-99).
+    ``jrpo = (records', critic_rows, critic_chunks)``: the joint-action loss (ppo.py:254-300) - the policy's rows read the
+    adjusted records of ``orl_rnn_jrpo_records`` (joint ratio, agent 0's advantage / active mask), the critic runs on agent
+    0's rows only; the caller has already updated ValueNorm from those rows."""
     mod = algo.algo_module
     rec = buffer.records
     Dp, Dc, a_w, K = buffer.Dp, buffer.Dc, buffer.act_shape, buffer.K
     hp = algo.hp
     vn = mod.get_critic_value_normalizer() if algo._use_valuenorm else None
     vn_state = None
-    if vn is not None:
+    idx_c, mb_c = idx, mb
+    if jrpo is not None:
+        rec, idx_c, nc_c = jrpo
+        mb_c = rnn[0] * nc_c
+        vn_state = vn.state if vn is not None else None
+    elif vn is not None:
         if not algo._full_batch_moments:
             ret_col = Dp + Dc + 2 * a_w + 2
             ops.minibatch_moments(rec, ret_col, idx, mb, algo._mom_scratch, algo._moments)
@@ -43,10 +51,17 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
         else:
             ops.valuenorm_update(vn.state, algo._moments, vn.beta)  # BEFORE normalize (ppo.py:190-195)
         vn_state = vn.state
-    den = algo._gen_den
+    den = den_c = algo._gen_den
     ops_gen.denoms(rec, Dp, Dc, a_w, idx, mb, den, algo._gen_den_scratch)
     if algo.world_size > 1:
         dist_utils.allreduce_(den)  # global masked-mean denominators
+    if jrpo is not None:  # the value loss averages over agent 0's rows
+        if getattr(algo, "_gen_den_c", None) is None:
+            algo._gen_den_c = torch.zeros_like(algo._gen_den)
+        den_c = algo._gen_den_c
+        ops_gen.denoms(rec, Dp, Dc, a_w, idx_c, mb_c, den_c, algo._gen_den_scratch)
+        if algo.world_size > 1:
+            dist_utils.allreduce_(den_c)
     pn, cn = mod.policy_net, mod.critic_net
     shared = mod.share_model
     one_pass = shared and buffer.critic_obs is buffer.policy_obs
@@ -68,14 +83,16 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     if one_pass:
         wc, feats_c = wp, feats_p
     else:
-        wc = mod.workspace(cn, mb, True, "c")
-        xc = wc.v(wc.x0, mb, Dc)
-        ops_gen.gather_cols(rec, Dp, Dc, idx, mb, xc)
+        wc = mod.workspace(cn, mb_c, True, "c")
+        xc = wc.v(wc.x0, mb_c, Dc)
+        ops_gen.gather_cols(rec, Dp, Dc, idx_c, mb_c, xc)
         feats_c = gn.trunk_forward(cn, wc, xc, True)
         if rnn is not None:
-            h0c = buffer.rnn_states_critic.reshape(-1, cn.H)[idx[:Nc]]
-            gc = mod.gru_workspace(cn, L, Nc, True, "c")
-            trunk_c, feats_c = feats_c, gn.gru_forward(cn, gc, feats_c, h0c, mrows, L, Nc, True)
+            Ncc = mb_c // L
+            mrows_c = mrows if idx_c is idx else buffer.masks.reshape(-1)[idx_c]
+            h0c = buffer.rnn_states_critic.reshape(-1, cn.H)[idx_c[:Ncc]]
+            gc = mod.gru_workspace(cn, L, Ncc, True, "c")
+            trunk_c, feats_c = feats_c, gn.gru_forward(cn, gc, feats_c, h0c, mrows_c, L, Ncc, True)
     values = gn.head_forward(cn, wc, "v_out", feats_c)
 
     # ---- losses: d loss / d head outputs (already divided by the denominators) + statistics
@@ -84,8 +101,8 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     nb = ops_gen.policy_loss(head, logits, mod._logstd(), rec, Dp, Dc, a_w, K, idx, mb, den, hp, dlogits,
                              wp.loss_partials)
     psums = _loss_sums(wp, "act", nb, 20)
-    dvalues = wc.v(wc.dhead["v_out"], mb, 1)
-    nb = ops_gen.value_loss(values.view(-1), rec, Dp, Dc, a_w, K, idx, mb, vn_state, den, hp, dvalues.view(-1),
+    dvalues = wc.v(wc.dhead["v_out"], mb_c, 1)
+    nb = ops_gen.value_loss(values.view(-1), rec, Dp, Dc, a_w, K, idx_c, mb_c, vn_state, den_c, hp, dvalues.view(-1),
                             wc.loss_partials)
     vsums = _loss_sums(wc, "v_out", nb, 1)
 
@@ -139,10 +156,10 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
             gn.trunk_backward(pn, wp, dfeat)
             step(pn, popt, 1, 3, -1)
         cn.grad.zero_()
-        dfeat = wc.v(wc.dfeat, mb, cn.H)
+        dfeat = wc.v(wc.dfeat, mb_c, cn.H)
         gn.head_backward(cn, wc, "v_out", feats_c, dvalues, dfeat, False)
         if rnn is not None:
-            dfeat = gn.gru_backward(cn, gc, trunk_c, mrows, dfeat, L, Nc)
+            dfeat = gn.gru_backward(cn, gc, trunk_c, mrows_c, dfeat, L, mb_c // L)
         gn.trunk_backward(cn, wc, dfeat)
         step(cn, copt, 1, 4, -1)
 
@@ -153,4 +170,8 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     gauss = head.kind == ops_gen.HEAD_GAUSSIAN
     ent_div = float(head.n_out) if (gauss and not hp.use_policy_active_masks) else 1.0
     ratio_div = float(a_w) if head.kind != ops_gen.HEAD_CATEGORICAL else 1.0
-    ops_gen.info(psums, vsums, den, hp, ent_div, ratio_div, algo._info)
+    if jrpo is None:
+        ops_gen.info(psums, vsums, den, hp, ent_div, ratio_div, algo._info)
+    else:  # the value loss is a mean over agent 0's rows
+        ops_gen.info(psums, None, den, hp, ent_div, ratio_div, algo._info)
+        ops_gen.info(None, vsums, den_c, hp, ent_div, ratio_div, algo._info)

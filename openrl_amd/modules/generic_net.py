@@ -489,8 +489,7 @@ class GenericPPOModule(PPOModule):
                  device="cuda:0", rank=None, world_size=None, model_dict=None):
         if model_dict:
             raise NotImplementedError("custom model_dict networks are not built")
-        for flag in ("use_influence_policy", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp", "use_deepspeed",
-                     "use_joint_action_loss"):
+        for flag in ("use_influence_policy", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp", "use_deepspeed"):
             if getattr(cfg, flag, False):
                 raise NotImplementedError("cfg.%s=True is not built for the general towers" % flag)
         self.cfg = cfg

@@ -660,6 +660,9 @@ def main():
         "train_recurrent_gen_h128": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--hidden_size", "128", "--lr", "7e-4", "--critic_lr", "7e-4"],
             18, 54, lambda: Discrete(5), N=6, A=3, T=7, seed=31),
+        "train_recurrent_gen_jrpo": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--use_joint_action_loss", "true", "--hidden_size", "96",
+                "--layer_N", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 18, 54, lambda: Discrete(5), N=6, A=3, T=8, seed=33),
         "train_recurrent_gen_l2_tanh_fn": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--hidden_size", "32", "--layer_N", "2", "--activation_id",
                 "0", "--use_feature_normalization", "true", "--data_chunk_length", "4"], 6, 6,

@@ -168,13 +168,15 @@ def _fill(buf, g):
 
 
 @pytest.mark.parametrize("perm_mode", ["reference", "device"])
-def test_jrpo_train_matches_reference_golden(perm_mode):
+@pytest.mark.parametrize("case", ["train_recurrent_jrpo", "train_recurrent_gen_jrpo"])
+def test_jrpo_train_matches_reference_golden(case, perm_mode):
     """use_joint_action_loss (JRPO): recurrent_generator_v3 + joint ratio over agents, critic on agent 0 only
     (algorithms/ppo.py:254-300, buffers/replay_data.py:425-551) - the engine's pre-pass + adjusted-records update against
-    the REAL reference's PPOAlgorithm.train (golden train_recurrent_jrpo)."""
-    g = H.load_golden("train_recurrent_jrpo")
+    the REAL reference's PPOAlgorithm.train: the default recurrent tower (fused kernels) and a general one (hidden 96,
+    layer_N 2: layer-wise update with the GRU, the critic on agent 0's rows)."""
+    g = H.load_golden(case)
     cfg, module, buf, algo = build_engine(g)
-    assert algo.use_joint_action_loss and algo.recurrent
+    assert algo.use_joint_action_loss and algo.recurrent and module.generic == ("gen" in case)
     module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
     module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
     _fill(buf, g)
