@@ -87,18 +87,26 @@ def main():
     nv = (0.3 * rs.randn(N, 1, 1)).astype(np.float32)
     argv = ["--episode_length", str(T), "--ppo_epoch", "3", "--num_mini_batch", "1", "--amd_perm_mode", "device",
             "--amd_collective", collective]
-    recurrent = "rnn" in sys.argv[1:]
+    mode = sys.argv[1] if len(sys.argv) > 1 else "mlp"
+    recurrent = mode in ("rnn", "genrnn")
+    generic = mode in ("gen", "genrnn")  # general towers: torch.distributed all-reduces of the flat gradients
+    Hs = 64
+    if generic:
+        Hs = 96
+        argv += ["--hidden_size", str(Hs), "--layer_N", "2", "--activation_id", "0"]
     if recurrent:  # T is even: chunks of 2 never straddle env lanes, so shards see the same chunks as one process
         argv += ["--use_recurrent_policy", "true", "--data_chunk_length", "2"]
-        host["rnn_states"] = (0.3 * rs.randn(T + 1, N, 1, 1, 64)).astype(np.float32)
-        host["rnn_states_critic"] = (0.3 * rs.randn(T + 1, N, 1, 1, 64)).astype(np.float32)
+        host["rnn_states"] = (0.3 * rs.randn(T + 1, N, 1, 1, Hs)).astype(np.float32)
+        host["rnn_states_critic"] = (0.3 * rs.randn(T + 1, N, 1, 1, Hs)).astype(np.float32)
 
     # sharded run (all ranks)
     cfg = default_cfg(argv)
     module, buf, algo = build(cfg, Nl, D, n_act, world, dev)
     lo, hi = du.shard_range(N, rank, world)
     buf.compute_returns(fill(buf, host, lo, hi, nv), module.get_critic_value_normalizer())
-    assert (algo._comm is not None) == (collective == "p2p"), "the fused orl_comm path must be the one that runs"
+    assert algo.generic == generic
+    if not generic:
+        assert (algo._comm is not None) == (collective == "p2p"), "the fused orl_comm path must be the one that runs"
     info = algo.train(buf)
     torch.cuda.synchronize()
     if algo._comm is not None:
@@ -112,6 +120,7 @@ def main():
     b2.compute_returns(fill(b2, host, lo, hi, nv), m2.get_critic_value_normalizer())
     a2.train(b2)
     torch.cuda.synchronize()
+    # (general towers have one collective only: this second run then checks run-to-run determinism of the sharded update)
     same_coll = all(torch.equal(module.models[k].theta, m2.models[k].theta) for k in ("policy", "critic"))
     flag = torch.tensor([1.0 if same_coll else 0.0])
     torch.distributed.all_reduce(flag)

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["mlp", "rnn"])
+@pytest.mark.parametrize("mode", ["mlp", "rnn", "gen", "genrnn"])
 def test_two_ranks_equal_one_rank_on_the_concatenated_batch(mode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multirank_equiv.py"), mode]
