@@ -9,12 +9,13 @@ from openrl_amd.envs.common import make
 from openrl_amd.modules.common import PPONet
 dev, N, T = "cuda:0", 1024, 25
 rec = sys.argv[1] if len(sys.argv) > 1 else "true"
+extra = sys.argv[2:]  # e.g. --hidden_size 128 --layer_N 2: the general towers
 cfg = default_cfg(["--seed", "0", "--lr", "7e-4", "--critic_lr", "7e-4", "--episode_length", str(T),
                    "--use_recurrent_policy", rec, "--use_valuenorm", "true", "--use_adv_normalize", "true",
-                   "--amd_perm_mode", "device", "--log_interval", "1000000"])
+                   "--amd_perm_mode", "device", "--log_interval", "1000000"] + extra)
 env = make("simple_spread", env_num=N, device=dev)
 net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=N)
-iters = 600
+iters = int(os.environ.get("ORL_ITERS", "600"))
 cfg.num_env_steps = N * T * iters
 class _A: num_time_steps = 0
 tr = PPOAlgorithm(cfg, net.module, agent_num=3, device=dev)
