@@ -33,8 +33,9 @@ GAINS = ["tanh", "relu", "leaky_relu", "selu"]  # calculate_gain names per activ
 def needs_generic(cfg, act_space, share_model: bool) -> bool:
     """Does this configuration fall outside the fused default-tower kernels?"""
     kind = spaces.kind(act_space)
+    stacked = bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy) and cfg.recurrent_N != 1
     return bool(share_model or cfg.use_share_model or cfg.layer_N != 1 or cfg.hidden_size != 64
-                or cfg.activation_id != 1 or cfg.use_feature_normalization or kind == "MultiDiscrete")
+                or cfg.activation_id != 1 or cfg.use_feature_normalization or kind == "MultiDiscrete" or stacked)
 
 
 def _act_head(act_space):
@@ -77,10 +78,16 @@ class GenNet:
         if role == "model":  # self.common = MLPLayer(H, H, layer_N=0, ...)  (policy_value_network.py:78-84)
             self._mlp_layer("common", H, H, 0)
         self.rnn: Optional[Dict] = None
+        self.recurrent_N = 1
         if self.recurrent:  # RNNLayer (networks/utils/rnn.py:5-27): nn.GRU(H, H, num_layers=1) + LayerNorm(H)
-            self.rnn = dict(Wih=self._add("rnn.rnn.weight_ih_l0", (3 * H, H)), Whh=self._add("rnn.rnn.weight_hh_l0", (3 * H, H)),
-                            bih=self._add("rnn.rnn.bias_ih_l0", (3 * H,)), bhh=self._add("rnn.rnn.bias_hh_l0", (3 * H,)),
-                            g=self._add("rnn.norm.weight", (H,)), be=self._add("rnn.norm.bias", (H,)))
+            self.recurrent_N = rN = int(cfg.recurrent_N)
+            layers = []
+            for k in range(rN):  # nn.GRU registers weight_ih, weight_hh, bias_ih, bias_hh layer by layer
+                layers.append(dict(Wih=self._add("rnn.rnn.weight_ih_l%d" % k, (3 * H, H)),
+                                   Whh=self._add("rnn.rnn.weight_hh_l%d" % k, (3 * H, H)),
+                                   bih=self._add("rnn.rnn.bias_ih_l%d" % k, (3 * H,)),
+                                   bhh=self._add("rnn.rnn.bias_hh_l%d" % k, (3 * H,))))
+            self.rnn = dict(layers=layers, g=self._add("rnn.norm.weight", (H,)), be=self._add("rnn.norm.bias", (H,)))
         self.heads: Dict[str, Dict] = OrderedDict()
         if role in ("critic", "model"):
             self.heads["v_out"] = dict(W=self._add("v_out.weight", (1, H)), b=self._add("v_out.bias", (1,)), n=1,
@@ -277,13 +284,15 @@ class GenNet:
                     fill(L, w)
         if self.rnn is not None:  # nn.GRU's default init, then orthogonal_/xavier on both weights, biases 0 (rnn.py:14-26)
             H = self.H
-            gru = torch.nn.GRU(H, H, num_layers=1)
-            init_method(gru.weight_ih_l0.data)
-            init_method(gru.weight_hh_l0.data)
-            self.v(self.rnn["Wih"], 3 * H * H).copy_(gru.weight_ih_l0.data.reshape(-1))
-            self.v(self.rnn["Whh"], 3 * H * H).copy_(gru.weight_hh_l0.data.reshape(-1))
-            self.v(self.rnn["bih"], 3 * H).zero_()
-            self.v(self.rnn["bhh"], 3 * H).zero_()
+            gru = torch.nn.GRU(H, H, num_layers=self.recurrent_N)
+            for k, ly in enumerate(self.rnn["layers"]):  # named_parameters order: w_ih, w_hh (biases draw nothing)
+                wih, whh = getattr(gru, "weight_ih_l%d" % k), getattr(gru, "weight_hh_l%d" % k)
+                init_method(wih.data)
+                init_method(whh.data)
+                self.v(ly["Wih"], 3 * H * H).copy_(wih.data.reshape(-1))
+                self.v(ly["Whh"], 3 * H * H).copy_(whh.data.reshape(-1))
+                self.v(ly["bih"], 3 * H).zero_()
+                self.v(ly["bhh"], 3 * H).zero_()
             self.v(self.rnn["g"], H).fill_(1.0)
             self.v(self.rnn["be"], H).zero_()
         for name, h in self.heads.items():
@@ -408,72 +417,88 @@ def trunk_backward(net: GenNet, ws: GenWorkspace, dfeat: torch.Tensor) -> None:
 
 
 class GruWorkspace:
-    """Buffers of the GRU between trunk and head over ``L`` steps of ``N`` sequences (rows ordered [L, N], the layout of
-    ``recurrent_generator``): projections, masked inputs, gate values and the LayerNorm after the cell."""
+    """Buffers of the GRU stack between trunk and head over ``L`` steps of ``N`` sequences (rows ordered [L, N], the
+    layout of ``recurrent_generator``): per layer the projections, masked inputs and gate values; the LayerNorm after the
+    last layer."""
 
     def __init__(self, net: GenNet, L: int, N: int, training: bool) -> None:
         H, dev = net.H, net.device
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.L, self.N = L, N
-        self.gi, self.gh = e(L * N, 3 * H), e(L * N, 3 * H)
-        self.h_in, self.h = e(L * N, H), e(L * N, H)   # masked input / output state of every step
-        self.y = e(L * N, H)                            # LayerNorm(h): what the head reads
+        self.layers = []
+        for _ in net.rnn["layers"]:
+            d = dict(gi=e(L * N, 3 * H), gh=e(L * N, 3 * H), h_in=e(L * N, H), h=e(L * N, H))
+            if training:
+                d.update(save=e(L * N, 4 * H), dgi=e(L * N, 3 * H), dgh=e(L * N, 3 * H), dx=e(L * N, H))
+            self.layers.append(d)
+        self.h = self.layers[-1]["h"]      # output states of the last layer, every step
+        self.y = e(L * N, H)                # LayerNorm(h): what the head reads
+        self.h_last = e(N, len(self.layers), H)  # states after the last step, [N, recurrent_N, H]
         if training:
-            self.save = e(L * N, 4 * H)
             self.xhat, self.rstd = e(L * N, H), e(L * N)
-            self.dh, self.dh_dir, self.carry, self.tmp = e(L * N, H), e(N, H), e(N, H), e(N, H)
-            self.dgi, self.dgh = e(L * N, 3 * H), e(L * N, 3 * H)
-            self.dfeat = e(L * N, H)
+            self.dh, self.dh_dir, self.tmp = e(L * N, H), e(N, H), e(N, H)
             self.col_partials = e(ops_gen.MAX_BLOCKS * 3 * 3 * H)
             self.wgrad_partials = e(max(4 * 3 * H * H, min(256 * 3 * H * H, 1 << 24)))
 
 
 def gru_forward(net: GenNet, gw: GruWorkspace, feats: torch.Tensor, h0: torch.Tensor, masks: torch.Tensor, L: int, N: int,
                 save: bool) -> torch.Tensor:
-    """RNNLayer.forward (rnn.py:39-99) on [L * N, H] features: h_t = GRU(feats_t, h_{t-1} * mask_t), y = LayerNorm(h).
-    One projection GEMM for all steps' inputs; per step one recurrent GEMM + one gate launch.  Returns y [L * N, H];
-    ``gw.h[(L-1) * N:]`` is the state after the last step."""
+    """RNNLayer.forward (rnn.py:39-99) on [L * N, H] features: per layer h_t = GRU(x_t, h_{t-1} * mask_t) with the layer
+    below's output sequence as input, y = LayerNorm(h of the last layer).  ``h0``: [N, recurrent_N, H] (or [N, H] for
+    one layer).  Per layer ONE projection GEMM for all steps' inputs; per step one recurrent GEMM + one gate launch.
+    Returns y [L * N, H]; ``gw.h_last`` [N, recurrent_N, H] holds the states after the last step."""
     H, r = net.H, net.rnn
-    Wih, Whh = net.v(r["Wih"], 3 * H, H), net.v(r["Whh"], 3 * H, H)
-    bih, bhh = net.v(r["bih"], 3 * H), net.v(r["bhh"], 3 * H)
     B = L * N
-    ops_gen.layer_fwd(feats, Wih, bih, ops_gen.ACT_NONE, None, None, None, None, gw.gi[:B])
-    ops_gen.row_affine(h0, None, masks[:N], None, gw.h_in[:N])
-    for t in range(L):
-        s, nx = slice(t * N, (t + 1) * N), slice((t + 1) * N, (t + 2) * N)
-        ops_gen.layer_fwd(gw.h_in[s], Whh, bhh, ops_gen.ACT_NONE, None, None, None, None, gw.gh[s])
-        last = t == L - 1
-        ops_gen.gru_gate_fwd(gw.gi[s], gw.gh[s], gw.h_in[s], None if last else masks[nx], gw.h[s],
-                             None if last else gw.h_in[nx], gw.save[s] if save else None)
-    ops_gen.row_fwd(gw.h[:B], None, ops_gen.ACT_NONE, net.v(r["g"], H), net.v(r["be"], H), None,
+    h0 = h0.reshape(N, len(r["layers"]), H)
+    x = feats
+    for k, (ly, w) in enumerate(zip(r["layers"], gw.layers)):
+        Wih, Whh = net.v(ly["Wih"], 3 * H, H), net.v(ly["Whh"], 3 * H, H)
+        bih, bhh = net.v(ly["bih"], 3 * H), net.v(ly["bhh"], 3 * H)
+        ops_gen.layer_fwd(x, Wih, bih, ops_gen.ACT_NONE, None, None, None, None, w["gi"][:B])
+        h0k = h0[:, k].contiguous() if h0.shape[1] > 1 else h0.reshape(N, H)
+        ops_gen.row_affine(h0k, None, masks[:N], None, w["h_in"][:N])
+        for t in range(L):
+            s, nx = slice(t * N, (t + 1) * N), slice((t + 1) * N, (t + 2) * N)
+            ops_gen.layer_fwd(w["h_in"][s], Whh, bhh, ops_gen.ACT_NONE, None, None, None, None, w["gh"][s])
+            last = t == L - 1
+            ops_gen.gru_gate_fwd(w["gi"][s], w["gh"][s], w["h_in"][s], None if last else masks[nx], w["h"][s],
+                                 None if last else w["h_in"][nx], w["save"][s] if save else None)
+        gw.h_last[:N, k].copy_(w["h"][(L - 1) * N:B])
+        x = w["h"][:B]
+    ops_gen.row_fwd(x, None, ops_gen.ACT_NONE, net.v(r["g"], H), net.v(r["be"], H), None,
                     gw.xhat[:B] if save else None, gw.rstd[:B] if save else None, gw.y[:B])
     return gw.y[:B]
 
 
 def gru_backward(net: GenNet, gw: GruWorkspace, feats: torch.Tensor, masks: torch.Tensor, dy: torch.Tensor, L: int,
                  N: int) -> torch.Tensor:
-    """Back-propagation through ``gru_forward``: writes the GRU's and its LayerNorm's gradients into ``net.grad`` and
-    returns d feats [L * N, H].  The chunk's initial state is data (rnn.py / recurrent_generator): no gradient leaves."""
+    """Back-propagation through ``gru_forward`` (time and depth): writes the GRU stack's and its LayerNorm's gradients
+    into ``net.grad`` and returns d feats [L * N, H].  The chunk's initial states are data: no gradient leaves."""
     H, r = net.H, net.rnn
-    Wih, Whh = net.v(r["Wih"], 3 * H, H), net.v(r["Whh"], 3 * H, H)
     B = L * N
-    # LayerNorm after the cell: dy -> dh (all steps), d gamma / d beta
+    # LayerNorm after the last layer: dy -> dh of that layer (all steps), d gamma / d beta
     nb = ops_gen.row_bwd(dy, net.v(r["g"], H), gw.xhat[:B], gw.rstd[:B], None, ops_gen.ACT_NONE, gw.dh[:B], gw.col_partials)
     ops_gen.colsum(gw.col_partials, nb, [(net.v(r["g"], H, grad=True), H), (net.v(r["be"], H, grad=True), H), (None, H)])
-    for t in range(L - 1, -1, -1):
-        s = slice(t * N, (t + 1) * N)
-        # gw.dh[s] already holds the total gradient at h_t (its LayerNorm path + the carry added below for t < L-1)
-        ops_gen.gru_gate_bwd(gw.dh[s], gw.save[s], gw.h_in[s], gw.dgi[s], gw.dgh[s], gw.dh_dir)
-        if t > 0:  # d h_{t-1} += (dgh W_hh + z * dh) * mask_t
-            p = slice((t - 1) * N, t * N)
-            ops_gen.linear_dgrad(gw.dgh[s], Whh, gw.tmp)
-            ops_gen.row_affine(gw.tmp, gw.dh_dir, masks[s], gw.dh[p], gw.dh[p])
-    ops_gen.wgrad(gw.dgi[:B], feats, net.v(r["Wih"], 3 * H, H, grad=True), gw.wgrad_partials)
-    ops_gen.wgrad(gw.dgh[:B], gw.h_in[:B], net.v(r["Whh"], 3 * H, H, grad=True), gw.wgrad_partials)
-    for d, off in ((gw.dgi, r["bih"]), (gw.dgh, r["bhh"])):
-        ops_gen.colsum_rows(d[:B], net.v(off, 3 * H, grad=True), gw.col_partials)
-    ops_gen.linear_dgrad(gw.dgi[:B], Wih, gw.dfeat[:B])
-    return gw.dfeat[:B]
+    dh = gw.dh
+    for k in range(len(r["layers"]) - 1, -1, -1):
+        ly, w = r["layers"][k], gw.layers[k]
+        Wih, Whh = net.v(ly["Wih"], 3 * H, H), net.v(ly["Whh"], 3 * H, H)
+        x_in = feats if k == 0 else gw.layers[k - 1]["h"][:B]
+        for t in range(L - 1, -1, -1):
+            s = slice(t * N, (t + 1) * N)
+            # dh[s] holds the total gradient at h_t: from above (LayerNorm or the next layer's input gradient) + the carry
+            ops_gen.gru_gate_bwd(dh[s], w["save"][s], w["h_in"][s], w["dgi"][s], w["dgh"][s], gw.dh_dir)
+            if t > 0:  # d h_{t-1} += (dgh W_hh + z * dh) * mask_t
+                p = slice((t - 1) * N, t * N)
+                ops_gen.linear_dgrad(w["dgh"][s], Whh, gw.tmp[:N])
+                ops_gen.row_affine(gw.tmp[:N], gw.dh_dir[:N], masks[s], dh[p], dh[p])
+        ops_gen.wgrad(w["dgi"][:B], x_in, net.v(ly["Wih"], 3 * H, H, grad=True), gw.wgrad_partials)
+        ops_gen.wgrad(w["dgh"][:B], w["h_in"][:B], net.v(ly["Whh"], 3 * H, H, grad=True), gw.wgrad_partials)
+        ops_gen.colsum_rows(w["dgi"][:B], net.v(ly["bih"], 3 * H, grad=True), gw.col_partials)
+        ops_gen.colsum_rows(w["dgh"][:B], net.v(ly["bhh"], 3 * H, grad=True), gw.col_partials)
+        ops_gen.linear_dgrad(w["dgi"][:B], Wih, w["dx"][:B])  # gradient at this layer's input sequence
+        dh = w["dx"]
+    return gw.layers[0]["dx"][:B]
 
 
 class GenAdam(FusedAdam):
@@ -497,8 +522,8 @@ class GenericPPOModule(PPOModule):
         # use_naive_recurrent_policy builds the same RNNLayer towers (policy_network.py:82-90)
         self.recurrent = bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy)
         if self.recurrent:
-            if cfg.recurrent_N != 1 or getattr(cfg, "rnn_type", "gru") != "gru":
-                raise NotImplementedError("recurrent towers are built for a one-layer GRU (recurrent_N=1, rnn_type=gru)")
+            if cfg.recurrent_N < 1 or getattr(cfg, "rnn_type", "gru") != "gru":
+                raise NotImplementedError("recurrent towers are built for GRUs (rnn_type=gru, recurrent_N >= 1)")
             if share_model or cfg.use_share_model:
                 raise NotImplementedError("use_share_model with a recurrent policy is not built")
         self.lr, self.critic_lr = cfg.lr, cfg.critic_lr
@@ -633,7 +658,7 @@ class GenericPPOModule(PPOModule):
             feats = trunk_forward(net, ws, x, False)
         gw = self.gru_workspace(net, 1, B, False, tag)
         y = gru_forward(net, gw, feats, h_in, mk, 1, B, False)
-        return ws, y, gw.h[:B]
+        return ws, y, gw.h_last[:B]
 
     @torch.no_grad()
     def _forward_rnn(self, critic_obs, obs, h_policy, h_critic, masks, action_masks, deterministic, want_value=True,
@@ -641,7 +666,7 @@ class GenericPPOModule(PPOModule):
         """Recurrent get_actions / get_values / act (same contract as ``PPOModule._forward_rnn``): states [B, (1,) H] in,
         new states out (``h_out`` = pair of destination tensors, e.g. the buffer's next slot)."""
         pn, cn = self.policy_net, self.critic_net
-        H = pn.H
+        H = pn.H * pn.recurrent_N  # a row of states: [recurrent_N, H] flattened
         x = self._dev(obs, self.Dp) if want_action else None
         xc = self._dev(critic_obs, self.Dc) if want_value else None
         B = (x if x is not None else xc).shape[0]
@@ -670,9 +695,11 @@ class GenericPPOModule(PPOModule):
 
     def get_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks=None,
                     deterministic=False):
-        if self.recurrent:
-            return PPOModule.get_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks,
-                                         deterministic)
+        if self.recurrent:  # states come back as [B, recurrent_N, H] (rnn.py:49)
+            v, a, lp, hp, hc = self._forward_rnn(critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks,
+                                                 deterministic)
+            rN, Hh = self.policy_net.recurrent_N, self.policy_net.H
+            return v, a, lp, hp.reshape(-1, rN, Hh), hc.reshape(-1, rN, Hh)
         values, actions, logp = self._forward(critic_obs, obs, action_masks, deterministic)
         return values, actions, logp, rnn_states_actor, rnn_states_critic
 
@@ -683,7 +710,9 @@ class GenericPPOModule(PPOModule):
 
     def act(self, obs, rnn_states_actor, masks, action_masks=None, deterministic=False):
         if self.recurrent:
-            return PPOModule.act(self, obs, rnn_states_actor, masks, action_masks, deterministic)
+            _, actions, _, hp, _ = self._forward_rnn(None, obs, rnn_states_actor, None, masks, action_masks, deterministic,
+                                                     want_value=False)
+            return actions, hp.reshape(-1, self.policy_net.recurrent_N, self.policy_net.H)
         _, actions, _ = self._forward(None, obs, action_masks, deterministic, want_value=False)
         return actions, rnn_states_actor
 
@@ -731,7 +760,7 @@ class GenericPPOModule(PPOModule):
         """Recurrent evaluate_actions (policy_network.py:164-203 + RNNLayer.forward): the rows are L steps of N sequences
         flattened [L * N, ...] (recurrent_generator's layout), the states [N, (1,) H] enter step 0."""
         pn, cn = self.policy_net, self.critic_net
-        H = pn.H
+        H = pn.H * pn.recurrent_N
         x = self._dev(obs, self.Dp)
         hp = self._dev(h_policy, H)
         Np, Bp = hp.shape[0], x.shape[0]

@@ -107,7 +107,8 @@ def buffer_insert(buf: BufferPtrs, step: int, next_policy_obs, next_critic_obs, 
     else:
         rc = _lib().orl_buffer_insert_rnn(C.byref(buf), step, fptr(next_policy_obs), fptr(next_critic_obs),
                                           fptr(rewards), ptr(dones), ptr(bad_transition), fptr(next_action_masks),
-                                          fptr(h_policy_next), fptr(h_critic_next), int(h_policy_next.shape[-1]),
+                                          fptr(h_policy_next), fptr(h_critic_next),
+                                          int(h_policy_next.shape[-1] * (h_policy_next.shape[-2] if h_policy_next.dim() >= 4 else 1)),
                                           stream_ptr(dev))
     nat.check(rc, "orl_buffer_insert")
 

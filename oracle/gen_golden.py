@@ -663,6 +663,10 @@ def main():
         "train_recurrent_gen_jrpo": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--use_joint_action_loss", "true", "--hidden_size", "96",
                 "--layer_N", "2", "--lr", "7e-4", "--critic_lr", "7e-4"], 18, 54, lambda: Discrete(5), N=6, A=3, T=8, seed=33),
+        # a stack of two GRU layers (recurrent_N 2) on the DEFAULT trunk: states [.., 2, H]
+        "train_recurrent_gen_n2": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--recurrent_N", "2", "--data_chunk_length", "3"], 7, 7,
+            lambda: Discrete(4), N=5, A=2, T=9, seed=34),
         "train_recurrent_gen_l2_tanh_fn": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--hidden_size", "32", "--layer_N", "2", "--activation_id",
                 "0", "--use_feature_normalization", "true", "--data_chunk_length", "4"], 6, 6,
