@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 204 /* 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 205 /* 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -708,6 +708,15 @@ int orl_gen_gru_gate_fwd(const float* gi, const float* gh, const float* h_in, co
  * to h_in (the path through gh is dgh W_hh, a GEMM). */
 int orl_gen_gru_gate_bwd(const float* dh, const float* save, const float* h_in, int N, int H, float* dgi, float* dgh,
                          float* dh_in, void* stream);
+/* One step of torch.nn.LSTM (one layer; rnn_type lstm of RNNLayer) after its projections gi, gh [N, 4H] (blocks i | f | g | o):
+ * c_out = f c_in + i g, h_out = o tanh(c_out).  save [N, 5H] = (i, f, g, o, tanh(c_out)) or NULL; h_in_next / c_in_next =
+ * the next step's masked inputs (all three of them and mask_next, or none). */
+int orl_gen_lstm_gate_fwd(const float* gi, const float* gh, const float* c_in, const float* mask_next, int N, int H,
+                          float* h_out, float* c_out, float* h_in_next, float* c_in_next, float* save, void* stream);
+/* Its backward: dh, dc (NULL = 0) at h_out / c_out -> dgates [N, 4H] (the gradient at both projections' outputs) and
+ * dc_in, the gradient at c_in. */
+int orl_gen_lstm_gate_bwd(const float* dh, const float* dc, const float* save, const float* c_in, int N, int H,
+                          float* dgates, float* dc_in, void* stream);
 /* out[row, :] = (a[row, :] + b[row, :]) * row_scale[row] + add[row, :]; b, row_scale, add may be NULL.  Masks on hidden
  * states and the carry of back-propagation through time. */
 int orl_gen_row_affine(const float* a, const float* b, const float* row_scale, const float* add, int N, int H, float* out,

@@ -19,7 +19,7 @@ ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL, ORL_ENV_MPE_SPREAD = 0, 1, 2, 3, 4
 ORL_GATHER_MAX = 12
 ORL_IPC_HANDLE_BYTES = 64
-ORL_VERSION = 204  # must equal include/orl_hip.h; checked against the loaded library
+ORL_VERSION = 205  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -203,6 +203,8 @@ _SIGNATURES = {
     "orl_gen_colsum_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int64, _P]),
     "orl_gen_gru_gate_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "orl_gen_gru_gate_bwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "orl_gen_lstm_gate_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "orl_gen_lstm_gate_bwd": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "orl_gen_row_affine": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "orl_vec_add": (C.c_int, [_P, _P, C.c_int64, _P]),
     "orl_gen_info": (C.c_int, [_P, _P, _P, C.POINTER(PPOHParams), C.c_float, C.c_float, _P, _P]),

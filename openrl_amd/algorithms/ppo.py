@@ -320,7 +320,7 @@ class PPOAlgorithm(BaseAlgorithm):
 
         mod = self.algo_module
         T, N, A, L = buffer.episode_length, buffer.n_rollout_threads, buffer.num_agents, self.data_chunk_length
-        H = mod.policy_net.H * mod.policy_net.recurrent_N
+        H = mod.policy_net.state_w * mod.policy_net.recurrent_N
         rec = buffer.records
         Dp, Dc, a_w, K = buffer.Dp, buffer.Dc, buffer.act_shape, buffer.K
         ns, dev = n_chunks * A, self.device

@@ -74,7 +74,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     trunk_p = trunk_c = gp = gc = mrows = None
     if rnn is not None:
         L, Nc = rnn
-        H = pn.H * pn.recurrent_N
+        H = pn.state_w * pn.recurrent_N
         mrows = buffer.masks.reshape(-1)[idx]                    # mask of step l of chunk i: the same row index
         h0p = buffer.rnn_states.reshape(-1, H)[idx[:Nc]]         # stored states at the chunk starts [Nc, recurrent_N * H]
         gp = mod.gru_workspace(pn, L, Nc, True, "p")
@@ -90,7 +90,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
         if rnn is not None:
             Ncc = mb_c // L
             mrows_c = mrows if idx_c is idx else buffer.masks.reshape(-1)[idx_c]
-            h0c = buffer.rnn_states_critic.reshape(-1, cn.H * cn.recurrent_N)[idx_c[:Ncc]]
+            h0c = buffer.rnn_states_critic.reshape(-1, cn.state_w * cn.recurrent_N)[idx_c[:Ncc]]
             gc = mod.gru_workspace(cn, L, Ncc, True, "c")
             trunk_c, feats_c = feats_c, gn.gru_forward(cn, gc, feats_c, h0c, mrows_c, L, Ncc, True)
     values = gn.head_forward(cn, wc, "v_out", feats_c)

@@ -633,6 +633,63 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restri
   }
 }
 
+// torch.nn.LSTM cell (one layer) after its two projections gi = x W_ih^T + b_ih, gh = h_in W_hh^T + b_hh ([N, 4H], column
+// blocks i | f | g | o):  i, f, o = sigmoid, g = tanh;  c = f * c_in + i * g;  h = o * tanh(c).
+// save [N, 5H] = (i, f, g, o, tanh(c)); h_in_next / c_in_next = the next step's masked inputs.
+__global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                            const float* __restrict__ c_in,
+                                                            const float* __restrict__ mask_next, long long n_el, int H,
+                                                            float* __restrict__ h_out, float* __restrict__ c_out,
+                                                            float* __restrict__ h_in_next, float* __restrict__ c_in_next,
+                                                            float* __restrict__ save) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / H;
+    const int c = (int)(e % H);
+    const float* a = gi + row * 4 * H;
+    const float* b = gh + row * 4 * H;
+    const float ig = sigmoidf_(a[c] + b[c]);
+    const float fg = sigmoidf_(a[H + c] + b[H + c]);
+    const float gg = tanhf(a[2 * H + c] + b[2 * H + c]);
+    const float og = sigmoidf_(a[3 * H + c] + b[3 * H + c]);
+    const float cn = fg * c_in[e] + ig * gg;
+    const float tc = tanhf(cn);
+    const float h = og * tc;
+    h_out[e] = h;
+    c_out[e] = cn;
+    if (h_in_next) {
+      const float m = mask_next[row];
+      h_in_next[e] = h * m;
+      c_in_next[e] = cn * m;
+    }
+    if (save) {
+      float* sv = save + row * 5 * H;
+      sv[c] = ig; sv[H + c] = fg; sv[2 * H + c] = gg; sv[3 * H + c] = og; sv[4 * H + c] = tc;
+    }
+  }
+}
+
+// dh, dc = gradients at h and c of this step (dc may be NULL = 0) -> dgates [N, 4H] (the gradient at BOTH projections'
+// outputs) and dc_in = the gradient at c_in
+__global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc,
+                                                            const float* __restrict__ save, const float* __restrict__ c_in,
+                                                            long long n_el, int H, float* __restrict__ dgates,
+                                                            float* __restrict__ dc_in) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / H;
+    const int c = (int)(e % H);
+    const float* sv = save + row * 5 * H;
+    const float ig = sv[c], fg = sv[H + c], gg = sv[2 * H + c], og = sv[3 * H + c], tc = sv[4 * H + c];
+    const float g = dh[e];
+    const float dct = (dc ? dc[e] : 0.f) + g * og * (1.0f - tc * tc);
+    float* d = dgates + row * 4 * H;
+    d[c] = dct * gg * ig * (1.0f - ig);
+    d[H + c] = dct * c_in[e] * fg * (1.0f - fg);
+    d[2 * H + c] = dct * ig * (1.0f - gg * gg);
+    d[3 * H + c] = g * tc * og * (1.0f - og);
+    dc_in[e] = dct * fg;
+  }
+}
+
 // out[row, :] = (a[row, :] + b[row, :]) * scale[row] + add[row, :]   (b, scale, add may be NULL): masks on hidden states
 // and the carry of back-propagation through time
 __global__ __launch_bounds__(256) void row_affine_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -873,6 +930,26 @@ int orl_gen_gru_gate_bwd(const float* dh, const float* save, const float* h_in, 
   hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dh, save, h_in, n, H, dgi, dgh,
                      dh_in);
   return launch_status("orl_gen_gru_gate_bwd");
+}
+
+int orl_gen_lstm_gate_fwd(const float* gi, const float* gh, const float* c_in, const float* mask_next, int N, int H,
+                          float* h_out, float* c_out, float* h_in_next, float* c_in_next, float* save, void* stream) {
+  ORL_REQUIRE(gi && gh && c_in && h_out && c_out && N > 0 && H > 0, "orl_gen_lstm_gate_fwd: bad arguments");
+  ORL_REQUIRE((h_in_next == nullptr) == (mask_next == nullptr) && (h_in_next == nullptr) == (c_in_next == nullptr),
+              "orl_gen_lstm_gate_fwd: h_in_next, c_in_next and mask_next come together");
+  const long long n = (long long)N * H;
+  hipLaunchKernelGGL(lstm_gate_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, gi, gh, c_in, mask_next, n, H,
+                     h_out, c_out, h_in_next, c_in_next, save);
+  return launch_status("orl_gen_lstm_gate_fwd");
+}
+
+int orl_gen_lstm_gate_bwd(const float* dh, const float* dc, const float* save, const float* c_in, int N, int H,
+                          float* dgates, float* dc_in, void* stream) {
+  ORL_REQUIRE(dh && save && c_in && dgates && dc_in && N > 0 && H > 0, "orl_gen_lstm_gate_bwd: bad arguments");
+  const long long n = (long long)N * H;
+  hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dh, dc, save, c_in, n, H,
+                     dgates, dc_in);
+  return launch_status("orl_gen_lstm_gate_bwd");
 }
 
 int orl_gen_row_affine(const float* a, const float* b, const float* row_scale, const float* add, int N, int H, float* out,

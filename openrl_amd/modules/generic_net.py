@@ -33,7 +33,8 @@ GAINS = ["tanh", "relu", "leaky_relu", "selu"]  # calculate_gain names per activ
 def needs_generic(cfg, act_space, share_model: bool) -> bool:
     """Does this configuration fall outside the fused default-tower kernels?"""
     kind = spaces.kind(act_space)
-    stacked = bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy) and cfg.recurrent_N != 1
+    stacked = bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy) and (
+        cfg.recurrent_N != 1 or getattr(cfg, "rnn_type", "gru") != "gru")  # GRU stacks and LSTMs: the general towers
     return bool(share_model or cfg.use_share_model or cfg.layer_N != 1 or cfg.hidden_size != 64
                 or cfg.activation_id != 1 or cfg.use_feature_normalization or kind == "MultiDiscrete" or stacked)
 
@@ -78,15 +79,19 @@ class GenNet:
         if role == "model":  # self.common = MLPLayer(H, H, layer_N=0, ...)  (policy_value_network.py:78-84)
             self._mlp_layer("common", H, H, 0)
         self.rnn: Optional[Dict] = None
-        self.recurrent_N = 1
+        self.recurrent_N, self.cell, self.G, self.state_w = 1, "gru", 3, H
         if self.recurrent:  # RNNLayer (networks/utils/rnn.py:5-27): nn.GRU(H, H, num_layers=1) + LayerNorm(H)
             self.recurrent_N = rN = int(cfg.recurrent_N)
+            self.cell = str(getattr(cfg, "rnn_type", "gru"))
+            assert self.cell in ("gru", "lstm")
+            self.G = G = 3 if self.cell == "gru" else 4          # gate blocks of the projections
+            self.state_w = H if self.cell == "gru" else 2 * H   # stored state per layer: h, or [h | c] (rnn.py:31-37)
             layers = []
-            for k in range(rN):  # nn.GRU registers weight_ih, weight_hh, bias_ih, bias_hh layer by layer
-                layers.append(dict(Wih=self._add("rnn.rnn.weight_ih_l%d" % k, (3 * H, H)),
-                                   Whh=self._add("rnn.rnn.weight_hh_l%d" % k, (3 * H, H)),
-                                   bih=self._add("rnn.rnn.bias_ih_l%d" % k, (3 * H,)),
-                                   bhh=self._add("rnn.rnn.bias_hh_l%d" % k, (3 * H,))))
+            for k in range(rN):  # nn.GRU / nn.LSTM register weight_ih, weight_hh, bias_ih, bias_hh layer by layer
+                layers.append(dict(Wih=self._add("rnn.rnn.weight_ih_l%d" % k, (G * H, H)),
+                                   Whh=self._add("rnn.rnn.weight_hh_l%d" % k, (G * H, H)),
+                                   bih=self._add("rnn.rnn.bias_ih_l%d" % k, (G * H,)),
+                                   bhh=self._add("rnn.rnn.bias_hh_l%d" % k, (G * H,))))
             self.rnn = dict(layers=layers, g=self._add("rnn.norm.weight", (H,)), be=self._add("rnn.norm.bias", (H,)))
         self.heads: Dict[str, Dict] = OrderedDict()
         if role in ("critic", "model"):
@@ -120,7 +125,7 @@ class GenNet:
         self.grad = torch.zeros_like(self.theta)
         self.training = False
         self.value_normalizer: Optional[ValueNorm] = None
-        self.max_width = max([self.D, H] + [h["n"] for h in self.heads.values()] + ([3 * H] if self.recurrent else []))
+        self.max_width = max([self.D, H] + [h["n"] for h in self.heads.values()] + ([self.G * H] if self.recurrent else []))
 
     # ------------------------------------------------------------------ layout
     def _add(self, key: str, shape) -> int:
@@ -284,15 +289,16 @@ class GenNet:
                     fill(L, w)
         if self.rnn is not None:  # nn.GRU's default init, then orthogonal_/xavier on both weights, biases 0 (rnn.py:14-26)
             H = self.H
-            gru = torch.nn.GRU(H, H, num_layers=self.recurrent_N)
+            G = self.G
+            gru = (torch.nn.GRU if self.cell == "gru" else torch.nn.LSTM)(H, H, num_layers=self.recurrent_N)
             for k, ly in enumerate(self.rnn["layers"]):  # named_parameters order: w_ih, w_hh (biases draw nothing)
                 wih, whh = getattr(gru, "weight_ih_l%d" % k), getattr(gru, "weight_hh_l%d" % k)
                 init_method(wih.data)
                 init_method(whh.data)
-                self.v(ly["Wih"], 3 * H * H).copy_(wih.data.reshape(-1))
-                self.v(ly["Whh"], 3 * H * H).copy_(whh.data.reshape(-1))
-                self.v(ly["bih"], 3 * H).zero_()
-                self.v(ly["bhh"], 3 * H).zero_()
+                self.v(ly["Wih"], G * H * H).copy_(wih.data.reshape(-1))
+                self.v(ly["Whh"], G * H * H).copy_(whh.data.reshape(-1))
+                self.v(ly["bih"], G * H).zero_()
+                self.v(ly["bhh"], G * H).zero_()
             self.v(self.rnn["g"], H).fill_(1.0)
             self.v(self.rnn["be"], H).zero_()
         for name, h in self.heads.items():
@@ -417,53 +423,68 @@ def trunk_backward(net: GenNet, ws: GenWorkspace, dfeat: torch.Tensor) -> None:
 
 
 class GruWorkspace:
-    """Buffers of the GRU stack between trunk and head over ``L`` steps of ``N`` sequences (rows ordered [L, N], the
+    """Buffers of the GRU / LSTM stack between trunk and head over ``L`` steps of ``N`` sequences (rows ordered [L, N], the
     layout of ``recurrent_generator``): per layer the projections, masked inputs and gate values; the LayerNorm after the
     last layer."""
 
     def __init__(self, net: GenNet, L: int, N: int, training: bool) -> None:
-        H, dev = net.H, net.device
+        H, G, dev = net.H, net.G, net.device
+        lstm = net.cell == "lstm"
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.L, self.N = L, N
         self.layers = []
         for _ in net.rnn["layers"]:
-            d = dict(gi=e(L * N, 3 * H), gh=e(L * N, 3 * H), h_in=e(L * N, H), h=e(L * N, H))
+            d = dict(gi=e(L * N, G * H), gh=e(L * N, G * H), h_in=e(L * N, H), h=e(L * N, H))
+            if lstm:
+                d.update(c_in=e(L * N, H), c=e(L * N, H))
             if training:
-                d.update(save=e(L * N, 4 * H), dgi=e(L * N, 3 * H), dgh=e(L * N, 3 * H), dx=e(L * N, H))
+                d.update(save=e(L * N, (5 if lstm else 4) * H), dgi=e(L * N, G * H), dx=e(L * N, H))
+                d["dgh"] = d["dgi"] if lstm else e(L * N, G * H)  # an LSTM's two projections share one gradient
             self.layers.append(d)
         self.h = self.layers[-1]["h"]      # output states of the last layer, every step
         self.y = e(L * N, H)                # LayerNorm(h): what the head reads
-        self.h_last = e(N, len(self.layers), H)  # states after the last step, [N, recurrent_N, H]
+        self.h_last = e(N, len(self.layers), net.state_w)  # states after the last step, [N, recurrent_N, H or 2H]
         if training:
             self.xhat, self.rstd = e(L * N, H), e(L * N)
             self.dh, self.dh_dir, self.tmp = e(L * N, H), e(N, H), e(N, H)
-            self.col_partials = e(ops_gen.MAX_BLOCKS * 3 * 3 * H)
-            self.wgrad_partials = e(max(4 * 3 * H * H, min(256 * 3 * H * H, 1 << 24)))
+            if lstm:
+                self.dc = [e(N, H), e(N, H)]
+            self.col_partials = e(ops_gen.MAX_BLOCKS * 3 * G * H)
+            self.wgrad_partials = e(max(4 * G * H * H, min(256 * G * H * H, 1 << 24)))
 
 
 def gru_forward(net: GenNet, gw: GruWorkspace, feats: torch.Tensor, h0: torch.Tensor, masks: torch.Tensor, L: int, N: int,
                 save: bool) -> torch.Tensor:
-    """RNNLayer.forward (rnn.py:39-99) on [L * N, H] features: per layer h_t = GRU(x_t, h_{t-1} * mask_t) with the layer
-    below's output sequence as input, y = LayerNorm(h of the last layer).  ``h0``: [N, recurrent_N, H] (or [N, H] for
-    one layer).  Per layer ONE projection GEMM for all steps' inputs; per step one recurrent GEMM + one gate launch.
-    Returns y [L * N, H]; ``gw.h_last`` [N, recurrent_N, H] holds the states after the last step."""
-    H, r = net.H, net.rnn
+    """RNNLayer.forward (rnn.py:39-99) on [L * N, H] features: per layer h_t = cell(x_t, state_{t-1} * mask_t) with the
+    layer below's output sequence as input, y = LayerNorm(h of the last layer).  ``h0``: [N, recurrent_N, state_w]
+    (state_w = H for a GRU, 2 H = [h | c] for an LSTM).  Per layer ONE projection GEMM for all steps' inputs; per step one
+    recurrent GEMM + one gate launch.  Returns y [L * N, H]; ``gw.h_last`` holds the states after the last step."""
+    H, G, r = net.H, net.G, net.rnn
+    lstm = net.cell == "lstm"
     B = L * N
-    h0 = h0.reshape(N, len(r["layers"]), H)
+    h0 = h0.reshape(N, len(r["layers"]), net.state_w)
     x = feats
     for k, (ly, w) in enumerate(zip(r["layers"], gw.layers)):
-        Wih, Whh = net.v(ly["Wih"], 3 * H, H), net.v(ly["Whh"], 3 * H, H)
-        bih, bhh = net.v(ly["bih"], 3 * H), net.v(ly["bhh"], 3 * H)
+        Wih, Whh = net.v(ly["Wih"], G * H, H), net.v(ly["Whh"], G * H, H)
+        bih, bhh = net.v(ly["bih"], G * H), net.v(ly["bhh"], G * H)
         ops_gen.layer_fwd(x, Wih, bih, ops_gen.ACT_NONE, None, None, None, None, w["gi"][:B])
-        h0k = h0[:, k].contiguous() if h0.shape[1] > 1 else h0.reshape(N, H)
-        ops_gen.row_affine(h0k, None, masks[:N], None, w["h_in"][:N])
+        ops_gen.row_affine(h0[:, k, :H].contiguous(), None, masks[:N], None, w["h_in"][:N])
+        if lstm:
+            ops_gen.row_affine(h0[:, k, H:].contiguous(), None, masks[:N], None, w["c_in"][:N])
         for t in range(L):
             s, nx = slice(t * N, (t + 1) * N), slice((t + 1) * N, (t + 2) * N)
             ops_gen.layer_fwd(w["h_in"][s], Whh, bhh, ops_gen.ACT_NONE, None, None, None, None, w["gh"][s])
             last = t == L - 1
-            ops_gen.gru_gate_fwd(w["gi"][s], w["gh"][s], w["h_in"][s], None if last else masks[nx], w["h"][s],
-                                 None if last else w["h_in"][nx], w["save"][s] if save else None)
-        gw.h_last[:N, k].copy_(w["h"][(L - 1) * N:B])
+            if lstm:
+                ops_gen.lstm_gate_fwd(w["gi"][s], w["gh"][s], w["c_in"][s], None if last else masks[nx], w["h"][s], w["c"][s],
+                                      None if last else w["h_in"][nx], None if last else w["c_in"][nx],
+                                      w["save"][s] if save else None)
+            else:
+                ops_gen.gru_gate_fwd(w["gi"][s], w["gh"][s], w["h_in"][s], None if last else masks[nx], w["h"][s],
+                                     None if last else w["h_in"][nx], w["save"][s] if save else None)
+        gw.h_last[:N, k, :H].copy_(w["h"][(L - 1) * N:B])
+        if lstm:
+            gw.h_last[:N, k, H:].copy_(w["c"][(L - 1) * N:B])
         x = w["h"][:B]
     ops_gen.row_fwd(x, None, ops_gen.ACT_NONE, net.v(r["g"], H), net.v(r["be"], H), None,
                     gw.xhat[:B] if save else None, gw.rstd[:B] if save else None, gw.y[:B])
@@ -472,9 +493,10 @@ def gru_forward(net: GenNet, gw: GruWorkspace, feats: torch.Tensor, h0: torch.Te
 
 def gru_backward(net: GenNet, gw: GruWorkspace, feats: torch.Tensor, masks: torch.Tensor, dy: torch.Tensor, L: int,
                  N: int) -> torch.Tensor:
-    """Back-propagation through ``gru_forward`` (time and depth): writes the GRU stack's and its LayerNorm's gradients
-    into ``net.grad`` and returns d feats [L * N, H].  The chunk's initial states are data: no gradient leaves."""
-    H, r = net.H, net.rnn
+    """Back-propagation through ``gru_forward`` (time and depth): writes the stack's and its LayerNorm's gradients into
+    ``net.grad`` and returns d feats [L * N, H].  The chunk's initial states are data: no gradient leaves."""
+    H, G, r = net.H, net.G, net.rnn
+    lstm = net.cell == "lstm"
     B = L * N
     # LayerNorm after the last layer: dy -> dh of that layer (all steps), d gamma / d beta
     nb = ops_gen.row_bwd(dy, net.v(r["g"], H), gw.xhat[:B], gw.rstd[:B], None, ops_gen.ACT_NONE, gw.dh[:B], gw.col_partials)
@@ -482,20 +504,28 @@ def gru_backward(net: GenNet, gw: GruWorkspace, feats: torch.Tensor, masks: torc
     dh = gw.dh
     for k in range(len(r["layers"]) - 1, -1, -1):
         ly, w = r["layers"][k], gw.layers[k]
-        Wih, Whh = net.v(ly["Wih"], 3 * H, H), net.v(ly["Whh"], 3 * H, H)
+        Wih, Whh = net.v(ly["Wih"], G * H, H), net.v(ly["Whh"], G * H, H)
         x_in = feats if k == 0 else gw.layers[k - 1]["h"][:B]
+        dc = None  # LSTM: gradient at c_t carried from step t + 1
         for t in range(L - 1, -1, -1):
             s = slice(t * N, (t + 1) * N)
             # dh[s] holds the total gradient at h_t: from above (LayerNorm or the next layer's input gradient) + the carry
-            ops_gen.gru_gate_bwd(dh[s], w["save"][s], w["h_in"][s], w["dgi"][s], w["dgh"][s], gw.dh_dir)
-            if t > 0:  # d h_{t-1} += (dgh W_hh + z * dh) * mask_t
+            if lstm:
+                dc_in = gw.dc[t & 1][:N]
+                ops_gen.lstm_gate_bwd(dh[s], dc, w["save"][s], w["c_in"][s], w["dgi"][s], dc_in)
+            else:
+                ops_gen.gru_gate_bwd(dh[s], w["save"][s], w["h_in"][s], w["dgi"][s], w["dgh"][s], gw.dh_dir)
+            if t > 0:  # d h_{t-1} += (dgh W_hh [+ z * dh]) * mask_t;  LSTM: d c_{t-1} = dc_in * mask_t
                 p = slice((t - 1) * N, t * N)
                 ops_gen.linear_dgrad(w["dgh"][s], Whh, gw.tmp[:N])
-                ops_gen.row_affine(gw.tmp[:N], gw.dh_dir[:N], masks[s], dh[p], dh[p])
-        ops_gen.wgrad(w["dgi"][:B], x_in, net.v(ly["Wih"], 3 * H, H, grad=True), gw.wgrad_partials)
-        ops_gen.wgrad(w["dgh"][:B], w["h_in"][:B], net.v(ly["Whh"], 3 * H, H, grad=True), gw.wgrad_partials)
-        ops_gen.colsum_rows(w["dgi"][:B], net.v(ly["bih"], 3 * H, grad=True), gw.col_partials)
-        ops_gen.colsum_rows(w["dgh"][:B], net.v(ly["bhh"], 3 * H, grad=True), gw.col_partials)
+                ops_gen.row_affine(gw.tmp[:N], None if lstm else gw.dh_dir[:N], masks[s], dh[p], dh[p])
+                if lstm:
+                    ops_gen.row_affine(dc_in, None, masks[s], None, dc_in)
+                    dc = dc_in
+        ops_gen.wgrad(w["dgi"][:B], x_in, net.v(ly["Wih"], G * H, H, grad=True), gw.wgrad_partials)
+        ops_gen.wgrad(w["dgh"][:B], w["h_in"][:B], net.v(ly["Whh"], G * H, H, grad=True), gw.wgrad_partials)
+        ops_gen.colsum_rows(w["dgi"][:B], net.v(ly["bih"], G * H, grad=True), gw.col_partials)
+        ops_gen.colsum_rows(w["dgh"][:B], net.v(ly["bhh"], G * H, grad=True), gw.col_partials)
         ops_gen.linear_dgrad(w["dgi"][:B], Wih, w["dx"][:B])  # gradient at this layer's input sequence
         dh = w["dx"]
     return gw.layers[0]["dx"][:B]
@@ -522,8 +552,8 @@ class GenericPPOModule(PPOModule):
         # use_naive_recurrent_policy builds the same RNNLayer towers (policy_network.py:82-90)
         self.recurrent = bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy)
         if self.recurrent:
-            if cfg.recurrent_N < 1 or getattr(cfg, "rnn_type", "gru") != "gru":
-                raise NotImplementedError("recurrent towers are built for GRUs (rnn_type=gru, recurrent_N >= 1)")
+            if cfg.recurrent_N < 1 or getattr(cfg, "rnn_type", "gru") not in ("gru", "lstm"):
+                raise NotImplementedError("recurrent towers: rnn_type gru or lstm, recurrent_N >= 1")
             if share_model or cfg.use_share_model:
                 raise NotImplementedError("use_share_model with a recurrent policy is not built")
         self.lr, self.critic_lr = cfg.lr, cfg.critic_lr
@@ -666,7 +696,7 @@ class GenericPPOModule(PPOModule):
         """Recurrent get_actions / get_values / act (same contract as ``PPOModule._forward_rnn``): states [B, (1,) H] in,
         new states out (``h_out`` = pair of destination tensors, e.g. the buffer's next slot)."""
         pn, cn = self.policy_net, self.critic_net
-        H = pn.H * pn.recurrent_N  # a row of states: [recurrent_N, H] flattened
+        H = pn.state_w * pn.recurrent_N  # a row of states: [recurrent_N, H (GRU) or 2 H (LSTM: h | c)] flattened
         x = self._dev(obs, self.Dp) if want_action else None
         xc = self._dev(critic_obs, self.Dc) if want_value else None
         B = (x if x is not None else xc).shape[0]
@@ -698,7 +728,7 @@ class GenericPPOModule(PPOModule):
         if self.recurrent:  # states come back as [B, recurrent_N, H] (rnn.py:49)
             v, a, lp, hp, hc = self._forward_rnn(critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks,
                                                  deterministic)
-            rN, Hh = self.policy_net.recurrent_N, self.policy_net.H
+            rN, Hh = self.policy_net.recurrent_N, self.policy_net.state_w
             return v, a, lp, hp.reshape(-1, rN, Hh), hc.reshape(-1, rN, Hh)
         values, actions, logp = self._forward(critic_obs, obs, action_masks, deterministic)
         return values, actions, logp, rnn_states_actor, rnn_states_critic
@@ -712,7 +742,7 @@ class GenericPPOModule(PPOModule):
         if self.recurrent:
             _, actions, _, hp, _ = self._forward_rnn(None, obs, rnn_states_actor, None, masks, action_masks, deterministic,
                                                      want_value=False)
-            return actions, hp.reshape(-1, self.policy_net.recurrent_N, self.policy_net.H)
+            return actions, hp.reshape(-1, self.policy_net.recurrent_N, self.policy_net.state_w)
         _, actions, _ = self._forward(None, obs, action_masks, deterministic, want_value=False)
         return actions, rnn_states_actor
 
@@ -760,7 +790,7 @@ class GenericPPOModule(PPOModule):
         """Recurrent evaluate_actions (policy_network.py:164-203 + RNNLayer.forward): the rows are L steps of N sequences
         flattened [L * N, ...] (recurrent_generator's layout), the states [N, (1,) H] enter step 0."""
         pn, cn = self.policy_net, self.critic_net
-        H = pn.H * pn.recurrent_N
+        H = pn.state_w * pn.recurrent_N
         x = self._dev(obs, self.Dp)
         hp = self._dev(h_policy, H)
         Np, Bp = hp.shape[0], x.shape[0]

@@ -229,6 +229,20 @@ def gru_gate_bwd(dh, save, h_in, dgi, dgh, dh_in) -> None:
     nat.check(rc, "orl_gen_gru_gate_bwd")
 
 
+def lstm_gate_fwd(gi, gh, c_in, mask_next, h_out, c_out, h_in_next, c_in_next, save) -> None:
+    N, H = c_in.shape
+    rc = _lib().orl_gen_lstm_gate_fwd(fptr(gi), fptr(gh), fptr(c_in), fptr(mask_next), N, H, fptr(h_out), fptr(c_out),
+                                      fptr(h_in_next), fptr(c_in_next), fptr(save), stream_ptr(nat.require_gpu(c_in.device)))
+    nat.check(rc, "orl_gen_lstm_gate_fwd")
+
+
+def lstm_gate_bwd(dh, dc, save, c_in, dgates, dc_in) -> None:
+    N, H = c_in.shape
+    rc = _lib().orl_gen_lstm_gate_bwd(fptr(dh), fptr(dc), fptr(save), fptr(c_in), N, H, fptr(dgates), fptr(dc_in),
+                                      stream_ptr(nat.require_gpu(c_in.device)))
+    nat.check(rc, "orl_gen_lstm_gate_bwd")
+
+
 def row_affine(a, b, row_scale, add, out) -> None:
     """out = (a + b) * row_scale[:, None] + add; ``b`` / ``row_scale`` / ``add`` may be None."""
     N, H = a.shape

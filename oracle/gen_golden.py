@@ -34,7 +34,7 @@ def _cfg(argv, N, T):
     cfg.num_agents = 1
     cfg.n_rollout_threads = N
     cfg.learner_n_rollout_threads = N
-    cfg.rnn_hidden_size = cfg.hidden_size
+    cfg.rnn_hidden_size = cfg.hidden_size * (2 if cfg.rnn_type == "lstm" else 1)  # modules/common/ppo_net.py:72-81
     cfg.episode_length = T
     return cfg
 
@@ -497,7 +497,8 @@ def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=
     # deterministic probe with non-trivial states and a zero mask on theta1
     B = 12
     pp, pc = rs.randn(B, Dp).astype(np.float32), rs.randn(B, Dc).astype(np.float32)
-    ha, hc = (0.5 * rs.randn(B, 1, H)).astype(np.float32), (0.5 * rs.randn(B, 1, H)).astype(np.float32)
+    sw = (cfg.recurrent_N, cfg.rnn_hidden_size)  # [recurrent_N, H] (GRU) or [recurrent_N, 2 H] (LSTM: h | c)
+    ha, hc = (0.5 * rs.randn(B, *sw)).astype(np.float32), (0.5 * rs.randn(B, *sw)).astype(np.float32)
     pm = np.ones((B, 1), np.float32)
     pm[::3] = 0.0
     algo.prep_rollout()
@@ -667,6 +668,13 @@ def main():
         "train_recurrent_gen_n2": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--recurrent_N", "2", "--data_chunk_length", "3"], 7, 7,
             lambda: Discrete(4), N=5, A=2, T=9, seed=34),
+        # LSTM cells (rnn_type lstm): states [h | c] of width 2 H; one layer on a non-default trunk, two layers on the default
+        "train_recurrent_gen_lstm": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--rnn_type", "lstm", "--hidden_size", "48", "--data_chunk_length",
+                "3"], 7, 7, lambda: Discrete(4), N=5, A=2, T=9, seed=35),
+        "train_recurrent_gen_lstm_n2": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--rnn_type", "lstm", "--recurrent_N", "2"], 6, 6,
+            lambda: Box(-1, 1, (2,)), N=4, A=1, T=8, seed=36),
         "train_recurrent_gen_l2_tanh_fn": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--hidden_size", "32", "--layer_N", "2", "--activation_id",
                 "0", "--use_feature_normalization", "true", "--data_chunk_length", "4"], 6, 6,

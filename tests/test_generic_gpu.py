@@ -283,9 +283,10 @@ def test_whole_tower_launch_equals_the_layer_by_layer_forward(argv, D, B):
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
 @pytest.mark.parametrize("H,L,N,rN", [(128, 5, 70, 1), (36, 3, 200, 1), (64, 10, 33, 1), (168, 2, 50, 1), (256, 3, 40, 1),
                                        (512, 2, 20, 1), (64, 4, 60, 2), (32, 3, 50, 3)])
-def test_gru_sequence_forward_backward_against_torch_fp64(H, L, N, rN):
+def test_gru_sequence_forward_backward_against_torch_fp64(H, L, N, rN, cell):
     """generic_net.gru_forward / gru_backward (projection GEMMs + orl_gen_gru_gate_fwd/_bwd + the LayerNorm after the
     stack) vs a stack of GRU cells + LayerNorm under torch autograd in fp64, with the reference's masking
     h_{t-1} * mask_t on every layer (networks/utils/rnn.py:39-99); recurrent_N = 1, 2, 3 layers."""
@@ -293,32 +294,42 @@ def test_gru_sequence_forward_backward_against_torch_fp64(H, L, N, rN):
     from openrl_amd.configs.config import default_cfg
     from openrl_amd.modules import generic_net as gn
 
-    cfg = default_cfg(["--hidden_size", str(H), "--use_recurrent_policy", "true", "--recurrent_N", str(rN)])
+    cfg = default_cfg(["--hidden_size", str(H), "--use_recurrent_policy", "true", "--recurrent_N", str(rN), "--rnn_type", cell])
     net = gn.GenNet("policy", cfg, 6, spaces.Discrete(3), DEV, recurrent=True)
+    G, SW = net.G, net.state_w
+    assert (G, SW) == ((3, H) if cell == "gru" else (4, 2 * H))
     torch.manual_seed(H + L)
     net.host_init(cfg)
     net.theta.add_(0.05 * torch.randn_like(net.theta))
     r = net.rnn
     t64 = lambda off, *sh: net.v(off, *sh).detach().cpu().double().clone().requires_grad_(True)
-    P = [dict(Wih=t64(ly["Wih"], 3 * H, H), Whh=t64(ly["Whh"], 3 * H, H), bih=t64(ly["bih"], 3 * H), bhh=t64(ly["bhh"], 3 * H))
+    P = [dict(Wih=t64(ly["Wih"], G * H, H), Whh=t64(ly["Whh"], G * H, H), bih=t64(ly["bih"], G * H), bhh=t64(ly["bhh"], G * H))
          for ly in r["layers"]]
     g, be = t64(r["g"], H), t64(r["be"], H)
     feats = torch.randn(L * N, H, dtype=torch.float64, requires_grad=True)
-    h0 = torch.randn(N, rN, H, dtype=torch.float64)
+    h0 = torch.randn(N, rN, SW, dtype=torch.float64)
     masks = (torch.rand(L * N) > 0.2).double()
     dy = torch.randn(L * N, H, dtype=torch.float64)
-    hs, ys = [h0[:, k] for k in range(rN)], []
+    hs, ys = [h0[:, k] for k in range(rN)], []   # per layer: h (GRU) or [h | c] (LSTM)
     for t in range(L):
         s = slice(t * N, (t + 1) * N)
         x = feats[s]
         for k, p in enumerate(P):
-            hin = hs[k] * masks[s, None]
+            st = hs[k] * masks[s, None]
+            hin = st[:, :H]
             gi, gh = x @ p["Wih"].t() + p["bih"], hin @ p["Whh"].t() + p["bhh"]
-            rr = torch.sigmoid(gi[:, :H] + gh[:, :H])
-            zz = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
-            nn_ = torch.tanh(gi[:, 2 * H:] + rr * gh[:, 2 * H:])
-            hs[k] = (1 - zz) * nn_ + zz * hin
-            x = hs[k]
+            if cell == "gru":
+                rr = torch.sigmoid(gi[:, :H] + gh[:, :H])
+                zz = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+                nn_ = torch.tanh(gi[:, 2 * H:] + rr * gh[:, 2 * H:])
+                hs[k] = (1 - zz) * nn_ + zz * hin
+                x = hs[k]
+            else:
+                a = gi + gh
+                ig, fg, gg, og = torch.sigmoid(a[:, :H]), torch.sigmoid(a[:, H:2 * H]), torch.tanh(a[:, 2 * H:3 * H]), torch.sigmoid(a[:, 3 * H:])
+                cn = fg * st[:, H:] + ig * gg
+                x = og * torch.tanh(cn)
+                hs[k] = torch.cat([x, cn], -1)
         ys.append(torch.nn.functional.layer_norm(x, (H,), g, be, 1e-5))
     y_ref = torch.cat(ys)
     (y_ref * dy).sum().backward()
@@ -335,8 +346,8 @@ def test_gru_sequence_forward_backward_against_torch_fp64(H, L, N, rN):
     np.testing.assert_allclose(dfeat.cpu().numpy(), feats.grad.numpy(), rtol=2e-4, atol=2e-4)
     checks = [(r["g"], g, (H,)), (r["be"], be, (H,))]
     for ly, p in zip(r["layers"], P):
-        checks += [(ly["Wih"], p["Wih"], (3 * H, H)), (ly["Whh"], p["Whh"], (3 * H, H)), (ly["bih"], p["bih"], (3 * H,)),
-                   (ly["bhh"], p["bhh"], (3 * H,))]
+        checks += [(ly["Wih"], p["Wih"], (G * H, H)), (ly["Whh"], p["Whh"], (G * H, H)), (ly["bih"], p["bih"], (G * H,)),
+                   (ly["bhh"], p["bhh"], (G * H,))]
     for off, ref, sh in checks:
         np.testing.assert_allclose(net.v(off, *sh, grad=True).cpu().numpy(), ref.grad.numpy(), rtol=3e-4, atol=4e-5 * sB)
 

@@ -38,7 +38,7 @@ def build_engine(g, seed=None):
     cfg = H.case_cfg(g)
     T, N, A = g["buf_actions"].shape[:3]
     cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents = T, N, A
-    cfg.rnn_hidden_size = cfg.hidden_size
+    cfg.rnn_hidden_size = cfg.hidden_size * (2 if cfg.rnn_type == "lstm" else 1)  # modules/common/ppo_net.py:72-81
     obs_space, act_space = _spaces(g)
     if seed is not None:
         import random
@@ -228,7 +228,8 @@ def test_recurrent_evaluate_actions_vs_oracle():
 
 
 # ---- recurrent GENERAL towers (hidden_size / layer_N / activation / feature norm + the GRU): modules/generic_net.py ----
-GEN_RNN_CASES = [("train_recurrent_gen_h128", 31), ("train_recurrent_gen_l2_tanh_fn", 32), ("train_recurrent_gen_n2", 34)]
+GEN_RNN_CASES = [("train_recurrent_gen_h128", 31), ("train_recurrent_gen_l2_tanh_fn", 32), ("train_recurrent_gen_n2", 34),
+                 ("train_recurrent_gen_lstm", 35), ("train_recurrent_gen_lstm_n2", 36)]
 _BUF_FIELDS = ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks",
                "bad_masks", "active_masks", "action_masks", "rnn_states", "rnn_states_critic")
 
@@ -250,7 +251,8 @@ def test_general_recurrent_towers_init_and_state_dict_are_the_reference_s(case, 
     np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c0"], rtol=1e-4, atol=3e-5)
     Hs = cfg.hidden_size
     sd = module.models["critic"].state_dict()
-    assert sd["rnn.rnn.weight_hh_l0"].shape == (3 * Hs, Hs) and sd["rnn.norm.weight"].shape == (Hs,)
+    G = 4 if cfg.rnn_type == "lstm" else 3
+    assert sd["rnn.rnn.weight_hh_l0"].shape == (G * Hs, Hs) and sd["rnn.norm.weight"].shape == (Hs,)
     assert ("rnn.rnn.bias_hh_l1" in sd) == (cfg.recurrent_N == 2)
     keys = [k for k in sd if not k.startswith("value_normalizer")]
     assert keys.index("rnn.rnn.weight_ih_l0") < keys.index("v_out.weight") and keys[-1] == "v_out.bias"
@@ -291,7 +293,7 @@ def test_general_recurrent_stepwise_rollout_reproduces_the_reference_buffer(case
     _load_case(g, buf, module)
     buf.rnn_states.zero_(); buf.rnn_states_critic.zero_()
     T, N, A = g["buf_actions"].shape[:3]
-    Hs, rN = cfg.hidden_size, cfg.recurrent_N
+    Hs, rN = cfg.rnn_hidden_size, cfg.recurrent_N   # state width: H, or 2 H = [h | c] for an LSTM
     for t in range(T):
         v, a, lp, hp, hc = module.get_actions(buf.get_batch_data("critic_obs", t), buf.get_batch_data("policy_obs", t),
                                               buf.get_batch_data("rnn_states", t), buf.get_batch_data("rnn_states_critic", t),
@@ -310,7 +312,7 @@ def test_general_recurrent_stepwise_rollout_reproduces_the_reference_buffer(case
 
 @pytest.mark.parametrize("argv", [["--hidden_size", "128"], ["--hidden_size", "32", "--layer_N", "2", "--activation_id", "0",
                                                              "--use_naive_recurrent_policy", "true", "--use_recurrent_policy", "false"],
-                                  ["--recurrent_N", "2"]])
+                                  ["--recurrent_N", "2"], ["--rnn_type", "lstm", "--hidden_size", "96"]])
 def test_general_recurrent_agent_trains_mpe_end_to_end(argv, tmp_path):
     """make / PPONet / PPOAgent.train with a recurrent policy on NON-default towers on the device MPE env: the stepwise
     rollout (captured into a hipGraph after the first iteration) carries the GRU states through the buffer, the update
