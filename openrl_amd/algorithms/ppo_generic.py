@@ -64,7 +64,8 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
             dist_utils.allreduce_(den_c)
     pn, cn = mod.policy_net, mod.critic_net
     shared = mod.share_model
-    one_pass = shared and buffer.critic_obs is buffer.policy_obs
+    # (recurrent: the actor and the critic carry their own stored states through the shared GRU - two passes)
+    one_pass = shared and buffer.critic_obs is buffer.policy_obs and rnn is None
 
     # ---- forward
     wp = mod.workspace(pn, mb, True, "p")
@@ -130,14 +131,18 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
                 logstd_grad(model)
             gn.trunk_backward(model, wp, dfeat)
         else:
-            dfeat = wc.v(wc.dfeat, mb, model.H)
+            dfeat = wc.v(wc.dfeat, mb_c, model.H)
             gn.head_backward(model, wc, "v_out", feats_c, dvalues, dfeat, False)
+            if rnn is not None:
+                dfeat = gn.gru_backward(model, gc, trunk_c, mrows_c, dfeat, L, mb_c // L)
             gn.trunk_backward(model, wc, dfeat)
             if turn_on:
                 g1 = model.grad.clone()
                 dfeat = wp.v(wp.dfeat, mb, model.H)
                 gn.head_backward(model, wp, "act", feats_p, dlogits, dfeat, False)
                 logstd_grad(model)
+                if rnn is not None:  # rewrites the GRU's slots like the trunk's; g1 holds the critic pass's
+                    dfeat = gn.gru_backward(model, gp, trunk_p, mrows, dfeat, L, Nc)
                 gn.trunk_backward(model, wp, dfeat)  # rewrites the trunk slots; head slots of the other pass stay
                 hv = model.heads["v_out"]
                 lo, hi = hv["W"], hv["b"] + 1

@@ -56,7 +56,6 @@ class GenNet:
 
     def __init__(self, role: str, cfg, obs_dim: int, act_space, device, recurrent: bool = False) -> None:
         assert role in ("policy", "critic", "model")
-        assert not (recurrent and role == "model")
         self.role, self.device, self.recurrent = role, device, bool(recurrent)
         self.H = H = int(cfg.hidden_size)
         if H % 4 or H > 512:
@@ -82,7 +81,8 @@ class GenNet:
         self.recurrent_N, self.cell, self.G, self.state_w = 1, "gru", 3, H
         if self.recurrent:  # RNNLayer (networks/utils/rnn.py:5-27): nn.GRU(H, H, num_layers=1) + LayerNorm(H)
             self.recurrent_N = rN = int(cfg.recurrent_N)
-            self.cell = str(getattr(cfg, "rnn_type", "gru"))
+            # PolicyValueNetwork builds its RNNLayer without rnn_type: always a GRU (policy_value_network.py:85-91)
+            self.cell = "gru" if role == "model" else str(getattr(cfg, "rnn_type", "gru"))
             assert self.cell in ("gru", "lstm")
             self.G = G = 3 if self.cell == "gru" else 4          # gate blocks of the projections
             self.state_w = H if self.cell == "gru" else 2 * H   # stored state per layer: h, or [h | c] (rnn.py:31-37)
@@ -554,8 +554,9 @@ class GenericPPOModule(PPOModule):
         if self.recurrent:
             if cfg.recurrent_N < 1 or getattr(cfg, "rnn_type", "gru") not in ("gru", "lstm"):
                 raise NotImplementedError("recurrent towers: rnn_type gru or lstm, recurrent_N >= 1")
-            if share_model or cfg.use_share_model:
-                raise NotImplementedError("use_share_model with a recurrent policy is not built")
+            if (share_model or cfg.use_share_model) and getattr(cfg, "rnn_type", "gru") != "gru":
+                raise NotImplementedError("use_share_model with rnn_type lstm: the reference's shared network is a GRU "
+                                          "while PPONet sizes the stored states for an LSTM")
         self.lr, self.critic_lr = cfg.lr, cfg.critic_lr
         self.opti_eps, self.weight_decay = cfg.opti_eps, cfg.weight_decay
         self.act_space = act_space
@@ -568,7 +569,7 @@ class GenericPPOModule(PPOModule):
             if self.Dc != self.Dp:
                 raise NotImplementedError("use_share_model: critic observations go through the policy's obs_prep "
                                           "(policy_value_network.py:75) and must have the same width")
-            model = GenNet("model", cfg, self.Dp, act_space, self.device)
+            model = GenNet("model", cfg, self.Dp, act_space, self.device, recurrent=self.recurrent)
             model.host_init(cfg)
             if cfg.use_valuenorm:
                 model.value_normalizer = ValueNorm(1, device=self.device)

@@ -407,7 +407,7 @@ def _train_case_full(name, argv, N, T, D, n_act, seed=0):
     print(name + ".npz", {k: float(info[k]) for k in info})
 
 
-def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=0, naive=False):
+def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=0, naive=False, share=False):
     """use_recurrent_policy: hand-driven rollout (rnn states zeroed on env-done, onpolicy_driver.py:91-108),
     then PPOAlgorithm.train with recurrent_generator (ppo.py:363-372, replay_data.py:1062-1258)."""
     from gymnasium.spaces import Box, Dict as DictSpace
@@ -429,8 +429,11 @@ def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=
         obs_space = DictSpace({"policy": Box(-np.inf, np.inf, (Dp,)), "critic": Box(-np.inf, np.inf, (Dc,))})
     set_seed(cfg.seed)
     module = PPOModule(cfg, policy_input_space=obs_space, critic_input_space=obs_space, act_space=act_space,
-                       share_model=False, rank=0, world_size=1)
-    out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"])}
+                       share_model=share, rank=0, world_size=1)
+    if share:  # PolicyValueNetwork with its own RNNLayer (policy_value_network.py:85-91): one network, one optimizer
+        out = {"theta_m0": _flat(module.models["model"])}
+    else:
+        out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"])}
     buffer = NormalReplayBuffer(cfg, A, obs_space, act_space, data_client=None)
     algo = PPOAlgorithm(cfg, module, agent_num=A)
     rs = np.random.RandomState(200 + seed)
@@ -487,8 +490,11 @@ def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=
     out["train_info"] = np.array([float(info[k]) for k in
                                   ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
                                    "ratio")], np.float64)
-    out["theta_p1"] = _flat(module.models["policy"])
-    out["theta_c1"] = _flat(module.models["critic"])
+    if share:
+        out["theta_m1"] = _flat(module.models["model"])
+    else:
+        out["theta_p1"] = _flat(module.models["policy"])
+        out["theta_c1"] = _flat(module.models["critic"])
     if vn is not None:
         out["vn_state1"] = np.array([vn.running_mean.item(), vn.running_mean_sq.item(), vn.debiasing_term.item()],
                                     np.float32)
@@ -675,6 +681,10 @@ def main():
         "train_recurrent_gen_lstm_n2": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--rnn_type", "lstm", "--recurrent_N", "2"], 6, 6,
             lambda: Box(-1, 1, (2,)), N=4, A=1, T=8, seed=36),
+        # the shared PolicyValueNetwork with its RNNLayer: both passes (actor / critic states) go through one GRU
+        "train_share_recurrent": lambda n: _train_case_recurrent(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--use_share_model", "true", "--hidden_size", "40",
+                "--data_chunk_length", "3"], 6, 6, lambda: Discrete(4), N=5, A=2, T=9, seed=37, share=True),
         "train_recurrent_gen_l2_tanh_fn": lambda n: _train_case_recurrent(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--hidden_size", "32", "--layer_N", "2", "--activation_id",
                 "0", "--use_feature_normalization", "true", "--data_chunk_length", "4"], 6, 6,

@@ -339,3 +339,50 @@ def test_general_recurrent_agent_trains_mpe_end_to_end(argv, tmp_path):
     action, _ = agent.act(obs, deterministic=True)
     assert action.shape == (16, 3, 1)
     env.close()
+
+
+def test_shared_recurrent_network_matches_reference_golden():
+    """use_share_model + use_recurrent_policy: ONE PolicyValueNetwork whose GRU serves the actor pass (rnn_states) and the
+    critic pass (rnn_states_critic) - policy_value_network.py:85-91,113-172.  Init, the update (two passes through the
+    shared trunk + GRU, gradients summed, both clips) and the stored states of a stepwise rollout vs the reference."""
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers.replay_data import ReplayData
+    from openrl_amd.modules.ppo_module import PPOModule
+
+    g = H.load_golden("train_share_recurrent")
+    cfg = H.case_cfg(g)
+    T, N, A = g["buf_actions"].shape[:3]
+    cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = T, N, A, cfg.hidden_size
+    obs_space, act_space = _spaces(g)
+    import random
+    random.seed(37); np.random.seed(37); torch.manual_seed(37)
+    module = PPOModule(cfg, obs_space, obs_space, act_space, share_model=True, device=DEV, rank=0, world_size=1)
+    model = module.models["model"]
+    assert module.generic and module.recurrent and module.share_model
+    np.testing.assert_allclose(model.reference_flat().cpu().numpy(), g["theta_m0"], rtol=1e-4, atol=3e-5)
+    model.load_reference_flat(g["theta_m0"])
+    buf = ReplayData(cfg, A, obs_space, act_space, device=DEV)
+    for f in _BUF_FIELDS:
+        if "buf_" + f in g and getattr(buf, f) is not None:
+            getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+    algo = PPOAlgorithm(cfg, module, agent_num=A, device=DEV)
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    info = algo.train(buf)
+    np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
+    np.testing.assert_allclose(model.reference_flat().cpu().numpy(), g["theta_m1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
+    # teacher-forced stepwise rollout on the initial weights: both state streams of the buffer
+    model.load_reference_flat(g["theta_m0"])
+    buf.rnn_states.zero_(); buf.rnn_states_critic.zero_()
+    Hs = cfg.hidden_size
+    for t in range(T):
+        v, a, lp, hp, hc = module.get_actions(buf.get_batch_data("critic_obs", t), buf.get_batch_data("policy_obs", t),
+                                              buf.get_batch_data("rnn_states", t), buf.get_batch_data("rnn_states_critic", t),
+                                              buf.get_batch_data("masks", t))
+        m = buf.masks[t + 1].unsqueeze(-1)
+        buf.rnn_states[t + 1].copy_(hp.view(N, A, 1, Hs) * m)
+        buf.rnn_states_critic[t + 1].copy_(hc.view(N, A, 1, Hs) * m)
+        np.testing.assert_allclose(v.cpu().numpy().reshape(N, A, 1), g["buf_value_preds"][t], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(buf.rnn_states.cpu().numpy(), g["buf_rnn_states"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(buf.rnn_states_critic.cpu().numpy(), g["buf_rnn_states_critic"], rtol=3e-4, atol=3e-5)
