@@ -599,6 +599,7 @@ class GenericPPOModule(PPOModule):
         self.rng_step = 0
         self.rng_step_dev = None
         self._ws: Dict = {}
+        self._ws_retired: List = []  # outgrown workspaces, kept alive for hipGraphs captured while they were current
 
     # ------------------------------------------------------------------ nets
     @property
@@ -613,6 +614,8 @@ class GenericPPOModule(PPOModule):
         key = (id(net), training, tag)
         ws = self._ws.get(key)
         if ws is None or ws.rows < rows:
+            if ws is not None:  # a captured rollout hipGraph may still point into the old buffers: never free them
+                self._ws_retired.append(ws)
             ws = self._ws[key] = GenWorkspace(net, rows, training)
         return ws
 
@@ -620,6 +623,9 @@ class GenericPPOModule(PPOModule):
         key = ("gru", id(net), training, tag)
         gw = self._ws.get(key)
         if gw is None or gw.L * gw.N < L * N or gw.N < N:
+            if gw is not None:
+                self._ws_retired.append(gw)
+                L, N = max(L, gw.L), max(N, gw.N)
             gw = self._ws[key] = GruWorkspace(net, L, N, training)
         return gw
 
