@@ -349,8 +349,11 @@ class PPOAlgorithm(BaseAlgorithm):
         ops_gen.gather_cols(rec, o_act, a_w, rows_p, B, act)
         if K:
             ops_gen.gather_cols(rec, o_act + 2 * a_w + 4, K, rows_p, B, am)
-        h0 = buffer.rnn_states.reshape(-1, H)[rows_p[:ns]]
-        mk = buffer.masks.reshape(-1)[rows_p]
+        if j.get("h0") is None or j["h0"].shape != (ns, H):
+            j["h0"], j["mk"] = torch.empty(ns, H, dtype=torch.float32, device=dev), torch.empty(L * ns, dtype=torch.float32, device=dev)
+        h0, mk = j["h0"], j["mk"][:B]
+        ops_gen.gather_cols(buffer.rnn_states.view(-1, H), 0, H, rows_p[:ns], ns, h0)
+        ops_gen.gather_cols(buffer.masks.view(-1, 1), 0, 1, rows_p, B, mk.view(B, 1))
         _, logp, _, _ = mod._evaluate_actions_rnn(None, x, h0, None, act, mk, am, None)
         # (2) joint-ratio records
         rec2 = j["rec2"]

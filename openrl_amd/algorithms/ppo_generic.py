@@ -76,9 +76,10 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     if rnn is not None:
         L, Nc = rnn
         H = pn.state_w * pn.recurrent_N
-        mrows = buffer.masks.reshape(-1)[idx]                    # mask of step l of chunk i: the same row index
-        h0p = buffer.rnn_states.reshape(-1, H)[idx[:Nc]]         # stored states at the chunk starts [Nc, recurrent_N * H]
         gp = mod.gru_workspace(pn, L, Nc, True, "p")
+        mrows, h0p = gp.mrows[:mb], gp.h0[:Nc]
+        ops_gen.gather_cols(buffer.masks.view(-1, 1), 0, 1, idx, mb, mrows.view(mb, 1))   # mask of step l of chunk i
+        ops_gen.gather_cols(buffer.rnn_states.view(-1, H), 0, H, idx[:Nc], Nc, h0p)        # states at the chunk starts
         trunk_p, feats_p = feats_p, gn.gru_forward(pn, gp, feats_p, h0p, mrows, L, Nc, True)
     logits = gn.head_forward(pn, wp, "act", feats_p)
     if one_pass:
@@ -89,10 +90,13 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
         ops_gen.gather_cols(rec, Dp, Dc, idx_c, mb_c, xc)
         feats_c = gn.trunk_forward(cn, wc, xc, True)
         if rnn is not None:
-            Ncc = mb_c // L
-            mrows_c = mrows if idx_c is idx else buffer.masks.reshape(-1)[idx_c]
-            h0c = buffer.rnn_states_critic.reshape(-1, cn.state_w * cn.recurrent_N)[idx_c[:Ncc]]
+            Ncc, Hc = mb_c // L, cn.state_w * cn.recurrent_N
             gc = mod.gru_workspace(cn, L, Ncc, True, "c")
+            mrows_c, h0c = mrows, gc.h0[:Ncc]
+            if idx_c is not idx:
+                mrows_c = gc.mrows[:mb_c]
+                ops_gen.gather_cols(buffer.masks.view(-1, 1), 0, 1, idx_c, mb_c, mrows_c.view(mb_c, 1))
+            ops_gen.gather_cols(buffer.rnn_states_critic.view(-1, Hc), 0, Hc, idx_c[:Ncc], Ncc, h0c)
             trunk_c, feats_c = feats_c, gn.gru_forward(cn, gc, feats_c, h0c, mrows_c, L, Ncc, True)
     values = gn.head_forward(cn, wc, "v_out", feats_c)
 

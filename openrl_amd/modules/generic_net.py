@@ -444,6 +444,8 @@ class GruWorkspace:
         self.h = self.layers[-1]["h"]      # output states of the last layer, every step
         self.y = e(L * N, H)                # LayerNorm(h): what the head reads
         self.h_last = e(N, len(self.layers), net.state_w)  # states after the last step, [N, recurrent_N, H or 2H]
+        self.h0 = e(N, len(self.layers) * net.state_w)     # gathered initial states / masks of an update minibatch
+        self.mrows = e(L * N)
         if training:
             self.xhat, self.rstd = e(L * N, H), e(L * N)
             self.dh, self.dh_dir, self.tmp = e(L * N, H), e(N, H), e(N, H)
