@@ -232,6 +232,8 @@ def trunk_forward(p: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
 
 
 def tower_forward(spec: TowerSpec, theta: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    if getattr(spec, "general", False):  # general towers restate their own forward (oracle/gen_oracle.py)
+        return spec.forward(theta, x)
     p = spec.split(theta)
     return F.linear(trunk_forward(p, x), p["W3"], p["b3"])
 

@@ -79,6 +79,8 @@ def rnn_tower_forward(spec: RnnTowerSpec, theta: torch.Tensor, x: torch.Tensor, 
                       masks: torch.Tensor):
     """``x`` [L*N, D] (row = l*N + n, rnn.py:50-57), ``h0`` [N, H], ``masks`` [L*N, 1].
     Returns (head output [L*N, K], final state [N, H])."""
+    if getattr(spec, "general", False):  # general trunks, GRU / LSTM stacks: oracle/gen_oracle.py
+        return spec.rnn_forward(theta, x, h0, masks)
     p = spec.split(theta)
     H = spec.hidden
     N = h0.shape[0]
@@ -208,7 +210,7 @@ def ppo_update(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, sample_np: Di
 
 def buffer_rows(buf: Dict[str, np.ndarray], adv: np.ndarray) -> Dict[str, Optional[np.ndarray]]:
     """The ``_cast`` views of replay_data.py:1127-1145 (rnn states: [T+1,N,A,1,H] -> [N*A*T, H])."""
-    H = buf["rnn_states"].shape[-1]
+    H = buf["rnn_states"].shape[-1] * buf["rnn_states"].shape[-2]  # [recurrent_N, state width] flattened per position
     cs = lambda x: np.ascontiguousarray(x[:-1].transpose(1, 2, 0, 3, 4)).reshape(-1, H)
     return {
         "critic_obs": cast_rows(buf["critic_obs"][:-1]), "policy_obs": cast_rows(buf["policy_obs"][:-1]),

@@ -106,3 +106,51 @@ def test_deterministic_probe_matches_reference(case):
     np.testing.assert_allclose(v, g["probe_values"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(a, g["probe_actions"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(lp, g["probe_logp"], rtol=1e-5, atol=1e-6)
+
+
+# ---- general towers: oracle/gen_oracle.py pinned on the goldens minted from the reference ---------------------------
+GEN_FF_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3"]
+
+
+def _gen_specs(g):
+    from oracle import gen_oracle as go
+
+    cfg = H.case_cfg(g)
+    D = g["buf_policy_obs"].shape[-1]
+    if "buf_action_masks" in g:
+        return cfg, go.specs_from_cfg(cfg, D, g["buf_action_masks"].shape[-1], po.HEAD_CATEGORICAL)
+    return cfg, go.specs_from_cfg(cfg, D, g["buf_actions"].shape[-1], po.HEAD_GAUSSIAN)
+
+
+@pytest.mark.parametrize("case", GEN_FF_CASES)
+def test_general_tower_oracle_replays_the_reference(case):
+    """MLPBase / MLPLayer of any hidden_size / layer_N / activation / feature norm (mlp.py:8-46,100-180), restated on one
+    flat vector incl. the dead ``fc_h`` block: parameter count, the full ``PPOAlgorithm.train`` replay and the
+    deterministic probe against the reference's outputs."""
+    g = H.load_golden(case)
+    cfg, (pspec, cspec) = _gen_specs(g)
+    assert pspec.n_params() == g["theta_p0"].size and cspec.n_params() == g["theta_c0"].size
+    hp = po.hyper_from_cfg(cfg)
+    ptheta, ctheta = torch.tensor(g["theta_p0"]).clone(), torch.tensor(g["theta_c0"]).clone()
+    padam = po.AdamOracle(ptheta.numel(), cfg.lr, cfg.opti_eps, cfg.weight_decay)
+    cadam = po.AdamOracle(ctheta.numel(), cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)
+    vn = po.ValueNormOracle() if cfg.use_valuenorm else None
+    torch.manual_seed(int(g["perm_seed"]))
+    info, _, used = po.train_ppo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, H.case_buffer(g), cfg.ppo_epoch,
+                                 cfg.num_mini_batch)
+    assert len(used) == cfg.ppo_epoch * cfg.num_mini_batch
+    np.testing.assert_allclose(ptheta.numpy(), g["theta_p1"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(ctheta.numpy(), g["theta_c1"], rtol=2e-5, atol=2e-6)
+    got = np.array([info[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
+                                      "ratio")])
+    np.testing.assert_allclose(got, g["train_info"], rtol=1e-5, atol=1e-6)
+    if cfg.layer_N > 1:  # the dead fc_h block never moved
+        o = [n for n, _ in pspec.sizes()].index("fc_h_W")
+        lo = sum(int(np.prod(s)) for _, s in pspec.sizes()[:o])
+        hi = lo + sum(int(np.prod(s)) for _, s in pspec.sizes()[o:o + 4])
+        assert np.array_equal(ptheta.numpy()[lo:hi], g["theta_p0"][lo:hi])
+    v, a, lp = po.get_actions(pspec, torch.tensor(g["theta_p1"]), cspec, torch.tensor(g["theta_c1"]), g["probe_obs"],
+                              g["probe_obs"], g.get("probe_masks"), deterministic=True)
+    np.testing.assert_allclose(v, g["probe_values"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(a, g["probe_actions"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lp, g["probe_logp"], rtol=1e-5, atol=1e-6)

@@ -104,3 +104,64 @@ def test_jrpo_oracle_replays_the_reference_golden():
     np.testing.assert_allclose(pt.numpy(), g["theta_p1"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(ct.numpy(), g["theta_c1"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(vn.state(), g["vn_state1"], rtol=1e-6)
+
+
+# ---- recurrent GENERAL towers: oracle/gen_oracle.GenRnnTowerSpec pinned on the goldens minted from the reference ------
+GEN_RNN_CASES = ["train_recurrent_gen_h128", "train_recurrent_gen_l2_tanh_fn", "train_recurrent_gen_n2",
+                 "train_recurrent_gen_lstm", "train_recurrent_gen_lstm_n2"]
+
+
+def _gen_rnn_specs(g):
+    from oracle import gen_oracle as go
+
+    cfg = H.case_cfg(g)
+    Dp, Dc = g["buf_policy_obs"].shape[-1], g["buf_critic_obs"].shape[-1]
+    if "buf_action_masks" in g:
+        return cfg, go.rnn_specs_from_cfg(cfg, Dp, Dc, g["buf_action_masks"].shape[-1], po.HEAD_CATEGORICAL)
+    return cfg, go.rnn_specs_from_cfg(cfg, Dp, Dc, g["buf_actions"].shape[-1], po.HEAD_GAUSSIAN)
+
+
+@pytest.mark.parametrize("case", GEN_RNN_CASES)
+def test_general_recurrent_oracle_replays_the_reference(case):
+    """General trunks + GRU / LSTM stacks (mlp.py:8-46,100-180; rnn.py:5-99) restated on one flat vector: parameter
+    count, the full recurrent ``PPOAlgorithm.train`` replay (recurrent_generator chunks) and the deterministic probe incl.
+    the new states against the reference's outputs."""
+    g = H.load_golden(case)
+    cfg, (pspec, cspec) = _gen_rnn_specs(g)
+    assert pspec.n_params() == g["theta_p0"].size and cspec.n_params() == g["theta_c0"].size
+    hp = po.hyper_from_cfg(cfg)
+    pt, ct = torch.tensor(g["theta_p0"]).clone(), torch.tensor(g["theta_c0"]).clone()
+    pa = po.AdamOracle(pt.numel(), cfg.lr, cfg.opti_eps, cfg.weight_decay)
+    ca = po.AdamOracle(ct.numel(), cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)
+    vn = po.ValueNormOracle() if cfg.use_valuenorm else None
+    torch.manual_seed(int(g["perm_seed"]))
+    info, _, used = ro.train_ppo(hp, pspec, pt, cspec, ct, pa, ca, vn, H.case_buffer(g), cfg.ppo_epoch, cfg.num_mini_batch,
+                                 cfg.data_chunk_length)
+    assert len(used) == cfg.ppo_epoch * cfg.num_mini_batch
+    np.testing.assert_allclose(pt.numpy(), g["theta_p1"], rtol=3e-5, atol=3e-6)
+    np.testing.assert_allclose(ct.numpy(), g["theta_c1"], rtol=3e-5, atol=3e-6)
+    np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(vn.state(), g["vn_state1"], rtol=1e-6)
+    v, a, lp, h1, hc1 = ro.get_actions(pspec, torch.tensor(g["theta_p1"]), cspec, torch.tensor(g["theta_c1"]),
+                                       g["probe_policy_obs"], g["probe_critic_obs"], g["probe_h"], g["probe_hc"],
+                                       g["probe_masks"], deterministic=True)
+    np.testing.assert_allclose(v, g["probe_values"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lp, g["probe_logp"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(h1, g["probe_h1"].reshape(h1.shape), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(hc1, g["probe_hc1"].reshape(hc1.shape), rtol=1e-5, atol=1e-6)
+
+
+def test_general_recurrent_jrpo_oracle_replays_the_reference():
+    g = H.load_golden("train_recurrent_gen_jrpo")
+    cfg, (pspec, cspec) = _gen_rnn_specs(g)
+    hp = po.hyper_from_cfg(cfg)
+    pt, ct = torch.tensor(g["theta_p0"]).clone(), torch.tensor(g["theta_c0"]).clone()
+    pa = po.AdamOracle(pt.numel(), cfg.lr, cfg.opti_eps, cfg.weight_decay)
+    ca = po.AdamOracle(ct.numel(), cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)
+    vn = po.ValueNormOracle()
+    torch.manual_seed(int(g["perm_seed"]))
+    info, _, used = ro.train_ppo_jrpo(hp, pspec, pt, cspec, ct, pa, ca, vn, H.case_buffer(g), cfg.ppo_epoch,
+                                      cfg.num_mini_batch, cfg.data_chunk_length)
+    np.testing.assert_allclose([info[k] for k in KEYS], g["train_info"], rtol=3e-5, atol=1e-6)
+    np.testing.assert_allclose(pt.numpy(), g["theta_p1"], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(ct.numpy(), g["theta_c1"], rtol=1e-4, atol=3e-6)
