@@ -144,3 +144,159 @@ def rnn_specs_from_cfg(cfg, Dp: int, Dc: int, n_act: int, head: int):
     kw = dict(hidden=int(cfg.hidden_size), layer_N=int(cfg.layer_N), activation_id=int(cfg.activation_id),
               feature_norm=bool(cfg.use_feature_normalization), cell=str(cfg.rnn_type), recurrent_N=int(cfg.recurrent_N))
     return GenRnnTowerSpec(Dp, n_act, head, **kw), GenRnnTowerSpec(Dc, 1, po.HEAD_VALUE, **kw)
+
+
+# =====================================================================================================
+# PolicyValueNetwork (use_share_model; policy_value_network.py:34-172): obs_prep (MLPBase) -> common
+# (MLPLayer(H, H, layer_N = 0) = fc1 + fc3) -> [RNNLayer, always a GRU] -> v_out / act heads on ONE parameter vector
+# =====================================================================================================
+@dataclass
+class SharedSpec(GenRnnTowerSpec):
+    """One instance per ROLE ("actor": the action head's output, "critic": v_out's) over the same flat vector; ``n_out`` /
+    ``head`` describe the role's output, ``n_act`` / ``act_head`` the action head (both heads are always in the vector)."""
+    role: str = "actor"
+    n_act: int = 1
+    act_head: int = po.HEAD_CATEGORICAL
+    recurrent: bool = False
+
+    def sizes(self):
+        D, H = self.obs_dim, self.hidden
+        s = []
+        if self.feature_norm:
+            s += [("fn_g", (D,)), ("fn_b", (D,))]
+        seq = lambda name, n_in: [(name + "_W", (H, n_in)), (name + "_b", (H,)), (name + "_g", (H,)), (name + "_be", (H,))]
+        s += seq("fc1", D)
+        if self.layer_N > 1:
+            s += seq("fc_h", H)
+            for i in range(self.layer_N - 1):
+                s += seq("fc2_%d" % i, H)
+        s += seq("fc3", H) + seq("c1", H) + seq("c3", H)  # obs_prep.mlp, then common.fc1 / common.fc3
+        if self.recurrent:
+            for l in range(self.recurrent_N):
+                s += [("Wih%d" % l, (3 * H, H)), ("Whh%d" % l, (3 * H, H)), ("bih%d" % l, (3 * H,)), ("bhh%d" % l, (3 * H,))]
+            s += [("rg", (H,)), ("rb", (H,))]
+        s += [("Wv", (1, H)), ("bv", (1,)), ("Wa", (self.n_act, H)), ("ba", (self.n_act,))]
+        if self.act_head == po.HEAD_GAUSSIAN:
+            s.append(("logstd", (self.n_act,)))
+        return s
+
+    def trunk(self, p, x):
+        H, act = self.hidden, _ACTS[self.activation_id]
+        x = GenRnnTowerSpec.trunk(self, p, x)
+        x = F.layer_norm(act(F.linear(x, p["c1_W"], p["c1_b"])), (H,), p["c1_g"], p["c1_be"], 1e-5)
+        return F.layer_norm(F.linear(x, p["c3_W"], p["c3_b"]), (H,), p["c3_g"], p["c3_be"], 1e-5)
+
+    def _head(self, p, y):
+        return F.linear(y, p["Wa"], p["ba"]) if self.role == "actor" else F.linear(y, p["Wv"], p["bv"])
+
+    def forward(self, theta, x):
+        p = self.split(theta)
+        return self._head(p, self.trunk(p, x))
+
+    def rnn_forward(self, theta, x, h0, masks):
+        p = self.split(theta)
+        p["W3"], p["b3"] = (p["Wa"], p["ba"]) if self.role == "actor" else (p["Wv"], p["bv"])
+        self_split, self.split = self.split, (lambda th: p)  # reuse the stack code of GenRnnTowerSpec on this layout
+        try:
+            return GenRnnTowerSpec.rnn_forward(self, theta, x, h0, masks)
+        finally:
+            self.split = self_split
+
+
+def shared_specs_from_cfg(cfg, obs_dim: int, n_act: int, act_head: int):
+    kw = dict(hidden=int(cfg.hidden_size), layer_N=int(cfg.layer_N), activation_id=int(cfg.activation_id),
+              feature_norm=bool(cfg.use_feature_normalization), cell="gru", recurrent_N=int(cfg.recurrent_N), n_act=n_act,
+              act_head=act_head, recurrent=bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy))
+    return (SharedSpec(obs_dim, n_act, act_head, role="actor", **kw),
+            SharedSpec(obs_dim, 1, po.HEAD_VALUE, role="critic", **kw))
+
+
+def shared_ppo_update(hp, aspec, cspec, theta, adam, vn, sample, recurrent: bool):
+    """ppo_update with ``use_share_model`` (ppo.py:46-176): both losses back-propagate into the ONE parameter vector;
+    ``get_actor_para()`` and ``get_critic_para()`` both return all of it, so ``clip_grad_norm_`` runs twice -
+    actor_grad_norm is the raw norm, critic_grad_norm the once-clipped one - then one Adam step."""
+    from . import rnn_oracle as ro
+
+    t = lambda a: None if a is None else torch.as_tensor(a, dtype=torch.float32)
+    th = theta.detach().clone().requires_grad_(True)
+    if recurrent:
+        loss_list, value_loss, policy_loss, dist_entropy, ratio = ro.prepare_loss(hp, aspec, th, cspec, th, vn,
+                                                                                  {k: t(v) for k, v in sample.items()})
+    else:
+        loss_list, value_loss, policy_loss, dist_entropy, ratio = po.prepare_loss(hp, aspec, th, cspec, th, vn,
+                                                                                  tuple(t(a) for a in sample))
+    for loss in loss_list:
+        loss.backward()
+    g = th.grad
+    if hp.use_max_grad_norm:
+        g, an = po.clip_grad_norm(g, hp.max_grad_norm)
+        g, cn = po.clip_grad_norm(g, hp.max_grad_norm)
+    else:
+        an = cn = float(g.norm(2))
+    adam.step(theta, g)
+    return dict(value_loss=value_loss.item(), policy_loss=policy_loss.item(), dist_entropy=dist_entropy.item(),
+                actor_grad_norm=an, critic_grad_norm=cn, ratio=ratio.mean().item())
+
+
+def train_shared(hp, aspec, cspec, theta, adam, vn, buf, ppo_epoch: int, num_mini_batch: int, data_chunk_length: int = 0):
+    """PPOAlgorithm.train_ppo (ppo.py:383-458) on the shared network; ``data_chunk_length > 0`` = recurrent_generator."""
+    from . import rnn_oracle as ro
+
+    adv = po.advantages(buf["returns"], buf["value_preds"], buf["active_masks"], vn if hp.use_valuenorm else None,
+                        hp.use_adv_normalize)
+    keys = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
+    info = {k: 0.0 for k in keys}
+    vnn = vn if hp.use_valuenorm else None
+    if data_chunk_length:
+        rows = ro.buffer_rows(buf, adv)
+        M = rows["adv"].shape[0]
+    else:
+        rows = {"critic_obs": po.flat_rows(buf["critic_obs"][:-1]), "policy_obs": po.flat_rows(buf["policy_obs"][:-1]),
+                "actions": po.flat_rows(buf["actions"]), "value_preds": po.flat_rows(buf["value_preds"][:-1]),
+                "returns": po.flat_rows(buf["returns"][:-1]), "active_masks": po.flat_rows(buf["active_masks"][:-1]),
+                "action_log_probs": po.flat_rows(buf["action_log_probs"]), "adv": adv.reshape(-1, 1),
+                "action_masks": po.flat_rows(buf["action_masks"][:-1]) if buf.get("action_masks") is not None else None}
+        M = rows["adv"].shape[0]
+    for _ in range(ppo_epoch):
+        if data_chunk_length:
+            for chunks in ro.recurrent_chunk_order(M, data_chunk_length, num_mini_batch):
+                step = shared_ppo_update(hp, aspec, cspec, theta, adam, vnn, ro.chunk_sample(rows, chunks, data_chunk_length), True)
+                for k in keys:
+                    info[k] += step[k]
+        else:
+            for idx in po.feed_forward_indices(M, num_mini_batch):
+                g = lambda k: None if rows[k] is None else rows[k][idx]
+                sample = (g("critic_obs"), g("policy_obs"), g("actions"), g("value_preds"), g("returns"), g("active_masks"),
+                          g("action_log_probs"), g("adv"), g("action_masks"))
+                step = shared_ppo_update(hp, aspec, cspec, theta, adam, vnn, sample, False)
+                for k in keys:
+                    info[k] += step[k]
+    n = ppo_epoch * num_mini_batch
+    return {k: v / n for k, v in info.items()}
+
+
+def multidiscrete_evaluate(x, weights, biases, actions, active_masks=None):
+    """ACTLayer.evaluate_actions for a MultiDiscrete space (act.py:136-151): one Categorical per component over the same
+    features; log-probs concatenated per component; the entropy is the active-mask weighted (or plain) mean of each
+    component's entropy, then the mean over components of DETACHED floats (``torch.tensor(dist_entropy).mean()``: no
+    gradient flows into the entropy term for this head)."""
+    logps, ents = [], []
+    for W, b, a in zip(weights, biases, actions.transpose(0, 1)):
+        dist = torch.distributions.Categorical(logits=F.linear(x, W, b))
+        logps.append(dist.log_prob(a.long()).unsqueeze(-1))
+        if active_masks is not None:
+            ents.append((dist.entropy() * active_masks.squeeze(-1)).sum() / active_masks.sum())
+        else:
+            ents.append(dist.entropy().mean())
+    return torch.cat(logps, -1), torch.tensor([float(e) for e in ents]).mean()
+
+
+def multidiscrete_mode(x, weights, biases):
+    """ACTLayer.forward(deterministic=True) for MultiDiscrete (act.py:60-72): per-component argmax + its log-prob."""
+    acts, lps = [], []
+    for W, b in zip(weights, biases):
+        dist = torch.distributions.Categorical(logits=F.linear(x, W, b))
+        a = dist.probs.argmax(dim=-1)
+        acts.append(a.float().unsqueeze(-1))
+        lps.append(dist.log_prob(a).unsqueeze(-1))
+    return torch.cat(acts, -1), torch.cat(lps, -1)

@@ -154,3 +154,57 @@ def test_general_tower_oracle_replays_the_reference(case):
     np.testing.assert_allclose(v, g["probe_values"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(a, g["probe_actions"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(lp, g["probe_logp"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["train_share", "train_share_box_fn", "train_share_recurrent"])
+def test_shared_network_oracle_replays_the_reference(case):
+    """PolicyValueNetwork (use_share_model; policy_value_network.py:34-172) restated on one flat vector - obs_prep, common,
+    [GRU], v_out, act - with the reference's two clips of the same gradient (ppo.py:126-145): full train replay."""
+    from oracle import gen_oracle as go
+
+    g = H.load_golden(case)
+    cfg = H.case_cfg(g)
+    D = g["buf_policy_obs"].shape[-1]
+    if "buf_action_masks" in g:
+        aspec, cspec = go.shared_specs_from_cfg(cfg, D, g["buf_action_masks"].shape[-1], po.HEAD_CATEGORICAL)
+    else:
+        aspec, cspec = go.shared_specs_from_cfg(cfg, D, g["buf_actions"].shape[-1], po.HEAD_GAUSSIAN)
+    assert aspec.n_params() == g["theta_m0"].size
+    hp = po.hyper_from_cfg(cfg)
+    theta = torch.tensor(g["theta_m0"]).clone()
+    adam = po.AdamOracle(theta.numel(), cfg.lr, cfg.opti_eps, cfg.weight_decay)
+    vn = po.ValueNormOracle() if cfg.use_valuenorm else None
+    torch.manual_seed(int(g["perm_seed"]))
+    rec = bool(cfg.use_recurrent_policy)
+    info = go.train_shared(hp, aspec, cspec, theta, adam, vn, H.case_buffer(g), cfg.ppo_epoch, cfg.num_mini_batch,
+                           cfg.data_chunk_length if rec else 0)
+    np.testing.assert_allclose(theta.numpy(), g["theta_m1"], rtol=3e-5, atol=3e-6)
+    got = np.array([info[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
+                                      "ratio")])
+    np.testing.assert_allclose(got, g["train_info"], rtol=2e-5, atol=1e-6)
+    if vn is not None:
+        np.testing.assert_allclose(vn.state(), g["vn_state1"], rtol=1e-6)
+
+
+def test_multidiscrete_actlayer_oracle_matches_the_reference():
+    """ACTLayer with MultiDiscrete([3, 2, 5]) (act.py:26-34,60-72,136-151): log-probs, the detached entropy, the gradient
+    of sum(log-probs) w.r.t. features and head parameters, and the deterministic actions."""
+    from oracle import gen_oracle as go
+
+    g = H.load_golden("actlayer_multidiscrete")
+    n = len(g["nvec"])
+    t = lambda a: torch.tensor(a)
+    x = t(g["x"]).clone().requires_grad_(True)
+    Ws = [t(g["W%d" % i]).clone().requires_grad_(True) for i in range(n)]
+    bs = [t(g["b%d" % i]).clone().requires_grad_(True) for i in range(n)]
+    logp, ent = go.multidiscrete_evaluate(x, Ws, bs, t(g["actions"]), t(g["active"]))
+    logp.sum().backward()
+    np.testing.assert_allclose(logp.detach().numpy(), g["logp"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(float(ent), float(g["entropy"]), rtol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=1e-5, atol=1e-6)
+    for i in range(n):
+        np.testing.assert_allclose(Ws[i].grad.numpy(), g["dW%d" % i], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bs[i].grad.numpy(), g["db%d" % i], rtol=1e-5, atol=1e-6)
+    a, lp = go.multidiscrete_mode(t(g["x"]), [w.detach() for w in Ws], [b.detach() for b in bs])
+    assert np.array_equal(a.numpy(), g["det_actions"])
+    np.testing.assert_allclose(lp.numpy(), g["det_logp"], rtol=1e-6, atol=1e-6)
