@@ -630,6 +630,10 @@ def main():
         "train_gen_leaky_l3": lambda n: _train_case(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--layer_N", "3", "--activation_id", "2",
                 "--use_adv_normalize", "true"], 4, lambda: Discrete(2), use_masks=True, seed=13),
+        # A2CAlgorithm on a general tower (the loss variant through the general path's loss kernels)
+        "train_gen_a2c": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "3", "--hidden_size", "48", "--layer_N", "2", "--activation_id", "0"],
+            5, lambda: Discrete(4), use_masks=True, seed=17, a2c=True),
         "train_share": lambda n: _train_case(
             n, ["--ppo_epoch", "3", "--num_mini_batch", "2", "--use_share_model", "true"], 5, lambda: Discrete(4),
             seed=14, share=True),

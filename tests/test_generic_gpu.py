@@ -10,7 +10,8 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-GEN_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_share", "train_share_box_fn"]
+GEN_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_share", "train_share_box_fn",
+             "train_gen_a2c"]
 # fp32 tolerances of the update path (MFMA k-order, tile-wise gradient sums); same as tests/test_ppo_update_gpu.py
 THETA_RTOL, THETA_ATOL = 2e-3, 3e-5
 INFO_RTOL, INFO_ATOL = 3e-4, 3e-5
@@ -70,12 +71,14 @@ def test_train_matches_reference_golden(case):
               "active_masks", "action_masks"):
         if "buf_" + f in g:
             getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+    if "a2c" in g:  # A2CAlgorithm: policy-gradient loss, one minibatch per epoch, no ratio (a2c.py:27-145)
+        from openrl_amd.algorithms.a2c import A2CAlgorithm as PPOAlgorithm  # noqa: F811
     algo = PPOAlgorithm(cfg, module, agent_num=1, device=DEV)
     torch.manual_seed(int(g["perm_seed"]))
     algo.prep_training()
     info = algo.train(buf)
-    got = np.array([info[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
-                                      "critic_grad_norm", "ratio")])
+    got = np.array([info.get(k, 0.0) for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
+                                               "critic_grad_norm", "ratio")])
     np.testing.assert_allclose(got, g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
     for name, _, k1 in nets(module, g):
         np.testing.assert_allclose(module.models[name].reference_flat().cpu().numpy(), g[k1], rtol=THETA_RTOL,
@@ -476,3 +479,32 @@ def test_loading_a_state_dict_saved_by_the_reference_reproduces_its_outputs(tag)
     np.testing.assert_allclose(vn.state.cpu().numpy(),
                                [float(g["%s/%s/value_normalizer.%s" % (tag, cname, k)].reshape(-1)[0])
                                 for k in ("running_mean", "running_mean_sq", "debiasing_term")], rtol=1e-6)
+
+
+@pytest.mark.parametrize("algo", ["a2c", "mat"])
+def test_algorithm_variants_run_on_general_towers(algo):
+    """A2CAlgorithm (policy-gradient loss bit of the hyper-parameters) and MATAlgorithm ((step, env)-pair minibatches) on
+    NON-default towers: the general path's loss kernels / index handling take both; A2C's update must equal a PPO update
+    with an infinite clip range in its first epoch only up to the loss definition, so the check is end-to-end sanity -
+    finite losses, parameters that move, `ratio` absent for A2C."""
+    from openrl_amd.configs.config import create_config_parser
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet as Net
+    from openrl_amd.runners.common import A2CAgent, MATAgent
+
+    cfg = create_config_parser().parse_args("--hidden_size 96 --layer_N 2 --activation_id 0 --episode_length 20 --ppo_epoch 2 "
+                                            "--num_mini_batch 2".split())
+    env = make("simple_spread", env_num=8)
+    agent = (A2CAgent if algo == "a2c" else MATAgent)(Net(env, cfg=cfg))
+    mod = agent.net.module
+    assert mod.generic
+    th0 = mod.models["policy"].theta.clone()
+    agent.train(total_time_steps=8 * 20 * 3)
+    tr = agent.driver.trainer
+    assert tr.__class__.__name__ == ("A2CAlgorithm" if algo == "a2c" else "MATAlgorithm") and tr.generic
+    assert not torch.equal(th0, mod.models["policy"].theta) and torch.isfinite(mod.models["policy"].theta).all()
+    assert torch.isfinite(mod.models["critic"].theta).all()
+    if algo == "mat":
+        idx = tr.last_indices[-1].cpu().numpy().reshape(-1, 3)
+        assert np.all(idx % 3 == np.arange(3)) and np.all(idx // 3 == idx[:, :1] // 3)
+    env.close()

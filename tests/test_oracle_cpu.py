@@ -109,7 +109,7 @@ def test_deterministic_probe_matches_reference(case):
 
 
 # ---- general towers: oracle/gen_oracle.py pinned on the goldens minted from the reference ---------------------------
-GEN_FF_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3"]
+GEN_FF_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_gen_a2c"]
 
 
 def _gen_specs(g):
@@ -131,14 +131,16 @@ def test_general_tower_oracle_replays_the_reference(case):
     cfg, (pspec, cspec) = _gen_specs(g)
     assert pspec.n_params() == g["theta_p0"].size and cspec.n_params() == g["theta_c0"].size
     hp = po.hyper_from_cfg(cfg)
+    nmb = cfg.num_mini_batch
+    if "a2c" in g:  # A2CAlgorithm: policy-gradient loss, num_mini_batch forced to 1 (a2c.py:37)
+        hp.a2c, nmb = True, 1
     ptheta, ctheta = torch.tensor(g["theta_p0"]).clone(), torch.tensor(g["theta_c0"]).clone()
     padam = po.AdamOracle(ptheta.numel(), cfg.lr, cfg.opti_eps, cfg.weight_decay)
     cadam = po.AdamOracle(ctheta.numel(), cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)
     vn = po.ValueNormOracle() if cfg.use_valuenorm else None
     torch.manual_seed(int(g["perm_seed"]))
-    info, _, used = po.train_ppo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, H.case_buffer(g), cfg.ppo_epoch,
-                                 cfg.num_mini_batch)
-    assert len(used) == cfg.ppo_epoch * cfg.num_mini_batch
+    info, _, used = po.train_ppo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, H.case_buffer(g), cfg.ppo_epoch, nmb)
+    assert len(used) == cfg.ppo_epoch * nmb
     np.testing.assert_allclose(ptheta.numpy(), g["theta_p1"], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(ctheta.numpy(), g["theta_c1"], rtol=2e-5, atol=2e-6)
     got = np.array([info[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
