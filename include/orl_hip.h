@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 205 /* 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 206 /* 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -643,6 +643,16 @@ typedef struct orl_gen_mlp_desc {
 } orl_gen_mlp_desc;
 int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* head_out0, float* head_out1,
                     float* feats_out, void* stream);
+/* One rollout step of a policy / critic pair in ONE launch (OnPolicyDriver.act -> PPOModule.get_actions:
+ * openrl/modules/ppo_module.py:118-150 -> PolicyNetwork.forward + ValueNetwork.forward): the policy tower as
+ * orl_gen_mlp_fwd runs it, ACTLayer.forward on its first head's logits exactly as orl_gen_sample does it (same
+ * arithmetic, same Philox counters: the two routes agree bit for bit), and either the critic tower on critic_obs
+ * (critic != NULL: grid.y = 2) or the shared network's second head (policy->n_heads == 2, critic == NULL).
+ * logits_out [B, head->n_out] may be NULL; values [B] is NULL exactly when there is no value head. */
+int orl_gen_act(const orl_gen_mlp_desc* policy, const float* obs, const orl_gen_mlp_desc* critic, const float* critic_obs,
+                int B, float* logits_out, float* values, const orl_head_desc* head, const float* logstd,
+                const float* action_masks, int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step,
+                const uint64_t* rng_step_dev, const float* forced_u, int a_w, float* actions, float* logp, void* stream);
 /* Its backward in one launch: dy [B, n_out] -> dz_out [B, n_out] (gradient at the Linear's output; may be NULL),
  * col_partials[n_blocks][3 n_out] = [d gamma | d beta | d bias] per workgroup (sum them with orl_gen_colsum), and - for a
  * square layer, when dx_out != NULL - the input gradient dx_out [B, n_in] = dz W of the same row tile without re-reading

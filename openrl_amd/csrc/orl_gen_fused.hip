@@ -18,6 +18,8 @@
 //   orl_gen_colsum      fixed-order column sums of per-workgroup partial rows, written to up to 3 destinations.
 //   orl_gen_mlp_fwd     rollout side: the WHOLE tower (feature norm, every layer, 1-2 heads) of a 16-row tile in one
 //                       launch, weights straight from L2 as the MFMA B operand.
+//   orl_gen_act         a rollout step in one launch: the policy tower + ACTLayer sampling on its logits, and the
+//                       critic tower (grid.y) or the shared network's value head.
 //
 // Widths that are not a multiple of 4 or parameter vectors that are not 16-byte aligned take the same kernels on a
 // scalar / fragment-layout path; n_out > 512 is refused (GenNet refuses it first).
@@ -25,6 +27,7 @@
 #include "orl_common.h"
 #include "orl_mlp.h"
 #include "orl_gen_act.h"
+#include "orl_gen_sample.h"
 
 namespace orl {
 
@@ -721,9 +724,24 @@ struct MlpArgs {
 
 constexpr int MLP_KPRE = 8;  // 16-k blocks whose weights are in flight together
 
+// ACTLayer.forward on the first head's logits inside the same launch (orl_gen_act): the 16 rows' logits go through a
+// [16][GEN_MAX_OUT] LDS tile behind the slab and lanes 0-15 of wave 0 run gen_sample_row - the arithmetic and Philox
+// counters of orl_gen_sample on the same fp32 logits, so the two routes agree bit for bit.
+struct ActArgs {
+  orl_head_desc hd;
+  const float* logstd;
+  const float* amask;
+  int deterministic;
+  uint64_t seed, row0, rng_step;
+  const unsigned long long* rng_dev;
+  const float* forced;
+  int a_w;
+  float* actions;
+  float* logp;
+};
+
 template <int NBW>
-__global__ __launch_bounds__(256) void gen_mlp_fwd_kernel(MlpArgs A, int SLD) {
-  extern __shared__ float slab[];  // [16][SLD]
+__device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __restrict__ slab, const ActArgs* S) {
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
   const long long m0 = (long long)blockIdx.x * 16;
   const int B = A.B;
@@ -795,14 +813,28 @@ __global__ __launch_bounds__(256) void gen_mlp_fwd_kernel(MlpArgs A, int SLD) {
     if (L + 1 < n_total) loadw(L + 1, 0);  // in flight during this layer's epilogue
     if (is_head) {  // heads read the trunk's features and leave the slab alone (a second head reads them again)
       float* out = A.head_out[L - A.d.n_layers];
+      const bool samp = S != nullptr && L == A.d.n_layers;
+      float* lgs = slab + 16 * SLD;  // [16][GEN_MAX_OUT], only there when S is
 #pragma unroll
       for (int j = 0; j < NBW; ++j) {
         const int col = 16 * (wave * NBW + j) + i;
         if (col < n_out) {
           const float bv = ly.bias ? ly.bias[col] : 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (m0 + 4 * q + r < B) out[(m0 + 4 * q + r) * n_out + col] = acc[j][r] + bv;
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[j][r] + bv;
+            if (samp) lgs[(4 * q + r) * GEN_MAX_OUT + col] = v;
+            if (out && m0 + 4 * q + r < B) out[(m0 + 4 * q + r) * n_out + col] = v;
+          }
+        }
+      }
+      if (samp) {
+        __syncthreads();
+        if (tid < 16 && m0 + tid < B) {
+          const long long row = m0 + tid;
+          gen_sample_row(S->hd, lgs + tid * GEN_MAX_OUT, S->logstd, S->amask ? S->amask + row * n_out : nullptr,
+                         S->deterministic, S->seed, S->row0 + (uint64_t)row, S->rng_step + (S->rng_dev ? *S->rng_dev : 0ull),
+                         S->forced ? S->forced + row * S->a_w : nullptr, S->actions + row * S->a_w, S->logp + row * S->a_w);
         }
       }
       continue;
@@ -867,6 +899,20 @@ __global__ __launch_bounds__(256) void gen_mlp_fwd_kernel(MlpArgs A, int SLD) {
     }
     __syncthreads();
   }
+}
+
+template <int NBW>
+__global__ __launch_bounds__(256) void gen_mlp_fwd_kernel(MlpArgs A, int SLD) {
+  extern __shared__ float slab[];  // [16][SLD]
+  mlp_tile<NBW>(A, SLD, slab, nullptr);
+}
+
+// Rollout step of a policy / critic pair: blockIdx.y = 0 runs the policy tower and samples, 1 the critic tower.
+template <int NBW>
+__global__ __launch_bounds__(256) void gen_act_kernel(MlpArgs Ap, MlpArgs Ac, ActArgs S, int SLD) {
+  extern __shared__ float slab[];  // [16][SLD] + [16][GEN_MAX_OUT]
+  if (blockIdx.y == 0) mlp_tile<NBW>(Ap, SLD, slab, &S);
+  else mlp_tile<NBW>(Ac, SLD, slab, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -1162,35 +1208,47 @@ int orl_gen_colsum(const float* partials, int n_rows, int width, float* dst0, in
   return launch_status("orl_gen_colsum");
 }
 
-int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* head_out0, float* head_out1,
-                    float* feats_out, void* stream) {
-  ORL_REQUIRE(desc && x && B > 0, "orl_gen_mlp_fwd: bad arguments");
-  ORL_REQUIRE(desc->n_layers >= 1 && desc->n_heads >= 0 && desc->n_heads <= 2 && (desc->n_heads >= 1 || feats_out) &&
+// validates a tower description; widest layer -> *wmax, slab columns -> *width
+static int check_mlp_desc(const orl_gen_mlp_desc* desc, bool out0, bool out1, bool feats, const char* who, int* wmax_io,
+                          int* width_io) {
+  ORL_REQUIRE(desc->n_layers >= 1 && desc->n_heads >= 0 && desc->n_heads <= 2 && (desc->n_heads >= 1 || feats) &&
                   desc->n_layers + desc->n_heads <= ORL_GEN_MLP_MAX_LAYERS,
-              "orl_gen_mlp_fwd: %d layers + %d heads (at most %d entries, 0-2 heads, features or a head wanted)",
-              desc->n_layers, desc->n_heads, ORL_GEN_MLP_MAX_LAYERS);
-  ORL_REQUIRE((desc->n_heads < 1 || head_out0) && (desc->n_heads < 2 || head_out1), "orl_gen_mlp_fwd: a head has no output buffer");
-  ORL_REQUIRE((desc->fn_gamma == nullptr) == (desc->fn_beta == nullptr), "orl_gen_mlp_fwd: fn_gamma and fn_beta come together");
-  int wmax = 0, width = (desc->layer[0].n_in + 15) & ~15;
+              "%s: %d layers + %d heads (at most %d entries, 0-2 heads, features or a head wanted)", who, desc->n_layers,
+              desc->n_heads, ORL_GEN_MLP_MAX_LAYERS);
+  ORL_REQUIRE((desc->n_heads < 1 || out0) && (desc->n_heads < 2 || out1), "%s: a head has no output buffer", who);
+  ORL_REQUIRE((desc->fn_gamma == nullptr) == (desc->fn_beta == nullptr), "%s: fn_gamma and fn_beta come together", who);
+  int wmax = *wmax_io, width = *width_io;
+  const int w0 = (desc->layer[0].n_in + 15) & ~15;
+  if (w0 > width) width = w0;
   for (int L = 0; L < desc->n_layers + desc->n_heads; ++L) {
     const orl_gen_mlp_layer& ly = desc->layer[L];
     const bool head = L >= desc->n_layers;
-    ORL_REQUIRE(ly.W && ly.n_in > 0 && ly.n_out > 0 && ly.n_out <= 256, "orl_gen_mlp_fwd: entry %d: n_in %d, n_out %d (<= 256)", L,
-                ly.n_in, ly.n_out);
-    ORL_REQUIRE(ly.act >= ORL_ACT_NONE && ly.act <= ORL_ACT_ELU, "orl_gen_mlp_fwd: entry %d: activation id %d", L, ly.act);
+    ORL_REQUIRE(ly.W && ly.n_in > 0 && ly.n_out > 0 && ly.n_out <= 256, "%s: entry %d: n_in %d, n_out %d (<= 256)", who, L, ly.n_in,
+                ly.n_out);
+    ORL_REQUIRE(ly.act >= ORL_ACT_NONE && ly.act <= ORL_ACT_ELU, "%s: entry %d: activation id %d", who, L, ly.act);
     if (!head) {
-      ORL_REQUIRE(ly.gamma && ly.beta && (ly.n_out & 3) == 0, "orl_gen_mlp_fwd: layer %d needs LayerNorm parameters and a width that is a multiple of 4", L);
-      ORL_REQUIRE(L == 0 || ly.n_in == desc->layer[L - 1].n_out, "orl_gen_mlp_fwd: layer %d reads %d columns, layer %d writes %d", L, ly.n_in, L - 1, desc->layer[L - 1].n_out);
+      ORL_REQUIRE(ly.gamma && ly.beta && (ly.n_out & 3) == 0, "%s: layer %d needs LayerNorm parameters and a width that is a multiple of 4", who, L);
+      ORL_REQUIRE(L == 0 || ly.n_in == desc->layer[L - 1].n_out, "%s: layer %d reads %d columns, layer %d writes %d", who, L, ly.n_in, L - 1, desc->layer[L - 1].n_out);
     } else {
       ORL_REQUIRE(ly.n_in == desc->layer[desc->n_layers - 1].n_out && ly.act == ORL_ACT_NONE && !ly.gamma,
-                  "orl_gen_mlp_fwd: head %d must be a plain Linear on the trunk's %d features", L - desc->n_layers,
+                  "%s: head %d must be a plain Linear on the trunk's %d features", who, L - desc->n_layers,
                   desc->layer[desc->n_layers - 1].n_out);
     }
     if (ly.n_out > wmax) wmax = ly.n_out;
     const int w16 = (ly.n_out + 15) & ~15;
     if (w16 > width) width = w16;
   }
-  ORL_REQUIRE(width <= 1024, "orl_gen_mlp_fwd: %d columns do not fit the wave's LDS slab", width);
+  ORL_REQUIRE(width <= 1024, "%s: %d columns do not fit the wave's LDS slab", who, width);
+  *wmax_io = wmax; *width_io = width;
+  return 0;
+}
+
+int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* head_out0, float* head_out1,
+                    float* feats_out, void* stream) {
+  ORL_REQUIRE(desc && x && B > 0, "orl_gen_mlp_fwd: bad arguments");
+  int wmax = 0, width = 0;
+  int rc = check_mlp_desc(desc, head_out0 != nullptr, head_out1 != nullptr, feats_out != nullptr, "orl_gen_mlp_fwd", &wmax, &width);
+  if (rc) return rc;
   MlpArgs A;
   A.d = *desc; A.x = x; A.B = B; A.head_out[0] = head_out0; A.head_out[1] = head_out1; A.feats = feats_out;
   // NBW output tiles per wave, 4 waves: widths up to 64 NBW; a row's float4 slots are 16 NBW
@@ -1209,6 +1267,63 @@ int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* 
   else ORL_MLP_LAUNCH(4);
 #undef ORL_MLP_LAUNCH
   return launch_status("orl_gen_mlp_fwd");
+}
+
+int orl_gen_act(const orl_gen_mlp_desc* policy, const float* obs, const orl_gen_mlp_desc* critic, const float* critic_obs,
+                int B, float* logits_out, float* values, const orl_head_desc* head, const float* logstd,
+                const float* action_masks, int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step,
+                const uint64_t* rng_step_dev, const float* forced_u, int a_w, float* actions, float* logp, void* stream) {
+  ORL_REQUIRE(policy && obs && head && actions && logp && B > 0 && a_w > 0, "orl_gen_act: bad arguments");
+  ORL_REQUIRE(policy->n_heads >= 1 && (critic == nullptr || (policy->n_heads == 1 && critic->n_heads == 1 && critic_obs)),
+              "orl_gen_act: the policy carries the action head (+ the value head of a shared network), a separate critic one value head");
+  ORL_REQUIRE((policy->n_heads == 2 || critic) == (values != nullptr), "orl_gen_act: values goes with a value head");
+  ORL_REQUIRE(head->kind == ORL_HEAD_CATEGORICAL || head->kind == ORL_HEAD_GAUSSIAN || head->kind == ORL_HEAD_MULTI_DISCRETE,
+              "orl_gen_act: head kind %d", head->kind);
+  ORL_REQUIRE(head->n_out >= 1 && head->n_out <= GEN_MAX_OUT && head->n_out == policy->layer[policy->n_layers].n_out,
+              "orl_gen_act: the head has %d logits (1..%d), the tower's first head %d", head->n_out, GEN_MAX_OUT,
+              policy->layer[policy->n_layers].n_out);
+  if (head->kind == ORL_HEAD_MULTI_DISCRETE) {
+    ORL_REQUIRE(head->n_heads >= 1 && head->n_heads <= ORL_MAX_HEADS && a_w == head->n_heads, "orl_gen_act: %d components, a_w %d", head->n_heads, a_w);
+    int tot = 0;
+    for (int h = 0; h < head->n_heads; ++h) { ORL_REQUIRE(head->nvec[h] >= 1, "orl_gen_act: nvec[%d] = %d", h, head->nvec[h]); tot += head->nvec[h]; }
+    ORL_REQUIRE(tot == head->n_out, "orl_gen_act: nvec sums to %d, n_out is %d", tot, head->n_out);
+  } else {
+    ORL_REQUIRE(a_w == (head->kind == ORL_HEAD_GAUSSIAN ? head->n_out : 1), "orl_gen_act: a_w %d for head kind %d", a_w, head->kind);
+  }
+  ORL_REQUIRE(head->kind != ORL_HEAD_GAUSSIAN || logstd, "orl_gen_act: Gaussian head without logstd");
+  int wmax = 0, width = 0;
+  int rc = check_mlp_desc(policy, true, policy->n_heads == 2, false, "orl_gen_act(policy)", &wmax, &width);
+  if (rc) return rc;
+  if (critic) {
+    ORL_REQUIRE(critic->layer[critic->n_layers].n_out == 1, "orl_gen_act: the critic's head has %d outputs", critic->layer[critic->n_layers].n_out);
+    rc = check_mlp_desc(critic, true, false, false, "orl_gen_act(critic)", &wmax, &width);
+    if (rc) return rc;
+  } else if (policy->n_heads == 2) {
+    ORL_REQUIRE(policy->layer[policy->n_layers + 1].n_out == 1, "orl_gen_act: the value head has %d outputs", policy->layer[policy->n_layers + 1].n_out);
+  }
+  MlpArgs Ap, Ac;
+  Ap.d = *policy; Ap.x = obs; Ap.B = B; Ap.head_out[0] = logits_out; Ap.head_out[1] = critic ? nullptr : values; Ap.feats = nullptr;
+  Ac = Ap;
+  if (critic) { Ac.d = *critic; Ac.x = critic_obs; Ac.head_out[0] = values; Ac.head_out[1] = nullptr; }
+  ActArgs S;
+  S.hd = *head; S.logstd = logstd; S.amask = action_masks; S.deterministic = deterministic; S.seed = seed; S.row0 = row0;
+  S.rng_step = rng_step; S.rng_dev = (const unsigned long long*)rng_step_dev; S.forced = forced_u; S.a_w = a_w;
+  S.actions = actions; S.logp = logp;
+  const int NBW = wmax <= 64 ? 1 : wmax <= 128 ? 2 : 4;
+  if (width < 64 * NBW) width = 64 * NBW;
+  const int SLD = width + 4;
+  const size_t lds = ((size_t)16 * SLD + 16 * GEN_MAX_OUT) * sizeof(float);
+  const dim3 grid((unsigned)(((long long)B + 15) / 16), critic ? 2 : 1);
+#define ORL_ACT_LAUNCH(NBX)                                                                                          \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)gen_act_kernel<NBX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((gen_act_kernel<NBX>), grid, dim3(256), lds, (hipStream_t)stream, Ap, Ac, S, SLD);             \
+  } while (0)
+  if (NBW == 1) ORL_ACT_LAUNCH(1);
+  else if (NBW == 2) ORL_ACT_LAUNCH(2);
+  else ORL_ACT_LAUNCH(4);
+#undef ORL_ACT_LAUNCH
+  return launch_status("orl_gen_act");
 }
 
 int orl_gen_matmul(const float* x, int B, int K, const float* W, int N, float* y, void* stream) {

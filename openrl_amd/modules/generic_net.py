@@ -651,6 +651,18 @@ class GenericPPOModule(PPOModule):
             values, actions, logp = out
         feats_p = None
         shared_once = self.share_model and want_action and want_value and xc.data_ptr() == x.data_ptr()
+        if want_action and want_value and values.is_contiguous() and (shared_once or not self.share_model):
+            # the whole step - both towers and the sampling - in one launch
+            dp = pn.mlp_desc(("act", "v_out") if shared_once else ("act",))
+            dc = None if shared_once else cn.mlp_desc(("v_out",))
+            if dp is not None and (shared_once or dc is not None):
+                am = self._dev(action_masks, self.n_logits) if (action_masks is not None and self.K) else None
+                ops_gen.act_step(dp, x, dc, xc, values, pn.head_desc, self._logstd(), am, deterministic, self.act_seed, 0,
+                                 self.rng_step, self.rng_step_dev, self._dev(forced_u, self.act_width), self.act_width,
+                                 actions, logp)
+                if not deterministic:
+                    self.rng_step += 1
+                return values, actions, logp
         if want_action:
             ws = self.workspace(pn, B, False, "p")
             logits = ws.v(ws.head_out["act"], B, pn.heads["act"]["n"])

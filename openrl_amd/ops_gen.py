@@ -108,6 +108,23 @@ def mlp_fwd(desc, x, head_out0, head_out1=None, feats_out=None) -> None:
     nat.check(rc, "orl_gen_mlp_fwd")
 
 
+def act_step(policy_desc, obs, critic_desc, critic_obs, values, head: HeadDesc, logstd, action_masks, deterministic: bool,
+        seed: int, row0: int, rng_step: int, rng_step_dev, forced_u, a_w: int, actions, logp, logits_out=None) -> None:
+    """A rollout step in one launch (``orl_gen_act``): the policy tower, ``sample`` on its logits, and the critic tower
+    (``critic_desc``) or the shared network's value head (``policy_desc`` with two heads); ``values`` [B] contiguous."""
+    dev = nat.require_gpu(obs.device)
+    assert obs.is_contiguous() and obs.shape[1] == policy_desc.layer[0].n_in
+    assert critic_desc is None or (critic_obs.is_contiguous() and critic_obs.shape[0] == obs.shape[0] and
+                                   critic_obs.shape[1] == critic_desc.layer[0].n_in)
+    assert values is None or values.is_contiguous()
+    rc = _lib().orl_gen_act(C.byref(policy_desc), fptr(obs), C.byref(critic_desc) if critic_desc is not None else None,
+                            fptr(critic_obs) if critic_desc is not None else None, obs.shape[0], fptr(logits_out),
+                            fptr(values), C.byref(head), fptr(logstd), fptr(action_masks), int(bool(deterministic)),
+                            seed & (2 ** 64 - 1), row0, rng_step, ptr(rng_step_dev), fptr(forced_u), a_w, fptr(actions),
+                            fptr(logp), stream_ptr(dev))
+    nat.check(rc, "orl_gen_act")
+
+
 def layer_bwd(dy, a, stats, gamma, act: int, W, dz_out, dx_out, col_partials) -> int:
     """dy -> dz (+ dx = dz @ W for a square layer when ``dx_out`` is given) and the [d gamma | d beta | d bias] partial
     rows; returns their count."""

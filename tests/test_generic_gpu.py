@@ -286,6 +286,66 @@ def test_whole_tower_launch_equals_the_layer_by_layer_forward(argv, D, B):
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("argv,D,Dc,space,B", [
+    (["--hidden_size", "128"], 4, 4, "disc", 4096),
+    (["--hidden_size", "128", "--layer_N", "4", "--activation_id", "0"], 18, 54, "disc", 1000),
+    (["--hidden_size", "36", "--layer_N", "2", "--use_feature_normalization", "true", "--activation_id", "3"], 7, 7, "box", 333),
+    (["--hidden_size", "256", "--layer_N", "2", "--activation_id", "2"], 54, 20, "md", 77),
+    (["--hidden_size", "64", "--use_share_model", "true", "--layer_N", "2"], 6, 6, "disc", 500),
+    (["--hidden_size", "64", "--use_share_model", "true"], 6, 6, "box", 17)])
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_one_launch_act_step_is_bit_identical_to_the_three_launch_route(argv, D, Dc, space, B, deterministic):
+    """orl_gen_act (policy tower + ACTLayer sampling + critic tower / shared value head in one launch) against
+    orl_gen_mlp_fwd + orl_gen_sample + orl_gen_mlp_fwd: the same MFMA order and the same Philox counters, so actions,
+    log-probs and values are equal bit for bit; a device step counter and action masks are covered too."""
+    from openrl_amd import spaces
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.modules import generic_net as gn
+    from openrl_amd import ops_gen
+
+    cfg = default_cfg(argv)
+    share = bool(cfg.use_share_model)
+    asp = {"disc": spaces.Discrete(5), "box": spaces.Box(-1.0, 1.0, (6,)), "md": spaces.MultiDiscrete([3, 4, 2])}[space]
+    mod = gn.GenericPPOModule(cfg, spaces.Box(-np.inf, np.inf, (D,)), spaces.Box(-np.inf, np.inf, (Dc,)), asp,
+                              share_model=share, device=DEV)
+    torch.manual_seed(B)
+    pn, cn = mod.policy_net, mod.critic_net
+    for net in ({id(pn): pn, id(cn): cn}).values():
+        net.theta.add_(0.05 * torch.randn_like(net.theta))
+    x, xc = torch.randn(B, D, device=DEV), torch.randn(B, Dc, device=DEV)
+    am = None
+    if space == "disc":
+        am = (torch.rand(B, 5, device=DEV) > 0.3).float()
+        am[:, 2] = 1.0
+    a_w, nl = mod.act_width, pn.heads["act"]["n"]
+    step_dev = torch.tensor([12345], dtype=torch.int64, device=DEV)
+    f = lambda *sh: torch.full(sh, 7.0, device=DEV)
+    # --- three launches
+    logits, v_ref, a_ref, lp_ref = f(B, nl), f(B, 1), f(B, a_w), f(B, a_w)
+    if share:
+        ops_gen.mlp_fwd(pn.mlp_desc(("act", "v_out")), x, logits, v_ref)
+    else:
+        ops_gen.mlp_fwd(pn.mlp_desc(("act",)), x, logits)
+        ops_gen.mlp_fwd(cn.mlp_desc(("v_out",)), xc, v_ref)
+    ops_gen.sample(pn.head_desc, logits, mod._logstd(), am, B, deterministic, 11, 3, 99, step_dev, None, a_w, a_ref, lp_ref)
+    # --- one launch
+    lg2, v, a, lp = f(B, nl), f(B, 1), f(B, a_w), f(B, a_w)
+    ops_gen.act_step(pn.mlp_desc(("act", "v_out")) if share else pn.mlp_desc(("act",)), x,
+                     None if share else cn.mlp_desc(("v_out",)), None if share else xc, v, pn.head_desc, mod._logstd(), am,
+                     deterministic, 11, 3, 99, step_dev, None, a_w, a, lp, logits_out=lg2)
+    assert torch.equal(lg2, logits) and torch.equal(v, v_ref)
+    assert torch.equal(a, a_ref) and torch.equal(lp, lp_ref)
+    if space == "disc":
+        assert bool((am.gather(1, a.long()) == 1).all())
+    # --- the module's rollout entry takes the one-launch route and draws what the three launches draw
+    mod.act_seed, mod.rng_step, mod.rng_step_dev = 11, 99, step_dev
+    vals, acts, lps = mod._forward(x if share else xc, x, am, deterministic)
+    a_ref2, lp_ref2 = f(B, a_w), f(B, a_w)
+    ops_gen.sample(pn.head_desc, logits, mod._logstd(), am, B, deterministic, 11, 0, 99, step_dev, None, a_w, a_ref2, lp_ref2)
+    assert torch.equal(acts, a_ref2) and torch.equal(lps, lp_ref2) and torch.equal(vals, v_ref)
+    assert mod.rng_step == (99 if deterministic else 100)
+
+
 @pytest.mark.parametrize("cell", ["gru", "lstm"])
 @pytest.mark.parametrize("H,L,N,rN", [(128, 5, 70, 1), (36, 3, 200, 1), (64, 10, 33, 1), (168, 2, 50, 1), (256, 3, 40, 1),
                                        (512, 2, 20, 1), (64, 4, 60, 2), (32, 3, 50, 3)])
