@@ -459,7 +459,9 @@ __global__ __launch_bounds__(256) void gen_sample_kernel(orl_head_desc hd, const
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const int NT = hd.n_out;
-  gen_sample_row(hd, logits + (size_t)i * NT, logstd, amask ? amask + (size_t)i * NT : nullptr, deterministic, seed,
+  float lg[GEN_MAX_OUT];
+  for (int k = 0; k < NT; ++k) lg[k] = logits[(size_t)i * NT + k];
+  gen_sample_row(hd, lg, logstd, amask ? amask + (size_t)i * NT : nullptr, deterministic, seed,
                  row0 + (uint64_t)i, rng_step + (rng_dev ? *rng_dev : 0ull), forced ? forced + (size_t)i * a_w : nullptr,
                  actions + (size_t)i * a_w, logp + (size_t)i * a_w);
 }

@@ -43,6 +43,13 @@ __device__ inline float sum16(float v) {
   return v;
 }
 
+template <int LPR>
+__device__ inline float sum_row(float v) {  // sum16's order, over an aligned group of LPR lanes
+#pragma unroll
+  for (int off = 1; off < LPR; off <<= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
 __device__ inline bool aligned16(const void* p) { return (((unsigned long long)p) & 15ull) == 0; }
 
 // Row layout of a 16-row wave slab of NP = 16 NB columns: LPR lanes (a power of two <= 64) walk one row in float4
@@ -707,8 +714,9 @@ __global__ __launch_bounds__(512) void gen_layer_bwd_res_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ whole-MLP inference
-// Rollout side: the entire tower (optional feature LayerNorm, every MLPLayer, up to two heads) in ONE launch.  A 4-wave
-// workgroup owns 16 rows whose activations never leave an LDS slab; wave w computes the output tiles [w NBW, (w+1) NBW)
+// Rollout side: the entire tower (optional feature LayerNorm, every MLPLayer, up to two heads) in ONE launch.  A WAVES-wave
+// workgroup (4 up to 64 columns, 8 beyond: the tile is a latency chain as long as one wave's instruction stream, see
+// DESIGN.md section 11) owns 16 rows whose activations never leave an LDS slab; wave w computes the output tiles [w NBW, (w+1) NBW)
 // of every layer.  The B operand (weights) comes straight from L2 as one float4 per lane and 16-k block - lane (i, q)
 // reads W[16 t + i][k0 + 4 q .. + 3], i.e. the MFMA of sub-step s multiplies k = k0 + 4 q + s, and the A operand is read
 // from the slab with the same k permutation (a dot product does not care) - and ALL of a layer's weight loads (up to
@@ -725,8 +733,10 @@ struct MlpArgs {
 constexpr int MLP_KPRE = 8;  // 16-k blocks whose weights are in flight together
 
 // ACTLayer.forward on the first head's logits inside the same launch (orl_gen_act): the 16 rows' logits go through a
-// [16][GEN_MAX_OUT] LDS tile behind the slab and lanes 0-15 of wave 0 run gen_sample_row - the arithmetic and Philox
+// [16][LGS_LD] LDS tile behind the slab and lanes 0-15 of wave 0 run gen_sample_row ON that tile (its working copy) - the arithmetic and Philox
 // counters of orl_gen_sample on the same fp32 logits, so the two routes agree bit for bit.
+constexpr int LGS_LD = GEN_MAX_OUT + 1;  // odd stride: the 16 sampling lanes walk their rows conflict-free
+
 struct ActArgs {
   orl_head_desc hd;
   const float* logstd;
@@ -740,7 +750,7 @@ struct ActArgs {
   float* logp;
 };
 
-template <int NBW>
+template <int NBW, int WAVES>
 __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __restrict__ slab, const ActArgs* S) {
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
   const long long m0 = (long long)blockIdx.x * 16;
@@ -771,7 +781,7 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
   // ---- input rows (+ MLPBase.feature_norm) into the slab, zero-padded to a multiple of 16 columns
   {
     const int D = A.d.layer[0].n_in, DP = (D + 15) & ~15;
-    for (int e = tid; e < 16 * DP; e += 256) {
+    for (int e = tid; e < 16 * DP; e += 64 * WAVES) {
       const int r = e / DP, c = e % DP;
       slab[r * SLD + c] = (c < D && m0 + r < B) ? A.x[(m0 + r) * D + c] : 0.f;
     }
@@ -814,7 +824,7 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
     if (is_head) {  // heads read the trunk's features and leave the slab alone (a second head reads them again)
       float* out = A.head_out[L - A.d.n_layers];
       const bool samp = S != nullptr && L == A.d.n_layers;
-      float* lgs = slab + 16 * SLD;  // [16][GEN_MAX_OUT], only there when S is
+      float* lgs = slab + 16 * SLD;  // [16][LGS_LD], only there when S is
 #pragma unroll
       for (int j = 0; j < NBW; ++j) {
         const int col = 16 * (wave * NBW + j) + i;
@@ -823,18 +833,9 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = acc[j][r] + bv;
-            if (samp) lgs[(4 * q + r) * GEN_MAX_OUT + col] = v;
+            if (samp) lgs[(4 * q + r) * LGS_LD + col] = v;
             if (out && m0 + 4 * q + r < B) out[(m0 + 4 * q + r) * n_out + col] = v;
           }
-        }
-      }
-      if (samp) {
-        __syncthreads();
-        if (tid < 16 && m0 + tid < B) {
-          const long long row = m0 + tid;
-          gen_sample_row(S->hd, lgs + tid * GEN_MAX_OUT, S->logstd, S->amask ? S->amask + row * n_out : nullptr,
-                         S->deterministic, S->seed, S->row0 + (uint64_t)row, S->rng_step + (S->rng_dev ? *S->rng_dev : 0ull),
-                         S->forced ? S->forced + row * S->a_w : nullptr, S->actions + row * S->a_w, S->logp + row * S->a_w);
         }
       }
       continue;
@@ -850,34 +851,35 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
       }
     }
     __syncthreads();
-    // LayerNorm in place: wave w takes rows 4 w .. 4 w + 3, 16 lanes x float4 slots per row (n_out % 4 == 0)
+    // LayerNorm in place: wave w takes rows RPW w .. RPW w + RPW - 1, LPR lanes x float4 slots per row (n_out % 4 == 0)
     {
-      const int rl = 4 * wave + q, VPR = n_out >> 2;
+      constexpr int RPW = 16 / WAVES, LPR = 64 / RPW;
+      const int rl = RPW * wave + l / LPR, ls = l % LPR, VPR = n_out >> 2;
       const float inv_n = 1.0f / (float)n_out;
       const bool gal = aligned16(ly.gamma) && aligned16(ly.beta);
       f32x4 v[NBW];
       float sm = 0.f;
 #pragma unroll
       for (int j = 0; j < NBW; ++j) {
-        const int sl = i + 16 * j;
+        const int sl = ls + LPR * j;
         v[j] = sl < VPR ? *(const f32x4*)(slab + rl * SLD + 4 * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
         sm += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
       }
-      const float mean = sum16(sm) * inv_n;
+      const float mean = sum_row<LPR>(sm) * inv_n;
       float v2 = 0.f;
 #pragma unroll
       for (int j = 0; j < NBW; ++j) {
-        const bool ok = i + 16 * j < VPR;
+        const bool ok = ls + LPR * j < VPR;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[j][e] = ok ? v[j][e] - mean : 0.f;
           v2 += v[j][e] * v[j][e];
         }
       }
-      const float rstd = 1.0f / sqrtf(sum16(v2) * inv_n + 1e-5f);
+      const float rstd = 1.0f / sqrtf(sum_row<LPR>(v2) * inv_n + 1e-5f);
 #pragma unroll
       for (int j = 0; j < NBW; ++j) {
-        const int sl = i + 16 * j;
+        const int sl = ls + LPR * j;
         if (sl < VPR) {
           f32x4 g, b, o;
           if (gal) { g = *(const f32x4*)(ly.gamma + 4 * sl); b = *(const f32x4*)(ly.beta + 4 * sl); }
@@ -899,20 +901,33 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
     }
     __syncthreads();
   }
+  // sampling comes last, when nothing of the tile's state is live any more (its registers would otherwise add to the
+  // layer loop's and halve the occupancy); the logits tile sits behind the slab and is still intact
+  if (S != nullptr) {
+    float* lgs = slab + 16 * SLD;
+    __syncthreads();
+    if (tid < 16 && m0 + tid < B) {
+      const long long row = m0 + tid;
+      const int NT = S->hd.n_out;
+      gen_sample_row(S->hd, lgs + tid * LGS_LD, S->logstd, S->amask ? S->amask + row * NT : nullptr, S->deterministic,
+                     S->seed, S->row0 + (uint64_t)row, S->rng_step + (S->rng_dev ? *S->rng_dev : 0ull),
+                     S->forced ? S->forced + row * S->a_w : nullptr, S->actions + row * S->a_w, S->logp + row * S->a_w);
+    }
+  }
 }
 
-template <int NBW>
-__global__ __launch_bounds__(256) void gen_mlp_fwd_kernel(MlpArgs A, int SLD) {
+template <int NBW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gen_mlp_fwd_kernel(MlpArgs A, int SLD) {
   extern __shared__ float slab[];  // [16][SLD]
-  mlp_tile<NBW>(A, SLD, slab, nullptr);
+  mlp_tile<NBW, WAVES>(A, SLD, slab, nullptr);
 }
 
 // Rollout step of a policy / critic pair: blockIdx.y = 0 runs the policy tower and samples, 1 the critic tower.
-template <int NBW>
-__global__ __launch_bounds__(256) void gen_act_kernel(MlpArgs Ap, MlpArgs Ac, ActArgs S, int SLD) {
-  extern __shared__ float slab[];  // [16][SLD] + [16][GEN_MAX_OUT]
-  if (blockIdx.y == 0) mlp_tile<NBW>(Ap, SLD, slab, &S);
-  else mlp_tile<NBW>(Ac, SLD, slab, nullptr);
+template <int NBW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gen_act_kernel(MlpArgs Ap, MlpArgs Ac, ActArgs S, int SLD) {
+  extern __shared__ float slab[];  // [16][SLD] + [16][LGS_LD]
+  if (blockIdx.y == 0) mlp_tile<NBW, WAVES>(Ap, SLD, slab, &S);
+  else mlp_tile<NBW, WAVES>(Ac, SLD, slab, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -1251,20 +1266,21 @@ int orl_gen_mlp_fwd(const orl_gen_mlp_desc* desc, const float* x, int B, float* 
   if (rc) return rc;
   MlpArgs A;
   A.d = *desc; A.x = x; A.B = B; A.head_out[0] = head_out0; A.head_out[1] = head_out1; A.feats = feats_out;
-  // NBW output tiles per wave, 4 waves: widths up to 64 NBW; a row's float4 slots are 16 NBW
-  const int NBW = wmax <= 64 ? 1 : wmax <= 128 ? 2 : 4;
-  if (width < 64 * NBW) width = 64 * NBW;
+  // NBW output tiles per wave: widths up to 64 with 4 waves, beyond that 8 waves - a rollout step is one wave per SIMD
+  // walking a latency chain whose length is its instruction count, so wide layers are split over more waves
+  const int NBW = wmax <= 128 ? 1 : 2, WV = wmax <= 64 ? 4 : 8;
+  if (width < 16 * WV * NBW) width = 16 * WV * NBW;
   const int SLD = width + 4;
   const size_t lds = (size_t)16 * SLD * sizeof(float);
   const unsigned grid = (unsigned)(((long long)B + 15) / 16);
-#define ORL_MLP_LAUNCH(NBX)                                                                                          \
+#define ORL_MLP_LAUNCH(NBX, WVX)                                                                                     \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)gen_mlp_fwd_kernel<NBX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((gen_mlp_fwd_kernel<NBX>), dim3(grid), dim3(256), lds, (hipStream_t)stream, A, SLD);          \
+    (void)hipFuncSetAttribute((const void*)gen_mlp_fwd_kernel<NBX, WVX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((gen_mlp_fwd_kernel<NBX, WVX>), dim3(grid), dim3(64 * WVX), lds, (hipStream_t)stream, A, SLD); \
   } while (0)
-  if (NBW == 1) ORL_MLP_LAUNCH(1);
-  else if (NBW == 2) ORL_MLP_LAUNCH(2);
-  else ORL_MLP_LAUNCH(4);
+  if (WV == 4) ORL_MLP_LAUNCH(1, 4);
+  else if (NBW == 1) ORL_MLP_LAUNCH(1, 8);
+  else ORL_MLP_LAUNCH(2, 8);
 #undef ORL_MLP_LAUNCH
   return launch_status("orl_gen_mlp_fwd");
 }
@@ -1309,19 +1325,19 @@ int orl_gen_act(const orl_gen_mlp_desc* policy, const float* obs, const orl_gen_
   S.hd = *head; S.logstd = logstd; S.amask = action_masks; S.deterministic = deterministic; S.seed = seed; S.row0 = row0;
   S.rng_step = rng_step; S.rng_dev = (const unsigned long long*)rng_step_dev; S.forced = forced_u; S.a_w = a_w;
   S.actions = actions; S.logp = logp;
-  const int NBW = wmax <= 64 ? 1 : wmax <= 128 ? 2 : 4;
-  if (width < 64 * NBW) width = 64 * NBW;
+  const int NBW = wmax <= 128 ? 1 : 2, WV = wmax <= 64 ? 4 : 8;  // as orl_gen_mlp_fwd picks them
+  if (width < 16 * WV * NBW) width = 16 * WV * NBW;
   const int SLD = width + 4;
-  const size_t lds = ((size_t)16 * SLD + 16 * GEN_MAX_OUT) * sizeof(float);
+  const size_t lds = ((size_t)16 * SLD + 16 * LGS_LD) * sizeof(float);
   const dim3 grid((unsigned)(((long long)B + 15) / 16), critic ? 2 : 1);
-#define ORL_ACT_LAUNCH(NBX)                                                                                          \
+#define ORL_ACT_LAUNCH(NBX, WVX)                                                                                     \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)gen_act_kernel<NBX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((gen_act_kernel<NBX>), grid, dim3(256), lds, (hipStream_t)stream, Ap, Ac, S, SLD);             \
+    (void)hipFuncSetAttribute((const void*)gen_act_kernel<NBX, WVX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((gen_act_kernel<NBX, WVX>), grid, dim3(64 * WVX), lds, (hipStream_t)stream, Ap, Ac, S, SLD);  \
   } while (0)
-  if (NBW == 1) ORL_ACT_LAUNCH(1);
-  else if (NBW == 2) ORL_ACT_LAUNCH(2);
-  else ORL_ACT_LAUNCH(4);
+  if (WV == 4) ORL_ACT_LAUNCH(1, 4);
+  else if (NBW == 1) ORL_ACT_LAUNCH(1, 8);
+  else ORL_ACT_LAUNCH(2, 8);
 #undef ORL_ACT_LAUNCH
   return launch_status("orl_gen_act");
 }

@@ -8,9 +8,11 @@ namespace orl {
 
 constexpr int GEN_MAX_OUT = 64;  // logits per row the loss / sampling code keeps in registers
 
-// One row: logits -> (actions, log-probs).  ``logits`` / ``amask`` / ``forced`` / ``actions`` / ``logp`` point at THIS
-// row; ``i`` is only the row's index for the Philox counter (row0 + i).
-__device__ inline void gen_sample_row(const orl_head_desc& hd, const float* __restrict__ logits_row,
+// One row: logits -> (actions, log-probs).  ``lg`` is a WORKING copy of the row's hd.n_out logits (masked entries are
+// overwritten): a local array in gen_sample_kernel, the row of the LDS logits tile in the act kernel.  ``amask`` /
+// ``forced`` / ``actions`` / ``logp`` point at THIS row; ``grow`` is the row's index in the Philox counter.
+template <typename LgPtr>
+__device__ inline void gen_sample_row(const orl_head_desc& hd, LgPtr lg,
                                       const float* __restrict__ logstd, const float* __restrict__ amask_row,
                                       int deterministic, uint64_t seed, uint64_t grow, uint64_t step,
                                       const float* __restrict__ forced_row, float* __restrict__ actions_row,
@@ -21,8 +23,6 @@ __device__ inline void gen_sample_row(const orl_head_desc& hd, const float* __re
                          ((uint32_t)(step >> 32) << 8) | (uint32_t)b);
   };
   auto word = [&](const u4& r, int k) -> uint32_t { return k == 0 ? r.x : k == 1 ? r.y : k == 2 ? r.z : r.w; };
-  float lg[GEN_MAX_OUT];
-  for (int k = 0; k < NT; ++k) lg[k] = logits_row[k];
   if (hd.kind == ORL_HEAD_CATEGORICAL || hd.kind == ORL_HEAD_MULTI_DISCRETE) {
     const int nh = hd.kind == ORL_HEAD_CATEGORICAL ? 1 : hd.n_heads;
     int off = 0;
