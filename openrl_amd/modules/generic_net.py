@@ -602,6 +602,7 @@ class GenericPPOModule(PPOModule):
         self.rng_step_dev = None
         self._ws: Dict = {}
         self._ws_retired: List = []  # outgrown workspaces, kept alive for hipGraphs captured while they were current
+        self._side_stream = None  # the critic's chain of a recurrent rollout step (_forward_rnn)
 
     # ------------------------------------------------------------------ nets
     @property
@@ -729,8 +730,27 @@ class GenericPPOModule(PPOModule):
         else:
             values, actions, logp = out
         hp_out, hc_out = h_out if h_out is not None else (f(B, H) if want_action else None, f(B, H) if want_value else None)
+        hp_in = self._dev(h_policy, H) if want_action else None
+        hc_in = self._dev(h_critic, H) if want_value else None
+
+        def critic_step():
+            ws, y, h_new = self._tower_step(cn, "c", xc, hc_in, mk, B)
+            values.copy_(head_forward(cn, ws, "v_out", y))
+            hc_out.copy_(h_new.view_as(hc_out))
+
+        # A recurrent step is a chain of ~10 small launches per tower: with separate networks and caller-owned outputs
+        # (the driver's buffer slots - nothing is allocated below) the critic's chain runs on a second stream beside
+        # the policy's, forked and joined here, also inside a captured rollout graph.
+        fork = want_action and want_value and not self.share_model and out is not None and h_out is not None
+        if fork:
+            main = torch.cuda.current_stream(self.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(self.device)
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                critic_step()
         if want_action:
-            ws, y, h_new = self._tower_step(pn, "p", x, self._dev(h_policy, H), mk, B)
+            ws, y, h_new = self._tower_step(pn, "p", x, hp_in, mk, B)
             logits = head_forward(pn, ws, "act", y)
             am = self._dev(action_masks, self.n_logits) if (action_masks is not None and self.K) else None
             ops_gen.sample(pn.head_desc, logits, self._logstd(), am, B, deterministic, self.act_seed, 0, self.rng_step,
@@ -738,10 +758,10 @@ class GenericPPOModule(PPOModule):
             if not deterministic:
                 self.rng_step += 1
             hp_out.copy_(h_new.view_as(hp_out))
-        if want_value:
-            ws, y, h_new = self._tower_step(cn, "c", xc, self._dev(h_critic, H), mk, B)
-            values.copy_(head_forward(cn, ws, "v_out", y))
-            hc_out.copy_(h_new.view_as(hc_out))
+        if fork:
+            main.wait_stream(self._side_stream)
+        elif want_value:
+            critic_step()
         return values, actions, logp, hp_out, hc_out
 
     def get_actions(self, critic_obs, obs, rnn_states_actor, rnn_states_critic, masks, action_masks=None,
