@@ -71,8 +71,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     wp = mod.workspace(pn, mb, True, "p")
     xp = wp.v(wp.x0, mb, Dp)
     ops_gen.gather_cols(rec, 0, Dp, idx, mb, xp)
-    feats_p = gn.trunk_forward(pn, wp, xp, True)
-    trunk_p = trunk_c = gp = gc = mrows = None
+    trunk_p = gp = mrows = None
     if rnn is not None:
         L, Nc = rnn
         H = pn.state_w * pn.recurrent_N
@@ -80,15 +79,24 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
         mrows, h0p = gp.mrows[:mb], gp.h0[:Nc]
         ops_gen.gather_cols(buffer.masks.view(-1, 1), 0, 1, idx, mb, mrows.view(mb, 1))   # mask of step l of chunk i
         ops_gen.gather_cols(buffer.rnn_states.view(-1, H), 0, H, idx[:Nc], Nc, h0p)        # states at the chunk starts
-        trunk_p, feats_p = feats_p, gn.gru_forward(pn, gp, feats_p, h0p, mrows, L, Nc, True)
-    logits = gn.head_forward(pn, wp, "act", feats_p)
-    if one_pass:
-        wc, feats_c = wp, feats_p
-    else:
+
+    def policy_forward():
+        feats = gn.trunk_forward(pn, wp, xp, True)
+        trunk = None
+        if rnn is not None:
+            trunk, feats = feats, gn.gru_forward(pn, gp, feats, h0p, mrows, L, Nc, True)
+        return trunk, feats, gn.head_forward(pn, wp, "act", feats)
+
+    def critic_forward():
+        """The critic's trunk (+ recurrent stack) + value head on its rows -> (workspace, features, trunk features, GRU
+        workspace, mask rows, values)."""
+        if one_pass:  # (after policy_forward)
+            return wp, feats_p, None, None, None, gn.head_forward(cn, wp, "v_out", feats_p)
         wc = mod.workspace(cn, mb_c, True, "c")
         xc = wc.v(wc.x0, mb_c, Dc)
         ops_gen.gather_cols(rec, Dp, Dc, idx_c, mb_c, xc)
         feats_c = gn.trunk_forward(cn, wc, xc, True)
+        trunk_c = gc = mrows_c = None
         if rnn is not None:
             Ncc, Hc = mb_c // L, cn.state_w * cn.recurrent_N
             gc = mod.gru_workspace(cn, L, Ncc, True, "c")
@@ -98,7 +106,38 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
                 ops_gen.gather_cols(buffer.masks.view(-1, 1), 0, 1, idx_c, mb_c, mrows_c.view(mb_c, 1))
             ops_gen.gather_cols(buffer.rnn_states_critic.view(-1, Hc), 0, Hc, idx_c[:Ncc], Ncc, h0c)
             trunk_c, feats_c = feats_c, gn.gru_forward(cn, gc, feats_c, h0c, mrows_c, L, Ncc, True)
-    values = gn.head_forward(cn, wc, "v_out", feats_c)
+        return wc, feats_c, trunk_c, gc, mrows_c, gn.head_forward(cn, wc, "v_out", feats_c)
+
+    def critic_loss(wc, values):
+        dvalues = wc.v(wc.dhead["v_out"], mb_c, 1)
+        nb = ops_gen.value_loss(values.view(-1), rec, Dp, Dc, a_w, K, idx_c, mb_c, vn_state, den_c, hp, dvalues.view(-1),
+                                wc.loss_partials)
+        return dvalues, _loss_sums(wc, "v_out", nb, 1)
+
+    def critic_backward(wc, feats_c, trunk_c, gc, mrows_c, dvalues):
+        cn.grad.zero_()
+        dfeat = wc.v(wc.dfeat, mb_c, cn.H)
+        gn.head_backward(cn, wc, "v_out", feats_c, dvalues, dfeat, False)
+        if rnn is not None:
+            dfeat = gn.gru_backward(cn, gc, trunk_c, mrows_c, dfeat, L, mb_c // L)
+        gn.trunk_backward(cn, wc, dfeat)
+
+    # Separate networks: the critic's whole chain (forward, value loss, backward) is independent of the policy's - it runs
+    # on a second stream beside it, so one tower's K loops fill the other's store phases; the optimiser steps (shared
+    # norm scratch, the gradient all-reduce of a multi-GPU run) follow the join on the main stream.
+    fork = not shared and turn_on
+    side = main = None
+    if fork:
+        main = torch.cuda.current_stream(algo.device)
+        side = mod.side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            wc, feats_c, trunk_c, gc, mrows_c, values = critic_forward()
+            dvalues, vsums = critic_loss(wc, values)
+            critic_backward(wc, feats_c, trunk_c, gc, mrows_c, dvalues)
+    trunk_p, feats_p, logits = policy_forward()
+    if not fork:
+        wc, feats_c, trunk_c, gc, mrows_c, values = critic_forward()
 
     # ---- losses: d loss / d head outputs (already divided by the denominators) + statistics
     head = pn.head_desc
@@ -106,10 +145,8 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     nb = ops_gen.policy_loss(head, logits, mod._logstd(), rec, Dp, Dc, a_w, K, idx, mb, den, hp, dlogits,
                              wp.loss_partials)
     psums = _loss_sums(wp, "act", nb, 20)
-    dvalues = wc.v(wc.dhead["v_out"], mb_c, 1)
-    nb = ops_gen.value_loss(values.view(-1), rec, Dp, Dc, a_w, K, idx_c, mb_c, vn_state, den_c, hp, dvalues.view(-1),
-                            wc.loss_partials)
-    vsums = _loss_sums(wc, "v_out", nb, 1)
+    if not fork:
+        dvalues, vsums = critic_loss(wc, values)
 
     # ---- backward + optimiser
     def step(net, opt, n_clips, slot_first, slot_second):
@@ -163,13 +200,12 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
             if rnn is not None:
                 dfeat = gn.gru_backward(pn, gp, trunk_p, mrows, dfeat, L, Nc)
             gn.trunk_backward(pn, wp, dfeat)
+        if fork:
+            main.wait_stream(side)
+        else:
+            critic_backward(wc, feats_c, trunk_c, gc, mrows_c, dvalues)
+        if turn_on:
             step(pn, popt, 1, 3, -1)
-        cn.grad.zero_()
-        dfeat = wc.v(wc.dfeat, mb_c, cn.H)
-        gn.head_backward(cn, wc, "v_out", feats_c, dvalues, dfeat, False)
-        if rnn is not None:
-            dfeat = gn.gru_backward(cn, gc, trunk_c, mrows_c, dfeat, L, mb_c // L)
-        gn.trunk_backward(cn, wc, dfeat)
         step(cn, copt, 1, 4, -1)
 
     # ---- train_info (device-side accumulation; the sums are global in a multi-GPU run)

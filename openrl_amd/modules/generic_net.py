@@ -613,6 +613,13 @@ class GenericPPOModule(PPOModule):
     def critic_net(self) -> GenNet:
         return self.models["model" if self.share_model else "critic"]
 
+    def side_stream(self):
+        """The second stream the critic's chain runs on beside the policy's (rollout steps of recurrent towers, updates of
+        separate networks)."""
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(self.device)
+        return self._side_stream
+
     def workspace(self, net: GenNet, rows: int, training: bool, tag: str = "") -> GenWorkspace:
         key = (id(net), training, tag)
         ws = self._ws.get(key)
@@ -744,9 +751,7 @@ class GenericPPOModule(PPOModule):
         fork = want_action and want_value and not self.share_model and out is not None and h_out is not None
         if fork:
             main = torch.cuda.current_stream(self.device)
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(self.device)
-            self._side_stream.wait_stream(main)
+            self.side_stream().wait_stream(main)
             with torch.cuda.stream(self._side_stream):
                 critic_step()
         if want_action:
