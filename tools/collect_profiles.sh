@@ -55,6 +55,7 @@ timeout 600 python benchmarks/host_env_bench.py > $OUT/${TAG}_host_env_line.json
  python benchmarks/generic_bench.py --steps 3 --warmup 3 --hidden_size 256; python benchmarks/generic_bench.py --steps 3 --warmup 3 --share) \
   2>/dev/null | grep generic_tower_path > $OUT/${TAG}_generic_lines.jsonl
 stats generic_h128 python benchmarks/generic_bench.py --steps 3 --warmup 3
+stats generic_recurrent_h128 python benchmarks/cfg4_mpe_bench.py --hidden_size 128 --steps 3 --warmup 3
 (python benchmarks/cfg4_mpe_bench.py --hidden_size 128 --steps 5 --warmup 3; python benchmarks/cfg4_mpe_bench.py --hidden_size 256 --steps 3 --warmup 3
  python benchmarks/cfg4_mpe_bench.py --hidden_size 64 --layer_N 2 --steps 5 --warmup 3) 2>/dev/null | grep cfg4_mpe > $OUT/${TAG}_generic_recurrent_lines.jsonl
 # 6. the per-rank shard of the strong-scaling bench at 8 and 2 GPUs (512 / 2048 of the 4096 envs), on one GPU
