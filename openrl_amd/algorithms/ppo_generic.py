@@ -125,7 +125,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     # Separate networks: the critic's whole chain (forward, value loss, backward) is independent of the policy's - it runs
     # on a second stream beside it, so one tower's K loops fill the other's store phases; the optimiser steps (shared
     # norm scratch, the gradient all-reduce of a multi-GPU run) follow the join on the main stream.
-    fork = not shared and turn_on
+    fork = not shared and turn_on and mod.two_stream
     side = main = None
     if fork:
         main = torch.cuda.current_stream(algo.device)

@@ -602,7 +602,8 @@ class GenericPPOModule(PPOModule):
         self.rng_step_dev = None
         self._ws: Dict = {}
         self._ws_retired: List = []  # outgrown workspaces, kept alive for hipGraphs captured while they were current
-        self._side_stream = None  # the critic's chain of a recurrent rollout step (_forward_rnn)
+        self._side_stream = None  # the critic's chain of a recurrent rollout step (_forward_rnn) / of an update
+        self.two_stream = True    # False: everything on the caller's stream (the equality test of the two routes)
 
     # ------------------------------------------------------------------ nets
     @property
@@ -748,7 +749,8 @@ class GenericPPOModule(PPOModule):
         # A recurrent step is a chain of ~10 small launches per tower: with separate networks and caller-owned outputs
         # (the driver's buffer slots - nothing is allocated below) the critic's chain runs on a second stream beside
         # the policy's, forked and joined here, also inside a captured rollout graph.
-        fork = want_action and want_value and not self.share_model and out is not None and h_out is not None
+        fork = (want_action and want_value and not self.share_model and out is not None and h_out is not None
+                and self.two_stream)
         if fork:
             main = torch.cuda.current_stream(self.device)
             self.side_stream().wait_stream(main)

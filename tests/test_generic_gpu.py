@@ -508,6 +508,37 @@ def test_general_towers_train_cartpole_end_to_end_and_checkpoint(argv, tmp_path)
         assert float(np.mean(ep)) > 60, stats
 
 
+@pytest.mark.parametrize("kind", ["mlp", "gru"])
+def test_two_stream_and_one_stream_routes_give_identical_weights(kind):
+    """The critic's chain on a second stream (updates of separate networks, rollout steps of recurrent towers) against
+    everything on one stream: every kernel writes its own buffers in a fixed order, so the parameters after three
+    iterations are equal bit for bit."""
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+    from openrl_amd.runners.common import PPOAgent
+
+    def run(two_stream):
+        if kind == "mlp":
+            argv, name, n, T = ["--hidden_size", "128", "--layer_N", "2"], "CartPole-v1", 256, 32
+        else:
+            argv, name, n, T = ["--hidden_size", "128", "--use_recurrent_policy", "true", "--data_chunk_length", "5"], "simple_spread", 64, 25
+        cfg = default_cfg(argv + ["--episode_length", str(T), "--seed", "3", "--log_interval", "100000", "--ppo_epoch", "3"])
+        env = make(name, env_num=n, device=DEV, seed=3)
+        net = PPONet(env, cfg=cfg, device=DEV)
+        assert net.module.generic
+        net.module.two_stream = two_stream
+        agent = PPOAgent(net)
+        agent.train(total_time_steps=n * T * 3)
+        torch.cuda.synchronize()
+        return {k: m.theta.clone() for k, m in net.module.models.items()}
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.isfinite(a[k]).all()
+        assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("tag", ["default", "general", "shared"])
 def test_loading_a_state_dict_saved_by_the_reference_reproduces_its_outputs(tag):
     """Checkpoint compatibility in the direction that matters for a drop-in: ``state_dict()`` tensors produced by the
