@@ -13,7 +13,8 @@ statistics are summed over ranks once per optimiser step by the one-shot xGMI al
 optimiser-step launches (``orl_comm``; ``--collective rccl`` = one RCCL all-reduce instead).  ``--scaling weak`` keeps
 4096 envs on EVERY rank.
 
-    python bench.py [--gpus N --steps K --warmup W]           (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+        (N>1: spawns its own N ranks through torch.distributed.run, or joins the group torchrun already made)
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel pair (``orl_ppo_fwd_bwd`` =
 ppo_tower_kernel policy + critic, fp32 MFMA bound) timed live with HIP events on the launch stream;
@@ -40,6 +41,21 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (dense)
 HBM_PEAK_GBS = 8000.0
 
 
+def self_launch(n: int) -> int:
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and the hipIpc inboxes of orl_comm need it
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,7 +70,14 @@ def main():
     ap.add_argument("--envs", type=int, default=N_ENVS, help="global env count (default: the metric's 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the few untimed iterations of BASELINE.json's other single-GPU configs (other_configs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: re-launch as N ranks, one process per GPU (torch.distributed.run is what
+        # the driver's own N>1 command line uses); rank 0's JSON line passes through on stdout
+        return self_launch(args.gpus)
 
     from openrl_amd import distributed as du
     from openrl_amd import ops
@@ -68,8 +91,8 @@ def main():
     local_rank = du.init_from_env()
     world = du.world_size()
     rank = du.rank()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:  # never a silent 1-rank run under an N-GPU label (or the other way round)
+        raise SystemExit("--gpus %d but the process group has %d rank(s)" % (args.gpus, world))
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
 
@@ -196,17 +219,29 @@ def main():
                        "source": "profiles/r02_ref_cpu_line.json"}
         except Exception:
             pass
+        if ref_run is not None:  # top-level scalars: the REAL reference classes' rate survives any truncation of the object
+            out["cpu_reference_value"] = ref_run["value"]
+            out["cpu_reference_cores"] = ref_run["cores"]
         out["cpu_baseline"] = {"value": round(cb["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": cb["cores"],
                                "kind": "port", "reference_run": ref_run,
                                "sample": "1 iteration of the oracle port: %d envs x %d-step rollout + %d full-batch "
                                          "epochs (%.1f s; act %.1f s, insert %.1f s, update %.1f s)"
                                          % (N_ENVS, cb["T"], PPO_EPOCH, cb["seconds"], cb["phase_act"],
                                             cb["phase_insert"], cb["phase_update"])}
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        # BASELINE.json's other single-GPU configs, a few iterations each, AFTER and outside the timed region
+        from benchmarks.other_configs import run_all
+
+        out["other_configs"] = run_all(steps=3, warmup=2, dev=dev)
+    if world > 1:
+        out["scaling_note"] = ("per-rank work is 1/%d of the 4096 global envs; no multi-GPU hardware curve has been measured "
+                               "by the builder - this line is the measurement" % world)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 206 /* 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 300 /* 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -342,6 +342,10 @@ int orl_comm_create(int rank, int world, int64_t capacity_floats, orl_comm** com
 int orl_comm_connect(orl_comm* comm, const unsigned char* all_handles);
 int orl_comm_destroy(orl_comm* comm);
 int orl_comm_error(orl_comm* comm, void* stream);
+/* The same error word copied into a caller-owned int32 on the device, asynchronously on `stream` (no synchronisation):
+ * the caller folds it into a read-back it does anyway (the train_info scalars), so a timeout in the middle of an update
+ * surfaces at the end of that update instead of never. */
+int orl_comm_error_copy(orl_comm* comm, int* err_out_dev, void* stream);
 /* data[0..n) <- sum over ranks of data[0..n), in place, n <= capacity; no-op for world == 1. */
 int orl_allreduce_small(orl_comm* comm, float* data, int n, void* stream);
 /* The same collective fused into the optimiser step, so that a multi-GPU step is the same TWO launches as a

@@ -19,7 +19,7 @@ ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL, ORL_ENV_MPE_SPREAD = 0, 1, 2, 3, 4
 ORL_GATHER_MAX = 12
 ORL_IPC_HANDLE_BYTES = 64
-ORL_VERSION = 206  # must equal include/orl_hip.h; checked against the loaded library
+ORL_VERSION = 300  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -173,6 +173,7 @@ _SIGNATURES = {
     "orl_comm_connect": (C.c_int, [_P, _P]),
     "orl_comm_destroy": (C.c_int, [_P]),
     "orl_comm_error": (C.c_int, [_P, _P]),
+    "orl_comm_error_copy": (C.c_int, [_P, _P, _P]),
     "orl_allreduce_small": (C.c_int, [_P, _P, C.c_int, _P]),
     "orl_ppo_reduce_pair_comm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "orl_ppo_apply_comm": (C.c_int, [_P, C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
@@ -316,3 +317,32 @@ def require_gpu(device) -> torch.device:
             "openrl_amd is a MI355X (ROCm) engine: device %r has no HIP runtime behind it and there is no CPU "
             "fallback. Use the reference on CPU, or run on a gfx950 device." % (str(device),))
     return device
+
+
+class DeviceErrorWatch:
+    """Host-side view of a device error word that kernels may set while the host runs ahead (the 10 s peer timeout of
+    ``orl_comm``, the bounded critic-chases-policy wait of ``orl_rnn_rollout_fused``).  ``post(flag)`` queues an
+    asynchronous copy of the int32 device word into pinned host memory behind the work already on the stream;
+    ``poll()`` raises if a completed copy carried a non-zero word - without synchronising (``wait=True``: after waiting
+    for the copy).  Callers post once per update / rollout and poll at their next natural host touch point, so a
+    failure surfaces at most one iteration late and never costs a sync."""
+
+    def __init__(self, what: str) -> None:
+        self.what = what
+        self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._event = None
+
+    def post(self, flag: torch.Tensor) -> None:
+        self.poll()  # the previous copy, if it has landed
+        self._host.copy_(flag.reshape(-1)[:1], non_blocking=True)
+        if self._event is None:
+            self._event = torch.cuda.Event()
+        self._event.record(torch.cuda.current_stream(flag.device))
+
+    def poll(self, wait: bool = False) -> None:
+        if self._event is None:
+            return
+        if wait:
+            self._event.synchronize()
+        if self._event.query() and int(self._host[0]) != 0:
+            raise NativeError("%s (device error word = %d)" % (self.what, int(self._host[0])))

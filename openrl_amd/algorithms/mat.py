@@ -36,6 +36,11 @@ class MATAlgorithm(PPOAlgorithm):
                                       "hands stored hidden states to a feed-forward pass)")
         self.fuse_next_perm = False  # the fused next-epoch permutation is over rows, this one is over (step, env) pairs
 
+    def _update_minibatch(self, buffer, idx, mb: int, turn_on: bool, next_perm=None):
+        # the reference's MATAlgorithm.construct_loss_list (mat.py:24-38) ignores ``turn_on``: the summed loss always
+        # contains policy_loss, so the policy is stepped even when the caller passes turn_on=False
+        return super()._update_minibatch(buffer, idx, mb, True, next_perm)
+
     def _minibatch_indices(self, M: int, perm=None):
         A = int(self.agent_num)
         assert M % A == 0

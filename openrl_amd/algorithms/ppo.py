@@ -32,13 +32,16 @@ class DeviceTrainInfo(dict):
     """The train_info dict of ``PPOAlgorithm.train`` (ppo.py:445-458) whose values are still on the device: the one
     device->host copy happens on first access (any read of the dict), not at the end of every update."""
 
-    def __init__(self, keys, device_values: torch.Tensor):
+    def __init__(self, keys, device_values: torch.Tensor, after_sync=None):
         super().__init__()
-        self._keys, self._dev = tuple(keys), device_values
+        self._keys, self._dev, self._after_sync = tuple(keys), device_values, after_sync
 
     def _materialize(self) -> None:
         if self._dev is not None:
             vals, self._dev = self._dev.cpu().tolist(), None
+            if self._after_sync is not None:  # e.g. the collective's error word, posted behind this update's launches
+                cb, self._after_sync = self._after_sync, None
+                cb()
             for k, v in zip(self._keys, vals):
                 super().__setitem__(k, v)
 
@@ -138,9 +141,31 @@ class PPOAlgorithm(BaseAlgorithm):
             self._rnn_rows = None
             self.fuse_next_perm = False
             self._comm = None
-            self._gen_den = torch.zeros(2, dtype=torch.float32, device=self.device)
+            self._gen_den4 = torch.zeros(4, dtype=torch.float32, device=self.device)  # [policy den | value den (JRPO)]
+            self._gen_den = self._gen_den4[:2]
+            self._gen_den_c = self._gen_den4[2:]
             self._gen_den_scratch = torch.zeros(257, dtype=torch.float32, device=self.device)
             self._gen_scratch = torch.zeros(256, dtype=torch.float32, device=self.device)
+            self._gen_flat = self._gen_sums = None
+            self._gen_den_stamp = None
+            self._comm_watch = None
+            if self.world_size > 1:
+                # multi-GPU: ONE flat vector per optimiser step - every network's gradient and the
+                # two 20-float loss / logging sum rows live in one allocation (the networks' ``grad`` become views of it),
+                # summed over ranks by one collective after the backward passes
+                nets = [m for m in self.algo_module.models.values()]
+                n = sum(int(m.n_params) for m in nets) + 40
+                self._gen_flat = torch.zeros(n, dtype=torch.float32, device=self.device)
+                o = 0
+                for m in nets:
+                    m.grad = self._gen_flat[o:o + int(m.n_params)]
+                    o += int(m.n_params)
+                self._gen_sums = (self._gen_flat[o:o + 20], self._gen_flat[o + 20:o + 40])
+                self._comm = dist_utils.make_small_allreduce(n, self.device, getattr(cfg, "amd_collective", "p2p")) \
+                    if n <= (1 << 22) else None
+                if self._comm is not None:
+                    self._comm_watch = nat.DeviceErrorWatch("orl_comm: a peer's contribution did not arrive within 10 s - "
+                                                            "the optimiser step ran on a partial gradient sum")
             return
         p, c = self.algo_module.models["policy"], self.algo_module.models["critic"]
         self.recurrent = bool(getattr(self.algo_module, "recurrent", False))
@@ -160,6 +185,19 @@ class PPOAlgorithm(BaseAlgorithm):
         self._comm = dist_utils.make_small_allreduce(self._sums.numel(), dev, getattr(cfg, "amd_collective", "p2p")) \
             if self.world_size > 1 else None
         self.fuse_next_perm = True  # device permutation of epoch e+1 rides in epoch e's optimiser-step launch
+        self._comm_watch = nat.DeviceErrorWatch("orl_comm: a peer's contribution did not arrive within 10 s - the "
+                                                "optimiser step ran on a partial gradient sum") \
+            if self._comm is not None else None
+
+    def _allreduce_vec(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place SUM of a small fp32 vector over the ranks: the one-shot xGMI push when the comm is up, else
+        torch.distributed (RCCL)."""
+        if self.world_size > 1:
+            if self._comm is not None and t.dtype == torch.float32 and t.numel() <= self._comm.capacity:
+                self._comm.allreduce_(t)
+            else:
+                dist_utils.allreduce_(t)
+        return t
 
     # ------------------------------------------------------------------------------------------ advantages
     def _advantages_and_records(self, buffer) -> None:
@@ -404,8 +442,15 @@ class PPOAlgorithm(BaseAlgorithm):
         need = ops_rnn.rnn_workspace_floats(p.net, c.net, n_chunks, L)
         if self._rnn_ws is None or self._rnn_ws.numel() < need:
             self._rnn_ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        ev = getattr(self, "profile_events", None)
+        if ev is not None:  # benchmarks: HIP events on the launch stream around the recurrent forward + backward
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         ops_rnn.rnn_ppo_fwd_bwd(p.net, p.theta, c.net, c.theta, rec, rows, buffer.masks, buffer.rnn_states,
                                 buffer.rnn_states_critic, n_chunks, L, vn_state, self.hp, self._rnn_ws, self._sums)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         if self.world_size > 1:
             if self._comm is not None:
                 self._comm.allreduce_(self._sums)
@@ -469,6 +514,8 @@ class PPOAlgorithm(BaseAlgorithm):
     def train_ppo(self, buffer, turn_on: bool = True) -> Dict[str, float]:
         if self.naive_recurrent:
             self.data_chunk_length = buffer.episode_length
+        if getattr(self, "_comm_watch", None) is not None:
+            self._comm_watch.poll()  # the previous update's collectives (no sync)
         self._advantages_and_records(buffer)
         M = buffer.episode_length * buffer.n_rollout_threads * buffer.num_agents
         # one minibatch == every sample (recurrent: every chunk, when the chunks tile the batch exactly)
@@ -506,7 +553,13 @@ class PPOAlgorithm(BaseAlgorithm):
         scale = torch.full((len(keys),), 1.0 / float(num_updates), dtype=torch.float32, device=self.device)
         if self.use_joint_action_loss:  # every agent row (and action dim) of a (step, chunk) carried the joint term
             scale[1] /= float(buffer.num_agents * buffer.act_shape)
-        return DeviceTrainInfo(keys, self._info[:len(keys)] * scale)
+        watch = getattr(self, "_comm_watch", None)
+        if watch is None:
+            return DeviceTrainInfo(keys, self._info[:len(keys)] * scale)
+        # multi-GPU: the comm's error word rides behind this update's launches; it is looked at when train_info is read
+        # and (without a sync) when the next update starts - a timed-out peer never stays silent
+        watch.post(self._comm.error_flag())
+        return DeviceTrainInfo(keys, self._info[:len(keys)] * scale, after_sync=lambda: watch.poll(wait=True))
 
     def train(self, buffer, turn_on: bool = True) -> Dict[str, float]:
         if len(self.train_list) == 1:

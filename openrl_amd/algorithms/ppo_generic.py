@@ -17,9 +17,10 @@ from .. import ops, ops_gen
 from ..modules import generic_net as gn
 
 
-def _loss_sums(ws, name: str, nb: int, width: int):
-    ops_gen.colsum(ws.loss_partials, nb, [(ws.loss_sums[name], width)])
-    return ws.loss_sums[name]
+def _loss_sums(ws, name: str, nb: int, width: int, out=None):
+    out = ws.loss_sums[name] if out is None else out
+    ops_gen.colsum(ws.loss_partials, nb, [(out, width)])
+    return out
 
 
 def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None, jrpo=None) -> None:
@@ -52,16 +53,19 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
             ops.valuenorm_update(vn.state, algo._moments, vn.beta)  # BEFORE normalize (ppo.py:190-195)
         vn_state = vn.state
     den = den_c = algo._gen_den
-    ops_gen.denoms(rec, Dp, Dc, a_w, idx, mb, den, algo._gen_den_scratch)
-    if algo.world_size > 1:
-        dist_utils.allreduce_(den)  # global masked-mean denominators
-    if jrpo is not None:  # the value loss averages over agent 0's rows
-        if getattr(algo, "_gen_den_c", None) is None:
-            algo._gen_den_c = torch.zeros_like(algo._gen_den)
+    # one minibatch == the whole batch: the masked-mean denominators (counts of 0 / 1 floats - exact in fp32) are the
+    # same for every epoch of this train() call, so they are computed and summed over ranks once per call
+    stamp = (algo._jrpo_epoch_id, mb) if (jrpo is None and algo.num_mini_batch == 1) else None
+    if stamp is None or stamp != algo._gen_den_stamp:
+        ops_gen.denoms(rec, Dp, Dc, a_w, idx, mb, den, algo._gen_den_scratch)
+        if jrpo is not None:  # the value loss averages over agent 0's rows
+            den_c = algo._gen_den_c
+            ops_gen.denoms(rec, Dp, Dc, a_w, idx_c, mb_c, den_c, algo._gen_den_scratch)
+        if algo.world_size > 1:  # global denominators: ONE tiny collective ahead of the losses (2 or 4 floats)
+            algo._allreduce_vec(algo._gen_den4 if jrpo is not None else den)
+        algo._gen_den_stamp = stamp
+    elif jrpo is not None:
         den_c = algo._gen_den_c
-        ops_gen.denoms(rec, Dp, Dc, a_w, idx_c, mb_c, den_c, algo._gen_den_scratch)
-        if algo.world_size > 1:
-            dist_utils.allreduce_(den_c)
     pn, cn = mod.policy_net, mod.critic_net
     shared = mod.share_model
     # (recurrent: the actor and the critic carry their own stored states through the shared GRU - two passes)
@@ -112,7 +116,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
         dvalues = wc.v(wc.dhead["v_out"], mb_c, 1)
         nb = ops_gen.value_loss(values.view(-1), rec, Dp, Dc, a_w, K, idx_c, mb_c, vn_state, den_c, hp, dvalues.view(-1),
                                 wc.loss_partials)
-        return dvalues, _loss_sums(wc, "v_out", nb, 1)
+        return dvalues, _loss_sums(wc, "v_out", nb, 1, None if algo._gen_sums is None else algo._gen_sums[1])
 
     def critic_backward(wc, feats_c, trunk_c, gc, mrows_c, dvalues):
         cn.grad.zero_()
@@ -144,14 +148,18 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     dlogits = wp.v(wp.dhead["act"], mb, head.n_out)
     nb = ops_gen.policy_loss(head, logits, mod._logstd(), rec, Dp, Dc, a_w, K, idx, mb, den, hp, dlogits,
                              wp.loss_partials)
-    psums = _loss_sums(wp, "act", nb, 20)
+    gsums = algo._gen_sums  # multi-GPU: the sum rows live in the flat vector the one collective reduces
+    psums = _loss_sums(wp, "act", nb, 20, None if gsums is None else gsums[0])
     if not fork:
         dvalues, vsums = critic_loss(wc, values)
 
     # ---- backward + optimiser
-    def step(net, opt, n_clips, slot_first, slot_second):
+    def reduce_over_ranks():
+        # ONE collective per optimiser step - every network's gradient + the loss / logging sums
         if algo.world_size > 1:
-            dist_utils.allreduce_(net.grad)
+            algo._allreduce_vec(algo._gen_flat)
+
+    def step(net, opt, n_clips, slot_first, slot_second):
         opt.step_count += 1
         ops_gen.adam(opt.native_state(opt.step_count), net.n_params, hp.max_grad_norm, bool(hp.use_max_grad_norm), n_clips,
                      algo._gen_scratch, algo._info, slot_first, slot_second, algo.device)
@@ -189,6 +197,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
                 lo, hi = hv["W"], hv["b"] + 1
                 g1[lo:hi] = 0.0  # v_out's gradient is already in model.grad (the second pass did not touch it)
                 ops_gen.vec_add(model.grad, g1)
+        reduce_over_ranks()
         step(model, opt, 2, 3, 4)  # actor_grad_norm, then critic_grad_norm of the once-clipped gradient
     else:
         popt, copt = mod.optimizers["policy"], mod.optimizers["critic"]
@@ -204,14 +213,12 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
             main.wait_stream(side)
         else:
             critic_backward(wc, feats_c, trunk_c, gc, mrows_c, dvalues)
+        reduce_over_ranks()
         if turn_on:
             step(pn, popt, 1, 3, -1)
         step(cn, copt, 1, 4, -1)
 
-    # ---- train_info (device-side accumulation; the sums are global in a multi-GPU run)
-    if algo.world_size > 1:
-        dist_utils.allreduce_(psums)
-        dist_utils.allreduce_(vsums)
+    # ---- train_info (device-side accumulation; the sums are global in a multi-GPU run: they rode in the flat vector)
     gauss = head.kind == ops_gen.HEAD_GAUSSIAN
     ent_div = float(head.n_out) if (gauss and not hp.use_policy_active_masks) else 1.0
     ratio_div = float(a_w) if head.kind != ops_gen.HEAD_CATEGORICAL else 1.0

@@ -136,6 +136,13 @@ int orl_comm_error(orl_comm* c, void* stream) {
   return 0;
 }
 
+int orl_comm_error_copy(orl_comm* c, int* err_out_dev, void* stream) {
+  ORL_REQUIRE(c && err_out_dev, "orl_comm_error_copy: null pointer");
+  const hipError_t e = hipMemcpyAsync(err_out_dev, c->err_dev, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return fail((int)e, "orl_comm_error_copy: %s", hipGetErrorString(e));
+  return 0;
+}
+
 int orl_allreduce_small(orl_comm* c, float* data, int n, void* stream) {
   ORL_REQUIRE(c && data, "orl_allreduce_small: null pointer");
   ORL_REQUIRE(c->connected, "orl_allreduce_small: orl_comm_connect has not run");

@@ -73,7 +73,11 @@ class SmallAllreduce:
     with ``torch.distributed.all_gather_object`` (any backend), then each collective is ONE kernel per rank - or no
     extra kernel at all when fused into the optimiser step (``ops.ppo_reduce_pair(comm=...)`` /
     ``ops.ppo_apply(comm=...)``).  All ranks of the comm must live on one node.  Results are bit-identical on every
-    rank (rank-ordered summation)."""
+    rank (rank-ordered summation).
+
+    The constructor only does the LOCAL half (allocate + export the inbox) and issues no collective;
+    ``make_small_allreduce`` drives the exchange so that every rank runs the same sequence of collectives whether or
+    not its local steps succeeded."""
 
     def __init__(self, capacity_floats: int, device) -> None:
         import ctypes as C
@@ -85,22 +89,23 @@ class SmallAllreduce:
         self.capacity = int(capacity_floats)
         self._lib = nat.load()
         self.handle = C.c_void_p()
+        self._err_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         buf = (C.c_ubyte * nat.ORL_IPC_HANDLE_BYTES)()
         with torch.cuda.device(self.device):
             nat.check(self._lib.orl_comm_create(self.rank, self.world, self.capacity, C.byref(self.handle), buf),
                       "orl_comm_create")
-            if self.world > 1:
-                mine = bytes(buf)
-                gathered = [None] * self.world
-                dist.all_gather_object(gathered, mine)
-                blob = b"".join(gathered)
-                all_h = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
-                try:
-                    nat.check(self._lib.orl_comm_connect(self.handle, all_h), "orl_comm_connect")
-                except Exception:
-                    self.close()
-                    raise
-                dist.barrier()  # every inbox is mapped before anybody pushes
+        self.ipc_handle = bytes(buf)
+
+    def connect(self, handles) -> None:
+        """Map the peers' inboxes (``handles`` = every rank's ``ipc_handle`` in rank order).  Local, no collective."""
+        import ctypes as C
+
+        from . import _native as nat
+
+        blob = b"".join(handles)
+        all_h = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.orl_comm_connect(self.handle, all_h), "orl_comm_connect")
 
     def allreduce_(self, t: torch.Tensor) -> torch.Tensor:
         from . import _native as nat
@@ -117,6 +122,15 @@ class SmallAllreduce:
 
         nat.check(self._lib.orl_comm_error(self.handle, nat.stream_ptr(self.device)), "orl_comm_error")
 
+    def error_flag(self) -> torch.Tensor:
+        """The comm's error word copied (asynchronously, on the current stream) into an int32 device tensor: callers fold
+        it into a read-back they do anyway (``DeviceTrainInfo``) so a peer that timed out mid-update is never silent."""
+        from . import _native as nat
+
+        nat.check(self._lib.orl_comm_error_copy(self.handle, self._err_dev.data_ptr(), nat.stream_ptr(self.device)),
+                  "orl_comm_error_copy")
+        return self._err_dev
+
     def close(self) -> None:
         if getattr(self, "handle", None) is not None and self.handle.value:
             self._lib.orl_comm_destroy(self.handle)
@@ -129,38 +143,66 @@ class SmallAllreduce:
             pass
 
 
+#: test hook (tests/multirank_equiv.py): {"rank": r, "stage": "create" | "connect" | "selftest"} makes that stage fail on
+#: rank r, to exercise the collective fallback.  Never set by product code.
+_FAULT_INJECT = None
+
+
+def _fault(stage: str) -> None:
+    f = _FAULT_INJECT
+    if f and f.get("stage") == stage and f.get("rank") == rank():
+        raise RuntimeError("injected %s failure on rank %d" % (stage, rank()))
+
+
 def make_small_allreduce(capacity_floats: int, device, mode: str = "p2p"):
     """A ``SmallAllreduce`` for this process group, or None (-> torch.distributed / RCCL all-reduces) when the run is
     single-process, ``mode == "rccl"``, or peer memory cannot be mapped.  The decision is made collectively: if ANY
-    rank fails to set the comm up, every rank falls back."""
+    rank fails to set the comm up, every rank falls back.  Every rank executes the SAME three collectives (handle
+    gather, connect-status gather, self-test-status gather) whatever happened locally - a rank never raises between
+    them, so the group cannot fall out of step."""
     if not (is_initialized() and dist.get_world_size() > 1) or mode != "p2p":
         return None
-    comm, ok = None, 1
-    try:
-        comm = SmallAllreduce(capacity_floats, device)
-    except Exception as e:  # IPC not permitted / peers on another node / more than 8 ranks
-        ok = 0
-        import warnings
+    import warnings
 
-        warnings.warn("orl_comm unavailable (%s): falling back to torch.distributed all-reduces" % (e,))
-    if ok:  # self-test on THIS node's links before anything depends on it: a known sum, both inbox parities
-        try:
-            W, r = dist.get_world_size(), dist.get_rank()
+    W, r = dist.get_world_size(), dist.get_rank()
+
+    def agree(local_ok: bool, payload=None):
+        got = [None] * W
+        dist.all_gather_object(got, (bool(local_ok), payload))
+        return all(g[0] for g in got), [g[1] for g in got]
+
+    comm, why = None, None
+    try:  # 1. local create + export
+        _fault("create")
+        comm = SmallAllreduce(capacity_floats, device)
+    except Exception as e:  # IPC not permitted / more than 8 ranks
+        why = "create: %s" % (e,)
+    ok, handles = agree(comm is not None, comm.ipc_handle if comm is not None else None)
+    if ok:
+        try:  # 2. map the peers' inboxes
+            _fault("connect")
+            comm.connect(handles)
+            local = True
+        except Exception as e:  # peers on another node / no peer access
+            local, why = False, "connect: %s" % (e,)
+        ok, _ = agree(local)  # also the barrier: every inbox is mapped before anybody pushes
+    if ok:
+        try:  # 3. self-test on THIS node's links before anything depends on it: a known sum, both inbox parities
+            _fault("selftest")
             pat = (1 + torch.arange(comm.capacity, device=comm.device) % 7).to(torch.float32)
             for _ in range(2):
                 t = pat * float(r + 1)
                 comm.allreduce_(t)
                 comm.check()
                 if not torch.equal(t, pat * float(W * (W + 1) // 2)):
-                    raise RuntimeError("orl_allreduce_small self-test: wrong sum on rank %d" % r)
+                    raise RuntimeError("wrong sum on rank %d" % r)
+            local = True
         except Exception as e:
-            ok = 0
-            import warnings
-
-            warnings.warn("orl_comm self-test failed (%s): falling back to torch.distributed all-reduces" % (e,))
-    flags = [None] * dist.get_world_size()
-    dist.all_gather_object(flags, ok)
-    if not all(flags):
+            local, why = False, "self-test: %s" % (e,)
+        ok, _ = agree(local)
+    if not ok:
+        warnings.warn("orl_comm unavailable on rank %d (%s): every rank falls back to torch.distributed all-reduces"
+                      % (r, why or "a peer failed"))
         if comm is not None:
             comm.close()
         return None

@@ -157,6 +157,7 @@ class OnPolicyDriver:
         self._graph = None
         self._rng_ctr = None
         self._chase_flags = None  # orl_rnn_rollout_fused step counters (recurrent fused rollout)
+        self._chase_watch = None
         self._staging = None if dev_env else HostStaging(self.device)
         d = self.buffer.data
         self._next_value = torch.zeros(d.n_rollout_threads, d.num_agents, 1, dtype=torch.float32, device=self.device)
@@ -188,6 +189,13 @@ class OnPolicyDriver:
             self.episode = episode
             if not self._inner_loop():
                 break
+        self.check_device_errors()
+
+    def check_device_errors(self) -> None:
+        """Raise if a kernel set an error word during the run (waits for the last posted copies)."""
+        for w in (self._chase_watch, getattr(self.trainer, "_comm_watch", None)):
+            if w is not None:
+                w.poll(wait=True)
 
     def learner_update(self):
         if self.use_linear_lr_decay:
@@ -260,6 +268,12 @@ class OnPolicyDriver:
                                                     device=self.device)
                 a.sync_flags = nat.ptr(self._chase_flags)
             ops_rnn.rnn_rollout_fused(p.net, p.theta, c.net, c.theta, a, self.device)
+            if self._chase_flags is not None:  # the kernel's error word: looked at (without a sync) next rollout / at the end
+                if self._chase_watch is None:
+                    self._chase_watch = nat.DeviceErrorWatch(
+                        "orl_rnn_rollout_fused: a critic workgroup's bounded wait for its policy workgroup timed out - "
+                        "the rollout's value predictions are incomplete")
+                self._chase_watch.post(self._chase_flags[-1:])
             env.global_step += self.episode_length
             mod.rng_step += self.episode_length
             self._have_next_value = True
@@ -327,9 +341,10 @@ class OnPolicyDriver:
             # host envs get the reference's action dtype: integer indices for Discrete / MultiDiscrete spaces (the
             # reference's ACTLayer samples int64, act.py:59-83), float32 for Box; the buffer keeps them as floats
             # (the float -> int64 conversion runs on the host copy: one device launch less per step)
+            # a FRESH array every step, like the reference: envs / wrappers / callbacks may keep it (recording, replay),
+            # and the pinned staging buffer is overwritten by the next step
             host_actions = self._staging.to_host("actions", actions)
-            if self.buffer.data.act_is_index:
-                host_actions = host_actions.astype(np.int64)
+            host_actions = host_actions.astype(np.int64) if self.buffer.data.act_is_index else host_actions.copy()
             obs, rewards, dones, infos = self.envs.step(host_actions, extra_data)
         self.agent.num_time_steps += self.envs.parallel_env_num
         self.callback.update_locals(locals())

@@ -358,7 +358,13 @@ class EvalCallback(EventCallback):
         obs = env.reset_device(seed=getattr(env, "seed", 0))
         env.ep_stats.zero_()
         target = self.n_eval_episodes * n
-        h = torch.zeros(n * a, module.cfg.hidden_size, device=env.device) if getattr(module, "recurrent", False) else None
+        h = None
+        if getattr(module, "recurrent", False):
+            # one row of recurrent state per lane: [recurrent_N x (H | 2 H for an LSTM)] on the general towers, H on the
+            # default one
+            pn = getattr(module, "policy_net", None)
+            width = pn.state_w * pn.recurrent_N if pn is not None and hasattr(pn, "state_w") else module.cfg.hidden_size
+            h = torch.zeros(n * a, width, device=env.device)
         masks = torch.ones(n * a, 1, device=env.device)
         run_len = torch.zeros(n, device=env.device)
         fin_len = torch.zeros(n, device=env.device)

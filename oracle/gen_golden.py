@@ -407,6 +407,70 @@ def _train_case_full(name, argv, N, T, D, n_act, seed=0):
     print(name + ".npz", {k: float(info[k]) for k in info})
 
 
+def _train_case_full_general(name, argv, N, T, Dp, Dc, kind, n_act, A=1, legal_masks=False, recurrent=False, seed=0):
+    """Full-size updates at the other BASELINE.json shapes - configs[2] (1024 x 200, obs 17, Box(6)), configs[4]
+    (4096 x 200, obs 18, Discrete(9) + random legal-move masks) and configs[3] (2048 envs x 3 agents x 25, Dict obs
+    18/54, Discrete(5), GRU, chunks of 2 through ``recurrent_generator``).  Same recipe as ``_train_case_full``: the
+    buffer is regenerated from a seed (``oracle.fixtures.synth_update_buffer_general``), ``compute_returns`` and
+    ``PPOAlgorithm.train`` are the reference's own (algorithms/ppo.py:383-458, buffers/replay_data.py:320-423,
+    553-646, 1062-1258), only outputs are stored."""
+    from gymnasium.spaces import Box, Dict as DictSpace, Discrete
+    from openrl.algorithms.ppo import PPOAlgorithm
+    from openrl.buffers import NormalReplayBuffer
+    from openrl.modules.ppo_module import PPOModule
+    from openrl.utils.util import set_seed
+
+    from .fixtures import synth_update_buffer_general
+
+    argv = (["--use_recurrent_policy", "true"] if recurrent else []) + argv
+    cfg = _cfg(argv, N, T)
+    cfg.num_agents = A
+    cfg.seed = seed
+    box = lambda d: Box(-np.inf, np.inf, (d,))
+    obs_space = box(Dp) if Dp == Dc else DictSpace({"policy": box(Dp), "critic": box(Dc)})
+    act_space = Discrete(n_act) if kind == "discrete" else Box(-1, 1, (n_act,))
+    set_seed(cfg.seed)
+    module = PPOModule(cfg, policy_input_space=obs_space, critic_input_space=obs_space, act_space=act_space,
+                       share_model=False, rank=0, world_size=1)
+    out = {"theta_p0": _flat(module.models["policy"]), "theta_c0": _flat(module.models["critic"])}
+    buffer = NormalReplayBuffer(cfg, A, obs_space, act_space, data_client=None)
+    algo = PPOAlgorithm(cfg, module, agent_num=A)
+    d = buffer.data
+    src = synth_update_buffer_general(2000 + seed, N, T, Dp, Dc, kind, n_act, A, legal_masks,
+                                      cfg.hidden_size if recurrent else 0)
+    d.policy_obs[:] = src["policy_obs"]  # Dict{"policy","critic"} spaces: one plain array per side (replay_data.py:70-71)
+    d.critic_obs[:] = src["critic_obs"]
+    fields = ["rewards", "value_preds", "masks", "active_masks", "bad_masks", "actions", "action_log_probs"]
+    if kind == "discrete":
+        fields.append("action_masks")
+    if recurrent:
+        fields += ["rnn_states", "rnn_states_critic"]
+    for f in fields:
+        getattr(d, f)[:] = src[f]
+    vn = module.get_critic_value_normalizer()
+    buffer.compute_returns(src["next_value"].copy(), vn)
+    out["returns_probe_idx"] = np.array([[0, 0, 0], [T // 2, N // 3, A - 1], [T - 1, N - 1, 0], [17, 5, A // 2],
+                                         [T - 2, 11, 0]])
+    out["returns_probe"] = np.array([d.returns[t, n, a, 0] for t, n, a in out["returns_probe_idx"]], np.float32)
+    out["returns_sum"] = np.array(d.returns[:-1].astype(np.float64).sum())
+    torch.manual_seed(1234 + seed)
+    algo.prep_training()
+    info = algo.train(d)
+    out["train_info"] = np.array([float(info.get(k, 0.0)) for k in
+                                  ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm",
+                                   "ratio")], np.float64)
+    out["theta_p1"] = _flat(module.models["policy"])
+    out["theta_c1"] = _flat(module.models["critic"])
+    out["vn_state1"] = np.array([vn.running_mean.item(), vn.running_mean_sq.item(), vn.debiasing_term.item()],
+                                np.float32)
+    out["argv"] = np.array(" ".join(argv))
+    out["perm_seed"] = np.array(1234 + seed)
+    out["shape"] = np.array([N, T, Dp, Dc, n_act, A, 2000 + seed, int(legal_masks), int(recurrent)])
+    out["kind"] = np.array(kind)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name + ".npz", {k: float(info[k]) for k in info})
+
+
 def _train_case_recurrent(name, argv, Dp, Dc, act_space_fn, N=6, A=2, T=7, seed=0, naive=False, share=False):
     """use_recurrent_policy: hand-driven rollout (rnn states zeroed on env-done, onpolicy_driver.py:91-108),
     then PPOAlgorithm.train with recurrent_generator (ppo.py:363-372, replay_data.py:1062-1258)."""
@@ -654,6 +718,15 @@ def main():
             lambda: Discrete(5), N=6, A=3, T=7, seed=5),
         # BASELINE.json configs[1] at full size (what bench.py runs): only outputs are stored, inputs come from a seed
         "train_cfg2_full": lambda n: _train_case_full(n, ["--ppo_epoch", "10", "--num_mini_batch", "1"], 4096, 128, 4, 2),
+        # the other BASELINE.json shapes at full size: the launch branches of the tower pair that only large batches take
+        # (uneven CU split, back-to-back order), the ragged multi-chunk-per-wave rounds of the recurrent update
+        "train_cfg3_full": lambda n: _train_case_full_general(
+            n, ["--ppo_epoch", "10", "--num_mini_batch", "1"], 1024, 200, 17, 17, "box", 6, seed=3),
+        "train_cfg5_full": lambda n: _train_case_full_general(
+            n, ["--ppo_epoch", "10", "--num_mini_batch", "1"], 4096, 200, 18, 18, "discrete", 9, legal_masks=True, seed=5),
+        "train_cfg4_full": lambda n: _train_case_full_general(
+            n, ["--ppo_epoch", "10", "--num_mini_batch", "1", "--data_chunk_length", "2", "--lr", "7e-4", "--critic_lr",
+                "7e-4", "--use_adv_normalize", "true"], 2048, 25, 18, 54, "discrete", 5, A=3, recurrent=True, seed=4),
         # JRPO: use_joint_action_loss -> recurrent_generator_v3 (agent axis kept) + joint ratio, critic on agent 0 only
         # (algorithms/ppo.py:254-300, buffers/replay_data.py:425-551)
         "train_recurrent_jrpo": lambda n: _train_case_recurrent(

@@ -1,4 +1,4 @@
-"""Worker for tests/test_multirank_gpu.py (launched with torch.distributed.run, 2 ranks, gloo, one GPU).
+"""Worker for tests/test_multirank_gpu.py (launched with torch.distributed.run, 2 - 8 ranks, gloo, one GPU).
 
 "G ranks == 1 rank on the concatenated batch" (SURVEY.md section 8e): a global buffer of 2*Nl env lanes is split
 by env between the ranks; every rank runs PPOAlgorithm.train on its shard with the all-reduces of
@@ -35,23 +35,29 @@ def fill(buf, host, lo, hi, nv):
 
 
 def comm_main(du, rank, world, dev):
-    """orl_allreduce_small (one-shot P2P push over hipIpc-mapped peer memory; both ranks share cuda:0 here) against
-    torch.distributed's all_reduce: bit-identical for 2 ranks (a + b is commutative in fp32), over many
-    back-to-back collectives of different sizes (exercises the parity double-buffering of the inboxes)."""
+    """orl_allreduce_small (one-shot P2P push over hipIpc-mapped peer memory; all ranks share cuda:0 here) against an
+    all_gather of the contributions summed explicitly in RANK ORDER in fp32 - the order the kernel promises - so the
+    comparison is bit-exact for any world size (torch.distributed's own all_reduce orders the sum differently beyond
+    2 ranks); many back-to-back collectives of different sizes exercise the parity double-buffering and the
+    [parity][source rank][capacity] stride of the inboxes."""
     comm = du.make_small_allreduce(20000, dev)
     ok = comm is not None
     if ok:
         rs = np.random.RandomState(100 + rank)
         for k, n in enumerate([1, 63, 64, 9702, 20000, 7, 9702, 9702, 4096, 1]):
             x = torch.tensor(rs.randn(n).astype(np.float32) * (1 + k), device=dev)
-            want = x.clone()
-            torch.distributed.all_reduce(want)  # gloo on CUDA tensors
+            parts = [torch.zeros_like(x) for _ in range(world)]
+            torch.distributed.all_gather(parts, x)  # gloo on CUDA tensors
+            want = torch.zeros_like(x)
+            for r in range(world):  # 0 + x_0 + x_1 + ... : comm_sum's order (csrc/orl_comm.h)
+                want = want + parts[r]
             got = comm.allreduce_(x.clone())
             torch.cuda.synchronize()
             if not torch.equal(got, want):
                 ok = False
                 print("rank %d: collective %d (n=%d) differs: max|d| %.3e" % (rank, k, n, (got - want).abs().max().item()))
         comm.check()
+        assert int(comm.error_flag().item()) == 0
         # every rank holds the identical vector
         g = [torch.zeros_like(got) for _ in range(world)]
         torch.distributed.all_gather(g, got)
@@ -75,8 +81,12 @@ def main():
     if "comm" in sys.argv[1:]:
         return comm_main(du, rank, world, dev)
     collective = "rccl" if "rccl" in sys.argv[1:] else "p2p"
+    fallback = "fallback" in sys.argv[1:]  # one rank's comm self-test fails -> EVERY rank must fall back, in step
+    if fallback:
+        du._FAULT_INJECT = {"rank": world - 1, "stage": "selftest"}
     T, Nl, D, n_act = 12, 24, 4, 2
-    N = Nl * world
+    # "odd": a global env count the ranks do not divide (shard_range hands the remainder to the low ranks)
+    N = Nl * world + ((world - 1) if "odd" in sys.argv[1:] else 0)
     rs = np.random.RandomState(5)
     host = dict(policy_obs=rs.randn(T + 1, N, 1, D).astype(np.float32), rewards=rs.rand(T, N, 1, 1).astype(np.float32),
                 value_preds=(0.3 * rs.randn(T + 1, N, 1, 1)).astype(np.float32),
@@ -101,12 +111,17 @@ def main():
 
     # sharded run (all ranks)
     cfg = default_cfg(argv)
-    module, buf, algo = build(cfg, Nl, D, n_act, world, dev)
     lo, hi = du.shard_range(N, rank, world)
+    sizes = [du.shard_range(N, r, world) for r in range(world)]
+    assert sizes[0][0] == 0 and sizes[-1][1] == N and all(a[1] == b[0] for a, b in zip(sizes, sizes[1:]))
+    Nl = hi - lo
+    module, buf, algo = build(cfg, Nl, D, n_act, world, dev)
     buf.compute_returns(fill(buf, host, lo, hi, nv), module.get_critic_value_normalizer())
     assert algo.generic == generic
-    if not generic:
-        assert (algo._comm is not None) == (collective == "p2p"), "the fused orl_comm path must be the one that runs"
+    assert (algo._comm is not None) == (collective == "p2p" and not fallback), \
+        "the fused orl_comm path must be the one that runs (and must be off on every rank after a failed self-test)"
+    if fallback:
+        du._FAULT_INJECT = None
     info = algo.train(buf)
     torch.cuda.synchronize()
     if algo._comm is not None:
@@ -121,7 +136,11 @@ def main():
     a2.train(b2)
     torch.cuda.synchronize()
     # (general towers have one collective only: this second run then checks run-to-run determinism of the sharded update)
-    same_coll = all(torch.equal(module.models[k].theta, m2.models[k].theta) for k in ("policy", "critic"))
+    if world == 2 or fallback:  # a + b is commutative; beyond 2 ranks gloo's reduction order is not the rank order
+        same_coll = all(torch.equal(module.models[k].theta, m2.models[k].theta) for k in ("policy", "critic"))
+    else:
+        same_coll = all(torch.allclose(module.models[k].theta, m2.models[k].theta, rtol=1e-4, atol=2e-6)
+                        for k in ("policy", "critic"))
     flag = torch.tensor([1.0 if same_coll else 0.0])
     torch.distributed.all_reduce(flag)
     if rank == 0:

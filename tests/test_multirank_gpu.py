@@ -19,32 +19,46 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["mlp", "rnn", "gen", "genrnn"])
-def test_two_ranks_equal_one_rank_on_the_concatenated_batch(mode):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multirank_equiv.py"), mode]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    out = res.stdout + res.stderr
+def _run(args, timeout=900, env=None, nproc=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + args
+    e = dict(os.environ)
+    e.setdefault("OMP_NUM_THREADS", "1")
+    e.update(env or {})
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)
+    return res, res.stdout + res.stderr
+
+
+# (mode, ranks, extra): beyond 2 ranks the sum is no longer commutative-trivial - rank-ordered summation, the 8-source
+# inbox stride and shard_range remainders ("odd": 24 * G + G - 1 envs) are all live
+@pytest.mark.parametrize("mode,nproc,extra", [("mlp", 2, []), ("rnn", 2, []), ("gen", 2, []), ("genrnn", 2, []),
+                                              ("mlp", 3, ["odd"]), ("mlp", 4, []), ("mlp", 8, ["odd"]),
+                                              ("rnn", 4, ["odd"]), ("gen", 3, ["odd"]), ("genrnn", 4, [])])
+def test_ranks_equal_one_rank_on_the_concatenated_batch(mode, nproc, extra):
+    res, out = _run([os.path.join(ROOT, "tests", "multirank_equiv.py"), mode] + extra, nproc=nproc)
     assert "MULTIRANK_EQUIV_OK" in out, out[-3000:]
     assert "REPLICAS_IDENTICAL" in out, out[-3000:]
     assert "COLLECTIVES_BITWISE_EQUAL" in out, out[-3000:]
     assert res.returncode == 0, out[-3000:]
 
 
-def _run(args, timeout=600, env=None):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port())] + args
-    e = dict(os.environ)
-    e.update(env or {})
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)
-    return res, res.stdout + res.stderr
-
-
-def test_one_shot_p2p_allreduce_equals_torch_distributed_bitwise():
-    """orl_allreduce_small (hipIpc-mapped peer inboxes, 8-byte {value, sequence} granules, rank-ordered sum) vs
-    torch.distributed.all_reduce over 10 back-to-back collectives of sizes 1 .. 20 000 floats; 2 processes on cuda:0."""
-    res, out = _run([os.path.join(ROOT, "tests", "multirank_equiv.py"), "comm"])
+@pytest.mark.parametrize("nproc", [2, 4, 8])
+def test_one_shot_p2p_allreduce_is_the_rank_ordered_sum_bitwise(nproc):
+    """orl_allreduce_small (hipIpc-mapped peer inboxes, 8-byte {value, sequence} granules, rank-ordered sum) vs an
+    all_gather + explicit rank-order fp32 sum over 10 back-to-back collectives of sizes 1 .. 20 000 floats; 2 / 4 / 8
+    processes on cuda:0."""
+    res, out = _run([os.path.join(ROOT, "tests", "multirank_equiv.py"), "comm"], nproc=nproc)
     assert "COMM_OK" in out, out[-3000:]
+    assert res.returncode == 0, out[-3000:]
+
+
+def test_every_rank_falls_back_when_one_ranks_comm_self_test_fails():
+    """A failure injected into the LAST rank's orl_comm self-test: every rank must decide to fall back to
+    torch.distributed all-reduces (no rank left behind in a different collective), and the update must still equal
+    the single-process one."""
+    res, out = _run([os.path.join(ROOT, "tests", "multirank_equiv.py"), "mlp", "fallback"], nproc=3)
+    assert "MULTIRANK_EQUIV_OK" in out and "REPLICAS_IDENTICAL" in out, out[-3000:]
+    assert "falls back to torch.distributed" in out, out[-3000:]
     assert res.returncode == 0, out[-3000:]
 
 
@@ -55,10 +69,35 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu():
 
     res, out = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                      "--no-cpu-baseline"], env={"ORL_DIST_BACKEND": "gloo"})
+    _check_bench_line(res, out, 2)
+
+
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_bench_launches_its_own_ranks(gpus):
+    """``python bench.py --gpus N`` with NO outer torchrun must spawn N ranks itself and report n_gpus == N (round 2's
+    bench silently ran one rank this way); the ranks share cuda:0 here, rendezvous over gloo."""
+    e = dict(os.environ)
+    e["ORL_DIST_BACKEND"] = "gloo"
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup",
+                          "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=e)
+    _check_bench_line(res, res.stdout + res.stderr, gpus)
+
+
+def test_bench_refuses_a_group_that_does_not_match_gpus():
+    res, out = _run([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                    env={"ORL_DIST_BACKEND": "gloo"})
+    assert res.returncode != 0 and "--gpus 1 but the process group has 2" in out, out[-2000:]
+
+
+def _check_bench_line(res, out, gpus):
+    import json
+
     assert res.returncode == 0, out[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong"
-    assert rec["config"]["global_envs"] == 4096 and rec["config"]["envs_per_gpu"] == 2048
+    assert rec["n_gpus"] == gpus and rec["scaling"] == "strong"
+    assert rec["config"]["global_envs"] == 4096 and rec["config"]["envs_per_gpu"] == 4096 // gpus
     assert rec["config"]["collective"].startswith("orl_comm")
     assert rec["value"] > 0 and rec["roofline"]["frac"] > 0

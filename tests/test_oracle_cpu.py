@@ -210,3 +210,42 @@ def test_multidiscrete_actlayer_oracle_matches_the_reference():
     a, lp = go.multidiscrete_mode(t(g["x"]), [w.detach() for w in Ws], [b.detach() for b in bs])
     assert np.array_equal(a.numpy(), g["det_actions"])
     np.testing.assert_allclose(lp.numpy(), g["det_logp"], rtol=1e-6, atol=1e-6)
+
+
+def _oracle_full_general(name):
+    """Replay a ``train_cfg{3,5}_full`` golden (feed-forward, full BASELINE size) with the oracle restatement."""
+    from oracle.fixtures import synth_update_buffer_general
+
+    g = H.load_golden(name)
+    N, T, Dp, Dc, n_act, A, seed, legal, rec = (int(x) for x in g["shape"])
+    kind = str(g["kind"])
+    assert not rec and Dp == Dc
+    cfg = H.case_cfg(g)
+    hp = po.hyper_from_cfg(cfg)
+    buf = synth_update_buffer_general(seed, N, T, Dp, Dc, kind, n_act, A, bool(legal), 0)
+    vn = po.ValueNormOracle()
+    nv = buf.pop("next_value")
+    buf["returns"], buf["value_preds"] = po.compute_returns(buf["rewards"], buf["value_preds"], buf["masks"],
+                                                            buf["bad_masks"], nv, cfg.gamma, cfg.gae_lambda,
+                                                            value_normalizer=vn)
+    buf.setdefault("action_masks", None)
+    probe = np.array([buf["returns"][t, n, a, 0] for t, n, a in g["returns_probe_idx"]])
+    np.testing.assert_array_equal(probe, g["returns_probe"])
+    pspec = po.TowerSpec(Dp, n_act, po.HEAD_CATEGORICAL if kind == "discrete" else po.HEAD_GAUSSIAN)
+    cspec = po.TowerSpec(Dc, 1, po.HEAD_VALUE)
+    ptheta, ctheta = torch.tensor(g["theta_p0"]).clone(), torch.tensor(g["theta_c0"]).clone()
+    padam = po.AdamOracle(ptheta.numel(), cfg.lr, cfg.opti_eps, cfg.weight_decay)
+    cadam = po.AdamOracle(ctheta.numel(), cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)
+    torch.manual_seed(int(g["perm_seed"]))
+    info, _, _ = po.train_ppo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, buf, cfg.ppo_epoch, cfg.num_mini_batch)
+    keys = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
+    np.testing.assert_allclose([info[k] for k in keys], g["train_info"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(ptheta.numpy(), g["theta_p1"], rtol=3e-4, atol=3e-6)
+    np.testing.assert_allclose(ctheta.numpy(), g["theta_c1"], rtol=3e-4, atol=3e-6)
+    np.testing.assert_allclose(vn.state(), g["vn_state1"], rtol=1e-5)
+
+
+def test_oracle_replays_the_full_size_cfg3_reference_update():
+    """BASELINE.json configs[2] at full size (1024 x 200 rows, obs 17, Box(6), 10 epochs): the oracle restatement lands on
+    the REAL reference's outputs (per-dimension Gaussian log-probs, FixedNormal.log_probs) - ~10 s of torch CPU."""
+    _oracle_full_general("train_cfg3_full")

@@ -307,3 +307,77 @@ def test_single_update_at_baseline_shapes_vs_oracle(D, kind, n_act, N, T, masks)
     want = np.array([info_o[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
                                          "critic_grad_norm", "ratio")])
     np.testing.assert_allclose(algo._info[:6].cpu().numpy(), want, rtol=3e-4, atol=3e-5)
+
+
+def _full_general_engine(g, perm_mode):
+    """Engine + buffer of a ``train_cfg{3,4,5}_full`` case (inputs regenerated from the seed, oracle/fixtures.py);
+    ``compute_returns`` has run and its probes were checked against the reference's."""
+    from openrl_amd import spaces
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers.replay_data import ReplayData
+    from openrl_amd.modules.ppo_module import PPOModule
+    from oracle.fixtures import synth_update_buffer_general
+
+    N, T, Dp, Dc, n_act, A, seed, legal, recurrent = (int(x) for x in g["shape"])
+    kind = str(g["kind"])
+    cfg = H.case_cfg(g)
+    cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = T, N, A, cfg.hidden_size
+    box = lambda d: spaces.Box(-np.inf, np.inf, (d,))
+    obs_space = box(Dp) if Dp == Dc else spaces.Dict({"policy": box(Dp), "critic": box(Dc)})
+    act_space = spaces.Discrete(n_act) if kind == "discrete" else spaces.Box(-1, 1, (n_act,))
+    torch.manual_seed(0)
+    module = PPOModule(cfg, obs_space, obs_space, act_space, device=DEV, rank=0, world_size=1)
+    module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+    module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+    buf = ReplayData(cfg, A, obs_space, act_space, device=DEV)
+    src = synth_update_buffer_general(seed, N, T, Dp, Dc, kind, n_act, A, bool(legal), cfg.hidden_size if recurrent else 0)
+    for f in ("policy_obs", "critic_obs", "rewards", "value_preds", "masks", "active_masks", "bad_masks", "actions",
+              "action_log_probs", "action_masks", "rnn_states", "rnn_states_critic"):
+        if f in src and getattr(buf, f, None) is not None and (f != "critic_obs" or Dp != Dc):
+            getattr(buf, f).copy_(torch.tensor(src[f]))
+    buf.compute_returns(torch.tensor(src["next_value"]), module.get_critic_value_normalizer())
+    ret = buf.returns.cpu().numpy()
+    probe = np.array([ret[t, n, a, 0] for t, n, a in g["returns_probe_idx"]])
+    np.testing.assert_allclose(probe, g["returns_probe"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ret[:-1].astype(np.float64).sum(), float(g["returns_sum"]), rtol=1e-6)
+    algo = PPOAlgorithm(cfg, module, agent_num=A, device=DEV)
+    algo.perm_mode = perm_mode
+    return cfg, module, buf, algo
+
+
+@pytest.mark.parametrize("perm_mode", ["device", "identity", "reference"])
+@pytest.mark.parametrize("case,branch", [("train_cfg3_full", "uneven_split"), ("train_cfg5_full", "back_to_back")])
+def test_full_size_update_other_baseline_shapes_match_reference_golden(case, branch, perm_mode):
+    """BASELINE.json configs[2] (1024 x 200 rows, obs 17, Box(6)) and configs[4] (4096 x 200, obs 18, Discrete(9) with
+    random legal-move masks) at FULL size against the REAL reference's ``compute_returns`` + ``PPOAlgorithm.train``
+    (10 epochs; oracle/gen_golden.py::_train_case_full_general).  These are the batches where ``launch_pair_nd``
+    (csrc/orl_ppo.hip) leaves its small-batch route: 12 800 tiles -> the UNEVEN side-by-side CU split of a wide head,
+    51 200 tiles -> policy and critic workgroups BACK TO BACK; the test asserts from the workgroup counts the launch
+    reports that the branch was really taken, with the wide-observation (ND = 1) pair kernel builds several tiles deep
+    per wave."""
+    from openrl_amd import ops
+
+    g = H.load_golden(case)
+    cfg, module, buf, algo = _full_general_engine(g, perm_mode)
+    grids, orig = [], ops.ppo_fwd_bwd
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        grids.append(r)
+        return r
+
+    ops.ppo_fwd_bwd = spy
+    try:
+        torch.manual_seed(int(g["perm_seed"]))
+        algo.prep_training()
+        info = algo.train(buf)
+    finally:
+        ops.ppo_fwd_bwd = orig
+    mb = ops.ppo_max_blocks()
+    assert len(grids) == cfg.ppo_epoch
+    for gp, gc in grids:
+        if branch == "uneven_split":
+            assert gp + gc == mb and gp > gc, (gp, gc)
+        else:
+            assert gp == mb and gc == mb, (gp, gc)
+    _assert_golden_outputs(g, module, info)

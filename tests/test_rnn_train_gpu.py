@@ -386,3 +386,24 @@ def test_shared_recurrent_network_matches_reference_golden():
         np.testing.assert_allclose(v.cpu().numpy().reshape(N, A, 1), g["buf_value_preds"][t], rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(buf.rnn_states.cpu().numpy(), g["buf_rnn_states"], rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(buf.rnn_states_critic.cpu().numpy(), g["buf_rnn_states_critic"], rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("perm_mode", ["device", "identity", "reference"])
+def test_full_size_recurrent_update_matches_reference_golden(perm_mode):
+    """BASELINE.json configs[3] at FULL size: 2048 envs x 3 agents x 25 steps = 153 600 rows = 76 800 chunks of 2 (the
+    odd T makes chunks straddle lanes), Dict obs 18 / 54, Discrete(5), GRU, adv-normalise on (examples/mpe/mpe_ppo.yaml),
+    3 epochs through the REAL reference's ``recurrent_generator`` + ``PPOAlgorithm.train`` (oracle/gen_golden.py::
+    _train_case_full_general; reference buffers/replay_data.py:1062-1258, algorithms/ppo.py:383-458).  This is the
+    batch of benchmarks/cfg4_mpe_bench.py: several chunks per wave with a ragged last round."""
+    from tests.test_ppo_update_gpu import _full_general_engine
+
+    g = H.load_golden("train_cfg4_full")
+    cfg, module, buf, algo = _full_general_engine(g, perm_mode)
+    assert algo.recurrent and not algo.generic
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    info = algo.train(buf)
+    np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
+    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
