@@ -28,13 +28,107 @@ constexpr int TILE_B = 16; // batch rows per wave tile
 
 #define ORL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// ---- three-term bf16 splitting (tools/split_bf16_gemm.hip) ----------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (32 cycles per 2 048 flop) and blocks the SIMD's VALU while it
+// does; v_mfma_f32_16x16x32_bf16 retires 16 384 flop in 16 cycles and overlaps VALU.  An fp32 number is EXACTLY
+// hi + mid + lo with three bf16 terms when each term truncates the running remainder (8 + 8 + 8 significand bits), so
+// a.b is the sum of 9 bf16 products; the 6 largest leave an error of about one fp32 rounding of the product (measured
+// on N(0,1) operands over K = 64: rms 8.9e-7 against 1.17e-6 for the fp32 MFMA itself, profiles/r03_split_bf16_gemm.txt).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WBS = 72;                            // bf16 image row stride (elements): 144-byte rows, bank-skewed
+constexpr int WB_IMG_FLOATS = 3 * HID * WBS / 2;   // three parts x 64 rows, in floats (6 912)
+
+__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
+// one dword = {bf16 truncation of a (low half), of b (high half)}: v_perm_b32 picks the two upper halves
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) { return __builtin_amdgcn_perm(f2u(b), f2u(a), 0x07060302u); }
+
+// 8 fp32 values -> three bf16x8 MFMA fragments (hi, mid, lo); x = hi + mid + lo exactly.  11 VALU per 2 values.
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = x[2 * p], b = x[2 * p + 1];
+    hi[p] = pack_hi16(a, b);
+    const float ra = a - u2f(f2u(a) & 0xffff0000u), rb = b - u2f(f2u(b) & 0xffff0000u);
+    mid[p] = pack_hi16(ra, rb);
+    const float sa = ra - u2f(f2u(ra) & 0xffff0000u), sb = rb - u2f(f2u(rb) & 0xffff0000u);
+    lo[p] = pack_hi16(sa, sb);
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16_16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_bf16_32(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// bf16 weight image of a 64 x 64 matrix A (rows = MFMA M index, 64 reduction indices k): part p (0 hi, 1 mid, 2 lo),
+// row o; the 64 k's of a row are stored as [K-step h][lane group q][slot s] with k = 16 (2h + s/4) + 4q + s%4 - the
+// order in which a T-layout activation tile (lane (j, q) holds k = 16m + 4q + r) fills the 8 slots of its B fragment,
+// so the A fragment of lane (j, q) for (row block mo, step h) is ONE 16-byte read.
+__device__ __forceinline__ int wb_off(int p, int o, int h, int q) { return (p * HID + o) * WBS + h * 32 + q * 8; }
+
+// store element A[o][k] = w into the three images at `img`
+__device__ __forceinline__ void split_weight_store(unsigned short* __restrict__ img, int o, int k, float w) {
+  const int m = k >> 4, q = (k >> 2) & 3, r = k & 3, h = m >> 1, sl = (m & 1) * 4 + r;
+  const float h1 = u2f(f2u(w) & 0xffff0000u), r1 = w - h1;
+  const float m1 = u2f(f2u(r1) & 0xffff0000u), l1 = r1 - m1;
+  img[wb_off(0, o, h, q) + sl] = (unsigned short)(f2u(h1) >> 16);
+  img[wb_off(1, o, h, q) + sl] = (unsigned short)(f2u(m1) >> 16);
+  img[wb_off(2, o, h, q) + sl] = (unsigned short)(f2u(l1) >> 16);
+}
+
+// the B fragments of a T-layout activation tile: xs[h][part]
+__device__ __forceinline__ void split_T(const f32x4 (&in)[4], u32x4 (&xs)[2][3]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float x[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x[r] = in[2 * h][r]; x[4 + r] = in[2 * h + 1][r]; }
+    split8(x, xs[h][0], xs[h][1], xs[h][2]);
+  }
+}
+
+// acc += A in (both T layout), A = the bf16 images at Wb: 48 bf16 MFMAs (6 products x 4 row blocks x 2 K-steps),
+// 24 ds_read_b128.  Products are issued smallest first.
+__device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][3],
+                                             f32x4 (&acc)[4], int j, int q) {
+  u32x4 w[2][3];  // A fragments double-buffered over the 8 (h, mo) steps
+#pragma unroll
+  for (int p = 0; p < 3; ++p) w[0][p] = *(const u32x4*)(Wb + wb_off(p, j, 0, q));
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int h = st >> 2, mo = st & 3;
+    if (st < 7) {
+      const int h2 = (st + 1) >> 2, mo2 = (st + 1) & 3;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) w[(st + 1) & 1][p] = *(const u32x4*)(Wb + wb_off(p, 16 * mo2 + j, h2, q));
+    }
+    const u32x4 wh = w[st & 1][0], wm = w[st & 1][1], wl = w[st & 1][2];
+    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
+    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
+  }
+}
+
 // LDS image of one tower (offsets in floats, all multiples of 4 => 16-byte aligned).
 struct TowerLds {
   int DP, n_out, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, logstd, W2T, W3P, total;
   __host__ __device__ TowerLds() {}
   // with_w3p: a second image of W3, zero padded to 16 rows at the conflict-free stride W2S - the MFMA operand of the
   // head GEMMs of wide heads (orl_ppo_tower.h, NO > 4)
-  __host__ __device__ TowerLds(int D, int n_out_, bool gaussian, bool with_w2t, bool with_w3p = false) {
+  // split: W2 (and W2T) are the three-term bf16 images of split_weight_store (mm64_T_split's A operands) instead of
+  // fp32 rows - the update towers' SPLIT builds (orl_ppo_tower.h)
+  __host__ __device__ TowerLds(int D, int n_out_, bool gaussian, bool with_w2t, bool with_w3p = false,
+                               bool split = false) {
+    const int w2_floats = split ? WB_IMG_FLOATS : HID * W2S;
     DP = (D + 3) & ~3;
     n_out = n_out_;
     const int no4 = (n_out + 3) & ~3;
@@ -43,14 +137,14 @@ struct TowerLds {
     b1 = o; o += HID;
     g1 = o; o += HID;
     be1 = o; o += HID;
-    W2 = o; o += HID * W2S;
+    W2 = o; o += w2_floats;
     b2 = o; o += HID;
     g2 = o; o += HID;
     be2 = o; o += HID;
     W3 = o; o += with_w3p ? 0 : no4 * HID;  // wide heads read the padded image W3P only
     b3 = o; o += no4;
     logstd = o; o += gaussian ? no4 : 0;
-    W2T = o; o += with_w2t ? HID * W2S : 0;
+    W2T = o; o += with_w2t ? w2_floats : 0;
     W3P = o; o += with_w3p ? 16 * W2S : 0;
     total = o;
   }
@@ -59,7 +153,8 @@ struct TowerLds {
 // Cooperative global -> LDS staging of a tower (any thread count).  W1 is zero padded to DP
 // columns, W2 re-strided to W2S, optionally also stored transposed (for the backward GEMM).
 __device__ inline void stage_tower(float* __restrict__ lds, const float* __restrict__ theta, const TowerLayout& tl,
-                                   const TowerLds& tw, bool with_w2t, int tid, int nthreads, bool with_w3p = false) {
+                                   const TowerLds& tw, bool with_w2t, int tid, int nthreads, bool with_w3p = false,
+                                   bool split = false) {
   if (with_w3p) {
     for (int e = tid; e < 16 * W2S; e += nthreads) {
       const int c = e / W2S, i = e - c * W2S;
@@ -79,6 +174,16 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
     lds[tw.g2 + e] = theta[tl.og2 + e];
     lds[tw.be2 + e] = theta[tl.obe2 + e];
   }
+  if (split) {  // bf16 images: fc2's A = W2 (rows o, reduction over i), dgrad's A = W2^T (rows i, reduction over o)
+    unsigned short* b2 = (unsigned short*)(lds + tw.W2);
+    unsigned short* b2t = (unsigned short*)(lds + tw.W2T);
+    for (int e = tid; e < HID * HID; e += nthreads) {
+      const int o = e >> 6, i = e & 63;
+      const float w = theta[tl.oW2 + e];
+      split_weight_store(b2, o, i, w);
+      if (with_w2t) split_weight_store(b2t, i, o, w);
+    }
+  } else
   for (int e = tid; e < HID * HID; e += nthreads) {
     const int o = e >> 6, i = e & 63;
     const float w = theta[tl.oW2 + e];

@@ -7,6 +7,11 @@
 #include "orl_mlp.h"
 #include "orl_ppo_tower.h"
 
+// build-time A/B switch (ORL_BUILD_DEFS="-DORL_TOWER_FIRST_VARIANT=1" = never the split build); never read at run time
+#ifndef ORL_TOWER_FIRST_VARIANT
+#define ORL_TOWER_FIRST_VARIANT 0
+#endif
+
 namespace orl {
 
 static int check_tower(const orl_net_desc* n, const char* who) {
@@ -62,9 +67,14 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
 template <int HEADP, int NOP_, int ND>
 static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int* gc_out, hipStream_t s) {
   constexpr int NOPP = NOP_ > 4 ? 16 : ((NOP_ + 3) & ~3);
-  for (int w2t = 1; w2t >= (ND == 0 ? 1 : 0); --w2t) {  // same LDS policy as launch_tower: W2^T goes before a pair of waves
-    const size_t lp = tower_lds_floats(P.net, P.R, NOPP, 8, HEADP == ORL_HEAD_GAUSSIAN, w2t != 0) * sizeof(float);
-    const size_t lc = tower_lds_floats(Cc.net, Cc.R, 4, 8, false, w2t != 0) * sizeof(float);
+  // variants in order of preference: the split build (bf16 MFMAs over three-term splits; needs both bf16 images of W2 in
+  // LDS), then fp32 MFMA with and without the W2^T copy (same LDS policy as launch_tower: W2^T goes before a pair of waves)
+  for (int var = ORL_TOWER_FIRST_VARIANT; var < 3; ++var) {
+    const bool sp = var == 0;
+    const int w2t = var <= 1;
+    if (var == 2 && ND == 0) break;
+    const size_t lp = tower_lds_floats(P.net, P.R, NOPP, 8, HEADP == ORL_HEAD_GAUSSIAN, w2t != 0, sp) * sizeof(float);
+    const size_t lc = tower_lds_floats(Cc.net, Cc.R, 4, 8, false, w2t != 0, sp) * sizeof(float);
     const size_t lds = lp > lc ? lp : lc;
     if (lds > 160 * 1024) continue;
     PpoArgs P2 = P, C2 = Cc;
@@ -101,9 +111,15 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
       gp = best_g;
       gc = PPO_MAX_BLOCKS - best_g;
     }
-    (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND>), dim3(gp + gc), dim3(512), lds, s, P2, C2, gp);
+    if (sp) {
+      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, true>), dim3(gp + gc), dim3(512), lds, s, P2, C2, gp);
+    } else {
+      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, false>), dim3(gp + gc), dim3(512), lds, s, P2, C2, gp);
+    }
     const int rc = launch_status("orl_ppo_fwd_bwd(pair)");
     if (rc) return -1000 - rc;
     *gp_out = gp; *gc_out = gc;

@@ -131,7 +131,10 @@ __device__ inline void mm64_T_wt(const float* __restrict__ Ws, const f32x4 (&in)
 
 // HEAD: ORL_HEAD_VALUE / _CATEGORICAL / _GAUSSIAN; NO: padded head width; ND: ceil(D/16) for the MFMA
 // dW1 path, 0 = VALU path (D <= 4, 16-byte aligned obs column).
-template <int HEAD, int NO, int ND>
+// SP: the three 64-wide GEMMs of a tile (fc2, dgrad, wgrad) on bf16 MFMAs over three-term splits of their fp32 operands
+// (orl_mlp.h) instead of v_mfma_f32_16x16x4_f32; needs the W2^T image.  fc1, the wide-head GEMMs and the MFMA dW1 path
+// stay on the fp32 MFMA (a few instructions per tile).
+template <int HEAD, int NO, int ND, bool SP = false>
 __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const TowerLayout tl(A.net);
@@ -141,8 +144,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // wide heads (NO > 4: Discrete(5..16), Box(5..16)) run their three head GEMMs - logits, dn2 = W3^T dhead,
   // S3 += dhead^T xhat2 - on MFMA; with NO x 64 scalar FMAs per lane they were 2/3 of the tile and spilled 360 VGPRs
   constexpr bool HMM = NO > 4;
-  const bool w2t = ND == 0 || A.use_w2t;  // compile-time true on the small-observation path
-  const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, w2t, HMM);
+  const bool w2t = ND == 0 || SP || A.use_w2t;  // compile-time true on the small-observation path and in split builds
+  const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, w2t, HMM, SP);
   const int DP = tw.DP;
   const int D = A.net.obs_dim;
   const int n_out = A.net.n_out;
@@ -168,6 +171,16 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // split builds: G as 2 x 2 blocks of the 32x32x16 bf16 MFMA (rows o = 32 bo + .., columns i = 32 bi + ..), and db2 as
+  // per-lane partial column sums of the wgrad's own operand reads (lane (c, kb): column 32 bo + c over rows 8kb .. 8kb+7)
+  f32x16 GS[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) GS[a][b][r] = 0.f;
+  float a_db2s[2] = {0.f, 0.f};
   constexpr int NDA = ND > 0 ? ND : 1;
   f32x4 G1[4][NDA];
 #pragma unroll
@@ -236,7 +249,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // the tower image is staged AFTER the first tile's index loads and record DMA are in flight (their latency chain -
   // index -> record rows -> LDS - overlaps the parameter loads instead of following them); the record ring and the
   // image are disjoint LDS regions
-  stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM);
+  stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM, SP);
   __syncthreads();
 
 #ifdef ORL_PROF
@@ -286,7 +299,13 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       load_vec_T(lw + tw.b2, q, xh2);
       ORL_T(1);  // fc1, relu, LN1, slab store, affine
       ORL_PRIO(1);
-      mm64_T(lw + tw.W2, n1, xh2, j, q);
+      if constexpr (SP) {
+        u32x4 xs[2][3];
+        split_T(n1, xs);
+        mm64_T_split((const unsigned short*)(lw + tw.W2), xs, xh2, j, q);
+      } else {
+        mm64_T(lw + tw.W2, n1, xh2, j, q);
+      }
       ORL_PRIO(0);
       ORL_T(2);  // fc2: 64 MFMA
       ln_normalize_T(xh2, rstd2);
@@ -630,6 +649,38 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     store_slab_T(SS, d2, j, q);
     wave_lds_fence();
     ORL_T(6);  // dn2, LN2 backward, dz2 slab store
+    if constexpr (SP) {
+      // wgrad on the 32x32x16 bf16 MFMA (K = the tile's 16 rows): lane (c = l & 31, kb = l >> 5) reads rows 8kb..8kb+7 of
+      // columns 32b + c of both slabs (32 conflict-free 4-byte reads, as many as the fp32 path), splits them in
+      // registers and issues 6 products x 4 blocks = 24 MFMAs.  db2 falls out of the same reads.
+      const int c = l & 31, kb = l >> 5;
+      u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float xa[8], xb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          xa[k] = SS[(8 * kb + k) * TS + 32 * b + c];
+          xb[k] = X1[(8 * kb + k) * TS + 32 * b + c];
+        }
+        a_db2s[b] += ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
+        split8(xa, fa[b][0], fa[b][1], fa[b][2]);
+        split8(xb, fb[b][0], fb[b][1], fb[b][2]);
+      }
+#pragma unroll
+      for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) {
+          f32x16 g = GS[bo][bi];
+          g = mfma_bf16_32(fa[bo][2], fb[bi][0], g);
+          g = mfma_bf16_32(fa[bo][0], fb[bi][2], g);
+          g = mfma_bf16_32(fa[bo][1], fb[bi][1], g);
+          g = mfma_bf16_32(fa[bo][1], fb[bi][0], g);
+          g = mfma_bf16_32(fa[bo][0], fb[bi][1], g);
+          g = mfma_bf16_32(fa[bo][0], fb[bi][0], g);
+          GS[bo][bi] = g;
+        }
+    } else
     {
       // wgrad: G += dz2^T xhat1 (operands straight from the slabs in F layout), db2.  Issued as a burst of its own:
       // an fp32 MFMA blocks the issuing wave's VALU for its whole 32 cycles on gfx950 (tools/mfma_valu_overlap.hip),
@@ -669,8 +720,14 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     // dgrad A operand: a transposed copy of W2 in LDS read by 16-byte rows (16 reads per 64 MFMA); reading W2 by
     // columns (64 four-byte reads, one per MFMA) made this the slowest phase of the tile: 5 100 vs 3 100 cycles
-    if (w2t) mm64_T(lw + tw.W2T, d2, d1, j, q);
-    else mm64_T_wt(lw + tw.W2, d2, d1, j, q);
+    if constexpr (SP) {
+      u32x4 xs[2][3];
+      split_T(d2, xs);
+      mm64_T_split((const unsigned short*)(lw + tw.W2T), xs, d1, j, q);
+    } else {
+      if (w2t) mm64_T(lw + tw.W2T, d2, d1, j, q);
+      else mm64_T_wt(lw + tw.W2, d2, d1, j, q);
+    }
     ORL_T(8);  // dgrad: 64 MFMA
     {
       f32x4 xh1[4];
@@ -766,15 +823,31 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     if (wave / NREG == p) {
       const bool first = p == 0;
       auto put = [&](int idx, float v) { acc[idx] = first ? v : acc[idx] + v; };
-      // G tiles: lane (c = j, q), reg r -> G[o = 16mo+4q+r][i = 16mi+c]
-#pragma unroll
-      for (int mo = 0; mo < 4; ++mo)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) put(rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j, G[mo][mi][r]);
       const int f = l;
-      put(rl.odb2 + f, a_db2);
+      if constexpr (SP) {
+        // 32x32 C fragment: lane (c = l & 31, kb = l >> 5), reg r -> G[o = 32bo + (r&3) + 8(r>>2) + 4kb][i = 32bi + c]
+#pragma unroll
+        for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              put(rl.oG + (32 * bo + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * HID + 32 * bi + (l & 31), GS[bo][bi][r]);
+        const float d0 = a_db2s[0] + __shfl_xor(a_db2s[0], 32), d1s = a_db2s[1] + __shfl_xor(a_db2s[1], 32);
+        if (l < 32) {
+          put(rl.odb2 + l, d0);
+          put(rl.odb2 + 32 + l, d1s);
+        }
+      } else {
+        // G tiles: lane (c = j, q), reg r -> G[o = 16mo+4q+r][i = 16mi+c]
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) put(rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j, G[mo][mi][r]);
+        put(rl.odb2 + f, a_db2);
+      }
       put(rl.odb1 + f, a_db1);
       if constexpr (HMM) {
 #pragma unroll
@@ -836,15 +909,16 @@ __global__ __launch_bounds__(512, 2) void ppo_tower_kernel(PpoArgs A) {
 // Both towers of one minibatch in ONE launch (the default 8-wave build): workgroups [0, gp) are the policy tower,
 // the rest the critic tower.  No kernel boundary between the two: critic workgroups start on a CU as soon as its
 // policy workgroup retires instead of waiting for the slowest policy workgroup of the whole chip.
-template <int HEADP, int NOP_, int ND>
+template <int HEADP, int NOP_, int ND, bool SP = false>
 __global__ __launch_bounds__(512, 2) void ppo_tower_pair_kernel(PpoArgs P, PpoArgs Cc, int gp) {
-  if ((int)blockIdx.x < gp) ppo_tower_body<HEADP, NOP_, ND>(P, (int)blockIdx.x, gp);
-  else ppo_tower_body<ORL_HEAD_VALUE, 1, ND>(Cc, (int)blockIdx.x - gp, (int)gridDim.x - gp);
+  if ((int)blockIdx.x < gp) ppo_tower_body<HEADP, NOP_, ND, SP>(P, (int)blockIdx.x, gp);
+  else ppo_tower_body<ORL_HEAD_VALUE, 1, ND, SP>(Cc, (int)blockIdx.x - gp, (int)gridDim.x - gp);
 }
 
 // LDS bytes needed by `waves` waves of this tower
-inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian, bool w2t = true) {
-  const TowerLds tw(net.obs_dim, net.n_out, gaussian, w2t, nop == 16);
+inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian, bool w2t = true,
+                               bool split = false) {
+  const TowerLds tw(net.obs_dim, net.n_out, gaussian, w2t, nop == 16, split);
   const RawLayout rl(net);
   const int rts = net.obs_dim <= 4 ? (((R >> 2) + 3) >> 2) * 256 : (R >> 2) * 64;  // >= what the kernel uses
   const size_t per_wave = 2 * SLAB + 2 * rts + TILE_B * nop;
