@@ -154,11 +154,16 @@ struct TowerLds {
 // columns, W2 re-strided to W2S, optionally also stored transposed (for the backward GEMM).
 __device__ inline void stage_tower(float* __restrict__ lds, const float* __restrict__ theta, const TowerLayout& tl,
                                    const TowerLds& tw, bool with_w2t, int tid, int nthreads, bool with_w3p = false,
-                                   bool split = false) {
+                                   bool split = false, bool fold = false) {
+  // fold (the update towers): the LayerNorm affines are folded into the next Linear - exact algebra,
+  //   W2 (xhat1 * g1 + be1) + b2 = (W2 diag(g1)) xhat1 + (b2 + W2 be1),   W3 (xhat2 * g2 + be2) + b3 likewise,
+  // so a tile's forward feeds xhat straight into the GEMMs and its backward gets d xhat = (W diag(g))^T d out from the
+  // same images: no per-tile reads of g / be, no affine or d*g passes.  The images of W2, W2^T, W3 hold W diag(g), the
+  // b2 / b3 slots hold the folded biases; the raw gradient sums (G = dz2^T xhat1, ...) are unchanged.
   if (with_w3p) {
     for (int e = tid; e < 16 * W2S; e += nthreads) {
       const int c = e / W2S, i = e - c * W2S;
-      lds[tw.W3P + e] = (c < tl.n_out && i < HID) ? theta[tl.oW3 + c * HID + i] : 0.f;
+      lds[tw.W3P + e] = (c < tl.n_out && i < HID) ? theta[tl.oW3 + c * HID + i] * (fold ? theta[tl.og2 + i] : 1.f) : 0.f;
     }
   }
   const int D = tl.D;
@@ -179,23 +184,46 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
     unsigned short* b2t = (unsigned short*)(lds + tw.W2T);
     for (int e = tid; e < HID * HID; e += nthreads) {
       const int o = e >> 6, i = e & 63;
-      const float w = theta[tl.oW2 + e];
+      const float w = theta[tl.oW2 + e] * (fold ? theta[tl.og1 + i] : 1.f);
       split_weight_store(b2, o, i, w);
       if (with_w2t) split_weight_store(b2t, i, o, w);
     }
   } else
   for (int e = tid; e < HID * HID; e += nthreads) {
     const int o = e >> 6, i = e & 63;
-    const float w = theta[tl.oW2 + e];
+    const float w = theta[tl.oW2 + e] * (fold ? theta[tl.og1 + i] : 1.f);
     lds[tw.W2 + o * W2S + i] = w;
     if (with_w2t) lds[tw.W2T + i * W2S + o] = w;
   }
   const int no4 = (tl.n_out + 3) & ~3;
   if (!with_w3p)
-    for (int e = tid; e < no4 * HID; e += nthreads) lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] : 0.f;
+    for (int e = tid; e < no4 * HID; e += nthreads)
+      lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] * (fold ? theta[tl.og2 + (e & 63)] : 1.f) : 0.f;
   for (int e = tid; e < no4; e += nthreads) {
     lds[tw.b3 + e] = (e < tl.n_out) ? theta[tl.ob3 + e] : 0.f;
     if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = (e < tl.n_out) ? theta[tl.ologstd + e] : 0.f;
+  }
+  if (fold) {
+    // folded biases: 8 threads per output (aligned groups of 8 lanes), each sums 8 terms, xor-shuffle over the group.
+    // Every lane of a wave runs the same number of rounds (the shuffles are wave-wide).
+    const int rows = HID + tl.n_out;  // b2' rows, then b3' rows
+    for (int e0 = 0; e0 < rows * 8; e0 += nthreads) {
+      const int e = e0 + tid, o = e >> 3, part = e & 7;
+      float acc = 0.f;
+      if (o < rows) {
+        const float* wrow = o < HID ? theta + tl.oW2 + o * HID : theta + tl.oW3 + (o - HID) * HID;
+        const float* be = theta + (o < HID ? tl.obe1 : tl.obe2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += wrow[8 * part + k] * be[8 * part + k];
+      }
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 4);
+      if (o < rows && part == 0) {
+        if (o < HID) lds[tw.b2 + o] = theta[tl.ob2 + o] + acc;
+        else lds[tw.b3 + (o - HID)] = theta[tl.ob3 + (o - HID)] + acc;
+      }
+    }
   }
 }
 

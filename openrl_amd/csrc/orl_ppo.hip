@@ -11,6 +11,9 @@
 #ifndef ORL_TOWER_FIRST_VARIANT
 #define ORL_TOWER_FIRST_VARIANT 0
 #endif
+#ifndef ORL_PAIR_WAVES  // build-time experiment: waves per workgroup of the pair launch (8 = two per SIMD)
+#define ORL_PAIR_WAVES 8
+#endif
 
 namespace orl {
 
@@ -114,11 +117,11 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
     if (sp) {
       (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, true>), dim3(gp + gc), dim3(512), lds, s, P2, C2, gp);
+      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, true>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
     } else {
       (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, false>), dim3(gp + gc), dim3(512), lds, s, P2, C2, gp);
+      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, false>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
     }
     const int rc = launch_status("orl_ppo_fwd_bwd(pair)");
     if (rc) return -1000 - rc;

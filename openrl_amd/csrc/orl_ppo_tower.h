@@ -89,14 +89,12 @@ __device__ inline void load_slab_T(const float* __restrict__ slab, f32x4 (&x)[4]
   for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(slab + j * TS + 16 * m + 4 * q);
 }
 
-// LayerNorm backward in T layout, in place: d <- rstd * (d*g - mean(d*g) - xhat * mean(d*g*xhat))
-__device__ inline void ln_bwd_T(f32x4 (&d)[4], const f32x4 (&xhat)[4], const float* __restrict__ g, float rstd,
-                                int q) {
+// LayerNorm backward in T layout, in place, on d = d loss / d xhat (the affine's gamma is folded into the weights the
+// incoming gradient was multiplied with, stage_tower(fold)):  d <- rstd * (d - mean(d) - xhat * mean(d * xhat))
+__device__ inline void ln_bwd_T(f32x4 (&d)[4], const f32x4 (&xhat)[4], float rstd) {
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    const f32x4 gg = *(const f32x4*)(g + 16 * m + 4 * q);
-    d[m] = d[m] * gg;
     const f32x4 t = d[m] * xhat[m];
     s1 += (d[m][0] + d[m][1]) + (d[m][2] + d[m][3]);
     s2 += (t[0] + t[1]) + (t[2] + t[3]);
@@ -249,7 +247,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // the tower image is staged AFTER the first tile's index loads and record DMA are in flight (their latency chain -
   // index -> record rows -> LDS - overlaps the parameter loads instead of following them); the record ring and the
   // image are disjoint LDS regions
-  stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM, SP);
+  stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM, SP, true);
   __syncthreads();
 
 #ifdef ORL_PROF
@@ -282,7 +280,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     float hd[NO];
     f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};  // wide heads: this lane's 4 logits
     {
-      f32x4 z[4], n1[4], xh2[4];
+      f32x4 z[4], xh2[4];
       load_vec_T(lw + tw.b1, q, z);
       // columns >= D of a record are other (finite) fields; W1's LDS image is zero-padded there
       fc1_T(lw + tw.W1, DP, [&](int s) -> float { return REC(A.o_x + 4 * s + q); }, z, j, q);
@@ -295,22 +293,22 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         }
       ln_normalize_T(z, rstd1);  // z = xhat1
       store_slab_T(X1, z, j, q);
-      ln_affine_T(z, lw + tw.g1, lw + tw.be1, q, n1);
-      load_vec_T(lw + tw.b2, q, xh2);
+      load_vec_T(lw + tw.b2, q, xh2);  // the folded bias b2 + W2 be1; the GEMM runs on xhat1 itself (W2 diag(g1) image)
       ORL_T(1);  // fc1, relu, LN1, slab store, affine
       ORL_PRIO(1);
       if constexpr (SP) {
         u32x4 xs[2][3];
-        split_T(n1, xs);
+        split_T(z, xs);
         mm64_T_split((const unsigned short*)(lw + tw.W2), xs, xh2, j, q);
       } else {
-        mm64_T(lw + tw.W2, n1, xh2, j, q);
+        mm64_T(lw + tw.W2, z, xh2, j, q);
       }
       ORL_PRIO(0);
       ORL_T(2);  // fc2: 64 MFMA
       ln_normalize_T(xh2, rstd2);
       store_slab_T(SS, xh2, j, q);  // parked in the scratch slab: read back in F layout (S3) and T layout (LN2')
-      ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, z);  // z = n2
+#pragma unroll
+      for (int m = 0; m < 4; ++m) z[m] = xh2[m];  // the head runs on xhat2 (W3 diag(g2) image, folded bias)
       if constexpr (HMM) {
         // logits^T[16 c x 16 rows] = W3p n2^T: lane (j, q) keeps logits c = 4q..4q+3 of row j - the layout the loss,
         // the dhead tile and the dn2 GEMM below all work in (no redistribution)
@@ -643,7 +641,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     {
       f32x4 xh2[4];
       load_slab_T(SS, xh2, j, q);
-      ln_bwd_T(d2, xh2, lw + tw.g2, rstd2, q);
+      ln_bwd_T(d2, xh2, rstd2);
     }
     wave_lds_fence();
     store_slab_T(SS, d2, j, q);
@@ -732,7 +730,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     {
       f32x4 xh1[4];
       load_slab_T(X1, xh1, j, q);
-      ln_bwd_T(d1, xh1, lw + tw.g1, rstd1, q);
+      ln_bwd_T(d1, xh1, rstd1);
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
