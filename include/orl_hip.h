@@ -596,9 +596,14 @@ int orl_rnn_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const o
 #define ORL_ACT_LEAKY_RELU 2
 #define ORL_ACT_ELU 3
 #define ORL_HEAD_MULTI_DISCRETE 3 /* MultiDiscrete(nvec): n_heads Categoricals over one concatenated logits row */
+/* Tuple(Box(cd), Discrete(n)) - the reference's "mixed" ACTLayer branch (act.py:33-63, 126-147): a DiagGaussian over cd
+ * dims and a Categorical over n classes on the same features; logits row = [means (cd) | class logits (n)], nvec = {cd, n};
+ * stored actions = cd floats + the class index, ONE joint log-prob (the sum over both parts) replicated over the cd + 1
+ * stored columns, dist_entropy = 0.0025 * Gaussian + 0.01 * Categorical (both hard-coded there). */
+#define ORL_HEAD_MIXED 4
 #define ORL_MAX_HEADS 8
 typedef struct orl_head_desc {
-  int32_t kind;    /* ORL_HEAD_CATEGORICAL / _GAUSSIAN / _MULTI_DISCRETE */
+  int32_t kind;    /* ORL_HEAD_CATEGORICAL / _GAUSSIAN / _MULTI_DISCRETE / _MIXED */
   int32_t n_out;   /* logits per row (MultiDiscrete: sum of nvec) */
   int32_t n_heads; /* MultiDiscrete: components, else 1 */
   int32_t nvec[ORL_MAX_HEADS];

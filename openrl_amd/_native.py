@@ -118,6 +118,7 @@ class GenMlpDesc(C.Structure):
 
 ORL_ACT_NONE, ORL_ACT_TANH, ORL_ACT_RELU, ORL_ACT_LEAKY_RELU, ORL_ACT_ELU = -1, 0, 1, 2, 3
 ORL_HEAD_MULTI_DISCRETE = 3
+ORL_HEAD_MIXED = 4
 
 # order of orl_abi_struct_size(which)
 _ABI_STRUCTS = (NetDesc, PackSrc, BufferPtrs, CopyDesc, GatherDesc, PPOHParams, AdamState, RolloutArgs, RnnBatch,

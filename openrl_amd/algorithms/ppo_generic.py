@@ -167,7 +167,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     def logstd_grad(net):
         h = net.heads["act"]
         if "logstd" in h:
-            ops.multi_copy([(net.v(h["logstd"], h["n"], grad=True), psums[4:4 + h["n"]])])
+            ops.multi_copy([(net.v(h["logstd"], h["n_ls"], grad=True), psums[4:4 + h["n_ls"]])])
 
     if shared:
         model, opt = mod.models["model"], mod.optimizers["model"]

@@ -360,6 +360,57 @@ __global__ __launch_bounds__(256) void policy_loss_kernel(orl_head_desc hd, cons
           st_ent += (hd.kind == ORL_HEAD_CATEGORICAL ? ent_sum : ent_sum / (float)nh) * w;
           st_ratio += ratio_sum;
         }
+      } else if (hd.kind == ORL_HEAD_MIXED) {
+        // Tuple(Box(cd), Discrete(n)) - ACTLayer.evaluate_actions' mixed branch (act.py:126-147) under prepare_loss
+        // (ppo.py:302-361): ONE joint log-prob lp = sum_k lp_gauss_k + lp_cat against cd + 1 stored (identical) old
+        // log-probs -> cd + 1 ratio / surrogate columns, summed (dim=-1); dist_entropy = 0.0025 * (Gaussian entropy
+        // summed over dims, masked mean over rows - or the mean over rows AND dims without active masks) + 0.01 *
+        // (Categorical entropy, masked mean), both differentiable.
+        const int cd = hd.nvec[0], n = hd.nvec[1];
+        const float ent_scale = hp.use_policy_active_masks ? 1.f : 1.f / (float)cd;
+        float lp = 0.f, ent_g = 0.f;
+        for (int k = 0; k < cd; ++k) {
+          const float ls = logstd[k], sd = expf(ls), var = sd * sd;
+          const float dmu = r[c.o_act + k] - lg[k];
+          lp += -(dmu * dmu) / (2.f * var) - ls - 0.91893853320467274178f;
+          ent_g += 1.41893853320467274178f + ls;
+        }
+        float mx = -3.0e38f;
+        for (int k = 0; k < n; ++k) mx = fmaxf(mx, lg[cd + k]);
+        float se = 0.f;
+        for (int k = 0; k < n; ++k) se += __expf(lg[cd + k] - mx);
+        const float lse = mx + __logf(se);
+        const int a = (int)r[c.o_act + cd];
+        float ent_c = 0.f;
+        for (int k = 0; k < n; ++k) {
+          const float ell = lg[cd + k] - lse;
+          ent_c -= __expf(ell) * ell;
+        }
+        lp += lg[cd + a] - lse;
+        const float ent_row = 0.0025f * ent_scale * ent_g + 0.01f * ent_c;
+        if (mode == 1) {
+          for (int k = 0; k <= cd; ++k) logp_out[(size_t)i * c.a_w + k] = lp;
+          ent_out[i] = ent_row;
+        } else {
+          float surr_sum = 0.f, ratio_sum = 0.f, gl = 0.f;
+          for (int k = 0; k <= cd; ++k) {
+            const Surr s = ppo_surr(lp, r[c.o_lp + k], adv, hp);
+            surr_sum += s.surr; ratio_sum += s.ratio; gl += s.gl;
+          }
+          for (int k = 0; k < cd; ++k) {
+            const float ls = logstd[k], sd = expf(ls), var = sd * sd;
+            const float dmu = r[c.o_act + k] - lg[k];
+            dl[k] = w * gl * dmu / var * inv_den;
+            dls[k & 15] += w * (gl * (dmu * dmu / var - 1.f) * inv_den
+                                - hp.entropy_coef * 0.0025f * ent_scale * inv_ent_den);
+          }
+          for (int k = 0; k < n; ++k) {
+            const float ell = lg[cd + k] - lse, p = __expf(ell);
+            dl[cd + k] = w * (gl * ((k == a ? 1.f : 0.f) - p) * inv_den
+                              + hp.entropy_coef * 0.01f * p * (ell + ent_c) * inv_ent_den);
+          }
+          st_loss += -surr_sum * w; st_ent += ent_row * w; st_ratio += ratio_sum;
+        }
       } else if (hd.kind == ORL_HEAD_GAUSSIAN) {
         // DiagGaussian, everything per action dimension (distributions.py:34-43, ppo.py:302-317)
         const float ent_scale = hp.use_policy_active_masks ? 1.f : 1.f / (float)NT;
@@ -732,6 +783,7 @@ int orl_gather_cols(const float* records, int rec_width, int col0, int width, co
 }
 
 static int head_total(const orl_head_desc* h) {
+  if (h->kind == ORL_HEAD_MIXED) return h->nvec[0] + h->nvec[1];
   if (h->kind == ORL_HEAD_MULTI_DISCRETE) {
     int t = 0;
     for (int k = 0; k < h->n_heads; ++k) t += h->nvec[k];
@@ -742,8 +794,10 @@ static int head_total(const orl_head_desc* h) {
 
 static int check_head(const orl_head_desc* h, const char* who) {
   if (!h) return fail(ORL_E_INVALID, "%s: null head descriptor", who);
-  if (h->kind < ORL_HEAD_CATEGORICAL || h->kind > ORL_HEAD_MULTI_DISCRETE)
+  if (h->kind < ORL_HEAD_CATEGORICAL || h->kind > ORL_HEAD_MIXED)
     return fail(ORL_E_UNSUPPORTED, "%s: head kind %d", who, h->kind);
+  if (h->kind == ORL_HEAD_MIXED && (h->n_heads != 2 || h->nvec[0] < 1 || h->nvec[0] > 15 || h->nvec[1] < 1))
+    return fail(ORL_E_UNSUPPORTED, "%s: mixed head needs nvec = {Box dims (1..15), Discrete classes}", who);
   if (h->kind == ORL_HEAD_MULTI_DISCRETE && (h->n_heads < 1 || h->n_heads > ORL_MAX_HEADS))
     return fail(ORL_E_UNSUPPORTED, "%s: MultiDiscrete with %d components (max %d)", who, h->n_heads, ORL_MAX_HEADS);
   if (h->n_out < 1 || h->n_out > GEN_MAX_OUT || head_total(h) != h->n_out)
@@ -782,7 +836,8 @@ int orl_gen_policy_loss(const orl_head_desc* head, const float* logits, const fl
   ORL_REQUIRE(logits && records && hp && mb > 0, "orl_gen_policy_loss: null pointer");
   ORL_REQUIRE(eval ? (logp_out && ent_out) : (den && partials && n_blocks_out && max_blocks > 0),
               "orl_gen_policy_loss: training needs dlogits/den/partials, evaluation needs logp_out/ent_out");
-  ORL_REQUIRE(head->kind != ORL_HEAD_GAUSSIAN || logstd, "orl_gen_policy_loss: Gaussian head without logstd");
+  ORL_REQUIRE((head->kind != ORL_HEAD_GAUSSIAN && head->kind != ORL_HEAD_MIXED) || logstd,
+              "orl_gen_policy_loss: Gaussian head without logstd");
   ORL_REQUIRE(orl_record_width(Dp, Dc, a_w, K) == rec_width, "orl_gen_policy_loss: record width %d != %d", rec_width,
               orl_record_width(Dp, Dc, a_w, K));
   int grid = (mb + 255) / 256;
@@ -815,7 +870,8 @@ int orl_gen_sample(const orl_head_desc* head, const float* logits, const float* 
   int rc = check_head(head, "orl_gen_sample");
   if (rc) return rc;
   ORL_REQUIRE(logits && actions && logp && B > 0 && a_w > 0, "orl_gen_sample: bad arguments");
-  ORL_REQUIRE(head->kind != ORL_HEAD_GAUSSIAN || logstd, "orl_gen_sample: Gaussian head without logstd");
+  ORL_REQUIRE((head->kind != ORL_HEAD_GAUSSIAN && head->kind != ORL_HEAD_MIXED) || logstd,
+              "orl_gen_sample: Gaussian head without logstd");
   hipLaunchKernelGGL(gen_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, *head, logits, logstd,
                      action_masks, B, deterministic, seed, row0, rng_step, (const unsigned long long*)rng_step_dev,
                      forced_u, a_w, actions, logp);

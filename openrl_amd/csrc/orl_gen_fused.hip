@@ -1293,7 +1293,8 @@ int orl_gen_act(const orl_gen_mlp_desc* policy, const float* obs, const orl_gen_
   ORL_REQUIRE(policy->n_heads >= 1 && (critic == nullptr || (policy->n_heads == 1 && critic->n_heads == 1 && critic_obs)),
               "orl_gen_act: the policy carries the action head (+ the value head of a shared network), a separate critic one value head");
   ORL_REQUIRE((policy->n_heads == 2 || critic) == (values != nullptr), "orl_gen_act: values goes with a value head");
-  ORL_REQUIRE(head->kind == ORL_HEAD_CATEGORICAL || head->kind == ORL_HEAD_GAUSSIAN || head->kind == ORL_HEAD_MULTI_DISCRETE,
+  ORL_REQUIRE(head->kind == ORL_HEAD_CATEGORICAL || head->kind == ORL_HEAD_GAUSSIAN || head->kind == ORL_HEAD_MULTI_DISCRETE ||
+                  head->kind == ORL_HEAD_MIXED,
               "orl_gen_act: head kind %d", head->kind);
   ORL_REQUIRE(head->n_out >= 1 && head->n_out <= GEN_MAX_OUT && head->n_out == policy->layer[policy->n_layers].n_out,
               "orl_gen_act: the head has %d logits (1..%d), the tower's first head %d", head->n_out, GEN_MAX_OUT,
@@ -1303,10 +1304,14 @@ int orl_gen_act(const orl_gen_mlp_desc* policy, const float* obs, const orl_gen_
     int tot = 0;
     for (int h = 0; h < head->n_heads; ++h) { ORL_REQUIRE(head->nvec[h] >= 1, "orl_gen_act: nvec[%d] = %d", h, head->nvec[h]); tot += head->nvec[h]; }
     ORL_REQUIRE(tot == head->n_out, "orl_gen_act: nvec sums to %d, n_out is %d", tot, head->n_out);
+  } else if (head->kind == ORL_HEAD_MIXED) {
+    ORL_REQUIRE(head->n_heads == 2 && head->nvec[0] >= 1 && head->nvec[0] <= 15 && head->nvec[1] >= 1 &&
+                    head->nvec[0] + head->nvec[1] == head->n_out && a_w == head->nvec[0] + 1,
+                "orl_gen_act: mixed head {%d, %d}, n_out %d, a_w %d", head->nvec[0], head->nvec[1], head->n_out, a_w);
   } else {
     ORL_REQUIRE(a_w == (head->kind == ORL_HEAD_GAUSSIAN ? head->n_out : 1), "orl_gen_act: a_w %d for head kind %d", a_w, head->kind);
   }
-  ORL_REQUIRE(head->kind != ORL_HEAD_GAUSSIAN || logstd, "orl_gen_act: Gaussian head without logstd");
+  ORL_REQUIRE((head->kind != ORL_HEAD_GAUSSIAN && head->kind != ORL_HEAD_MIXED) || logstd, "orl_gen_act: Gaussian head without logstd");
   int wmax = 0, width = 0;
   int rc = check_mlp_desc(policy, true, policy->n_heads == 2, false, "orl_gen_act(policy)", &wmax, &width);
   if (rc) return rc;

@@ -62,6 +62,57 @@ __device__ inline void gen_sample_row(const orl_head_desc& hd, LgPtr lg,
       logp_row[h] = lg[off + a] - lse;
       off += n;
     }
+  } else if (hd.kind == ORL_HEAD_MIXED) {
+    // Tuple(Box(cd), Discrete(n)): ACTLayer.forward's mixed branch (act.py:46-63) - the Gaussian part, then the
+    // Categorical (no action masks there), ONE joint log-prob (the sum) in every stored column.  forced_row = cd normal
+    // deviates + the categorical's uniform.  Philox blocks 0 .. ceil(cd/4)-1 feed the Gaussian, the next one the class.
+    const int cd = hd.nvec[0], n = hd.nvec[1];
+    float joint = 0.f;
+    for (int b = 0; 4 * b < cd; ++b) {
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!deterministic && forced_row == nullptr) {
+        const u4 r = draw(b);
+        box_muller(r.x, r.y, e[0], e[1]);
+        box_muller(r.z, r.w, e[2], e[3]);
+      }
+      for (int k = 0; k < 4 && 4 * b + k < cd; ++k) {
+        const int cdim = 4 * b + k;
+        const float ls = logstd[cdim], sd = expf(ls);
+        float eps = e[k];
+        if (forced_row != nullptr && !deterministic) eps = forced_row[cdim];
+        const float av = deterministic ? lg[cdim] : lg[cdim] + sd * eps;
+        const float d = av - lg[cdim];
+        actions_row[cdim] = av;
+        joint += -(d * d) / (2.f * (sd * sd)) - ls - 0.91893853320467274178f;
+      }
+    }
+    float mx = -3.0e38f;
+    for (int k = 0; k < n; ++k) mx = fmaxf(mx, lg[cd + k]);
+    float se = 0.f;
+    for (int k = 0; k < n; ++k) se += __expf(lg[cd + k] - mx);
+    const float lse = mx + __logf(se);
+    int a = 0;
+    if (deterministic) {
+      for (int k = 1; k < n; ++k) if (lg[cd + k] > lg[cd + a]) a = k;
+    } else {
+      const float u = forced_row ? forced_row[cd] : u01(draw((cd + 3) >> 2).x);
+      float tot = 0.f;
+      for (int k = 0; k < n; ++k) tot += __expf(lg[cd + k] - lse);
+      const float ut = u * tot;
+      float cum = 0.f;
+      int last = 0;
+      a = -1;
+      for (int k = 0; k < n; ++k) {
+        const float p = __expf(lg[cd + k] - lse);
+        cum += p;
+        if (p > 0.f) last = k;
+        if (a < 0 && cum > ut) a = k;
+      }
+      if (a < 0) a = last;
+    }
+    actions_row[cd] = (float)a;
+    joint += lg[cd + a] - lse;
+    for (int k = 0; k <= cd; ++k) logp_row[k] = joint;
   } else if (hd.kind == ORL_HEAD_GAUSSIAN) {
     for (int b = 0; 4 * b < NT; ++b) {
       float e[4] = {0.f, 0.f, 0.f, 0.f};

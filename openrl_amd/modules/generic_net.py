@@ -36,7 +36,7 @@ def needs_generic(cfg, act_space, share_model: bool) -> bool:
     stacked = bool(cfg.use_recurrent_policy or cfg.use_naive_recurrent_policy) and (
         cfg.recurrent_N != 1 or getattr(cfg, "rnn_type", "gru") != "gru")  # GRU stacks and LSTMs: the general towers
     return bool(share_model or cfg.use_share_model or cfg.layer_N != 1 or cfg.hidden_size != 64
-                or cfg.activation_id != 1 or cfg.use_feature_normalization or kind == "MultiDiscrete" or stacked)
+                or cfg.activation_id != 1 or cfg.use_feature_normalization or kind in ("MultiDiscrete", "Tuple") or stacked)
 
 
 def _act_head(act_space):
@@ -48,7 +48,11 @@ def _act_head(act_space):
     if kind == "MultiDiscrete":
         nvec = [int(h - l + 1) for h, l in zip(np.asarray(act_space.high).reshape(-1), np.asarray(act_space.low).reshape(-1))]
         return ops_gen.HEAD_MULTI_DISCRETE, nvec
-    raise NotImplementedError("action space %s not built (Discrete / Box / MultiDiscrete)" % kind)
+    if kind == "Tuple":  # the reference's mixed branch: (Box(cd), Discrete(n)) - act.py:33-43
+        if len(act_space) != 2 or spaces.kind(act_space[0]) != "Box" or spaces.kind(act_space[1]) != "Discrete":
+            raise NotImplementedError("Tuple action spaces: (Box, Discrete) only - the reference's mixed ACTLayer branch")
+        return ops_gen.HEAD_MIXED, [int(act_space[0].shape[0]), int(act_space[1].n)]
+    raise NotImplementedError("action space %s not built (Discrete / Box / MultiDiscrete / Tuple(Box, Discrete))" % kind)
 
 
 class GenNet:
@@ -111,15 +115,27 @@ class GenNet:
             elif kind == ops_gen.HEAD_GAUSSIAN:
                 self.entries.append(("act.action_out.fc_mean.weight", (n, H), oW))
                 self.entries.append(("act.action_out.fc_mean.bias", (n,), ob))
+            elif kind == ops_gen.HEAD_MIXED:  # ModuleList([DiagGaussian, Categorical]) (act.py:37-42), registration order
+                cd, nc = nvec
+                self.entries.append(("act.action_outs.0.fc_mean.weight", (cd, H), oW))
+                self.entries.append(("act.action_outs.0.fc_mean.bias", (cd,), ob))
+                ols = self._add("act.action_outs.0.logstd._bias", (cd, 1))
+                self.entries.append(("act.action_outs.1.linear.weight", (nc, H), oW + cd * H))
+                self.entries.append(("act.action_outs.1.linear.bias", (nc,), ob + cd))
             else:
                 self.entries.append(("act.action_out.linear.weight", (n, H), oW))
                 self.entries.append(("act.action_out.linear.bias", (n,), ob))
             self.heads["act"] = dict(W=oW, b=ob, n=n, gain=float(cfg.gain), parts=nvec, kind=kind)
             if kind == ops_gen.HEAD_GAUSSIAN:
                 self.heads["act"]["logstd"] = self._add("act.action_out.logstd._bias", (n, 1))
-            self.head_desc = ops_gen.head_desc(kind, n, nvec if kind == ops_gen.HEAD_MULTI_DISCRETE else None)
+                self.heads["act"]["n_ls"] = n
+            elif kind == ops_gen.HEAD_MIXED:
+                self.heads["act"]["logstd"], self.heads["act"]["n_ls"] = ols, nvec[0]
+            self.head_desc = ops_gen.head_desc(kind, n, nvec if kind in (ops_gen.HEAD_MULTI_DISCRETE, ops_gen.HEAD_MIXED)
+                                               else None)
             self.act_kind, self.nvec = kind, nvec
-            self.act_width = 1 if kind == ops_gen.HEAD_CATEGORICAL else len(nvec) if kind == ops_gen.HEAD_MULTI_DISCRETE else n
+            self.act_width = (1 if kind == ops_gen.HEAD_CATEGORICAL else len(nvec) if kind == ops_gen.HEAD_MULTI_DISCRETE
+                              else nvec[0] + 1 if kind == ops_gen.HEAD_MIXED else n)
         self.n_params = self._o
         self.theta = torch.zeros(self.n_params, dtype=torch.float32, device=device)
         self.grad = torch.zeros_like(self.theta)
@@ -312,7 +328,7 @@ class GenNet:
                     r += k
                 self.v(h["b"], h["n"]).zero_()
                 if "logstd" in h:
-                    self.v(h["logstd"], h["n"]).zero_()
+                    self.v(h["logstd"], h["n_ls"]).zero_()
 
 
 class GenWorkspace:
@@ -544,8 +560,9 @@ class GenericPPOModule(PPOModule):
 
     def __init__(self, cfg, policy_input_space, critic_input_space, act_space, share_model: bool = False,
                  device="cuda:0", rank=None, world_size=None, model_dict=None):
-        if model_dict:
-            raise NotImplementedError("custom model_dict networks are not built")
+        from .ppo_module import check_model_dict
+
+        check_model_dict(model_dict)
         for flag in ("use_influence_policy", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp", "use_deepspeed"):
             if getattr(cfg, flag, False):
                 raise NotImplementedError("cfg.%s=True is not built for the general towers" % flag)
@@ -642,7 +659,7 @@ class GenericPPOModule(PPOModule):
 
     def _logstd(self):
         h = self.policy_net.heads["act"]
-        return self.policy_net.v(h["logstd"], h["n"]) if "logstd" in h else None
+        return self.policy_net.v(h["logstd"], h["n_ls"]) if "logstd" in h else None
 
     # ------------------------------------------------------------------ rollout side
     @torch.no_grad()

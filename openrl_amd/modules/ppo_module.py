@@ -231,6 +231,27 @@ def _host_init_tower(D: int, H: int, K: int, gaussian: bool, gain_head: float, u
     return torch.cat(parts).clone()
 
 
+#: model_dict keys -> the reference network class whose construction the built towers reproduce (ppo_module.py:58-89)
+BUILT_NETWORKS = {"policy": "PolicyNetwork", "critic": "ValueNetwork", "model": "PolicyValueNetwork"}
+
+
+def check_model_dict(model_dict) -> None:
+    """``model_dict`` (ppo_net.py:57-58 -> ppo_module.py:58-89) injects network CLASSES per role.  The engine runs its
+    own HIP towers, so what it can honour is an entry that names the reference's stock class for that role -
+    ``PolicyNetwork`` / ``ValueNetwork`` / ``PolicyValueNetwork``, the reference's own or the markers of
+    ``openrl_amd.modules.networks`` - whose constructor reads nothing but ``cfg`` and the spaces: the built towers are that
+    network.  Anything else (a subclass with its own forward, a foreign ``nn.Module``) cannot run on the kernels and is
+    refused loudly rather than silently replaced."""
+    for key, net_cls in (model_dict or {}).items():
+        if key not in BUILT_NETWORKS:
+            raise KeyError("model_dict key %r: the reference reads 'policy', 'critic' and 'model'" % (key,))
+        name = getattr(net_cls, "__name__", type(net_cls).__name__)
+        if name != BUILT_NETWORKS[key]:
+            raise NotImplementedError(
+                "model_dict[%r] = %s: only the stock %s is accepted (the engine's built towers reproduce it from cfg); a "
+                "custom network class cannot run on the HIP towers" % (key, name, BUILT_NETWORKS[key]))
+
+
 class PPOModule:
     #: False = the fused default-tower kernels; True = the layer-wise general path (modules/generic_net.py)
     generic = False
@@ -253,8 +274,7 @@ class PPOModule:
         # routed to GenericPPOModule by __new__, so what is refused here is a RECURRENT policy outside the default tower
         if share_model or cfg.use_share_model:
             raise NotImplementedError("use_share_model with use_recurrent_policy is not built (feed-forward only)")
-        if model_dict:
-            raise NotImplementedError("custom model_dict towers are not built: the engine runs its own towers")
+        check_model_dict(model_dict)
         for flag in ("use_influence_policy",
                      "use_feature_normalization", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp",
                      "use_deepspeed", "use_single_network"):

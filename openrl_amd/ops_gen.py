@@ -15,6 +15,7 @@ from ._native import AdamState, HeadDesc, PPOHParams, fptr, ptr, stream_ptr
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LEAKY_RELU, ACT_ELU = (nat.ORL_ACT_NONE, nat.ORL_ACT_TANH, nat.ORL_ACT_RELU,
                                                          nat.ORL_ACT_LEAKY_RELU, nat.ORL_ACT_ELU)
 HEAD_CATEGORICAL, HEAD_GAUSSIAN, HEAD_MULTI_DISCRETE = nat.ORL_HEAD_CATEGORICAL, nat.ORL_HEAD_GAUSSIAN, nat.ORL_HEAD_MULTI_DISCRETE
+HEAD_MIXED = nat.ORL_HEAD_MIXED
 MAX_BLOCKS = 1024  # rows of every per-workgroup partial buffer of this path
 
 

@@ -110,6 +110,27 @@ class MultiDiscrete(Space):
         return "MultiDiscrete(%s)" % self.nvec.tolist()
 
 
+class Tuple(Space):  # noqa: A001 - the name is the contract
+    """gymnasium.spaces.Tuple.  As an ACTION space the reference reads it as "continuous + discrete" (its mixed / agar
+    branch: ``action_space[0]`` a Box, ``action_space[1]`` a Discrete - act.py:33-43, buffers/utils/util.py:83-84)."""
+
+    def __init__(self, spaces):
+        super().__init__(None, None)
+        self.spaces = tuple(spaces)
+
+    def __getitem__(self, i):
+        return self.spaces[i]
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def sample(self, mask=None):
+        return tuple(s.sample() for s in self.spaces)
+
+    def __repr__(self):
+        return "Tuple(%s)" % ", ".join(repr(s) for s in self.spaces)
+
+
 class Dict(Space):  # noqa: A001 - the name is the contract
     def __init__(self, spaces=None, **kw):
         super().__init__(None, None)
@@ -161,4 +182,7 @@ def act_shape(space) -> int:
         return int(space.shape[0])
     if k == "MultiDiscrete":  # one stored column per component (buffers/utils/util.py:80-81: space.shape)
         return int(np.asarray(space.shape).reshape(-1)[0])
-    raise NotImplementedError("action space type %s not built in the MI355X engine (Discrete / Box / MultiDiscrete)" % k)
+    if k == "Tuple":  # the mixed branch: continuous dims + ONE stored column for the discrete action (util.py:83-84)
+        return int(space[0].shape[0]) + 1
+    raise NotImplementedError("action space type %s not built in the MI355X engine (Discrete / Box / MultiDiscrete / Tuple)"
+                              % k)

@@ -166,6 +166,8 @@ def _train_case(name, argv, obs_dim, act_space_fn, N=8, T=12, use_masks=False, s
         out["buf_" + f] = getattr(d, f).copy()
     if d.action_masks is not None:
         out["buf_action_masks"] = d.action_masks.copy()
+    if act_space.__class__.__name__ == "Tuple":  # the mixed branch: (Box(cd), Discrete(n))
+        out["mixed"] = np.array([act_space[0].shape[0], act_space[1].n])
     out["next_values"] = next_values
     # the update: RNG state at entry decides the permutations
     torch.manual_seed(1234 + seed)
@@ -311,6 +313,44 @@ def actlayer_multidiscrete_case():
         out["dW%d" % i], out["db%d" % i] = lin.linear.weight.grad.numpy(), lin.linear.bias.grad.numpy()
     np.savez_compressed(os.path.join(OUT, "actlayer_multidiscrete.npz"), **out)
     print("actlayer_multidiscrete.npz", float(ent))
+
+
+def actlayer_mixed_case():
+    """ACTLayer with a Tuple(Box(2), Discrete(n)) space - the "mixed" branch (act.py:33-43 construction, 46-63 forward,
+    126-147 evaluate_actions with its hard-coded ``split((2, 1))`` and 0.0025 / 0.01 entropy weights): joint log-prob of
+    given actions, the combined entropy with and without active masks, deterministic actions, and the gradient of
+    sum(log-prob) + entropy w.r.t. the features and the head parameters."""
+    from gymnasium.spaces import Box, Discrete, Tuple
+    from openrl.modules.networks.utils.act import ACTLayer
+
+    torch.manual_seed(23)
+    cd, n, H, B = 2, 5, 64, 24
+    layer = ACTLayer(Tuple((Box(-1, 1, (cd,)), Discrete(n))), H, True, 0.01)
+    rs = np.random.RandomState(23)
+    g, c = layer.action_outs[0], layer.action_outs[1]
+    g.fc_mean.weight.data.copy_(torch.tensor(0.3 * rs.randn(cd, H).astype(np.float32)))
+    g.fc_mean.bias.data.copy_(torch.tensor(0.1 * rs.randn(cd).astype(np.float32)))
+    g.logstd._bias.data.copy_(torch.tensor(0.2 * rs.randn(cd, 1).astype(np.float32)))
+    c.linear.weight.data.copy_(torch.tensor(0.4 * rs.randn(n, H).astype(np.float32)))
+    c.linear.bias.data.copy_(torch.tensor(0.1 * rs.randn(n).astype(np.float32)))
+    x = torch.tensor(rs.randn(B, H).astype(np.float32), requires_grad=True)
+    actions = torch.tensor(np.concatenate([rs.randn(B, cd), rs.randint(0, n, (B, 1))], 1).astype(np.float32))
+    active = torch.tensor((rs.rand(B, 1) > 0.2).astype(np.float32))
+    logp, ent = layer.evaluate_actions(x, actions, None, active)
+    (logp.sum() + 3.0 * ent).backward()
+    with torch.no_grad():
+        _, ent_nomask = layer.evaluate_actions(x.detach(), actions, None, None)
+        det_a, det_lp = layer(x.detach(), None, True)
+    out = dict(shape=np.array([cd, n]), x=x.detach().numpy(), actions=actions.numpy(), active=active.numpy(),
+               logp=logp.detach().numpy(), entropy=np.array(float(ent)), entropy_nomask=np.array(float(ent_nomask)),
+               dx=x.grad.numpy(), det_actions=det_a.numpy().astype(np.float32), det_logp=det_lp.numpy(),
+               Wm=g.fc_mean.weight.detach().numpy(), bm=g.fc_mean.bias.detach().numpy(),
+               logstd=g.logstd._bias.detach().numpy().reshape(-1), Wc=c.linear.weight.detach().numpy(),
+               bc=c.linear.bias.detach().numpy(), dWm=g.fc_mean.weight.grad.numpy(), dbm=g.fc_mean.bias.grad.numpy(),
+               dlogstd=g.logstd._bias.grad.numpy().reshape(-1), dWc=c.linear.weight.grad.numpy(),
+               dbc=c.linear.bias.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "actlayer_mixed.npz"), **out)
+    print("actlayer_mixed.npz", float(ent), float(ent_nomask))
 
 
 def state_dict_case():
@@ -664,6 +704,8 @@ def main():
         state_dict_case()
     if want("actlayer_multidiscrete"):
         actlayer_multidiscrete_case()
+    if want("actlayer_mixed"):
+        actlayer_mixed_case()
     cases = {
         "train_discrete": lambda n: _train_case(n, ["--ppo_epoch", "3", "--num_mini_batch", "2"], 4, lambda: Discrete(2)),
         "train_discrete_masks": lambda n: _train_case(
@@ -698,6 +740,11 @@ def main():
         "train_gen_a2c": lambda n: _train_case(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "3", "--hidden_size", "48", "--layer_N", "2", "--activation_id", "0"],
             5, lambda: Discrete(4), use_masks=True, seed=17, a2c=True),
+        # the mixed ACTLayer branch through a whole PPOAlgorithm.train: Tuple(Box(2), Discrete(4)) actions, one joint
+        # log-prob broadcast over the 3 stored columns (-> 3 summed surrogate columns), 0.0025 / 0.01 entropy weights
+        "train_gen_mixed": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2"], 5,
+            lambda: __import__("gymnasium").spaces.Tuple((Box(-1, 1, (2,)), Discrete(4))), seed=18),
         "train_share": lambda n: _train_case(
             n, ["--ppo_epoch", "3", "--num_mini_batch", "2", "--use_share_model", "true"], 5, lambda: Discrete(4),
             seed=14, share=True),

@@ -300,3 +300,33 @@ def multidiscrete_mode(x, weights, biases):
         acts.append(a.float().unsqueeze(-1))
         lps.append(dist.log_prob(a).unsqueeze(-1))
     return torch.cat(acts, -1), torch.cat(lps, -1)
+
+
+def mixed_evaluate(x, Wm, bm, logstd, Wc, bc, actions, active_masks=None):
+    """ACTLayer.evaluate_actions for Tuple(Box(cd), Discrete(n)) - the mixed branch (act.py:126-147): a DiagGaussian with
+    per-dimension log-probs (distributions.py:30-33, 85-98) and a Categorical on the same features; the log-probs are
+    concatenated and SUMMED to one joint column; the entropy is 0.0025 * Gaussian + 0.01 * Categorical, each an
+    active-mask weighted mean over rows (the Gaussian one summed over its dimensions) or a plain mean (the Gaussian one
+    over rows and dimensions)."""
+    cd = Wm.shape[0]
+    a, b = actions[:, :cd], actions[:, cd:].long()
+    normal = torch.distributions.Normal(F.linear(x, Wm, bm), logstd.reshape(1, -1).exp().expand(x.shape[0], cd))
+    cat = torch.distributions.Categorical(logits=F.linear(x, Wc, bc))
+    lps = torch.cat([normal.log_prob(a), cat.log_prob(b.squeeze(-1)).unsqueeze(-1)], -1)
+    if active_masks is not None:
+        e0 = (normal.entropy() * active_masks).sum() / active_masks.sum()
+        e1 = (cat.entropy() * active_masks.squeeze(-1)).sum() / active_masks.sum()
+    else:
+        e0, e1 = normal.entropy().mean(), cat.entropy().mean()
+    return lps.sum(-1, keepdim=True), e0 * 0.0025 + e1 * 0.01
+
+
+def mixed_mode(x, Wm, bm, logstd, Wc, bc):
+    """ACTLayer.forward(deterministic=True), mixed branch (act.py:46-63): the Gaussian mean + the Categorical argmax, and
+    the joint log-prob."""
+    mean = F.linear(x, Wm, bm)
+    normal = torch.distributions.Normal(mean, logstd.reshape(1, -1).exp().expand_as(mean))
+    cat = torch.distributions.Categorical(logits=F.linear(x, Wc, bc))
+    a = cat.probs.argmax(dim=-1, keepdim=True)
+    lp = torch.cat([normal.log_prob(mean), cat.log_prob(a.squeeze(-1)).unsqueeze(-1)], -1).sum(-1, keepdim=True)
+    return torch.cat([mean, a.float()], -1), lp

@@ -11,7 +11,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GEN_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_share", "train_share_box_fn",
-             "train_gen_a2c"]
+             "train_gen_a2c", "train_gen_mixed"]
 # fp32 tolerances of the update path (MFMA k-order, tile-wise gradient sums); same as tests/test_ppo_update_gpu.py
 THETA_RTOL, THETA_ATOL = 2e-3, 3e-5
 INFO_RTOL, INFO_ATOL = 3e-4, 3e-5
@@ -29,7 +29,9 @@ def build(g, load_theta0=True):
     T, N, D = g["buf_policy_obs"].shape[0] - 1, g["buf_policy_obs"].shape[1], g["buf_policy_obs"].shape[-1]
     cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = T, N, 1, cfg.hidden_size
     obs_space = spaces.Box(-np.inf, np.inf, (D,))
-    if "buf_action_masks" in g:
+    if "mixed" in g:  # the reference's mixed branch: Tuple(Box(cd), Discrete(n))
+        act_space = spaces.Tuple((spaces.Box(-1, 1, (int(g["mixed"][0]),)), spaces.Discrete(int(g["mixed"][1]))))
+    elif "buf_action_masks" in g:
         act_space = spaces.Discrete(g["buf_action_masks"].shape[-1])
     else:
         act_space = spaces.Box(-1, 1, (g["buf_actions"].shape[-1],))
@@ -95,7 +97,11 @@ def test_train_matches_reference_golden(case):
                                          deterministic=True)
     np.testing.assert_allclose(v.cpu().numpy(), g["probe_values"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(a.cpu().numpy(), g["probe_actions"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(lp.cpu().numpy(), g["probe_logp"], rtol=2e-4, atol=2e-5)
+    lp = lp.cpu().numpy()
+    if "mixed" in g:  # ONE joint log-prob [B, 1] in the reference, replicated over the stored columns here
+        assert np.all(lp == lp[:, :1])
+        lp = lp[:, :1]
+    np.testing.assert_allclose(lp, g["probe_logp"], rtol=2e-4, atol=2e-5)
 
 
 def test_dead_fc_h_block_never_moves():
@@ -113,6 +119,63 @@ def test_dead_fc_h_block_never_moves():
         if ".fc_h." in k:
             assert np.array_equal(flat0[o:o + n], flat1[o:o + n]), k  # the reference itself never moves it
         o += n
+
+
+def test_mixed_actlayer_vs_reference():
+    """ACTLayer with Tuple(Box(2), Discrete(5)) - the reference's mixed branch (act.py:33-63, 126-147) - through the
+    general path's head kernels: joint log-prob in every stored column, the 0.0025 / 0.01-weighted entropy with and
+    without active masks, deterministic actions (Gaussian mean + argmax) with their joint log-prob."""
+    from openrl_amd import ops, ops_gen, spaces
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.modules import generic_net as gn
+
+    g = H.load_golden("actlayer_mixed")
+    cd, n = (int(v) for v in g["shape"])
+    net = gn.GenNet("policy", default_cfg([]), 4, spaces.Tuple((spaces.Box(-1, 1, (cd,)), spaces.Discrete(n))), DEV)
+    sd = {"act.action_outs.0.fc_mean.weight": g["Wm"], "act.action_outs.0.fc_mean.bias": g["bm"],
+          "act.action_outs.0.logstd._bias": g["logstd"], "act.action_outs.1.linear.weight": g["Wc"],
+          "act.action_outs.1.linear.bias": g["bc"]}
+    seen = set()
+    for k, t in net.named_parameters():
+        if k in sd:
+            t.copy_(torch.tensor(sd[k]).reshape(t.shape))
+            seen.add(k)
+    assert seen == set(sd), "the mixed head's state_dict keys are the reference's"
+    B = g["x"].shape[0]
+    feats = torch.tensor(g["x"], device=DEV)
+    ws = gn.GenWorkspace(net, B, True)
+    logits = gn.head_forward(net, ws, "act", feats)
+    a_w = cd + 1
+    logstd = net.v(net.heads["act"]["logstd"], cd)
+    R = ops.record_width(4, 4, a_w, 0)
+    for masks in (True, False):
+        cfg = default_cfg([])
+        cfg.use_policy_active_masks = masks
+        rec = torch.zeros(B, R, device=DEV)
+        rec[:, 8:8 + a_w] = torch.tensor(g["actions"], device=DEV)
+        rec[:, 8 + 2 * a_w + 3] = torch.tensor(g["active"][:, 0], device=DEV)
+        logp, ent = torch.empty(B, a_w, device=DEV), torch.empty(B, device=DEV)
+        ops_gen.policy_eval(net.head_desc, logits, logstd, rec, 4, 4, a_w, 0, B, ops.make_hparams(cfg), logp, ent)
+        for k in range(a_w):  # ONE joint log-prob, replicated over the stored columns
+            np.testing.assert_allclose(logp[:, k:k + 1].cpu().numpy(), g["logp"], rtol=1e-5, atol=1e-6)
+        if masks:
+            act = torch.tensor(g["active"][:, 0], device=DEV)
+            np.testing.assert_allclose(float((ent * act).sum() / act.sum()), float(g["entropy"]), rtol=1e-5)
+        else:
+            np.testing.assert_allclose(float(ent.mean()), float(g["entropy_nomask"]), rtol=1e-5)
+    a = torch.empty(B, a_w, device=DEV)
+    lp = torch.empty(B, a_w, device=DEV)
+    ops_gen.sample(net.head_desc, logits, logstd, None, B, True, 0, 0, 0, None, None, a_w, a, lp)
+    np.testing.assert_allclose(a.cpu().numpy(), g["det_actions"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lp[:, :1].cpu().numpy(), g["det_logp"], rtol=1e-5, atol=1e-6)
+    # stochastic draws under forced deviates: a = mean + std * eps, class = inverse CDF of the forced uniform
+    forced = torch.tensor(np.concatenate([g["actions"][:, :cd] * 0 + 0.5, np.full((B, 1), 0.999, np.float32)], 1), device=DEV)
+    ops_gen.sample(net.head_desc, logits, logstd, None, B, False, 0, 0, 0, None, forced, a_w, a, lp)
+    mean = logits[:, :cd]
+    np.testing.assert_allclose(a[:, :cd].cpu().numpy(), (mean + logstd.exp() * 0.5).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    cum = torch.softmax(logits[:, cd:].double(), -1).cumsum(-1)
+    want = (cum > 0.999 * cum[:, -1:]).float().argmax(-1)
+    assert (a[:, cd].long() == want).float().mean() >= 0.95  # a CDF edge within fp32 rounding of the uniform may flip
 
 
 def test_multidiscrete_actlayer_vs_reference():
@@ -599,3 +662,28 @@ def test_algorithm_variants_run_on_general_towers(algo):
         idx = tr.last_indices[-1].cpu().numpy().reshape(-1, 3)
         assert np.all(idx % 3 == np.arange(3)) and np.all(idx // 3 == idx[:, :1] // 3)
     env.close()
+
+
+def test_model_dict_with_the_stock_network_classes_builds_the_usual_towers():
+    """``PPONet(env, cfg, model_dict={"policy": PolicyNetwork, "critic": ValueNetwork})`` (ppo_net.py:57-58): the stock
+    classes select the engine's built towers - same initial weights as without model_dict; a custom class is refused."""
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+    from openrl_amd.modules.networks import PolicyNetwork, ValueNetwork
+    from openrl_amd.utils.util import set_seed
+
+    thetas = []
+    for md in (None, {"policy": PolicyNetwork, "critic": ValueNetwork}):
+        cfg = default_cfg(["--seed", "3"])
+        env = make("CartPole-v1", env_num=4, device=DEV)
+        set_seed(3)
+        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=4, model_dict=md)
+        thetas.append(net.module.models["policy"].theta.clone())
+    assert torch.equal(thetas[0], thetas[1])
+
+    class Custom(torch.nn.Module):
+        pass
+
+    with pytest.raises(NotImplementedError):
+        PPONet(make("CartPole-v1", env_num=4, device=DEV), cfg=default_cfg([]), device=DEV, model_dict={"policy": Custom})

@@ -113,3 +113,30 @@ def test_shard_sums_reproduce_the_full_batch_gradient():
         gp, gc, den = gp + a, gc + c, den + d
     np.testing.assert_allclose((gp / den).numpy(), pth.grad.numpy(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose((gc / den).numpy(), cth.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_model_dict_accepts_the_stock_network_classes_and_refuses_foreign_ones():
+    """ppo_net.py:57-58 / ppo_module.py:58-89: model_dict names network classes per role.  The stock classes (the
+    reference's or this package's markers of the same names) select the built towers; anything else is refused."""
+    import pytest
+
+    from openrl_amd.modules.networks import PolicyNetwork, PolicyValueNetwork, ValueNetwork
+    from openrl_amd.modules.ppo_module import check_model_dict
+
+    check_model_dict(None)
+    check_model_dict({"policy": PolicyNetwork, "critic": ValueNetwork})
+    check_model_dict({"model": PolicyValueNetwork})
+    ref_like = type("PolicyNetwork", (), {})  # e.g. openrl.modules.networks.policy_network.PolicyNetwork itself
+    check_model_dict({"policy": ref_like})
+
+    class MyNet(PolicyNetwork):  # a custom forward cannot run on the HIP towers
+        pass
+
+    with pytest.raises(NotImplementedError, match="only the stock PolicyNetwork"):
+        check_model_dict({"policy": MyNet})
+    with pytest.raises(NotImplementedError):
+        check_model_dict({"critic": PolicyNetwork})
+    with pytest.raises(KeyError):
+        check_model_dict({"actor": PolicyNetwork})
+    with pytest.raises(TypeError):
+        PolicyNetwork()

@@ -249,3 +249,28 @@ def test_oracle_replays_the_full_size_cfg3_reference_update():
     """BASELINE.json configs[2] at full size (1024 x 200 rows, obs 17, Box(6), 10 epochs): the oracle restatement lands on
     the REAL reference's outputs (per-dimension Gaussian log-probs, FixedNormal.log_probs) - ~10 s of torch CPU."""
     _oracle_full_general("train_cfg3_full")
+
+
+def test_mixed_actlayer_oracle_matches_the_reference():
+    """ACTLayer with Tuple(Box(2), Discrete(5)) - the mixed branch (act.py:33-63,126-147): joint log-prob, the
+    0.0025 / 0.01-weighted entropy with and without active masks, the gradient of sum(log-prob) + 3 * entropy w.r.t.
+    features and head parameters, and the deterministic actions."""
+    from oracle import gen_oracle as go
+
+    g = H.load_golden("actlayer_mixed")
+    t = lambda a: torch.tensor(a)
+    x = t(g["x"]).clone().requires_grad_(True)
+    P = {k: t(g[k]).clone().requires_grad_(True) for k in ("Wm", "bm", "logstd", "Wc", "bc")}
+    logp, ent = go.mixed_evaluate(x, P["Wm"], P["bm"], P["logstd"], P["Wc"], P["bc"], t(g["actions"]), t(g["active"]))
+    (logp.sum() + 3.0 * ent).backward()
+    np.testing.assert_allclose(logp.detach().numpy(), g["logp"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(float(ent), float(g["entropy"]), rtol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=1e-5, atol=1e-6)
+    for k in P:
+        np.testing.assert_allclose(P[k].grad.numpy(), g["d" + k], rtol=1e-5, atol=1e-6, err_msg=k)
+    with torch.no_grad():
+        _, ent0 = go.mixed_evaluate(x, P["Wm"], P["bm"], P["logstd"], P["Wc"], P["bc"], t(g["actions"]), None)
+        a, lp = go.mixed_mode(x, P["Wm"], P["bm"], P["logstd"], P["Wc"], P["bc"])
+    np.testing.assert_allclose(float(ent0), float(g["entropy_nomask"]), rtol=1e-6)
+    np.testing.assert_allclose(a.numpy(), g["det_actions"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(lp.numpy(), g["det_logp"], rtol=1e-6, atol=1e-6)
