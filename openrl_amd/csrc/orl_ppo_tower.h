@@ -279,8 +279,11 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     unsigned long long relu_mask[16];
     float hd[NO];
     f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};  // wide heads: this lane's 4 logits
+    // xhat2 stays in registers from LN2 to LN2' (16 VGPRs through the head / loss / S3 phases, where pressure is low): its
+    // T-layout reload from the scratch slab was an exposed LDS round trip in front of the backward pass
+    f32x4 xh2[4];
     {
-      f32x4 z[4], xh2[4];
+      f32x4 z[4];
       load_vec_T(lw + tw.b1, q, z);
       // columns >= D of a record are other (finite) fields; W1's LDS image is zero-padded there
       fc1_T(lw + tw.W1, DP, [&](int s) -> float { return REC(A.o_x + 4 * s + q); }, z, j, q);
@@ -638,11 +641,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         }
       }
     }
-    {
-      f32x4 xh2[4];
-      load_slab_T(SS, xh2, j, q);
-      ln_bwd_T(d2, xh2, rstd2);
-    }
+    ln_bwd_T(d2, xh2, rstd2);
     wave_lds_fence();
     store_slab_T(SS, d2, j, q);
     wave_lds_fence();
