@@ -11,6 +11,9 @@
 #ifndef ORL_TOWER_FIRST_VARIANT
 #define ORL_TOWER_FIRST_VARIANT 0
 #endif
+#ifndef ORL_TOWER_WGRAD_SPLIT  // build-time experiment: 0 = the fallback variants keep the fp32 wgrad
+#define ORL_TOWER_WGRAD_SPLIT 1
+#endif
 #ifndef ORL_PAIR_WAVES  // build-time experiment: waves per workgroup of the pair launch (8 = two per SIMD)
 #define ORL_PAIR_WAVES 8
 #endif
@@ -70,8 +73,9 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
 template <int HEADP, int NOP_, int ND>
 static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int* gc_out, hipStream_t s) {
   constexpr int NOPP = NOP_ > 4 ? 16 : ((NOP_ + 3) & ~3);
-  // variants in order of preference: the split build (bf16 MFMAs over three-term splits; needs both bf16 images of W2 in
-  // LDS), then fp32 MFMA with and without the W2^T copy (same LDS policy as launch_tower: W2^T goes before a pair of waves)
+  // variants in order of preference: the full split build (bf16 MFMAs over three-term splits for fc2 / dgrad / wgrad;
+  // needs both bf16 images of W2 in LDS), then fp32 GEMMs + split wgrad with and without the W2^T copy (same LDS policy
+  // as launch_tower: W2^T goes before a pair of waves)
   for (int var = ORL_TOWER_FIRST_VARIANT; var < 3; ++var) {
     const bool sp = var == 0;
     const int w2t = var <= 1;
@@ -115,13 +119,13 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
       gc = PPO_MAX_BLOCKS - best_g;
     }
     if (sp) {
-      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, true>,
+      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, 2>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, true>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 2>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
     } else {
-      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, false>,
+      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, ORL_TOWER_WGRAD_SPLIT>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, false>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, ORL_TOWER_WGRAD_SPLIT>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
     }
     const int rc = launch_status("orl_ppo_fwd_bwd(pair)");
     if (rc) return -1000 - rc;

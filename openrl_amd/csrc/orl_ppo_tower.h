@@ -129,10 +129,12 @@ __device__ inline void mm64_T_wt(const float* __restrict__ Ws, const f32x4 (&in)
 
 // HEAD: ORL_HEAD_VALUE / _CATEGORICAL / _GAUSSIAN; NO: padded head width; ND: ceil(D/16) for the MFMA
 // dW1 path, 0 = VALU path (D <= 4, 16-byte aligned obs column).
-// SP: the three 64-wide GEMMs of a tile (fc2, dgrad, wgrad) on bf16 MFMAs over three-term splits of their fp32 operands
-// (orl_mlp.h) instead of v_mfma_f32_16x16x4_f32; needs the W2^T image.  fc1, the wide-head GEMMs and the MFMA dW1 path
-// stay on the fp32 MFMA (a few instructions per tile).
-template <int HEAD, int NO, int ND, bool SP = false>
+// SP: bf16 MFMAs over three-term splits of the fp32 operands (orl_mlp.h) instead of v_mfma_f32_16x16x4_f32:
+//   2 = the three 64-wide GEMMs of a tile (fc2, dgrad, wgrad); needs the bf16 images of W2 and W2^T in LDS (+ 20 KB);
+//   1 = the wgrad only - its operands come from the slabs, no LDS image is involved - for towers whose records leave no
+//       room for the bf16 images (wide observations / heads);
+//   0 = none.  fc1, the wide-head GEMMs and the MFMA dW1 path stay on the fp32 MFMA (a few instructions per tile).
+template <int HEAD, int NO, int ND, int SP_ = 0>
 __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const TowerLayout tl(A.net);
@@ -142,6 +144,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // wide heads (NO > 4: Discrete(5..16), Box(5..16)) run their three head GEMMs - logits, dn2 = W3^T dhead,
   // S3 += dhead^T xhat2 - on MFMA; with NO x 64 scalar FMAs per lane they were 2/3 of the tile and spilled 360 VGPRs
   constexpr bool HMM = NO > 4;
+  constexpr bool SP = SP_ == 2;   // the GEMMs with LDS images
+  constexpr bool SPW = SP_ >= 1;  // the wgrad
   const bool w2t = ND == 0 || SP || A.use_w2t;  // compile-time true on the small-observation path and in split builds
   const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, w2t, HMM, SP);
   const int DP = tw.DP;
@@ -646,7 +650,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     store_slab_T(SS, d2, j, q);
     wave_lds_fence();
     ORL_T(6);  // dn2, LN2 backward, dz2 slab store
-    if constexpr (SP) {
+    if constexpr (SPW) {
       // wgrad on the 32x32x16 bf16 MFMA (K = the tile's 16 rows): lane (c = l & 31, kb = l >> 5) reads rows 8kb..8kb+7 of
       // columns 32b + c of both slabs (32 conflict-free 4-byte reads, as many as the fp32 path), splits them in
       // registers and issues 6 products x 4 blocks = 24 MFMAs.  db2 falls out of the same reads.
@@ -821,7 +825,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       const bool first = p == 0;
       auto put = [&](int idx, float v) { acc[idx] = first ? v : acc[idx] + v; };
       const int f = l;
-      if constexpr (SP) {
+      if constexpr (SPW) {
         // 32x32 C fragment: lane (c = l & 31, kb = l >> 5), reg r -> G[o = 32bo + (r&3) + 8(r>>2) + 4kb][i = 32bi + c]
 #pragma unroll
         for (int bo = 0; bo < 2; ++bo)
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(512, 2) void ppo_tower_kernel(PpoArgs A) {
 // Both towers of one minibatch in ONE launch (the default 8-wave build): workgroups [0, gp) are the policy tower,
 // the rest the critic tower.  No kernel boundary between the two: critic workgroups start on a CU as soon as its
 // policy workgroup retires instead of waiting for the slowest policy workgroup of the whole chip.
-template <int HEADP, int NOP_, int ND, bool SP = false>
+template <int HEADP, int NOP_, int ND, int SP = 0>
 __global__ __launch_bounds__(512, 2) void ppo_tower_pair_kernel(PpoArgs P, PpoArgs Cc, int gp) {
   if ((int)blockIdx.x < gp) ppo_tower_body<HEADP, NOP_, ND, SP>(P, (int)blockIdx.x, gp);
   else ppo_tower_body<ORL_HEAD_VALUE, 1, ND, SP>(Cc, (int)blockIdx.x - gp, (int)gridDim.x - gp);

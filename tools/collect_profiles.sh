@@ -11,13 +11,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 
 # 2. per-kernel time of the same command (no CPU leg: it is not GPU work)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- \
-    python bench.py --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
+    python bench.py --no-cpu-baseline --no-other-configs > $OUT/${TAG}_stats.log 2>&1
 find $OUT/${TAG}_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_kernel_stats.csv
 
 # 3. HBM traffic counters, one pass each
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -- \
-      python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$C.log 2>&1
+      python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/${TAG}_pmc_$C.log 2>&1
   find $OUT/${TAG}_pmc_$C -name '*counter_collection.csv' | head -1 | xargs -I{} cp {} $OUT/${TAG}_pmc_$C.csv
 done
 python tools/summarize_pmc.py $OUT/${TAG}_pmc_FETCH_SIZE.csv $OUT/${TAG}_pmc_WRITE_SIZE.csv > $OUT/${TAG}_pmc_hbm.json
@@ -60,9 +60,9 @@ stats generic_recurrent_h128 python benchmarks/cfg4_mpe_bench.py --hidden_size 1
  python benchmarks/cfg4_mpe_bench.py --hidden_size 64 --layer_N 2 --steps 5 --warmup 3) 2>/dev/null | grep cfg4_mpe > $OUT/${TAG}_generic_recurrent_lines.jsonl
 # 6. the per-rank shard of the strong-scaling bench at 8 and 2 GPUs (512 / 2048 of the 4096 envs), on one GPU
 for E in 512 2048; do
-  timeout 600 python bench.py --no-cpu-baseline --envs $E > $OUT/${TAG}_bench_envs${E}_line.json 2>/dev/null
+  timeout 600 python bench.py --no-cpu-baseline --no-other-configs --envs $E > $OUT/${TAG}_bench_envs${E}_line.json 2>/dev/null
 done
-stats bench_envs512 python bench.py --no-cpu-baseline --envs 512
+stats bench_envs512 python bench.py --no-cpu-baseline --no-other-configs --envs 512
 # 7. issue / wait counters of the tower kernel
 bash tools/pmc_tower.sh > $OUT/${TAG}_pmc_tower.txt 2>&1
 # 8. the GPU test suite
