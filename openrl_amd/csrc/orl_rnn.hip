@@ -698,6 +698,16 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // waves 0-6: their 64 x 64 product runs on the 32x32x16 bf16 MFMA over three-term splits of the fp32 tape operands
+  // (orl_mlp.h: exact hi + mid + lo, 6 of the 9 products; 24 MFMAs of 32 cycles per tape block instead of 64 fp32 MFMAs
+  // of 32 cycles that also block the VALU) - 2 x 2 blocks of 32 x 32 accumulators, rows = delta features
+  f32x16 GS[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) GS[a][b][r] = 0.f;
   f32x4 G5 = {0.f, 0.f, 0.f, 0.f};  // waves 0-3: dhead x xhat3 tile `wave` (S5 columns 16*wave .. +15)
   float bsum = 0.f;  // column sum of delta column `threadIdx.x` (threads 0..399)
 
@@ -732,18 +742,40 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
     if (wave < 7) {
       const float* dvp = blk + dv * TV;
       const float* ivp = blk + iv * TV;
+      {
+        // lane (c32 = l & 31, kb = l >> 5): rows 8kb .. 8kb+7 of feature 32b + c32 of both vectors (element (row, f) of a
+        // staged vector sits at [(f >> 2) * 16 + ((row + 4 ((f >> 2) & 3)) & 15)] * 4 + (f & 3): tape_opnd's layout)
+        const int c32 = l & 31, kb = l >> 5;
+        u32x4 fa[2][3], fb[2][3];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float av[4], bv[4];
+        for (int b2 = 0; b2 < 2; ++b2) {
+          const int f = 32 * b2 + c32, grp = f >> 2, rot = 4 * (grp & 3);
+          float xa[8], xb[8];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          av[m] = tape_opnd(dvp, m, s, c, q);
-          bv[m] = tape_opnd(ivp, m, s, c, q);
+          for (int k = 0; k < 8; ++k) {
+            const int off = (grp * 16 + ((8 * kb + k + rot) & 15)) * 4 + (f & 3);
+            xa[k] = dvp[off];
+            xb[k] = ivp[off];
+          }
+          split8(xa, fa[b2][0], fa[b2][1], fa[b2][2]);
+          split8(xb, fb[b2][0], fb[b2][1], fb[b2][2]);
         }
 #pragma unroll
-        for (int mo = 0; mo < 4; ++mo)
+        for (int bo = 0; bo < 2; ++bo)
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi) G[mo][mi] = ORL_MFMA(av[mo], bv[mi], G[mo][mi]);
+          for (int bi = 0; bi < 2; ++bi) {
+            f32x16 g = GS[bo][bi];
+            g = mfma_bf16_32(fa[bo][2], fb[bi][0], g);
+            g = mfma_bf16_32(fa[bo][0], fb[bi][2], g);
+            g = mfma_bf16_32(fa[bo][1], fb[bi][1], g);
+            g = mfma_bf16_32(fa[bo][1], fb[bi][0], g);
+            g = mfma_bf16_32(fa[bo][0], fb[bi][1], g);
+            g = mfma_bf16_32(fa[bo][0], fb[bi][0], g);
+            GS[bo][bi] = g;
+          }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
         if (wave < 4) {
           const int qq = c >> 2;
           const float ah = blk[TAPE_HEAD + (qq * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3)];
@@ -793,12 +825,14 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
   // C fragment: lane (c, q), reg r -> out row 16*mo + 4q + r, in column 16*mi + c
   if (wave < 7) {
     float* o = out + (wave == 6 ? rl.oS2 : (wave < 3 ? rl.oS3 : rl.oP4) + g3 * 64 * 64);
+    // 32x32 C fragment: lane (c32 = l & 31, kb = l >> 5), reg r -> row 32bo + (r & 3) + 8 (r >> 2) + 4kb, column 32bi + c32
 #pragma unroll
-    for (int mo = 0; mo < 4; ++mo)
+    for (int bo = 0; bo < 2; ++bo)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[(16 * mo + 4 * q + r) * HID + 16 * mi + c] = G[mo][mi][r];
+        for (int r = 0; r < 16; ++r)
+          o[(32 * bo + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * HID + 32 * bi + (l & 31)] = GS[bo][bi][r];
     if (wave < 4) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
