@@ -38,6 +38,7 @@ import torch  # noqa: E402
 
 N_ENVS, T_ROLL, OBS_DIM, N_ACT, PPO_EPOCH = 4096, 128, 4, 2, 10
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (dense)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -171,7 +172,7 @@ def main():
     # HBM bytes per launch: NOT measured in this process (PMC needs rocprofv3) - read from the committed summary of the
     # separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, and only quoted for the shape it was taken at
     traffic, traffic_source = None, None
-    for name in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+    for name in ("r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 blob = json.load(fh)["orl_ppo_fwd_bwd_pair"]
@@ -187,6 +188,13 @@ def main():
                 "traffic_source": traffic_source,
                 "launch_ms": round(k_ms, 4), "launches_timed": len(ev),
                 "flops_per_launch": flops_per_launch,
+                # how the flops are executed: the three 64 x 64 GEMMs of a tile (92 % of the algorithmic flops) run as 6
+                # bf16 products per fp32 product over EXACT three-term bf16 splits of both operands, fp32 accumulation -
+                # error <= the fp32 MFMA's own (profiles/r03_split_bf16_gemm.txt); `frac` stays priced on ALGORITHMIC fp32
+                # flops against the fp32 MFMA peak, `bf16_mfma_frac` is the share of the dense bf16 MFMA peak issued
+                "mfma_path": "bf16x3 split (6 of 9 products) on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16; fc1 + head on "
+                             "v_mfma_f32_16x16x4_f32",
+                "bf16_mfma_frac": round(6 * (16384.0 / 17792.0) * achieved_tf / BF16_MFMA_PEAK_TFLOPS, 4),
                 "gae_scan": {"bound": "hbm", "achieved": round(gae_bytes / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else 0,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "launch_ms": round(gae_ms, 4),
                              "note": "%.1f MB per launch: latency-bound, includes adv statistics" % (gae_bytes / 1e6)}}
@@ -195,6 +203,8 @@ def main():
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "dtype_note": "fp32 storage and accumulation everywhere; GEMM products as exact bf16x3 splits (f32-equivalent: "
+                         "measured error <= v_mfma_f32_16x16x4_f32's)",
            "config": {"workload": "configs[1]: PPO, %d global envs x 128-step rollout (%d envs per GPU), obs 4, "
                                   "Discrete(2), MLP 64x64, ppo_epoch 10, num_mini_batch 1, ValueNorm on; synthetic "
                                   "fixed-step env" % (global_envs, n_local),
