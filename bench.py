@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--envs", type=int, default=N_ENVS, help="global env count (default: the metric's 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--tower-gemm", default="split", choices=["split", "fp32"],
+                    help="A/B: form the tower's GEMMs on the fp32 MFMA instead of the bf16x3 split (same results, slower)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few untimed iterations of BASELINE.json's other single-GPU configs (other_configs)")
     args = ap.parse_args()
@@ -98,7 +100,8 @@ def main():
     torch.cuda.set_device(local_rank)
 
     cfg = default_cfg(["--episode_length", str(T_ROLL), "--ppo_epoch", str(PPO_EPOCH), "--amd_perm_mode", args.perm,
-                       "--log_interval", "1000000", "--amd_collective", args.collective])
+                       "--log_interval", "1000000", "--amd_collective", args.collective, "--amd_tower_gemm",
+                       args.tower_gemm])
     if args.scaling == "strong":  # the metric: the global envs shard contiguously, N/G per GPU
         lo, hi = du.shard_range(args.envs, rank, world)
         n_local = hi - lo
@@ -192,9 +195,10 @@ def main():
                 # bf16 products per fp32 product over EXACT three-term bf16 splits of both operands, fp32 accumulation -
                 # error <= the fp32 MFMA's own (profiles/r03_split_bf16_gemm.txt); `frac` stays priced on ALGORITHMIC fp32
                 # flops against the fp32 MFMA peak, `bf16_mfma_frac` is the share of the dense bf16 MFMA peak issued
-                "mfma_path": "bf16x3 split (6 of 9 products) on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16; fc1 + head on "
-                             "v_mfma_f32_16x16x4_f32",
-                "bf16_mfma_frac": round(6 * (16384.0 / 17792.0) * achieved_tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                "mfma_path": ("bf16x3 split (6 of 9 products) on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16; fc1 + head on "
+                              "v_mfma_f32_16x16x4_f32") if args.tower_gemm == "split" else "v_mfma_f32_16x16x4_f32 (--tower-gemm fp32)",
+                "bf16_mfma_frac": round(6 * (16384.0 / 17792.0) * achieved_tf / BF16_MFMA_PEAK_TFLOPS, 4)
+                if args.tower_gemm == "split" else 0.0,
                 "gae_scan": {"bound": "hbm", "achieved": round(gae_bytes / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else 0,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "launch_ms": round(gae_ms, 4),
                              "note": "%.1f MB per launch: latency-bound, includes adv statistics" % (gae_bytes / 1e6)}}

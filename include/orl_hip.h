@@ -268,7 +268,9 @@ typedef struct orl_ppo_hparams {
   int32_t dual_clip_ppo;
   int32_t use_max_grad_norm;
   int32_t reserved; /* flag bits: 1 = critic-only update (turn_on == False, ppo.py:226-236);
-                     * 2 = A2C policy loss -adv*logp instead of the clipped surrogate (algorithms/a2c.py:88-98) */
+                     * 2 = A2C policy loss -adv*logp instead of the clipped surrogate (algorithms/a2c.py:88-98);
+                     * 4 = orl_ppo_fwd_bwd forms every GEMM on v_mfma_f32_16x16x4_f32 instead of the bf16x3 split (a
+                     *     measurement / comparison switch: same results within fp32 rounding, ~1.4x slower) */
 } orl_ppo_hparams;
 
 /* size (floats) of the raw gradient-sum vector of one tower and of the stats vector */

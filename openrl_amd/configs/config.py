@@ -31,6 +31,9 @@ AMD_FLAGS = [
     # fused recurrent rollout (orl_rnn_rollout_fused): critic workgroups in the same launch, one step behind their
     # policy workgroups (true), or a second launch after the policy's (false).
     ("amd_rnn_rollout_chase", "bool", True, "opt", None),
+    # GEMMs of the fused tower update: "split" = exact three-term bf16 splits on the bf16 MFMA (default; error <= the fp32
+    # MFMA's), "fp32" = v_mfma_f32_16x16x4_f32 (comparison / measurement).
+    ("amd_tower_gemm", "str", "split", "opt", ["split", "fp32"]),
 ]
 
 

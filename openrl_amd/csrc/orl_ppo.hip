@@ -76,7 +76,8 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
   // variants in order of preference: the full split build (bf16 MFMAs over three-term splits for fc2 / dgrad / wgrad;
   // needs both bf16 images of W2 in LDS), then fp32 GEMMs + split wgrad with and without the W2^T copy (same LDS policy
   // as launch_tower: W2^T goes before a pair of waves)
-  for (int var = ORL_TOWER_FIRST_VARIANT; var < 3; ++var) {
+  // hp.reserved & 4: the caller asks for the fp32-MFMA GEMMs (measurement / comparison switch, bench.py --tower-gemm fp32)
+  for (int var = (P.hp.reserved & 4) ? 1 : ORL_TOWER_FIRST_VARIANT; var < 3; ++var) {
     const bool sp = var == 0;
     const int w2t = var <= 1;
     if (var == 2 && ND == 0) break;
@@ -123,9 +124,15 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 2>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
     } else {
-      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, ORL_TOWER_WGRAD_SPLIT>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, ORL_TOWER_WGRAD_SPLIT>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+      if (P.hp.reserved & 4) {  // every GEMM on v_mfma_f32_16x16x4_f32 (round 2's kernel + the LayerNorm fold)
+        (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, 0>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 0>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+      } else {
+        (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, ORL_TOWER_WGRAD_SPLIT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, ORL_TOWER_WGRAD_SPLIT>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+      }
     }
     const int rc = launch_status("orl_ppo_fwd_bwd(pair)");
     if (rc) return -1000 - rc;

@@ -381,3 +381,78 @@ def test_full_size_update_other_baseline_shapes_match_reference_golden(case, bra
         else:
             assert gp == mb and gc == mb, (gp, gc)
     _assert_golden_outputs(g, module, info)
+
+
+def test_split_bf16_gemms_are_as_accurate_as_the_fp32_mfma_at_full_size():
+    """The tower update's GEMMs as exact three-term bf16 splits (default) vs the fp32 MFMA (``amd_tower_gemm=fp32``,
+    ``orl_ppo_hparams.reserved & 4``): one full-batch update at BASELINE configs[1]'s size (524 288 rows), clipped
+    parameter gradients of both towers against a FLOAT64 autograd reference of the same loss.  The split build must be at
+    least as close to fp64 as the fp32-MFMA build (up to 1.5x - both are dominated by the fp32 accumulation order), and
+    the two builds must agree with each other to fp32 rounding of the sums."""
+    from openrl_amd import spaces
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers.replay_data import ReplayData
+    from openrl_amd.modules.ppo_module import PPOModule
+    from oracle.fixtures import synth_update_buffer
+
+    g = H.load_golden("train_cfg2_full")
+    N, T, D, n_act, seed = (int(x) for x in g["shape"])
+    src = synth_update_buffer(seed, N, T, D, n_act)
+    grads = {}
+    for mode in ("split", "fp32"):
+        cfg = H.case_cfg(g)
+        cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = T, N, 1, cfg.hidden_size
+        cfg.amd_tower_gemm = mode
+        obs_space, act_space = spaces.Box(-np.inf, np.inf, (D,)), spaces.Discrete(n_act)
+        module = PPOModule(cfg, obs_space, obs_space, act_space, device=DEV, rank=0, world_size=1)
+        module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+        module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+        buf = ReplayData(cfg, 1, obs_space, act_space, device=DEV)
+        for f in ("policy_obs", "rewards", "value_preds", "masks", "active_masks", "bad_masks", "actions",
+                  "action_log_probs", "action_masks"):
+            getattr(buf, f).copy_(torch.tensor(src[f]))
+        buf.compute_returns(torch.tensor(src["next_value"]), module.get_critic_value_normalizer())
+        algo = PPOAlgorithm(cfg, module, agent_num=1, device=DEV)
+        assert bool(algo.hp.reserved & 4) == (mode == "fp32")
+        algo._advantages_and_records(buf)
+        algo._info.zero_()
+        vn = module.get_critic_value_normalizer()
+        algo._update_minibatch(buf, None, N * T, True)  # ValueNorm.update(return_batch) runs inside, before the loss
+        grads[mode] = (module.models["policy"].grad.double().cpu(), module.models["critic"].grad.double().cpu())
+        if mode == "split":  # what the fp64 reference needs: the engine's own returns / advantages / ValueNorm state
+            ret, adv = buf.returns.cpu().numpy(), buf.advantages.cpu().numpy()
+            vn_state = vn.state.double().cpu().numpy()
+    # float64 reference of prepare_loss + clip on the same batch (oracle functions are dtype-generic)
+    cfg = H.case_cfg(g)
+    hp = po.hyper_from_cfg(cfg)
+    d = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    fr = po.flat_rows
+    sample = (d(fr(src["policy_obs"][:-1])), d(fr(src["policy_obs"][:-1])), d(fr(src["actions"])),
+              d(fr(src["value_preds"][:-1])), d(fr(ret[:-1])), d(fr(src["active_masks"][:-1])),
+              d(fr(src["action_log_probs"])), d(adv.reshape(-1, 1)), d(fr(src["action_masks"][:-1])))
+
+    class VN64:  # ValueNorm.normalize with the engine's state (valuenorm.py:79-91) in float64
+        def normalize(self, x):
+            deb = max(vn_state[2], 1e-5)
+            mean, msq = vn_state[0] / deb, vn_state[1] / deb
+            return (x - mean) / np.sqrt(max(msq - mean * mean, 1e-2))
+
+        def update(self, x):
+            pass
+
+    pth = d(g["theta_p0"]).requires_grad_(True)
+    cth = d(g["theta_c0"]).requires_grad_(True)
+    pspec, cspec = po.TowerSpec(D, n_act, po.HEAD_CATEGORICAL), po.TowerSpec(D, 1, po.HEAD_VALUE)
+    loss_list, *_ = po.prepare_loss(hp, pspec, pth, cspec, cth, VN64(), sample)
+    for loss in loss_list:
+        loss.backward()
+    ref = [po.clip_grad_norm(pth.grad, hp.max_grad_norm)[0], po.clip_grad_norm(cth.grad, hp.max_grad_norm)[0]]
+    for k, name in enumerate(("policy", "critic")):
+        scale = float(ref[k].abs().max())
+        e_split = float((grads["split"][k] - ref[k]).abs().max()) / scale
+        e_fp32 = float((grads["fp32"][k] - ref[k]).abs().max()) / scale
+        e_pair = float((grads["split"][k] - grads["fp32"][k]).abs().max()) / scale
+        print("%s tower: max |g - g64| / max |g64|: split %.3e, fp32 MFMA %.3e; split vs fp32 MFMA %.3e"
+              % (name, e_split, e_fp32, e_pair))
+        assert e_split < 1e-4 and e_fp32 < 1e-4, (name, e_split, e_fp32)
+        assert e_split <= 1.5 * e_fp32 + 2e-7, (name, e_split, e_fp32)
