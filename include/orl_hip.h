@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 300 /* 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 302 /* 0.3.2: orl_gen_rollout_fused, ORL_HEAD_MIXED, hparams.reserved & 4; 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -664,7 +664,18 @@ int orl_gen_act(const orl_gen_mlp_desc* policy, const float* obs, const orl_gen_
                 int B, float* logits_out, float* values, const orl_head_desc* head, const float* logstd,
                 const float* action_masks, int deterministic, uint64_t seed, uint64_t row0, uint64_t rng_step,
                 const uint64_t* rng_step_dev, const float* forced_u, int a_w, float* actions, float* logp, void* stream);
-/* Its backward in one launch: dy [B, n_out] -> dz_out [B, n_out] (gradient at the Linear's output; may be NULL),
+/* The fused rollout of the general tower path: all buf->T steps of {policy tower (+ a shared network's value head, policy
+ * descriptor with two heads), ACTLayer sampling, env.step of a device-resident single-agent env (ORL_ENV_SYNTH /
+ * ORL_ENV_CARTPOLE), ReplayData.insert} in ONE launch - openrl/drivers/onpolicy_driver.py:154-203 for towers outside the
+ * default one.  Reads slot 0 of the buffer, fills slots 1..T (observations, masks), rewards, actions / log-probs [T][N][a_w]
+ * and, with a value head, value_preds[0..T).  A separate critic is evaluated by the caller afterwards in one
+ * orl_gen_mlp_fwd launch over all (T + 1) N rows.  Philox counters as orl_gen_act at rng_step0 + t; the env advances from
+ * its global step env_step0. */
+int orl_gen_rollout_fused(const orl_gen_mlp_desc* policy, const orl_head_desc* head, const float* logstd,
+                          const orl_buffer_ptrs* buf, float* value_preds, float* actions, float* action_log_probs,
+                          float* env_state, float* ep_stats, int env_kind, int episode_limit, uint64_t env_seed,
+                          uint64_t env_step0, uint64_t act_seed, uint64_t rng_step0, int a_w, void* stream);
+/* orl_gen_layer_fwd's backward in one launch: dy [B, n_out] -> dz_out [B, n_out] (gradient at the Linear's output; may be NULL),
  * col_partials[n_blocks][3 n_out] = [d gamma | d beta | d bias] per workgroup (sum them with orl_gen_colsum), and - for a
  * square layer, when dx_out != NULL - the input gradient dx_out [B, n_in] = dz W of the same row tile without re-reading
  * dz.  a / stats as written by orl_gen_layer_fwd (stats unused without gamma, a unused without gamma and activation). */

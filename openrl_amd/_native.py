@@ -19,7 +19,7 @@ ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL, ORL_ENV_MPE_SPREAD = 0, 1, 2, 3, 4
 ORL_GATHER_MAX = 12
 ORL_IPC_HANDLE_BYTES = 64
-ORL_VERSION = 300  # must equal include/orl_hip.h; checked against the loaded library
+ORL_VERSION = 302  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -180,6 +180,8 @@ _SIGNATURES = {
     "orl_ppo_apply_comm": (C.c_int, [_P, C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
                                      C.POINTER(AdamState), C.POINTER(AdamState), _P, _P, C.c_int64, C.c_uint64,
                                      C.c_uint64, _P, _P, C.c_double, _P]),
+    "orl_gen_rollout_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                        C.c_uint64, C.c_uint64, C.c_int, _P]),
     "orl_gemm": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
                            C.c_int, _P, _P]),
     "orl_row_fwd": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),

@@ -12,6 +12,7 @@
 #include "orl_common.h"
 #include "orl_mlp.h"
 #include "orl_heads.h"
+#include "orl_env.h"
 #include "orl_ttt.h"
 
 namespace orl {
@@ -137,48 +138,6 @@ __global__ void opponent_sample_kernel(int* __restrict__ opp_index, const uint8_
     k = k < n_filled - 1 ? k : n_filled - 1;
   }
   opp_index[n] = k < 0 ? 0 : k;
-}
-
-// --------------------------------------------------------------------------------------------------
-// Device-resident envs.  State lives in `env_state[N][W]`; one lane (q == 0) owns one env.
-// --------------------------------------------------------------------------------------------------
-constexpr int SYNTH_STATE_W = 4;     // {steps_in_episode, -, -, -}
-constexpr int CARTPOLE_STATE_W = 8;  // {x, x_dot, theta, theta_dot, steps_in_episode, episodes, -, -}
-
-// synthetic obs component block b (4 normals) for (env, global time t)
-__device__ inline void synth_obs_block(uint64_t seed, uint32_t env, uint64_t t, uint32_t b, float (&o)[4]) {
-  const u4 r = philox4x32_10(seed, env, 0x0B5E0000u + b, (uint32_t)t, (uint32_t)(t >> 32));
-  box_muller(r.x, r.y, o[0], o[1]);
-  box_muller(r.z, r.w, o[2], o[3]);
-}
-__device__ inline float synth_reward(uint64_t seed, uint32_t env, uint64_t t) {
-  const u4 r = philox4x32_10(seed, env, 0x4E3A0000u, (uint32_t)t, (uint32_t)(t >> 32));
-  return u01(r.x);
-}
-
-// CartPole-v1 (gymnasium/envs/classic_control/cartpole.py, euler integrator) in fp32.
-__device__ inline void cartpole_reset(uint64_t seed, uint32_t env, uint32_t episode, float (&s)[4]) {
-  const u4 r = philox4x32_10(seed, env, 0xCA470000u, episode, 0u);
-  s[0] = u01(r.x) * 0.1f - 0.05f;
-  s[1] = u01(r.y) * 0.1f - 0.05f;
-  s[2] = u01(r.z) * 0.1f - 0.05f;
-  s[3] = u01(r.w) * 0.1f - 0.05f;
-}
-__device__ inline bool cartpole_step(float (&s)[4], int action) {
-  const float gravity = 9.8f, masspole = 0.1f, total_mass = 1.1f, length = 0.5f, polemass_length = 0.05f,
-              force_mag = 10.0f, tau = 0.02f;
-  const float force = action == 1 ? force_mag : -force_mag;
-  const float costh = cosf(s[2]), sinth = sinf(s[2]);
-  const float temp = (force + polemass_length * s[3] * s[3] * sinth) / total_mass;
-  const float thetaacc =
-      (gravity * sinth - costh * temp) / (length * (4.0f / 3.0f - masspole * costh * costh / total_mass));
-  const float xacc = temp - polemass_length * thetaacc * costh / total_mass;
-  s[0] = s[0] + tau * s[1];
-  s[1] = s[1] + tau * xacc;
-  s[2] = s[2] + tau * s[3];
-  s[3] = s[3] + tau * thetaacc;
-  const float th_lim = 12.0f * 2.0f * 3.14159265358979323846f / 360.0f;
-  return (s[0] < -2.4f) || (s[0] > 2.4f) || (s[2] < -th_lim) || (s[2] > th_lim);
 }
 
 template <int ENV>
@@ -870,39 +829,10 @@ __global__ __launch_bounds__(256) void env_step_kernel(float* __restrict__ env_s
   if (tg_dev) tg += (uint64_t)*tg_dev;  // hipGraph replays: the host part is frozen, the device part advances
   float r;
   bool d;
-  if (ENV == ORL_ENV_SYNTH) {
-    float* st = env_state + (size_t)n * SYNTH_STATE_W;
-    r = synth_reward(seed, (uint32_t)n, tg);
-    float c = st[0] + 1.f;
-    d = c >= (float)episode_limit;
-    st[0] = d ? 0.f : c;
-    for (int b = 0; b < (D + 3) / 4; ++b) {
-      float o[4];
-      synth_obs_block(seed, (uint32_t)n, tg + 1, (uint32_t)b, o);
-      for (int k = 0; k < 4; ++k)
-        if (4 * b + k < D) obs[(size_t)n * D + 4 * b + k] = o[k];
-    }
-  } else {
-    float* st = env_state + (size_t)n * CARTPOLE_STATE_W;
-    float s[4] = {st[0], st[1], st[2], st[3]};
-    const bool term = cartpole_step(s, (int)actions[(size_t)n * a_w]);
-    const float steps = st[4] + 1.f;
-    d = term || steps >= (float)episode_limit;
-    r = 1.0f;
-    st[4] = d ? 0.f : steps;
-    if (d) {
-      st[5] += 1.f;
-      cartpole_reset(seed, (uint32_t)n, (uint32_t)st[5], s);
-    }
-    for (int k = 0; k < 4; ++k) { st[k] = s[k]; obs[(size_t)n * 4 + k] = s[k]; }
-  }
+  env_step_one<ENV>(env_state, ep_stats, n, D, seed, episode_limit, tg, ENV == ORL_ENV_SYNTH ? 0 : (int)actions[(size_t)n * a_w],
+                    obs + (size_t)n * D, r, d);
   rew[n] = r;
   done[n] = d ? 1 : 0;
-  if (ep_stats != nullptr) {
-    float* e = ep_stats + (size_t)n * 4;
-    e[0] += r; e[1] += 1.f;
-    if (d) { e[2] += e[0]; e[3] += 1.f; e[0] = 0.f; e[1] = 0.f; }
-  }
 }
 
 // --------------------------------------------------------------------------------------------------

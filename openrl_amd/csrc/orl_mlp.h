@@ -175,7 +175,7 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
     lds[tw.b1 + e] = theta[tl.ob1 + e];
     lds[tw.g1 + e] = theta[tl.og1 + e];
     lds[tw.be1 + e] = theta[tl.obe1 + e];
-    lds[tw.b2 + e] = theta[tl.ob2 + e];
+    if (!fold) lds[tw.b2 + e] = theta[tl.ob2 + e];  // (fold: ONE writer per slot - the folded-bias loop below)
     lds[tw.g2 + e] = theta[tl.og2 + e];
     lds[tw.be2 + e] = theta[tl.obe2 + e];
   }
@@ -200,7 +200,7 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
     for (int e = tid; e < no4 * HID; e += nthreads)
       lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] * (fold ? theta[tl.og2 + (e & 63)] : 1.f) : 0.f;
   for (int e = tid; e < no4; e += nthreads) {
-    lds[tw.b3 + e] = (e < tl.n_out) ? theta[tl.ob3 + e] : 0.f;
+    if (!fold || e >= tl.n_out) lds[tw.b3 + e] = (e < tl.n_out) ? theta[tl.ob3 + e] : 0.f;
     if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = (e < tl.n_out) ? theta[tl.ologstd + e] : 0.f;
   }
   if (fold) {

@@ -137,15 +137,20 @@ class OnPolicyDriver:
             raise ValueError("amd_rollout_mode=fused needs a device-resident env")
         recurrent = bool(getattr(self.trainer.algo_module, "recurrent", False))
         generic = bool(getattr(self.trainer.algo_module, "generic", False))  # general towers roll out stepwise
-        if mode == "fused" and generic:
-            raise ValueError("amd_rollout_mode=fused is built for the default tower only (hidden 64, layer_N 1, ReLU)")
+        # general towers: the fused rollout (orl_gen_rollout_fused) on the device-resident single-agent envs, feed-forward
+        self.fused_generic = (dev_env and generic and not recurrent
+                              and getattr(self.envs, "env_kind", None) in (ops.ENV_SYNTH, ops.ENV_CARTPOLE)
+                              and self.trainer.algo_module.fused_rollout_ready(self.buffer.data))
+        if mode == "fused" and generic and not self.fused_generic:
+            raise ValueError("amd_rollout_mode=fused with general towers: feed-forward towers of widths <= 256 on the "
+                             "device synthetic / CartPole envs")
         # recurrent policies: fused on envs orl_rnn_rollout_fused steps in-kernel (the device MPE simple_spread)
         self.fused_rnn = (dev_env and recurrent and not generic
                           and bool(getattr(self.envs, "supports_fused_rnn_rollout", False)))
         if mode == "fused" and recurrent and not self.fused_rnn:
             raise ValueError("amd_rollout_mode=fused with a recurrent policy is built for the device MPE env only")
-        can_fuse = self.fused_rnn or (dev_env and bool(getattr(self.envs, "supports_fused_rollout", True))
-                                      and not recurrent and not generic)
+        can_fuse = self.fused_rnn or self.fused_generic or (
+            dev_env and bool(getattr(self.envs, "supports_fused_rollout", True)) and not recurrent and not generic)
         if mode == "fused" and not can_fuse:
             raise ValueError("amd_rollout_mode=fused is not built for env %r" % getattr(self.envs, "env_name", "?"))
         self.fused = can_fuse and mode in ("auto", "fused") and not per_step_cb
@@ -248,6 +253,15 @@ class OnPolicyDriver:
     def _fused_rollout(self) -> None:
         d = self.buffer.data
         mod = self.trainer.algo_module
+        if self.fused_generic:  # general towers: policy + sampling + env + insert in one launch, the critic in a second
+            env = self.envs
+            mod.rollout_fused(d, env, self._next_value)
+            env.global_step += self.episode_length
+            self._have_next_value = not mod.share_model
+            d.step = 0
+            d._adv_fresh = False
+            self.agent.num_time_steps += env.parallel_env_num * self.episode_length
+            return
         p, c = mod.models["policy"], mod.models["critic"]
         env = self.envs
         f = nat.fptr

@@ -657,6 +657,35 @@ class GenericPPOModule(PPOModule):
             gw = self._ws[key] = GruWorkspace(net, L, N, training)
         return gw
 
+    # ------------------------------------------------------------------ fused rollout (device envs, feed-forward)
+    def fused_rollout_ready(self, data) -> bool:
+        """True when ``orl_gen_rollout_fused`` can run this module's rollouts on ``data``: feed-forward towers whose widths
+        the one-launch tower takes, single-agent buffers whose critic observations alias the policy's."""
+        if self.recurrent or data.num_agents != 1 or data.critic_obs is not data.policy_obs:
+            return False
+        pn, cn = self.policy_net, self.critic_net
+        if pn.mlp_desc(("act", "v_out") if self.share_model else ("act",)) is None:
+            return False
+        return self.share_model or cn.mlp_desc(("v_out",)) is not None
+
+    @torch.no_grad()
+    def rollout_fused(self, data, env, next_value_out) -> None:
+        """One whole rollout (onpolicy_driver.py:154-203) in two launches: ``orl_gen_rollout_fused`` (policy tower, sampling,
+        env.step, insert for all episode_length steps) and, for separate networks, ONE critic forward over all T + 1
+        observation slots - slot T's value is the bootstrap value of ``compute_returns``."""
+        pn, cn = self.policy_net, self.critic_net
+        T, N = data.episode_length, data.n_rollout_threads
+        desc = pn.mlp_desc(("act", "v_out") if self.share_model else ("act",))
+        ops_gen.rollout_fused(desc, pn.head_desc, self._logstd(), data.buffer_ptrs(),
+                              data.value_preds if self.share_model else None, data.actions, data.action_log_probs,
+                              env.env_state, env.ep_stats, env.env_kind, env.episode_limit, env.seed, env.global_step,
+                              self.act_seed, self.rng_step, self.act_width, self.device)
+        self.rng_step += T
+        if not self.share_model:
+            rows = (T + 1) * N
+            ops_gen.mlp_fwd(cn.mlp_desc(("v_out",)), data.critic_obs.view(rows, self.Dc), data.value_preds.view(rows, 1), None)
+            next_value_out.copy_(data.value_preds[T])
+
     def _logstd(self):
         h = self.policy_net.heads["act"]
         return self.policy_net.v(h["logstd"], h["n_ls"]) if "logstd" in h else None

@@ -126,6 +126,19 @@ def act_step(policy_desc, obs, critic_desc, critic_obs, values, head: HeadDesc, 
     nat.check(rc, "orl_gen_act")
 
 
+def rollout_fused(policy_desc, head: HeadDesc, logstd, buf_ptrs, value_preds, actions, logp, env_state, ep_stats,
+                  env_kind: int, episode_limit: int, env_seed: int, env_step0: int, act_seed: int, rng_step0: int,
+                  a_w: int, device) -> None:
+    """All episode_length rollout steps of a general policy tower on a device-resident single-agent env in one launch
+    (``orl_gen_rollout_fused``); ``value_preds`` only for a shared network (policy descriptor with two heads)."""
+    dev = nat.require_gpu(device)
+    rc = _lib().orl_gen_rollout_fused(C.byref(policy_desc), C.byref(head), fptr(logstd), C.byref(buf_ptrs),
+                                      fptr(value_preds), fptr(actions), fptr(logp), fptr(env_state), fptr(ep_stats),
+                                      env_kind, episode_limit, env_seed & (2 ** 64 - 1), env_step0 & (2 ** 64 - 1),
+                                      act_seed & (2 ** 64 - 1), rng_step0 & (2 ** 64 - 1), a_w, stream_ptr(dev))
+    nat.check(rc, "orl_gen_rollout_fused")
+
+
 def layer_bwd(dy, a, stats, gamma, act: int, W, dz_out, dx_out, col_partials) -> int:
     """dy -> dz (+ dx = dz @ W for a square layer when ``dx_out`` is given) and the [d gamma | d beta | d bias] partial
     rows; returns their count."""

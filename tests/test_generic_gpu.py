@@ -541,7 +541,7 @@ def test_multidiscrete_policy_learns_end_to_end_on_a_host_env():
                                   ["--use_share_model", "true"]])
 def test_general_towers_train_cartpole_end_to_end_and_checkpoint(argv, tmp_path):
     """make -> PPONet -> PPOAgent.train on the device-resident CartPole with a non-default tower / the shared model
-    (stepwise rollout, hipGraph replay), then save -> load -> identical greedy actions."""
+    (the fused general rollout, orl_gen_rollout_fused), then save -> load -> identical greedy actions."""
     from openrl_amd.configs.config import default_cfg
     from openrl_amd.envs.common import make
     from openrl_amd.modules.common import PPONet
@@ -553,7 +553,7 @@ def test_general_towers_train_cartpole_end_to_end_and_checkpoint(argv, tmp_path)
     assert net.module.generic
     agent = PPOAgent(net)
     agent.train(total_time_steps=256 * 32 * 25)
-    assert not agent.driver.fused
+    assert agent.driver.fused and agent.driver.fused_generic
     stats = env.statistics(agent.driver.buffer) if hasattr(env, "statistics") else {}
     obs = torch.randn(64, 4, device=DEV) * 0.05
     a1, _ = net.module.act(obs, None, None, deterministic=True)
@@ -687,3 +687,72 @@ def test_model_dict_with_the_stock_network_classes_builds_the_usual_towers():
 
     with pytest.raises(NotImplementedError):
         PPONet(make("CartPole-v1", env_num=4, device=DEV), cfg=default_cfg([]), device=DEV, model_dict={"policy": Custom})
+
+
+@pytest.mark.parametrize("argv,env_id,kw,N,T", [
+    (["--hidden_size", "128"], "SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=7), 50, 23),
+    (["--hidden_size", "128", "--layer_N", "2", "--activation_id", "0", "--use_feature_normalization", "true"],
+     "SyntheticFixedStep-v0", dict(obs_dim=17, episode_limit=9, action_space="box6"), 70, 21),
+    (["--hidden_size", "32", "--activation_id", "3"], "CartPole-v1", {}, 50, 23),
+    (["--use_share_model", "true", "--hidden_size", "48"], "SyntheticFixedStep-v0", dict(obs_dim=5, episode_limit=6), 40, 11),
+    (["--hidden_size", "256"], "SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=200), 1024, 32),
+])
+def test_fused_general_rollout_equals_stepwise_rollout(argv, env_id, kw, N, T):
+    """``orl_gen_rollout_fused`` (all steps of {general policy tower, sampling, env.step, insert} in ONE launch + ONE
+    batched critic forward over the T + 1 slots) against the stepwise route (``orl_gen_act`` + ``orl_env_step`` +
+    ``orl_buffer_insert`` per step): same Philox counters and env streams, the same tile arithmetic compiled in another
+    translation unit (a few ulp on float fields; a sampled class may flip only on a CDF edge)."""
+    from openrl_amd import spaces
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+    from openrl_amd.utils.util import set_seed
+
+    box = None
+    if isinstance(kw.get("action_space"), str):
+        box = int(kw["action_space"][3:])
+        kw = dict(kw, action_space=spaces.Box(-1.0, 1.0, (box,)))
+    bufs = []
+    for mode in ("fused", "stepwise"):
+        cfg = default_cfg(["--seed", "3", "--episode_length", str(T), "--amd_rollout_mode", mode] + argv)
+        env = make(env_id, env_num=N, device=DEV, seed=3, **kw)
+        set_seed(3)
+        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+        assert net.module.generic
+
+        class _Agent:
+            num_time_steps = 0
+
+        cfg.num_env_steps = N * T
+        trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=DEV)
+        buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=DEV)
+        agent = _Agent()
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, agent)
+        assert drv.fused == (mode == "fused")
+        drv.reset_and_buffer_init()
+        drv.actor_rollout()
+        drv.compute_returns()
+        assert agent.num_time_steps == N * T and env.global_step == T and net.module.rng_step == T
+        bufs.append(buf.data)
+    a, b = bufs
+    act_a, act_b = a.actions.cpu().numpy(), b.actions.cpu().numpy()
+    if box is not None:
+        np.testing.assert_allclose(act_a, act_b, rtol=1e-5, atol=2e-6)
+        same = np.ones_like(act_a, dtype=bool)
+    else:
+        same = act_a == act_b
+    assert same.mean() >= 0.999, same.mean()
+    if env_id.startswith("Synthetic"):
+        for f in ("policy_obs", "rewards", "masks", "active_masks", "bad_masks"):
+            assert np.array_equal(getattr(a, f).cpu().numpy(), getattr(b, f).cpu().numpy()), f
+        np.testing.assert_allclose(a.value_preds.cpu().numpy(), b.value_preds.cpu().numpy(), rtol=2e-5, atol=2e-6)
+        lp_a, lp_b = a.action_log_probs.cpu().numpy(), b.action_log_probs.cpu().numpy()
+        np.testing.assert_allclose(lp_a[same], lp_b[same], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(a.returns.cpu().numpy(), b.returns.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    else:
+        for f in ("policy_obs", "value_preds", "action_log_probs", "rewards", "masks"):
+            x, y = getattr(a, f).cpu().numpy()[:3], getattr(b, f).cpu().numpy()[:3]
+            np.testing.assert_allclose(x, y, rtol=2e-5, atol=2e-6, err_msg=f)
