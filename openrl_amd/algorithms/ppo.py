@@ -550,9 +550,13 @@ class PPOAlgorithm(BaseAlgorithm):
         # no device->host sync here: the averages stay on the device until somebody reads the dict (logging every
         # log_interval iterations, tests), so the host can enqueue the next rollout while this update still runs
         keys = self.info_keys
-        scale = torch.full((len(keys),), 1.0 / float(num_updates), dtype=torch.float32, device=self.device)
-        if self.use_joint_action_loss:  # every agent row (and action dim) of a (step, chunk) carried the joint term
-            scale[1] /= float(buffer.num_agents * buffer.act_shape)
+        skey = (len(keys), num_updates, buffer.num_agents * buffer.act_shape if self.use_joint_action_loss else 0)
+        if getattr(self, "_info_scale_key", None) != skey:  # built once: two launches less per update
+            scale = torch.full((len(keys),), 1.0 / float(num_updates), dtype=torch.float32, device=self.device)
+            if self.use_joint_action_loss:  # every agent row (and action dim) of a (step, chunk) carried the joint term
+                scale[1] /= float(buffer.num_agents * buffer.act_shape)
+            self._info_scale, self._info_scale_key = scale, skey
+        scale = self._info_scale
         watch = getattr(self, "_comm_watch", None)
         if watch is None:
             return DeviceTrainInfo(keys, self._info[:len(keys)] * scale)
