@@ -96,7 +96,7 @@ class RnnRolloutArgs(C.Structure):
                 ("obs_critic_out", C.c_void_p), ("next_value", C.c_void_p), ("env_kind", C.c_int32),
                 ("world_length", C.c_int32), ("deterministic", C.c_int32), ("reserved", C.c_int32),
                 ("env_seed", C.c_uint64), ("act_seed", C.c_uint64), ("rng_step0", C.c_uint64),
-                ("rng_step_dev", C.c_void_p), ("sync_flags", C.c_void_p)]
+                ("rng_step_dev", C.c_void_p), ("sync_flags", C.c_void_p), ("env_step0", C.c_uint64)]
 
 
 class HeadDesc(C.Structure):

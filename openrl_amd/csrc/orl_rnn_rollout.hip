@@ -24,6 +24,7 @@
 #include "orl_heads.h"
 #include "orl_rnn.h"
 #include "orl_mpe.h"
+#include "orl_env.h"
 
 namespace orl {
 
@@ -37,6 +38,7 @@ struct RnnRolloutArgs {
   uint64_t env_seed, act_seed, rng_step0;
   const unsigned long long* rng_dev;
   int* flags;  // [n_pairs + 1]: steps published by policy workgroup b; [n_pairs] = error word (chase timed out)
+  uint64_t env_step0;  // single-agent envs: the env's global step at the first rollout step
 };
 
 constexpr unsigned long long CHASE_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
@@ -272,6 +274,86 @@ __device__ __forceinline__ void rnn_rollout_critic_body(const RnnRolloutArgs& A,
   }
 }
 
+// Single-agent device envs (synthetic fixed-step env, CartPole): one wave = one 16-env tile for the whole rollout - hidden
+// state in registers, the tile's observations in a wave-private LDS slab, the env stepped by lane (j, q == 0) with the
+// shared device functions of orl_env.h.  Waves are independent (no workgroup barrier after the tower image is staged);
+// the critic follows in a second launch (rnn_rollout_critic_kernel) over the stored observations.
+template <int NO, int HEAD, int ENV>
+__global__ __launch_bounds__(256, 1) void rnn_rollout_single_policy_kernel(RnnRolloutArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const orl_buffer_ptrs& b = A.buf;
+  const RnnLayout tl(A.pnet);
+  const int D = tl.D;
+  const RnnLds tw(D, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN);
+  stage_rnn_tower(smem, A.ptheta, tl, tw, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const float* lw = smem;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4, nwv = blockDim.x >> 6;
+  float* slab = smem + tw.total + wave * (TILE_B * 64 + TILE_B);  // [16][DP] observations + [16] done flags
+  float* s_done = slab + TILE_B * 64;
+  const int N = b.N, T = b.T, DP = tw.DP;
+  const int n_out = tl.n_out;
+  const int a_w = (HEAD == ORL_HEAD_CATEGORICAL) ? 1 : n_out;
+  const int tile = blockIdx.x * nwv + wave;
+  const int env = tile * TILE_B + j;
+  if (tile * TILE_B >= N) return;
+  const bool ok = env < N;
+  const int row = ok ? env : 0;
+  const uint64_t rng0 = A.rng_step0 + (A.rng_dev ? *A.rng_dev : 0ull);
+  for (int e = l; e < TILE_B * DP; e += 64) {
+    const int jj = e / DP, k = e - jj * DP, nn = tile * TILE_B + jj;
+    slab[e] = (nn < N && k < D) ? b.policy_obs[(size_t)nn * D + k] : 0.f;
+  }
+  f32x4 h[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(A.hp + (size_t)row * HID + 16 * m + 4 * q);
+  float mk = b.masks[row];
+  wave_lds_fence();
+  for (int t = 0; t < T; ++t) {
+    f32x4 hin[4], hnew[4], n3[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hin[m] = h[m] * mk;
+    const float* xrow = slab + j * DP;
+    rnn_tower_fwd_lds(lw, tw, [&](int s) -> float { return xrow[4 * s + q]; }, hin, hnew, n3, j, q);
+    float hd[NO], act_o[NO], lp_o[NO];
+    head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, n3, q, hd);
+    sample_head<NO, HEAD>(hd, n_out, lw + tw.logstd, nullptr, nullptr, A.deterministic, A.act_seed, (uint64_t)row,
+                          rng0 + (uint64_t)t, act_o, lp_o);
+    wave_lds_fence();  // every lane of the wave is done reading this step's observations
+    if (q == 0 && ok) {
+#pragma unroll
+      for (int c = 0; c < NO; ++c)
+        if (c < a_w) {
+          A.actions[((size_t)t * N + row) * a_w + c] = act_o[c];
+          A.logp[((size_t)t * N + row) * a_w + c] = lp_o[c];
+        }
+      float r;
+      bool d;
+      float* orow = slab + j * DP;  // the next observation lands in the slab (next step's fc1) and in slot t + 1
+      env_step_one<ENV>(A.env_state, A.ep_stats, env, D, A.env_seed, A.world_length, A.env_step0 + (uint64_t)t,
+                        ENV == ORL_ENV_SYNTH ? 0 : (int)act_o[0], orow, r, d);
+      const size_t s1 = (size_t)(t + 1) * N + row;
+      for (int k = 0; k < D; ++k) b.policy_obs[s1 * D + k] = orow[k];
+      b.rewards[(size_t)t * N + row] = r;
+      b.masks[s1] = d ? 0.f : 1.f;
+      b.active_masks[s1] = 1.f;
+      b.bad_masks[s1] = 1.f;
+      if (b.K > 0 && b.action_masks != nullptr)
+        for (int k = 0; k < b.K; ++k) b.action_masks[s1 * b.K + k] = 1.f;
+      s_done[j] = d ? 1.f : 0.f;
+    }
+    wave_lds_fence();
+    // masks[t + 1] = 0 and rnn_states = 0 where the env finished (onpolicy_driver.py:100-113)
+    mk = (ok && s_done[j] != 0.f) ? 0.f : 1.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) h[m] = hnew[m] * mk;
+    if (ok) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) *(f32x4*)(A.hp + ((size_t)(t + 1) * N + row) * HID + 16 * m + 4 * q) = h[m];
+    }
+  }
+}
+
 template <int NO>
 __global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_policy_kernel(RnnRolloutArgs A) {
   rnn_rollout_policy_body<NO, false>(A, (int)blockIdx.x);
@@ -298,9 +380,64 @@ extern "C" {
 int orl_rnn_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
                           const orl_rnn_rollout_args* a, void* stream) {
   ORL_REQUIRE(pnet && ptheta && cnet && ctheta && a, "orl_rnn_rollout_fused: null argument");
-  ORL_REQUIRE(a->env_kind == ORL_ENV_MPE_SPREAD, "orl_rnn_rollout_fused: env kind %d not built (MPE simple_spread only)",
-              a->env_kind);
   const orl_buffer_ptrs& b = a->buf;
+  if (a->env_kind == ORL_ENV_SYNTH || a->env_kind == ORL_ENV_CARTPOLE) {
+    // single-agent device envs: policy launch (one wave per 16-env tile) + the generic critic sweep
+    ORL_REQUIRE(b.A == 1 && b.N > 0 && b.T > 0 && b.Dp >= 1 && b.Dp <= 64 && b.Dc == b.Dp && b.policy_obs &&
+                    (b.critic_obs == b.policy_obs) && b.rewards && b.masks && b.bad_masks && b.active_masks,
+                "orl_rnn_rollout_fused: single-agent envs need one shared observation array of width <= 64");
+    ORL_REQUIRE(pnet->hidden == HID && cnet->hidden == HID && pnet->obs_dim == b.Dp && cnet->obs_dim == b.Dp &&
+                    cnet->n_out == 1 && pnet->n_out >= 1 && pnet->n_out <= 16 &&
+                    (pnet->head_kind == ORL_HEAD_CATEGORICAL || pnet->head_kind == ORL_HEAD_GAUSSIAN),
+                "orl_rnn_rollout_fused: towers do not match the buffer (obs %d, hidden 64)", b.Dp);
+    ORL_REQUIRE(a->env_kind != ORL_ENV_CARTPOLE || (b.Dp == 4 && pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 2),
+                "orl_rnn_rollout_fused: CartPole needs 4-d observations and a Discrete(2) head");
+    ORL_REQUIRE(a->value_preds && a->actions && a->action_log_probs && a->rnn_states && a->rnn_states_critic &&
+                    a->env_state && a->world_length > 0, "orl_rnn_rollout_fused: null buffer / env pointer");
+    RnnRolloutArgs A;
+    A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.buf = b;
+    A.value_preds = a->value_preds; A.actions = a->actions; A.logp = a->action_log_probs; A.hp = a->rnn_states;
+    A.hc = a->rnn_states_critic; A.env_state = a->env_state; A.ep_stats = a->ep_stats; A.obs_p_out = nullptr;
+    A.obs_c_out = nullptr; A.next_value = a->next_value; A.world_length = a->world_length;
+    A.deterministic = a->deterministic; A.env_seed = a->env_seed; A.act_seed = a->act_seed; A.rng_step0 = a->rng_step0;
+    A.rng_dev = (const unsigned long long*)a->rng_step_dev; A.flags = nullptr; A.env_step0 = a->env_step0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool gauss = pnet->head_kind == ORL_HEAD_GAUSSIAN;
+    const RnnLds twp(b.Dp, pnet->n_out, gauss), twc(b.Dp, 1, false);
+    const int nwv = 4;
+    const size_t lds_p = (size_t)(twp.total + nwv * (TILE_B * 64 + TILE_B)) * sizeof(float);
+    const size_t lds_c = (size_t)(twc.total + 3 * TILE_B * 64) * sizeof(float);
+    ORL_REQUIRE(lds_p <= 160 * 1024 && lds_c <= 160 * 1024, "orl_rnn_rollout_fused: tower image exceeds the LDS");
+    const int n_tiles = (b.N + TILE_B - 1) / TILE_B;
+    const dim3 grid((unsigned)((n_tiles + nwv - 1) / nwv));
+    const int no = pnet->n_out;
+#define ORL_RS(NOX, HDX, ENVX)                                                                                              \
+  do {                                                                                                                      \
+    (void)hipFuncSetAttribute((const void*)rnn_rollout_single_policy_kernel<NOX, HDX, ENVX>,                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);                                      \
+    hipLaunchKernelGGL((rnn_rollout_single_policy_kernel<NOX, HDX, ENVX>), grid, dim3(64 * nwv), lds_p, s, A);             \
+  } while (0)
+    if (a->env_kind == ORL_ENV_CARTPOLE) ORL_RS(2, ORL_HEAD_CATEGORICAL, ORL_ENV_CARTPOLE);
+    else if (!gauss) {
+      if (no <= 2) ORL_RS(2, ORL_HEAD_CATEGORICAL, ORL_ENV_SYNTH);
+      else if (no <= 8) ORL_RS(8, ORL_HEAD_CATEGORICAL, ORL_ENV_SYNTH);
+      else ORL_RS(16, ORL_HEAD_CATEGORICAL, ORL_ENV_SYNTH);
+    } else {
+      if (no <= 2) ORL_RS(2, ORL_HEAD_GAUSSIAN, ORL_ENV_SYNTH);
+      else if (no <= 8) ORL_RS(8, ORL_HEAD_GAUSSIAN, ORL_ENV_SYNTH);
+      else ORL_RS(16, ORL_HEAD_GAUSSIAN, ORL_ENV_SYNTH);
+    }
+#undef ORL_RS
+    int rc = launch_status("orl_rnn_rollout_fused(policy, single-agent)");
+    if (rc) return rc;
+    (void)hipFuncSetAttribute((const void*)rnn_rollout_critic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+    int cg = (n_tiles + 1) / 2;
+    if (cg > 1024) cg = 1024;
+    hipLaunchKernelGGL(rnn_rollout_critic_kernel, dim3(cg), dim3(128), lds_c, s, A);
+    return launch_status("orl_rnn_rollout_fused(critic)");
+  }
+  ORL_REQUIRE(a->env_kind == ORL_ENV_MPE_SPREAD, "orl_rnn_rollout_fused: env kind %d not built (MPE simple_spread, synthetic, CartPole)",
+              a->env_kind);
   ORL_REQUIRE(b.A == MPE_A && b.Dp == MPE_OBS && b.Dc == MPE_COBS && b.N > 0 && b.T > 0,
               "orl_rnn_rollout_fused: buffer (A %d, Dp %d, Dc %d) is not simple_spread's (3, 18, 54)", b.A, b.Dp, b.Dc);
   ORL_REQUIRE(pnet->hidden == HID && cnet->hidden == HID && pnet->obs_dim == MPE_OBS && cnet->obs_dim == MPE_COBS &&
@@ -317,7 +454,7 @@ int orl_rnn_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const o
   A.obs_c_out = a->obs_critic_out; A.next_value = a->next_value; A.world_length = a->world_length;
   A.deterministic = a->deterministic; A.env_seed = a->env_seed; A.act_seed = a->act_seed; A.rng_step0 = a->rng_step0;
   A.rng_dev = (const unsigned long long*)a->rng_step_dev;
-  A.flags = a->sync_flags;
+  A.flags = a->sync_flags; A.env_step0 = 0;
   hipStream_t s = (hipStream_t)stream;
   const RnnLds twp(MPE_OBS, 5, false), twc(MPE_COBS, 1, false);
   const size_t lds_p = (size_t)(twp.total + MPE_A * TILE_B * OBS_S + MPE_A * TILE_B + 2 * TILE_B) * sizeof(float);

@@ -145,8 +145,13 @@ class OnPolicyDriver:
             raise ValueError("amd_rollout_mode=fused with general towers: feed-forward towers of widths <= 256 on the "
                              "device synthetic / CartPole envs")
         # recurrent policies: fused on envs orl_rnn_rollout_fused steps in-kernel (the device MPE simple_spread)
+        # ... and on the single-agent device envs (synthetic, CartPole: one shared observation array of width <= 64)
+        single_rnn = (getattr(self.envs, "env_kind", None) in (ops.ENV_SYNTH, ops.ENV_CARTPOLE)
+                      and self.buffer.data.num_agents == 1 and self.buffer.data.critic_obs is self.buffer.data.policy_obs
+                      and self.buffer.data.Dp <= 64)
         self.fused_rnn = (dev_env and recurrent and not generic
-                          and bool(getattr(self.envs, "supports_fused_rnn_rollout", False)))
+                          and (bool(getattr(self.envs, "supports_fused_rnn_rollout", False)) or single_rnn))
+        self._fused_rnn_single = self.fused_rnn and single_rnn
         if mode == "fused" and recurrent and not self.fused_rnn:
             raise ValueError("amd_rollout_mode=fused with a recurrent policy is built for the device MPE env only")
         can_fuse = self.fused_rnn or self.fused_generic or (
@@ -271,18 +276,21 @@ class OnPolicyDriver:
             a.value_preds, a.actions, a.action_log_probs = f(d.value_preds), f(d.actions), f(d.action_log_probs)
             a.rnn_states, a.rnn_states_critic = f(d.rnn_states), f(d.rnn_states_critic)
             a.env_state, a.ep_stats = f(env.env_state), f(env.ep_stats)
-            a.obs_policy_out, a.obs_critic_out = f(env.obs["policy"]), f(env.obs["critic"])
+            if not self._fused_rnn_single:
+                a.obs_policy_out, a.obs_critic_out = f(env.obs["policy"]), f(env.obs["critic"])
             a.next_value = f(self._next_value)
             a.env_kind, a.world_length, a.deterministic = env.env_kind, env.episode_limit, 0
             a.env_seed, a.act_seed = env.seed & (2 ** 64 - 1), mod.act_seed & (2 ** 64 - 1)
             a.rng_step0 = int(mod.rng_step)
-            if bool(getattr(self.cfg, "amd_rnn_rollout_chase", True)):  # critic in the same launch, one step behind
+            a.env_step0 = int(env.global_step) & (2 ** 64 - 1)
+            # critic in the same launch, one step behind (the MPE kernel; single-agent envs: policy launch + critic sweep)
+            if bool(getattr(self.cfg, "amd_rnn_rollout_chase", True)) and not self._fused_rnn_single:
                 if self._chase_flags is None:
                     self._chase_flags = torch.zeros((d.n_rollout_threads + 15) // 16 + 1, dtype=torch.int32,
                                                     device=self.device)
                 a.sync_flags = nat.ptr(self._chase_flags)
             ops_rnn.rnn_rollout_fused(p.net, p.theta, c.net, c.theta, a, self.device)
-            if self._chase_flags is not None:  # the kernel's error word: looked at (without a sync) next rollout / at the end
+            if self._chase_flags is not None and not self._fused_rnn_single:  # the kernel's error word: looked at (without a sync) next rollout / at the end
                 if self._chase_watch is None:
                     self._chase_watch = nat.DeviceErrorWatch(
                         "orl_rnn_rollout_fused: a critic workgroup's bounded wait for its policy workgroup timed out - "
