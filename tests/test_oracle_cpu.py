@@ -274,3 +274,9 @@ def test_mixed_actlayer_oracle_matches_the_reference():
     np.testing.assert_allclose(float(ent0), float(g["entropy_nomask"]), rtol=1e-6)
     np.testing.assert_allclose(a.numpy(), g["det_actions"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(lp.numpy(), g["det_logp"], rtol=1e-6, atol=1e-6)
+
+
+def test_oracle_replays_the_full_size_cfg5_reference_update():
+    """BASELINE.json configs[4] at full size (4096 x 200 rows, obs 18, Discrete(9) with random legal-move masks, 10
+    epochs): the oracle restatement lands on the REAL reference's outputs - ~40 s of torch CPU."""
+    _oracle_full_general("train_cfg5_full")

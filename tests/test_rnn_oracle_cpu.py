@@ -165,3 +165,42 @@ def test_general_recurrent_jrpo_oracle_replays_the_reference():
     np.testing.assert_allclose([info[k] for k in KEYS], g["train_info"], rtol=3e-5, atol=1e-6)
     np.testing.assert_allclose(pt.numpy(), g["theta_p1"], rtol=1e-4, atol=3e-6)
     np.testing.assert_allclose(ct.numpy(), g["theta_c1"], rtol=1e-4, atol=3e-6)
+
+
+def test_rnn_oracle_replays_the_full_size_cfg4_reference_update():
+    """BASELINE.json configs[3] at full size (2048 envs x 3 agents x 25 steps = 76 800 chunks of 2, Dict obs 18 / 54,
+    Discrete(5), GRU, 10 epochs): the recurrent oracle restatement lands on the REAL reference's outputs (a few seconds:
+    the oracle batches the chunk loop the reference walks in Python)."""
+    import numpy as np
+    import torch
+
+    from oracle import ppo_oracle as po
+    from oracle import rnn_oracle as ro
+    from oracle.fixtures import synth_update_buffer_general
+    from tests import helpers as H
+
+    g = H.load_golden("train_cfg4_full")
+    N, T, Dp, Dc, n_act, A, seed, legal, rec = (int(x) for x in g["shape"])
+    assert rec and str(g["kind"]) == "discrete"
+    cfg = H.case_cfg(g)
+    hp = po.hyper_from_cfg(cfg)
+    buf = synth_update_buffer_general(seed, N, T, Dp, Dc, "discrete", n_act, A, bool(legal), cfg.hidden_size)
+    vn = po.ValueNormOracle()
+    nv = buf.pop("next_value")
+    buf["returns"], buf["value_preds"] = po.compute_returns(buf["rewards"], buf["value_preds"], buf["masks"],
+                                                            buf["bad_masks"], nv, cfg.gamma, cfg.gae_lambda,
+                                                            value_normalizer=vn)
+    probe = np.array([buf["returns"][t, n, a, 0] for t, n, a in g["returns_probe_idx"]])
+    np.testing.assert_array_equal(probe, g["returns_probe"])
+    pspec, cspec = ro.RnnTowerSpec(Dp, n_act, po.HEAD_CATEGORICAL), ro.RnnTowerSpec(Dc, 1, po.HEAD_VALUE)
+    ptheta, ctheta = torch.tensor(g["theta_p0"]).clone(), torch.tensor(g["theta_c0"]).clone()
+    padam = po.AdamOracle(ptheta.numel(), cfg.lr, cfg.opti_eps, cfg.weight_decay)
+    cadam = po.AdamOracle(ctheta.numel(), cfg.critic_lr, cfg.opti_eps, cfg.weight_decay)
+    torch.manual_seed(int(g["perm_seed"]))
+    info, _, _ = ro.train_ppo(hp, pspec, ptheta, cspec, ctheta, padam, cadam, vn, buf, cfg.ppo_epoch, cfg.num_mini_batch,
+                              cfg.data_chunk_length)
+    keys = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
+    np.testing.assert_allclose([info[k] for k in keys], g["train_info"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(ptheta.numpy(), g["theta_p1"], rtol=3e-4, atol=3e-6)
+    np.testing.assert_allclose(ctheta.numpy(), g["theta_c1"], rtol=3e-4, atol=3e-6)
+    np.testing.assert_allclose(vn.state(), g["vn_state1"], rtol=1e-5)
