@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--hidden_size", type=int, default=128)
     ap.add_argument("--layer_N", type=int, default=1)
     ap.add_argument("--share", action="store_true")
+    ap.add_argument("--gen_update", default="fused", choices=["fused", "layerwise"])
+    ap.add_argument("--activation_id", type=int, default=1)
+    ap.add_argument("--obs_dim", type=int, default=4)
     a = ap.parse_args()
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers import NormalReplayBuffer
@@ -32,11 +35,12 @@ def main():
 
     dev, N, T = "cuda:0", a.envs, a.T
     argv = ["--episode_length", str(T), "--ppo_epoch", "10", "--amd_perm_mode", "device", "--log_interval", "1000000",
-            "--hidden_size", str(a.hidden_size), "--layer_N", str(a.layer_N)]
+            "--hidden_size", str(a.hidden_size), "--layer_N", str(a.layer_N), "--amd_gen_update", a.gen_update,
+            "--activation_id", str(a.activation_id)]
     if a.share:
         argv += ["--use_share_model", "true"]
     cfg = default_cfg(argv)
-    env = make("SyntheticFixedStep-v0", env_num=N, obs_dim=4, episode_limit=200, device=dev)
+    env = make("SyntheticFixedStep-v0", env_num=N, obs_dim=a.obs_dim, episode_limit=200, device=dev)
     net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=N)
     cfg.num_env_steps = N * T * (a.steps + a.warmup)
 
@@ -66,7 +70,7 @@ def main():
         t_upd += time.perf_counter() - tb
     dt = time.perf_counter() - t0
     print(json.dumps({"bench": "generic_tower_path", "envs": N, "rollout_len": T, "hidden_size": a.hidden_size,
-                      "layer_N": a.layer_N, "share_model": a.share, "generic": bool(getattr(net.module, "generic", False)),
+                      "layer_N": a.layer_N, "share_model": a.share, "gen_update": a.gen_update, "generic": bool(getattr(net.module, "generic", False)),
                       "env_steps_per_s": N * T * a.steps / dt, "ms_per_iteration": dt / a.steps * 1e3,
                       "rollout": "fused" if drv.fused else "graph" if drv._graph is not None else "stepwise",
                       "ms_rollout": t_roll / a.steps * 1e3, "ms_update": t_upd / a.steps * 1e3}))

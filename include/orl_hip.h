@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 302 /* 0.3.2: orl_gen_rollout_fused, ORL_HEAD_MIXED, hparams.reserved & 4; 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 303 /* 0.3.3: orl_gt_* (cross-layer fused general towers); 0.3.2: orl_gen_rollout_fused, ORL_HEAD_MIXED, hparams.reserved & 4; 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -759,6 +759,41 @@ int orl_gen_row_affine(const float* a, const float* b, const float* row_scale, c
 /* train_info_accum {value_loss, policy_loss, dist_entropy, -, -, ratio} += the reduced loss sums / denominators. */
 int orl_gen_info(const float* policy_sums, const float* value_sums, const float* den, const orl_ppo_hparams* hp,
                  float entropy_div, float ratio_div, float* train_info_accum, void* stream);
+
+/* ---- cross-layer fused general towers (csrc/orl_gen_tower.{h,hip}) ----------------------------------------------------
+ * MLPBase.forward (openrl/modules/networks/utils/mlp.py:8-48, 100-180: optional feature LayerNorm, fc1, layer_N - 1 fc2
+ * clones, fc3 - each nn.Sequential(Linear, [activation], LayerNorm)) + the Linear head(s) on its features
+ * (ACTLayer's action_out / v_out: networks/policy_network.py:130-162, value_network.py:113-136,
+ * policy_value_network.py:34-110), forward and backward, for hidden_size 64 / 128 with the activations kept on chip:
+ * what orl_gen_layer_fwd / _bwd / orl_gen_wgrad do layer by layer through HBM.  The descriptor points into one flat
+ * parameter vector (offsets in floats); layer 0 is [H, D], the others [H, H]; act[l] = ORL_ACT_* of layer l. */
+#define ORL_GT_MAX_LAYERS 4
+typedef struct orl_gt_desc {
+  const float* theta;
+  int32_t D, H, n_layers, n_heads;
+  int32_t o_fn_g, o_fn_be; /* MLPBase.feature_norm weight / bias, -1 without feature normalisation */
+  int32_t oW[ORL_GT_MAX_LAYERS], ob[ORL_GT_MAX_LAYERS], og[ORL_GT_MAX_LAYERS], obe[ORL_GT_MAX_LAYERS], act[ORL_GT_MAX_LAYERS];
+  int32_t head_oW[2], head_ob[2], head_n[2]; /* head h: weight [head_n, H], bias [head_n]; all heads together <= 16 outputs */
+} orl_gt_desc;
+/* 1 when the fused kernels take this tower (hidden_size 64 with 2..4 layers or 128 with 2..3, D <= 64, the weights and
+ * the exchange slab within 160 KiB of LDS), else 0 (orl_last_error says why). */
+int orl_gt_supported(const orl_gt_desc* d);
+/* Sizes (floats) of the image orl_gt_prep writes and of the raw gradient-sum vector; -1 when unsupported. */
+int64_t orl_gt_image_floats(const orl_gt_desc* d);
+int64_t orl_gt_raw_floats(const orl_gt_desc* d);
+/* theta -> image (LayerNorm affines folded into the following Linear, the H x H matrices as three-term bf16 split images
+ * in streaming order).  Run after every optimiser step, before orl_gt_fwd / orl_gt_bwd. */
+int orl_gt_prep(const orl_gt_desc* d, float* image, void* stream);
+/* Head outputs of rows i = 0..mb-1 read at x + (idx ? idx[i] : i) * ldx + col0 (D floats each): head_out0 [mb, head_n[0]],
+ * head_out1 [mb, head_n[1]] (two heads: the shared network's act / v_out). */
+int orl_gt_fwd(const orl_gt_desc* d, const float* image, const float* x, int ldx, int col0, const int64_t* idx, int mb,
+               float* head_out0, float* head_out1, void* stream);
+/* Backward of the same rows given dhead = d loss / d head outputs [mb, head_n]: the forward is recomputed on chip, the
+ * gradient of every parameter the descriptor names is WRITTEN into grad (same offsets as theta).  partials: scratch of
+ * >= raw floats (up to 256 rows of them are used: one per workgroup, summed in a fixed order), raw: raw floats. */
+int orl_gt_bwd(const orl_gt_desc* d, const float* image, const float* x, int ldx, int col0, const int64_t* idx, int mb,
+               const float* dhead0, const float* dhead1, float* partials, int64_t partials_floats, float* raw, float* grad,
+               void* stream);
 
 #ifdef __cplusplus
 }

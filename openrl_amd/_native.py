@@ -19,7 +19,7 @@ ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL, ORL_ENV_MPE_SPREAD = 0, 1, 2, 3, 4
 ORL_GATHER_MAX = 12
 ORL_IPC_HANDLE_BYTES = 64
-ORL_VERSION = 302  # must equal include/orl_hip.h; checked against the loaded library
+ORL_VERSION = 303  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -116,13 +116,26 @@ class GenMlpDesc(C.Structure):
                 ("layer", GenMlpLayer * ORL_GEN_MLP_MAX_LAYERS)]
 
 
+ORL_GT_MAX_LAYERS = 4
+
+
+class GtDesc(C.Structure):
+    """``orl_gt_desc``: a feed-forward general tower for the cross-layer fused kernels (offsets into ``theta``)."""
+    _fields_ = [("theta", C.c_void_p), ("D", C.c_int32), ("H", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32),
+                ("o_fn_g", C.c_int32), ("o_fn_be", C.c_int32),
+                ("oW", C.c_int32 * ORL_GT_MAX_LAYERS), ("ob", C.c_int32 * ORL_GT_MAX_LAYERS),
+                ("og", C.c_int32 * ORL_GT_MAX_LAYERS), ("obe", C.c_int32 * ORL_GT_MAX_LAYERS),
+                ("act", C.c_int32 * ORL_GT_MAX_LAYERS),
+                ("head_oW", C.c_int32 * 2), ("head_ob", C.c_int32 * 2), ("head_n", C.c_int32 * 2)]
+
+
 ORL_ACT_NONE, ORL_ACT_TANH, ORL_ACT_RELU, ORL_ACT_LEAKY_RELU, ORL_ACT_ELU = -1, 0, 1, 2, 3
 ORL_HEAD_MULTI_DISCRETE = 3
 ORL_HEAD_MIXED = 4
 
 # order of orl_abi_struct_size(which)
 _ABI_STRUCTS = (NetDesc, PackSrc, BufferPtrs, CopyDesc, GatherDesc, PPOHParams, AdamState, RolloutArgs, RnnBatch,
-                RnnRolloutArgs, GenMlpDesc)
+                RnnRolloutArgs, GenMlpDesc, GtDesc)
 
 # name -> (restype, argtypes); must list EVERY symbol of include/orl_hip.h (tests check this)
 _P = C.c_void_p
@@ -187,6 +200,12 @@ _SIGNATURES = {
     "orl_row_fwd": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "orl_row_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int), _P]),
     "orl_gen_layer_fwd": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "orl_gt_supported": (C.c_int, [C.POINTER(GtDesc)]),
+    "orl_gt_image_floats": (C.c_int64, [C.POINTER(GtDesc)]),
+    "orl_gt_raw_floats": (C.c_int64, [C.POINTER(GtDesc)]),
+    "orl_gt_prep": (C.c_int, [C.POINTER(GtDesc), _P, _P]),
+    "orl_gt_fwd": (C.c_int, [C.POINTER(GtDesc), _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "orl_gt_bwd": (C.c_int, [C.POINTER(GtDesc), _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "orl_gen_mlp_fwd": (C.c_int, [C.POINTER(GenMlpDesc), _P, C.c_int, _P, _P, _P, _P]),
     "orl_gen_act": (C.c_int, [C.POINTER(GenMlpDesc), _P, C.POINTER(GenMlpDesc), _P, C.c_int, _P, _P, C.POINTER(HeadDesc), _P,
                               _P, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, C.c_int, _P, _P, _P]),

@@ -71,6 +71,105 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     # (recurrent: the actor and the critic carry their own stored states through the shared GRU - two passes)
     one_pass = shared and buffer.critic_obs is buffer.policy_obs and rnn is None
 
+    head = pn.head_desc
+    gsums = algo._gen_sums  # multi-GPU: the sum rows live in the flat vector the one collective reduces
+
+    def reduce_over_ranks():
+        # SURVEY.md section 8e: ONE collective per optimiser step - every network's gradient + the loss / logging sums
+        if algo.world_size > 1:
+            algo._allreduce_vec(algo._gen_flat)
+
+    def step(net, opt, n_clips, slot_first, slot_second):
+        opt.step_count += 1
+        ops_gen.adam(opt.native_state(opt.step_count), net.n_params, hp.max_grad_norm, bool(hp.use_max_grad_norm), n_clips,
+                     algo._gen_scratch, algo._info, slot_first, slot_second, algo.device)
+
+    def finish(psums, vsums):
+        # train_info (device-side accumulation; the sums are global in a multi-GPU run: they rode in the flat vector)
+        gauss = head.kind == ops_gen.HEAD_GAUSSIAN
+        ent_div = float(head.n_out) if (gauss and not hp.use_policy_active_masks) else 1.0
+        ratio_div = float(a_w) if head.kind != ops_gen.HEAD_CATEGORICAL else 1.0
+        if jrpo is None:
+            ops_gen.info(psums, vsums, den, hp, ent_div, ratio_div, algo._info)
+        else:  # the value loss is a mean over agent 0's rows
+            ops_gen.info(psums, None, den, hp, ent_div, ratio_div, algo._info)
+            ops_gen.info(None, vsums, den_c, hp, ent_div, ratio_div, algo._info)
+
+    # ---- cross-layer fused towers (csrc/orl_gen_tower.h): forward = one launch per tower straight from the records,
+    # backward = one launch (+ the fixed-order reduction of its per-workgroup sums) writing every gradient
+    fused = mod.fused_towers(one_pass) if (rnn is None and jrpo is None) else None
+    if fused is not None:
+        ftp, ftc = fused
+        wp = mod.workspace(pn, mb, True, "pf", heads_only=True)
+        wc = wp if shared else mod.workspace(cn, mb, True, "cf", heads_only=True)
+        logits, values = wp.v(wp.head_out["act"], mb, head.n_out), wc.v(wc.head_out["v_out"], mb, 1)
+        dlogits, dvalues = wp.v(wp.dhead["act"], mb, head.n_out), wc.v(wc.dhead["v_out"], mb, 1)
+
+        def value_part():
+            nb = ops_gen.value_loss(values.view(-1), rec, Dp, Dc, a_w, K, idx, mb, vn_state, den, hp, dvalues.view(-1),
+                                    wc.loss_partials)
+            return _loss_sums(wc, "v_out", nb, 1, None if gsums is None else gsums[1])
+
+        def policy_part():
+            nb = ops_gen.policy_loss(head, logits, mod._logstd(), rec, Dp, Dc, a_w, K, idx, mb, den, hp, dlogits,
+                                     wp.loss_partials)
+            return _loss_sums(wp, "act", nb, 20, None if gsums is None else gsums[0])
+
+        def logstd_grad_f(net, psums):
+            h = net.heads["act"]
+            if "logstd" in h:
+                ops.multi_copy([(net.v(h["logstd"], h["n_ls"], grad=True), psums[4:4 + h["n_ls"]])])
+
+        if shared:  # one tower, two heads: one forward, one backward
+            model, opt = mod.models["model"], mod.optimizers["model"]
+            ftp.prep()
+            ftp.forward(rec, 0, idx, mb, logits, values)
+            psums = policy_part()
+            vsums = value_part()
+            model.grad.zero_()
+            if not turn_on:
+                dlogits.zero_()
+            ftp.backward(rec, 0, idx, mb, dlogits, dvalues)
+            if turn_on:
+                logstd_grad_f(model, psums)
+            reduce_over_ranks()
+            step(model, opt, 2, 3, 4)
+        else:
+            popt, copt = mod.optimizers["policy"], mod.optimizers["critic"]
+
+            def critic_chain():
+                ftc.prep()
+                ftc.forward(rec, Dp, idx, mb, values)
+                sums = value_part()
+                cn.grad.zero_()
+                ftc.backward(rec, Dp, idx, mb, dvalues)
+                return sums
+
+            fork = turn_on and mod.two_stream
+            if fork:  # the critic's chain beside the policy's, as on the layer-wise route
+                main = torch.cuda.current_stream(algo.device)
+                side = mod.side_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    vsums = critic_chain()
+            ftp.prep()
+            ftp.forward(rec, 0, idx, mb, logits)
+            psums = policy_part()
+            if turn_on:
+                pn.grad.zero_()
+                ftp.backward(rec, 0, idx, mb, dlogits)
+                logstd_grad_f(pn, psums)
+            if fork:
+                main.wait_stream(side)
+            else:
+                vsums = critic_chain()
+            reduce_over_ranks()
+            if turn_on:
+                step(pn, popt, 1, 3, -1)
+            step(cn, copt, 1, 4, -1)
+        finish(psums, vsums)
+        return
+
     # ---- forward
     wp = mod.workspace(pn, mb, True, "p")
     xp = wp.v(wp.x0, mb, Dp)
@@ -144,26 +243,14 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
         wc, feats_c, trunk_c, gc, mrows_c, values = critic_forward()
 
     # ---- losses: d loss / d head outputs (already divided by the denominators) + statistics
-    head = pn.head_desc
     dlogits = wp.v(wp.dhead["act"], mb, head.n_out)
     nb = ops_gen.policy_loss(head, logits, mod._logstd(), rec, Dp, Dc, a_w, K, idx, mb, den, hp, dlogits,
                              wp.loss_partials)
-    gsums = algo._gen_sums  # multi-GPU: the sum rows live in the flat vector the one collective reduces
     psums = _loss_sums(wp, "act", nb, 20, None if gsums is None else gsums[0])
     if not fork:
         dvalues, vsums = critic_loss(wc, values)
 
     # ---- backward + optimiser
-    def reduce_over_ranks():
-        # SURVEY.md section 8e: ONE collective per optimiser step - every network's gradient + the loss / logging sums
-        if algo.world_size > 1:
-            algo._allreduce_vec(algo._gen_flat)
-
-    def step(net, opt, n_clips, slot_first, slot_second):
-        opt.step_count += 1
-        ops_gen.adam(opt.native_state(opt.step_count), net.n_params, hp.max_grad_norm, bool(hp.use_max_grad_norm), n_clips,
-                     algo._gen_scratch, algo._info, slot_first, slot_second, algo.device)
-
     def logstd_grad(net):
         h = net.heads["act"]
         if "logstd" in h:
@@ -218,12 +305,4 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
             step(pn, popt, 1, 3, -1)
         step(cn, copt, 1, 4, -1)
 
-    # ---- train_info (device-side accumulation; the sums are global in a multi-GPU run: they rode in the flat vector)
-    gauss = head.kind == ops_gen.HEAD_GAUSSIAN
-    ent_div = float(head.n_out) if (gauss and not hp.use_policy_active_masks) else 1.0
-    ratio_div = float(a_w) if head.kind != ops_gen.HEAD_CATEGORICAL else 1.0
-    if jrpo is None:
-        ops_gen.info(psums, vsums, den, hp, ent_div, ratio_div, algo._info)
-    else:  # the value loss is a mean over agent 0's rows
-        ops_gen.info(psums, None, den, hp, ent_div, ratio_div, algo._info)
-        ops_gen.info(None, vsums, den_c, hp, ent_div, ratio_div, algo._info)
+    finish(psums, vsums)

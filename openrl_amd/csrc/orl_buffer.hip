@@ -543,6 +543,7 @@ int orl_abi_struct_size(int which) {
     case 8: return (int)sizeof(orl_rnn_batch);
     case 9: return (int)sizeof(orl_rnn_rollout_args);
     case 10: return (int)sizeof(orl_gen_mlp_desc);
+    case 11: return (int)sizeof(orl_gt_desc);
     default: return ORL_E_INVALID;
   }
 }

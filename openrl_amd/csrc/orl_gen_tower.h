@@ -1,0 +1,556 @@
+// orl_gen_tower.h - cross-layer FUSED update kernels of the general feed-forward towers (hidden_size 64 / 128, any
+// layer_N the registers hold, four activations, feature norm, one or two heads): the shapes outside the default tower
+// that orl_gen_fused.hip runs layer by layer with every activation array crossing HBM.
+//
+// What is computed: MLPBase.forward (openrl/modules/networks/utils/mlp.py:8-48, 100-180) + the Linear heads of
+// ACTLayer / v_out on the rows idx[0..mb) of the update records, and the backward of that chain.
+//
+//   orl_gt_prep  theta -> "image": LayerNorm affines folded into the next Linear (exact algebra:
+//                W (xhat g + be) + b = (W diag g) xhat + (b + W be)), the H x H matrices as three-term bf16 split
+//                images (orl_mlp.h) of W' and W'^T in the chunk order the kernels stream them
+//   gt_kernel<H, NL, ND, false>  forward: rows -> head outputs (logits / values); activations never leave the chip
+//   gt_kernel<H, NL, ND, true>   backward: recomputes the forward of its rows, takes d loss / d head outputs and
+//                accumulates the RAW gradient sums G_l = dz_l^T xhat_{l-1}, db_l = sum dz_l in registers
+//   gt_finalize  raw sums -> gradients in the parameter vector's layout (dW = G diag g + db be^T, d g_l / d be_l as
+//                linear images of the next layer's sums - the relations of orl_common.h's RawLayout)
+//
+// Work distribution.  A workgroup = 8 waves = one CU; a pass = 128 rows, 16 per wave.  Within a wave the rows live in
+// the T layout of orl_mlp.h (features down the MFMA M dimension, the 16 rows across N): a layer's C fragment is the
+// next layer's B operand, LayerNorm statistics are in-lane sums + two permlane swaps.  The H x H GEMMs (forward and
+// input gradient) run on v_mfma_f32_16x16x32_bf16 over exact three-term splits - the six largest of the nine partial
+// products, error below the fp32 MFMA's own (profiles/r03_split_bf16_gemm.txt).  Their A operands (the bf16 images)
+// do not fit LDS beside everything else at H = 128, so they are STREAMED: 32 output rows of the three parts per chunk
+// (26 KB at H = 128), a linear global -> LDS DMA (global_load_lds_dwordx4) one chunk ahead into a double buffer, one
+// workgroup barrier per chunk; all 8 waves consume the same chunk, so a CU reads each image once per pass from L2.
+// The weight gradients cannot stay wave-private at H = 128 (128 x 128 accumulators = 256 VGPRs): they are COOPERATIVE -
+// wave w owns the output-feature slice [16 os, 16 os + 16) x an input-feature part of every G_l, the pass's dz_l and
+// xhat_{l-1} go through one [feature][row] LDS slab (first dz_l: every wave takes its slice as 32 A registers, then
+// xhat_{l-1}: streamed as the B operand), products on v_mfma_f32_16x16x4_f32 with the 128 rows as K.
+#pragma once
+#include "orl_common.h"
+#include "orl_mlp.h"
+#include "orl_gen_act.h"
+
+namespace orl {
+
+constexpr int GT_WAVES = 8;          // waves per workgroup
+constexpr int GT_ROWS = 128;         // rows per workgroup pass
+constexpr int GT_RS = GT_ROWS + 4;   // slab row stride (floats): [feature][row], conflict-free both ways
+constexpr int GT_HEADS = 16;         // head outputs (all heads together) are padded to 16
+
+template <int H>
+struct GtC {
+  static constexpr int NT = H / 16;                        // M tiles of a layer
+  static constexpr int KS = H / 32;                        // bf16 k-steps
+  static constexpr int KC = H / 32;                        // chunks (32 A rows each) per GEMM
+  static constexpr int WBS = H + 8;                        // bf16 image row stride (elements): 16-byte skew
+  static constexpr int CB = 3 * 32 * WBS * 2;              // chunk bytes
+  static constexpr int CBP = (CB + 1023) / 1024 * 1024;    // padded to whole-wave DMA blocks
+  static constexpr int NOS = H / 16;                       // output-feature slices of the cooperative wgrad
+  static constexpr int IPARTS = GT_WAVES / NOS;            // input-feature parts (H = 128: 1, H = 64: 2)
+  static constexpr int NTW = NT / IPARTS;                  // 16-column tiles of G_l per wave
+};
+
+// Offsets (floats) of the image and of the raw gradient-sum vector; evaluated on host and device from the descriptor
+// (closed forms only: no local arrays, everything stays in scalar registers).
+struct GtLay {
+  int H, D, NLt, NL, DP, DPS, DP16, ntot;
+  int iW0, ib0, ib3, iW3T, iW3P, res_bwd, res_fwd, iChunks, chunk_floats, n_chunks, img_total;
+  int rG0, rG1, rG3, rdb0, rdb3, raw_total;
+  __host__ __device__ GtLay() {}
+  __host__ __device__ explicit GtLay(const orl_gt_desc& d) {
+    H = d.H; D = d.D; NLt = d.n_layers; NL = d.n_layers - 1;
+    DP = (D + 3) & ~3;
+    DPS = ((DP >> 2) & 1) ? DP : DP + 4;  // DPS / 4 odd: 16 rows of a 4-byte column read land on distinct banks
+    DP16 = (D + 15) & ~15;
+    ntot = d.head_n[0] + (d.n_heads > 1 ? d.head_n[1] : 0);
+    int o = 0;
+    iW0 = o; o += H * DPS;
+    ib0 = o; o += NLt * H;
+    ib3 = o; o += GT_HEADS;
+    iW3T = o; o += H * 20;
+    res_bwd = o;
+    iW3P = o; o += GT_HEADS * (H + 4);
+    res_fwd = o;
+    o = (o + 255) & ~255;  // chunks start on a 1 KB boundary
+    iChunks = o;
+    const int cbp = H == 128 ? GtC<128>::CBP : GtC<64>::CBP;
+    chunk_floats = cbp / 4;
+    n_chunks = 2 * NL * (H / 32);  // forward images of layers 1..NL, then the transposed images of layers NL..1
+    o += n_chunks * chunk_floats;
+    img_total = o;
+    int r = 0;
+    rG0 = r; r += H * DP16;
+    rG1 = r; r += NL * H * H;
+    rG3 = r; r += GT_HEADS * H;
+    rdb0 = r; r += NLt * H;
+    rdb3 = r; r += GT_HEADS;
+    raw_total = r;
+  }
+  __host__ __device__ int ib(int l) const { return ib0 + l * H; }                 // folded bias of layer l
+  __host__ __device__ int rG(int l) const { return rG1 + (l - 1) * H * H; }      // G_l, l >= 1
+  __host__ __device__ int rdb(int l) const { return rdb0 + l * H; }
+  // chunk index (in consumption order) of chunk c of layer l's forward / transposed image
+  __host__ __device__ int fchunk(int l, int c) const { return (l - 1) * (H / 32) + c; }
+  __host__ __device__ int bchunk(int l, int c) const { return (NL + (NL - l)) * (H / 32) + c; }
+};
+
+struct GtArgs {
+  orl_gt_desc d;
+  const float* image;
+  const float* x;          // rows: x + row * ldx + col0
+  int ldx, col0;
+  const long long* idx;    // minibatch order (NULL: identity)
+  int mb;
+  float* out0;             // forward: head outputs [mb, head_n]
+  float* out1;
+  const float* dh0;        // backward: d loss / d head outputs [mb, head_n]
+  const float* dh1;
+  float* partials;         // backward: [gridDim.x][raw_total]
+};
+
+// ------------------------------------------------------------------------------------------------ chunk stream
+template <int H>
+struct GtStream {
+  static constexpr int CBP = GtC<H>::CBP;
+  const char* gsrc;   // this lane's global source of chunk 0: image chunks + wave * 1024 + lane * 16
+  unsigned ldst;      // LDS byte address of this wave's first block in buffer 0
+  char* lbase;        // generic pointer to buffer 0
+  int cpp, total, n, pos, wave;
+
+  __device__ __forceinline__ void issue(int p, int buf) {
+    const char* src = gsrc + (size_t)p * CBP;
+    const unsigned dst = ldst + (unsigned)buf * CBP;
+#pragma unroll
+    for (int off = 0; off < CBP; off += GT_WAVES * 1024) {
+      if (off + wave * 1024 < CBP) {
+        // (asm on purpose - see orl_ppo_tower.h: hipcc would drain a __builtin_amdgcn_global_load_lds right after the issue)
+        unsigned keep;
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(dst + (unsigned)off);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src + off), "s"(m0v)
+                     : "memory");
+      }
+    }
+  }
+  __device__ __forceinline__ void start(const float* chunks, float* lds_buf, int cpp_, int total_, int wave_, int lane) {
+    gsrc = (const char*)chunks + wave_ * 1024 + lane * 16;
+    lbase = (char*)lds_buf;
+    ldst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lbase + (unsigned)wave_ * 1024u;
+    cpp = cpp_; total = total_; n = 0; pos = 0; wave = wave_;
+    if (total > 0) issue(0, 0);
+  }
+  // chunk n is complete in LDS for every wave, chunk n + 1 is on its way; returns chunk n
+  __device__ __forceinline__ const unsigned short* consume() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nx = n + 1;
+    if (nx < total) {
+      pos = pos + 1 == cpp ? 0 : pos + 1;
+      issue(pos, nx & 1);
+    }
+    const unsigned short* r = (const unsigned short*)(lbase + (size_t)(n & 1) * CBP);
+    n = nx;
+    return r;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ T-layout helpers
+template <int NT>
+__device__ __forceinline__ void gt_split(const f32x4 (&in)[NT], u32x4 (&xs)[NT / 2][3]) {
+#pragma unroll
+  for (int h = 0; h < NT / 2; ++h) {
+    float x[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x[r] = in[2 * h][r]; x[4 + r] = in[2 * h + 1][r]; }
+    split8(x, xs[h][0], xs[h][1], xs[h][2]);
+  }
+}
+
+// acc += A in over the streamed chunks of one image (A = the image, T layout in / out): KC chunks x 2 row blocks x KS
+// k-steps x 6 products
+template <int H>
+__device__ __forceinline__ void gt_gemm(GtStream<H>& st, const u32x4 (&xs)[H / 32][3], f32x4 (&acc)[H / 16], int j, int q) {
+  constexpr int KS = GtC<H>::KS, KC = GtC<H>::KC, WBS = GtC<H>::WBS;
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const unsigned short* Wb = st.consume();
+    u32x4 w[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) w[0][p] = *(const u32x4*)(Wb + (p * 32 + j) * WBS + q * 8);
+#pragma unroll
+    for (int s = 0; s < 2 * KS; ++s) {
+      const int mo2 = s / KS, h = s % KS;
+      if (s + 1 < 2 * KS) {
+        const int mo3 = (s + 1) / KS, h3 = (s + 1) % KS;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          w[(s + 1) & 1][p] = *(const u32x4*)(Wb + (p * 32 + 16 * mo3 + j) * WBS + h3 * 32 + q * 8);
+      }
+      const u32x4 wh = w[s & 1][0], wm = w[s & 1][1], wl = w[s & 1][2];
+      const int mo = 2 * c + mo2;
+      acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
+      acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
+      acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+      acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
+      acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
+      acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void gt_load_vec(const float* __restrict__ v, int q, f32x4 (&acc)[NT]) {
+#pragma unroll
+  for (int m = 0; m < NT; ++m) acc[m] = *(const f32x4*)(v + 16 * m + 4 * q);
+}
+
+// activation in place; returns the sign bit field (bit 4m + r set when the pre-activation is > 0) used by the backward
+template <int NT, int ACT>
+__device__ __forceinline__ unsigned gt_act_k(f32x4 (&z)[NT]) {
+  unsigned bits = 0u;
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = z[m][r];
+      bits |= (v > 0.f ? 1u : 0u) << (4 * m + r);
+      z[m][r] = act_fwd(v, ACT);
+    }
+  return bits;
+}
+template <int NT>
+__device__ __forceinline__ unsigned gt_act(f32x4 (&z)[NT], int act) {
+  switch (act) {
+    case ORL_ACT_TANH: return gt_act_k<NT, ORL_ACT_TANH>(z);
+    case ORL_ACT_RELU: return gt_act_k<NT, ORL_ACT_RELU>(z);
+    case ORL_ACT_LEAKY_RELU: return gt_act_k<NT, ORL_ACT_LEAKY_RELU>(z);
+    case ORL_ACT_ELU: return gt_act_k<NT, ORL_ACT_ELU>(z);
+    default: return 0u;
+  }
+}
+
+// LayerNorm statistics over the NT * 16 features of a row + normalisation in place (eps 1e-5, biased variance)
+template <int NT>
+__device__ __forceinline__ void gt_ln(f32x4 (&x)[NT], float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < NT; ++m) s += (x[m][0] + x[m][1]) + (x[m][2] + x[m][3]);
+  s = row_allsum(s);
+  mean = s * (1.0f / (16 * NT));
+  float v = 0.f;
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    x[m] = x[m] - mean;
+    v += (x[m][0] * x[m][0] + x[m][1] * x[m][1]) + (x[m][2] * x[m][2] + x[m][3] * x[m][3]);
+  }
+  v = row_allsum(v);
+  rstd = __builtin_amdgcn_rsqf(v * (1.0f / (16 * NT)) + 1e-5f);
+#pragma unroll
+  for (int m = 0; m < NT; ++m) x[m] = x[m] * rstd;
+}
+
+// d <- gradient at the Linear's output, given d = gradient at xhat (the LayerNorm's affine lives in the next layer's
+// image), xhat, the row statistics and the activation between Linear and LayerNorm
+template <int NT, int ACT>
+__device__ __forceinline__ void gt_ln_act_bwd_k(f32x4 (&d)[NT], const f32x4 (&xhat)[NT], float mean, float rstd, unsigned bits) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    s1 += (d[m][0] + d[m][1]) + (d[m][2] + d[m][3]);
+    s2 += (d[m][0] * xhat[m][0] + d[m][1] * xhat[m][1]) + (d[m][2] * xhat[m][2] + d[m][3] * xhat[m][3]);
+  }
+  row_allsum2(s1, s2);
+  const float m1 = s1 * (1.0f / (16 * NT)), m2 = s2 * (1.0f / (16 * NT));
+  const float sig = 1.0f / rstd;
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = rstd * (d[m][r] - m1 - xhat[m][r] * m2);
+      if (ACT != ORL_ACT_NONE) {
+        const bool pos = (bits >> (4 * m + r)) & 1u;
+        const float a = xhat[m][r] * sig + mean;  // the activation's output, what orl_gen_layer_bwd reads back
+        float g;
+        if (ACT == ORL_ACT_TANH) g = 1.f - a * a;
+        else if (ACT == ORL_ACT_RELU) g = pos ? 1.f : 0.f;
+        else if (ACT == ORL_ACT_LEAKY_RELU) g = pos ? 1.f : 0.01f;
+        else g = pos ? 1.f : a + 1.f;  // ELU
+        t *= g;
+      }
+      d[m][r] = t;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void gt_ln_act_bwd(f32x4 (&d)[NT], const f32x4 (&xhat)[NT], float mean, float rstd, int act,
+                                              unsigned bits) {
+  switch (act) {
+    case ORL_ACT_TANH: gt_ln_act_bwd_k<NT, ORL_ACT_TANH>(d, xhat, mean, rstd, bits); break;
+    case ORL_ACT_RELU: gt_ln_act_bwd_k<NT, ORL_ACT_RELU>(d, xhat, mean, rstd, bits); break;
+    case ORL_ACT_LEAKY_RELU: gt_ln_act_bwd_k<NT, ORL_ACT_LEAKY_RELU>(d, xhat, mean, rstd, bits); break;
+    case ORL_ACT_ELU: gt_ln_act_bwd_k<NT, ORL_ACT_ELU>(d, xhat, mean, rstd, bits); break;
+    default: gt_ln_act_bwd_k<NT, ORL_ACT_NONE>(d, xhat, mean, rstd, bits); break;
+  }
+}
+
+// T layout -> slab [feature][row]: feature 16m + 4q + r of row 16 wave + j
+template <int NT>
+__device__ __forceinline__ void gt_slab_store(float* __restrict__ slab, const f32x4 (&x)[NT], int wave, int j, int q) {
+#pragma unroll
+  for (int m = 0; m < NT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[(16 * m + 4 * q + r) * GT_RS + 16 * wave + j] = x[m][r];
+}
+
+// the A registers of a 16-feature slice: lane (m = j, kq = q) takes feature f0 + j, rows 16 g + 4 q + e
+__device__ __forceinline__ void gt_slab_A(const float* __restrict__ slab, int f0, int j, int q, f32x4 (&A)[8], float& colsum) {
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    A[g] = *(const f32x4*)(slab + (f0 + j) * GT_RS + 16 * g + 4 * q);
+    s += (A[g][0] + A[g][1]) + (A[g][2] + A[g][3]);
+  }
+  colsum += s;
+}
+
+// acc[16 x 16 tile] += A^T-slice (registers) x slab features [n0, n0 + 16) over the 128 rows: 32 fp32 MFMAs
+__device__ __forceinline__ void gt_wgrad_tile(const float* __restrict__ slab, int n0, int j, int q, const f32x4 (&A)[8],
+                                              f32x4& acc) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const f32x4 b = *(const f32x4*)(slab + (n0 + j) * GT_RS + 16 * g + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = ORL_MFMA(A[g][e], b[e], acc);
+  }
+  asm volatile("" ::: "memory");  // keeps hipcc from hoisting the next tile's 8 operand reads (32 VGPRs each) above this one
+}
+
+// ------------------------------------------------------------------------------------------------ the kernel
+// H: hidden width (64 / 128); NL: number of H x H layers (n_layers - 1); ND: 16-column blocks of observation registers
+// (1: D <= 16, 4: D <= 64); BWD: backward kernel (forward recompute + gradients) or forward kernel (head outputs).
+template <int H, int NL, int ND, bool BWD>
+__device__ __forceinline__ void gt_body(const GtArgs& A) {
+  using Cn = GtC<H>;
+  constexpr int NT = Cn::NT, KS = Cn::KS;
+  extern __shared__ __attribute__((aligned(1024))) float smem[];
+  const GtLay ly(A.d);
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int res = BWD ? ly.res_bwd : ly.res_fwd;
+  const int res_pad = (res + 255) & ~255;
+  float* cbuf = smem + res_pad;                                   // two chunk buffers
+  float* slab = cbuf + 2 * (Cn::CBP / 4);                         // [H][GT_RS] (backward only)
+  const float* lw = smem;
+
+  const int n_tiles = (A.mb + 15) >> 4;
+  const int n_pass = (n_tiles + GT_WAVES - 1) / GT_WAVES;
+  const int my_pass = ((int)blockIdx.x < n_pass) ? (n_pass - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int cpp = (BWD ? 2 : 1) * NL * Cn::KC;
+
+  GtStream<H> st;
+  st.start(A.image + ly.iChunks, cbuf, cpp, my_pass * cpp, wave, l);
+  // resident part of the image: fc1's fp32 matrix, the folded biases, the head matrices
+  for (int e = threadIdx.x * 4; e < res; e += GT_WAVES * 64 * 4) *(f32x4*)(smem + e) = *(const f32x4*)(A.image + e);
+  __syncthreads();
+
+  const int D = ly.D, DPS = ly.DPS, nks = ly.DP >> 2;
+  const int n0 = A.d.head_n[0], n1 = A.d.n_heads > 1 ? A.d.head_n[1] : 0;
+  const bool fn = A.d.o_fn_g >= 0;
+
+  // ---- persistent accumulators of the cooperative weight gradients (backward)
+  const int os = wave % Cn::NOS, ip = wave / Cn::NOS;
+  f32x4 G[NL > 0 ? NL : 1][Cn::NTW];
+  f32x4 G0[ND];
+  f32x4 G3 = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbs[NL + 1];
+  float db3 = 0.f;
+  if constexpr (BWD) {
+#pragma unroll
+    for (int a = 0; a < NL; ++a)
+#pragma unroll
+      for (int b = 0; b < Cn::NTW; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < ND; ++b) G0[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a <= NL; ++a) dbs[a] = 0.f;
+  }
+
+  for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+    const int i = (pass * GT_WAVES + wave) * 16 + j;
+    const bool valid = i < A.mb;
+    const long long row = (A.idx != nullptr) ? A.idx[valid ? i : 0] : (long long)(valid ? i : 0);
+    const float* xr = A.x + (size_t)row * A.ldx + A.col0;
+
+    // ---- observations: lane (j, q) holds x[j][4 s + q]; feature norm (LayerNorm over the D real columns)
+    float x0[4 * ND];
+#pragma unroll
+    for (int s = 0; s < 4 * ND; ++s) x0[s] = (4 * s + q < D) ? xr[4 * s + q] : 0.f;
+    if (fn) {
+      float sm = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4 * ND; ++s) sm += x0[s];
+      sm = row_allsum(sm);
+      const float mean = sm / (float)D;
+      float v = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4 * ND; ++s) {
+        x0[s] = (4 * s + q < D) ? x0[s] - mean : 0.f;
+        v += x0[s] * x0[s];
+      }
+      v = row_allsum(v);
+      const float rs = __builtin_amdgcn_rsqf(v / (float)D + 1e-5f);
+#pragma unroll
+      for (int s = 0; s < 4 * ND; ++s) x0[s] *= rs;
+    }
+
+    // ---- forward (recomputed in the backward kernel): xh[l] = LayerNorm output of layer l without its affine
+    f32x4 xh[NL + 1][NT];
+    float mu[NL + 1], rstd[NL + 1];
+    unsigned bits[NL + 1];
+    gt_load_vec<NT>(lw + ly.ib(0), q, xh[0]);
+#pragma unroll
+    for (int s = 0; s < 4 * ND; ++s) {
+      if (s < nks) {
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+          const float a = lw[ly.iW0 + (16 * m + j) * DPS + 4 * s + q];
+          xh[0][m] = ORL_MFMA(a, x0[s], xh[0][m]);
+        }
+      }
+    }
+    bits[0] = gt_act<NT>(xh[0], A.d.act[0]);
+    gt_ln<NT>(xh[0], mu[0], rstd[0]);
+#pragma unroll
+    for (int k = 1; k <= NL; ++k) {
+      u32x4 xs[KS][3];
+      gt_split<NT>(xh[k - 1], xs);
+      gt_load_vec<NT>(lw + ly.ib(k), q, xh[k]);
+      gt_gemm<H>(st, xs, xh[k], j, q);
+      bits[k] = gt_act<NT>(xh[k], A.d.act[k]);
+      gt_ln<NT>(xh[k], mu[k], rstd[k]);
+    }
+
+    if constexpr (!BWD) {
+      // ---- heads: out^T[16 c x 16 rows] = W3' xhat_NL^T + b3'; lane (j, q) keeps outputs c = 4q .. 4q + 3 of row j
+      f32x4 hv = *(const f32x4*)(lw + ly.ib3 + 4 * q);
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        const f32x4 a4 = *(const f32x4*)(lw + ly.iW3P + j * (H + 4) + 16 * m + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv = ORL_MFMA(a4[r], xh[NL][m][r], hv);
+      }
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * q + r;
+          if (c < n0) A.out0[(size_t)i * n0 + c] = hv[r];
+          else if (c - n0 < n1) A.out1[(size_t)i * n1 + (c - n0)] = hv[r];
+        }
+      }
+    } else {
+      // ---- d loss / d head outputs of this lane's row: c = 4q + s
+      float dh[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int c = 4 * q + s;
+        float v = 0.f;
+        if (valid) {
+          if (c < n0) v = A.dh0[(size_t)i * n0 + c];
+          else if (c - n0 < n1) v = A.dh1[(size_t)i * n1 + (c - n0)];
+        }
+        dh[s] = v;
+      }
+      // ---- G3 += dhead^T xhat_NL, db3 += sum dhead
+      f32x4 Areg[8];
+      __syncthreads();  // (the previous pass's last slab reads are done)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) slab[(4 * q + s) * GT_RS + 16 * wave + j] = dh[s];
+      __syncthreads();
+      {
+        float cs = 0.f;
+        gt_slab_A(slab, 0, j, q, Areg, cs);
+        db3 += cs;
+      }
+      __syncthreads();
+      gt_slab_store<NT>(slab, xh[NL], wave, j, q);
+      __syncthreads();
+      if (wave < NT) gt_wgrad_tile(slab, 16 * wave, j, q, Areg, G3);
+      // ---- d xhat_NL = W3'^T dhead (A = the [H][20] transposed head image, K = the 16 head outputs)
+      f32x4 d[NT];
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 a4 = *(const f32x4*)(lw + ly.iW3T + (16 * m + j) * 20 + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) d[m] = ORL_MFMA(a4[s], dh[s], d[m]);
+      }
+#pragma unroll
+      for (int k = NL; k >= 0; --k) {
+        // d = gradient at xhat_k  ->  dz_k
+        gt_ln_act_bwd<NT>(d, xh[k], mu[k], rstd[k], A.d.act[k], bits[k]);
+        __syncthreads();  // every wave has finished reading the slab's previous contents
+        gt_slab_store<NT>(slab, d, wave, j, q);
+        __syncthreads();
+        gt_slab_A(slab, 16 * os, j, q, Areg, dbs[k]);
+        __syncthreads();
+        if (k > 0) {
+          gt_slab_store<NT>(slab, xh[k - 1], wave, j, q);
+          __syncthreads();
+#pragma unroll
+          for (int t = 0; t < Cn::NTW; ++t) gt_wgrad_tile(slab, 16 * (ip * Cn::NTW + t), j, q, Areg, G[k - 1][t]);
+          // input gradient d xhat_{k-1} = W_k'^T dz_k through the transposed image's chunks
+          u32x4 xs[KS][3];
+          gt_split<NT>(d, xs);
+#pragma unroll
+          for (int m = 0; m < NT; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+          gt_gemm<H>(st, xs, d, j, q);
+        } else {
+          // the observations as the B operand: rows d = 4 s + q of the slab
+#pragma unroll
+          for (int s = 0; s < 4 * ND; ++s) slab[(4 * s + q) * GT_RS + 16 * wave + j] = x0[s];
+          __syncthreads();
+#pragma unroll
+          for (int t = 0; t < ND; ++t)
+            if (16 * t < D && (t % Cn::IPARTS) == ip) gt_wgrad_tile(slab, 16 * t, j, q, Areg, G0[t]);
+        }
+      }
+    }
+  }
+
+  if constexpr (BWD) {
+    // ---- this workgroup's partial row of the raw sums.  A tile's lane (jj = j, qq = q) register r holds
+    // (output feature 16 os + 4 q + r, input feature 16 t + j)
+    float* P = A.partials + (size_t)blockIdx.x * ly.raw_total;
+#pragma unroll
+    for (int k = 1; k <= NL; ++k)
+#pragma unroll
+      for (int t = 0; t < Cn::NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          P[ly.rG(k) + (16 * os + 4 * q + r) * H + 16 * (ip * Cn::NTW + t) + j] = G[k - 1][t][r];
+#pragma unroll
+    for (int t = 0; t < ND; ++t)
+      if (16 * t < ly.DP16 && (t % Cn::IPARTS) == ip) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[ly.rG0 + (16 * os + 4 * q + r) * ly.DP16 + 16 * t + j] = G0[t][r];
+      }
+    if (wave < NT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[ly.rG3 + (4 * q + r) * H + 16 * wave + j] = G3[r];
+    }
+    // column sums: lane (m = j, kq = q) holds a partial of feature 16 os + j (every wave of an output slice holds the
+    // same sums: the ip == 0 wave writes); db3: feature c = j, identical in all waves - wave 0 writes
+#pragma unroll
+    for (int k = 0; k <= NL; ++k) {
+      const float s = row_allsum(dbs[k]);
+      if (ip == 0 && q == 0) P[ly.rdb(k) + 16 * os + j] = s;
+    }
+    {
+      const float s = row_allsum(db3);
+      if (wave == 0 && q == 0) P[ly.rdb3 + j] = s;
+    }
+  }
+}
+
+}  // namespace orl

@@ -1,0 +1,292 @@
+// orl_gen_tower.hip - C ABI of the cross-layer fused general towers (kernels in orl_gen_tower.h): orl_gt_supported,
+// orl_gt_image_floats, orl_gt_raw_floats, orl_gt_prep, orl_gt_fwd, orl_gt_bwd.
+#include "orl_gen_tower.h"
+
+namespace orl {
+
+template <int H, int NL, int ND, bool BWD>
+__global__ __launch_bounds__(GT_WAVES * 64, 2) void gt_kernel(GtArgs A) {
+  gt_body<H, NL, ND, BWD>(A);
+}
+
+// ------------------------------------------------------------------------------------------------ image
+// LayerNorm affine feeding layer l (l = 0: the feature norm, or identity)
+__device__ __forceinline__ float gt_gin(const orl_gt_desc& d, int l, int i) {
+  if (l == 0) return d.o_fn_g >= 0 ? d.theta[d.o_fn_g + i] : 1.f;
+  return d.theta[d.og[l - 1] + i];
+}
+__device__ __forceinline__ float gt_bein(const orl_gt_desc& d, int l, int i) {
+  if (l == 0) return d.o_fn_be >= 0 ? d.theta[d.o_fn_be + i] : 0.f;
+  return d.theta[d.obe[l - 1] + i];
+}
+// row c of the stacked head matrix [ntot][H] and its bias
+__device__ __forceinline__ const float* gt_head_row(const orl_gt_desc& d, int c) {
+  return c < d.head_n[0] ? d.theta + d.head_oW[0] + c * d.H : d.theta + d.head_oW[1] + (c - d.head_n[0]) * d.H;
+}
+__device__ __forceinline__ float gt_head_bias(const orl_gt_desc& d, int c) {
+  return c < d.head_n[0] ? d.theta[d.head_ob[0] + c] : d.theta[d.head_ob[1] + (c - d.head_n[0])];
+}
+
+// element (row mrow, reduction index k) of an image: chunk mrow / 32, then [part][row % 32][k in fragment order]
+__device__ __forceinline__ void gt_image_store(unsigned short* __restrict__ chunks, int chunk0, int chunk_ushorts, int WBS,
+                                               int mrow, int k, float w) {
+  const int m = k >> 4, qq = (k >> 2) & 3, r = k & 3, h = m >> 1, sl = (m & 1) * 4 + r;
+  unsigned short* base = chunks + (size_t)(chunk0 + (mrow >> 5)) * chunk_ushorts + (mrow & 31) * WBS + h * 32 + qq * 8 + sl;
+  const float h1 = u2f(f2u(w) & 0xffff0000u), r1 = w - h1;
+  const float m1 = u2f(f2u(r1) & 0xffff0000u), l1 = r1 - m1;
+  base[0] = (unsigned short)(f2u(h1) >> 16);
+  base[32 * WBS] = (unsigned short)(f2u(m1) >> 16);
+  base[64 * WBS] = (unsigned short)(f2u(l1) >> 16);
+}
+
+__global__ __launch_bounds__(256) void gt_prep_kernel(orl_gt_desc d, float* __restrict__ img) {
+  const GtLay ly(d);
+  const int H = ly.H, D = ly.D, NLt = ly.NLt, ntot = ly.ntot;
+  const int nA = H * ly.DPS, nB = NLt * H, nC = GT_HEADS, nD = H * 20, nE = GT_HEADS * (H + 4), nF = ly.NL * H * H;
+  const int total = nA + nB + nC + nD + nE + nF;
+  const int WBS = H + 8, chunk_ushorts = ly.chunk_floats * 2;
+  unsigned short* chunks = (unsigned short*)(img + ly.iChunks);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int t = e;
+    if (t < nA) {  // fc1: W0 diag(g_fn), zero padded to DPS columns
+      const int o = t / ly.DPS, k = t - o * ly.DPS;
+      img[ly.iW0 + t] = k < D ? d.theta[d.oW[0] + o * D + k] * gt_gin(d, 0, k) : 0.f;
+      continue;
+    }
+    t -= nA;
+    if (t < nB) {  // folded biases b_l + W_l be_{l-1}
+      const int l = t / H, o = t - l * H, n_in = l == 0 ? D : H;
+      float acc = 0.f;
+      if (l > 0 || d.o_fn_be >= 0) {
+        const float* wrow = d.theta + d.oW[l] + o * n_in;
+        for (int k = 0; k < n_in; ++k) acc += wrow[k] * gt_bein(d, l, k);
+      }
+      img[ly.ib(l) + o] = d.theta[d.ob[l] + o] + acc;
+      continue;
+    }
+    t -= nB;
+    if (t < nC) {  // head biases b3 + W3 be_NL
+      float v = 0.f;
+      if (t < ntot) {
+        const float* wrow = gt_head_row(d, t);
+        float acc = 0.f;
+        for (int f = 0; f < H; ++f) acc += wrow[f] * d.theta[d.obe[NLt - 1] + f];
+        v = gt_head_bias(d, t) + acc;
+      }
+      img[ly.ib3 + t] = v;
+      continue;
+    }
+    t -= nC;
+    if (t < nD) {  // (W3 diag(g_NL))^T as [H][20]
+      const int f = t / 20, c = t - f * 20;
+      img[ly.iW3T + t] = c < ntot ? gt_head_row(d, c)[f] * d.theta[d.og[NLt - 1] + f] : 0.f;
+      continue;
+    }
+    t -= nD;
+    if (t < nE) {  // W3 diag(g_NL) as [16][H + 4]
+      const int c = t / (H + 4), f = t - c * (H + 4);
+      img[ly.iW3P + t] = (c < ntot && f < H) ? gt_head_row(d, c)[f] * d.theta[d.og[NLt - 1] + f] : 0.f;
+      continue;
+    }
+    t -= nE;
+    {  // H x H layers: three-term bf16 images of W' = W diag(g_{l-1}) (rows o, reduction i) and W'^T (rows i, reduction o)
+      const int l = 1 + t / (H * H), oi = t - (l - 1) * H * H, o = oi / H, i = oi - o * H;
+      const float w = d.theta[d.oW[l] + oi] * gt_gin(d, l, i);
+      gt_image_store(chunks, ly.fchunk(l, 0), chunk_ushorts, WBS, o, i, w);
+      gt_image_store(chunks, ly.bchunk(l, 0), chunk_ushorts, WBS, i, o, w);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ raw sums -> gradients
+__global__ __launch_bounds__(256) void gt_finalize_kernel(orl_gt_desc d, const float* __restrict__ raw, float* __restrict__ grad) {
+  const GtLay ly(d);
+  const int H = ly.H, D = ly.D, NLt = ly.NLt, ntot = ly.ntot;
+  const bool fn = d.o_fn_g >= 0;
+  // work items: [fn: 2 D] + per layer (n_in H + 3 H) + per head (n H + n)
+  int total = fn ? 2 * D : 0;
+  for (int l = 0; l < NLt; ++l) total += (l == 0 ? D : H) * H + 3 * H;
+  total += ntot * H + ntot;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int t = e;
+    if (fn) {
+      if (t < 2 * D) {  // d g_fn[k] = sum_o W0[o][k] G0[o][k],  d be_fn[k] = sum_o W0[o][k] db0[o]
+        const int which = t / D, k = t - which * D;
+        float acc = 0.f;
+        for (int o = 0; o < H; ++o)
+          acc += d.theta[d.oW[0] + o * D + k] * (which == 0 ? raw[ly.rG0 + o * ly.DP16 + k] : raw[ly.rdb(0) + o]);
+        grad[(which == 0 ? d.o_fn_g : d.o_fn_be) + k] = acc;
+        continue;
+      }
+      t -= 2 * D;
+    }
+    bool done = false;
+    for (int l = 0; l < NLt && !done; ++l) {
+      const int n_in = l == 0 ? D : H;
+      const int nW = n_in * H;
+      if (t < nW) {  // dW_l[o][i] = G_l[o][i] g_in[i] + db_l[o] be_in[i]
+        const int o = t / n_in, i = t - o * n_in;
+        const float g = l == 0 ? raw[ly.rG0 + o * ly.DP16 + i] : raw[ly.rG(l) + o * H + i];
+        grad[d.oW[l] + t] = g * gt_gin(d, l, i) + raw[ly.rdb(l) + o] * gt_bein(d, l, i);
+        done = true;
+        break;
+      }
+      t -= nW;
+      if (t < H) {
+        grad[d.ob[l] + t] = raw[ly.rdb(l) + t];
+        done = true;
+        break;
+      }
+      t -= H;
+      if (t < 2 * H) {  // the LayerNorm behind layer l: linear images of the NEXT Linear's sums
+        const int which = t / H, i = t - which * H;
+        float acc = 0.f;
+        if (l + 1 < NLt) {
+          const float* W = d.theta + d.oW[l + 1];
+          for (int o = 0; o < H; ++o) acc += W[o * H + i] * (which == 0 ? raw[ly.rG(l + 1) + o * H + i] : raw[ly.rdb(l + 1) + o]);
+        } else {
+          for (int c = 0; c < ntot; ++c)
+            acc += gt_head_row(d, c)[i] * (which == 0 ? raw[ly.rG3 + c * H + i] : raw[ly.rdb3 + c]);
+        }
+        grad[(which == 0 ? d.og[l] : d.obe[l]) + i] = acc;
+        done = true;
+        break;
+      }
+      t -= 2 * H;
+    }
+    if (done) continue;
+    if (t < ntot * H) {  // head weights: G3[c][f] g_NL[f] + db3[c] be_NL[f]
+      const int c = t / H, f = t - c * H;
+      const float v = raw[ly.rG3 + t] * d.theta[d.og[NLt - 1] + f] + raw[ly.rdb3 + c] * d.theta[d.obe[NLt - 1] + f];
+      if (c < d.head_n[0]) grad[d.head_oW[0] + c * H + f] = v;
+      else grad[d.head_oW[1] + (c - d.head_n[0]) * H + f] = v;
+      continue;
+    }
+    t -= ntot * H;
+    if (t < d.head_n[0]) grad[d.head_ob[0] + t] = raw[ly.rdb3 + t];
+    else grad[d.head_ob[1] + (t - d.head_n[0])] = raw[ly.rdb3 + t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static size_t gt_lds_bytes(const GtLay& ly, bool bwd) {
+  const int res = bwd ? ly.res_bwd : ly.res_fwd;
+  size_t fl = (size_t)((res + 255) & ~255) + 2 * (size_t)ly.chunk_floats;
+  if (bwd) fl += (size_t)ly.H * GT_RS;
+  return fl * sizeof(float);
+}
+
+static int gt_check(const orl_gt_desc* d, const char* who) {
+  ORL_REQUIRE(d && d->theta, "%s: null descriptor", who);
+  if (d->H != 64 && d->H != 128) return fail(ORL_E_UNSUPPORTED, "%s: hidden_size %d (the fused towers take 64 / 128)", who, d->H);
+  const int max_layers = d->H == 64 ? 4 : 3;
+  if (d->n_layers < 2 || d->n_layers > max_layers)
+    return fail(ORL_E_UNSUPPORTED, "%s: %d layers at hidden_size %d (2..%d)", who, d->n_layers, d->H, max_layers);
+  if (d->D < 1 || d->D > 64) return fail(ORL_E_UNSUPPORTED, "%s: obs_dim %d outside [1, 64]", who, d->D);
+  if (d->n_heads < 1 || d->n_heads > 2) return fail(ORL_E_UNSUPPORTED, "%s: %d heads", who, d->n_heads);
+  const int ntot = d->head_n[0] + (d->n_heads > 1 ? d->head_n[1] : 0);
+  if (d->head_n[0] < 1 || ntot > GT_HEADS) return fail(ORL_E_UNSUPPORTED, "%s: %d head outputs (<= 16)", who, ntot);
+  for (int l = 0; l < d->n_layers; ++l)
+    if (d->act[l] < ORL_ACT_NONE || d->act[l] > ORL_ACT_ELU) return fail(ORL_E_INVALID, "%s: activation %d", who, d->act[l]);
+  const GtLay ly(*d);
+  if (gt_lds_bytes(ly, true) > 160 * 1024)
+    return fail(ORL_E_UNSUPPORTED, "%s: %zu bytes of LDS (obs_dim %d at hidden_size %d)", who, gt_lds_bytes(ly, true), d->D, d->H);
+  return 0;
+}
+
+template <int H, int NL, int ND, bool BWD>
+static void gt_launch_inst(const GtArgs& A, int grid, size_t lds, hipStream_t s) {
+  (void)hipFuncSetAttribute((const void*)gt_kernel<H, NL, ND, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((gt_kernel<H, NL, ND, BWD>), dim3(grid), dim3(GT_WAVES * 64), lds, s, A);
+}
+
+template <bool BWD>
+static int gt_launch(const GtArgs& A, int grid, size_t lds, hipStream_t s) {
+  const int H = A.d.H, NL = A.d.n_layers - 1, ND = A.d.D <= 16 ? 1 : 4;
+#define ORL_GT_CASE(h, nl)                                              \
+  if (H == h && NL == nl) {                                             \
+    if (ND == 1) gt_launch_inst<h, nl, 1, BWD>(A, grid, lds, s);        \
+    else gt_launch_inst<h, nl, 4, BWD>(A, grid, lds, s);                \
+    return 0;                                                           \
+  }
+  ORL_GT_CASE(64, 1)
+  ORL_GT_CASE(64, 2)
+  ORL_GT_CASE(64, 3)
+  ORL_GT_CASE(128, 1)
+  ORL_GT_CASE(128, 2)
+#undef ORL_GT_CASE
+  return fail(ORL_E_UNSUPPORTED, "orl_gt: no kernel for hidden_size %d with %d layers", H, NL + 1);
+}
+
+}  // namespace orl
+
+using namespace orl;
+
+extern "C" {
+
+int orl_gt_supported(const orl_gt_desc* d) { return gt_check(d, "orl_gt_supported") == 0 ? 1 : 0; }
+
+int64_t orl_gt_image_floats(const orl_gt_desc* d) {
+  if (gt_check(d, "orl_gt_image_floats")) return -1;
+  return GtLay(*d).img_total;
+}
+
+int64_t orl_gt_raw_floats(const orl_gt_desc* d) {
+  if (gt_check(d, "orl_gt_raw_floats")) return -1;
+  return GtLay(*d).raw_total;
+}
+
+int orl_gt_prep(const orl_gt_desc* d, float* image, void* stream) {
+  int rc = gt_check(d, "orl_gt_prep");
+  if (rc) return rc;
+  ORL_REQUIRE(image, "orl_gt_prep: null image");
+  hipLaunchKernelGGL(gt_prep_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, *d, image);
+  return launch_status("orl_gt_prep");
+}
+
+int orl_gt_fwd(const orl_gt_desc* d, const float* image, const float* x, int ldx, int col0, const int64_t* idx, int mb,
+               float* head_out0, float* head_out1, void* stream) {
+  int rc = gt_check(d, "orl_gt_fwd");
+  if (rc) return rc;
+  ORL_REQUIRE(image && x && head_out0 && mb > 0 && ldx >= col0 + d->D && col0 >= 0, "orl_gt_fwd: bad arguments");
+  ORL_REQUIRE(d->n_heads == 1 || head_out1, "orl_gt_fwd: two heads need two outputs");
+  const GtLay ly(*d);
+  GtArgs A{};
+  A.d = *d; A.image = image; A.x = x; A.ldx = ldx; A.col0 = col0; A.idx = (const long long*)idx; A.mb = mb;
+  A.out0 = head_out0; A.out1 = head_out1;
+  const int n_pass = ((mb + 15) / 16 + GT_WAVES - 1) / GT_WAVES;
+  const int grid = n_pass < 256 ? n_pass : 256;
+  rc = gt_launch<false>(A, grid, gt_lds_bytes(ly, false), (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_status("orl_gt_fwd");
+}
+
+int orl_gt_bwd(const orl_gt_desc* d, const float* image, const float* x, int ldx, int col0, const int64_t* idx, int mb,
+               const float* dhead0, const float* dhead1, float* partials, int64_t partials_floats, float* raw, float* grad,
+               void* stream) {
+  int rc = gt_check(d, "orl_gt_bwd");
+  if (rc) return rc;
+  ORL_REQUIRE(image && x && dhead0 && partials && raw && grad && mb > 0 && ldx >= col0 + d->D && col0 >= 0,
+              "orl_gt_bwd: bad arguments");
+  ORL_REQUIRE(d->n_heads == 1 || dhead1, "orl_gt_bwd: two heads need two gradients");
+  const GtLay ly(*d);
+  ORL_REQUIRE(partials_floats >= ly.raw_total, "orl_gt_bwd: the partials buffer holds %lld floats, one row is %d",
+              (long long)partials_floats, ly.raw_total);
+  GtArgs A{};
+  A.d = *d; A.image = image; A.x = x; A.ldx = ldx; A.col0 = col0; A.idx = (const long long*)idx; A.mb = mb;
+  A.dh0 = dhead0; A.dh1 = dhead1; A.partials = partials;
+  const int n_pass = ((mb + 15) / 16 + GT_WAVES - 1) / GT_WAVES;
+  int grid = n_pass < 256 ? n_pass : 256;
+  const int64_t fit = partials_floats / ly.raw_total;
+  if (grid > fit) grid = (int)fit;
+  rc = gt_launch<true>(A, grid, gt_lds_bytes(ly, true), (hipStream_t)stream);
+  if (rc) return rc;
+  rc = launch_status("orl_gt_bwd");
+  if (rc) return rc;
+  rc = orl_gen_colsum(partials, grid, ly.raw_total, raw, ly.raw_total, nullptr, 0, nullptr, 0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gt_finalize_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, *d, raw, grad);
+  return launch_status("orl_gt_bwd(finalize)");
+}
+
+}  // extern "C"

@@ -201,6 +201,18 @@ class GenNet:
         self._mlp_desc = (key, d)
         return d
 
+    def gt(self, head_names):
+        """The cross-layer fused update tower (``FusedTower``: ``orl_gt_prep / _fwd / _bwd``) of this network with the
+        given heads, or None when the fused kernels do not take it (recurrent towers, widths other than 64 / 128, too
+        many layers or LDS).  Cached per parameter vector."""
+        key = (self.theta.data_ptr(), self.grad.data_ptr(), tuple(head_names))
+        hit = getattr(self, "_gt", None)
+        if hit is None:
+            hit = self._gt = {}
+        if key not in hit:
+            hit[key] = FusedTower.build(self, head_names)
+        return hit[key]
+
     def v(self, off: int, *shape, grad: bool = False) -> torch.Tensor:
         t = self.grad if grad else self.theta
         return t[off:off + int(np.prod(shape))].view(*shape)
@@ -331,28 +343,75 @@ class GenNet:
                     self.v(h["logstd"], h["n_ls"]).zero_()
 
 
+class FusedTower:
+    """A feed-forward ``GenNet`` as the cross-layer fused kernels see it (csrc/orl_gen_tower.h): the descriptor, the folded /
+    split weight image ``orl_gt_prep`` rebuilds after every optimiser step, and the scratch of the backward's per-workgroup
+    gradient sums.  ``forward`` = the trunk and head(s) of the rows in one launch, ``backward`` = recomputed forward +
+    every parameter gradient written into ``net.grad``."""
+
+    @staticmethod
+    def build(net: "GenNet", head_names):
+        if net.recurrent or not 1 <= len(head_names) <= 2 or len(net.layers) > nat.ORL_GT_MAX_LAYERS:
+            return None
+        if any(L["n_out"] != net.H or (k > 0 and L["n_in"] != net.H) for k, L in enumerate(net.layers)):
+            return None
+        d = nat.GtDesc()
+        d.theta = net.theta.data_ptr()
+        d.D, d.H, d.n_layers, d.n_heads = net.D, net.H, len(net.layers), len(head_names)
+        d.o_fn_g, d.o_fn_be = (net.fn["g"], net.fn["be"]) if net.fn is not None else (-1, -1)
+        for k, L in enumerate(net.layers):
+            d.oW[k], d.ob[k], d.og[k], d.obe[k], d.act[k] = L["W"], L["b"], L["g"], L["be"], L["act"]
+        for k, name in enumerate(head_names):
+            h = net.heads[name]
+            d.head_oW[k], d.head_ob[k], d.head_n[k] = h["W"], h["b"], h["n"]
+        if not ops_gen.gt_supported(d):
+            return None
+        return FusedTower(net, d, head_names)
+
+    def __init__(self, net: "GenNet", desc, head_names) -> None:
+        self.net, self.desc, self.head_names = net, desc, tuple(head_names)
+        n_img, n_raw = ops_gen.gt_sizes(desc)
+        dev = net.device
+        self.image = torch.zeros(n_img, dtype=torch.float32, device=dev)
+        self.raw = torch.empty(n_raw, dtype=torch.float32, device=dev)
+        self.partials = torch.empty(256 * n_raw, dtype=torch.float32, device=dev)
+
+    def prep(self) -> None:
+        ops_gen.gt_prep(self.desc, self.image)
+
+    def forward(self, x: torch.Tensor, col0: int, idx, mb: int, out0: torch.Tensor, out1=None) -> None:
+        ops_gen.gt_fwd(self.desc, self.image, x, col0, idx, mb, out0, out1)
+
+    def backward(self, x: torch.Tensor, col0: int, idx, mb: int, dh0: torch.Tensor, dh1=None) -> None:
+        ops_gen.gt_bwd(self.desc, self.image, x, col0, idx, mb, dh0, dh1, self.partials, self.raw, self.net.grad)
+
+
 class GenWorkspace:
     """Activation / gradient buffers of one trunk pass over up to ``rows`` rows (allocated once, reused).  Per layer the
     forward keeps ``a`` (post-activation, pre-LayerNorm), the row statistics (mean, rstd) and ``y`` - what
     ``orl_gen_layer_bwd`` and the next layer's weight gradient read."""
 
-    def __init__(self, net: GenNet, rows: int, training: bool) -> None:
+    def __init__(self, net: GenNet, rows: int, training: bool, heads_only: bool = False) -> None:
+        """``heads_only``: the fused towers' workspace - head outputs / gradients and the loss scratch, no per-layer arrays."""
         dev, f = net.device, torch.float32
         e = lambda *s: torch.empty(*s, dtype=f, device=dev)
         self.rows = rows
+        self.heads_only = heads_only
         W = net.max_width
-        self.x0 = e(rows, net.D)
-        self.fn = dict(xhat=e(rows, net.D), rstd=e(rows), y=e(rows, net.D)) if net.fn is not None else None
-        self.layers = []
-        for L in net.layers:
-            self.layers.append(dict(a=e(rows, L["n_out"]) if training else None,
-                                    stats=e(rows, 2) if training else None, y=e(rows, L["n_out"])))
         self.head_out = {k: e(rows, h["n"]) for k, h in net.heads.items()}
+        if not heads_only:
+            self.x0 = e(rows, net.D)
+            self.fn = dict(xhat=e(rows, net.D), rstd=e(rows), y=e(rows, net.D)) if net.fn is not None else None
+            self.layers = []
+            for L in net.layers:
+                self.layers.append(dict(a=e(rows, L["n_out"]) if training else None,
+                                        stats=e(rows, 2) if training else None, y=e(rows, L["n_out"])))
         if training:
             self.dhead = {k: e(rows, h["n"]) for k, h in net.heads.items()}
-            self.da, self.db2, self.dz, self.dfeat = e(rows, W), e(rows, W), e(rows, W), e(rows, W)
-            self.col_partials = e(ops_gen.MAX_BLOCKS * 3 * W)
-            self.wgrad_partials = e(max(4 * W * W, min(512 * W * W, 1 << 24)))
+            if not heads_only:
+                self.da, self.db2, self.dz, self.dfeat = e(rows, W), e(rows, W), e(rows, W), e(rows, W)
+                self.col_partials = e(ops_gen.MAX_BLOCKS * 3 * W)
+                self.wgrad_partials = e(max(4 * W * W, min(512 * W * W, 1 << 24)))
             self.loss_partials = e(ops_gen.MAX_BLOCKS * 20)
             self.loss_sums = {"act": e(20), "v_out": e(20)}
 
@@ -638,14 +697,28 @@ class GenericPPOModule(PPOModule):
             self._side_stream = torch.cuda.Stream(self.device)
         return self._side_stream
 
-    def workspace(self, net: GenNet, rows: int, training: bool, tag: str = "") -> GenWorkspace:
-        key = (id(net), training, tag)
+    def workspace(self, net: GenNet, rows: int, training: bool, tag: str = "", heads_only: bool = False) -> GenWorkspace:
+        key = (id(net), training, tag, heads_only)
         ws = self._ws.get(key)
         if ws is None or ws.rows < rows:
             if ws is not None:  # a captured rollout hipGraph may still point into the old buffers: never free them
                 self._ws_retired.append(ws)
-            ws = self._ws[key] = GenWorkspace(net, rows, training)
+            ws = self._ws[key] = GenWorkspace(net, rows, training, heads_only)
         return ws
+
+    def fused_towers(self, one_pass: bool):
+        """(policy tower, critic tower) of the cross-layer fused update (``cfg.amd_gen_update = fused``), or None when a
+        network is outside what the fused kernels take.  The shared network is ONE tower with both heads and needs the
+        one-pass case (critic observations alias the policy's)."""
+        if getattr(self.cfg, "amd_gen_update", "fused") != "fused" or self.recurrent:
+            return None
+        if self.share_model:
+            if not one_pass:
+                return None
+            ft = self.policy_net.gt(("act", "v_out"))
+            return None if ft is None else (ft, ft)
+        fp, fc = self.policy_net.gt(("act",)), self.critic_net.gt(("v_out",))
+        return None if fp is None or fc is None else (fp, fc)
 
     def gru_workspace(self, net: GenNet, L: int, N: int, training: bool, tag: str = "") -> "GruWorkspace":
         key = ("gru", id(net), training, tag)

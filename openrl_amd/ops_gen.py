@@ -109,6 +109,45 @@ def mlp_fwd(desc, x, head_out0, head_out1=None, feats_out=None) -> None:
     nat.check(rc, "orl_gen_mlp_fwd")
 
 
+def gt_supported(desc) -> bool:
+    return bool(_lib().orl_gt_supported(C.byref(desc)))
+
+
+def gt_sizes(desc):
+    """(image floats, raw gradient-sum floats) of a fused general tower (``orl_gt_image_floats`` / ``orl_gt_raw_floats``)."""
+    a, b = _lib().orl_gt_image_floats(C.byref(desc)), _lib().orl_gt_raw_floats(C.byref(desc))
+    if a < 0 or b < 0:
+        nat.check(-2, "orl_gt_image_floats")
+    return int(a), int(b)
+
+
+def gt_prep(desc, image) -> None:
+    """theta -> the folded / split image the fused tower kernels read (``orl_gt_prep``); after every optimiser step."""
+    dev = nat.require_gpu(image.device)
+    nat.check(_lib().orl_gt_prep(C.byref(desc), fptr(image), stream_ptr(dev)), "orl_gt_prep")
+
+
+def gt_fwd(desc, image, x, col0: int, idx, mb: int, out0, out1=None) -> None:
+    """Head outputs of rows ``x[idx[i] or i, col0 : col0 + D]`` in one launch (``orl_gt_fwd``)."""
+    dev = nat.require_gpu(x.device)
+    assert x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float32 and col0 + desc.D <= x.shape[1]
+    assert out0.is_contiguous() and out0.numel() >= mb * desc.head_n[0]
+    assert idx is None or (idx.dtype == torch.int64 and idx.numel() >= mb)
+    rc = _lib().orl_gt_fwd(C.byref(desc), fptr(image), fptr(x), x.shape[1], col0, ptr(idx), mb, fptr(out0), fptr(out1),
+                           stream_ptr(dev))
+    nat.check(rc, "orl_gt_fwd")
+
+
+def gt_bwd(desc, image, x, col0: int, idx, mb: int, dh0, dh1, partials, raw, grad) -> None:
+    """Backward of the same rows: every gradient the descriptor names is written into ``grad`` (``orl_gt_bwd``)."""
+    dev = nat.require_gpu(x.device)
+    assert x.dim() == 2 and x.is_contiguous() and col0 + desc.D <= x.shape[1]
+    assert dh0.is_contiguous() and dh0.numel() >= mb * desc.head_n[0] and (dh1 is None or dh1.is_contiguous())
+    rc = _lib().orl_gt_bwd(C.byref(desc), fptr(image), fptr(x), x.shape[1], col0, ptr(idx), mb, fptr(dh0), fptr(dh1),
+                           fptr(partials), partials.numel(), fptr(raw), fptr(grad), stream_ptr(dev))
+    nat.check(rc, "orl_gt_bwd")
+
+
 def act_step(policy_desc, obs, critic_desc, critic_obs, values, head: HeadDesc, logstd, action_masks, deterministic: bool,
         seed: int, row0: int, rng_step: int, rng_step_dev, forced_u, a_w: int, actions, logp, logits_out=None) -> None:
     """A rollout step in one launch (``orl_gen_act``): the policy tower, ``sample`` on its logits, and the critic tower
