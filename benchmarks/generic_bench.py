@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--gen_update", default="fused", choices=["fused", "layerwise"])
     ap.add_argument("--activation_id", type=int, default=1)
     ap.add_argument("--obs_dim", type=int, default=4)
+    ap.add_argument("--one_stream", action="store_true", help="both towers' update chains on one stream (per-kernel timing)")
     a = ap.parse_args()
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers import NormalReplayBuffer
@@ -43,6 +44,8 @@ def main():
     env = make("SyntheticFixedStep-v0", env_num=N, obs_dim=a.obs_dim, episode_limit=200, device=dev)
     net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=N)
     cfg.num_env_steps = N * T * (a.steps + a.warmup)
+    if a.one_stream and getattr(net.module, "generic", False):
+        net.module.two_stream = False
 
     class _Agent:
         num_time_steps = 0

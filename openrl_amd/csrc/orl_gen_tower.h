@@ -170,26 +170,29 @@ __device__ __forceinline__ void gt_split(const f32x4 (&in)[NT], u32x4 (&xs)[NT /
 }
 
 // acc += A in over the streamed chunks of one image (A = the image, T layout in / out): KC chunks x 2 row blocks x KS
-// k-steps x 6 products
-template <int H>
+// k-steps x 6 products.  The A fragments of a (row block, k-step) are read PF steps ahead of their MFMAs: with one step
+// the loop is bound by the LDS round trip (~250 cycles per step against 96 of MFMA work, phase profile).
+template <int H, int PF>
 __device__ __forceinline__ void gt_gemm(GtStream<H>& st, const u32x4 (&xs)[H / 32][3], f32x4 (&acc)[H / 16], int j, int q) {
-  constexpr int KS = GtC<H>::KS, KC = GtC<H>::KC, WBS = GtC<H>::WBS;
+  constexpr int KS = GtC<H>::KS, KC = GtC<H>::KC, WBS = GtC<H>::WBS, NS = 2 * KS;
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
     const unsigned short* Wb = st.consume();
-    u32x4 w[2][3];
+    u32x4 w[PF + 1][3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) w[0][p] = *(const u32x4*)(Wb + (p * 32 + j) * WBS + q * 8);
+    for (int s = 0; s < PF; ++s)
 #pragma unroll
-    for (int s = 0; s < 2 * KS; ++s) {
+      for (int p = 0; p < 3; ++p) w[s][p] = *(const u32x4*)(Wb + (p * 32 + 16 * (s / KS) + j) * WBS + (s % KS) * 32 + q * 8);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
       const int mo2 = s / KS, h = s % KS;
-      if (s + 1 < 2 * KS) {
-        const int mo3 = (s + 1) / KS, h3 = (s + 1) % KS;
+      if (s + PF < NS) {
+        const int mo3 = (s + PF) / KS, h3 = (s + PF) % KS;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          w[(s + 1) & 1][p] = *(const u32x4*)(Wb + (p * 32 + 16 * mo3 + j) * WBS + h3 * 32 + q * 8);
+          w[(s + PF) % (PF + 1)][p] = *(const u32x4*)(Wb + (p * 32 + 16 * mo3 + j) * WBS + h3 * 32 + q * 8);
       }
-      const u32x4 wh = w[s & 1][0], wm = w[s & 1][1], wl = w[s & 1][2];
+      const u32x4 wh = w[s % (PF + 1)][0], wm = w[s % (PF + 1)][1], wl = w[s % (PF + 1)][2];
       const int mo = 2 * c + mo2;
       acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
       acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
@@ -327,6 +330,22 @@ __device__ __forceinline__ void gt_wgrad_tile(const float* __restrict__ slab, in
   asm volatile("" ::: "memory");  // keeps hipcc from hoisting the next tile's 8 operand reads (32 VGPRs each) above this one
 }
 
+#ifdef ORL_PROF
+// phase timing build (python -m openrl_amd.csrc.build --prof; tools/gt_phase_prof.py): wave 0 of workgroup 0 adds the
+// s_memtime delta of each phase of its pass loop to an LDS counter
+__device__ unsigned long long g_gt_prof[16];
+#define GT_T(k)                                                                   \
+  do {                                                                            \
+    if (prof_on) {                                                                \
+      const unsigned long long t_now = __builtin_readcyclecounter();              \
+      if (l == 0) atomicAdd(&prof_lds[k], t_now - t_last);                        \
+      t_last = t_now;                                                             \
+    }                                                                             \
+  } while (0)
+#else
+#define GT_T(k) ((void)0)
+#endif
+
 // ------------------------------------------------------------------------------------------------ the kernel
 // H: hidden width (64 / 128); NL: number of H x H layers (n_layers - 1); ND: 16-column blocks of observation registers
 // (1: D <= 16, 4: D <= 64); BWD: backward kernel (forward recompute + gradients) or forward kernel (head outputs).
@@ -334,6 +353,11 @@ template <int H, int NL, int ND, bool BWD>
 __device__ __forceinline__ void gt_body(const GtArgs& A) {
   using Cn = GtC<H>;
   constexpr int NT = Cn::NT, KS = Cn::KS;
+#ifdef ORL_GT_PF_BWD  // build-time experiment
+  constexpr int PF = BWD ? ORL_GT_PF_BWD : 2;
+#else
+  constexpr int PF = BWD ? 1 : 2;  // A-fragment read-ahead (the backward kernel has no registers for a second step)
+#endif
   extern __shared__ __attribute__((aligned(1024))) float smem[];
   const GtLay ly(A.d);
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
@@ -376,10 +400,25 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
     for (int a = 0; a <= NL; ++a) dbs[a] = 0.f;
   }
 
+  auto row_of = [&](int pass) -> long long {
+    const int ii = (pass * GT_WAVES + wave) * 16 + j;
+    const int iv = (pass < n_pass && ii < A.mb) ? ii : 0;  // invalid lanes read row 0 (finite data, zero gradient)
+    return (A.idx != nullptr) ? A.idx[iv] : (long long)iv;
+  };
+  long long row_next = row_of(blockIdx.x);
+#ifdef ORL_PROF
+  __shared__ unsigned long long prof_lds[16];
+  const bool prof_on = BWD && blockIdx.x == 0 && wave == 0;
+  if (prof_on && l < 16) prof_lds[l] = 0ull;
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
   for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+    GT_T(9);
     const int i = (pass * GT_WAVES + wave) * 16 + j;
     const bool valid = i < A.mb;
-    const long long row = (A.idx != nullptr) ? A.idx[valid ? i : 0] : (long long)(valid ? i : 0);
+    // this pass's row index was loaded one pass ago; the next pass's is requested now
+    const long long row = row_next;
+    row_next = row_of(pass + gridDim.x);
     const float* xr = A.x + (size_t)row * A.ldx + A.col0;
 
     // ---- observations: lane (j, q) holds x[j][4 s + q]; feature norm (LayerNorm over the D real columns)
@@ -421,15 +460,17 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
     }
     bits[0] = gt_act<NT>(xh[0], A.d.act[0]);
     gt_ln<NT>(xh[0], mu[0], rstd[0]);
+    GT_T(0);  // observations, fc1, activation, LayerNorm
 #pragma unroll
     for (int k = 1; k <= NL; ++k) {
       u32x4 xs[KS][3];
       gt_split<NT>(xh[k - 1], xs);
       gt_load_vec<NT>(lw + ly.ib(k), q, xh[k]);
-      gt_gemm<H>(st, xs, xh[k], j, q);
+      gt_gemm<H, PF>(st, xs, xh[k], j, q);
       bits[k] = gt_act<NT>(xh[k], A.d.act[k]);
       gt_ln<NT>(xh[k], mu[k], rstd[k]);
     }
+    GT_T(1);  // forward H x H layers: split, streamed GEMM, activation, LayerNorm
 
     if constexpr (!BWD) {
       // ---- heads: out^T[16 c x 16 rows] = W3' xhat_NL^T + b3'; lane (j, q) keeps outputs c = 4q .. 4q + 3 of row j
@@ -485,26 +526,32 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) d[m] = ORL_MFMA(a4[s], dh[s], d[m]);
       }
+      GT_T(2);  // dhead loads, the head's exchange + G3, head input gradient
 #pragma unroll
       for (int k = NL; k >= 0; --k) {
         // d = gradient at xhat_k  ->  dz_k
         gt_ln_act_bwd<NT>(d, xh[k], mu[k], rstd[k], A.d.act[k], bits[k]);
+        GT_T(3);  // LayerNorm + activation backward
         __syncthreads();  // every wave has finished reading the slab's previous contents
         gt_slab_store<NT>(slab, d, wave, j, q);
         __syncthreads();
         gt_slab_A(slab, 16 * os, j, q, Areg, dbs[k]);
         __syncthreads();
+        GT_T(4);  // dz through the slab: 3 barriers, store, A reads
         if (k > 0) {
           gt_slab_store<NT>(slab, xh[k - 1], wave, j, q);
           __syncthreads();
+          GT_T(5);  // xhat through the slab: store + barrier
 #pragma unroll
           for (int t = 0; t < Cn::NTW; ++t) gt_wgrad_tile(slab, 16 * (ip * Cn::NTW + t), j, q, Areg, G[k - 1][t]);
+          GT_T(6);  // G_k MFMAs
           // input gradient d xhat_{k-1} = W_k'^T dz_k through the transposed image's chunks
           u32x4 xs[KS][3];
           gt_split<NT>(d, xs);
 #pragma unroll
           for (int m = 0; m < NT; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-          gt_gemm<H>(st, xs, d, j, q);
+          gt_gemm<H, PF>(st, xs, d, j, q);
+          GT_T(7);  // input gradient: split + streamed GEMM
         } else {
           // the observations as the B operand: rows d = 4 s + q of the slab
 #pragma unroll
@@ -513,11 +560,16 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
 #pragma unroll
           for (int t = 0; t < ND; ++t)
             if (16 * t < D && (t % Cn::IPARTS) == ip) gt_wgrad_tile(slab, 16 * t, j, q, Areg, G0[t]);
+          GT_T(8);  // observations through the slab + G0
         }
       }
     }
   }
 
+#ifdef ORL_PROF
+  if (prof_on && l < 12) atomicAdd(&g_gt_prof[l], prof_lds[l]);
+  if (prof_on && l == 12) atomicAdd(&g_gt_prof[12], (unsigned long long)my_pass);
+#endif
   if constexpr (BWD) {
     // ---- this workgroup's partial row of the raw sums.  A tile's lane (jj = j, qq = q) register r holds
     // (output feature 16 os + 4 q + r, input feature 16 t + j)

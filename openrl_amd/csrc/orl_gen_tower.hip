@@ -4,9 +4,15 @@
 
 namespace orl {
 
-template <int H, int NL, int ND, bool BWD>
-__global__ __launch_bounds__(GT_WAVES * 64, 2) void gt_kernel(GtArgs A) {
-  gt_body<H, NL, ND, BWD>(A);
+// backward: one workgroup per CU (2 waves per SIMD, 256 VGPRs, ~135 KB of LDS); forward: at most 128 VGPRs and ~75 KB, so
+// TWO workgroups share a CU and one's barrier / LDS waits overlap the other's MFMAs
+template <int H, int NL, int ND>
+__global__ __launch_bounds__(GT_WAVES * 64, 2) void gt_bwd_kernel(GtArgs A) {
+  gt_body<H, NL, ND, true>(A);
+}
+template <int H, int NL, int ND>
+__global__ __launch_bounds__(GT_WAVES * 64, 4) void gt_fwd_kernel(GtArgs A) {
+  gt_body<H, NL, ND, false>(A);
 }
 
 // ------------------------------------------------------------------------------------------------ image
@@ -39,11 +45,52 @@ __device__ __forceinline__ void gt_image_store(unsigned short* __restrict__ chun
   base[64 * WBS] = (unsigned short)(f2u(l1) >> 16);
 }
 
+// sum over the 16 lanes of an aligned lane group, result in all of them
+__device__ __forceinline__ float gt_sum16(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+// Work split of the two small kernels: DOT items (a reduction of up to 128 terms) take 16 lanes each, 4 items per wave
+// and round, every lane of a wave running the same number of rounds (the shuffles are wave-wide); ELEMENT items take one
+// thread each.
 __global__ __launch_bounds__(256) void gt_prep_kernel(orl_gt_desc d, float* __restrict__ img) {
   const GtLay ly(d);
   const int H = ly.H, D = ly.D, NLt = ly.NLt, ntot = ly.ntot;
-  const int nA = H * ly.DPS, nB = NLt * H, nC = GT_HEADS, nD = H * 20, nE = GT_HEADS * (H + 4), nF = ly.NL * H * H;
-  const int total = nA + nB + nC + nD + nE + nF;
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+  const int wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  // ---- folded biases: item = (layer l, output o) for l < NLt, then the head outputs c
+  const int n_dot = NLt * H + GT_HEADS;
+  for (int base = wave_g * 4; base < n_dot; base += n_waves * 4) {
+    const int it = base + grp;
+    float acc = 0.f, b = 0.f;
+    int dst = -1;
+    if (it < NLt * H) {
+      const int l = it / H, o = it - l * H, n_in = l == 0 ? D : H;
+      dst = ly.ib(l) + o;
+      b = d.theta[d.ob[l] + o];
+      if (l > 0 || d.o_fn_be >= 0) {
+        const float* wrow = d.theta + d.oW[l] + o * n_in;
+        for (int k = sub; k < n_in; k += 16) acc += wrow[k] * gt_bein(d, l, k);
+      }
+    } else if (it < n_dot) {
+      const int c = it - NLt * H;
+      dst = ly.ib3 + c;
+      if (c < ntot) {
+        const float* wrow = gt_head_row(d, c);
+        b = gt_head_bias(d, c);
+        for (int f = sub; f < H; f += 16) acc += wrow[f] * d.theta[d.obe[NLt - 1] + f];
+      }
+    }
+    acc = gt_sum16(acc);
+    if (dst >= 0 && sub == 0) img[dst] = b + acc;
+  }
+  // ---- element items
+  const int nA = H * ly.DPS, nD = H * 20, nE = GT_HEADS * (H + 4), nF = ly.NL * H * H;
+  const int total = nA + nD + nE + nF;
   const int WBS = H + 8, chunk_ushorts = ly.chunk_floats * 2;
   unsigned short* chunks = (unsigned short*)(img + ly.iChunks);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -54,29 +101,6 @@ __global__ __launch_bounds__(256) void gt_prep_kernel(orl_gt_desc d, float* __re
       continue;
     }
     t -= nA;
-    if (t < nB) {  // folded biases b_l + W_l be_{l-1}
-      const int l = t / H, o = t - l * H, n_in = l == 0 ? D : H;
-      float acc = 0.f;
-      if (l > 0 || d.o_fn_be >= 0) {
-        const float* wrow = d.theta + d.oW[l] + o * n_in;
-        for (int k = 0; k < n_in; ++k) acc += wrow[k] * gt_bein(d, l, k);
-      }
-      img[ly.ib(l) + o] = d.theta[d.ob[l] + o] + acc;
-      continue;
-    }
-    t -= nB;
-    if (t < nC) {  // head biases b3 + W3 be_NL
-      float v = 0.f;
-      if (t < ntot) {
-        const float* wrow = gt_head_row(d, t);
-        float acc = 0.f;
-        for (int f = 0; f < H; ++f) acc += wrow[f] * d.theta[d.obe[NLt - 1] + f];
-        v = gt_head_bias(d, t) + acc;
-      }
-      img[ly.ib3 + t] = v;
-      continue;
-    }
-    t -= nC;
     if (t < nD) {  // (W3 diag(g_NL))^T as [H][20]
       const int f = t / 20, c = t - f * 20;
       img[ly.iW3T + t] = c < ntot ? gt_head_row(d, c)[f] * d.theta[d.og[NLt - 1] + f] : 0.f;
@@ -103,23 +127,41 @@ __global__ __launch_bounds__(256) void gt_finalize_kernel(orl_gt_desc d, const f
   const GtLay ly(d);
   const int H = ly.H, D = ly.D, NLt = ly.NLt, ntot = ly.ntot;
   const bool fn = d.o_fn_g >= 0;
-  // work items: [fn: 2 D] + per layer (n_in H + 3 H) + per head (n H + n)
-  int total = fn ? 2 * D : 0;
-  for (int l = 0; l < NLt; ++l) total += (l == 0 ? D : H) * H + 3 * H;
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+  const int wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  // ---- DOT items: the LayerNorm affines as linear images of the NEXT Linear's sums.  item = (layer l, which, column i),
+  // l = -1 for the feature norm: d g[i] = sum_o W[o][i] G[o][i], d be[i] = sum_o W[o][i] db[o]
+  const int n_fn = fn ? 2 * D : 0, n_dot = n_fn + NLt * 2 * H;
+  for (int base = wave_g * 4; base < n_dot; base += n_waves * 4) {
+    const int it = base + grp;
+    float acc = 0.f;
+    int dst = -1;
+    if (it < n_fn) {
+      const int which = it / D, k = it - which * D;
+      dst = (which == 0 ? d.o_fn_g : d.o_fn_be) + k;
+      for (int o = sub; o < H; o += 16)
+        acc += d.theta[d.oW[0] + o * D + k] * (which == 0 ? raw[ly.rG0 + o * ly.DP16 + k] : raw[ly.rdb(0) + o]);
+    } else if (it < n_dot) {
+      const int t = it - n_fn, l = t / (2 * H), r = t - l * 2 * H, which = r / H, i = r - which * H;
+      dst = (which == 0 ? d.og[l] : d.obe[l]) + i;
+      if (l + 1 < NLt) {
+        const float* W = d.theta + d.oW[l + 1];
+        for (int o = sub; o < H; o += 16)
+          acc += W[o * H + i] * (which == 0 ? raw[ly.rG(l + 1) + o * H + i] : raw[ly.rdb(l + 1) + o]);
+      } else {
+        for (int c = sub; c < ntot; c += 16)
+          acc += gt_head_row(d, c)[i] * (which == 0 ? raw[ly.rG3 + c * H + i] : raw[ly.rdb3 + c]);
+      }
+    }
+    acc = gt_sum16(acc);
+    if (dst >= 0 && sub == 0) grad[dst] = acc;
+  }
+  // ---- ELEMENT items: per layer (n_in H weights + H biases), per head output (H weights + 1 bias)
+  int total = 0;
+  for (int l = 0; l < NLt; ++l) total += (l == 0 ? D : H) * H + H;
   total += ntot * H + ntot;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     int t = e;
-    if (fn) {
-      if (t < 2 * D) {  // d g_fn[k] = sum_o W0[o][k] G0[o][k],  d be_fn[k] = sum_o W0[o][k] db0[o]
-        const int which = t / D, k = t - which * D;
-        float acc = 0.f;
-        for (int o = 0; o < H; ++o)
-          acc += d.theta[d.oW[0] + o * D + k] * (which == 0 ? raw[ly.rG0 + o * ly.DP16 + k] : raw[ly.rdb(0) + o]);
-        grad[(which == 0 ? d.o_fn_g : d.o_fn_be) + k] = acc;
-        continue;
-      }
-      t -= 2 * D;
-    }
     bool done = false;
     for (int l = 0; l < NLt && !done; ++l) {
       const int n_in = l == 0 ? D : H;
@@ -138,21 +180,6 @@ __global__ __launch_bounds__(256) void gt_finalize_kernel(orl_gt_desc d, const f
         break;
       }
       t -= H;
-      if (t < 2 * H) {  // the LayerNorm behind layer l: linear images of the NEXT Linear's sums
-        const int which = t / H, i = t - which * H;
-        float acc = 0.f;
-        if (l + 1 < NLt) {
-          const float* W = d.theta + d.oW[l + 1];
-          for (int o = 0; o < H; ++o) acc += W[o * H + i] * (which == 0 ? raw[ly.rG(l + 1) + o * H + i] : raw[ly.rdb(l + 1) + o]);
-        } else {
-          for (int c = 0; c < ntot; ++c)
-            acc += gt_head_row(d, c)[i] * (which == 0 ? raw[ly.rG3 + c * H + i] : raw[ly.rdb3 + c]);
-        }
-        grad[(which == 0 ? d.og[l] : d.obe[l]) + i] = acc;
-        done = true;
-        break;
-      }
-      t -= 2 * H;
     }
     if (done) continue;
     if (t < ntot * H) {  // head weights: G3[c][f] g_NL[f] + db3[c] be_NL[f]
@@ -196,8 +223,13 @@ static int gt_check(const orl_gt_desc* d, const char* who) {
 
 template <int H, int NL, int ND, bool BWD>
 static void gt_launch_inst(const GtArgs& A, int grid, size_t lds, hipStream_t s) {
-  (void)hipFuncSetAttribute((const void*)gt_kernel<H, NL, ND, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((gt_kernel<H, NL, ND, BWD>), dim3(grid), dim3(GT_WAVES * 64), lds, s, A);
+  if constexpr (BWD) {
+    (void)hipFuncSetAttribute((const void*)gt_bwd_kernel<H, NL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gt_bwd_kernel<H, NL, ND>), dim3(grid), dim3(GT_WAVES * 64), lds, s, A);
+  } else {
+    (void)hipFuncSetAttribute((const void*)gt_fwd_kernel<H, NL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gt_fwd_kernel<H, NL, ND>), dim3(grid), dim3(GT_WAVES * 64), lds, s, A);
+  }
 }
 
 template <bool BWD>
@@ -224,6 +256,16 @@ using namespace orl;
 
 extern "C" {
 
+#ifdef ORL_PROF
+int orl_gt_debug_prof(unsigned long long* out16) {
+  unsigned long long zero[16] = {0};
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gt_prof), sizeof(zero));
+  hipMemcpyToSymbol(HIP_SYMBOL(g_gt_prof), zero, sizeof(zero));
+  return 0;
+}
+#endif
+
 int orl_gt_supported(const orl_gt_desc* d) { return gt_check(d, "orl_gt_supported") == 0 ? 1 : 0; }
 
 int64_t orl_gt_image_floats(const orl_gt_desc* d) {
@@ -240,7 +282,7 @@ int orl_gt_prep(const orl_gt_desc* d, float* image, void* stream) {
   int rc = gt_check(d, "orl_gt_prep");
   if (rc) return rc;
   ORL_REQUIRE(image, "orl_gt_prep: null image");
-  hipLaunchKernelGGL(gt_prep_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, *d, image);
+  hipLaunchKernelGGL(gt_prep_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, *d, image);
   return launch_status("orl_gt_prep");
 }
 
@@ -255,7 +297,9 @@ int orl_gt_fwd(const orl_gt_desc* d, const float* image, const float* x, int ldx
   A.d = *d; A.image = image; A.x = x; A.ldx = ldx; A.col0 = col0; A.idx = (const long long*)idx; A.mb = mb;
   A.out0 = head_out0; A.out1 = head_out1;
   const int n_pass = ((mb + 15) / 16 + GT_WAVES - 1) / GT_WAVES;
-  const int grid = n_pass < 256 ? n_pass : 256;
+  const size_t lds_fwd = gt_lds_bytes(ly, false);
+  const int per_cu = lds_fwd <= 80 * 1024 ? 2 : 1;
+  const int grid = n_pass < 256 * per_cu ? n_pass : 256 * per_cu;
   rc = gt_launch<false>(A, grid, gt_lds_bytes(ly, false), (hipStream_t)stream);
   if (rc) return rc;
   return launch_status("orl_gt_fwd");

@@ -756,7 +756,13 @@ class GenericPPOModule(PPOModule):
         self.rng_step += T
         if not self.share_model:
             rows = (T + 1) * N
-            ops_gen.mlp_fwd(cn.mlp_desc(("v_out",)), data.critic_obs.view(rows, self.Dc), data.value_preds.view(rows, 1), None)
+            ft = cn.gt(("v_out",)) if getattr(self.cfg, "amd_gen_update", "fused") == "fused" else None
+            if ft is not None:  # the update's forward kernel: activations on chip, two workgroups per CU
+                ft.prep()
+                ft.forward(data.critic_obs.view(rows, self.Dc), 0, None, rows, data.value_preds.view(rows, 1))
+            else:
+                ops_gen.mlp_fwd(cn.mlp_desc(("v_out",)), data.critic_obs.view(rows, self.Dc), data.value_preds.view(rows, 1),
+                                None)
             next_value_out.copy_(data.value_preds[T])
 
     def _logstd(self):
