@@ -790,7 +790,7 @@ int orl_gt_fwd(const orl_gt_desc* d, const float* image, const float* x, int ldx
                float* head_out0, float* head_out1, void* stream);
 /* Backward of the same rows given dhead = d loss / d head outputs [mb, head_n]: the forward is recomputed on chip, the
  * gradient of every parameter the descriptor names is WRITTEN into grad (same offsets as theta).  partials: scratch of
- * >= raw floats (up to 256 rows of them are used: one per workgroup, summed in a fixed order), raw: raw floats. */
+ * >= raw floats (up to 512 rows of them are used: one per workgroup, summed in a fixed order), raw: raw floats. */
 int orl_gt_bwd(const orl_gt_desc* d, const float* image, const float* x, int ldx, int col0, const int64_t* idx, int mb,
                const float* dhead0, const float* dhead1, float* partials, int64_t partials_floats, float* raw, float* grad,
                void* stream);

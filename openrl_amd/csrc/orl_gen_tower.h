@@ -8,8 +8,8 @@
 //   orl_gt_prep  theta -> "image": LayerNorm affines folded into the next Linear (exact algebra:
 //                W (xhat g + be) + b = (W diag g) xhat + (b + W be)), the H x H matrices as three-term bf16 split
 //                images (orl_mlp.h) of W' and W'^T in the chunk order the kernels stream them
-//   gt_kernel<H, NL, ND, false>  forward: rows -> head outputs (logits / values); activations never leave the chip
-//   gt_kernel<H, NL, ND, true>   backward: recomputes the forward of its rows, takes d loss / d head outputs and
+//   gt_fwd_kernel<H, NL, ND>  forward: rows -> head outputs (logits / values); activations never leave the chip
+//   gt_bwd_kernel<H, NL, ND, NW>  backward: recomputes the forward of its rows, takes d loss / d head outputs and
 //                accumulates the RAW gradient sums G_l = dz_l^T xhat_{l-1}, db_l = sum dz_l in registers
 //   gt_finalize  raw sums -> gradients in the parameter vector's layout (dW = G diag g + db be^T, d g_l / d be_l as
 //                linear images of the next layer's sums - the relations of orl_common.h's RawLayout)
@@ -33,9 +33,7 @@
 
 namespace orl {
 
-constexpr int GT_WAVES = 8;          // waves per workgroup
-constexpr int GT_ROWS = 128;         // rows per workgroup pass
-constexpr int GT_RS = GT_ROWS + 4;   // slab row stride (floats): [feature][row], conflict-free both ways
+constexpr int GT_WAVES = 8;          // waves per workgroup of the forward kernel (and of the backward's 8-wave build)
 constexpr int GT_HEADS = 16;         // head outputs (all heads together) are padded to 16
 
 template <int H>
@@ -46,9 +44,21 @@ struct GtC {
   static constexpr int WBS = H + 8;                        // bf16 image row stride (elements): 16-byte skew
   static constexpr int CB = 3 * 32 * WBS * 2;              // chunk bytes
   static constexpr int CBP = (CB + 1023) / 1024 * 1024;    // padded to whole-wave DMA blocks
-  static constexpr int NOS = H / 16;                       // output-feature slices of the cooperative wgrad
-  static constexpr int IPARTS = GT_WAVES / NOS;            // input-feature parts (H = 128: 1, H = 64: 2)
-  static constexpr int NTW = NT / IPARTS;                  // 16-column tiles of G_l per wave
+};
+
+// Partition of the cooperative weight gradients over the NW waves of a workgroup (a pass = 16 NW rows): wave w owns OSW
+// output-feature slices of 16 x an input-feature part of NTW 16-column tiles of every G_l.
+template <int H, int NW>
+struct GtW {
+  static constexpr int NT = H / 16;
+  static constexpr int R = 16 * NW;                        // rows per pass
+  static constexpr int RS = R + 4;                         // slab row stride (floats): [feature][row]
+  static constexpr int RG = R / 16;                        // 16-row groups of the pass = b128 reads per operand column
+  static constexpr int OSW = NT >= NW ? NT / NW : 1;       // output slices per wave
+  static constexpr int NOSG = NT / OSW;                    // groups of output slices
+  static constexpr int IPARTS = NW / NOSG;                 // input-feature parts
+  static constexpr int NTW = NT / IPARTS;                  // input tiles per owned output slice
+  static constexpr int G3T = (NT + NW - 1) / NW;           // head feature tiles per wave
 };
 
 // Offsets (floats) of the image and of the raw gradient-sum vector; evaluated on host and device from the descriptor
@@ -110,19 +120,23 @@ struct GtArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ chunk stream
-template <int H>
+// Two buffers: chunk n lands in buffer n & 1.  Buffer 1 may ALIAS the backward kernel's exchange slab: a GEMM has an even
+// number of chunks and starts in buffer 0, the chunk prefetched across the exchange phases is always a GEMM's first one
+// (buffer 0), and buffer 1 is only written after the barrier of a consume() inside a GEMM, when every wave has left the
+// preceding exchange phase; the slab is only written after a barrier that follows the GEMM's last chunk.
+template <int H, int NW>
 struct GtStream {
   static constexpr int CBP = GtC<H>::CBP;
   const char* gsrc;   // this lane's global source of chunk 0: image chunks + wave * 1024 + lane * 16
-  unsigned ldst;      // LDS byte address of this wave's first block in buffer 0
-  char* lbase;        // generic pointer to buffer 0
+  unsigned ldst[2];   // LDS byte address of this wave's first block in the two buffers
+  char* lbase[2];     // generic pointers to the buffers
   int cpp, total, n, pos, wave;
 
   __device__ __forceinline__ void issue(int p, int buf) {
     const char* src = gsrc + (size_t)p * CBP;
-    const unsigned dst = ldst + (unsigned)buf * CBP;
+    const unsigned dst = ldst[buf];
 #pragma unroll
-    for (int off = 0; off < CBP; off += GT_WAVES * 1024) {
+    for (int off = 0; off < CBP; off += NW * 1024) {
       if (off + wave * 1024 < CBP) {
         // (asm on purpose - see orl_ppo_tower.h: hipcc would drain a __builtin_amdgcn_global_load_lds right after the issue)
         unsigned keep;
@@ -135,10 +149,13 @@ struct GtStream {
       }
     }
   }
-  __device__ __forceinline__ void start(const float* chunks, float* lds_buf, int cpp_, int total_, int wave_, int lane) {
+  __device__ __forceinline__ void start(const float* chunks, float* buf0, float* buf1, int cpp_, int total_, int wave_,
+                                        int lane) {
     gsrc = (const char*)chunks + wave_ * 1024 + lane * 16;
-    lbase = (char*)lds_buf;
-    ldst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lbase + (unsigned)wave_ * 1024u;
+    lbase[0] = (char*)buf0;
+    lbase[1] = (char*)buf1;
+    ldst[0] = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lbase[0] + (unsigned)wave_ * 1024u;
+    ldst[1] = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lbase[1] + (unsigned)wave_ * 1024u;
     cpp = cpp_; total = total_; n = 0; pos = 0; wave = wave_;
     if (total > 0) issue(0, 0);
   }
@@ -151,7 +168,7 @@ struct GtStream {
       pos = pos + 1 == cpp ? 0 : pos + 1;
       issue(pos, nx & 1);
     }
-    const unsigned short* r = (const unsigned short*)(lbase + (size_t)(n & 1) * CBP);
+    const unsigned short* r = (const unsigned short*)((n & 1) ? lbase[1] : lbase[0]);
     n = nx;
     return r;
   }
@@ -169,39 +186,79 @@ __device__ __forceinline__ void gt_split(const f32x4 (&in)[NT], u32x4 (&xs)[NT /
   }
 }
 
+// ---- LDS reads the compiler cannot reschedule.  hipcc, close to the VGPR limit, sinks every ds_read of a software-
+// pipelined loop right in front of its consumer and waits lgkmcnt(0) there: the GEMM loops then pay a full LDS round
+// trip per 16-byte fragment (measured: 4 500 cycles per chunk against 770 of MFMA work).  These reads are volatile asm
+// (issued where they are written), and the wait is an asm that "modifies" the registers it guards, so that the MFMAs
+// consuming them cannot move above it.  LDS operations of a wave complete in order, so lgkmcnt(n) with n younger reads in
+// flight guarantees the guarded ones; compiler-issued LDS / scalar loads in between only make a wait conservative.
+__device__ __forceinline__ unsigned gt_lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 gt_ds_read128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void gt_lds_wait(u32x4& a, u32x4& b, u32x4& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void gt_lds_wait(u32x4& a) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I = B .. E-1 (asm immediates need constant expressions)
+template <int I> struct GtIdx { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void gt_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(GtIdx<B>{});
+    gt_static_for<B + 1, E>(f);
+  }
+}
+
 // acc += A in over the streamed chunks of one image (A = the image, T layout in / out): KC chunks x 2 row blocks x KS
-// k-steps x 6 products.  The A fragments of a (row block, k-step) are read PF steps ahead of their MFMAs: with one step
-// the loop is bound by the LDS round trip (~250 cycles per step against 96 of MFMA work, phase profile).
-template <int H, int PF>
-__device__ __forceinline__ void gt_gemm(GtStream<H>& st, const u32x4 (&xs)[H / 32][3], f32x4 (&acc)[H / 16], int j, int q) {
+// k-steps x 6 products.  The three A fragments of a (row block, k-step) are read PF steps ahead of their MFMAs.
+template <int H, int NW, int PF>
+__device__ __forceinline__ void gt_gemm(GtStream<H, NW>& st, const u32x4 (&xs)[H / 32][3], f32x4 (&acc)[H / 16], int j, int q) {
   constexpr int KS = GtC<H>::KS, KC = GtC<H>::KC, WBS = GtC<H>::WBS, NS = 2 * KS;
-#pragma unroll
-  for (int c = 0; c < KC; ++c) {
+  gt_static_for<0, KC>([&](auto ci) {
+    constexpr int c = decltype(ci)::value;
     const unsigned short* Wb = st.consume();
+    const unsigned base = gt_lds_addr(Wb) + (unsigned)(j * WBS + q * 8) * 2u;
     u32x4 w[PF + 1][3];
-#pragma unroll
-    for (int s = 0; s < PF; ++s)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) w[s][p] = *(const u32x4*)(Wb + (p * 32 + 16 * (s / KS) + j) * WBS + (s % KS) * 32 + q * 8);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int mo2 = s / KS, h = s % KS;
-      if (s + PF < NS) {
-        const int mo3 = (s + PF) / KS, h3 = (s + PF) % KS;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          w[(s + PF) % (PF + 1)][p] = *(const u32x4*)(Wb + (p * 32 + 16 * mo3 + j) * WBS + h3 * 32 + q * 8);
+#define GT_FRAG_OFF(p, s) ((((p) * 32 + 16 * ((s) / KS)) * WBS + ((s) % KS) * 32) * 2)
+    gt_static_for<0, PF>([&](auto si) {
+      constexpr int s = decltype(si)::value;
+      w[s][0] = gt_ds_read128<GT_FRAG_OFF(0, s)>(base);
+      w[s][1] = gt_ds_read128<GT_FRAG_OFF(1, s)>(base);
+      w[s][2] = gt_ds_read128<GT_FRAG_OFF(2, s)>(base);
+    });
+    gt_static_for<0, NS>([&](auto si) {
+      constexpr int s = decltype(si)::value;
+      if constexpr (s + PF < NS) {
+        w[(s + PF) % (PF + 1)][0] = gt_ds_read128<GT_FRAG_OFF(0, s + PF)>(base);
+        w[(s + PF) % (PF + 1)][1] = gt_ds_read128<GT_FRAG_OFF(1, s + PF)>(base);
+        w[(s + PF) % (PF + 1)][2] = gt_ds_read128<GT_FRAG_OFF(2, s + PF)>(base);
       }
-      const u32x4 wh = w[s % (PF + 1)][0], wm = w[s % (PF + 1)][1], wl = w[s % (PF + 1)][2];
-      const int mo = 2 * c + mo2;
+      constexpr int ahead = (NS - 1 - s) < PF ? (NS - 1 - s) : PF;  // younger steps in flight
+      u32x4& wh = w[s % (PF + 1)][0];
+      u32x4& wm = w[s % (PF + 1)][1];
+      u32x4& wl = w[s % (PF + 1)][2];
+      gt_lds_wait<3 * ahead>(wh, wm, wl);
+      constexpr int mo = 2 * c + s / KS, h = s % KS;
       acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
       acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
       acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
       acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
       acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
       acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
-    }
-  }
+    });
+#undef GT_FRAG_OFF
+  });
 }
 
 template <int NT>
@@ -299,35 +356,50 @@ __device__ __forceinline__ void gt_ln_act_bwd(f32x4 (&d)[NT], const f32x4 (&xhat
 }
 
 // T layout -> slab [feature][row]: feature 16m + 4q + r of row 16 wave + j
-template <int NT>
+template <int NT, int RS>
 __device__ __forceinline__ void gt_slab_store(float* __restrict__ slab, const f32x4 (&x)[NT], int wave, int j, int q) {
 #pragma unroll
   for (int m = 0; m < NT; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) slab[(16 * m + 4 * q + r) * GT_RS + 16 * wave + j] = x[m][r];
+    for (int r = 0; r < 4; ++r) slab[(16 * m + 4 * q + r) * RS + 16 * wave + j] = x[m][r];
 }
 
 // the A registers of a 16-feature slice: lane (m = j, kq = q) takes feature f0 + j, rows 16 g + 4 q + e
-__device__ __forceinline__ void gt_slab_A(const float* __restrict__ slab, int f0, int j, int q, f32x4 (&A)[8], float& colsum) {
+template <int RG, int RS>
+__device__ __forceinline__ void gt_slab_A(const float* __restrict__ slab, int f0, int j, int q, f32x4 (&A)[RG], float& colsum) {
   float s = 0.f;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    A[g] = *(const f32x4*)(slab + (f0 + j) * GT_RS + 16 * g + 4 * q);
+  for (int g = 0; g < RG; ++g) {
+    A[g] = *(const f32x4*)(slab + (f0 + j) * RS + 16 * g + 4 * q);
     s += (A[g][0] + A[g][1]) + (A[g][2] + A[g][3]);
   }
   colsum += s;
 }
 
-// acc[16 x 16 tile] += A^T-slice (registers) x slab features [n0, n0 + 16) over the 128 rows: 32 fp32 MFMAs
-__device__ __forceinline__ void gt_wgrad_tile(const float* __restrict__ slab, int n0, int j, int q, const f32x4 (&A)[8],
-                                              f32x4& acc) {
+// acc[t] (16 x 16 tiles) += A^T-slice (registers) x slab features [16 t, 16 t + 16) beyond `base` over the pass's rows:
+// 4 RG fp32 MFMAs per tile; the B operand reads (one 16-byte read per 4 MFMAs) run two reads ahead (see gt_ds_read128).
+// base = LDS byte address of this lane's first read: slab + ((first feature + j) * RS + 4 q) * 4.
+template <int NTILES, int RG, int RS>
+__device__ __forceinline__ void gt_wgrad_tiles(unsigned base, const f32x4 (&A)[RG], f32x4 (&acc)[NTILES]) {
+  constexpr int N = NTILES * RG, PFW = 2;
+  u32x4 b[PFW + 1];
+#define GT_B_OFF(n) ((((n) / RG) * 16 * RS + ((n) % RG) * 16) * 4)
+  gt_static_for<0, (PFW < N ? PFW : N)>([&](auto ni) {
+    constexpr int n = decltype(ni)::value;
+    b[n] = gt_ds_read128<GT_B_OFF(n)>(base);
+  });
+  gt_static_for<0, N>([&](auto ni) {
+    constexpr int n = decltype(ni)::value;
+    if constexpr (n + PFW < N) b[(n + PFW) % (PFW + 1)] = gt_ds_read128<GT_B_OFF(n + PFW)>(base);
+    constexpr int ahead = (N - 1 - n) < PFW ? (N - 1 - n) : PFW;
+    u32x4& bb = b[n % (PFW + 1)];
+    gt_lds_wait<ahead>(bb);
+    const f32x4 bv = __builtin_bit_cast(f32x4, bb);
+    constexpr int t = n / RG, g = n % RG;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    const f32x4 b = *(const f32x4*)(slab + (n0 + j) * GT_RS + 16 * g + 4 * q);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = ORL_MFMA(A[g][e], b[e], acc);
-  }
-  asm volatile("" ::: "memory");  // keeps hipcc from hoisting the next tile's 8 operand reads (32 VGPRs each) above this one
+    for (int e = 0; e < 4; ++e) acc[t] = ORL_MFMA(A[g][e], bv[e], acc[t]);
+  });
+#undef GT_B_OFF
 }
 
 #ifdef ORL_PROF
@@ -349,10 +421,13 @@ __device__ unsigned long long g_gt_prof[16];
 // ------------------------------------------------------------------------------------------------ the kernel
 // H: hidden width (64 / 128); NL: number of H x H layers (n_layers - 1); ND: 16-column blocks of observation registers
 // (1: D <= 16, 4: D <= 64); BWD: backward kernel (forward recompute + gradients) or forward kernel (head outputs).
-template <int H, int NL, int ND, bool BWD>
+// NW: waves per workgroup - the backward kernel is built with 4 (two workgroups per CU when the LDS allows, their phases
+// interleave) and 8 (one workgroup per CU, wide observations); the forward kernel with 8.
+template <int H, int NL, int ND, bool BWD, int NW>
 __device__ __forceinline__ void gt_body(const GtArgs& A) {
   using Cn = GtC<H>;
-  constexpr int NT = Cn::NT, KS = Cn::KS;
+  using Wn = GtW<H, NW>;
+  constexpr int NT = Cn::NT, KS = Cn::KS, RS = Wn::RS, RG = Wn::RG, OSW = Wn::OSW, NTW = Wn::NTW;
 #ifdef ORL_GT_PF_BWD  // build-time experiment
   constexpr int PF = BWD ? ORL_GT_PF_BWD : 2;
 #else
@@ -363,19 +438,20 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
   const int res = BWD ? ly.res_bwd : ly.res_fwd;
   const int res_pad = (res + 255) & ~255;
-  float* cbuf = smem + res_pad;                                   // two chunk buffers
-  float* slab = cbuf + 2 * (Cn::CBP / 4);                         // [H][GT_RS] (backward only)
+  float* cbuf = smem + res_pad;                                   // chunk buffer 0
+  // backward: the exchange slab [H][RS], which is also chunk buffer 1 (see GtStream); forward: a second chunk buffer
+  float* slab = cbuf + Cn::CBP / 4;
   const float* lw = smem;
 
   const int n_tiles = (A.mb + 15) >> 4;
-  const int n_pass = (n_tiles + GT_WAVES - 1) / GT_WAVES;
+  const int n_pass = (n_tiles + NW - 1) / NW;
   const int my_pass = ((int)blockIdx.x < n_pass) ? (n_pass - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int cpp = (BWD ? 2 : 1) * NL * Cn::KC;
 
-  GtStream<H> st;
-  st.start(A.image + ly.iChunks, cbuf, cpp, my_pass * cpp, wave, l);
+  GtStream<H, NW> st;
+  st.start(A.image + ly.iChunks, cbuf, slab, cpp, my_pass * cpp, wave, l);
   // resident part of the image: fc1's fp32 matrix, the folded biases, the head matrices
-  for (int e = threadIdx.x * 4; e < res; e += GT_WAVES * 64 * 4) *(f32x4*)(smem + e) = *(const f32x4*)(A.image + e);
+  for (int e = threadIdx.x * 4; e < res; e += NW * 64 * 4) *(f32x4*)(smem + e) = *(const f32x4*)(A.image + e);
   __syncthreads();
 
   const int D = ly.D, DPS = ly.DPS, nks = ly.DP >> 2;
@@ -383,25 +459,33 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
   const bool fn = A.d.o_fn_g >= 0;
 
   // ---- persistent accumulators of the cooperative weight gradients (backward)
-  const int os = wave % Cn::NOS, ip = wave / Cn::NOS;
-  f32x4 G[NL > 0 ? NL : 1][Cn::NTW];
-  f32x4 G0[ND];
-  f32x4 G3 = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbs[NL + 1];
+  const int osg = wave % Wn::NOSG, ip = wave / Wn::NOSG;  // output slices 16 (osg OSW + a), input tiles ip NTW + t
+  f32x4 G[NL > 0 ? NL : 1][OSW][NTW];
+  f32x4 G0[OSW][ND];
+  f32x4 G3[Wn::G3T];
+  float dbs[NL + 1][OSW];
   float db3 = 0.f;
   if constexpr (BWD) {
 #pragma unroll
     for (int a = 0; a < NL; ++a)
 #pragma unroll
-      for (int b = 0; b < Cn::NTW; ++b) G[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int o = 0; o < OSW; ++o)
 #pragma unroll
-    for (int b = 0; b < ND; ++b) G0[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTW; ++t) G[a][o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int a = 0; a <= NL; ++a) dbs[a] = 0.f;
+    for (int o = 0; o < OSW; ++o)
+#pragma unroll
+      for (int t = 0; t < ND; ++t) G0[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < Wn::G3T; ++u) G3[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a <= NL; ++a)
+#pragma unroll
+      for (int o = 0; o < OSW; ++o) dbs[a][o] = 0.f;
   }
 
   auto row_of = [&](int pass) -> long long {
-    const int ii = (pass * GT_WAVES + wave) * 16 + j;
+    const int ii = (pass * NW + wave) * 16 + j;
     const int iv = (pass < n_pass && ii < A.mb) ? ii : 0;  // invalid lanes read row 0 (finite data, zero gradient)
     return (A.idx != nullptr) ? A.idx[iv] : (long long)iv;
   };
@@ -414,7 +498,7 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
 #endif
   for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
     GT_T(9);
-    const int i = (pass * GT_WAVES + wave) * 16 + j;
+    const int i = (pass * NW + wave) * 16 + j;
     const bool valid = i < A.mb;
     // this pass's row index was loaded one pass ago; the next pass's is requested now
     const long long row = row_next;
@@ -466,7 +550,7 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
       u32x4 xs[KS][3];
       gt_split<NT>(xh[k - 1], xs);
       gt_load_vec<NT>(lw + ly.ib(k), q, xh[k]);
-      gt_gemm<H, PF>(st, xs, xh[k], j, q);
+      gt_gemm<H, NW, PF>(st, xs, xh[k], j, q);
       bits[k] = gt_act<NT>(xh[k], A.d.act[k]);
       gt_ln<NT>(xh[k], mu[k], rstd[k]);
     }
@@ -503,20 +587,26 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
         dh[s] = v;
       }
       // ---- G3 += dhead^T xhat_NL, db3 += sum dhead
-      f32x4 Areg[8];
-      __syncthreads();  // (the previous pass's last slab reads are done)
+      f32x4 Areg[OSW][RG];
+      __syncthreads();  // (the forward's last chunk - buffer 1 = the slab - has been consumed by every wave)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) slab[(4 * q + s) * GT_RS + 16 * wave + j] = dh[s];
+      for (int s = 0; s < 4; ++s) slab[(4 * q + s) * RS + 16 * wave + j] = dh[s];
       __syncthreads();
       {
         float cs = 0.f;
-        gt_slab_A(slab, 0, j, q, Areg, cs);
+        gt_slab_A<RG, RS>(slab, 0, j, q, Areg[0], cs);
         db3 += cs;
       }
       __syncthreads();
-      gt_slab_store<NT>(slab, xh[NL], wave, j, q);
+      gt_slab_store<NT, RS>(slab, xh[NL], wave, j, q);
       __syncthreads();
-      if (wave < NT) gt_wgrad_tile(slab, 16 * wave, j, q, Areg, G3);
+      const unsigned slab_lane = gt_lds_addr(slab) + (unsigned)(j * RS + 4 * q) * 4u;  // this lane's operand-read origin
+#pragma unroll
+      for (int u = 0; u < Wn::G3T; ++u)
+        if (wave + NW * u < NT) {
+          f32x4 (&g3)[1] = *(f32x4(*)[1])&G3[u];
+          gt_wgrad_tiles<1, RG, RS>(slab_lane + (unsigned)(16 * (wave + NW * u) * RS) * 4u, Areg[0], g3);
+        }
       // ---- d xhat_NL = W3'^T dhead (A = the [H][20] transposed head image, K = the 16 head outputs)
       f32x4 d[NT];
 #pragma unroll
@@ -532,34 +622,41 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
         // d = gradient at xhat_k  ->  dz_k
         gt_ln_act_bwd<NT>(d, xh[k], mu[k], rstd[k], A.d.act[k], bits[k]);
         GT_T(3);  // LayerNorm + activation backward
-        __syncthreads();  // every wave has finished reading the slab's previous contents
-        gt_slab_store<NT>(slab, d, wave, j, q);
+        __syncthreads();  // every wave has finished reading the slab's previous contents (operand reads / chunk reads)
+        gt_slab_store<NT, RS>(slab, d, wave, j, q);
         __syncthreads();
-        gt_slab_A(slab, 16 * os, j, q, Areg, dbs[k]);
+#pragma unroll
+        for (int o = 0; o < OSW; ++o) gt_slab_A<RG, RS>(slab, 16 * (osg * OSW + o), j, q, Areg[o], dbs[k][o]);
         __syncthreads();
         GT_T(4);  // dz through the slab: 3 barriers, store, A reads
         if (k > 0) {
-          gt_slab_store<NT>(slab, xh[k - 1], wave, j, q);
+          gt_slab_store<NT, RS>(slab, xh[k - 1], wave, j, q);
           __syncthreads();
           GT_T(5);  // xhat through the slab: store + barrier
 #pragma unroll
-          for (int t = 0; t < Cn::NTW; ++t) gt_wgrad_tile(slab, 16 * (ip * Cn::NTW + t), j, q, Areg, G[k - 1][t]);
+          for (int o = 0; o < OSW; ++o)
+            gt_wgrad_tiles<NTW, RG, RS>(slab_lane + (unsigned)(16 * ip * NTW * RS) * 4u, Areg[o], G[k - 1][o]);
           GT_T(6);  // G_k MFMAs
           // input gradient d xhat_{k-1} = W_k'^T dz_k through the transposed image's chunks
           u32x4 xs[KS][3];
           gt_split<NT>(d, xs);
 #pragma unroll
           for (int m = 0; m < NT; ++m) d[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-          gt_gemm<H, PF>(st, xs, d, j, q);
+          gt_gemm<H, NW, PF>(st, xs, d, j, q);
           GT_T(7);  // input gradient: split + streamed GEMM
         } else {
           // the observations as the B operand: rows d = 4 s + q of the slab
 #pragma unroll
-          for (int s = 0; s < 4 * ND; ++s) slab[(4 * s + q) * GT_RS + 16 * wave + j] = x0[s];
+          for (int s = 0; s < 4 * ND; ++s) slab[(4 * s + q) * RS + 16 * wave + j] = x0[s];
           __syncthreads();
 #pragma unroll
-          for (int t = 0; t < ND; ++t)
-            if (16 * t < D && (t % Cn::IPARTS) == ip) gt_wgrad_tile(slab, 16 * t, j, q, Areg, G0[t]);
+          for (int o = 0; o < OSW; ++o)
+#pragma unroll
+            for (int t = 0; t < ND; ++t)
+              if (16 * t < D && (t % Wn::IPARTS) == ip) {
+                f32x4 (&g0)[1] = *(f32x4(*)[1])&G0[o][t];
+                gt_wgrad_tiles<1, RG, RS>(slab_lane + (unsigned)(16 * t * RS) * 4u, Areg[o], g0);
+              }
           GT_T(8);  // observations through the slab + G0
         }
       }
@@ -571,36 +668,44 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
   if (prof_on && l == 12) atomicAdd(&g_gt_prof[12], (unsigned long long)my_pass);
 #endif
   if constexpr (BWD) {
-    // ---- this workgroup's partial row of the raw sums.  A tile's lane (jj = j, qq = q) register r holds
-    // (output feature 16 os + 4 q + r, input feature 16 t + j)
+    // ---- this workgroup's partial row of the raw sums.  A tile's lane (j, q) register r holds
+    // (output feature 16 slice + 4 q + r, input feature 16 tile + j)
     float* P = A.partials + (size_t)blockIdx.x * ly.raw_total;
 #pragma unroll
     for (int k = 1; k <= NL; ++k)
 #pragma unroll
-      for (int t = 0; t < Cn::NTW; ++t)
+      for (int o = 0; o < OSW; ++o)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          P[ly.rG(k) + (16 * os + 4 * q + r) * H + 16 * (ip * Cn::NTW + t) + j] = G[k - 1][t][r];
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
-    for (int t = 0; t < ND; ++t)
-      if (16 * t < ly.DP16 && (t % Cn::IPARTS) == ip) {
+          for (int r = 0; r < 4; ++r)
+            P[ly.rG(k) + (16 * (osg * OSW + o) + 4 * q + r) * H + 16 * (ip * NTW + t) + j] = G[k - 1][o][t][r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) P[ly.rG0 + (16 * os + 4 * q + r) * ly.DP16 + 16 * t + j] = G0[t][r];
+    for (int o = 0; o < OSW; ++o)
+#pragma unroll
+      for (int t = 0; t < ND; ++t)
+        if (16 * t < ly.DP16 && (t % Wn::IPARTS) == ip) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[ly.rG0 + (16 * (osg * OSW + o) + 4 * q + r) * ly.DP16 + 16 * t + j] = G0[o][t][r];
+        }
+#pragma unroll
+    for (int u = 0; u < Wn::G3T; ++u)
+      if (wave + NW * u < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[ly.rG3 + (4 * q + r) * H + 16 * (wave + NW * u) + j] = G3[u][r];
       }
-    if (wave < NT) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) P[ly.rG3 + (4 * q + r) * H + 16 * wave + j] = G3[r];
-    }
-    // column sums: lane (m = j, kq = q) holds a partial of feature 16 os + j (every wave of an output slice holds the
+    // column sums: lane (m = j, kq = q) holds a partial of feature 16 slice + j (every wave of an output slice holds the
     // same sums: the ip == 0 wave writes); db3: feature c = j, identical in all waves - wave 0 writes
 #pragma unroll
-    for (int k = 0; k <= NL; ++k) {
-      const float s = row_allsum(dbs[k]);
-      if (ip == 0 && q == 0) P[ly.rdb(k) + 16 * os + j] = s;
-    }
+    for (int k = 0; k <= NL; ++k)
+#pragma unroll
+      for (int o = 0; o < OSW; ++o) {
+        const float sm = row_allsum(dbs[k][o]);
+        if (ip == 0 && q == 0) P[ly.rdb(k) + 16 * (osg * OSW + o) + j] = sm;
+      }
     {
-      const float s = row_allsum(db3);
-      if (wave == 0 && q == 0) P[ly.rdb3 + j] = s;
+      const float sm = row_allsum(db3);
+      if (wave == 0 && q == 0) P[ly.rdb3 + j] = sm;
     }
   }
 }

@@ -4,15 +4,15 @@
 
 namespace orl {
 
-// backward: one workgroup per CU (2 waves per SIMD, 256 VGPRs, ~135 KB of LDS); forward: at most 128 VGPRs and ~75 KB, so
-// TWO workgroups share a CU and one's barrier / LDS waits overlap the other's MFMAs
-template <int H, int NL, int ND>
-__global__ __launch_bounds__(GT_WAVES * 64, 2) void gt_bwd_kernel(GtArgs A) {
-  gt_body<H, NL, ND, true>(A);
+// backward: one 8-wave workgroup per CU (256 VGPRs per wave); forward: 8-wave workgroups at <= 128 VGPRs and ~75 KB of
+// LDS, TWO per CU, so that one's barrier / LDS waits overlap the other's MFMAs
+template <int H, int NL, int ND, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gt_bwd_kernel(GtArgs A) {
+  gt_body<H, NL, ND, true, NW>(A);
 }
 template <int H, int NL, int ND>
 __global__ __launch_bounds__(GT_WAVES * 64, 4) void gt_fwd_kernel(GtArgs A) {
-  gt_body<H, NL, ND, false>(A);
+  gt_body<H, NL, ND, false, GT_WAVES>(A);
 }
 
 // ------------------------------------------------------------------------------------------------ image
@@ -196,11 +196,26 @@ __global__ __launch_bounds__(256) void gt_finalize_kernel(orl_gt_desc d, const f
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static size_t gt_lds_bytes(const GtLay& ly, bool bwd) {
-  const int res = bwd ? ly.res_bwd : ly.res_fwd;
-  size_t fl = (size_t)((res + 255) & ~255) + 2 * (size_t)ly.chunk_floats;
-  if (bwd) fl += (size_t)ly.H * GT_RS;
+// bwd_waves = 0: the forward kernel; 4 / 8: the backward kernel's builds
+static size_t gt_lds_bytes(const GtLay& ly, int bwd_waves) {
+  const int res = bwd_waves ? ly.res_bwd : ly.res_fwd;
+  size_t fl = (size_t)((res + 255) & ~255) + (size_t)ly.chunk_floats;
+  // backward: the exchange slab [H][16 waves + 4], which doubles as the second chunk buffer
+  const size_t slab = (size_t)ly.H * (16 * bwd_waves + 4);
+  fl += bwd_waves ? (slab > (size_t)ly.chunk_floats ? slab : (size_t)ly.chunk_floats) : (size_t)ly.chunk_floats;
   return fl * sizeof(float);
+}
+// One 8-wave workgroup per CU.  The 4-wave build (ORL_BUILD_DEFS=-DORL_GT_BWD_WAVES=4: two independent workgroups per
+// CU whenever they fit 80 KB each, so that one's exchange / barrier phases could overlap the other's MFMAs) was measured
+// SLOWER - 531 against 495 us per launch at hidden 128 (twice the G accumulators per wave, 169 spilled VGPRs against 99):
+// the kernel is not waiting on its barriers, it is bound by each wave's own instruction stream.
+static int gt_bwd_waves(const GtLay& ly) {
+#ifdef ORL_GT_BWD_WAVES  // build-time experiment
+  return (ORL_GT_BWD_WAVES == 4 && gt_lds_bytes(ly, 4) <= 80 * 1024) ? 4 : 8;
+#else
+  (void)ly;
+  return 8;
+#endif
 }
 
 static int gt_check(const orl_gt_desc* d, const char* who) {
@@ -216,37 +231,45 @@ static int gt_check(const orl_gt_desc* d, const char* who) {
   for (int l = 0; l < d->n_layers; ++l)
     if (d->act[l] < ORL_ACT_NONE || d->act[l] > ORL_ACT_ELU) return fail(ORL_E_INVALID, "%s: activation %d", who, d->act[l]);
   const GtLay ly(*d);
-  if (gt_lds_bytes(ly, true) > 160 * 1024)
-    return fail(ORL_E_UNSUPPORTED, "%s: %zu bytes of LDS (obs_dim %d at hidden_size %d)", who, gt_lds_bytes(ly, true), d->D, d->H);
+  if (gt_lds_bytes(ly, 8) > 160 * 1024)
+    return fail(ORL_E_UNSUPPORTED, "%s: %zu bytes of LDS (obs_dim %d at hidden_size %d)", who, gt_lds_bytes(ly, 8), d->D, d->H);
   return 0;
 }
 
-template <int H, int NL, int ND, bool BWD>
-static void gt_launch_inst(const GtArgs& A, int grid, size_t lds, hipStream_t s) {
-  if constexpr (BWD) {
-    (void)hipFuncSetAttribute((const void*)gt_bwd_kernel<H, NL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gt_bwd_kernel<H, NL, ND>), dim3(grid), dim3(GT_WAVES * 64), lds, s, A);
-  } else {
-    (void)hipFuncSetAttribute((const void*)gt_fwd_kernel<H, NL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gt_fwd_kernel<H, NL, ND>), dim3(grid), dim3(GT_WAVES * 64), lds, s, A);
-  }
+template <int H, int NL, int ND>
+static void gt_launch_fwd(const GtArgs& A, int grid, size_t lds, hipStream_t s) {
+  (void)hipFuncSetAttribute((const void*)gt_fwd_kernel<H, NL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((gt_fwd_kernel<H, NL, ND>), dim3(grid), dim3(GT_WAVES * 64), lds, s, A);
+}
+template <int H, int NL, int ND, int NW>
+static void gt_launch_bwd(const GtArgs& A, int grid, size_t lds, hipStream_t s) {
+  (void)hipFuncSetAttribute((const void*)gt_bwd_kernel<H, NL, ND, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((gt_bwd_kernel<H, NL, ND, NW>), dim3(grid), dim3(NW * 64), lds, s, A);
 }
 
-template <bool BWD>
-static int gt_launch(const GtArgs& A, int grid, size_t lds, hipStream_t s) {
+#ifdef ORL_GT_BWD_WAVES
+#define ORL_GT_NW4 4
+#else
+#define ORL_GT_NW4 8  // the 4-wave build is not instantiated
+#endif
+// bwd_waves = 0: forward
+static int gt_launch(const GtArgs& A, int bwd_waves, int grid, size_t lds, hipStream_t s) {
   const int H = A.d.H, NL = A.d.n_layers - 1, ND = A.d.D <= 16 ? 1 : 4;
-#define ORL_GT_CASE(h, nl)                                              \
-  if (H == h && NL == nl) {                                             \
-    if (ND == 1) gt_launch_inst<h, nl, 1, BWD>(A, grid, lds, s);        \
-    else gt_launch_inst<h, nl, 4, BWD>(A, grid, lds, s);                \
-    return 0;                                                           \
+#define ORL_GT_CASE3(h, nl, nd)                                                    \
+  if (H == h && NL == nl && ND == nd) {                                            \
+    if (bwd_waves == 0) gt_launch_fwd<h, nl, nd>(A, grid, lds, s);                 \
+    else if (bwd_waves == 4) gt_launch_bwd<h, nl, nd, ORL_GT_NW4>(A, grid, lds, s); \
+    else gt_launch_bwd<h, nl, nd, 8>(A, grid, lds, s);                             \
+    return 0;                                                                      \
   }
+#define ORL_GT_CASE(h, nl) ORL_GT_CASE3(h, nl, 1) ORL_GT_CASE3(h, nl, 4)
   ORL_GT_CASE(64, 1)
   ORL_GT_CASE(64, 2)
   ORL_GT_CASE(64, 3)
   ORL_GT_CASE(128, 1)
   ORL_GT_CASE(128, 2)
 #undef ORL_GT_CASE
+#undef ORL_GT_CASE3
   return fail(ORL_E_UNSUPPORTED, "orl_gt: no kernel for hidden_size %d with %d layers", H, NL + 1);
 }
 
@@ -297,10 +320,10 @@ int orl_gt_fwd(const orl_gt_desc* d, const float* image, const float* x, int ldx
   A.d = *d; A.image = image; A.x = x; A.ldx = ldx; A.col0 = col0; A.idx = (const long long*)idx; A.mb = mb;
   A.out0 = head_out0; A.out1 = head_out1;
   const int n_pass = ((mb + 15) / 16 + GT_WAVES - 1) / GT_WAVES;
-  const size_t lds_fwd = gt_lds_bytes(ly, false);
+  const size_t lds_fwd = gt_lds_bytes(ly, 0);
   const int per_cu = lds_fwd <= 80 * 1024 ? 2 : 1;
   const int grid = n_pass < 256 * per_cu ? n_pass : 256 * per_cu;
-  rc = gt_launch<false>(A, grid, gt_lds_bytes(ly, false), (hipStream_t)stream);
+  rc = gt_launch(A, 0, grid, lds_fwd, (hipStream_t)stream);
   if (rc) return rc;
   return launch_status("orl_gt_fwd");
 }
@@ -319,11 +342,14 @@ int orl_gt_bwd(const orl_gt_desc* d, const float* image, const float* x, int ldx
   GtArgs A{};
   A.d = *d; A.image = image; A.x = x; A.ldx = ldx; A.col0 = col0; A.idx = (const long long*)idx; A.mb = mb;
   A.dh0 = dhead0; A.dh1 = dhead1; A.partials = partials;
-  const int n_pass = ((mb + 15) / 16 + GT_WAVES - 1) / GT_WAVES;
-  int grid = n_pass < 256 ? n_pass : 256;
+  const int nw = gt_bwd_waves(ly);
+  const size_t lds_bwd = gt_lds_bytes(ly, nw);
+  const int n_pass = ((mb + 15) / 16 + nw - 1) / nw;
+  const int max_grid = 256 * (lds_bwd <= 80 * 1024 ? 2 : 1);
+  int grid = n_pass < max_grid ? n_pass : max_grid;
   const int64_t fit = partials_floats / ly.raw_total;
   if (grid > fit) grid = (int)fit;
-  rc = gt_launch<true>(A, grid, gt_lds_bytes(ly, true), (hipStream_t)stream);
+  rc = gt_launch(A, nw, grid, lds_bwd, (hipStream_t)stream);
   if (rc) return rc;
   rc = launch_status("orl_gt_bwd");
   if (rc) return rc;

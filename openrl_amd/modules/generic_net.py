@@ -374,7 +374,7 @@ class FusedTower:
         dev = net.device
         self.image = torch.zeros(n_img, dtype=torch.float32, device=dev)
         self.raw = torch.empty(n_raw, dtype=torch.float32, device=dev)
-        self.partials = torch.empty(256 * n_raw, dtype=torch.float32, device=dev)
+        self.partials = torch.empty(512 * n_raw, dtype=torch.float32, device=dev)  # one row per workgroup
 
     def prep(self) -> None:
         ops_gen.gt_prep(self.desc, self.image)
