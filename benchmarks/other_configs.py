@@ -23,6 +23,11 @@ CONFIGS = [
          argv=["--lr", "7e-4", "--critic_lr", "7e-4", "--use_recurrent_policy", "true", "--use_adv_normalize", "true"]),
     dict(name="configs[4] env: tic-tac-toe vs random opponent, 4096 envs x 200, Discrete(9) + masks, device env",
          env="tictactoe_v3", envs=4096, T=200, agents=1, env_kw=dict(opponent="random"), argv=[]),
+    # not a BASELINE config: the general tower path at configs[1]'s shape - the cross-layer fused
+    # kernels of csrc/orl_gen_tower.h; dominant_kernel_ms = the policy tower's backward launch
+    dict(name="non-default tower: configs[1]'s shape with hidden_size 128 (cross-layer fused general towers)",
+         env="SyntheticFixedStep-v0", envs=4096, T=128, agents=1, env_kw=dict(obs_dim=4, episode_limit=200),
+         argv=["--hidden_size", "128"]),
 ]
 
 

@@ -157,7 +157,14 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
             psums = policy_part()
             if turn_on:
                 pn.grad.zero_()
+                ev = getattr(algo, "profile_events", None)
+                if ev is not None:  # benchmarks: HIP events on the launch stream around the policy tower's backward
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 ftp.backward(rec, 0, idx, mb, dlogits)
+                if ev is not None:
+                    e1.record()
+                    ev.append((e0, e1))
                 logstd_grad_f(pn, psums)
             if fork:
                 main.wait_stream(side)

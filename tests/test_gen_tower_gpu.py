@@ -169,3 +169,51 @@ def test_unsupported_shapes_fall_back():
     assert net.gt(("act",)) is None
     _, net = make_net("policy", 128, 3, 1, False, 4, spaces.Discrete(2))  # 4 layers at 128: registers
     assert net.gt(("act",)) is None
+
+
+@pytest.mark.parametrize("argv,kw", [
+    (["--hidden_size", "128"], dict(obs_dim=4, episode_limit=7)),
+    (["--hidden_size", "64", "--layer_N", "2", "--activation_id", "0", "--use_feature_normalization", "true"],
+     dict(obs_dim=17, episode_limit=9, action_space="box6")),
+    (["--use_share_model", "true", "--hidden_size", "64"], dict(obs_dim=5, episode_limit=6)),
+])
+def test_training_with_fused_towers_equals_the_layerwise_route(argv, kw):
+    """One whole iteration (rollout, returns, 3 PPO epochs x 2 minibatches) with cfg.amd_gen_update = fused against
+    layerwise: same seeds, same rollout, the weights after the update within the update path's fp32 tolerance."""
+    from openrl_amd import spaces
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+    from openrl_amd.utils.util import set_seed
+
+    if isinstance(kw.get("action_space"), str):
+        kw = dict(kw, action_space=spaces.Box(-1.0, 1.0, (int(kw["action_space"][3:]),)))
+    N, T = 96, 20
+    thetas, infos = [], []
+    for mode in ("fused", "layerwise"):
+        cfg = default_cfg(["--seed", "5", "--episode_length", str(T), "--ppo_epoch", "3", "--num_mini_batch", "2",
+                           "--amd_gen_update", mode] + argv)
+        env = make("SyntheticFixedStep-v0", env_num=N, device=DEV, seed=5, **kw)
+        set_seed(5)
+        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+        assert net.module.generic
+        used = net.module.fused_towers(one_pass=True)
+        assert (used is not None) == (mode == "fused")
+
+        class _Agent:
+            num_time_steps = 0
+
+        cfg.num_env_steps = N * T
+        trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=DEV)
+        buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=DEV)
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, _Agent())
+        drv.reset_and_buffer_init()
+        drv.episode = 0
+        drv._inner_loop()
+        torch.cuda.synchronize()
+        thetas.append({k: m.theta.cpu().numpy().copy() for k, m in net.module.models.items()})
+    for k in thetas[0]:
+        np.testing.assert_allclose(thetas[0][k], thetas[1][k], rtol=2e-3, atol=3e-5, err_msg=k)

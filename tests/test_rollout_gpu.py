@@ -292,21 +292,23 @@ def test_extreme_tower_shapes_train_end_to_end(obs_dim, act):
         assert torch.isfinite(m.theta).all() and torch.isfinite(m.grad).all()
 
 
+@pytest.mark.parametrize("mode", ["stepwise", "auto"])
 @pytest.mark.parametrize("obs_dim,n_act", [(64, 16), (18, 5), (1, 2)])
-def test_extreme_recurrent_tower_shapes_train_end_to_end(obs_dim, n_act):
-    """Same for the recurrent (GRU) towers: stepwise rollout (hipGraph from the second iteration) + chunked BPTT update."""
+def test_extreme_recurrent_tower_shapes_train_end_to_end(obs_dim, n_act, mode):
+    """Same for the recurrent (GRU) towers: stepwise rollout (hipGraph from the second iteration) or, since round 3, the
+    fused recurrent rollout on the single-agent device envs (amd_rollout_mode auto) + chunked BPTT update."""
     from openrl_amd import spaces
     from openrl_amd.envs.common import make
     from openrl_amd.modules.common import PPONet as Net
     from openrl_amd.runners.common import PPOAgent as Agent
 
     cfg = _cfg(["--episode_length", "12", "--ppo_epoch", "2", "--amd_perm_mode", "device", "--use_recurrent_policy", "true",
-                "--data_chunk_length", "4"])
+                "--data_chunk_length", "4", "--amd_rollout_mode", mode])
     env = make("SyntheticFixedStep-v0", env_num=40, obs_dim=obs_dim, action_space=spaces.Discrete(n_act), episode_limit=5,
                device=DEV)
     agent = Agent(Net(env, cfg=cfg, device=DEV))
     agent.train(total_time_steps=40 * 12 * 3)
-    assert not agent.driver.fused and agent.num_time_steps == 40 * 12 * 3
+    assert agent.driver.fused == (mode == "auto") and agent.num_time_steps == 40 * 12 * 3
     d = agent.driver.buffer.data
     assert torch.isfinite(d.returns).all() and d.rnn_states.abs().max() > 0
     assert d.actions.min() >= 0 and d.actions.max() <= n_act - 1
