@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 303 /* 0.3.3: orl_gt_* (cross-layer fused general towers); 0.3.2: orl_gen_rollout_fused, ORL_HEAD_MIXED, hparams.reserved & 4; 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 304 /* 0.3.4: orl_gt_train; 0.3.3: orl_gt_* (cross-layer fused general towers); 0.3.2: orl_gen_rollout_fused, ORL_HEAD_MIXED, hparams.reserved & 4; 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -790,10 +790,29 @@ int orl_gt_fwd(const orl_gt_desc* d, const float* image, const float* x, int ldx
                float* head_out0, float* head_out1, void* stream);
 /* Backward of the same rows given dhead = d loss / d head outputs [mb, head_n]: the forward is recomputed on chip, the
  * gradient of every parameter the descriptor names is WRITTEN into grad (same offsets as theta).  partials: scratch of
- * >= raw floats (up to 512 rows of them are used: one per workgroup, summed in a fixed order), raw: raw floats. */
+ * >= raw + 24 floats (up to 256 rows of raw + 24 are used: one per workgroup, summed in a fixed order), raw: raw floats. */
 int orl_gt_bwd(const orl_gt_desc* d, const float* image, const float* x, int ldx, int col0, const int64_t* idx, int mb,
                const float* dhead0, const float* dhead1, float* partials, int64_t partials_floats, float* raw, float* grad,
                void* stream);
+/* The whole update of a minibatch for one tower in ONE launch (+ the reduction of its per-workgroup sums): forward of the
+ * rows of the update records, PPOAlgorithm.prepare_loss on the head outputs (openrl/algorithms/ppo.py:178-361 - the same
+ * per-row code as orl_gen_policy_loss / orl_gen_value_loss, csrc/orl_gen_loss.h), backward, gradients written into grad;
+ * no head output or gradient crosses HBM.  policy_head / value_head: index of the descriptor's head each loss applies to
+ * (-1: none); policy_grad = 0 drops the policy head's gradient but keeps its logging sums (turn_on = False on a shared
+ * network).  sums_out [24] = {policy-loss sum, entropy sum, ratio sum, -, dlogstd[16], value-loss sum, -, -, -}: what the two
+ * loss kernels' partials reduce to.  partials: rows of raw + 24 floats. */
+typedef struct orl_gt_loss {
+  orl_head_desc head;   /* the policy head's distribution (ignored when policy_head < 0) */
+  const float* logstd;  /* Gaussian / mixed heads */
+  const float* den;     /* {sum of active masks, rows}: orl_gen_denoms */
+  const float* vn_state;/* ValueNorm running state or NULL */
+  orl_ppo_hparams hp;
+  int32_t Dp, Dc, a_w, K; /* record layout (orl_record_width) */
+  int32_t policy_head, value_head, policy_grad, reserved;
+} orl_gt_loss;
+int orl_gt_train(const orl_gt_desc* d, const float* image, const float* records, int rec_width, int col0,
+                 const int64_t* idx, int mb, const orl_gt_loss* loss, float* partials, int64_t partials_floats, float* raw,
+                 float* grad, float* sums_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL, ORL_ENV_MPE_SPREAD = 0, 1, 2, 3, 4
 ORL_GATHER_MAX = 12
 ORL_IPC_HANDLE_BYTES = 64
-ORL_VERSION = 303  # must equal include/orl_hip.h; checked against the loaded library
+ORL_VERSION = 304  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -129,13 +129,20 @@ class GtDesc(C.Structure):
                 ("head_oW", C.c_int32 * 2), ("head_ob", C.c_int32 * 2), ("head_n", C.c_int32 * 2)]
 
 
+class GtLoss(C.Structure):
+    """``orl_gt_loss``: what ``orl_gt_train`` needs to evaluate the losses of its rows in the backward kernel."""
+    _fields_ = [("head", HeadDesc), ("logstd", C.c_void_p), ("den", C.c_void_p), ("vn_state", C.c_void_p),
+                ("hp", PPOHParams), ("Dp", C.c_int32), ("Dc", C.c_int32), ("a_w", C.c_int32), ("K", C.c_int32),
+                ("policy_head", C.c_int32), ("value_head", C.c_int32), ("policy_grad", C.c_int32), ("reserved", C.c_int32)]
+
+
 ORL_ACT_NONE, ORL_ACT_TANH, ORL_ACT_RELU, ORL_ACT_LEAKY_RELU, ORL_ACT_ELU = -1, 0, 1, 2, 3
 ORL_HEAD_MULTI_DISCRETE = 3
 ORL_HEAD_MIXED = 4
 
 # order of orl_abi_struct_size(which)
 _ABI_STRUCTS = (NetDesc, PackSrc, BufferPtrs, CopyDesc, GatherDesc, PPOHParams, AdamState, RolloutArgs, RnnBatch,
-                RnnRolloutArgs, GenMlpDesc, GtDesc)
+                RnnRolloutArgs, GenMlpDesc, GtDesc, GtLoss)
 
 # name -> (restype, argtypes); must list EVERY symbol of include/orl_hip.h (tests check this)
 _P = C.c_void_p
@@ -206,6 +213,8 @@ _SIGNATURES = {
     "orl_gt_prep": (C.c_int, [C.POINTER(GtDesc), _P, _P]),
     "orl_gt_fwd": (C.c_int, [C.POINTER(GtDesc), _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
     "orl_gt_bwd": (C.c_int, [C.POINTER(GtDesc), _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "orl_gt_train": (C.c_int, [C.POINTER(GtDesc), _P, _P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(GtLoss), _P, C.c_int64, _P, _P,
+                               _P, _P]),
     "orl_gen_mlp_fwd": (C.c_int, [C.POINTER(GenMlpDesc), _P, C.c_int, _P, _P, _P, _P]),
     "orl_gen_act": (C.c_int, [C.POINTER(GenMlpDesc), _P, C.POINTER(GenMlpDesc), _P, C.c_int, _P, _P, C.POINTER(HeadDesc), _P,
                               _P, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, C.c_int, _P, _P, _P]),

@@ -95,41 +95,31 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
             ops_gen.info(psums, None, den, hp, ent_div, ratio_div, algo._info)
             ops_gen.info(None, vsums, den_c, hp, ent_div, ratio_div, algo._info)
 
-    # ---- cross-layer fused towers (csrc/orl_gen_tower.h): forward = one launch per tower straight from the records,
-    # backward = one launch (+ the fixed-order reduction of its per-workgroup sums) writing every gradient
+    # ---- cross-layer fused towers (csrc/orl_gen_tower.h): ONE launch per tower and minibatch straight from the records -
+    # forward, the losses of prepare_loss on the head outputs, backward (+ the fixed-order reduction of its per-workgroup
+    # sums); no activation, head output or head gradient crosses HBM
     fused = mod.fused_towers(one_pass) if (rnn is None and jrpo is None) else None
     if fused is not None:
         ftp, ftc = fused
-        wp = mod.workspace(pn, mb, True, "pf", heads_only=True)
-        wc = wp if shared else mod.workspace(cn, mb, True, "cf", heads_only=True)
-        logits, values = wp.v(wp.head_out["act"], mb, head.n_out), wc.v(wc.head_out["v_out"], mb, 1)
-        dlogits, dvalues = wp.v(wp.dhead["act"], mb, head.n_out), wc.v(wc.dhead["v_out"], mb, 1)
-
-        def value_part():
-            nb = ops_gen.value_loss(values.view(-1), rec, Dp, Dc, a_w, K, idx, mb, vn_state, den, hp, dvalues.view(-1),
-                                    wc.loss_partials)
-            return _loss_sums(wc, "v_out", nb, 1, None if gsums is None else gsums[1])
-
-        def policy_part():
-            nb = ops_gen.policy_loss(head, logits, mod._logstd(), rec, Dp, Dc, a_w, K, idx, mb, den, hp, dlogits,
-                                     wp.loss_partials)
-            return _loss_sums(wp, "act", nb, 20, None if gsums is None else gsums[0])
-
         def logstd_grad_f(net, psums):
             h = net.heads["act"]
             if "logstd" in h:
                 ops.multi_copy([(net.v(h["logstd"], h["n_ls"], grad=True), psums[4:4 + h["n_ls"]])])
 
-        if shared:  # one tower, two heads: one forward, one backward
+        def take(sums, lo, hi, dst):
+            # multi-GPU: the sums ride in the flat vector the one collective reduces
+            if dst is None:
+                return sums[lo:hi]
+            dst[:hi - lo].copy_(sums[lo:hi])
+            return dst
+
+        if shared:  # one tower, two heads: forward, both losses and backward in ONE launch
             model, opt = mod.models["model"], mod.optimizers["model"]
             ftp.prep()
-            ftp.forward(rec, 0, idx, mb, logits, values)
-            psums = policy_part()
-            vsums = value_part()
             model.grad.zero_()
-            if not turn_on:
-                dlogits.zero_()
-            ftp.backward(rec, 0, idx, mb, dlogits, dvalues)
+            sums = ftp.train(rec, 0, idx, mb, head, mod._logstd(), Dp, Dc, a_w, K, den, vn_state, hp, policy_grad=turn_on)
+            psums = take(sums, 0, 20, None if gsums is None else gsums[0])
+            vsums = take(sums, 20, 21, None if gsums is None else gsums[1])
             if turn_on:
                 logstd_grad_f(model, psums)
             reduce_over_ranks()
@@ -139,11 +129,9 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
 
             def critic_chain():
                 ftc.prep()
-                ftc.forward(rec, Dp, idx, mb, values)
-                sums = value_part()
                 cn.grad.zero_()
-                ftc.backward(rec, Dp, idx, mb, dvalues)
-                return sums
+                sums = ftc.train(rec, Dp, idx, mb, None, None, Dp, Dc, a_w, K, den, vn_state, hp)
+                return take(sums, 20, 21, None if gsums is None else gsums[1])
 
             fork = turn_on and mod.two_stream
             if fork:  # the critic's chain beside the policy's, as on the layer-wise route
@@ -153,18 +141,19 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
                 with torch.cuda.stream(side):
                     vsums = critic_chain()
             ftp.prep()
-            ftp.forward(rec, 0, idx, mb, logits)
-            psums = policy_part()
             if turn_on:
                 pn.grad.zero_()
-                ev = getattr(algo, "profile_events", None)
-                if ev is not None:  # benchmarks: HIP events on the launch stream around the policy tower's backward
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                ftp.backward(rec, 0, idx, mb, dlogits)
-                if ev is not None:
-                    e1.record()
-                    ev.append((e0, e1))
+            ev = getattr(algo, "profile_events", None)
+            if ev is not None:  # benchmarks: HIP events on the launch stream around the policy tower's launch
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            # (turn_on = False: the launch still runs for the logging sums; its gradient is never applied)
+            sums = ftp.train(rec, 0, idx, mb, head, mod._logstd(), Dp, Dc, a_w, K, den, None, hp)
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
+            psums = take(sums, 0, 20, None if gsums is None else gsums[0])
+            if turn_on:
                 logstd_grad_f(pn, psums)
             if fork:
                 main.wait_stream(side)

@@ -544,6 +544,7 @@ int orl_abi_struct_size(int which) {
     case 9: return (int)sizeof(orl_rnn_rollout_args);
     case 10: return (int)sizeof(orl_gen_mlp_desc);
     case 11: return (int)sizeof(orl_gt_desc);
+    case 12: return (int)sizeof(orl_gt_loss);
     default: return ORL_E_INVALID;
   }
 }

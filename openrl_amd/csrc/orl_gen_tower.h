@@ -30,11 +30,13 @@
 #include "orl_common.h"
 #include "orl_mlp.h"
 #include "orl_gen_act.h"
+#include "orl_gen_loss.h"
 
 namespace orl {
 
 constexpr int GT_WAVES = 8;          // waves per workgroup of the forward kernel (and of the backward's 8-wave build)
 constexpr int GT_HEADS = 16;         // head outputs (all heads together) are padded to 16
+constexpr int GT_LOSS_SUMS = 24;     // orl_gt_train: {policy-loss sum, entropy sum, ratio sum, -, dlogstd[16], value-loss sum, -, -, -}
 
 template <int H>
 struct GtC {
@@ -59,6 +61,7 @@ struct GtW {
   static constexpr int IPARTS = NW / NOSG;                 // input-feature parts
   static constexpr int NTW = NT / IPARTS;                  // input tiles per owned output slice
   static constexpr int G3T = (NT + NW - 1) / NW;           // head feature tiles per wave
+  static constexpr int SLAB_FLOATS = H * RS;
 };
 
 // Offsets (floats) of the image and of the raw gradient-sum vector; evaluated on host and device from the descriptor
@@ -79,9 +82,9 @@ struct GtLay {
     ib0 = o; o += NLt * H;
     ib3 = o; o += GT_HEADS;
     iW3T = o; o += H * 20;
-    res_bwd = o;
     iW3P = o; o += GT_HEADS * (H + 4);
     res_fwd = o;
+    res_bwd = o;  // (the backward kernel evaluates the heads too when it computes the losses itself)
     o = (o + 255) & ~255;  // chunks start on a 1 KB boundary
     iChunks = o;
     const int cbp = H == 128 ? GtC<128>::CBP : GtC<64>::CBP;
@@ -96,6 +99,7 @@ struct GtLay {
     rdb0 = r; r += NLt * H;
     rdb3 = r; r += GT_HEADS;
     raw_total = r;
+    // (a partial row of the backward kernel carries GT_LOSS_SUMS more floats: the loss / logging sums of orl_gt_train)
   }
   __host__ __device__ int ib(int l) const { return ib0 + l * H; }                 // folded bias of layer l
   __host__ __device__ int rG(int l) const { return rG1 + (l - 1) * H * H; }      // G_l, l >= 1
@@ -105,8 +109,23 @@ struct GtLay {
   __host__ __device__ int bchunk(int l, int c) const { return (NL + (NL - l)) * (H / 32) + c; }
 };
 
+// orl_gt_train: the backward kernel evaluates the heads and the losses of its rows itself (no forward launch, no loss
+// launches, no head outputs / gradients through HBM); x = the update records, ldx = the record width
+struct GtLossArgs {
+  int on;                      // 0: d loss / d head outputs come from dh0 / dh1
+  int policy_head, value_head; // index of the head the policy / value loss applies to, or -1
+  int policy_grad;             // 0: the policy head's gradient is dropped (turn_on = False on a shared network)
+  orl_head_desc hd;
+  const float* logstd;
+  const float* den;
+  const float* vn_state;
+  orl_ppo_hparams hp;
+  GenCols c;
+};
+
 struct GtArgs {
   orl_gt_desc d;
+  GtLossArgs loss;
   const float* image;
   const float* x;          // rows: x + row * ldx + col0
   int ldx, col0;
@@ -116,7 +135,7 @@ struct GtArgs {
   float* out1;
   const float* dh0;        // backward: d loss / d head outputs [mb, head_n]
   const float* dh1;
-  float* partials;         // backward: [gridDim.x][raw_total]
+  float* partials;         // backward: [gridDim.x][raw_total + GT_LOSS_SUMS]
 };
 
 // ------------------------------------------------------------------------------------------------ chunk stream
@@ -441,6 +460,10 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
   float* cbuf = smem + res_pad;                                   // chunk buffer 0
   // backward: the exchange slab [H][RS], which is also chunk buffer 1 (see GtStream); forward: a second chunk buffer
   float* slab = cbuf + Cn::CBP / 4;
+  // fused losses: per wave a [16 rows][16] head-output tile (the row's loss turns it into d loss / d outputs in place)
+  // and a [16 rows][16] d logstd accumulator
+  float* ltile = slab + Wn::SLAB_FLOATS + wave * 256;
+  float* dls_rows = slab + Wn::SLAB_FLOATS + NW * 256 + wave * 256;
   const float* lw = smem;
 
   const int n_tiles = (A.mb + 15) >> 4;
@@ -484,6 +507,17 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
       for (int o = 0; o < OSW; ++o) dbs[a][o] = 0.f;
   }
 
+  // fused losses: denominators, ValueNorm coefficients, per-lane sums (lanes q == 0 own a row each)
+  float inv_den_p = 1.f, inv_den_v = 1.f, vn_mean = 0.f, vn_sd = 1.f;
+  float st_loss = 0.f, st_ent = 0.f, st_ratio = 0.f, st_v = 0.f;
+  if constexpr (BWD) {
+    if (A.loss.on) {
+      inv_den_p = 1.f / (A.loss.hp.use_policy_active_masks ? A.loss.den[0] : A.loss.den[1]);
+      inv_den_v = 1.f / (A.loss.hp.use_value_active_masks ? A.loss.den[0] : A.loss.den[1]);
+      gen_vn_coeffs(A.loss.vn_state, A.loss.hp, vn_mean, vn_sd);
+      for (int e = l; e < 256; e += 64) dls_rows[e] = 0.f;
+    }
+  }
   auto row_of = [&](int pass) -> long long {
     const int ii = (pass * NW + wave) * 16 + j;
     const int iv = (pass < n_pass && ii < A.mb) ? ii : 0;  // invalid lanes read row 0 (finite data, zero gradient)
@@ -576,15 +610,60 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
     } else {
       // ---- d loss / d head outputs of this lane's row: c = 4q + s
       float dh[4];
+      if (A.loss.on) {
+        // heads: out^T[16 c x 16 rows] = W3' xhat_NL^T + b3' (as the forward kernel), through the wave's tile to the row's
+        // owner lane (q == 0), which evaluates the losses of its row with the stand-alone kernels' code (orl_gen_loss.h)
+        f32x4 hv = *(const f32x4*)(lw + ly.ib3 + 4 * q);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int c = 4 * q + s;
-        float v = 0.f;
-        if (valid) {
-          if (c < n0) v = A.dh0[(size_t)i * n0 + c];
-          else if (c - n0 < n1) v = A.dh1[(size_t)i * n1 + (c - n0)];
+        for (int m = 0; m < NT; ++m) {
+          const f32x4 a4 = *(const f32x4*)(lw + ly.iW3P + j * (H + 4) + 16 * m + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv = ORL_MFMA(a4[r], xh[NL][m][r], hv);
         }
-        dh[s] = v;
+        *(f32x4*)(ltile + j * 16 + 4 * q) = hv;
+        wave_lds_fence();
+        if (q == 0) {
+          float* trow = ltile + j * 16;
+          const float* rr = A.x + (size_t)row * A.ldx;
+          if (A.loss.policy_head >= 0) {
+            float* lg = trow + (A.loss.policy_head == 0 ? 0 : n0);
+            const int np = A.loss.hd.n_out;
+            if (valid && A.loss.policy_grad) {
+              float (&dls)[16] = *(float(*)[16])(dls_rows + j * 16);
+              gen_policy_loss_row(A.loss.hd, lg, A.loss.logstd, rr, A.loss.c, inv_den_p, inv_den_p, A.loss.hp, 0, lg, nullptr,
+                                  nullptr, st_loss, st_ent, st_ratio, dls);
+            } else {
+              if (valid) {  // statistics only (the logging sums of a policy that is not stepped), gradient dropped
+                float scratch_dls[16];
+                float (&dls)[16] = scratch_dls;
+                for (int k = 0; k < 16; ++k) dls[k] = 0.f;
+                gen_policy_loss_row(A.loss.hd, lg, A.loss.logstd, rr, A.loss.c, inv_den_p, inv_den_p, A.loss.hp, 0, lg, nullptr,
+                                    nullptr, st_loss, st_ent, st_ratio, dls);
+              }
+              for (int k = 0; k < np; ++k) lg[k] = 0.f;
+            }
+          }
+          if (A.loss.value_head >= 0) {
+            float* vv = trow + (A.loss.value_head == 0 ? 0 : n0);
+            vv[0] = valid ? gen_value_loss_row(vv[0], rr, A.loss.c, vn_mean, vn_sd, inv_den_v, A.loss.hp, st_v) : 0.f;
+          }
+        }
+        wave_lds_fence();
+        const f32x4 dv = *(const f32x4*)(ltile + j * 16 + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dh[s] = (4 * q + s < n0 + n1) ? dv[s] : 0.f;
+        wave_lds_fence();
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int c = 4 * q + s;
+          float v = 0.f;
+          if (valid) {
+            if (c < n0) v = A.dh0[(size_t)i * n0 + c];
+            else if (c - n0 < n1) v = A.dh1[(size_t)i * n1 + (c - n0)];
+          }
+          dh[s] = v;
+        }
       }
       // ---- G3 += dhead^T xhat_NL, db3 += sum dhead
       f32x4 Areg[OSW][RG];
@@ -670,7 +749,7 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
   if constexpr (BWD) {
     // ---- this workgroup's partial row of the raw sums.  A tile's lane (j, q) register r holds
     // (output feature 16 slice + 4 q + r, input feature 16 tile + j)
-    float* P = A.partials + (size_t)blockIdx.x * ly.raw_total;
+    float* P = A.partials + (size_t)blockIdx.x * (ly.raw_total + GT_LOSS_SUMS);
 #pragma unroll
     for (int k = 1; k <= NL; ++k)
 #pragma unroll
@@ -694,6 +773,32 @@ __device__ __forceinline__ void gt_body(const GtArgs& A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) P[ly.rG3 + (4 * q + r) * H + 16 * (wave + NW * u) + j] = G3[u][r];
       }
+    // loss / logging sums of orl_gt_train: GT_LOSS_SUMS floats behind the raw sums, fixed summation order
+    if (A.loss.on) {
+      __syncthreads();
+      float* red = slab;  // (the slab is free: every wave is past its last pass)
+      const float v4[4] = {wave_sum(st_loss), wave_sum(st_ent), wave_sum(st_ratio), wave_sum(st_v)};
+      if (l == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave * 4 + k] = v4[k];
+      }
+      __syncthreads();
+      if (wave == 0) {
+        if (l < 4) {
+          float t = 0.f;
+          for (int w = 0; w < NW; ++w) t += red[w * 4 + l];
+          if (l < 3) P[ly.raw_total + l] = t;
+          else { P[ly.raw_total + 20] = t; P[ly.raw_total + 3] = 0.f; }
+        } else if (l >= 16 && l < 32) {  // d logstd column l - 16: the rows of all waves in order
+          const float* dr = slab + Wn::SLAB_FLOATS + NW * 256;
+          float t = 0.f;
+          for (int rw = 0; rw < NW * 16; ++rw) t += dr[rw * 16 + (l - 16)];
+          P[ly.raw_total + 4 + (l - 16)] = t;
+        } else if (l >= 32 && l < 35) {
+          P[ly.raw_total + 21 + (l - 32)] = 0.f;
+        }
+      }
+    }
     // column sums: lane (m = j, kq = q) holds a partial of feature 16 slice + j (every wave of an output slice holds the
     // same sums: the ip == 0 wave writes); db3: feature c = j, identical in all waves - wave 0 writes
 #pragma unroll

@@ -203,6 +203,7 @@ static size_t gt_lds_bytes(const GtLay& ly, int bwd_waves) {
   // backward: the exchange slab [H][16 waves + 4], which doubles as the second chunk buffer
   const size_t slab = (size_t)ly.H * (16 * bwd_waves + 4);
   fl += bwd_waves ? (slab > (size_t)ly.chunk_floats ? slab : (size_t)ly.chunk_floats) : (size_t)ly.chunk_floats;
+  if (bwd_waves) fl += (size_t)bwd_waves * 512;  // per wave: the head-output tile and the d logstd rows of the fused losses
   return fl * sizeof(float);
 }
 // One 8-wave workgroup per CU.  The 4-wave build (ORL_BUILD_DEFS=-DORL_GT_BWD_WAVES=4: two independent workgroups per
@@ -328,6 +329,33 @@ int orl_gt_fwd(const orl_gt_desc* d, const float* image, const float* x, int ldx
   return launch_status("orl_gt_fwd");
 }
 
+static int gt_backward(const orl_gt_desc* d, const GtLossArgs& loss, const float* image, const float* x, int ldx, int col0,
+                       const int64_t* idx, int mb, const float* dhead0, const float* dhead1, float* partials,
+                       int64_t partials_floats, float* raw, float* grad, float* sums_out, void* stream, const char* who) {
+  const GtLay ly(*d);
+  const int row_floats = ly.raw_total + GT_LOSS_SUMS;
+  ORL_REQUIRE(partials_floats >= row_floats, "%s: the partials buffer holds %lld floats, one row is %d", who,
+              (long long)partials_floats, row_floats);
+  GtArgs A{};
+  A.d = *d; A.loss = loss; A.image = image; A.x = x; A.ldx = ldx; A.col0 = col0; A.idx = (const long long*)idx; A.mb = mb;
+  A.dh0 = dhead0; A.dh1 = dhead1; A.partials = partials;
+  const int nw = gt_bwd_waves(ly);
+  const size_t lds_bwd = gt_lds_bytes(ly, nw);
+  const int n_pass = ((mb + 15) / 16 + nw - 1) / nw;
+  const int max_grid = 256 * (lds_bwd <= 80 * 1024 ? 2 : 1);
+  int grid = n_pass < max_grid ? n_pass : max_grid;
+  const int64_t fit = partials_floats / row_floats;
+  if (grid > fit) grid = (int)fit;
+  int rc = gt_launch(A, nw, grid, lds_bwd, (hipStream_t)stream);
+  if (rc) return rc;
+  rc = launch_status(who);
+  if (rc) return rc;
+  rc = orl_gen_colsum(partials, grid, row_floats, raw, ly.raw_total, sums_out, GT_LOSS_SUMS, nullptr, 0, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gt_finalize_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, *d, raw, grad);
+  return launch_status(who);
+}
+
 int orl_gt_bwd(const orl_gt_desc* d, const float* image, const float* x, int ldx, int col0, const int64_t* idx, int mb,
                const float* dhead0, const float* dhead1, float* partials, int64_t partials_floats, float* raw, float* grad,
                void* stream) {
@@ -336,27 +364,38 @@ int orl_gt_bwd(const orl_gt_desc* d, const float* image, const float* x, int ldx
   ORL_REQUIRE(image && x && dhead0 && partials && raw && grad && mb > 0 && ldx >= col0 + d->D && col0 >= 0,
               "orl_gt_bwd: bad arguments");
   ORL_REQUIRE(d->n_heads == 1 || dhead1, "orl_gt_bwd: two heads need two gradients");
-  const GtLay ly(*d);
-  ORL_REQUIRE(partials_floats >= ly.raw_total, "orl_gt_bwd: the partials buffer holds %lld floats, one row is %d",
-              (long long)partials_floats, ly.raw_total);
-  GtArgs A{};
-  A.d = *d; A.image = image; A.x = x; A.ldx = ldx; A.col0 = col0; A.idx = (const long long*)idx; A.mb = mb;
-  A.dh0 = dhead0; A.dh1 = dhead1; A.partials = partials;
-  const int nw = gt_bwd_waves(ly);
-  const size_t lds_bwd = gt_lds_bytes(ly, nw);
-  const int n_pass = ((mb + 15) / 16 + nw - 1) / nw;
-  const int max_grid = 256 * (lds_bwd <= 80 * 1024 ? 2 : 1);
-  int grid = n_pass < max_grid ? n_pass : max_grid;
-  const int64_t fit = partials_floats / ly.raw_total;
-  if (grid > fit) grid = (int)fit;
-  rc = gt_launch(A, nw, grid, lds_bwd, (hipStream_t)stream);
+  GtLossArgs loss{};
+  return gt_backward(d, loss, image, x, ldx, col0, idx, mb, dhead0, dhead1, partials, partials_floats, raw, grad, nullptr,
+                     stream, "orl_gt_bwd");
+}
+
+int orl_gt_train(const orl_gt_desc* d, const float* image, const float* records, int rec_width, int col0,
+                 const int64_t* idx, int mb, const orl_gt_loss* L, float* partials, int64_t partials_floats, float* raw,
+                 float* grad, float* sums_out, void* stream) {
+  int rc = gt_check(d, "orl_gt_train");
   if (rc) return rc;
-  rc = launch_status("orl_gt_bwd");
-  if (rc) return rc;
-  rc = orl_gen_colsum(partials, grid, ly.raw_total, raw, ly.raw_total, nullptr, 0, nullptr, 0, stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(gt_finalize_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, *d, raw, grad);
-  return launch_status("orl_gt_bwd(finalize)");
+  ORL_REQUIRE(image && records && L && partials && raw && grad && sums_out && mb > 0 && col0 >= 0 &&
+                  rec_width >= col0 + d->D, "orl_gt_train: bad arguments");
+  ORL_REQUIRE(L->den, "orl_gt_train: null denominators");
+  ORL_REQUIRE(orl_record_width(L->Dp, L->Dc, L->a_w, L->K) == rec_width, "orl_gt_train: record width %d != %d", rec_width,
+              orl_record_width(L->Dp, L->Dc, L->a_w, L->K));
+  ORL_REQUIRE(L->policy_head < d->n_heads && L->value_head < d->n_heads && (L->policy_head >= 0 || L->value_head >= 0) &&
+                  L->policy_head != L->value_head, "orl_gt_train: heads %d / %d of %d", L->policy_head, L->value_head,
+              d->n_heads);
+  if (L->policy_head >= 0) {
+    ORL_REQUIRE(L->head.n_out == d->head_n[L->policy_head], "orl_gt_train: the policy head has %d outputs, the loss %d",
+                d->head_n[L->policy_head], L->head.n_out);
+    ORL_REQUIRE((L->head.kind != ORL_HEAD_GAUSSIAN && L->head.kind != ORL_HEAD_MIXED) || L->logstd,
+                "orl_gt_train: Gaussian head without logstd");
+  }
+  if (L->value_head >= 0) ORL_REQUIRE(d->head_n[L->value_head] == 1, "orl_gt_train: the value head must have one output");
+  GtLossArgs loss{};
+  loss.on = 1;
+  loss.policy_head = L->policy_head; loss.value_head = L->value_head; loss.policy_grad = L->policy_grad;
+  loss.hd = L->head; loss.logstd = L->logstd; loss.den = L->den; loss.vn_state = L->vn_state; loss.hp = L->hp;
+  loss.c = gen_cols(L->Dp, L->Dc, L->a_w, L->K);
+  return gt_backward(d, loss, image, records, rec_width, col0, idx, mb, nullptr, nullptr, partials, partials_floats, raw,
+                     grad, sums_out, stream, "orl_gt_train");
 }
 
 }  // extern "C"

@@ -374,7 +374,8 @@ class FusedTower:
         dev = net.device
         self.image = torch.zeros(n_img, dtype=torch.float32, device=dev)
         self.raw = torch.empty(n_raw, dtype=torch.float32, device=dev)
-        self.partials = torch.empty(512 * n_raw, dtype=torch.float32, device=dev)  # one row per workgroup
+        self.partials = torch.empty(256 * (n_raw + 24), dtype=torch.float32, device=dev)  # one row per workgroup
+        self.sums = torch.zeros(24, dtype=torch.float32, device=dev)  # loss / logging sums of ``train``
 
     def prep(self) -> None:
         ops_gen.gt_prep(self.desc, self.image)
@@ -384,6 +385,26 @@ class FusedTower:
 
     def backward(self, x: torch.Tensor, col0: int, idx, mb: int, dh0: torch.Tensor, dh1=None) -> None:
         ops_gen.gt_bwd(self.desc, self.image, x, col0, idx, mb, dh0, dh1, self.partials, self.raw, self.net.grad)
+
+    def train(self, records: torch.Tensor, col0: int, idx, mb: int, head_desc, logstd, Dp: int, Dc: int, a_w: int, K: int,
+              den: torch.Tensor, vn_state, hp, policy_grad: bool = True) -> torch.Tensor:
+        """The minibatch's whole update of this tower in one launch (``orl_gt_train``): forward, PPO policy / value loss on
+        the head outputs, backward into ``net.grad``.  Returns the 24 loss / logging sums: [0:20] what
+        ``orl_gen_policy_loss``'s partials reduce to, [20] the value-loss sum."""
+        L = nat.GtLoss()
+        names = self.head_names
+        L.policy_head = names.index("act") if "act" in names else -1
+        L.value_head = names.index("v_out") if "v_out" in names else -1
+        L.policy_grad = 1 if policy_grad else 0
+        if L.policy_head >= 0:
+            L.head = head_desc
+            L.logstd = logstd.data_ptr() if logstd is not None else None
+        L.den = den.data_ptr()
+        L.vn_state = vn_state.data_ptr() if vn_state is not None else None
+        L.hp = hp
+        L.Dp, L.Dc, L.a_w, L.K = Dp, Dc, a_w, K
+        ops_gen.gt_train(self.desc, self.image, records, col0, idx, mb, L, self.partials, self.raw, self.net.grad, self.sums)
+        return self.sums
 
 
 class GenWorkspace:

@@ -148,6 +148,16 @@ def gt_bwd(desc, image, x, col0: int, idx, mb: int, dh0, dh1, partials, raw, gra
     nat.check(rc, "orl_gt_bwd")
 
 
+def gt_train(desc, image, records, col0: int, idx, mb: int, loss, partials, raw, grad, sums_out) -> None:
+    """Forward + losses + backward of one tower's minibatch in one launch (``orl_gt_train``); ``loss``: ``_native.GtLoss``;
+    ``sums_out`` [24] receives the loss / logging sums the two loss kernels' partials would reduce to."""
+    dev = nat.require_gpu(records.device)
+    assert records.dim() == 2 and records.is_contiguous() and sums_out.numel() >= 24 and sums_out.is_contiguous()
+    rc = _lib().orl_gt_train(C.byref(desc), fptr(image), fptr(records), records.shape[1], col0, ptr(idx), mb, C.byref(loss),
+                             fptr(partials), partials.numel(), fptr(raw), fptr(grad), fptr(sums_out), stream_ptr(dev))
+    nat.check(rc, "orl_gt_train")
+
+
 def act_step(policy_desc, obs, critic_desc, critic_obs, values, head: HeadDesc, logstd, action_masks, deterministic: bool,
         seed: int, row0: int, rng_step: int, rng_step_dev, forced_u, a_w: int, actions, logp, logits_out=None) -> None:
     """A rollout step in one launch (``orl_gen_act``): the policy tower, ``sample`` on its logits, and the critic tower
