@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--hidden_size", type=int, default=128)
     ap.add_argument("--layer_N", type=int, default=1)
     ap.add_argument("--rows", type=int, default=524288)
+    ap.add_argument("--train", action="store_true", help="orl_gt_train (losses in the kernel) instead of orl_gt_bwd")
     a = ap.parse_args()
     from openrl_amd import _native as nat, spaces
     from openrl_amd.configs.config import default_cfg
@@ -37,8 +38,24 @@ def main():
         raise SystemExit("liborl_hip.so is not the timing build: python -m openrl_amd.csrc.build --prof")
     out = (C.c_ulonglong * 16)()
     ft.prep()
+    if a.train:  # the one-launch update: heads + losses inside the backward kernel (records of configs[1]'s layout)
+        from openrl_amd import ops_gen
+        from openrl_amd.configs.config import default_cfg as _dc
+
+        rec = torch.randn(B, 16, device=dev)
+        rec[:, 8] = torch.randint(0, 2, (B,), device=dev).float()  # action
+        rec[:, 9] = -0.69                                           # old log-prob
+        rec[:, 13] = 1.0                                            # active mask
+        den = torch.tensor([float(B), float(B)], device=dev)
+        hp = nat.PPOHParams()
+        hp.clip_param, hp.value_loss_coef, hp.entropy_coef, hp.huber_delta = 0.2, 0.5, 0.01, 10.0
+        hp.use_clipped_value_loss, hp.use_huber_loss = 1, 1
+        head = ops_gen.head_desc(ops_gen.HEAD_CATEGORICAL, 2)
     for it in range(3):
-        ft.backward(x, 0, idx, B, dh)
+        if a.train:
+            ft.train(rec, 0, idx, B, head, None, 4, 4, 1, 0, den, None, hp)
+        else:
+            ft.backward(x, 0, idx, B, dh)
         lib.orl_gt_debug_prof(out)
     passes = out[12]
     tot = sum(out[k] for k in range(10))
