@@ -116,7 +116,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
         if shared:  # one tower, two heads: forward, both losses and backward in ONE launch
             model, opt = mod.models["model"], mod.optimizers["model"]
             ftp.prep()
-            model.grad.zero_()
+            ftp.zero_grad_once()
             sums = ftp.train(rec, 0, idx, mb, head, mod._logstd(), Dp, Dc, a_w, K, den, vn_state, hp, policy_grad=turn_on)
             psums = take(sums, 0, 20, None if gsums is None else gsums[0])
             vsums = take(sums, 20, 21, None if gsums is None else gsums[1])
@@ -129,7 +129,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
 
             def critic_chain():
                 ftc.prep()
-                cn.grad.zero_()
+                ftc.zero_grad_once()
                 sums = ftc.train(rec, Dp, idx, mb, None, None, Dp, Dc, a_w, K, den, vn_state, hp)
                 return take(sums, 20, 21, None if gsums is None else gsums[1])
 
@@ -141,8 +141,7 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
                 with torch.cuda.stream(side):
                     vsums = critic_chain()
             ftp.prep()
-            if turn_on:
-                pn.grad.zero_()
+            ftp.zero_grad_once()
             ev = getattr(algo, "profile_events", None)
             if ev is not None:  # benchmarks: HIP events on the launch stream around the policy tower's launch
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

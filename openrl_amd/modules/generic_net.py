@@ -380,6 +380,14 @@ class FusedTower:
     def prep(self) -> None:
         ops_gen.gt_prep(self.desc, self.image)
 
+    def zero_grad_once(self) -> None:
+        """``orl_gt_bwd`` / ``orl_gt_train`` WRITE every gradient the reference trains; what they never touch (the dead
+        ``fc_h`` block) only has to be zero once per gradient vector."""
+        key = self.net.grad.data_ptr()
+        if getattr(self, "_zeroed", None) != key:
+            self.net.grad.zero_()
+            self._zeroed = key
+
     def forward(self, x: torch.Tensor, col0: int, idx, mb: int, out0: torch.Tensor, out1=None) -> None:
         ops_gen.gt_fwd(self.desc, self.image, x, col0, idx, mb, out0, out1)
 
