@@ -114,3 +114,34 @@ def test_header_is_plain_c():
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "orl_hip.h")
     res = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_fused_general_tower_host_queries(lib):
+    """orl_gt_supported / orl_gt_image_floats / orl_gt_raw_floats (no launch): which general towers the cross-layer fused
+    kernels take, and the sizes a caller allocates (csrc/orl_gen_tower.h: GtLay)."""
+    from openrl_amd import _native as n
+
+    def desc(H, D, n_layers, heads=(2,)):
+        d = n.GtDesc()
+        d.theta, d.D, d.H, d.n_layers, d.n_heads = 1, D, H, n_layers, len(heads)
+        d.o_fn_g = d.o_fn_be = -1
+        for k in range(min(n_layers, n.ORL_GT_MAX_LAYERS)):
+            d.act[k] = n.ORL_ACT_RELU if k + 1 < n_layers else n.ORL_ACT_NONE
+        for k, h in enumerate(heads):
+            d.head_n[k] = h
+        return d
+
+    d = desc(128, 4, 2)
+    assert lib.orl_gt_supported(C.byref(d)) == 1
+    # raw sums: G0 [128 x 16] + G1 [128 x 128] + G3 [16 x 128] + db [2 x 128] + db3 [16]
+    assert lib.orl_gt_raw_floats(C.byref(d)) == 128 * 16 + 128 * 128 + 16 * 128 + 2 * 128 + 16
+    # image: resident part (fc1 [128 x 4], biases, head matrices) padded to 1 KB + 2 x 4 chunks of 26 KB
+    chunk = (3 * 32 * (128 + 8) * 2 + 1023) // 1024 * 1024 // 4
+    res = 128 * 4 + 2 * 128 + 16 + 128 * 20 + 16 * 132
+    assert lib.orl_gt_image_floats(C.byref(d)) == (res + 255) // 256 * 256 + 8 * chunk
+    for H, D, nl, ok in [(64, 64, 4, 1), (64, 4, 5, 0), (128, 4, 3, 1), (128, 4, 4, 0), (128, 32, 2, 1), (128, 64, 2, 0),
+                         (96, 4, 2, 0), (256, 4, 2, 0), (64, 65, 2, 0)]:
+        assert lib.orl_gt_supported(C.byref(desc(H, D, nl))) == ok, (H, D, nl)
+    assert lib.orl_gt_supported(C.byref(desc(64, 4, 2, heads=(15, 1)))) == 1   # shared network: act + v_out
+    assert lib.orl_gt_supported(C.byref(desc(64, 4, 2, heads=(16, 1)))) == 0   # 17 head outputs
+    assert lib.orl_gt_raw_floats(C.byref(desc(256, 4, 2))) == -1
