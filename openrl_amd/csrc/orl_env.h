@@ -51,14 +51,14 @@ __device__ inline bool cartpole_step(float (&s)[4], int action) {
 }
 
 
-// One env.step of env `n` at global time `tg` (the stand-alone env_step_kernel's body): updates the env's state row and
-// episode statistics, writes the next observation to obs_out[0..D), returns the reward and whether the episode ended.
+// One env.step of env `n` at global time `tg` on the env's state row `st` / episode statistics `e` (register or memory
+// copies): writes the next observation to obs_out[0..D), returns the reward and whether the episode ended.  The one
+// definition of the envs' arithmetic: every route steps through it.
 template <int ENV>
-__device__ inline void env_step_one(float* __restrict__ env_state, float* __restrict__ ep_stats, int n, int D,
-                                    uint64_t seed, int episode_limit, uint64_t tg, int action,
-                                    float* __restrict__ obs_out, float& r, bool& d) {
+__device__ inline void env_step_state(float* __restrict__ st, float* __restrict__ e, int n, int D, uint64_t seed,
+                                      int episode_limit, uint64_t tg, int action, float* __restrict__ obs_out, float& r,
+                                      bool& d) {
   if (ENV == ORL_ENV_SYNTH) {
-    float* st = env_state + (size_t)n * SYNTH_STATE_W;
     r = synth_reward(seed, (uint32_t)n, tg);
     const float c = st[0] + 1.f;
     d = c >= (float)episode_limit;
@@ -70,7 +70,6 @@ __device__ inline void env_step_one(float* __restrict__ env_state, float* __rest
         if (4 * b + k < D) obs_out[4 * b + k] = o[k];
     }
   } else {
-    float* st = env_state + (size_t)n * CARTPOLE_STATE_W;
     float s[4] = {st[0], st[1], st[2], st[3]};
     const bool term = cartpole_step(s, action);
     const float steps = st[4] + 1.f;
@@ -83,11 +82,20 @@ __device__ inline void env_step_one(float* __restrict__ env_state, float* __rest
     }
     for (int k = 0; k < 4; ++k) { st[k] = s[k]; obs_out[k] = s[k]; }
   }
-  if (ep_stats != nullptr) {
-    float* e = ep_stats + (size_t)n * 4;
+  if (e != nullptr) {
     e[0] += r; e[1] += 1.f;
     if (d) { e[2] += e[0]; e[3] += 1.f; e[0] = 0.f; e[1] = 0.f; }
   }
+}
+
+// the same on the state arrays in memory (the stand-alone env_step_kernel's body)
+template <int ENV>
+__device__ inline void env_step_one(float* __restrict__ env_state, float* __restrict__ ep_stats, int n, int D,
+                                    uint64_t seed, int episode_limit, uint64_t tg, int action,
+                                    float* __restrict__ obs_out, float& r, bool& d) {
+  constexpr int W = ENV == ORL_ENV_SYNTH ? SYNTH_STATE_W : CARTPOLE_STATE_W;
+  env_step_state<ENV>(env_state + (size_t)n * W, ep_stats != nullptr ? ep_stats + (size_t)n * 4 : nullptr, n, D, seed,
+                      episode_limit, tg, action, obs_out, r, d);
 }
 
 }  // namespace orl

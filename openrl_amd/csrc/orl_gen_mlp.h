@@ -38,6 +38,44 @@ struct MlpArgs {
 
 constexpr int MLP_KPRE = 8;  // 16-k blocks whose weights are in flight together
 
+// LDS-resident copy of a tower's parameters (the fused general rollout stages it once and walks it for all T steps:
+// per step the weights then cost an LDS round trip instead of an L2 one on a latency chain): per entry L the weight
+// matrix [n_out][ld] (ld = n_in rounded up to 4, + 4: zero padded, rows 16 bytes apart in bank space) at off[L], then
+// bias / gamma / beta [n_out rounded up to 4] each at voff[L].  Offsets in floats from `base`.
+struct MlpLds {
+  int off[ORL_GEN_MLP_MAX_LAYERS], ld[ORL_GEN_MLP_MAX_LAYERS], voff[ORL_GEN_MLP_MAX_LAYERS];
+  int total;
+};
+__host__ inline MlpLds mlp_lds_layout(const orl_gen_mlp_desc& d) {
+  MlpLds w;
+  memset(&w, 0, sizeof(w));
+  int o = 0;
+  for (int L = 0; L < d.n_layers + d.n_heads; ++L) {
+    const int n4 = (d.layer[L].n_in + 3) & ~3, o4 = (d.layer[L].n_out + 3) & ~3;
+    w.ld[L] = n4 + 4;
+    w.off[L] = o; o += d.layer[L].n_out * w.ld[L];
+    w.voff[L] = o; o += 3 * o4;
+  }
+  w.total = o;
+  return w;
+}
+// cooperative staging (any thread count); the caller synchronises
+__device__ inline void mlp_lds_stage(const orl_gen_mlp_desc& d, const MlpLds& w, float* __restrict__ base, int tid, int nthreads) {
+  for (int L = 0; L < d.n_layers + d.n_heads; ++L) {
+    const orl_gen_mlp_layer& ly = d.layer[L];
+    const int n_in = ly.n_in, n_out = ly.n_out, ld = w.ld[L], o4 = (n_out + 3) & ~3;
+    for (int e = tid; e < n_out * ld; e += nthreads) {
+      const int n = e / ld, k = e - n * ld;
+      base[w.off[L] + e] = k < n_in ? ly.W[(long long)n * n_in + k] : 0.f;
+    }
+    for (int e = tid; e < 3 * o4; e += nthreads) {
+      const int which = e / o4, c = e - which * o4;
+      const float* src = which == 0 ? ly.bias : which == 1 ? ly.gamma : ly.beta;
+      base[w.voff[L] + e] = (src != nullptr && c < n_out) ? src[c] : 0.f;
+    }
+  }
+}
+
 // ACTLayer.forward on the first head's logits inside the same launch (orl_gen_act): the 16 rows' logits go through a
 // [16][LGS_LD] LDS tile behind the slab and lanes 0-15 of wave 0 run gen_sample_row ON that tile (its working copy) - the arithmetic and Philox
 // counters of orl_gen_sample on the same fp32 logits, so the two routes agree bit for bit.
@@ -56,13 +94,19 @@ struct ActArgs {
   float* logp;
 };
 
-template <int NBW, int WAVES>
+template <int NBW, int WAVES, bool WL = false>
+// WL: the parameters come from the LDS copy `wl` / `wbase` (mlp_lds_stage) instead of global memory.
 // roff: row offset applied to the input rows, to every head / feature output and to the sampling's action-mask / action /
 // log-prob rows (the fused rollout walks the buffer's [T + 1][N] slots with roff = t * N; the tile's own rows stay
 // m0 .. m0 + 15 < B = N and keep their Philox row counter); rng_add is added to the sampling's step counter.  Both are
 // plain scalars on purpose: a per-step COPY of the argument structs would live in scratch memory.
 __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __restrict__ slab, const ActArgs* S,
-                                         const long long roff = 0, const unsigned long long rng_add = 0) {
+                                         const long long roff = 0, const unsigned long long rng_add = 0,
+                                         const MlpLds* wl = nullptr, const float* __restrict__ wbase = nullptr,
+                                         const bool input_in_slab = false, float* __restrict__ act_lds = nullptr) {
+  // input_in_slab: the caller has already put the 16 raw input rows (zero padded to 16 columns) into the slab;
+  // act_lds: the sampling writes row r's actions / log-probs to act_lds[r][0..a_w) / [a_w..2 a_w) (LDS) instead of S's
+  // global arrays - the fused rollout's env step needs the action at once, a global round trip would sit on its chain
   const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
   const long long m0 = (long long)blockIdx.x * 16;
   const int B = A.B;
@@ -72,6 +116,19 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
   auto loadw = [&](int L, int kb0) {
     const orl_gen_mlp_layer& ly = A.d.layer[L];
     const int n_in = ly.n_in, n_out = ly.n_out;
+    if constexpr (WL) {  // zero-padded rows of ld floats, 16-byte aligned: whole float4 reads
+      const float* Wl = wbase + wl->off[L];
+      const int ld = wl->ld[L];
+#pragma unroll
+      for (int kb = 0; kb < MLP_KPRE; ++kb)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+          wr[kb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int n = 16 * (wave * NBW + j) + i, k = 16 * (kb0 + kb) + 4 * q;
+          if (n < n_out && k < n_in) wr[kb][j] = *(const f32x4*)(Wl + n * ld + k);
+        }
+      return;
+    }
     const bool vec = (n_in & 3) == 0 && aligned16(ly.W);
 #pragma unroll
     for (int kb = 0; kb < MLP_KPRE; ++kb)
@@ -92,9 +149,11 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
   // ---- input rows (+ MLPBase.feature_norm) into the slab, zero-padded to a multiple of 16 columns
   {
     const int D = A.d.layer[0].n_in, DP = (D + 15) & ~15;
-    for (int e = tid; e < 16 * DP; e += 64 * WAVES) {
-      const int r = e / DP, c = e % DP;
-      slab[r * SLD + c] = (c < D && m0 + r < B) ? A.x[(roff + m0 + r) * D + c] : 0.f;
+    if (!input_in_slab) {
+      for (int e = tid; e < 16 * DP; e += 64 * WAVES) {
+        const int r = e / DP, c = e % DP;
+        slab[r * SLD + c] = (c < D && m0 + r < B) ? A.x[(roff + m0 + r) * D + c] : 0.f;
+      }
     }
     __syncthreads();
     if (A.d.fn_gamma != nullptr) {
@@ -140,7 +199,7 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
       for (int j = 0; j < NBW; ++j) {
         const int col = 16 * (wave * NBW + j) + i;
         if (col < n_out) {
-          const float bv = ly.bias ? ly.bias[col] : 0.f;
+          const float bv = WL ? wbase[wl->voff[L] + col] : (ly.bias ? ly.bias[col] : 0.f);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = acc[j][r] + bv;
@@ -156,7 +215,7 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
     for (int j = 0; j < NBW; ++j) {
       const int col = 16 * (wave * NBW + j) + i;
       if (col < ((n_out + 15) & ~15)) {
-        const float bv = (col < n_out && ly.bias) ? ly.bias[col] : 0.f;
+        const float bv = WL ? (col < n_out ? wbase[wl->voff[L] + col] : 0.f) : ((col < n_out && ly.bias) ? ly.bias[col] : 0.f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab[(4 * q + r) * SLD + col] = col < n_out ? act_fwd(acc[j][r] + bv, ly.act) : 0.f;
       }
@@ -193,7 +252,11 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
         const int sl = ls + LPR * j;
         if (sl < VPR) {
           f32x4 g, b, o;
-          if (gal) { g = *(const f32x4*)(ly.gamma + 4 * sl); b = *(const f32x4*)(ly.beta + 4 * sl); }
+          if constexpr (WL) {
+            const int o4 = (n_out + 3) & ~3;
+            g = *(const f32x4*)(wbase + wl->voff[L] + o4 + 4 * sl);
+            b = *(const f32x4*)(wbase + wl->voff[L] + 2 * o4 + 4 * sl);
+          } else if (gal) { g = *(const f32x4*)(ly.gamma + 4 * sl); b = *(const f32x4*)(ly.beta + 4 * sl); }
           else
 #pragma unroll
             for (int e = 0; e < 4; ++e) { g[e] = ly.gamma[4 * sl + e]; b[e] = ly.beta[4 * sl + e]; }
@@ -222,8 +285,9 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs& A, int SLD, float* __res
       const int NT = S->hd.n_out;
       gen_sample_row(S->hd, lgs + tid * LGS_LD, S->logstd, S->amask ? S->amask + (roff + row) * NT : nullptr, S->deterministic,
                      S->seed, S->row0 + (uint64_t)row, S->rng_step + rng_add + (S->rng_dev ? *S->rng_dev : 0ull),
-                     S->forced ? S->forced + row * S->a_w : nullptr, S->actions + (roff + row) * S->a_w,
-                     S->logp + (roff + row) * S->a_w);
+                     S->forced ? S->forced + row * S->a_w : nullptr,
+                     act_lds ? act_lds + tid * 2 * S->a_w : S->actions + (roff + row) * S->a_w,
+                     act_lds ? act_lds + tid * 2 * S->a_w + S->a_w : S->logp + (roff + row) * S->a_w);
     }
   }
 }

@@ -28,34 +28,74 @@ struct GenRollArgs {
   uint64_t env_seed, tg0;  // env's global step at the first rollout step
 };
 
-template <int NBW, int WAVES, int ENV>
-__global__ __launch_bounds__(64 * WAVES) void gen_rollout_kernel(MlpArgs A, ActArgs S, GenRollArgs R, int SLD) {
-  extern __shared__ float slab[];  // [16][SLD] + [16][LGS_LD]
+// WL: the tower's parameters fit LDS behind the slab (MlpLds): staged once, read from there by all T steps
+template <int NBW, int WAVES, int ENV, bool WL>
+__global__ __launch_bounds__(64 * WAVES) void gen_rollout_kernel(MlpArgs A, ActArgs S, GenRollArgs R, int SLD, MlpLds WLY) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];  // [16][SLD] + [16][LGS_LD] (+ the parameters' copy)
   const orl_buffer_ptrs& b = R.buf;
   const int N = b.N, T = b.T, D = b.Dp, K = b.K;
   const int tid = threadIdx.x;
   const long long m0 = (long long)blockIdx.x * 16;
+  float* wbase = slab + ((16 * SLD + 16 * LGS_LD + 3) & ~3);
+  float* act_lds = wbase + (WL ? WLY.total : 0);  // [16][2 a_w]: the step's sampled actions / log-probs
+  if constexpr (WL) {
+    mlp_lds_stage(A.d, WLY, wbase, tid, 64 * WAVES);
+    __syncthreads();
+  }
+  // lanes 0-15 own an env each: its state row and episode statistics stay in registers for the whole rollout, the next
+  // observation goes straight into the slab (and to the buffer), the action comes out of LDS - no global round trip
+  // on the step's dependent chain (state load -> store -> load, action store -> load, observation store -> load)
+  constexpr int SW = ENV == ORL_ENV_SYNTH ? SYNTH_STATE_W : CARTPOLE_STATE_W;
+  const int n = (int)(m0 + tid);
+  const bool own = tid < 16 && n < N;
+  const bool has_stats = R.ep_stats != nullptr;
+  float est[SW], eps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < SW; ++k) est[k] = own ? R.env_state[(size_t)n * SW + k] : 0.f;
+  if (own && has_stats) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) eps[k] = R.ep_stats[(size_t)n * 4 + k];
+  }
+  const int DP = (D + 15) & ~15, a_w = S.a_w;
   for (int t = 0; t < T; ++t) {
     // A.x = slot 0 of the observations, A.head_out / S.actions / S.logp / S.amask = slot 0 of their arrays (set by the
     // host): the row offset t * N selects slot t, the step counter advances by t
-    mlp_tile<NBW, WAVES>(A, SLD, slab, &S, (long long)t * N, (unsigned long long)t);
+    mlp_tile<NBW, WAVES, WL>(A, SLD, slab, &S, (long long)t * N, (unsigned long long)t, &WLY, wbase, t > 0, act_lds);
     // lanes 0-15 sampled row m0 + tid just above: the same lanes step that env and insert (onpolicy_driver.py:80-152)
-    if (tid < 16 && m0 + tid < N) {
-      const int n = (int)(m0 + tid);
-      const int action = ENV == ORL_ENV_SYNTH ? 0 : (int)S.actions[((size_t)t * N + n) * S.a_w];
+    if (own) {
+      const float* al = act_lds + tid * 2 * a_w;
+      for (int k = 0; k < a_w; ++k) {
+        S.actions[((size_t)t * N + n) * a_w + k] = al[k];
+        S.logp[((size_t)t * N + n) * a_w + k] = al[a_w + k];
+      }
+      const int action = ENV == ORL_ENV_SYNTH ? 0 : (int)al[0];
       float r;
       bool d;
       const size_t s1 = (size_t)(t + 1) * N + n;
-      env_step_one<ENV>(R.env_state, R.ep_stats, n, D, R.env_seed, R.episode_limit, R.tg0 + (uint64_t)t, action,
-                        b.policy_obs + s1 * D, r, d);
+      float* orow = slab + tid * SLD;  // the next step's input row
+      env_step_state<ENV>(est, has_stats ? eps : nullptr, n, D, R.env_seed, R.episode_limit, R.tg0 + (uint64_t)t, action,
+                          orow, r, d);
+      for (int c = D; c < DP; ++c) orow[c] = 0.f;  // (the layers' outputs went through these columns)
+      for (int c = 0; c < D; ++c) b.policy_obs[s1 * D + c] = orow[c];
       b.rewards[(size_t)t * N + n] = r;
       b.masks[s1] = d ? 0.f : 1.f;
       b.active_masks[s1] = 1.f;
       b.bad_masks[s1] = 1.f;
       if (K > 0 && b.action_masks != nullptr)
         for (int k = 0; k < K; ++k) b.action_masks[s1 * K + k] = 1.f;  // these envs have no illegal actions
+    } else if (tid < 16) {
+      float* orow = slab + tid * SLD;  // rows beyond N: keep the tile's input finite
+      for (int c = 0; c < DP; ++c) orow[c] = 0.f;
     }
-    __syncthreads();  // the next step's input rows (slot t + 1) were written by this workgroup's lanes 0-15
+    __syncthreads();  // the next step's input rows are in the slab
+  }
+  if (own) {
+#pragma unroll
+    for (int k = 0; k < SW; ++k) R.env_state[(size_t)n * SW + k] = est[k];
+    if (has_stats) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) R.ep_stats[(size_t)n * 4 + k] = eps[k];
+    }
   }
 }
 
@@ -113,13 +153,24 @@ int orl_gen_rollout_fused(const orl_gen_mlp_desc* policy, const orl_head_desc* h
   const int NBW = wmax <= 128 ? 1 : 2, WV = wmax <= 64 ? 4 : 8;  // as orl_gen_act picks them
   if (width < 16 * WV * NBW) width = 16 * WV * NBW;
   const int SLD = width + 4;
-  const size_t lds = ((size_t)16 * SLD + 16 * LGS_LD) * sizeof(float);
+  // the tower's parameters behind the slab when everything fits the CU's 160 KB (a workgroup per CU at 4096 envs)
+  const MlpLds wly = mlp_lds_layout(*policy);
+  const size_t lds_slab = ((size_t)((16 * SLD + 16 * LGS_LD + 3) & ~3)) * sizeof(float);
+  const size_t lds_act = (size_t)16 * 2 * a_w * sizeof(float);  // the step's sampled actions / log-probs
+  const bool wl = lds_slab + lds_act + (size_t)wly.total * sizeof(float) <= 160 * 1024;
+  const size_t lds = lds_slab + lds_act + (wl ? (size_t)wly.total * sizeof(float) : 0);
   const dim3 grid((unsigned)((buf->N + 15) / 16));
-#define ORL_ROLL_LAUNCH(NBX, WVX, ENVX)                                                                                   \
+#define ORL_ROLL_LAUNCH2(NBX, WVX, ENVX, WLX)                                                                             \
   do {                                                                                                                    \
-    (void)hipFuncSetAttribute((const void*)gen_rollout_kernel<NBX, WVX, ENVX>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds);                                                                                  \
-    hipLaunchKernelGGL((gen_rollout_kernel<NBX, WVX, ENVX>), grid, dim3(64 * WVX), lds, (hipStream_t)stream, A, S, R, SLD); \
+    (void)hipFuncSetAttribute((const void*)gen_rollout_kernel<NBX, WVX, ENVX, WLX>,                                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
+    hipLaunchKernelGGL((gen_rollout_kernel<NBX, WVX, ENVX, WLX>), grid, dim3(64 * WVX), lds, (hipStream_t)stream, A, S, R, \
+                       SLD, wly);                                                                                         \
+  } while (0)
+#define ORL_ROLL_LAUNCH(NBX, WVX, ENVX)                 \
+  do {                                                  \
+    if (wl) ORL_ROLL_LAUNCH2(NBX, WVX, ENVX, true);     \
+    else ORL_ROLL_LAUNCH2(NBX, WVX, ENVX, false);       \
   } while (0)
 #define ORL_ROLL_ENV(NBX, WVX)                                         \
   do {                                                                 \
@@ -131,6 +182,7 @@ int orl_gen_rollout_fused(const orl_gen_mlp_desc* policy, const orl_head_desc* h
   else ORL_ROLL_ENV(2, 8);
 #undef ORL_ROLL_ENV
 #undef ORL_ROLL_LAUNCH
+#undef ORL_ROLL_LAUNCH2
   return launch_status("orl_gen_rollout_fused");
 }
 
