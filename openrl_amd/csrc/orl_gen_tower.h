@@ -205,39 +205,7 @@ __device__ __forceinline__ void gt_split(const f32x4 (&in)[NT], u32x4 (&xs)[NT /
   }
 }
 
-// ---- LDS reads the compiler cannot reschedule.  hipcc, close to the VGPR limit, sinks every ds_read of a software-
-// pipelined loop right in front of its consumer and waits lgkmcnt(0) there: the GEMM loops then pay a full LDS round
-// trip per 16-byte fragment (measured: 4 500 cycles per chunk against 770 of MFMA work).  These reads are volatile asm
-// (issued where they are written), and the wait is an asm that "modifies" the registers it guards, so that the MFMAs
-// consuming them cannot move above it.  LDS operations of a wave complete in order, so lgkmcnt(n) with n younger reads in
-// flight guarantees the guarded ones; compiler-issued LDS / scalar loads in between only make a wait conservative.
-__device__ __forceinline__ unsigned gt_lds_addr(const void* p) {
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
-}
-template <int OFF>
-__device__ __forceinline__ u32x4 gt_ds_read128(unsigned addr) {
-  u32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
-}
-template <int N>
-__device__ __forceinline__ void gt_lds_wait(u32x4& a, u32x4& b, u32x4& c) {
-  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void gt_lds_wait(u32x4& a) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
-}
-
-// compile-time loop: f(integral_constant<int, I>) for I = B .. E-1 (asm immediates need constant expressions)
-template <int I> struct GtIdx { static constexpr int value = I; };
-template <int B, int E, class F>
-__device__ __forceinline__ void gt_static_for(F&& f) {
-  if constexpr (B < E) {
-    f(GtIdx<B>{});
-    gt_static_for<B + 1, E>(f);
-  }
-}
+// (pinned LDS reads gt_ds_read128 / gt_lds_wait and the compile-time loop gt_static_for: orl_mlp.h)
 
 // acc += A in over the streamed chunks of one image (A = the image, T layout in / out): KC chunks x 2 row blocks x KS
 // k-steps x 6 products.  The three A fragments of a (row block, k-step) are read PF steps ahead of their MFMAs.

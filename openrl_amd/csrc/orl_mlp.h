@@ -93,8 +93,86 @@ __device__ __forceinline__ void split_T(const f32x4 (&in)[4], u32x4 (&xs)[2][3])
   }
 }
 
+// ---- LDS reads the compiler cannot reschedule.  hipcc, close to the VGPR limit, sinks every ds_read of a software-
+// pipelined loop right in front of its consumer and waits lgkmcnt(0) there: the GEMM loops then pay a full LDS round
+// trip per 16-byte fragment (measured: 4 500 cycles per chunk against 770 of MFMA work).  These reads are volatile asm
+// (issued where they are written), and the wait is an asm that "modifies" the registers it guards, so that the MFMAs
+// consuming them cannot move above it.  LDS operations of a wave complete in order, so lgkmcnt(n) with n younger reads in
+// flight guarantees the guarded ones; compiler-issued LDS / scalar loads in between only make a wait conservative.
+__device__ __forceinline__ unsigned gt_lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 gt_ds_read128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void gt_lds_wait(u32x4& a, u32x4& b, u32x4& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void gt_lds_wait(u32x4& a) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I = B .. E-1 (asm immediates need constant expressions)
+template <int I> struct GtIdx { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void gt_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(GtIdx<B>{});
+    gt_static_for<B + 1, E>(f);
+  }
+}
+
 // acc += A in (both T layout), A = the bf16 images at Wb: 48 bf16 MFMAs (6 products x 4 row blocks x 2 K-steps),
 // 24 ds_read_b128.  Products are issued smallest first.
+#ifndef ORL_MM64_PF   // build-time experiment: A-fragment read-ahead (steps) of the pinned variant; 0 = the plain loop below
+#define ORL_MM64_PF 0
+#endif
+#if ORL_MM64_PF > 0
+// Experiment (ORL_BUILD_DEFS=-DORL_MM64_PF=1|2): the fragment reads pinned (volatile asm, issued PF steps = 3 PF reads ahead
+// of their MFMAs, explicit lgkmcnt waits).  Left to itself hipcc batches the reads of two steps right in front of their
+// twelve MFMAs and waits lgkmcnt(0) there, so in ONE wave every pair of steps opens with an exposed LDS round trip - but
+// with two waves per SIMD the other wave fills it: 0.2278 - 0.2290 ms per pair launch with PF = 2 (256 VGPRs, 4 spilled),
+// 0.2297 - 0.2319 with PF = 1, against 0.2266 - 0.2287 for the plain loop (interleaved A/B on one box).  Not the default.
+__device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][3],
+                                             f32x4 (&acc)[4], int j, int q) {
+  constexpr int PF = ORL_MM64_PF, NS = 8;
+  const unsigned base = gt_lds_addr(Wb) + (unsigned)(j * WBS + q * 8) * 2u;
+  u32x4 w[PF + 1][3];
+#define ORL_FRAG_OFF(p, s) ((((p) * HID + 16 * ((s) & 3)) * WBS + ((s) >> 2) * 32) * 2)
+  gt_static_for<0, PF>([&](auto si) {
+    constexpr int s = decltype(si)::value;
+    w[s][0] = gt_ds_read128<ORL_FRAG_OFF(0, s)>(base);
+    w[s][1] = gt_ds_read128<ORL_FRAG_OFF(1, s)>(base);
+    w[s][2] = gt_ds_read128<ORL_FRAG_OFF(2, s)>(base);
+  });
+  gt_static_for<0, NS>([&](auto si) {
+    constexpr int s = decltype(si)::value;
+    if constexpr (s + PF < NS) {
+      w[(s + PF) % (PF + 1)][0] = gt_ds_read128<ORL_FRAG_OFF(0, s + PF)>(base);
+      w[(s + PF) % (PF + 1)][1] = gt_ds_read128<ORL_FRAG_OFF(1, s + PF)>(base);
+      w[(s + PF) % (PF + 1)][2] = gt_ds_read128<ORL_FRAG_OFF(2, s + PF)>(base);
+    }
+    constexpr int ahead = (NS - 1 - s) < PF ? (NS - 1 - s) : PF;
+    u32x4& wh = w[s % (PF + 1)][0];
+    u32x4& wm = w[s % (PF + 1)][1];
+    u32x4& wl = w[s % (PF + 1)][2];
+    gt_lds_wait<3 * ahead>(wh, wm, wl);
+    constexpr int h = s >> 2, mo = s & 3;
+    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
+    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
+  });
+#undef ORL_FRAG_OFF
+}
+#else
 __device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][3],
                                              f32x4 (&acc)[4], int j, int q) {
   u32x4 w[2][3];  // A fragments double-buffered over the 8 (h, mo) steps
@@ -117,6 +195,7 @@ __device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ 
     acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
   }
 }
+#endif
 
 // LDS image of one tower (offsets in floats, all multiples of 4 => 16-byte aligned).
 struct TowerLds {
