@@ -6,8 +6,11 @@ namespace orl {
 
 // backward: one 8-wave workgroup per CU (256 VGPRs per wave); forward: 8-wave workgroups at <= 128 VGPRs and ~75 KB of
 // LDS, TWO per CU, so that one's barrier / LDS waits overlap the other's MFMAs
+#ifndef ORL_GT_BWD_MINWAVES  // build-time experiment: 1 = one 4-wave workgroup per CU with 512 registers per wave
+#define ORL_GT_BWD_MINWAVES 2
+#endif
 template <int H, int NL, int ND, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void gt_bwd_kernel(GtArgs A) {
+__global__ __launch_bounds__(NW * 64, ORL_GT_BWD_MINWAVES) void gt_bwd_kernel(GtArgs A) {
   gt_body<H, NL, ND, true, NW>(A);
 }
 template <int H, int NL, int ND>
@@ -342,7 +345,7 @@ static int gt_backward(const orl_gt_desc* d, const GtLossArgs& loss, const float
   const int nw = gt_bwd_waves(ly);
   const size_t lds_bwd = gt_lds_bytes(ly, nw);
   const int n_pass = ((mb + 15) / 16 + nw - 1) / nw;
-  const int max_grid = 256 * (lds_bwd <= 80 * 1024 ? 2 : 1);
+  const int max_grid = 256 * ((lds_bwd <= 80 * 1024 && ORL_GT_BWD_MINWAVES > 1) ? 2 : 1);
   int grid = n_pass < max_grid ? n_pass : max_grid;
   const int64_t fit = partials_floats / row_floats;
   if (grid > fit) grid = (int)fit;
