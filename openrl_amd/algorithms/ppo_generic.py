@@ -146,8 +146,9 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
             if ev is not None:  # benchmarks: HIP events on the launch stream around the policy tower's launch
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            # (turn_on = False: the launch still runs for the logging sums; its gradient is never applied)
-            sums = ftp.train(rec, 0, idx, mb, head, mod._logstd(), Dp, Dc, a_w, K, den, None, hp)
+            # (turn_on = False: the launch still runs for the logging sums; the policy's gradient is dropped in the kernel
+            # and the optimiser step below is skipped - ppo.py:226-236)
+            sums = ftp.train(rec, 0, idx, mb, head, mod._logstd(), Dp, Dc, a_w, K, den, None, hp, policy_grad=turn_on)
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))

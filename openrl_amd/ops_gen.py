@@ -117,7 +117,8 @@ def gt_sizes(desc):
     """(image floats, raw gradient-sum floats) of a fused general tower (``orl_gt_image_floats`` / ``orl_gt_raw_floats``)."""
     a, b = _lib().orl_gt_image_floats(C.byref(desc)), _lib().orl_gt_raw_floats(C.byref(desc))
     if a < 0 or b < 0:
-        nat.check(-2, "orl_gt_image_floats")
+        msg = _lib().orl_last_error_string()
+        raise nat.NativeError("orl_gt_image_floats / orl_gt_raw_floats: %s" % (msg.decode() if msg else "unsupported tower"))
     return int(a), int(b)
 
 
