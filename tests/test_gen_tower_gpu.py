@@ -217,3 +217,54 @@ def test_training_with_fused_towers_equals_the_layerwise_route(argv, kw):
         thetas.append({k: m.theta.cpu().numpy().copy() for k, m in net.module.models.items()})
     for k in thetas[0]:
         np.testing.assert_allclose(thetas[0][k], thetas[1][k], rtol=2e-3, atol=3e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("argv", [["--hidden_size", "128"], ["--use_share_model", "true", "--hidden_size", "64"]])
+def test_turn_on_false_on_fused_general_towers(argv):
+    """PPOAlgorithm.train(buffer, turn_on=False) (ppo.py:226-236: the policy loss is not in the loss list) through the
+    one-launch update: separate networks - the policy's parameters do not move and the critic gets bit for bit the update it
+    gets with turn_on=True; shared network - the update equals the layer-wise route's (value loss only)."""
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+    from openrl_amd.utils.util import set_seed
+
+    N, T = 64, 16
+    shared = "--use_share_model" in argv
+
+    def run(turn_on, mode="fused"):
+        cfg = default_cfg(["--seed", "7", "--episode_length", str(T), "--ppo_epoch", "2", "--amd_gen_update", mode] + argv)
+        env = make("SyntheticFixedStep-v0", env_num=N, device=DEV, seed=7, obs_dim=6, episode_limit=5)
+        set_seed(7)
+        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+
+        class _Agent:
+            num_time_steps = 0
+
+        cfg.num_env_steps = N * T
+        trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=DEV)
+        buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=DEV)
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, _Agent())
+        drv.reset_and_buffer_init()
+        drv.episode = 0
+        drv.actor_rollout()
+        drv.compute_returns()
+        before = {k: m.theta.clone() for k, m in net.module.models.items()}
+        trainer.prep_training()
+        trainer.train(buf.data, turn_on=turn_on)
+        torch.cuda.synchronize()
+        return before, {k: m.theta.clone() for k, m in net.module.models.items()}
+
+    if shared:
+        _, a = run(False, "fused")
+        _, b = run(False, "layerwise")
+        np.testing.assert_allclose(a["model"].cpu().numpy(), b["model"].cpu().numpy(), rtol=2e-3, atol=3e-5)
+    else:
+        b0, off = run(False)
+        _, on = run(True)
+        assert torch.equal(off["policy"], b0["policy"]), "the policy moved with turn_on=False"
+        assert not torch.equal(on["policy"], b0["policy"])
+        assert torch.equal(off["critic"], on["critic"])
