@@ -775,7 +775,7 @@ typedef struct orl_gt_desc {
   int32_t oW[ORL_GT_MAX_LAYERS], ob[ORL_GT_MAX_LAYERS], og[ORL_GT_MAX_LAYERS], obe[ORL_GT_MAX_LAYERS], act[ORL_GT_MAX_LAYERS];
   int32_t head_oW[2], head_ob[2], head_n[2]; /* head h: weight [head_n, H], bias [head_n]; all heads together <= 16 outputs */
 } orl_gt_desc;
-/* 1 when the fused kernels take this tower (hidden_size 64 with 2..4 layers or 128 with 2..3, D <= 64, the weights and
+/* 1 when the fused kernels take this tower (hidden_size 64 or 128 with 2..4 layers, D <= 64, the weights and
  * the exchange slab within 160 KiB of LDS), else 0 (orl_last_error says why). */
 int orl_gt_supported(const orl_gt_desc* d);
 /* Sizes (floats) of the image orl_gt_prep writes and of the raw gradient-sum vector; -1 when unsupported. */

@@ -225,7 +225,7 @@ static int gt_bwd_waves(const GtLay& ly) {
 static int gt_check(const orl_gt_desc* d, const char* who) {
   ORL_REQUIRE(d && d->theta, "%s: null descriptor", who);
   if (d->H != 64 && d->H != 128) return fail(ORL_E_UNSUPPORTED, "%s: hidden_size %d (the fused towers take 64 / 128)", who, d->H);
-  const int max_layers = d->H == 64 ? 4 : 3;
+  const int max_layers = ORL_GT_MAX_LAYERS;  // (three 128-wide hidden layers spill ~700 VGPRs; the kernel is issue-bound, it still wins)
   if (d->n_layers < 2 || d->n_layers > max_layers)
     return fail(ORL_E_UNSUPPORTED, "%s: %d layers at hidden_size %d (2..%d)", who, d->n_layers, d->H, max_layers);
   if (d->D < 1 || d->D > 64) return fail(ORL_E_UNSUPPORTED, "%s: obs_dim %d outside [1, 64]", who, d->D);
@@ -272,6 +272,7 @@ static int gt_launch(const GtArgs& A, int bwd_waves, int grid, size_t lds, hipSt
   ORL_GT_CASE(64, 3)
   ORL_GT_CASE(128, 1)
   ORL_GT_CASE(128, 2)
+  ORL_GT_CASE(128, 3)
 #undef ORL_GT_CASE
 #undef ORL_GT_CASE3
   return fail(ORL_E_UNSUPPORTED, "orl_gt: no kernel for hidden_size %d with %d layers", H, NL + 1);

@@ -139,7 +139,7 @@ def test_fused_general_tower_host_queries(lib):
     chunk = (3 * 32 * (128 + 8) * 2 + 1023) // 1024 * 1024 // 4
     res = 128 * 4 + 2 * 128 + 16 + 128 * 20 + 16 * 132
     assert lib.orl_gt_image_floats(C.byref(d)) == (res + 255) // 256 * 256 + 8 * chunk
-    for H, D, nl, ok in [(64, 64, 4, 1), (64, 4, 5, 0), (128, 4, 3, 1), (128, 4, 4, 0), (128, 32, 2, 1), (128, 64, 2, 0),
+    for H, D, nl, ok in [(64, 64, 4, 1), (64, 4, 5, 0), (128, 4, 3, 1), (128, 4, 4, 1), (128, 4, 5, 0), (128, 32, 2, 1), (128, 64, 2, 0),
                          (96, 4, 2, 0), (256, 4, 2, 0), (64, 65, 2, 0)]:
         assert lib.orl_gt_supported(C.byref(desc(H, D, nl))) == ok, (H, D, nl)
     assert lib.orl_gt_supported(C.byref(desc(64, 4, 2, heads=(15, 1)))) == 1   # shared network: act + v_out

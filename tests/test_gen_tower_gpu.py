@@ -73,6 +73,8 @@ CASES = [
     (128, 1, 2, False, 30, ("critic", None, 1), 5),
     (64, 1, 3, True, 8, ("model", "box", 3), 1300),
     (128, 1, 1, False, 4, ("policy", "disc", 2), 128 * 300 + 9),
+    (128, 3, 0, True, 12, ("policy", "box", 2), 900),     # four 128-wide layers (the spilling build)
+    (128, 1, 1, False, 6, ("model", "disc", 4), 1111),     # the shared network at 128: base + common = four layers
 ]
 
 
@@ -167,7 +169,9 @@ def test_unsupported_shapes_fall_back():
 
     _, net = make_net("policy", 96, 1, 1, False, 4, spaces.Discrete(2))
     assert net.gt(("act",)) is None
-    _, net = make_net("policy", 128, 3, 1, False, 4, spaces.Discrete(2))  # 4 layers at 128: registers
+    _, net = make_net("policy", 128, 4, 1, False, 4, spaces.Discrete(2))  # five layers
+    assert net.gt(("act",)) is None
+    _, net = make_net("policy", 128, 1, 1, False, 64, spaces.Discrete(2))  # obs 64 at 128: LDS
     assert net.gt(("act",)) is None
 
 
