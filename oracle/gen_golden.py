@@ -745,6 +745,14 @@ def main():
         "train_gen_mixed": lambda n: _train_case(
             n, ["--ppo_epoch", "2", "--num_mini_batch", "2"], 5,
             lambda: __import__("gymnasium").spaces.Tuple((Box(-1, 1, (2,)), Discrete(4))), seed=18),
+        # four 128-wide layers (the widest instances of the cross-layer fused update kernels, csrc/orl_gen_tower.h): the
+        # shared network at hidden 128 (base + common) and layer_N 3 with ELU + feature norm + Box actions
+        "train_share_h128": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "2", "--use_share_model", "true", "--hidden_size", "128"], 6,
+            lambda: Discrete(3), seed=41, share=True),
+        "train_gen_h128_l3_elu_fn": lambda n: _train_case(
+            n, ["--ppo_epoch", "2", "--num_mini_batch", "1", "--hidden_size", "128", "--layer_N", "3", "--activation_id", "3",
+                "--use_feature_normalization", "true"], 9, lambda: Box(-1, 1, (2,)), seed=42),
         "train_share": lambda n: _train_case(
             n, ["--ppo_epoch", "3", "--num_mini_batch", "2", "--use_share_model", "true"], 5, lambda: Discrete(4),
             seed=14, share=True),

@@ -9,7 +9,8 @@ from openrl_amd.modules import generic_net as gn
 from openrl_amd.utils.util import set_seed
 from tests import helpers as H
 
-CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_share", "train_share_box_fn"]
+CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_share", "train_share_box_fn",
+         "train_share_h128", "train_gen_h128_l3_elu_fn"]
 
 
 def _spaces(g):

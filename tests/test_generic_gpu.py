@@ -11,6 +11,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GEN_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_share", "train_share_box_fn",
+             "train_share_h128", "train_gen_h128_l3_elu_fn",
              "train_gen_a2c", "train_gen_mixed"]
 # fp32 tolerances of the update path (MFMA k-order, tile-wise gradient sums); same as tests/test_ppo_update_gpu.py
 THETA_RTOL, THETA_ATOL = 2e-3, 3e-5

@@ -109,7 +109,8 @@ def test_deterministic_probe_matches_reference(case):
 
 
 # ---- general towers: oracle/gen_oracle.py pinned on the goldens minted from the reference ---------------------------
-GEN_FF_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_gen_a2c"]
+GEN_FF_CASES = ["train_gen_h128_l2_tanh_fn", "train_gen_elu_box", "train_gen_leaky_l3", "train_gen_a2c",
+                "train_gen_h128_l3_elu_fn"]
 
 
 def _gen_specs(g):
@@ -158,7 +159,7 @@ def test_general_tower_oracle_replays_the_reference(case):
     np.testing.assert_allclose(lp, g["probe_logp"], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("case", ["train_share", "train_share_box_fn", "train_share_recurrent"])
+@pytest.mark.parametrize("case", ["train_share", "train_share_box_fn", "train_share_recurrent", "train_share_h128"])
 def test_shared_network_oracle_replays_the_reference(case):
     """PolicyValueNetwork (use_share_model; policy_value_network.py:34-172) restated on one flat vector - obs_prep, common,
     [GRU], v_out, act - with the reference's two clips of the same gradient (ppo.py:126-145): full train replay."""
