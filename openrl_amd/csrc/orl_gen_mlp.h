@@ -3,6 +3,7 @@
 // one-launch rollout step (orl_gen_fused.hip: orl_gen_mlp_fwd / orl_gen_act) and the fused general rollout
 // (orl_gen_rollout.hip: all episode_length steps in one launch).  Not part of the C ABI.
 #pragma once
+#include <string.h>
 #include "orl_common.h"
 #include "orl_mlp.h"
 #include "orl_gen_act.h"
