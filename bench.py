@@ -20,7 +20,7 @@ Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel pair (``
 ppo_tower_kernel policy + critic, fp32 MFMA bound) timed live with HIP events on the launch stream;
 ``cpu_baseline`` times the oracle port of the reference's CPU path (oracle/cpu_trainer.py) on the host
 cores and cites the committed run of the REAL reference objects (oracle/ref_cpu_baseline.py,
-profiles/r02_ref_cpu_line.json) - a reported baseline, not the target.
+profiles/r04_ref_cpu_line.json) - a reported baseline, not the target.
 """
 from __future__ import annotations
 
@@ -57,6 +57,94 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def link_type_rank0_rank1():
+    """Link type between the devices of ranks 0 and 1 as `rocm-smi --showtopotype` prints it (XGMI / PCIE), or a reason."""
+    import subprocess
+
+    try:
+        if torch.cuda.device_count() < 2:
+            return "same device (ranks share the one visible GPU)"
+        txt = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=30).stdout
+        rows = [ln.split() for ln in txt.splitlines() if ln.strip().startswith("GPU")]
+        hdr = next((r for r in rows if len(r) > 1 and all(c.startswith("GPU") for c in r)), None)
+        row0 = next((r for r in rows if r[0] == "GPU0" and not all(c.startswith("GPU") for c in r)), None)
+        if hdr and row0 and "GPU1" in hdr:
+            return row0[1 + hdr.index("GPU1")]
+        return "unparsed: " + " | ".join(txt.splitlines()[:12])[:400]
+    except Exception as e:  # rocm-smi missing / hung: report, never fail the bench over it
+        return "unavailable: %s" % (e,)
+
+
+def multi_gpu_report(trainer, args, dev, world, rank, make_engine):
+    """Outside the timed region, world > 1 only (round-3 VERDICT item 4a): what the first contact with real xGMI links should
+    tell - latency of the one-shot all-reduce and of one RCCL all-reduce at the optimiser step's message size, which
+    collective the timed run used and how the comm's self-test went, the weak-scaling rate next to the strong one, the link
+    type.  Raises (rc != 0) if any rank's comm error word is set."""
+    from openrl_amd import distributed as du
+
+    rep = {"collective_setup": dict(du.LAST_SETUP), "link_rank0_rank1": link_type_rank0_rank1(),
+           "backend": torch.distributed.get_backend()}
+    n = int(trainer._sums.numel())
+    rep["message_bytes"] = 4 * n
+    reps = 1000
+
+    def timed(fn):
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / reps * 1e6
+        t = torch.tensor([us], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return round(float(t.item()), 2)
+
+    vec = torch.zeros(n, dtype=torch.float32, device=dev)
+    comm = getattr(trainer, "_comm", None)
+    if comm is not None:
+        rep["orl_allreduce_small_us"] = timed(lambda: comm.allreduce_(vec))
+        comm.check()
+    else:
+        rep["orl_allreduce_small_us"] = None
+    rep["torch_all_reduce_us"] = timed(lambda: torch.distributed.all_reduce(vec))
+    rep["latency_note"] = ("%d back-to-back calls, host clock around the loop, max over ranks; the fused path carries the same "
+                           "exchange INSIDE the reduce/apply launches (no extra launch)" % reps)
+    # the comm's device error word on every rank: one MAX all-reduce, then fail loudly
+    err = comm.error_flag().clone().to(torch.int32) if comm is not None else torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.distributed.all_reduce(err, op=torch.distributed.ReduceOp.MAX)
+    rep["comm_error_word_max_over_ranks"] = int(err.item())
+    if int(err.item()) != 0:
+        raise SystemExit("orl_comm error word set on some rank (%d): a peer's contribution timed out - the timed run summed "
+                         "partial gradients" % int(err.item()))
+    if args.scaling == "strong" and not args.no_weak_leg:
+        # weak scaling next to the strong number: the full 4096 envs on EVERY rank, a short run of the same loop
+        drv_w, trainer_w = make_engine(args.envs)
+        k = max(2, min(args.steps, 8))
+        for i in range(2):
+            drv_w.episode = i
+            drv_w._inner_loop()
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            drv_w.episode = 2 + i
+            drv_w._inner_loop()
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        if getattr(trainer_w, "_comm", None) is not None:
+            trainer_w._comm.check()
+        rep["weak_scaling"] = {"value": round(args.envs * world * T_ROLL * k / float(t.item()), 1), "unit": "env-steps/s",
+                               "envs_per_gpu": args.envs, "steps": k, "ms_per_step": round(float(t.item()) / k * 1e3, 4)}
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +161,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--tower-gemm", default="split", choices=["split", "fp32"],
                     help="A/B: form the tower's GEMMs on the fp32 MFMA instead of the bf16x3 split (same results, slower)")
+    ap.add_argument("--no-weak-leg", action="store_true",
+                    help="world > 1: skip the short weak-scaling run (4096 envs per rank) reported next to the strong number")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the few untimed iterations of BASELINE.json's other single-GPU configs (other_configs)")
     args = ap.parse_args()
@@ -99,9 +189,6 @@ def main():
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
 
-    cfg = default_cfg(["--episode_length", str(T_ROLL), "--ppo_epoch", str(PPO_EPOCH), "--amd_perm_mode", args.perm,
-                       "--log_interval", "1000000", "--amd_collective", args.collective, "--amd_tower_gemm",
-                       args.tower_gemm])
     if args.scaling == "strong":  # the metric: the global envs shard contiguously, N/G per GPU
         lo, hi = du.shard_range(args.envs, rank, world)
         n_local = hi - lo
@@ -109,20 +196,28 @@ def main():
         n_local = args.envs
     if n_local < 1:
         raise SystemExit("%d envs cannot be sharded over %d ranks" % (args.envs, world))
-    env = make("SyntheticFixedStep-v0", env_num=n_local, obs_dim=OBS_DIM, episode_limit=200, device=dev,
-               seed=cfg.seed + 10086 * rank)
-    net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=n_local)
-    cfg.num_env_steps = n_local * T_ROLL * (args.steps + args.warmup)
-
     class _Agent:
         num_time_steps = 0
 
-    trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=dev)
-    buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=dev)
-    drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": dev}, trainer, buf,
-                         _Agent(), rank=rank, world_size=world)
-    assert drv.fused
-    drv.reset_and_buffer_init()
+    def make_engine(n_envs_local):
+        cfg_e = default_cfg(["--episode_length", str(T_ROLL), "--ppo_epoch", str(PPO_EPOCH), "--amd_perm_mode", args.perm,
+                             "--log_interval", "1000000", "--amd_collective", args.collective, "--amd_tower_gemm",
+                             args.tower_gemm])
+        env_e = make("SyntheticFixedStep-v0", env_num=n_envs_local, obs_dim=OBS_DIM, episode_limit=200, device=dev,
+                     seed=cfg_e.seed + 10086 * rank)
+        net_e = PPONet(env_e, cfg=cfg_e, device=dev, n_rollout_threads=n_envs_local)
+        cfg_e.num_env_steps = n_envs_local * T_ROLL * (args.steps + args.warmup + 16)
+        trainer_e = PPOAlgorithm(cfg_e, net_e.module, agent_num=1, device=dev)
+        buf_e = NormalReplayBuffer(cfg_e, 1, env_e.observation_space, env_e.action_space, device=dev)
+        drv_e = OnPolicyDriver({"cfg": cfg_e, "num_agents": 1, "run_dir": None, "envs": env_e, "device": dev}, trainer_e,
+                               buf_e, _Agent(), rank=rank, world_size=world)
+        assert drv_e.fused
+        drv_e.reset_and_buffer_init()
+        drv_e._bench_buf = buf_e
+        return drv_e, trainer_e
+
+    drv, trainer = make_engine(n_local)
+    buf = drv._bench_buf
 
     def barrier():
         if world > 1:
@@ -174,31 +269,60 @@ def main():
     gae_bytes = 16 * M  # S_gae: 3 reads + 1 write per sample
     # HBM bytes per launch: NOT measured in this process (PMC needs rocprofv3) - read from the committed summary of the
     # separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, and only quoted for the shape it was taken at
-    traffic, traffic_source = None, None
-    for name in ("r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+    traffic, traffic_source, traffic_reason = None, None, None
+    for name in ("r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 blob = json.load(fh)["orl_ppo_fwd_bwd_pair"]
-            if M == N_ENVS * T_ROLL:
-                traffic = blob.get("hbm_bytes_per_launch", blob.get("hbm_bytes_per_launch_raw"))
-                traffic_source = "profiles/" + name
+        except Exception:
+            continue
+        if M == N_ENVS * T_ROLL:
+            traffic = blob.get("hbm_bytes_per_launch", blob.get("hbm_bytes_per_launch_raw"))
+            traffic_source = "profiles/" + name
+        else:
+            traffic_reason = ("the committed PMC passes (profiles/%s) were taken at the full-size launch (%d rows); this "
+                              "launch has %d rows" % (name, N_ENVS * T_ROLL, M))
+        break
+    else:
+        traffic_reason = "no committed PMC summary under profiles/"
+    # pipe occupancy of the same kernel from the committed counter passes (tools/pmc_tower.sh -> profiles/rNN_pmc_tower.txt):
+    # MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), VALU-busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4
+    # / (4 x SQ_BUSY_CU_CYCLES); only quoted for the shape and GEMM path they were taken at
+    busy = {}
+    for name in ("r04_pmc_tower.txt", "r03_pmc_tower.txt"):
+        try:
+            ctr = {}
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                for line in fh:
+                    f = line.split()
+                    if len(f) >= 2 and f[0].startswith("SQ_"):
+                        ctr[f[0]] = float(f[1])
+            if M == N_ENVS * T_ROLL and args.tower_gemm == "split" and ctr.get("SQ_BUSY_CU_CYCLES"):
+                cu = 4.0 * ctr["SQ_BUSY_CU_CYCLES"]
+                busy = {"mfma_busy_frac": round(ctr["SQ_VALU_MFMA_BUSY_CYCLES"] / cu, 4),
+                        "valu_busy_frac": round(4.0 * ctr["SQ_ACTIVE_INST_VALU"] / cu, 4),
+                        "busy_source": "profiles/" + name}
             break
         except Exception:
             continue
     roofline = {"kernel": "orl_ppo_fwd_bwd (ppo_tower_pair_kernel: policy + critic towers in one launch)", "bound": "mfma",
                 "achieved": round(achieved_tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_source": traffic_source,
+                "frac": round(achieved_tf / F32_MFMA_PEAK_TFLOPS, 4),
+                "frac_label": "fp32-equivalent: ALGORITHMIC fp32 flops / the fp32 MFMA peak (SURVEY 8d's pricing); with "
+                              "tower_gemm=split the products run on the bf16 pipe - bf16_mfma_frac / mfma_busy_frac / "
+                              "valu_busy_frac are the utilisation figures",
+                "traffic": traffic, "traffic_source": traffic_source, "traffic_reason": traffic_reason,
                 "launch_ms": round(k_ms, 4), "launches_timed": len(ev),
                 "flops_per_launch": flops_per_launch,
-                # how the flops are executed: the three 64 x 64 GEMMs of a tile (92 % of the algorithmic flops) run as 6
-                # bf16 products per fp32 product over EXACT three-term bf16 splits of both operands, fp32 accumulation -
-                # error <= the fp32 MFMA's own (profiles/r03_split_bf16_gemm.txt); `frac` stays priced on ALGORITHMIC fp32
+                # how the flops are executed: the three 64 x 64 GEMMs of a tile (92 % of the algorithmic flops) run as 6 of
+                # the 9 bf16 products of three-term bf16 splits of both operands (the splits are exact, the three smallest
+                # cross terms are dropped: ~2^-24 relative), fp32 accumulation - measured error <= the fp32 MFMA's own (profiles/r03_split_bf16_gemm.txt); `frac` stays priced on ALGORITHMIC fp32
                 # flops against the fp32 MFMA peak, `bf16_mfma_frac` is the share of the dense bf16 MFMA peak issued
                 "mfma_path": ("bf16x3 split (6 of 9 products) on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16; fc1 + head on "
                               "v_mfma_f32_16x16x4_f32") if args.tower_gemm == "split" else "v_mfma_f32_16x16x4_f32 (--tower-gemm fp32)",
                 "bf16_mfma_frac": round(6 * (16384.0 / 17792.0) * achieved_tf / BF16_MFMA_PEAK_TFLOPS, 4)
                 if args.tower_gemm == "split" else 0.0,
+                **busy,
                 "gae_scan": {"bound": "hbm", "achieved": round(gae_bytes / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else 0,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "launch_ms": round(gae_ms, 4),
                              "note": "%.1f MB per launch: latency-bound, includes adv statistics" % (gae_bytes / 1e6)}}
@@ -207,8 +331,9 @@ def main():
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "dtype_note": "fp32 storage and accumulation everywhere; GEMM products as exact bf16x3 splits (f32-equivalent: "
-                         "measured error <= v_mfma_f32_16x16x4_f32's)",
+           "dtype_note": "fp32 storage and accumulation everywhere; the 64-wide GEMM products at fp32 ACCURACY on the bf16 "
+                         "MFMA: 6 of the 9 products of three-term bf16 splits (dropped terms ~2^-24 relative; measured error "
+                         "<= v_mfma_f32_16x16x4_f32's, profiles/r03_split_bf16_gemm.txt)",
            "config": {"workload": "configs[1]: PPO, %d global envs x 128-step rollout (%d envs per GPU), obs 4, "
                                   "Discrete(2), MLP 64x64, ppo_epoch 10, num_mini_batch 1, ValueNorm on; synthetic "
                                   "fixed-step env" % (global_envs, n_local),
@@ -225,12 +350,12 @@ def main():
         cb = time_cpu_baseline_bounded(n_envs=N_ENVS, ppo_epoch=PPO_EPOCH, target_seconds=args.cpu_seconds)
         ref_run = None
         try:  # the REAL reference objects, timed where /root/reference exists (oracle/ref_cpu_baseline.py), committed
-            with open(os.path.join(ROOT, "profiles", "r02_ref_cpu_line.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r04_ref_cpu_line.json")) as fh:
                 ref = json.loads(fh.readline())
             ref_run = {"value": round(ref["value"], 1), "unit": "env-steps/s", "cores": ref["cores"],
                        "sample": "1 warm-up + %d iterations of the full configs[1] workload with the reference's own "
                                  "classes, timed in the build container" % ref["iters"],
-                       "source": "profiles/r02_ref_cpu_line.json"}
+                       "source": "profiles/r04_ref_cpu_line.json"}
         except Exception:
             pass
         if ref_run is not None:  # top-level scalars: the REAL reference classes' rate survives any truncation of the object
@@ -248,6 +373,8 @@ def main():
 
         out["other_configs"] = run_all(steps=3, warmup=2, dev=dev)
     if world > 1:
+        rep = multi_gpu_report(trainer, args, dev, world, rank, make_engine)  # collective on every rank; rank 0 prints it
+        out["multi_gpu"] = rep
         out["scaling_note"] = ("per-rank work is 1/%d of the 4096 global envs; no multi-GPU hardware curve has been measured "
                                "by the builder - this line is the measurement" % world)
     if rank == 0:

@@ -16,6 +16,10 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 CONFIGS = [
+    # the metric's NAME says CartPole: configs[1] on the device CartPole-v1 PHYSICS (csrc/orl_act.hip, gymnasium's dynamics
+    # and termination, in-kernel auto-reset), default tower, fused rollout - next to the headline's synthetic fixed-step env
+    dict(name="configs[1] on the device CartPole-v1 physics: PPO, 4096 envs x 128, obs 4, Discrete(2), fused rollout",
+         env="CartPole-v1", envs=4096, T=128, agents=1, env_kw={}, argv=[]),
     dict(name="configs[2] shape: PPO, 1024 envs x 200, obs 17, Box(6), synthetic fixed-step env", env="SyntheticFixedStep-v0",
          envs=1024, T=200, agents=1, env_kw=dict(obs_dim=17, episode_limit=200, box=6), argv=[]),
     dict(name="configs[3]: MPE simple_spread MAPPO, 2048 envs x 3 agents x 25, GRU, device env", env="simple_spread",

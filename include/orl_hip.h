@@ -578,8 +578,9 @@ typedef struct orl_rnn_rollout_args {
   uint64_t env_seed, act_seed, rng_step0;
   const uint64_t* rng_step_dev; /* optional device-side addend of rng_step0 (see orl_act_step) */
   int32_t* sync_flags;       /* optional [ceil(N/16) + 1] int32 scratch: with it the critic workgroups run in the SAME
-                              * launch, one step behind their policy workgroups (per-group step counters; the last word
-                              * is set to 1 if a critic's bounded wait ever timed out); NULL = two launches */
+                              * launch, one step behind their policy workgroups (per-group step counters, cleared by every
+                              * call; the last word is set to 1 if a critic's bounded wait ever timed out - STICKY: the
+                              * caller zeroes it once and it is never cleared here); NULL = two launches */
   uint64_t env_step0;        /* ORL_ENV_SYNTH / ORL_ENV_CARTPOLE (single agent, A == 1, one shared observation array; then
                               * world_length = the episode limit, env_state as orl_env_reset leaves it, sync_flags unused):
                               * the env's global step at the first rollout step */

@@ -355,8 +355,12 @@ class DeviceErrorWatch:
     ``orl_comm``, the bounded critic-chases-policy wait of ``orl_rnn_rollout_fused``).  ``post(flag)`` queues an
     asynchronous copy of the int32 device word into pinned host memory behind the work already on the stream;
     ``poll()`` raises if a completed copy carried a non-zero word - without synchronising (``wait=True``: after waiting
-    for the copy).  Callers post once per update / rollout and poll at their next natural host touch point, so a
-    failure surfaces at most one iteration late and never costs a sync."""
+    for the copy).  Callers post once per update / rollout and poll at their next natural host touch point and never
+    pay a sync for it.  The contract that makes ONE pinned word enough: the device word is STICKY (kernels only ever set
+    it; neither ``orl_comm`` nor ``orl_rnn_rollout_fused`` clears it), so when the host has run ahead and a posted
+    copy is overwritten by a later one before any poll saw it, the later copy carries the error too - a failure in
+    iteration k surfaces at the first poll that finds ANY completed copy posted at or after k, at the latest the
+    ``wait=True`` poll at the end of training."""
 
     def __init__(self, what: str) -> None:
         self.what = what

@@ -161,8 +161,11 @@ class PPOAlgorithm(BaseAlgorithm):
                     m.grad = self._gen_flat[o:o + int(m.n_params)]
                     o += int(m.n_params)
                 self._gen_sums = (self._gen_flat[o:o + 20], self._gen_flat[o + 20:o + 40])
+                # the one-shot xGMI push is built for the latency regime (every rank pushes its whole vector to every
+                # peer, 8-byte tagged granules, <= 32 blocks): above P2P_MAX_FLOATS the vector goes through RCCL, whose
+                # ring is bandwidth-optimal there
                 self._comm = dist_utils.make_small_allreduce(n, self.device, getattr(cfg, "amd_collective", "p2p")) \
-                    if n <= (1 << 22) else None
+                    if n <= self.P2P_MAX_FLOATS else None
                 if self._comm is not None:
                     self._comm_watch = nat.DeviceErrorWatch("orl_comm: a peer's contribution did not arrive within 10 s - "
                                                             "the optimiser step ran on a partial gradient sum")
@@ -188,6 +191,9 @@ class PPOAlgorithm(BaseAlgorithm):
         self._comm_watch = nat.DeviceErrorWatch("orl_comm: a peer's contribution did not arrive within 10 s - the "
                                                 "optimiser step ran on a partial gradient sum") \
             if self._comm is not None else None
+
+    #: largest flat gradient vector (floats) the one-shot P2P all-reduce carries; wider general towers use RCCL
+    P2P_MAX_FLOATS = 1 << 16
 
     def _allreduce_vec(self, t: torch.Tensor) -> torch.Tensor:
         """In-place SUM of a small fp32 vector over the ranks: the one-shot xGMI push when the comm is up, else

@@ -55,7 +55,10 @@ def update_minibatch_generic(algo, buffer, idx, mb: int, turn_on: bool, rnn=None
     den = den_c = algo._gen_den
     # one minibatch == the whole batch: the masked-mean denominators (counts of 0 / 1 floats - exact in fp32) are the
     # same for every epoch of this train() call, so they are computed and summed over ranks once per call
-    stamp = (algo._jrpo_epoch_id, mb) if (jrpo is None and algo.num_mini_batch == 1) else None
+    # keyed on the train() call, the batch size AND the record tensor (a direct caller handing another buffer of the same
+    # size must not reuse - or, multi-GPU, skip the collective of - stale denominators)
+    stamp = ((getattr(algo, "_jrpo_epoch_id", 0), mb, int(rec.data_ptr()))
+             if (jrpo is None and algo.num_mini_batch == 1) else None)
     if stamp is None or stamp != algo._gen_den_stamp:
         ops_gen.denoms(rec, Dp, Dc, a_w, idx, mb, den, algo._gen_den_scratch)
         if jrpo is not None:  # the value loss averages over agent 0's rows

@@ -462,7 +462,9 @@ int orl_rnn_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const o
   ORL_REQUIRE(lds_p <= 160 * 1024 && lds_c <= 160 * 1024, "orl_rnn_rollout_fused: tower image exceeds the LDS");
   const int n_groups = (b.N + TILE_B - 1) / TILE_B;
   if (a->sync_flags != nullptr) {  // one launch, critic workgroups chase their policy workgroups
-    if (hipMemsetAsync(a->sync_flags, 0, (size_t)(n_groups + 1) * sizeof(int), s) != hipSuccess)
+    // only the n_groups step counters are cleared: the error word flags[n_groups] is STICKY (caller-zeroed once, like
+    // orl_comm's) - a timeout in rollout k must still be visible after rollout k + 1 when the host polls late
+    if (hipMemsetAsync(a->sync_flags, 0, (size_t)n_groups * sizeof(int), s) != hipSuccess)
       return fail(ORL_E_INVALID, "orl_rnn_rollout_fused: clearing the step counters failed");
     const size_t lds = lds_p > lds_c ? lds_p : lds_c;
     (void)hipFuncSetAttribute((const void*)rnn_rollout_mpe_chase_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,

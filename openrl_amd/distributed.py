@@ -154,6 +154,11 @@ def _fault(stage: str) -> None:
         raise RuntimeError("injected %s failure on rank %d" % (stage, rank()))
 
 
+#: outcome of the most recent make_small_allreduce() on this rank, for run reports (bench.py's multi_gpu object):
+#: {"requested": mode, "used": "p2p" | "torch.distributed", "selftest": "passed" | "skipped" | "<why it failed>"}
+LAST_SETUP = {"requested": None, "used": "none (single process)", "selftest": "skipped"}
+
+
 def make_small_allreduce(capacity_floats: int, device, mode: str = "p2p"):
     """A ``SmallAllreduce`` for this process group, or None (-> torch.distributed / RCCL all-reduces) when the run is
     single-process, ``mode == "rccl"``, or peer memory cannot be mapped.  The decision is made collectively: if ANY
@@ -161,6 +166,8 @@ def make_small_allreduce(capacity_floats: int, device, mode: str = "p2p"):
     gather, connect-status gather, self-test-status gather) whatever happened locally - a rank never raises between
     them, so the group cannot fall out of step."""
     if not (is_initialized() and dist.get_world_size() > 1) or mode != "p2p":
+        if is_initialized() and dist.get_world_size() > 1:
+            LAST_SETUP.update(requested=mode, used="torch.distributed", selftest="skipped (amd_collective=%s)" % mode)
         return None
     import warnings
 
@@ -205,7 +212,9 @@ def make_small_allreduce(capacity_floats: int, device, mode: str = "p2p"):
                       % (r, why or "a peer failed"))
         if comm is not None:
             comm.close()
+        LAST_SETUP.update(requested=mode, used="torch.distributed", selftest="failed: %s" % (why or "a peer failed"))
         return None
+    LAST_SETUP.update(requested=mode, used="p2p", selftest="passed (known sum, both inbox parities, %d floats)" % comm.capacity)
     return comm
 
 

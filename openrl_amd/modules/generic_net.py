@@ -648,9 +648,10 @@ class GenericPPOModule(PPOModule):
 
     def __init__(self, cfg, policy_input_space, critic_input_space, act_space, share_model: bool = False,
                  device="cuda:0", rank=None, world_size=None, model_dict=None):
-        from .ppo_module import check_model_dict
+        from .ppo_module import check_model_dict, check_model_dict_roles
 
         check_model_dict(model_dict)
+        check_model_dict_roles(model_dict, bool(share_model or cfg.use_share_model))
         for flag in ("use_influence_policy", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp", "use_deepspeed"):
             if getattr(cfg, flag, False):
                 raise NotImplementedError("cfg.%s=True is not built for the general towers" % flag)

@@ -246,10 +246,27 @@ def check_model_dict(model_dict) -> None:
         if key not in BUILT_NETWORKS:
             raise KeyError("model_dict key %r: the reference reads 'policy', 'critic' and 'model'" % (key,))
         name = getattr(net_cls, "__name__", type(net_cls).__name__)
-        if name != BUILT_NETWORKS[key]:
+        module = getattr(net_cls, "__module__", "") or ""
+        # identity, not name: the stock class is one DEFINED in the reference's openrl.modules.networks package or the
+        # marker of openrl_amd.modules.networks - a user class that merely shares the name has its own forward
+        stock = name == BUILT_NETWORKS[key] and (module.startswith("openrl.modules.networks.")
+                                                  or module.startswith("openrl_amd.modules.networks"))
+        if not stock:
             raise NotImplementedError(
-                "model_dict[%r] = %s: only the stock %s is accepted (the engine's built towers reproduce it from cfg); a "
-                "custom network class cannot run on the HIP towers" % (key, name, BUILT_NETWORKS[key]))
+                "model_dict[%r] = %s.%s: only the stock %s (openrl.modules.networks / openrl_amd.modules.networks) is "
+                "accepted - the engine's built towers reproduce it from cfg; a custom network class cannot run on the HIP "
+                "towers" % (key, module, name, BUILT_NETWORKS[key]))
+
+
+def check_model_dict_roles(model_dict, share_model: bool) -> None:
+    """ppo_module.py:58-89: with ``use_share_model`` the reference reads ONLY model_dict['model'], without it only
+    'policy' / 'critic'.  An entry for the other mode would be silently ignored there; here it is refused."""
+    keys = set(model_dict or {})
+    if share_model and keys - {"model"}:
+        raise ValueError("model_dict has %s but use_share_model is on: the shared network is model_dict['model']"
+                         % sorted(keys - {"model"}))
+    if not share_model and "model" in keys:
+        raise ValueError("model_dict['model'] is the shared PolicyValueNetwork: it needs use_share_model=True")
 
 
 class PPOModule:
@@ -275,6 +292,7 @@ class PPOModule:
         if share_model or cfg.use_share_model:
             raise NotImplementedError("use_share_model with use_recurrent_policy is not built (feed-forward only)")
         check_model_dict(model_dict)
+        check_model_dict_roles(model_dict, False)
         for flag in ("use_influence_policy",
                      "use_feature_normalization", "use_policy_vhead", "use_attn", "use_conv1d", "use_amp",
                      "use_deepspeed", "use_single_network"):

@@ -22,7 +22,9 @@ def test_a2c_oracle_replay_matches_reference():
 
 
 @pytest.mark.gpu
-def test_a2c_engine_matches_reference_golden():
+@pytest.mark.parametrize("skip_epochs", [0, 1])
+def test_a2c_engine_matches_reference_golden(skip_epochs):
+    """skip_epochs = 1 is the negative control of the d_theta bar: the same run one epoch short must be refused."""
     from openrl_amd import spaces
     from openrl_amd.algorithms.a2c import A2CAlgorithm
     from openrl_amd.buffers.replay_data import ReplayData
@@ -43,12 +45,20 @@ def test_a2c_engine_matches_reference_golden():
         getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
     algo = A2CAlgorithm(cfg, module, agent_num=1, device=dev)
     assert algo.num_mini_batch == 1
+    algo.ppo_epoch -= skip_epochs
     torch.manual_seed(int(g["perm_seed"]))
     info = algo.train(buf)
+    if skip_epochs:
+        for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
+            H.assert_update_parity_rejects(g[k0], module.models[name].theta.cpu().numpy(), g[k1],
+                                           name + ", last epoch skipped")
+        return
     assert "ratio" not in info and len(algo.last_indices) == 3
     np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"][:5], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=2e-3, atol=3e-5)
-    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=2e-3, atol=3e-5)
+    for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
+        got_flat = module.models[name].theta.cpu().numpy()
+        H.assert_update_parity(g[k0], got_flat, g[k1], name)  # the bar on d_theta (tests/helpers.py)
+        np.testing.assert_allclose(got_flat, g[k1], rtol=2e-3, atol=3e-5)
 
 
 # ---- MATAlgorithm: one summed loss (same gradients with separate towers) + the transformer generator ----------------
@@ -132,7 +142,9 @@ def test_mat_engine_matches_reference_golden(case, perm_mode):
         for got, w in zip(algo.last_indices, want):
             assert np.array_equal(got.cpu().numpy(), w)
     np.testing.assert_allclose(np.array([info[k] for k in ALL_KEYS]), g["train_info"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=2e-3, atol=3e-5)
-    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=2e-3, atol=3e-5)
+    for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
+        got_flat = module.models[name].theta.cpu().numpy()
+        H.assert_update_parity(g[k0], got_flat, g[k1], name)  # the bar on d_theta (tests/helpers.py)
+        np.testing.assert_allclose(got_flat, g[k1], rtol=2e-3, atol=3e-5)
     if "vn_state1" in g:
         np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)

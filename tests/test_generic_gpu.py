@@ -63,6 +63,30 @@ def test_initial_weights_reproduce_the_reference(case):
         np.testing.assert_allclose(got, g[k0], rtol=0, atol=1e-5, err_msg=name)
 
 
+@pytest.mark.parametrize("case", ["train_gen_h128_l2_tanh_fn", "train_share"])
+def test_update_parity_bar_rejects_a_short_general_update(case):
+    """Negative control of the d_theta bar on the general towers: the golden case with its last epoch skipped must be
+    refused (and 'no update' as well)."""
+    g = H.load_golden(case)
+    cfg, module, obs_space, act_space, ReplayData, PPOAlgorithm = build(g)
+    for name, k0, _ in nets(module, g):
+        module.models[name].load_reference_flat(g[k0])
+    buf = ReplayData(cfg, 1, obs_space, act_space, device=DEV)
+    for f in ("policy_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks", "bad_masks",
+              "active_masks", "action_masks"):
+        if "buf_" + f in g:
+            getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+    algo = PPOAlgorithm(cfg, module, agent_num=1, device=DEV)
+    algo.ppo_epoch -= 1
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    algo.train(buf)
+    for name, k0, k1 in nets(module, g):
+        H.assert_update_parity_rejects(g[k0], module.models[name].reference_flat().cpu().numpy(), g[k1],
+                                       name + ", last epoch skipped")
+        H.assert_update_parity_rejects(g[k0], g[k0], g[k1], name + ", no update")
+
+
 @pytest.mark.parametrize("case", GEN_CASES)
 def test_train_matches_reference_golden(case):
     g = H.load_golden(case)
@@ -83,9 +107,10 @@ def test_train_matches_reference_golden(case):
     got = np.array([info.get(k, 0.0) for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
                                                "critic_grad_norm", "ratio")])
     np.testing.assert_allclose(got, g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
-    for name, _, k1 in nets(module, g):
-        np.testing.assert_allclose(module.models[name].reference_flat().cpu().numpy(), g[k1], rtol=THETA_RTOL,
-                                   atol=THETA_ATOL, err_msg=name)
+    for name, k0, k1 in nets(module, g):
+        got_flat = module.models[name].reference_flat().cpu().numpy()
+        H.assert_update_parity(g[k0], got_flat, g[k1], name)  # the bar on d_theta (tests/helpers.py)
+        np.testing.assert_allclose(got_flat, g[k1], rtol=THETA_RTOL, atol=THETA_ATOL, err_msg=name)
     if "vn_state1" in g:
         np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"],
                                    rtol=1e-5)

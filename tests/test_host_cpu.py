@@ -126,8 +126,20 @@ def test_model_dict_accepts_the_stock_network_classes_and_refuses_foreign_ones()
     check_model_dict(None)
     check_model_dict({"policy": PolicyNetwork, "critic": ValueNetwork})
     check_model_dict({"model": PolicyValueNetwork})
-    ref_like = type("PolicyNetwork", (), {})  # e.g. openrl.modules.networks.policy_network.PolicyNetwork itself
+    # the reference's own class: identified by the module that DEFINES it, not by its name alone
+    ref_like = type("PolicyNetwork", (), {"__module__": "openrl.modules.networks.policy_network"})
     check_model_dict({"policy": ref_like})
+    impostor = type("PolicyNetwork", (), {"__module__": "my_project.nets", "forward": lambda self, x: x})
+    with pytest.raises(NotImplementedError, match="only the stock PolicyNetwork"):
+        check_model_dict({"policy": impostor})  # same NAME, its own forward: refused, not silently replaced
+    from openrl_amd.modules.ppo_module import check_model_dict_roles
+
+    check_model_dict_roles({"policy": PolicyNetwork, "critic": ValueNetwork}, share_model=False)
+    check_model_dict_roles({"model": PolicyValueNetwork}, share_model=True)
+    with pytest.raises(ValueError):
+        check_model_dict_roles({"model": PolicyValueNetwork}, share_model=False)
+    with pytest.raises(ValueError):
+        check_model_dict_roles({"policy": PolicyNetwork}, share_model=True)
 
     class MyNet(PolicyNetwork):  # a custom forward cannot run on the HIP towers
         pass

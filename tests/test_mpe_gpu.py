@@ -183,6 +183,46 @@ def test_graph_captured_rollout_equals_eager_rollout(recurrent):
     assert torch.equal(tha, thb)
 
 
+def test_chase_error_word_is_sticky_across_rollouts():
+    """a critic-wait timeout recorded by rollout k must survive rollout k + 1's launch (which used to
+    memset the error word together with the step counters), so that a host that polls late - DeviceErrorWatch reuses one
+    pinned word - still sees it.  The timeout is simulated by setting the device word between two rollouts."""
+    from openrl_amd import _native as nat
+    from openrl_amd.algorithms.ppo import PPOAlgorithm
+    from openrl_amd.buffers import NormalReplayBuffer
+    from openrl_amd.configs.config import default_cfg
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from openrl_amd.envs.common import make
+    from openrl_amd.modules.common import PPONet
+
+    N, T = 48, 6
+    cfg = default_cfg(["--seed", "3", "--episode_length", str(T), "--use_recurrent_policy", "true", "--ppo_epoch", "1",
+                       "--amd_perm_mode", "device", "--amd_use_graph", "false", "--amd_rollout_mode", "fused",
+                       "--amd_rnn_rollout_chase", "true", "--log_interval", "1000000"])
+    env = make("simple_spread", env_num=N, device=DEV, seed=3)
+    net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+    cfg.num_env_steps = N * T * 3
+
+    class _Agent:
+        num_time_steps = 0
+
+    trainer = PPOAlgorithm(cfg, net.module, agent_num=3, device=DEV)
+    buf = NormalReplayBuffer(cfg, 3, env.observation_space, env.action_space, device=DEV)
+    drv = OnPolicyDriver({"cfg": cfg, "num_agents": 3, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, _Agent())
+    drv.reset_and_buffer_init()
+    drv.actor_rollout()
+    torch.cuda.synchronize()
+    assert drv._chase_flags is not None and int(drv._chase_flags[-1]) == 0
+    drv._chase_flags[-1] = 1            # "a critic workgroup timed out in this rollout"
+    drv.learner_update()
+    buf.data.after_update()
+    with pytest.raises(nat.NativeError, match="timed out"):
+        drv.actor_rollout()             # re-launch: counters cleared, error word kept; post() copies it, poll() raises
+        torch.cuda.synchronize()
+        assert int(drv._chase_flags[-1]) == 1 and int(drv._chase_flags[:-1].min()) == T
+        drv._chase_watch.poll(wait=True)
+
+
 @pytest.mark.parametrize("N,chase", [(96, "true"), (50, "true"), (96, "false"), (2048, "true")])
 def test_fused_recurrent_rollout_equals_stepwise_rollout(N, chase):
     """orl_rnn_rollout_fused (policy + MPE world in one launch, critic sweep in a second) against the stepwise

@@ -101,3 +101,11 @@ def _check_bench_line(res, out, gpus):
     assert rec["config"]["global_envs"] == 4096 and rec["config"]["envs_per_gpu"] == 4096 // gpus
     assert rec["config"]["collective"].startswith("orl_comm")
     assert rec["value"] > 0 and rec["roofline"]["frac"] > 0
+    # the first-contact report of a multi-GPU run (round-3 VERDICT item 4a): latencies of both collectives at the optimiser
+    # step's message size, the comm's self-test outcome and the collective used, the weak-scaling rate, the link type
+    mg = rec["multi_gpu"]
+    assert mg["message_bytes"] > 30000 and mg["orl_allreduce_small_us"] > 0 and mg["torch_all_reduce_us"] > 0
+    assert mg["collective_setup"]["used"] == "p2p" and mg["collective_setup"]["selftest"].startswith("passed")
+    assert mg["comm_error_word_max_over_ranks"] == 0 and isinstance(mg["link_rank0_rank1"], str)
+    assert mg["weak_scaling"]["envs_per_gpu"] == 4096 and mg["weak_scaling"]["value"] > 0
+    assert "scaling_note" in rec

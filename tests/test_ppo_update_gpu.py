@@ -17,6 +17,15 @@ THETA_RTOL, THETA_ATOL = 2e-3, 3e-5
 INFO_RTOL, INFO_ATOL = 2e-4, 2e-5
 
 
+def _assert_thetas(g, module):
+    """First line: the bar on the UPDATE d_theta = theta_1 - theta_0 (cosine + 2 % of |d_ref| on >= 99 % of the
+    entries, tests/helpers.py) - the claim that can fail; second line: the historical check on theta_1 itself."""
+    for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
+        got = module.models[name].theta.cpu().numpy()
+        H.assert_update_parity(g[k0], got, g[k1], name)
+        np.testing.assert_allclose(got, g[k1], rtol=THETA_RTOL, atol=THETA_ATOL)
+
+
 def build_engine(g):
     from openrl_amd import spaces
     from openrl_amd.algorithms.ppo import PPOAlgorithm
@@ -62,10 +71,7 @@ def test_train_matches_reference_golden(case):
     got = np.array([info[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
                                       "critic_grad_norm", "ratio")])
     np.testing.assert_allclose(got, g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
-    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL,
-                               atol=THETA_ATOL)
-    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL,
-                               atol=THETA_ATOL)
+    _assert_thetas(g, module)
     if "vn_state1" in g:
         np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"],
                                    rtol=1e-5)
@@ -75,10 +81,7 @@ def _assert_golden_outputs(g, module, info):
     got = np.array([info[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
                                       "critic_grad_norm", "ratio")])
     np.testing.assert_allclose(got, g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
-    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL,
-                               atol=THETA_ATOL)
-    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL,
-                               atol=THETA_ATOL)
+    _assert_thetas(g, module)
     if "vn_state1" in g:
         np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"],
                                    rtol=1e-5)
@@ -97,6 +100,32 @@ def test_device_and_identity_permutation_land_on_the_reference_golden(case, perm
     algo.prep_training()
     info = algo.train(buf)
     _assert_golden_outputs(g, module, info)
+
+
+@pytest.mark.parametrize("case", ["train_discrete", "train_gaussian"])
+def test_update_parity_bar_rejects_a_short_or_partial_engine_update(case):
+    """Negative controls of the d_theta bar ON THE ENGINE: the same golden case with the last epoch skipped, and the
+    engine's own full update with one layer's block left at theta_0 (= that layer's gradient dropped), must both be
+    refused - while the historical assert_allclose on theta_1 accepts the short run on most entries."""
+    g = H.load_golden(case)
+    cfg, module, buf, algo = build_engine(g)
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    algo.train(buf)
+    _assert_thetas(g, module)
+    full_p = module.models["policy"].theta.cpu().numpy()
+    pspec, _ = H.case_specs(g)
+    for block in ("W1", "W2", "b2", "W3"):
+        H.assert_update_parity_rejects(g["theta_p0"], H.without_block_update(g["theta_p0"], full_p, pspec, block),
+                                       g["theta_p1"], "policy without d" + block)
+    cfg2, module2, buf2, algo2 = build_engine(g)
+    algo2.ppo_epoch -= 1
+    torch.manual_seed(int(g["perm_seed"]))
+    algo2.prep_training()
+    algo2.train(buf2)
+    for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
+        H.assert_update_parity_rejects(g[k0], module2.models[name].theta.cpu().numpy(), g[k1],
+                                       name + ", last epoch skipped")
 
 
 @pytest.mark.parametrize("perm_mode", ["device", "identity", "reference"])

@@ -13,8 +13,18 @@ from tests import rnn_helpers as RH
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 THETA_RTOL, THETA_ATOL = 2e-3, 4e-5
+
 INFO_RTOL, INFO_ATOL = 3e-4, 3e-5
 KEYS = ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm", "critic_grad_norm", "ratio")
+
+
+def _assert_thetas(g, module):
+    """The bar on the UPDATE d_theta = theta_1 - theta_0 first (tests/helpers.py: cosine >= 0.9999 and 2 % of |d_ref| on
+    >= 99 % of the entries), then the historical check on theta_1."""
+    for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
+        got = module.models[name].theta.cpu().numpy()
+        H.assert_update_parity(g[k0], got, g[k1], name)
+        np.testing.assert_allclose(got, g[k1], rtol=THETA_RTOL, atol=THETA_ATOL)
 
 
 def _spaces(g):
@@ -79,9 +89,43 @@ def test_recurrent_train_matches_reference_golden(case):
     for got, want in zip(algo.last_indices, r["used"]):  # torch.randperm(data_chunks) stream of replay_data.py:1078
         assert np.array_equal(got.cpu().numpy(), want)
     np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
-    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL, atol=THETA_ATOL)
-    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    _assert_thetas(g, module)
     np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["train_recurrent", "train_recurrent_chunk5"])
+def test_update_parity_bar_rejects_a_short_recurrent_update(case):
+    """Negative control of the d_theta bar on the recurrent engine: the golden case with its last epoch skipped, and the
+    full update with the GRU's input-weight block left at theta_0, must be refused."""
+    g = H.load_golden(case)
+
+    def run(skip):
+        cfg, module, buf, algo = build_engine(g)
+        algo.ppo_epoch -= skip
+        module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
+        module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
+        for f in ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks",
+                  "bad_masks", "active_masks", "action_masks", "rnn_states", "rnn_states_critic"):
+            if "buf_" + f in g and getattr(buf, f) is not None:
+                getattr(buf, f).copy_(torch.tensor(g["buf_" + f]))
+        torch.manual_seed(int(g["perm_seed"]))
+        algo.prep_training()
+        algo.train(buf)
+        return module
+
+    full = run(0)
+    _assert_thetas(g, full)
+    sd = full.models["policy"].state_dict()
+    flat = full.models["policy"].theta.cpu().numpy().copy()
+    # the GRU's W_ih block (192 x 64) inside the flat vector: found by value, reset to theta_0
+    wih = sd["rnn.rnn.weight_ih_l0"].detach().cpu().numpy().ravel()
+    pos = next(o for o in range(0, flat.size - wih.size + 1) if flat[o] == wih[0] and np.array_equal(flat[o:o + wih.size], wih))
+    broken = flat.copy()
+    broken[pos:pos + wih.size] = g["theta_p0"][pos:pos + wih.size]
+    H.assert_update_parity_rejects(g["theta_p0"], broken, g["theta_p1"], "recurrent policy without dW_ih")
+    short = run(1)
+    for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
+        H.assert_update_parity_rejects(g[k0], short.models[name].theta.cpu().numpy(), g[k1], name + ", last epoch skipped")
 
 
 @pytest.mark.parametrize("case", ["train_recurrent", "train_recurrent_chunk5"])
@@ -189,8 +233,7 @@ def test_jrpo_train_matches_reference_golden(case, perm_mode):
     assert len(algo.last_indices) == cfg.ppo_epoch * cfg.num_mini_batch and algo.last_indices[0].numel() == n_chunks
     if perm_mode == "reference":  # with two minibatches per epoch only the reference's own chunk order is comparable
         np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
-        np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL, atol=THETA_ATOL)
-        np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+        _assert_thetas(g, module)
         np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
     else:
         assert np.isfinite([info[k] for k in KEYS]).all()
@@ -280,8 +323,7 @@ def test_general_recurrent_train_matches_reference_golden(case, seed):
     for got, w in zip(algo.last_indices, want):
         assert np.array_equal(got.cpu().numpy(), w)
     np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
-    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL, atol=THETA_ATOL)
-    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    _assert_thetas(g, module)
     np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
 
 
@@ -370,6 +412,7 @@ def test_shared_recurrent_network_matches_reference_golden():
     algo.prep_training()
     info = algo.train(buf)
     np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
+    H.assert_update_parity(g["theta_m0"], model.reference_flat().cpu().numpy(), g["theta_m1"], "shared model")
     np.testing.assert_allclose(model.reference_flat().cpu().numpy(), g["theta_m1"], rtol=THETA_RTOL, atol=THETA_ATOL)
     np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
     # teacher-forced stepwise rollout on the initial weights: both state streams of the buffer
@@ -404,8 +447,7 @@ def test_full_size_recurrent_update_matches_reference_golden(perm_mode):
     algo.prep_training()
     info = algo.train(buf)
     np.testing.assert_allclose(np.array([info[k] for k in KEYS]), g["train_info"], rtol=INFO_RTOL, atol=INFO_ATOL)
-    np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), g["theta_p1"], rtol=THETA_RTOL, atol=THETA_ATOL)
-    np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), g["theta_c1"], rtol=THETA_RTOL, atol=THETA_ATOL)
+    _assert_thetas(g, module)
     np.testing.assert_allclose(module.get_critic_value_normalizer().state.cpu().numpy(), g["vn_state1"], rtol=1e-5)
 
 
