@@ -21,7 +21,7 @@ SHAPES = {
 }
 
 
-def run(name, shp, steps, warmup, dev="cuda:0"):
+def run(name, shp, steps, warmup, dev="cuda:0", tower_gemm="split"):
     import torch
 
     from openrl_amd import spaces
@@ -36,7 +36,7 @@ def run(name, shp, steps, warmup, dev="cuda:0"):
     kind, n = shp["act"]
     act = spaces.Discrete(n) if kind == "discrete" else spaces.Box(-1.0, 1.0, (n,))
     cfg = default_cfg(["--episode_length", str(T), "--ppo_epoch", "10", "--amd_perm_mode", "device",
-                       "--log_interval", "1000000"])
+                       "--log_interval", "1000000", "--amd_tower_gemm", tower_gemm])
     env = make("SyntheticFixedStep-v0", env_num=N, obs_dim=shp["obs"], action_space=act, episode_limit=200, device=dev)
     net = PPONet(env, cfg=cfg, device=dev, n_rollout_threads=N)
     cfg.num_env_steps = N * T * (steps + warmup)
@@ -51,6 +51,7 @@ def run(name, shp, steps, warmup, dev="cuda:0"):
     for i in range(warmup):
         drv.episode = i
         drv._inner_loop()
+    trainer.profile_events = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -58,9 +59,13 @@ def run(name, shp, steps, warmup, dev="cuda:0"):
         drv._inner_loop()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ev = trainer.profile_events
+    k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
     flop_fwd = 2 * (2 * shp["obs"] * 64 + 2 * 64 * 64 + 64 * (n + 1))
     out = {"bench": name, "envs": N, "rollout_len": T, "obs_dim": shp["obs"], "action_space": "%s(%d)" % (kind, n),
-           "fused_rollout": bool(drv.fused), "ms_per_iteration": round(1e3 * dt / steps, 4),
+           "fused_rollout": bool(drv.fused), "tower_gemm": tower_gemm, "tower_pair_ms": round(k_ms, 4),
+           "tower_pair_frac_of_fp32_mfma_peak": round(3 * flop_fwd * N * T / (k_ms * 1e-3) / 157.3e12, 4) if k_ms else None,
+           "ms_per_iteration": round(1e3 * dt / steps, 4),
            "env_steps_per_s": round(N * T * steps / dt, 1),
            "update_tflops_algorithmic": round(3 * flop_fwd * N * T * 10 * steps / dt / 1e12, 2)}
     print(json.dumps(out), flush=True)
@@ -71,11 +76,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--tower-gemm", default="split", choices=["split", "fp32", "split_two_image"],
+                    help="split_two_image = round 3's variants (no transposing-read full split): the A/B switch")
     a = ap.parse_args()
     for name, shp in SHAPES.items():
         if a.only and a.only not in name:
             continue
-        run(name, shp, a.steps, a.warmup)
+        run(name, shp, a.steps, a.warmup, tower_gemm=a.tower_gemm)
 
 
 if __name__ == "__main__":

@@ -270,7 +270,10 @@ typedef struct orl_ppo_hparams {
   int32_t reserved; /* flag bits: 1 = critic-only update (turn_on == False, ppo.py:226-236);
                      * 2 = A2C policy loss -adv*logp instead of the clipped surrogate (algorithms/a2c.py:88-98);
                      * 4 = orl_ppo_fwd_bwd forms every GEMM on v_mfma_f32_16x16x4_f32 instead of the bf16x3 split (a
-                     *     measurement / comparison switch: same results within fp32 rounding, ~1.4x slower) */
+                     *     measurement / comparison switch: same results within fp32 rounding, ~1.4x slower);
+                     * 8 = orl_ppo_fwd_bwd skips the transposing-read full-split build (dgrad through
+                     *     ds_read_b64_tr_b16 of W2's bf16 image, the wide-observation towers' default) and takes round 3's
+                     *     variants (two images, or wgrad-only split) - comparison switch, same arithmetic */
 } orl_ppo_hparams;
 
 /* size (floats) of the raw gradient-sum vector of one tower and of the stats vector */

@@ -33,7 +33,7 @@ AMD_FLAGS = [
     ("amd_rnn_rollout_chase", "bool", True, "opt", None),
     # GEMMs of the fused tower update: "split" = exact three-term bf16 splits on the bf16 MFMA (default; error <= the fp32
     # MFMA's), "fp32" = v_mfma_f32_16x16x4_f32 (comparison / measurement).
-    ("amd_tower_gemm", "str", "split", "opt", ["split", "fp32"]),
+    ("amd_tower_gemm", "str", "split", "opt", ["split", "fp32", "split_two_image"]),
     # general (non-default) feed-forward towers: "fused" = the cross-layer kernels of csrc/orl_gen_tower.h where they take
     # the shape (hidden_size 64 / 128), "layerwise" = one launch per layer and direction everywhere.
     ("amd_gen_update", "str", "fused", "opt", ["fused", "layerwise"]),

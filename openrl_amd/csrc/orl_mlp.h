@@ -197,6 +197,48 @@ __device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ 
 }
 #endif
 
+// acc += A^T in (both T layout) with A = the SAME bf16 images mm64_T_split reads (A = W2 -> acc += W2^T in: the dgrad)
+// through gfx950's transposing LDS read (tools/ds_read_tr_probe.hip pins its semantics: within a 16-lane group lane s
+// passes the address of an 8-byte chunk E_s and lane n receives E_{(n >> 2) + 4 jj}[n & 3], jj = 0..3).  Lane s of group
+// q points at image row o = 32 h + 16 half + 4 q + (s >> 2), the 4 consecutive elements i = 16 mo + 4 (s & 3) .. + 3 of
+// that row (wb_off stores them contiguously); lane n then holds W2[o = 32 h + 16 half + 4 q + jj][i = 16 mo + n], jj =
+// 0..3 - slots 4 half .. 4 half + 3 of its A fragment for (row block mo, K-step h), whose slot s carries reduction
+// index o = 16 (2 h + s / 4) + 4 q + s % 4 exactly as split_T lays out the B operand.  Two 8-byte reads per fragment
+// instead of one 16-byte read, and no second (transposed) image in LDS: - 27.6 KB.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 ds_read_tr16(const unsigned short* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  return __builtin_bit_cast(u32x2, v);
+}
+__device__ __forceinline__ void mm64_T_split_tr(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][3],
+                                                f32x4 (&acc)[4], int j, int q) {
+  const unsigned short* base = Wb + (4 * q + (j >> 2)) * WBS + (j & 3) * 8;
+  auto frag = [&](int p, int h, int mo) -> u32x4 {
+    const unsigned short* a = base + (p * HID + 32 * h) * WBS + (mo >> 1) * 32 + (mo & 1) * 4;
+    const u32x2 lo = ds_read_tr16(a), hi = ds_read_tr16(a + 16 * WBS);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
+  u32x4 w[2][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) w[0][p] = frag(p, 0, 0);
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int h = st >> 2, mo = st & 3;
+    if (st < 7) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) w[(st + 1) & 1][p] = frag(p, (st + 1) >> 2, (st + 1) & 3);
+    }
+    const u32x4 wh = w[st & 1][0], wm = w[st & 1][1], wl = w[st & 1][2];
+    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
+    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
+  }
+}
+
 // LDS image of one tower (offsets in floats, all multiples of 4 => 16-byte aligned).
 struct TowerLds {
   int DP, n_out, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, logstd, W2T, W3P, total;

@@ -7,9 +7,18 @@
 #include "orl_mlp.h"
 #include "orl_ppo_tower.h"
 
-// build-time A/B switch (ORL_BUILD_DEFS="-DORL_TOWER_FIRST_VARIANT=1" = never the split build); never read at run time
+// build-time A/B switch (ORL_BUILD_DEFS="-DORL_TOWER_FIRST_VARIANT=1" = never a full-split build); never read at run time
 #ifndef ORL_TOWER_FIRST_VARIANT
-#define ORL_TOWER_FIRST_VARIANT 0
+#define ORL_TOWER_FIRST_VARIANT -1
+#endif
+#ifndef ORL_TOWER_TR       // wide-observation pair builds (ND >= 1): try the transposing-read full split first
+#define ORL_TOWER_TR 1
+#endif
+#ifndef ORL_ND_REM         // build-time experiment: remainder columns (D - 16 ND, up to this many) of dW1 on the VALU; 0 = a
+#define ORL_ND_REM 4       // whole extra 16-column MFMA block instead (D = 17..20 take the ND = 2 build)
+#endif
+#ifndef ORL_TOWER_TR_ND0   // build-time experiment: the same for the small-observation build (it fits both images anyway)
+#define ORL_TOWER_TR_ND0 0
 #endif
 #ifndef ORL_TOWER_WGRAD_SPLIT  // build-time experiment: 0 = the fallback variants keep the fp32 wgrad
 #define ORL_TOWER_WGRAD_SPLIT 1
@@ -54,9 +63,11 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
 #endif
     // the transposed W2 copy (17 KB, +2 % on the dgrad GEMM) is the first thing to go when it would cost a pair of waves
     for (int w2t = 1; w2t >= (ND == 0 ? 1 : 0); --w2t) {
-      const size_t lds = tower_lds_floats(A.net, A.R, NOP, waves, HEAD == ORL_HEAD_GAUSSIAN, w2t != 0) * sizeof(float);
-      if (lds > 160 * 1024) continue;
       PpoArgs B = A;
+      const int ring_nch = ring_chunks(B, ND > 0);
+      const size_t lds = tower_lds_floats(A.net, A.R, NOP, waves, HEAD == ORL_HEAD_GAUSSIAN, w2t != 0, false, ring_nch) *
+                         sizeof(float);
+      if (lds > 160 * 1024) continue;
       B.use_w2t = w2t;
       const int grid = launch_tower_w<HEAD, NO, ND>(B, waves, lds, s);
       const int rc = launch_status("orl_ppo_fwd_bwd");
@@ -77,15 +88,22 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
   // needs both bf16 images of W2 in LDS), then fp32 GEMMs + split wgrad with and without the W2^T copy (same LDS policy
   // as launch_tower: W2^T goes before a pair of waves)
   // hp.reserved & 4: the caller asks for the fp32-MFMA GEMMs (measurement / comparison switch, bench.py --tower-gemm fp32)
+  // variant -1 (the wide-observation builds' first choice, ORL_TOWER_TR; the small-observation build takes it only with
+  // -DORL_TOWER_TR_ND0): the full split with the dgrad through transposing reads of W2's image - no W2^T image
   for (int var = (P.hp.reserved & 4) ? 1 : ORL_TOWER_FIRST_VARIANT; var < 3; ++var) {
-    const bool sp = var == 0;
-    const int w2t = var <= 1;
+    const bool spt = var == -1;
+    const bool sp = var <= 0;
+    const int w2t = var == 0 || var == 1;
     if (var == 2 && ND == 0) break;
-    const size_t lp = tower_lds_floats(P.net, P.R, NOPP, 8, HEADP == ORL_HEAD_GAUSSIAN, w2t != 0, sp) * sizeof(float);
-    const size_t lc = tower_lds_floats(Cc.net, Cc.R, 4, 8, false, w2t != 0, sp) * sizeof(float);
+    if (spt && !(ND > 0 ? ORL_TOWER_TR : ORL_TOWER_TR_ND0)) continue;
+    if (spt && (P.hp.reserved & 8)) continue;  // amd_tower_gemm=split_two_image: round 3's variants (comparison switch)
+    PpoArgs P2 = P, C2 = Cc;
+    const int nch_p = ring_chunks(P2, ND > 0), nch_c = ring_chunks(C2, ND > 0);
+    const size_t lp = tower_lds_floats(P.net, P.R, NOPP, ORL_PAIR_WAVES, HEADP == ORL_HEAD_GAUSSIAN, w2t != 0, sp, nch_p) *
+                      sizeof(float);
+    const size_t lc = tower_lds_floats(Cc.net, Cc.R, 4, ORL_PAIR_WAVES, false, w2t != 0, sp, nch_c) * sizeof(float);
     const size_t lds = lp > lc ? lp : lc;
     if (lds > 160 * 1024) continue;
-    PpoArgs P2 = P, C2 = Cc;
     P2.use_w2t = w2t; C2.use_w2t = w2t;
     const int n_tiles = (P.mb + TILE_B - 1) / TILE_B;
     // One workgroup fits a CU (LDS).  Two ways to run 2 x g workgroups on 256 CUs:
@@ -119,7 +137,11 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
       gp = best_g;
       gc = PPO_MAX_BLOCKS - best_g;
     }
-    if (sp) {
+    if (spt) {
+      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, 3>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 3>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+    } else if (sp) {
       (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, 2>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 2>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
@@ -152,7 +174,7 @@ static int try_launch_pair(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int
 #endif
   auto nd_of = [](const PpoArgs& A) {  // = launch_tower_nd's choice
     const int D = A.net.obs_dim;
-    return (D <= 4 && (A.o_x & 3) == 0) ? 0 : D <= 20 ? 1 : D <= 36 ? 2 : 4;
+    return (D <= 4 && (A.o_x & 3) == 0) ? 0 : D <= 16 + ORL_ND_REM ? 1 : D <= 32 + ORL_ND_REM ? 2 : 4;
   };
   const int nd = nd_of(P);
   if (nd != nd_of(Cc)) return 0;
@@ -167,8 +189,8 @@ static int launch_tower_nd(const PpoArgs& A, hipStream_t s) {
   const int D = A.net.obs_dim;
   if (D <= 4 && (A.o_x & 3) == 0) return launch_tower<HEAD, NO, 0>(A, s);
   // ND = 16-column MFMA blocks of the dW1 accumulator; up to 4 remainder columns go to the VALU (17..20, 33..36)
-  if (D <= 20) return launch_tower<HEAD, NO, 1>(A, s);
-  if (D <= 36) return launch_tower<HEAD, NO, 2>(A, s);
+  if (D <= 16 + ORL_ND_REM) return launch_tower<HEAD, NO, 1>(A, s);
+  if (D <= 32 + ORL_ND_REM) return launch_tower<HEAD, NO, 2>(A, s);
   return launch_tower<HEAD, NO, 4>(A, s);
 }
 

@@ -43,6 +43,10 @@ __device__ unsigned long long g_orl_prof[16];
       t_last = t_now;                                                             \
     }                                                                             \
   } while (0)
+#elif defined(ORL_MARK)
+// ISA phase markers (tools/tower_valu_budget.py: hipcc -S -DORL_MARK): an asm comment per phase boundary; the statement is
+// volatile, so the markers keep their order and the instruction mix between two of them is the phase's
+#define ORL_T(k) asm volatile("; ORL_PHASE " #k ::: "memory")
 #else
 #define ORL_T(k) ((void)0)
 #endif
@@ -66,7 +70,26 @@ struct PpoArgs {
   int K;               // action-mask width (0 = none)
   int mb;              // rows in this minibatch
   int use_w2t;         // keep a transposed LDS copy of W2 for the dgrad GEMM (dropped when it costs a pair of waves)
+  // record ring of the wide-observation builds (ND >= 1): only the 16-byte chunks this tower reads travel to LDS - its
+  // observation columns (chunks [c0_beg, c0_beg + c0_n)) and the tail fields from its first one on ([c1_beg, R / 4)) -
+  // stored back to back (ring_chunks()); the ND == 0 build keeps whole records (4 chunks)
+  int c0_beg, c0_n, c1_beg;
 };
+
+// which chunks of a record a tower needs: fills A.c0_beg / c0_n / c1_beg, returns the number of chunks per row in the ring
+__host__ __device__ inline int ring_chunks(PpoArgs& A, bool compact) {
+  const int nch = A.R >> 2;
+  if (!compact) { A.c0_beg = 0; A.c0_n = nch; A.c1_beg = nch; return nch; }
+  const int DP = (A.net.obs_dim + 3) & ~3;
+  const int first_tail = A.net.head_kind == ORL_HEAD_VALUE ? A.o_vp : A.o_act;
+  A.c0_beg = A.o_x >> 2;
+  int c0_end = ((A.o_x + DP - 1) >> 2) + 1;   // fc1 reads DP columns from o_x (W1's image is zero beyond D)
+  if (c0_end > nch) c0_end = nch;
+  A.c0_n = c0_end - A.c0_beg;
+  A.c1_beg = first_tail >> 2;
+  if (A.c1_beg < c0_end) A.c1_beg = c0_end;   // ranges touch / overlap: one contiguous run
+  return A.c0_n + (nch - A.c1_beg);
+}
 
 __device__ inline float huber_or_mse(float e, float d, int use_huber, float& de) {
   if (use_huber) {
@@ -133,6 +156,8 @@ __device__ inline void mm64_T_wt(const float* __restrict__ Ws, const f32x4 (&in)
 //   2 = the three 64-wide GEMMs of a tile (fc2, dgrad, wgrad); needs the bf16 images of W2 and W2^T in LDS (+ 20 KB);
 //   1 = the wgrad only - its operands come from the slabs, no LDS image is involved - for towers whose records leave no
 //       room for the bf16 images (wide observations / heads);
+//   3 = as 2, but the dgrad reads W2's image through the transposing LDS read (mm64_T_split_tr) instead of a second,
+//       transposed image: 27.6 KB less LDS - what lets the wide-observation towers (cfg3 / cfg5) take the full split;
 //   0 = none.  fc1, the wide-head GEMMs and the MFMA dW1 path stay on the fp32 MFMA (a few instructions per tile).
 template <int HEAD, int NO, int ND, int SP_ = 0>
 __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, const int nblk) {
@@ -144,17 +169,20 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // wide heads (NO > 4: Discrete(5..16), Box(5..16)) run their three head GEMMs - logits, dn2 = W3^T dhead,
   // S3 += dhead^T xhat2 - on MFMA; with NO x 64 scalar FMAs per lane they were 2/3 of the tile and spilled 360 VGPRs
   constexpr bool HMM = NO > 4;
-  constexpr bool SP = SP_ == 2;   // the GEMMs with LDS images
+  constexpr bool SP = SP_ >= 2;   // the GEMMs with LDS images
+  constexpr bool SPT = SP_ == 3;  // ... the dgrad through transposing reads of W2's image (no W2^T image)
   constexpr bool SPW = SP_ >= 1;  // the wgrad
-  const bool w2t = ND == 0 || SP || A.use_w2t;  // compile-time true on the small-observation path and in split builds
+  // compile-time true on the small-observation path and in the two-image split builds, false with transposing reads
+  const bool w2t = SPT ? false : (ND == 0 || SP || A.use_w2t);
   const TowerLds tw(ND == 0 ? 4 : A.net.obs_dim, NO <= 4 ? 4 : A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, w2t, HMM, SP);
   const int DP = tw.DP;
   const int D = A.net.obs_dim;
   const int n_out = A.net.n_out;
   constexpr int NOP = HMM ? 16 : ((NO + 3) & ~3);  // width of the dhead tile in LDS
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
-  const int nch = A.R >> 2;
-  // floats per record-ring slot (chunk c of row r at c*64 + r*4); the small-observation path keeps the form that is
+  // chunks per record row in the ring: whole records on the small-observation path, this tower's chunks otherwise
+  const int nch = ND == 0 ? (A.R >> 2) : A.c0_n + ((A.R >> 2) - A.c1_beg);
+  // floats per record-ring slot (ring chunk c of row r at c*64 + r*4); the small-observation path keeps the form that is
   // visibly a multiple of 256 (measured: 1.2 % faster tower at config 2), wider records are sized exactly
   const int rts = ND == 0 ? ((nch + 3) >> 2) * 256 : nch * 64;
   const int per_wave = 2 * SLAB + 2 * rts + TILE_B * NOP;
@@ -230,7 +258,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     const float* src = A.records + (size_t)row * A.R;
 #pragma unroll 1
     for (int g = 0; 4 * g < nch; ++g) {
-      const int c = 4 * g + q;
+      const int c = 4 * g + q;  // ring chunk; record chunk = c (ND == 0) or through the tower's two ranges
+      const int rc = ND == 0 ? c : (c < A.c0_n ? A.c0_beg + c : A.c1_beg + (c - A.c0_n));
       const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
           (unsigned)(size_t)(__attribute__((address_space(3))) float*)(slot + g * 256));
       if (c < nch) {
@@ -238,7 +267,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(src + 4 * c), "s"(lds_dst)
+                     : "v"(src + 4 * rc), "s"(lds_dst)
                      : "memory");
       }
     }
@@ -272,8 +301,13 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     row_next = row_of(tile + 2 * n_waves);
     issue_dma(RR + (ring ^ 1) * rts, row_cur);        // next tile's records, hidden behind this tile
     ring ^= 1;
-#define REC(col) RT[(((col) >> 2) << 6) + (j << 2) + ((col) & 3)]
-#define REC_R(r, col) RT[(((col) >> 2) << 6) + ((r) << 2) + ((col) & 3)]
+    // column -> ring position: observation columns live in range 0 (ring chunk = record chunk - c0_beg), every other field
+    // in range 1 (ring chunk = record chunk - c1_beg + c0_n); both biases fold into the base pointer.  ND == 0: identity.
+    const float* RTX = ND == 0 ? RT : RT - 64 * A.c0_beg;
+    const float* RTT = ND == 0 ? RT : RT + 64 * (A.c0_n - A.c1_beg);
+#define REC(col) RTT[(((col) >> 2) << 6) + (j << 2) + ((col) & 3)]
+#define RECX(col) RTX[(((col) >> 2) << 6) + (j << 2) + ((col) & 3)]
+#define REC_R(r, col) RTX[(((col) >> 2) << 6) + ((r) << 2) + ((col) & 3)]
 
     ORL_T(0);  // record DMA wait + next issue
     // ---------------- forward ----------------
@@ -290,7 +324,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       f32x4 z[4];
       load_vec_T(lw + tw.b1, q, z);
       // columns >= D of a record are other (finite) fields; W1's LDS image is zero-padded there
-      fc1_T(lw + tw.W1, DP, [&](int s) -> float { return REC(A.o_x + 4 * s + q); }, z, j, q);
+      fc1_T(lw + tw.W1, DP, [&](int s) -> float { return RECX(A.o_x + 4 * s + q); }, z, j, q);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -724,7 +758,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     if constexpr (SP) {
       u32x4 xs[2][3];
       split_T(d2, xs);
-      mm64_T_split((const unsigned short*)(lw + tw.W2T), xs, d1, j, q);
+      if constexpr (SPT) mm64_T_split_tr((const unsigned short*)(lw + tw.W2), xs, d1, j, q);
+      else mm64_T_split((const unsigned short*)(lw + tw.W2T), xs, d1, j, q);
     } else {
       if (w2t) mm64_T(lw + tw.W2T, d2, d1, j, q);
       else mm64_T_wt(lw + tw.W2, d2, d1, j, q);
@@ -798,6 +833,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     atomicAdd(&g_orl_prof[13], (unsigned long long)((n_tiles - wave_g + n_waves - 1) / n_waves));
 #endif
 #undef REC
+#undef RECX
 #undef REC_R
 
   // ---- workgroup reduction of the waves' accumulators, fixed order (deterministic) ---------------------
@@ -917,11 +953,13 @@ __global__ __launch_bounds__(512, 2) void ppo_tower_pair_kernel(PpoArgs P, PpoAr
 }
 
 // LDS bytes needed by `waves` waves of this tower
+// ring_nch: chunks per record row in the ring (ring_chunks(); R / 4 when whole records are staged)
 inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int waves, bool gaussian, bool w2t = true,
-                               bool split = false) {
+                               bool split = false, int ring_nch = -1) {
   const TowerLds tw(net.obs_dim, net.n_out, gaussian, w2t, nop == 16, split);
   const RawLayout rl(net);
-  const int rts = net.obs_dim <= 4 ? (((R >> 2) + 3) >> 2) * 256 : (R >> 2) * 64;  // >= what the kernel uses
+  if (ring_nch < 0) ring_nch = R >> 2;
+  const int rts = net.obs_dim <= 4 ? (((R >> 2) + 3) >> 2) * 256 : ring_nch * 64;  // >= what the kernel uses
   const size_t per_wave = 2 * SLAB + 2 * rts + TILE_B * nop;
   size_t fl = (size_t)tw.total + (size_t)waves * per_wave;
   const size_t need_acc = (size_t)tw.total + rl.total + ORL_N_STATS;

@@ -338,4 +338,4 @@ def make_hparams(cfg) -> PPOHParams:
                       use_policy_active_masks=int(bool(cfg.use_policy_active_masks)),
                       use_valuenorm=int(bool(cfg.use_valuenorm or cfg.use_popart)),
                       dual_clip_ppo=int(bool(cfg.dual_clip_ppo)), use_max_grad_norm=int(bool(cfg.use_max_grad_norm)),
-                      reserved=4 if str(getattr(cfg, "amd_tower_gemm", "split")) == "fp32" else 0)
+                      reserved={"fp32": 4, "split_two_image": 8}.get(str(getattr(cfg, "amd_tower_gemm", "split")), 0))

@@ -118,8 +118,13 @@ def main():
     module, buf, algo = build(cfg, Nl, D, n_act, world, dev)
     buf.compute_returns(fill(buf, host, lo, hi, nv), module.get_critic_value_normalizer())
     assert algo.generic == generic
-    assert (algo._comm is not None) == (collective == "p2p" and not fallback), \
+    # general towers wider than PPOAlgorithm.P2P_MAX_FLOATS send their flat gradient vector through torch.distributed:
+    # the one-shot push is a latency-regime collective (round-3 ADVICE: every rank pushes the whole vector to every peer)
+    small = (not generic) or algo._gen_flat.numel() <= algo.P2P_MAX_FLOATS
+    assert (algo._comm is not None) == (collective == "p2p" and not fallback and small), \
         "the fused orl_comm path must be the one that runs (and must be off on every rank after a failed self-test)"
+    if generic and not small:
+        print("GEN_FLAT_OVER_P2P_THRESHOLD n=%d -> torch.distributed" % algo._gen_flat.numel(), flush=True)
     if fallback:
         du._FAULT_INJECT = None
     info = algo.train(buf)
