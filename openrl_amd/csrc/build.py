@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["orl_buffer.hip", "orl_act.hip", "orl_ppo.hip", "orl_apply.hip", "orl_rnn.hip", "orl_rnn_rollout.hip", "orl_mpe.hip", "orl_ttt.hip", "orl_comm.hip", "orl_gen.hip", "orl_gen_fused.hip", "orl_gen_rollout.hip", "orl_gen_tower.hip"]
-HEADERS = ["orl_common.h", "orl_mlp.h", "orl_ppo_tower.h", "orl_heads.h", "orl_loss.h", "orl_rnn.h", "orl_mpe.h", "orl_perm.h", "orl_ttt.h", "orl_comm.h", "orl_gen_act.h", "orl_gen_sample.h", "orl_gen_mlp.h", "orl_env.h", "orl_gen_tower.h", "orl_gen_loss.h", os.path.join("..", "..", "include", "orl_hip.h")]
+HEADERS = ["orl_common.h", "orl_mlp.h", "orl_ppo_tower.h", "orl_heads.h", "orl_loss.h", "orl_rnn.h", "orl_mpe.h", "orl_perm.h", "orl_ttt.h", "orl_comm.h", "orl_gen_act.h", "orl_gen_sample.h", "orl_gen_mlp.h", "orl_env.h", "orl_gen_tower.h", "orl_gen_loss.h", "orl_rnn_stream.h", os.path.join("..", "..", "include", "orl_hip.h")]
 # orl_mpe.hip shares orl_mpe.h with the fused recurrent rollout: same flags, so both step a world with the same code
 FAST_MATH = {"orl_ppo.hip", "orl_rnn.hip", "orl_rnn_rollout.hip", "orl_mpe.hip", "orl_act.hip", "orl_gen_rollout.hip"}  # NOT orl_gen.hip: torch-like IEEE arithmetic there
 LIB = os.path.join(HERE, "liborl_hip.so")

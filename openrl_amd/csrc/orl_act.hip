@@ -208,41 +208,94 @@ struct RollProf {
 struct RollProf {};
 #define RO_T(rp, k) do {} while (0)
 #endif
-template <class XB>
-__device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const TowerLds& tw, XB xb, float* __restrict__ gA,
-                                      float* __restrict__ gB, int gw, int j, int q, f32x4 (&n2)[4], RollProf& rp) {
-  f32x4 acc = *(const f32x4*)(lds + tw.b1 + 16 * gw + 4 * q);
-  for (int s = 0; s < (tw.DP >> 2); ++s) {
-    const float a = lds[tw.W1 + (16 * gw + j) * tw.DP + 4 * s + q];
-    acc = ORL_MFMA(a, xb(s), acc);
+// Round 4: three cuts of the per-step chain:
+//  * the towers' LDS images are staged with the LayerNorm affines FOLDED into the next Linear (stage_tower(fold), exact
+//    algebra, the update kernel's form): both affine passes of a step (8 LDS reads + 16 FMAs each, in the dependent
+//    chain) are gone - the GEMMs run on xhat;
+//  * every operand that does not change over the T steps - this wave's 16 rows of W2 (4 fragments), its bias slices, and
+//    on the small-observation path W1 - is read from LDS ONCE into registers (CoopRegs); hipcc cannot hoist those reads
+//    itself (LDS stores inside the loop may alias);
+//  * small observations (DP <= 8: 1 - 2 k-steps): every wave computes ALL four M-tiles of fc1 itself (4 - 8 independent
+//    MFMAs instead of 1 - 2) and skips the first all-gather - one workgroup barrier and one LDS round trip per step less.
+//    Same k order per output element: bit-identical to the gathered form.
+// trunk_barriers(DP) = workgroup barriers one call executes (callers that only keep the barrier count need it).
+constexpr int COOP_SMALL_DP = 8;
+__host__ __device__ inline int trunk_barriers(int DP) { return DP <= COOP_SMALL_DP ? 1 : 2; }
+
+struct CoopRegs {
+  f32x4 w2[4];     // W2 (folded) rows 16 gw + j, columns 16 mi + 4 q .. + 3
+  f32x4 b2;        // folded bias slice 16 gw + 4 q ..
+  f32x4 b1;        // gathered path: bias slice of this wave's M-tile
+  f32x4 b1a[4];    // small-observation path: all four M-tiles' bias slices
+  float w1[4][2];  // small-observation path: W1[16 m + j][4 s + q], s < DP / 4 <= 2
+};
+__device__ inline void coop_load(const float* __restrict__ lds, const TowerLds& tw, int gw, int j, int q, CoopRegs& R) {
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) R.w2[mi] = *(const f32x4*)(lds + tw.W2 + (16 * gw + j) * W2S + 16 * mi + 4 * q);
+  R.b2 = *(const f32x4*)(lds + tw.b2 + 16 * gw + 4 * q);
+  R.b1 = *(const f32x4*)(lds + tw.b1 + 16 * gw + 4 * q);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    R.b1a[m] = *(const f32x4*)(lds + tw.b1 + 16 * m + 4 * q);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      R.w1[m][s] = (tw.DP <= COOP_SMALL_DP && 4 * s < tw.DP) ? lds[tw.W1 + (16 * m + j) * tw.DP + 4 * s + q] : 0.f;
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
-  *(f32x4*)(gA + j * GS + 16 * gw + 4 * q) = acc;
-  RO_T(rp, 0);
-  __syncthreads();
-  RO_T(rp, 1);
-  f32x4 x[4], n1[4];
+}
+
+// returns xhat2 (post-LN2, pre-affine: the head images carry diag(g2) and the folded bias)
+template <class XB>
+__device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const TowerLds& tw, const CoopRegs& R, XB xb,
+                                      float* __restrict__ gA, float* __restrict__ gB, int gw, int j, int q,
+                                      f32x4 (&n2)[4], RollProf& rp) {
+  f32x4 x[4];
   float rstd;
+  if (tw.DP <= COOP_SMALL_DP) {
 #pragma unroll
-  for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(gA + j * GS + 16 * m + 4 * q);
-  ln_normalize_T(x, rstd);
-  ln_affine_T(x, lds + tw.g1, lds + tw.be1, q, n1);
-  acc = *(const f32x4*)(lds + tw.b2 + 16 * gw + 4 * q);
+    for (int m = 0; m < 4; ++m) x[m] = R.b1a[m];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (4 * s < tw.DP) {
+        const float b = xb(s);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) x[m] = ORL_MFMA(R.w1[m][s], b, x[m]);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[m][r] = fmaxf(x[m][r], 0.f);
+    RO_T(rp, 0);
+    RO_T(rp, 1);
+  } else {
+    f32x4 acc = R.b1;
+    for (int s = 0; s < (tw.DP >> 2); ++s) {
+      const float a = lds[tw.W1 + (16 * gw + j) * tw.DP + 4 * s + q];
+      acc = ORL_MFMA(a, xb(s), acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+    *(f32x4*)(gA + j * GS + 16 * gw + 4 * q) = acc;
+    RO_T(rp, 0);
+    __syncthreads();
+    RO_T(rp, 1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(gA + j * GS + 16 * m + 4 * q);
+  }
+  ln_normalize_T(x, rstd);  // xhat1: the GEMM runs on it (W2 diag(g1) image, folded bias)
+  f32x4 acc = R.b2;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
-    const f32x4 a4 = *(const f32x4*)(lds + tw.W2 + (16 * gw + j) * W2S + 16 * mi + 4 * q);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = ORL_MFMA(a4[r], n1[mi][r], acc);
+    for (int r = 0; r < 4; ++r) acc = ORL_MFMA(R.w2[mi][r], x[mi][r], acc);
   }
   *(f32x4*)(gB + j * GS + 16 * gw + 4 * q) = acc;
   RO_T(rp, 2);
   __syncthreads();
   RO_T(rp, 3);
 #pragma unroll
-  for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(gB + j * GS + 16 * m + 4 * q);
-  ln_normalize_T(x, rstd);
-  ln_affine_T(x, lds + tw.g2, lds + tw.be2, q, n2);
+  for (int m = 0; m < 4; ++m) n2[m] = *(const f32x4*)(gB + j * GS + 16 * m + 4 * q);
+  ln_normalize_T(n2, rstd);
   RO_T(rp, 4);
 }
 
@@ -265,8 +318,9 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   constexpr bool HMM = NO > 4;  // wide heads on MFMA (head_mfma_T)
   const TowerLds twp(D, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false, HMM);
   const TowerLds twc(D, 1, false, false);
-  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
-  if (WC) stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x);
+  // LayerNorm affines folded into W2 / W3 / the biases (see trunk_fwd_coop)
+  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM, false, true);
+  if (WC) stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x, false, false, true);
   const int DP = twp.DP;
   float* s_obs = smem + twp.total + (WC ? twc.total : 0);  // [2][16][DP]
   float* s_gather = s_obs + 2 * TILE_B * DP;    // [2 towers][2 slabs][16][GS]
@@ -315,13 +369,13 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   if constexpr (PERK) {
     for (int k = 0; k < n_img; ++k)
       stage_tower(s_opp + k * twp.total, A.r.opp_thetas + (size_t)k * A.r.opp_theta_stride, tlp, twp, false, threadIdx.x,
-                  blockDim.x, HMM);
+                  blockDim.x, HMM, false, true);
     my_opp = ok ? A.r.opp_index[n] : 0;
   } else if constexpr (IS_POOL) {
     const int first = blockIdx.x * TILE_B;  // opp_index: uniform over the tile (orl_opponent_sample per_tile)
     const int og = A.r.opp_index != nullptr ? A.r.opp_index[first < N ? first : N - 1] : first / A.r.opp_group_rows;
     const float* oth = A.r.opp_thetas + (size_t)og * A.r.opp_theta_stride;
-    stage_tower(s_opp, oth, tlp, twp, false, threadIdx.x, blockDim.x, HMM);
+    stage_tower(s_opp, oth, tlp, twp, false, threadIdx.x, blockDim.x, HMM, false, true);
   }
   if (IS_TTT && wave == 0 && q == 0) {
     for (int c = 0; c < 16; ++c) s_mask[j * 16 + c] = (ok && c < 9) ? b.action_masks[(size_t)n * 9 + c] : (c == 0 ? 1.f : 0.f);
@@ -352,6 +406,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   };
   if (wave == NOISE_WAVE) draw_noise(A.r.rng_step0, s_noise);
   __syncthreads();
+  CoopRegs creg;  // this wave's loop-invariant trunk operands, out of LDS once
+  coop_load(tlds, tww, gw, j, q, creg);
   RollProf rp;
 #ifdef ORL_PROF
   __shared__ unsigned long long prof_lds[16];
@@ -367,7 +423,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
     const uint64_t tg = A.r.rng_step0 + (uint64_t)t;
     f32x4 n2[4];
-    trunk_fwd_coop(tlds, tww, xb, gA, gB, gw, j, q, n2, rp);
+    trunk_fwd_coop(tlds, tww, creg, xb, gA, gB, gw, j, q, n2, rp);
     float act_o[NO];
     if constexpr (HMM && HEAD == ORL_HEAD_GAUSSIAN) {
       // Wide Gaussian heads: the MFMA leaves means 4q..4q+3 of row j in lane (j, q) - each lane samples exactly those
@@ -494,10 +550,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
         f32x4 o2[4];
         if (grp == 0) {
           auto xo = [&](int s) -> float { return s_oobs[j * DP + 4 * s + q]; };
-          trunk_fwd_coop(img, twp, xo, gA, gB, gw, j, q, o2, rp);
+          CoopRegs oreg;  // the opponent's image (a pool slot): read per walk
+          coop_load(img, twp, gw, j, q, oreg);
+          trunk_fwd_coop(img, twp, oreg, xo, gA, gB, gw, j, q, o2, rp);
         } else {
-          __syncthreads();
-          __syncthreads();
+          for (int nb = 0; nb < trunk_barriers(twp.DP); ++nb) __syncthreads();
         }
         if (wave == 0) {  // sampled on the MFMA fragment like the learner's action
           const int no4 = (n_out + 3) & ~3;
@@ -751,7 +808,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     const float* cur = s_obs + (T & 1) * TILE_B * DP;
     auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
     f32x4 n2[4];
-    trunk_fwd_coop(tlds, tww, xb, gA, gB, gw, j, q, n2, rp);
+    trunk_fwd_coop(tlds, tww, creg, xb, gA, gB, gw, j, q, n2, rp);
     if (wave == 4) {
       const float* lc = smem + twp.total;
       float v[1];

@@ -211,6 +211,17 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) GS[a][b][r] = 0.f;
   float a_db2s[2] = {0.f, 0.f};
+  // split builds with one observation block (ND == 1: obs <= 20 columns): dW1 = dz1^T x on the 32x32x16 bf16 MFMA like the
+  // wgrad - 2 row blocks x ONE 32-column block (columns >= obs_dim are dead), operands split in registers, db1 from the
+  // operand reads.  Replaces 16 VALU-blocking fp32 MFMAs + the <= 4-column VALU remainder + a 16-read column sum: the
+  // phase profile had this phase at 3 200 of a tile's 21 200 cycles at obs 18 (534 of 15 900 on the small-observation path).
+  constexpr bool W1S = SPW && ND == 1;
+  f32x16 G1S[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G1S[a][r] = 0.f;
+  float a_db1s[2] = {0.f, 0.f};
   constexpr int NDA = ND > 0 ? ND : 1;
   f32x4 G1[4][NDA];
 #pragma unroll
@@ -324,7 +335,30 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       f32x4 z[4];
       load_vec_T(lw + tw.b1, q, z);
       // columns >= D of a record are other (finite) fields; W1's LDS image is zero-padded there
-      fc1_T(lw + tw.W1, DP, [&](int s) -> float { return RECX(A.o_x + 4 * s + q); }, z, j, q);
+      if constexpr (ND == 0 || ND > 2) {  // (ND = 4: 17 k-steps of operands would not fit the registers - rolled loop)
+        fc1_T(lw + tw.W1, DP, [&](int s) -> float { return RECX(A.o_x + 4 * s + q); }, z, j, q);
+      } else {
+        // wide observations: every operand of the <= 4 ND + 1 k-steps is requested BEFORE the first MFMA (the rolled loop
+        // of fc1_T opened each k-step with an exposed LDS round trip: this phase was 3 560 of a tile's 20 900 cycles at obs
+        // 18, against 1 500 on the small-observation path)
+        constexpr int MAXS = 4 * ND + 1;
+        const int nks = DP >> 2;
+        float bq[MAXS], aq[MAXS][4];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+          const bool on = s < nks;
+          bq[s] = on ? RECX(A.o_x + 4 * s + q) : 0.f;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) aq[s][m] = on ? lw[tw.W1 + (16 * m + j) * DP + 4 * s + q] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+          if (s < nks) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) z[m] = ORL_MFMA(aq[s][m], bq[s], z[m]);
+          }
+        }
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -780,7 +814,34 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     wave_lds_fence();
     ORL_T(9);  // LN1 backward, relu backward, dz1 slab store
     // dW1 += dz1^T x, db1
-    {
+    if constexpr (W1S) {
+      const int c = l & 31, kb = l >> 5;
+      // this lane's observation column, clamped into the tower's staged columns (results of columns >= D are dropped)
+      const int colx = A.o_x + (c < DP ? c : DP - 1);
+      const float* xcol = RTX + ((colx >> 2) << 6) + (colx & 3);
+      float xv8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) xv8[k] = xcol[(8 * kb + k) << 2];
+      u32x4 fx[3];
+      split8(xv8, fx[0], fx[1], fx[2]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float xa[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xa[k] = SS[(8 * kb + k) * TS + 32 * b + c];
+        a_db1s[b] += ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
+        u32x4 fa[3];
+        split8(xa, fa[0], fa[1], fa[2]);
+        f32x16 g = G1S[b];
+        g = mfma_bf16_32(fa[2], fx[0], g);
+        g = mfma_bf16_32(fa[0], fx[2], g);
+        g = mfma_bf16_32(fa[1], fx[1], g);
+        g = mfma_bf16_32(fa[1], fx[0], g);
+        g = mfma_bf16_32(fa[0], fx[1], g);
+        g = mfma_bf16_32(fa[0], fx[0], g);
+        G1S[b] = g;
+      }
+    } else {
       const int f = l;
       float s_db = 0.f;
       if (ND == 0) {
@@ -885,7 +946,15 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
             for (int r = 0; r < 4; ++r) put(rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j, G[mo][mi][r]);
         put(rl.odb2 + f, a_db2);
       }
-      put(rl.odb1 + f, a_db1);
+      if constexpr (W1S) {
+        const float e0 = a_db1s[0] + __shfl_xor(a_db1s[0], 32), e1 = a_db1s[1] + __shfl_xor(a_db1s[1], 32);
+        if (l < 32) {
+          put(rl.odb1 + l, e0);
+          put(rl.odb1 + 32 + l, e1);
+        }
+      } else {
+        put(rl.odb1 + f, a_db1);
+      }
       if constexpr (HMM) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -899,7 +968,16 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       }
       if (f < n_out) put(rl.odb3 + f, a_db3);
       if (HEAD == ORL_HEAD_GAUSSIAN && f < n_out) put(rl.odlogstd + f, a_dls);
-      if (ND == 0) {
+      if constexpr (W1S) {
+        // 32x32 C fragment: lane (c = l & 31, kb = l >> 5), reg r -> dW1[f = 32bo + (r&3) + 8(r>>2) + 4kb][column c]
+        if ((l & 31) < D) {
+#pragma unroll
+          for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              put(rl.odW1 + (32 * bo + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * D + (l & 31), G1S[bo][r]);
+        }
+      } else if (ND == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (k < D) put(rl.odW1 + f * D + k, w1v[k]);

@@ -77,7 +77,9 @@ struct RnnLds {
   int DP, W1, b1, g1, be1, W2, b2, g2, be2, Wih, Whh, bih, bhh, g3, be3, W3, b3, logstd, W3P, total;
   __host__ __device__ RnnLds() {}
   // with_w3p: W3 zero padded to [16][W2S] - the MFMA operand of the wide categorical head in the row kernel
-  __host__ __device__ RnnLds(int D, int n_out, bool gaussian, bool with_w3p = false) {
+  // stream: the seven 64 x 64 matrices (W2, Wih, Whh) are NOT resident - the streamed row kernel (orl_rnn_stream.h) pulls
+  // their bf16 images through a ring behind `total`
+  __host__ __device__ RnnLds(int D, int n_out, bool gaussian, bool with_w3p = false, bool stream = false) {
     DP = (D + 3) & ~3;
     const int no4 = (n_out + 3) & ~3;
     int o = 0;
@@ -85,12 +87,12 @@ struct RnnLds {
     b1 = o; o += HID;
     g1 = o; o += HID;
     be1 = o; o += HID;
-    W2 = o; o += HID * W2S;
+    W2 = o; o += stream ? 0 : HID * W2S;
     b2 = o; o += HID;
     g2 = o; o += HID;
     be2 = o; o += HID;
-    Wih = o; o += 3 * HID * W2S;
-    Whh = o; o += 3 * HID * W2S;
+    Wih = o; o += stream ? 0 : 3 * HID * W2S;
+    Whh = o; o += stream ? 0 : 3 * HID * W2S;
     bih = o; o += 3 * HID;
     bhh = o; o += 3 * HID;
     g3 = o; o += HID;
@@ -104,7 +106,8 @@ struct RnnLds {
 };
 
 __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __restrict__ theta, const RnnLayout& tl,
-                                       const RnnLds& tw, int tid, int nthreads, bool with_w3p = false) {
+                                       const RnnLds& tw, int tid, int nthreads, bool with_w3p = false,
+                                       bool stream = false) {
   const int D = tl.D;
   if (with_w3p) {
     for (int e = tid; e < 16 * W2S; e += nthreads) {
@@ -130,10 +133,12 @@ __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __r
     lds[tw.bih + e] = theta[tl.obih + e];
     lds[tw.bhh + e] = theta[tl.obhh + e];
   }
-  for (int e = tid; e < HID * HID; e += nthreads) lds[tw.W2 + (e >> 6) * W2S + (e & 63)] = theta[tl.oW2 + e];
-  for (int e = tid; e < 3 * HID * HID; e += nthreads) {
-    lds[tw.Wih + (e >> 6) * W2S + (e & 63)] = theta[tl.oWih + e];
-    lds[tw.Whh + (e >> 6) * W2S + (e & 63)] = theta[tl.oWhh + e];
+  if (!stream) {
+    for (int e = tid; e < HID * HID; e += nthreads) lds[tw.W2 + (e >> 6) * W2S + (e & 63)] = theta[tl.oW2 + e];
+    for (int e = tid; e < 3 * HID * HID; e += nthreads) {
+      lds[tw.Wih + (e >> 6) * W2S + (e & 63)] = theta[tl.oWih + e];
+      lds[tw.Whh + (e >> 6) * W2S + (e & 63)] = theta[tl.oWhh + e];
+    }
   }
   const int no4 = (tl.n_out + 3) & ~3;
   for (int e = tid; e < no4 * HID; e += nthreads) lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] : 0.f;

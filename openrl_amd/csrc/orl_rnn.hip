@@ -658,6 +658,10 @@ __global__ __launch_bounds__(512, 2) void rnn_row_pair_kernel(RnnRowArgs P, RnnR
   else rnn_row_body<ORL_HEAD_VALUE, 1>(Cc, blockIdx.x - split, gridDim.x - split);
 }
 
+}  // namespace orl
+#include "orl_rnn_stream.h"  // the same row kernel with its 64 x 64 GEMMs on the bf16 MFMA over streamed images (round 4)
+namespace orl {
+
 // =====================================================================================================
 // update: weight-gradient GEMM over the tape
 // =====================================================================================================
@@ -1079,7 +1083,7 @@ static int check_rnn_net(const orl_net_desc* n, const char* who, bool value) {
 }
 
 struct RnnWs {  // workspace carve-up (floats) for one tower
-  size_t htape, tape, rpart, wpart, total;
+  size_t htape, tape, rpart, wpart, img, total;
   int n_tiles, n_blocks, grid_row, grid_wg, rpw, wpw;
   RnnWs(const orl_net_desc& n, int n_chunks, int L) {
     const RnnRaw rl(n);
@@ -1096,9 +1100,30 @@ struct RnnWs {  // workspace carve-up (floats) for one tower
     tape = o; o += (size_t)n_blocks * tape_block_floats(n.obs_dim);
     rpart = o; o += (size_t)RNN_ROW_BLOCKS * rpw;
     wpart = o; o += (size_t)RNN_WG_BLOCKS * wpw;
+    o = (o + 63) & ~(size_t)63;
+    img = o; o += (size_t)RS_NIMG * RS_IMG_FLOATS;  // bf16 images of W2 / Wih / Whh (streamed row kernel), 256-byte aligned
     total = (o + 63) & ~(size_t)63;
   }
 };
+
+// the streamed split kernel: images first (one small launch per optimiser step), then the row pair
+template <int HEAD, int NO>
+static int launch_rnn_rows_stream(const RnnRowArgs& P, const RnnRowArgs& Cc, float* img_p, float* img_c, int grid_p,
+                                  int grid_c, hipStream_t s) {
+  const RnnLds twp(P.net.obs_dim, P.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HEAD == ORL_HEAD_CATEGORICAL && NO > 4, true);
+  const RnnLds twc(Cc.net.obs_dim, 1, false, false, true);
+  const size_t lds = (size_t)((twp.total > twc.total ? twp.total : twc.total) + RS_NSLOT * RS_IMG_FLOATS) * sizeof(float);
+  if (lds > 160 * 1024) return fail(ORL_E_UNSUPPORTED, "orl_rnn_ppo_fwd_bwd: tower needs %zu B of LDS", lds);
+  hipLaunchKernelGGL(rnn_images_kernel, dim3(RS_NIMG, 2), dim3(256), 0, s, P.theta, Cc.theta, RnnLayout(P.net),
+                     RnnLayout(Cc.net), img_p, img_c);
+  int rc = launch_status("orl_rnn_ppo_fwd_bwd(images)");
+  if (rc) return rc;
+  (void)hipFuncSetAttribute((const void*)rnn_row_pair_stream_kernel<HEAD, NO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((rnn_row_pair_stream_kernel<HEAD, NO>), dim3(grid_p + grid_c), dim3(512), lds, s, P, Cc,
+                     (const float*)img_p, (const float*)img_c, grid_p);
+  return launch_status("orl_rnn_ppo_fwd_bwd(row, streamed split)");
+}
 
 template <int HEAD, int NO>
 static int launch_rnn_rows(const RnnRowArgs& P, const RnnRowArgs& Cc, int grid_p, int grid_c, hipStream_t s) {
@@ -1299,15 +1324,29 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
   C2.net = *cnet; C2.theta = ctheta; C2.hbuf = batch->h_critic; C2.o_x = o_co;
   if (batch->rows_critic) { C2.rows = batch->rows_critic; C2.Nc = nc_c; }
   C2.htape = base_c + wc.htape; C2.tape = base_c + wc.tape; C2.partials = base_c + wc.rpart;
-  // (1) row kernels of both towers, one launch
+  // (1) row kernels of both towers, one launch: the streamed bf16-split build, or (hp.reserved & 4, the comparison
+  // switch cfg.amd_tower_gemm = fp32) every GEMM on the fp32 MFMA out of resident LDS images
   const int no = pnet->n_out;
-  if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
-    if (no <= 2) rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 2>(A, C2, wp.grid_row, wc.grid_row, s);
-    else if (no <= 8) rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 8>(A, C2, wp.grid_row, wc.grid_row, s);
-    else rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 16>(A, C2, wp.grid_row, wc.grid_row, s);
+  if (hp->reserved & 4) {
+    if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
+      if (no <= 2) rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 2>(A, C2, wp.grid_row, wc.grid_row, s);
+      else if (no <= 8) rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 8>(A, C2, wp.grid_row, wc.grid_row, s);
+      else rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 16>(A, C2, wp.grid_row, wc.grid_row, s);
+    } else {
+      if (no <= 8) rc = launch_rnn_rows<ORL_HEAD_GAUSSIAN, 8>(A, C2, wp.grid_row, wc.grid_row, s);
+      else rc = launch_rnn_rows<ORL_HEAD_GAUSSIAN, 16>(A, C2, wp.grid_row, wc.grid_row, s);
+    }
   } else {
-    if (no <= 8) rc = launch_rnn_rows<ORL_HEAD_GAUSSIAN, 8>(A, C2, wp.grid_row, wc.grid_row, s);
-    else rc = launch_rnn_rows<ORL_HEAD_GAUSSIAN, 16>(A, C2, wp.grid_row, wc.grid_row, s);
+    float* ip = base_p + wp.img;
+    float* ic = base_c + wc.img;
+    if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
+      if (no <= 2) rc = launch_rnn_rows_stream<ORL_HEAD_CATEGORICAL, 2>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
+      else if (no <= 8) rc = launch_rnn_rows_stream<ORL_HEAD_CATEGORICAL, 8>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
+      else rc = launch_rnn_rows_stream<ORL_HEAD_CATEGORICAL, 16>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
+    } else {
+      if (no <= 8) rc = launch_rnn_rows_stream<ORL_HEAD_GAUSSIAN, 8>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
+      else rc = launch_rnn_rows_stream<ORL_HEAD_GAUSSIAN, 16>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
+    }
   }
   if (rc) return rc;
   // (2) weight-gradient GEMMs over both tapes, one launch

@@ -74,7 +74,7 @@ class CPUReplayData:
 class CPUTrainer:
     def __init__(self, n_envs: int, T: int, obs_dim: int = 4, n_actions: int = 2, seed: int = 0, ppo_epoch: int = 10,
                  num_mini_batch: int = 1, episode_limit: int = 200, hp: po.PPOHyper = None, lr: float = 5e-4,
-                 threads: int = None):
+                 threads: int = None, env=None):
         if threads:
             torch.set_num_threads(threads)
         self.N, self.T, self.D, self.K = n_envs, T, obs_dim, n_actions
@@ -90,7 +90,9 @@ class CPUTrainer:
         self.padam = po.AdamOracle(self.ptheta.numel(), lr)
         self.cadam = po.AdamOracle(self.ctheta.numel(), lr)
         self.vn = po.ValueNormOracle() if self.hp.use_valuenorm else None
-        self.env = po.SynthEnvOracle(n_envs, obs_dim, seed, episode_limit)
+        # env: any duck-typed host env (reset() -> [N, 1, D], step(actions) -> obs, rewards, dones, infos), e.g.
+        # po.CartPoleEnvOracle for the learning comparison of tests/test_learning_gpu.py
+        self.env = env if env is not None else po.SynthEnvOracle(n_envs, obs_dim, seed, episode_limit)
         self.buf = CPUReplayData(T, n_envs, 1, obs_dim, 1, n_actions)
         self.buf.policy_obs[0] = self.env.reset()
         self.buf.critic_obs[0] = self.buf.policy_obs[0]

@@ -506,6 +506,35 @@ def cartpole_reset_state(seed: int, env: np.ndarray, episode: np.ndarray) -> np.
     return np.stack([px.u01(c) * f(0.1) - f(0.05) for c in (x, y, z, w)], axis=-1).astype(np.float32)
 
 
+class CartPoleEnvOracle:
+    """Vectorised CartPole-v1 on the host with the device env's semantics (csrc/orl_env.h: gymnasium's Euler step in
+    float32, termination |x| > 2.4 or |theta| > 12 deg, truncation at ``episode_limit`` = 500, auto-reset to the Philox
+    start state of (seed, env, episode) with the observation of the NEW episode returned - sync_venv.py:178-247);
+    reward 1 per step.  Duck-typed like SynthEnvOracle; drives oracle/cpu_trainer.py's learning comparison."""
+
+    def __init__(self, n_envs, seed, episode_limit=500):
+        self.N, self.seed, self.limit = n_envs, seed, episode_limit
+        self.reset()
+
+    def reset(self):
+        self.episode = np.zeros(self.N, np.int64)
+        self.steps = np.zeros(self.N, np.int64)
+        self.state = cartpole_reset_state(self.seed, np.arange(self.N), self.episode)
+        return self.state[:, None, :].copy()
+
+    def step(self, actions):
+        a = np.asarray(actions).reshape(self.N).astype(np.int64)
+        out, term = cartpole_step_f32(self.state, a)
+        self.steps = self.steps + 1
+        done = term | (self.steps >= self.limit)
+        self.episode = np.where(done, self.episode + 1, self.episode)
+        fresh = cartpole_reset_state(self.seed, np.arange(self.N), self.episode)
+        self.state = np.where(done[:, None], fresh, out).astype(np.float32)
+        self.steps = np.where(done, 0, self.steps)
+        rew = np.ones((self.N, 1, 1), np.float32)
+        return self.state[:, None, :].copy(), rew, done[:, None], [{} for _ in range(self.N)]
+
+
 # =====================================================================================================
 # train_ppo  (openrl/algorithms/ppo.py:383-458) over a dict of buffer arrays [T(+1), N, A, .]
 # =====================================================================================================

@@ -19,7 +19,7 @@ def main():
     lib = nat.load()
     if not hasattr(lib, "orl_debug_rollout_prof"):
         raise SystemExit("liborl_hip.so is not the timing build: python -m openrl_amd.csrc.build --prof")
-    sys.argv = [sys.argv[0], "--no-cpu-baseline", "--steps", "5", "--warmup", "2"]
+    sys.argv = [sys.argv[0], "--no-cpu-baseline", "--no-other-configs", "--steps", "5", "--warmup", "2"]
     out = (C.c_ulonglong * 16)()
     lib.orl_debug_rollout_prof.argtypes = [C.c_void_p]
     bench.main()
