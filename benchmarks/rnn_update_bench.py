@@ -27,8 +27,9 @@ def main():
     ap.add_argument("--agents", type=int, default=3)
     ap.add_argument("--T", type=int, default=25)
     ap.add_argument("--epochs", type=int, default=10)
-    ap.add_argument("--tower-gemm", default="split", choices=["split", "fp32"],
-                    help="fp32 = the round-3 row kernel (every GEMM on v_mfma_f32_16x16x4_f32): the A/B switch")
+    ap.add_argument("--tower-gemm", default="fp32", choices=["split", "fp32", "split_w4"],
+                    help="cfg.amd_rnn_gemm: fp32 (default) = every GEMM on v_mfma_f32_16x16x4_f32 out of resident LDS images; "
+                         "split / split_w4 = the streamed bf16-split row kernel (8 / 4 waves per workgroup)")
     a = ap.parse_args()
     from openrl_amd import spaces
     from openrl_amd.algorithms.ppo import PPOAlgorithm
@@ -40,7 +41,7 @@ def main():
     N, A, T = a.envs, a.agents, a.T
     cfg = default_cfg(["--episode_length", str(T), "--ppo_epoch", str(a.epochs), "--use_recurrent_policy", "true",
                        "--data_chunk_length", str(a.chunk), "--amd_perm_mode", "device",
-                       "--amd_tower_gemm", a.tower_gemm])
+                       "--amd_rnn_gemm", a.tower_gemm])
     cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = N, A, cfg.hidden_size
     box = lambda d: spaces.Box(-np.inf, np.inf, (d,))
     obs_space = spaces.Dict({"policy": box(18), "critic": box(54)})

@@ -273,7 +273,11 @@ typedef struct orl_ppo_hparams {
                      *     measurement / comparison switch: same results within fp32 rounding, ~1.4x slower);
                      * 8 = orl_ppo_fwd_bwd skips the transposing-read full-split build (dgrad through
                      *     ds_read_b64_tr_b16 of W2's bf16 image, the wide-observation towers' default) and takes round 3's
-                     *     variants (two images, or wgrad-only split) - comparison switch, same arithmetic */
+                     *     variants (two images, or wgrad-only split) - comparison switch, same arithmetic;
+                     * 16 = orl_rnn_ppo_fwd_bwd runs its streamed split row kernel with 4 waves per workgroup (one wave per
+                     *     SIMD, 512 registers) instead of 8 - comparison switch, same arithmetic;
+                     * 32 = orl_ppo_apply* OVERWRITES its train_info slots instead of adding to them (the first optimiser step
+                     *     of a train() call: saves the caller a zero-fill launch) */
 } orl_ppo_hparams;
 
 /* size (floats) of the raw gradient-sum vector of one tower and of the stats vector */

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 from typing import Dict, Union
 
+import numpy as np
 import torch
 
 from .. import _native as nat
@@ -32,13 +33,19 @@ class DeviceTrainInfo(dict):
     """The train_info dict of ``PPOAlgorithm.train`` (ppo.py:445-458) whose values are still on the device: the one
     device->host copy happens on first access (any read of the dict), not at the end of every update."""
 
-    def __init__(self, keys, device_values: torch.Tensor, after_sync=None):
+    def __init__(self, keys, device_values: torch.Tensor, after_sync=None, scale=None):
+        """``scale``: per-key fp32 factors applied on the HOST at read time (the 1 / num_updates of ppo.py:453-456) - the
+        device tensor holds the raw sums and belongs to this dict alone (every train() call accumulates into a fresh
+        one), so no multiply launch is needed to snapshot it."""
         super().__init__()
-        self._keys, self._dev, self._after_sync = tuple(keys), device_values, after_sync
+        self._keys, self._dev, self._after_sync, self._scale = tuple(keys), device_values, after_sync, scale
 
     def _materialize(self) -> None:
         if self._dev is not None:
-            vals, self._dev = self._dev.cpu().tolist(), None
+            raw, self._dev = self._dev.cpu().numpy(), None
+            if self._scale is not None:  # fp32 product, bit-identical to the device multiply it replaces
+                raw = raw * np.asarray(self._scale, dtype=np.float32)
+            vals = raw.tolist()
             if self._after_sync is not None:  # e.g. the collective's error word, posted behind this update's launches
                 cb, self._after_sync = self._after_sync, None
                 cb()
@@ -123,7 +130,7 @@ class PPOAlgorithm(BaseAlgorithm):
         # through the chunked update with L = T (set per update from the buffer)
         self.naive_recurrent = bool(cfg.use_naive_recurrent_policy) and not bool(cfg.use_recurrent_policy)
         self.train_list = [self.train_ppo]
-        self.hp = ops.make_hparams(cfg)
+        self.hp = ops.make_hparams(cfg, recurrent=bool(getattr(self.algo_module, "recurrent", False)))
         self.generic = bool(getattr(self.algo_module, "generic", False))
         self.use_joint_action_loss = bool(cfg.use_joint_action_loss)
         self.perm_mode = getattr(cfg, "amd_perm_mode", "reference")
@@ -267,9 +274,14 @@ class PPOAlgorithm(BaseAlgorithm):
         po.step_count += 1 if turn_on else 0
         co.step_count += 1
         hp = self.hp
-        if not turn_on:
+        first = getattr(self, "_info_first", False)
+        if not turn_on or first:
             hp = nat.PPOHParams.from_buffer_copy(self.hp)
-            hp.reserved |= 1  # critic-only update (construct_loss_list, ppo.py:226-236)
+            if not turn_on:
+                hp.reserved |= 1  # critic-only update (construct_loss_list, ppo.py:226-236)
+            if first:
+                hp.reserved |= 32  # first optimiser step of this train() call: the apply launch starts the averages
+                self._info_first = False
         return ops.ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
                              co.native_state(co.step_count), self._info, next_perm, comm=comm)
 
@@ -528,7 +540,13 @@ class PPOAlgorithm(BaseAlgorithm):
         self._full_batch_moments = self.num_mini_batch == 1 and (not self.recurrent or M % self.data_chunk_length == 0)
         # full batch: {sum ret, sum ret^2, count} are already in the statistics row the pack kernel wrote (a view, no copy)
         self._moments = self._adv_stats[8:11] if self._full_batch_moments else self._moments_mb
-        self._info.zero_()
+        # a FRESH accumulator per call (torch.empty: no launch): the returned DeviceTrainInfo keeps it, so nothing has to be
+        # copied or scaled on the device afterwards.  Default MLP towers: the first apply launch overwrites its slots
+        # (hparams.reserved & 32) - no zero fill either; the other update paths accumulate from zero.
+        self._info = torch.empty(8, dtype=torch.float32, device=self.device)
+        self._info_first = not (self.generic or self.recurrent)
+        if not self._info_first:
+            self._info.zero_()
         self.last_indices = []
         next_perm = None
         self._jrpo_epoch_id = getattr(self, "_jrpo_epoch_id", 0) + 1  # a fresh records copy per train() call
@@ -556,20 +574,16 @@ class PPOAlgorithm(BaseAlgorithm):
         # no device->host sync here: the averages stay on the device until somebody reads the dict (logging every
         # log_interval iterations, tests), so the host can enqueue the next rollout while this update still runs
         keys = self.info_keys
-        skey = (len(keys), num_updates, buffer.num_agents * buffer.act_shape if self.use_joint_action_loss else 0)
-        if getattr(self, "_info_scale_key", None) != skey:  # built once: two launches less per update
-            scale = torch.full((len(keys),), 1.0 / float(num_updates), dtype=torch.float32, device=self.device)
-            if self.use_joint_action_loss:  # every agent row (and action dim) of a (step, chunk) carried the joint term
-                scale[1] /= float(buffer.num_agents * buffer.act_shape)
-            self._info_scale, self._info_scale_key = scale, skey
-        scale = self._info_scale
+        scale = np.full(len(keys), np.float32(1.0) / np.float32(num_updates), dtype=np.float32)
+        if self.use_joint_action_loss:  # every agent row (and action dim) of a (step, chunk) carried the joint term
+            scale[1] /= np.float32(buffer.num_agents * buffer.act_shape)
         watch = getattr(self, "_comm_watch", None)
         if watch is None:
-            return DeviceTrainInfo(keys, self._info[:len(keys)] * scale)
+            return DeviceTrainInfo(keys, self._info[:len(keys)], scale=scale)
         # multi-GPU: the comm's error word rides behind this update's launches; it is looked at when train_info is read
         # and (without a sync) when the next update starts - a timed-out peer never stays silent
         watch.post(self._comm.error_flag())
-        return DeviceTrainInfo(keys, self._info[:len(keys)] * scale, after_sync=lambda: watch.poll(wait=True))
+        return DeviceTrainInfo(keys, self._info[:len(keys)], after_sync=lambda: watch.poll(wait=True), scale=scale)
 
     def train(self, buffer, turn_on: bool = True) -> Dict[str, float]:
         if len(self.train_list) == 1:

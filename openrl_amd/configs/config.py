@@ -33,7 +33,13 @@ AMD_FLAGS = [
     ("amd_rnn_rollout_chase", "bool", True, "opt", None),
     # GEMMs of the fused tower update: "split" = exact three-term bf16 splits on the bf16 MFMA (default; error <= the fp32
     # MFMA's), "fp32" = v_mfma_f32_16x16x4_f32 (comparison / measurement).
+    # "split_two_image" = round 3's variants (no transposing-read full split for wide observations): comparison switch.
     ("amd_tower_gemm", "str", "split", "opt", ["split", "fp32", "split_two_image"]),
+    # GEMMs of the RECURRENT row kernel: "fp32" (default) = v_mfma_f32_16x16x4_f32 out of resident LDS images (the faster one:
+    # 0.80 ms per epoch at the cfg4 shape); "split" = bf16x3 splits over images STREAMED through an LDS ring
+    # (csrc/orl_rnn_stream.h; 0.83 ms - the stream's waits cost more than the MFMA time it saves),
+    # "split_w4" = the same with 4 waves per workgroup / 512 registers per wave (1.07 ms).  All three are parity-tested.
+    ("amd_rnn_gemm", "str", "fp32", "opt", ["fp32", "split", "split_w4"]),
     # general (non-default) feed-forward towers: "fused" = the cross-layer kernels of csrc/orl_gen_tower.h where they take
     # the shape (hidden_size 64 / 128), "layerwise" = one launch per layer and direction everywhere.
     ("amd_gen_update", "str", "fused", "opt", ["fused", "layerwise"]),

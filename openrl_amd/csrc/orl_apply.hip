@@ -143,6 +143,7 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
       // turn_on == False: the policy loss is not in the loss list (ppo.py:226-236) -> no gradient, no step
       for (int p = threadIdx.x; p < tl.total; p += blockDim.x) W.ad.grad[p] = 0.f;
       if (threadIdx.x == 0 && info != nullptr) {
+        if (hp.reserved & 32) info[1] = info[2] = info[3] = info[5] = 0.f;  // first step of a train() call: overwrite
         info[1] += stp[ST_PLOSS_SUM] / den_p;
         float ent_den0 = den_p;
         if (!hp.use_policy_active_masks && P.net.head_kind == ORL_HEAD_GAUSSIAN) ent_den0 = den_p * (float)P.net.n_out;
@@ -213,6 +214,12 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
   if (threadIdx.x == 0 && info != nullptr) {
     const float* stp = st;
     const float* stc = st;
+    // hp.reserved & 32: the first optimiser step of a train() call starts the averages instead of adding to them (the
+    // caller then needs no zero-fill launch); each workgroup owns its slots
+    if (hp.reserved & 32) {
+      if (blockIdx.x == 0) info[1] = info[2] = info[3] = info[5] = 0.f;
+      else info[0] = info[4] = 0.f;
+    }
     if (blockIdx.x == 0) {
       float ent_den = den_p;
       if (!hp.use_policy_active_masks && P.net.head_kind == ORL_HEAD_GAUSSIAN) ent_den = den_p * (float)P.net.n_out;

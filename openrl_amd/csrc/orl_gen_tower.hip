@@ -6,8 +6,17 @@ namespace orl {
 
 // backward: one 8-wave workgroup per CU (256 VGPRs per wave); forward: 8-wave workgroups at <= 128 VGPRs and ~75 KB of
 // LDS, TWO per CU, so that one's barrier / LDS waits overlap the other's MFMAs
-#ifndef ORL_GT_BWD_MINWAVES  // build-time experiment: 1 = one 4-wave workgroup per CU with 512 registers per wave
-#define ORL_GT_BWD_MINWAVES 2
+// Round 4: the backward launch ships as 4-wave workgroups, ONE per CU, 512 registers per wave (ORL_GT_BWD_WAVES = 4,
+// ORL_GT_BWD_MINWAVES = 1) wherever its LDS fits 80 KB: the 8-wave / 256-register build spilled 121 - 177 VGPRs and moved
+// 221 MB in + 394 MB out of HBM per launch as scratch (profiles/r03_pmc_gen_fused_hbm.txt, 15x the algorithmic traffic)
+// for the SAME time (12.65 vs 12.65 ms per iteration at hidden 128, profiles/r04_generic_lines.jsonl) - the policy and
+// critic chains run on two streams and, multi-GPU, beside peer pushes, where 1.2 GB of scratch per epoch pair is not free.
+// -DORL_GT_BWD_WAVES=8 -DORL_GT_BWD_MINWAVES=2 rebuilds round 3's.
+#ifndef ORL_GT_BWD_MINWAVES
+#define ORL_GT_BWD_MINWAVES 1
+#endif
+#ifndef ORL_GT_BWD_WAVES
+#define ORL_GT_BWD_WAVES 4
 #endif
 template <int H, int NL, int ND, int NW>
 __global__ __launch_bounds__(NW * 64, ORL_GT_BWD_MINWAVES) void gt_bwd_kernel(GtArgs A) {
@@ -209,17 +218,12 @@ static size_t gt_lds_bytes(const GtLay& ly, int bwd_waves) {
   if (bwd_waves) fl += (size_t)bwd_waves * 512;  // per wave: the head-output tile and the d logstd rows of the fused losses
   return fl * sizeof(float);
 }
-// One 8-wave workgroup per CU.  The 4-wave build (ORL_BUILD_DEFS=-DORL_GT_BWD_WAVES=4: two independent workgroups per
-// CU whenever they fit 80 KB each, so that one's exchange / barrier phases could overlap the other's MFMAs) was measured
-// SLOWER - 531 against 495 us per launch at hidden 128 (twice the G accumulators per wave, 169 spilled VGPRs against 99):
-// the kernel is not waiting on its barriers, it is bound by each wave's own instruction stream.
+// Waves per backward workgroup: 4 (one workgroup per CU, one wave per SIMD, 512 registers, no scratch traffic) when its
+// LDS fits 80 KB, else 8.  (Round 3 measured TWO 4-wave workgroups per CU at 256 registers - ORL_GT_BWD_MINWAVES = 2 -
+// slower, 531 vs 495 us: twice the G accumulators per wave, 169 spilled VGPRs; with the whole register file per wave the
+// 4-wave form costs the same time as the 8-wave one and spills nothing.)
 static int gt_bwd_waves(const GtLay& ly) {
-#ifdef ORL_GT_BWD_WAVES  // build-time experiment
   return (ORL_GT_BWD_WAVES == 4 && gt_lds_bytes(ly, 4) <= 80 * 1024) ? 4 : 8;
-#else
-  (void)ly;
-  return 8;
-#endif
 }
 
 static int gt_check(const orl_gt_desc* d, const char* who) {
@@ -251,7 +255,7 @@ static void gt_launch_bwd(const GtArgs& A, int grid, size_t lds, hipStream_t s) 
   hipLaunchKernelGGL((gt_bwd_kernel<H, NL, ND, NW>), dim3(grid), dim3(NW * 64), lds, s, A);
 }
 
-#ifdef ORL_GT_BWD_WAVES
+#if ORL_GT_BWD_WAVES == 4
 #define ORL_GT_NW4 4
 #else
 #define ORL_GT_NW4 8  // the 4-wave build is not instantiated

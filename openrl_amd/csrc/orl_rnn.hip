@@ -1101,7 +1101,7 @@ struct RnnWs {  // workspace carve-up (floats) for one tower
     rpart = o; o += (size_t)RNN_ROW_BLOCKS * rpw;
     wpart = o; o += (size_t)RNN_WG_BLOCKS * wpw;
     o = (o + 63) & ~(size_t)63;
-    img = o; o += (size_t)RS_NIMG * RS_IMG_FLOATS;  // bf16 images of W2 / Wih / Whh (streamed row kernel), 256-byte aligned
+    img = o; o += (size_t)RS_NIMG * RS_IMG_FLOATS + 128;  // bf16 images of W2 / Wih / Whh + the stream's two flag rows
     total = (o + 63) & ~(size_t)63;
   }
 };
@@ -1112,15 +1112,23 @@ static int launch_rnn_rows_stream(const RnnRowArgs& P, const RnnRowArgs& Cc, flo
                                   int grid_c, hipStream_t s) {
   const RnnLds twp(P.net.obs_dim, P.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HEAD == ORL_HEAD_CATEGORICAL && NO > 4, true);
   const RnnLds twc(Cc.net.obs_dim, 1, false, false, true);
-  const size_t lds = (size_t)((twp.total > twc.total ? twp.total : twc.total) + RS_NSLOT * RS_IMG_FLOATS) * sizeof(float);
+  const size_t lds = (size_t)((twp.total > twc.total ? twp.total : twc.total) + RS_NSLOT * RS_IMG_FLOATS +
+                             RnnStream::extra_floats()) * sizeof(float);
   if (lds > 160 * 1024) return fail(ORL_E_UNSUPPORTED, "orl_rnn_ppo_fwd_bwd: tower needs %zu B of LDS", lds);
   hipLaunchKernelGGL(rnn_images_kernel, dim3(RS_NIMG, 2), dim3(256), 0, s, P.theta, Cc.theta, RnnLayout(P.net),
                      RnnLayout(Cc.net), img_p, img_c);
   int rc = launch_status("orl_rnn_ppo_fwd_bwd(images)");
   if (rc) return rc;
-  (void)hipFuncSetAttribute((const void*)rnn_row_pair_stream_kernel<HEAD, NO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (P.hp.reserved & 16) {  // 4 waves per workgroup: one wave per SIMD, 512 registers (the caller sized the grid for it)
+    (void)hipFuncSetAttribute((const void*)rnn_row_pair_stream_kernel<HEAD, NO, 4>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((rnn_row_pair_stream_kernel<HEAD, NO, 4>), dim3(grid_p + grid_c), dim3(256), lds, s, P, Cc,
+                       (const float*)img_p, (const float*)img_c, grid_p);
+    return launch_status("orl_rnn_ppo_fwd_bwd(row, streamed split, 4 waves)");
+  }
+  (void)hipFuncSetAttribute((const void*)rnn_row_pair_stream_kernel<HEAD, NO, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  hipLaunchKernelGGL((rnn_row_pair_stream_kernel<HEAD, NO>), dim3(grid_p + grid_c), dim3(512), lds, s, P, Cc,
+  hipLaunchKernelGGL((rnn_row_pair_stream_kernel<HEAD, NO, 8>), dim3(grid_p + grid_c), dim3(512), lds, s, P, Cc,
                      (const float*)img_p, (const float*)img_c, grid_p);
   return launch_status("orl_rnn_ppo_fwd_bwd(row, streamed split)");
 }
@@ -1327,6 +1335,13 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
   // (1) row kernels of both towers, one launch: the streamed bf16-split build, or (hp.reserved & 4, the comparison
   // switch cfg.amd_tower_gemm = fp32) every GEMM on the fp32 MFMA out of resident LDS images
   const int no = pnet->n_out;
+  int grid_rp = wp.grid_row, grid_rc = wc.grid_row;  // workgroups (= rows of the row partials) per tower
+  if (!(hp->reserved & 4) && (hp->reserved & 16)) {  // streamed kernel with 4 waves per workgroup: 4 tiles per group
+    grid_rp = (wp.n_tiles + 3) / 4;
+    grid_rc = (wc.n_tiles + 3) / 4;
+    if (grid_rp > RNN_ROW_BLOCKS / 2) grid_rp = RNN_ROW_BLOCKS / 2;
+    if (grid_rc > RNN_ROW_BLOCKS / 2) grid_rc = RNN_ROW_BLOCKS / 2;
+  }
   if (hp->reserved & 4) {
     if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
       if (no <= 2) rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 2>(A, C2, wp.grid_row, wc.grid_row, s);
@@ -1340,12 +1355,12 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
     float* ip = base_p + wp.img;
     float* ic = base_c + wc.img;
     if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
-      if (no <= 2) rc = launch_rnn_rows_stream<ORL_HEAD_CATEGORICAL, 2>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
-      else if (no <= 8) rc = launch_rnn_rows_stream<ORL_HEAD_CATEGORICAL, 8>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
-      else rc = launch_rnn_rows_stream<ORL_HEAD_CATEGORICAL, 16>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
+      if (no <= 2) rc = launch_rnn_rows_stream<ORL_HEAD_CATEGORICAL, 2>(A, C2, ip, ic, grid_rp, grid_rc, s);
+      else if (no <= 8) rc = launch_rnn_rows_stream<ORL_HEAD_CATEGORICAL, 8>(A, C2, ip, ic, grid_rp, grid_rc, s);
+      else rc = launch_rnn_rows_stream<ORL_HEAD_CATEGORICAL, 16>(A, C2, ip, ic, grid_rp, grid_rc, s);
     } else {
-      if (no <= 8) rc = launch_rnn_rows_stream<ORL_HEAD_GAUSSIAN, 8>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
-      else rc = launch_rnn_rows_stream<ORL_HEAD_GAUSSIAN, 16>(A, C2, ip, ic, wp.grid_row, wc.grid_row, s);
+      if (no <= 8) rc = launch_rnn_rows_stream<ORL_HEAD_GAUSSIAN, 8>(A, C2, ip, ic, grid_rp, grid_rc, s);
+      else rc = launch_rnn_rows_stream<ORL_HEAD_GAUSSIAN, 16>(A, C2, ip, ic, grid_rp, grid_rc, s);
     }
   }
   if (rc) return rc;
@@ -1363,7 +1378,7 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
   float* sums_c = sums + RnnRaw(*pnet).total + ORL_N_STATS;
   rc = orl_ppo_reduce_pair2(Gp.partials, wp.grid_wg, wp.wpw, sums, Gc.partials, wc.grid_wg, wc.wpw, sums_c, s);
   if (rc) return rc;
-  return orl_ppo_reduce_pair2(A.partials, wp.grid_row, wp.rpw, sums + wp.wpw, C2.partials, wc.grid_row, wc.rpw,
+  return orl_ppo_reduce_pair2(A.partials, grid_rp, wp.rpw, sums + wp.wpw, C2.partials, grid_rc, wc.rpw,
                               sums_c + wc.wpw, s);
 }
 

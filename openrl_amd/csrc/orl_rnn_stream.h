@@ -1,23 +1,25 @@
-// orl_rnn_stream.h - the recurrent ROW kernel with its fourteen 64 x 64 GEMMs per step on the bf16 MFMA (round 4).
+// orl_rnn_stream.h - the recurrent ROW kernel with its fourteen 64 x 64 GEMMs per BPTT step on the bf16 MFMA (round 4).
 // Included by orl_rnn.hip after rnn_row_body (it uses RnnRowArgs / RNN_T and the loss helpers of that translation unit).
+// NOT the default: cfg.amd_rnn_gemm = split selects it (orl_ppo_hparams.reserved & 4 clear in orl_rnn_ppo_fwd_bwd); the
+// default stays rnn_row_body's fp32 MFMAs, which is faster (0.80 vs 0.83 ms per epoch at the cfg4 shape).  Measured why,
+// with the stream's waits compiled out (-DORL_RS_NODMA) this kernel runs the epoch in 0.65 ms, with the
+// tape stores out too 0.55 - the bf16 GEMMs themselves are worth 0.15 ms, the image stream gives it back.
 //
-// rnn_row_body (orl_rnn.hip) forms W2, the GRU's W_ih / W_hh gate blocks and their transposes with
-// v_mfma_f32_16x16x4_f32: ~900 VALU-blocking fp32 MFMAs per 16-row tile and step, the M / (M + V) regime the split
-// removed from the feed-forward tower.  The three-term bf16 images of the seven matrices are
-// 7 x 27.6 KB = 193 KB - they do not fit the 160 KB of LDS next to each other, so they are STREAMED: a small kernel
-// splits the weights once per optimiser step into global images (rnn_images_kernel, 14 x 27.6 KB, L2 resident), and the row
-// kernel's 8 waves walk their tiles in LOCKSTEP through one cyclic schedule of images,
-//     forward sweep step   : W2  Wih_r Wih_z Wih_n  Whh_r Whh_z Whh_n
-//     backward sweep step  : the same seven (forward recompute), then Whh_r Wih_r  Whh_z Wih_z  Whh_n  Wih_n  W2 read
-//                            TRANSPOSED out of the same images (mm64_T_split_tr, ds_read_b64_tr_b16) - the order that lets
-//                            each of dr / dz / dghn / dn / dz2 be split once,
-// through a 4-slot LDS ring filled by global_load_lds DMA three chunks ahead.  Chunk m is issued as a whole (27 x 1 KiB) by
-// wave m % 8 right after the barrier of chunk m - 3; that wave alone waits for it (s_waitcnt vmcnt(0) at the top of its
-// consume(m)), every wave meets at ONE workgroup barrier per GEMM, which is also what frees slot (m - 1) % 4 for chunk
-// m + 3.  The B operands (activations / deltas) are split in registers (split_T): n1, n2, h_in per forward, dr, dz, dghn,
-// dn, dz2 per backward step.  Arithmetic: 6 of the 9 bf16 products, fp32 accumulation - the feed-forward tower's
-// (error <= the fp32 MFMA's own, profiles/r03_split_bf16_gemm.txt); fc1, the heads and everything element-wise are unchanged.
-// orl_ppo_hparams.reserved & 4 selects the fp32 kernel (comparison switch, cfg.amd_tower_gemm = fp32).
+// rnn_row_body forms W2, the GRU's W_ih / W_hh gate blocks and their transposes with v_mfma_f32_16x16x4_f32: ~900
+// VALU-blocking fp32 MFMAs per 16-row tile and step.  The three-term bf16 images of the seven matrices are 7 x 27.6 KB =
+// 193 KB - they do not fit the 160 KB of LDS next to each other, so they are STREAMED: a small kernel splits the weights
+// once per optimiser step into global images (rnn_images_kernel, 14 x 27.6 KB, L2 resident), and the row kernel's waves
+// walk their tiles through one cyclic schedule of images,
+//     forward group  : W2  Wih_r Wih_z Wih_n  Whh_r Whh_z Whh_n                      (every step phase starts with it)
+//     backward group : Whh_r Wih_r  Whh_z Wih_z  Whh_n  Wih_n  W2, read TRANSPOSED out of the same images
+//                      (mm64_T_split_tr, ds_read_b64_tr_b16) - the order that lets each of dr / dz / dghn / dn / dz2 be
+//                      split once,
+// through a 4-slot LDS ring filled by global_load_lds DMA three chunks ahead; readiness and slot reuse are signalled
+// through LDS flag rows / counters (RnnStream below) - no workgroup barrier and no vmcnt wait in the tile loop.  A tile
+// runs as ONE loop over its 2 L - 1 step phases so that the forward code exists once (instruction cache).  The B operands
+// (activations / deltas) are split in registers (split_T): n1, n2, h_in per forward, dr, dz, dghn, dn, dz2 per backward
+// step.  Arithmetic: 6 of the 9 bf16 products, fp32 accumulation - the feed-forward tower's (error <= the fp32 MFMA's own,
+// profiles/r03_split_bf16_gemm.txt); fc1, the heads and everything element-wise are unchanged.
 #pragma once
 #include "orl_rnn.h"
 
@@ -28,6 +30,7 @@ constexpr int RS_NSLOT = 4;                    // LDS ring slots
 constexpr int RS_IMG_FLOATS = WB_IMG_FLOATS;   // 6 912 floats
 constexpr int RS_IMG_BYTES = RS_IMG_FLOATS * 4;  // 27 648 B = 27 x 1 KiB
 static_assert(RS_IMG_BYTES % 1024 == 0, "an image is a whole number of 1 KiB DMA blocks");
+constexpr int RS_SPIN_LIMIT = 1 << 22;         // polls (~100 cycles each) before a wait is declared dead: ~0.2 s
 
 // global images of one optimiser step: grid (7 images, 2 towers), any block size
 __global__ __launch_bounds__(256) void rnn_images_kernel(const float* __restrict__ ptheta, const float* __restrict__ ctheta,
@@ -40,26 +43,79 @@ __global__ __launch_bounds__(256) void rnn_images_kernel(const float* __restrict
   unsigned short* img = (unsigned short*)((pol ? img_p : img_c) + (size_t)im * RS_IMG_FLOATS);
   const float* W = th + (im == 0 ? tl.oW2 : im <= 3 ? tl.oWih + (im - 1) * HID * HID : tl.oWhh + (im - 4) * HID * HID);
   for (int e = threadIdx.x; e < HID * HID; e += blockDim.x) split_weight_store(img, e >> 6, e & 63, W[e]);
+  if (im == 0) {  // the two constant rows the stream's READY flags are loaded from (RnnStream::issue)
+    unsigned* fr = (unsigned*)((pol ? img_p : img_c) + (size_t)RS_NIMG * RS_IMG_FLOATS);
+    for (int e = threadIdx.x; e < 128; e += blockDim.x) fr[e] = (unsigned)(e >> 6);
+  }
 }
 
-struct RnnStream {
-  const char* gsrc;  // this tower's images in global memory, + lane * 16
-  char* lbase;       // ring slot 0 (generic pointer)
-  unsigned lds0;     // ... its LDS byte address
-  int n, total;      // next chunk to consume; chunks this workgroup consumes in all
-  int cyc, nfw;      // chunks per tile iteration: 7 (L - 1) forward-sweep chunks, then 14 per backward step
-  int wave;
+// LDS helpers with explicit instructions (the compiler must neither cache nor reorder these)
+__device__ __forceinline__ unsigned rs_lds_peek(unsigned addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
 
-  __device__ __forceinline__ int img_of(int m) const {
-    const unsigned FW = 0x6543210u, BW = 0x0362514u;  // nibble k = image of position k of a forward / backward group
-    const int p = m % cyc;
-    if (p < nfw) return (int)((FW >> (4 * (p % 7))) & 15u);
-    const int u = (p - nfw) % 14;
-    return (int)(((u < 7 ? FW >> (4 * u) : BW >> (4 * (u - 7)))) & 15u);
+// The stream WITHOUT workgroup barriers and WITHOUT vmcnt waits (the first version had one barrier per GEMM and the
+// issuing wave draining vmcnt(0) - i.e. every tape store it had in flight - in front of it: 3 700 cycles per GEMM in the
+// phase profile against ~1 000 of work, profiles/r04_rnn_phase_prof.txt):
+//  * READY: the wave that issues chunk m appends one more DMA load behind the chunk's 27 - 64 dwords of a constant row of
+//    the value (m / NSLOT) & 1 into the slot's flag row.  Loads of a wave return in order, so when the flag row shows the
+//    expected parity the image is complete; consumers poll the row (one LDS read), nobody waits on vmcnt;
+//  * FREE: a wave that has finished its GEMM on a slot adds 1 to the slot's counter (LDS operations of a wave execute in
+//    order, so the add follows its last fragment read); the issuer of the slot's next occupant waits for
+//    nwaves x (uses so far) before it overwrites the slot.
+// The waves of a workgroup therefore run up to NSLOT - 1 chunks apart instead of in lockstep.
+struct RnnStream {
+  const char* gsrc;   // this tower's images in global memory, + lane * 16
+  char* lbase;        // ring slot 0 (generic pointer)
+  unsigned lds0;      // ... its LDS byte address (flag rows and counters follow the ring)
+  int n, total;       // next chunk to consume; chunks this workgroup consumes in all
+  int wave, wmask, nwaves, lane;
+  int cur;            // slot of the chunk handed out by the last consume()
+  int dead;           // a wait ran into RS_SPIN_LIMIT: the wave went on with whatever the slot held; the kernel then poisons
+                      // its loss statistics with NaN, so the failure is in train_info instead of being silent (or a hang)
+
+  static __host__ __device__ constexpr int extra_floats() { return RS_NSLOT * 64 + 16; }  // flag rows + counters
+  __device__ __forceinline__ unsigned flags0() const { return lds0 + (unsigned)RS_NSLOT * (unsigned)RS_IMG_BYTES; }
+  __device__ __forceinline__ unsigned done0() const { return flags0() + (unsigned)RS_NSLOT * 256u; }
+  // Image of the chunk consumed at GEMM site S of a step phase.  Every phase starts with the forward group
+  // (W2, Wih r z n, Whh r z n = images 0..6, sites 0..6); a BPTT phase continues with the backward group
+  // (Whh_r Wih_r Whh_z Wih_z Whh_n Wih_n W2 = images 4 1 5 2 6 3 0, sites 7..13).  The chunk issued from site S is the one
+  // consumed RS_NSLOT - 1 sites later - in this phase, or at the start of the next one (always a forward group).
+  static __device__ __forceinline__ constexpr int site_image(int site) {
+    return site < 7 ? site : (int)((0x0362514u >> (4 * (site - 7))) & 15u);
   }
-  __device__ __forceinline__ void issue(int m) {  // the whole chunk, by ONE wave (asm: see orl_ppo_tower.h issue_dma)
-    const char* src = gsrc + (size_t)img_of(m) * RS_IMG_BYTES;
-    const unsigned dst = lds0 + (unsigned)(m % RS_NSLOT) * (unsigned)RS_IMG_BYTES;
+  template <int S>
+  static __device__ __forceinline__ int ahead_image(bool bwd) {
+    constexpr int A = S + RS_NSLOT - 1;
+    if constexpr (A < 7) return site_image(A);
+    else if constexpr (S < 7) return bwd ? site_image(A) : site_image(A - 7);   // (A < 14 here: S <= 6, NSLOT <= 8)
+    else if constexpr (A < 14) return site_image(A);
+    else return site_image(A - 14);
+  }
+  // ring / flag / counter addresses; every thread of the workgroup calls this, then a __syncthreads(), then start()
+  __device__ __forceinline__ void init(const float* images, float* ring, int total_, int wave_, int lane_, int nwaves_) {
+    gsrc = (const char*)images + lane_ * 16;
+    lbase = (char*)ring;
+    lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lbase;
+    n = 0; total = total_; wave = wave_; wmask = nwaves_ - 1; nwaves = nwaves_; lane = lane_; cur = 0; dead = 0;
+    unsigned* fl = (unsigned*)(lbase + (size_t)RS_NSLOT * RS_IMG_BYTES);
+    for (int e = wave_ * 64 + lane_; e < RS_NSLOT * 64 + 16; e += nwaves_ * 64) fl[e] = e < RS_NSLOT * 64 ? 1u : 0u;
+  }
+  __device__ __forceinline__ void issue(int m, int image) {  // the whole chunk + its flag row, by ONE wave
+    const int slot = m & (RS_NSLOT - 1), use = m / RS_NSLOT;
+    if (use > 0) {  // the slot's previous occupants have been released by every wave
+      const unsigned need = (unsigned)(nwaves * use);
+      int spins = 0;
+#pragma nounroll
+      while (__builtin_amdgcn_readfirstlane(rs_lds_peek(done0() + 4u * (unsigned)slot)) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > RS_SPIN_LIMIT) { dead = 1; break; }  // a protocol error must never hang the GPU: see `dead`
+      }
+    }
+    const char* src = gsrc + (size_t)image * RS_IMG_BYTES;
+    const unsigned dst = lds0 + (unsigned)slot * (unsigned)RS_IMG_BYTES;
 #pragma unroll 1
     for (int off = 0; off < RS_IMG_BYTES; off += 1024) {
       unsigned keep;
@@ -70,26 +126,53 @@ struct RnnStream {
                    : "v"(src + off), "s"(m0v)
                    : "memory");
     }
+    {  // the READY row: 64 dwords of (use & 1) from the constant rows behind the images (lane * 4 = (lane * 16) / 4)
+      unsigned keep;
+      const char* fsrc = gsrc - lane * 12 + (size_t)RS_NIMG * RS_IMG_BYTES + 256 * (use & 1);
+      const unsigned m0v = __builtin_amdgcn_readfirstlane(flags0() + 256u * (unsigned)slot);
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(fsrc), "s"(m0v)
+                   : "memory");
+    }
   }
-  __device__ __forceinline__ void start(const float* images, float* ring, int cyc_, int nfw_, int total_, int wave_, int lane) {
-    gsrc = (const char*)images + lane * 16;
-    lbase = (char*)ring;
-    lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lbase;
-    n = 0; total = total_; cyc = cyc_; nfw = nfw_; wave = wave_;
+  // WHO issues chunk m: wave m % nwaves.  (Tried: "the first wave that needs it" - one LDS compare-and-swap on a next-chunk
+  // counter - 0.849 against 0.827 ms per epoch: the waits are not caused by a lagging issuer)
+  __device__ __forceinline__ void start() {  // the first chunks of the first phase: forward group, sites 0 ..
     for (int m = 0; m < RS_NSLOT - 1 && m < total; ++m)
-      if (wave == (m & 7)) issue(m);
+      if (wave == (m & wmask)) issue(m, site_image(m));
   }
-  // chunk n is complete in LDS for every wave; returns its image.  ONE workgroup barrier.
-  __device__ __forceinline__ const unsigned short* consume() {
-    if (wave == (n & 7)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the issuing wave's DMA has landed
-    __syncthreads();
-    const int ahead = n + RS_NSLOT - 1;  // its slot held chunk n - 1, which every wave left before this barrier
-    if (ahead < total && wave == (ahead & 7)) issue(ahead);
-    const unsigned short* r = (const unsigned short*)(lbase + (size_t)(n % RS_NSLOT) * RS_IMG_BYTES);
+  // the image of chunk n (GEMM site S of the current phase), complete in LDS
+  template <int S>
+  __device__ __forceinline__ const unsigned short* consume(bool bwd) {
+#ifdef ORL_RS_NODMA  // TIMING experiment only (wrong results): every GEMM reads whatever the first fill left in its slot
+    cur = n & (RS_NSLOT - 1);
     ++n;
-    return r;
+    (void)bwd;
+    return (const unsigned short*)(lbase + (size_t)cur * RS_IMG_BYTES);
+#endif
+    const int ahead = n + RS_NSLOT - 1;
+    if (ahead < total && wave == (ahead & wmask)) issue(ahead, ahead_image<S>(bwd));
+    cur = n & (RS_NSLOT - 1);
+    const unsigned want = (unsigned)((n / RS_NSLOT) & 1);
+    const unsigned fa = flags0() + 256u * (unsigned)cur + 4u * (unsigned)lane;
+    int spins = 0;
+#pragma nounroll
+    while (__builtin_amdgcn_ballot_w64(rs_lds_peek(fa) == want) != ~0ull) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > RS_SPIN_LIMIT) { dead = 1; break; }
+    }
+    ++n;
+    return (const unsigned short*)(lbase + (size_t)cur * RS_IMG_BYTES);
+  }
+  // this wave is done with the chunk of the last consume()
+  __device__ __forceinline__ void release() {
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(done0() + 4u * (unsigned)cur), "v"(1u) : "memory");
+    else asm volatile("" ::: "memory");
   }
 };
+static_assert((RS_NSLOT & (RS_NSLOT - 1)) == 0 && RS_NSLOT <= 8, "ring slots: a power of two, at most 8");
 
 template <int HEAD, int NO>
 __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const float* __restrict__ images, const int bid,
@@ -98,7 +181,10 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
   const RnnLayout tl(A.net);
   constexpr bool HMM = HEAD == ORL_HEAD_CATEGORICAL && NO > 4;
   const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HMM, true);
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  // the wave index as a SCALAR (readfirstlane): everything derived from it - the wave's tile, tile_ok, its DMA turns - is
+  // then wave-uniform for the compiler too (s_cbranch instead of exec masking around every predicated store)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int l = threadIdx.x & 63, j = l & 15, q = l >> 4;
   const int D = A.net.obs_dim, n_out = A.net.n_out, DP = tw.DP;
   const int Nc = A.Nc, L = A.L;
   const orl_ppo_hparams hp = A.hp;
@@ -112,7 +198,9 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
   int n_iter = 0;
   if (bid * nwv < n_tiles) n_iter = (n_tiles - bid * nwv + per - 1) / per;
   RnnStream st_w;
-  st_w.start(images, smem + tw.total, 7 * (L - 1) + 14 * L, 7 * (L - 1), n_iter * (7 * (L - 1) + 14 * L), wave, l);
+  st_w.init(images, smem + tw.total, n_iter * (7 * (L - 1) + 14 * L), wave, l, nwv);
+  __syncthreads();  // flag rows / counters initialised before the first DMA may land in them
+  st_w.start();
   stage_rnn_tower(smem, A.theta, tl, tw, threadIdx.x, blockDim.x, HMM, true);
   __syncthreads();
   const float* lw = smem;
@@ -128,15 +216,35 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
   float a_dls[NO];
 #pragma unroll
   for (int c = 0; c < NO; ++c) a_dls[c] = 0.f;
+#ifdef ORL_PROF
+  __shared__ unsigned long long rprof_lds[16];
+  const bool prof_on = blockIdx.x == 0 && wave == 0;
+  if (prof_on && l < 16) rprof_lds[l] = 0ull;
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
 
   // acc += image x (forward) / image^T x (backward) for the next image of the stream; xs = split_T of the operand
-  auto gemm = [&](const u32x4 (&xs)[2][3], f32x4 (&acc)[4]) { mm64_T_split(st_w.consume(), xs, acc, j, q); };
-  auto gemm_t = [&](const u32x4 (&xs)[2][3], f32x4 (&acc)[4]) { mm64_T_split_tr(st_w.consume(), xs, acc, j, q); };
+  // `site` (GtIdx<S>): the GEMM's position in the phase's image schedule (RnnStream::site_image); bwd_phase: the current
+  // phase is a BPTT step (set at the top of the phase loop)
+  bool bwd_phase = false;
+  auto gemm = [&](auto site, const u32x4 (&xs)[2][3], f32x4 (&acc)[4]) {
+    mm64_T_split(st_w.template consume<decltype(site)::value>(bwd_phase), xs, acc, j, q);
+    st_w.release();
+  };
+  auto gemm_t = [&](auto site, const u32x4 (&xs)[2][3], f32x4 (&acc)[4]) {
+    mm64_T_split_tr(st_w.template consume<decltype(site)::value>(bwd_phase), xs, acc, j, q);
+    st_w.release();
+  };
 
   for (int it = 0; it < n_iter; ++it) {
     int tile = it * per + bid * nwv + wave;
+#ifdef ORL_RS_NOTAPE  // TIMING experiment only (wrong results): no tape / state-tape stores at all
+    const bool tile_ok = false;
+    if (tile >= n_tiles) tile = n_tiles - 1;
+#else
     const bool tile_ok = tile < n_tiles;  // ragged last group: the wave shadows the last tile - all loads, NO stores,
     if (!tile_ok) tile = n_tiles - 1;     // and its loss statistics are dropped below
+#endif
     const LossStats st_keep = st;
     float dls_keep[NO];
 #pragma unroll
@@ -177,7 +285,7 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
       {
         u32x4 xs[2][3];
         split_T(n1, xs);
-        gemm(xs, xh2);  // W2
+        gemm(GtIdx<0>{}, xs, xh2);  // W2
       }
       ln_normalize_T(xh2, rstd2);
       ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, n2);
@@ -199,16 +307,16 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
       {
         u32x4 xs[2][3];
         split_T(x, xs);
-        gemm(xs, r);
-        gemm(xs, z);
-        gemm(xs, n);
+        gemm(GtIdx<1>{}, xs, r);
+        gemm(GtIdx<2>{}, xs, z);
+        gemm(GtIdx<3>{}, xs, n);
       }
       {
         u32x4 xs[2][3];
         split_T(hin, xs);
-        gemm(xs, r);
-        gemm(xs, z);
-        gemm(xs, ghn);
+        gemm(GtIdx<4>{}, xs, r);
+        gemm(GtIdx<5>{}, xs, z);
+        gemm(GtIdx<6>{}, xs, ghn);
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -224,43 +332,28 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
         }
     };
 
-    long long row_c = A.rows[cis];
+    // ONE loop over the 2 L - 1 step phases of a tile - forward-only steps s = 0 .. L-2 (the hidden state entering every step
+    // goes to htape), then the BPTT steps s = L-1 .. 0 with the forward recomputed - so that the forward code (trunk, GRU:
+    // 7 GEMM sites, 3 operand splits, the gates) exists ONCE in the kernel.  With a separate forward sweep the tile loop
+    // was ~64 KB of instructions per tower body: it did not fit the 64 KB instruction cache two CUs share, and every GEMM
+    // took 3 700 - 5 000 cycles instead of ~1 000 (profiles/r04_rnn_phase_prof.txt).
+    // `state`: the running hidden state during the forward phases, the gradient carried back in time (dt * z + Whh^T ...)
+    // during the backward phases - never both.
+    auto step_of = [&](int ph) -> int { return ph >= L - 1 ? 2 * L - 2 - ph : ph; };
+    const int n_ph = 2 * L - 1;
+    long long row_c = A.rows[(size_t)step_of(0) * Nc + cis];
     float mk_c = A.masks[row_c];
-
-    // ---------------- forward sweep: hidden state entering every step -> htape ----------------
+    f32x4 state[4];
     {
-      f32x4 h[4];
-      const float* h0 = A.hbuf + (size_t)row_c * HID;
+      const float* h0 = A.hbuf + (size_t)row_c * HID;  // (L > 1: the row of step 0; L == 1: the only row)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(h0 + 16 * m + 4 * q);
-      for (int s = 0; s < L; ++s) {
-        if (tile_ok) {
-          float* ht = A.htape + ((size_t)tile * L + s) * TV;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) *(f32x4*)(ht + (m * 64 + l) * 4) = h[m];
-        }
-        if (s == L - 1) break;
-        float xv_c[16];
-        load_x(A.records + (size_t)row_c * A.R, xv_c);
-        const long long row_n = A.rows[(size_t)(s + 1) * Nc + cis];
-        const float mk_n = A.masks[row_n];
-        f32x4 hin[4], xh1[4], xh2[4], n2[4], r[4], z[4], n[4], g[4];
-        float r1, r2;
-        unsigned rb;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) hin[m] = h[m] * mk_c;
-        trunk(xv_c, xh1, r1, rb, xh2, r2, n2);
-        gru(n2, hin, r, z, n, g, h);
-        row_c = row_n;
-        mk_c = mk_n;
-      }
+      for (int m = 0; m < 4; ++m) state[m] = *(const f32x4*)(h0 + 16 * m + 4 * q);
     }
-
-    // ---------------- backward sweep (BPTT), forward recomputed per step ----------------
-    f32x4 carry[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) carry[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = L - 1; s >= 0; --s) {
+#pragma unroll 1
+    for (int ph = 0; ph < n_ph; ++ph) {
+      const bool bwd = ph >= L - 1;
+      bwd_phase = bwd;
+      const int s = step_of(ph);
       const long long row = row_c;
       const float* rec = A.records + (size_t)row * A.R;
       const float mk = mk_c;
@@ -290,31 +383,54 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
       // a shadowing wave (ragged last group) must not touch the tape: every store below is predicated on tile_ok
       float* tb = A.tape + ((size_t)tile * L + s) * BLK;
       f32x4 hin[4];
-      {
+      if (bwd && s < L - 1) {  // the state entering step s, left by the forward phases
         const float* ht = A.htape + ((size_t)tile * L + s) * TV;
 #pragma unroll
         for (int m = 0; m < 4; ++m) hin[m] = *(const f32x4*)(ht + (m * 64 + l) * 4) * mk;
+      } else {                 // forward phases, and the first backward step (s = L - 1): the running state
+        if (!bwd && tile_ok) {
+          float* ht = A.htape + ((size_t)tile * L + s) * TV;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) *(f32x4*)(ht + (m * 64 + l) * 4) = state[m];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hin[m] = state[m] * mk;
+        if (bwd) {             // from here on `state` is the carried gradient
+#pragma unroll
+          for (int m = 0; m < 4; ++m) state[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
-      if (s > 0) {
-        row_c = A.rows[(size_t)(s - 1) * Nc + cis];
+      if (ph + 1 < n_ph) {  // the next phase's row and mask, one phase ahead
+        row_c = A.rows[(size_t)step_of(ph + 1) * Nc + cis];
         mk_c = A.masks[row_c];
       }
-      if (tile_ok) tape_store(tb + TV_HIN * TV, hin, j, q);
+      RNN_T(1);  // step inputs: record / state-tape loads
+      if (bwd && tile_ok) tape_store(tb + TV_HIN * TV, hin, j, q);
       float rstd1, rstd2, rstd3;
       unsigned relu_bits;
       f32x4 gr[4], gz[4], gn[4], ghn[4];
       float dh[NO], dls[NO];
       f32x4 dhv = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 xh3[4];  // xhat3 stays in registers from LN3 to its backward (head + loss in between: low pressure) - its
+                     // reload from the tape queued behind the tape stores just issued (vmcnt returns in order)
       {
         f32x4 xh1[4], xh2[4], n2[4], hnew[4];
         trunk(xv, xh1, rstd1, relu_bits, xh2, rstd2, n2);
-        if (tile_ok) {
+        if (bwd && tile_ok) {
           tape_store(tb + TV_XH1 * TV, xh1, j, q);
           tape_store(tb + TV_XH2 * TV, xh2, j, q);
         }
+        RNN_T(2);  // trunk (fc1 + W2) + tape stores
         gru(n2, hin, gr, gz, gn, ghn, hnew);
+        RNN_T(3);  // GRU forward: 6 GEMMs + gates
+        if (!bwd) {  // a forward-only phase ends here: the new state enters step s + 1
+#pragma unroll
+          for (int m = 0; m < 4; ++m) state[m] = hnew[m];
+        } else {
         ln_normalize_T(hnew, rstd3);  // hnew = xhat3
         if (tile_ok) tape_store(tb + TV_XH3 * TV, hnew, j, q);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xh3[m] = hnew[m];
         f32x4 n3[4];
         ln_affine_T(hnew, lw + tw.g3, lw + tw.be3, q, n3);
         if constexpr (HMM) {
@@ -337,7 +453,10 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
             for (int c = 0; c < NO; ++c) a_dls[c] += dls[c];
           }
         }
+        }  // bwd: LN3, head, loss
       }
+      if (bwd) {  // ---- the backward half of a BPTT step
+      RNN_T(4);  // LN3, head, loss
       if (tile_ok) {
         // head deltas and the observation tile -> tape
         f32x4 dv = {0.f, 0.f, 0.f, 0.f};
@@ -377,19 +496,13 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
           }
         }
       }
-      // xhat3 / xhat2 / xhat1 come back from the tape (through a laundered pointer, as in rnn_row_body: otherwise the
-      // stored registers are forwarded to these loads and 48 VGPRs stay live across the GRU).  A shadowing wave reads
-      // whatever the tile's owner has or has not written there - its results are dropped.
-      {
-        const float* tbr = tb;
-        asm volatile("" : "+v"(tbr));
-        f32x4 xh3[4];
+      // (xhat2 / xhat1 come back from the tape further down, through a laundered pointer as in rnn_row_body: otherwise the
+      // stored registers are forwarded to those loads and 32 VGPRs stay live across the GRU.  A shadowing wave reads
+      // whatever the tile's owner has or has not written there - its results are dropped.)
+      ln_bwd_rnn(dt, xh3, lw + tw.g3, rstd3, q);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xh3[m] = *(const f32x4*)(tbr + TV_XH3 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
-        ln_bwd_rnn(dt, xh3, lw + tw.g3, rstd3, q);
-      }
-#pragma unroll
-      for (int m = 0; m < 4; ++m) dt[m] += carry[m];
+      for (int m = 0; m < 4; ++m) dt[m] += state[m];
+      RNN_T(5);  // dhead / obs tape, W3^T dhead, LN3 backward
       // GRU cell backward (element-wise part): gr/gz/gn/ghn become dr/dz/dn/dghn, carry collects dt * z
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -403,7 +516,7 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
           gz[m][k] = dz_pre;
           gn[m][k] = dn_pre;
           ghn[m][k] = dn_pre * rr;
-          carry[m][k] = d * zz;
+          state[m][k] = d * zz;
         }
       if (tile_ok) {
         tape_store(tb + TV_DR * TV, gr, j, q);
@@ -411,34 +524,36 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
         tape_store(tb + TV_DN * TV, gn, j, q);
         tape_store(tb + TV_DGHN * TV, ghn, j, q);
       }
-      // dgrad: carry += Whh^T [dr dz dghn], dn2 = Wih^T [dr dz dn]; stream order Whh_r Wih_r Whh_z Wih_z Whh_n Wih_n
+      RNN_T(6);  // GRU elementwise backward + 4 tape vectors
+      // dgrad: state (the carried gradient) += Whh^T [dr dz dghn], dn2 = Wih^T [dr dz dn]; stream order Whh_r Wih_r Whh_z Wih_z Whh_n Wih_n
       f32x4 d2[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) d2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       {
         u32x4 xs[2][3];
         split_T(gr, xs);
-        gemm_t(xs, carry);
-        gemm_t(xs, d2);
+        gemm_t(GtIdx<7>{}, xs, state);
+        gemm_t(GtIdx<8>{}, xs, d2);
       }
       {
         u32x4 xs[2][3];
         split_T(gz, xs);
-        gemm_t(xs, carry);
-        gemm_t(xs, d2);
+        gemm_t(GtIdx<9>{}, xs, state);
+        gemm_t(GtIdx<10>{}, xs, d2);
       }
       {
         u32x4 xs[2][3];
         split_T(ghn, xs);
-        gemm_t(xs, carry);
+        gemm_t(GtIdx<11>{}, xs, state);
       }
       {
         u32x4 xs[2][3];
         split_T(gn, xs);
-        gemm_t(xs, d2);
+        gemm_t(GtIdx<12>{}, xs, d2);
       }
 #pragma unroll
-      for (int m = 0; m < 4; ++m) carry[m] = carry[m] * mk;  // h_in = h * mask
+      for (int m = 0; m < 4; ++m) state[m] = state[m] * mk;  // h_in = h * mask
+      RNN_T(7);  // GRU dgrad: 6 transposed GEMMs
       {
         const float* tbr = tb;
         asm volatile("" : "+v"(tbr));
@@ -454,7 +569,7 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
       {
         u32x4 xs[2][3];
         split_T(d2, xs);
-        gemm_t(xs, d1);  // W2^T
+        gemm_t(GtIdx<13>{}, xs, d1);  // W2^T
       }
       {
         const float* tbr = tb;
@@ -470,6 +585,8 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
         for (int r = 0; r < 4; ++r)
           if (!((relu_bits >> (4 * m + r)) & 1u)) d1[m][r] = 0.f;
       if (tile_ok) tape_store(tb + TV_DZ1 * TV, d1, j, q);
+      RNN_T(8);  // LN2 backward, W2 dgrad, LN1 / relu backward, tapes
+      }  // if (bwd)
     }
     if (!tile_ok) {  // a shadowing wave contributes nothing
       st = st_keep;
@@ -478,6 +595,12 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
     }
   }
 
+#ifdef ORL_PROF
+  if (prof_on && l < 12) atomicAdd(&g_rnn_prof[l], rprof_lds[l]);
+  if (prof_on && l == 12) atomicAdd(&g_rnn_prof[12], 1ull);
+  if (prof_on && l == 13) atomicAdd(&g_rnn_prof[13], (unsigned long long)n_iter);
+#endif
+  if (st_w.dead) st.loss = u2f(0x7fc00000u);  // a stream wait timed out (RnnStream::dead): NaN into train_info
   // ---- workgroup reduction of {dlogstd, stats}: fixed order (as rnn_row_body) ----
   __syncthreads();
   float* acc = smem;  // the resident image is dead, the ring has no DMA in flight (every issued chunk was consumed)
@@ -508,10 +631,14 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
   for (int e = threadIdx.x; e < PW; e += blockDim.x) A.partials[(size_t)bid * PW + e] = acc[e];
 }
 
-// blocks [0, split) = policy tower, [split, gridDim) = critic tower
-template <int HEADP, int NOP>
-__global__ __launch_bounds__(512, 2) void rnn_row_pair_stream_kernel(RnnRowArgs P, RnnRowArgs Cc, const float* img_p,
-                                                                     const float* img_c, int split) {
+// blocks [0, split) = policy tower, [split, gridDim) = critic tower.  NW = 8: two waves per SIMD, 256 registers each;
+// NW = 4: ONE wave per SIMD with the whole 512-entry register budget (256 VGPRs + 256 AccVGPRs the allocator spills into
+// instead of scratch memory) - the row kernel's hot loop has ~170 live vector registers per wave before address
+// arithmetic, and a scratch reload is a VMEM operation that queues behind the tape stores (vmcnt is in order)
+template <int HEADP, int NOP, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void rnn_row_pair_stream_kernel(RnnRowArgs P, RnnRowArgs Cc,
+                                                                                    const float* img_p,
+                                                                                    const float* img_c, int split) {
   if ((int)blockIdx.x < split) rnn_row_body_stream<HEADP, NOP>(P, img_p, blockIdx.x, split);
   else rnn_row_body_stream<ORL_HEAD_VALUE, 1>(Cc, img_c, blockIdx.x - split, gridDim.x - split);
 }

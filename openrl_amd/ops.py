@@ -327,8 +327,15 @@ def rollout_fused(pnet, ptheta, cnet, ctheta, args: RolloutArgs, next_value) -> 
     nat.check(rc, "orl_rollout_fused")
 
 
-def make_hparams(cfg) -> PPOHParams:
-    """cfg flags -> orl_ppo_hparams (defaults: SURVEY.md section 5.6)."""
+def make_hparams(cfg, recurrent: bool = False) -> PPOHParams:
+    """cfg flags -> orl_ppo_hparams (defaults: SURVEY.md section 5.6).  ``recurrent``: the GEMM-path bits of ``reserved``
+    come from ``amd_rnn_gemm`` (the recurrent row kernel) instead of ``amd_tower_gemm`` (the feed-forward tower pair)."""
+    tower = str(getattr(cfg, "amd_tower_gemm", "split"))
+    if recurrent:
+        rnn = "fp32" if tower == "fp32" else str(getattr(cfg, "amd_rnn_gemm", "fp32"))
+        gemm_bits = {"fp32": 4, "split": 0, "split_w4": 16}[rnn]
+    else:
+        gemm_bits = {"fp32": 4, "split_two_image": 8}.get(tower, 0)
     return PPOHParams(clip_param=float(cfg.clip_param), entropy_coef=float(cfg.entropy_coef),
                       value_loss_coef=float(cfg.value_loss_coef), huber_delta=float(cfg.huber_delta),
                       dual_clip_coeff=float(cfg.dual_clip_coeff), max_grad_norm=float(cfg.max_grad_norm),
@@ -338,4 +345,4 @@ def make_hparams(cfg) -> PPOHParams:
                       use_policy_active_masks=int(bool(cfg.use_policy_active_masks)),
                       use_valuenorm=int(bool(cfg.use_valuenorm or cfg.use_popart)),
                       dual_clip_ppo=int(bool(cfg.dual_clip_ppo)), use_max_grad_norm=int(bool(cfg.use_max_grad_norm)),
-                      reserved={"fp32": 4, "split_two_image": 8}.get(str(getattr(cfg, "amd_tower_gemm", "split")), 0))
+                      reserved=gemm_bits)

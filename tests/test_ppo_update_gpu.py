@@ -338,7 +338,7 @@ def test_single_update_at_baseline_shapes_vs_oracle(D, kind, n_act, N, T, masks)
     np.testing.assert_allclose(algo._info[:6].cpu().numpy(), want, rtol=3e-4, atol=3e-5)
 
 
-def _full_general_engine(g, perm_mode):
+def _full_general_engine(g, perm_mode, gemm=None):
     """Engine + buffer of a ``train_cfg{3,4,5}_full`` case (inputs regenerated from the seed, oracle/fixtures.py);
     ``compute_returns`` has run and its probes were checked against the reference's."""
     from openrl_amd import spaces
@@ -351,6 +351,11 @@ def _full_general_engine(g, perm_mode):
     kind = str(g["kind"])
     cfg = H.case_cfg(g)
     cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = T, N, A, cfg.hidden_size
+    if gemm is not None:  # the update kernels' GEMM path: amd_tower_gemm (split | fp32 | split_two_image) for the
+        if gemm in ("split", "fp32", "split_two_image"):  # feed-forward pair, amd_rnn_gemm (fp32 | split | split_w4) for the
+            cfg.amd_tower_gemm = gemm                      # recurrent row kernel
+        if gemm in ("split", "fp32", "split_w4"):
+            cfg.amd_rnn_gemm = gemm
     box = lambda d: spaces.Box(-np.inf, np.inf, (d,))
     obs_space = box(Dp) if Dp == Dc else spaces.Dict({"policy": box(Dp), "critic": box(Dc)})
     act_space = spaces.Discrete(n_act) if kind == "discrete" else spaces.Box(-1, 1, (n_act,))
@@ -374,9 +379,10 @@ def _full_general_engine(g, perm_mode):
     return cfg, module, buf, algo
 
 
-@pytest.mark.parametrize("perm_mode", ["device", "identity", "reference"])
+@pytest.mark.parametrize("perm_mode,gemm", [("device", "split"), ("identity", "split"), ("reference", "split"),
+                                            ("device", "split_two_image"), ("device", "fp32")])
 @pytest.mark.parametrize("case,branch", [("train_cfg3_full", "uneven_split"), ("train_cfg5_full", "back_to_back")])
-def test_full_size_update_other_baseline_shapes_match_reference_golden(case, branch, perm_mode):
+def test_full_size_update_other_baseline_shapes_match_reference_golden(case, branch, perm_mode, gemm):
     """BASELINE.json configs[2] (1024 x 200 rows, obs 17, Box(6)) and configs[4] (4096 x 200, obs 18, Discrete(9) with
     random legal-move masks) at FULL size against the REAL reference's ``compute_returns`` + ``PPOAlgorithm.train``
     (10 epochs; oracle/gen_golden.py::_train_case_full_general).  These are the batches where ``launch_pair_nd``
@@ -386,8 +392,10 @@ def test_full_size_update_other_baseline_shapes_match_reference_golden(case, bra
     per wave."""
     from openrl_amd import ops
 
+    # gemm: the default is round 4's full split through transposing reads of W2's image (+ dW1 on the bf16 MFMA);
+    # split_two_image = round 3's variants (wgrad-only split at these widths), fp32 = every GEMM on the fp32 MFMA
     g = H.load_golden(case)
-    cfg, module, buf, algo = _full_general_engine(g, perm_mode)
+    cfg, module, buf, algo = _full_general_engine(g, perm_mode, gemm)
     grids, orig = [], ops.ppo_fwd_bwd
 
     def spy(*a, **k):

@@ -40,7 +40,7 @@ def _spaces(g):
     return obs_space, act_space
 
 
-def build_engine(g, seed=None):
+def build_engine(g, seed=None, gemm=None):
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers.replay_data import ReplayData
     from openrl_amd.modules.ppo_module import PPOModule
@@ -49,6 +49,8 @@ def build_engine(g, seed=None):
     T, N, A = g["buf_actions"].shape[:3]
     cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents = T, N, A
     cfg.rnn_hidden_size = cfg.hidden_size * (2 if cfg.rnn_type == "lstm" else 1)  # modules/common/ppo_net.py:72-81
+    if gemm is not None:  # the recurrent row kernel's GEMM path (cfg.amd_rnn_gemm: fp32 = default | split | split_w4)
+        cfg.amd_rnn_gemm = gemm
     obs_space, act_space = _spaces(g)
     if seed is not None:
         import random
@@ -71,10 +73,13 @@ def test_recurrent_module_init_is_the_reference_init(case, seed):
     assert sd["rnn.rnn.weight_ih_l0"].shape == (192, 64) and sd["rnn.norm.bias"].shape == (64,)
 
 
+@pytest.mark.parametrize("gemm", ["split", "fp32", "split_w4"])
 @pytest.mark.parametrize("case", RH.RNN_CASES)
-def test_recurrent_train_matches_reference_golden(case):
+def test_recurrent_train_matches_reference_golden(case, gemm):
+    """gemm: the row kernel's GEMM path (cfg.amd_rnn_gemm) - the fp32-MFMA kernel (default) and the streamed bf16-split
+    build with 8 or (split_w4) 4 waves per workgroup; all three must land on the reference's update."""
     g = H.load_golden(case)
-    cfg, module, buf, algo = build_engine(g)
+    cfg, module, buf, algo = build_engine(g, gemm=gemm)
     module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
     module.models["critic"].theta.copy_(torch.tensor(g["theta_c0"]))
     for f in ("policy_obs", "critic_obs", "actions", "action_log_probs", "value_preds", "returns", "rewards", "masks",
@@ -431,8 +436,9 @@ def test_shared_recurrent_network_matches_reference_golden():
     np.testing.assert_allclose(buf.rnn_states_critic.cpu().numpy(), g["buf_rnn_states_critic"], rtol=3e-4, atol=3e-5)
 
 
-@pytest.mark.parametrize("perm_mode", ["device", "identity", "reference"])
-def test_full_size_recurrent_update_matches_reference_golden(perm_mode):
+@pytest.mark.parametrize("perm_mode,gemm", [("device", "split"), ("identity", "split"), ("reference", "split"),
+                                            ("device", "fp32"), ("device", "split_w4")])
+def test_full_size_recurrent_update_matches_reference_golden(perm_mode, gemm):
     """BASELINE.json configs[3] at FULL size: 2048 envs x 3 agents x 25 steps = 153 600 rows = 76 800 chunks of 2 (the
     odd T makes chunks straddle lanes), Dict obs 18 / 54, Discrete(5), GRU, adv-normalise on (examples/mpe/mpe_ppo.yaml),
     3 epochs through the REAL reference's ``recurrent_generator`` + ``PPOAlgorithm.train`` (oracle/gen_golden.py::
@@ -441,7 +447,7 @@ def test_full_size_recurrent_update_matches_reference_golden(perm_mode):
     from tests.test_ppo_update_gpu import _full_general_engine
 
     g = H.load_golden("train_cfg4_full")
-    cfg, module, buf, algo = _full_general_engine(g, perm_mode)
+    cfg, module, buf, algo = _full_general_engine(g, perm_mode, gemm)
     assert algo.recurrent and not algo.generic
     torch.manual_seed(int(g["perm_seed"]))
     algo.prep_training()

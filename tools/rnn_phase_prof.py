@@ -13,7 +13,8 @@ PH = ["forward sweep (per tile)", "step inputs (loads)", "trunk recompute + tape
 def main():
     import torch
     from openrl_amd import _native as nat
-    sys.argv = [sys.argv[0], "--iters", "1", "--warmup", "1", "--epochs", "4"]
+    gemm = sys.argv[1] if len(sys.argv) > 1 else "split"  # split | fp32 | split_w4
+    sys.argv = [sys.argv[0], "--iters", "1", "--warmup", "1", "--epochs", "4", "--tower-gemm", gemm]
     lib = nat.load()
     if not hasattr(lib, "orl_debug_rnn_prof"):
         raise SystemExit("not the timing build")
@@ -24,6 +25,9 @@ def main():
     lib.orl_debug_rnn_prof(out)
     launches = out[12]
     tiles = launches * 4800 // (128 * 8)          # tiles of the probe wave (policy tower: 128 workgroups x 8 waves)
+    if out[13]:                                   # the streamed kernel counts its probe wave's tile iterations itself
+        tiles = out[13]
+    print("row kernel GEMM path:", gemm)
     steps = tiles * 2
     tot = sum(out[k] for k in range(9))
     print("%d launches, ~%d tiles / %d backward steps by the probe wave; %.0f cycles per tile" % (launches, tiles, steps, tot / max(tiles, 1)))
