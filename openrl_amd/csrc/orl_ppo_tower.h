@@ -265,7 +265,13 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // the phase profile).  An asm statement is invisible to that bookkeeping; the one wait this pipeline needs is the
   // explicit vmcnt(0) at the top of the tile loop, a whole tile after the issue (guide section 5.7: M0 is written in
   // the same statement that reads it; the s_nop covers the SALU-write -> M0 use hazard).
+#ifdef ORL_TOWER_NODMA  // TIMING experiment only (wrong results): what does the record fetch cost the tile loop?
+  int dma_calls = 0;
+#endif
   auto issue_dma = [&](float* slot, long long row) {
+#ifdef ORL_TOWER_NODMA
+    if (dma_calls++ >= 2) return;  // the two ring slots are filled once, every later tile re-reads them
+#endif
     const float* src = A.records + (size_t)row * A.R;
 #pragma unroll 1
     for (int g = 0; 4 * g < nch; ++g) {
