@@ -7,16 +7,16 @@ namespace orl {
 // backward: one 8-wave workgroup per CU (256 VGPRs per wave); forward: 8-wave workgroups at <= 128 VGPRs and ~75 KB of
 // LDS, TWO per CU, so that one's barrier / LDS waits overlap the other's MFMAs
 // Round 4: the backward launch ships as 4-wave workgroups, ONE per CU, 512 registers per wave (ORL_GT_BWD_WAVES = 4,
-// ORL_GT_BWD_MINWAVES = 1) wherever its LDS fits 80 KB: the 8-wave / 256-register build spilled 121 - 177 VGPRs and moved
-// 221 MB in + 394 MB out of HBM per launch as scratch (profiles/r03_pmc_gen_fused_hbm.txt, 15x the algorithmic traffic)
-// for the SAME time (12.65 vs 12.65 ms per iteration at hidden 128, profiles/r04_generic_lines.jsonl) - the policy and
-// critic chains run on two streams and, multi-GPU, beside peer pushes, where 1.2 GB of scratch per epoch pair is not free.
-// -DORL_GT_BWD_WAVES=8 -DORL_GT_BWD_MINWAVES=2 rebuilds round 3's.
+// ORL_GT_BWD_MINWAVES = 1: no scratch traffic) wherever its LDS fits ORL_GT_BWD_LDS_CAP_KB (gt_bwd_waves below has the
+// measurements that set the cap); -DORL_GT_BWD_WAVES=8 -DORL_GT_BWD_MINWAVES=2 rebuilds round 3's.
 #ifndef ORL_GT_BWD_MINWAVES
 #define ORL_GT_BWD_MINWAVES 1
 #endif
 #ifndef ORL_GT_BWD_WAVES
 #define ORL_GT_BWD_WAVES 4
+#endif
+#ifndef ORL_GT_BWD_LDS_CAP_KB
+#define ORL_GT_BWD_LDS_CAP_KB 80
 #endif
 template <int H, int NL, int ND, int NW>
 __global__ __launch_bounds__(NW * 64, ORL_GT_BWD_MINWAVES) void gt_bwd_kernel(GtArgs A) {
@@ -223,7 +223,14 @@ static size_t gt_lds_bytes(const GtLay& ly, int bwd_waves) {
 // slower, 531 vs 495 us: twice the G accumulators per wave, 169 spilled VGPRs; with the whole register file per wave the
 // 4-wave form costs the same time as the 8-wave one and spills nothing.)
 static int gt_bwd_waves(const GtLay& ly) {
-  return (ORL_GT_BWD_WAVES == 4 && gt_lds_bytes(ly, 4) <= 80 * 1024) ? 4 : 8;
+  // ORL_GT_BWD_LDS_CAP_KB: towers whose 4-wave LDS footprint exceeds it take the 8-wave build.  Measured (round 4, same box,
+  // profiles/r04_experiments.md): hidden 64 (<= 80 KB) - both forms the same time, so the scratch-free 4-wave form ships;
+  // hidden 128 (85 KB) - 4 waves 13.69 ms per iteration with 37 + 21 MB of HBM traffic per backward launch, 8 waves 12.69 ms
+  // with 221 + 394 MB (its 121 - 177 spilled VGPRs): the spilling build is 8 % FASTER there and stays the default;
+  // -DORL_GT_BWD_LDS_CAP_KB=160 ships the scratch-free form everywhere.  (Round 3's "no-spill variant, same time" at hidden
+  // 128 compared the 8-wave kernel with itself: the 80 KB bound of the two-workgroups-per-CU form had been left in.)
+  const size_t cap = (size_t)ORL_GT_BWD_LDS_CAP_KB * 1024;
+  return (ORL_GT_BWD_WAVES == 4 && gt_lds_bytes(ly, 4) <= cap) ? 4 : 8;
 }
 
 static int gt_check(const orl_gt_desc* d, const char* who) {

@@ -10,6 +10,8 @@ pair kernel holds two bodies (policy, critic), each with one tile loop.  For eve
 k-1 and marker k INSIDE the tile loop are attributed to phase k (phase 0 = loop top .. marker 0) and classified:
 MFMA / VALU (other v_*) / LDS (ds_*) / VMEM (global_, buffer_, scratch_) / SALU (s_* except s_waitcnt, s_nop, s_barrier) /
 WAIT (s_waitcnt).  Scratch traffic inside the loop is listed separately (= spills actually paid per tile).
+The markers order the phases but are no scheduling barriers for register-only instructions: hipcc moves e.g. an operand
+split into the neighbouring phase, so single rows are +-40 instructions - the TOTAL per tile is exact.
 Runs on the CPU; needs no GPU."""
 import re
 import sys
@@ -108,7 +110,9 @@ def main():
         for b, body in enumerate(bodies(kl)):
             tab = budget(kl, body)
             cols = ["VALU", "MFMA", "LDS", "SALU", "WAIT", "VMEM", "SCRATCH", "CTRL"]
-            print("  body %d (%s tower)" % (b, "policy" if b == 0 else "critic"))
+            # (hipcc lays the `else` branch of the pair kernel out first: judge the tower by its loss / head rows - the value
+            # head's loss is ~55 VALU, a categorical head's 100 - 280)
+            print("  body %d (in ISA order)" % b)
             print("    %-24s" % "phase" + "".join("%8s" % c for c in cols))
             tot = dict.fromkeys(cols, 0)
             for k, cnt in tab.items():
