@@ -104,14 +104,22 @@ def multi_gpu_report(trainer, args, dev, world, rank, make_engine):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return round(float(t.item()), 2)
 
+    # Every rank runs the SAME sequence of collectives below whatever happens locally (a diagnostic that throws on one rank
+    # only would leave the others inside a collective): failures are recorded as strings, never raised - except the comm's
+    # error word, which must fail the run.
     vec = torch.zeros(n, dtype=torch.float32, device=dev)
     comm = getattr(trainer, "_comm", None)
     if comm is not None:
-        rep["orl_allreduce_small_us"] = timed(lambda: comm.allreduce_(vec))
-        comm.check()
+        try:
+            rep["orl_allreduce_small_us"] = timed(lambda: comm.allreduce_(vec))
+        except Exception as e:  # noqa: BLE001
+            rep["orl_allreduce_small_us"] = "error: %s" % (e,)
     else:
         rep["orl_allreduce_small_us"] = None
-    rep["torch_all_reduce_us"] = timed(lambda: torch.distributed.all_reduce(vec))
+    try:
+        rep["torch_all_reduce_us"] = timed(lambda: torch.distributed.all_reduce(vec))
+    except Exception as e:  # noqa: BLE001
+        rep["torch_all_reduce_us"] = "error: %s" % (e,)
     rep["latency_note"] = ("%d back-to-back calls, host clock around the loop, max over ranks; the fused path carries the same "
                            "exchange INSIDE the reduce/apply launches (no extra launch)" % reps)
     # the comm's device error word on every rank: one MAX all-reduce, then fail loudly
@@ -122,27 +130,34 @@ def multi_gpu_report(trainer, args, dev, world, rank, make_engine):
         raise SystemExit("orl_comm error word set on some rank (%d): a peer's contribution timed out - the timed run summed "
                          "partial gradients" % int(err.item()))
     if args.scaling == "strong" and not args.no_weak_leg:
-        # weak scaling next to the strong number: the full 4096 envs on EVERY rank, a short run of the same loop
-        drv_w, trainer_w = make_engine(args.envs)
-        k = max(2, min(args.steps, 8))
-        for i in range(2):
-            drv_w.episode = i
-            drv_w._inner_loop()
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(k):
-            drv_w.episode = 2 + i
-            drv_w._inner_loop()
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        if getattr(trainer_w, "_comm", None) is not None:
-            trainer_w._comm.check()
-        rep["weak_scaling"] = {"value": round(args.envs * world * T_ROLL * k / float(t.item()), 1), "unit": "env-steps/s",
-                               "envs_per_gpu": args.envs, "steps": k, "ms_per_step": round(float(t.item()) / k * 1e3, 4)}
+        try:
+            rep["weak_scaling"] = _weak_leg(args, dev, world, make_engine)
+        except Exception as e:  # noqa: BLE001 - the strong-scaling line must survive a failing extra
+            rep["weak_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return rep
+
+
+def _weak_leg(args, dev, world, make_engine):
+    """Weak scaling next to the strong number: the full 4096 envs on EVERY rank, a short run of the same loop."""
+    drv_w, trainer_w = make_engine(args.envs)
+    k = max(2, min(args.steps, 8))
+    for i in range(2):
+        drv_w.episode = i
+        drv_w._inner_loop()
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(k):
+        drv_w.episode = 2 + i
+        drv_w._inner_loop()
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    if getattr(trainer_w, "_comm", None) is not None:
+        trainer_w._comm.check()
+    return {"value": round(args.envs * world * T_ROLL * k / float(t.item()), 1), "unit": "env-steps/s",
+            "envs_per_gpu": args.envs, "steps": k, "ms_per_step": round(float(t.item()) / k * 1e3, 4)}
 
 
 def main():
