@@ -82,6 +82,17 @@ __device__ __forceinline__ void split_weight_store(unsigned short* __restrict__ 
   img[wb_off(2, o, h, q) + sl] = (unsigned short)(f2u(l1) >> 16);
 }
 
+// two neighbouring reduction indices k (even), k + 1 of row o at once: their slots are adjacent, so each part is ONE dword
+// store (pack_hi16) instead of two sub-dword ones - half the LDS store instructions of an image's staging
+__device__ __forceinline__ void split_weight_store2(unsigned short* __restrict__ img, int o, int k, float w0, float w1) {
+  const int m = k >> 4, q = (k >> 2) & 3, r = k & 3, h = m >> 1, sl = (m & 1) * 4 + r;  // r is 0 or 2
+  const float r0 = w0 - u2f(f2u(w0) & 0xffff0000u), r1 = w1 - u2f(f2u(w1) & 0xffff0000u);
+  const float s0 = r0 - u2f(f2u(r0) & 0xffff0000u), s1 = r1 - u2f(f2u(r1) & 0xffff0000u);
+  *(unsigned*)(img + wb_off(0, o, h, q) + sl) = pack_hi16(w0, w1);
+  *(unsigned*)(img + wb_off(1, o, h, q) + sl) = pack_hi16(r0, r1);
+  *(unsigned*)(img + wb_off(2, o, h, q) + sl) = pack_hi16(s0, s1);
+}
+
 // the B fragments of a T-layout activation tile: xs[h][part]
 __device__ __forceinline__ void split_T(const f32x4 (&in)[4], u32x4 (&xs)[2][3]) {
 #pragma unroll
@@ -303,11 +314,19 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
   if (split) {  // bf16 images: fc2's A = W2 (rows o, reduction over i), dgrad's A = W2^T (rows i, reduction over o)
     unsigned short* b2 = (unsigned short*)(lds + tw.W2);
     unsigned short* b2t = (unsigned short*)(lds + tw.W2T);
-    for (int e = tid; e < HID * HID; e += nthreads) {
-      const int o = e >> 6, i = e & 63;
-      const float w = theta[tl.oW2 + e] * (fold ? theta[tl.og1 + i] : 1.f);
-      split_weight_store(b2, o, i, w);
-      if (with_w2t) split_weight_store(b2t, i, o, w);
+    // one 2 x 2 block of W2 per thread and trip: its two row pairs are dword stores of W2's image, its two column pairs dword
+    // stores of the transposed image (split_weight_store2) - no sub-dword LDS store in the staging
+    for (int b = tid; b < (HID / 2) * (HID / 2); b += nthreads) {
+      const int o = 2 * (b >> 5), i = 2 * (b & 31);
+      const float g0 = fold ? theta[tl.og1 + i] : 1.f, g1v = fold ? theta[tl.og1 + i + 1] : 1.f;
+      const float w00 = theta[tl.oW2 + o * HID + i] * g0, w01 = theta[tl.oW2 + o * HID + i + 1] * g1v;
+      const float w10 = theta[tl.oW2 + (o + 1) * HID + i] * g0, w11 = theta[tl.oW2 + (o + 1) * HID + i + 1] * g1v;
+      split_weight_store2(b2, o, i, w00, w01);
+      split_weight_store2(b2, o + 1, i, w10, w11);
+      if (with_w2t) {
+        split_weight_store2(b2t, i, o, w00, w10);
+        split_weight_store2(b2t, i + 1, o, w01, w11);
+      }
     }
   } else
   for (int e = tid; e < HID * HID; e += nthreads) {

@@ -17,6 +17,12 @@
 #ifndef ORL_ND_REM         // build-time experiment: remainder columns (D - 16 ND, up to this many) of dW1 on the VALU; 0 = a
 #define ORL_ND_REM 4       // whole extra 16-column MFMA block instead (D = 17..20 take the ND = 2 build)
 #endif
+// cost of a wide-head policy tile relative to a critic tile (the side-by-side CU split follows it).  Round 2 measured 1.24
+// on the fp32-GEMM builds; with the full split under the wide towers the head's fp32 MFMAs weigh less - re-measured at the
+// cfg3 shape (pair launch, two alternations on one box): 1.24 -> 155.9 us, 1.15 -> 154.8, 1.10 -> 154.1
+#ifndef ORL_PAIR_WP_WIDE
+#define ORL_PAIR_WP_WIDE 1.10
+#endif
 #ifndef ORL_TOWER_TR_ND0   // build-time experiment: the same for the small-observation build (it fits both images anyway)
 #define ORL_TOWER_TR_ND0 0
 #endif
@@ -112,14 +118,15 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
     //    reduction) is paid twice in sequence;
     //  * side by side: the CUs are split between the towers (both resident from the first cycle, one prologue /
     //    epilogue per launch), each wave loops over about twice as many tiles.  The split follows the towers' cost per
-    //    tile (single-tower launches at the three BASELINE shapes: policy / critic = 1.05 with a narrow head, 1.24 with
-    //    the wide-head MFMA path of either distribution) and minimises the later tower's finish in whole tiles per wave.
+    //    tile (single-tower launches at the three BASELINE shapes: policy / critic = 1.05 with a narrow head,
+    //    ORL_PAIR_WP_WIDE with the wide-head MFMA path of either distribution) and minimises the later tower's finish in
+    //    whole tiles per wave.
     // Measured pair launch, back to back -> side by side: configuration 2's towers 63.7 -> 55.2 us at 512 envs,
     // 100.4 -> 94.3 us at 1024, 323.9 -> 319.8 us at 4096; cfg3 shape (12 800 tiles) 198 -> 186 us; cfg5 shape (51 200
     // tiles, wide head) 678 -> 694 us.  Hence side by side when the towers are nearly equal or the launch is short.
     int gp = (n_tiles + 7) / 8, gc = gp;
     if (gp > PPO_MAX_BLOCKS) gp = gc = PPO_MAX_BLOCKS;
-    const double w_p = NOP_ > 4 ? 1.24 : 1.05;
+    const double w_p = NOP_ > 4 ? ORL_PAIR_WP_WIDE : 1.05;
     const bool side_by_side = w_p < 1.1 || n_tiles <= 12 * 8 * PPO_MAX_BLOCKS;
     if (gp + gc > PPO_MAX_BLOCKS && side_by_side) {
       double best = 1e30;

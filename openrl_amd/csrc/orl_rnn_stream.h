@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void rnn_images_kernel(const float* __restrict
   const RnnLayout& tl = pol ? tlp : tlc;
   unsigned short* img = (unsigned short*)((pol ? img_p : img_c) + (size_t)im * RS_IMG_FLOATS);
   const float* W = th + (im == 0 ? tl.oW2 : im <= 3 ? tl.oWih + (im - 1) * HID * HID : tl.oWhh + (im - 4) * HID * HID);
-  for (int e = threadIdx.x; e < HID * HID; e += blockDim.x) split_weight_store(img, e >> 6, e & 63, W[e]);
+  for (int e = 2 * threadIdx.x; e < HID * HID; e += 2 * blockDim.x) split_weight_store2(img, e >> 6, e & 63, W[e], W[e + 1]);
   if (im == 0) {  // the two constant rows the stream's READY flags are loaded from (RnnStream::issue)
     unsigned* fr = (unsigned*)((pol ? img_p : img_c) + (size_t)RS_NIMG * RS_IMG_FLOATS);
     for (int e = threadIdx.x; e < 128; e += blockDim.x) fr[e] = (unsigned)(e >> 6);
