@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   constexpr bool IS_POOL = ENV == ORL_ENV_TTT_POOL || PERK;
   constexpr bool IS_TTT = ENV == ORL_ENV_TTT || IS_POOL;
   constexpr int ESW = IS_TTT ? TTT_STATE_W : 8;
-  float est[ESW];
+  float est[ESW] = {};
   const int SW = (ENV == ORL_ENV_SYNTH) ? SYNTH_STATE_W : IS_TTT ? TTT_STATE_W : CARTPOLE_STATE_W;
   float ep_ret = 0.f, ep_len = 0.f, fin_ret = 0.f, fin_cnt = 0.f;
   // tic-tac-toe: the legal-move mask of the current step lives in LDS (written with the board one step earlier)
@@ -386,6 +386,63 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     ep_ret = A.r.ep_stats[n * 4 + 0]; ep_len = A.r.ep_stats[n * 4 + 1];
     fin_ret = A.r.ep_stats[n * 4 + 2]; fin_cnt = A.r.ep_stats[n * 4 + 3];
   }
+  // tic-tac-toe: the game state of the owning lanes as bitboards (cell c = bit c per player; env_state keeps its
+  // float[12] rows in HBM), and one word per row - agent bits | opponent bits << 9 | valid << 18 - in LDS, from which every
+  // consumer expands what it needs: fc1 its operands, wave 0 the legal-move mask, all threads the rows of the rollout
+  // buffer.  The logits tile is free here (fragment-sampled categorical head).
+  int* s_word = (int*)s_logits;  // [16] the learner's view; [16] more behind it: the opponent's view (self-play)
+  int* s_oword = s_word + TILE_B;
+  int* s_meta = s_oword + TILE_B;                      // [2][16] opponent moves this game, episode (for the draws)
+  uint32_t* s_draw = (uint32_t*)(s_meta + 2 * TILE_B);  // [4][16] the step's Philox words, from wave 1
+  int tA = 0, tO = 0, tmoves = 0, tep = 0;
+  if (IS_TTT && wave == 0 && q == 0) {
+    if (ok) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        tA |= (est[c] == 1.f ? 1 : 0) << c;
+        tO |= (est[c] == 2.f ? 1 : 0) << c;
+      }
+      tmoves = (int)est[9]; tep = (int)est[10];
+    }
+    s_word[j] = ok ? (tA | (tO << 9) | (1 << 18)) : 0;  // = slot 0's observation row (the env keeps them in step)
+    s_meta[j] = tmoves; s_meta[TILE_B + j] = tep;
+  }
+  // the loads above must have landed before the step loop: a pending load into a loop-carried register makes the
+  // compiler wait for ALL but the newest stores of the wave at its first use in every iteration (s_waitcnt vmcnt(2)
+  // in the middle of the env step)
+  asm volatile("" : "+v"(ep_ret), "+v"(ep_len), "+v"(fin_ret), "+v"(fin_cnt));
+#pragma unroll
+  for (int k = 0; k < ESW; ++k) asm volatile("" : "+v"(est[k]));
+  // Observations never exist as an LDS tile here: lane (j, q)'s fc1 operands of row j - features 4 s + q = cell
+  // (4 s + q) >> 1 of player q & 1 - are bits 2 s of ttt_operand_bits(word, q).
+  auto ttt_operand_bits = [&](int w) -> int {
+    return (w >> ((q & 1) * 9 + (q >> 1))) & (q < 2 ? 0x155 : 0x55);
+  };
+  // classes 4 q .. 4 q + 3 of row j's legal-move mask; an invalid row has class 0 legal
+  auto ttt_mask_to_lds = [&](int w, float* mask_tile) {
+    const int emp = (((w >> 18) & 1) ? (~(w | (w >> 9)) & 0x1FF) : 1) >> (4 * q);
+    *(f32x4*)(mask_tile + j * 16 + 4 * q) = f32x4{(float)(emp & 1), (float)((emp >> 1) & 1), (float)((emp >> 2) & 1),
+                                                  (float)((emp >> 3) & 1)};
+  };
+  // slot t + 1 of the [T+1, N, 18] observation and [T+1, N, 9] mask arrays: coalesced rows expanded from the tile's board
+  // words by ALL threads of the workgroup (one pass of 512), after the step's last barrier - off wave 0's serial chain
+  auto ttt_rows_to_buffer = [&](const int* words, int t) {
+    const int row0 = blockIdx.x * TILE_B;
+    const unsigned nrow = (unsigned)((N - row0) < TILE_B ? (N - row0) : TILE_B);
+    const size_t base = (size_t)(t + 1) * N + row0;
+    for (unsigned e = threadIdx.x; e < nrow * 27u; e += blockDim.x) {
+      if (e < nrow * 18u) {
+        const unsigned rr = e / 18u, d = e - rr * 18u;
+        const float v = (float)((words[rr] >> ((d & 1u) * 9u + (d >> 1))) & 1);
+        b.policy_obs[base * 18 + e] = v;
+        if (sep_c) b.critic_obs[base * 18 + e] = v;
+      } else {
+        const unsigned e2 = e - nrow * 18u, rr = e2 / 9u, c = e2 - rr * 9u;
+        const int w = words[rr];
+        b.action_masks[base * 9 + e2] = (float)((~(w | (w >> 9)) >> c) & 1);
+      }
+    }
+  };
   // The sampling noise does not depend on the network output: wave 3 (idle while wave 0 runs the head) draws the
   // NEXT step's uniforms / normals into LDS with the same Philox counters sample_head would use, and wave 0 consumes
   // them through sample_head's forced-noise argument - bit-identical actions, Philox off the critical path.
@@ -420,7 +477,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   for (int t = 0; t < T; ++t) {
     const float* cur = s_obs + (t & 1) * TILE_B * DP;
     float* nxt = s_obs + ((t + 1) & 1) * TILE_B * DP;
-    auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
+    const int wq = IS_TTT ? ttt_operand_bits(s_word[j]) : 0;
+    auto xb = [&](int s) -> float {
+      if constexpr (IS_TTT) return (float)((wq >> (2 * s)) & 1);
+      else return cur[j * DP + 4 * s + q];
+    };
     const uint64_t tg = A.r.rng_step0 + (uint64_t)t;
     f32x4 n2[4];
     trunk_fwd_coop(tlds, tww, creg, xb, gA, gB, gw, j, q, n2, rp);
@@ -494,54 +555,57 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
       }
     }
     if constexpr (IS_POOL) {
+      // The step's Philox draws, one pass over the four lanes of a row ON WAVE 1 (idle while wave 0 runs the head; they
+      // were up to four passes on wave 0 behind divergent branches), handed over by phase A's barrier: q = 0 the
+      // opponent's uniform (its own stream, sample_head's counter layout), 1 = who opens the next game, 2 = that game's
+      // opening move, 3 (PERK) = the next game's opponent (opponent_sample_kernel's draw).
+      if (wave == 1) {
+        const int ep = s_meta[TILE_B + j];
+        const uint64_t og = A.r.opp_rng_step0 + (uint64_t)t, id = A.r.opp_draw_id0 + (uint64_t)t;
+        const uint64_t key = q == 0 ? A.r.opp_seed : (q == 3 ? A.r.opp_sample_seed : A.r.env_seed);
+        const uint32_t c1 = q == 0 ? (uint32_t)((uint64_t)n >> 32) : q == 1 ? 0x77C7FFFFu : q == 2 ? 0x77C70000u : 0x0FF05A3Fu;
+        const uint32_t c2 = q == 0 ? (uint32_t)og : q == 3 ? (uint32_t)id : (uint32_t)(ep + 1);
+        const uint32_t c3 = q == 0 ? (uint32_t)(og >> 32) << 8 : q == 3 ? (uint32_t)(id >> 32) : 0u;
+        s_draw[q * TILE_B + j] = philox4x32_10(key, (uint32_t)n, c1, c2, c3).x;
+      }
       // ---- phase A (orl_ttt_agent_move): the agent's move on the owning lanes of wave 0; boards from the opponent's
       // side go to LDS for the opponent's policy
       int ph = 2;
       float rew_a = 0.f;
-      if (wave == 0 && q == 0) {
-        int bd[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) bd[c] = (int)est[c];
-        if (ok) {
-          const int a = (int)act_o[0];
-          bool legal = false;
-#pragma unroll
-          for (int c = 0; c < 9; ++c) legal = legal || (c == a && bd[c] == 0);
-          ph = 1;
-          if (!legal) { rew_a = -1.f; ph = 2; }
-          else {
-#pragma unroll
-            for (int c = 0; c < 9; ++c)
-              if (c == a) bd[c] = 1;
-            if (ttt_wins(bd, 1)) { rew_a = 1.f; ph = 2; }
-            else if (ttt_empty(bd) == 0) ph = 2;
+      if (wave == 0) {
+        if (q == 0) {
+          if (ok) {
+            const int a = (int)act_o[0];
+            const int e0 = ~(tA | tO) & 0x1FF;
+            const bool legal = (unsigned)a < 9u && ((e0 >> a) & 1) != 0;
+            ph = 1;
+            if (!legal) { rew_a = -1.f; ph = 2; }
+            else {
+              tA |= 1 << a;
+              if (ttt_wins_bits(tA)) { rew_a = 1.f; ph = 2; }
+              else if ((tA | tO) == 0x1FF) ph = 2;
+            }
           }
-#pragma unroll
-          for (int c = 0; c < 9; ++c) est[c] = (float)bd[c];
+          s_oword[j] = ph == 1 ? (tO | (tA << 9) | (1 << 18)) : 0;  // the board as the opponent sees it
+          if (PERK) s_oppk[j] = (ok && ph == 1) ? (float)my_opp : -1.f;
         }
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-          s_oobs[j * DP + 2 * c] = (ph == 1 && bd[c] == 2) ? 1.f : 0.f;
-          s_oobs[j * DP + 2 * c + 1] = (ph == 1 && bd[c] == 1) ? 1.f : 0.f;
-          s_omask[j * 16 + c] = ph == 1 ? (bd[c] == 0 ? 1.f : 0.f) : (c == 0 ? 1.f : 0.f);
-        }
-        for (int d = 18; d < DP; ++d) s_oobs[j * DP + d] = 0.f;
-        if (PERK) s_oppk[j] = (ok && ph == 1) ? (float)my_opp : -1.f;
+        wave_lds_fence();
+        ttt_mask_to_lds(s_oword[j], s_omask);
       }
       __syncthreads();
+      const int wqo = ttt_operand_bits(s_oword[j]);
+      float ou = 0.f;
+      uint32_t r_begin = 0u, r_open = 0u, r_samp = 0u;
+      if (wave == 0) {
+        ou = u01(s_draw[j]);
+        r_begin = s_draw[TILE_B + j]; r_open = s_draw[2 * TILE_B + j]; r_samp = s_draw[3 * TILE_B + j];
+      }
       // ---- the opponent's policy: cooperative trunk of the policy group on the opponent-side boards (the critic
       // group only keeps the barrier count)
       // One walk of the opponent tower per image: PERK walks image k only if some row of the tile plays slot k this
       // step (workgroup-uniform test), rows keep the action sampled from their own slot's logits.
       float oact[NO], olp = 0.f;
       oact[0] = 0.f;
-      float ou = 0.f;  // the opponent's uniform: its own Philox stream (sample_head's counter layout), one per row
-      if (wave == 0) {
-        const uint64_t og = A.r.opp_rng_step0 + (uint64_t)t;
-        const u4 rr = philox4x32_10(A.r.opp_seed, (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)og,
-                                    (uint32_t)(og >> 32) << 8);
-        ou = u01(rr.x);
-      }
       for (int k = 0; k < (PERK ? n_img : 1); ++k) {
         const float* img = s_opp + k * twp.total;
         if (PERK) {
@@ -549,7 +613,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
         }
         f32x4 o2[4];
         if (grp == 0) {
-          auto xo = [&](int s) -> float { return s_oobs[j * DP + 4 * s + q]; };
+          auto xo = [&](int s) -> float { return (float)((wqo >> (2 * s)) & 1); };
           CoopRegs oreg;  // the opponent's image (a pool slot): read per walk
           coop_load(img, twp, gw, j, q, oreg);
           trunk_fwd_coop(img, twp, oreg, xo, gA, gB, gw, j, q, o2, rp);
@@ -575,30 +639,17 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
         // ---- phase B (orl_ttt_opponent_move) ----
         if (q == 0) {
           const size_t s1 = (size_t)(t + 1) * N + n;
-          int bd[9];
-#pragma unroll
-          for (int c = 0; c < 9; ++c) bd[c] = (int)est[c];
-          int moves = (int)est[9], episode = (int)est[10];
           if (ok) {
             float rew = rew_a;
             bool done = ph == 2;
             if (ph == 1) {
-              int a = (int)oact[0];
-              bool legal = false;
-#pragma unroll
-              for (int c = 0; c < 9; ++c) legal = legal || (c == a && bd[c] == 0);
-              if (!legal) {
-                a = -1;
-#pragma unroll
-                for (int c = 8; c >= 0; --c)
-                  if (bd[c] == 0) a = c;
-              }
-#pragma unroll
-              for (int c = 0; c < 9; ++c)
-                if (c == a) bd[c] = 2;
-              ++moves;
-              if (ttt_wins(bd, 2)) { rew = -1.f; done = true; }
-              else if (ttt_empty(bd) == 0) done = true;
+              const int e0 = ~(tA | tO) & 0x1FF;
+              const int a = (int)oact[0];
+              const bool legal = (unsigned)a < 9u && ((e0 >> a) & 1) != 0;
+              tO |= legal ? (1 << a) : (e0 & -e0);  // an illegal sample falls back to the lowest empty cell
+              ++tmoves;
+              if (ttt_wins_bits(tO)) { rew = -1.f; done = true; }
+              else if ((tA | tO) == 0x1FF) done = true;
             }
             b.rewards[(size_t)t * N + n] = rew;
             b.masks[s1] = done ? 0.f : 1.f;
@@ -607,48 +658,34 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
             ep_ret += rew; ep_len += 1.f;
             if (done) {
               fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f;
-              ++episode;
-              moves = ttt_begin(bd, A.r.env_seed, (uint32_t)n, (uint32_t)episode);
+              ++tep;
+              tA = 0; tO = 0; tmoves = 0;
+              if (r_begin & 1u) { tO = ttt_pick_empty_bits(0x1FF, r_open); tmoves = 1; }
               if (PERK) {  // a finished game -> a fresh opponent for the next one (opponent_sample_kernel's draw)
                 int k = A.r.opp_last_slot;
                 if (A.r.opp_strategy == 0) {
-                  const uint64_t id = A.r.opp_draw_id0 + (uint64_t)t;
-                  const u4 r = philox4x32_10(A.r.opp_sample_seed, (uint32_t)n, 0x0FF05A3Fu, (uint32_t)id, (uint32_t)(id >> 32));
-                  k = (int)(u01(r.x) * (float)A.r.opp_n_filled);
+                  k = (int)(u01(r_samp) * (float)A.r.opp_n_filled);
                   k = k < A.r.opp_n_filled - 1 ? k : A.r.opp_n_filled - 1;
                 }
                 my_opp = k < 0 ? 0 : k;
               }
             }
-#pragma unroll
-            for (int c = 0; c < 9; ++c) est[c] = (float)bd[c];
-            est[9] = (float)moves; est[10] = (float)episode;
           }
-#pragma unroll
-          for (int c = 0; c < 9; ++c) {
-            nxt[j * DP + 2 * c] = (ok && bd[c] == 1) ? 1.f : 0.f;
-            nxt[j * DP + 2 * c + 1] = (ok && bd[c] == 2) ? 1.f : 0.f;
-            s_mask[j * 16 + c] = (!ok && c == 0) ? 1.f : ((ok && bd[c] == 0) ? 1.f : 0.f);
-          }
-          for (int d = 18; d < DP; ++d) nxt[j * DP + d] = 0.f;
+          s_word[j] = ok ? (tA | (tO << 9) | (1 << 18)) : 0;
+          s_meta[j] = tmoves; s_meta[TILE_B + j] = tep;
         }
         wave_lds_fence();
-        {
-          const int row0 = blockIdx.x * TILE_B;
-          const int nrow = (N - row0) < TILE_B ? (N - row0) : TILE_B;
-          const size_t base = (size_t)(t + 1) * N + row0;
-          for (int e = l; e < nrow * 18; e += 64) {
-            const int rr = e / 18, d = e - rr * 18;
-            const float v = nxt[rr * DP + d];
-            b.policy_obs[base * 18 + e] = v;
-            if (sep_c) b.critic_obs[base * 18 + e] = v;
-          }
-          for (int e = l; e < nrow * 9; e += 64) {
-            const int rr = e / 9, c = e - rr * 9;
-            b.action_masks[base * 9 + e] = s_mask[rr * 16 + c];
-          }
-        }
+        ttt_mask_to_lds(s_word[j], s_mask);
       }
+    }
+    if constexpr (ENV == ORL_ENV_TTT) {
+      // the step's three Philox draws (ttt_draw: q = 0 the opponent's reply, 1 = who opens the next game, 2 = that game's
+      // opening move) in one pass over the lanes of wave 1 while wave 0 runs the head - they were three passes on wave 0,
+      // behind divergent branches; one more barrier hands them over
+      if (wave == 1 && q < 3)
+        s_draw[q * TILE_B + j] = ttt_draw(A.r.env_seed, (uint32_t)n, q, (uint32_t)(s_meta[TILE_B + j] + (q != 0 ? 1 : 0)),
+                                          (uint32_t)s_meta[j]);
+      __syncthreads();
     }
     RO_T(rp, 5);
     if (wave == NOISE_WAVE) draw_noise(tg + 1, s_noise + ((t + 1) & 1) * TILE_B * 16);
@@ -687,31 +724,26 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
           if (done) { fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f; }
         }
       } else if (ENV == ORL_ENV_TTT) {
-        // orl_ttt_step's game logic on the owning lane; the new observation / mask rows go through LDS and leave as
-        // coalesced rows of the [T+1, N, 18] / [T+1, N, 9] arrays (all 64 lanes store)
+        // orl_ttt_step's game logic on the owning lane, on bitboards; the step's draws come from wave 1 (above), the new
+        // board leaves as one word per row.
+        const uint32_t rx = s_draw[j], r_begin = s_draw[TILE_B + j], r_open = s_draw[2 * TILE_B + j];
         if (q == 0) {
-          int bd[9];
-#pragma unroll
-          for (int c = 0; c < 9; ++c) bd[c] = (int)est[c];
-          int moves = (int)est[9], episode = (int)est[10];
           if (ok) {
             const int a = (int)act_o[0];
+            const int e0 = ~(tA | tO) & 0x1FF;
             float rew = 0.f;
-            bool done = false, legal = false;
-#pragma unroll
-            for (int c = 0; c < 9; ++c) legal = legal || (c == a && bd[c] == 0);
+            bool done = false;
+            const bool legal = (unsigned)a < 9u && ((e0 >> a) & 1) != 0;
             if (!legal) { rew = -1.f; done = true; }
             else {
-#pragma unroll
-              for (int c = 0; c < 9; ++c)
-                if (c == a) bd[c] = 1;
-              if (ttt_wins(bd, 1)) { rew = 1.f; done = true; }
-              else if (ttt_empty(bd) == 0) done = true;
+              tA |= 1 << a;
+              if (ttt_wins_bits(tA)) { rew = 1.f; done = true; }
+              else if ((tA | tO) == 0x1FF) done = true;
               else {
-                ttt_opponent_move(bd, A.r.env_seed, (uint32_t)n, (uint32_t)episode, (uint32_t)moves);
-                ++moves;
-                if (ttt_wins(bd, 2)) { rew = -1.f; done = true; }
-                else if (ttt_empty(bd) == 0) done = true;
+                tO |= ttt_pick_empty_bits(~(tA | tO) & 0x1FF, rx);
+                ++tmoves;
+                if (ttt_wins_bits(tO)) { rew = -1.f; done = true; }
+                else if ((tA | tO) == 0x1FF) done = true;
               }
             }
             b.rewards[(size_t)t * N + n] = rew;
@@ -721,37 +753,16 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
             ep_ret += rew; ep_len += 1.f;
             if (done) {
               fin_ret += ep_ret; fin_cnt += 1.f; ep_ret = 0.f; ep_len = 0.f;
-              ++episode;
-              moves = ttt_begin(bd, A.r.env_seed, (uint32_t)n, (uint32_t)episode);
+              ++tep;
+              tA = 0; tO = 0; tmoves = 0;
+              if (r_begin & 1u) { tO = ttt_pick_empty_bits(0x1FF, r_open); tmoves = 1; }
             }
-#pragma unroll
-            for (int c = 0; c < 9; ++c) est[c] = (float)bd[c];
-            est[9] = (float)moves; est[10] = (float)episode;
           }
-#pragma unroll
-          for (int c = 0; c < 9; ++c) {
-            nxt[j * DP + 2 * c] = (ok && bd[c] == 1) ? 1.f : 0.f;
-            nxt[j * DP + 2 * c + 1] = (ok && bd[c] == 2) ? 1.f : 0.f;
-            s_mask[j * 16 + c] = (!ok && c == 0) ? 1.f : ((ok && bd[c] == 0) ? 1.f : 0.f);
-          }
-          for (int d = 18; d < DP; ++d) nxt[j * DP + d] = 0.f;
+          s_word[j] = ok ? (tA | (tO << 9) | (1 << 18)) : 0;
+          s_meta[j] = tmoves; s_meta[TILE_B + j] = tep;
         }
         wave_lds_fence();
-        {
-          const int row0 = blockIdx.x * TILE_B;
-          const int nrow = (N - row0) < TILE_B ? (N - row0) : TILE_B;
-          const size_t base = (size_t)(t + 1) * N + row0;
-          for (int e = l; e < nrow * 18; e += 64) {
-            const int rr = e / 18, d = e - rr * 18;
-            const float v = nxt[rr * DP + d];
-            b.policy_obs[base * 18 + e] = v;
-            if (sep_c) b.critic_obs[base * 18 + e] = v;
-          }
-          for (int e = l; e < nrow * 9; e += 64) {
-            const int rr = e / 9, c = e - rr * 9;
-            b.action_masks[base * 9 + e] = s_mask[rr * 16 + c];
-          }
-        }
+        ttt_mask_to_lds(s_word[j], s_mask);
       } else if (ENV == ORL_ENV_CARTPOLE) {
         if (q == 0 && ok) {
           float s[4] = {est[0], est[1], est[2], est[3]};
@@ -797,6 +808,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     RO_T(rp, 6);
     __syncthreads();
     RO_T(rp, 7);
+    if constexpr (IS_TTT) ttt_rows_to_buffer(s_word, t);
   }
 #ifdef ORL_PROF
   __syncthreads();
@@ -806,7 +818,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   // all waves walk the cooperative trunk once more (barriers), only the critic leader uses the result
   if (WC && A.next_value != nullptr) {
     const float* cur = s_obs + (T & 1) * TILE_B * DP;
-    auto xb = [&](int s) -> float { return cur[j * DP + 4 * s + q]; };
+    const int wq = IS_TTT ? ttt_operand_bits(s_word[j]) : 0;
+    auto xb = [&](int s) -> float {
+      if constexpr (IS_TTT) return (float)((wq >> (2 * s)) & 1);
+      else return cur[j * DP + 4 * s + q];
+    };
     f32x4 n2[4];
     trunk_fwd_coop(tlds, tww, creg, xb, gA, gB, gw, j, q, n2, rp);
     if (wave == 4) {
@@ -817,6 +833,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     }
   }
   if (wave == ENV_WAVE && q == 0 && ok) {
+    if constexpr (IS_TTT) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) est[c] = ((tA >> c) & 1) ? 1.f : (((tO >> c) & 1) ? 2.f : 0.f);
+      est[9] = (float)tmoves; est[10] = (float)tep;
+    }
 #pragma unroll
     for (int k = 0; k < ESW; ++k)
       if (k < SW) A.r.env_state[(size_t)n * SW + k] = est[k];

@@ -70,22 +70,23 @@ __device__ inline void sample_head(float (&hd)[NO], int n_out, const float* lds_
 // Every lane of the row returns the action and its log-probability.
 __device__ inline void sample_cat_frag(const f32x4& lgv, int n_out, int q, const float* __restrict__ mask_row, float u,
                                        float& act, float& logp) {
+  // Branch-free: the four classes of a lane go through selects (the short-circuit form compiled to ~20 exec-mask
+  // branches on the step's serial chain).  mask_row = 16 floats, 16-byte aligned; classes >= n_out drop out through
+  // val[] exactly as before (their terms are +0 in every sum).
+  const f32x4 mk = mask_row != nullptr ? *(const f32x4*)(mask_row + 4 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
   float lg[4];
   bool val[4];
   float mx = -3.0e38f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int c = 4 * q + r;
-    val[r] = c < n_out;
-    lg[r] = lgv[r];
-    if (val[r] && mask_row != nullptr && mask_row[c] == 0.f) lg[r] = -6e4f;
-    if (val[r]) mx = fmaxf(mx, lg[r]);
+    val[r] = 4 * q + r < n_out;
+    lg[r] = mk[r] == 0.f ? -6e4f : lgv[r];
+    mx = val[r] ? fmaxf(mx, lg[r]) : mx;
   }
   mx = row_allmax(mx);
   float se = 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (val[r]) se += __expf(lg[r] - mx);
+  for (int r = 0; r < 4; ++r) se += val[r] ? __expf(lg[r] - mx) : 0.f;
   se = row_allsum(se);
   const float lse = mx + __logf(se);
   float p[4], ps = 0.f;
@@ -101,19 +102,16 @@ __device__ inline void sample_cat_frag(const f32x4& lgv, int n_out, int q, const
   float cand = 999.f, last = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (val[r]) {
-      cum += p[r];
-      if (p[r] > 0.f) last = (float)(4 * q + r);
-      if (cand == 999.f && cum > ut) cand = (float)(4 * q + r);
-    }
+    cum += p[r];  // + 0 for a class that is not there
+    last = p[r] > 0.f ? (float)(4 * q + r) : last;
+    cand = (val[r] & (cand == 999.f) & (cum > ut)) ? (float)(4 * q + r) : cand;
   }
   const float first = -row_allmax(-cand);  // the lowest class whose cumulative probability exceeds u * total
   last = row_allmax(last);
   const float a = first == 999.f ? last : first;
   float pk = 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if ((float)(4 * q + r) == a) pk = lg[r];
+  for (int r = 0; r < 4; ++r) pk = (float)(4 * q + r) == a ? lg[r] : pk;
   act = a;
   logp = row_allsum(pk) - lse;
 }

@@ -49,4 +49,30 @@ __device__ inline int ttt_begin(int (&b)[9], uint64_t seed, uint32_t env, uint32
   return 0;
 }
 
+// ---- bitboard forms (the fused rollout kernel): cell c = bit c of a 9-bit mask per player; the same rules and the same
+// draws as the array forms above (tests/test_ttt_gpu.py holds the fused rollout bit-exact against the step kernel) ----
+__device__ inline bool ttt_wins_bits(int m) {
+  const int rows = m & (m >> 1) & (m >> 2) & 0x49;  // (0,1,2) (3,4,5) (6,7,8)
+  const int cols = m & (m >> 3) & (m >> 6) & 0x7;   // (0,3,6) (1,4,7) (2,5,8)
+  return (rows | cols) != 0 || (m & 0x111) == 0x111 || (m & 0x54) == 0x54;
+}
+
+// ttt_opponent_move's choice given its Philox word: the k-th empty cell (one-hot), k = floor(u * n_empty)
+__device__ inline int ttt_pick_empty_bits(int empty, uint32_t rx) {
+  const int n = __popc((unsigned)empty);
+  int k = (int)(u01(rx) * (float)n);
+  k = k < n - 1 ? k : n - 1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < k) empty &= empty - 1;
+  return empty & -empty;
+}
+
+// Philox counter words of the env's three draws (ttt_opponent_move / ttt_begin above): which = 0 the opponent's reply to
+// move `move` of `episode`, 1 = who opens `episode`, 2 = the opening move of `episode`
+__device__ inline uint32_t ttt_draw(uint64_t seed, uint32_t env, int which, uint32_t episode, uint32_t move) {
+  const uint32_t c1 = which == 1 ? 0x77C7FFFFu : 0x77C70000u + (which == 0 ? move : 0u);
+  return philox4x32_10(seed, env, c1, episode, 0u).x;
+}
+
 }  // namespace orl
