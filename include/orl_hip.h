@@ -369,6 +369,22 @@ int orl_ppo_apply_comm(orl_comm* comm, const orl_net_desc* pnet, const orl_net_d
                        float* train_info_accum, int64_t* next_idx, int64_t n, uint64_t seed, uint64_t stream_id,
                        float* vn_state, const double* moments, double beta, void* stream);
 
+/* The optimiser step of an MLP-tower minibatch in ONE launch = orl_ppo_reduce_pair(_comm) + orl_ppo_apply(_perm / _comm)
+ * with the same arguments and the same results (same summation orders, same Adam arithmetic): the reducing workgroups
+ * take a ticket per tower, and the one that draws a tower's last ticket runs that tower's step (clip_grad_norm_ + Adam,
+ * openrl/algorithms/ppo.py:132-164) behind a device-scope fence; the others share the next epoch's permutation job
+ * (next_idx != NULL).  Measured on MI355X it does NOT pay: the device-scope release / acquire around the ticket (L2
+ * write-back + invalidate across 8 XCDs) costs more than the kernel boundary it removes (15.7 us against 4.4 + 9.3 us);
+ * the host mirror keeps the two-launch form as its default (cfg.amd_optim_step).  comm == NULL: single GPU; else the collective of the _comm pair, opened and
+ * closed by this launch.  sync_ctr: 4 x uint32 of device memory, zero before the first call, owned by the calls that
+ * share a stream (every launch leaves it zero). */
+int orl_ppo_reduce_apply(orl_comm* comm, const float* partials, int n_blocks_policy, int width_policy,
+                         int n_blocks_critic, int width_critic, float* sums, const orl_net_desc* pnet,
+                         const orl_net_desc* cnet, const orl_ppo_hparams* hp, const orl_adam_state* padam,
+                         const orl_adam_state* cadam, float* train_info_accum, int64_t* next_idx, int64_t n, uint64_t seed,
+                         uint64_t stream_id, float* vn_state, const double* moments, double beta, uint32_t* sync_ctr,
+                         void* stream);
+
 /* ValueNorm.update (openrl/modules/utils/valuenorm.py:58-77) from reduced batch sums:
  * moments = {sum(x), sum(x^2), count} as doubles on the device; beta = 0.99999. */
 int orl_valuenorm_update(float* vn_state, const double* moments, double beta, void* stream);

@@ -200,6 +200,10 @@ _SIGNATURES = {
     "orl_ppo_apply_comm": (C.c_int, [_P, C.POINTER(NetDesc), C.POINTER(NetDesc), _P, C.POINTER(PPOHParams),
                                      C.POINTER(AdamState), C.POINTER(AdamState), _P, _P, C.c_int64, C.c_uint64,
                                      C.c_uint64, _P, _P, C.c_double, _P]),
+    "orl_ppo_reduce_apply": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(NetDesc),
+                                       C.POINTER(NetDesc), C.POINTER(PPOHParams), C.POINTER(AdamState),
+                                       C.POINTER(AdamState), _P, _P, C.c_int64, C.c_uint64, C.c_uint64, _P, _P, C.c_double,
+                                       _P, _P]),
     "orl_gen_rollout_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                         C.c_uint64, C.c_uint64, C.c_int, _P]),
     "orl_gemm": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, C.c_int,

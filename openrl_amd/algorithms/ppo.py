@@ -190,6 +190,10 @@ class PPOAlgorithm(BaseAlgorithm):
         self._rnn_rows = None    # [L, n_chunks] record rows of the current minibatch
         self._rnn_scratch = torch.zeros(512, dtype=torch.float32, device=dev) if self.recurrent else None
         self._sums = torch.zeros(self._raw_p + self._raw_c, dtype=torch.float32, device=dev)
+        # reduce + optimiser step of an MLP-tower minibatch in two launches (default) or in one (orl_ppo_reduce_apply:
+        # built, bit-identical, 1 % slower - the comparison switch amd_optim_step)
+        self._fused_step = getattr(cfg, "amd_optim_step", "two_launch") == "fused"
+        self._sync_ctr = torch.zeros(4, dtype=torch.int32, device=dev)  # its tickets; every launch leaves them zero
         # multi-GPU: the one-shot xGMI all-reduce of the sums vector, fused into the optimiser-step launches (MLP towers)
         # or as its own launch (recurrent); None = single process or amd_collective=rccl -> torch.distributed
         self._comm = dist_utils.make_small_allreduce(self._sums.numel(), dev, getattr(cfg, "amd_collective", "p2p")) \
@@ -268,9 +272,11 @@ class PPOAlgorithm(BaseAlgorithm):
         # ONE small collective per optimiser step: pushed by the reduce launch, summed by the apply
         # launch (orl_comm), or one RCCL all-reduce between them
         comm = self._comm
-        ops.ppo_reduce_pair(self._partials, nb_p, self._raw_p, nb_c, self._raw_c, self._sums, comm=comm)
-        if self.world_size > 1 and comm is None:
-            dist_utils.allreduce_(self._sums)
+        fused = self._fused_step and (self.world_size == 1 or comm is not None)  # an RCCL all-reduce sits between the two
+        if not fused:
+            ops.ppo_reduce_pair(self._partials, nb_p, self._raw_p, nb_c, self._raw_c, self._sums, comm=comm)
+            if self.world_size > 1 and comm is None:
+                dist_utils.allreduce_(self._sums)
         po.step_count += 1 if turn_on else 0
         co.step_count += 1
         hp = self.hp
@@ -282,6 +288,10 @@ class PPOAlgorithm(BaseAlgorithm):
             if first:
                 hp.reserved |= 32  # first optimiser step of this train() call: the apply launch starts the averages
                 self._info_first = False
+        if fused:
+            return ops.ppo_reduce_apply(self._partials, nb_p, self._raw_p, nb_c, self._raw_c, self._sums, p.net, c.net, hp,
+                                        po.native_state(max(po.step_count, 1)), co.native_state(co.step_count),
+                                        self._info, self._sync_ctr, next_perm, comm=comm)
         return ops.ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
                              co.native_state(co.step_count), self._info, next_perm, comm=comm)
 

@@ -40,6 +40,12 @@ AMD_FLAGS = [
     # (csrc/orl_rnn_stream.h; 0.83 ms - the stream's waits cost more than the MFMA time it saves),
     # "split_w4" = the same with 4 waves per workgroup / 512 registers per wave (1.07 ms).  All three are parity-tested.
     ("amd_rnn_gemm", "str", "fp32", "opt", ["fp32", "split", "split_w4"]),
+    # optimiser step of an MLP-tower minibatch: "two_launch" (default) = orl_ppo_reduce_pair then orl_ppo_apply(_perm);
+    # "fused" = column sums of the towers' partials + clip + Adam (+ the next epoch's permutation) in ONE launch
+    # (orl_ppo_reduce_apply: ticketed workgroups, the last one of a tower steps it) - same results bit for bit, but the
+    # device-scope release / acquire around the ticket (L2 write-back + invalidate across the 8 XCDs) costs more than the
+    # kernel boundary it removes: 15.7 us against 4.4 + 9.3 us, iteration + 1 %.
+    ("amd_optim_step", "str", "two_launch", "opt", ["two_launch", "fused"]),
     # general (non-default) feed-forward towers: "fused" = the cross-layer kernels of csrc/orl_gen_tower.h where they take
     # the shape (hidden_size 64 / 128), "layerwise" = one launch per layer and direction everywhere.
     ("amd_gen_update", "str", "fused", "opt", ["fused", "layerwise"]),

@@ -48,6 +48,19 @@ struct ApplyTower {
   int sums_off;  // offset of this tower's raw vector in `sums`
 };
 
+// n floats HBM -> LDS by DMA (global_load_lds: no registers, nothing to wait for per element): every iteration of the
+// rolled register loop this replaces was one serialized HBM round trip (load -> s_waitcnt vmcnt(0) -> ds_write), ~4.5 of
+// them per array at configuration 2's towers.  The caller waits vmcnt(0) + barrier once, after its last call.
+__device__ inline void stage_dma(float* lds_dst, const float* __restrict__ src, int n) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll 1
+  for (int e0 = (threadIdx.x & ~63); e0 < n; e0 += blockDim.x) {
+    if (e0 + lane < n)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + e0 + lane),
+                                       (__attribute__((address_space(3))) void*)(lds_dst + e0), 4, 0, 0);
+  }
+}
+
 __device__ inline float block_sum_1024(float v, float* sh) {
   v = wave_sum(v);
   const int w = threadIdx.x >> 6;
@@ -67,12 +80,16 @@ __device__ inline float raw_to_grad(const float* __restrict__ raw, const float* 
   if (p < tl.ob1) g = raw[rl.odW1 + (p - tl.oW1)];
   else if (p < tl.og1) g = raw[rl.odb1 + (p - tl.ob1)];
   else if (p < tl.obe1) {  // LN1 weight: dg1[i] = sum_o W2[o][i] * G[o][i]
+    // (both 64-term loops: operands of 8 terms requested together, summed in the same order - the rolled form was 64
+    // dependent LDS round trips on one wave while the rest of the workgroup waited at the norm's barrier)
     const int i = p - tl.og1;
     g = 0.f;
+#pragma unroll 8
     for (int o = 0; o < H; ++o) g += theta[tl.oW2 + o * H + i] * raw[rl.oG + o * H + i];
   } else if (p < tl.oW2) {  // LN1 bias: dbe1[i] = sum_o W2[o][i] * db2[o]
     const int i = p - tl.obe1;
     g = 0.f;
+#pragma unroll 8
     for (int o = 0; o < H; ++o) g += theta[tl.oW2 + o * H + i] * raw[rl.odb2 + o];
   } else if (p < tl.ob2) {
     const int e = p - tl.oW2, o = e / H, i = e - o * H;
@@ -94,23 +111,14 @@ __device__ inline float raw_to_grad(const float* __restrict__ raw, const float* 
   return g * inv_den;
 }
 
-// One workgroup per tower (blockIdx.x = 0 policy, 1 critic).  The tower's raw sums and parameters are
-// staged in LDS first so the 64-term LayerNorm-affine dot products of raw_to_grad run out of LDS.
-// Workgroups >= 2 (orl_ppo_apply_perm only) produce the NEXT epoch's minibatch permutation and ValueNorm.update in the
-// same launch: both are independent of this optimiser step, and the two apply workgroups leave 254 CUs idle.
-__global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTower Cc, float* __restrict__ sums,
-                                                         orl_ppo_hparams hp, float* __restrict__ info, PermJob J,
-                                                         int stage_mv, CommDev CM, int use_comm) {
-  extern __shared__ __attribute__((aligned(16))) float s_apply[];
-  if (blockIdx.x >= 2) {
-    perm_job_block(J, (int)blockIdx.x - 2, (int)gridDim.x - 2);
-    return;
-  }
-  __shared__ float sh[16];
+// The optimiser step of tower t (0 policy, 1 critic) by ONE workgroup of 1024 threads.  The tower's raw sums and
+// parameters are staged in LDS first so the 64-term LayerNorm-affine dot products of raw_to_grad run out of LDS.
+__device__ inline void apply_tower_block(const int t, const ApplyTower& P, const ApplyTower& Cc, float* __restrict__ sums,
+                                         const orl_ppo_hparams& hp, float* __restrict__ info, const int stage_mv,
+                                         const CommDev& CM, const int use_comm, float* s_apply, float* sh) {
   const TowerLayout tlp(P.net), tlc(Cc.net);
   const RawLayout rlp(P.net), rlc(Cc.net);
   float norms[2] = {0.f, 0.f};
-  const int t = blockIdx.x;
   // this tower's raw sums + statistics, staged in LDS first.  Multi-GPU (use_comm): every element is the sum over
   // ranks, in rank order, of the local column sum and the peers' pushed granules (orl_ppo_reduce_pair_comm); the
   // reduced vector is also written back to `sums` so the caller observes the global sums.
@@ -121,14 +129,15 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     const RawLayout& rl0 = t == 0 ? rlp : rlc;
     const int off = t == 0 ? P.sums_off : Cc.sums_off;
     const int nraw = rl0.total + ORL_N_STATS;
+    if (use_comm) {
 #pragma unroll 1
-    for (int e = threadIdx.x; e < nraw; e += blockDim.x) {
-      float v = sums[off + e];
-      if (use_comm) {
-        v = comm_sum(CM, off + e, v);
+      for (int e = threadIdx.x; e < nraw; e += blockDim.x) {
+        const float v = comm_sum(CM, off + e, sums[off + e]);
         sums[off + e] = v;
+        raw[e] = v;
       }
-      raw[e] = v;
+    } else {
+      stage_dma(raw, sums + off, nraw);
     }
     st = raw + rl0.total;
   }
@@ -155,20 +164,17 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     }
     float* th_s = s_apply + rl.total + ORL_N_STATS;
     // latency plan for a one-shot, two-workgroup kernel: everything that comes from HBM (raw sums, parameters, Adam
-    // moments) is requested up front into LDS, the double-precision bias corrections are evaluated while those loads
-    // are in flight, gradients stay in LDS between the norm and the Adam pass, and every loop stays ROLLED - the code
+    // moments) is requested up front into LDS by DMA, the double-precision bias corrections are evaluated while those
+    // loads are in flight, gradients stay in LDS between the norm and the Adam pass, and every loop stays ROLLED - the code
     // is fetched cold on each launch, so instruction bytes cost more than loop overhead (an unrolled variant of this
     // body measured 17.2 us against 13.3 us).
     float* g_s = th_s + tl.total;
     float* m_s = g_s + tl.total;  // Adam moments: staged too when everything fits 160 KiB (stage_mv), else read from HBM
     float* v_s = m_s + tl.total;
-#pragma unroll 1
-    for (int e = threadIdx.x; e < tl.total; e += blockDim.x) {
-      th_s[e] = W.ad.theta[e];
-      if (stage_mv) {
-        m_s[e] = W.ad.m[e];
-        v_s[e] = W.ad.v[e];
-      }
+    stage_dma(th_s, W.ad.theta, tl.total);
+    if (stage_mv) {
+      stage_dma(m_s, W.ad.m, tl.total);
+      stage_dma(v_s, W.ad.v, tl.total);
     }
     // torch.optim.Adam (single tensor math, betas (0.9, 0.999), amsgrad off)
     // scalar coefficients are python doubles in torch/optim/adam.py; only tensor math is fp32
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
     const double bc2 = 1.0 - powi_d(b2d, (long long)W.ad.step);
     const float step_size = (float)((double)W.ad.lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed
     __syncthreads();
     den_p = hp.use_policy_active_masks ? st[ST_ACTIVE_SUM] : st[ST_ROWS];
     den_v = hp.use_value_active_masks ? st[ST_ACTIVE_SUM] : st[ST_ROWS];
@@ -189,64 +196,82 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
       g_s[p] = g;
       ss += g * g;
     }
-    // one Adam loop for both cases: generic pointers to the staged copies (LDS) or to the moments in HBM
-    const float* mp = stage_mv ? (const float*)m_s : (const float*)W.ad.m;
-    const float* vp = stage_mv ? (const float*)v_s : (const float*)W.ad.v;
     const float total = sqrtf(block_sum_1024(ss, sh));
     norms[t] = total;
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
     float coef = 1.f;
     if (hp.use_max_grad_norm) coef = fminf(hp.max_grad_norm / (total + 1e-6f), 1.f);
-#pragma unroll 1
-    for (int p = threadIdx.x; p < tl.total; p += blockDim.x) {
+    // The loop reads LDS (or, for the widest towers, the moments in HBM through their own pointers) and only STORES to
+    // HBM: one loop over generic pointers for both cases made every iteration drain the previous iteration's stores
+    // (flat loads -> s_waitcnt vmcnt(0) lgkmcnt(0) inside the loop, ~1 us each).
+    auto adam = [&](int p, float m, float v) {
       float g = g_s[p] * coef;
       W.ad.grad[p] = g;
       float th = th_s[p];
       if (W.ad.weight_decay != 0.f) g += W.ad.weight_decay * th;
-      float m = mp[p], v = vp[p];
       m = m + (g - m) * omb1;          // exp_avg.lerp_(grad, 1 - beta1)
       v = v * b2 + omb2 * (g * g);     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
       const float denom = sqrtf(v) / bc2_sqrt + W.ad.eps;
       th = th - step_size * (m / denom);
       W.ad.m[p] = m; W.ad.v[p] = v; W.ad.theta[p] = th;
+    };
+    if (stage_mv) {
+#pragma unroll 1
+      for (int p = threadIdx.x; p < tl.total; p += blockDim.x) adam(p, m_s[p], v_s[p]);
+    } else {
+#pragma unroll 1
+      for (int p = threadIdx.x; p < tl.total; p += blockDim.x) adam(p, W.ad.m[p], W.ad.v[p]);
     }
   }
   if (threadIdx.x == 0 && info != nullptr) {
     const float* stp = st;
     const float* stc = st;
-    // hp.reserved & 32: the first optimiser step of a train() call starts the averages instead of adding to them (the
-    // caller then needs no zero-fill launch); each workgroup owns its slots
-    if (hp.reserved & 32) {
-      if (blockIdx.x == 0) info[1] = info[2] = info[3] = info[5] = 0.f;
-      else info[0] = info[4] = 0.f;
-    }
-    if (blockIdx.x == 0) {
+    // each workgroup owns its slots (one writer): the running sums are kept with return-less float atomics - a plain
+    // `info[k] += x` is a load -> add -> store chain, one more HBM round trip on the tail of a latency-bound launch.
+    // hp.reserved & 32: the first optimiser step of a train() call STORES (the caller then needs no zero-fill launch).
+    const bool first = (hp.reserved & 32) != 0;
+    auto acc = [&](int k, float x) {
+      if (first) info[k] = x;
+      else unsafeAtomicAdd(info + k, x);
+    };
+    if (t == 0) {
       float ent_den = den_p;
       if (!hp.use_policy_active_masks && P.net.head_kind == ORL_HEAD_GAUSSIAN) ent_den = den_p * (float)P.net.n_out;
-      info[1] += stp[ST_PLOSS_SUM] / den_p;                 // policy_loss
-      info[2] += stp[ST_ENT_SUM] / ent_den;                 // dist_entropy
-      info[3] += norms[0];                                  // actor_grad_norm
+      acc(1, stp[ST_PLOSS_SUM] / den_p);                 // policy_loss
+      acc(2, stp[ST_ENT_SUM] / ent_den);                 // dist_entropy
+      acc(3, norms[0]);                                  // actor_grad_norm
       const float a_w = P.net.head_kind == ORL_HEAD_GAUSSIAN ? (float)P.net.n_out : 1.f;
-      info[5] += stp[ST_RATIO_SUM] / (stp[ST_ROWS] * a_w);  // ratio.mean()
+      acc(5, stp[ST_RATIO_SUM] / (stp[ST_ROWS] * a_w));  // ratio.mean()
     } else {
-      info[0] += stc[ST_VLOSS_SUM] / den_v;                 // value_loss
-      info[4] += norms[1];                                  // critic_grad_norm
+      acc(0, stc[ST_VLOSS_SUM] / den_v);                 // value_loss
+      acc(4, norms[1]);                                  // critic_grad_norm
     }
   }
 }
 
-// both towers' partial regions in one launch: blocks [0, gp) reduce the policy region, the rest the critic's
-__global__ __launch_bounds__(1024) void ppo_reduce_pair_kernel(const float* __restrict__ pp, int nb_p, int wp, int gp,
-                                                               const float* __restrict__ pc, int nb_c, int wc,
-                                                               float* __restrict__ sums, CommDev CM, int use_comm) {
-  // 64 columns x 16 row groups per workgroup: at 256 partial rows every thread has 16 independent loads in flight
-  __shared__ float sh[16][64];
-  const bool pol = (int)blockIdx.x < gp;
-  const float* partials = pol ? pp : pc;
-  const int n_blocks = pol ? nb_p : nb_c, width = pol ? wp : wc;
-  float* out = pol ? sums : sums + wp;
+// One workgroup per tower (blockIdx.x = 0 policy, 1 critic).  Workgroups >= 2 (orl_ppo_apply_perm only) produce the NEXT
+// epoch's minibatch permutation and ValueNorm.update in the same launch: both are independent of this optimiser step, and
+// the two apply workgroups leave 254 CUs idle.
+__global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTower Cc, float* __restrict__ sums,
+                                                         orl_ppo_hparams hp, float* __restrict__ info, PermJob J,
+                                                         int stage_mv, CommDev CM, int use_comm) {
+  extern __shared__ __attribute__((aligned(16))) float s_apply[];
+  if (blockIdx.x >= 2) {
+    perm_job_block(J, (int)blockIdx.x - 2, (int)gridDim.x - 2);
+    return;
+  }
+  __shared__ float sh[16];
+  apply_tower_block((int)blockIdx.x, P, Cc, sums, hp, info, stage_mv, CM, use_comm, s_apply, sh);
+}
+
+// 64 columns x 16 row groups of one tower's partial region by a workgroup of 1024 threads: at 256 partial rows every
+// thread has 16 independent loads in flight.  `sh` = 16 x 64 floats of LDS.  Multi-GPU: the column sum also goes
+// straight to every peer's inbox (one 8-byte granule each).
+__device__ inline void reduce_columns_block(const float* __restrict__ partials, int n_blocks, int width, int col0,
+                                            float* __restrict__ out, int comm_off, const CommDev& CM, int use_comm,
+                                            float (*sh)[64]) {
   const int lc = threadIdx.x & 63;
-  const int col = (pol ? blockIdx.x : blockIdx.x - gp) * 64 + lc;
+  const int col = col0 + lc;
   const int rg = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (col < width) {
@@ -267,12 +292,70 @@ __global__ __launch_bounds__(1024) void ppo_reduce_pair_kernel(const float* __re
     for (int k = 0; k < 4; ++k) t[k] = (sh[4 * k][lc] + sh[4 * k + 1][lc]) + (sh[4 * k + 2][lc] + sh[4 * k + 3][lc]);
     const float v = (t[0] + t[1]) + (t[2] + t[3]);
     out[col] = v;
-    if (use_comm) {  // multi-GPU: the column sum goes straight to every peer's inbox (one 8-byte granule each)
-      const int e = pol ? col : wp + col;
+    if (use_comm) {
       for (int p = 0; p < CM.world; ++p)
-        if (p != CM.rank) comm_push(CM, p, e, v);
+        if (p != CM.rank) comm_push(CM, p, comm_off + col, v);
     }
   }
+}
+
+// Reduce + optimiser step in ONE launch (orl_ppo_reduce_apply): workgroups [0, gp) / [gp, gp + gc) sum 64 columns each
+// of the policy / critic partial region, then take a ticket; the workgroup that draws a tower's LAST ticket has every
+// column sum of that tower behind a device-scope fence and runs the tower's optimiser step (apply_tower_block).  Every
+// other workgroup - and the extra ones behind gp + gc - draws one share of the next epoch's permutation job.  One
+// kernel boundary (~2.4 us of dependent-dispatch latency on this stack) less than orl_ppo_reduce_pair +
+// orl_ppo_apply_perm - and measured SLOWER: 15.7 us against 4.4 + 9.3 us, the fences and the ticket's round trip to
+// memory cost more than the boundary (cfg.amd_optim_step keeps two launches as the default).  ctr[0..2]: tickets of the two towers
+// and of the permutation shares; each is reset by the workgroup that draws its last value, so a zero-initialised array
+// serves every launch on the stream.
+__global__ __launch_bounds__(1024) void ppo_reduce_apply_kernel(const float* __restrict__ pp, int nb_p, int wp, int gp,
+                                                                const float* __restrict__ pc, int nb_c, int wc, int gc,
+                                                                ApplyTower P, ApplyTower Cc, float* __restrict__ sums,
+                                                                orl_ppo_hparams hp, float* __restrict__ info, PermJob J,
+                                                                int stage_mv, CommDev CM, int use_comm,
+                                                                unsigned* __restrict__ ctr) {
+  extern __shared__ __attribute__((aligned(16))) float s_apply[];
+  __shared__ float sh[16];
+  __shared__ unsigned s_ticket;
+  const int b = blockIdx.x;
+  if (b < gp + gc) {
+    const bool pol = b < gp;
+    // the reduce's 4 KB of scratch are the head of the apply's staging area (used strictly before it)
+    reduce_columns_block(pol ? pp : pc, pol ? nb_p : nb_c, pol ? wp : wc, (pol ? b : b - gp) * 64, pol ? sums : sums + wp,
+                         pol ? 0 : wp, CM, use_comm, (float(*)[64])s_apply);
+    // Wave 0 wrote the 64 column sums: ITS release fence (stores retired, written back so that the other XCDs' L2s can
+    // see them) precedes the ticket.  One fence per workgroup - a __threadfence() by all 16 waves of all 146 workgroups was
+    // 2 336 L2 write-back + invalidate sequences and cost 35 us per launch.
+    if (threadIdx.x < 64) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (threadIdx.x == 0) s_ticket = atomicAdd(ctr + (pol ? 0 : 1), 1u);
+    }
+    __syncthreads();
+    if (s_ticket == (unsigned)((pol ? gp : gc) - 1)) {
+      if (threadIdx.x == 0) ctr[pol ? 0 : 1] = 0u;  // nobody draws from it again in this launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' column sums, not a stale line
+      apply_tower_block(pol ? 0 : 1, P, Cc, sums, hp, info, stage_mv, CM, use_comm, s_apply, sh);
+      return;
+    }
+  }
+  if (J.idx == nullptr) return;
+  const unsigned shares = gridDim.x - 2u;  // every workgroup but the two that ran an optimiser step
+  __syncthreads();
+  if (threadIdx.x == 0) s_ticket = atomicAdd(ctr + 2, 1u);
+  __syncthreads();
+  const unsigned k = s_ticket;
+  if (k == shares - 1u && threadIdx.x == 0) ctr[2] = 0u;
+  perm_job_block(J, (int)k, (int)shares);
+}
+
+// both towers' partial regions in one launch: blocks [0, gp) reduce the policy region, the rest the critic's
+__global__ __launch_bounds__(1024) void ppo_reduce_pair_kernel(const float* __restrict__ pp, int nb_p, int wp, int gp,
+                                                               const float* __restrict__ pc, int nb_c, int wc,
+                                                               float* __restrict__ sums, CommDev CM, int use_comm) {
+  __shared__ float sh[16][64];
+  const bool pol = (int)blockIdx.x < gp;
+  reduce_columns_block(pol ? pp : pc, pol ? nb_p : nb_c, pol ? wp : wc, (pol ? blockIdx.x : blockIdx.x - gp) * 64,
+                       pol ? sums : sums + wp, pol ? 0 : wp, CM, use_comm, sh);
 }
 
 static int check_tower(const orl_net_desc* n, const char* who) {
@@ -373,6 +456,67 @@ int orl_ppo_apply_perm(const orl_net_desc* pnet, const orl_net_desc* cnet, const
   ORL_REQUIRE(!vn_state || moments, "orl_ppo_apply_perm: vn_state needs moments");
   const PermJob J = make_perm_job(next_idx, n, seed, stream_id, vn_state, moments, beta);
   return launch_apply("orl_ppo_apply_perm", pnet, cnet, (float*)sums, hp, padam, cadam, train_info_accum, J, stream);
+}
+
+int orl_ppo_reduce_apply(orl_comm* comm, const float* partials, int n_blocks_policy, int width_policy,
+                         int n_blocks_critic, int width_critic, float* sums, const orl_net_desc* pnet,
+                         const orl_net_desc* cnet, const orl_ppo_hparams* hp, const orl_adam_state* padam,
+                         const orl_adam_state* cadam, float* train_info_accum, int64_t* next_idx, int64_t n, uint64_t seed,
+                         uint64_t stream_id, float* vn_state, const double* moments, double beta, uint32_t* sync_ctr,
+                         void* stream) {
+  const char* what = "orl_ppo_reduce_apply";
+  int rc = check_tower(pnet, what);
+  if (rc) return rc;
+  rc = check_tower(cnet, what);
+  if (rc) return rc;
+  ORL_REQUIRE(partials && sums && hp && padam && cadam && sync_ctr, "%s: null pointer", what);
+  ORL_REQUIRE(n_blocks_policy > 0 && n_blocks_critic > 0, "%s: bad arguments", what);
+  ORL_REQUIRE(padam->theta && padam->grad && padam->m && padam->v && cadam->theta && cadam->grad && cadam->m && cadam->v,
+              "%s: null optimizer buffer", what);
+  ORL_REQUIRE(padam->step >= 1 && cadam->step >= 1, "%s: Adam step counts are 1-based", what);
+  ApplyTower P, Cc;
+  P.net = *pnet; P.ad = *padam; P.sums_off = 0;
+  Cc.net = *cnet; Cc.ad = *cadam; Cc.sums_off = RawLayout(*pnet).total + ORL_N_STATS;
+  ORL_REQUIRE(width_policy == Cc.sums_off && width_critic == RawLayout(*cnet).total + ORL_N_STATS,
+              "%s: partial widths %d / %d do not match the towers' raw vectors (%d / %d)", what, width_policy, width_critic,
+              Cc.sums_off, RawLayout(*cnet).total + ORL_N_STATS);
+  PermJob J;
+  memset(&J, 0, sizeof(J));
+  if (next_idx != nullptr) {
+    ORL_REQUIRE(n > 0 && n <= ((int64_t)1 << 62), "%s: bad permutation arguments", what);
+    ORL_REQUIRE(!vn_state || moments, "%s: vn_state needs moments", what);
+    J = make_perm_job(next_idx, n, seed, stream_id, vn_state, moments, beta);
+  }
+  auto need = [&](int k) {  // launch_apply's LDS plan; the reduce's 4 KB of scratch fit its head
+    const size_t lp = (size_t)(RawLayout(*pnet).total + ORL_N_STATS + k * TowerLayout(*pnet).total) * sizeof(float);
+    const size_t lc = (size_t)(RawLayout(*cnet).total + ORL_N_STATS + k * TowerLayout(*cnet).total) * sizeof(float);
+    return lp > lc ? lp : lc;
+  };
+  const int stage_mv = need(4) <= 156 * 1024;
+  const size_t lds = need(stage_mv ? 4 : 2);
+  ORL_REQUIRE(lds <= 156 * 1024 && lds >= 16 * 64 * sizeof(float), "%s: tower needs %zu B of LDS", what, lds);
+  const int gp = (width_policy + 63) / 64, gc = (width_critic + 63) / 64;
+  int extra = 0;
+  if (J.idx != nullptr) {  // one workgroup per CU (the launch's LDS footprint): fill the chip, never less than one share
+    extra = (int)((J.n + 1023) / 1024) - (gp + gc - 2);
+    if (extra > 256 - gp - gc) extra = 256 - gp - gc;
+    if (extra < (gp + gc == 2 ? 1 : 0)) extra = gp + gc == 2 ? 1 : 0;
+  }
+  CommDev CM;
+  memset(&CM, 0, sizeof(CM));
+  int use_comm = 0;
+  if (comm != nullptr) {
+    ORL_REQUIRE(width_policy + width_critic <= orl_comm_capacity(comm), "%s: %d floats exceed the comm's capacity %d", what,
+                width_policy + width_critic, orl_comm_capacity(comm));
+    rc = orl_comm_next(comm, &CM);  // one collective: pushed by the reducing workgroups, summed by the optimiser step's
+    if (rc) return rc;
+    use_comm = CM.world > 1;
+  }
+  (void)hipFuncSetAttribute((const void*)ppo_reduce_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ppo_reduce_apply_kernel, dim3(gp + gc + extra), dim3(1024), lds, (hipStream_t)stream, partials,
+                     n_blocks_policy, width_policy, gp, partials + (size_t)PPO_MAX_BLOCKS * width_policy, n_blocks_critic,
+                     width_critic, gc, P, Cc, sums, *hp, train_info_accum, J, stage_mv, CM, use_comm, sync_ctr);
+  return launch_status(what);
 }
 
 static int launch_reduce_pair(const char* what, orl_comm* comm, const float* partials, int n_blocks_policy,

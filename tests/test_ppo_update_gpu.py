@@ -135,13 +135,22 @@ def test_full_size_update_matches_reference_golden(perm_mode):
     ``gae_max_partials`` regime of the bench.  The buffer is regenerated from the seed (oracle/fixtures.py); the
     expected outputs are the REAL reference's ``compute_returns`` + ``PPOAlgorithm.train`` (oracle/gen_golden.py,
     case train_cfg2_full; reference algorithms/ppo.py:383-458, buffers/replay_data.py:320-423,553-646)."""
+    g = H.load_golden("train_cfg2_full")
+    cfg, module, buf, algo = _cfg2_full_engine(g)
+    algo.perm_mode = perm_mode
+    torch.manual_seed(int(g["perm_seed"]))
+    algo.prep_training()
+    info = algo.train(buf)
+    _assert_golden_outputs(g, module, info)
+
+
+def _cfg2_full_engine(g):
     from openrl_amd import spaces
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers.replay_data import ReplayData
     from openrl_amd.modules.ppo_module import PPOModule
     from oracle.fixtures import synth_update_buffer
 
-    g = H.load_golden("train_cfg2_full")
     N, T, D, n_act, seed = (int(x) for x in g["shape"])
     cfg = H.case_cfg(g)
     cfg.episode_length, cfg.n_rollout_threads, cfg.num_agents, cfg.rnn_hidden_size = T, N, 1, cfg.hidden_size
@@ -161,11 +170,7 @@ def test_full_size_update_matches_reference_golden(perm_mode):
     np.testing.assert_allclose(probe, g["returns_probe"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(ret[:-1].astype(np.float64).sum(), float(g["returns_sum"]), rtol=1e-6)
     algo = PPOAlgorithm(cfg, module, agent_num=1, device=DEV)
-    algo.perm_mode = perm_mode
-    torch.manual_seed(int(g["perm_seed"]))
-    algo.prep_training()
-    info = algo.train(buf)
-    _assert_golden_outputs(g, module, info)
+    return cfg, module, buf, algo
 
 
 @pytest.mark.parametrize("case", H.TRAIN_CASES)
@@ -237,6 +242,39 @@ def test_next_epoch_permutation_in_the_apply_launch_changes_nothing(case):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert (a[2] is None and b[2] is None) or torch.equal(a[2], b[2])
     assert len(a[3]) == len(b[3]) and all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+
+
+@pytest.mark.parametrize("turn_on", [True, False])
+@pytest.mark.parametrize("perm_mode", ["device", "reference"])
+@pytest.mark.parametrize("case", ["train_discrete", "train_discrete_masks", "train_gaussian", "train_cfg2_full"])
+def test_one_launch_optimiser_step_equals_the_two_launch_one_bit_for_bit(case, perm_mode, turn_on):
+    """orl_ppo_reduce_apply (ticketed workgroups: column sums, then the last workgroup of a tower runs its clip + Adam,
+    the others the next epoch's permutation) == orl_ppo_reduce_pair + orl_ppo_apply(_perm): weights, Adam moments, sums,
+    train_info, ValueNorm state and every epoch's indices identical; the tickets are back at zero after every call."""
+    if case == "train_cfg2_full" and (perm_mode, turn_on) != ("device", True):
+        pytest.skip("the full-size case runs once")
+    g = H.load_golden(case)
+    outs = []
+    for step in ("fused", "two_launch"):
+        cfg, module, buf, algo = _cfg2_full_engine(g) if case == "train_cfg2_full" else build_engine(g)
+        assert not algo._fused_step  # two launches are the default (the faster form, DESIGN.md section 6)
+        algo._fused_step = step == "fused"
+        algo.perm_mode = perm_mode
+        info = [dict(algo.train(buf, turn_on=turn_on)) for _ in range(2)]  # the second call starts from a used ticket array
+        assert algo._sync_ctr.cpu().tolist() == [0, 0, 0, 0]
+        vn = module.get_critic_value_normalizer()
+        opt = module.optimizers
+        outs.append(dict(p=module.models["policy"].theta.clone(), c=module.models["critic"].theta.clone(),
+                         pm=opt["policy"].exp_avg.clone(), pv=opt["policy"].exp_avg_sq.clone(),
+                         cm=opt["critic"].exp_avg.clone(), cv=opt["critic"].exp_avg_sq.clone(), sums=algo._sums.clone(),
+                         vn=None if vn is None else vn.state.clone(), idx=[i.clone() for i in algo.last_indices],
+                         info=info))
+    a, b = outs
+    for k in ("p", "c", "pm", "pv", "cm", "cv", "sums"):
+        assert torch.equal(a[k], b[k]), k
+    assert (a["vn"] is None and b["vn"] is None) or torch.equal(a["vn"], b["vn"])
+    assert len(a["idx"]) == len(b["idx"]) and all(torch.equal(x, y) for x, y in zip(a["idx"], b["idx"]))
+    assert a["info"] == b["info"]
 
 
 @pytest.mark.parametrize("case", ["train_discrete", "train_gaussian"])
