@@ -320,9 +320,64 @@ __global__ __launch_bounds__(256) void adv_normalize_pack_kernel(float* __restri
       s_tile[rr * R + off + c] = p[row0 * w + e];
     }
   };
+  // Narrow records (every source slab of a tile <= 4 elements per thread: configuration 2's obs 4 / Discrete(2)): all of a
+  // tile's global loads are issued into registers BEFORE the first LDS write.  The slab-by-slab form below is a chain of
+  // load -> s_waitcnt vmcnt(0) -> ds_write per slab, 5 serialized HBM round trips per tile.
+  int wmax = Dp > Dc ? Dp : Dc;
+  wmax = wmax > a ? wmax : a;
+  wmax = wmax > K ? wmax : K;
+  const bool narrow = (long long)PACK_ROWS * wmax <= 4LL * nth && PACK_ROWS <= nth;
   for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const long long row0 = t * PACK_ROWS;
     const int nrow = (M - row0) < PACK_ROWS ? (int)(M - row0) : PACK_ROWS;
+    if (narrow) {
+      float v_po[4], v_co[4], v_ac[4], v_lp[4], v_mk[4];
+      auto ld = [&](const float* __restrict__ p, int w, float (&v)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = tid + k * nth;
+          v[k] = e < nrow * w ? p[row0 * w + e] : 0.f;
+        }
+      };
+      auto st = [&](int w, int off, const float (&v)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = tid + k * nth;
+          if (e < nrow * w) {
+            const int rr = e / w;
+            s_tile[rr * R + off + (e - rr * w)] = v[k];
+          }
+        }
+      };
+      const bool has_mk = K > 0 && src.action_masks != nullptr;
+      const long long row = row0 + (tid < nrow ? tid : 0);  // clamped: the loads below are unconditional (one batch)
+      float x = adv[row];
+      const float pv = src.value_preds[row], rt = src.returns[row], am = src.active_masks[row];
+      ld(src.policy_obs, Dp, v_po);
+      ld(src.critic_obs, Dc, v_co);
+      ld(src.actions, a, v_ac);
+      ld(src.action_log_probs, a, v_lp);
+      if (has_mk) ld(src.action_masks, K, v_mk);
+      asm volatile("" ::"v"(x), "v"(pv), "v"(rt), "v"(am));  // keep them with the batch: one round trip per tile
+      st(Dp, 0, v_po);
+      st(Dc, o_co, v_co);
+      st(a, o_ac, v_ac);
+      st(a, o_lp, v_lp);
+      if (has_mk) st(K, o_mk, v_mk);
+      else
+        for (int e = tid; e < nrow * K; e += nth) s_tile[(e / K) * R + o_mk + (e % K)] = 1.f;
+      if (tid < nrow) {
+        if (use_adv_normalize) x = (x - c.m1) / c.s1;
+        const float v = (x - c.m2) / c.s2;
+        adv[row0 + tid] = v;
+        float* o = s_tile + tid * R;
+        o[o_adv] = v;
+        o[o_vp] = pv;
+        o[o_rt] = rt;
+        o[o_am] = am;
+        for (int k = o_end; k < R; ++k) o[k] = 0.f;
+      }
+    } else {
     slab(src.policy_obs, Dp, 0, row0, nrow);
     slab(src.critic_obs, Dc, o_co, row0, nrow);
     slab(src.actions, a, o_ac, row0, nrow);
@@ -344,6 +399,7 @@ __global__ __launch_bounds__(256) void adv_normalize_pack_kernel(float* __restri
       if (src.action_masks != nullptr) slab(src.action_masks, K, o_mk, row0, nrow);
       else
         for (int e = tid; e < nrow * K; e += nth) s_tile[(e / K) * R + o_mk + (e % K)] = 1.f;
+    }
     }
     __syncthreads();
     {
