@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   // self-play (ORL_ENV_TTT_POOL): the opponent's tower image, the opponent-side boards and masks of the current step
   float* s_opp = s_mask + TILE_B * 16;                         // TowerLds image of this tile's opponent policy
   const int n_img = PERK ? A.r.opp_n_policies : (IS_POOL ? 1 : 0);
-  float* s_oobs = s_opp + n_img * twp.total;                   // [16][DP]
+  float* s_oobs = s_opp + n_img * twp.total;                   // [16][DP] (unused: the opponent's fc1 reads s_oword)
   float* s_omask = s_oobs + TILE_B * DP;                       // [16][16]
   float* s_oppk = s_omask + TILE_B * 16;                       // [16] PERK: slot of the row's opponent this step, -1 = none
   int my_opp = 0;                                              // PERK: this env's pool slot (owning lanes)
