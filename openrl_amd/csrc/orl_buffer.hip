@@ -256,7 +256,11 @@ __device__ inline void reduce_partials(const double* __restrict__ partials, int 
   }
 }
 
-__global__ __launch_bounds__(256) void adv_normalize_pack_kernel(float* __restrict__ adv,
+// NV = source elements per thread and slab that the batched-load path of the record assembly holds in registers (4: narrow
+// records such as configuration 2's; 20: observations up to 20 wide at 256 rows per tile, wider ones at the smaller tiles
+// their records get); shapes beyond NV take the slab-by-slab loops.
+template <int NV>
+__global__ __launch_bounds__(256, 2) void adv_normalize_pack_kernel(float* __restrict__ adv,
                                                                  const double* __restrict__ partials, int n_partials,
                                                                  long long M, int L, int use_adv_normalize,
                                                                  double* __restrict__ stats_out, orl_pack_src src,
@@ -320,28 +324,35 @@ __global__ __launch_bounds__(256) void adv_normalize_pack_kernel(float* __restri
       s_tile[rr * R + off + c] = p[row0 * w + e];
     }
   };
-  // Narrow records (every source slab of a tile <= 4 elements per thread: configuration 2's obs 4 / Discrete(2)): all of a
-  // tile's global loads are issued into registers BEFORE the first LDS write.  The slab-by-slab form below is a chain of
-  // load -> s_waitcnt vmcnt(0) -> ds_write per slab, 5 serialized HBM round trips per tile.
+  // Every source slab of a tile <= NV elements per thread: all of a tile's global loads are issued into registers BEFORE
+  // the first LDS write - one HBM round trip per tile.  The slab-by-slab form below is a chain of (4 loads -> waits ->
+  // ds_writes) per slab: 5 serialized round trips per tile at configuration 2, 16 at configuration 5's 52-float records.
   int wmax = Dp > Dc ? Dp : Dc;
   wmax = wmax > a ? wmax : a;
   wmax = wmax > K ? wmax : K;
-  const bool narrow = (long long)PACK_ROWS * wmax <= 4LL * nth && PACK_ROWS <= nth;
+  constexpr int NA = NV < 16 ? NV : 16;  // registers for the action-side slabs (actions, log-probs, masks)
+  const int wa = a > K ? a : K;
+  const bool narrow = (long long)PACK_ROWS * wmax <= (long long)NV * nth && (long long)PACK_ROWS * wa <= (long long)NA * nth &&
+                      PACK_ROWS <= nth;
   for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const long long row0 = t * PACK_ROWS;
     const int nrow = (M - row0) < PACK_ROWS ? (int)(M - row0) : PACK_ROWS;
     if (narrow) {
-      float v_po[4], v_co[4], v_ac[4], v_lp[4], v_mk[4];
-      auto ld = [&](const float* __restrict__ p, int w, float (&v)[4]) {
+      float v_po[NV], v_co[NV], v_ac[NA], v_lp[NA], v_mk[NA];
+      auto ld = [&](const float* __restrict__ p, int w, auto& v) {
+        constexpr int N = sizeof(v) / sizeof(float);
+        const float* __restrict__ pb = p + row0 * w;  // wave-uniform base + a 32-bit lane offset: one address register per load
+        const int n = nrow * w;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < N; ++k) {
           const int e = tid + k * nth;
-          v[k] = e < nrow * w ? p[row0 * w + e] : 0.f;
+          v[k] = e < n ? pb[e] : 0.f;
         }
       };
-      auto st = [&](int w, int off, const float (&v)[4]) {
+      auto st = [&](int w, int off, const auto& v) {
+        constexpr int N = sizeof(v) / sizeof(float);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < N; ++k) {
           const int e = tid + k * nth;
           if (e < nrow * w) {
             const int rr = e / w;
@@ -692,8 +703,15 @@ int orl_adv_normalize_pack(float* adv, const double* stat_partials, int n_partia
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   const size_t tile_bytes = records ? (size_t)prow * R * sizeof(float) : 0;
-  hipLaunchKernelGGL(adv_normalize_pack_kernel, dim3(grid), dim3(256), tile_bytes, (hipStream_t)stream, adv, stat_partials,
-                     n_partials, M, L, use_adv_normalize, stats_out, s0, records, R, prow);
+  int wmax = s0.Dp > s0.Dc ? s0.Dp : s0.Dc;
+  wmax = wmax > s0.a ? wmax : s0.a;
+  wmax = wmax > s0.K ? wmax : s0.K;
+  if ((long long)prow * wmax <= 4LL * 256)
+    hipLaunchKernelGGL(adv_normalize_pack_kernel<4>, dim3(grid), dim3(256), tile_bytes, (hipStream_t)stream, adv,
+                       stat_partials, n_partials, M, L, use_adv_normalize, stats_out, s0, records, R, prow);
+  else
+    hipLaunchKernelGGL(adv_normalize_pack_kernel<20>, dim3(grid), dim3(256), tile_bytes, (hipStream_t)stream, adv,
+                       stat_partials, n_partials, M, L, use_adv_normalize, stats_out, s0, records, R, prow);
   return launch_status("orl_adv_normalize_pack");
 }
 
