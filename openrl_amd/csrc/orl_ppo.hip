@@ -75,6 +75,7 @@ static int launch_tower(const PpoArgs& A, hipStream_t s) {
                          sizeof(float);
       if (lds > 160 * 1024) continue;
       B.use_w2t = w2t;
+      B.lds_floats = (int)(lds / sizeof(float));
       const int grid = launch_tower_w<HEAD, NO, ND>(B, waves, lds, s);
       const int rc = launch_status("orl_ppo_fwd_bwd");
       return rc ? -1000 - rc : grid;
@@ -111,6 +112,7 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
     const size_t lds = lp > lc ? lp : lc;
     if (lds > 160 * 1024) continue;
     P2.use_w2t = w2t; C2.use_w2t = w2t;
+    P2.lds_floats = C2.lds_floats = (int)(lds / sizeof(float));
     const int n_tiles = (P.mb + TILE_B - 1) / TILE_B;
     // One workgroup fits a CU (LDS).  Two ways to run 2 x g workgroups on 256 CUs:
     //  * back to back: 256 + 256 workgroups, a critic workgroup starts on a CU when its policy workgroup retires - exact
@@ -211,8 +213,8 @@ int orl_ppo_max_blocks(void) { return PPO_MAX_BLOCKS; }
 
 #ifdef ORL_PROF
 // debug build only: cumulative per-phase cycle counts of wave 0 / workgroup 0 of every tower launch; reset on read
-int orl_debug_prof(unsigned long long* out16) {
-  unsigned long long zero[16] = {0};
+int orl_debug_prof(unsigned long long* out16) {  // 24 counters
+  unsigned long long zero[24] = {0};
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_orl_prof), sizeof(zero));
   hipMemcpyToSymbol(HIP_SYMBOL(g_orl_prof), zero, sizeof(zero));
@@ -239,7 +241,7 @@ int orl_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl_net
   PpoArgs A;
   A.records = records; A.idx = idx; A.vn_state = vn_state; A.hp = *hp; A.R = rec_width;
   A.o_act = o_ac; A.o_lp = o_lp; A.o_adv = o_adv; A.o_vp = o_adv + 1; A.o_rt = o_adv + 2; A.o_am = o_adv + 3;
-  A.o_mk = o_adv + 4; A.a_w = a_w; A.mb = mb; A.use_w2t = 1;
+  A.o_mk = o_adv + 4; A.a_w = a_w; A.mb = mb; A.use_w2t = 1; A.lds_floats = 0;
   // action-mask width: categorical records always carry n_out mask floats (ReplayData keeps ones)
   A.K = pnet->head_kind == ORL_HEAD_CATEGORICAL ? pnet->n_out : 0;
   ORL_REQUIRE(orl_record_width(Dp, Dc, a_w, A.K) == rec_width, "orl_ppo_fwd_bwd: record width %d != %d", rec_width,

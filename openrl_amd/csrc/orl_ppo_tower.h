@@ -34,7 +34,7 @@ namespace orl {
 // s_memtime after each phase of its tile loop and lane 0 adds the delta to an LDS counter (ds_add, no return value:
 // nothing on the vmcnt path - register accumulators were spilled to scratch by hipcc and global atomics sit in front
 // of the tile's own s_waitcnt vmcnt(0), both of which distorted the phases being measured).
-__device__ unsigned long long g_orl_prof[16];
+__device__ unsigned long long g_orl_prof[24];
 #define ORL_T(k)                                                                  \
   do {                                                                            \
     if (prof_on) {                                                                \
@@ -74,6 +74,7 @@ struct PpoArgs {
   // observation columns (chunks [c0_beg, c0_beg + c0_n)) and the tail fields from its first one on ([c1_beg, R / 4)) -
   // stored back to back (ring_chunks()); the ND == 0 build keeps whole records (4 chunks)
   int c0_beg, c0_n, c1_beg;
+  int lds_floats;  // dynamic LDS of the launch, in floats (the epilogue spreads the waves' accumulators over all of it)
 };
 
 // which chunks of a record a tower needs: fills A.c0_beg / c0_n / c1_beg, returns the number of chunks per row in the ring
@@ -162,6 +163,9 @@ __device__ inline void mm64_T_wt(const float* __restrict__ Ws, const f32x4 (&in)
 template <int HEAD, int NO, int ND, int SP_ = 0>
 __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef ORL_PROF
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
   const TowerLayout tl(A.net);
   const RawLayout rl(A.net);
   // On the ND == 0 path the padded obs width is 4 and for NO <= 4 the padded head width is 4: every LDS
@@ -305,6 +309,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   const bool prof_on = bid == 0 && wave == 0;
   if (prof_on && l < 16) prof_lds[l] = 0ull;
   unsigned long long t_last = __builtin_readcyclecounter();
+  const unsigned long long t_loop0 = t_last;
 #endif
   for (int tile = wave_g; tile < n_tiles; tile += n_waves) {
     const int i = tile * TILE_B + j;
@@ -898,6 +903,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   if (prof_on && l == 12) atomicAdd(&g_orl_prof[12], 1ull);
   if (prof_on && l == 13)  // tiles the probe wave walked (depends on how launch_pair_nd split the CUs)
     atomicAdd(&g_orl_prof[13], (unsigned long long)((n_tiles - wave_g + n_waves - 1) / n_waves));
+  if (prof_on && l == 14) atomicAdd(&g_orl_prof[14], t_loop0 - t_entry);  // prologue: entry -> first tile
+  const unsigned long long t_loop1 = __builtin_readcyclecounter();
 #endif
 #undef REC
 #undef RECX
@@ -905,16 +912,26 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 
   // ---- workgroup reduction of the waves' accumulators, fixed order (deterministic) ---------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before LDS is reused
+#ifdef ORL_PROF
+  if (prof_on && l == 16) atomicAdd(&g_orl_prof[16], __builtin_readcyclecounter() - t_loop1);  // ... the DMA drain
+#endif
   __syncthreads();
+#ifdef ORL_PROF
+  if (prof_on && l == 17) atomicAdd(&g_orl_prof[17], __builtin_readcyclecounter() - t_loop1);  // ... + waiting for the other waves
+#endif
   // The waves' accumulators are combined in a few PARALLEL rounds instead of one serial round per wave: the slab area
   // holds up to NREG full images of the partial row; in round p waves [p*NREG, (p+1)*NREG) each write (p == 0) or add
   // (p > 0) their accumulators into image (wave % NREG), and the images are then summed element-wise in image order.
   // Every element is produced by the same fixed sequence of additions on every launch (deterministic), the 8 serial
   // read-modify-write rounds + zero fill of the first version become 2 rounds + one pass at configuration 2.
+  // All of the workgroup's LDS is free now (the tower image is dead too).  One image per wave where that fits (configuration
+  // 2 with the launch's LDS rounded up to 8 x 18.4 KB): ONE round of plain stores - no read-modify-write round, no second
+  // barrier; otherwise as many images as divide the wave count.
   const int PW = rl.total + ORL_N_STATS;
-  float* img0 = smem + tw.total;  // reuse the slab area
-  int NREG = (nwv * per_wave) / PW;
-  NREG = NREG > 4 ? 4 : NREG < 1 ? 1 : NREG;
+  float* img0 = smem;
+  const int lds_have = A.lds_floats > 0 ? A.lds_floats : tw.total + nwv * per_wave;
+  int NREG = lds_have / PW;
+  NREG = NREG > nwv ? nwv : NREG < 1 ? 1 : NREG;
   while (nwv % NREG) --NREG;
   // only the statistics tail has slots no wave writes: zero it in every image, the rest is written by round 0
   for (int e = threadIdx.x; e < NREG * ORL_N_STATS; e += blockDim.x)
@@ -926,6 +943,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   for (int p = 0; p < nwv / NREG; ++p) {
     if (wave / NREG == p) {
       const bool first = p == 0;
+      // (later rounds as LDS float atomics instead of read-add-write were measured 4x SLOWER: 18 000 -> 79 000 cycles at
+      // configuration 3's two rounds)
       auto put = [&](int idx, float v) { acc[idx] = first ? v : acc[idx] + v; };
       const int f = l;
       if constexpr (SPW) {
@@ -1014,12 +1033,25 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     }
     __syncthreads();
   }
+#ifdef ORL_PROF
+  if (prof_on && l == 18) atomicAdd(&g_orl_prof[18], __builtin_readcyclecounter() - t_loop1);  // ... + the accumulator images
+#endif
   float* out = A.partials + (size_t)bid * PW;
+  // all images of an element are requested together and summed in image order (the rolled form was NREG dependent LDS round
+  // trips per element: 6 500 of the epilogue's 12 600 cycles at configuration 2)
+#pragma unroll 2
   for (int e = threadIdx.x; e < PW; e += blockDim.x) {
-    float t = img0[e];
-    for (int g = 1; g < NREG; ++g) t += img0[(size_t)g * PW + e];
+    float v[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v[g] = g < NREG ? img0[(size_t)g * PW + e] : 0.f;
+    float t = v[0];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += v[g];  // + 0.f for an image that is not there
     out[e] = t;
   }
+#ifdef ORL_PROF
+  if (prof_on && l == 15) atomicAdd(&g_orl_prof[15], __builtin_readcyclecounter() - t_loop1);  // epilogue: last tile -> end
+#endif
 }
 
 template <int HEAD, int NO, int ND>
@@ -1046,7 +1078,10 @@ inline size_t tower_lds_floats(const orl_net_desc& net, int R, int nop, int wave
   const int rts = net.obs_dim <= 4 ? (((R >> 2) + 3) >> 2) * 256 : ring_nch * 64;  // >= what the kernel uses
   const size_t per_wave = 2 * SLAB + 2 * rts + TILE_B * nop;
   size_t fl = (size_t)tw.total + (size_t)waves * per_wave;
-  const size_t need_acc = (size_t)tw.total + rl.total + ORL_N_STATS;
+  const size_t pw = (size_t)rl.total + ORL_N_STATS;
+  const size_t need_acc = pw;                      // the epilogue needs at least one image of the partial row
+  const size_t all_waves = (size_t)waves * pw;     // ... and takes one per wave when that still fits the CU's 160 KiB
+  if (fl < all_waves && all_waves * sizeof(float) <= 160 * 1024) fl = all_waves;
   return fl > need_acc ? fl : need_acc;
 }
 

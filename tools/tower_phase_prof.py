@@ -58,7 +58,7 @@ def main():
     lib = nat.load()
     if not hasattr(lib, "orl_debug_prof"):
         raise SystemExit("liborl_hip.so is not the timing build: python -m openrl_amd.csrc.build --prof")
-    out = (C.c_ulonglong * 16)()
+    out = (C.c_ulonglong * 24)()
     for it in range(3):
         buf.compute_returns(torch.zeros(N, 1, 1, device=dev), module.get_critic_value_normalizer())
         algo.train(buf)
@@ -70,6 +70,12 @@ def main():
                                                                                           tot / tiles))
     for k, name in enumerate(PHASES):
         print("  %-30s %8.0f  %5.1f %%" % (name, out[k] / tiles, 100.0 * out[k] / tot))
+    # per launch of the probe wave: kernel entry -> first tile (staging, first record DMA) and last tile -> end (accumulator
+    # reduction over the waves, partial row store); 2.4 cycles per ns at the 2.4 GHz shader clock
+    print("  per launch: prologue %.0f cycles, epilogue %.0f cycles, tiles %.0f cycles (%.1f tiles)" %
+          (out[14] / launches, out[15] / launches, tot / launches, tiles / launches))
+    print("  epilogue, cumulative: last DMA drained %.0f, all waves arrived %.0f, accumulator images written %.0f, partial row "
+          "stored %.0f" % (out[16] / launches, out[17] / launches, out[18] / launches, out[15] / launches))
 
 
 if __name__ == "__main__":
