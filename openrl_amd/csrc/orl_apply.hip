@@ -275,14 +275,36 @@ __device__ inline void reduce_columns_block(const float* __restrict__ partials, 
   const int rg = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (col < width) {
-    int b = rg;
-    for (; b + 48 < n_blocks; b += 64) {
-      s0 += partials[(size_t)b * width + col];
-      s1 += partials[(size_t)(b + 16) * width + col];
-      s2 += partials[(size_t)(b + 32) * width + col];
-      s3 += partials[(size_t)(b + 48) * width + col];
+    if (n_blocks <= 256) {
+      // the usual case (<= PPO_MAX_BLOCKS partial rows = <= 16 per thread): every load of the thread in ONE batch, then the
+      // additions of the loop below in its order (rows rg + 64 k + {0, 16, 32, 48} into s0..s3, the remainder into s0) -
+      // the loop form is one HBM round trip per 4 rows
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int b = rg + 16 * k;
+        v[k] = b < n_blocks ? partials[(size_t)b * width + col] : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (rg + 64 * g + 48 < n_blocks) {  // a complete group of four rows (these form a prefix of the groups)
+          s0 += v[4 * g]; s1 += v[4 * g + 1]; s2 += v[4 * g + 2]; s3 += v[4 * g + 3];
+        } else {                            // the remainder (all rows of any later group are >= n_blocks)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (rg + 64 * g + 16 * k < n_blocks) s0 += v[4 * g + k];
+        }
+      }
+    } else {
+      int b = rg;
+      for (; b + 48 < n_blocks; b += 64) {
+        s0 += partials[(size_t)b * width + col];
+        s1 += partials[(size_t)(b + 16) * width + col];
+        s2 += partials[(size_t)(b + 32) * width + col];
+        s3 += partials[(size_t)(b + 48) * width + col];
+      }
+      for (; b < n_blocks; b += 16) s0 += partials[(size_t)b * width + col];
     }
-    for (; b < n_blocks; b += 16) s0 += partials[(size_t)b * width + col];
   }
   sh[rg][lc] = (s0 + s1) + (s2 + s3);
   __syncthreads();
