@@ -465,6 +465,20 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
   __syncthreads();
   CoopRegs creg;  // this wave's loop-invariant trunk operands, out of LDS once
   coop_load(tlds, tww, gw, j, q, creg);
+  // ... and the head's: the policy head on wave 0 (narrow heads: W3 rows; wide heads: the 16 x 64 MFMA image's fragments and
+  // the bias quad), the value head on wave 4
+  HeadRegs<HMM ? 1 : NO> hreg_p;
+  HeadRegs<1> hreg_c;
+  f32x4 hfrag[4], hbias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (HMM) {
+    const int no4 = (A.pnet.n_out + 3) & ~3;
+    if (4 * q < no4) hbias = *(const f32x4*)(smem + twp.b3 + 4 * q);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) hfrag[mi] = *(const f32x4*)(smem + twp.W3P + j * W2S + 16 * mi + 4 * q);
+  } else {
+    head_regs_load<NO>(smem + twp.W3, smem + twp.b3, A.pnet.n_out, q, hreg_p);
+  }
+  if (WC) head_regs_load<1>(smem + twp.total + twc.W3, smem + twp.total + twc.b3, 1, q, hreg_c);
   RollProf rp;
 #ifdef ORL_PROF
   __shared__ unsigned long long prof_lds[16];
@@ -491,14 +505,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
       // dimensions (same expressions as sample_head) and stores them, instead of every lane of a row walking all NO
       // dimensions after a trip of the tile through LDS: this phase was 3 300 of the step's 7 900 cycles at Box(6).
       if (wave == 0) {
-        const int no4 = (n_out + 3) & ~3;
-        f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (4 * q < no4) mu = *(const f32x4*)(smem + twp.b3 + 4 * q);
+        f32x4 mu = hbias;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-          const f32x4 a4 = *(const f32x4*)(smem + twp.W3P + j * W2S + 16 * mi + 4 * q);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mu = ORL_MFMA(a4[r], n2[mi][r], mu);
+          for (int r = 0; r < 4; ++r) mu = ORL_MFMA(hfrag[mi][r], n2[mi][r], mu);
         }
         const float* noise = s_noise + (t & 1) * TILE_B * 16 + j * 16;
 #pragma unroll
@@ -519,14 +530,11 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
       // Wide categorical heads: sampled on the MFMA fragment (sample_cat_frag) - no trip of the logits tile through
       // LDS, 4 classes per lane instead of NO per lane: this phase was 4 200 of the step's 8 900 cycles at Discrete(9).
       if (wave == 0) {
-        const int no4 = (n_out + 3) & ~3;
-        f32x4 lgv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (4 * q < no4) lgv = *(const f32x4*)(smem + twp.b3 + 4 * q);
+        f32x4 lgv = hbias;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-          const f32x4 a4 = *(const f32x4*)(smem + twp.W3P + j * W2S + 16 * mi + 4 * q);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) lgv = ORL_MFMA(a4[r], n2[mi][r], lgv);
+          for (int r = 0; r < 4; ++r) lgv = ORL_MFMA(hfrag[mi][r], n2[mi][r], lgv);
         }
         float av, lp;
         sample_cat_frag(lgv, n_out, q, IS_TTT ? s_mask + j * 16 : nullptr, s_noise[(t & 1) * TILE_B * 16 + j * 16], av, lp);
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     } else if (wave == 0) {
       float hd[NO], lp_o[NO];
       if constexpr (HMM) head_mfma_T<NO>(smem + twp.W3P, smem + twp.b3, n_out, n2, s_logits, j, q, hd);
-      else head_T<NO>(smem + twp.W3, smem + twp.b3, n_out, n2, q, hd);
+      else head_T_regs<NO>(hreg_p, n2, hd);
       // the built-in device envs never mask actions (their action_masks rows stay all-ones), so the mask is
       // not re-read from HBM on the per-step critical path
       sample_head<NO, HEAD>(hd, n_out, smem + twp.logstd, IS_TTT ? s_mask + j * 16 : nullptr,
@@ -800,9 +808,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
       }
     }
     if (WC && wave == 4) {
-      const float* lc = smem + twp.total;
       float v[1];
-      head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
+      head_T_regs<1>(hreg_c, n2, v);
       if (ok && q == 0) A.r.value_preds[(size_t)t * N + n] = v[0];
     }
     RO_T(rp, 6);
@@ -826,9 +833,8 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
     f32x4 n2[4];
     trunk_fwd_coop(tlds, tww, creg, xb, gA, gB, gw, j, q, n2, rp);
     if (wave == 4) {
-      const float* lc = smem + twp.total;
       float v[1];
-      head_T<1>(lc + twc.W3, lc + twc.b3, 1, n2, q, v);
+      head_T_regs<1>(hreg_c, n2, v);
       if (ok && q == 0) A.next_value[n] = v[0];
     }
   }

@@ -474,6 +474,43 @@ __device__ inline void head_T(const float* __restrict__ W3s, const float* __rest
   }
 }
 
+// head_T with the head's weights resident in registers (the fused rollout: W3 / b3 do not change during a launch, but the
+// compiler may not keep LDS contents in registers across a barrier - 8 ds_read_b128 + 2 ds_read_b32 and their waits on every
+// step's serial chain at Discrete(2)).  Same products, same order of additions as head_T; classes >= n_out hold zeros, so
+// all NO chains run unconditionally (no scalar branch between them: they interleave) and return 0 as head_T does.
+template <int NO>
+struct HeadRegs {
+  f32x4 w[NO][4];
+  float b[NO];
+};
+
+template <int NO>
+__device__ inline void head_regs_load(const float* __restrict__ W3s, const float* __restrict__ b3s, int n_out, int q,
+                                      HeadRegs<NO>& H) {
+#pragma unroll
+  for (int c = 0; c < NO; ++c) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      H.w[c][m] = c < n_out ? *(const f32x4*)(W3s + c * HID + 16 * m + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    H.b[c] = c < n_out ? b3s[c] : 0.f;
+  }
+}
+
+template <int NO>
+__device__ inline void head_T_regs(const HeadRegs<NO>& H, const f32x4 (&n2)[4], float (&out)[NO]) {
+#pragma unroll
+  for (int c = 0; c < NO; ++c) {
+    float p = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 w = H.w[c][m];
+      p += (w[0] * n2[m][0] + w[1] * n2[m][1]) + (w[2] * n2[m][2] + w[3] * n2[m][3]);
+    }
+    p = row_allsum(p);
+    out[c] = p + H.b[c];
+  }
+}
+
 // LDS operations of one wave execute in issue order, so a later ds_read observes an earlier ds_write of
 // ANY lane of the same wave; only the compiler has to be kept from reordering across this point (it still
 // inserts the lgkmcnt wait before a read's first use).
