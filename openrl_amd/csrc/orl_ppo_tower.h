@@ -949,13 +949,34 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       const int f = l;
       if constexpr (SPW) {
         // 32x32 C fragment: lane (c = l & 31, kb = l >> 5), reg r -> G[o = 32bo + (r&3) + 8(r>>2) + 4kb][i = 32bi + c]
+        // G is 64 of a lane's ~90 elements.  A later round reads ALL 64 old values first, then adds and stores: element by
+        // element (`put`) the compiler kept every read-add-write a dependent LDS round trip - 11 000 cycles for the second
+        // round at configuration 3.
+        auto g_idx = [&](int bo, int bi, int r) {
+          return rl.oG + (32 * bo + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * HID + 32 * bi + (l & 31);
+        };
+        if (first) {
 #pragma unroll
-        for (int bo = 0; bo < 2; ++bo)
+          for (int bo = 0; bo < 2; ++bo)
 #pragma unroll
-          for (int bi = 0; bi < 2; ++bi)
+            for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              put(rl.oG + (32 * bo + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * HID + 32 * bi + (l & 31), GS[bo][bi][r]);
+              for (int r = 0; r < 16; ++r) acc[g_idx(bo, bi, r)] = GS[bo][bi][r];
+        } else {
+          float old[2][2][16];
+#pragma unroll
+          for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) old[bo][bi][r] = acc[g_idx(bo, bi, r)];
+#pragma unroll
+          for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[g_idx(bo, bi, r)] = old[bo][bi][r] + GS[bo][bi][r];
+        }
         const float d0 = a_db2s[0] + __shfl_xor(a_db2s[0], 32), d1s = a_db2s[1] + __shfl_xor(a_db2s[1], 32);
         if (l < 32) {
           put(rl.odb2 + l, d0);
@@ -963,12 +984,29 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         }
       } else {
         // G tiles: lane (c = j, q), reg r -> G[o = 16mo+4q+r][i = 16mi+c]
+        auto g_idx = [&](int mo, int mi, int r) { return rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j; };
+        if (first) {
 #pragma unroll
-        for (int mo = 0; mo < 4; ++mo)
+          for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) put(rl.oG + (16 * mo + 4 * q + r) * HID + 16 * mi + j, G[mo][mi][r]);
+              for (int r = 0; r < 4; ++r) acc[g_idx(mo, mi, r)] = G[mo][mi][r];
+        } else {  // all old values first, then add + store (see the split build above)
+          float old[4][4][4];
+#pragma unroll
+          for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) old[mo][mi][r] = acc[g_idx(mo, mi, r)];
+#pragma unroll
+          for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[g_idx(mo, mi, r)] = old[mo][mi][r] + G[mo][mi][r];
+        }
         put(rl.odb2 + f, a_db2);
       }
       if constexpr (W1S) {
@@ -981,11 +1019,20 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         put(rl.odb1 + f, a_db1);
       }
       if constexpr (HMM) {
+        // wide heads: 16 more elements per lane, batched like G
+        auto s_idx = [&](int mi, int r) { return rl.oS3 + (4 * q + r) * HID + 16 * mi + j; };
+        float old[4][4];
+        if (!first) {
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) old[mi][r] = 4 * q + r < n_out ? acc[s_idx(mi, r)] : 0.f;
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (4 * q + r < n_out) put(rl.oS3 + (4 * q + r) * HID + 16 * mi + j, S3acc[mi][r]);
+            if (4 * q + r < n_out) acc[s_idx(mi, r)] = first ? S3acc[mi][r] : old[mi][r] + S3acc[mi][r];
       } else {
 #pragma unroll
         for (int c = 0; c < NO; ++c)
@@ -995,12 +1042,19 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       if (HEAD == ORL_HEAD_GAUSSIAN && f < n_out) put(rl.odlogstd + f, a_dls);
       if constexpr (W1S) {
         // 32x32 C fragment: lane (c = l & 31, kb = l >> 5), reg r -> dW1[f = 32bo + (r&3) + 8(r>>2) + 4kb][column c]
-        if ((l & 31) < D) {
+        if ((l & 31) < D) {  // 32 elements per lane, batched like G
+          auto w_idx = [&](int bo, int r) { return rl.odW1 + (32 * bo + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * D + (l & 31); };
+          float old[2][16];
+          if (!first) {
+#pragma unroll
+            for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) old[bo][r] = acc[w_idx(bo, r)];
+          }
 #pragma unroll
           for (int bo = 0; bo < 2; ++bo)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              put(rl.odW1 + (32 * bo + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * D + (l & 31), G1S[bo][r]);
+            for (int r = 0; r < 16; ++r) acc[w_idx(bo, r)] = first ? G1S[bo][r] : old[bo][r] + G1S[bo][r];
         }
       } else if (ND == 0) {
 #pragma unroll
