@@ -292,78 +292,137 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
   // so a tile's forward feeds xhat straight into the GEMMs and its backward gets d xhat = (W diag(g))^T d out from the
   // same images: no per-tile reads of g / be, no affine or d*g passes.  The images of W2, W2^T, W3 hold W diag(g), the
   // b2 / b3 slots hold the folded biases; the raw gradient sums (G = dz2^T xhat1, ...) are unchanged.
-  if (with_w3p) {
-    for (int e = tid; e < 16 * W2S; e += nthreads) {
-      const int c = e / W2S, i = e - c * W2S;
-      lds[tw.W3P + e] = (c < tl.n_out && i < HID) ? theta[tl.oW3 + c * HID + i] * (fold ? theta[tl.og2 + i] : 1.f) : 0.f;
-    }
-  }
+  // Staging runs in ROUNDS: in round r every array contributes its element tid + r * nthreads, all of the round's global loads
+  // are issued before the first LDS store (phase 1 / phase 2 below).  Array by array - one rolled loop each - every loop
+  // iteration was a global round trip of its own: 12 in a row for a wide-observation tower on 512 threads, 12 000 cycles of
+  // prologue per launch (tools/tower_phase_prof.py).  Same expressions per element as before: bit-identical images.
   const int D = tl.D;
-  for (int e = tid; e < HID * tw.DP; e += nthreads) {
-    const int f = e / tw.DP, k = e - f * tw.DP;
-    lds[tw.W1 + e] = (k < D) ? theta[tl.oW1 + f * D + k] : 0.f;
-  }
-  for (int e = tid; e < HID; e += nthreads) {
-    lds[tw.b1 + e] = theta[tl.ob1 + e];
-    lds[tw.g1 + e] = theta[tl.og1 + e];
-    lds[tw.be1 + e] = theta[tl.obe1 + e];
-    if (!fold) lds[tw.b2 + e] = theta[tl.ob2 + e];  // (fold: ONE writer per slot - the folded-bias loop below)
-    lds[tw.g2 + e] = theta[tl.og2 + e];
-    lds[tw.be2 + e] = theta[tl.obe2 + e];
-  }
-  if (split) {  // bf16 images: fc2's A = W2 (rows o, reduction over i), dgrad's A = W2^T (rows i, reduction over o)
-    unsigned short* b2 = (unsigned short*)(lds + tw.W2);
-    unsigned short* b2t = (unsigned short*)(lds + tw.W2T);
-    // one 2 x 2 block of W2 per thread and trip: its two row pairs are dword stores of W2's image, its two column pairs dword
-    // stores of the transposed image (split_weight_store2) - no sub-dword LDS store in the staging
-    for (int b = tid; b < (HID / 2) * (HID / 2); b += nthreads) {
-      const int o = 2 * (b >> 5), i = 2 * (b & 31);
-      const float g0 = fold ? theta[tl.og1 + i] : 1.f, g1v = fold ? theta[tl.og1 + i + 1] : 1.f;
-      const float w00 = theta[tl.oW2 + o * HID + i] * g0, w01 = theta[tl.oW2 + o * HID + i + 1] * g1v;
-      const float w10 = theta[tl.oW2 + (o + 1) * HID + i] * g0, w11 = theta[tl.oW2 + (o + 1) * HID + i + 1] * g1v;
-      split_weight_store2(b2, o, i, w00, w01);
-      split_weight_store2(b2, o + 1, i, w10, w11);
-      if (with_w2t) {
-        split_weight_store2(b2t, i, o, w00, w10);
-        split_weight_store2(b2t, i + 1, o, w01, w11);
+  const int no4 = (tl.n_out + 3) & ~3;
+  const int n_w3p = with_w3p ? 16 * W2S : 0;
+  const int n_w1 = HID * tw.DP;
+  const int n_w2 = split ? (HID / 2) * (HID / 2) : HID * HID;  // 2 x 2 blocks (bf16 images) or elements
+  const int n_w3 = with_w3p ? 0 : no4 * HID;
+  const int rows = HID + tl.n_out;  // folded biases: b2' rows, then b3' rows; 8 threads (aligned lane groups) per row
+  const int n_fb = fold ? rows * 8 : 0;
+  int n_max = n_w3p > n_w1 ? n_w3p : n_w1;
+  n_max = n_w2 > n_max ? n_w2 : n_max;
+  n_max = n_w3 > n_max ? n_w3 : n_max;
+  n_max = n_fb > n_max ? n_fb : n_max;
+  n_max = HID > n_max ? HID : n_max;
+  unsigned short* b2i = (unsigned short*)(lds + tw.W2);
+  unsigned short* b2t = (unsigned short*)(lds + tw.W2T);
+  struct Round {  // one round's loaded values of one thread
+    float p_w, p_g, w1v, vb1, vg1, vbe1, vb2, vg2, vbe2, w00, w01, w10, w11, g0, g1v, w3v, w3g, vb3, vls, fw[8], fbe[8], fb;
+  };
+  // ---- phase 1: loads -----------------------------------------------------------------------------------------------------
+  auto load_round = [&](int e, Round& R) {
+    R.p_w = 0.f; R.p_g = 1.f;                      // W3P
+    const int pc = e / W2S, pi = e - pc * W2S;
+    if (e < n_w3p && pc < tl.n_out && pi < HID) {
+      R.p_w = theta[tl.oW3 + pc * HID + pi];
+      if (fold) R.p_g = theta[tl.og2 + pi];
+    }
+    R.w1v = 0.f;                                   // W1
+    const int w1f = e / tw.DP, w1k = e - w1f * tw.DP;
+    if (e < n_w1 && w1k < D) R.w1v = theta[tl.oW1 + w1f * D + w1k];
+    R.vb1 = R.vg1 = R.vbe1 = R.vb2 = R.vg2 = R.vbe2 = 0.f;  // the 64-wide vectors
+    if (e < HID) {
+      R.vb1 = theta[tl.ob1 + e]; R.vg1 = theta[tl.og1 + e]; R.vbe1 = theta[tl.obe1 + e];
+      if (!fold) R.vb2 = theta[tl.ob2 + e];  // (fold: ONE writer per slot - the folded biases below)
+      R.vg2 = theta[tl.og2 + e]; R.vbe2 = theta[tl.obe2 + e];
+    }
+    R.w00 = R.w01 = R.w10 = R.w11 = 0.f; R.g0 = R.g1v = 1.f;  // W2
+    const int bo = split ? 2 * (e >> 5) : (e >> 6), bi = split ? 2 * (e & 31) : (e & 63);
+    if (e < n_w2) {
+      if (fold) R.g0 = theta[tl.og1 + bi];
+      R.w00 = theta[tl.oW2 + bo * HID + bi];
+      if (split) {
+        if (fold) R.g1v = theta[tl.og1 + bi + 1];
+        R.w01 = theta[tl.oW2 + bo * HID + bi + 1];
+        R.w10 = theta[tl.oW2 + (bo + 1) * HID + bi];
+        R.w11 = theta[tl.oW2 + (bo + 1) * HID + bi + 1];
       }
     }
-  } else
-  for (int e = tid; e < HID * HID; e += nthreads) {
-    const int o = e >> 6, i = e & 63;
-    const float w = theta[tl.oW2 + e] * (fold ? theta[tl.og1 + i] : 1.f);
-    lds[tw.W2 + o * W2S + i] = w;
-    if (with_w2t) lds[tw.W2T + i * W2S + o] = w;
-  }
-  const int no4 = (tl.n_out + 3) & ~3;
-  if (!with_w3p)
-    for (int e = tid; e < no4 * HID; e += nthreads)
-      lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] * (fold ? theta[tl.og2 + (e & 63)] : 1.f) : 0.f;
-  for (int e = tid; e < no4; e += nthreads) {
-    if (!fold || e >= tl.n_out) lds[tw.b3 + e] = (e < tl.n_out) ? theta[tl.ob3 + e] : 0.f;
-    if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = (e < tl.n_out) ? theta[tl.ologstd + e] : 0.f;
-  }
-  if (fold) {
-    // folded biases: 8 threads per output (aligned groups of 8 lanes), each sums 8 terms, xor-shuffle over the group.
-    // Every lane of a wave runs the same number of rounds (the shuffles are wave-wide).
-    const int rows = HID + tl.n_out;  // b2' rows, then b3' rows
-    for (int e0 = 0; e0 < rows * 8; e0 += nthreads) {
-      const int e = e0 + tid, o = e >> 3, part = e & 7;
-      float acc = 0.f;
-      if (o < rows) {
-        const float* wrow = o < HID ? theta + tl.oW2 + o * HID : theta + tl.oW3 + (o - HID) * HID;
-        const float* be = theta + (o < HID ? tl.obe1 : tl.obe2);
+    R.w3v = 0.f; R.w3g = 1.f;                      // W3 (narrow heads)
+    if (e < n_w3 && e < tl.n_out * HID) {
+      R.w3v = theta[tl.oW3 + e];
+      if (fold) R.w3g = theta[tl.og2 + (e & 63)];
+    }
+    R.vb3 = R.vls = 0.f;                           // b3 / logstd
+    if (e < no4 && e < tl.n_out) {
+      if (!fold) R.vb3 = theta[tl.ob3 + e];
+      if (tl.head == ORL_HEAD_GAUSSIAN) R.vls = theta[tl.ologstd + e];
+    }
+    const int fo = e >> 3, part = e & 7;           // folded biases: 8 terms of row fo, part `part`
+    R.fb = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc += wrow[8 * part + k] * be[8 * part + k];
+    for (int k = 0; k < 8; ++k) R.fw[k] = R.fbe[k] = 0.f;
+    if (fold && fo < rows) {
+      const float* wrow = fo < HID ? theta + tl.oW2 + fo * HID : theta + tl.oW3 + (fo - HID) * HID;
+      const float* be = theta + (fo < HID ? tl.obe1 : tl.obe2);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        R.fw[k] = wrow[8 * part + k];
+        R.fbe[k] = be[8 * part + k];
       }
+      if (part == 0) R.fb = fo < HID ? theta[tl.ob2 + fo] : theta[tl.ob3 + (fo - HID)];
+    }
+  };
+  // ---- phase 2: stores ----------------------------------------------------------------------------------------------------
+  auto store_round = [&](int e, const Round& R) {
+    const int pc = e / W2S, pi = e - pc * W2S;
+    if (e < n_w3p) lds[tw.W3P + e] = (pc < tl.n_out && pi < HID) ? R.p_w * R.p_g : 0.f;
+    if (e < n_w1) lds[tw.W1 + e] = R.w1v;
+    if (e < HID) {
+      lds[tw.b1 + e] = R.vb1; lds[tw.g1 + e] = R.vg1; lds[tw.be1 + e] = R.vbe1;
+      if (!fold) lds[tw.b2 + e] = R.vb2;
+      lds[tw.g2 + e] = R.vg2; lds[tw.be2 + e] = R.vbe2;
+    }
+    if (e < n_w2) {
+      const int bo = split ? 2 * (e >> 5) : (e >> 6), bi = split ? 2 * (e & 31) : (e & 63);
+      if (split) {
+        // bf16 images: fc2's A = W2 (rows o, reduction over i), dgrad's A = W2^T (rows i, reduction over o).  One 2 x 2
+        // block of W2 per thread and round: its two row pairs are dword stores of W2's image, its two column pairs dword
+        // stores of the transposed image (split_weight_store2) - no sub-dword LDS store in the staging
+        const float a00 = R.w00 * R.g0, a01 = R.w01 * R.g1v, a10 = R.w10 * R.g0, a11 = R.w11 * R.g1v;
+        split_weight_store2(b2i, bo, bi, a00, a01);
+        split_weight_store2(b2i, bo + 1, bi, a10, a11);
+        if (with_w2t) {
+          split_weight_store2(b2t, bi, bo, a00, a10);
+          split_weight_store2(b2t, bi + 1, bo, a01, a11);
+        }
+      } else {
+        const float w = R.w00 * R.g0;
+        lds[tw.W2 + bo * W2S + bi] = w;
+        if (with_w2t) lds[tw.W2T + bi * W2S + bo] = w;
+      }
+    }
+    if (e < n_w3) lds[tw.W3 + e] = e < tl.n_out * HID ? R.w3v * R.w3g : 0.f;
+    if (e < no4) {
+      if (!fold || e >= tl.n_out) lds[tw.b3 + e] = R.vb3;
+      if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = R.vls;
+    }
+    if (fold) {
+      const int fo = e >> 3, part = e & 7;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += R.fw[k] * R.fbe[k];
       acc += __shfl_xor(acc, 1);
       acc += __shfl_xor(acc, 2);
       acc += __shfl_xor(acc, 4);
-      if (o < rows && part == 0) {
-        if (o < HID) lds[tw.b2 + o] = theta[tl.ob2 + o] + acc;
-        else lds[tw.b3 + (o - HID)] = theta[tl.ob3 + (o - HID)] + acc;
+      if (fo < rows && part == 0) {
+        if (fo < HID) lds[tw.b2 + fo] = R.fb + acc;
+        else lds[tw.b3 + (fo - HID)] = R.fb + acc;
       }
     }
+  };
+  // one round per trip (two rounds in flight per trip were measured no faster at configuration 2 and slower at the wide
+  // towers: 9 500 -> 10 900 cycles of prologue); every lane of a wave runs the same trips - the shuffles of the folded
+  // biases are wave-wide
+  for (int e0 = 0; e0 < n_max; e0 += nthreads) {
+    Round R;
+    load_round(e0 + tid, R);
+    store_round(e0 + tid, R);
   }
 }
 
