@@ -134,11 +134,20 @@ __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __r
     lds[tw.bhh + e] = theta[tl.obhh + e];
   }
   if (!stream) {
-    for (int e = tid; e < HID * HID; e += nthreads) lds[tw.W2 + (e >> 6) * W2S + (e & 63)] = theta[tl.oW2 + e];
-    for (int e = tid; e < 3 * HID * HID; e += nthreads) {
-      lds[tw.Wih + (e >> 6) * W2S + (e & 63)] = theta[tl.oWih + e];
-      lds[tw.Whh + (e >> 6) * W2S + (e & 63)] = theta[tl.oWhh + e];
-    }
+    // The seven 64 x 64 matrices are plain copies with a new row stride: one LDS-DMA instruction per row (a wave's 64 lanes
+    // = the row's 64 floats, written at a wave-uniform LDS address), all 448 of a workgroup in flight at once.  The register
+    // loops they replace were 8 loads in flight per trip - 7 to 28 global round trips in a row on 512 to 128 threads.
+    const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;  // every caller launches whole waves
+    // (one loop per matrix with scalar bases: selecting the layout fields by a matrix index sent them through scratch, and
+    // every trip then waited vmcnt(0) - for its predecessor's DMA - before it could issue its own)
+    auto rows = [&](const float* __restrict__ src, float* __restrict__ dst, int n_rows) {
+      for (int r = wave; r < n_rows; r += nw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * HID + lane),
+                                         (__attribute__((address_space(3))) void*)(dst + r * W2S), 4, 0, 0);
+    };
+    rows(theta + tl.oW2, lds + tw.W2, HID);
+    rows(theta + tl.oWih, lds + tw.Wih, 3 * HID);
+    rows(theta + tl.oWhh, lds + tw.Whh, 3 * HID);
   }
   const int no4 = (tl.n_out + 3) & ~3;
   for (int e = tid; e < no4 * HID; e += nthreads) lds[tw.W3 + e] = (e < tl.n_out * HID) ? theta[tl.oW3 + e] : 0.f;
@@ -146,6 +155,7 @@ __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __r
     lds[tw.b3 + e] = (e < tl.n_out) ? theta[tl.ob3 + e] : 0.f;
     if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = (e < tl.n_out) ? theta[tl.ologstd + e] : 0.f;
   }
+  if (!stream) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA rows have landed (callers barrier next)
 }
 
 // acc += W[64 x 64, row stride S] * in   (T layout; S = W2S for the LDS image, 64 for weights read from global)
