@@ -152,3 +152,30 @@ def test_model_dict_accepts_the_stock_network_classes_and_refuses_foreign_ones()
         check_model_dict({"actor": PolicyNetwork})
     with pytest.raises(TypeError):
         PolicyNetwork()
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """profiles/r04_bench_line.json is what `python bench.py` printed on an MI355X for the final tree: the fields the
+    driver's contract names are all there, typed, and consistent with each other (a schema check - no GPU needed)."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_bench_line.json")
+    line = json.load(open(path))
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(line[k], t), k
+    assert "vs_baseline" in line and line["n_gpus"] == 1 and line["higher_is_better"] is True
+    assert "workload" in line["config"] and "model" not in line["config"]
+    # value = env-steps of the timed steps / their wall time
+    steps_total = line["config"]["global_envs"] * line["config"]["rollout_len"] * line["steps"]
+    assert abs(line["value"] - steps_total / (line["ms_per_step"] * 1e-3 * line["steps"])) <= 1e-3 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["launch_ms"] * 1e-3) / 1e12) < 0.05  # TFLOP/s from the live launch time
+    assert r["launches_timed"] > 0 and (r["traffic"] is None or r["traffic"] > 0)
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == line["unit"]
+    assert isinstance(c["sample"], str) and c["sample"]
