@@ -130,32 +130,71 @@ def multi_gpu_report(trainer, args, dev, world, rank, make_engine):
         raise SystemExit("orl_comm error word set on some rank (%d): a peer's contribution timed out - the timed run summed "
                          "partial gradients" % int(err.item()))
     if args.scaling == "strong" and not args.no_weak_leg:
-        try:
-            rep["weak_scaling"] = _weak_leg(args, dev, world, make_engine)
-        except Exception as e:  # noqa: BLE001 - the strong-scaling line must survive a failing extra
-            rep["weak_scaling"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # (never raises between collectives: every local stage's outcome is agreed on by all ranks, see _weak_leg)
+        rep["weak_scaling"] = _weak_leg(args, dev, world, make_engine, first_comm=comm)
     return rep
 
 
-def _weak_leg(args, dev, world, make_engine):
-    """Weak scaling next to the strong number: the full 4096 envs on EVERY rank, a short run of the same loop."""
-    drv_w, trainer_w = make_engine(args.envs)
+def _all_ok(local_ok, dev):
+    """One MIN all-reduce of a status flag: every rank learns whether EVERY rank got through its last local stage."""
+    t = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def _weak_leg(args, dev, world, make_engine, first_comm=None):
+    """Weak scaling next to the strong number: the full 4096 envs on EVERY rank, a short run of the same loop.
+
+    Local failures never skip a collective: after each local stage (engine construction, warm-up, timed loop) the ranks
+    agree on its outcome with one status all-reduce (`_all_ok`) and either all go on or all return the error record.  The
+    strong leg's comm is closed first, so that only one set of peer mappings is open at a time."""
+    if first_comm is not None:
+        try:
+            first_comm.close()
+        except Exception:  # noqa: BLE001
+            pass
+    why = None
+    drv_w = trainer_w = None
+    try:
+        drv_w, trainer_w = make_engine(args.envs)  # (its comm set-up is itself collective and never raises in between)
+    except Exception as e:  # noqa: BLE001
+        why = "make_engine: %s: %s" % (type(e).__name__, e)
+    if not _all_ok(why is None, dev):
+        return {"error": why or "a peer failed in make_engine"}
     k = max(2, min(args.steps, 8))
-    for i in range(2):
-        drv_w.episode = i
-        drv_w._inner_loop()
+    try:
+        for i in range(2):
+            drv_w.episode = i
+            drv_w._inner_loop()
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        why = "warm-up: %s: %s" % (type(e).__name__, e)
+    if not _all_ok(why is None, dev):
+        return {"error": why or "a peer failed in the warm-up"}
     torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(k):
-        drv_w.episode = 2 + i
-        drv_w._inner_loop()
+    try:
+        for i in range(k):
+            drv_w.episode = 2 + i
+            drv_w._inner_loop()
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        why = "timed loop: %s: %s" % (type(e).__name__, e)
+    if not _all_ok(why is None, dev):
+        return {"error": why or "a peer failed in the timed loop"}
     torch.distributed.barrier()
     torch.cuda.synchronize()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    err = 0
     if getattr(trainer_w, "_comm", None) is not None:
-        trainer_w._comm.check()
+        try:
+            trainer_w._comm.check()
+        except Exception:  # noqa: BLE001
+            err = 1
+    if not _all_ok(err == 0, dev):
+        return {"error": "orl_comm error word set on some rank during the weak leg"}
     return {"value": round(args.envs * world * T_ROLL * k / float(t.item()), 1), "unit": "env-steps/s",
             "envs_per_gpu": args.envs, "steps": k, "ms_per_step": round(float(t.item()) / k * 1e3, 4)}
 

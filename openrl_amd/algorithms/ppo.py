@@ -554,8 +554,12 @@ class PPOAlgorithm(BaseAlgorithm):
         # copied or scaled on the device afterwards.  Default MLP towers: the first apply launch overwrites its slots
         # (hparams.reserved & 32) - no zero fill either; the other update paths accumulate from zero.
         self._info = torch.empty(8, dtype=torch.float32, device=self.device)
+        num_updates = self.ppo_epoch * self.num_mini_batch
+        if num_updates <= 0:
+            raise ValueError("train_ppo: ppo_epoch * num_mini_batch must be positive (got %d x %d)"
+                             % (self.ppo_epoch, self.num_mini_batch))
         self._info_first = not (self.generic or self.recurrent)
-        if not self._info_first:
+        if not self._info_first:  # (slots 6 and 7 are no train_info keys: only [:len(info_keys)] is ever returned)
             self._info.zero_()
         self.last_indices = []
         next_perm = None
@@ -580,7 +584,7 @@ class PPOAlgorithm(BaseAlgorithm):
                         and self.perm_mode == "device"):
                     job = self._perm_job(M)
                 next_perm = self._update_minibatch(buffer, idx, mbs, turn_on, job)
-        num_updates = self.ppo_epoch * self.num_mini_batch
+        self._info_first = False  # armed for this call's first apply launch only
         # no device->host sync here: the averages stay on the device until somebody reads the dict (logging every
         # log_interval iterations, tests), so the host can enqueue the next rollout while this update still runs
         keys = self.info_keys

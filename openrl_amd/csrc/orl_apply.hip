@@ -146,6 +146,7 @@ __device__ inline void apply_tower_block(const int t, const ApplyTower& P, const
     const TowerLayout& tl = t == 0 ? tlp : tlc;
     const RawLayout& rl = t == 0 ? rlp : rlc;
     if (t == 0 && (hp.reserved & 1)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA (stage_dma above) has landed, as on the main path
       __syncthreads();
       den_p = hp.use_policy_active_masks ? st[ST_ACTIVE_SUM] : st[ST_ROWS];
       const float* stp = st;

@@ -931,7 +931,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   float* img0 = smem;
   const int lds_have = A.lds_floats > 0 ? A.lds_floats : tw.total + nwv * per_wave;
   int NREG = lds_have / PW;
+  constexpr int NREG_MAX = 8;  // images the final element-wise sum below requests together (v[NREG_MAX])
   NREG = NREG > nwv ? nwv : NREG < 1 ? 1 : NREG;
+  NREG = NREG > NREG_MAX ? NREG_MAX : NREG;
   while (nwv % NREG) --NREG;
   // only the statistics tail has slots no wave writes: zero it in every image, the rest is written by round 0
   for (int e = threadIdx.x; e < NREG * ORL_N_STATS; e += blockDim.x)
@@ -1095,12 +1097,12 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // trips per element: 6 500 of the epilogue's 12 600 cycles at configuration 2)
 #pragma unroll 2
   for (int e = threadIdx.x; e < PW; e += blockDim.x) {
-    float v[8];
+    float v[NREG_MAX];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) v[g] = g < NREG ? img0[(size_t)g * PW + e] : 0.f;
+    for (int g = 0; g < NREG_MAX; ++g) v[g] = g < NREG ? img0[(size_t)g * PW + e] : 0.f;
     float t = v[0];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) t += v[g];  // + 0.f for an image that is not there
+    for (int g = 1; g < NREG_MAX; ++g) t += v[g];  // + 0.f for an image that is not there
     out[e] = t;
   }
 #ifdef ORL_PROF

@@ -22,7 +22,9 @@ def _assert_thetas(g, module):
     entries, tests/helpers.py) - the claim that can fail; second line: the historical check on theta_1 itself."""
     for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
         got = module.models[name].theta.cpu().numpy()
-        H.assert_update_parity(g[k0], got, g[k1], name)
+        spec = H.case_specs(g)[0 if name == "policy" else 1]
+        # + the per-block bar: every parameter block (W1 .. b3 / logstd) points the reference's way on its own
+        H.assert_update_parity(g[k0], got, g[k1], name, blocks=H.tower_blocks(spec))
         np.testing.assert_allclose(got, g[k1], rtol=THETA_RTOL, atol=THETA_ATOL)
 
 
@@ -118,6 +120,15 @@ def test_update_parity_bar_rejects_a_short_or_partial_engine_update(case):
     for block in ("W1", "W2", "b2", "W3"):
         H.assert_update_parity_rejects(g["theta_p0"], H.without_block_update(g["theta_p0"], full_p, pspec, block),
                                        g["theta_p1"], "policy without d" + block)
+    # a bug confined to a tiny block (b3: 1 - 6 entries; logstd) fits the global bar's 1 % exception budget: the per-block bar
+    # (tests/helpers.py::assert_block_update_parity) has to refuse it, on both towers
+    for name, k0, k1, spec in (("policy", "theta_p0", "theta_p1", pspec), ("critic", "theta_c0", "theta_c1", H.case_specs(g)[1])):
+        full = module.models[name].theta.cpu().numpy()
+        blocks = H.tower_blocks(spec)
+        for block in ("b3", "logstd"):
+            if block in blocks:
+                H.assert_update_parity_rejects(g[k0], H.without_block_update(g[k0], full, spec, block), g[k1],
+                                               "%s without d%s" % (name, block), blocks=blocks)
     cfg2, module2, buf2, algo2 = build_engine(g)
     algo2.ppo_epoch -= 1
     torch.manual_seed(int(g["perm_seed"]))
