@@ -82,9 +82,47 @@ def measure(c, steps=3, warmup=2, dev="cuda:0"):
     ev = trainer.profile_events
     trainer.profile_events = None
     k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
-    return {"workload": c["name"], "ms_per_iteration": round(1e3 * dt / steps, 4),
-            "env_steps_per_s": round(N * T * steps / dt, 1), "dominant_kernel_ms": round(k_ms, 4),
-            "rollout": "fused" if drv.fused else "stepwise (hipGraph)", "iterations": steps}
+    out = {"workload": c["name"], "ms_per_iteration": round(1e3 * dt / steps, 4),
+           "env_steps_per_s": round(N * T * steps / dt, 1), "dominant_kernel_ms": round(k_ms, 4),
+           "rollout": "fused" if drv.fused else "stepwise (hipGraph)", "iterations": steps}
+    try:
+        out.update(pricing(cfg, env, N * T * A, k_ms, bool(getattr(trainer, "generic", False))))
+    except Exception as e:  # noqa: BLE001 - the pricing must not take the measurement with it
+        out["pricing_error"] = "%s: %s" % (type(e).__name__, e)
+    if getattr(trainer, "recurrent", False) and not getattr(trainer, "generic", False):
+        # the recurrent update launches row kernel + weight-gradient kernel + 2 reduces per epoch inside ONE C call: the events
+        # bracket that group (= dominant_kernel_ms); the split between its kernels is in the rocprofv3 CSV of
+        # benchmarks/cfg4_mpe_bench.py (profiles/r05_cfg4_mpe_kernel_stats.csv)
+        out["ms_per_epoch_fwd_bwd_launch_group"] = round(k_ms, 4)
+        out["launch_group"] = "rnn row kernel (both towers) + rnn_wgrad_kernel + 2 x reduce_pair, one orl_rnn_ppo_fwd_bwd call"
+    return out
+
+
+def pricing(cfg, env, rows, k_ms, generic):
+    """Algorithmic flops of ONE forward + backward launch (group) of the update over the whole batch and its fraction of the
+    fp32 MFMA peak - the same pricing as bench.py's `roofline`: per row and for both towers,
+    3 x (forward flops) = forward + input gradients + weight gradients, forward = 2 x (fc1 + fc2 [+ the GRU's six 64 x 64
+    products] + head) multiply-adds."""
+    from openrl_amd import spaces
+
+    H = int(cfg.hidden_size)
+    osp, asp = env.observation_space, env.action_space
+    if isinstance(osp, spaces.Dict):
+        Dp, Dc = int(osp["policy"].shape[-1]), int(osp["critic"].shape[-1])
+    else:
+        Dp = Dc = int(osp.shape[-1])
+    n_out = int(asp.n) if isinstance(asp, spaces.Discrete) else int(asp.shape[-1])
+    fwd = 2 * ((Dp + Dc) * H + 2 * H * H + H * (n_out + 1))
+    if bool(cfg.use_recurrent_policy):
+        fwd += 2 * (2 * 6 * H * H)  # W_ih and W_hh, three gates each, both towers
+    if generic:  # the events bracket the policy tower's backward launch only on the general path: not priced per launch
+        return {"flops_fwd_per_row_both_towers": fwd, "flops_per_launch": None, "frac": None,
+                "frac_note": "general tower path: dominant_kernel_ms is one tower's backward launch, not the whole forward + backward"}
+    fl = 3 * fwd * rows
+    return {"flops_fwd_per_row_both_towers": fwd, "flops_per_launch": fl,
+            "achieved_tflops": round(fl / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else None,
+            "frac": round(fl / (k_ms * 1e-3) / 157.3e12, 4) if k_ms > 0 else None,
+            "frac_label": "algorithmic fp32 flops of the launch (group) / the fp32 MFMA peak 157.3 TFLOP/s"}
 
 
 def run_all(steps=3, warmup=2, dev="cuda:0"):

@@ -60,12 +60,19 @@ def _first_termination_port(seed):
 
 def test_cartpole_learning_five_seeds_engine_vs_cpu_port():
     """Engine and port train with the reference's recipe on 5 seeds; the engine's median first-termination length must be
-    within 15 % of the port's (or above it) and >= 300 of 500 (a random policy lasts ~10-20 steps)."""
+    within 15 % of the port's (or above it) AND the engine's 5-seed mean must be >= 350 of 500 (a random policy lasts
+    ~10-20 steps).
+
+    The reference's own bar (>= 450, tests/test_examples/test_train_cartpole.py:53, on real gymnasium with its seeding) is
+    NOT reachable on the restated env with this 20 000-step budget - for the CPU port of the reference's maths either:
+    round 4 measured engine 328 / 500 / 500 / 365 / 246 and port 343 / 500 / 432 / 342 / 289 (both miss 450 on 3 of 5
+    seeds; the score is the FIRST of 9 envs to terminate, i.e. a minimum over 9 episodes).  What this test can carry is
+    engine == port behaviourally; "learns like the reference" rests on the port being pinned on the reference's goldens."""
     eng = [_first_termination_engine(s) for s in SEEDS]
     port = [_first_termination_port(s) for s in SEEDS]
     print("first-termination length, seeds %s: engine %s  port %s" % (SEEDS, eng, port))
     assert np.median(eng) >= 0.85 * np.median(port), (eng, port)
-    assert np.median(eng) >= 300, (eng, port)
+    assert np.mean(eng) >= 350, (eng, port)
 
 
 def test_mpe_mappo_learning_three_seeds():
