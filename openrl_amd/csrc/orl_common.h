@@ -139,7 +139,29 @@ __device__ inline float row_allsum(float s) {
 
 // Two independent row sums in one go: the swaps of the two values share their wait states and the dependent
 // add -> swap -> add chain of one value hides behind the other's (LayerNorm needs its two statistics together).
+#ifndef ORL_ROWSUM2_HALVES
+#define ORL_ROWSUM2_HALVES 1   // build-time A/B switch: 0 = two independent butterflies (rounds 1 - 4)
+#endif
 __device__ inline void row_allsum2(float& x, float& y) {
+#if ORL_ROWSUM2_HALVES
+  // Round 5: the two sums share ONE butterfly.  permlane32_swap(a, b) exchanges a's upper half-wave with b's lower one, so
+  // with a = x, b = y the sum a + b holds x[l] + x[l ^ 32] in lanes 0 - 31 and y[l] + y[l ^ 32] in lanes 32 - 63; one 16-lane
+  // level on that register finishes both sums, each in its own half-wave, and a last permlane32_swap of the result with a
+  // copy of itself spreads the halves: the first operand ends up holding x's total in every lane, the second y's.
+  // 3 swaps + 2 adds + 2 copies instead of 4 swaps + 4 adds + 4 copies.
+  float a = x, b = y;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  const float t = a + b;
+  a = t;
+  b = t;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  const float u = a + b;
+  a = u;
+  b = u;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  x = a;
+  y = b;
+#else
   float a = x, b = x, c = y, d = y;
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
@@ -149,6 +171,7 @@ __device__ inline void row_allsum2(float& x, float& y) {
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
   x = a + b;
   y = c + d;
+#endif
 }
 
 // The 4 values of a row (lanes q = 0..3 of the tile row), in every one of its lanes: permlane16_swap of a value with

@@ -38,7 +38,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WBS = 72;                            // bf16 image row stride (elements): 144-byte rows, bank-skewed
+// bf16 image row stride (elements).  mm64_T_split's A fragments are ds_read_b128 of row j at 16 q bytes: serviced in four
+// 16-lane groups {0-3,12-15,20-27} .. over 64 banks (MI355X guide, LDS section), a row stride of 36 dwords (72 elements,
+// rounds 3 - 4) puts two lanes of EVERY group on the same 4 banks - each fragment read takes 8 LDS cycles instead of 4, and the
+// 48 reads of a tile were 81 % of the kernel's SQ_LDS_BANK_CONFLICT cycles (237 per tile, profiles/r04_pmc_tower.txt).  40
+// dwords (80 elements) is conflict free for that pattern (tools/lds_bank_model.py enumerates the strides).
+#ifndef ORL_WBS
+#define ORL_WBS 80
+#endif
+constexpr int WBS = ORL_WBS;
 constexpr int WB_IMG_FLOATS = 3 * HID * WBS / 2;   // three parts x 64 rows, in floats (6 912)
 
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
@@ -46,15 +54,40 @@ __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(flo
 // one dword = {bf16 truncation of a (low half), of b (high half)}: v_perm_b32 picks the two upper halves
 __device__ __forceinline__ unsigned pack_hi16(float a, float b) { return __builtin_amdgcn_perm(f2u(b), f2u(a), 0x07060302u); }
 
-// 8 fp32 values -> three bf16x8 MFMA fragments (hi, mid, lo); x = hi + mid + lo exactly.  11 VALU per 2 values.
+// Remainder of a truncation in ONE instruction (round 5).  pk = {bf16 of a (low half), bf16 of b (high half)} is the dword
+// pack_hi16 has just produced as the MFMA operand; v_dot2c_f32_bf16 computes D += A.lo * B.lo + A.hi * B.hi, so with
+// B = (-1, 0) resp. (0, -1) it returns  a - bf16(a)  resp.  b - bf16(b)  - exactly: the remainder of a truncation is
+// representable (the low 16 significand bits of the operand), so no rounding mode of the dot product can change it
+// (tools/split_dot2c_probe.hip compares both forms bit for bit on the GPU).  Replaces v_and_b32 + v_sub_f32 per value:
+// 7 instead of 11 VALU per pair of values, - 128 of the tower tile's 984.  Finite operands only (0 * Inf is NaN).
+#ifndef ORL_SPLIT_DOT2C
+#define ORL_SPLIT_DOT2C 1   // build-time A/B switch: 0 = the and / sub form
+#endif
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rem_lo(float a, unsigned pk) {
+#if ORL_SPLIT_DOT2C
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, 0x0000bf80u), a, false);
+#else
+  return a - u2f(f2u(a) & 0xffff0000u);
+#endif
+}
+__device__ __forceinline__ float rem_hi(float b, unsigned pk) {
+#if ORL_SPLIT_DOT2C
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, 0xbf800000u), b, false);
+#else
+  return b - u2f(f2u(b) & 0xffff0000u);
+#endif
+}
+
+// 8 fp32 values -> three bf16x8 MFMA fragments (hi, mid, lo); x = hi + mid + lo exactly.  7 VALU per 2 values.
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const float a = x[2 * p], b = x[2 * p + 1];
     hi[p] = pack_hi16(a, b);
-    const float ra = a - u2f(f2u(a) & 0xffff0000u), rb = b - u2f(f2u(b) & 0xffff0000u);
+    const float ra = rem_lo(a, hi[p]), rb = rem_hi(b, hi[p]);
     mid[p] = pack_hi16(ra, rb);
-    const float sa = ra - u2f(f2u(ra) & 0xffff0000u), sb = rb - u2f(f2u(rb) & 0xffff0000u);
+    const float sa = rem_lo(ra, mid[p]), sb = rem_hi(rb, mid[p]);
     lo[p] = pack_hi16(sa, sb);
   }
 }
@@ -468,24 +501,49 @@ __device__ inline void mm64_T(const float* __restrict__ Ws, const f32x4 (&in)[4]
   }
 }
 
-// sum over the 64 features of batch row j (in-lane 16 + lanes l^16, l^32)
-__device__ inline float feat_sum(const f32x4 (&x)[4]) {
+// In-lane part of a 16-value reduction: the four f32x4 registers are added element-wise first (v_pk_add_f32 / v_pk_fma_f32: two
+// values per instruction), the horizontal sum of the one remaining vector comes last - 9 instructions per sum (11 for a sum of
+// products) instead of 15 / 24 scalar ones (round 5; ORL_PACKED_SUMS = 0 restores the scalar order for A/B).
+#ifndef ORL_PACKED_SUMS
+#define ORL_PACKED_SUMS 1
+#endif
+__device__ __forceinline__ float hsum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+__device__ __forceinline__ float lane_sum16(const f32x4 (&x)[4]) {
+#if ORL_PACKED_SUMS
+  return hsum4((x[0] + x[1]) + (x[2] + x[3]));
+#else
   float s = 0.f;
 #pragma unroll
   for (int m = 0; m < 4; ++m) s += (x[m][0] + x[m][1]) + (x[m][2] + x[m][3]);
-  s = row_allsum(s);
   return s;
+#endif
+}
+__device__ __forceinline__ float lane_dot16(const f32x4 (&x)[4], const f32x4 (&y)[4]) {
+#if ORL_PACKED_SUMS
+  f32x4 v = x[0] * y[0];
+  v = x[1] * y[1] + v;
+  v = x[2] * y[2] + v;
+  v = x[3] * y[3] + v;
+  return hsum4(v);
+#else
+  float s = 0.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) s += (x[m][0] * y[m][0] + x[m][1] * y[m][1]) + (x[m][2] * y[m][2] + x[m][3] * y[m][3]);
+  return s;
+#endif
+}
+
+// sum over the 64 features of batch row j (in-lane 16 + lanes l^16, l^32)
+__device__ inline float feat_sum(const f32x4 (&x)[4]) {
+  return row_allsum(lane_sum16(x));
 }
 
 // LayerNorm statistics + normalisation in place: x <- (x - mean) * rstd   (eps = 1e-5, biased var)
 __device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd) {
   const float mean = feat_sum(x) * (1.0f / 64.0f);
-  float v = 0.f;
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    x[m] = x[m] - mean;
-    v += (x[m][0] * x[m][0] + x[m][1] * x[m][1]) + (x[m][2] * x[m][2] + x[m][3] * x[m][3]);
-  }
+  for (int m = 0; m < 4; ++m) x[m] = x[m] - mean;
+  float v = lane_dot16(x, x);
   v = row_allsum(v);
   // v_rsq_f32 (1 ulp) instead of the ~20-instruction correctly-rounded sqrt + IEEE division sequence
   rstd = __builtin_amdgcn_rsqf(v * (1.0f / 64.0f) + 1e-5f);

@@ -51,6 +51,9 @@ __device__ unsigned long long g_orl_prof[24];
 #define ORL_T(k) ((void)0)
 #endif
 
+#ifndef ORL_DB3_ROWLANE
+#define ORL_DB3_ROWLANE 1   // build-time A/B switch (round 5): db3 of narrow heads from per-row register partials
+#endif
 constexpr int PPO_MAX_BLOCKS = 256;  // one workgroup per CU
 constexpr int TS = 68;               // slab row stride (floats): 16-byte rows, bank-skewed
 constexpr int SLAB = TILE_B * TS;
@@ -116,13 +119,7 @@ __device__ inline void load_slab_T(const float* __restrict__ slab, f32x4 (&x)[4]
 // LayerNorm backward in T layout, in place, on d = d loss / d xhat (the affine's gamma is folded into the weights the
 // incoming gradient was multiplied with, stage_tower(fold)):  d <- rstd * (d - mean(d) - xhat * mean(d * xhat))
 __device__ inline void ln_bwd_T(f32x4 (&d)[4], const f32x4 (&xhat)[4], float rstd) {
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const f32x4 t = d[m] * xhat[m];
-    s1 += (d[m][0] + d[m][1]) + (d[m][2] + d[m][3]);
-    s2 += (t[0] + t[1]) + (t[2] + t[3]);
-  }
+  float s1 = lane_sum16(d), s2 = lane_dot16(d, xhat);
   row_allsum2(s1, s2);
   // rstd * (d*g - c1 - xhat*c2) as two FMAs per element
   const float k1 = -s1 * (1.0f / 64.0f) * rstd, k2 = -s2 * (1.0f / 64.0f) * rstd;
@@ -234,6 +231,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     for (int b = 0; b < NDA; ++b) G1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float w1v[4] = {0.f, 0.f, 0.f, 0.f};  // VALU dW1 (ND == 0): lane f, k = 0..3
   float a_db2 = 0.f, a_db1 = 0.f, a_db3 = 0.f, a_dls = 0.f;
+  float a_db3r[NO];  // narrow heads (ORL_DB3_ROWLANE): db3 partials of this lane's batch row, combined in the epilogue
+#pragma unroll
+  for (int c = 0; c < NO; ++c) a_db3r[c] = 0.f;
   constexpr int NS3 = HMM ? 1 : NO;
   float a_S3[NS3];  // narrow heads: S3[c][f = lane] sums on the VALU
 #pragma unroll
@@ -688,6 +688,20 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       a_db3 += s_db3;
     } else {
       const int f = l;
+#if ORL_DB3_ROWLANE
+      // db3 = the column sums of dhead: every lane of a batch row holds that row's dh[] already, so the q == 0 lane of each
+      // row accumulates it in registers across tiles and the 16 rows are combined ONCE, in the epilogue (wave_sum) - no
+      // per-tile LDS reads for it, and the S3 loop is a plain chain of FMAs (with db3 inside, hipcc paired {S3, db3} into
+      // v_pk_add_f32 with a v_mov + v_mul per row: 3 instructions where one v_fmac does)
+#pragma unroll
+      for (int c = 0; c < NO; ++c) a_db3r[c] += q == 0 ? dh[c] : 0.f;
+#pragma unroll
+      for (int r = 0; r < TILE_B; ++r) {
+        const float xh = SS[r * TS + f];
+#pragma unroll
+        for (int c = 0; c < NO; ++c) a_S3[c < NS3 ? c : 0] += DH[r * NOP + c] * xh;
+      }
+#else
       float s3[NO];
 #pragma unroll
       for (int c = 0; c < NO; ++c) s3[c] = 0.f;
@@ -701,6 +715,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #pragma unroll
       for (int c = 0; c < NO; ++c) a_S3[c < NS3 ? c : 0] += s3[c];
       a_db3 += s_db3;
+#endif
     }
     ORL_T(5);  // dhead store, S3 / db3 column sums
     // dn2 = W3^T dhead (T layout), LN2 backward -> dz2
@@ -716,11 +731,14 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         for (int mo = 0; mo < 4; ++mo)
           d2[mo] = ORL_MFMA(lw[tw.W3P + (4 * q + r) * W2S + 16 * mo + j], dv[r], d2[mo]);
     } else {
+      // (no test on n_out: dh[c] is 0 and W3's LDS image is zero padded for classes >= n_out - the test was a branch around
+      // sixteen v_mov 0 per tile)
 #pragma unroll
       for (int c = 0; c < NO; ++c) {
-        if (c < n_out) {
 #pragma unroll
-          for (int m = 0; m < 4; ++m) d2[m] += *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q) * dh[c];
+        for (int m = 0; m < 4; ++m) {
+          const f32x4 w3 = *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q);
+          d2[m] = c == 0 ? w3 * dh[0] : w3 * dh[c] + d2[m];
         }
       }
     }
@@ -856,12 +874,22 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       const int f = l;
       float s_db = 0.f;
       if (ND == 0) {
-        for (int r = 0; r < TILE_B; ++r) {
-          const float dzv = SS[r * TS + f];
-          const f32x4 xv = *(const f32x4*)(&REC_R(r, A.o_x));  // o_x % 4 == 0 on this path
-          s_db += dzv;
-          w1v[0] += dzv * xv[0]; w1v[1] += dzv * xv[1]; w1v[2] += dzv * xv[2]; w1v[3] += dzv * xv[3];
+        // written on f32x4 / pairs so that it compiles to 2 v_pk_fma_f32 per row and 1 v_pk_add_f32 per two rows (left to its
+        // SLP pass hipcc built the pairs with v_mov copies: 37 - 75 VALU for this phase instead of 42)
+        f32x4 w4 = f32x4{w1v[0], w1v[1], w1v[2], w1v[3]};
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 sd2 = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < TILE_B; r += 2) {
+          const f32x2 dz = f32x2{SS[r * TS + f], SS[(r + 1) * TS + f]};
+          const f32x4 x0 = *(const f32x4*)(&REC_R(r, A.o_x));  // o_x % 4 == 0 on this path
+          const f32x4 x1 = *(const f32x4*)(&REC_R(r + 1, A.o_x));
+          sd2 += dz;
+          w4 = x0 * dz[0] + w4;
+          w4 = x1 * dz[1] + w4;
         }
+        s_db += sd2[0] + sd2[1];
+        w1v[0] = w4[0]; w1v[1] = w4[1]; w1v[2] = w4[2]; w1v[3] = w4[3];
       } else {
         // columns [0, 16 ND) of dW1 on MFMA; a remainder of up to 4 columns (D = 17..20, 33..36: launch_tower_nd) on
         // the VALU like the ND == 0 path instead of a whole extra 16-column accumulator block
@@ -941,6 +969,15 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   __syncthreads();
   st_active = wave_sum(st_active); st_rows = wave_sum(st_rows); st_loss = wave_sum(st_loss);
   st_ent = wave_sum(st_ent); st_ratio = wave_sum(st_ratio);
+#if ORL_DB3_ROWLANE
+  if constexpr (!HMM) {  // lane c of the wave ends up with db3[c], as the per-tile column sums left it
+#pragma unroll
+    for (int c = 0; c < NO; ++c) {
+      const float tot = wave_sum(a_db3r[c]);
+      if (l == c) a_db3 = tot;
+    }
+  }
+#endif
   float* acc = img0 + (size_t)(wave % NREG) * PW;
   for (int p = 0; p < nwv / NREG; ++p) {
     if (wave / NREG == p) {

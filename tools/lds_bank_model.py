@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""LDS bank-conflict model of the tower kernel's read / write patterns (MI355X guide, LDS section: lane groups and bank
+modulus per instruction) and the LDS budget of the pair launch per image stride.  CPU only.
+
+    python tools/lds_bank_model.py
+
+Answers two questions of round 5: which access of the tower tile produces the 25 % bank-conflict cycles measured in
+profiles/r04_pmc_tower.txt (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE), and which image row stride removes them."""
+
+# ds_read_b128: four non-contiguous 16-lane groups, bank = (addr / 4) mod 64, a lane covers 4 consecutive banks
+G128 = [[*range(0, 4), *range(12, 16), *range(20, 28)], [*range(4, 12), *range(16, 20), *range(28, 32)],
+        [*range(32, 36), *range(44, 48), *range(52, 60)], [*range(36, 44), *range(48, 52), *range(60, 64)]]
+G32x2 = [list(range(0, 32)), list(range(32, 64))]            # ds_read_b32 / ds_read_b64 / ds_write_b32 / tr16_b64
+G8x8 = [list(range(8 * g, 8 * g + 8)) for g in range(8)]     # ds_write_b96 / b128
+
+
+def cycles(groups, addr, width, nbanks):
+    """LDS-array cycles of one wave instruction: per lane group, the largest number of DISTINCT dword addresses on one bank."""
+    tot = 0
+    for g in groups:
+        banks = {}
+        for l in g:
+            a = addr(l)
+            if a is None:
+                continue
+            for d in range(width):
+                banks.setdefault((a + d) % nbanks, set()).add(a + d)
+        tot += max((len(v) for v in banks.values()), default=0)
+    return tot
+
+
+def jq(l):
+    return l & 15, l >> 4
+
+
+def report():
+    print("pattern                                              cycles  ideal")
+    for wbs in (72, 80, 88):
+        s = wbs // 2  # dwords per image row
+        c = cycles(G128, lambda l: s * jq(l)[0] + 4 * jq(l)[1], 4, 64)
+        print("mm64_T_split A fragment, ds_read_b128, WBS = %-3d        %4d   %4d" % (wbs, c, 4))
+        # transposing read (cfg3 / cfg5 dgrad): lane (j, q) addresses row 4q + (j >> 2), 8-byte chunk (j & 3) -> dword 2 (j & 3)
+        c = cycles(G32x2, lambda l: s * (4 * jq(l)[1] + (jq(l)[0] >> 2)) + 4 * (jq(l)[0] & 3), 2, 64)
+        print("mm64_T_split_tr fragment, ds_read_b64_tr_b16, WBS = %-3d  %4d   %4d  (plus unknown tr conflict classes)" % (wbs, c, 2))
+    for ts in (68, 72):
+        c = cycles(G128, lambda l: ts * jq(l)[0] + 4 * jq(l)[1], 4, 64)
+        print("load_slab_T, ds_read_b128, TS = %-3d                    %4d   %4d" % (ts, c, 4))
+        c = cycles(G8x8, lambda l: ts * jq(l)[0] + 4 * jq(l)[1], 4, 32)
+        print("store_slab_T, ds_write_b128, TS = %-3d                  %4d   %4d" % (ts, c, 8))
+        c = cycles(G32x2, lambda l: ts * (8 * (l >> 5)) + (l & 31), 1, 32)
+        print("wgrad operand column read, ds_read_b32, TS = %-3d       %4d   %4d" % (ts, c, 2))
+    c = cycles(G32x2, lambda l: 4 * jq(l)[0], 1, 32)
+    print("record field REC(col), ds_read_b32 (4 lanes / address) %4d   %4d" % (c, 2))
+    c = cycles(G32x2, lambda l: (16 * 0 + jq(l)[0]) * 4 + jq(l)[1], 1, 32)
+    print("fc1 A operand W1[(16m + j) * 4 + q], ds_read_b32        %4d   %4d" % (c, 2))
+
+
+def tower_lds_floats(D, n_out, R, nop, waves, gaussian, w2t, split, ring_nch, wbs):
+    HID, W2S, TILE_B, TS = 64, 68, 16, 68
+    w2 = 3 * HID * wbs // 2 if split else HID * W2S
+    DP = (D + 3) & ~3
+    no4 = (n_out + 3) & ~3
+    with_w3p = nop == 16
+    tot = HID * DP + 3 * HID + w2 + 3 * HID + (0 if with_w3p else no4 * HID) + no4 + (no4 if gaussian else 0)
+    tot += (w2 if w2t else 0) + (16 * W2S if with_w3p else 0)
+    raw = HID * HID + n_out * HID + n_out + HID + HID * D + HID + (n_out if gaussian else 0)
+    rts = (((R >> 2) + 3) >> 2) * 256 if D <= 4 else ring_nch * 64
+    per_wave = 2 * TILE_B * TS + 2 * rts + TILE_B * nop
+    fl = tot + waves * per_wave
+    pw = raw + 16
+    if fl < waves * pw and waves * pw * 4 <= 160 * 1024:
+        fl = waves * pw
+    return max(fl, pw)
+
+
+def budgets():
+    print("\nLDS of the 8-wave pair launch (KiB; limit 160), max over the two towers")
+    shapes = [("cfg2  obs 4  Discrete(2)", 4, 4, 2, False, 1, 2), ("cfg3  obs 17 Box(6)", 17, 17, 6, True, 6, 0),
+              ("cfg5  obs 18 Discrete(9)", 18, 18, 9, False, 1, 9), ("cfg4-like obs 18/54 Discrete(5)", 18, 54, 5, False, 1, 5)]
+    for name, Dp, Dc, n_out, gauss, a_w, K in shapes:
+        R = (Dp + Dc + 2 * a_w + 4 + K + 3) & ~3
+        for wbs in (72, 80):
+            row = []
+            for label, w2t, split in (("tr-read full split (1 image)", False, True), ("two-image full split", True, True),
+                                      ("fp32 + W2T", True, False), ("fp32", False, False)):
+                def ring(D, o_x, first_tail):
+                    if D <= 4:
+                        return R >> 2
+                    DP = (D + 3) & ~3
+                    c0b, c0e = o_x >> 2, min(((o_x + DP - 1) >> 2) + 1, R >> 2)
+                    c1 = max(first_tail >> 2, c0e)
+                    return (c0e - c0b) + ((R >> 2) - c1)
+                o_ac = Dp + Dc
+                o_vp = o_ac + 2 * a_w + 1
+                nop = 16 if n_out > 4 else 4
+                lp = tower_lds_floats(Dp, n_out, R, nop, 8, gauss, w2t, split, ring(Dp, 0, o_ac), wbs)
+                lc = tower_lds_floats(Dc, 1, R, 4, 8, False, w2t, split, ring(Dc, Dp, o_vp), wbs)
+                row.append("%s %.1f" % (label, max(lp, lc) * 4 / 1024))
+            print("  %-32s WBS %d: %s" % (name, wbs, " | ".join(row)))
+
+
+if __name__ == "__main__":
+    report()
+    budgets()
