@@ -54,40 +54,60 @@ __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(flo
 // one dword = {bf16 truncation of a (low half), of b (high half)}: v_perm_b32 picks the two upper halves
 __device__ __forceinline__ unsigned pack_hi16(float a, float b) { return __builtin_amdgcn_perm(f2u(b), f2u(a), 0x07060302u); }
 
-// Remainder of a truncation in ONE instruction (round 5).  pk = {bf16 of a (low half), bf16 of b (high half)} is the dword
-// pack_hi16 has just produced as the MFMA operand; v_dot2c_f32_bf16 computes D += A.lo * B.lo + A.hi * B.hi, so with
-// B = (-1, 0) resp. (0, -1) it returns  a - bf16(a)  resp.  b - bf16(b)  - exactly: the remainder of a truncation is
-// representable (the low 16 significand bits of the operand), so no rounding mode of the dot product can change it
-// (tools/split_dot2c_probe.hip compares both forms bit for bit on the GPU).  Replaces v_and_b32 + v_sub_f32 per value:
-// 7 instead of 11 VALU per pair of values, - 128 of the tower tile's 984.  Finite operands only (0 * Inf is NaN).
-#ifndef ORL_SPLIT_DOT2C
-#define ORL_SPLIT_DOT2C 1   // build-time A/B switch: 0 = the and / sub form
+// Remainder of a truncation (round 5 experiments; build-time switch ORL_SPLIT_FORM):
+//   0  v_and_b32 + v_sub_f32 per value (rounds 3 - 4): 11 VALU per pair of values;
+//   1  ONE v_dot2c_f32_bf16 per value: pk = {bf16 of a (low half), bf16 of b (high half)} is the dword pack_hi16 has just
+//      produced as the MFMA operand, and D += A.lo * B.lo + A.hi * B.hi with B = (-1, -0) resp. (-0, -1) returns a - bf16(a)
+//      resp. b - bf16(b) exactly (the remainder of a truncation is representable): 7 VALU per pair.  The constants carry -0 in
+//      the unused half ON PURPOSE: hipcc encodes the bf16 pair (lo = -1, hi = +0) as the INLINE constant -1.0, which the
+//      hardware reads as the fp32 pattern 0xbf800000 = (lo = +0, hi = -1) - the other half (tools/split_dot2c_probe.hip's
+//      first run: every pair wrong).  A pattern with a sign bit in the other half is no inline constant and travels as a
+//      32-bit literal.  Measured: NOT faster than form 0 (profiles/r05_experiments.md) - v_dot2c is not a full-rate op;
+//   2  the two subtractions of a pair as ONE v_pk_add_f32 with negated operand: 9 VALU per pair.
+#ifndef ORL_SPLIT_FORM
+#define ORL_SPLIT_FORM 0
 #endif
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float rem_lo(float a, unsigned pk) {
-#if ORL_SPLIT_DOT2C
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, 0x0000bf80u), a, false);
+#if ORL_SPLIT_FORM == 1
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, 0x8000bf80u), a, false);
 #else
   return a - u2f(f2u(a) & 0xffff0000u);
 #endif
 }
 __device__ __forceinline__ float rem_hi(float b, unsigned pk) {
-#if ORL_SPLIT_DOT2C
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, 0xbf800000u), b, false);
+#if ORL_SPLIT_FORM == 1
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, 0xbf808000u), b, false);
 #else
   return b - u2f(f2u(b) & 0xffff0000u);
 #endif
 }
+// both remainders of a pair
+__device__ __forceinline__ void rem_pair(float a, float b, unsigned pk, float& ra, float& rb) {
+#if ORL_SPLIT_FORM == 2
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  const f32x2 ab = f32x2{a, b};
+  const f32x2 t = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2_, ab) & u32x2_{0xffff0000u, 0xffff0000u});
+  const f32x2 r = ab - t;
+  ra = r[0];
+  rb = r[1];
+#else
+  ra = rem_lo(a, pk);
+  rb = rem_hi(b, pk);
+#endif
+}
 
-// 8 fp32 values -> three bf16x8 MFMA fragments (hi, mid, lo); x = hi + mid + lo exactly.  7 VALU per 2 values.
+// 8 fp32 values -> three bf16x8 MFMA fragments (hi, mid, lo); x = hi + mid + lo exactly.  11 / 7 / 9 VALU per 2 values.
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const float a = x[2 * p], b = x[2 * p + 1];
     hi[p] = pack_hi16(a, b);
-    const float ra = rem_lo(a, hi[p]), rb = rem_hi(b, hi[p]);
+    float ra, rb, sa, sb;
+    rem_pair(a, b, hi[p], ra, rb);
     mid[p] = pack_hi16(ra, rb);
-    const float sa = rem_lo(ra, mid[p]), sb = rem_hi(rb, mid[p]);
+    rem_pair(ra, rb, mid[p], sa, sb);
     lo[p] = pack_hi16(sa, sb);
   }
 }

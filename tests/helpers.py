@@ -156,6 +156,17 @@ def tower_blocks(spec):
     return out
 
 
+def blocks_of(tower, recurrent=False):
+    """Block layout of an engine tower (openrl_amd.modules.ppo_module.Tower) from its net descriptor - for golden cases that
+    do not carry their buffers (the full-size ones regenerate them from a seed)."""
+    n = tower.net
+    if recurrent:
+        from oracle import rnn_oracle as ro
+
+        return tower_blocks(ro.RnnTowerSpec(int(n.obs_dim), int(n.n_out), int(n.head_kind)))
+    return tower_blocks(po.TowerSpec(int(n.obs_dim), int(n.n_out), int(n.head_kind)))
+
+
 def without_block_update(theta0, theta1, spec, block):
     """theta1 with `block` reset to theta0: the update a kernel would produce had it dropped that block's gradient."""
     off, n = tower_blocks(spec)[block]

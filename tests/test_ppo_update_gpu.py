@@ -22,9 +22,8 @@ def _assert_thetas(g, module):
     entries, tests/helpers.py) - the claim that can fail; second line: the historical check on theta_1 itself."""
     for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
         got = module.models[name].theta.cpu().numpy()
-        spec = H.case_specs(g)[0 if name == "policy" else 1]
         # + the per-block bar: every parameter block (W1 .. b3 / logstd) points the reference's way on its own
-        H.assert_update_parity(g[k0], got, g[k1], name, blocks=H.tower_blocks(spec))
+        H.assert_update_parity(g[k0], got, g[k1], name, blocks=H.blocks_of(module.models[name]))
         np.testing.assert_allclose(got, g[k1], rtol=THETA_RTOL, atol=THETA_ATOL)
 
 

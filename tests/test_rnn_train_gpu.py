@@ -23,8 +23,11 @@ def _assert_thetas(g, module):
     >= 99 % of the entries), then the historical check on theta_1."""
     for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
         got = module.models[name].theta.cpu().numpy()
-        blocks = H.tower_blocks(RH.rnn_specs(g)[0 if name == "policy" else 1])
-        if sum(n for _, n in blocks.values()) != g[k0].size:  # (a general recurrent tower: another flat layout)
+        try:
+            blocks = H.blocks_of(module.models[name], recurrent=True)
+            if sum(n for _, n in blocks.values()) != g[k0].size:  # (a general recurrent tower: another flat layout)
+                blocks = None
+        except AttributeError:  # (general towers keep their layout elsewhere)
             blocks = None
         H.assert_update_parity(g[k0], got, g[k1], name, blocks=blocks)  # + the per-block bar (W1 .. Wih / Whh .. b3)
         np.testing.assert_allclose(got, g[k1], rtol=THETA_RTOL, atol=THETA_ATOL)

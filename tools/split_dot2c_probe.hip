@@ -1,5 +1,7 @@
 // Probe (round 5): is  a - bf16_trunc(a)  through v_dot2c_f32_bf16 bit-identical to the v_and_b32 + v_sub_f32 form?
 //   hipcc --offload-arch=gfx950 -O3 tools/split_dot2c_probe.hip -o /tmp/split_probe && /tmp/split_probe
+// (First run, constants (lo = -1, hi = +0) / 0xbf800000: hipcc encoded the first as the inline constant -1.0, which the hardware
+// reads as 0xbf800000 - every pair came out wrong.  With a sign bit in the unused half both constants are 32-bit literals.)
 // Both forms of the three-term split run over 2^24 operand pairs: N(0,1) x 2^e for e in [-40, 40], every exponent of the
 // normal range once, signed zeros, denormals.  Prints the number of differing (hi, mid, lo) words and the first few.
 #include <hip/hip_runtime.h>
@@ -27,7 +29,7 @@ __global__ void probe(const float* __restrict__ x, unsigned* __restrict__ out_an
     out_and[3 * i] = hi; out_and[3 * i + 1] = mid; out_and[3 * i + 2] = pack_hi16(sa, sb);
   }
   {  // dot2c
-    const bf16x2 m_lo = __builtin_bit_cast(bf16x2, 0x0000bf80u), m_hi = __builtin_bit_cast(bf16x2, 0xbf800000u);
+    const bf16x2 m_lo = __builtin_bit_cast(bf16x2, 0x8000bf80u), m_hi = __builtin_bit_cast(bf16x2, 0xbf808000u);  // -0 in the unused half: no inline constant
     const unsigned hi = pack_hi16(a, b);
     const float ra = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, hi), m_lo, a, false);
     const float rb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, hi), m_hi, b, false);
