@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--agents", type=int, default=3)
     ap.add_argument("--T", type=int, default=25)
     ap.add_argument("--epochs", type=int, default=10)
-    ap.add_argument("--tower-gemm", default="fp32", choices=["split", "fp32", "split_w4"],
+    ap.add_argument("--tower-gemm", default="fp32", choices=["split", "fp32", "fp32_recompute", "split_w4"],
                     help="cfg.amd_rnn_gemm: fp32 (default) = every GEMM on v_mfma_f32_16x16x4_f32 out of resident LDS images; "
                          "split / split_w4 = the streamed bf16-split row kernel (8 / 4 waves per workgroup)")
     a = ap.parse_args()

@@ -271,11 +271,15 @@ typedef struct orl_ppo_hparams {
                      * 2 = A2C policy loss -adv*logp instead of the clipped surrogate (algorithms/a2c.py:88-98);
                      * 4 = orl_ppo_fwd_bwd forms every GEMM on v_mfma_f32_16x16x4_f32 instead of the bf16x3 split (a
                      *     measurement / comparison switch: same results within fp32 rounding, ~1.4x slower);
+                     *     orl_rnn_ppo_fwd_bwd: the row kernel with forward recompute (rnn_row_pair_kernel) whatever the chunk
+                     *     length - comparison switch; 0 = the default: chunks of 2 steps run rnn_row2_pair_kernel (both steps
+                     *     resident in registers), any other length rnn_row_pair_kernel;
                      * 8 = orl_ppo_fwd_bwd skips the transposing-read full-split build (dgrad through
                      *     ds_read_b64_tr_b16 of W2's bf16 image, the wide-observation towers' default) and takes round 3's
                      *     variants (two images, or wgrad-only split) - comparison switch, same arithmetic;
-                     * 16 = orl_rnn_ppo_fwd_bwd runs its streamed split row kernel with 4 waves per workgroup (one wave per
-                     *     SIMD, 512 registers) instead of 8 - comparison switch, same arithmetic;
+                     *     orl_rnn_ppo_fwd_bwd: round 4's streamed bf16-split row kernel - comparison switch;
+                     * 16 = orl_rnn_ppo_fwd_bwd with 8: the streamed kernel with 4 waves per workgroup (one wave per SIMD,
+                     *     512 registers) instead of 8 - comparison switch, same arithmetic;
                      * 32 = orl_ppo_apply* OVERWRITES its train_info slots instead of adding to them (the first optimiser step
                      *     of a train() call: saves the caller a zero-fill launch) */
 } orl_ppo_hparams;

@@ -39,7 +39,10 @@ AMD_FLAGS = [
     # 0.80 ms per epoch at the cfg4 shape); "split" = bf16x3 splits over images STREAMED through an LDS ring
     # (csrc/orl_rnn_stream.h; 0.83 ms - the stream's waits cost more than the MFMA time it saves),
     # "split_w4" = the same with 4 waves per workgroup / 512 registers per wave (1.07 ms).  All three are parity-tested.
-    ("amd_rnn_gemm", "str", "fp32", "opt", ["fp32", "split", "split_w4"]),
+    # Round 5: with "fp32" chunks of data_chunk_length == 2 (the reference default) run the register-resident row kernel
+    # (csrc/orl_rnn_l2.h: both steps of a chunk in one wave's registers, no forward recompute, no state tape); other lengths,
+    # and every length under "fp32_recompute" (comparison switch), the forward-sweep + recompute kernel of rounds 1 - 4.
+    ("amd_rnn_gemm", "str", "fp32", "opt", ["fp32", "fp32_recompute", "split", "split_w4"]),
     # optimiser step of an MLP-tower minibatch: "two_launch" (default) = orl_ppo_reduce_pair then orl_ppo_apply(_perm);
     # "fused" = column sums of the towers' partials + clip + Adam (+ the next epoch's permutation) in ONE launch
     # (orl_ppo_reduce_apply: ticketed workgroups, the last one of a tower steps it) - same results bit for bit, but the

@@ -660,6 +660,7 @@ __global__ __launch_bounds__(512, 2) void rnn_row_pair_kernel(RnnRowArgs P, RnnR
 
 }  // namespace orl
 #include "orl_rnn_stream.h"  // the same row kernel with its 64 x 64 GEMMs on the bf16 MFMA over streamed images (round 4)
+#include "orl_rnn_l2.h"      // data_chunk_length == 2: both steps of a chunk resident in registers, no recompute (round 5)
 namespace orl {
 
 // =====================================================================================================
@@ -1133,6 +1134,19 @@ static int launch_rnn_rows_stream(const RnnRowArgs& P, const RnnRowArgs& Cc, flo
   return launch_status("orl_rnn_ppo_fwd_bwd(row, streamed split)");
 }
 
+// data_chunk_length == 2: rnn_row2_pair_kernel, 4 waves per workgroup (one per SIMD, 512 registers), one workgroup per CU
+template <int HEAD, int NO>
+static int launch_rnn_rows_l2(const RnnRowArgs& P, const RnnRowArgs& Cc, int grid_p, int grid_c, hipStream_t s) {
+  const RnnLds twp(P.net.obs_dim, P.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HEAD == ORL_HEAD_CATEGORICAL && NO > 4);
+  const RnnLds twc(Cc.net.obs_dim, 1, false);
+  const size_t lds = (size_t)(twp.total > twc.total ? twp.total : twc.total) * sizeof(float);
+  if (lds > 160 * 1024) return fail(ORL_E_UNSUPPORTED, "orl_rnn_ppo_fwd_bwd: tower needs %zu B of LDS", lds);
+  (void)hipFuncSetAttribute((const void*)rnn_row2_pair_kernel<HEAD, NO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((rnn_row2_pair_kernel<HEAD, NO>), dim3(grid_p + grid_c), dim3(256), lds, s, P, Cc, grid_p);
+  return launch_status("orl_rnn_ppo_fwd_bwd(row, L = 2)");
+}
+
 template <int HEAD, int NO>
 static int launch_rnn_rows(const RnnRowArgs& P, const RnnRowArgs& Cc, int grid_p, int grid_c, hipStream_t s) {
   const RnnLds twp(P.net.obs_dim, P.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HEAD == ORL_HEAD_CATEGORICAL && NO > 4);
@@ -1332,17 +1346,31 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
   C2.net = *cnet; C2.theta = ctheta; C2.hbuf = batch->h_critic; C2.o_x = o_co;
   if (batch->rows_critic) { C2.rows = batch->rows_critic; C2.Nc = nc_c; }
   C2.htape = base_c + wc.htape; C2.tape = base_c + wc.tape; C2.partials = base_c + wc.rpart;
-  // (1) row kernels of both towers, one launch: the streamed bf16-split build, or (hp.reserved & 4, the comparison
-  // switch cfg.amd_tower_gemm = fp32) every GEMM on the fp32 MFMA out of resident LDS images
+  // (1) row kernels of both towers, one launch.  hp.reserved selects the build (include/orl_hip.h):
+  //   0 (the default): data_chunk_length == 2 -> rnn_row2_pair_kernel (both steps of a chunk in registers, no forward
+  //     recompute, no state tape); any other length -> rnn_row_pair_kernel (forward sweep + BPTT sweep with recompute);
+  //   4: rnn_row_pair_kernel whatever the length (comparison switch, cfg.amd_rnn_gemm = fp32_recompute);
+  //   8 (| 16): the streamed bf16-split row kernel of round 4 with 8 (4) waves per workgroup (comparison switches)
   const int no = pnet->n_out;
   int grid_rp = wp.grid_row, grid_rc = wc.grid_row;  // workgroups (= rows of the row partials) per tower
-  if (!(hp->reserved & 4) && (hp->reserved & 16)) {  // streamed kernel with 4 waves per workgroup: 4 tiles per group
+  const bool streamed = (hp->reserved & 8) != 0;
+  const bool l2 = !streamed && !(hp->reserved & 4) && batch->L == 2;
+  if ((streamed && (hp->reserved & 16)) || l2) {  // 4 waves per workgroup: 4 tiles per group and round
     grid_rp = (wp.n_tiles + 3) / 4;
     grid_rc = (wc.n_tiles + 3) / 4;
     if (grid_rp > RNN_ROW_BLOCKS / 2) grid_rp = RNN_ROW_BLOCKS / 2;
     if (grid_rc > RNN_ROW_BLOCKS / 2) grid_rc = RNN_ROW_BLOCKS / 2;
   }
-  if (hp->reserved & 4) {
+  if (l2) {
+    if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
+      if (no <= 2) rc = launch_rnn_rows_l2<ORL_HEAD_CATEGORICAL, 2>(A, C2, grid_rp, grid_rc, s);
+      else if (no <= 8) rc = launch_rnn_rows_l2<ORL_HEAD_CATEGORICAL, 8>(A, C2, grid_rp, grid_rc, s);
+      else rc = launch_rnn_rows_l2<ORL_HEAD_CATEGORICAL, 16>(A, C2, grid_rp, grid_rc, s);
+    } else {
+      if (no <= 8) rc = launch_rnn_rows_l2<ORL_HEAD_GAUSSIAN, 8>(A, C2, grid_rp, grid_rc, s);
+      else rc = launch_rnn_rows_l2<ORL_HEAD_GAUSSIAN, 16>(A, C2, grid_rp, grid_rc, s);
+    }
+  } else if (!streamed) {
     if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
       if (no <= 2) rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 2>(A, C2, wp.grid_row, wc.grid_row, s);
       else if (no <= 8) rc = launch_rnn_rows<ORL_HEAD_CATEGORICAL, 8>(A, C2, wp.grid_row, wc.grid_row, s);

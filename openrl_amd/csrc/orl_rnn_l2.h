@@ -1,0 +1,408 @@
+// orl_rnn_l2.h - the recurrent ROW kernel for data_chunk_length == 2 (the reference default, cfg4) with both steps of a
+// chunk RESIDENT IN REGISTERS (round 5).  Included by orl_rnn.hip after rnn_row_body (RnnRowArgs, RNN_T, loss helpers).
+// Reference: openrl/modules/networks/utils/rnn.py:39-99 (masked GRU over a chunk), openrl/buffers/replay_data.py:1062-1258
+// (recurrent_generator: chunks of data_chunk_length steps, the stored state of the chunk's first step), openrl/algorithms/
+// ppo.py:363-372.
+//
+// rnn_row_body walks a chunk as "forward sweep (state tape) + backward sweep with the forward RECOMPUTED per step" at two
+// waves per SIMD and 256 registers per wave: 35 64 x 64 GEMMs per 16-chunk tile at L = 2 (step 0 forward twice, and the
+// hidden-state dgrad of step 0, whose result nobody reads), x-hat vectors parked on the HBM tape and reloaded behind the
+// tape's own stores (vmcnt returns in order: the reload waits for every store in front of it).  With two steps the whole
+// chunk fits ONE wave's register file when the wave has a SIMD to itself (4-wave workgroups, 512 registers: 256 VGPRs + 256
+// AccVGPRs the allocator moves values through):
+//
+//   step 0 forward   trunk, GRU, LN3, head, loss  -> keeps x-hat1/2, the gates, h_in, the relu mask and
+//                    dt0 = LN3'(W3^T dhead_0) (the loss's own gradient w.r.t. h1)
+//   step 1 forward   the same from h1 * mask_1
+//   step 1 backward  gate deltas, W_hh^T / W_ih^T dgrad (carry -> h1), LN2', W2^T, LN1', relu'
+//   step 0 backward  d = dt0 + carry; gate deltas; W_ih^T dgrad only (the gradient w.r.t. the stored state h0 is not
+//                    needed); LN2', W2^T, LN1', relu'
+//
+// = 7 + 7 + 7 + 4 = 25 GEMMs per tile instead of 35, no forward recompute, no state tape (htape), and NO global load behind a
+// tape store inside a tile: the x-hat vectors never leave the registers, the tile's inputs (row indices, records, masks,
+// stored states) are requested one tile ahead.  The wgrad tape is written exactly as rnn_row_body writes it (same block
+// layout, same values up to summation order), so rnn_wgrad_kernel and everything downstream are unchanged.  GEMMs stay on
+// v_mfma_f32_16x16x4_f32 out of the resident fp32 LDS images (RnnLds).
+#pragma once
+#include "orl_rnn.h"
+
+namespace orl {
+
+// what one step of one 16-chunk tile reads from global memory (requested a tile ahead)
+struct Row2In {
+  f32x4 xo[4];        // observation columns 16m + 4q .. + 3 of this lane's row (0 beyond D): fc1's B operands AND the tape tile
+  float am, adv, act, lp, vp, rt;  // the record's scalar loss fields
+  float mkc[4];       // wide categorical head: action masks of this lane's 4 classes
+  float mask;         // masks[row]
+  const float* rec;   // the record row (fields outside the prefetched set: Gaussian per-dimension columns)
+};
+
+template <int HEAD, int NO>
+__device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid, const int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const RnnLayout tl(A.net);
+  constexpr bool HMM = HEAD == ORL_HEAD_CATEGORICAL && NO > 4;
+  const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HMM);
+  stage_rnn_tower(smem, A.theta, tl, tw, threadIdx.x, blockDim.x, HMM);
+  __syncthreads();
+  const float* lw = smem;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int D = A.net.obs_dim, n_out = A.net.n_out, DP = tw.DP;
+  const int Nc = A.Nc;
+  const orl_ppo_hparams hp = A.hp;
+  const int BLK = tape_block_floats(D);
+  const int ND = (D + 15) >> 4;
+
+  float vn_mean = 0.f, vn_sd = 1.f;
+  if (HEAD == ORL_HEAD_VALUE && hp.use_valuenorm && A.vn_state != nullptr) {
+    const float deb = fmaxf(A.vn_state[2], 1e-5f);
+    vn_mean = A.vn_state[0] / deb;
+    const float msq = A.vn_state[1] / deb;
+    vn_sd = sqrtf(fmaxf(msq - vn_mean * vn_mean, 1e-2f));
+  }
+  LossStats st = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float a_dls[NO];
+#pragma unroll
+  for (int c = 0; c < NO; ++c) a_dls[c] = 0.f;
+
+  const int n_tiles = (Nc + TILE_B - 1) / TILE_B;
+  const int nwv = blockDim.x >> 6;
+  const int stride = nblk * nwv;
+
+  // ---- input pipeline: row indices two tiles ahead, everything read through them one tile ahead ---------------------
+  auto rows_of = [&](int tile, long long& r0, long long& r1) {
+    const int ci = tile * TILE_B + j;
+    const int cis = (tile < n_tiles && ci < Nc) ? ci : 0;  // padding lanes / tiles shadow chunk 0: finite data, zero weight
+    r0 = A.rows[cis];
+    r1 = A.rows[(size_t)Nc + cis];
+  };
+  auto fetch = [&](long long row, Row2In& I) {
+    const float* rec = A.records + (size_t)row * A.R;
+    I.rec = rec;
+    I.mask = A.masks[row];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      I.xo[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < ND) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * m + 4 * q + r;
+          I.xo[m][r] = f < D ? rec[A.o_x + f] : 0.f;
+        }
+      }
+    }
+    I.am = rec[A.cols.o_am]; I.adv = rec[A.cols.o_adv]; I.act = rec[A.cols.o_act];
+    I.lp = rec[A.cols.o_lp]; I.vp = rec[A.cols.o_vp]; I.rt = rec[A.cols.o_rt];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) I.mkc[r] = 1.f;
+    if (HMM && A.cols.K > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * q + r < n_out) I.mkc[r] = rec[A.cols.o_mk + 4 * q + r];
+    }
+  };
+  auto fetch_h = [&](long long row, f32x4 (&h)[4]) {
+    const float* h0 = A.hbuf + (size_t)row * HID;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(h0 + 16 * m + 4 * q);
+  };
+
+  // ---- pieces of a step ---------------------------------------------------------------------------------------------
+  // trunk: fc1 enumerates its reduction index like the 64-wide layers do ((m, r) -> column 16m + 4q + r), so the observation
+  // registers are the tape's tile as they are; W1's LDS image is read 16 bytes at a time (columns >= DP of a row run into
+  // the next row / the vectors behind W1: finite values that meet x = 0)
+  auto trunk = [&](const f32x4 (&xo)[4], f32x4 (&xh1)[4], float& rstd1, unsigned& relu_bits, f32x4 (&xh2)[4], float& rstd2,
+                   f32x4 (&n2)[4]) {
+    f32x4 n1[4];
+    load_vec_T(lw + tw.b1, q, xh1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (m < ND) {
+        f32x4 a4[4];
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) a4[mo] = *(const f32x4*)(lw + tw.W1 + (16 * mo + j) * DP + 16 * m + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mo = 0; mo < 4; ++mo) xh1[mo] = ORL_MFMA(a4[mo][r], xo[m][r], xh1[mo]);
+      }
+    }
+    relu_bits = 0u;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (xh1[m][r] > 0.f) relu_bits |= 1u << (4 * m + r);
+        xh1[m][r] = fmaxf(xh1[m][r], 0.f);
+      }
+    ln_normalize_T(xh1, rstd1);
+    ln_affine_T(xh1, lw + tw.g1, lw + tw.be1, q, n1);
+    load_vec_T(lw + tw.b2, q, xh2);
+    mm64_T(lw + tw.W2, n1, xh2, j, q);
+    ln_normalize_T(xh2, rstd2);
+    ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, n2);
+  };
+  // LN3 + head + loss of a step from its new hidden state; leaves x-hat3, the head deltas (dh / dhv) and
+  // dt = LN3'(W3^T dhead) and writes x-hat3, the head deltas and the observation tile to the step's tape block
+  auto head_loss = [&](const f32x4 (&hnew)[4], const Row2In& I, bool valid, float* __restrict__ tb, f32x4 (&dt)[4]) {
+    auto recf = [&](int col) -> float {
+      if (col == A.cols.o_am) return I.am;
+      if (col == A.cols.o_adv) return I.adv;
+      if (col == A.cols.o_act) return I.act;
+      if (col == A.cols.o_lp) return I.lp;
+      if (col == A.cols.o_vp) return I.vp;
+      if (col == A.cols.o_rt) return I.rt;
+      if (HMM) {
+        const int d = col - (A.cols.o_mk + 4 * q);
+        if (d >= 0 && d < 4) return d == 0 ? I.mkc[0] : d == 1 ? I.mkc[1] : d == 2 ? I.mkc[2] : I.mkc[3];
+      }
+      return I.rec[col];
+    };
+    f32x4 xh3[4], n3[4];
+    float rstd3;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) xh3[m] = hnew[m];
+    ln_normalize_T(xh3, rstd3);
+    tape_store(tb + TV_XH3 * TV, xh3, j, q);
+    ln_affine_T(xh3, lw + tw.g3, lw + tw.be3, q, n3);
+    float dh[NO], dls[NO];
+    f32x4 dhv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (HMM) {
+      const int no4 = (n_out + 3) & ~3;
+      f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (4 * q < no4) hv = *(const f32x4*)(lw + tw.b3 + 4 * q);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const f32x4 a4 = *(const f32x4*)(lw + tw.W3P + j * W2S + 16 * mi + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv = ORL_MFMA(a4[r], n3[mi][r], hv);
+      }
+      ppo_cat_loss_dist(hv, n_out, q, valid, recf, A.cols, hp, dhv, st, q == 0);
+    } else {
+      float hd[NO];
+      head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, n3, q, hd);
+      ppo_row_loss<HEAD, NO>(hd, n_out, valid, recf, A.cols, hp, vn_mean, vn_sd, lw + tw.logstd, dh, dls, st, q == 0);
+      if (q == 0) {
+#pragma unroll
+        for (int c = 0; c < NO; ++c) a_dls[c] += dls[c];
+      }
+    }
+    {  // head deltas -> tape (16-wide vector: lane (j, q) owns columns 4q .. 4q + 3)
+      f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (HMM) dv = dhv;
+      else {
+#pragma unroll
+        for (int c = 0; c < NO; ++c)
+          if ((c >> 2) == q) dv[c & 3] = dh[c];
+      }
+      *(f32x4*)(tb + TAPE_HEAD + (q * 16 + ((j + 4 * q) & 15)) * 4) = dv;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)  // (constant indices: a rolled loop over ND would put I.xo into scratch memory)
+      if (m < ND) *(f32x4*)(tb + TAPE_X + m * 256 + (q * 16 + ((j + 4 * q) & 15)) * 4) = I.xo[m];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dt[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (HMM) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) dt[mo] = ORL_MFMA(lw[tw.W3P + (4 * q + r) * W2S + 16 * mo + j], dhv[r], dt[mo]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NO; ++c) {
+        if (c < n_out) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) dt[m] += *(const f32x4*)(lw + tw.W3 + c * HID + 16 * m + 4 * q) * dh[c];
+        }
+      }
+    }
+    ln_bwd_rnn(dt, xh3, lw + tw.g3, rstd3, q);
+  };
+  // GRU cell backward (element-wise): gates -> deltas in place, carry = d * z; the four delta vectors go to the tape
+  auto gate_bwd = [&](const f32x4 (&d)[4], const f32x4 (&hin)[4], f32x4 (&gr)[4], f32x4 (&gz)[4], f32x4 (&gn)[4],
+                      f32x4 (&ghn)[4], f32x4 (&carry)[4], float* __restrict__ tb) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float rr = gr[m][k], zz = gz[m][k], nn = gn[m][k], gg = ghn[m][k], dd = d[m][k], hh = hin[m][k];
+        const float dn_pre = dd * (1.0f - zz) * (1.0f - nn * nn);
+        const float dz_pre = dd * (hh - nn) * zz * (1.0f - zz);
+        const float dr_pre = dn_pre * gg * rr * (1.0f - rr);
+        gr[m][k] = dr_pre;
+        gz[m][k] = dz_pre;
+        gn[m][k] = dn_pre;
+        ghn[m][k] = dn_pre * rr;
+        carry[m][k] = dd * zz;
+      }
+    tape_store(tb + TV_DR * TV, gr, j, q);
+    tape_store(tb + TV_DZ * TV, gz, j, q);
+    tape_store(tb + TV_DN * TV, gn, j, q);
+    tape_store(tb + TV_DGHN * TV, ghn, j, q);
+  };
+  // input-side dgrad of the GRU, then LN2' -> dz2 -> W2^T -> LN1' -> relu' -> dz1 (both to the tape)
+  auto trunk_bwd = [&](const f32x4 (&gr)[4], const f32x4 (&gz)[4], const f32x4 (&gn)[4], const f32x4 (&xh1)[4], float rstd1,
+                       unsigned relu_bits, const f32x4 (&xh2)[4], float rstd2, float* __restrict__ tb) {
+    f32x4 d2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) d2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mm64_S_wt<W2S>(lw + tw.Wih, gr, d2, j, q);
+    mm64_S_wt<W2S>(lw + tw.Wih + HID * W2S, gz, d2, j, q);
+    mm64_S_wt<W2S>(lw + tw.Wih + 2 * HID * W2S, gn, d2, j, q);
+    ln_bwd_rnn(d2, xh2, lw + tw.g2, rstd2, q);
+    tape_store(tb + TV_DZ2 * TV, d2, j, q);
+    f32x4 d1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mm64_S_wt<W2S>(lw + tw.W2, d2, d1, j, q);
+    ln_bwd_rnn(d1, xh1, lw + tw.g1, rstd1, q);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (!((relu_bits >> (4 * m + r)) & 1u)) d1[m][r] = 0.f;
+    tape_store(tb + TV_DZ1 * TV, d1, j, q);
+  };
+
+#ifdef ORL_PROF
+  __shared__ unsigned long long rprof_lds[16];
+  const bool prof_on = blockIdx.x == 0 && wave == 0;
+  if (prof_on && l < 16) rprof_lds[l] = 0ull;
+  unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+
+  const int tile0 = bid * nwv + wave;
+  long long rn0, rn1;        // row indices of the NEXT tile
+  Row2In In0, In1;           // inputs of the CURRENT tile's two steps
+  f32x4 h0[4];
+  {
+    long long r0, r1;
+    rows_of(tile0, r0, r1);
+    rows_of(tile0 + stride, rn0, rn1);
+    fetch(r0, In0);
+    fetch(r1, In1);
+    fetch_h(r0, h0);
+  }
+  for (int tile = tile0; tile < n_tiles; tile += stride) {
+    const bool valid = tile * TILE_B + j < Nc;
+    float* tb0 = A.tape + ((size_t)tile * 2 + 0) * BLK;
+    float* tb1 = A.tape + ((size_t)tile * 2 + 1) * BLK;
+    RNN_T(1);  // input hand-over
+
+    // ---------------- step 0 forward ----------------
+    f32x4 hin0[4], xh1_0[4], xh2_0[4], r0g[4], z0g[4], n0g[4], g0g[4], h1[4], dt0[4];
+    float rs1_0, rs2_0;
+    unsigned rb0;
+    {
+      f32x4 n2[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) hin0[m] = h0[m] * In0.mask;
+      tape_store(tb0 + TV_HIN * TV, hin0, j, q);
+      trunk(In0.xo, xh1_0, rs1_0, rb0, xh2_0, rs2_0, n2);
+      tape_store(tb0 + TV_XH1 * TV, xh1_0, j, q);
+      tape_store(tb0 + TV_XH2 * TV, xh2_0, j, q);
+      RNN_T(2);  // trunk (fc1 + 64 MFMA) + tape stores
+      gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
+      RNN_T(3);  // GRU forward: 384 MFMA + gates
+      head_loss(h1, In0, valid, tb0, dt0);
+      RNN_T(4);  // LN3, head, loss, W3^T dhead, LN3'
+    }
+    // ---------------- step 1 forward + backward ----------------
+    f32x4 carry[4];
+    {
+      f32x4 hin1[4], xh1_1[4], xh2_1[4], gr[4], gz[4], gn[4], ghn[4], dt1[4];
+      float rs1_1, rs2_1;
+      unsigned rb1;
+      {
+        f32x4 n2[4], h2[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hin1[m] = h1[m] * In1.mask;
+        tape_store(tb1 + TV_HIN * TV, hin1, j, q);
+        trunk(In1.xo, xh1_1, rs1_1, rb1, xh2_1, rs2_1, n2);
+        tape_store(tb1 + TV_XH1 * TV, xh1_1, j, q);
+        tape_store(tb1 + TV_XH2 * TV, xh2_1, j, q);
+        RNN_T(2);
+        gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
+        RNN_T(3);
+        head_loss(h2, In1, valid, tb1, dt1);
+        RNN_T(4);
+      }
+      gate_bwd(dt1, hin1, gr, gz, gn, ghn, carry, tb1);
+      RNN_T(6);  // GRU element-wise backward + 4 tape vectors
+      mm64_S_wt<W2S>(lw + tw.Whh, gr, carry, j, q);
+      mm64_S_wt<W2S>(lw + tw.Whh + HID * W2S, gz, carry, j, q);
+      mm64_S_wt<W2S>(lw + tw.Whh + 2 * HID * W2S, ghn, carry, j, q);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) carry[m] = carry[m] * In1.mask;  // h_in = h * mask
+      RNN_T(7);  // hidden-state dgrad: 192 MFMA (column reads)
+      trunk_bwd(gr, gz, gn, xh1_1, rs1_1, rb1, xh2_1, rs2_1, tb1);
+      RNN_T(8);  // W_ih^T dgrad, LN2', W2^T, LN1', relu', tapes
+    }
+    // The next tile's inputs are requested HERE, in front of the last phase (4 GEMMs, ~3 us: longer than a chain of two
+    // dependent global loads), not at the top of the tile: ~110 registers of prefetched values held through both steps
+    // pushed the allocation past 512 registers into scratch.  The row indices travel one tile further ahead.
+    Row2In Nx0, Nx1;
+    f32x4 hn0[4];
+    fetch(rn0, Nx0);
+    fetch(rn1, Nx1);
+    fetch_h(rn0, hn0);
+    rows_of(tile + 2 * stride, rn0, rn1);
+    // ---------------- step 0 backward ----------------
+    {
+      f32x4 d[4], cdead[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) d[m] = dt0[m] + carry[m];
+      gate_bwd(d, hin0, r0g, z0g, n0g, g0g, cdead, tb0);  // (the carry into the stored state h0 is not needed)
+      RNN_T(6);
+      trunk_bwd(r0g, z0g, n0g, xh1_0, rs1_0, rb0, xh2_0, rs2_0, tb0);
+      RNN_T(8);
+    }
+    // hand the prefetched inputs over
+    In0 = Nx0;
+    In1 = Nx1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) h0[m] = hn0[m];
+  }
+#ifdef ORL_PROF
+  if (prof_on && l < 12) atomicAdd(&g_rnn_prof[l], rprof_lds[l]);
+  if (prof_on && l == 12) atomicAdd(&g_rnn_prof[12], 1ull);
+#endif
+
+  // ---- workgroup reduction of {dlogstd, stats}: fixed order (as rnn_row_body) ------------------------------------------
+  __syncthreads();
+  float* acc = smem;  // weights are dead
+  const int PW = RnnRaw(A.net).n_logstd + ORL_N_STATS;
+  const int nls = PW - ORL_N_STATS;
+  for (int e = threadIdx.x; e < PW; e += blockDim.x) acc[e] = 0.f;
+  __syncthreads();
+  st.active = wave_sum(st.active); st.rows = wave_sum(st.rows); st.loss = wave_sum(st.loss);
+  st.ent = wave_sum(st.ent); st.ratio = wave_sum(st.ratio);
+#pragma unroll
+  for (int c = 0; c < NO; ++c) a_dls[c] = wave_sum(a_dls[c]);
+  for (int w = 0; w < nwv; ++w) {
+    if (wave == w && l == 0) {
+#pragma unroll
+      for (int c = 0; c < NO; ++c)
+        if (c < nls) acc[c] += a_dls[c];
+      acc[nls + ST_ACTIVE_SUM] += st.active;
+      acc[nls + ST_ROWS] += st.rows;
+      if (HEAD == ORL_HEAD_VALUE) acc[nls + ST_VLOSS_SUM] += st.loss;
+      else {
+        acc[nls + ST_PLOSS_SUM] += st.loss;
+        acc[nls + ST_ENT_SUM] += st.ent;
+        acc[nls + ST_RATIO_SUM] += st.ratio;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < PW; e += blockDim.x) A.partials[(size_t)bid * PW + e] = acc[e];
+}
+
+// blocks [0, split) = policy tower, [split, gridDim) = critic tower; 4 waves per workgroup = one wave per SIMD
+template <int HEADP, int NOP>
+__global__ __launch_bounds__(256, 1) void rnn_row2_pair_kernel(RnnRowArgs P, RnnRowArgs Cc, int split) {
+  if ((int)blockIdx.x < split) rnn_row2_body<HEADP, NOP>(P, blockIdx.x, split);
+  else rnn_row2_body<ORL_HEAD_VALUE, 1>(Cc, blockIdx.x - split, gridDim.x - split);
+}
+
+}  // namespace orl

@@ -350,8 +350,10 @@ def make_hparams(cfg, recurrent: bool = False) -> PPOHParams:
     come from ``amd_rnn_gemm`` (the recurrent row kernel) instead of ``amd_tower_gemm`` (the feed-forward tower pair)."""
     tower = str(getattr(cfg, "amd_tower_gemm", "split"))
     if recurrent:
+        # fp32 (default): chunks of 2 steps -> the register-resident row kernel of round 5, other lengths -> the recompute
+        # kernel; fp32_recompute: the recompute kernel whatever the length; split / split_w4: round 4's streamed kernel
         rnn = "fp32" if tower == "fp32" else str(getattr(cfg, "amd_rnn_gemm", "fp32"))
-        gemm_bits = {"fp32": 4, "split": 0, "split_w4": 16}[rnn]
+        gemm_bits = {"fp32": 0, "fp32_recompute": 4, "split": 8, "split_w4": 8 | 16}[rnn]
     else:
         gemm_bits = {"fp32": 4, "split_two_image": 8}.get(tower, 0)
     return PPOHParams(clip_param=float(cfg.clip_param), entropy_coef=float(cfg.entropy_coef),

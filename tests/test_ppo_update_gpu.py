@@ -402,7 +402,7 @@ def _full_general_engine(g, perm_mode, gemm=None):
     if gemm is not None:  # the update kernels' GEMM path: amd_tower_gemm (split | fp32 | split_two_image) for the
         if gemm in ("split", "fp32", "split_two_image"):  # feed-forward pair, amd_rnn_gemm (fp32 | split | split_w4) for the
             cfg.amd_tower_gemm = gemm                      # recurrent row kernel
-        if gemm in ("split", "fp32", "split_w4"):
+        if gemm in ("split", "fp32", "split_w4", "fp32_recompute"):
             cfg.amd_rnn_gemm = gemm
     box = lambda d: spaces.Box(-np.inf, np.inf, (d,))
     obs_space = box(Dp) if Dp == Dc else spaces.Dict({"policy": box(Dp), "critic": box(Dc)})

@@ -79,11 +79,12 @@ def test_recurrent_module_init_is_the_reference_init(case, seed):
     assert sd["rnn.rnn.weight_ih_l0"].shape == (192, 64) and sd["rnn.norm.bias"].shape == (64,)
 
 
-@pytest.mark.parametrize("gemm", ["split", "fp32", "split_w4"])
+@pytest.mark.parametrize("gemm", ["split", "fp32", "fp32_recompute", "split_w4"])
 @pytest.mark.parametrize("case", RH.RNN_CASES)
 def test_recurrent_train_matches_reference_golden(case, gemm):
-    """gemm: the row kernel's GEMM path (cfg.amd_rnn_gemm) - the fp32-MFMA kernel (default) and the streamed bf16-split
-    build with 8 or (split_w4) 4 waves per workgroup; all three must land on the reference's update."""
+    """gemm: the row kernel (cfg.amd_rnn_gemm) - fp32 (default: the register-resident kernel of csrc/orl_rnn_l2.h for chunks of
+    2 steps, the recompute kernel for other lengths), fp32_recompute (the recompute kernel whatever the length) and the
+    streamed bf16-split build with 8 or (split_w4) 4 waves per workgroup; all must land on the reference's update."""
     g = H.load_golden(case)
     cfg, module, buf, algo = build_engine(g, gemm=gemm)
     module.models["policy"].theta.copy_(torch.tensor(g["theta_p0"]))
@@ -443,7 +444,8 @@ def test_shared_recurrent_network_matches_reference_golden():
 
 
 @pytest.mark.parametrize("perm_mode,gemm", [("device", "split"), ("identity", "split"), ("reference", "split"),
-                                            ("device", "fp32"), ("device", "split_w4")])
+                                            ("device", "fp32"), ("identity", "fp32"), ("reference", "fp32"),
+                                            ("device", "fp32_recompute"), ("device", "split_w4")])
 def test_full_size_recurrent_update_matches_reference_golden(perm_mode, gemm):
     """BASELINE.json configs[3] at FULL size: 2048 envs x 3 agents x 25 steps = 153 600 rows = 76 800 chunks of 2 (the
     odd T makes chunks straddle lanes), Dict obs 18 / 54, Discrete(5), GRU, adv-normalise on (examples/mpe/mpe_ppo.yaml),
