@@ -34,7 +34,7 @@ struct Row2In {
   float am, adv, act, lp, vp, rt;  // the record's scalar loss fields
   float mkc[4];       // wide categorical head: action masks of this lane's 4 classes
   float mask;         // masks[row]
-  const float* rec;   // the record row (fields outside the prefetched set: Gaussian per-dimension columns)
+  int row;            // the record row (fields outside the prefetched set - Gaussian per-dimension columns - are read through it)
 };
 
 template <int HEAD, int NO>
@@ -46,7 +46,8 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
   stage_rnn_tower(smem, A.theta, tl, tw, threadIdx.x, blockDim.x, HMM);
   __syncthreads();
   const float* lw = smem;
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, q = l >> 4;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  int j = l & 15, q = l >> 4;  // (not const: redefined opaquely at the top of every tile, see the tile loop)
   const int D = A.net.obs_dim, n_out = A.net.n_out, DP = tw.DP;
   const int Nc = A.Nc;
   const orl_ppo_hparams hp = A.hp;
@@ -70,15 +71,21 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
   const int stride = nblk * nwv;
 
   // ---- input pipeline: row indices two tiles ahead, everything read through them one tile ahead ---------------------
-  auto rows_of = [&](int tile, long long& r0, long long& r1) {
+  // (row indices are kept as 32-bit values: they live in registers across a whole tile - see the prefetch point below - and a
+  // spilled one comes back through a scratch load, whose vmcnt(0) drains every tape store in flight)
+  auto rows_of = [&](int tile, int& r0, int& r1) {
     const int ci = tile * TILE_B + j;
     const int cis = (tile < n_tiles && ci < Nc) ? ci : 0;  // padding lanes / tiles shadow chunk 0: finite data, zero weight
-    r0 = A.rows[cis];
-    r1 = A.rows[(size_t)Nc + cis];
+    r0 = (int)A.rows[cis];
+    r1 = (int)A.rows[(size_t)Nc + cis];
   };
-  auto fetch = [&](long long row, Row2In& I) {
+  // Every load is unconditional (clamped column) and NOTHING is computed from a loaded value here: a test per column became
+  // an exec-mask branch around each global load, and a select right behind the load is a first use - hipcc schedules it
+  // where it is written and waits for the load on the spot (vmcnt(0): the tape stores in flight drain).  Columns >= D are
+  // zeroed where they are used, with the NEXT tile's (opaquely redefined) lane coordinates: that cannot move up here.
+  auto fetch = [&](int row, Row2In& I) {
     const float* rec = A.records + (size_t)row * A.R;
-    I.rec = rec;
+    I.row = row;
     I.mask = A.masks[row];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -87,7 +94,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * m + 4 * q + r;
-          I.xo[m][r] = f < D ? rec[A.o_x + f] : 0.f;
+          I.xo[m][r] = rec[A.o_x + (f < D ? f : D - 1)];
         }
       }
     }
@@ -95,13 +102,15 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     I.lp = rec[A.cols.o_lp]; I.vp = rec[A.cols.o_vp]; I.rt = rec[A.cols.o_rt];
 #pragma unroll
     for (int r = 0; r < 4; ++r) I.mkc[r] = 1.f;
-    if (HMM && A.cols.K > 0) {
+    if (HEAD == ORL_HEAD_CATEGORICAL && A.cols.K > 0) {  // wide heads: this lane's classes 4q .. 4q + 3; narrow ones: 0 .. 3
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * q + r < n_out) I.mkc[r] = rec[A.cols.o_mk + 4 * q + r];
+      for (int r = 0; r < 4; ++r) {
+        const int c = (HMM ? 4 * q : 0) + r;
+        I.mkc[r] = rec[A.cols.o_mk + (c < n_out ? c : n_out - 1)];  // (classes >= n_out are never looked at)
+      }
     }
   };
-  auto fetch_h = [&](long long row, f32x4 (&h)[4]) {
+  auto fetch_h = [&](int row, f32x4 (&h)[4]) {
     const float* h0 = A.hbuf + (size_t)row * HID;
 #pragma unroll
     for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(h0 + 16 * m + 4 * q);
@@ -143,7 +152,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, n2);
   };
   // LN3 + head + loss of a step from its new hidden state; leaves x-hat3, the head deltas (dh / dhv) and
-  // dt = LN3'(W3^T dhead) and writes x-hat3, the head deltas and the observation tile to the step's tape block
+  // dt = LN3'(W3^T dhead) and writes x-hat3 and the head deltas to the step's tape block
   auto head_loss = [&](const f32x4 (&hnew)[4], const Row2In& I, bool valid, float* __restrict__ tb, f32x4 (&dt)[4]) {
     auto recf = [&](int col) -> float {
       if (col == A.cols.o_am) return I.am;
@@ -152,11 +161,11 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       if (col == A.cols.o_lp) return I.lp;
       if (col == A.cols.o_vp) return I.vp;
       if (col == A.cols.o_rt) return I.rt;
-      if (HMM) {
-        const int d = col - (A.cols.o_mk + 4 * q);
+      if (HEAD == ORL_HEAD_CATEGORICAL) {
+        const int d = col - (A.cols.o_mk + (HMM ? 4 * q : 0));
         if (d >= 0 && d < 4) return d == 0 ? I.mkc[0] : d == 1 ? I.mkc[1] : d == 2 ? I.mkc[2] : I.mkc[3];
       }
-      return I.rec[col];
+      return A.records[(size_t)I.row * A.R + col];
     };
     f32x4 xh3[4], n3[4];
     float rstd3;
@@ -198,9 +207,6 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       *(f32x4*)(tb + TAPE_HEAD + (q * 16 + ((j + 4 * q) & 15)) * 4) = dv;
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m)  // (constant indices: a rolled loop over ND would put I.xo into scratch memory)
-      if (m < ND) *(f32x4*)(tb + TAPE_X + m * 256 + (q * 16 + ((j + 4 * q) & 15)) * 4) = I.xo[m];
-#pragma unroll
     for (int m = 0; m < 4; ++m) dt[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (HMM) {
 #pragma unroll
@@ -217,6 +223,17 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       }
     }
     ln_bwd_rnn(dt, xh3, lw + tw.g3, rstd3, q);
+  };
+  // the observation tile of a step -> its tape block (constant indices: a rolled loop over ND would put xo into scratch memory)
+  auto obs_to_tape = [&](const f32x4 (&xo)[4], float* __restrict__ tb) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m < ND) *(f32x4*)(tb + TAPE_X + m * 256 + (q * 16 + ((j + 4 * q) & 15)) * 4) = xo[m];
+  };
+  // a 64-wide vector this wave stored to its tape block earlier, back into registers (tape_store's layout)
+  auto tape_load = [&](const float* __restrict__ v, f32x4 (&x)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(v + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
   };
   // GRU cell backward (element-wise): gates -> deltas in place, carry = d * z; the four delta vectors go to the tape
   auto gate_bwd = [&](const f32x4 (&d)[4], const f32x4 (&hin)[4], f32x4 (&gr)[4], f32x4 (&gz)[4], f32x4 (&gn)[4],
@@ -272,29 +289,51 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
 #endif
 
   const int tile0 = bid * nwv + wave;
-  long long rn0, rn1;        // row indices of the NEXT tile
+  // Input pipeline.  A wait on a load also waits for everything OLDER in the wave's VMEM queue (vmcnt returns in order), so
+  // a load is harmless when it is issued long before its first use and fatal when it is issued right in front of it (the
+  // tape stores in flight are drained).  Hence:
+  //   row indices      two tiles ahead (rn0 / rn1: two registers that live across the whole tile);
+  //   step 0's inputs  (record fields, mask, stored state) one tile ahead, in front of the previous tile's last phase;
+  //   step 1's inputs  at the top of their own tile, a whole step-0 forward before their first use.
+  int rc1, rn0, rn1;         // row of this tile's step 1; rows of the NEXT tile's two steps
   Row2In In0, In1;           // inputs of the CURRENT tile's two steps
   f32x4 h0[4];
   {
-    long long r0, r1;
-    rows_of(tile0, r0, r1);
+    int r0;
+    rows_of(tile0, r0, rc1);
     rows_of(tile0 + stride, rn0, rn1);
     fetch(r0, In0);
-    fetch(r1, In1);
     fetch_h(r0, h0);
   }
   for (int tile = tile0; tile < n_tiles; tile += stride) {
+    // The tower image never changes inside this loop, and hipcc knows it: left alone it hoists the loop-invariant LDS reads
+    // (16 bias / LayerNorm vectors x 16 registers, the first fragments of every GEMM: 54 ds_read_b128 in front of the loop)
+    // and holds them across the whole tile - on top of a working set that already fills the file (72 - 240 spilled registers,
+    // and a spill's reload drains the tape stores through its vmcnt(0)).  An opaque redefinition of the lane coordinates per
+    // tile makes every LDS address loop-variant; immediate offsets from the known base still fold.
+    asm volatile("" : "+v"(j), "+v"(q));
     const bool valid = tile * TILE_B + j < Nc;
+    fetch(rc1, In1);
     float* tb0 = A.tape + ((size_t)tile * 2 + 0) * BLK;
     float* tb1 = A.tape + ((size_t)tile * 2 + 1) * BLK;
     RNN_T(1);  // input hand-over
 
+    auto zero_pad = [&](f32x4 (&xo)[4]) {  // observation columns >= D (clamped re-reads of column D - 1) -> 0
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xo[m][r] = (m < ND && 16 * m + 4 * q + r < D) ? xo[m][r] : 0.f;
+    };
     // ---------------- step 0 forward ----------------
-    f32x4 hin0[4], xh1_0[4], xh2_0[4], r0g[4], z0g[4], n0g[4], g0g[4], h1[4], dt0[4];
+    zero_pad(In0.xo);
+    obs_to_tape(In0.xo, tb0);
+    // x-hat1 / x-hat2 of step 0 are NOT held through step 1 (32 registers at the tile's pressure peak): they are on the tape
+    // already and come back at the prefetch point, three GEMMs ahead of their first use (h_in is needed at once there: kept)
+    f32x4 hin0[4], r0g[4], z0g[4], n0g[4], g0g[4], h1[4], dt0[4];
     float rs1_0, rs2_0;
     unsigned rb0;
     {
-      f32x4 n2[4];
+      f32x4 n2[4], xh1_0[4], xh2_0[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) hin0[m] = h0[m] * In0.mask;
       tape_store(tb0 + TV_HIN * TV, hin0, j, q);
@@ -315,6 +354,8 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       unsigned rb1;
       {
         f32x4 n2[4], h2[4];
+        zero_pad(In1.xo);
+        obs_to_tape(In1.xo, tb1);
 #pragma unroll
         for (int m = 0; m < 4; ++m) hin1[m] = h1[m] * In1.mask;
         tape_store(tb1 + TV_HIN * TV, hin1, j, q);
@@ -338,15 +379,22 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       trunk_bwd(gr, gz, gn, xh1_1, rs1_1, rb1, xh2_1, rs2_1, tb1);
       RNN_T(8);  // W_ih^T dgrad, LN2', W2^T, LN1', relu', tapes
     }
-    // The next tile's inputs are requested HERE, in front of the last phase (4 GEMMs, ~3 us: longer than a chain of two
-    // dependent global loads), not at the top of the tile: ~110 registers of prefetched values held through both steps
-    // pushed the allocation past 512 registers into scratch.  The row indices travel one tile further ahead.
-    Row2In Nx0, Nx1;
+    // The next tile's step-0 inputs are requested HERE, in front of the last phase (4 GEMMs, ~3 us: longer than a global load's
+    // round trip), not at the top of the tile: ~110 registers of prefetched values held through both steps pushed the
+    // allocation past 512 registers into scratch.  The row indices travel one tile further ahead.
+    Row2In Nx0;
     f32x4 hn0[4];
     fetch(rn0, Nx0);
-    fetch(rn1, Nx1);
     fetch_h(rn0, hn0);
+    rc1 = rn1;
     rows_of(tile + 2 * stride, rn0, rn1);
+    f32x4 xh1_0[4], xh2_0[4];
+    {
+      const float* tbr = tb0;
+      asm volatile("" : "+v"(tbr));  // (a laundered pointer: otherwise the stored registers are forwarded and stay live)
+      tape_load(tbr + TV_XH1 * TV, xh1_0);
+      tape_load(tbr + TV_XH2 * TV, xh2_0);
+    }
     // ---------------- step 0 backward ----------------
     {
       f32x4 d[4], cdead[4];
@@ -359,13 +407,14 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     }
     // hand the prefetched inputs over
     In0 = Nx0;
-    In1 = Nx1;
 #pragma unroll
     for (int m = 0; m < 4; ++m) h0[m] = hn0[m];
   }
 #ifdef ORL_PROF
   if (prof_on && l < 12) atomicAdd(&g_rnn_prof[l], rprof_lds[l]);
   if (prof_on && l == 12) atomicAdd(&g_rnn_prof[12], 1ull);
+  if (prof_on && l == 13) atomicAdd(&g_rnn_prof[13], (unsigned long long)((n_tiles - tile0 + stride - 1) / stride));
+  if (prof_on && l == 14) atomicAdd(&g_rnn_prof[14], 1ull);  // marks the L = 2 kernel for tools/rnn_phase_prof.py
 #endif
 
   // ---- workgroup reduction of {dlogstd, stats}: fixed order (as rnn_row_body) ------------------------------------------

@@ -28,6 +28,15 @@ def main():
     if out[13]:                                   # the streamed kernel counts its probe wave's tile iterations itself
         tiles = out[13]
     print("row kernel GEMM path:", gemm)
+    if out[14]:  # the register-resident L = 2 kernel (csrc/orl_rnn_l2.h): phases per TILE (two steps)
+        names = {1: "input hand-over (waits for the prefetched loads)", 2: "trunk fwd + tapes (x2)", 3: "GRU forward (x2)",
+                 4: "LN3 + head + loss + W3^T + LN3' (x2)", 6: "gate deltas + 4 tape vectors (x2)",
+                 7: "hidden-state dgrad (step 1 only)", 8: "W_ih^T dgrad, LN2', W2^T, LN1', relu', tapes (x2)"}
+        tot = sum(out[k] for k in names)
+        print("L = 2 register-resident kernel: %d launches, %d tiles by the probe wave; %.0f cycles per tile" % (launches, tiles, tot / max(tiles, 1)))
+        for k, n in names.items():
+            print("  %-56s %8.0f cycles per tile  %5.1f %%" % (n, out[k] / max(tiles, 1), 100.0 * out[k] / tot))
+        return
     steps = tiles * 2
     tot = sum(out[k] for k in range(9))
     print("%d launches, ~%d tiles / %d backward steps by the probe wave; %.0f cycles per tile" % (launches, tiles, steps, tot / max(tiles, 1)))
