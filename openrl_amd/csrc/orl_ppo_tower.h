@@ -51,6 +51,9 @@ __device__ unsigned long long g_orl_prof[24];
 #define ORL_T(k) ((void)0)
 #endif
 
+#ifndef ORL_HMM_XH2_RELOAD
+#define ORL_HMM_XH2_RELOAD 0   // build-time experiment (round 5): no fewer spilled registers (20 / 29 either way) - off
+#endif
 #ifndef ORL_DB3_ROWLANE
 #define ORL_DB3_ROWLANE 1   // build-time A/B switch (round 5): db3 of narrow heads from per-row register partials
 #endif
@@ -742,6 +745,18 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         }
       }
     }
+#if ORL_HMM_XH2_RELOAD
+    if constexpr (HMM && ND > 0) {
+      // wide head + wide observations: x-hat2 comes back from the scratch slab here (it still holds it: dz2 is stored below)
+      // instead of staying in 16 registers through the loss - the build sits at 256 registers and spilled 20 - 33 of them
+      // around the loss phase (profiles/r04_tower_isa_budget.txt: 7 - 15 scratch operations per tile there)
+      const float* ssr = SS;
+      asm volatile("" : "+v"(ssr));  // (a laundered pointer: otherwise the stored registers are forwarded and stay live)
+      f32x4 xh2r[4];
+      load_slab_T(ssr, xh2r, j, q);
+      ln_bwd_T(d2, xh2r, rstd2);
+    } else
+#endif
     ln_bwd_T(d2, xh2, rstd2);
     wave_lds_fence();
     store_slab_T(SS, d2, j, q);
@@ -1155,8 +1170,13 @@ __global__ __launch_bounds__(512, 2) void ppo_tower_kernel(PpoArgs A) {
 // Both towers of one minibatch in ONE launch (the default 8-wave build): workgroups [0, gp) are the policy tower,
 // the rest the critic tower.  No kernel boundary between the two: critic workgroups start on a CU as soon as its
 // policy workgroup retires instead of waiting for the slowest policy workgroup of the whole chip.
+// ORL_PAIR_WAVES (build-time experiment, orl_ppo.hip): waves per workgroup of the pair launch; 8 = two per SIMD (256 registers
+// each), 12 = three per SIMD (168 registers)
+#ifndef ORL_PAIR_WAVES
+#define ORL_PAIR_WAVES 8
+#endif
 template <int HEADP, int NOP_, int ND, int SP = 0>
-__global__ __launch_bounds__(512, 2) void ppo_tower_pair_kernel(PpoArgs P, PpoArgs Cc, int gp) {
+__global__ __launch_bounds__(64 * ORL_PAIR_WAVES, (ORL_PAIR_WAVES + 3) / 4) void ppo_tower_pair_kernel(PpoArgs P, PpoArgs Cc, int gp) {
   if ((int)blockIdx.x < gp) ppo_tower_body<HEADP, NOP_, ND, SP>(P, (int)blockIdx.x, gp);
   else ppo_tower_body<ORL_HEAD_VALUE, 1, ND, SP>(Cc, (int)blockIdx.x - gp, (int)gridDim.x - gp);
 }
