@@ -307,6 +307,11 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM, SP, true);
   __syncthreads();
 
+#ifdef ORL_TOWER_STAGGER
+  // build-time experiment (round 5): the two waves of a SIMD (waves w and w + 4) start their tile loops half a tile apart, so
+  // that one is in a GEMM phase while the other is in a LayerNorm / loss phase; ORL_TOWER_STAGGER = s_sleep units of 64 cycles
+  if (wave >= 4) __builtin_amdgcn_s_sleep(ORL_TOWER_STAGGER);
+#endif
 #ifdef ORL_PROF
   __shared__ unsigned long long prof_lds[16];
   const bool prof_on = bid == 0 && wave == 0;

@@ -191,10 +191,8 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       float hd[NO];
       head_T<NO>(lw + tw.W3, lw + tw.b3, n_out, n3, q, hd);
       ppo_row_loss<HEAD, NO>(hd, n_out, valid, recf, A.cols, hp, vn_mean, vn_sd, lw + tw.logstd, dh, dls, st, q == 0);
-      if (q == 0) {
 #pragma unroll
-        for (int c = 0; c < NO; ++c) a_dls[c] += dls[c];
-      }
+      for (int c = 0; c < NO; ++c) a_dls[c] += q == 0 ? dls[c] : 0.f;  // (a select: no exec-masked region in the tile loop)
     }
     {  // head deltas -> tape (16-wide vector: lane (j, q) owns columns 4q .. 4q + 3)
       f32x4 dv = {0.f, 0.f, 0.f, 0.f};
@@ -282,10 +280,26 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
   };
 
 #ifdef ORL_PROF
-  __shared__ unsigned long long rprof_lds[16];
-  const bool prof_on = blockIdx.x == 0 && wave == 0;
-  if (prof_on && l < 16) rprof_lds[l] = 0ull;
+  // Timing build.  The probe of rnn_row_body (lane 0 adds to an LDS counter: an exec-masked region per stamp) FAULTS in this
+  // kernel ("Memory access fault", round 5): with 480 live registers the allocator parks values in AccVGPRs wherever it
+  // likes, also inside the probe's divergent regions.  Here every lane of the probe wave adds to ITS OWN LDS slot under a
+  // wave-uniform branch - no exec-masked region is added to the tile loop.
+  __shared__ unsigned long long rprof_lds[16 * 64];
+  const bool prof_on = __builtin_amdgcn_readfirstlane((int)(blockIdx.x == 0 && wave == 0)) != 0;
+  if (prof_on) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rprof_lds[k * 64 + l] = 0ull;
+  }
   unsigned long long t_last = __builtin_readcyclecounter();
+#undef RNN_T
+#define RNN_T(k)                                                      \
+  do {                                                                \
+    if (prof_on) {                                                    \
+      const unsigned long long t_now = __builtin_readcyclecounter();  \
+      rprof_lds[(k) * 64 + l] += t_now - t_last;                      \
+      t_last = t_now;                                                 \
+    }                                                                 \
+  } while (0)
 #endif
 
   const int tile0 = bid * nwv + wave;
@@ -411,7 +425,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     for (int m = 0; m < 4; ++m) h0[m] = hn0[m];
   }
 #ifdef ORL_PROF
-  if (prof_on && l < 12) atomicAdd(&g_rnn_prof[l], rprof_lds[l]);
+  if (prof_on && l < 12) atomicAdd(&g_rnn_prof[l], rprof_lds[l * 64]);
   if (prof_on && l == 12) atomicAdd(&g_rnn_prof[12], 1ull);
   if (prof_on && l == 13) atomicAdd(&g_rnn_prof[13], (unsigned long long)((n_tiles - tile0 + stride - 1) / stride));
   if (prof_on && l == 14) atomicAdd(&g_rnn_prof[14], 1ull);  // marks the L = 2 kernel for tools/rnn_phase_prof.py

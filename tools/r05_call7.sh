@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+set -u
+export ORL_KEEP_BUILD=1
+OUT=gpurun_out/r05c7
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+: > $OUT/ab_tower.txt
+for rep in 1 2 3; do
+  for v in default stagger setprio; do
+    cp variants/$v.so openrl_amd/csrc/liborl_hip.so
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | \
+      python -c "import sys,json; r=json.loads(sys.stdin.read()); print('$v', 'ms_per_step', r['ms_per_step'], 'pair_ms', r['roofline']['launch_ms'], 'frac', r['roofline']['frac'])" >> $OUT/ab_tower.txt
+  done
+done
+cat $OUT/ab_tower.txt
+cp variants/prof_rnn.so openrl_amd/csrc/liborl_hip.so
+python tools/rnn_phase_prof.py fp32 2>&1 | grep -v "^{" | tail -12 | tee $OUT/rnn_l2_phase_prof.txt
+cp variants/default.so openrl_amd/csrc/liborl_hip.so
