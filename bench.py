@@ -343,7 +343,7 @@ def main():
     # HBM bytes per launch: NOT measured in this process (PMC needs rocprofv3) - read from the committed summary of the
     # separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, and only quoted for the shape it was taken at
     traffic, traffic_source, traffic_reason = None, None, None
-    for name in ("r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+    for name in ("r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 blob = json.load(fh)["orl_ppo_fwd_bwd_pair"]
@@ -362,7 +362,7 @@ def main():
     # MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), VALU-busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4
     # / (4 x SQ_BUSY_CU_CYCLES); only quoted for the shape and GEMM path they were taken at
     busy = {}
-    for name in ("r04_pmc_tower.txt", "r03_pmc_tower.txt"):
+    for name in ("r05_pmc_tower.txt", "r04_pmc_tower.txt", "r03_pmc_tower.txt"):
         try:
             ctr = {}
             with open(os.path.join(ROOT, "profiles", name)) as fh:

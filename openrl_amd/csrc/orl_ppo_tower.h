@@ -22,11 +22,20 @@
 
 namespace orl {
 
-// A/B knob: raise the wave's issue priority around MFMA bursts (cdna guide T5).
-#ifdef ORL_USE_SETPRIO
+// A/B knob: raise the wave's issue priority around MFMA bursts (cdna guide T5).  ORL_USE_SETPRIO = 1: the fc2 burst only (the
+// round-2 form), 2: the dgrad and wgrad bursts too.
+#ifndef ORL_USE_SETPRIO
+#define ORL_USE_SETPRIO 1   // round 5: -0.8 % on the pair launch in four same-box alternations (profiles/r05_experiments.md)
+#endif
+#if ORL_USE_SETPRIO >= 1
 #define ORL_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
 #define ORL_PRIO(x) ((void)0)
+#endif
+#if ORL_USE_SETPRIO >= 2
+#define ORL_PRIO2(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define ORL_PRIO2(x) ((void)0)
 #endif
 
 #ifdef ORL_PROF
@@ -785,6 +794,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         split8(xa, fa[b][0], fa[b][1], fa[b][2]);
         split8(xb, fb[b][0], fb[b][1], fb[b][2]);
       }
+      ORL_PRIO2(1);
 #pragma unroll
       for (int bo = 0; bo < 2; ++bo)
 #pragma unroll
@@ -798,6 +808,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
           g = mfma_bf16_32(fa[bo][0], fb[bi][0], g);
           GS[bo][bi] = g;
         }
+      ORL_PRIO2(0);
     } else
     {
       // wgrad: G += dz2^T xhat1 (operands straight from the slabs in F layout), db2.  Issued as a burst of its own:
@@ -841,8 +852,10 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     if constexpr (SP) {
       u32x4 xs[2][3];
       split_T(d2, xs);
+      ORL_PRIO2(1);
       if constexpr (SPT) mm64_T_split_tr((const unsigned short*)(lw + tw.W2), xs, d1, j, q);
       else mm64_T_split((const unsigned short*)(lw + tw.W2T), xs, d1, j, q);
+      ORL_PRIO2(0);
     } else {
       if (w2t) mm64_T(lw + tw.W2T, d2, d1, j, q);
       else mm64_T_wt(lw + tw.W2, d2, d1, j, q);

@@ -14,8 +14,8 @@ acc=defaultdict(list)
 try:
     for r in csv.DictReader(open(sys.argv[1])):
         k=r["Kernel_Name"]
-        if "rnn_row_pair" in k or "rnn_wgrad" in k:
-            acc[("row" if "row_pair" in k else "wgrad", r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if "rnn_row" in k or "rnn_wgrad" in k:
+            acc[("row" if "rnn_row" in k else "wgrad", r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k,v in sorted(acc.items()): print(k, round(sum(v)/len(v),1), len(v))
 except Exception as e: print("ERR", e)
 PY
