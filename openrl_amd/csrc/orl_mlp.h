@@ -236,6 +236,25 @@ __device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ 
   });
 #undef ORL_FRAG_OFF
 }
+#elif defined(ORL_MM64_SINGLE)
+// build-time experiment (round 5, three waves per SIMD): A fragments NOT double-buffered - 12 registers less, the LDS round trip
+// of every step is left to the other waves of the SIMD
+__device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][3],
+                                             f32x4 (&acc)[4], int j, int q) {
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int h = st >> 2, mo = st & 3;
+    const u32x4 wh = *(const u32x4*)(Wb + wb_off(0, 16 * mo + j, h, q));
+    const u32x4 wm = *(const u32x4*)(Wb + wb_off(1, 16 * mo + j, h, q));
+    const u32x4 wl = *(const u32x4*)(Wb + wb_off(2, 16 * mo + j, h, q));
+    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
+    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
+    acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
+  }
+}
 #else
 __device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][3],
                                              f32x4 (&acc)[4], int j, int q) {
@@ -283,6 +302,12 @@ __device__ __forceinline__ void mm64_T_split_tr(const unsigned short* __restrict
     const u32x2 lo = ds_read_tr16(a), hi = ds_read_tr16(a + 16 * WBS);
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
   };
+#ifdef ORL_MM64_SINGLE
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int h = st >> 2, mo = st & 3;
+    const u32x4 wh = frag(0, h, mo), wm = frag(1, h, mo), wl = frag(2, h, mo);
+#else
   u32x4 w[2][3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) w[0][p] = frag(p, 0, 0);
@@ -294,6 +319,7 @@ __device__ __forceinline__ void mm64_T_split_tr(const unsigned short* __restrict
       for (int p = 0; p < 3; ++p) w[(st + 1) & 1][p] = frag(p, (st + 1) >> 2, (st + 1) & 3);
     }
     const u32x4 wh = w[st & 1][0], wm = w[st & 1][1], wl = w[st & 1][2];
+#endif
     acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
     acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);

@@ -760,7 +760,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       }
     }
 #if ORL_HMM_XH2_RELOAD
-    if constexpr (HMM && ND > 0) {
+    if constexpr ((HMM && ND > 0) || ORL_HMM_XH2_RELOAD == 2) {
       // wide head + wide observations: x-hat2 comes back from the scratch slab here (it still holds it: dz2 is stored below)
       // instead of staying in 16 registers through the loss - the build sits at 256 registers and spilled 20 - 33 of them
       // around the loss phase (profiles/r04_tower_isa_budget.txt: 7 - 15 scratch operations per tile there)
@@ -781,6 +781,42 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       // columns 32b + c of both slabs (32 conflict-free 4-byte reads, as many as the fp32 path), splits them in
       // registers and issues 6 products x 4 blocks = 24 MFMAs.  db2 falls out of the same reads.
       const int c = l & 31, kb = l >> 5;
+#ifdef ORL_WGRAD_HALVES
+      // build-time experiment (round 5, three waves per SIMD): the dz2 fragments of ONE 32-row block at a time - 12 registers less
+      {
+        u32x4 fb[2][3];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float xb[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xb[k] = X1[(8 * kb + k) * TS + 32 * b + c];
+          split8(xb, fb[b][0], fb[b][1], fb[b][2]);
+        }
+#pragma unroll
+        for (int bo = 0; bo < 2; ++bo) {
+          float xa[8];
+          u32x4 fa[3];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xa[k] = SS[(8 * kb + k) * TS + 32 * bo + c];
+          a_db2s[bo] += ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
+          split8(xa, fa[0], fa[1], fa[2]);
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi) {
+            f32x16 g = GS[bo][bi];
+            g = mfma_bf16_32(fa[2], fb[bi][0], g);
+            g = mfma_bf16_32(fa[0], fb[bi][2], g);
+            g = mfma_bf16_32(fa[1], fb[bi][1], g);
+            g = mfma_bf16_32(fa[1], fb[bi][0], g);
+            g = mfma_bf16_32(fa[0], fb[bi][1], g);
+            g = mfma_bf16_32(fa[0], fb[bi][0], g);
+            GS[bo][bi] = g;
+          }
+        }
+      }
+      if (false) {
+#else
+      {
+#endif
       u32x4 fa[2][3], fb[2][3];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -809,6 +845,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
           GS[bo][bi] = g;
         }
       ORL_PRIO2(0);
+      }
     } else
     {
       // wgrad: G += dz2^T xhat1 (operands straight from the slabs in F layout), db2.  Issued as a burst of its own:
