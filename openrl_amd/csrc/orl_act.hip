@@ -219,6 +219,9 @@ struct RollProf {};
 //    MFMAs instead of 1 - 2) and skips the first all-gather - one workgroup barrier and one LDS round trip per step less.
 //    Same k order per output element: bit-identical to the gathered form.
 // trunk_barriers(DP) = workgroup barriers one call executes (callers that only keep the barrier count need it).
+#ifndef ORL_COOP_FC2_CHAINS
+#define ORL_COOP_FC2_CHAINS 2
+#endif
 constexpr int COOP_SMALL_DP = 8;
 __host__ __device__ inline int trunk_barriers(int DP) { return DP <= COOP_SMALL_DP ? 1 : 2; }
 
@@ -284,11 +287,27 @@ __device__ inline void trunk_fwd_coop(const float* __restrict__ lds, const Tower
   }
   ln_normalize_T(x, rstd);  // xhat1: the GEMM runs on it (W2 diag(g1) image, folded bias)
   f32x4 acc = R.b2;
+#if ORL_COOP_FC2_CHAINS == 2
+  // build-time switch (round 5): the 16 dependent fp32 MFMAs of this wave's fc2 M-tile as TWO chains of 8 (k-blocks 0 - 1 and
+  // 2 - 3) that interleave in the MFMA pipe - the step's dependent chain is 8 x 32 cycles + one add instead of 16 x 32.  A
+  // different fp32 summation order than the stepwise kernel (the fused-vs-stepwise tests compare at rtol 1e-5 already).
+  f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc = ORL_MFMA(R.w2[mi][r], x[mi][r], acc);
+      acc2 = ORL_MFMA(R.w2[mi + 2][r], x[mi + 2][r], acc2);
+    }
+  }
+  acc = acc + acc2;
+#else
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc = ORL_MFMA(R.w2[mi][r], x[mi][r], acc);
   }
+#endif
   *(f32x4*)(gB + j * GS + 16 * gw + 4 * q) = acc;
   RO_T(rp, 2);
   __syncthreads();

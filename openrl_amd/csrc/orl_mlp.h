@@ -585,7 +585,25 @@ __device__ inline float feat_sum(const f32x4 (&x)[4]) {
 }
 
 // LayerNorm statistics + normalisation in place: x <- (x - mean) * rstd   (eps = 1e-5, biased var)
+// ORL_LN_ONEPASS (build-time switch, round 5): sum and sum of squares in ONE cross-lane butterfly (row_allsum2), var = E[x^2] -
+// mean^2 (clamped at 0), x <- x * rstd - mean * rstd: one dependent cross-lane round trip and 16 subtractions less per pass.  The
+// subtraction loses ~eps32 * mean^2 / var of relative accuracy in var - 1e-7 for the activations of these towers (mean^2 ~ var),
+// and is bounded by eps = 1e-5 under the root when a row is nearly constant.
+#ifndef ORL_LN_ONEPASS
+#define ORL_LN_ONEPASS 1   // round 5: headline 2.702 -> 2.668 ms, 512-env shard 0.848 -> 0.831 ms in three same-box alternations; every parity test unchanged
+#endif
 __device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd) {
+#if ORL_LN_ONEPASS
+  float s1 = lane_sum16(x), s2 = lane_dot16(x, x);
+  row_allsum2(s1, s2);
+  const float mean1 = s1 * (1.0f / 64.0f);
+  const float var1 = fmaxf(s2 * (1.0f / 64.0f) - mean1 * mean1, 0.f);
+  rstd = __builtin_amdgcn_rsqf(var1 + 1e-5f);
+  const float shift = -mean1 * rstd;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) x[m] = x[m] * rstd + shift;
+  return;
+#endif
   const float mean = feat_sum(x) * (1.0f / 64.0f);
 #pragma unroll
   for (int m = 0; m < 4; ++m) x[m] = x[m] - mean;
