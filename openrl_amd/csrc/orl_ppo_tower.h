@@ -1026,16 +1026,46 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // 2 with the launch's LDS rounded up to 8 x 18.4 KB): ONE round of plain stores - no read-modify-write round, no second
   // barrier; otherwise as many images as divide the wave count.
   const int PW = rl.total + ORL_N_STATS;
-  float* img0 = smem;
   const int lds_have = A.lds_floats > 0 ? A.lds_floats : tw.total + nwv * per_wave;
-  int NREG = lds_have / PW;
   constexpr int NREG_MAX = 8;  // images the final element-wise sum below requests together (v[NREG_MAX])
+  // Round 5 (ORL_EPI_FRAG): the 64 x 64 block G - 4 096 of a partial row's ~4 600 elements, 64 registers per lane - travels in
+  // the MFMA's FRAGMENT order: every wave stores its registers as sixteen 16-byte rows into an image of its own (no
+  // read-modify-write round, 16 ds_write_b128 per lane instead of 64 scattered ds_write_b32), the final pass sums the waves'
+  // images chunk by chunk in wave order (8 ds_read_b128 per chunk) and scatters a chunk's four values to the row-major
+  // positions the fragment stands for (for one register, 32 consecutive lanes are 32 consecutive columns: coalesced).  Only
+  // the remaining elements (biases, S3, dW1, statistics: PW - 4 096) go through the image rounds below.  rl.oG == 0.
+#ifndef ORL_EPI_FRAG
+#define ORL_EPI_FRAG 1
+#endif
+  constexpr int GN = HID * HID;
+  // (small-observation builds only: with wide observations / heads the remaining elements are ~1 900 per row and their image
+  // rounds double next to 128 KB of fragment images - measured no gain at the cfg3 / cfg5 shapes, - 2 % of the launch at a
+  // 512-env shard of configuration 2, profiles/r05_experiments.md)
+  const bool frag_g = ORL_EPI_FRAG && SPW && ND == 0 && nwv <= NREG_MAX && lds_have >= nwv * GN + (PW - GN);
+  const int PWI = frag_g ? PW - GN : PW;   // floats per image of the rounds below
+  const int IOFF = frag_g ? GN : 0;        // row element e lives at image offset e - IOFF
+  float* gimg = smem;                      // frag_g: nwv fragment images of G
+  float* img0 = smem + (frag_g ? nwv * GN : 0);
+  int NREG = (lds_have - (frag_g ? nwv * GN : 0)) / PWI;
   NREG = NREG > nwv ? nwv : NREG < 1 ? 1 : NREG;
   NREG = NREG > NREG_MAX ? NREG_MAX : NREG;
   while (nwv % NREG) --NREG;
   // only the statistics tail has slots no wave writes: zero it in every image, the rest is written by round 0
   for (int e = threadIdx.x; e < NREG * ORL_N_STATS; e += blockDim.x)
-    img0[(size_t)(e / ORL_N_STATS) * PW + rl.total + (e % ORL_N_STATS)] = 0.f;
+    img0[(size_t)(e / ORL_N_STATS) * PWI + rl.total - IOFF + (e % ORL_N_STATS)] = 0.f;
+  if constexpr (SPW) {
+    if (frag_g) {
+      float* gw = gimg + (size_t)wave * GN + l * 4;
+#pragma unroll
+      for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+            *(f32x4*)(gw + ((bo * 2 + bi) * 4 + rq) * 256) = f32x4{GS[bo][bi][4 * rq], GS[bo][bi][4 * rq + 1],
+                                                                   GS[bo][bi][4 * rq + 2], GS[bo][bi][4 * rq + 3]};
+    }
+  }
   __syncthreads();
   st_active = wave_sum(st_active); st_rows = wave_sum(st_rows); st_loss = wave_sum(st_loss);
   st_ent = wave_sum(st_ent); st_ratio = wave_sum(st_ratio);
@@ -1048,7 +1078,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     }
   }
 #endif
-  float* acc = img0 + (size_t)(wave % NREG) * PW;
+  float* acc = img0 + (size_t)(wave % NREG) * PWI - IOFF;  // (indexed with row positions >= IOFF only)
   for (int p = 0; p < nwv / NREG; ++p) {
     if (wave / NREG == p) {
       const bool first = p == 0;
@@ -1064,7 +1094,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         auto g_idx = [&](int bo, int bi, int r) {
           return rl.oG + (32 * bo + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * HID + 32 * bi + (l & 31);
         };
-        if (first) {
+        if (frag_g) {
+          // (G went out in fragment order above)
+        } else if (first) {
 #pragma unroll
           for (int bo = 0; bo < 2; ++bo)
 #pragma unroll
@@ -1200,13 +1232,30 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   if (prof_on && l == 18) atomicAdd(&g_orl_prof[18], __builtin_readcyclecounter() - t_loop1);  // ... + the accumulator images
 #endif
   float* out = A.partials + (size_t)bid * PW;
+  if (frag_g) {
+    // chunk k = (register quad Rq = k >> 6, lane ln = k & 63) of the fragment images: the quad's registers 4 Rq .. + 3 of block
+    // (bo, bi) = (Rq >> 3, (Rq >> 2) & 1) stand for rows 32 bo + 8 (Rq & 3) + 4 (ln >> 5) + 0 .. 3, column 32 bi + (ln & 31)
+    for (int k = threadIdx.x; k < GN / 4; k += blockDim.x) {
+      const int Rq = k >> 6, ln = k & 63;
+      f32x4 v[NREG_MAX];
+#pragma unroll
+      for (int w = 0; w < NREG_MAX; ++w)
+        v[w] = w < nwv ? *(const f32x4*)(gimg + (size_t)w * GN + Rq * 256 + ln * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 t = v[0];
+#pragma unroll
+      for (int w = 1; w < NREG_MAX; ++w) t += v[w];  // wave order; + 0 for a wave that is not there
+      const int o0 = 32 * (Rq >> 3) + 8 * (Rq & 3) + 4 * (ln >> 5), i = 32 * ((Rq >> 2) & 1) + (ln & 31);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) out[(o0 + rr) * HID + i] = t[rr];
+    }
+  }
   // all images of an element are requested together and summed in image order (the rolled form was NREG dependent LDS round
   // trips per element: 6 500 of the epilogue's 12 600 cycles at configuration 2)
 #pragma unroll 2
-  for (int e = threadIdx.x; e < PW; e += blockDim.x) {
+  for (int e = IOFF + threadIdx.x; e < PW; e += blockDim.x) {
     float v[NREG_MAX];
 #pragma unroll
-    for (int g = 0; g < NREG_MAX; ++g) v[g] = g < NREG ? img0[(size_t)g * PW + e] : 0.f;
+    for (int g = 0; g < NREG_MAX; ++g) v[g] = g < NREG ? img0[(size_t)g * PWI + e - IOFF] : 0.f;
     float t = v[0];
 #pragma unroll
     for (int g = 1; g < NREG_MAX; ++g) t += v[g];  // + 0.f for an image that is not there

@@ -1360,6 +1360,30 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
     grid_rc = (wc.n_tiles + 3) / 4;
     if (grid_rp > RNN_ROW_BLOCKS / 2) grid_rp = RNN_ROW_BLOCKS / 2;
     if (grid_rc > RNN_ROW_BLOCKS / 2) grid_rc = RNN_ROW_BLOCKS / 2;
+    // Both towers capped at half of the CUs: the split follows the towers' cost per tile and minimises the later tower's
+    // finish in whole rounds of tiles (as launch_pair_nd does for the feed-forward pair).  A policy tile with a wide head
+    // (MFMA head + distributed loss) costs ~1.1 critic tiles: at cfg4 (4 800 tiles per tower) 136 / 120 workgroups =
+    // 9 policy rounds against 10 critic rounds instead of 10 / 10 - 0.728 -> 0.718 ms per epoch in two alternations
+    // (profiles/r05_experiments.md; 120 / 136 and 124 / 132 measured no better than even).
+    if (l2 && grid_rp == RNN_ROW_BLOCKS / 2 && grid_rc == RNN_ROW_BLOCKS / 2) {
+#ifdef ORL_RNN_L2_GRID_P  // build-time experiment: a fixed split
+      grid_rp = ORL_RNN_L2_GRID_P;
+#else
+      const double w_p = (pnet->head_kind == ORL_HEAD_CATEGORICAL && no > 4) ? 1.10 : 1.0;
+      double best = 1e30;
+      for (int d = 0; d <= RNN_ROW_BLOCKS / 4; ++d) {  // nearest to an even split first: ties keep it
+        for (int sgn = 1; sgn >= -1; sgn -= 2) {
+          const int g = RNN_ROW_BLOCKS / 2 + sgn * d;
+          const double tp = (double)((wp.n_tiles + 4 * g - 1) / (4 * g)) * w_p;
+          const double tc = (double)((wc.n_tiles + 4 * (RNN_ROW_BLOCKS - g) - 1) / (4 * (RNN_ROW_BLOCKS - g)));
+          const double t = tp > tc ? tp : tc;
+          if (t < best - 1e-9) { best = t; grid_rp = g; }
+          if (d == 0) break;
+        }
+      }
+#endif
+      grid_rc = RNN_ROW_BLOCKS - grid_rp;
+    }
   }
   if (l2) {
     if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
