@@ -155,12 +155,12 @@ def test_model_dict_accepts_the_stock_network_classes_and_refuses_foreign_ones()
 
 
 def test_committed_bench_line_carries_the_contract_fields():
-    """profiles/r04_bench_line.json is what `python bench.py` printed on an MI355X for the final tree: the fields the
+    """profiles/r05_bench_line.json is what `python bench.py` printed on an MI355X for the final tree: the fields the
     driver's contract names are all there, typed, and consistent with each other (a schema check - no GPU needed)."""
     import json
     import os
 
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_bench_line.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_bench_line.json")
     line = json.load(open(path))
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
@@ -179,3 +179,10 @@ def test_committed_bench_line_carries_the_contract_fields():
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == line["unit"]
     assert isinstance(c["sample"], str) and c["sample"]
+    # round 5: every other_configs entry prices its dominant launch (flops per launch, fraction of the fp32 MFMA peak)
+    for o in line.get("other_configs", []):
+        if "error" in o:
+            continue
+        assert "flops_fwd_per_row_both_towers" in o and "flops_per_launch" in o and "frac" in o, o.get("workload")
+        if o["flops_per_launch"] is not None:
+            assert abs(o["frac"] - o["flops_per_launch"] / (o["dominant_kernel_ms"] * 1e-3) / 157.3e12) < 2e-3
