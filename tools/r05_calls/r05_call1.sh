@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Round 5, GPU call 1 (gpurun --timeout 1500 -- 'bash tools/r05_call1.sh'): dot2c split probe, same-box A/B of the tower
+# Round 5, GPU call 1 (gpurun --timeout 1500 -- 'bash tools/r05_calls/r05_call1.sh'): dot2c split probe, same-box A/B of the tower
 # variants, LDS bank-conflict counters per image stride, parity tests of the touched kernels.
 set -u
 export ORL_KEEP_BUILD=1
