@@ -60,6 +60,9 @@ __device__ unsigned long long g_orl_prof[24];
 #define ORL_T(k) ((void)0)
 #endif
 
+#ifndef ORL_WGRAD_HALVES
+#define ORL_WGRAD_HALVES 1
+#endif
 #ifndef ORL_HMM_XH2_RELOAD
 #define ORL_HMM_XH2_RELOAD 0   // build-time experiment (round 5): no fewer spilled registers (20 / 29 either way) - off
 #endif
@@ -781,8 +784,11 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       // columns 32b + c of both slabs (32 conflict-free 4-byte reads, as many as the fp32 path), splits them in
       // registers and issues 6 products x 4 blocks = 24 MFMAs.  db2 falls out of the same reads.
       const int c = l & 31, kb = l >> 5;
-#ifdef ORL_WGRAD_HALVES
-      // build-time experiment (round 5, three waves per SIMD): the dz2 fragments of ONE 32-row block at a time - 12 registers less
+#if ORL_WGRAD_HALVES
+      // round 5: the dz2 fragments of ONE 32-row block at a time - 12 registers less at the kernel's pressure peak.  The wide
+      // builds (256 registers, wide head + MFMA dW1) spill 10 / 19 registers instead of 20 / 27 with it and every scratch reload
+      // of a tile waits vmcnt(0) behind the record DMA: cfg3 pair 0.1448 / 0.1437 / 0.1503 -> 0.1382 / 0.1392 / 0.1388 ms, cfg5
+      // 0.4627 / 0.4670 / 0.4631 -> 0.4450 / 0.4487 / 0.4441 ms, cfg2 unchanged (three alternations, profiles/r05_experiments.md)
       {
         u32x4 fb[2][3];
 #pragma unroll
@@ -831,6 +837,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         split8(xb, fb[b][0], fb[b][1], fb[b][2]);
       }
       ORL_PRIO2(1);
+#ifdef ORL_IGLP_WGRAD  // build-time experiment (round 5): let hipcc's IGroupLP pipeline the splits under the MFMAs of this block
+      __builtin_amdgcn_iglp_opt(ORL_IGLP_WGRAD);
+#endif
 #pragma unroll
       for (int bo = 0; bo < 2; ++bo)
 #pragma unroll
