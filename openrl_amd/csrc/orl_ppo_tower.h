@@ -60,6 +60,9 @@ __device__ unsigned long long g_orl_prof[24];
 #define ORL_T(k) ((void)0)
 #endif
 
+#ifndef ORL_DMA_LATE
+#define ORL_DMA_LATE 0
+#endif
 #ifndef ORL_WGRAD_HALVES
 #define ORL_WGRAD_HALVES 1
 #endif
@@ -339,10 +342,12 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     // Order matters: the index prefetch (a load hipcc counts) is re-issued BEFORE the DMA (which it cannot see).  The
     // other way round, hipcc's own "previous load into these registers must have landed" wait sits behind the DMA
     // and drains it.
+#if !ORL_DMA_LATE
     const long long row_cur = row_next;
     row_next = row_of(tile + 2 * n_waves);
     issue_dma(RR + (ring ^ 1) * rts, row_cur);        // next tile's records, hidden behind this tile
     ring ^= 1;
+#endif
     // column -> ring position: observation columns live in range 0 (ring chunk = record chunk - c0_beg), every other field
     // in range 1 (ring chunk = record chunk - c1_beg + c0_n); both biases fold into the base pointer.  ND == 0: identity.
     const float* RTX = ND == 0 ? RT : RT - 64 * A.c0_beg;
@@ -686,6 +691,17 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     }
 
     ORL_T(4);  // loss
+#if ORL_DMA_LATE
+    // build-time experiment (round 5): the next tile's records are requested HERE, behind the loss phase, instead of at the top
+    // of the tile - a scratch reload of the spilling wide builds (fc1 and loss phases) then never waits vmcnt(0) behind a DMA
+    // that has just been issued; ~10 000 cycles of the tile remain for the records to land
+    {
+      const long long row_cur = row_next;
+      row_next = row_of(tile + 2 * n_waves);
+      issue_dma(RR + (ring ^ 1) * rts, row_cur);
+      ring ^= 1;
+    }
+#endif
     // ---------------- backward ----------------
     // S3 += dhead^T xhat2, db3 (F layout: lane = feature f); xhat2 comes from the scratch slab
     if constexpr (HMM) {
