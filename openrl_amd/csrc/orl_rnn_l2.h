@@ -28,6 +28,12 @@
 
 namespace orl {
 
+// ORL_RNN_L2_OSPLIT (build-time switch): the kernel's 25 GEMMs per tile on the bf16 MFMA with the fp32 LDS images split on the fly
+// (orl_rnn.h: mm64_S_osplit / mm64_S_wt_osplit) instead of v_mfma_f32_16x16x4_f32
+#ifndef ORL_RNN_L2_OSPLIT
+#define ORL_RNN_L2_OSPLIT 0
+#endif
+
 // what one step of one 16-chunk tile reads from global memory (requested a tile ahead)
 struct Row2In {
   f32x4 xo[4];        // observation columns 16m + 4q .. + 3 of this lane's row (0 beyond D): fc1's B operands AND the tape tile
@@ -147,7 +153,15 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     ln_normalize_T(xh1, rstd1);
     ln_affine_T(xh1, lw + tw.g1, lw + tw.be1, q, n1);
     load_vec_T(lw + tw.b2, q, xh2);
+#if ORL_RNN_L2_OSPLIT
+    {
+      u32x4 xs[2][3];
+      split_T(n1, xs);
+      mm64_S_osplit<W2S>(lw + tw.W2, xs, xh2, j, q);
+    }
+#else
     mm64_T(lw + tw.W2, n1, xh2, j, q);
+#endif
     ln_normalize_T(xh2, rstd2);
     ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, n2);
   };
@@ -261,15 +275,35 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     f32x4 d2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) d2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if ORL_RNN_L2_OSPLIT
+    {
+      u32x4 xs[2][3];
+      split_T(gr, xs);
+      mm64_S_wt_osplit<W2S>(lw + tw.Wih, xs, d2, j, q);
+      split_T(gz, xs);
+      mm64_S_wt_osplit<W2S>(lw + tw.Wih + HID * W2S, xs, d2, j, q);
+      split_T(gn, xs);
+      mm64_S_wt_osplit<W2S>(lw + tw.Wih + 2 * HID * W2S, xs, d2, j, q);
+    }
+#else
     mm64_S_wt<W2S>(lw + tw.Wih, gr, d2, j, q);
     mm64_S_wt<W2S>(lw + tw.Wih + HID * W2S, gz, d2, j, q);
     mm64_S_wt<W2S>(lw + tw.Wih + 2 * HID * W2S, gn, d2, j, q);
+#endif
     ln_bwd_rnn(d2, xh2, lw + tw.g2, rstd2, q);
     tape_store(tb + TV_DZ2 * TV, d2, j, q);
     f32x4 d1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if ORL_RNN_L2_OSPLIT
+    {
+      u32x4 xs[2][3];
+      split_T(d2, xs);
+      mm64_S_wt_osplit<W2S>(lw + tw.W2, xs, d1, j, q);
+    }
+#else
     mm64_S_wt<W2S>(lw + tw.W2, d2, d1, j, q);
+#endif
     ln_bwd_rnn(d1, xh1, lw + tw.g1, rstd1, q);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -355,7 +389,11 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       tape_store(tb0 + TV_XH1 * TV, xh1_0, j, q);
       tape_store(tb0 + TV_XH2 * TV, xh2_0, j, q);
       RNN_T(2);  // trunk (fc1 + 64 MFMA) + tape stores
+#if ORL_RNN_L2_OSPLIT
+      gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
+#else
       gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
+#endif
       RNN_T(3);  // GRU forward: 384 MFMA + gates
       head_loss(h1, In0, valid, tb0, dt0);
       RNN_T(4);  // LN3, head, loss, W3^T dhead, LN3'
@@ -377,16 +415,32 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
         tape_store(tb1 + TV_XH1 * TV, xh1_1, j, q);
         tape_store(tb1 + TV_XH2 * TV, xh2_1, j, q);
         RNN_T(2);
+#if ORL_RNN_L2_OSPLIT
+        gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
+#else
         gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
+#endif
         RNN_T(3);
         head_loss(h2, In1, valid, tb1, dt1);
         RNN_T(4);
       }
       gate_bwd(dt1, hin1, gr, gz, gn, ghn, carry, tb1);
       RNN_T(6);  // GRU element-wise backward + 4 tape vectors
+#if ORL_RNN_L2_OSPLIT
+      {
+        u32x4 xs[2][3];
+        split_T(gr, xs);
+        mm64_S_wt_osplit<W2S>(lw + tw.Whh, xs, carry, j, q);
+        split_T(gz, xs);
+        mm64_S_wt_osplit<W2S>(lw + tw.Whh + HID * W2S, xs, carry, j, q);
+        split_T(ghn, xs);
+        mm64_S_wt_osplit<W2S>(lw + tw.Whh + 2 * HID * W2S, xs, carry, j, q);
+      }
+#else
       mm64_S_wt<W2S>(lw + tw.Whh, gr, carry, j, q);
       mm64_S_wt<W2S>(lw + tw.Whh + HID * W2S, gz, carry, j, q);
       mm64_S_wt<W2S>(lw + tw.Whh + 2 * HID * W2S, ghn, carry, j, q);
+#endif
 #pragma unroll
       for (int m = 0; m < 4; ++m) carry[m] = carry[m] * In1.mask;  // h_in = h * mask
       RNN_T(7);  // hidden-state dgrad: 192 MFMA (column reads)
