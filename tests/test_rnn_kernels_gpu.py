@@ -182,3 +182,67 @@ def test_rnn_act_step_large_batch_path_equals_small_batch_path():
     for x, y in ((v1, v2), (l1, l2), (hp1, hp2), (hc1, hc2)):
         torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
     assert (a1 == a2).float().mean() > 0.999 and a1.max() <= K - 1
+
+
+@pytest.mark.parametrize("head,n_out,Dp,Dc,T,lanes", [
+    ("cat", 5, 18, 54, 25, 96),     # cfg4's towers: wide categorical head (MFMA head + distributed loss), Dict obs
+    ("cat", 2, 4, 4, 9, 37),        # narrow categorical head with action masks, ragged tile (166 chunks)
+    ("box", 3, 11, 11, 7, 50),      # Gaussian head (per-dimension record columns are read through the fallback)
+])
+def test_l2_row_kernel_equals_the_recompute_kernel(head, n_out, Dp, Dc, T, lanes):
+    """Round 5: with data_chunk_length == 2 orl_rnn_ppo_fwd_bwd runs the register-resident row kernel (csrc/orl_rnn_l2.h,
+    hparams.reserved == 0); reserved & 4 forces the forward-sweep + recompute kernel of rounds 1 - 4.  Same inputs (random
+    buffers, stored states, 10 % zero masks, a shuffled chunk order, a chunk count that does not fill the last tile) -> the
+    same raw sums: every weight-gradient sum, bias sum, dlogstd and the statistics row, up to fp32 summation order."""
+    from openrl_amd import ops, ops_rnn
+    from openrl_amd.configs.config import default_cfg
+
+    L = 2
+    rs = np.random.RandomState(11)
+    a_w = 1 if head == "cat" else n_out
+    K = n_out if head == "cat" else 0
+    pnet = ops.net_desc(Dp, n_out, ops.HEAD_CATEGORICAL if head == "cat" else ops.HEAD_GAUSSIAN)
+    cnet = ops.net_desc(Dc, 1, ops.HEAD_VALUE)
+    M = T * lanes
+    R = ops.record_width(Dp, Dc, a_w, K)
+    rec = np.zeros((M, R), np.float32)
+    o = 0
+    rec[:, o:o + Dp] = rs.randn(M, Dp); o += Dp
+    rec[:, o:o + Dc] = rs.randn(M, Dc); o += Dc
+    rec[:, o:o + a_w] = rs.randint(0, n_out, (M, 1)) if head == "cat" else rs.randn(M, a_w); o += a_w
+    rec[:, o:o + a_w] = np.log(1.0 / max(n_out, 2)) + 0.1 * rs.randn(M, a_w); o += a_w
+    rec[:, o] = rs.randn(M); o += 1                       # advantage
+    rec[:, o] = 0.3 * rs.randn(M); o += 1                 # value prediction
+    rec[:, o] = 0.5 * rs.randn(M); o += 1                 # return
+    rec[:, o] = (rs.rand(M) > 0.05).astype(np.float32); o += 1   # active mask
+    if K:
+        am = (rs.rand(M, K) > 0.3).astype(np.float32)
+        am[np.arange(M), rec[:, Dp + Dc].astype(int)] = 1.0    # the taken action is legal
+        rec[:, o:o + K] = am
+    masks = (rs.rand(T + 1, lanes) > 0.1).astype(np.float32)
+    h_p, h_c = 0.4 * rs.randn(T + 1, lanes, 64).astype(np.float32), 0.4 * rs.randn(T + 1, lanes, 64).astype(np.float32)
+    n_chunks = M // L
+    chunks = rs.permutation(n_chunks)
+    rows = torch.zeros(L * n_chunks, dtype=torch.int64, device=DEV)
+    ops_rnn.rnn_chunk_rows(_t(chunks, torch.int64), n_chunks, L, T, lanes, rows)
+    thp = _t(0.15 * rs.randn(ops_rnn.rnn_param_count(pnet)))
+    thc = _t(0.15 * rs.randn(ops_rnn.rnn_param_count(cnet)))
+    vn_state = _t(np.array([0.1, 0.5, 1.0], np.float32))
+    cfg = default_cfg(["--use_recurrent_policy", "true", "--data_chunk_length", "2"])
+    raw_np, raw_nc = ops_rnn.rnn_raw_grad_count(pnet), ops_rnn.rnn_raw_grad_count(cnet)
+    out = {}
+    for mode in ("fp32", "fp32_recompute"):
+        cfg.amd_rnn_gemm = mode
+        hp = ops.make_hparams(cfg, recurrent=True)
+        assert hp.reserved == (0 if mode == "fp32" else 4)
+        ws = torch.zeros(ops_rnn.rnn_workspace_floats(pnet, cnet, n_chunks, L), device=DEV)
+        sums = torch.zeros(raw_np + raw_nc + 2 * ops.N_STATS, device=DEV)
+        ops_rnn.rnn_ppo_fwd_bwd(pnet, thp, cnet, thc, _t(rec), rows, _t(masks), _t(h_p), _t(h_c), n_chunks, L, vn_state, hp,
+                                ws, sums)
+        out[mode] = sums.cpu().numpy()
+    a, b = out["fp32"], out["fp32_recompute"]
+    assert np.isfinite(a).all() and np.abs(b).max() > 0
+    for lo, hi, name in ((0, raw_np, "policy raw sums"), (raw_np, raw_np + ops.N_STATS, "policy statistics"),
+                         (raw_np + ops.N_STATS, raw_np + ops.N_STATS + raw_nc, "critic raw sums"),
+                         (raw_np + ops.N_STATS + raw_nc, a.size, "critic statistics")):
+        np.testing.assert_allclose(a[lo:hi], b[lo:hi], rtol=2e-4, atol=2e-5 * np.abs(b[lo:hi]).max() + 1e-7, err_msg=name)
