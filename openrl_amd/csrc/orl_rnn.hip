@@ -1064,7 +1064,48 @@ __global__ __launch_bounds__(1024) void rnn_reduce_pair_kernel(const float* __re
   }
 }
 
-static int orl_ppo_reduce_pair2(const float* pa, int nb_a, int wa, float* oa, const float* pb, int nb_b, int wb,
+// Round 5: the four partial regions of a recurrent optimiser step (weight-gradient partials and row-kernel partials of both
+// towers) in ONE launch instead of two launches of rnn_reduce_pair_kernel - same per-column arithmetic and order
+struct RnnReduce4 {
+  const float* p[4];
+  float* o[4];
+  int nb[4], w[4], g0[5];  // g0[k] = first workgroup of region k (g0[4] = grid)
+};
+__global__ __launch_bounds__(1024) void rnn_reduce4_kernel(RnnReduce4 R) {
+  __shared__ float sh[16][64];
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) k = (int)blockIdx.x >= R.g0[i] ? i : k;
+  const float* partials = k == 0 ? R.p[0] : k == 1 ? R.p[1] : k == 2 ? R.p[2] : R.p[3];
+  float* out = k == 0 ? R.o[0] : k == 1 ? R.o[1] : k == 2 ? R.o[2] : R.o[3];
+  const int n_blocks = k == 0 ? R.nb[0] : k == 1 ? R.nb[1] : k == 2 ? R.nb[2] : R.nb[3];
+  const int width = k == 0 ? R.w[0] : k == 1 ? R.w[1] : k == 2 ? R.w[2] : R.w[3];
+  const int gbase = k == 0 ? R.g0[0] : k == 1 ? R.g0[1] : k == 2 ? R.g0[2] : R.g0[3];
+  const int lc = threadIdx.x & 63;
+  const int col = ((int)blockIdx.x - gbase) * 64 + lc;
+  const int rg = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < width) {
+    int b = rg;
+    for (; b + 48 < n_blocks; b += 64) {
+      s0 += partials[(size_t)b * width + col];
+      s1 += partials[(size_t)(b + 16) * width + col];
+      s2 += partials[(size_t)(b + 32) * width + col];
+      s3 += partials[(size_t)(b + 48) * width + col];
+    }
+    for (; b < n_blocks; b += 16) s0 += partials[(size_t)b * width + col];
+  }
+  sh[rg][lc] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && col < width) {
+    float t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = (sh[4 * q][lc] + sh[4 * q + 1][lc]) + (sh[4 * q + 2][lc] + sh[4 * q + 3][lc]);
+    out[col] = (t[0] + t[1]) + (t[2] + t[3]);
+  }
+}
+
+__attribute__((unused)) static int orl_ppo_reduce_pair2(const float* pa, int nb_a, int wa, float* oa, const float* pb, int nb_b, int wb,
                                 float* ob, hipStream_t s) {
   const int ga = (wa + 63) / 64, gb = (wb + 63) / 64;
   hipLaunchKernelGGL(rnn_reduce_pair_kernel, dim3(ga + gb), dim3(1024), 0, s, pa, nb_a, wa, ga, oa, pb, nb_b, wb, ob);
@@ -1428,10 +1469,22 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
   if (rc) return rc;
   // (3) sums of each tower: [raw without logstd | dlogstd | stats]
   float* sums_c = sums + RnnRaw(*pnet).total + ORL_N_STATS;
+#ifdef ORL_RNN_REDUCE_TWO_LAUNCHES  // rounds 1 - 4 (comparison switch)
   rc = orl_ppo_reduce_pair2(Gp.partials, wp.grid_wg, wp.wpw, sums, Gc.partials, wc.grid_wg, wc.wpw, sums_c, s);
   if (rc) return rc;
   return orl_ppo_reduce_pair2(A.partials, grid_rp, wp.rpw, sums + wp.wpw, C2.partials, grid_rc, wc.rpw,
                               sums_c + wc.wpw, s);
+#else
+  RnnReduce4 R;
+  R.p[0] = Gp.partials; R.nb[0] = wp.grid_wg; R.w[0] = wp.wpw; R.o[0] = sums;
+  R.p[1] = Gc.partials; R.nb[1] = wc.grid_wg; R.w[1] = wc.wpw; R.o[1] = sums_c;
+  R.p[2] = A.partials;  R.nb[2] = grid_rp;    R.w[2] = wp.rpw; R.o[2] = sums + wp.wpw;
+  R.p[3] = C2.partials; R.nb[3] = grid_rc;    R.w[3] = wc.rpw; R.o[3] = sums_c + wc.wpw;
+  R.g0[0] = 0;
+  for (int k = 0; k < 4; ++k) R.g0[k + 1] = R.g0[k] + (R.w[k] + 63) / 64;
+  hipLaunchKernelGGL(rnn_reduce4_kernel, dim3(R.g0[4]), dim3(1024), 0, s, R);
+  return launch_status("orl_rnn_ppo_fwd_bwd(reduce)");
+#endif
 }
 
 int orl_rnn_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const float* sums, const orl_ppo_hparams* hp,
