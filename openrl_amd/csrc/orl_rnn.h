@@ -79,11 +79,13 @@ struct RnnLds {
   // with_w3p: W3 zero padded to [16][W2S] - the MFMA operand of the wide categorical head in the row kernel
   // stream: the seven 64 x 64 matrices (W2, Wih, Whh) are NOT resident - the streamed row kernel (orl_rnn_stream.h) pulls
   // their bf16 images through a ring behind `total`
-  __host__ __device__ RnnLds(int D, int n_out, bool gaussian, bool with_w3p = false, bool stream = false) {
+  // no_w1: W1 is not resident either (the cooperative rollout's critic holds its 16 rows of W1 in registers)
+  __host__ __device__ RnnLds(int D, int n_out, bool gaussian, bool with_w3p = false, bool stream = false,
+                             bool no_w1 = false) {
     DP = (D + 3) & ~3;
     const int no4 = (n_out + 3) & ~3;
     int o = 0;
-    W1 = o; o += HID * DP;
+    W1 = o; o += no_w1 ? 0 : HID * DP;
     b1 = o; o += HID;
     g1 = o; o += HID;
     be1 = o; o += HID;
@@ -107,7 +109,7 @@ struct RnnLds {
 
 __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __restrict__ theta, const RnnLayout& tl,
                                        const RnnLds& tw, int tid, int nthreads, bool with_w3p = false,
-                                       bool stream = false) {
+                                       bool stream = false, bool no_w1 = false) {
   const int D = tl.D;
   if (with_w3p) {
     for (int e = tid; e < 16 * W2S; e += nthreads) {
@@ -115,7 +117,7 @@ __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __r
       lds[tw.W3P + e] = (c < tl.n_out && i < HID) ? theta[tl.oW3 + c * HID + i] : 0.f;
     }
   }
-  for (int e = tid; e < HID * tw.DP; e += nthreads) {
+  for (int e = tid; e < (no_w1 ? 0 : HID * tw.DP); e += nthreads) {
     const int f = e / tw.DP, k = e - f * tw.DP;
     lds[tw.W1 + e] = (k < D) ? theta[tl.oW1 + f * D + k] : 0.f;
   }

@@ -371,6 +371,11 @@ __global__ __launch_bounds__(192, 1) void rnn_rollout_mpe_chase_kernel(RnnRollou
   else rnn_rollout_critic_body<true>(A, bid, (int)gridDim.x >> 1);
 }
 
+#ifndef ORL_RNN_ROLLOUT_COOP
+#define ORL_RNN_ROLLOUT_COOP 1  // 1: four cooperating waves per tile (round 5, default); 0: one wave per tile (rounds 3 - 4)
+#endif
+#include "orl_rnn_rollout_coop.h"
+
 }  // namespace orl
 
 using namespace orl;
@@ -461,6 +466,34 @@ int orl_rnn_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const o
   const size_t lds_c = (size_t)(twc.total + 3 * TILE_B * 64) * sizeof(float);
   ORL_REQUIRE(lds_p <= 160 * 1024 && lds_c <= 160 * 1024, "orl_rnn_rollout_fused: tower image exceeds the LDS");
   const int n_groups = (b.N + TILE_B - 1) / TILE_B;
+#if ORL_RNN_ROLLOUT_COOP
+  {
+    const RnnLds twc2(MPE_COBS, 1, false, false, false, true);
+    const size_t lp = lds_p + (size_t)(MPE_A * 2 * XCH + 4) * sizeof(float);  // + exchange buffers and counters
+    const size_t lc = (size_t)(twc2.total + 3 * 2 * XCH + 4) * sizeof(float);
+    ORL_REQUIRE(lp <= 160 * 1024 && lc <= 160 * 1024, "orl_rnn_rollout_fused: tower image exceeds the LDS");
+    if (a->sync_flags != nullptr) {
+      if (hipMemsetAsync(a->sync_flags, 0, (size_t)n_groups * sizeof(int), s) != hipSuccess)
+        return fail(ORL_E_INVALID, "orl_rnn_rollout_fused: clearing the step counters failed");
+      const size_t lds = lp > lc ? lp : lc;
+      (void)hipFuncSetAttribute((const void*)rnn_rollout_mpe_chase_coop_kernel<8>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((rnn_rollout_mpe_chase_coop_kernel<8>), dim3(2 * n_groups), dim3(COOP_THREADS), lds, s, A);
+      return launch_status("orl_rnn_rollout_fused(chase)");
+    }
+    (void)hipFuncSetAttribute((const void*)rnn_rollout_mpe_policy_coop_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lp);
+    hipLaunchKernelGGL((rnn_rollout_mpe_policy_coop_kernel<8>), dim3(n_groups), dim3(COOP_THREADS), lp, s, A);
+    const int rc = launch_status("orl_rnn_rollout_fused(policy)");
+    if (rc) return rc;
+    (void)hipFuncSetAttribute((const void*)rnn_rollout_critic_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
+    const int n_tiles = (b.N * b.A + TILE_B - 1) / TILE_B;
+    int grid = (n_tiles + 2) / 3;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(rnn_rollout_critic_coop_kernel, dim3(grid), dim3(COOP_THREADS), lc, s, A);
+    return launch_status("orl_rnn_rollout_fused(critic)");
+  }
+#endif
   if (a->sync_flags != nullptr) {  // one launch, critic workgroups chase their policy workgroups
     // only the n_groups step counters are cleared: the error word flags[n_groups] is STICKY (caller-zeroed once, like
     // orl_comm's) - a timeout in rollout k must still be visible after rollout k + 1 when the host polls late
