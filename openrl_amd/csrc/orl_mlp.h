@@ -801,9 +801,15 @@ __device__ inline int cat_mode(const float (&lg)[NO], int n_out) {
 
 template <int NO>
 __device__ inline float pick(const float (&v)[NO], int a) {
+  // every candidate goes through an opaque copy: hipcc recognises the plain select chain as a table lookup and compiles it to an
+  // INDEXED SCRATCH LOAD of v[] followed by s_waitcnt vmcnt(0) (found in cfg4's rollout, profiles/r05_experiments.md section 8)
   float r = v[0];
 #pragma unroll
-  for (int c = 1; c < NO; ++c) r = (c == a) ? v[c] : r;
+  for (int c = 1; c < NO; ++c) {
+    float x = v[c];
+    asm volatile("" : "+v"(x));
+    r = (c == a) ? x : r;
+  }
   return r;
 }
 

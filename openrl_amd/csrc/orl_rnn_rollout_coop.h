@@ -93,13 +93,44 @@ __device__ __forceinline__ void tile_sync(unsigned* __restrict__ cnt, unsigned& 
 #endif
 }
 
+template <int S>
+__device__ __forceinline__ void mm64_blk2(const float* __restrict__ Wc, const f32x4 (&in)[4], f32x4& a0, f32x4& a1, int j, int q) {
+  f32x4 w[2][2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) w[0][g] = *(const f32x4*)(Wc + g * HID * S + j * S + 4 * q);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    if (mi < 3) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) w[(mi + 1) & 1][g] = *(const f32x4*)(Wc + g * HID * S + j * S + 16 * (mi + 1) + 4 * q);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a0 = ORL_MFMA(w[mi & 1][0][r], in[mi][r], a0);
+      a1 = ORL_MFMA(w[mi & 1][1][r], in[mi][r], a1);
+    }
+  }
+}
+
 // base -> GRU -> LayerNorm of one 16-row tile by four waves (this one = block c).  wa(s) = this lane's fc1 A operand
 // W1[16c + j][4s + q], xb(s) = obs column 4s + q of row j (both 0 beyond D), KS = fc1's k-steps.  xbuf = the tile's two exchange
 // buffers, par = which one the next exchange writes (toggled here: exchange k writes buffer k & 1 after barrier k - 1, which
 // every wave reaches only after its reads of exchange k - 2).  EVERY wave of the workgroup must call this (3 barriers).
-template <int KS, class WA, class XB>
+// gh_n block of this wave for the hidden state hin: b_hn + W_hn[rows 16c + j] * hin - its OWN accumulator in gru_fwd_T, so it
+// can be computed apart from (and before) the rest of a step without changing any sum
+__device__ __forceinline__ f32x4 gru_ghn_blk(const float* __restrict__ lw, const RnnLds& tw, const f32x4 (&hin)[4], int c,
+                                             int j, int q) {
+  f32x4 ag = *(const f32x4*)(lw + tw.bhh + 2 * HID + 16 * c + 4 * q);
+  mm64_blk<W2S>(lw + tw.Whh + 2 * HID * W2S + 16 * c * W2S, hin, ag, j, q);
+  return ag;
+}
+
+// PRE: the caller supplies the gh_n block (gru_ghn_blk of the same hin) - the policy computes it in the idle windows of the
+// previous step
+template <int KS, bool PRE, class WA, class XB>
 __device__ __forceinline__ void rnn_tower_fwd_coop(const float* __restrict__ lw, const RnnLds& tw, WA wa, XB xb,
-                                                   const f32x4 (&hin)[4], f32x4 (&hnew)[4], f32x4 (&n3)[4],
+                                                   const f32x4 (&hin)[4], const f32x4 ghn_pre, f32x4 (&hnew)[4],
+                                                   f32x4 (&n3)[4],
                                                    float* __restrict__ xbuf, int& par, unsigned* __restrict__ cnt,
                                                    unsigned& seq, int* err, int c, int j, int q) {
   const int co = 16 * c + 4 * q;
@@ -132,9 +163,10 @@ __device__ __forceinline__ void rnn_tower_fwd_coop(const float* __restrict__ lw,
     f32x4 ar = *(const f32x4*)(lw + tw.bih + co) + *(const f32x4*)(lw + tw.bhh + co);
     f32x4 az = *(const f32x4*)(lw + tw.bih + HID + co) + *(const f32x4*)(lw + tw.bhh + HID + co);
     f32x4 an = *(const f32x4*)(lw + tw.bih + 2 * HID + co);
-    f32x4 ag = *(const f32x4*)(lw + tw.bhh + 2 * HID + co);
+    f32x4 ag = PRE ? ghn_pre : *(const f32x4*)(lw + tw.bhh + 2 * HID + co);
     mm64_blk3<W2S>(lw + tw.Wih + 16 * c * W2S, n1, ar, az, an, j, q);
-    mm64_blk3<W2S>(lw + tw.Whh + 16 * c * W2S, hin, ar, az, ag, j, q);
+    if (PRE) mm64_blk2<W2S>(lw + tw.Whh + 16 * c * W2S, hin, ar, az, j, q);
+    else mm64_blk3<W2S>(lw + tw.Whh + 16 * c * W2S, hin, ar, az, ag, j, q);
     const f32x4 hc = pick4(hin, c);
     f32x4 hb;
 #pragma unroll
@@ -155,6 +187,12 @@ __device__ __forceinline__ void rnn_tower_fwd_coop(const float* __restrict__ lw,
   ln_affine_T(z, lw + tw.g3, lw + tw.be3, q, n3);
 }
 
+#ifndef ORL_COOP_GHN_EARLY
+#define ORL_COOP_GHN_EARLY 1  // policy: the next step's gh_n GEMM block in the idle windows of this step (head / env phases)
+#endif
+#ifndef ORL_COOP_CRITIC_SHARE
+#define ORL_COOP_CRITIC_SHARE 1  // the critic workgroups build share_obs (= the world's three observations, contiguous in policy_obs)
+#endif                           // and store it; the policy only stores its own observations
 #ifndef ORL_COOP_DBG
 #define ORL_COOP_DBG 0  // timing builds only (results are wrong): 1 no env step, 2 no tower, 4 no observation copies, 8 no head /
 #endif                  // sampler, 16 no critic
@@ -197,7 +235,9 @@ __device__ __forceinline__ void rnn_rollout_policy_body_coop(const RnnRolloutArg
 #pragma unroll
   for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(A.hp + (size_t)row * HID + 16 * m + 4 * q);
   float mk = b.masks[row];
-  const bool world_lane = wv == 0 && q == 0 && ok;
+  // the worlds live on wave 3 (agent 0, block 3): SIMD 3 carries no head wave (those are waves 0, 5, 10 on SIMDs 0, 1, 2)
+  constexpr int ENV_WAVE = 3;
+  const bool world_lane = wv == ENV_WAVE && q == 0 && ok;
   MpeWorld w;
   float est[4] = {0.f, 0.f, 0.f, 0.f};
   if (world_lane) {
@@ -218,6 +258,17 @@ __device__ __forceinline__ void rnn_rollout_policy_body_coop(const RnnRolloutArg
 #endif
   const float* w1row = lw + tw.W1 + (16 * c + j) * tw.DP + q;
 
+#if ORL_COOP_GHN_EARLY
+  f32x4 ghn;
+  {
+    f32x4 hin0[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hin0[m] = h[m] * mk;
+    ghn = gru_ghn_blk(lw, tw, hin0, c, j, q);
+  }
+#else
+  const f32x4 ghn = {0.f, 0.f, 0.f, 0.f};
+#endif
   for (int t = 0; t < T; ++t) {
     f32x4 hin[4], hnew[4], n3[4];
 #pragma unroll
@@ -227,9 +278,14 @@ __device__ __forceinline__ void rnn_rollout_policy_body_coop(const RnnRolloutArg
 #pragma unroll
     for (int m = 0; m < 4; ++m) hnew[m] = hin[m] + xrow[0], n3[m] = hin[m];
 #else
-    rnn_tower_fwd_coop<MPE_KS_P>(
-        lw, tw, [&](int s) -> float { return w1row[4 * s]; }, [&](int s) -> float { return xrow[4 * s]; }, hin, hnew, n3,
-        xbuf, par, s_cnt + ag, seq, err, c, j, q);
+    rnn_tower_fwd_coop<MPE_KS_P, ORL_COOP_GHN_EARLY != 0>(
+        lw, tw, [&](int s) -> float { return w1row[4 * s]; }, [&](int s) -> float { return xrow[4 * s]; }, hin, ghn, hnew,
+        n3, xbuf, par, s_cnt + ag, seq, err, c, j, q);
+#endif
+#if ORL_COOP_GHN_EARLY
+    // the NEXT step's gh_n block on the unmasked h' (rows whose world ends get the bias below: W * 0 adds exact zeros), in this
+    // step's idle windows: now for the waves without a head to compute, behind the actions barrier for the three head waves
+    if (c != ag) ghn = gru_ghn_blk(lw, tw, hnew, c, j, q);
 #endif
     float hd[NO], act_o[NO], lp_o[NO];
 #if ORL_COOP_DBG & 8
@@ -270,6 +326,9 @@ __device__ __forceinline__ void rnn_rollout_policy_body_coop(const RnnRolloutArg
       }
     }
     __syncthreads();  // actions of the 3 agents visible; every wave is done reading this step's observations
+#if ORL_COOP_GHN_EARLY
+    if (c == ag) ghn = gru_ghn_blk(lw, tw, hnew, c, j, q);
+#endif
     if (world_lane) {
       int act[3];
 #pragma unroll
@@ -295,6 +354,9 @@ __device__ __forceinline__ void rnn_rollout_policy_body_coop(const RnnRolloutArg
     }
     __syncthreads();  // next observations, rewards and done flags visible
     mk = s_done[j] != 0.f ? 0.f : 1.f;
+#if ORL_COOP_GHN_EARLY
+    if (mk == 0.f) ghn = *(const f32x4*)(lw + tw.bhh + 2 * HID + 16 * c + 4 * q);
+#endif
 #pragma unroll
     for (int m = 0; m < 4; ++m) h[m] = hnew[m] * mk;
     if (ok) *(f32x4*)(A.hp + ((size_t)(t + 1) * LA + row) * HID + 16 * c + 4 * q) = pick4(h, c);  // this wave's quarter
@@ -312,10 +374,24 @@ __device__ __forceinline__ void rnn_rollout_policy_body_coop(const RnnRolloutArg
       for (int e = threadIdx.x; e < n_here * MPE_A * MPE_OBS; e += blockDim.x) {
         const int jj = e / (MPE_A * MPE_OBS), r = e - jj * (MPE_A * MPE_OBS), i = r / MPE_OBS, k = r - i * MPE_OBS;
         const float v = s_obs[(i * TILE_B + jj) * OBS_S + k];
+#if ORL_COOP_CRITIC_SHARE
+        if (CHASE) st_agent(dp + e, v);  // read by the critic workgroup of this group
+        else dp[e] = v;
+#else
         dp[e] = v;
+#endif
         if (t == T - 1 && A.obs_p_out != nullptr) A.obs_p_out[(size_t)e0 * MPE_A * MPE_OBS + e] = v;
       }
       float* dc = b.critic_obs + ((size_t)(t + 1) * LA + (size_t)e0 * MPE_A) * MPE_COBS;
+#if ORL_COOP_CRITIC_SHARE
+      if (t == T - 1 && A.obs_c_out != nullptr)  // only the env's final share_obs is still written here
+        for (int e = threadIdx.x; e < n_here * MPE_A * MPE_COBS; e += blockDim.x) {
+          const int jj = e / (MPE_A * MPE_COBS), r = e - jj * (MPE_A * MPE_COBS), cc = r % MPE_COBS;
+          const int i2 = cc / MPE_OBS, k = cc - i2 * MPE_OBS;
+          A.obs_c_out[(size_t)e0 * MPE_A * MPE_COBS + e] = s_obs[(i2 * TILE_B + jj) * OBS_S + k];
+        }
+      (void)dc;
+#else
       for (int e = threadIdx.x; e < n_here * MPE_A * MPE_COBS; e += blockDim.x) {
         const int jj = e / (MPE_A * MPE_COBS), r = e - jj * (MPE_A * MPE_COBS), cc = r % MPE_COBS;
         const int i2 = cc / MPE_OBS, k = cc - i2 * MPE_OBS;
@@ -324,6 +400,7 @@ __device__ __forceinline__ void rnn_rollout_policy_body_coop(const RnnRolloutArg
         else dc[e] = v;
         if (t == T - 1 && A.obs_c_out != nullptr) A.obs_c_out[(size_t)e0 * MPE_A * MPE_COBS + e] = v;
       }
+#endif
     }
     if (CHASE) {  // slot t+1 (share_obs, masks) is complete: publish it to the critic workgroup of this group
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -380,7 +457,14 @@ __device__ __forceinline__ void rnn_rollout_critic_body_coop(const RnnRolloutArg
     for (int m = 0; m < 4; ++m) h[m] = *(const f32x4*)(A.hc + (size_t)rr * HID + 16 * m + 4 * q);
     float xv[KS], mk = b.masks[rr];
     auto load_x = [&](int t, float (&x)[KS]) {
+#if ORL_COOP_CRITIC_SHARE
+      // slot 0 is the caller's; later slots are read where the policy workgroup wrote them: the three observations of a world
+      // are contiguous in policy_obs ([world][agent][18]) = the share_obs row of each of its agents
+      const float* xr = t == 0 ? b.critic_obs + (size_t)rr * D + q
+                               : b.policy_obs + ((size_t)t * LA + (size_t)(rr / MPE_A) * MPE_A) * MPE_OBS + q;
+#else
       const float* xr = b.critic_obs + ((size_t)t * LA + rr) * D + q;
+#endif
 #pragma unroll
       for (int s = 0; s < KS; ++s) x[s] = (4 * s + q < D) ? (CHASE && t > 0 ? ld_agent(xr + 4 * s) : xr[4 * s]) : 0.f;
     };
@@ -405,9 +489,9 @@ __device__ __forceinline__ void rnn_rollout_critic_body_coop(const RnnRolloutArg
       f32x4 hin[4], hnew[4], n3[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) hin[m] = h[m] * mk;
-      rnn_tower_fwd_coop<KS>(
-          lw, tw, [&](int s) -> float { return w1r[s]; }, [&](int s) -> float { return xv[s]; }, hin, hnew, n3, xbuf, par,
-          s_cnt + ti, seq, err, c, j, q);
+      rnn_tower_fwd_coop<KS, false>(
+          lw, tw, [&](int s) -> float { return w1r[s]; }, [&](int s) -> float { return xv[s]; }, hin,
+          f32x4{0.f, 0.f, 0.f, 0.f}, hnew, n3, xbuf, par, s_cnt + ti, seq, err, c, j, q);
       float v[1];
       head_T<1>(lw + tw.W3, lw + tw.b3, 1, n3, q, v);
       if (t == T) {
@@ -420,6 +504,14 @@ __device__ __forceinline__ void rnn_rollout_critic_body_coop(const RnnRolloutArg
         load_x(t + 1, xn);
         mkn = ld_agent(b.masks + (size_t)(t + 1) * LA + rr);
       }
+#if ORL_COOP_CRITIC_SHARE
+      if (ok) {  // share_obs of slot t + 1 for the update: k-steps s = c, c + 4, .. from this wave
+        float* dc = b.critic_obs + ((size_t)(t + 1) * LA + row) * D + q;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          if ((s & 3) == c && 4 * s + q < D) dc[4 * s] = xn[s];
+      }
+#endif
 #pragma unroll
       for (int m = 0; m < 4; ++m) h[m] = hnew[m] * mkn;  // rnn_states_critic[dones_env] = 0
       if (ok) *(f32x4*)(A.hc + ((size_t)(t + 1) * LA + row) * HID + 16 * c + 4 * q) = pick4(h, c);

@@ -11,7 +11,7 @@ timeout 900 python -m pytest tests/test_mpe_gpu.py -m gpu -x -q 2>&1 | tail -3 |
 for v in "$@"; do
   cp variants/$v.so openrl_amd/csrc/liborl_hip.so
   echo "== $v" >> $OUT/kstat.txt
-  bash tools/kstat.sh c4_$v python benchmarks/cfg4_mpe_bench.py --steps 3 --warmup 1 2>&1 | grep rollout >> $OUT/kstat.txt
+  bash tools/kstat.sh c4_${v}_$RANDOM python benchmarks/cfg4_mpe_bench.py --steps 3 --warmup 1 2>&1 | grep rollout >> $OUT/kstat.txt
 done
 cat $OUT/kstat.txt
 cp variants/coop.so openrl_amd/csrc/liborl_hip.so
