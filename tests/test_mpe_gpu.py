@@ -223,7 +223,7 @@ def test_chase_error_word_is_sticky_across_rollouts():
         drv._chase_watch.poll(wait=True)
 
 
-@pytest.mark.parametrize("N,chase", [(96, "true"), (50, "true"), (96, "false"), (2048, "true")])
+@pytest.mark.parametrize("N,chase", [(96, "true"), (50, "true"), (96, "false"), (50, "false"), (2048, "true")])
 def test_fused_recurrent_rollout_equals_stepwise_rollout(N, chase):
     """orl_rnn_rollout_fused (policy + MPE world in one launch, critic sweep in a second) against the stepwise
     T x {orl_rnn_act_step, orl_mpe_step, orl_buffer_insert_rnn} rollout: same per-tile arithmetic and Philox counters,
