@@ -679,6 +679,9 @@ __device__ inline float tape_opnd(const float* __restrict__ v, int m, int s, int
   return v[((m * 4 + qq) * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3)];
 }
 
+#ifndef ORL_RNN_WGRAD_REVERSE
+#define ORL_RNN_WGRAD_REVERSE 1
+#endif
 __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArgs Cc, int split) {
   extern __shared__ __attribute__((aligned(16))) float ring[];  // 3 slots of one tape block each
   // blocks [0, split) sweep the policy tower's tape, the rest the critic's (one launch for both)
@@ -722,7 +725,13 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
   const int n_inst = BLK >> 8;                       // 1 KiB DMA instructions per block (BLK is a multiple of 256)
   const int my_inst = (n_inst - wave + 7) >> 3;      // instructions k = wave, wave + 8, ... issued by this wave
   auto issue = [&](int b, int slot) {
+#if ORL_RNN_WGRAD_REVERSE
+    // the tape is walked from its END: the row kernel wrote the high blocks last, so they are what the 256 MiB Infinity Cache
+    // still holds when this kernel starts - read in writing order, the oldest blocks come from HBM and evict the newest on the way
+    const float* src = A.tape + (size_t)(A.n_blocks - 1 - b) * BLK + l * 4;
+#else
     const float* src = A.tape + (size_t)b * BLK + l * 4;
+#endif
     float* dst = ring + (size_t)slot * BLK;
     for (int k = wave; k < n_inst; k += 8)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 256),
