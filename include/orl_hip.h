@@ -582,9 +582,11 @@ int orl_rnn_ppo_apply(const orl_net_desc* pnet, const orl_net_desc* cnet, const 
 /* OnPolicyDriver.actor_rollout (openrl/drivers/onpolicy_driver.py:154-233) of a recurrent policy on a device-resident
  * multi-agent env, fused: policy + env workgroups step all T = buf.T steps (hidden states in registers, worlds stepped
  * in-kernel like orl_mpe_step, every per-step buffer field written from the kernel incl. masks[t+1] and
- * rnn_states[dones_env] = 0 of add2buffer, :80-152), critic workgroups sweep the stored share_obs and fill
+ * rnn_states[dones_env] = 0 of add2buffer, :80-152), critic workgroups sweep share_obs and fill
  * value_preds[0..T), rnn_states_critic[1..T] and `next_value` (the bootstrap value compute_returns needs, :205-233) -
- * in the same launch when `sync_flags` is given, as a second launch otherwise.
+ * in the same launch when `sync_flags` is given, as a second launch otherwise.  On ORL_ENV_MPE_SPREAD share_obs of slots 1..T
+ * (the concatenation of a world's three observations, envs/mpe/environment.py) is read by the critic workgroups from the world's
+ * three contiguous rows of policy_obs and WRITTEN by them to critic_obs; slot 0 of critic_obs is the caller's.
  * Reads slot 0 of obs / masks / rnn_states* (ReplayData.after_update / init_buffer put them there).  Same per-row
  * arithmetic and Philox counters (act_seed, row, rng_step0 + t [+ *rng_step_dev]) as T x {orl_rnn_act_step,
  * orl_mpe_step, orl_buffer_insert_rnn}.  Built for env_kind ORL_ENV_MPE_SPREAD (3 agents, obs 18 / 54, Discrete(5)). */
@@ -606,8 +608,9 @@ typedef struct orl_rnn_rollout_args {
   const uint64_t* rng_step_dev; /* optional device-side addend of rng_step0 (see orl_act_step) */
   int32_t* sync_flags;       /* optional [ceil(N/16) + 1] int32 scratch: with it the critic workgroups run in the SAME
                               * launch, one step behind their policy workgroups (per-group step counters, cleared by every
-                              * call; the last word is set to 1 if a critic's bounded wait ever timed out - STICKY: the
-                              * caller zeroes it once and it is never cleared here); NULL = two launches */
+                              * call; the last word is set to 1 if a critic's bounded wait - or a bounded wait between the
+                              * four waves that share a 16-row tile - ever timed out - STICKY: the caller zeroes it once and it
+                              * is never cleared here); NULL = two launches */
   uint64_t env_step0;        /* ORL_ENV_SYNTH / ORL_ENV_CARTPOLE (single agent, A == 1, one shared observation array; then
                               * world_length = the episode limit, env_state as orl_env_reset leaves it, sync_flags unused):
                               * the env's global step at the first rollout step */
