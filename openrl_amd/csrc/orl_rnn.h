@@ -415,8 +415,8 @@ __device__ inline void rnn_tower_fwd_lds(const float* __restrict__ lw, const Rnn
 // ---- wgrad tape ---------------------------------------------------------------------------------------------
 // One block per (tile, step): 10 activation vectors of 16 rows x 64 features, the head deltas (16 x 16) and the
 // observation tile (16 x 16*ND).  Element (row, feature f = 16m + 4qq + r) of a 64-wide vector sits at float
-//     ((m*4 + qq)*16 + ((row + 4*qq) & 15))*4 + r
-// i.e. the writer's own register layout with the 16 rows of each qq group rotated by 4*qq: the row kernel's
+//     ((m*4 + qq)*16 + ((row + rot(m*4 + qq)) & 15))*4 + r          (tape_off below)
+// i.e. the writer's own register layout with the 16 rows of each 4-feature group rotated: the row kernel's
 // stores stay 1 KiB-contiguous per m, and the wgrad kernel's 4-byte MFMA operand reads (16 consecutive features
 // x 4 rows per instruction) fall on 32 distinct LDS banks.
 constexpr int TV = 1024;  // floats per 64-wide vector
@@ -425,9 +425,23 @@ constexpr int TAPE_HEAD = TV_NVEC * TV;  // head deltas: 256 floats
 constexpr int TAPE_X = TAPE_HEAD + 256;  // observation m-blocks: ND * 256 floats
 __host__ __device__ inline int tape_block_floats(int D) { return TAPE_X + ((D + 15) >> 4) * 256; }
 
+// Round 5: the rotation of 4-feature group g is g & 7 instead of 4 * (g & 3).  The wgrad kernel's bf16 operand reads take 8 rows of
+// 32 consecutive features (8 groups) x 2 row halves per instruction: with 4 * (g & 3) they fell on 32 of the 64 LDS banks (2-way
+// conflict, SQ_LDS_BANK_CONFLICT 3.7 x SQ_ACTIVE_INST_LDS in profiles/r05_pmc_rnn.txt), with g & 7 the 16 (group, half) pairs
+// take 16 different row slots = all 64 banks.  Its fp32-MFMA operand reads (tape_opnd) then walk rows s, s+4, s+8, s+12 per
+// k-step instead of 4s .. 4s+3 (tape_krow: 4q + qq is again a bijection onto the 16 slots).  -DORL_TAPE_ROT8=0: rounds 2 - 4.
+#ifndef ORL_TAPE_ROT8
+#define ORL_TAPE_ROT8 1
+#endif
+__host__ __device__ constexpr int tape_rot(int g) { return ORL_TAPE_ROT8 ? (g & 7) : 4 * (g & 3); }
+// float offset of (group g, row) inside a 64-wide vector (g = 4m + qq) or a 16-wide block (head deltas, observation m-blocks: g = qq)
+__host__ __device__ constexpr int tape_off(int g, int row) { return (g * 16 + ((row + tape_rot(g)) & 15)) * 4; }
+// the row lane q supplies at k-step s of a 16x16x4 operand read (any fixed bijection of the 16 rows serves both operands alike)
+__host__ __device__ constexpr int tape_krow(int s, int q) { return ORL_TAPE_ROT8 ? s + 4 * q : 4 * s + q; }
+
 __device__ inline void tape_store(float* __restrict__ v, const f32x4 (&x)[4], int j, int q) {
 #pragma unroll
-  for (int m = 0; m < 4; ++m) *(f32x4*)(v + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4) = x[m];
+  for (int m = 0; m < 4; ++m) *(f32x4*)(v + tape_off(m * 4 + q, j)) = x[m];
 }
 
 }  // namespace orl

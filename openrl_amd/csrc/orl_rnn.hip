@@ -509,7 +509,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
           for (int c = 0; c < NO; ++c)
             if ((c >> 2) == q) dv[c & 3] = dh[c];
         }
-        *(f32x4*)(tb + TAPE_HEAD + (q * 16 + ((j + 4 * q) & 15)) * 4) = dv;
+        *(f32x4*)(tb + TAPE_HEAD + tape_off(q, j)) = dv;
       }
       // observation tile -> tape
       for (int m = 0; m < ND; ++m) {
@@ -519,7 +519,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
           const int f = 16 * m + 4 * q + r;
           xv[r] = f < D ? rec[A.o_x + f] : 0.f;
         }
-        *(f32x4*)(tb + TAPE_X + m * 256 + (q * 16 + ((j + 4 * q) & 15)) * 4) = xv;
+        *(f32x4*)(tb + TAPE_X + m * 256 + tape_off(q, j)) = xv;
       }
       // d(features) = W3^T dhead, LN3 backward, + gradient carried from step s+1
       f32x4 dt[4];
@@ -543,7 +543,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
       {
         f32x4 xh3[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xh3[m] = *(const f32x4*)(tb + TV_XH3 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        for (int m = 0; m < 4; ++m) xh3[m] = *(const f32x4*)(tb + TV_XH3 * TV + tape_off(m * 4 + q, j));
         ln_bwd_rnn(dt, xh3, lw + tw.g3, rstd3, q);
       }
 #pragma unroll
@@ -590,7 +590,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
         asm volatile("" : "+v"(tbr));
         f32x4 xh2[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xh2[m] = *(const f32x4*)(tbr + TV_XH2 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        for (int m = 0; m < 4; ++m) xh2[m] = *(const f32x4*)(tbr + TV_XH2 * TV + tape_off(m * 4 + q, j));
         ln_bwd_rnn(d2, xh2, lw + tw.g2, rstd2, q);
       }
       tape_store(tb + TV_DZ2 * TV, d2, j, q);
@@ -604,7 +604,7 @@ __device__ __forceinline__ void rnn_row_body(const RnnRowArgs& A, const int bid,
         asm volatile("" : "+v"(tbr));
         f32x4 xh1[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xh1[m] = *(const f32x4*)(tbr + TV_XH1 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        for (int m = 0; m < 4; ++m) xh1[m] = *(const f32x4*)(tbr + TV_XH1 * TV + tape_off(m * 4 + q, j));
         ln_bwd_rnn(d1, xh1, lw + tw.g1, rstd1, q);
       }
 #pragma unroll
@@ -673,10 +673,10 @@ struct RnnWgArgs {
   int n_blocks;     // tape blocks (tile-steps)
 };
 
-// MFMA operand of feature tile `m` of a staged 64-wide vector for k-step s (rows 4s..4s+3), lane (c, q)
+// MFMA operand of feature tile `m` of a staged 64-wide vector for k-step s (row tape_krow(s, q)), lane (c, q)
 __device__ inline float tape_opnd(const float* __restrict__ v, int m, int s, int c, int q) {
   const int qq = c >> 2;
-  return v[((m * 4 + qq) * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3)];
+  return v[tape_off(m * 4 + qq, tape_krow(s, q)) + (c & 3)];
 }
 
 #ifndef ORL_RNN_WGRAD_REVERSE
@@ -758,16 +758,16 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
       const float* ivp = blk + iv * TV;
       {
         // lane (c32 = l & 31, kb = l >> 5): rows 8kb .. 8kb+7 of feature 32b + c32 of both vectors (element (row, f) of a
-        // staged vector sits at [(f >> 2) * 16 + ((row + 4 ((f >> 2) & 3)) & 15)] * 4 + (f & 3): tape_opnd's layout)
+        // staged vector sits at tape_off(f >> 2, row) + (f & 3); with rot = g & 7 the 64 reads of an instruction hit 64 banks)
         const int c32 = l & 31, kb = l >> 5;
         u32x4 fa[2][3], fb[2][3];
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2) {
-          const int f = 32 * b2 + c32, grp = f >> 2, rot = 4 * (grp & 3);
+          const int f = 32 * b2 + c32, grp = f >> 2;
           float xa[8], xb[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const int off = (grp * 16 + ((8 * kb + k + rot) & 15)) * 4 + (f & 3);
+            const int off = tape_off(grp, 8 * kb + k) + (f & 3);
             xa[k] = dvp[off];
             xb[k] = ivp[off];
           }
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
       for (int s = 0; s < 4; ++s) {
         if (wave < 4) {
           const int qq = c >> 2;
-          const float ah = blk[TAPE_HEAD + (qq * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3)];
+          const float ah = blk[TAPE_HEAD + tape_off(qq, tape_krow(s, q)) + (c & 3)];
           G5 = ORL_MFMA(ah, tape_opnd(blk + TV_XH3 * TV, wave, s, c, q), G5);
         }
       }
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void rnn_wgrad_kernel(RnnWgArgs P, RnnWgArg
       for (int s = 0; s < 4; ++s) {
         float av[4], bv[4];
         const int qq = c >> 2;
-        const int off = (qq * 16 + ((4 * s + q + 4 * qq) & 15)) * 4 + (c & 3);
+        const int off = tape_off(qq, tape_krow(s, q)) + (c & 3);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           av[m] = tape_opnd(dvp, m, s, c, q);

@@ -216,7 +216,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
         for (int c = 0; c < NO; ++c)
           if ((c >> 2) == q) dv[c & 3] = dh[c];
       }
-      *(f32x4*)(tb + TAPE_HEAD + (q * 16 + ((j + 4 * q) & 15)) * 4) = dv;
+      *(f32x4*)(tb + TAPE_HEAD + tape_off(q, j)) = dv;
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) dt[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -240,12 +240,12 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
   auto obs_to_tape = [&](const f32x4 (&xo)[4], float* __restrict__ tb) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-      if (m < ND) *(f32x4*)(tb + TAPE_X + m * 256 + (q * 16 + ((j + 4 * q) & 15)) * 4) = xo[m];
+      if (m < ND) *(f32x4*)(tb + TAPE_X + m * 256 + tape_off(q, j)) = xo[m];
   };
   // a 64-wide vector this wave stored to its tape block earlier, back into registers (tape_store's layout)
   auto tape_load = [&](const float* __restrict__ v, f32x4 (&x)[4]) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(v + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+    for (int m = 0; m < 4; ++m) x[m] = *(const f32x4*)(v + tape_off(m * 4 + q, j));
   };
   // GRU cell backward (element-wise): gates -> deltas in place, carry = d * z; the four delta vectors go to the tape
   auto gate_bwd = [&](const f32x4 (&d)[4], const f32x4 (&hin)[4], f32x4 (&gr)[4], f32x4 (&gz)[4], f32x4 (&gn)[4],

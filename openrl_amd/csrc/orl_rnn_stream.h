@@ -466,7 +466,7 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
           for (int c = 0; c < NO; ++c)
             if ((c >> 2) == q) dv[c & 3] = dh[c];
         }
-        *(f32x4*)(tb + TAPE_HEAD + (q * 16 + ((j + 4 * q) & 15)) * 4) = dv;
+        *(f32x4*)(tb + TAPE_HEAD + tape_off(q, j)) = dv;
         for (int m = 0; m < ND; ++m) {
           f32x4 xo;
 #pragma unroll
@@ -474,7 +474,7 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
             const int f = 16 * m + 4 * q + r;
             xo[r] = f < D ? rec[A.o_x + f] : 0.f;
           }
-          *(f32x4*)(tb + TAPE_X + m * 256 + (q * 16 + ((j + 4 * q) & 15)) * 4) = xo;
+          *(f32x4*)(tb + TAPE_X + m * 256 + tape_off(q, j)) = xo;
         }
       }
       // d(features) = W3^T dhead, LN3 backward, + gradient carried from step s+1
@@ -559,7 +559,7 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
         asm volatile("" : "+v"(tbr));
         f32x4 xh2[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xh2[m] = *(const f32x4*)(tbr + TV_XH2 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        for (int m = 0; m < 4; ++m) xh2[m] = *(const f32x4*)(tbr + TV_XH2 * TV + tape_off(m * 4 + q, j));
         ln_bwd_rnn(d2, xh2, lw + tw.g2, rstd2, q);
       }
       if (tile_ok) tape_store(tb + TV_DZ2 * TV, d2, j, q);
@@ -576,7 +576,7 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
         asm volatile("" : "+v"(tbr));
         f32x4 xh1[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xh1[m] = *(const f32x4*)(tbr + TV_XH1 * TV + ((m * 4 + q) * 16 + ((j + 4 * q) & 15)) * 4);
+        for (int m = 0; m < 4; ++m) xh1[m] = *(const f32x4*)(tbr + TV_XH1 * TV + tape_off(m * 4 + q, j));
         ln_bwd_rnn(d1, xh1, lw + tw.g1, rstd1, q);
       }
 #pragma unroll
