@@ -13,7 +13,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["orl_buffer.hip", "orl_act.hip", "orl_ppo.hip", "orl_apply.hip", "orl_rnn.hip", "orl_rnn_rollout.hip", "orl_mpe.hip", "orl_ttt.hip", "orl_comm.hip", "orl_gen.hip", "orl_gen_fused.hip", "orl_gen_rollout.hip", "orl_gen_tower.hip"]
-HEADERS = ["orl_common.h", "orl_mlp.h", "orl_ppo_tower.h", "orl_heads.h", "orl_loss.h", "orl_rnn.h", "orl_mpe.h", "orl_perm.h", "orl_ttt.h", "orl_comm.h", "orl_gen_act.h", "orl_gen_sample.h", "orl_gen_mlp.h", "orl_env.h", "orl_gen_tower.h", "orl_gen_loss.h", "orl_rnn_stream.h", os.path.join("..", "..", "include", "orl_hip.h")]
+# every header of this directory enters the up-to-date digest (a hand-kept list missed orl_rnn_l2.h and orl_rnn_rollout_coop.h: an
+# edit of either left a stale library behind unless the build was forced)
+HEADERS = sorted(f for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join("..", "..", "include", "orl_hip.h")]
 # orl_mpe.hip shares orl_mpe.h with the fused recurrent rollout: same flags, so both step a world with the same code
 FAST_MATH = {"orl_ppo.hip", "orl_rnn.hip", "orl_rnn_rollout.hip", "orl_mpe.hip", "orl_act.hip", "orl_gen_rollout.hip"}  # NOT orl_gen.hip: torch-like IEEE arithmetic there
 LIB = os.path.join(HERE, "liborl_hip.so")
@@ -44,7 +46,9 @@ def _digest() -> str:
 
 def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str:
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-    dig = _digest()
+    # build-time A/B switches for kernel experiments (e.g. ORL_BUILD_DEFS="-DORL_TOWER_ILV"); never read at run time
+    extra = os.environ.get("ORL_BUILD_DEFS", "").split()
+    dig = _digest() + ("-prof" if prof else "") + "".join(extra)  # a library built with other switches is not up to date
     if not force and os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as fh:
             if fh.read().strip() == dig:
@@ -54,8 +58,6 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str
     # the bench iteration, every parity test unchanged); the buffer kernels are NOT (the GAE scan is bit-exact with
     # the reference's operation order) and neither is the MPE physics (compared with a float64 reference).
     base = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-    # build-time A/B switches for kernel experiments (e.g. ORL_BUILD_DEFS="-DORL_TOWER_ILV"); never read at run time
-    extra = os.environ.get("ORL_BUILD_DEFS", "").split()
     base += extra
     if prof:  # phase-timing build of the tower kernels (orl_debug_prof); never the shipped configuration
         base.append("-DORL_PROF")
@@ -84,7 +86,7 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str
     if res.returncode != 0:
         raise RuntimeError("hipcc (link) failed:\n" + res.stdout + res.stderr)
     with open(STAMP, "w") as fh:
-        fh.write(dig + ("-prof" if prof else "") + ("".join(extra)))
+        fh.write(dig)
     return LIB
 
 
