@@ -186,3 +186,25 @@ def test_committed_bench_line_carries_the_contract_fields():
         assert "flops_fwd_per_row_both_towers" in o and "flops_per_launch" in o and "frac" in o, o.get("workload")
         if o["flops_per_launch"] is not None:
             assert abs(o["frac"] - o["flops_per_launch"] / (o["dominant_kernel_ms"] * 1e-3) / 157.3e12) < 2e-3
+
+
+def test_tape_layout_is_a_bijection_and_its_operand_reads_are_conflict_free():
+    """The recurrent update's tape is streamed HBM -> LDS verbatim, so its HBM layout IS the LDS access pattern of the weight-gradient
+    kernel (csrc/orl_rnn.h: tape_rot / tape_off / tape_krow).  The model of tools/lds_bank_model.py (lane groups and bank modulus of
+    ds_read_b32 from the MI355X guide) must say: every (group, row, element) has its own slot, the k-step row map covers the 16 rows,
+    and both operand reads take the ideal 2 cycles - round 4's rotation took 8 / 4 (measured: SQ_LDS_BANK_CONFLICT 28.1 M -> 0)."""
+    import importlib.util
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lds_bank_model", os.path.join(root, "tools", "lds_bank_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.tape_report(True) == (True, 2, 2, 2)
+    old = m.tape_report(False)
+    assert old[0] and old[1] > 2  # the old rotation was a valid layout with conflicting bf16 operand reads
+    # the header states the same two maps (and ships with the new rotation on)
+    src = open(os.path.join(root, "openrl_amd", "csrc", "orl_rnn.h")).read()
+    assert re.search(r"#define ORL_TAPE_ROT8 1\b", src)
+    assert "ORL_TAPE_ROT8 ? (g & 7) : 4 * (g & 3)" in src and "ORL_TAPE_ROT8 ? s + 4 * q : 4 * s + q" in src

@@ -99,6 +99,35 @@ def budgets():
             print("  %-32s WBS %d: %s" % (name, wbs, " | ".join(row)))
 
 
+# ---- the recurrent update's tape (csrc/orl_rnn.h: tape_rot / tape_off / tape_krow), streamed HBM -> LDS verbatim ----------------
+def tape_rot(g, rot8=True):
+    return (g & 7) if rot8 else 4 * (g & 3)
+
+
+def tape_off(g, row, rot8=True):
+    return (g * 16 + ((row + tape_rot(g, rot8)) & 15)) * 4
+
+
+def tape_krow(s, q, rot8=True):
+    return s + 4 * q if rot8 else 4 * s + q
+
+
+def tape_report(rot8=True):
+    """(bijection?, worst cycles of the wgrad kernel's bf16 operand reads, of its fp32 operand reads, the ideals) for a rotation."""
+    offs = sorted(tape_off(g, r, rot8) + e for g in range(16) for r in range(16) for e in range(4))
+    bij = offs == list(range(1024)) and sorted(tape_krow(s, q, rot8) for s in range(4) for q in range(4)) == list(range(16))
+    # bf16 operands: lane (c32 = l & 31, kb = l >> 5) reads row 8 kb + k of feature 32 b2 + c32 (ds_read_b32)
+    w_bf16 = max(cycles(G32x2, lambda l: tape_off((32 * b2 + (l & 31)) >> 2, 8 * (l >> 5) + k, rot8) + (l & 3), 1, 32)
+                 for b2 in range(2) for k in range(8))
+    # fp32 operands (tape_opnd): lane (c = l & 15, q = l >> 4) reads row tape_krow(s, q) of feature 16 m + c
+    w_f32 = max(cycles(G32x2, lambda l: tape_off(4 * m + ((l & 15) >> 2), tape_krow(s, l >> 4, rot8), rot8) + (l & 3), 1, 32)
+                for m in range(4) for s in range(4))
+    return bij, w_bf16, w_f32, 2
+
+
 if __name__ == "__main__":
     report()
     budgets()
+    for r8 in (False, True):
+        print("\ntape rotation %s: bijection %s, bf16 operand read %d cycles, fp32 operand read %d cycles (ideal %d)"
+              % ((("g & 7" if r8 else "4 (g & 3)"),) + tape_report(r8)))
