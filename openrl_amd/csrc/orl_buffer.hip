@@ -695,6 +695,13 @@ int orl_adv_normalize_pack(float* adv, const double* stat_partials, int n_partia
   const long long M = (long long)T * L;
   int prow = PACK_ROWS_MAX;  // one LDS tile of prow records per workgroup and trip, at most 64 KiB
   while (prow > 16 && (size_t)prow * R * sizeof(float) > 64 * 1024) prow >>= 1;
+  int wmax = s0.Dp > s0.Dc ? s0.Dp : s0.Dc;
+  wmax = wmax > s0.a ? wmax : s0.a;
+  wmax = wmax > s0.K ? wmax : s0.K;
+  // wide observations (configuration 4's 54-wide share_obs at 128 rows): shrink the tile until every source slab fits the kernel's
+  // batched-load path (<= 20 elements per thread: ONE HBM round trip per tile) instead of falling to the slab-by-slab loops (five
+  // serialised round trips and run-time divisions: 70 us for 100 MB)
+  while (records && prow > 32 && (long long)prow * wmax > 20LL * 256) prow >>= 1;
   long long work = records ? (M + prow - 1) / prow * 256 : M;
   int grid = (int)((work + 255) / 256);
   // every workgroup re-reduces the GAE partial rows first and then walks its tiles: 1024 workgroups measured best
@@ -703,9 +710,6 @@ int orl_adv_normalize_pack(float* adv, const double* stat_partials, int n_partia
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   const size_t tile_bytes = records ? (size_t)prow * R * sizeof(float) : 0;
-  int wmax = s0.Dp > s0.Dc ? s0.Dp : s0.Dc;
-  wmax = wmax > s0.a ? wmax : s0.a;
-  wmax = wmax > s0.K ? wmax : s0.K;
   if ((long long)prow * wmax <= 4LL * 256)
     hipLaunchKernelGGL(adv_normalize_pack_kernel<4>, dim3(grid), dim3(256), tile_bytes, (hipStream_t)stream, adv,
                        stat_partials, n_partials, M, L, use_adv_normalize, stats_out, s0, records, R, prow);
