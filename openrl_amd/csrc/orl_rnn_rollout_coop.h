@@ -193,6 +193,9 @@ __device__ __forceinline__ void rnn_tower_fwd_coop(const float* __restrict__ lw,
 #ifndef ORL_COOP_CRITIC_SHARE
 #define ORL_COOP_CRITIC_SHARE 1  // the critic workgroups build share_obs (= the world's three observations, contiguous in policy_obs)
 #endif                           // and store it; the policy only stores its own observations
+#ifndef ORL_COOP_LATE_STORES
+#define ORL_COOP_LATE_STORES 1  // chase: hidden-state / reward / constant-mask stores behind the publication instead of in front of its vmcnt(0)
+#endif
 #ifndef ORL_COOP_DBG
 #define ORL_COOP_DBG 0  // timing builds only (results are wrong): 1 no env step, 2 no tower, 4 no observation copies, 8 no head /
 #endif                  // sampler, 16 no critic
@@ -359,15 +362,32 @@ __device__ __forceinline__ void rnn_rollout_policy_body_coop(const RnnRolloutArg
 #endif
 #pragma unroll
     for (int m = 0; m < 4; ++m) h[m] = hnew[m] * mk;
-    if (ok) *(f32x4*)(A.hp + ((size_t)(t + 1) * LA + row) * HID + 16 * c + 4 * q) = pick4(h, c);  // this wave's quarter
-    if ((int)threadIdx.x < MPE_A * n_here) {
-      const int jj = threadIdx.x / MPE_A;
-      const size_t r1 = (size_t)(t + 1) * LA + (size_t)e0 * MPE_A + threadIdx.x;
-      b.rewards[(size_t)t * LA + (size_t)e0 * MPE_A + threadIdx.x] = s_rew[jj];
-      if (CHASE) st_agent(b.masks + r1, s_done[jj] != 0.f ? 0.f : 1.f);
-      else b.masks[r1] = s_done[jj] != 0.f ? 0.f : 1.f;
-      b.active_masks[r1] = 1.f;
-      b.bad_masks[r1] = 1.f;
+    // What the critic workgroup reads (masks, the observations below) is stored FIRST and alone in front of the publication's
+    // vmcnt(0); the stores nobody waits for inside this launch (hidden states, rewards, the constant masks) follow behind it.
+    auto late_stores = [&]() {
+      if (ok) *(f32x4*)(A.hp + ((size_t)(t + 1) * LA + row) * HID + 16 * c + 4 * q) = pick4(h, c);  // this wave's quarter
+      if ((int)threadIdx.x < MPE_A * n_here) {
+        const int jj = threadIdx.x / MPE_A;
+        const size_t r1 = (size_t)(t + 1) * LA + (size_t)e0 * MPE_A + threadIdx.x;
+        b.rewards[(size_t)t * LA + (size_t)e0 * MPE_A + threadIdx.x] = s_rew[jj];
+        b.active_masks[r1] = 1.f;
+        b.bad_masks[r1] = 1.f;
+      }
+    };
+    if constexpr (CHASE && ORL_COOP_LATE_STORES) {
+      if ((int)threadIdx.x < MPE_A * n_here)
+        st_agent(b.masks + (size_t)(t + 1) * LA + (size_t)e0 * MPE_A + threadIdx.x, s_done[threadIdx.x / MPE_A] != 0.f ? 0.f : 1.f);
+    } else {
+      if (ok) *(f32x4*)(A.hp + ((size_t)(t + 1) * LA + row) * HID + 16 * c + 4 * q) = pick4(h, c);
+      if ((int)threadIdx.x < MPE_A * n_here) {
+        const int jj = threadIdx.x / MPE_A;
+        const size_t r1 = (size_t)(t + 1) * LA + (size_t)e0 * MPE_A + threadIdx.x;
+        b.rewards[(size_t)t * LA + (size_t)e0 * MPE_A + threadIdx.x] = s_rew[jj];
+        if (CHASE) st_agent(b.masks + r1, s_done[jj] != 0.f ? 0.f : 1.f);
+        else b.masks[r1] = s_done[jj] != 0.f ? 0.f : 1.f;
+        b.active_masks[r1] = 1.f;
+        b.bad_masks[r1] = 1.f;
+      }
     }
     if (!(ORL_COOP_DBG & 4)) {
       float* dp = b.policy_obs + ((size_t)(t + 1) * LA + (size_t)e0 * MPE_A) * MPE_OBS;
@@ -406,6 +426,7 @@ __device__ __forceinline__ void rnn_rollout_policy_body_coop(const RnnRolloutArg
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(A.flags + bid, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (ORL_COOP_LATE_STORES != 0) late_stores();
     }
   }
   if (world_lane) {
