@@ -589,16 +589,46 @@ __device__ inline float feat_sum(const f32x4 (&x)[4]) {
 // mean^2 (clamped at 0), x <- x * rstd - mean * rstd: one dependent cross-lane round trip and 16 subtractions less per pass.  The
 // subtraction loses ~eps32 * mean^2 / var of relative accuracy in var - 1e-7 for the activations of these towers (mean^2 ~ var),
 // and is bounded by eps = 1e-5 under the root when a row is nearly constant.
+// Round 6 (VERDICT r5 item 4 / ADVICE r5): the shortcut is GUARDED.  E[x^2] - mean^2 is trusted only while it keeps at least
+// 1 / LN_GUARD of E[x^2], i.e. mean^2 <= (LN_GUARD - 1) var: the cancellation then costs at most ~LN_GUARD eps32 ~ 1e-6 of relative
+// accuracy in var.  A tile with ANY row beyond that (a large common offset: big b1 / b2 after long training, un-normalised
+// observations) takes the reference's two-pass form (x - mean first, then the centred sum of squares - nn.LayerNorm,
+// /root/reference/openrl/modules/networks/utils/mlp.py:8-46, is stable for any row).  The test is one v_cmp + one wave-uniform
+// branch on the one-pass path; the mean of both forms is the same sum.  tests/test_layernorm_adversarial_gpu.py drives
+// mean / std up to 3 000 through act / evaluate / update / recurrent update.
 #ifndef ORL_LN_ONEPASS
 #define ORL_LN_ONEPASS 1   // round 5: headline 2.702 -> 2.668 ms, 512-env shard 0.848 -> 0.831 ms in three same-box alternations; every parity test unchanged
+#endif
+#ifndef ORL_LN_GUARD
+#define ORL_LN_GUARD 17.0f
 #endif
 __device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd) {
 #if ORL_LN_ONEPASS
   float s1 = lane_sum16(x), s2 = lane_dot16(x, x);
   row_allsum2(s1, s2);
   const float mean1 = s1 * (1.0f / 64.0f);
-  const float var1 = fmaxf(s2 * (1.0f / 64.0f) - mean1 * mean1, 0.f);
-  rstd = __builtin_amdgcn_rsqf(var1 + 1e-5f);
+  const float ex2 = s2 * (1.0f / 64.0f);
+  const float var1 = ex2 - mean1 * mean1;
+#ifndef ORL_LN_NOGUARD   // (A/B switch: the unguarded round-5 form)
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(var1 * ORL_LN_GUARD < ex2) != 0ull, 0)) {
+    // ill-conditioned row in this tile: centre first, then both statistics of the CENTRED values in one butterfly.  The first
+    // mean carries a rounding error of ~eps32 |mean| - at mean / std = 3 000 that alone is 2e-4 std, a common shift of the row
+    // (measured: values 3.7 x further from the float64 result than torch's own fp32 LayerNorm); the centred values are small
+    // and their sum is nearly exact, so one more subtraction removes it (error ~eps32 std: closer to float64 than torch's).
+#pragma unroll
+    for (int m = 0; m < 4; ++m) x[m] = x[m] - mean1;
+    float c1 = lane_sum16(x), c2 = lane_dot16(x, x);
+    row_allsum2(c1, c2);
+    const float dm = c1 * (1.0f / 64.0f);
+    const float v = fmaxf(c2 * (1.0f / 64.0f) - dm * dm, 0.f);
+    rstd = __builtin_amdgcn_rsqf(v + 1e-5f);
+    const float sh2 = -dm * rstd;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) x[m] = x[m] * rstd + sh2;
+    return;
+  }
+#endif
+  rstd = __builtin_amdgcn_rsqf(fmaxf(var1, 0.f) + 1e-5f);
   const float shift = -mean1 * rstd;
 #pragma unroll
   for (int m = 0; m < 4; ++m) x[m] = x[m] * rstd + shift;

@@ -186,7 +186,12 @@ def _cfg2_full_engine(g):
 @pytest.mark.parametrize("case", H.TRAIN_CASES)
 def test_single_update_gradients_vs_oracle(case):
     """One minibatch: clipped parameter gradients of both towers against torch autograd on the oracle."""
-    g = H.load_golden(case)
+    single_update_vs_oracle(H.load_golden(case))
+
+
+def single_update_vs_oracle(g, grad_atol=2e-5, info_rtol=INFO_RTOL, info_atol=INFO_ATOL):
+    """(also driven by tests/test_layernorm_adversarial_gpu.py on golden cases with shifted initial weights; grad_atol is
+    relative to the largest gradient entry of the tower)"""
     cfg, module, buf, algo = build_engine(g)
     r0 = H.oracle_replay(g)  # for cfg/hp/specs only
     hp, pspec, cspec = r0["hp"], r0["pspec"], r0["cspec"]
@@ -211,12 +216,12 @@ def test_single_update_gradients_vs_oracle(case):
     got_p = module.models["policy"].grad.cpu().numpy()
     got_c = module.models["critic"].grad.cpu().numpy()
     scale_p, scale_c = np.abs(gp).max(), np.abs(gc).max()
-    np.testing.assert_allclose(got_p, gp, rtol=1e-3, atol=2e-5 * scale_p + 1e-7)
-    np.testing.assert_allclose(got_c, gc, rtol=1e-3, atol=2e-5 * scale_c + 1e-7)
+    np.testing.assert_allclose(got_p, gp, rtol=1e-3, atol=grad_atol * scale_p + 1e-7)
+    np.testing.assert_allclose(got_c, gc, rtol=1e-3, atol=grad_atol * scale_c + 1e-7)
     got_info = algo._info[:6].cpu().numpy()
     want = np.array([info_o[k] for k in ("value_loss", "policy_loss", "dist_entropy", "actor_grad_norm",
                                          "critic_grad_norm", "ratio")])
-    np.testing.assert_allclose(got_info, want, rtol=INFO_RTOL, atol=INFO_ATOL)
+    np.testing.assert_allclose(got_info, want, rtol=info_rtol, atol=info_atol)
     np.testing.assert_allclose(module.models["policy"].theta.cpu().numpy(), ptheta.numpy(), rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(module.models["critic"].theta.cpu().numpy(), ctheta.numpy(), rtol=1e-3, atol=1e-5)
 
