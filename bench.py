@@ -211,6 +211,14 @@ def main():
     ap.add_argument("--collective", default="p2p", choices=["p2p", "rccl"],
                     help="gradient exchange: fused one-shot xGMI push all-reduce (orl_comm) or one RCCL all-reduce")
     ap.add_argument("--envs", type=int, default=N_ENVS, help="global env count (default: the metric's 4096)")
+    ap.add_argument("--env", default="synthetic", choices=["synthetic", "cartpole"],
+                    help="synthetic = the metric's fixed-step env of the named shape (the headline); cartpole = the same "
+                         "configuration on the device CartPole-v1 physics (a measurement beside the headline)")
+    ap.add_argument("--rollout-kernel", default="chain", choices=["chain", "lockstep"],
+                    help="cfg.amd_rollout_kernel: chain = round 6's policy-only step chain + batched critic sweep (default), "
+                         "lockstep = the round-5 kernel (comparison)")
+    ap.add_argument("--optim-step", default="step", choices=["step", "two_launch", "fused"],
+                    help="cfg.amd_optim_step: step = orl_ppo_step, one launch (default); two_launch = reduce + apply launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--tower-gemm", default="split", choices=["split", "fp32"],
@@ -256,9 +264,13 @@ def main():
     def make_engine(n_envs_local):
         cfg_e = default_cfg(["--episode_length", str(T_ROLL), "--ppo_epoch", str(PPO_EPOCH), "--amd_perm_mode", args.perm,
                              "--log_interval", "1000000", "--amd_collective", args.collective, "--amd_tower_gemm",
-                             args.tower_gemm])
-        env_e = make("SyntheticFixedStep-v0", env_num=n_envs_local, obs_dim=OBS_DIM, episode_limit=200, device=dev,
-                     seed=cfg_e.seed + 10086 * rank)
+                             args.tower_gemm, "--amd_rollout_kernel", args.rollout_kernel, "--amd_optim_step",
+                             args.optim_step])
+        if args.env == "cartpole":
+            env_e = make("CartPole-v1", env_num=n_envs_local, device=dev, seed=cfg_e.seed + 10086 * rank)
+        else:
+            env_e = make("SyntheticFixedStep-v0", env_num=n_envs_local, obs_dim=OBS_DIM, episode_limit=200, device=dev,
+                         seed=cfg_e.seed + 10086 * rank)
         net_e = PPONet(env_e, cfg=cfg_e, device=dev, n_rollout_threads=n_envs_local)
         cfg_e.num_env_steps = n_envs_local * T_ROLL * (args.steps + args.warmup + 16)
         trainer_e = PPOAlgorithm(cfg_e, net_e.module, agent_num=1, device=dev)
@@ -298,19 +310,33 @@ def main():
         e1.record()
         gae_events.append((e0, e1))
 
+    # the line's own spread: events at the boundaries of (up to) four blocks of the timed steps - marker packets on the launch
+    # stream, read after the run; `value` stays total steps / total time
+    n_blocks = min(4, args.steps)
+    block_edges = [round(k * args.steps / n_blocks) for k in range(n_blocks + 1)]
+    block_events = []
     barrier()
     t0 = time.perf_counter()
     info = {}
     for i in range(args.steps):
+        if i in block_edges:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            block_events.append(e)
         sampled = i % ev_stride == 0
         trainer.profile_events = tower_events if sampled else None
         buf.data.compute_returns = timed_compute_returns if sampled else orig_cr
         drv.episode = args.warmup + i
         drv._inner_loop()
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    block_events.append(e)
     trainer.profile_events = None
     buf.data.compute_returns = orig_cr
     barrier()
     dt = time.perf_counter() - t0
+    block_ms = [block_events[k].elapsed_time(block_events[k + 1]) / max(block_edges[k + 1] - block_edges[k], 1)
+                for k in range(len(block_events) - 1)]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -343,7 +369,7 @@ def main():
     # HBM bytes per launch: NOT measured in this process (PMC needs rocprofv3) - read from the committed summary of the
     # separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, and only quoted for the shape it was taken at
     traffic, traffic_source, traffic_reason = None, None, None
-    for name in ("r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+    for name in ("r06_pmc_hbm.json", "r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 blob = json.load(fh)["orl_ppo_fwd_bwd_pair"]
@@ -362,7 +388,7 @@ def main():
     # MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), VALU-busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4
     # / (4 x SQ_BUSY_CU_CYCLES); only quoted for the shape and GEMM path they were taken at
     busy = {}
-    for name in ("r05_pmc_tower.txt", "r04_pmc_tower.txt", "r03_pmc_tower.txt"):
+    for name in ("r06_pmc_tower.txt", "r05_pmc_tower.txt", "r04_pmc_tower.txt", "r03_pmc_tower.txt"):
         try:
             ctr = {}
             with open(os.path.join(ROOT, "profiles", name)) as fh:
@@ -398,6 +424,10 @@ def main():
                               "v_mfma_f32_16x16x4_f32") if args.tower_gemm == "split" else "v_mfma_f32_16x16x4_f32 (--tower-gemm fp32)",
                 "bf16_mfma_frac": round(6 * (16384.0 / 17792.0) * achieved_tf / BF16_MFMA_PEAK_TFLOPS, 4)
                 if args.tower_gemm == "split" else 0.0,
+                # the pipe the split GEMMs actually run on: 6 bf16 products per fp32 product -> its ceiling in fp32-equivalent
+                # flops is the dense bf16 MFMA peak / 6 (417 TFLOP/s); this says how far the kernel is from THAT
+                "frac_of_bf16_split_ceiling": round(achieved_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4)
+                if args.tower_gemm == "split" else None,
                 **busy,
                 "gae_scan": {"bound": "hbm", "achieved": round(gae_bytes / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else 0,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "launch_ms": round(gae_ms, 4),
@@ -405,14 +435,21 @@ def main():
 
     out = {"metric": "env-steps/sec (collect+PPO update), 4096-env CartPole-shape", "value": round(value, 1),
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+           "ms_per_step": round(dt / args.steps * 1e3, 4),
+           "ms_per_step_min": round(min(block_ms), 4) if block_ms else None,
+           "ms_per_step_max": round(max(block_ms), 4) if block_ms else None,
+           "ms_per_step_blocks": "device time per step of %d consecutive blocks of the timed steps (HIP events at the block "
+                                 "boundaries): the line's own spread" % len(block_ms),
+           "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "dtype_note": "fp32 storage and accumulation everywhere; the 64-wide GEMM products at fp32 ACCURACY on the bf16 "
                          "MFMA: 6 of the 9 products of three-term bf16 splits (dropped terms ~2^-24 relative; measured error "
                          "<= v_mfma_f32_16x16x4_f32's, profiles/r03_split_bf16_gemm.txt)",
            "config": {"workload": "configs[1]: PPO, %d global envs x 128-step rollout (%d envs per GPU), obs 4, "
-                                  "Discrete(2), MLP 64x64, ppo_epoch 10, num_mini_batch 1, ValueNorm on; synthetic "
-                                  "fixed-step env" % (global_envs, n_local),
+                                  "Discrete(2), MLP 64x64, ppo_epoch 10, num_mini_batch 1, ValueNorm on; %s" %
+                                  (global_envs, n_local, "synthetic fixed-step env" if args.env == "synthetic" else
+                                   "device CartPole-v1 physics (NOT the headline workload)"),
+                      "rollout_kernel": args.rollout_kernel, "optim_step": args.optim_step,
                       "global_envs": global_envs, "envs_per_gpu": n_local, "rollout_len": T_ROLL,
                       "ppo_epoch": PPO_EPOCH, "perm_mode": args.perm, "parallelism": "env-shard dp%d" % world,
                       "collective": ("none" if world == 1 else

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 304 /* 0.3.4: orl_gt_train; 0.3.3: orl_gt_* (cross-layer fused general towers); 0.3.2: orl_gen_rollout_fused, ORL_HEAD_MIXED, hparams.reserved & 4; 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 305 /* 0.3.5: orl_build_experiments; orl_rollout_args.opp_reserved selects the rollout kernel of the single-agent device envs; the GEMM bits of orl_ppo_hparams.reserved are as round 5 re-encoded them for orl_rnn_ppo_fwd_bwd (0 = the production row kernels, 4 = recompute kernel, 8 | 16 = streamed kernels) - undefined combinations are rejected, and the comparison builds behind 4 (orl_ppo_fwd_bwd) / 8 exist only in an ORL_BUILD_EXPERIMENTS library; 0.3.4: orl_gt_train; 0.3.3: orl_gt_* (cross-layer fused general towers); 0.3.2: orl_gen_rollout_fused, ORL_HEAD_MIXED, hparams.reserved & 4; 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -389,6 +389,19 @@ int orl_ppo_reduce_apply(orl_comm* comm, const float* partials, int n_blocks_pol
                          uint64_t stream_id, float* vn_state, const double* moments, double beta, uint32_t* sync_ctr,
                          void* stream);
 
+/* Round 6: the optimiser step of an MLP-tower minibatch in ONE launch, same arguments and same results as
+ * orl_ppo_reduce_pair(_comm) + orl_ppo_apply(_perm / _comm) (bit-identical sums, same clip_grad_norm_ + Adam arithmetic,
+ * openrl/algorithms/ppo.py:132-164).  Unlike orl_ppo_reduce_apply the two optimiser workgroups are DESIGNATED and launched
+ * with the reducing ones: they fetch parameters and Adam moments while the column sums are formed, wait on their tower's
+ * ticket word, and read the sums - published write-through, no L2 write-back / invalidate fence on either side - with
+ * system-scope loads.  Only those two workgroups ever wait (bounded; a timeout writes NaN into the train_info slots), so no
+ * co-residency of the grid is assumed.  sync_ctr: 4 x uint32 of device memory, zero before the first call. */
+int orl_ppo_step(orl_comm* comm, const float* partials, int n_blocks_policy, int width_policy, int n_blocks_critic,
+                 int width_critic, float* sums, const orl_net_desc* pnet, const orl_net_desc* cnet,
+                 const orl_ppo_hparams* hp, const orl_adam_state* padam, const orl_adam_state* cadam,
+                 float* train_info_accum, int64_t* next_idx, int64_t n, uint64_t seed, uint64_t stream_id, float* vn_state,
+                 const double* moments, double beta, uint32_t* sync_ctr, void* stream);
+
 /* ValueNorm.update (openrl/modules/utils/valuenorm.py:58-77) from reduced batch sums:
  * moments = {sum(x), sum(x^2), count} as doubles on the device; beta = 0.99999. */
 int orl_valuenorm_update(float* vn_state, const double* moments, double beta, void* stream);
@@ -422,7 +435,9 @@ typedef struct orl_rollout_args {
   const float* opp_thetas; /* parameters of policy g at opp_thetas + g*opp_theta_stride */
   int64_t opp_theta_stride;
   int32_t opp_group_rows;  /* envs [g*opp_group_rows, ...) play policy g; a multiple of 16 */
-  int32_t opp_reserved;
+  int32_t opp_reserved;    /* ORL_ENV_SYNTH / ORL_ENV_CARTPOLE: 0 = the round-6 rollout (policy-only step chain + one batched
+                            * critic sweep over the T + 1 stored observation slots), 1 = the round-5 kernel (both towers
+                            * in the step loop).  Ignored by the tic-tac-toe envs. */
   uint64_t opp_seed;       /* Philox seed of the opponents' sampling; counter = (env, opp_rng_step0 + t) */
   uint64_t opp_rng_step0;
   const int32_t* opp_index; /* optional [N]: env n plays pool policy opp_index[n] instead of n / opp_group_rows; unless
@@ -441,6 +456,10 @@ typedef struct orl_rollout_args {
   uint64_t opp_sample_seed; /* orl_opponent_sample's seed */
   uint64_t opp_draw_id0;    /* draw id of the rollout's first step */
 } orl_rollout_args;
+
+/* 1 when the loaded library was built with -DORL_BUILD_EXPERIMENTS=1 (the comparison kernels that lost their A/B are present:
+ * hparams.reserved & 4 / & 8 of orl_ppo_fwd_bwd, & 8 of orl_rnn_ppo_fwd_bwd, orl_ppo_reduce_apply), 0 for the shipped build. */
+int orl_build_experiments(void);
 
 int orl_env_state_width(int env_kind);
 int orl_env_reset(int env_kind, float* env_state, float* ep_stats, float* obs0, int N, int obs_dim,

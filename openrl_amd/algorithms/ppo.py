@@ -192,7 +192,8 @@ class PPOAlgorithm(BaseAlgorithm):
         self._sums = torch.zeros(self._raw_p + self._raw_c, dtype=torch.float32, device=dev)
         # reduce + optimiser step of an MLP-tower minibatch in two launches (default) or in one (orl_ppo_reduce_apply:
         # built, bit-identical, 1 % slower - the comparison switch amd_optim_step)
-        self._fused_step = getattr(cfg, "amd_optim_step", "two_launch") == "fused"
+        self._optim_step = str(getattr(cfg, "amd_optim_step", "step"))
+        self._fused_step = self._optim_step in ("fused", "step")
         self._sync_ctr = torch.zeros(4, dtype=torch.int32, device=dev)  # its tickets; every launch leaves them zero
         # multi-GPU: the one-shot xGMI all-reduce of the sums vector, fused into the optimiser-step launches (MLP towers)
         # or as its own launch (recurrent); None = single process or amd_collective=rccl -> torch.distributed
@@ -291,7 +292,8 @@ class PPOAlgorithm(BaseAlgorithm):
         if fused:
             return ops.ppo_reduce_apply(self._partials, nb_p, self._raw_p, nb_c, self._raw_c, self._sums, p.net, c.net, hp,
                                         po.native_state(max(po.step_count, 1)), co.native_state(co.step_count),
-                                        self._info, self._sync_ctr, next_perm, comm=comm)
+                                        self._info, self._sync_ctr, next_perm, comm=comm,
+                                        entry="orl_ppo_reduce_apply" if self._optim_step == "fused" else "orl_ppo_step")
         return ops.ppo_apply(p.net, c.net, self._sums, hp, po.native_state(max(po.step_count, 1)),
                              co.native_state(co.step_count), self._info, next_perm, comm=comm)
 

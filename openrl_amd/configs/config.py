@@ -22,6 +22,10 @@ AMD_FLAGS = [
     ("amd_perm_mode", "str", "reference", "opt", ["reference", "device", "identity"]),
     # rollout engine: "auto" picks the fused persistent kernel for device-resident envs.
     ("amd_rollout_mode", "str", "auto", "opt", ["auto", "fused", "stepwise"]),
+    # fused rollout of the single-agent device envs (synthetic, CartPole): "chain" (round 6, default) = the policy-only dependent
+    # chain of csrc/orl_rollout2.h + one batched critic sweep over the stored observations; "lockstep" = the round-5 kernel
+    # (policy and critic towers in the step loop) - the comparison switch.  Tic-tac-toe always runs the round-5 kernel.
+    ("amd_rollout_kernel", "str", "chain", "opt", ["chain", "lockstep"]),
     # capture the PPO update epoch in a hipGraph.
     ("amd_use_graph", "bool", True, "opt", None),
     # multi-GPU gradient exchange: "p2p" = the one-shot xGMI push all-reduce fused into the optimiser-step launches
@@ -48,7 +52,9 @@ AMD_FLAGS = [
     # (orl_ppo_reduce_apply: ticketed workgroups, the last one of a tower steps it) - same results bit for bit, but the
     # device-scope release / acquire around the ticket (L2 write-back + invalidate across the 8 XCDs) costs more than the
     # kernel boundary it removes: 15.7 us against 4.4 + 9.3 us, iteration + 1 %.
-    ("amd_optim_step", "str", "two_launch", "opt", ["two_launch", "fused"]),
+    # Round 6: "step" (default) = orl_ppo_step: ONE launch with two DESIGNATED optimiser workgroups that fetch parameters and
+    # moments while the column sums are formed and read them - published write-through - behind a ticket word; no cache fence.
+    ("amd_optim_step", "str", "step", "opt", ["step", "two_launch", "fused"]),
     # general (non-default) feed-forward towers: "fused" = the cross-layer kernels of csrc/orl_gen_tower.h where they take
     # the shape (hidden_size 64 / 128), "layerwise" = one launch per layer and direction everywhere.
     ("amd_gen_update", "str", "fused", "opt", ["fused", "layerwise"]),

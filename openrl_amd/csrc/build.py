@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["orl_buffer.hip", "orl_act.hip", "orl_ppo.hip", "orl_apply.hip", "orl_rnn.hip", "orl_rnn_rollout.hip", "orl_mpe.hip", "orl_ttt.hip", "orl_comm.hip", "orl_gen.hip", "orl_gen_fused.hip", "orl_gen_rollout.hip", "orl_gen_tower.hip"]
+SOURCES = ["orl_buffer.hip", "orl_act.hip", "orl_ppo.hip", "orl_apply.hip", "orl_rnn.hip", "orl_rnn_rollout.hip", "orl_mpe.hip", "orl_ttt.hip", "orl_comm.hip", "orl_gen.hip", "orl_gen_fused.hip", "orl_gen_rollout.hip", "orl_gen_tower.hip", "orl_gen_tower128.hip"]
 # every header of this directory enters the up-to-date digest (a hand-kept list missed orl_rnn_l2.h and orl_rnn_rollout_coop.h: an
 # edit of either left a stale library behind unless the build was forced)
 HEADERS = sorted(f for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join("..", "..", "include", "orl_hip.h")]

@@ -877,7 +877,10 @@ __global__ __launch_bounds__(512) void rollout_kernel(RolloutArgs A) {
 // observation fragments prefetched into registers.  Per-row arithmetic = act_step_kernel's critic wave (trunk_fwd_T).
 __global__ __launch_bounds__(512) void critic_values_kernel(orl_net_desc cnet, const float* __restrict__ ctheta,
                                                             const float* __restrict__ obs, long long rows,
-                                                            float* __restrict__ values) {
+                                                            float* __restrict__ values, float* __restrict__ tail_out,
+                                                            long long tail_row0) {
+  // tail_out (optional): rows >= tail_row0 are ALSO written to tail_out[row - tail_row0] - the bootstrap value of a rollout's
+  // slot T lands in the driver's next_value array without a copy launch
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const TowerLayout tl(cnet);
   const TowerLds tw(cnet.obs_dim, 1, false, false);
@@ -914,9 +917,14 @@ __global__ __launch_bounds__(512) void critic_values_kernel(orl_net_desc cnet, c
     float v[1];
     head_T<1>(smem + tw.W3, smem + tw.b3, 1, n2, q, v);
     const long long row = tile * TILE_B + j;
-    if (row < rows && q == 0) values[row] = v[0];
+    if (row < rows && q == 0) {
+      values[row] = v[0];
+      if (tail_out != nullptr && row >= tail_row0) tail_out[row - tail_row0] = v[0];
+    }
   }
 }
+
+#include "orl_rollout2.h"
 
 // Stand-alone env.step for device envs (evaluation loops, the stepwise driver): same dynamics and RNG
 // streams as the fused rollout; one thread per env.
@@ -1267,8 +1275,8 @@ int orl_debug_rollout_prof(unsigned long long* out16) {
 }
 #endif
 
-int orl_critic_values(const orl_net_desc* cnet, const float* ctheta, const float* critic_obs, int64_t rows,
-                      float* values, void* stream) {
+static int critic_values_launch(const orl_net_desc* cnet, const float* ctheta, const float* critic_obs, int64_t rows,
+                                float* values, float* tail_out, int64_t tail_row0, void* stream) {
   int rc = check_net(cnet, "orl_critic_values", true);
   if (rc) return rc;
   ORL_REQUIRE(ctheta && critic_obs && values && rows > 0, "orl_critic_values: bad arguments");
@@ -1279,8 +1287,13 @@ int orl_critic_values(const orl_net_desc* cnet, const float* ctheta, const float
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)critic_values_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(critic_values_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, *cnet, ctheta, critic_obs,
-                     (long long)rows, values);
+                     (long long)rows, values, tail_out, (long long)tail_row0);
   return launch_status("orl_critic_values");
+}
+
+int orl_critic_values(const orl_net_desc* cnet, const float* ctheta, const float* critic_obs, int64_t rows,
+                      float* values, void* stream) {
+  return critic_values_launch(cnet, ctheta, critic_obs, rows, values, nullptr, 0, stream);
 }
 
 int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_net_desc* cnet, const float* ctheta,
@@ -1334,6 +1347,34 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   RolloutArgs A;
   A.pnet = *pnet; A.cnet = *cnet; A.ptheta = ptheta; A.ctheta = ctheta; A.r = *args; A.next_value = next_value;
   const int grid = (b.N + TILE_B - 1) / TILE_B;
+  // Round 6: the synthetic env and CartPole roll out on the chain kernel (orl_rollout2.h: policy-only step chain, the critic on
+  // background waves of the same launch).  args.opp_reserved = 1 keeps the round-5 lock-step kernel (policy + critic in the
+  // step loop) - the A/B switch of tests and benchmarks.
+  const size_t lds2 = (size_t)ro2_lds(twp.total, TowerLds(cnet->obs_dim, 1, false, false, false, true).total, twp.DP).total *
+                      sizeof(float);
+  // (the widest towers - observations of ~60 columns with 16 outputs - do not fit the chain kernel's rings beside both tower
+  // images: they keep the round-5 kernel)
+  if ((args->env_kind == ORL_ENV_SYNTH || args->env_kind == ORL_ENV_CARTPOLE) && args->opp_reserved != 1 &&
+      lds2 <= 160 * 1024) {
+#define ORL_RO2_LAUNCH3(NO, HD, EV, KS)                                                                               \
+  do {                                                                                                               \
+    if (lds2 > 48 * 1024)                                                                                            \
+      (void)hipFuncSetAttribute((const void*)rollout2_kernel<NO, HD, EV, KS>,                                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                              \
+    hipLaunchKernelGGL((rollout2_kernel<NO, HD, EV, KS>), dim3(grid), dim3(RO2_THREADS), lds2, (hipStream_t)stream, A); \
+  } while (0)
+    if (args->env_kind == ORL_ENV_CARTPOLE) {
+      ORL_RO2_LAUNCH3(2, ORL_HEAD_CATEGORICAL, ORL_ENV_CARTPOLE, 1);
+    } else if (twp.DP == 4 && pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out <= 2) {
+      ORL_RO2_LAUNCH3(2, ORL_HEAD_CATEGORICAL, ORL_ENV_SYNTH, 1);  // configuration 2's shape: fc1's single k-step at compile time
+    } else {
+#define ORL_RO2_LAUNCH(NO, HD) ORL_RO2_LAUNCH3(NO, HD, ORL_ENV_SYNTH, 0)
+      ORL_DISPATCH_HEAD(ORL_RO2_LAUNCH);
+#undef ORL_RO2_LAUNCH
+    }
+#undef ORL_RO2_LAUNCH3
+    return launch_status("orl_rollout_fused");
+  }
 #define ORL_RO_LAUNCH3(NO, HD, EV, WC, THREADS)                                                                      \
   do {                                                                                                              \
     if (lds > 48 * 1024)                                                                                            \

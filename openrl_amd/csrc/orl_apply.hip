@@ -113,9 +113,15 @@ __device__ inline float raw_to_grad(const float* __restrict__ raw, const float* 
 
 // The optimiser step of tower t (0 policy, 1 critic) by ONE workgroup of 1024 threads.  The tower's raw sums and
 // parameters are staged in LDS first so the 64-term LayerNorm-affine dot products of raw_to_grad run out of LDS.
-__device__ inline void apply_tower_block(const int t, const ApplyTower& P, const ApplyTower& Cc, float* __restrict__ sums,
+// wait_ctr (orl_ppo_step, round 6): this workgroup was launched TOGETHER with the workgroups that produce `sums`; it requests
+// everything that does not depend on them first (parameters, Adam moments, the bias corrections), then waits until the ticket
+// word says that all `wait_target` producers have published, and reads the sums with system-scope loads (the producers stored
+// them write-through: orl_ppo_step's protocol below).  Returns false when the bounded wait ran out (nothing is written then
+// except NaN into the train_info slots - a loud failure, not a hang).
+__device__ inline bool apply_tower_block(const int t, const ApplyTower& P, const ApplyTower& Cc, float* __restrict__ sums,
                                          const orl_ppo_hparams& hp, float* __restrict__ info, const int stage_mv,
-                                         const CommDev& CM, const int use_comm, float* s_apply, float* sh) {
+                                         const CommDev& CM, const int use_comm, float* s_apply, float* sh,
+                                         unsigned* __restrict__ wait_ctr = nullptr, const unsigned wait_target = 0u) {
   const TowerLayout tlp(P.net), tlc(Cc.net);
   const RawLayout rlp(P.net), rlc(Cc.net);
   float norms[2] = {0.f, 0.f};
@@ -125,11 +131,54 @@ __device__ inline void apply_tower_block(const int t, const ApplyTower& P, const
   float* raw = s_apply;
   const float* st;  // this tower's statistics (ST_*), in LDS
   float den_p = 1.f, den_v = 1.f;
+  const bool policy_off = t == 0 && (hp.reserved & 1);
+  bool params_staged = false;
   {
     const RawLayout& rl0 = t == 0 ? rlp : rlc;
     const int off = t == 0 ? P.sums_off : Cc.sums_off;
     const int nraw = rl0.total + ORL_N_STATS;
-    if (use_comm) {
+    if (wait_ctr != nullptr) {
+      // (1) what does not depend on the producers: parameters and moments on their way into LDS
+      if (!policy_off) {
+        const ApplyTower& W0 = t == 0 ? P : Cc;
+        const TowerLayout& tl0 = t == 0 ? tlp : tlc;
+        float* th0 = s_apply + rl0.total + ORL_N_STATS;
+        stage_dma(th0, W0.ad.theta, tl0.total);
+        if (stage_mv) {
+          stage_dma(th0 + 2 * tl0.total, W0.ad.m, tl0.total);
+          stage_dma(th0 + 3 * tl0.total, W0.ad.v, tl0.total);
+        }
+        params_staged = true;
+      }
+      // (2) the ticket: one lane polls (relaxed agent-scope loads, s_sleep between them), bounded
+      __shared__ int s_wait_ok;
+      if (threadIdx.x == 0) {
+        int ok = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(wait_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_target) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 22)) { ok = 0; break; }  // ~1 s: the producers of THIS launch never take that long
+        }
+        s_wait_ok = ok;
+        if (ok) __hip_atomic_store(wait_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody draws again in this launch
+      }
+      __syncthreads();
+      if (!s_wait_ok) {
+        if (threadIdx.x == 0 && info != nullptr)
+          for (int k = 0; k < 6; ++k) info[k] = __builtin_bit_cast(float, 0x7fc00000u);
+        return false;
+      }
+      // (3) the sums: system-scope loads (the producers' write-through stores are in memory; no L2 line of this XCD is trusted)
+#pragma unroll 1
+      for (int e = threadIdx.x; e < nraw; e += blockDim.x) {
+        float v = __hip_atomic_load(sums + off + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (use_comm) {
+          v = comm_sum(CM, off + e, v);
+          sums[off + e] = v;
+        }
+        raw[e] = v;
+      }
+    } else if (use_comm) {
 #pragma unroll 1
       for (int e = threadIdx.x; e < nraw; e += blockDim.x) {
         const float v = comm_sum(CM, off + e, sums[off + e]);
@@ -145,7 +194,7 @@ __device__ inline void apply_tower_block(const int t, const ApplyTower& P, const
     const ApplyTower& W = t == 0 ? P : Cc;
     const TowerLayout& tl = t == 0 ? tlp : tlc;
     const RawLayout& rl = t == 0 ? rlp : rlc;
-    if (t == 0 && (hp.reserved & 1)) {
+    if (policy_off) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA (stage_dma above) has landed, as on the main path
       __syncthreads();
       den_p = hp.use_policy_active_masks ? st[ST_ACTIVE_SUM] : st[ST_ROWS];
@@ -161,7 +210,7 @@ __device__ inline void apply_tower_block(const int t, const ApplyTower& P, const
         const float aw0 = P.net.head_kind == ORL_HEAD_GAUSSIAN ? (float)P.net.n_out : 1.f;
         info[5] += stp[ST_RATIO_SUM] / (stp[ST_ROWS] * aw0);
       }
-      return;
+      return true;
     }
     float* th_s = s_apply + rl.total + ORL_N_STATS;
     // latency plan for a one-shot, two-workgroup kernel: everything that comes from HBM (raw sums, parameters, Adam
@@ -172,10 +221,12 @@ __device__ inline void apply_tower_block(const int t, const ApplyTower& P, const
     float* g_s = th_s + tl.total;
     float* m_s = g_s + tl.total;  // Adam moments: staged too when everything fits 160 KiB (stage_mv), else read from HBM
     float* v_s = m_s + tl.total;
-    stage_dma(th_s, W.ad.theta, tl.total);
-    if (stage_mv) {
-      stage_dma(m_s, W.ad.m, tl.total);
-      stage_dma(v_s, W.ad.v, tl.total);
+    if (!params_staged) {
+      stage_dma(th_s, W.ad.theta, tl.total);
+      if (stage_mv) {
+        stage_dma(m_s, W.ad.m, tl.total);
+        stage_dma(v_s, W.ad.v, tl.total);
+      }
     }
     // torch.optim.Adam (single tensor math, betas (0.9, 0.999), amsgrad off)
     // scalar coefficients are python doubles in torch/optim/adam.py; only tensor math is fp32
@@ -248,6 +299,7 @@ __device__ inline void apply_tower_block(const int t, const ApplyTower& P, const
       acc(4, norms[1]);                                  // critic_grad_norm
     }
   }
+  return true;
 }
 
 // One workgroup per tower (blockIdx.x = 0 policy, 1 critic).  Workgroups >= 2 (orl_ppo_apply_perm only) produce the NEXT
@@ -268,6 +320,9 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ApplyTower P, ApplyTowe
 // 64 columns x 16 row groups of one tower's partial region by a workgroup of 1024 threads: at 256 partial rows every
 // thread has 16 independent loads in flight.  `sh` = 16 x 64 floats of LDS.  Multi-GPU: the column sum also goes
 // straight to every peer's inbox (one 8-byte granule each).
+// PUBLISH (orl_ppo_step): the column sums are stored WRITE-THROUGH with system scope instead of plain - they are read in the
+// same launch by a workgroup on another CU / XCD, which no kernel boundary orders behind these stores
+template <bool PUBLISH = false>
 __device__ inline void reduce_columns_block(const float* __restrict__ partials, int n_blocks, int width, int col0,
                                             float* __restrict__ out, int comm_off, const CommDev& CM, int use_comm,
                                             float (*sh)[64]) {
@@ -314,7 +369,8 @@ __device__ inline void reduce_columns_block(const float* __restrict__ partials, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) t[k] = (sh[4 * k][lc] + sh[4 * k + 1][lc]) + (sh[4 * k + 2][lc] + sh[4 * k + 3][lc]);
     const float v = (t[0] + t[1]) + (t[2] + t[3]);
-    out[col] = v;
+    if (PUBLISH) __hip_atomic_store(out + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else out[col] = v;
     if (use_comm) {
       for (int p = 0; p < CM.world; ++p)
         if (p != CM.rank) comm_push(CM, p, comm_off + col, v);
@@ -322,6 +378,7 @@ __device__ inline void reduce_columns_block(const float* __restrict__ partials, 
   }
 }
 
+#if ORL_BUILD_EXPERIMENTS
 // Reduce + optimiser step in ONE launch (orl_ppo_reduce_apply): workgroups [0, gp) / [gp, gp + gc) sum 64 columns each
 // of the policy / critic partial region, then take a ticket; the workgroup that draws a tower's LAST ticket has every
 // column sum of that tower behind a device-scope fence and runs the tower's optimiser step (apply_tower_block).  Every
@@ -369,6 +426,43 @@ __global__ __launch_bounds__(1024) void ppo_reduce_apply_kernel(const float* __r
   const unsigned k = s_ticket;
   if (k == shares - 1u && threadIdx.x == 0) ctr[2] = 0u;
   perm_job_block(J, (int)k, (int)shares);
+}
+
+#endif
+
+// The optimiser step in ONE launch (orl_ppo_step, round 6).  Workgroups [0, gp) / [gp, gp + gc) sum 64
+// columns each of the policy / critic partial region exactly as ppo_reduce_pair does (bit-identical sums) and publish them:
+// write-through stores (system scope), s_waitcnt vmcnt(0), one agent-scope ticket.  Workgroups gp + gc and gp + gc + 1 are the
+// two optimiser workgroups - DESIGNATED, not "the last one to arrive" as in round 5's orl_ppo_reduce_apply: they are launched
+// with the producers, request parameters / moments / bias corrections while the producers work, poll their tower's ticket word
+// and then read the sums with system-scope loads.  No L2 write-back / invalidate fence anywhere (they were what made the
+// ticketed form slower than two launches: 15.7 us against 4.4 + 9.3), and no co-residency assumption: only the two optimiser
+// workgroups ever wait, every producer runs to completion whatever is resident.  Workgroups behind them draw the next epoch's
+// permutation job.  ctr[0..1]: the towers' ticket words, zero before the first call; each is reset by its optimiser workgroup.
+__global__ __launch_bounds__(1024) void ppo_step_kernel(const float* __restrict__ pp, int nb_p, int wp, int gp,
+                                                        const float* __restrict__ pc, int nb_c, int wc, int gc, ApplyTower P,
+                                                        ApplyTower Cc, float* __restrict__ sums, orl_ppo_hparams hp,
+                                                        float* __restrict__ info, PermJob J, int stage_mv, CommDev CM,
+                                                        int use_comm, unsigned* __restrict__ ctr) {
+  extern __shared__ __attribute__((aligned(16))) float s_apply[];
+  __shared__ float sh[16];
+  const int b = blockIdx.x;
+  if (b < gp + gc) {
+    const bool pol = b < gp;
+    reduce_columns_block<true>(pol ? pp : pc, pol ? nb_p : nb_c, pol ? wp : wc, (pol ? b : b - gp) * 64, pol ? sums : sums + wp,
+                               pol ? 0 : wp, CM, use_comm, (float(*)[64])s_apply);
+    if (threadIdx.x < 64) {  // wave 0 wrote the 64 column sums: its stores have left the CU before the ticket is drawn
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr + (pol ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  if (b < gp + gc + 2) {
+    const int t = b - gp - gc;
+    apply_tower_block(t, P, Cc, sums, hp, info, stage_mv, CM, use_comm, s_apply, sh, ctr + t, (unsigned)(t == 0 ? gp : gc));
+    return;
+  }
+  perm_job_block(J, b - (gp + gc + 2), (int)gridDim.x - (gp + gc + 2));
 }
 
 // both towers' partial regions in one launch: blocks [0, gp) reduce the policy region, the rest the critic's
@@ -488,6 +582,10 @@ int orl_ppo_reduce_apply(orl_comm* comm, const float* partials, int n_blocks_pol
                          uint64_t stream_id, float* vn_state, const double* moments, double beta, uint32_t* sync_ctr,
                          void* stream) {
   const char* what = "orl_ppo_reduce_apply";
+#if !ORL_BUILD_EXPERIMENTS
+  return fail(ORL_E_UNSUPPORTED, "%s: the ticketed one-launch optimiser step lost its A/B (15.7 us against 4.4 + 9.3 us for "
+              "orl_ppo_reduce_pair + orl_ppo_apply) and is only present in an ORL_BUILD_EXPERIMENTS library", what);
+#else
   int rc = check_tower(pnet, what);
   if (rc) return rc;
   rc = check_tower(cnet, what);
@@ -537,6 +635,67 @@ int orl_ppo_reduce_apply(orl_comm* comm, const float* partials, int n_blocks_pol
   }
   (void)hipFuncSetAttribute((const void*)ppo_reduce_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(ppo_reduce_apply_kernel, dim3(gp + gc + extra), dim3(1024), lds, (hipStream_t)stream, partials,
+                     n_blocks_policy, width_policy, gp, partials + (size_t)PPO_MAX_BLOCKS * width_policy, n_blocks_critic,
+                     width_critic, gc, P, Cc, sums, *hp, train_info_accum, J, stage_mv, CM, use_comm, sync_ctr);
+  return launch_status(what);
+#endif
+}
+
+int orl_ppo_step(orl_comm* comm, const float* partials, int n_blocks_policy, int width_policy, int n_blocks_critic,
+                 int width_critic, float* sums, const orl_net_desc* pnet, const orl_net_desc* cnet,
+                 const orl_ppo_hparams* hp, const orl_adam_state* padam, const orl_adam_state* cadam,
+                 float* train_info_accum, int64_t* next_idx, int64_t n, uint64_t seed, uint64_t stream_id, float* vn_state,
+                 const double* moments, double beta, uint32_t* sync_ctr, void* stream) {
+  const char* what = "orl_ppo_step";
+  int rc = check_tower(pnet, what);
+  if (rc) return rc;
+  rc = check_tower(cnet, what);
+  if (rc) return rc;
+  ORL_REQUIRE(partials && sums && hp && padam && cadam && sync_ctr, "%s: null pointer", what);
+  ORL_REQUIRE(n_blocks_policy > 0 && n_blocks_critic > 0, "%s: bad arguments", what);
+  ORL_REQUIRE(padam->theta && padam->grad && padam->m && padam->v && cadam->theta && cadam->grad && cadam->m && cadam->v,
+              "%s: null optimizer buffer", what);
+  ORL_REQUIRE(padam->step >= 1 && cadam->step >= 1, "%s: Adam step counts are 1-based", what);
+  ApplyTower P, Cc;
+  P.net = *pnet; P.ad = *padam; P.sums_off = 0;
+  Cc.net = *cnet; Cc.ad = *cadam; Cc.sums_off = RawLayout(*pnet).total + ORL_N_STATS;
+  ORL_REQUIRE(width_policy == Cc.sums_off && width_critic == RawLayout(*cnet).total + ORL_N_STATS,
+              "%s: partial widths %d / %d do not match the towers' raw vectors (%d / %d)", what, width_policy, width_critic,
+              Cc.sums_off, RawLayout(*cnet).total + ORL_N_STATS);
+  PermJob J;
+  memset(&J, 0, sizeof(J));
+  if (next_idx != nullptr) {
+    ORL_REQUIRE(n > 0 && n <= ((int64_t)1 << 62), "%s: bad permutation arguments", what);
+    ORL_REQUIRE(!vn_state || moments, "%s: vn_state needs moments", what);
+    J = make_perm_job(next_idx, n, seed, stream_id, vn_state, moments, beta);
+  }
+  auto need = [&](int k) {  // launch_apply's LDS plan; the reduce workgroups' 4 KB of scratch fit its head
+    const size_t lp = (size_t)(RawLayout(*pnet).total + ORL_N_STATS + k * TowerLayout(*pnet).total) * sizeof(float);
+    const size_t lc = (size_t)(RawLayout(*cnet).total + ORL_N_STATS + k * TowerLayout(*cnet).total) * sizeof(float);
+    return lp > lc ? lp : lc;
+  };
+  const int stage_mv = need(4) <= 160 * 1024;
+  const size_t lds = need(stage_mv ? 4 : 2);
+  ORL_REQUIRE(lds <= 160 * 1024 && lds >= 16 * 64 * sizeof(float), "%s: tower needs %zu B of LDS", what, lds);
+  const int gp = (width_policy + 63) / 64, gc = (width_critic + 63) / 64;
+  int perm_blocks = 0;
+  if (J.idx != nullptr) {
+    perm_blocks = (int)((J.n + 1023) / 1024);
+    const int room = 254 - (gp + gc) > 8 ? 254 - (gp + gc) : 8;  // one workgroup per CU (the launch's LDS footprint)
+    if (perm_blocks > room) perm_blocks = room;
+  }
+  CommDev CM;
+  memset(&CM, 0, sizeof(CM));
+  int use_comm = 0;
+  if (comm != nullptr) {
+    ORL_REQUIRE(width_policy + width_critic <= orl_comm_capacity(comm), "%s: %d floats exceed the comm's capacity %d", what,
+                width_policy + width_critic, orl_comm_capacity(comm));
+    rc = orl_comm_next(comm, &CM);  // one collective: pushed by the reducing workgroups, summed by the optimiser workgroups
+    if (rc) return rc;
+    use_comm = CM.world > 1;
+  }
+  (void)hipFuncSetAttribute((const void*)ppo_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ppo_step_kernel, dim3(gp + gc + 2 + perm_blocks), dim3(1024), lds, (hipStream_t)stream, partials,
                      n_blocks_policy, width_policy, gp, partials + (size_t)PPO_MAX_BLOCKS * width_policy, n_blocks_critic,
                      width_critic, gc, P, Cc, sums, *hp, train_info_accum, J, stage_mv, CM, use_comm, sync_ctr);
   return launch_status(what);

@@ -596,6 +596,7 @@ using namespace orl;
 extern "C" {
 
 int orl_version(void) { return ORL_VERSION; }
+int orl_build_experiments(void) { return ORL_BUILD_EXPERIMENTS; }
 
 int orl_abi_struct_size(int which) {
   switch (which) {

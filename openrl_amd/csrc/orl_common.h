@@ -9,6 +9,16 @@
 
 #define ORL_WAVE 64
 
+// Round 6: kernels that LOST their A/B against the production path - the streamed bf16-split recurrent row
+// kernel (orl_rnn_stream.h), the ticketed one-launch optimiser step (orl_ppo_reduce_apply), the fp32-MFMA and two-image
+// variants of the tower pair - are compiled only with -DORL_BUILD_EXPERIMENTS=1 (ORL_BUILD_DEFS of csrc/build.py).  The shipped
+// library leaves them out: their entry points / hparams.reserved bits return ORL_E_UNSUPPORTED, orl_build_experiments() says
+// which build is loaded, and the tests of those paths skip unless it is the experimental one (run once per round:
+// profiles/rNN_pytest_gpu_experiments.log).
+#ifndef ORL_BUILD_EXPERIMENTS
+#define ORL_BUILD_EXPERIMENTS 0
+#endif
+
 namespace orl {
 
 // ---- error reporting -----------------------------------------------------------------------

@@ -33,21 +33,38 @@ __device__ inline void cartpole_reset(uint64_t seed, uint32_t env, uint32_t epis
   s[2] = u01(r.z) * 0.1f - 0.05f;
   s[3] = u01(r.w) * 0.1f - 0.05f;
 }
-__device__ inline bool cartpole_step(float (&s)[4], int action) {
-  const float gravity = 9.8f, masspole = 0.1f, total_mass = 1.1f, length = 0.5f, polemass_length = 0.05f,
-              force_mag = 10.0f, tau = 0.02f;
+// The step in two halves (round 6): everything that does not depend on the ACTION - the trigonometry of the pole angle and
+// the terms built on it - and the rest.  The fused rollout computes the first half on a service wave while the policy is
+// still working on the step's action (orl_rollout2.h); cartpole_step() is the composition, so every route steps an env
+// through the same expressions.
+struct CartPolePre {
+  float costh, sinth, t1, den;  // cos / sin of theta, polemass_length * theta_dot^2 * sin, the angular denominator
+};
+__device__ inline CartPolePre cartpole_pre(const float (&s)[4]) {
+  const float masspole = 0.1f, total_mass = 1.1f, length = 0.5f, polemass_length = 0.05f;
+  CartPolePre p;
+  p.costh = cosf(s[2]);
+  p.sinth = sinf(s[2]);
+  p.t1 = polemass_length * s[3] * s[3] * p.sinth;
+  p.den = length * (4.0f / 3.0f - masspole * p.costh * p.costh / total_mass);
+  return p;
+}
+__device__ inline bool cartpole_post(float (&s)[4], const CartPolePre& p, int action) {
+  const float gravity = 9.8f, total_mass = 1.1f, polemass_length = 0.05f, force_mag = 10.0f, tau = 0.02f;
   const float force = action == 1 ? force_mag : -force_mag;
-  const float costh = cosf(s[2]), sinth = sinf(s[2]);
-  const float temp = (force + polemass_length * s[3] * s[3] * sinth) / total_mass;
-  const float thetaacc =
-      (gravity * sinth - costh * temp) / (length * (4.0f / 3.0f - masspole * costh * costh / total_mass));
-  const float xacc = temp - polemass_length * thetaacc * costh / total_mass;
+  const float temp = (force + p.t1) / total_mass;
+  const float thetaacc = (gravity * p.sinth - p.costh * temp) / p.den;
+  const float xacc = temp - polemass_length * thetaacc * p.costh / total_mass;
   s[0] = s[0] + tau * s[1];
   s[1] = s[1] + tau * xacc;
   s[2] = s[2] + tau * s[3];
   s[3] = s[3] + tau * thetaacc;
   const float th_lim = 12.0f * 2.0f * 3.14159265358979323846f / 360.0f;
   return (s[0] < -2.4f) || (s[0] > 2.4f) || (s[2] < -th_lim) || (s[2] > th_lim);
+}
+__device__ inline bool cartpole_step(float (&s)[4], int action) {
+  const CartPolePre p = cartpole_pre(s);
+  return cartpole_post(s, p, action);
 }
 
 

@@ -1,31 +1,8 @@
 // orl_gen_tower.hip - C ABI of the cross-layer fused general towers (kernels in orl_gen_tower.h): orl_gt_supported,
 // orl_gt_image_floats, orl_gt_raw_floats, orl_gt_prep, orl_gt_fwd, orl_gt_bwd.
-#include "orl_gen_tower.h"
+#include "orl_gen_tower_launch.h"
 
 namespace orl {
-
-// backward: one 8-wave workgroup per CU (256 VGPRs per wave); forward: 8-wave workgroups at <= 128 VGPRs and ~75 KB of
-// LDS, TWO per CU, so that one's barrier / LDS waits overlap the other's MFMAs
-// Round 4: the backward launch ships as 4-wave workgroups, ONE per CU, 512 registers per wave (ORL_GT_BWD_WAVES = 4,
-// ORL_GT_BWD_MINWAVES = 1: no scratch traffic) wherever its LDS fits ORL_GT_BWD_LDS_CAP_KB (gt_bwd_waves below has the
-// measurements that set the cap); -DORL_GT_BWD_WAVES=8 -DORL_GT_BWD_MINWAVES=2 rebuilds round 3's.
-#ifndef ORL_GT_BWD_MINWAVES
-#define ORL_GT_BWD_MINWAVES 1
-#endif
-#ifndef ORL_GT_BWD_WAVES
-#define ORL_GT_BWD_WAVES 4
-#endif
-#ifndef ORL_GT_BWD_LDS_CAP_KB
-#define ORL_GT_BWD_LDS_CAP_KB 80
-#endif
-template <int H, int NL, int ND, int NW>
-__global__ __launch_bounds__(NW * 64, ORL_GT_BWD_MINWAVES) void gt_bwd_kernel(GtArgs A) {
-  gt_body<H, NL, ND, true, NW>(A);
-}
-template <int H, int NL, int ND>
-__global__ __launch_bounds__(GT_WAVES * 64, 4) void gt_fwd_kernel(GtArgs A) {
-  gt_body<H, NL, ND, false, GT_WAVES>(A);
-}
 
 // ------------------------------------------------------------------------------------------------ image
 // LayerNorm affine feeding layer l (l = 0: the feature norm, or identity)
@@ -251,41 +228,13 @@ static int gt_check(const orl_gt_desc* d, const char* who) {
   return 0;
 }
 
-template <int H, int NL, int ND>
-static void gt_launch_fwd(const GtArgs& A, int grid, size_t lds, hipStream_t s) {
-  (void)hipFuncSetAttribute((const void*)gt_fwd_kernel<H, NL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((gt_fwd_kernel<H, NL, ND>), dim3(grid), dim3(GT_WAVES * 64), lds, s, A);
-}
-template <int H, int NL, int ND, int NW>
-static void gt_launch_bwd(const GtArgs& A, int grid, size_t lds, hipStream_t s) {
-  (void)hipFuncSetAttribute((const void*)gt_bwd_kernel<H, NL, ND, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((gt_bwd_kernel<H, NL, ND, NW>), dim3(grid), dim3(NW * 64), lds, s, A);
-}
-
-#if ORL_GT_BWD_WAVES == 4
-#define ORL_GT_NW4 4
-#else
-#define ORL_GT_NW4 8  // the 4-wave build is not instantiated
-#endif
 // bwd_waves = 0: forward
 static int gt_launch(const GtArgs& A, int bwd_waves, int grid, size_t lds, hipStream_t s) {
   const int H = A.d.H, NL = A.d.n_layers - 1, ND = A.d.D <= 16 ? 1 : 4;
-#define ORL_GT_CASE3(h, nl, nd)                                                    \
-  if (H == h && NL == nl && ND == nd) {                                            \
-    if (bwd_waves == 0) gt_launch_fwd<h, nl, nd>(A, grid, lds, s);                 \
-    else if (bwd_waves == 4) gt_launch_bwd<h, nl, nd, ORL_GT_NW4>(A, grid, lds, s); \
-    else gt_launch_bwd<h, nl, nd, 8>(A, grid, lds, s);                             \
-    return 0;                                                                      \
-  }
-#define ORL_GT_CASE(h, nl) ORL_GT_CASE3(h, nl, 1) ORL_GT_CASE3(h, nl, 4)
   ORL_GT_CASE(64, 1)
   ORL_GT_CASE(64, 2)
   ORL_GT_CASE(64, 3)
-  ORL_GT_CASE(128, 1)
-  ORL_GT_CASE(128, 2)
-  ORL_GT_CASE(128, 3)
-#undef ORL_GT_CASE
-#undef ORL_GT_CASE3
+  if (H == 128) return gt_launch_h128(A, bwd_waves, grid, lds, s);
   return fail(ORL_E_UNSUPPORTED, "orl_gt: no kernel for hidden_size %d with %d layers", H, NL + 1);
 }
 

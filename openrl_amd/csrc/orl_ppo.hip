@@ -97,6 +97,11 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
   // hp.reserved & 4: the caller asks for the fp32-MFMA GEMMs (measurement / comparison switch, bench.py --tower-gemm fp32)
   // variant -1 (the wide-observation builds' first choice, ORL_TOWER_TR; the small-observation build takes it only with
   // -DORL_TOWER_TR_ND0): the full split with the dgrad through transposing reads of W2's image - no W2^T image
+#if !ORL_BUILD_EXPERIMENTS
+  if (P.hp.reserved & (4 | 8))
+    return -1000 - fail(ORL_E_UNSUPPORTED, "orl_ppo_fwd_bwd: hparams.reserved & %d selects a comparison build (fp32-MFMA / two-image "
+                        "tower pair) that this library was built without (ORL_BUILD_EXPERIMENTS)", P.hp.reserved & (4 | 8));
+#endif
   for (int var = (P.hp.reserved & 4) ? 1 : ORL_TOWER_FIRST_VARIANT; var < 3; ++var) {
     const bool spt = var == -1;
     const bool sp = var <= 0;
@@ -146,25 +151,44 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
       gp = best_g;
       gc = PPO_MAX_BLOCKS - best_g;
     }
+    // Which builds exist (round 6): the shipped library instantiates only what the default path can reach - the full split
+    // with two images for the small-observation towers (ND == 0), the transposing-read full split and its LDS fallback (fp32
+    // GEMMs + split wgrad) for the wide ones - 25 of the 60 (head, ND, SP) combinations; the rest (the transposing build at
+    // ND == 0, two images at ND >= 1, every fp32-MFMA pair) are comparison builds of earlier rounds (ORL_BUILD_EXPERIMENTS).
+    constexpr bool HAVE_SPT = ND > 0 ? (ORL_TOWER_TR != 0) : (ORL_TOWER_TR_ND0 != 0);
+    constexpr bool HAVE_SP2 = ND == 0 || ORL_BUILD_EXPERIMENTS;
+    constexpr bool HAVE_FB = ND > 0 || ORL_BUILD_EXPERIMENTS;
+    bool launched = false;
     if (spt) {
-      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, 3>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 3>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+      if constexpr (HAVE_SPT) {
+        (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, 3>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 3>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+        launched = true;
+      }
     } else if (sp) {
-      (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, 2>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 2>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+      if constexpr (HAVE_SP2) {
+        (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, 2>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 2>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+        launched = true;
+      }
     } else {
       if (P.hp.reserved & 4) {  // every GEMM on v_mfma_f32_16x16x4_f32 (round 2's kernel + the LayerNorm fold)
+#if ORL_BUILD_EXPERIMENTS
         (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, 0>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, 0>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
-      } else {
+        launched = true;
+#endif
+      } else if constexpr (HAVE_FB) {
         (void)hipFuncSetAttribute((const void*)ppo_tower_pair_kernel<HEADP, NOP_, ND, ORL_TOWER_WGRAD_SPLIT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ppo_tower_pair_kernel<HEADP, NOP_, ND, ORL_TOWER_WGRAD_SPLIT>), dim3(gp + gc), dim3(64 * ORL_PAIR_WAVES), lds, s, P2, C2, gp);
+        launched = true;
       }
     }
+    if (!launched) continue;  // a build this library does not carry: the next variant
     const int rc = launch_status("orl_ppo_fwd_bwd(pair)");
     if (rc) return -1000 - rc;
     *gp_out = gp; *gc_out = gc;

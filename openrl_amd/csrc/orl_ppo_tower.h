@@ -60,9 +60,6 @@ __device__ unsigned long long g_orl_prof[24];
 #define ORL_T(k) ((void)0)
 #endif
 
-#ifndef ORL_DMA_LATE
-#define ORL_DMA_LATE 0
-#endif
 #ifndef ORL_WGRAD_HALVES
 #define ORL_WGRAD_HALVES 1
 #endif
@@ -287,13 +284,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // the phase profile).  An asm statement is invisible to that bookkeeping; the one wait this pipeline needs is the
   // explicit vmcnt(0) at the top of the tile loop, a whole tile after the issue (guide section 5.7: M0 is written in
   // the same statement that reads it; the s_nop covers the SALU-write -> M0 use hazard).
-#ifdef ORL_TOWER_NODMA  // TIMING experiment only (wrong results): what does the record fetch cost the tile loop?
-  int dma_calls = 0;
-#endif
   auto issue_dma = [&](float* slot, long long row) {
-#ifdef ORL_TOWER_NODMA
-    if (dma_calls++ >= 2) return;  // the two ring slots are filled once, every later tile re-reads them
-#endif
     const float* src = A.records + (size_t)row * A.R;
 #pragma unroll 1
     for (int g = 0; 4 * g < nch; ++g) {
@@ -322,11 +313,6 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM, SP, true);
   __syncthreads();
 
-#ifdef ORL_TOWER_STAGGER
-  // build-time experiment (round 5): the two waves of a SIMD (waves w and w + 4) start their tile loops half a tile apart, so
-  // that one is in a GEMM phase while the other is in a LayerNorm / loss phase; ORL_TOWER_STAGGER = s_sleep units of 64 cycles
-  if (wave >= 4) __builtin_amdgcn_s_sleep(ORL_TOWER_STAGGER);
-#endif
 #ifdef ORL_PROF
   __shared__ unsigned long long prof_lds[16];
   const bool prof_on = bid == 0 && wave == 0;
@@ -342,12 +328,10 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     // Order matters: the index prefetch (a load hipcc counts) is re-issued BEFORE the DMA (which it cannot see).  The
     // other way round, hipcc's own "previous load into these registers must have landed" wait sits behind the DMA
     // and drains it.
-#if !ORL_DMA_LATE
     const long long row_cur = row_next;
     row_next = row_of(tile + 2 * n_waves);
     issue_dma(RR + (ring ^ 1) * rts, row_cur);        // next tile's records, hidden behind this tile
     ring ^= 1;
-#endif
     // column -> ring position: observation columns live in range 0 (ring chunk = record chunk - c0_beg), every other field
     // in range 1 (ring chunk = record chunk - c1_beg + c0_n); both biases fold into the base pointer.  ND == 0: identity.
     const float* RTX = ND == 0 ? RT : RT - 64 * A.c0_beg;
@@ -691,17 +675,6 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     }
 
     ORL_T(4);  // loss
-#if ORL_DMA_LATE
-    // build-time experiment (round 5): the next tile's records are requested HERE, behind the loss phase, instead of at the top
-    // of the tile - a scratch reload of the spilling wide builds (fc1 and loss phases) then never waits vmcnt(0) behind a DMA
-    // that has just been issued; ~10 000 cycles of the tile remain for the records to land
-    {
-      const long long row_cur = row_next;
-      row_next = row_of(tile + 2 * n_waves);
-      issue_dma(RR + (ring ^ 1) * rts, row_cur);
-      ring ^= 1;
-    }
-#endif
     // ---------------- backward ----------------
     // S3 += dhead^T xhat2, db3 (F layout: lane = feature f); xhat2 comes from the scratch slab
     if constexpr (HMM) {

@@ -659,7 +659,9 @@ __global__ __launch_bounds__(512, 2) void rnn_row_pair_kernel(RnnRowArgs P, RnnR
 }
 
 }  // namespace orl
+#if ORL_BUILD_EXPERIMENTS
 #include "orl_rnn_stream.h"  // the same row kernel with its 64 x 64 GEMMs on the bf16 MFMA over streamed images (round 4)
+#endif
 #include "orl_rnn_l2.h"      // data_chunk_length == 2: both steps of a chunk resident in registers, no recompute (round 5)
 namespace orl {
 
@@ -1152,12 +1154,16 @@ struct RnnWs {  // workspace carve-up (floats) for one tower
     rpart = o; o += (size_t)RNN_ROW_BLOCKS * rpw;
     wpart = o; o += (size_t)RNN_WG_BLOCKS * wpw;
     o = (o + 63) & ~(size_t)63;
-    img = o; o += (size_t)RS_NIMG * RS_IMG_FLOATS + 128;  // bf16 images of W2 / Wih / Whh + the stream's two flag rows
+    img = o;
+#if ORL_BUILD_EXPERIMENTS
+    o += (size_t)RS_NIMG * RS_IMG_FLOATS + 128;  // bf16 images of W2 / Wih / Whh + the stream's two flag rows (streamed kernel)
+#endif
     total = (o + 63) & ~(size_t)63;
   }
 };
 
 // the streamed split kernel: images first (one small launch per optimiser step), then the row pair
+#if ORL_BUILD_EXPERIMENTS
 template <int HEAD, int NO>
 static int launch_rnn_rows_stream(const RnnRowArgs& P, const RnnRowArgs& Cc, float* img_p, float* img_c, int grid_p,
                                   int grid_c, hipStream_t s) {
@@ -1183,6 +1189,7 @@ static int launch_rnn_rows_stream(const RnnRowArgs& P, const RnnRowArgs& Cc, flo
                      (const float*)img_p, (const float*)img_c, grid_p);
   return launch_status("orl_rnn_ppo_fwd_bwd(row, streamed split)");
 }
+#endif
 
 // data_chunk_length == 2: rnn_row2_pair_kernel, 4 waves per workgroup (one per SIMD, 512 registers), one workgroup per CU
 template <int HEAD, int NO>
@@ -1404,6 +1411,17 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
   const int no = pnet->n_out;
   int grid_rp = wp.grid_row, grid_rc = wc.grid_row;  // workgroups (= rows of the row partials) per tower
   const bool streamed = (hp->reserved & 8) != 0;
+  // (round 6, ADVICE r5: undefined combinations are refused instead of silently meaning something)
+  if ((hp->reserved & 4) && (hp->reserved & (8 | 16)))
+    return fail(ORL_E_INVALID, "orl_rnn_ppo_fwd_bwd: hparams.reserved GEMM bits %d: 4 (recompute kernel) excludes 8 / 16 (streamed "
+                "kernels)", hp->reserved & 28);
+  if ((hp->reserved & 16) && !streamed)
+    return fail(ORL_E_INVALID, "orl_rnn_ppo_fwd_bwd: hparams.reserved & 16 (4 waves per workgroup) needs & 8 (the streamed kernel)");
+#if !ORL_BUILD_EXPERIMENTS
+  if (streamed)
+    return fail(ORL_E_UNSUPPORTED, "orl_rnn_ppo_fwd_bwd: hparams.reserved & 8 selects the streamed bf16-split row kernel, which this "
+                "library was built without (ORL_BUILD_EXPERIMENTS)");
+#endif
   const bool l2 = !streamed && !(hp->reserved & 4) && batch->L == 2;
   if ((streamed && (hp->reserved & 16)) || l2) {  // 4 waves per workgroup: 4 tiles per group and round
     grid_rp = (wp.n_tiles + 3) / 4;
@@ -1454,6 +1472,7 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
       else rc = launch_rnn_rows<ORL_HEAD_GAUSSIAN, 16>(A, C2, wp.grid_row, wc.grid_row, s);
     }
   } else {
+#if ORL_BUILD_EXPERIMENTS
     float* ip = base_p + wp.img;
     float* ic = base_c + wc.img;
     if (pnet->head_kind == ORL_HEAD_CATEGORICAL) {
@@ -1464,6 +1483,7 @@ int orl_rnn_ppo_fwd_bwd(const orl_net_desc* pnet, const float* ptheta, const orl
       if (no <= 8) rc = launch_rnn_rows_stream<ORL_HEAD_GAUSSIAN, 8>(A, C2, ip, ic, grid_rp, grid_rc, s);
       else rc = launch_rnn_rows_stream<ORL_HEAD_GAUSSIAN, 16>(A, C2, ip, ic, grid_rp, grid_rc, s);
     }
+#endif
   }
   if (rc) return rc;
   // (2) weight-gradient GEMMs over both tapes, one launch

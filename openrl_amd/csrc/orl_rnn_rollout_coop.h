@@ -79,12 +79,15 @@ __device__ __forceinline__ void tile_sync(unsigned* __restrict__ cnt, unsigned& 
   seq += 4;
   if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   // bounded like the chase wait: a wave that never arrives (a lost workgroup-mate) must not hang the GPU; ~0.5 s of polls, far
-  // beyond any exchange (< 10 us), after which the rollout's results are void: err = the chase protocol's sticky error word
-  // (sync_flags[n_groups], polled by the host's DeviceErrorWatch); without sync_flags the loss is only bounded, not reported
+  // beyond any exchange (< 10 us), after which the rollout's results are void (on the MPE env that includes critic_obs[1..T],
+  // which the critic workgroups store): err = the chase protocol's sticky error word (sync_flags[n_groups], polled by the
+  // host's DeviceErrorWatch).  Without sync_flags (the two-launch mode) there is no word to raise: the wave TRAPS - the launch
+  // fails and the next HIP call on the stream reports it (a timeout must never let the rollout continue silently)
   for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq; ++spins) {
     __builtin_amdgcn_s_sleep(1);
     if (spins > (1u << 22)) {
       if (err != nullptr) *err = 1;
+      else __builtin_trap();
       break;
     }
   }

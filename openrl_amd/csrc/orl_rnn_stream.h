@@ -238,13 +238,8 @@ __device__ __forceinline__ void rnn_row_body_stream(const RnnRowArgs& A, const f
 
   for (int it = 0; it < n_iter; ++it) {
     int tile = it * per + bid * nwv + wave;
-#ifdef ORL_RS_NOTAPE  // TIMING experiment only (wrong results): no tape / state-tape stores at all
-    const bool tile_ok = false;
-    if (tile >= n_tiles) tile = n_tiles - 1;
-#else
     const bool tile_ok = tile < n_tiles;  // ragged last group: the wave shadows the last tile - all loads, NO stores,
     if (!tile_ok) tile = n_tiles - 1;     // and its loss statistics are dropped below
-#endif
     const LossStats st_keep = st;
     float dls_keep[NO];
 #pragma unroll

@@ -282,20 +282,23 @@ def ppo_apply(pnet, cnet, sums, hp: PPOHParams, padam: AdamState, cadam: AdamSta
 
 
 def ppo_reduce_apply(partials, nb_p: int, width_p: int, nb_c: int, width_c: int, sums, pnet, cnet, hp: PPOHParams,
-                     padam: AdamState, cadam: AdamState, train_info_accum, sync_ctr, next_perm=None, comm=None):
-    """``ppo_reduce_pair`` + ``ppo_apply`` in ONE launch (orl_ppo_reduce_apply): same arguments, same results.
-    ``sync_ctr``: 4 x int32 device tensor, zero before the first call (every launch leaves it zero)."""
+                     padam: AdamState, cadam: AdamState, train_info_accum, sync_ctr, next_perm=None, comm=None,
+                     entry: str = "orl_ppo_reduce_apply"):
+    """``ppo_reduce_pair`` + ``ppo_apply`` in ONE launch: same arguments, same results.  ``entry``: ``orl_ppo_step`` (round 6:
+    designated optimiser workgroups behind write-through sums) or ``orl_ppo_reduce_apply`` (round 5's ticketed form, only in
+    an ORL_BUILD_EXPERIMENTS library).  ``sync_ctr``: 4 x int32 device tensor, zero before the first call (every launch
+    leaves it zero)."""
     dev = _dev(sums)
     idx, n, seed, stream_id, vn = None, 0, 0, 0, None
     if next_perm is not None:
         n, seed, stream_id, vn = next_perm
         idx = torch.empty(n, dtype=torch.int64, device=dev)
-    rc = _lib().orl_ppo_reduce_apply(comm.handle if comm is not None else None, fptr(partials), nb_p, width_p, nb_c,
-                                     width_c, fptr(sums), C.byref(pnet), C.byref(cnet), C.byref(hp), C.byref(padam),
-                                     C.byref(cadam), fptr(train_info_accum), ptr(idx), n, seed & (2 ** 64 - 1),
-                                     stream_id & (2 ** 64 - 1), fptr(vn[0]) if vn else None, ptr(vn[1]) if vn else None,
-                                     float(vn[2]) if vn else 0.0, ptr(sync_ctr), stream_ptr(dev))
-    nat.check(rc, "orl_ppo_reduce_apply")
+    rc = getattr(_lib(), entry)(comm.handle if comm is not None else None, fptr(partials), nb_p, width_p, nb_c,
+                                width_c, fptr(sums), C.byref(pnet), C.byref(cnet), C.byref(hp), C.byref(padam),
+                                C.byref(cadam), fptr(train_info_accum), ptr(idx), n, seed & (2 ** 64 - 1),
+                                stream_id & (2 ** 64 - 1), fptr(vn[0]) if vn else None, ptr(vn[1]) if vn else None,
+                                float(vn[2]) if vn else 0.0, ptr(sync_ctr), stream_ptr(dev))
+    nat.check(rc, entry)
     return idx
 
 

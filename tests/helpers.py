@@ -8,6 +8,27 @@ from openrl_amd.configs.config import default_cfg
 from oracle import ppo_oracle as po
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def experiments_built() -> bool:
+    """True when the loaded liborl_hip.so carries the comparison kernels that lost their A/B (ORL_BUILD_EXPERIMENTS: the
+    streamed recurrent row kernel, the ticketed one-launch optimiser step, the fp32-MFMA / two-image tower pairs).  The
+    shipped build leaves them out; their tests run once per round against an experimental build
+    (``ORL_BUILD_DEFS=-DORL_BUILD_EXPERIMENTS=1 python -m openrl_amd.csrc.build --force``, profiles/rNN_pytest_gpu_experiments.log)."""
+    try:
+        from openrl_amd import _native
+
+        return bool(_native.load(build_if_missing=False).orl_build_experiments())
+    except Exception:
+        return False
+
+
+def experimental(*values):
+    """pytest.param(...) that skips unless the experimental build is loaded."""
+    import pytest
+
+    return pytest.param(*values, marks=pytest.mark.skipif(not experiments_built(),
+                                                          reason="comparison kernel: needs an ORL_BUILD_EXPERIMENTS library"))
 TRAIN_CASES = ["train_discrete", "train_discrete_masks", "train_gaussian", "train_novn_proper", "train_popart"]
 
 

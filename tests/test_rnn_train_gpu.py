@@ -79,7 +79,7 @@ def test_recurrent_module_init_is_the_reference_init(case, seed):
     assert sd["rnn.rnn.weight_ih_l0"].shape == (192, 64) and sd["rnn.norm.bias"].shape == (64,)
 
 
-@pytest.mark.parametrize("gemm", ["split", "fp32", "fp32_recompute", "split_w4"])
+@pytest.mark.parametrize("gemm", [H.experimental("split"), "fp32", "fp32_recompute", H.experimental("split_w4")])
 @pytest.mark.parametrize("case", RH.RNN_CASES)
 def test_recurrent_train_matches_reference_golden(case, gemm):
     """gemm: the row kernel (cfg.amd_rnn_gemm) - fp32 (default: the register-resident kernel of csrc/orl_rnn_l2.h for chunks of
@@ -443,9 +443,10 @@ def test_shared_recurrent_network_matches_reference_golden():
     np.testing.assert_allclose(buf.rnn_states_critic.cpu().numpy(), g["buf_rnn_states_critic"], rtol=3e-4, atol=3e-5)
 
 
-@pytest.mark.parametrize("perm_mode,gemm", [("device", "split"), ("identity", "split"), ("reference", "split"),
+@pytest.mark.parametrize("perm_mode,gemm", [H.experimental("device", "split"), H.experimental("identity", "split"),
+                                            H.experimental("reference", "split"),
                                             ("device", "fp32"), ("identity", "fp32"), ("reference", "fp32"),
-                                            ("device", "fp32_recompute"), ("device", "split_w4")])
+                                            ("device", "fp32_recompute"), H.experimental("device", "split_w4")])
 def test_full_size_recurrent_update_matches_reference_golden(perm_mode, gemm):
     """BASELINE.json configs[3] at FULL size: 2048 envs x 3 agents x 25 steps = 153 600 rows = 76 800 chunks of 2 (the
     odd T makes chunks straddle lanes), Dict obs 18 / 54, Discrete(5), GRU, adv-normalise on (examples/mpe/mpe_ppo.yaml),

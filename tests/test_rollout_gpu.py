@@ -130,6 +130,67 @@ def test_fused_rollout_equals_stepwise_rollout(env_id, kw, N, T):
             np.testing.assert_allclose(x, y, rtol=1e-5, atol=1e-6, err_msg=f)
 
 
+@pytest.mark.parametrize("env_id,kw,N,T", [
+    ("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=7), 50, 23),
+    ("CartPole-v1", {}, 200, 40),
+    ("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=200), 4096, 128),
+    ("SyntheticFixedStep-v0", dict(obs_dim=17, episode_limit=9, action_space="box6"), 1024, 50),
+    ("SyntheticFixedStep-v0", dict(obs_dim=18, episode_limit=9, action_space="disc9"), 130, 20),
+    ("SyntheticFixedStep-v0", dict(obs_dim=5, episode_limit=9, action_space="box2"), 40, 11),
+])
+def test_chain_rollout_kernel_equals_the_lockstep_kernel(env_id, kw, N, T):
+    """Round 6: the policy-only chain kernel (csrc/orl_rollout2.h: head from per-wave partials of LayerNorm 2, services on
+    their own waves, values from one batched critic sweep) against the round-5 lock-step kernel on the same seeds: env
+    streams bit-exact, actions identical except where a uniform sits on a CDF edge, float fields to fp32 round-off.
+    (HIP against HIP: the reference-side evidence of both is test_fused_rollout_equals_stepwise_rollout +
+    test_fused_rollout_teacher_forced_vs_oracle_towers.)"""
+    from openrl_amd import spaces
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+
+    kind = kw.get("action_space")
+    if isinstance(kind, str):
+        k = int(kind[4:]) if kind.startswith("disc") else int(kind[3:])
+        kw = dict(kw, action_space=spaces.Discrete(k) if kind.startswith("disc") else spaces.Box(-1.0, 1.0, (k,)))
+    bufs, stats = [], []
+    for kernel in ("chain", "lockstep"):
+        cfg, env, net, trainer, buf, agent = _build(env_id, N, T, **kw)
+        cfg.amd_rollout_kernel = kernel
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, agent)
+        assert drv.fused
+        drv.reset_and_buffer_init()
+        for _ in range(2):  # the second rollout starts from the first one's env state / step counters
+            drv.actor_rollout()
+            drv.compute_returns()
+            bufs.append({f: getattr(buf.data, f).cpu().numpy().copy() for f in
+                         ("actions", "policy_obs", "rewards", "masks", "active_masks", "bad_masks", "value_preds",
+                          "action_log_probs", "returns")})
+            buf.data.after_update()
+        stats.append((env.env_state.cpu().numpy().copy(), env.ep_stats.cpu().numpy().copy()))
+    for a, b in ((bufs[0], bufs[2]), (bufs[1], bufs[3])):
+        if isinstance(kind, str) and kind.startswith("box"):
+            np.testing.assert_allclose(a["actions"], b["actions"], rtol=1e-5, atol=2e-6)
+            same = np.ones_like(a["actions"], dtype=bool)
+        else:
+            same = a["actions"] == b["actions"]
+        assert same.mean() >= 0.999, same.mean()
+        if env_id.startswith("Synthetic"):
+            for f in ("policy_obs", "rewards", "masks", "active_masks", "bad_masks"):
+                assert np.array_equal(a[f], b[f]), f
+            # (the chain kernel's values come from the bf16-split sweep - fp32 accuracy, another rounding pattern)
+            np.testing.assert_allclose(a["value_preds"], b["value_preds"], rtol=2e-5, atol=3e-6)
+            np.testing.assert_allclose(a["action_log_probs"][same], b["action_log_probs"][same], rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(a["returns"], b["returns"], rtol=1e-4, atol=1e-5)
+        else:  # CartPole: an env whose action flipped once is on another trajectory from there on, and the physics amplifies
+            #    the few-ulp differences of the two kernels' step arithmetic: the first steps tightly, the rest loosely
+            ok_env = same.all(axis=(0, 2, 3))
+            assert ok_env.mean() >= 0.97, ok_env.mean()
+            for f in ("policy_obs", "rewards", "masks", "value_preds", "action_log_probs"):
+                np.testing.assert_allclose(a[f][:4], b[f][:4], rtol=2e-5, atol=2e-6, err_msg=f)
+                np.testing.assert_allclose(a[f][:, ok_env], b[f][:, ok_env], rtol=2e-3, atol=2e-4, err_msg=f)
+    if env_id.startswith("Synthetic"):
+        assert np.array_equal(stats[0][0], stats[1][0]) and np.array_equal(stats[0][1], stats[1][1])
+
+
 def test_fused_rollout_teacher_forced_vs_oracle_towers():
     N, T = 64, 16
     cfg, env, net, trainer, buf, agent = _build("SyntheticFixedStep-v0", N, T, obs_dim=5, episode_limit=6)
