@@ -217,8 +217,8 @@ def main():
     ap.add_argument("--rollout-kernel", default="chain", choices=["chain", "lockstep"],
                     help="cfg.amd_rollout_kernel: chain = round 6's policy-only step chain + batched critic sweep (default), "
                          "lockstep = the round-5 kernel (comparison)")
-    ap.add_argument("--optim-step", default="step", choices=["step", "two_launch", "fused"],
-                    help="cfg.amd_optim_step: step = orl_ppo_step, one launch (default); two_launch = reduce + apply launches")
+    ap.add_argument("--optim-step", default="two_launch", choices=["two_launch", "step", "fused"],
+                    help="cfg.amd_optim_step: two_launch = reduce + apply launches (default); step = orl_ppo_step, one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--tower-gemm", default="split", choices=["split", "fp32"],

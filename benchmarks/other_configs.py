@@ -94,7 +94,7 @@ def measure(c, steps=3, warmup=2, dev="cuda:0"):
         # bracket that group (= dominant_kernel_ms); the split between its kernels is in the rocprofv3 CSV of
         # benchmarks/cfg4_mpe_bench.py (profiles/r05_cfg4_mpe_kernel_stats.csv)
         out["ms_per_epoch_fwd_bwd_launch_group"] = round(k_ms, 4)
-        out["launch_group"] = "rnn row kernel (both towers) + rnn_wgrad_kernel + 2 x reduce_pair, one orl_rnn_ppo_fwd_bwd call"
+        out["launch_group"] = "rnn row kernel (both towers) + rnn_wgrad_kernel + rnn_reduce4_kernel, one orl_rnn_ppo_fwd_bwd call"
     return out
 
 

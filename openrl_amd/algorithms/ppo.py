@@ -192,7 +192,7 @@ class PPOAlgorithm(BaseAlgorithm):
         self._sums = torch.zeros(self._raw_p + self._raw_c, dtype=torch.float32, device=dev)
         # reduce + optimiser step of an MLP-tower minibatch in two launches (default) or in one (orl_ppo_reduce_apply:
         # built, bit-identical, 1 % slower - the comparison switch amd_optim_step)
-        self._optim_step = str(getattr(cfg, "amd_optim_step", "step"))
+        self._optim_step = str(getattr(cfg, "amd_optim_step", "two_launch"))
         self._fused_step = self._optim_step in ("fused", "step")
         self._sync_ctr = torch.zeros(4, dtype=torch.int32, device=dev)  # its tickets; every launch leaves them zero
         # multi-GPU: the one-shot xGMI all-reduce of the sums vector, fused into the optimiser-step launches (MLP towers)

@@ -52,9 +52,12 @@ AMD_FLAGS = [
     # (orl_ppo_reduce_apply: ticketed workgroups, the last one of a tower steps it) - same results bit for bit, but the
     # device-scope release / acquire around the ticket (L2 write-back + invalidate across the 8 XCDs) costs more than the
     # kernel boundary it removes: 15.7 us against 4.4 + 9.3 us, iteration + 1 %.
-    # Round 6: "step" (default) = orl_ppo_step: ONE launch with two DESIGNATED optimiser workgroups that fetch parameters and
-    # moments while the column sums are formed and read them - published write-through - behind a ticket word; no cache fence.
-    ("amd_optim_step", "str", "step", "opt", ["step", "two_launch", "fused"]),
+    # Round 6: "step" = orl_ppo_step: ONE launch with two DESIGNATED optimiser workgroups that fetch parameters and moments
+    # while the column sums are formed and read them - published write-through - behind a ticket word; no cache fence.  Same
+    # results bit for bit, and the same time: 14.3 us against 4.7 + 9.7 us (profiles/r06_experiments.md) - the step is a chain of
+    # memory round trips (partials -> sums -> published -> fetched -> clip -> Adam -> stores), the kernel boundary was never the
+    # cost.  The two-launch form stays the default.
+    ("amd_optim_step", "str", "two_launch", "opt", ["two_launch", "step", "fused"]),
     # general (non-default) feed-forward towers: "fused" = the cross-layer kernels of csrc/orl_gen_tower.h where they take
     # the shape (hidden_size 64 / 128), "layerwise" = one launch per layer and direction everywhere.
     ("amd_gen_update", "str", "fused", "opt", ["fused", "layerwise"]),

@@ -47,7 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ORL_WBS 80
 #endif
 constexpr int WBS = ORL_WBS;
-constexpr int WB_IMG_FLOATS = 3 * HID * WBS / 2;   // three parts x 64 rows, in floats (6 912)
+constexpr int WB_IMG_FLOATS = 3 * HID * WBS / 2;   // three parts x 64 rows, in floats (7 680 at WBS = 80)
 
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }

@@ -27,9 +27,16 @@ namespace orl {
 
 constexpr int RS_NIMG = 7;                     // W2 | Wih r z n | Whh r z n
 constexpr int RS_NSLOT = 4;                    // LDS ring slots
-constexpr int RS_IMG_FLOATS = WB_IMG_FLOATS;   // 6 912 floats
+constexpr int RS_IMG_FLOATS = WB_IMG_FLOATS;   // 7 680 floats at WBS = 80
+// the streamed ring + the widest tower image must fit the CU: checked at build time for the largest supported observation
+// (a future WBS change fails here instead of returning ORL_E_UNSUPPORTED at run time)
 constexpr int RS_IMG_BYTES = RS_IMG_FLOATS * 4;  // 27 648 B = 27 x 1 KiB
 static_assert(RS_IMG_BYTES % 1024 == 0, "an image is a whole number of 1 KiB DMA blocks");
+// the ring beside the widest tower's resident arrays (obs 64: W1 64 x 64, ~24 vectors of 64, the 16 x W2S head image) and the
+// flag rows must fit the CU's 160 KiB - at build time (WBS 72 -> 80 grew the ring by 12 KB; only the run-time check
+// of launch_rnn_rows_stream guarded it)
+static_assert((RS_NSLOT * RS_IMG_FLOATS + HID * 64 + 24 * HID + 16 * W2S + RS_NSLOT * 64 + 16) * 4 <= 160 * 1024,
+              "the streamed row kernel's LDS ring does not fit beside the widest tower: shrink WBS or RS_NSLOT");
 constexpr int RS_SPIN_LIMIT = 1 << 22;         // polls (~100 cycles each) before a wait is declared dead: ~0.2 s
 
 // global images of one optimiser step: grid (7 images, 2 towers), any block size

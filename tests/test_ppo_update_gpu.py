@@ -266,8 +266,8 @@ def test_next_epoch_permutation_in_the_apply_launch_changes_nothing(case):
 def test_one_launch_optimiser_step_equals_the_two_launch_one_bit_for_bit(case, perm_mode, turn_on, one_launch):
     """The one-launch optimiser steps == orl_ppo_reduce_pair + orl_ppo_apply(_perm): weights, Adam moments, sums, train_info,
     ValueNorm state and every epoch's indices identical; the ticket words are back at zero after every call.
-    ``step`` = orl_ppo_step (round 6, the default: two designated optimiser workgroups wait for the write-through column
-    sums behind a ticket word); ``fused`` = orl_ppo_reduce_apply (round 5's ticketed form behind cache fences, a
+    ``step`` = orl_ppo_step (round 6: two designated optimiser workgroups wait for the write-through column sums behind a
+    ticket word - same time as two launches, so not the default); ``fused`` = orl_ppo_reduce_apply (round 5's ticketed form behind cache fences, a
     comparison kernel)."""
     if case == "train_cfg2_full" and (perm_mode, turn_on) != ("device", True):
         pytest.skip("the full-size case runs once")
@@ -275,7 +275,7 @@ def test_one_launch_optimiser_step_equals_the_two_launch_one_bit_for_bit(case, p
     outs = []
     for step in (one_launch, "two_launch"):
         cfg, module, buf, algo = _cfg2_full_engine(g) if case == "train_cfg2_full" else build_engine(g)
-        assert algo._optim_step == "step" and algo._fused_step  # orl_ppo_step is the default since round 6
+        assert algo._optim_step == "two_launch" and not algo._fused_step  # two launches are the default (equal time, simpler)
         algo._optim_step, algo._fused_step = step, step != "two_launch"
         algo.perm_mode = perm_mode
         info = [dict(algo.train(buf, turn_on=turn_on)) for _ in range(2)]  # the second call starts from a used ticket array

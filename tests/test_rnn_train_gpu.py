@@ -23,12 +23,16 @@ def _assert_thetas(g, module):
     >= 99 % of the entries), then the historical check on theta_1."""
     for name, k0, k1 in (("policy", "theta_p0", "theta_p1"), ("critic", "theta_c0", "theta_c1")):
         got = module.models[name].theta.cpu().numpy()
-        try:
-            blocks = H.blocks_of(module.models[name], recurrent=True)
-            if sum(n for _, n in blocks.values()) != g[k0].size:  # (a general recurrent tower: another flat layout)
-                blocks = None
-        except AttributeError:  # (general towers keep their layout elsewhere)
+        # The per-block bar needs the tower's flat layout.  Only GENERAL towers (non-default MLPBase shapes: another flat
+        # layout, kept by their own module) may go without it; for the default recurrent tower a missing or mis-sized block
+        # table is a test failure, not a silent fallback to the global bar (ADVICE r5).
+        model = module.models[name]
+        if getattr(module, "generic", False):  # PPOModule.generic: the layer-wise general path (modules/generic_net.py)
             blocks = None
+        else:
+            blocks = H.blocks_of(model, recurrent=True)
+            assert sum(n for _, n in blocks.values()) == g[k0].size, (
+                f"{name}: the block table covers {sum(n for _, n in blocks.values())} of {g[k0].size} parameters")
         H.assert_update_parity(g[k0], got, g[k1], name, blocks=blocks)  # + the per-block bar (W1 .. Wih / Whh .. b3)
         np.testing.assert_allclose(got, g[k1], rtol=THETA_RTOL, atol=THETA_ATOL)
 
