@@ -19,7 +19,7 @@ ROWS, REC_BYTES = 4096 * 128, 64
 KEYS = [("gae_scan", "gae_scan_kernel"), ("adv_normalize_pack", "adv_normalize_pack_kernel"),
         ("ppo_tower_pair", "ppo_tower_pair_kernel"),  # both towers in one launch (the default build)
         ("ppo_tower_policy", "ppo_tower_kernel<1,"), ("ppo_tower_critic", "ppo_tower_kernel<0,"),
-        ("rollout_fused", "rollout_kernel"), ("ppo_apply", "ppo_apply_kernel"), ("ppo_reduce_pair", "ppo_reduce_pair_kernel")]
+        ("rollout_chain", "rollout2_kernel"), ("rollout_fused", "rollout_kernel"), ("ppo_apply", "ppo_apply_kernel"), ("ppo_reduce_pair", "ppo_reduce_pair_kernel")]
 
 
 def per_kernel(path, counter):
