@@ -137,6 +137,10 @@ def test_fused_rollout_equals_stepwise_rollout(env_id, kw, N, T):
     ("SyntheticFixedStep-v0", dict(obs_dim=17, episode_limit=9, action_space="box6"), 1024, 50),
     ("SyntheticFixedStep-v0", dict(obs_dim=18, episode_limit=9, action_space="disc9"), 130, 20),
     ("SyntheticFixedStep-v0", dict(obs_dim=5, episode_limit=9, action_space="box2"), 40, 11),
+    # degenerate sizes: fewer envs than a tile, fewer steps than the rings are deep / than there are critic waves
+    ("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=3), 3, 1),
+    ("CartPole-v1", {}, 17, 2),
+    ("SyntheticFixedStep-v0", dict(obs_dim=8, episode_limit=4), 33, 5),
 ])
 def test_chain_rollout_kernel_equals_the_lockstep_kernel(env_id, kw, N, T):
     """Round 6: the policy-only chain kernel (csrc/orl_rollout2.h: head from per-wave partials of LayerNorm 2, services on
