@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--env", default="synthetic", choices=["synthetic", "cartpole"],
                     help="synthetic = the metric's fixed-step env of the named shape (the headline); cartpole = the same "
                          "configuration on the device CartPole-v1 physics (a measurement beside the headline)")
-    ap.add_argument("--rollout-kernel", default="chain", choices=["chain", "chain_nospec", "lockstep"],
+    ap.add_argument("--rollout-kernel", default="chain", choices=["chain", "lockstep"],
                     help="cfg.amd_rollout_kernel: chain = round 6's policy-only step chain + batched critic sweep (default), "
                          "lockstep = the round-5 kernel (comparison)")
     ap.add_argument("--optim-step", default="two_launch", choices=["two_launch", "step", "fused"],

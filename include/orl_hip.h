@@ -435,10 +435,9 @@ typedef struct orl_rollout_args {
   const float* opp_thetas; /* parameters of policy g at opp_thetas + g*opp_theta_stride */
   int64_t opp_theta_stride;
   int32_t opp_group_rows;  /* envs [g*opp_group_rows, ...) play policy g; a multiple of 16 */
-  int32_t opp_reserved;    /* ORL_ENV_SYNTH / ORL_ENV_CARTPOLE: 0 = the round-6 rollout (the policy's step chain on its own waves,
-                            * the critic on background waves; on Discrete(2) with <= 4 observation columns the policy tower
-                            * speculated over both actions), 1 = the round-5 kernel (both towers in one step loop), 2 = the
-                            * round-6 chain without the speculation.  Ignored by the tic-tac-toe envs. */
+  int32_t opp_reserved;    /* ORL_ENV_SYNTH / ORL_ENV_CARTPOLE: 0 = the round-6 rollout (policy-only step chain + one batched
+                            * critic sweep over the T + 1 stored observation slots), 1 = the round-5 kernel (both towers
+                            * in the step loop).  Ignored by the tic-tac-toe envs. */
   uint64_t opp_seed;       /* Philox seed of the opponents' sampling; counter = (env, opp_rng_step0 + t) */
   uint64_t opp_rng_step0;
   const int32_t* opp_index; /* optional [N]: env n plays pool policy opp_index[n] instead of n / opp_group_rows; unless

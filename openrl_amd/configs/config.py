@@ -25,9 +25,7 @@ AMD_FLAGS = [
     # fused rollout of the single-agent device envs (synthetic, CartPole): "chain" (round 6, default) = the policy-only dependent
     # chain of csrc/orl_rollout2.h + one batched critic sweep over the stored observations; "lockstep" = the round-5 kernel
     # (policy and critic towers in the step loop) - the comparison switch.  Tic-tac-toe always runs the round-5 kernel.
-    # On Discrete(2) with observations of <= 4 columns (configs[1]: CartPole, the synthetic env of its shape) "chain" also
-    # speculates the policy tower over both actions (csrc/orl_rollout3.h); "chain_nospec" = the chain without that (A/B switch).
-    ("amd_rollout_kernel", "str", "chain", "opt", ["chain", "chain_nospec", "lockstep"]),
+    ("amd_rollout_kernel", "str", "chain", "opt", ["chain", "lockstep"]),
     # capture the PPO update epoch in a hipGraph.
     ("amd_use_graph", "bool", True, "opt", None),
     # multi-GPU gradient exchange: "p2p" = the one-shot xGMI push all-reduce fused into the optimiser-step launches

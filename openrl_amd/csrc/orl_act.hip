@@ -925,7 +925,6 @@ __global__ __launch_bounds__(512) void critic_values_kernel(orl_net_desc cnet, c
 }
 
 #include "orl_rollout2.h"
-#include "orl_rollout3.h"
 
 // Stand-alone env.step for device envs (evaluation loops, the stepwise driver): same dynamics and RNG
 // streams as the fused rollout; one thread per env.
@@ -1364,21 +1363,6 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                              \
     hipLaunchKernelGGL((rollout2_kernel<NO, HD, EV, KS>), dim3(grid), dim3(RO2_THREADS), lds2, (hipStream_t)stream, A); \
   } while (0)
-    // Discrete(2) on observations of <= 4 columns (configs[1]: CartPole and the synthetic env of its shape): the chain with the
-    // policy tower speculated over both actions (orl_rollout3.h); args.opp_reserved = 2 keeps the unspeculated chain (A/B switch)
-    if (twp.DP == 4 && pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out == 2 && args->opp_reserved != 2) {
-      const size_t lds3 = (size_t)ro3_lds(twp.total, TowerLds(4, 1, false, false, false, true).total).total * sizeof(float);
-      if (lds3 > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void*)rollout3_kernel<ORL_ENV_SYNTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-        (void)hipFuncSetAttribute((const void*)rollout3_kernel<ORL_ENV_CARTPOLE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds3);
-      }
-      if (args->env_kind == ORL_ENV_CARTPOLE)
-        hipLaunchKernelGGL((rollout3_kernel<ORL_ENV_CARTPOLE>), dim3(grid), dim3(RO3_THREADS), lds3, (hipStream_t)stream, A);
-      else
-        hipLaunchKernelGGL((rollout3_kernel<ORL_ENV_SYNTH>), dim3(grid), dim3(RO3_THREADS), lds3, (hipStream_t)stream, A);
-      return launch_status("orl_rollout_fused");
-    }
     if (args->env_kind == ORL_ENV_CARTPOLE) {
       ORL_RO2_LAUNCH3(2, ORL_HEAD_CATEGORICAL, ORL_ENV_CARTPOLE, 1);
     } else if (twp.DP == 4 && pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out <= 2) {

@@ -43,12 +43,7 @@ constexpr int RO2_RING = 4;   // noise / env-service / staging rings (steps)
 constexpr int RO2_ORING = 8;  // observation ring (slots): the critic waves may lag the chain by a few steps
 constexpr int RO2_STG = 36;   // floats per staged row: actions[16] | log-probs[16] | reward | done | 2 pad
 constexpr int RO2_ENVW = 8;   // floats per env-service row
-#ifdef ORL_RO2_SHADOW  // TIMING experiment only: waves 12 - 15 run a second copy of the policy trunk beside waves 0 - 3 (results dropped) -
-// what two trunk groups sharing the four SIMDs cost the chain (profiles/r06_experiments.md section 7)
-constexpr int RO2_THREADS = 1024;
-#else
 constexpr int RO2_THREADS = 768;
-#endif
 // counter words (unsigned, 16-byte groups)
 enum { RC_OBS = 0, RC_STAGE = 1, RC_NOISE = 4, RC_ENV = 5, RC_STORED = 6, RC_ERR = 7, RC_PART = 8, RC_XG = 12, RC_CRIT = 16,
        RC_WORDS = 20 };
@@ -183,15 +178,10 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
   __syncthreads();
   const uint64_t tg0 = A.r.rng_step0;
 
-#ifdef ORL_RO2_SHADOW
-  const bool shadow = wave >= 12;
-#else
-  constexpr bool shadow = false;
-#endif
-  if (wave < 4 || shadow) {
+  if (wave < 4) {
     // ================================================================ the policy chain ==========================
     __builtin_amdgcn_s_setprio(3);
-    const int gw = wave & 3;
+    const int gw = wave;
     CoopRegs creg;
     coop_load(smem, twp, gw, j, q, creg);
     // wide observations: this wave's fc1 A operands W1[16 gw + j][4 s + q] in registers (<= 16 k-steps)
@@ -331,7 +321,7 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
       z = z + z2b;
       R2_T(3);
       // ---- this wave's partials of LayerNorm 2 + head, and the z slice for the guarded path
-      float* pw = shadow ? s_xg + gw * PSLOT : s_part + ((t & 1) * 4 + gw) * PSLOT;
+      float* pw = s_part + ((t & 1) * 4 + gw) * PSLOT;
       const float p1 = (z[0] + z[1]) + (z[2] + z[3]);
       const float p2 = (z[0] * z[0] + z[1] * z[1]) + (z[2] * z[2] + z[3] * z[3]);
       if constexpr (HMM) {
@@ -346,10 +336,6 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
         for (int c = 0; c < NO; ++c)
           pv[2 + c] = (w3s[c][0] * z[0] + w3s[c][1] * z[1]) + (w3s[c][2] * z[2] + w3s[c][3] * z[3]);
         *(f32x4*)(pw + (q * TILE_B + j) * 4) = pv;
-      }
-      if (shadow) {
-        *(f32x4*)(s_xg + 4 * PSLOT + j * 16 + 4 * q) = z;
-        continue;
       }
       *(f32x4*)(s_z2 + (t & 1) * TILE_B * GS + j * GS + 16 * gw + 4 * q) = z;
       ro2_post(ctr + RC_PART + gw, t + 1);
@@ -522,7 +508,7 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
 #ifdef ORL_PROF
     if (prof_on && l < 16) atomicAdd(&g_roll_prof[l], prof_lds[l]);
 #endif
-    if (gw == 0 && !shadow) {
+    if (gw == 0) {
       const bool poisoned = ro2_ld(err) != 0u;
       if (q == 0 && ok) {
 #pragma unroll

@@ -308,11 +308,8 @@ class OnPolicyDriver:
                                mod.act_seed & (2 ** 64 - 1), env.global_step)
         if hasattr(env, "fill_rollout_args"):  # env-specific extras (the self-play opponent pool)
             env.fill_rollout_args(args)
-        rk = getattr(self.cfg, "amd_rollout_kernel", "chain")
-        if rk == "lockstep":  # the round-5 kernel (comparison switch)
+        if getattr(self.cfg, "amd_rollout_kernel", "chain") == "lockstep":  # the round-5 kernel (comparison switch)
             args.opp_reserved = 1
-        elif rk == "chain_nospec":  # the chain kernel without the two-action speculation (comparison switch)
-            args.opp_reserved = 2
         ops.rollout_fused(p.net, p.theta, c.net, c.theta, args, self._next_value)
         if hasattr(env, "after_fused_rollout"):
             env.after_fused_rollout(self.episode_length)

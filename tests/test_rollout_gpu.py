@@ -195,47 +195,6 @@ def test_chain_rollout_kernel_equals_the_lockstep_kernel(env_id, kw, N, T):
         assert np.array_equal(stats[0][0], stats[1][0]) and np.array_equal(stats[0][1], stats[1][1])
 
 
-@pytest.mark.parametrize("env_id,kw,N,T", [
-    ("CartPole-v1", {}, 200, 60),
-    ("CartPole-v1", {}, 4096, 128),
-    ("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=7), 50, 23),
-    ("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=200), 4096, 128),
-    ("SyntheticFixedStep-v0", dict(obs_dim=3, episode_limit=5), 19, 9),
-    ("CartPole-v1", {}, 17, 2),
-    ("SyntheticFixedStep-v0", dict(obs_dim=4, episode_limit=3), 3, 1),
-])
-def test_speculative_rollout_kernel_equals_the_chain_kernel(env_id, kw, N, T):
-    """csrc/orl_rollout3.h (the policy tower evaluated on BOTH candidate next observations of a Discrete(2) env while the step
-    that decides between them is still being finished) against csrc/orl_rollout2.h (one step after the other): the selected
-    candidate is computed with the chain kernel's own arithmetic, so EVERYTHING the policy side writes is bit-identical -
-    actions, log-probabilities, observations, rewards, masks, env state, episode statistics - over three consecutive
-    rollouts; the critic's values are the same kernel code on the same observations (bit-identical too).  (HIP against HIP:
-    the chain kernel's own evidence is test_chain_rollout_kernel_equals_the_lockstep_kernel and the stepwise / oracle tests.)"""
-    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
-
-    runs = []
-    for kernel in ("chain", "chain_nospec"):
-        cfg, env, net, trainer, buf, agent = _build(env_id, N, T, **kw)
-        cfg.amd_rollout_kernel = kernel
-        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, agent)
-        assert drv.fused
-        drv.reset_and_buffer_init()
-        out = []
-        for _ in range(3):
-            drv.actor_rollout()
-            drv.compute_returns()
-            out.append({f: getattr(buf.data, f).clone() for f in
-                        ("actions", "action_log_probs", "policy_obs", "rewards", "masks", "active_masks", "bad_masks",
-                         "value_preds", "returns")})
-            buf.data.after_update()
-        runs.append((out, env.env_state.clone(), env.ep_stats.clone()))
-    (a, sa, ea), (b, sb, eb) = runs
-    for ra, rb in zip(a, b):
-        for f in ra:
-            assert torch.equal(ra[f], rb[f]), f
-    assert torch.equal(sa, sb) and torch.equal(ea, eb)
-
-
 def test_fused_rollout_teacher_forced_vs_oracle_towers():
     N, T = 64, 16
     cfg, env, net, trainer, buf, agent = _build("SyntheticFixedStep-v0", N, T, obs_dim=5, episode_limit=6)
