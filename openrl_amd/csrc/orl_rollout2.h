@@ -184,11 +184,12 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
     const int gw = wave;
     CoopRegs creg;
     coop_load(smem, twp, gw, j, q, creg);
-    // wide observations: this wave's fc1 A operands W1[16 gw + j][4 s + q] in registers (<= 16 k-steps)
-    float w1w[KS > 0 ? 1 : 16];
+    // wide observations: this wave's fc1 A operands W1[16 gw + j][4 s + q] of the first 8 k-steps in registers (observations
+    // of <= 32 columns: cfg3's 17, cfg5's 18); k-steps beyond come from the LDS image every step
+    float w1w[KS > 0 ? 1 : 8];
     if constexpr (KS == 0) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
+      for (int s = 0; s < 8; ++s)
         w1w[s] = (DP > COOP_SMALL_DP && 4 * s < DP) ? smem[twp.W1 + (16 * gw + j) * DP + 4 * s + q] : 0.f;
     }
     // head operands of this wave's 16 features: narrow W3g[c][16 gw + 4 q ..], wide the MFMA fragment W3P[j][16 gw + 4 q ..]
@@ -288,8 +289,10 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
         } else {
           f32x4 acc = creg.b1;
 #pragma unroll
-          for (int s = 0; s < 16; ++s)
+          for (int s = 0; s < 8; ++s)
             if (4 * s < DP) acc = ORL_MFMA(w1w[KS > 0 ? 0 : s], cur[j * DP + 4 * s + q], acc);
+          for (int s = 8; 4 * s < DP; ++s)
+            acc = ORL_MFMA(smem[twp.W1 + (16 * gw + j) * DP + 4 * s + q], cur[j * DP + 4 * s + q], acc);
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
           float* xg = s_xg + (t & 1) * TILE_B * GS;
@@ -442,6 +445,7 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
         for (int r = 0; r < 4; ++r) {
           const int c = 4 * q + r;
           if (c < n_out) {
+            // (hoisting log std / std out of the step loop costs 8 registers this build does not have at 768 threads: it spilled)
             const float ls = smem[twp.logstd + c];
             const float sd = expf(ls);
             const float av = lgv[r] + sd * nz4[r];
