@@ -30,6 +30,8 @@ def main():
                     help="pool opponent assignment: per_reset = the reference's per-episode draw (stepwise rollout as a "
                          "hipGraph, per-env pool act launch); per_rollout / static keep one snapshot per 16-env tile, "
                          "which the fused rollout kernel plays in-kernel")
+    ap.add_argument("--rollout-kernel", default="chain", choices=["chain", "lockstep"],
+                    help="random opponent: the round-6 chain kernel or the round-5 lock-step kernel (A/B)")
     a = ap.parse_args()
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers import NormalReplayBuffer
@@ -39,7 +41,8 @@ def main():
     from openrl_amd.modules.common import PPONet
 
     dev, N, T = "cuda:0", a.envs, a.T
-    cfg = default_cfg(["--seed", "0", "--episode_length", str(T), "--amd_perm_mode", "device", "--log_interval", "1000000"])
+    cfg = default_cfg(["--seed", "0", "--episode_length", str(T), "--amd_perm_mode", "device", "--log_interval", "1000000",
+                       "--amd_rollout_kernel", a.rollout_kernel])
     kw = dict(opponent_sampling=a.sampling) if a.opponent == "pool" else {}
     env = make("tictactoe_v3", env_num=N, device=dev, opponent=a.opponent, **kw)
     if a.opponent == "pool":

@@ -435,9 +435,9 @@ typedef struct orl_rollout_args {
   const float* opp_thetas; /* parameters of policy g at opp_thetas + g*opp_theta_stride */
   int64_t opp_theta_stride;
   int32_t opp_group_rows;  /* envs [g*opp_group_rows, ...) play policy g; a multiple of 16 */
-  int32_t opp_reserved;    /* ORL_ENV_SYNTH / ORL_ENV_CARTPOLE: 0 = the round-6 rollout (policy-only step chain + one batched
-                            * critic sweep over the T + 1 stored observation slots), 1 = the round-5 kernel (both towers
-                            * in the step loop).  Ignored by the tic-tac-toe envs. */
+  int32_t opp_reserved;    /* ORL_ENV_SYNTH / ORL_ENV_CARTPOLE / ORL_ENV_TTT: 0 = the round-6 chain rollout (policy-only step chain, the
+                            * critic on background waves of the same launch), 1 = the round-5 kernel (both towers in the
+                            * step loop).  Ignored by the tic-tac-toe POOL envs (always the round-5 kernel). */
   uint64_t opp_seed;       /* Philox seed of the opponents' sampling; counter = (env, opp_rng_step0 + t) */
   uint64_t opp_rng_step0;
   const int32_t* opp_index; /* optional [N]: env n plays pool policy opp_index[n] instead of n / opp_group_rows; unless

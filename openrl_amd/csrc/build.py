@@ -48,7 +48,8 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str
     srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     # build-time A/B switches for kernel experiments (e.g. ORL_BUILD_DEFS="-DORL_TOWER_ILV"); never read at run time
     extra = os.environ.get("ORL_BUILD_DEFS", "").split()
-    dig = _digest() + ("-prof" if prof else "") + "".join(extra)  # a library built with other switches is not up to date
+    compress = os.environ.get("ORL_NO_OFFLOAD_COMPRESS", "") == ""
+    dig = _digest() + ("-prof" if prof else "") + ("-oc" if compress else "") + "".join(extra)  # a library built with other switches is not up to date
     if not force and os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as fh:
             if fh.read().strip() == dig:
@@ -58,6 +59,10 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str
     # the bench iteration, every parity test unchanged); the buffer kernels are NOT (the GAE scan is bit-exact with
     # the reference's operation order) and neither is the MPE physics (compared with a float64 reference).
     base = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    # the gfx950 code objects are stored compressed in the fat binary (10.3 -> 2.75 MB; the HIP runtime inflates them when the
+    # library is loaded: no difference in load time, first-launch time or anything after - tools/r06_calls/r06_call13.sh)
+    if compress:
+        base.append("--offload-compress")
     base += extra
     if prof:  # phase-timing build of the tower kernels (orl_debug_prof); never the shipped configuration
         base.append("-DORL_PROF")

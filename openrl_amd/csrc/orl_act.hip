@@ -1354,8 +1354,8 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
                       sizeof(float);
   // (the widest towers - observations of ~60 columns with 16 outputs - do not fit the chain kernel's rings beside both tower
   // images: they keep the round-5 kernel)
-  if ((args->env_kind == ORL_ENV_SYNTH || args->env_kind == ORL_ENV_CARTPOLE) && args->opp_reserved != 1 &&
-      lds2 <= 160 * 1024) {
+  if ((args->env_kind == ORL_ENV_SYNTH || args->env_kind == ORL_ENV_CARTPOLE || args->env_kind == ORL_ENV_TTT) &&
+      args->opp_reserved != 1 && lds2 <= 160 * 1024) {
 #define ORL_RO2_LAUNCH3(NO, HD, EV, KS)                                                                               \
   do {                                                                                                               \
     if (lds2 > 48 * 1024)                                                                                            \
@@ -1365,6 +1365,8 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   } while (0)
     if (args->env_kind == ORL_ENV_CARTPOLE) {
       ORL_RO2_LAUNCH3(2, ORL_HEAD_CATEGORICAL, ORL_ENV_CARTPOLE, 1);
+    } else if (args->env_kind == ORL_ENV_TTT) {
+      ORL_RO2_LAUNCH3(16, ORL_HEAD_CATEGORICAL, ORL_ENV_TTT, 0);  // the random opponent (the pool variants keep the round-5 kernel)
     } else if (twp.DP == 4 && pnet->head_kind == ORL_HEAD_CATEGORICAL && pnet->n_out <= 2) {
       ORL_RO2_LAUNCH3(2, ORL_HEAD_CATEGORICAL, ORL_ENV_SYNTH, 1);  // configuration 2's shape: fc1's single k-step at compile time
     } else {

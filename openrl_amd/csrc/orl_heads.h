@@ -68,12 +68,18 @@ __device__ inline void sample_head(float (&hd)[NO], int n_out, const float* lds_
 // cat_lse + cat_sample + pick (masked classes at -6e4, inverse CDF in class order, fall back to the last class of
 // non-zero probability); the sums associate per lane first, so results agree with sample_head to fp32 round-off.
 // Every lane of the row returns the action and its log-probability.
+// (the mask of this lane's four classes as a value: the chain rollout derives it from the board word in registers)
+__device__ inline void sample_cat_frag_v(const f32x4& lgv, int n_out, int q, const f32x4 mk, float u, float& act, float& logp);
 __device__ inline void sample_cat_frag(const f32x4& lgv, int n_out, int q, const float* __restrict__ mask_row, float u,
                                        float& act, float& logp) {
-  // Branch-free: the four classes of a lane go through selects (the short-circuit form compiled to ~20 exec-mask
-  // branches on the step's serial chain).  mask_row = 16 floats, 16-byte aligned; classes >= n_out drop out through
-  // val[] exactly as before (their terms are +0 in every sum).
+  // mask_row = 16 floats, 16-byte aligned
   const f32x4 mk = mask_row != nullptr ? *(const f32x4*)(mask_row + 4 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
+  sample_cat_frag_v(lgv, n_out, q, mk, u, act, logp);
+}
+__device__ inline void sample_cat_frag_v(const f32x4& lgv, int n_out, int q, const f32x4 mk, float u, float& act, float& logp) {
+  // Branch-free: the four classes of a lane go through selects (the short-circuit form compiled to ~20 exec-mask
+  // branches on the step's serial chain).  Classes >= n_out drop out through val[] exactly as before (their terms are +0
+  // in every sum).
   float lg[4];
   bool val[4];
   float mx = -3.0e38f;

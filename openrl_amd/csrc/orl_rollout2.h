@@ -49,13 +49,14 @@ enum { RC_OBS = 0, RC_STAGE = 1, RC_NOISE = 4, RC_ENV = 5, RC_STORED = 6, RC_ERR
        RC_WORDS = 20 };
 
 struct Ro2Lds {
-  int critic, obs, xg, part, z2, noise, env, stage, ctr, total;  // float offsets
+  int critic, obs, word, xg, part, z2, noise, env, stage, ctr, total;  // float offsets
 };
 __host__ __device__ inline Ro2Lds ro2_lds(int policy_total, int critic_total, int DP) {
   Ro2Lds L;
   int o = policy_total;
   L.critic = o; o += critic_total;
   L.obs = o; o += RO2_ORING * TILE_B * DP;
+  L.word = o; o += RO2_ORING * TILE_B * 3;  // tic-tac-toe: [slot]{board word, opponent moves, episode}[row]
   L.xg = o; o += 2 * TILE_B * GS;
   L.part = o; o += 2 * 4 * (TILE_B * 16 + 4 * TILE_B * 2);  // [slot][wave]{16 x 16 logits | [q][row] 2 stats}; narrow heads use the head of it
   L.z2 = o; o += 2 * TILE_B * GS;
@@ -169,6 +170,29 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
   const int n_out = A.pnet.n_out;
   const int a_w = (HEAD == ORL_HEAD_CATEGORICAL) ? 1 : n_out;
   const bool sep_c = b.critic_obs != b.policy_obs;
+  // Tic-tac-toe vs the random opponent (ORL_ENV_TTT, round 6): the observation of a row travels as ONE board word - agent bits
+  // | opponent bits << 9 | valid << 18 (the round-5 kernel's form) - from which the trunk waves expand their fc1 operands
+  // (feature d = cell d >> 1 of player d & 1), wave 0 the legal-move mask of its four classes, the store wave the 18 + 9
+  // floats of the buffer rows; the env service draws the step's three Philox words (opponent reply, who opens the next game,
+  // its opening move) from the row's (episode, opponent moves) while the policy works.
+  constexpr bool IS_TTT = ENV == ORL_ENV_TTT;
+  int* s_word = (int*)(smem + L.word);               // [slot][16]
+  int* s_meta = s_word + RO2_ORING * TILE_B;        // [slot][2][16]: opponent moves this game, episode
+  auto ttt_operand_bits = [&](int w) -> int { return (w >> ((q & 1) * 9 + (q >> 1))) & (q < 2 ? 0x155 : 0x55); };
+  if (IS_TTT && threadIdx.x < TILE_B) {
+    const int jj = threadIdx.x, nn = n0 + jj;
+    int ta = 0, to = 0, mv = 0, epi = 0;
+    if (nn < N) {
+      const float* st = A.r.env_state + (size_t)nn * TTT_STATE_W;
+      for (int c = 0; c < 9; ++c) {
+        ta |= (st[c] == 1.f ? 1 : 0) << c;
+        to |= (st[c] == 2.f ? 1 : 0) << c;
+      }
+      mv = (int)st[9]; epi = (int)st[10];
+    }
+    s_word[jj] = nn < N ? (ta | (to << 9) | (1 << 18)) : 0;
+    s_meta[jj] = mv; s_meta[TILE_B + jj] = epi;
+  }
   // slot 0 of the observation ring comes from the buffer (after_update / init_buffer put it there)
   for (int e = threadIdx.x; e < TILE_B * DP; e += blockDim.x) {
     const int jj = e / DP, k = e - jj * DP;
@@ -190,7 +214,7 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
     if constexpr (KS == 0) {
 #pragma unroll
       for (int s = 0; s < 8; ++s)
-        w1w[s] = (DP > COOP_SMALL_DP && 4 * s < DP) ? smem[twp.W1 + (16 * gw + j) * DP + 4 * s + q] : 0.f;
+        w1w[s] = (DP > COOP_SMALL_DP && 4 * s < DP && (!IS_TTT || s < 5)) ? smem[twp.W1 + (16 * gw + j) * DP + 4 * s + q] : 0.f;
     }
     // head operands of this wave's 16 features: narrow W3g[c][16 gw + 4 q ..], wide the MFMA fragment W3P[j][16 gw + 4 q ..]
     static_assert(HMM || NO <= 2, "narrow heads: two classes ride in the 4-float partial");
@@ -226,7 +250,7 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
       }
     }
     // env state of the tile's rows (every lane of a row keeps a copy; lanes q == 0 write)
-    constexpr int SW = ENV == ORL_ENV_SYNTH ? SYNTH_STATE_W : CARTPOLE_STATE_W;
+    constexpr int SW = ENV == ORL_ENV_SYNTH ? SYNTH_STATE_W : IS_TTT ? 0 : CARTPOLE_STATE_W;  // (tic-tac-toe: bitboards below)
     float est[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ep_ret = 0.f, ep_len = 0.f, fin_ret = 0.f, fin_cnt = 0.f;
     if (gw == 0 && ok) {
@@ -234,6 +258,12 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
       for (int k = 0; k < 8; ++k) est[k] = k < SW ? A.r.env_state[(size_t)n * SW + k] : 0.f;
       ep_ret = A.r.ep_stats[n * 4 + 0]; ep_len = A.r.ep_stats[n * 4 + 1];
       fin_ret = A.r.ep_stats[n * 4 + 2]; fin_cnt = A.r.ep_stats[n * 4 + 3];
+    }
+    int tA = 0, tO = 0, tmoves = 0, tep = 0;  // tic-tac-toe: this row's bitboards and counters (wave 0)
+    if (IS_TTT && gw == 0) {
+      const int w0 = s_word[j];
+      tA = w0 & 0x1FF; tO = (w0 >> 9) & 0x1FF;
+      tmoves = s_meta[j]; tep = s_meta[TILE_B + j];
     }
     asm volatile("" : "+v"(ep_ret), "+v"(ep_len), "+v"(fin_ret), "+v"(fin_cnt));
 #pragma unroll
@@ -270,6 +300,11 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
       } else {
         ro2_wait<false>(ctr + RC_OBS, t + 1, err);
         R2_T(0);
+        const int wq = IS_TTT ? ttt_operand_bits(s_word[(t & (RO2_ORING - 1)) * TILE_B + j]) : 0;
+        auto xop = [&](int s) -> float {
+          if constexpr (IS_TTT) return (float)((wq >> (2 * s)) & 1);
+          else return cur[j * DP + 4 * s + q];
+        };
         // ---- fc1 + relu (small observations: all four M-tiles in every wave; wide: own M-tile, all-gather through LDS)
         if (DP <= COOP_SMALL_DP) {
 #pragma unroll
@@ -277,7 +312,7 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             if (4 * s < DP) {
-              const float xb = cur[j * DP + 4 * s + q];
+              const float xb = xop(s);
 #pragma unroll
               for (int m = 0; m < 4; ++m) x[m] = ORL_MFMA(creg.w1[m][s], xb, x[m]);
             }
@@ -290,9 +325,9 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
           f32x4 acc = creg.b1;
 #pragma unroll
           for (int s = 0; s < 8; ++s)
-            if (4 * s < DP) acc = ORL_MFMA(w1w[KS > 0 ? 0 : s], cur[j * DP + 4 * s + q], acc);
-          for (int s = 8; 4 * s < DP; ++s)
-            acc = ORL_MFMA(smem[twp.W1 + (16 * gw + j) * DP + 4 * s + q], cur[j * DP + 4 * s + q], acc);
+            if (4 * s < DP && (!IS_TTT || s < 5)) acc = ORL_MFMA(w1w[KS > 0 ? 0 : s], xop(s), acc);  // (tic-tac-toe: DP = 20)
+          for (int s = 8; !IS_TTT && 4 * s < DP; ++s)
+            acc = ORL_MFMA(smem[twp.W1 + (16 * gw + j) * DP + 4 * s + q], xop(s), acc);
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
           float* xg = s_xg + (t & 1) * TILE_B * GS;
@@ -458,7 +493,13 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
         *(f32x4*)(stg + 16 + 4 * q) = lp4;
       } else if constexpr (HMM) {
         float av, lp;
-        sample_cat_frag(lgv, n_out, q, nullptr, nz4[0], av, lp);
+        f32x4 mk = f32x4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (IS_TTT) {  // classes 4 q .. 4 q + 3 of the row's legal moves; an invalid row has class 0 legal
+          const int w0 = tA | (tO << 9);
+          const int emp = (ok ? (~(w0 | (w0 >> 9)) & 0x1FF) : 1) >> (4 * q);
+          mk = f32x4{(float)(emp & 1), (float)((emp >> 1) & 1), (float)((emp >> 2) & 1), (float)((emp >> 3) & 1)};
+        }
+        sample_cat_frag_v(lgv, n_out, q, mk, nz4[0], av, lp);
         act0 = av;
         if (q == 0) { stg[0] = av; stg[16] = lp; }
       } else {
@@ -487,6 +528,35 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
         done = c >= (float)A.r.episode_limit;
         est[0] = done ? 0.f : c;
         // (observation t + 1 is in the ring already: it does not depend on the action)
+      } else if constexpr (IS_TTT) {
+        // orl_ttt_step's game logic on bitboards (every lane of the row runs it: no divergence); the step's draws are wave 6's
+        const uint32_t rx = f2u(envr0[0]), r_begin = f2u(envr0[1]), r_open = f2u(envr0[2]);
+        const int a = (int)act0;
+        const int e0 = ~(tA | tO) & 0x1FF;
+        rew = 0.f; done = false;
+        const bool legal = (unsigned)a < 9u && ((e0 >> a) & 1) != 0;
+        if (!legal) { rew = -1.f; done = true; }
+        else {
+          tA |= 1 << a;
+          if (ttt_wins_bits(tA)) { rew = 1.f; done = true; }
+          else if ((tA | tO) == 0x1FF) done = true;
+          else {
+            tO |= ttt_pick_empty_bits(~(tA | tO) & 0x1FF, rx);
+            ++tmoves;
+            if (ttt_wins_bits(tO)) { rew = -1.f; done = true; }
+            else if ((tA | tO) == 0x1FF) done = true;
+          }
+        }
+        if (done) {
+          ++tep;
+          tA = 0; tO = 0; tmoves = 0;
+          if (r_begin & 1u) { tO = ttt_pick_empty_bits(0x1FF, r_open); tmoves = 1; }
+        }
+        if (q == 0) {
+          const int sl = ((t + 1) & (RO2_ORING - 1));
+          s_word[sl * TILE_B + j] = ok ? (tA | (tO << 9) | (1 << 18)) : 0;
+          s_meta[sl * 2 * TILE_B + j] = tmoves; s_meta[sl * 2 * TILE_B + TILE_B + j] = tep;
+        }
       } else {
         CartPolePre cp;
         cp.costh = envr0[0]; cp.sinth = envr0[1]; cp.t1 = envr0[2]; cp.den = envr0[3];
@@ -518,6 +588,12 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (k < SW) A.r.env_state[(size_t)n * SW + k] = est[k];
+        if constexpr (IS_TTT) {
+          float* st = A.r.env_state + (size_t)n * TTT_STATE_W;
+#pragma unroll
+          for (int c = 0; c < 9; ++c) st[c] = ((tA >> c) & 1) ? 1.f : (((tO >> c) & 1) ? 2.f : 0.f);
+          st[9] = (float)tmoves; st[10] = (float)tep;
+        }
         A.r.ep_stats[n * 4 + 0] = ep_ret; A.r.ep_stats[n * 4 + 1] = ep_len;
         A.r.ep_stats[n * 4 + 2] = poisoned ? u2f(0x7fc00000u) : fin_ret; A.r.ep_stats[n * 4 + 3] = fin_cnt;
       }
@@ -568,6 +644,13 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
             if (d < DP) nxt[j * DP + d] = (ok && d < D) ? o[k] : 0.f;
           }
         }
+      } else if constexpr (IS_TTT) {
+        // the step's three Philox words (ttt_draw: lane group q = 0 the opponent's reply, 1 = who opens the next game, 2 = that
+        // game's opening move) from the (episode, opponent moves) wave 0 published with observation t
+        ro2_wait(ctr + RC_OBS, t + 1, err);
+        const int* mt = s_meta + (t & (RO2_ORING - 1)) * 2 * TILE_B;
+        const int mv = mt[j], epi = mt[TILE_B + j];
+        if (q < 3) er[q] = u2f(ttt_draw(A.r.env_seed, (uint32_t)n, q, (uint32_t)(epi + (q != 0 ? 1 : 0)), (uint32_t)mv));
       } else {
         ro2_wait(ctr + RC_OBS, t + 1, err);
         if (t >= 1) ep += smem[L.stage + (((t - 1) & 3) * TILE_B + j) * RO2_STG + 33];  // done of step t - 1 (staged before obs t)
@@ -603,14 +686,31 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
         b.active_masks[r1 + l] = 1.f;
         b.bad_masks[r1 + l] = 1.f;
       }
-      for (int e = l; e < nrow * D; e += 64) {
-        const int rr = e / D, d = e - rr * D;
-        const float v = nxt[rr * DP + d];
-        b.policy_obs[r1 * D + e] = v;
-        if (sep_c) b.critic_obs[r1 * D + e] = v;
+      if constexpr (IS_TTT) {
+        // the 18 observation floats and 9 legal-move floats of every row, expanded from the tile's board words
+        const int* words = s_word + ((t + 1) & (RO2_ORING - 1)) * TILE_B;
+        for (unsigned e = l; e < (unsigned)nrow * 27u; e += 64u) {
+          if (e < (unsigned)nrow * 18u) {
+            const unsigned rr = e / 18u, d = e - rr * 18u;
+            const float v = (float)((words[rr] >> ((d & 1u) * 9u + (d >> 1))) & 1);
+            b.policy_obs[r1 * 18 + e] = v;
+            if (sep_c) b.critic_obs[r1 * 18 + e] = v;
+          } else {
+            const unsigned e2 = e - (unsigned)nrow * 18u, rr = e2 / 9u, c = e2 - rr * 9u;
+            const int w = words[rr];
+            b.action_masks[r1 * 9 + e2] = (float)((~(w | (w >> 9)) >> c) & 1);
+          }
+        }
+      } else {
+        for (int e = l; e < nrow * D; e += 64) {
+          const int rr = e / D, d = e - rr * D;
+          const float v = nxt[rr * DP + d];
+          b.policy_obs[r1 * D + e] = v;
+          if (sep_c) b.critic_obs[r1 * D + e] = v;
+        }
+        if (b.action_masks != nullptr)
+          for (int e = l; e < nrow * b.K; e += 64) b.action_masks[r1 * b.K + e] = 1.f;
       }
-      if (b.action_masks != nullptr)
-        for (int e = l; e < nrow * b.K; e += 64) b.action_masks[r1 * b.K + e] = 1.f;
       ro2_post(ctr + RC_STORED, t + 1);
     }
     if (ro2_ld(err) != 0u && l < nrow) b.rewards[(size_t)n0 + l] = u2f(0x7fc00000u);  // a poll timed out: the tile's data are void
@@ -637,8 +737,14 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
         for (int m = 0; m < 4; ++m) z[m] = ORL_MFMA(lc[twc.W1 + (16 * m + j) * 4 + q], xb, z[m]);
       } else {
         float xr[16];
+        if constexpr (IS_TTT) {
+          const int wq = ttt_operand_bits(s_word[(t & (RO2_ORING - 1)) * TILE_B + j]);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) xr[s] = s < nk ? cur[j * DP + 4 * s + q] : 0.f;
+          for (int s = 0; s < 16; ++s) xr[s] = (float)((wq >> (2 * s)) & 1);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) xr[s] = s < nk ? cur[j * DP + 4 * s + q] : 0.f;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the operands are in registers before the slot is released
         ro2_post(ctr + RC_CRIT + c, t + 1);
 #pragma unroll

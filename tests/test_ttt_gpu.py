@@ -84,9 +84,9 @@ def test_config5_end_to_end_masks_stay_on_device(mode):
         assert torch.isfinite(m.theta).all()
 
 
-def test_fused_rollout_equals_stepwise_rollout_on_tictactoe():
-    """The in-kernel game of orl_rollout_fused (ORL_ENV_TTT) and the stepwise orl_act_step + orl_ttt_step +
-    orl_buffer_insert path fill the buffer identically (same Philox streams for sampling and for the opponent)."""
+def _ttt_rollouts(mode, kernel, N, T, iters=2):
+    """`iters` rollouts of tic-tac-toe vs the random opponent through the driver; returns the buffers after each, the episode
+    statistics and the env state"""
     from openrl_amd.algorithms.ppo import PPOAlgorithm
     from openrl_amd.buffers import NormalReplayBuffer
     from openrl_amd.configs.config import default_cfg
@@ -94,40 +94,58 @@ def test_fused_rollout_equals_stepwise_rollout_on_tictactoe():
     from openrl_amd.envs.common import make
     from openrl_amd.modules.common import PPONet
 
-    def run(mode):
-        N, T = 150, 12   # N not a multiple of the 16-env tile
-        cfg = default_cfg(["--seed", "5", "--episode_length", str(T), "--ppo_epoch", "1", "--amd_perm_mode", "device",
-                           "--amd_use_graph", "false", "--amd_rollout_mode", mode, "--log_interval", "1000000"])
-        env = make("tictactoe_v3", env_num=N, device=DEV, seed=5)
-        net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
-        cfg.num_env_steps = N * T * 2
+    cfg = default_cfg(["--seed", "5", "--episode_length", str(T), "--ppo_epoch", "1", "--amd_perm_mode", "device",
+                       "--amd_use_graph", "false", "--amd_rollout_mode", mode, "--log_interval", "1000000",
+                       "--amd_rollout_kernel", kernel])
+    env = make("tictactoe_v3", env_num=N, device=DEV, seed=5)
+    net = PPONet(env, cfg=cfg, device=DEV, n_rollout_threads=N)
+    cfg.num_env_steps = N * T * iters
 
-        class _Agent:
-            num_time_steps = 0
+    class _Agent:
+        num_time_steps = 0
 
-        trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=DEV)
-        buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=DEV)
-        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, _Agent())
-        drv.reset_and_buffer_init()
-        out = []
-        for i in range(2):
-            drv.episode = i
-            drv.actor_rollout()
-            drv.compute_returns()
-            d = buf.data
-            out.append({k: getattr(d, k).clone() for k in ("policy_obs", "actions", "action_log_probs", "value_preds",
-                                                           "rewards", "masks", "action_masks", "returns")})
-            drv.buffer.after_update()
-        return out, env.ep_stats.clone(), env.env_state.clone()
+    trainer = PPOAlgorithm(cfg, net.module, agent_num=1, device=DEV)
+    buf = NormalReplayBuffer(cfg, 1, env.observation_space, env.action_space, device=DEV)
+    drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, _Agent())
+    drv.reset_and_buffer_init()
+    out = []
+    for i in range(iters):
+        drv.episode = i
+        drv.actor_rollout()
+        drv.compute_returns()
+        d = buf.data
+        out.append({k: getattr(d, k).clone() for k in ("policy_obs", "actions", "action_log_probs", "value_preds",
+                                                       "rewards", "masks", "action_masks", "returns")})
+        drv.buffer.after_update()
+    return out, env.ep_stats.clone(), env.env_state.clone()
 
-    (fa, sa, ea), (fb, sb, eb) = run("fused"), run("stepwise")
+
+def _same_rollouts(ra, rb):
+    (fa, sa, ea), (fb, sb, eb) = ra, rb
     for a, b in zip(fa, fb):
         for k in ("policy_obs", "actions", "rewards", "masks", "action_masks"):
             assert torch.equal(a[k], b[k]), k
-        # the two kernels' float arithmetic is contracted differently by hipcc: a few ulp, not bitwise
+        # the kernels' float arithmetic is contracted differently by hipcc (and the chain kernel's critic runs fc2 on the
+        # bf16 x 3 split): a few ulp, not bitwise
         for k in ("action_log_probs", "value_preds", "returns"):
-            torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-6, msg=k)
+            torch.testing.assert_close(a[k], b[k], rtol=2e-5, atol=3e-6, msg=k)
     assert torch.equal(sa, sb) and torch.equal(ea, eb)
+
+
+@pytest.mark.parametrize("kernel", ["chain", "lockstep"])
+def test_fused_rollout_equals_stepwise_rollout_on_tictactoe(kernel):
+    """The in-kernel game of orl_rollout_fused (ORL_ENV_TTT) and the stepwise orl_act_step + orl_ttt_step +
+    orl_buffer_insert path fill the buffer identically (same Philox streams for sampling and for the opponent).
+    `chain` = the round-6 kernel (csrc/orl_rollout2.h: the board travels as one word per row through its rings), `lockstep` =
+    round 5's.  N is not a multiple of the 16-env tile."""
+    _same_rollouts(_ttt_rollouts("fused", kernel, 150, 12), _ttt_rollouts("stepwise", kernel, 150, 12))
+
+
+@pytest.mark.parametrize("N,T", [(3, 1), (17, 2), (33, 5), (1000, 200)])
+def test_chain_rollout_equals_lockstep_rollout_on_tictactoe(N, T):
+    """The two fused kernels against each other at degenerate sizes (fewer rows than a tile, one step: the rings never wrap)
+    and at configuration 5's episode length (every ring wraps 25 - 50 times, thousands of auto-resets)."""
+    _same_rollouts(_ttt_rollouts("fused", "chain", N, T), _ttt_rollouts("fused", "lockstep", N, T))
 
 
 @pytest.mark.parametrize("sampling", ["static", "per_rollout", "per_reset"])

@@ -51,6 +51,8 @@ timeout 600 python benchmarks/cfg4_mpe_bench.py > $OUT/${TAG}_cfg4_mpe_line.json
 stats cfg4_mpe python benchmarks/cfg4_mpe_bench.py --steps 4 --warmup 2
 timeout 600 python benchmarks/cfg5_ttt_bench.py > $OUT/${TAG}_cfg5_ttt_line.json 2>/dev/null
 stats cfg5_ttt python benchmarks/cfg5_ttt_bench.py --steps 4 --warmup 2
+timeout 600 python benchmarks/cfg5_ttt_bench.py --rollout-kernel lockstep > $OUT/${TAG}_cfg5_ttt_lockstep_line.json 2>/dev/null
+stats cfg5_ttt_lockstep python benchmarks/cfg5_ttt_bench.py --steps 4 --warmup 2 --rollout-kernel lockstep
 timeout 600 python benchmarks/cfg5_ttt_bench.py --opponent pool --sampling per_rollout > $OUT/${TAG}_cfg5_selfplay_line.json 2>/dev/null
 timeout 600 python benchmarks/cfg5_ttt_bench.py --opponent pool --sampling per_reset >> $OUT/${TAG}_cfg5_selfplay_line.json 2>/dev/null
 timeout 600 python benchmarks/host_env_bench.py > $OUT/${TAG}_host_env_line.json 2>/dev/null
