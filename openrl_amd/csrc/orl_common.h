@@ -207,6 +207,22 @@ __device__ inline float row_allmax(float s) {
   return fmaxf(a, b);
 }
 
+// two independent row maxima through one butterfly (row_allsum2's scheme; max is exact, so the results are those of two row_allmax)
+__device__ inline void row_allmax2(float& x, float& y) {
+  float a = x, b = y;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  const float t = fmaxf(a, b);
+  a = t;
+  b = t;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  const float u = fmaxf(a, b);
+  a = u;
+  b = u;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  x = a;
+  y = b;
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

@@ -112,8 +112,9 @@ __device__ inline void sample_cat_frag_v(const f32x4& lgv, int n_out, int q, con
     last = p[r] > 0.f ? (float)(4 * q + r) : last;
     cand = (val[r] & (cand == 999.f) & (cum > ut)) ? (float)(4 * q + r) : cand;
   }
-  const float first = -row_allmax(-cand);  // the lowest class whose cumulative probability exceeds u * total
-  last = row_allmax(last);
+  float first = -cand;  // the lowest class whose cumulative probability exceeds u * total
+  row_allmax2(first, last);
+  first = -first;
   const float a = first == 999.f ? last : first;
   float pk = 0.f;
 #pragma unroll

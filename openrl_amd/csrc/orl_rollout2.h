@@ -49,7 +49,7 @@ enum { RC_OBS = 0, RC_STAGE = 1, RC_NOISE = 4, RC_ENV = 5, RC_STORED = 6, RC_ERR
        RC_WORDS = 20 };
 
 struct Ro2Lds {
-  int critic, obs, word, xg, part, z2, noise, env, stage, ctr, total;  // float offsets
+  int critic, obs, word, xg, part, z2, noise, env, stage, gtab, ctr, total;  // float offsets
 };
 __host__ __device__ inline Ro2Lds ro2_lds(int policy_total, int critic_total, int DP) {
   Ro2Lds L;
@@ -63,6 +63,7 @@ __host__ __device__ inline Ro2Lds ro2_lds(int policy_total, int critic_total, in
   L.noise = o; o += RO2_RING * TILE_B * 16;
   L.env = o; o += RO2_RING * TILE_B * RO2_ENVW;
   L.stage = o; o += RO2_RING * TILE_B * RO2_STG;
+  L.gtab = o; o += 3 * 16;  // Gaussian heads: {std, 1 / (2 std^2), log std + log sqrt(2 pi)} per action dimension
   L.ctr = o; o += RC_WORDS;
   L.total = o;
   return L;
@@ -248,6 +249,15 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
           b3v[c] = c < n_out ? smem[twp.b3 + c] : 0.f;
         }
       }
+    }
+    // wide Gaussian heads: the per-dimension constants of Normal.log_prob, once per launch (wave 0 writes and reads them: a
+    // wave's LDS operations execute in order) - per step they were an exp, a reciprocal and ~10 more instructions per dimension
+    if (HMM && HEAD == ORL_HEAD_GAUSSIAN && gw == 0 && l < 16) {
+      const float ls = l < n_out ? smem[twp.logstd + l] : 0.f;
+      const float sd = expf(ls);
+      smem[L.gtab + l] = sd;
+      smem[L.gtab + 16 + l] = 1.f / (2.f * (sd * sd));
+      smem[L.gtab + 32 + l] = ls + 0.91893853320467274178f;
     }
     // env state of the tile's rows (every lane of a row keeps a copy; lanes q == 0 write)
     constexpr int SW = ENV == ORL_ENV_SYNTH ? SYNTH_STATE_W : IS_TTT ? 0 : CARTPOLE_STATE_W;  // (tic-tac-toe: bitboards below)
@@ -476,17 +486,17 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
       float act0 = 0.f;
       if constexpr (HMM && HEAD == ORL_HEAD_GAUSSIAN) {
         f32x4 av4 = f32x4{0.f, 0.f, 0.f, 0.f}, lp4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (the constants live in LDS: hoisting them into registers costs 12 this build does not have at 768 threads - it spilled)
+        const f32x4 sd4 = *(const f32x4*)(smem + L.gtab + 4 * q), iv4 = *(const f32x4*)(smem + L.gtab + 16 + 4 * q),
+                    lc4 = *(const f32x4*)(smem + L.gtab + 32 + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = 4 * q + r;
           if (c < n_out) {
-            // (hoisting log std / std out of the step loop costs 8 registers this build does not have at 768 threads: it spilled)
-            const float ls = smem[twp.logstd + c];
-            const float sd = expf(ls);
-            const float av = lgv[r] + sd * nz4[r];
+            const float av = lgv[r] + sd4[r] * nz4[r];
             const float d = av - lgv[r];
             av4[r] = av;
-            lp4[r] = -(d * d) / (2.f * (sd * sd)) - ls - 0.91893853320467274178f;
+            lp4[r] = -(d * d) * iv4[r] - lc4[r];
           }
         }
         *(f32x4*)(stg + 4 * q) = av4;

@@ -1,6 +1,6 @@
 """Per-phase cycle breakdown of the round-6 chain rollout kernel (csrc/orl_rollout2.h), wave 0 of workgroup 0.  Timing build:
 python -m openrl_amd.csrc.build --prof (or variants/prof.so copied over liborl_hip.so with ORL_KEEP_BUILD=1).
-    python tools/rollout2_phase_prof.py [--env cartpole] [--envs N]"""
+    python tools/rollout2_phase_prof.py [--env cartpole] [--envs N] | --shape cfg3 | --shape cfg5"""
 import ctypes as C
 import os
 import sys
@@ -22,15 +22,23 @@ def main():
     if not hasattr(lib, "orl_debug_rollout_prof"):
         raise SystemExit("liborl_hip.so is not the timing build: python -m openrl_amd.csrc.build --prof")
     extra = sys.argv[1:]
-    sys.argv = [sys.argv[0], "--no-cpu-baseline", "--no-other-configs", "--steps", "5", "--warmup", "2"] + extra
     out = (C.c_ulonglong * 16)()
     lib.orl_debug_rollout_prof.argtypes = [C.c_void_p]
     lib.orl_debug_rollout_prof(out)  # reset
-    bench.main()
+    if extra[:1] == ["--shape"]:  # --shape cfg3 | cfg5: benchmarks/shape_sweep.py's shapes on the synthetic env (8 rollouts)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchmarks"))
+        import shape_sweep
+
+        name = [k for k in shape_sweep.SHAPES if extra[1] in k][0]
+        shape_sweep.run(name, shape_sweep.SHAPES[name], 5, 2)
+        steps = 8 * shape_sweep.SHAPES[name]["T"]
+    else:
+        sys.argv = [sys.argv[0], "--no-cpu-baseline", "--no-other-configs", "--steps", "5", "--warmup", "2"] + extra
+        bench.main()
+        steps = 7 * 128
     torch.cuda.synchronize()
     lib.orl_debug_rollout_prof(out)
     v = list(out)
-    steps = 7 * 128
     tot = sum(v[:9])
     print("wave 0: %.0f cycles/step" % (tot / steps))
     for k, name in enumerate(PHASES):
