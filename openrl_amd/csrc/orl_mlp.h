@@ -27,6 +27,13 @@ constexpr int W2S = 68;    // padded LDS row stride (floats) of the 64x64 matric
 constexpr int TILE_B = 16; // batch rows per wave tile
 
 #define ORL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// timing probe (ORL_BUILD_DEFS=-DORL_SPLIT_PROBE, never shipped: WRONG numerics): only the three largest products of every split
+// GEMM - what a two-term split (e.g. fp16 pairs) would issue; measures what halving the MFMA count of the towers could buy
+#ifdef ORL_SPLIT_PROBE
+#define ORL_IF_FULL(x)
+#else
+#define ORL_IF_FULL(x) x
+#endif
 
 // ---- three-term bf16 splitting (tools/split_bf16_gemm.hip) ----------------------------------------
 // v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (32 cycles per 2 048 flop) and blocks the SIMD's VALU while it
@@ -227,9 +234,9 @@ __device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ 
     u32x4& wl = w[s % (PF + 1)][2];
     gt_lds_wait<3 * ahead>(wh, wm, wl);
     constexpr int h = s >> 2, mo = s & 3;
-    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
-    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);)
     acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
@@ -247,9 +254,9 @@ __device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ 
     const u32x4 wh = *(const u32x4*)(Wb + wb_off(0, 16 * mo + j, h, q));
     const u32x4 wm = *(const u32x4*)(Wb + wb_off(1, 16 * mo + j, h, q));
     const u32x4 wl = *(const u32x4*)(Wb + wb_off(2, 16 * mo + j, h, q));
-    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
-    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);)
     acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
@@ -270,9 +277,9 @@ __device__ __forceinline__ void mm64_T_split(const unsigned short* __restrict__ 
       for (int p = 0; p < 3; ++p) w[(st + 1) & 1][p] = *(const u32x4*)(Wb + wb_off(p, 16 * mo2 + j, h2, q));
     }
     const u32x4 wh = w[st & 1][0], wm = w[st & 1][1], wl = w[st & 1][2];
-    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
-    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);)
     acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
@@ -320,18 +327,150 @@ __device__ __forceinline__ void mm64_T_split_tr(const unsigned short* __restrict
     }
     const u32x4 wh = w[st & 1][0], wm = w[st & 1][1], wl = w[st & 1][2];
 #endif
-    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
-    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);)
     acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
   }
 }
 
+// ---- two-term fp16 splitting (round 6; tools/split_f16_gemm.hip) --------------------------------------------------------------
+// A timing probe that issued 3 of the 6 bf16 products ran the tower pair 21 % faster (profiles/r06_experiments.md section 8):
+// the kernel is bound by its MFMA + splitting work.  x = hi + lo with hi = rn16(x), lo = rn16(x - hi) carries 11 + 11
+// significand bits (|x - hi - lo| <= 2^-22 |x|, the remainder x - hi is exact), and a.b ~ hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_16x16x32_f16 (the dropped lo.lo <= 2^-22 |a b|): THREE products instead of six, 4 VALU per pair of values
+// instead of 11.  Measured on one wave against float64 (N(0,1) operands, K = 64): rms 8.0e-8 of the output's rms, against
+// 8.3e-8 for the six bf16 products and 1.07e-7 for v_mfma_f32_16x16x4_f32 itself.  fp16's RANGE is the catch (the bf16
+// split has fp32's): an operand has to sit in [2^-14, 2^16) to keep its 22 bits, and gradients of 1e-6 lose everything
+// unscaled (rms 1e-2).  So every operand is scaled by an exact power of two chosen where it is produced -
+//   * a weight image by 2^kw, kw from the image's own maximum (stage_tower: max -> [2^13, 2^14)),
+//   * LayerNorm outputs (|xhat| < 8) as they are,
+//   * a tile of gradients by its own maximum (orl_ppo_tower.h: max -> [2^11, 2^12)),
+// and the accumulators are unscaled by the inverse power (exact).  fp16 subnormals pass through the MFMA unflushed
+// (probe), so a value far below its tile's maximum degrades gracefully: its absolute error is 2^-25 x 2^-scale, i.e.
+// <= 2^-36 of the tile's maximum.  ORL_TOWER_F16 = 0 keeps the three-term bf16 kernels of rounds 3 - 5 (A/B switch).
+#ifndef ORL_TOWER_F16
+#define ORL_TOWER_F16 1
+#endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int WBH_IMG_FLOATS = 2 * HID * WBS / 2;  // two parts x 64 rows (5 120 floats at WBS = 80)
+constexpr int TOWER_SPLIT_IMG_FLOATS = ORL_TOWER_F16 ? WBH_IMG_FLOATS : WB_IMG_FLOATS;
+constexpr int TOWER_SPLIT_PARTS = ORL_TOWER_F16 ? 2 : 3;
+// one dword = {rn16(a) (low half), rn16(b)}: v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
+// x - (float)half: ONE v_fma_mix_f32 (the fp16 half widened inside the FMA; the result is exact).  hipcc does not form it
+// from `x - (float)h` (it emits v_cvt_f32_f16 + v_sub_f32), hence the asm.
+__device__ __forceinline__ float rem16_lo(unsigned pk, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float rem16_hi(unsigned pk, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(x));
+  return r;
+}
+// 8 fp32 values -> two f16x8 MFMA fragments (hi, lo): 4 VALU per 2 values
+__device__ __forceinline__ void split8h(const float (&x)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = x[2 * p], b = x[2 * p + 1];
+    hi[p] = cvt_pk_f16(a, b);
+    lo[p] = cvt_pk_f16(rem16_lo(hi[p], a), rem16_hi(hi[p], b));
+  }
+}
+__device__ __forceinline__ f32x4 mfma_f16_16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_f16_32(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the two fp16 images of a (pre-scaled) 64 x 64 matrix: wb_off's layout with parts 0 (hi), 1 (lo)
+__device__ __forceinline__ void split_weight_store2h(unsigned short* __restrict__ img, int o, int k, float w0, float w1) {
+  const int m = k >> 4, q = (k >> 2) & 3, r = k & 3, h = m >> 1, sl = (m & 1) * 4 + r;  // r is 0 or 2
+  const unsigned hi = cvt_pk_f16(w0, w1);
+  *(unsigned*)(img + wb_off(0, o, h, q) + sl) = hi;
+  *(unsigned*)(img + wb_off(1, o, h, q) + sl) = cvt_pk_f16(rem16_lo(hi, w0), rem16_hi(hi, w1));
+}
+// the B fragments of a T-layout activation tile: xs[h][part]
+__device__ __forceinline__ void split_Th(const f32x4 (&in)[4], u32x4 (&xs)[2][2]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float x[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x[r] = in[2 * h][r]; x[4 + r] = in[2 * h + 1][r]; }
+    split8h(x, xs[h][0], xs[h][1]);
+  }
+}
+// acc += A in (both T layout), A = the fp16 images at Wb: 24 MFMAs (3 products x 4 row blocks x 2 K-steps), 16 ds_read_b128
+__device__ __forceinline__ void mm64_T_h2(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][2], f32x4 (&acc)[4], int j,
+                                          int q) {
+  u32x4 w[2][2];  // A fragments double-buffered over the 8 (h, mo) steps
+#pragma unroll
+  for (int p = 0; p < 2; ++p) w[0][p] = *(const u32x4*)(Wb + wb_off(p, j, 0, q));
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int h = st >> 2, mo = st & 3;
+    if (st < 7) {
+      const int h2 = (st + 1) >> 2, mo2 = (st + 1) & 3;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) w[(st + 1) & 1][p] = *(const u32x4*)(Wb + wb_off(p, 16 * mo2 + j, h2, q));
+    }
+    const u32x4 wh = w[st & 1][0], wl = w[st & 1][1];
+    acc[mo] = mfma_f16_16(wl, xs[h][0], acc[mo]);
+    acc[mo] = mfma_f16_16(wh, xs[h][1], acc[mo]);
+    acc[mo] = mfma_f16_16(wh, xs[h][0], acc[mo]);
+  }
+}
+// acc += A^T in through the transposing LDS read of the SAME images (mm64_T_split_tr's addressing)
+__device__ __forceinline__ void mm64_T_h2_tr(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][2], f32x4 (&acc)[4],
+                                             int j, int q) {
+  const unsigned short* base = Wb + (4 * q + (j >> 2)) * WBS + (j & 3) * 8;
+  auto frag = [&](int p, int h, int mo) -> u32x4 {
+    const unsigned short* a = base + (p * HID + 32 * h) * WBS + (mo >> 1) * 32 + (mo & 1) * 4;
+    const u32x2 lo = ds_read_tr16(a), hi = ds_read_tr16(a + 16 * WBS);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
+  u32x4 w[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) w[0][p] = frag(p, 0, 0);
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int h = st >> 2, mo = st & 3;
+    if (st < 7) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) w[(st + 1) & 1][p] = frag(p, (st + 1) >> 2, (st + 1) & 3);
+    }
+    const u32x4 wh = w[st & 1][0], wl = w[st & 1][1];
+    acc[mo] = mfma_f16_16(wl, xs[h][0], acc[mo]);
+    acc[mo] = mfma_f16_16(wh, xs[h][1], acc[mo]);
+    acc[mo] = mfma_f16_16(wh, xs[h][0], acc[mo]);
+  }
+}
+// maximum of |x| over the wave (every lane returns it): 4 DPP rotations inside the 16-lane rows + the two half-wave swaps
+__device__ __forceinline__ float wave_absmax(float v) {
+  v = fmaxf(v, u2f(__builtin_amdgcn_update_dpp(0u, f2u(v), 0x121, 0xf, 0xf, false)));  // row_ror:1
+  v = fmaxf(v, u2f(__builtin_amdgcn_update_dpp(0u, f2u(v), 0x122, 0xf, 0xf, false)));  // row_ror:2
+  v = fmaxf(v, u2f(__builtin_amdgcn_update_dpp(0u, f2u(v), 0x124, 0xf, 0xf, false)));  // row_ror:4
+  v = fmaxf(v, u2f(__builtin_amdgcn_update_dpp(0u, f2u(v), 0x128, 0xf, 0xf, false)));  // row_ror:8
+  return row_allmax(v);
+}
+// biased exponent E of a non-negative maximum, clamped so that 2^(138 - E) (which moves the maximum into [2^11, 2^12)) and its
+// inverse stay finite: zero / tiny tiles get the largest scale (their values underflow harmlessly), inf / nan a finite one
+__device__ __forceinline__ int scale_exponent(float mx) {
+  int e = (int)(f2u(mx) >> 23) & 0xff;
+  e = e < 20 ? 20 : e;
+  return e > 254 ? 254 : e;
+}
+
 // LDS image of one tower (offsets in floats, all multiples of 4 => 16-byte aligned).
 struct TowerLds {
-  int DP, n_out, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, logstd, W2T, W3P, total;
+  int DP, n_out, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, logstd, W2T, W3P, wsc, total;
   __host__ __device__ TowerLds() {}
   // with_w3p: a second image of W3, zero padded to 16 rows at the conflict-free stride W2S - the MFMA operand of the
   // head GEMMs of wide heads (orl_ppo_tower.h, NO > 4)
@@ -339,7 +478,7 @@ struct TowerLds {
   // fp32 rows - the update towers' SPLIT builds (orl_ppo_tower.h)
   __host__ __device__ TowerLds(int D, int n_out_, bool gaussian, bool with_w2t, bool with_w3p = false,
                                bool split = false) {
-    const int w2_floats = split ? WB_IMG_FLOATS : HID * W2S;
+    const int w2_floats = split ? TOWER_SPLIT_IMG_FLOATS : HID * W2S;
     DP = (D + 3) & ~3;
     n_out = n_out_;
     const int no4 = (n_out + 3) & ~3;
@@ -357,6 +496,9 @@ struct TowerLds {
     logstd = o; o += gaussian ? no4 : 0;
     W2T = o; o += with_w2t ? w2_floats : 0;
     W3P = o; o += with_w3p ? 16 * W2S : 0;
+    // fp16 split images (ORL_TOWER_F16): {kw as a float, 2^kw, 2^-kw, 1e-5 x 4^kw} of the image's scale, then 16 words of
+    // scratch for the staging's maximum
+    wsc = o; o += (split && ORL_TOWER_F16) ? 20 : 0;
     total = o;
   }
 };
@@ -390,6 +532,33 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
   n_max = HID > n_max ? HID : n_max;
   unsigned short* b2i = (unsigned short*)(lds + tw.W2);
   unsigned short* b2t = (unsigned short*)(lds + tw.W2T);
+  // fp16 images: the scale 2^kw that moves the image's largest |W2 diag(g1)| into [2^13, 2^14) - one pass over W2 (L2 hits
+  // again in the rounds below), a wave maximum per wave, one barrier.  The folded bias b2' is stored scaled as well: fc2's
+  // accumulators start from it and LayerNorm 2 takes them scaled (with eps scaled by 4^kw it returns the same xhat2).
+  float wscale = 1.f;
+  if (split && ORL_TOWER_F16) {
+    float mx = 0.f;
+    for (int e = tid; e < HID * HID; e += nthreads) {
+      const float w = theta[tl.oW2 + e] * (fold ? theta[tl.og1 + (e & 63)] : 1.f);
+      mx = fmaxf(mx, fabsf(w));
+    }
+    mx = wave_absmax(mx);
+    if ((tid & 63) == 0) lds[tw.wsc + 4 + (tid >> 6)] = mx;
+    __syncthreads();
+    mx = 0.f;
+    for (int w = 0; w < (nthreads + 63) / 64; ++w) mx = fmaxf(mx, lds[tw.wsc + 4 + w]);
+    int kw = 0;
+    const int eb = (int)(f2u(mx) >> 23) & 0xff;  // mx in [2^(eb - 127), 2^(eb - 126))
+    if (eb > 0 && eb < 255) kw = 13 - (eb - 127);
+    kw = kw < -40 ? -40 : (kw > 40 ? 40 : kw);
+    wscale = __builtin_ldexpf(1.f, kw);
+    if (tid == 0) {
+      lds[tw.wsc + 0] = (float)kw;
+      lds[tw.wsc + 1] = wscale;
+      lds[tw.wsc + 2] = __builtin_ldexpf(1.f, -kw);
+      lds[tw.wsc + 3] = __builtin_ldexpf(1e-5f, 2 * kw);
+    }
+  }
   struct Round {  // one round's loaded values of one thread
     float p_w, p_g, w1v, vb1, vg1, vbe1, vb2, vg2, vbe2, w00, w01, w10, w11, g0, g1v, w3v, w3g, vb3, vls, fw[8], fbe[8], fb;
   };
@@ -454,7 +623,7 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
     if (e < n_w1) lds[tw.W1 + e] = R.w1v;
     if (e < HID) {
       lds[tw.b1 + e] = R.vb1; lds[tw.g1 + e] = R.vg1; lds[tw.be1 + e] = R.vbe1;
-      if (!fold) lds[tw.b2 + e] = R.vb2;
+      if (!fold) lds[tw.b2 + e] = R.vb2 * wscale;
       lds[tw.g2 + e] = R.vg2; lds[tw.be2 + e] = R.vbe2;
     }
     if (e < n_w2) {
@@ -464,12 +633,21 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
         // block of W2 per thread and round: its two row pairs are dword stores of W2's image, its two column pairs dword
         // stores of the transposed image (split_weight_store2) - no sub-dword LDS store in the staging
         const float a00 = R.w00 * R.g0, a01 = R.w01 * R.g1v, a10 = R.w10 * R.g0, a11 = R.w11 * R.g1v;
+#if ORL_TOWER_F16
+        split_weight_store2h(b2i, bo, bi, a00 * wscale, a01 * wscale);
+        split_weight_store2h(b2i, bo + 1, bi, a10 * wscale, a11 * wscale);
+        if (with_w2t) {
+          split_weight_store2h(b2t, bi, bo, a00 * wscale, a10 * wscale);
+          split_weight_store2h(b2t, bi + 1, bo, a01 * wscale, a11 * wscale);
+        }
+#else
         split_weight_store2(b2i, bo, bi, a00, a01);
         split_weight_store2(b2i, bo + 1, bi, a10, a11);
         if (with_w2t) {
           split_weight_store2(b2t, bi, bo, a00, a10);
           split_weight_store2(b2t, bi + 1, bo, a01, a11);
         }
+#endif
       } else {
         const float w = R.w00 * R.g0;
         lds[tw.W2 + bo * W2S + bi] = w;
@@ -490,7 +668,7 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
       acc += __shfl_xor(acc, 2);
       acc += __shfl_xor(acc, 4);
       if (fo < rows && part == 0) {
-        if (fo < HID) lds[tw.b2 + fo] = R.fb + acc;
+        if (fo < HID) lds[tw.b2 + fo] = (R.fb + acc) * wscale;
         else lds[tw.b3 + (fo - HID)] = R.fb + acc;
       }
     }
@@ -602,7 +780,9 @@ __device__ inline float feat_sum(const f32x4 (&x)[4]) {
 #ifndef ORL_LN_GUARD
 #define ORL_LN_GUARD 17.0f
 #endif
-__device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd) {
+// eps: 1e-5, or 1e-5 x 4^k for rows that arrive scaled by 2^k (the fp16 split GEMMs' accumulators): the same xhat comes out and
+// rstd is that of the scaled row (= the true one x 2^-k: v_rsq of an argument scaled by an even power of two has the same mantissa)
+__device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd, const float eps = 1e-5f) {
 #if ORL_LN_ONEPASS
   float s1 = lane_sum16(x), s2 = lane_dot16(x, x);
   row_allsum2(s1, s2);
@@ -621,14 +801,14 @@ __device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd) {
     row_allsum2(c1, c2);
     const float dm = c1 * (1.0f / 64.0f);
     const float v = fmaxf(c2 * (1.0f / 64.0f) - dm * dm, 0.f);
-    rstd = __builtin_amdgcn_rsqf(v + 1e-5f);
+    rstd = __builtin_amdgcn_rsqf(v + eps);
     const float sh2 = -dm * rstd;
 #pragma unroll
     for (int m = 0; m < 4; ++m) x[m] = x[m] * rstd + sh2;
     return;
   }
 #endif
-  rstd = __builtin_amdgcn_rsqf(fmaxf(var1, 0.f) + 1e-5f);
+  rstd = __builtin_amdgcn_rsqf(fmaxf(var1, 0.f) + eps);
   const float shift = -mean1 * rstd;
 #pragma unroll
   for (int m = 0; m < 4; ++m) x[m] = x[m] * rstd + shift;
@@ -640,7 +820,7 @@ __device__ inline void ln_normalize_T(f32x4 (&x)[4], float& rstd) {
   float v = lane_dot16(x, x);
   v = row_allsum(v);
   // v_rsq_f32 (1 ulp) instead of the ~20-instruction correctly-rounded sqrt + IEEE division sequence
-  rstd = __builtin_amdgcn_rsqf(v * (1.0f / 64.0f) + 1e-5f);
+  rstd = __builtin_amdgcn_rsqf(v * (1.0f / 64.0f) + eps);
 #pragma unroll
   for (int m = 0; m < 4; ++m) x[m] = x[m] * rstd;
 }

@@ -312,6 +312,14 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   // image are disjoint LDS regions
   stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM, SP, true);
   __syncthreads();
+  // fp16 split builds (orl_mlp.h, ORL_TOWER_F16): the weight image's scale 2^kw (fc2's accumulators and LayerNorm 2 run scaled:
+  // eps x 4^kw), and the running scale 2^LS of this wave's wgrad accumulators (a tile's gradients are scaled by their own
+  // maximum, its xhat1 operand by what is left of 2^LS: LS only ever decreases, and the accumulators follow it)
+  constexpr bool F16W = SPW && ORL_TOWER_F16;  // the wgrad (and with it the tile scale of dz2)
+  constexpr bool F16G = SP && ORL_TOWER_F16;   // fc2 / dgrad over the fp16 images
+  const int kw = F16G ? (int)smem[tw.wsc] : 0;
+  const float w_scale = F16G ? smem[tw.wsc + 1] : 1.f, ln2_eps = F16G ? smem[tw.wsc + 3] : 1e-5f;
+  int LS = 1000;
 
 #ifdef ORL_PROF
   __shared__ unsigned long long prof_lds[16];
@@ -391,7 +399,11 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       load_vec_T(lw + tw.b2, q, xh2);  // the folded bias b2 + W2 be1; the GEMM runs on xhat1 itself (W2 diag(g1) image)
       ORL_T(1);  // fc1, relu, LN1, slab store, affine
       ORL_PRIO(1);
-      if constexpr (SP) {
+      if constexpr (F16G) {
+        u32x4 xs[2][2];
+        split_Th(z, xs);
+        mm64_T_h2((const unsigned short*)(lw + tw.W2), xs, xh2, j, q);  // 2^kw z2 (the bias slot holds 2^kw b2')
+      } else if constexpr (SP) {
         u32x4 xs[2][3];
         split_T(z, xs);
         mm64_T_split((const unsigned short*)(lw + tw.W2), xs, xh2, j, q);
@@ -400,7 +412,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       }
       ORL_PRIO(0);
       ORL_T(2);  // fc2: 64 MFMA
-      ln_normalize_T(xh2, rstd2);
+      ln_normalize_T(xh2, rstd2, ln2_eps);
+      if constexpr (F16G) rstd2 *= w_scale;  // of the unscaled row
       store_slab_T(SS, xh2, j, q);  // parked in the scratch slab: read back in F layout (S3) and T layout (LN2')
 #pragma unroll
       for (int m = 0; m < 4; ++m) z[m] = xh2[m];  // the head runs on xhat2 (W3 diag(g2) image, folded bias)
@@ -764,6 +777,32 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     } else
 #endif
     ln_bwd_T(d2, xh2, rstd2);
+    int eA = 138;  // the tile's dz2 leaves scaled by 2^(138 - eA): its largest |element| in [2^11, 2^12)
+    if constexpr (F16W) {
+      float mx = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d2[m][0]), fabsf(d2[m][1]))), fmaxf(fabsf(d2[m][2]), fabsf(d2[m][3])));
+      eA = __builtin_amdgcn_readfirstlane(scale_exponent(wave_absmax(mx)));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d2[m][r] = __builtin_ldexpf(d2[m][r], 138 - eA);
+      // G's scale: 2^LS x (dz2^T xhat1) = (2^(138 - eA) dz2)^T (2^LB xhat1) with LB = LS - (138 - eA) <= 12 (|xhat1| < 8 stays
+      // below 2^15); a tile with larger gradients than any before lowers LS, and the accumulators are rescaled (exact)
+      const int ls_new = 12 + 138 - eA;
+      if (ls_new < LS) {
+        const int dl = ls_new - LS;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) GS[a][b][r] = __builtin_ldexpf(GS[a][b][r], dl);
+          a_db2s[a] = __builtin_ldexpf(a_db2s[a], dl);
+        }
+        LS = ls_new;
+      }
+    }
     wave_lds_fence();
     store_slab_T(SS, d2, j, q);
     wave_lds_fence();
@@ -773,7 +812,37 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
       // columns 32b + c of both slabs (32 conflict-free 4-byte reads, as many as the fp32 path), splits them in
       // registers and issues 6 products x 4 blocks = 24 MFMAs.  db2 falls out of the same reads.
       const int c = l & 31, kb = l >> 5;
-#if ORL_WGRAD_HALVES
+#if ORL_TOWER_F16
+      {
+        const int LB = LS - (138 - eA);
+        u32x4 fb[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float xb[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xb[k] = __builtin_ldexpf(X1[(8 * kb + k) * TS + 32 * b + c], LB);
+          split8h(xb, fb[b][0], fb[b][1]);
+        }
+#pragma unroll
+        for (int bo = 0; bo < 2; ++bo) {
+          float xa[8];
+          u32x4 fa[2];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xa[k] = SS[(8 * kb + k) * TS + 32 * bo + c];
+          a_db2s[bo] += __builtin_ldexpf(((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7])), LB);
+          split8h(xa, fa[0], fa[1]);
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi) {
+            f32x16 g = GS[bo][bi];
+            g = mfma_f16_32(fa[1], fb[bi][0], g);
+            g = mfma_f16_32(fa[0], fb[bi][1], g);
+            g = mfma_f16_32(fa[0], fb[bi][0], g);
+            GS[bo][bi] = g;
+          }
+        }
+      }
+      if (false) {
+#elif ORL_WGRAD_HALVES
       // round 5: the dz2 fragments of ONE 32-row block at a time - 12 registers less at the kernel's pressure peak.  The wide
       // builds (256 registers, wide head + MFMA dW1) spill 10 / 19 registers instead of 20 / 27 with it and every scratch reload
       // of a tile waits vmcnt(0) behind the record DMA: cfg3 pair 0.1448 / 0.1437 / 0.1503 -> 0.1382 / 0.1392 / 0.1388 ms, cfg5
@@ -798,9 +867,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #pragma unroll
           for (int bi = 0; bi < 2; ++bi) {
             f32x16 g = GS[bo][bi];
-            g = mfma_bf16_32(fa[2], fb[bi][0], g);
-            g = mfma_bf16_32(fa[0], fb[bi][2], g);
-            g = mfma_bf16_32(fa[1], fb[bi][1], g);
+            ORL_IF_FULL(g = mfma_bf16_32(fa[2], fb[bi][0], g);)
+            ORL_IF_FULL(g = mfma_bf16_32(fa[0], fb[bi][2], g);)
+            ORL_IF_FULL(g = mfma_bf16_32(fa[1], fb[bi][1], g);)
             g = mfma_bf16_32(fa[1], fb[bi][0], g);
             g = mfma_bf16_32(fa[0], fb[bi][1], g);
             g = mfma_bf16_32(fa[0], fb[bi][0], g);
@@ -834,9 +903,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #pragma unroll
         for (int bi = 0; bi < 2; ++bi) {
           f32x16 g = GS[bo][bi];
-          g = mfma_bf16_32(fa[bo][2], fb[bi][0], g);
-          g = mfma_bf16_32(fa[bo][0], fb[bi][2], g);
-          g = mfma_bf16_32(fa[bo][1], fb[bi][1], g);
+          ORL_IF_FULL(g = mfma_bf16_32(fa[bo][2], fb[bi][0], g);)
+          ORL_IF_FULL(g = mfma_bf16_32(fa[bo][0], fb[bi][2], g);)
+          ORL_IF_FULL(g = mfma_bf16_32(fa[bo][1], fb[bi][1], g);)
           g = mfma_bf16_32(fa[bo][1], fb[bi][0], g);
           g = mfma_bf16_32(fa[bo][0], fb[bi][1], g);
           g = mfma_bf16_32(fa[bo][0], fb[bi][0], g);
@@ -884,7 +953,14 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     // dgrad A operand: a transposed copy of W2 in LDS read by 16-byte rows (16 reads per 64 MFMA); reading W2 by
     // columns (64 four-byte reads, one per MFMA) made this the slowest phase of the tile: 5 100 vs 3 100 cycles
-    if constexpr (SP) {
+    if constexpr (F16G) {
+      u32x4 xs[2][2];
+      split_Th(d2, xs);
+      ORL_PRIO2(1);
+      if constexpr (SPT) mm64_T_h2_tr((const unsigned short*)(lw + tw.W2), xs, d1, j, q);
+      else mm64_T_h2((const unsigned short*)(lw + tw.W2T), xs, d1, j, q);
+      ORL_PRIO2(0);
+    } else if constexpr (SP) {
       u32x4 xs[2][3];
       split_T(d2, xs);
       ORL_PRIO2(1);
@@ -899,7 +975,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     {
       f32x4 xh1[4];
       load_slab_T(X1, xh1, j, q);
-      ln_bwd_T(d1, xh1, rstd1);
+      // (fp16 builds: d1 = 2^(kw + 138 - eA) W2g^T dz2 - LayerNorm's backward is linear in it, the inverse power rides on rstd1)
+      ln_bwd_T(d1, xh1, F16W ? __builtin_ldexpf(rstd1, eA - 138 - kw) : rstd1);
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -930,9 +1007,9 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         u32x4 fa[3];
         split8(xa, fa[0], fa[1], fa[2]);
         f32x16 g = G1S[b];
-        g = mfma_bf16_32(fa[2], fx[0], g);
-        g = mfma_bf16_32(fa[0], fx[2], g);
-        g = mfma_bf16_32(fa[1], fx[1], g);
+        ORL_IF_FULL(g = mfma_bf16_32(fa[2], fx[0], g);)
+        ORL_IF_FULL(g = mfma_bf16_32(fa[0], fx[2], g);)
+        ORL_IF_FULL(g = mfma_bf16_32(fa[1], fx[1], g);)
         g = mfma_bf16_32(fa[1], fx[0], g);
         g = mfma_bf16_32(fa[0], fx[1], g);
         g = mfma_bf16_32(fa[0], fx[0], g);
@@ -1006,6 +1083,16 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #undef RECX
 #undef REC_R
 
+  if constexpr (F16W) {  // the wgrad accumulators back to their own units (a wave that walked no tile: zeros stay zeros)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) GS[a][b][r] = __builtin_ldexpf(GS[a][b][r], -LS);
+      a_db2s[a] = __builtin_ldexpf(a_db2s[a], -LS);
+    }
+  }
   // ---- workgroup reduction of the waves' accumulators, fixed order (deterministic) ---------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the last (unused) DMA before LDS is reused
 #ifdef ORL_PROF

@@ -770,12 +770,21 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
       ln_normalize_T(z, rstd);
       f32x4 acc[4];
       load_vec_T(lc + twc.b2, q, acc);
+#if ORL_TOWER_F16
+      {  // two-term fp16 split over the scaled image (orl_mlp.h): acc = 2^kw z2, LayerNorm 2 with eps x 4^kw returns xhat2 itself
+        u32x4 xs[2][2];
+        split_Th(z, xs);
+        mm64_T_h2((const unsigned short*)(lc + twc.W2), xs, acc, j, q);
+      }
+      ln_normalize_T(acc, rstd, lc[twc.wsc + 3]);
+#else
       {
         u32x4 xs[2][3];
         split_T(z, xs);
         mm64_T_split((const unsigned short*)(lc + twc.W2), xs, acc, j, q);
       }
       ln_normalize_T(acc, rstd);
+#endif
       float p = 0.f;
 #pragma unroll
       for (int m = 0; m < 4; ++m)

@@ -150,14 +150,16 @@ def test_one_update_with_ill_conditioned_layernorm_rows(case, ratio):
     Adam step) on the golden case with its initial weights shifted.  The checker here is torch's fp32 autograd, whose own
     xhat carries ~eps32 R of rounding at mean / std = R: the absolute tolerance on a gradient (2e-5 of the tower's largest
     entry) is widened by 4 eps32 R - 9e-5 at R = 300.  (At R = 3 000 the fp32 reference's gradients in front of the LayerNorm
-    are rounding noise - nothing to pin.)"""
+    are rounding noise - nothing to pin.)  The parameters after the Adam step get the same allowance: a parameter whose
+    gradient is of the size of Adam's eps moves by lr g / (|g| + eps), so a gradient difference d moves it by up to
+    lr d / (4 eps) - 12 d with the reference defaults (measured at R = 300: one entry of 4 801 at 1.4e-5)."""
     from tests import test_ppo_update_gpu as TU
 
     g = H.load_golden(case)
     specs = H.case_specs(g)
     obs = g["buf_policy_obs"][:-1].reshape(-1, specs[0].obs_dim)
     TU.single_update_vs_oracle(_shifted_golden(g, specs, ratio, obs, obs), grad_atol=2e-5 + 4 * EPS32 * ratio,
-                               info_rtol=TU.INFO_RTOL + 4 * EPS32 * ratio)
+                               info_rtol=TU.INFO_RTOL + 4 * EPS32 * ratio, theta_atol=1e-5 * (1.0 + ratio / 100.0))
 
 
 @pytest.mark.parametrize("ratio", [1, 30, 300])
