@@ -404,11 +404,15 @@ def main():
             break
         except Exception:
             continue
+    from openrl_amd import _native as nat
+
+    split_terms = int(nat.load().orl_tower_split_terms())
+    n_prod = 3.0 if split_terms == 2 else 6.0
     roofline = {"kernel": "orl_ppo_fwd_bwd (ppo_tower_pair_kernel: policy + critic towers in one launch)", "bound": "mfma",
                 "achieved": round(achieved_tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / F32_MFMA_PEAK_TFLOPS, 4),
                 "frac_label": "fp32-equivalent: ALGORITHMIC fp32 flops / the fp32 MFMA peak (SURVEY 8d's pricing); with "
-                              "tower_gemm=split the products run on the bf16 pipe - bf16_mfma_frac / mfma_busy_frac / "
+                              "tower_gemm=split the products run on the 16-bit MFMA pipe - mfma16_frac / mfma_busy_frac / "
                               "valu_busy_frac are the utilisation figures",
                 "traffic": traffic, "traffic_source": traffic_source, "traffic_reason": traffic_reason,
                 "launch_ms": round(k_ms, 4), "launches_timed": len(ev),
@@ -419,14 +423,24 @@ def main():
                 # how the flops are executed: the three 64 x 64 GEMMs of a tile (92 % of the algorithmic flops) run as 6 of
                 # the 9 bf16 products of three-term bf16 splits of both operands (the splits are exact, the three smallest
                 # cross terms are dropped: ~2^-24 relative), fp32 accumulation - measured error <= the fp32 MFMA's own (profiles/r03_split_bf16_gemm.txt); `frac` stays priced on ALGORITHMIC fp32
-                # flops against the fp32 MFMA peak, `bf16_mfma_frac` is the share of the dense bf16 MFMA peak issued
-                "mfma_path": ("bf16x3 split (6 of 9 products) on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16; fc1 + head on "
-                              "v_mfma_f32_16x16x4_f32") if args.tower_gemm == "split" else "v_mfma_f32_16x16x4_f32 (--tower-gemm fp32)",
-                "bf16_mfma_frac": round(6 * (16384.0 / 17792.0) * achieved_tf / BF16_MFMA_PEAK_TFLOPS, 4)
+                # flops against the fp32 MFMA peak, `mfma16_frac` is the share of the dense 16-bit MFMA peak issued
+                # round 6: two-term fp16 splits (hi = rn16(x), lo = rn16(x - hi): 22 significand bits), 3 of the 4 products, every
+                # operand scaled by an exact power of two chosen from its own maximum (fp16's range) - the same distance to float64
+                # as the three-term bf16 build and the fp32 MFMA (profiles/r06_experiments.md section 8); split_terms says which
+                # build is loaded (orl_tower_split_terms)
+                "mfma_path": (("fp16x2 split (3 of 4 products, power-of-two operand scaling) on v_mfma_f32_16x16x32_f16 / 32x32x16_f16"
+                               if split_terms == 2 else
+                               "bf16x3 split (6 of 9 products) on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16") +
+                              "; fc1 + head on v_mfma_f32_16x16x4_f32") if args.tower_gemm == "split" else "v_mfma_f32_16x16x4_f32 (--tower-gemm fp32)",
+                "split_terms": split_terms if args.tower_gemm == "split" else None,
+                "mfma16_frac": round(n_prod * (16384.0 / 17792.0) * achieved_tf / BF16_MFMA_PEAK_TFLOPS, 4)
                 if args.tower_gemm == "split" else 0.0,
-                # the pipe the split GEMMs actually run on: 6 bf16 products per fp32 product -> its ceiling in fp32-equivalent
-                # flops is the dense bf16 MFMA peak / 6 (417 TFLOP/s); this says how far the kernel is from THAT
-                "frac_of_bf16_split_ceiling": round(achieved_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4)
+                # the pipe the split GEMMs actually run on: n_prod 16-bit products per fp32 product -> its ceiling in
+                # fp32-equivalent flops is the dense fp16 / bf16 MFMA peak / n_prod (833 TFLOP/s at 3, 417 at 6)
+                "frac_of_split_ceiling": round(achieved_tf / (BF16_MFMA_PEAK_TFLOPS / n_prod), 4)
+                if args.tower_gemm == "split" else None,
+                # (round 5's key, kept: the ceiling of the split the LOADED build uses - / 3 for the fp16 pairs, / 6 for bf16 x 3)
+                "frac_of_bf16_split_ceiling": round(achieved_tf / (BF16_MFMA_PEAK_TFLOPS / n_prod), 4)
                 if args.tower_gemm == "split" else None,
                 **busy,
                 "gae_scan": {"bound": "hbm", "achieved": round(gae_bytes / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else 0,
@@ -442,9 +456,10 @@ def main():
                                  "boundaries): the line's own spread" % len(block_ms),
            "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "dtype_note": "fp32 storage and accumulation everywhere; the 64-wide GEMM products at fp32 ACCURACY on the bf16 "
-                         "MFMA: 6 of the 9 products of three-term bf16 splits (dropped terms ~2^-24 relative; measured error "
-                         "<= v_mfma_f32_16x16x4_f32's, profiles/r03_split_bf16_gemm.txt)",
+           "dtype_note": "fp32 storage and accumulation everywhere; the 64-wide GEMM products at fp32 ACCURACY on the 16-bit "
+                         "MFMA: 3 of the 4 products of two-term fp16 splits (22 significand bits per operand, operands scaled by "
+                         "exact powers of two; measured error <= v_mfma_f32_16x16x4_f32's: tools/split_f16_gemm.hip, "
+                         "profiles/r06_experiments.md section 8)",
            "config": {"workload": "configs[1]: PPO, %d global envs x 128-step rollout (%d envs per GPU), obs 4, "
                                   "Discrete(2), MLP 64x64, ppo_epoch 10, num_mini_batch 1, ValueNorm on; %s" %
                                   (global_envs, n_local, "synthetic fixed-step env" if args.env == "synthetic" else

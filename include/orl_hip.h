@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ORL_VERSION 305 /* 0.3.5: orl_build_experiments; orl_rollout_args.opp_reserved selects the rollout kernel of the single-agent device envs; the GEMM bits of orl_ppo_hparams.reserved are as round 5 re-encoded them for orl_rnn_ppo_fwd_bwd (0 = the production row kernels, 4 = recompute kernel, 8 | 16 = streamed kernels) - undefined combinations are rejected, and the comparison builds behind 4 (orl_ppo_fwd_bwd) / 8 exist only in an ORL_BUILD_EXPERIMENTS library; 0.3.4: orl_gt_train; 0.3.3: orl_gt_* (cross-layer fused general towers); 0.3.2: orl_gen_rollout_fused, ORL_HEAD_MIXED, hparams.reserved & 4; 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
+#define ORL_VERSION 306 /* 0.3.6: orl_tower_split_terms (the MLP towers' 64-wide GEMMs as two-term fp16 splits); 0.3.5: orl_build_experiments; orl_rollout_args.opp_reserved selects the rollout kernel of the single-agent device envs; the GEMM bits of orl_ppo_hparams.reserved are as round 5 re-encoded them for orl_rnn_ppo_fwd_bwd (0 = the production row kernels, 4 = recompute kernel, 8 | 16 = streamed kernels) - undefined combinations are rejected, and the comparison builds behind 4 (orl_ppo_fwd_bwd) / 8 exist only in an ORL_BUILD_EXPERIMENTS library; 0.3.4: orl_gt_train; 0.3.3: orl_gt_* (cross-layer fused general towers); 0.3.2: orl_gen_rollout_fused, ORL_HEAD_MIXED, hparams.reserved & 4; 0.3.0: orl_comm_error_copy; 0.2.6: orl_gen_act; 0.2.5: orl_gen_lstm_gate_fwd / _bwd, orl_gen_matmul, orl_gen_colsum_rows; 0.2.4: orl_gen_gru_gate_fwd / _bwd, orl_gen_row_affine, orl_gen_mlp_fwd feats; 0.2.3: orl_gen_layer_fwd / _bwd / orl_gen_wgrad / orl_gen_colsum; 0.2.2: orl_rollout_args.opp_per_reset..; 0.2.1: orl_rnn_rollout_fused; 0.2.0: rng_step_dev, struct sizes, collectives */
 
 #define ORL_E_INVALID (-1)     /* bad size / null pointer / unsupported combination */
 #define ORL_E_UNSUPPORTED (-2) /* legal in the reference, not built here (says which) */
@@ -460,6 +460,10 @@ typedef struct orl_rollout_args {
 /* 1 when the loaded library was built with -DORL_BUILD_EXPERIMENTS=1 (the comparison kernels that lost their A/B are present:
  * hparams.reserved & 4 / & 8 of orl_ppo_fwd_bwd, & 8 of orl_rnn_ppo_fwd_bwd, orl_ppo_reduce_apply), 0 for the shipped build. */
 int orl_build_experiments(void);
+/* How the MLP towers' 64-wide GEMMs (orl_ppo_fwd_bwd, the chain rollout's critic) form their fp32 products on the 16-bit MFMA:
+ * 2 = two-term fp16 splits, 3 products, operands scaled by exact powers of two (the shipped build, round 6);
+ * 3 = three-term bf16 splits, 6 of 9 products (rounds 3 - 5; ORL_BUILD_DEFS=-DORL_TOWER_F16=0).  Both at fp32 accuracy. */
+int orl_tower_split_terms(void);
 
 int orl_env_state_width(int env_kind);
 int orl_env_reset(int env_kind, float* env_state, float* ep_stats, float* obs0, int N, int obs_dim,

@@ -19,7 +19,7 @@ ORL_HEAD_VALUE, ORL_HEAD_CATEGORICAL, ORL_HEAD_GAUSSIAN = 0, 1, 2
 ORL_ENV_SYNTH, ORL_ENV_CARTPOLE, ORL_ENV_TTT, ORL_ENV_TTT_POOL, ORL_ENV_MPE_SPREAD = 0, 1, 2, 3, 4
 ORL_GATHER_MAX = 12
 ORL_IPC_HANDLE_BYTES = 64
-ORL_VERSION = 305  # must equal include/orl_hip.h; checked against the loaded library
+ORL_VERSION = 306  # must equal include/orl_hip.h; checked against the loaded library
 ORL_N_STATS = 16
 
 c_f32p = C.c_void_p  # device pointers travel as void*
@@ -149,6 +149,7 @@ _P = C.c_void_p
 _SIGNATURES = {
     "orl_version": (C.c_int, []),
     "orl_build_experiments": (C.c_int, []),
+    "orl_tower_split_terms": (C.c_int, []),
     "orl_abi_struct_size": (C.c_int, [C.c_int]),
     "orl_last_error_string": (C.c_char_p, []),
     "orl_param_count": (C.c_int, [C.POINTER(NetDesc)]),

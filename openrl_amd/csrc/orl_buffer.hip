@@ -597,6 +597,7 @@ extern "C" {
 
 int orl_version(void) { return ORL_VERSION; }
 int orl_build_experiments(void) { return ORL_BUILD_EXPERIMENTS; }
+int orl_tower_split_terms(void) { return ORL_TOWER_F16 ? 2 : 3; }
 
 int orl_abi_struct_size(int which) {
   switch (which) {

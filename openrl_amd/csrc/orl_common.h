@@ -15,6 +15,10 @@
 // library leaves them out: their entry points / hparams.reserved bits return ORL_E_UNSUPPORTED, orl_build_experiments() says
 // which build is loaded, and the tests of those paths skip unless it is the experimental one (run once per round:
 // profiles/rNN_pytest_gpu_experiments.log).
+// 1 = the MLP towers' 64-wide GEMMs as two-term fp16 splits (orl_mlp.h, round 6), 0 = the three-term bf16 splits of rounds 3 - 5
+#ifndef ORL_TOWER_F16
+#define ORL_TOWER_F16 1
+#endif
 #ifndef ORL_BUILD_EXPERIMENTS
 #define ORL_BUILD_EXPERIMENTS 0
 #endif

@@ -351,9 +351,6 @@ __device__ __forceinline__ void mm64_T_split_tr(const unsigned short* __restrict
 // and the accumulators are unscaled by the inverse power (exact).  fp16 subnormals pass through the MFMA unflushed
 // (probe), so a value far below its tile's maximum degrades gracefully: its absolute error is 2^-25 x 2^-scale, i.e.
 // <= 2^-36 of the tile's maximum.  ORL_TOWER_F16 = 0 keeps the three-term bf16 kernels of rounds 3 - 5 (A/B switch).
-#ifndef ORL_TOWER_F16
-#define ORL_TOWER_F16 1
-#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int WBH_IMG_FLOATS = 2 * HID * WBS / 2;  // two parts x 64 rows (5 120 floats at WBS = 80)
@@ -536,29 +533,6 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
   // again in the rounds below), a wave maximum per wave, one barrier.  The folded bias b2' is stored scaled as well: fc2's
   // accumulators start from it and LayerNorm 2 takes them scaled (with eps scaled by 4^kw it returns the same xhat2).
   float wscale = 1.f;
-  if (split && ORL_TOWER_F16) {
-    float mx = 0.f;
-    for (int e = tid; e < HID * HID; e += nthreads) {
-      const float w = theta[tl.oW2 + e] * (fold ? theta[tl.og1 + (e & 63)] : 1.f);
-      mx = fmaxf(mx, fabsf(w));
-    }
-    mx = wave_absmax(mx);
-    if ((tid & 63) == 0) lds[tw.wsc + 4 + (tid >> 6)] = mx;
-    __syncthreads();
-    mx = 0.f;
-    for (int w = 0; w < (nthreads + 63) / 64; ++w) mx = fmaxf(mx, lds[tw.wsc + 4 + w]);
-    int kw = 0;
-    const int eb = (int)(f2u(mx) >> 23) & 0xff;  // mx in [2^(eb - 127), 2^(eb - 126))
-    if (eb > 0 && eb < 255) kw = 13 - (eb - 127);
-    kw = kw < -40 ? -40 : (kw > 40 ? 40 : kw);
-    wscale = __builtin_ldexpf(1.f, kw);
-    if (tid == 0) {
-      lds[tw.wsc + 0] = (float)kw;
-      lds[tw.wsc + 1] = wscale;
-      lds[tw.wsc + 2] = __builtin_ldexpf(1.f, -kw);
-      lds[tw.wsc + 3] = __builtin_ldexpf(1e-5f, 2 * kw);
-    }
-  }
   struct Round {  // one round's loaded values of one thread
     float p_w, p_g, w1v, vb1, vg1, vbe1, vb2, vg2, vbe2, w00, w01, w10, w11, g0, g1v, w3v, w3g, vb3, vls, fw[8], fbe[8], fb;
   };
@@ -676,7 +650,36 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
   // one round per trip (two rounds in flight per trip were measured no faster at configuration 2 and slower at the wide
   // towers: 9 500 -> 10 900 cycles of prologue); every lane of a wave runs the same trips - the shuffles of the folded
   // biases are wave-wide
-  for (int e0 = 0; e0 < n_max; e0 += nthreads) {
+  // (fp16 images: round 0's loads are in flight while the image's maximum is formed - one global round trip for both)
+  {
+    Round R;
+    load_round(tid, R);
+    if (split && ORL_TOWER_F16) {
+      float mx = 0.f;
+      for (int e = tid; e < HID * HID; e += nthreads) {
+        const float w = theta[tl.oW2 + e] * (fold ? theta[tl.og1 + (e & 63)] : 1.f);
+        mx = fmaxf(mx, fabsf(w));
+      }
+      mx = wave_absmax(mx);
+      if ((tid & 63) == 0) lds[tw.wsc + 4 + (tid >> 6)] = mx;
+      __syncthreads();
+      mx = 0.f;
+      for (int w = 0; w < (nthreads + 63) / 64; ++w) mx = fmaxf(mx, lds[tw.wsc + 4 + w]);
+      int kw = 0;
+      const int eb = (int)(f2u(mx) >> 23) & 0xff;  // mx in [2^(eb - 127), 2^(eb - 126))
+      if (eb > 0 && eb < 255) kw = 13 - (eb - 127);
+      kw = kw < -40 ? -40 : (kw > 40 ? 40 : kw);
+      wscale = __builtin_ldexpf(1.f, kw);
+      if (tid == 0) {
+        lds[tw.wsc + 0] = (float)kw;
+        lds[tw.wsc + 1] = wscale;
+        lds[tw.wsc + 2] = __builtin_ldexpf(1.f, -kw);
+        lds[tw.wsc + 3] = __builtin_ldexpf(1e-5f, 2 * kw);
+      }
+    }
+    store_round(tid, R);
+  }
+  for (int e0 = nthreads; e0 < n_max; e0 += nthreads) {
     Round R;
     load_round(e0 + tid, R);
     store_round(e0 + tid, R);

@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_host_side_queries(lib):
     from openrl_amd import _native as n
 
-    assert lib.orl_version() == n.ORL_VERSION == 305
+    assert lib.orl_version() == n.ORL_VERSION == 306
     pol = n.NetDesc(4, 64, 2, n.ORL_HEAD_CATEGORICAL)
     cri = n.NetDesc(4, 64, 1, n.ORL_HEAD_VALUE)
     gau = n.NetDesc(17, 64, 6, n.ORL_HEAD_GAUSSIAN)

@@ -74,9 +74,21 @@ if [ -f variants/prof.so ]; then
   python tools/rnn_phase_prof.py fp32_recompute 2>/dev/null | grep -v "^{" >> $OUT/${TAG}_rnn_phase_prof.txt
   python tools/rollout2_phase_prof.py 2>/dev/null | grep -v "^{" > $OUT/${TAG}_rollout2_phase_prof.txt
   python tools/rollout2_phase_prof.py --env cartpole 2>/dev/null | grep -v "^{" >> $OUT/${TAG}_rollout2_phase_prof.txt
+  for shp in cfg3 cfg5; do
+    echo "== shape $shp (benchmarks/shape_sweep.py)" >> $OUT/${TAG}_rollout2_phase_prof.txt
+    python tools/rollout2_phase_prof.py --shape $shp 2>/dev/null | grep -v "^{" >> $OUT/${TAG}_rollout2_phase_prof.txt
+  done
   cp variants/default.so openrl_amd/csrc/liborl_hip.so
 fi
 # 10. the GPU test suite
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/${TAG}_pytest_gpu.log
+timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/${TAG}_pytest_gpu.log
+# 11. the comparison kernels' tests and the split's accuracy against float64 on the ORL_BUILD_EXPERIMENTS library
+if [ -f variants/experiments.so ]; then
+  cp variants/experiments.so openrl_amd/csrc/liborl_hip.so
+  timeout 2400 python -m pytest tests -m gpu -q -s -k "split or fp32 or one_launch or two_image" 2>&1 | grep -E "tower:|passed|failed" | cut -c1-250 > $OUT/${TAG}_pytest_gpu_experiments.log
+  cp variants/default.so openrl_amd/csrc/liborl_hip.so
+fi
+# 12. the split's own probe (one wave against float64)
+[ -x variants/bin/sfg ] && variants/bin/sfg > $OUT/${TAG}_split_f16_gemm.txt 2>&1
 tail -3 $OUT/${TAG}_pytest_gpu.log
 rm -rf $OUT/pmcrow_* $OUT/pmct_* $OUT/pmcgth_*
