@@ -231,9 +231,9 @@ __device__ __forceinline__ void mm64_S_osplit(const float* __restrict__ Ws, cons
     const float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     u32x4 wh, wm, wl;
     split8(x, wh, wm, wl);
-    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
-    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);)
     acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
@@ -260,9 +260,9 @@ __device__ __forceinline__ void mm64_S_wt_osplit(const float* __restrict__ Ws, c
                         a[st & 1][4], a[st & 1][5], a[st & 1][6], a[st & 1][7]};
     u32x4 wh, wm, wl;
     split8(x, wh, wm, wl);
-    acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);
-    acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);)
+    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);)
     acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
     acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
