@@ -60,6 +60,9 @@ __device__ unsigned long long g_orl_prof[24];
 #define ORL_T(k) ((void)0)
 #endif
 
+#ifndef ORL_DMA_WAIT_DEP
+#define ORL_DMA_WAIT_DEP 1
+#endif
 #ifndef ORL_WGRAD_HALVES
 #define ORL_WGRAD_HALVES 1
 #endif
@@ -331,8 +334,15 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   for (int tile = wave_g; tile < n_tiles; tile += n_waves) {
     const int i = tile * TILE_B + j;
     const bool valid = i < A.mb;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's records have landed in LDS
+    // This tile's records have landed in LDS.  On the small-observation build the wait orders only what reads the ring: it
+    // "redefines" the ring pointer instead of clobbering memory, so hipcc keeps scheduling the tile's other LDS traffic across
+    // it (- 1.5 % of the pair launch, tools/r06_calls/r06_call22.sh; the wide builds pay 23 more registers for it and spill: they
+    // keep the barrier form).  ORL_PROBE_NO_DMA_WAIT: timing probe, never shipped (reads the ring without waiting).
     const float* RT = RR + ring * rts;
+#if !defined(ORL_PROBE_NO_DMA_WAIT)
+    if constexpr (ND == 0 && ORL_DMA_WAIT_DEP) asm volatile("s_waitcnt vmcnt(0)" : "+v"(RT));
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     // Order matters: the index prefetch (a load hipcc counts) is re-issued BEFORE the DMA (which it cannot see).  The
     // other way round, hipcc's own "previous load into these registers must have landed" wait sits behind the DMA
     // and drains it.
