@@ -1350,7 +1350,9 @@ int orl_rollout_fused(const orl_net_desc* pnet, const float* ptheta, const orl_n
   // Round 6: the synthetic env and CartPole roll out on the chain kernel (orl_rollout2.h: policy-only step chain, the critic on
   // background waves of the same launch).  args.opp_reserved = 1 keeps the round-5 lock-step kernel (policy + critic in the
   // step loop) - the A/B switch of tests and benchmarks.
-  const size_t lds2 = (size_t)ro2_lds(twp.total, TowerLds(cnet->obs_dim, 1, false, false, false, true).total, twp.DP).total *
+  const size_t lds2 = (size_t)ro2_lds(TowerLds(pnet->obs_dim, pnet->n_out, pnet->head_kind == ORL_HEAD_GAUSSIAN, false, pnet->n_out > 2,
+                                               ORL_TOWER_F16 != 0).total,
+                                      TowerLds(cnet->obs_dim, 1, false, false, false, true).total, twp.DP).total *
                       sizeof(float);
   // (the widest towers - observations of ~60 columns with 16 outputs - do not fit the chain kernel's rings beside both tower
   // images: they keep the round-5 kernel)

@@ -154,9 +154,12 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
   const int N = b.N, T = b.T;
   const TowerLayout tlp(A.pnet), tlc(A.cnet);
   constexpr bool HMM = NO > 4;
-  const TowerLds twp(D, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false, HMM);
-  const TowerLds twc(D, 1, false, false, false, true);  // the critic's W2 as bf16 split images
-  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM, false, true);
+  // both towers' W2 diag(g1) as the scaled two-term fp16 images of orl_mlp.h (ORL_TOWER_F16; the policy's fc2 - 16 fp32 MFMAs of
+  // 32 cycles on every step's chain - is 6 fp16 MFMAs + 32 VALU of splitting: 710 -> ~300 cycles of the step)
+  constexpr bool PSPLIT = ORL_TOWER_F16 != 0;
+  const TowerLds twp(D, A.pnet.n_out, HEAD == ORL_HEAD_GAUSSIAN, false, HMM, PSPLIT);
+  const TowerLds twc(D, 1, false, false, false, true);  // the critic's W2 as split images
+  stage_tower(smem, A.ptheta, tlp, twp, false, threadIdx.x, blockDim.x, HMM, PSPLIT, true);
   stage_tower(smem + twp.total, A.ctheta, tlc, twc, false, threadIdx.x, blockDim.x, false, true, true);
   const int DP = KS > 0 ? 4 * KS : twp.DP;
   const Ro2Lds L = ro2_lds(twp.total, twc.total, DP);
@@ -209,6 +212,16 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
     const int gw = wave;
     CoopRegs creg;
     coop_load(smem, twp, gw, j, q, creg);
+    // fp16 images: this wave's 16 output rows of fc2 - A fragments (K-step h, part p) of row block gw, in registers for the launch
+    u32x4 wA[2][2];
+    float ln2_eps = 1e-5f;
+    if constexpr (PSPLIT) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) wA[h][pp] = *(const u32x4*)((const unsigned short*)(smem + twp.W2) + wb_off(pp, 16 * gw + j, h, q));
+      ln2_eps = smem[twp.wsc + 3];  // 1e-5 x 4^kw: the accumulators below are 2^kw z2
+    }
     // wide observations: this wave's fc1 A operands W1[16 gw + j][4 s + q] of the first 8 k-steps in registers (observations
     // of <= 32 columns: cfg3's 17, cfg5's 18); k-steps beyond come from the LDS image every step
     float w1w[KS > 0 ? 1 : 8];
@@ -358,15 +371,26 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
       R2_T(2);
       // ---- fc2: this wave's 16 output features, two chains of 8 MFMAs (the round-5 kernel's order)
       f32x4 z = creg.b2, z2b = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (PSPLIT) {
+        u32x4 xs[2][2];
+        split_Th(x, xs);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          z = ORL_MFMA(creg.w2[mi][r], x[mi][r], z);
-          z2b = ORL_MFMA(creg.w2[mi + 2][r], x[mi + 2][r], z2b);
+        for (int h = 0; h < 2; ++h) {  // mm64_T_h2's order for one row block
+          z = mfma_f16_16(wA[h][1], xs[h][0], z);
+          z = mfma_f16_16(wA[h][0], xs[h][1], z);
+          z = mfma_f16_16(wA[h][0], xs[h][0], z);
         }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            z = ORL_MFMA(creg.w2[mi][r], x[mi][r], z);
+            z2b = ORL_MFMA(creg.w2[mi + 2][r], x[mi + 2][r], z2b);
+          }
+        }
+        z = z + z2b;
       }
-      z = z + z2b;
       R2_T(3);
       // ---- this wave's partials of LayerNorm 2 + head, and the z slice for the guarded path
       float* pw = s_part + ((t & 1) * 4 + gw) * PSLOT;
@@ -452,7 +476,7 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
         const float* zt = s_z2 + (t & 1) * TILE_B * GS;
 #pragma unroll
         for (int m = 0; m < 4; ++m) zz[m] = *(const f32x4*)(zt + j * GS + 16 * m + 4 * q);
-        ln_normalize_T(zz, r2);
+        ln_normalize_T(zz, r2, ln2_eps);
         if constexpr (HMM) {
           const int no4 = (n_out + 3) & ~3;
           lgv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -470,7 +494,7 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
           for (int c = 0; c < NO; ++c) hd[c] = h2[c];
         }
       } else {
-        const float rstd2 = __builtin_amdgcn_rsqf(fmaxf(var2, 0.f) + 1e-5f);
+        const float rstd2 = __builtin_amdgcn_rsqf(fmaxf(var2, 0.f) + ln2_eps);
         const float mr = mean2 * rstd2;
         if constexpr (HMM) {
 #pragma unroll
