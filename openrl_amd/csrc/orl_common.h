@@ -227,6 +227,24 @@ __device__ inline void row_allmax2(float& x, float& y) {
   y = b;
 }
 
+// x[l] + x[l ^ 32] in every lane (one v_permlane32_swap instead of a ds_bpermute round trip)
+__device__ inline float xor32_sum(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
+// sum over the wave, in every lane, on the VALU: four DPP rotations inside the 16-lane rows, then row_allsum's two half-wave
+// swaps - wave_sum below takes six ds_bpermute round trips through the LDS queue (a different order of additions: results
+// differ in the last bits)
+__device__ inline float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  return row_allsum(v);
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

@@ -638,9 +638,11 @@ __device__ inline void stage_tower(float* __restrict__ lds, const float* __restr
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc += R.fw[k] * R.fbe[k];
-      acc += __shfl_xor(acc, 1);
-      acc += __shfl_xor(acc, 2);
-      acc += __shfl_xor(acc, 4);
+      // sum over the 8 aligned lanes of a row on the VALU (DPP quad permutes + half-row mirror: the same pairs as the
+      // ds_bpermute butterfly acc += xor 1, 2, 4 - three LDS round trips per round of the prologue)
+      acc += u2f(__builtin_amdgcn_update_dpp(0u, f2u(acc), 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
+      acc += u2f(__builtin_amdgcn_update_dpp(0u, f2u(acc), 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+      acc += u2f(__builtin_amdgcn_update_dpp(0u, f2u(acc), 0x141, 0xf, 0xf, false));  // row_half_mirror
       if (fo < rows && part == 0) {
         if (fo < HID) lds[tw.b2 + fo] = (R.fb + acc) * wscale;
         else lds[tw.b3 + (fo - HID)] = R.fb + acc;

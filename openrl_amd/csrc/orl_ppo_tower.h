@@ -1162,13 +1162,14 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     }
   }
   __syncthreads();
-  st_active = wave_sum(st_active); st_rows = wave_sum(st_rows); st_loss = wave_sum(st_loss);
-  st_ent = wave_sum(st_ent); st_ratio = wave_sum(st_ratio);
+  // (VALU reductions: the ds_bpermute form of wave_sum was 6 LDS round trips per sum in front of the image rounds)
+  st_active = wave_sum_dpp(st_active); st_rows = wave_sum_dpp(st_rows); st_loss = wave_sum_dpp(st_loss);
+  st_ent = wave_sum_dpp(st_ent); st_ratio = wave_sum_dpp(st_ratio);
 #if ORL_DB3_ROWLANE
   if constexpr (!HMM) {  // lane c of the wave ends up with db3[c], as the per-tile column sums left it
 #pragma unroll
     for (int c = 0; c < NO; ++c) {
-      const float tot = wave_sum(a_db3r[c]);
+      const float tot = wave_sum_dpp(a_db3r[c]);
       if (l == c) a_db3 = tot;
     }
   }
@@ -1213,7 +1214,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #pragma unroll
               for (int r = 0; r < 16; ++r) acc[g_idx(bo, bi, r)] = old[bo][bi][r] + GS[bo][bi][r];
         }
-        const float d0 = a_db2s[0] + __shfl_xor(a_db2s[0], 32), d1s = a_db2s[1] + __shfl_xor(a_db2s[1], 32);
+        const float d0 = xor32_sum(a_db2s[0]), d1s = xor32_sum(a_db2s[1]);
         if (l < 32) {
           put(rl.odb2 + l, d0);
           put(rl.odb2 + 32 + l, d1s);
@@ -1246,7 +1247,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         put(rl.odb2 + f, a_db2);
       }
       if constexpr (W1S) {
-        const float e0 = a_db1s[0] + __shfl_xor(a_db1s[0], 32), e1 = a_db1s[1] + __shfl_xor(a_db1s[1], 32);
+        const float e0 = xor32_sum(a_db1s[0]), e1 = xor32_sum(a_db1s[1]);
         if (l < 32) {
           put(rl.odb1 + l, e0);
           put(rl.odb1 + 32 + l, e1);
