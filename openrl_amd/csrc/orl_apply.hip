@@ -62,7 +62,7 @@ __device__ inline void stage_dma(float* lds_dst, const float* __restrict__ src, 
 }
 
 __device__ inline float block_sum_1024(float v, float* sh) {
-  v = wave_sum(v);
+  v = wave_sum_dpp(v);  // (on the VALU: the ds_bpermute butterfly was six LDS round trips on the optimiser step's serial chain)
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) sh[w] = v;
   __syncthreads();
