@@ -25,7 +25,7 @@ namespace orl {
 // A/B knob: raise the wave's issue priority around MFMA bursts (cdna guide T5).  ORL_USE_SETPRIO = 1: the fc2 burst only (the
 // round-2 form), 2: the dgrad and wgrad bursts too.
 #ifndef ORL_USE_SETPRIO
-#define ORL_USE_SETPRIO 1   // round 5: -0.8 % on the pair launch in four same-box alternations (profiles/r05_experiments.md)
+#define ORL_USE_SETPRIO 2   // round 5 (six bf16 products): 1 was - 0.8 % on the pair launch, 2 no better; round 6 (three fp16 products): 2 is - 3 % against 1, 0 is + 2 % (tools/r06_calls/r06_call27.sh)
 #endif
 #if ORL_USE_SETPRIO >= 1
 #define ORL_PRIO(x) __builtin_amdgcn_s_setprio(x)
@@ -33,7 +33,11 @@ namespace orl {
 #define ORL_PRIO(x) ((void)0)
 #endif
 #if ORL_USE_SETPRIO >= 2
-#define ORL_PRIO2(x) __builtin_amdgcn_s_setprio(x)
+// (the small-observation build only: the wide ones measured + 1 % with it at cfg5's shape, no difference at cfg3's; 3 = everywhere)
+#define ORL_PRIO2(x)                                                           \
+  do {                                                                         \
+    if constexpr (ND == 0 || ORL_USE_SETPRIO >= 3) __builtin_amdgcn_s_setprio(x); \
+  } while (0)
 #else
 #define ORL_PRIO2(x) ((void)0)
 #endif
