@@ -341,7 +341,10 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
     // This tile's records have landed in LDS.  On the small-observation build the wait orders only what reads the ring: it
     // "redefines" the ring pointer instead of clobbering memory, so hipcc keeps scheduling the tile's other LDS traffic across
     // it (- 1.5 % of the pair launch, tools/r06_calls/r06_call22.sh; the wide builds pay 23 more registers for it and spill: they
-    // keep the barrier form).  ORL_PROBE_NO_DMA_WAIT: timing probe, never shipped (reads the ring without waiting).
+    // keep the barrier form).  The laundered pointer is a GENERIC one: the ring's 20 reads per tile become flat_load (the vector
+    // memory path) - kept on purpose: laundering it as an address-space-3 pointer (ds_read again, 27 registers less) measured
+    // 0.1856 / 0.1832 ms per launch against 0.1777 / 0.1734 for this form (tools/r06_calls/r06_call29.sh).
+    // ORL_PROBE_NO_DMA_WAIT: timing probe, never shipped (reads the ring without waiting).
     const float* RT = RR + ring * rts;
 #if !defined(ORL_PROBE_NO_DMA_WAIT)
     if constexpr (ND == 0 && ORL_DMA_WAIT_DEP) asm volatile("s_waitcnt vmcnt(0)" : "+v"(RT));
