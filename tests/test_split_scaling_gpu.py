@@ -15,7 +15,6 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import ppo_oracle as po
 from tests import helpers as H
 from tests import test_ppo_update_gpu as TU
 

@@ -4,9 +4,10 @@
 
 Measured on the round-6 tree: 0.41 ms of host work per iteration (median 0.39, max 0.64) against 2.03 ms of GPU work - the launch
 queue deepens by ~1.6 ms per iteration, so host-side hiccups of tens of milliseconds do not reach the device."""
-import sys, time, json, os
+import os
+import sys
+import time
 sys.path.insert(0, os.getcwd())
-import torch
 import bench
 # monkeypatch: measure host time of _inner_loop calls inside bench.main()
 from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
