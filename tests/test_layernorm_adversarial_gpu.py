@@ -175,3 +175,54 @@ def test_one_recurrent_update_with_ill_conditioned_layernorm_rows(case, ratio):
     obs_p = g["buf_policy_obs"][:-1].reshape(-1, specs[0].obs_dim)
     obs_c = g["buf_critic_obs"][:-1].reshape(-1, specs[1].obs_dim)
     TR.rnn_update_vs_oracle(_shifted_golden(g, specs, ratio, obs_p, obs_c), grad_atol=3e-5 + 4 * EPS32 * ratio)
+
+
+@pytest.mark.parametrize("ratio", [30, 300])
+@pytest.mark.parametrize("kw,N,T", [
+    (dict(obs_dim=4, episode_limit=7), 80, 12),                                  # narrow head: two classes in the 4-float partial
+    (dict(obs_dim=17, episode_limit=9, action_space="box6"), 48, 10),            # wide Gaussian head: MFMA partial, wide fc1
+])
+def test_chain_rollout_with_ill_conditioned_layernorm_rows(kw, N, T, ratio):
+    """The chain rollout kernel (csrc/orl_rollout2.h) forms LayerNorm 2 and the head from per-wave PARTIAL sums of the policy's
+    fc2 - since round 6 accumulated as 2^kw z2 over the fp16 split - and falls back to the full guarded LayerNorm when a row of
+    the tile has mean^2 > 16 var.  Both towers' b1 / b2 shifted to mean / std = ratio: every tile takes that path.  Checked
+    against the round-5 lock-step kernel (whole-row guarded LayerNorm, fp32 MFMA) on the same seeds; the env stream of the
+    synthetic env does not depend on the actions, so every step compares."""
+    from openrl_amd import spaces
+    from openrl_amd.drivers.onpolicy_driver import OnPolicyDriver
+    from tests import test_rollout_gpu as TR
+
+    kind = kw.get("action_space")
+    if isinstance(kind, str):
+        kw = dict(kw, action_space=spaces.Box(-1.0, 1.0, (int(kind[3:]),)))
+    out = []
+    for kernel in ("chain", "lockstep"):
+        cfg, env, net, trainer, buf, agent = TR._build("SyntheticFixedStep-v0", N, T, **kw)
+        cfg.amd_rollout_kernel = kernel
+        drv = OnPolicyDriver({"cfg": cfg, "num_agents": 1, "run_dir": None, "envs": env, "device": DEV}, trainer, buf, agent)
+        assert drv.fused
+        drv.reset_and_buffer_init()
+        obs = buf.data.policy_obs[0].reshape(N, -1).cpu().numpy()
+        D = obs.shape[1]
+        for name, spec in (("policy", po.TowerSpec(D, net.module.models["policy"].net.n_out, net.module.models["policy"].net.head_kind)),
+                           ("critic", po.TowerSpec(D, 1, po.HEAD_VALUE))):
+            m = net.module.models[name]
+            th, (r1, r2) = _ill_condition(spec, m.theta.cpu().numpy(), obs, ratio)
+            assert r2 > 0.5 * ratio, (name, r1, r2)
+            m.theta.copy_(torch.tensor(th))
+        drv.actor_rollout()
+        d = buf.data
+        out.append({f: getattr(d, f).cpu().numpy().copy() for f in ("actions", "action_log_probs", "value_preds", "policy_obs", "rewards")})
+    a, b = out
+    assert np.array_equal(a["policy_obs"], b["policy_obs"]) and np.array_equal(a["rewards"], b["rewards"])
+    tol = 1e-4 + 8 * EPS32 * ratio  # both kernels' xhat carries ~eps32 ratio of rounding at mean / std = ratio
+    if isinstance(kind, str):
+        np.testing.assert_allclose(a["actions"], b["actions"], rtol=tol, atol=tol)
+        same = np.ones_like(a["actions"], dtype=bool)
+    else:
+        same = a["actions"] == b["actions"]
+        assert same.mean() >= 0.99, same.mean()
+    np.testing.assert_allclose(a["action_log_probs"][same], b["action_log_probs"][same], rtol=tol, atol=tol)
+    # (slot T is the bootstrap value: the chain kernel writes it in the rollout, the lock-step path in compute_returns)
+    va, vb = a["value_preds"][:-1], b["value_preds"][:-1]
+    np.testing.assert_allclose(va, vb, rtol=tol, atol=tol * max(1.0, float(np.abs(vb).max())))
