@@ -73,15 +73,30 @@ struct RnnRaw {
 };
 
 // ---- LDS image of a recurrent tower (row kernel): 64x64 blocks padded to W2S columns ----------------------
+// Round 6 (ORL_RNN_L2_H2): the seven 64 x 64 matrices of the register-resident L = 2 row kernel as two-term fp16 IMAGES (orl_mlp.h:
+// hi = rn16(x), lo = rn16(x - hi), 3 products per fp32 product) instead of fp32 rows under v_mfma_f32_16x16x4_f32.  At the row
+// stride RWBS = 72 elements two parts of a matrix are 18 KB (fp32 rows at stride 68: 17 KB) - seven of them fit beside W1 where
+// the fp32 rows are; the conflict-free stride 80 (orl_mlp.h: WBS) would not.  Scales: W2 by 2^kw2 from its own maximum, the six GRU
+// matrices by ONE 2^kwg (their products are added inside the gates); biases stored scaled.
+#ifndef ORL_RNN_L2_H2
+#define ORL_RNN_L2_H2 1
+#endif
+constexpr int RWBS = 72;
+constexpr int RIMG_FLOATS = 2 * HID * RWBS / 2;  // floats per matrix image (two parts x 64 rows)
+__device__ __forceinline__ int rwb_off(int p, int o, int h, int q) { return (p * HID + o) * RWBS + h * 32 + q * 8; }
+
 struct RnnLds {
-  int DP, W1, b1, g1, be1, W2, b2, g2, be2, Wih, Whh, bih, bhh, g3, be3, W3, b3, logstd, W3P, total;
+  int DP, W1, b1, g1, be1, W2, b2, g2, be2, Wih, Whh, bih, bhh, g3, be3, W3, b3, logstd, W3P, wsc, total;
   __host__ __device__ RnnLds() {}
   // with_w3p: W3 zero padded to [16][W2S] - the MFMA operand of the wide categorical head in the row kernel
   // stream: the seven 64 x 64 matrices (W2, Wih, Whh) are NOT resident - the streamed row kernel (orl_rnn_stream.h) pulls
   // their bf16 images through a ring behind `total`
   // no_w1: W1 is not resident either (the cooperative rollout's critic holds its 16 rows of W1 in registers)
+  // h2: W2 / Wih / Whh are fp16 images (RIMG_FLOATS each); wsc = {kw2, 2^kw2, 2^-kw2, 1e-5 x 4^kw2, kwg, 2^kwg, 2^-kwg, -} + 32
+  // words of scratch for the staging's maxima
   __host__ __device__ RnnLds(int D, int n_out, bool gaussian, bool with_w3p = false, bool stream = false,
-                             bool no_w1 = false) {
+                             bool no_w1 = false, bool h2 = false) {
+    const int mat = h2 ? RIMG_FLOATS : HID * W2S;
     DP = (D + 3) & ~3;
     const int no4 = (n_out + 3) & ~3;
     int o = 0;
@@ -89,12 +104,12 @@ struct RnnLds {
     b1 = o; o += HID;
     g1 = o; o += HID;
     be1 = o; o += HID;
-    W2 = o; o += stream ? 0 : HID * W2S;
+    W2 = o; o += stream ? 0 : mat;
     b2 = o; o += HID;
     g2 = o; o += HID;
     be2 = o; o += HID;
-    Wih = o; o += stream ? 0 : 3 * HID * W2S;
-    Whh = o; o += stream ? 0 : 3 * HID * W2S;
+    Wih = o; o += stream ? 0 : 3 * mat;
+    Whh = o; o += stream ? 0 : 3 * mat;
     bih = o; o += 3 * HID;
     bhh = o; o += 3 * HID;
     g3 = o; o += HID;
@@ -103,14 +118,48 @@ struct RnnLds {
     b3 = o; o += no4;
     logstd = o; o += gaussian ? no4 : 0;
     W3P = o; o += with_w3p ? 16 * W2S : 0;
+    wsc = o; o += h2 ? 40 : 0;
     total = o;
   }
 };
 
 __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __restrict__ theta, const RnnLayout& tl,
                                        const RnnLds& tw, int tid, int nthreads, bool with_w3p = false,
-                                       bool stream = false, bool no_w1 = false) {
+                                       bool stream = false, bool no_w1 = false, bool h2 = false) {
   const int D = tl.D;
+  // fp16 images: the two scales first (one pass over the seven matrices, a wave maximum per wave, one barrier)
+  float sc2 = 1.f, scg = 1.f;
+  if (h2) {
+    float m2 = 0.f, mg = 0.f;
+    for (int e = tid; e < HID * HID; e += nthreads) m2 = fmaxf(m2, fabsf(theta[tl.oW2 + e]));
+    for (int e = tid; e < 3 * HID * HID; e += nthreads)
+      mg = fmaxf(mg, fmaxf(fabsf(theta[tl.oWih + e]), fabsf(theta[tl.oWhh + e])));
+    m2 = wave_absmax(m2);
+    mg = wave_absmax(mg);
+    if ((tid & 63) == 0) {
+      lds[tw.wsc + 8 + (tid >> 6)] = m2;
+      lds[tw.wsc + 24 + (tid >> 6)] = mg;
+    }
+    __syncthreads();
+    m2 = mg = 0.f;
+    for (int w = 0; w < (nthreads + 63) / 64; ++w) {
+      m2 = fmaxf(m2, lds[tw.wsc + 8 + w]);
+      mg = fmaxf(mg, lds[tw.wsc + 24 + w]);
+    }
+    auto kof = [](float mx) -> int {  // the power of two that moves mx into [2^13, 2^14)
+      const int eb = (int)(f2u(mx) >> 23) & 0xff;
+      int k = (eb > 0 && eb < 255) ? 13 - (eb - 127) : 0;
+      return k < -40 ? -40 : (k > 40 ? 40 : k);
+    };
+    const int k2 = kof(m2), kg = kof(mg);
+    sc2 = __builtin_ldexpf(1.f, k2);
+    scg = __builtin_ldexpf(1.f, kg);
+    if (tid == 0) {
+      lds[tw.wsc + 0] = (float)k2; lds[tw.wsc + 1] = sc2; lds[tw.wsc + 2] = __builtin_ldexpf(1.f, -k2);
+      lds[tw.wsc + 3] = __builtin_ldexpf(1e-5f, 2 * k2);
+      lds[tw.wsc + 4] = (float)kg; lds[tw.wsc + 5] = scg; lds[tw.wsc + 6] = __builtin_ldexpf(1.f, -kg);
+    }
+  }
   if (with_w3p) {
     for (int e = tid; e < 16 * W2S; e += nthreads) {
       const int c = e / W2S, i = e - c * W2S;
@@ -125,17 +174,34 @@ __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __r
     lds[tw.b1 + e] = theta[tl.ob1 + e];
     lds[tw.g1 + e] = theta[tl.og1 + e];
     lds[tw.be1 + e] = theta[tl.obe1 + e];
-    lds[tw.b2 + e] = theta[tl.ob2 + e];
+    lds[tw.b2 + e] = theta[tl.ob2 + e] * sc2;
     lds[tw.g2 + e] = theta[tl.og2 + e];
     lds[tw.be2 + e] = theta[tl.obe2 + e];
     lds[tw.g3 + e] = theta[tl.og3 + e];
     lds[tw.be3 + e] = theta[tl.obe3 + e];
   }
   for (int e = tid; e < 3 * HID; e += nthreads) {
-    lds[tw.bih + e] = theta[tl.obih + e];
-    lds[tw.bhh + e] = theta[tl.obhh + e];
+    lds[tw.bih + e] = theta[tl.obih + e] * scg;
+    lds[tw.bhh + e] = theta[tl.obhh + e] * scg;
   }
-  if (!stream) {
+  if (h2) {
+    // images: element pairs (k even, k + 1) of row o -> one dword per part (split_weight_store2h's addressing at stride RWBS)
+    auto image = [&](const float* __restrict__ src, unsigned short* __restrict__ img, int n_rows, float sc) {
+      for (int e = tid; e < n_rows * (HID / 2); e += nthreads) {
+        const int o = e >> 5, k = 2 * (e & 31);
+        const float w0 = src[o * HID + k] * sc, w1 = src[o * HID + k + 1] * sc;
+        const int m = k >> 4, qq = (k >> 2) & 3, r = k & 3, h = m >> 1, sl = (m & 1) * 4 + r;
+        unsigned short* mat = img + (o >> 6) * (2 * RIMG_FLOATS);  // (o >> 6: which of the stacked matrices; in ushorts)
+        const int oo = o & 63;
+        const unsigned hi = cvt_pk_f16(w0, w1);
+        *(unsigned*)(mat + rwb_off(0, oo, h, qq) + sl) = hi;
+        *(unsigned*)(mat + rwb_off(1, oo, h, qq) + sl) = cvt_pk_f16(rem16_lo(hi, w0), rem16_hi(hi, w1));
+      }
+    };
+    image(theta + tl.oW2, (unsigned short*)(lds + tw.W2), HID, sc2);
+    image(theta + tl.oWih, (unsigned short*)(lds + tw.Wih), 3 * HID, scg);
+    image(theta + tl.oWhh, (unsigned short*)(lds + tw.Whh), 3 * HID, scg);
+  } else if (!stream) {
     // The seven 64 x 64 matrices are plain copies with a new row stride: one LDS-DMA instruction per row (a wave's 64 lanes
     // = the row's 64 floats, written at a wave-uniform LDS address), all 448 of a workgroup in flight at once.  The register
     // loops they replace were 8 loads in flight per trip - 7 to 28 global round trips in a row on 512 to 128 threads.
@@ -157,7 +223,7 @@ __device__ inline void stage_rnn_tower(float* __restrict__ lds, const float* __r
     lds[tw.b3 + e] = (e < tl.n_out) ? theta[tl.ob3 + e] : 0.f;
     if (tl.head == ORL_HEAD_GAUSSIAN) lds[tw.logstd + e] = (e < tl.n_out) ? theta[tl.ologstd + e] : 0.f;
   }
-  if (!stream) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA rows have landed (callers barrier next)
+  if (!stream && !h2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA rows have landed (callers barrier next)
 }
 
 // acc += W[64 x 64, row stride S] * in   (T layout; S = W2S for the LDS image, 64 for weights read from global)
@@ -384,6 +450,108 @@ __device__ inline void gru_fwd_T_osplit(const float* __restrict__ Wih, const flo
       r[m][k] = rr;
       z[m][k] = zz;
       n[m][k] = nn;
+      hnew[m][k] = (1.0f - zz) * nn + zz * hin[m][k];
+    }
+}
+
+// ---- round 6: the same GEMMs over the two-term fp16 images (RnnLds h2) ----------------------------------------------------
+// acc += W in / acc += W^T in (T layout) - orl_mlp.h's mm64_T_h2 / mm64_T_h2_tr at the recurrent images' stride
+__device__ __forceinline__ void mm64_R_h2(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][2], f32x4 (&acc)[4], int j,
+                                          int q) {
+  u32x4 w[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) w[0][p] = *(const u32x4*)(Wb + rwb_off(p, j, 0, q));
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int h = st >> 2, mo = st & 3;
+    if (st < 7) {
+      const int h2 = (st + 1) >> 2, mo2 = (st + 1) & 3;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) w[(st + 1) & 1][p] = *(const u32x4*)(Wb + rwb_off(p, 16 * mo2 + j, h2, q));
+    }
+    const u32x4 wh = w[st & 1][0], wl = w[st & 1][1];
+    acc[mo] = mfma_f16_16(wl, xs[h][0], acc[mo]);
+    acc[mo] = mfma_f16_16(wh, xs[h][1], acc[mo]);
+    acc[mo] = mfma_f16_16(wh, xs[h][0], acc[mo]);
+  }
+}
+__device__ __forceinline__ void mm64_R_h2_tr(const unsigned short* __restrict__ Wb, const u32x4 (&xs)[2][2], f32x4 (&acc)[4],
+                                             int j, int q) {
+  const unsigned short* base = Wb + (4 * q + (j >> 2)) * RWBS + (j & 3) * 8;
+  auto frag = [&](int p, int h, int mo) -> u32x4 {
+    const unsigned short* a = base + (p * HID + 32 * h) * RWBS + (mo >> 1) * 32 + (mo & 1) * 4;
+    const u32x2 lo = ds_read_tr16(a), hi = ds_read_tr16(a + 16 * RWBS);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
+  u32x4 w[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) w[0][p] = frag(p, 0, 0);
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int h = st >> 2, mo = st & 3;
+    if (st < 7) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) w[(st + 1) & 1][p] = frag(p, (st + 1) >> 2, (st + 1) & 3);
+    }
+    const u32x4 wh = w[st & 1][0], wl = w[st & 1][1];
+    acc[mo] = mfma_f16_16(wl, xs[h][0], acc[mo]);
+    acc[mo] = mfma_f16_16(wh, xs[h][1], acc[mo]);
+    acc[mo] = mfma_f16_16(wh, xs[h][0], acc[mo]);
+  }
+}
+// per-ROW scales of gradient vectors (lane (j, q) holds 16 values of batch row j per vector): absmax16 folds a vector into a
+// running lane maximum; row_shift turns the row's maximum (over its 4 lanes) into the power of two that moves it into
+// [2^11, 2^12); ldexp16 applies it
+__device__ __forceinline__ float absmax16(const f32x4 (&v)[4], float mx) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[m][0]), fabsf(v[m][1]))), fmaxf(fabsf(v[m][2]), fabsf(v[m][3])));
+  return mx;
+}
+__device__ __forceinline__ int row_shift(float lane_max) { return 138 - scale_exponent(row_allmax(lane_max)); }
+__device__ __forceinline__ void ldexp16(f32x4 (&v)[4], int sh) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[m][r] = __builtin_ldexpf(v[m][r], sh);
+}
+// gru_fwd_T over the images: Wih / Whh = three stacked images (r, z, n), bih / bhh scaled by 2^kwg like the images; ginv = 2^-kwg
+__device__ inline void gru_fwd_T_h2(const unsigned short* __restrict__ Wih, const unsigned short* __restrict__ Whh,
+                                    const float* __restrict__ bih, const float* __restrict__ bhh, const float ginv,
+                                    const f32x4 (&x)[4], const f32x4 (&hin)[4], f32x4 (&r)[4], f32x4 (&z)[4], f32x4 (&n)[4],
+                                    f32x4 (&ghn)[4], f32x4 (&hnew)[4], int j, int q) {
+  constexpr int IMG = 2 * RIMG_FLOATS;  // ushorts per matrix image
+  u32x4 xs[2][2], hs[2][2];
+  split_Th(x, xs);
+  split_Th(hin, hs);
+  f32x4 t[4];
+  load_vec_T(bih, q, r);
+  load_vec_T(bhh, q, t);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) r[m] += t[m];
+  mm64_R_h2(Wih, xs, r, j, q);
+  mm64_R_h2(Whh, hs, r, j, q);
+  load_vec_T(bih + HID, q, z);
+  load_vec_T(bhh + HID, q, t);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) z[m] += t[m];
+  mm64_R_h2(Wih + IMG, xs, z, j, q);
+  mm64_R_h2(Whh + IMG, hs, z, j, q);
+  load_vec_T(bih + 2 * HID, q, n);
+  mm64_R_h2(Wih + 2 * IMG, xs, n, j, q);
+  load_vec_T(bhh + 2 * HID, q, ghn);
+  mm64_R_h2(Whh + 2 * IMG, hs, ghn, j, q);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = ghn[m][k] * ginv;  // (the backward pass reads W_hn h + b_hn itself)
+      const float rr = sigmoid_f(r[m][k] * ginv);
+      const float zz = sigmoid_f(z[m][k] * ginv);
+      const float nn = tanh_f(n[m][k] * ginv + rr * gg);
+      r[m][k] = rr;
+      z[m][k] = zz;
+      n[m][k] = nn;
+      ghn[m][k] = gg;
       hnew[m][k] = (1.0f - zz) * nn + zz * hin[m][k];
     }
 }

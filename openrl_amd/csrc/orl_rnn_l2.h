@@ -48,10 +48,18 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const RnnLayout tl(A.net);
   constexpr bool HMM = HEAD == ORL_HEAD_CATEGORICAL && NO > 4;
-  const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HMM);
-  stage_rnn_tower(smem, A.theta, tl, tw, threadIdx.x, blockDim.x, HMM);
+  constexpr bool H2 = ORL_RNN_L2_H2 != 0;  // the seven 64 x 64 matrices as scaled two-term fp16 images (orl_rnn.h)
+  const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HMM, false, false, H2);
+  stage_rnn_tower(smem, A.theta, tl, tw, threadIdx.x, blockDim.x, HMM, false, false, H2);
   __syncthreads();
   const float* lw = smem;
+  // image scales: fc2 accumulates 2^kw2 z2 (LayerNorm 2 takes it with eps x 4^kw2), the GRU's products 2^kwg (.)
+  const int kw2 = H2 ? (int)smem[tw.wsc] : 0, kwg = H2 ? (int)smem[tw.wsc + 4] : 0;
+  const float sc2 = H2 ? smem[tw.wsc + 1] : 1.f, ln2_eps = H2 ? smem[tw.wsc + 3] : 1e-5f, ginv = H2 ? smem[tw.wsc + 6] : 1.f;
+  const unsigned short* iW2 = (const unsigned short*)(smem + tw.W2);
+  const unsigned short* iWih = (const unsigned short*)(smem + tw.Wih);
+  const unsigned short* iWhh = (const unsigned short*)(smem + tw.Whh);
+  constexpr int IMG = 2 * RIMG_FLOATS;  // ushorts per matrix image
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   int j = l & 15, q = l >> 4;  // (not const: redefined opaquely at the top of every tile, see the tile loop)
   const int D = A.net.obs_dim, n_out = A.net.n_out, DP = tw.DP;
@@ -153,16 +161,25 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     ln_normalize_T(xh1, rstd1);
     ln_affine_T(xh1, lw + tw.g1, lw + tw.be1, q, n1);
     load_vec_T(lw + tw.b2, q, xh2);
-#if ORL_RNN_L2_OSPLIT
+#if ORL_RNN_L2_H2
+    {
+      u32x4 xs[2][2];
+      split_Th(n1, xs);
+      mm64_R_h2(iW2, xs, xh2, j, q);
+    }
+    ln_normalize_T(xh2, rstd2, ln2_eps);
+    rstd2 *= sc2;  // of the unscaled row
+#elif ORL_RNN_L2_OSPLIT
     {
       u32x4 xs[2][3];
       split_T(n1, xs);
       mm64_S_osplit<W2S>(lw + tw.W2, xs, xh2, j, q);
     }
+    ln_normalize_T(xh2, rstd2);
 #else
     mm64_T(lw + tw.W2, n1, xh2, j, q);
-#endif
     ln_normalize_T(xh2, rstd2);
+#endif
     ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, n2);
   };
   // LN3 + head + loss of a step from its new hidden state; leaves x-hat3, the head deltas (dh / dhv) and
@@ -270,12 +287,25 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     tape_store(tb + TV_DGHN * TV, ghn, j, q);
   };
   // input-side dgrad of the GRU, then LN2' -> dz2 -> W2^T -> LN1' -> relu' -> dz1 (both to the tape)
+  // (H2: the gate deltas arrive scaled by 2^shg per row - row_shift - and every product carries its image's 2^kw: LayerNorm's
+  // backward is linear in the incoming gradient, the inverse powers ride on rstd)
   auto trunk_bwd = [&](const f32x4 (&gr)[4], const f32x4 (&gz)[4], const f32x4 (&gn)[4], const f32x4 (&xh1)[4], float rstd1,
-                       unsigned relu_bits, const f32x4 (&xh2)[4], float rstd2, float* __restrict__ tb) {
+                       unsigned relu_bits, const f32x4 (&xh2)[4], float rstd2, float* __restrict__ tb, int shg) {
     f32x4 d2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) d2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if ORL_RNN_L2_OSPLIT
+#if ORL_RNN_L2_H2
+    {
+      u32x4 xs[2][2];
+      split_Th(gr, xs);
+      mm64_R_h2_tr(iWih, xs, d2, j, q);
+      split_Th(gz, xs);
+      mm64_R_h2_tr(iWih + IMG, xs, d2, j, q);
+      split_Th(gn, xs);
+      mm64_R_h2_tr(iWih + 2 * IMG, xs, d2, j, q);
+    }
+    rstd2 = __builtin_ldexpf(rstd2, -shg - kwg);
+#elif ORL_RNN_L2_OSPLIT
     {
       u32x4 xs[2][3];
       split_T(gr, xs);
@@ -295,7 +325,16 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     f32x4 d1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if ORL_RNN_L2_OSPLIT
+#if ORL_RNN_L2_H2
+    {
+      const int shd = row_shift(absmax16(d2, 0.f));  // (d2 is on the tape already: scaled in place)
+      ldexp16(d2, shd);
+      u32x4 xs[2][2];
+      split_Th(d2, xs);
+      mm64_R_h2_tr(iW2, xs, d1, j, q);
+      rstd1 = __builtin_ldexpf(rstd1, -shd - kw2);
+    }
+#elif ORL_RNN_L2_OSPLIT
     {
       u32x4 xs[2][3];
       split_T(d2, xs);
@@ -389,7 +428,9 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       tape_store(tb0 + TV_XH1 * TV, xh1_0, j, q);
       tape_store(tb0 + TV_XH2 * TV, xh2_0, j, q);
       RNN_T(2);  // trunk (fc1 + 64 MFMA) + tape stores
-#if ORL_RNN_L2_OSPLIT
+#if ORL_RNN_L2_H2
+      gru_fwd_T_h2(iWih, iWhh, lw + tw.bih, lw + tw.bhh, ginv, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
+#elif ORL_RNN_L2_OSPLIT
       gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
 #else
       gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
@@ -415,7 +456,9 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
         tape_store(tb1 + TV_XH1 * TV, xh1_1, j, q);
         tape_store(tb1 + TV_XH2 * TV, xh2_1, j, q);
         RNN_T(2);
-#if ORL_RNN_L2_OSPLIT
+#if ORL_RNN_L2_H2
+        gru_fwd_T_h2(iWih, iWhh, lw + tw.bih, lw + tw.bhh, ginv, n2, hin1, gr, gz, gn, ghn, h2, j, q);
+#elif ORL_RNN_L2_OSPLIT
         gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
 #else
         gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
@@ -426,7 +469,28 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       }
       gate_bwd(dt1, hin1, gr, gz, gn, ghn, carry, tb1);
       RNN_T(6);  // GRU element-wise backward + 4 tape vectors
-#if ORL_RNN_L2_OSPLIT
+      int shg1 = 0;
+#if ORL_RNN_L2_H2
+      {
+        // the four delta vectors (on the tape already) scaled in place by ONE power of two per row; W_hh^T's three products go
+        // into an accumulator of their own and join the carry unscaled
+        shg1 = row_shift(absmax16(ghn, absmax16(gn, absmax16(gz, absmax16(gr, 0.f)))));
+        ldexp16(gr, shg1); ldexp16(gz, shg1); ldexp16(gn, shg1); ldexp16(ghn, shg1);
+        f32x4 ct[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) ct[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 xs[2][2];
+        split_Th(gr, xs);
+        mm64_R_h2_tr(iWhh, xs, ct, j, q);
+        split_Th(gz, xs);
+        mm64_R_h2_tr(iWhh + IMG, xs, ct, j, q);
+        split_Th(ghn, xs);
+        mm64_R_h2_tr(iWhh + 2 * IMG, xs, ct, j, q);
+        ldexp16(ct, -shg1 - kwg);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) carry[m] += ct[m];
+      }
+#elif ORL_RNN_L2_OSPLIT
       {
         u32x4 xs[2][3];
         split_T(gr, xs);
@@ -444,7 +508,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
 #pragma unroll
       for (int m = 0; m < 4; ++m) carry[m] = carry[m] * In1.mask;  // h_in = h * mask
       RNN_T(7);  // hidden-state dgrad: 192 MFMA (column reads)
-      trunk_bwd(gr, gz, gn, xh1_1, rs1_1, rb1, xh2_1, rs2_1, tb1);
+      trunk_bwd(gr, gz, gn, xh1_1, rs1_1, rb1, xh2_1, rs2_1, tb1, shg1);
       RNN_T(8);  // W_ih^T dgrad, LN2', W2^T, LN1', relu', tapes
     }
     // The next tile's step-0 inputs are requested HERE, in front of the last phase (4 GEMMs, ~3 us: longer than a global load's
@@ -470,7 +534,12 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       for (int m = 0; m < 4; ++m) d[m] = dt0[m] + carry[m];
       gate_bwd(d, hin0, r0g, z0g, n0g, g0g, cdead, tb0);  // (the carry into the stored state h0 is not needed)
       RNN_T(6);
-      trunk_bwd(r0g, z0g, n0g, xh1_0, rs1_0, rb0, xh2_0, rs2_0, tb0);
+      int shg0 = 0;
+#if ORL_RNN_L2_H2
+      shg0 = row_shift(absmax16(n0g, absmax16(z0g, absmax16(r0g, 0.f))));
+      ldexp16(r0g, shg0); ldexp16(z0g, shg0); ldexp16(n0g, shg0);
+#endif
+      trunk_bwd(r0g, z0g, n0g, xh1_0, rs1_0, rb0, xh2_0, rs2_0, tb0, shg0);
       RNN_T(8);
     }
     // hand the prefetched inputs over
