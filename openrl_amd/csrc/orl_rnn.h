@@ -81,6 +81,8 @@ struct RnnRaw {
 #ifndef ORL_RNN_L2_H2
 #define ORL_RNN_L2_H2 1
 #endif
+// which instances of the L = 2 row kernel take the images (host launch and kernel body agree through this one function)
+__host__ __device__ constexpr bool rnn_l2_h2(int head, int no) { return ORL_RNN_L2_H2 != 0 && !(head == ORL_HEAD_GAUSSIAN && no > 4); }
 constexpr int RWBS = 72;
 constexpr int RIMG_FLOATS = 2 * HID * RWBS / 2;  // floats per matrix image (two parts x 64 rows)
 __device__ __forceinline__ int rwb_off(int p, int o, int h, int q) { return (p * HID + o) * RWBS + h * 32 + q * 8; }

@@ -1195,8 +1195,8 @@ static int launch_rnn_rows_stream(const RnnRowArgs& P, const RnnRowArgs& Cc, flo
 template <int HEAD, int NO>
 static int launch_rnn_rows_l2(const RnnRowArgs& P, const RnnRowArgs& Cc, int grid_p, int grid_c, hipStream_t s) {
   const RnnLds twp(P.net.obs_dim, P.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HEAD == ORL_HEAD_CATEGORICAL && NO > 4, false, false,
-                   ORL_RNN_L2_H2 != 0);
-  const RnnLds twc(Cc.net.obs_dim, 1, false, false, false, false, ORL_RNN_L2_H2 != 0);
+                   rnn_l2_h2(HEAD, NO));
+  const RnnLds twc(Cc.net.obs_dim, 1, false, false, false, false, rnn_l2_h2(ORL_HEAD_VALUE, 1));
   const size_t lds = (size_t)(twp.total > twc.total ? twp.total : twc.total) * sizeof(float);
   if (lds > 160 * 1024) return fail(ORL_E_UNSUPPORTED, "orl_rnn_ppo_fwd_bwd: tower needs %zu B of LDS", lds);
   (void)hipFuncSetAttribute((const void*)rnn_row2_pair_kernel<HEAD, NO>, hipFuncAttributeMaxDynamicSharedMemorySize,

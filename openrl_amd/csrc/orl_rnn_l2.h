@@ -48,7 +48,9 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const RnnLayout tl(A.net);
   constexpr bool HMM = HEAD == ORL_HEAD_CATEGORICAL && NO > 4;
-  constexpr bool H2 = ORL_RNN_L2_H2 != 0;  // the seven 64 x 64 matrices as scaled two-term fp16 images (orl_rnn.h)
+  // the seven 64 x 64 matrices as scaled two-term fp16 images (orl_rnn.h); the wide Gaussian instances keep the fp32 rows (they
+  // sit at 512 registers already and spill 33 of them with the images' extra state)
+  constexpr bool H2 = rnn_l2_h2(HEAD, NO);
   const RnnLds tw(A.net.obs_dim, A.net.n_out, HEAD == ORL_HEAD_GAUSSIAN, HMM, false, false, H2);
   stage_rnn_tower(smem, A.theta, tl, tw, threadIdx.x, blockDim.x, HMM, false, false, H2);
   __syncthreads();
@@ -161,25 +163,22 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     ln_normalize_T(xh1, rstd1);
     ln_affine_T(xh1, lw + tw.g1, lw + tw.be1, q, n1);
     load_vec_T(lw + tw.b2, q, xh2);
-#if ORL_RNN_L2_H2
-    {
+    if constexpr (H2) {
       u32x4 xs[2][2];
       split_Th(n1, xs);
       mm64_R_h2(iW2, xs, xh2, j, q);
-    }
-    ln_normalize_T(xh2, rstd2, ln2_eps);
-    rstd2 *= sc2;  // of the unscaled row
-#elif ORL_RNN_L2_OSPLIT
-    {
+      ln_normalize_T(xh2, rstd2, ln2_eps);
+      rstd2 *= sc2;  // of the unscaled row
+    } else {
+#if ORL_RNN_L2_OSPLIT
       u32x4 xs[2][3];
       split_T(n1, xs);
       mm64_S_osplit<W2S>(lw + tw.W2, xs, xh2, j, q);
-    }
-    ln_normalize_T(xh2, rstd2);
 #else
-    mm64_T(lw + tw.W2, n1, xh2, j, q);
-    ln_normalize_T(xh2, rstd2);
+      mm64_T(lw + tw.W2, n1, xh2, j, q);
 #endif
+      ln_normalize_T(xh2, rstd2);
+    }
     ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, n2);
   };
   // LN3 + head + loss of a step from its new hidden state; leaves x-hat3, the head deltas (dh / dhv) and
@@ -294,8 +293,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     f32x4 d2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) d2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if ORL_RNN_L2_H2
-    {
+    if constexpr (H2) {
       u32x4 xs[2][2];
       split_Th(gr, xs);
       mm64_R_h2_tr(iWih, xs, d2, j, q);
@@ -303,10 +301,9 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       mm64_R_h2_tr(iWih + IMG, xs, d2, j, q);
       split_Th(gn, xs);
       mm64_R_h2_tr(iWih + 2 * IMG, xs, d2, j, q);
-    }
-    rstd2 = __builtin_ldexpf(rstd2, -shg - kwg);
-#elif ORL_RNN_L2_OSPLIT
-    {
+      rstd2 = __builtin_ldexpf(rstd2, -shg - kwg);
+    } else {
+#if ORL_RNN_L2_OSPLIT
       u32x4 xs[2][3];
       split_T(gr, xs);
       mm64_S_wt_osplit<W2S>(lw + tw.Wih, xs, d2, j, q);
@@ -314,35 +311,33 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       mm64_S_wt_osplit<W2S>(lw + tw.Wih + HID * W2S, xs, d2, j, q);
       split_T(gn, xs);
       mm64_S_wt_osplit<W2S>(lw + tw.Wih + 2 * HID * W2S, xs, d2, j, q);
-    }
 #else
-    mm64_S_wt<W2S>(lw + tw.Wih, gr, d2, j, q);
-    mm64_S_wt<W2S>(lw + tw.Wih + HID * W2S, gz, d2, j, q);
-    mm64_S_wt<W2S>(lw + tw.Wih + 2 * HID * W2S, gn, d2, j, q);
+      mm64_S_wt<W2S>(lw + tw.Wih, gr, d2, j, q);
+      mm64_S_wt<W2S>(lw + tw.Wih + HID * W2S, gz, d2, j, q);
+      mm64_S_wt<W2S>(lw + tw.Wih + 2 * HID * W2S, gn, d2, j, q);
 #endif
+    }
     ln_bwd_rnn(d2, xh2, lw + tw.g2, rstd2, q);
     tape_store(tb + TV_DZ2 * TV, d2, j, q);
     f32x4 d1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) d1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if ORL_RNN_L2_H2
-    {
+    if constexpr (H2) {
       const int shd = row_shift(absmax16(d2, 0.f));  // (d2 is on the tape already: scaled in place)
       ldexp16(d2, shd);
       u32x4 xs[2][2];
       split_Th(d2, xs);
       mm64_R_h2_tr(iW2, xs, d1, j, q);
       rstd1 = __builtin_ldexpf(rstd1, -shd - kw2);
-    }
-#elif ORL_RNN_L2_OSPLIT
-    {
+    } else {
+#if ORL_RNN_L2_OSPLIT
       u32x4 xs[2][3];
       split_T(d2, xs);
       mm64_S_wt_osplit<W2S>(lw + tw.W2, xs, d1, j, q);
-    }
 #else
-    mm64_S_wt<W2S>(lw + tw.W2, d2, d1, j, q);
+      mm64_S_wt<W2S>(lw + tw.W2, d2, d1, j, q);
 #endif
+    }
     ln_bwd_rnn(d1, xh1, lw + tw.g1, rstd1, q);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -428,13 +423,15 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       tape_store(tb0 + TV_XH1 * TV, xh1_0, j, q);
       tape_store(tb0 + TV_XH2 * TV, xh2_0, j, q);
       RNN_T(2);  // trunk (fc1 + 64 MFMA) + tape stores
-#if ORL_RNN_L2_H2
-      gru_fwd_T_h2(iWih, iWhh, lw + tw.bih, lw + tw.bhh, ginv, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
-#elif ORL_RNN_L2_OSPLIT
-      gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
+      if constexpr (H2) {
+        gru_fwd_T_h2(iWih, iWhh, lw + tw.bih, lw + tw.bhh, ginv, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
+      } else {
+#if ORL_RNN_L2_OSPLIT
+        gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
 #else
-      gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
+        gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
 #endif
+      }
       RNN_T(3);  // GRU forward: 384 MFMA + gates
       head_loss(h1, In0, valid, tb0, dt0);
       RNN_T(4);  // LN3, head, loss, W3^T dhead, LN3'
@@ -456,13 +453,15 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
         tape_store(tb1 + TV_XH1 * TV, xh1_1, j, q);
         tape_store(tb1 + TV_XH2 * TV, xh2_1, j, q);
         RNN_T(2);
-#if ORL_RNN_L2_H2
-        gru_fwd_T_h2(iWih, iWhh, lw + tw.bih, lw + tw.bhh, ginv, n2, hin1, gr, gz, gn, ghn, h2, j, q);
-#elif ORL_RNN_L2_OSPLIT
-        gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
+        if constexpr (H2) {
+          gru_fwd_T_h2(iWih, iWhh, lw + tw.bih, lw + tw.bhh, ginv, n2, hin1, gr, gz, gn, ghn, h2, j, q);
+        } else {
+#if ORL_RNN_L2_OSPLIT
+          gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
 #else
-        gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
+          gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
 #endif
+        }
         RNN_T(3);
         head_loss(h2, In1, valid, tb1, dt1);
         RNN_T(4);
@@ -470,8 +469,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       gate_bwd(dt1, hin1, gr, gz, gn, ghn, carry, tb1);
       RNN_T(6);  // GRU element-wise backward + 4 tape vectors
       int shg1 = 0;
-#if ORL_RNN_L2_H2
-      {
+      if constexpr (H2) {
         // the four delta vectors (on the tape already) scaled in place by ONE power of two per row; W_hh^T's three products go
         // into an accumulator of their own and join the carry unscaled
         shg1 = row_shift(absmax16(ghn, absmax16(gn, absmax16(gz, absmax16(gr, 0.f)))));
@@ -489,9 +487,8 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
         ldexp16(ct, -shg1 - kwg);
 #pragma unroll
         for (int m = 0; m < 4; ++m) carry[m] += ct[m];
-      }
-#elif ORL_RNN_L2_OSPLIT
-      {
+      } else {
+#if ORL_RNN_L2_OSPLIT
         u32x4 xs[2][3];
         split_T(gr, xs);
         mm64_S_wt_osplit<W2S>(lw + tw.Whh, xs, carry, j, q);
@@ -499,12 +496,12 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
         mm64_S_wt_osplit<W2S>(lw + tw.Whh + HID * W2S, xs, carry, j, q);
         split_T(ghn, xs);
         mm64_S_wt_osplit<W2S>(lw + tw.Whh + 2 * HID * W2S, xs, carry, j, q);
-      }
 #else
-      mm64_S_wt<W2S>(lw + tw.Whh, gr, carry, j, q);
-      mm64_S_wt<W2S>(lw + tw.Whh + HID * W2S, gz, carry, j, q);
-      mm64_S_wt<W2S>(lw + tw.Whh + 2 * HID * W2S, ghn, carry, j, q);
+        mm64_S_wt<W2S>(lw + tw.Whh, gr, carry, j, q);
+        mm64_S_wt<W2S>(lw + tw.Whh + HID * W2S, gz, carry, j, q);
+        mm64_S_wt<W2S>(lw + tw.Whh + 2 * HID * W2S, ghn, carry, j, q);
 #endif
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m) carry[m] = carry[m] * In1.mask;  // h_in = h * mask
       RNN_T(7);  // hidden-state dgrad: 192 MFMA (column reads)
@@ -535,10 +532,10 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       gate_bwd(d, hin0, r0g, z0g, n0g, g0g, cdead, tb0);  // (the carry into the stored state h0 is not needed)
       RNN_T(6);
       int shg0 = 0;
-#if ORL_RNN_L2_H2
-      shg0 = row_shift(absmax16(n0g, absmax16(z0g, absmax16(r0g, 0.f))));
-      ldexp16(r0g, shg0); ldexp16(z0g, shg0); ldexp16(n0g, shg0);
-#endif
+      if constexpr (H2) {
+        shg0 = row_shift(absmax16(n0g, absmax16(z0g, absmax16(r0g, 0.f))));
+        ldexp16(r0g, shg0); ldexp16(z0g, shg0); ldexp16(n0g, shg0);
+      }
       trunk_bwd(r0g, z0g, n0g, xh1_0, rs1_0, rb0, xh2_0, rs2_0, tb0, shg0);
       RNN_T(8);
     }
