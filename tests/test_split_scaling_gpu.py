@@ -1,4 +1,5 @@
-"""The power-of-two operand scaling of the towers' fp16 two-term split GEMMs (csrc/orl_mlp.h, ORL_TOWER_F16; round 6).
+"""The power-of-two operand scaling of the towers' fp16 two-term split GEMMs (csrc/orl_mlp.h, ORL_TOWER_F16; the recurrent row
+kernel's images: csrc/orl_rnn.h, ORL_RNN_L2_H2; round 6).
 
 fp16 keeps 11 + 11 significand bits of an operand only inside [2^-14, 2^16): the update tower scales a tile of gradients by
 its own maximum, the weight image by the image's maximum, and the wgrad accumulators follow a running scale.  These tests
@@ -88,3 +89,40 @@ def test_rows_of_very_different_gradient_magnitude_in_one_tile(case):
     g["buf_active_masks"] = act
     g["argv"] = str(g["argv"]) + " --use_valuenorm false --use_adv_normalize false"
     TU.single_update_vs_oracle(g, info_rtol=5e-4)
+
+
+# ---- the recurrent L = 2 row kernel over fp16 images (csrc/orl_rnn.h, ORL_RNN_L2_H2) -------------------------------------
+
+def _scaled_gru(g, specs, k, names):
+    g2 = dict(g)
+    for key, spec in (("theta_p0", specs[0]), ("theta_c0", specs[1])):
+        th = torch.tensor(g[key]).clone()
+        parts = spec.split(th)
+        for n in names:
+            parts[n].mul_(2.0 ** k)
+        g2[key] = th.numpy()
+    return g2
+
+
+@pytest.mark.parametrize("k", [-60, -30, 24])
+def test_recurrent_update_with_a_scaled_loss(k):
+    """data_chunk_length 2 = the register-resident row kernel: the gate deltas of a row are scaled by one power of two taken
+    from the row's own maximum.  value_loss_coef x 2^k moves the critic's deltas by as many binades; one update against the
+    oracle, gradients relative to their own largest entry."""
+    from tests import test_rnn_kernels_gpu as TR
+
+    g = dict(H.load_golden("train_recurrent"))
+    g["argv"] = str(g["argv"]) + " --value_loss_coef %r" % (2.0 ** k)
+    TR.rnn_update_vs_oracle(g)
+
+
+@pytest.mark.parametrize("k,names", [(-8, ("Wih", "Whh", "bih", "bhh")), (7, ("Wih", "Whh", "bih", "bhh")), (-9, ("W2", "b2")),
+                                     (8, ("W2", "b2"))])
+def test_recurrent_update_with_scaled_weight_images(k, names):
+    """The GRU's six matrices share ONE image scale (their products are added inside the gates), W2 has its own (LayerNorm 2
+    takes fc2's scaled accumulators): both moved by 2^k."""
+    from tests import rnn_helpers as RH
+    from tests import test_rnn_kernels_gpu as TR
+
+    g = H.load_golden("train_recurrent")
+    TR.rnn_update_vs_oracle(_scaled_gru(g, RH.rnn_specs(g), k, names))
