@@ -352,11 +352,11 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
   // kernel ("Memory access fault", round 5): with 480 live registers the allocator parks values in AccVGPRs wherever it
   // likes, also inside the probe's divergent regions.  Here every lane of the probe wave adds to ITS OWN LDS slot under a
   // wave-uniform branch - no exec-masked region is added to the tile loop.
-  __shared__ unsigned long long rprof_lds[16 * 64];
+  __shared__ unsigned rprof_lds[16 * 64];  // (32-bit sums: 4 KB - the fp16 images leave the timing build no room for 8)
   const bool prof_on = __builtin_amdgcn_readfirstlane((int)(blockIdx.x == 0 && wave == 0)) != 0;
   if (prof_on) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) rprof_lds[k * 64 + l] = 0ull;
+    for (int k = 0; k < 16; ++k) rprof_lds[k * 64 + l] = 0u;
   }
   unsigned long long t_last = __builtin_readcyclecounter();
 #undef RNN_T
@@ -364,7 +364,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
   do {                                                                \
     if (prof_on) {                                                    \
       const unsigned long long t_now = __builtin_readcyclecounter();  \
-      rprof_lds[(k) * 64 + l] += t_now - t_last;                      \
+      rprof_lds[(k) * 64 + l] += (unsigned)(t_now - t_last);          \
       t_last = t_now;                                                 \
     }                                                                 \
   } while (0)
@@ -545,7 +545,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
     for (int m = 0; m < 4; ++m) h0[m] = hn0[m];
   }
 #ifdef ORL_PROF
-  if (prof_on && l < 12) atomicAdd(&g_rnn_prof[l], rprof_lds[l * 64]);
+  if (prof_on && l < 12) atomicAdd(&g_rnn_prof[l], (unsigned long long)rprof_lds[l * 64]);
   if (prof_on && l == 12) atomicAdd(&g_rnn_prof[12], 1ull);
   if (prof_on && l == 13) atomicAdd(&g_rnn_prof[13], (unsigned long long)((n_tiles - tile0 + stride - 1) / stride));
   if (prof_on && l == 14) atomicAdd(&g_rnn_prof[14], 1ull);  // marks the L = 2 kernel for tools/rnn_phase_prof.py
