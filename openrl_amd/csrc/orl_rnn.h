@@ -77,7 +77,10 @@ struct RnnRaw {
 // hi = rn16(x), lo = rn16(x - hi), 3 products per fp32 product) instead of fp32 rows under v_mfma_f32_16x16x4_f32.  At the row
 // stride RWBS = 72 elements two parts of a matrix are 18 KB (fp32 rows at stride 68: 17 KB) - seven of them fit beside W1 where
 // the fp32 rows are; the conflict-free stride 80 (orl_mlp.h: WBS) would not.  Scales: W2 by 2^kw2 from its own maximum, the six GRU
-// matrices by ONE 2^kwg (their products are added inside the gates); biases stored scaled.
+// matrices by ONE 2^kwg (their products are added inside the gates); biases stored scaled.  The forward products' B operands - a
+// LayerNorm output after its affine (g xhat + be, |xhat| < 8) and the masked hidden state (|h| < 1) - enter unscaled: fp16's range
+// (65 504) is assumed to cover them, i.e. |g| + |be| / 8 < 8 000; the backward products' operands (gate deltas, dz2) are scaled per
+// row from their own maximum.
 #ifndef ORL_RNN_L2_H2
 #define ORL_RNN_L2_H2 1
 #endif
