@@ -58,6 +58,11 @@ timeout 600 python benchmarks/cfg5_ttt_bench.py --opponent pool --sampling per_r
 timeout 600 python benchmarks/host_env_bench.py > $OUT/${TAG}_host_env_line.json 2>/dev/null
 # 7. the recurrent update: the row kernels (L = 2 register-resident default, recompute), kernel stats, counters
 (for g in fp32 fp32_recompute; do python benchmarks/rnn_update_bench.py --tower-gemm $g; done) > $OUT/${TAG}_rnn_update_lines.jsonl 2>/dev/null
+if [ -f variants/rnnfp32.so ]; then  # the fp32-MFMA form of the L = 2 kernel (-DORL_RNN_L2_H2=0), same box
+  cp variants/rnnfp32.so openrl_amd/csrc/liborl_hip.so
+  python benchmarks/rnn_update_bench.py --tower-gemm fp32 2>/dev/null | sed 's/"bench": "rnn_update"/"bench": "rnn_update (ORL_RNN_L2_H2=0: fp32 MFMA rows)"/' >> $OUT/${TAG}_rnn_update_lines.jsonl
+  cp variants/default.so openrl_amd/csrc/liborl_hip.so
+fi
 stats rnn_update python benchmarks/rnn_update_bench.py --iters 3 --warmup 1
 stats rnn_update_recompute python benchmarks/rnn_update_bench.py --iters 3 --warmup 1 --tower-gemm fp32_recompute
 (bash tools/pmc_rnn_row.sh fp32; bash tools/pmc_rnn_row.sh fp32_recompute) > $OUT/${TAG}_pmc_rnn.txt 2>&1
