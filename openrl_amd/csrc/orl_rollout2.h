@@ -21,8 +21,8 @@
 //     a tile holding a row with mean^2 > 16 var takes the round-5 path (the z tile is always left in LDS for it);
 //   * the CRITIC runs in the same launch but off the chain and off wave 0's SIMD: waves 9-11 take the observation slots t = c, c + 3,
 //     ... (all T + 1 of them, slot T = the bootstrap value) out of the LDS ring as they are published and evaluate the value
-//     tower the way the update does - fc2 as three-term bf16 splits on the bf16 MFMA (exact hi + mid + lo, 6 of 9 products: fp32
-//     accuracy; a bf16 MFMA does not occupy the VALU datapath), LayerNorm affines folded - at priority 0, three steps of time per
+//     tower the way the update does - fc2 as two-term fp16 splits on the 16-bit MFMA (orl_mlp.h, ORL_TOWER_F16: 3 products over the scaled
+//     image, fp32 accuracy; rounds 3 - 5: three-term bf16 splits; a 16-bit MFMA does not occupy the VALU datapath), LayerNorm affines folded - at priority 0, three steps of time per
 //     tile.  Values are not needed to act;
 //   * waves 5-7 ("services") run AHEAD of or BEHIND the chain through small LDS rings: wave 5 draws the sampling noise two steps
 //     ahead, wave 6 the action-independent half of the env step (synthetic: reward + next observation; CartPole: cos / sin of
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(RO2_THREADS) void rollout2_kernel(RolloutArgs A) {
   } else if (wave >= 9 && wave <= 11) {
     // ================================================================ the critic, off the chain ==================
     // wave c evaluates V(observation t) for t = c, c + 3, ... <= T: the whole value tower for one 16-row tile per trip, fc2 on
-    // the bf16 MFMA (mm64_T_split over the split image of W2 diag(g1)), everything else as critic_sweep_kernel / the update tower
+    // the 16-bit MFMA (mm64_T_h2 over the scaled fp16 image of W2 diag(g1)), everything else as critic_sweep_kernel / the update tower
     const int c = wave - 9;
     const float* lc = smem + L.critic;
     f32x4 w3[4];
