@@ -462,7 +462,10 @@ typedef struct orl_rollout_args {
 int orl_build_experiments(void);
 /* How the MLP towers' 64-wide GEMMs (orl_ppo_fwd_bwd, the chain rollout's critic) form their fp32 products on the 16-bit MFMA:
  * 2 = two-term fp16 splits, 3 products, operands scaled by exact powers of two (the shipped build, round 6);
- * 3 = three-term bf16 splits, 6 of 9 products (rounds 3 - 5; ORL_BUILD_DEFS=-DORL_TOWER_F16=0).  Both at fp32 accuracy. */
+ * 3 = three-term bf16 splits, 6 of 9 products (rounds 3 - 5; ORL_BUILD_DEFS=-DORL_TOWER_F16=0).  Both at fp32 accuracy.
+ * (The recurrent towers' data_chunk_length == 2 row kernel of orl_rnn_ppo_fwd_bwd forms its 64-wide products the same two-term way
+ * over fp16 images of its seven matrices - ORL_RNN_L2_H2, on by default, independent of this value; every other recurrent kernel
+ * uses the fp32 MFMA.) */
 int orl_tower_split_terms(void);
 
 int orl_env_state_width(int env_kind);
