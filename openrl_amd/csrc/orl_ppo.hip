@@ -23,6 +23,11 @@
 #ifndef ORL_PAIR_WP_WIDE
 #define ORL_PAIR_WP_WIDE 1.10
 #endif
+// ... and with a wide GAUSSIAN head, re-measured after the fp16 split (tools/r06_calls/r06_call33.sh, cfg3's shape: 1.10 -> 134 + 122
+// workgroups, 12 / 14 tiles per wave, pair launch 0.1165 - 0.1186 ms; 1.30 .. 1.50 -> 146 + 110, 11 / 15 tiles, 0.1077 - 0.1095 ms)
+#ifndef ORL_PAIR_WP_WIDE_GAUSS
+#define ORL_PAIR_WP_WIDE_GAUSS 1.30
+#endif
 #ifndef ORL_TOWER_TR_ND0   // build-time experiment: the same for the small-observation build (it fits both images anyway)
 #define ORL_TOWER_TR_ND0 0
 #endif
@@ -133,7 +138,7 @@ static int launch_pair_nd(const PpoArgs& P, const PpoArgs& Cc, int* gp_out, int*
     // tiles, wide head) 678 -> 694 us.  Hence side by side when the towers are nearly equal or the launch is short.
     int gp = (n_tiles + 7) / 8, gc = gp;
     if (gp > PPO_MAX_BLOCKS) gp = gc = PPO_MAX_BLOCKS;
-    const double w_p = NOP_ > 4 ? ORL_PAIR_WP_WIDE : 1.05;
+    const double w_p = NOP_ > 4 ? (HEADP == ORL_HEAD_GAUSSIAN ? ORL_PAIR_WP_WIDE_GAUSS : ORL_PAIR_WP_WIDE) : 1.05;
     const bool side_by_side = w_p < 1.1 || n_tiles <= 12 * 8 * PPO_MAX_BLOCKS;
     if (gp + gc > PPO_MAX_BLOCKS && side_by_side) {
       double best = 1e30;
