@@ -64,6 +64,13 @@ __device__ unsigned long long g_orl_prof[24];
 #define ORL_T(k) ((void)0)
 #endif
 
+// 1 = ONE running scale of dz2 per wave (that of the largest tile so far) for both the dgrad and the wgrad, applied by explicit
+// v_ldexp: xhat1 enters the wgrad unscaled and db2 needs no rescaling - 18 VALU per tile less than a scale per tile (0), - 1.7 % of the
+// pair launch (tools/r06_calls/r06_call36.sh).  A tile 2^-k below the running maximum keeps an absolute error 2^-36 of that maximum;
+// everything downstream of dz2 ends in sums over the tiles.  (Folding the power into rstd2 instead of the v_ldexp pass was 1 % SLOWER.)
+#ifndef ORL_TOWER_RUNSCALE
+#define ORL_TOWER_RUNSCALE 1
+#endif
 #ifndef ORL_DMA_WAIT_DEP
 #define ORL_DMA_WAIT_DEP 1
 #endif
@@ -320,13 +327,15 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
   stage_tower(smem, A.theta, tl, tw, w2t, threadIdx.x, blockDim.x, HMM, SP, true);
   __syncthreads();
   // fp16 split builds (orl_mlp.h, ORL_TOWER_F16): the weight image's scale 2^kw (fc2's accumulators and LayerNorm 2 run scaled:
-  // eps x 4^kw), and the running scale 2^LS of this wave's wgrad accumulators (a tile's gradients are scaled by their own
-  // maximum, its xhat1 operand by what is left of 2^LS: LS only ever decreases, and the accumulators follow it)
+  // eps x 4^kw), and the scale 2^LS of this wave's wgrad accumulators: with ORL_TOWER_RUNSCALE every tile's dz2 is scaled by the
+  // power of two of the largest tile so far (e_run) and LS = 138 - e_run; without it a tile's gradients are scaled by their own
+  // maximum and its xhat1 operand by what is left of 2^LS.  LS only ever decreases, and the accumulators follow it.
   constexpr bool F16W = SPW && ORL_TOWER_F16;  // the wgrad (and with it the tile scale of dz2)
   constexpr bool F16G = SP && ORL_TOWER_F16;   // fc2 / dgrad over the fp16 images
   const int kw = F16G ? (int)smem[tw.wsc] : 0;
   const float w_scale = F16G ? smem[tw.wsc + 1] : 1.f, ln2_eps = F16G ? smem[tw.wsc + 3] : 1e-5f;
   int LS = 1000;
+  int e_run = 0;  // ORL_TOWER_RUNSCALE: the largest tile exponent so far
 
 #ifdef ORL_PROF
   __shared__ unsigned long long prof_lds[16];
@@ -800,10 +809,29 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
 #pragma unroll
       for (int m = 0; m < 4; ++m) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d2[m][0]), fabsf(d2[m][1]))), fmaxf(fabsf(d2[m][2]), fabsf(d2[m][3])));
       eA = __builtin_amdgcn_readfirstlane(scale_exponent(wave_absmax(mx)));
+#if ORL_TOWER_RUNSCALE
+      // ONE running scale (that of the largest tile so far) for dz2 in both the dgrad and the wgrad - xhat1 enters the wgrad
+      // unscaled, G / db2 are in units of 2^(138 - e_run); a larger tile rescales them (exact, rare after a wave's first tiles)
+      if (eA > e_run) {
+        const int dl = e_run - eA;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) GS[a][b][r] = __builtin_ldexpf(GS[a][b][r], dl);
+          a_db2s[a] = __builtin_ldexpf(a_db2s[a], dl);
+        }
+        e_run = eA;
+      }
+      eA = e_run;
+      LS = 138 - e_run;
+#endif
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) d2[m][r] = __builtin_ldexpf(d2[m][r], 138 - eA);
+#if !ORL_TOWER_RUNSCALE
       // G's scale: 2^LS x (dz2^T xhat1) = (2^(138 - eA) dz2)^T (2^LB xhat1) with LB = LS - (138 - eA) <= 12 (|xhat1| < 8 stays
       // below 2^15); a tile with larger gradients than any before lowers LS, and the accumulators are rescaled (exact)
       const int ls_new = 12 + 138 - eA;
@@ -819,6 +847,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         }
         LS = ls_new;
       }
+#endif
     }
     wave_lds_fence();
     store_slab_T(SS, d2, j, q);
@@ -837,7 +866,7 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
         for (int b = 0; b < 2; ++b) {
           float xb[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) xb[k] = __builtin_ldexpf(X1[(8 * kb + k) * TS + 32 * b + c], LB);
+          for (int k = 0; k < 8; ++k) xb[k] = ORL_TOWER_RUNSCALE ? X1[(8 * kb + k) * TS + 32 * b + c] : __builtin_ldexpf(X1[(8 * kb + k) * TS + 32 * b + c], LB);
           split8h(xb, fb[b][0], fb[b][1]);
         }
 #pragma unroll
@@ -846,7 +875,8 @@ __device__ __forceinline__ void ppo_tower_body(const PpoArgs& A, const int bid, 
           u32x4 fa[2];
 #pragma unroll
           for (int k = 0; k < 8; ++k) xa[k] = SS[(8 * kb + k) * TS + 32 * bo + c];
-          a_db2s[bo] += __builtin_ldexpf(((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7])), LB);
+          a_db2s[bo] += ORL_TOWER_RUNSCALE ? ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]))
+                                           : __builtin_ldexpf(((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7])), LB);
           split8h(xa, fa[0], fa[1]);
 #pragma unroll
           for (int bi = 0; bi < 2; ++bi) {
