@@ -25,7 +25,7 @@ namespace orl {
 // A/B knob: raise the wave's issue priority around MFMA bursts (cdna guide T5).  ORL_USE_SETPRIO = 1: the fc2 burst only (the
 // round-2 form), 2: the dgrad and wgrad bursts too.
 #ifndef ORL_USE_SETPRIO
-#define ORL_USE_SETPRIO 2   // round 5 (six bf16 products): 1 was - 0.8 % on the pair launch, 2 no better; round 6 (three fp16 products): 2 is - 3 % against 1, 0 is + 2 % (tools/r06_calls/r06_call27.sh)
+#define ORL_USE_SETPRIO 2   // round 5 (six bf16 products): 1 was - 0.8 % on the pair launch, 2 no better; round 6 (three fp16 products): 2 is - 3 % against 1, 0 is + 2 % (tools/r06_calls/r06_call27.sh).  In the fp16 builds "2" raises the priority around the DGRAD burst only: the fp16 wgrad block carries no s_setprio, and with one it is + 2 % (0.1820 against 0.1780 ms)
 #endif
 #if ORL_USE_SETPRIO >= 1
 #define ORL_PRIO(x) __builtin_amdgcn_s_setprio(x)
