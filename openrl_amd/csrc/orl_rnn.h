@@ -275,71 +275,6 @@ __device__ inline void mm64_S_wt(const float* __restrict__ Ws, const f32x4 (&in)
   }
 }
 
-// ---- round 5: the same two GEMMs on the bf16 MFMA with the A operand split ON THE FLY ------------------------------------
-// The seven 64 x 64 matrices of a recurrent tower do not fit the LDS as three-term bf16 images (193 KB), but their fp32 rows
-// do (122 KB) - so the weights stay fp32 in LDS and every A fragment is split in registers right before its MFMAs: per
-// (row block mo, K-step h) 8 fp32 values (two 16-byte reads, or eight 4-byte column reads for the transposed product) ->
-// split8 -> 6 bf16 MFMAs.  352 VALU + 48 MFMAs of 16 cycles per GEMM instead of 64 VALU-blocking fp32 MFMAs of 32 cycles.
-// xs = split_T of the input (the B operand), shared by every GEMM that consumes the same vector.  Same arithmetic as the
-// feed-forward tower's split GEMMs (exact hi + mid + lo, 6 of 9 products, fp32 accumulation).
-template <int S>
-__device__ __forceinline__ void mm64_S_osplit(const float* __restrict__ Ws, const u32x4 (&xs)[2][3], f32x4 (&acc)[4], int j,
-                                              int q) {
-  // slot s of the B fragment of K-step h carries reduction index k = 16 (2h + s / 4) + 4q + s % 4 (split_T): columns
-  // 32h + 4q .. + 3 and 32h + 16 + 4q .. + 3 of row 16 mo + j
-  f32x4 a[2][2];
-  a[0][0] = *(const f32x4*)(Ws + j * S + 4 * q);
-  a[0][1] = *(const f32x4*)(Ws + j * S + 16 + 4 * q);
-#pragma unroll
-  for (int st = 0; st < 8; ++st) {
-    const int h = st >> 2, mo = st & 3;
-    if (st < 7) {
-      const int h2 = (st + 1) >> 2, mo2 = (st + 1) & 3;
-      a[(st + 1) & 1][0] = *(const f32x4*)(Ws + (16 * mo2 + j) * S + 32 * h2 + 4 * q);
-      a[(st + 1) & 1][1] = *(const f32x4*)(Ws + (16 * mo2 + j) * S + 32 * h2 + 16 + 4 * q);
-    }
-    const f32x4 lo4 = a[st & 1][0], hi4 = a[st & 1][1];
-    const float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-    u32x4 wh, wm, wl;
-    split8(x, wh, wm, wl);
-    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);)
-    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);)
-    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);)
-    acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
-  }
-}
-
-// acc += W^T in: the A fragment of (row block mo, K-step h) is W[o][16 mo + j] for the 8 reduction indices o of the step -
-// eight 4-byte column reads (rows 4q apart hit banks 16 apart: conflict free, as mm64_S_wt)
-template <int S>
-__device__ __forceinline__ void mm64_S_wt_osplit(const float* __restrict__ Ws, const u32x4 (&xs)[2][3], f32x4 (&acc)[4],
-                                                 int j, int q) {
-  float a[2][8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) a[0][s] = Ws[(16 * (s >> 2) + 4 * q + (s & 3)) * S + j];
-#pragma unroll
-  for (int st = 0; st < 8; ++st) {
-    const int h = st >> 2, mo = st & 3;
-    if (st < 7) {
-      const int h2 = (st + 1) >> 2, mo2 = (st + 1) & 3;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) a[(st + 1) & 1][s] = Ws[(16 * (2 * h2 + (s >> 2)) + 4 * q + (s & 3)) * S + 16 * mo2 + j];
-    }
-    const float x[8] = {a[st & 1][0], a[st & 1][1], a[st & 1][2], a[st & 1][3],
-                        a[st & 1][4], a[st & 1][5], a[st & 1][6], a[st & 1][7]};
-    u32x4 wh, wm, wl;
-    split8(x, wh, wm, wl);
-    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wl, xs[h][0], acc[mo]);)
-    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wh, xs[h][2], acc[mo]);)
-    ORL_IF_FULL(acc[mo] = mfma_bf16_16(wm, xs[h][1], acc[mo]);)
-    acc[mo] = mfma_bf16_16(wm, xs[h][0], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][1], acc[mo]);
-    acc[mo] = mfma_bf16_16(wh, xs[h][0], acc[mo]);
-  }
-}
-
 // fc1 with W1 read from GLOBAL memory (row stride D, no padding)
 template <class XB>
 __device__ inline void fc1_g(const float* __restrict__ W1, int D, XB xb, f32x4 (&acc)[4], int j, int q) {
@@ -405,46 +340,6 @@ __device__ inline void gru_fwd_T(const float* __restrict__ Wih, const float* __r
   mm64_S<S>(Wih + 2 * HID * S, x, n, j, q);
   load_vec_T(bhh + 2 * HID, q, ghn);
   mm64_S<S>(Whh + 2 * HID * S, hin, ghn, j, q);
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float rr = sigmoid_f(r[m][k]);
-      const float zz = sigmoid_f(z[m][k]);
-      const float nn = tanh_f(n[m][k] + rr * ghn[m][k]);
-      r[m][k] = rr;
-      z[m][k] = zz;
-      n[m][k] = nn;
-      hnew[m][k] = (1.0f - zz) * nn + zz * hin[m][k];
-    }
-}
-
-// gru_fwd_T with every GEMM through mm64_S_osplit (x and hin are split once each)
-template <int S>
-__device__ inline void gru_fwd_T_osplit(const float* __restrict__ Wih, const float* __restrict__ Whh,
-                                        const float* __restrict__ bih, const float* __restrict__ bhh, const f32x4 (&x)[4],
-                                        const f32x4 (&hin)[4], f32x4 (&r)[4], f32x4 (&z)[4], f32x4 (&n)[4], f32x4 (&ghn)[4],
-                                        f32x4 (&hnew)[4], int j, int q) {
-  u32x4 xs[2][3], hs[2][3];
-  split_T(x, xs);
-  split_T(hin, hs);
-  f32x4 t[4];
-  load_vec_T(bih, q, r);
-  load_vec_T(bhh, q, t);
-#pragma unroll
-  for (int m = 0; m < 4; ++m) r[m] += t[m];
-  mm64_S_osplit<S>(Wih, xs, r, j, q);
-  mm64_S_osplit<S>(Whh, hs, r, j, q);
-  load_vec_T(bih + HID, q, z);
-  load_vec_T(bhh + HID, q, t);
-#pragma unroll
-  for (int m = 0; m < 4; ++m) z[m] += t[m];
-  mm64_S_osplit<S>(Wih + HID * S, xs, z, j, q);
-  mm64_S_osplit<S>(Whh + HID * S, hs, z, j, q);
-  load_vec_T(bih + 2 * HID, q, n);
-  mm64_S_osplit<S>(Wih + 2 * HID * S, xs, n, j, q);
-  load_vec_T(bhh + 2 * HID, q, ghn);
-  mm64_S_osplit<S>(Whh + 2 * HID * S, hs, ghn, j, q);
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll

@@ -21,18 +21,17 @@
 // = 7 + 7 + 7 + 4 = 25 GEMMs per tile instead of 35, no forward recompute, no state tape (htape), and NO global load behind a
 // tape store inside a tile: the x-hat vectors never leave the registers, the tile's inputs (row indices, records, masks,
 // stored states) are requested one tile ahead.  The wgrad tape is written exactly as rnn_row_body writes it (same block
-// layout, same values up to summation order), so rnn_wgrad_kernel and everything downstream are unchanged.  GEMMs stay on
-// v_mfma_f32_16x16x4_f32 out of the resident fp32 LDS images (RnnLds).
+// layout, same values up to summation order), so rnn_wgrad_kernel and everything downstream are unchanged.
+// Round 6: the 25 GEMMs run as two-term fp16 splits (3 products on v_mfma_f32_16x16x32_f16) over resident fp16 IMAGES of the seven
+// matrices (orl_rnn.h: ORL_RNN_L2_H2, RnnLds h2; per-row power-of-two scales of the gate deltas) - round 5's form, v_mfma_f32_16x16x4_f32
+// out of resident fp32 rows, remains for the wide Gaussian instances and under -DORL_RNN_L2_H2=0.
 #pragma once
 #include "orl_rnn.h"
 
 namespace orl {
 
-// ORL_RNN_L2_OSPLIT (build-time switch): the kernel's 25 GEMMs per tile on the bf16 MFMA with the fp32 LDS images split on the fly
-// (orl_rnn.h: mm64_S_osplit / mm64_S_wt_osplit) instead of v_mfma_f32_16x16x4_f32
-#ifndef ORL_RNN_L2_OSPLIT
-#define ORL_RNN_L2_OSPLIT 0
-#endif
+// (round 5's experiment with the fp32 LDS rows split on the fly - ORL_RNN_L2_OSPLIT, 0.807 against 0.716 ms per epoch - is gone: round
+// 6's fp16 IMAGES, ORL_RNN_L2_H2 in orl_rnn.h, are what the idea needed)
 
 // what one step of one 16-chunk tile reads from global memory (requested a tile ahead)
 struct Row2In {
@@ -170,13 +169,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       ln_normalize_T(xh2, rstd2, ln2_eps);
       rstd2 *= sc2;  // of the unscaled row
     } else {
-#if ORL_RNN_L2_OSPLIT
-      u32x4 xs[2][3];
-      split_T(n1, xs);
-      mm64_S_osplit<W2S>(lw + tw.W2, xs, xh2, j, q);
-#else
       mm64_T(lw + tw.W2, n1, xh2, j, q);
-#endif
       ln_normalize_T(xh2, rstd2);
     }
     ln_affine_T(xh2, lw + tw.g2, lw + tw.be2, q, n2);
@@ -303,19 +296,9 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       mm64_R_h2_tr(iWih + 2 * IMG, xs, d2, j, q);
       rstd2 = __builtin_ldexpf(rstd2, -shg - kwg);
     } else {
-#if ORL_RNN_L2_OSPLIT
-      u32x4 xs[2][3];
-      split_T(gr, xs);
-      mm64_S_wt_osplit<W2S>(lw + tw.Wih, xs, d2, j, q);
-      split_T(gz, xs);
-      mm64_S_wt_osplit<W2S>(lw + tw.Wih + HID * W2S, xs, d2, j, q);
-      split_T(gn, xs);
-      mm64_S_wt_osplit<W2S>(lw + tw.Wih + 2 * HID * W2S, xs, d2, j, q);
-#else
       mm64_S_wt<W2S>(lw + tw.Wih, gr, d2, j, q);
       mm64_S_wt<W2S>(lw + tw.Wih + HID * W2S, gz, d2, j, q);
       mm64_S_wt<W2S>(lw + tw.Wih + 2 * HID * W2S, gn, d2, j, q);
-#endif
     }
     ln_bwd_rnn(d2, xh2, lw + tw.g2, rstd2, q);
     tape_store(tb + TV_DZ2 * TV, d2, j, q);
@@ -330,13 +313,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       mm64_R_h2_tr(iW2, xs, d1, j, q);
       rstd1 = __builtin_ldexpf(rstd1, -shd - kw2);
     } else {
-#if ORL_RNN_L2_OSPLIT
-      u32x4 xs[2][3];
-      split_T(d2, xs);
-      mm64_S_wt_osplit<W2S>(lw + tw.W2, xs, d1, j, q);
-#else
       mm64_S_wt<W2S>(lw + tw.W2, d2, d1, j, q);
-#endif
     }
     ln_bwd_rnn(d1, xh1, lw + tw.g1, rstd1, q);
 #pragma unroll
@@ -426,11 +403,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
       if constexpr (H2) {
         gru_fwd_T_h2(iWih, iWhh, lw + tw.bih, lw + tw.bhh, ginv, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
       } else {
-#if ORL_RNN_L2_OSPLIT
-        gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
-#else
         gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin0, r0g, z0g, n0g, g0g, h1, j, q);
-#endif
       }
       RNN_T(3);  // GRU forward: 384 MFMA + gates
       head_loss(h1, In0, valid, tb0, dt0);
@@ -456,11 +429,7 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
         if constexpr (H2) {
           gru_fwd_T_h2(iWih, iWhh, lw + tw.bih, lw + tw.bhh, ginv, n2, hin1, gr, gz, gn, ghn, h2, j, q);
         } else {
-#if ORL_RNN_L2_OSPLIT
-          gru_fwd_T_osplit<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
-#else
           gru_fwd_T<W2S>(lw + tw.Wih, lw + tw.Whh, lw + tw.bih, lw + tw.bhh, n2, hin1, gr, gz, gn, ghn, h2, j, q);
-#endif
         }
         RNN_T(3);
         head_loss(h2, In1, valid, tb1, dt1);
@@ -488,19 +457,9 @@ __device__ __forceinline__ void rnn_row2_body(const RnnRowArgs& A, const int bid
 #pragma unroll
         for (int m = 0; m < 4; ++m) carry[m] += ct[m];
       } else {
-#if ORL_RNN_L2_OSPLIT
-        u32x4 xs[2][3];
-        split_T(gr, xs);
-        mm64_S_wt_osplit<W2S>(lw + tw.Whh, xs, carry, j, q);
-        split_T(gz, xs);
-        mm64_S_wt_osplit<W2S>(lw + tw.Whh + HID * W2S, xs, carry, j, q);
-        split_T(ghn, xs);
-        mm64_S_wt_osplit<W2S>(lw + tw.Whh + 2 * HID * W2S, xs, carry, j, q);
-#else
         mm64_S_wt<W2S>(lw + tw.Whh, gr, carry, j, q);
         mm64_S_wt<W2S>(lw + tw.Whh + HID * W2S, gz, carry, j, q);
         mm64_S_wt<W2S>(lw + tw.Whh + 2 * HID * W2S, ghn, carry, j, q);
-#endif
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m) carry[m] = carry[m] * In1.mask;  // h_in = h * mask
